@@ -1,0 +1,280 @@
+/*
+ * lmnet_hip.h -- C-ABI of liblmnet_hip.so: hand-written gfx950 (MI355X / CDNA4) kernels for the
+ * forward/backward hot path of Asunatan/LM-Net (core/LM_Net.py:95-123 and the live classes of
+ * core/modules.py).
+ *
+ * The reference has NO FFI/plugin layer for this path: its "operator API" is the Python
+ * nn.Module `core.LM_Net.LM_Net` (core/LM_Net.py:5-123), built from torch.nn ops plus the
+ * third-party CUDA ops natten2dqkrpb / natten2dav (natten, reached at core/modules.py:509,517).
+ * This header is therefore the boundary the reference WOULD bind if it had one: one entry per
+ * fused row of SURVEY.md section 8a, plain pointers + sizes + a stream, no torch types.
+ * Each entry cites the reference code whose arithmetic it replaces.
+ *
+ * Conventions
+ *   - all tensors are fp32 device pointers; activations are NHWC ("pixel-major"): element
+ *     (b,y,x,c) of a tensor with pixel stride `cstride` lives at ((b*H+y)*W+x)*cstride + c.
+ *     A pointer may address a channel slice of a wider buffer (cstride > C) -- this is how
+ *     torch.cat along channels (core/modules.py:104,139,497) is expressed without a copy.
+ *   - the caller owns every buffer (incl. workspace); kernels never allocate, free or synchronise;
+ *     everything is enqueued on `stream` (hipStream_t) and is stream-ordered and re-entrant.
+ *   - return value: 0 on success, <0 = LMN_E_* argument error, >0 = hipError_t from the launch.
+ *   - reductions into `stats`/gradient buffers use atomicAdd: the caller zeroes them first
+ *     (lmn_fill) unless stated otherwise.
+ */
+#ifndef LMNET_HIP_H
+#define LMNET_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* lmn_stream_t; /* hipStream_t */
+
+#define LMN_ABI_VERSION 1
+#define LMN_E_BADARG (-1)
+#define LMN_E_UNSUPPORTED (-2)
+
+int lmn_abi_version(void);
+/* sizeof() of the argument structs, so a binding can verify its mirror of the layout */
+int lmn_sizeof_conv_args(void);
+int lmn_sizeof_src(void);
+const char* lmn_last_error(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Dense convolution family on the matrix cores (v_mfma_f32_16x16x4_f32, exact fp32).
+ * Replaces every nn.Conv2d(k=1|3, stride=1|2) and nn.Linear of the path:
+ *   ReparamConv.expand_conv / pointwise_conv / shortcut   core/modules.py:537-539,576-584
+ *   down1..4, up1..4 convs, output of M2Skip/M3Skip convs   core/LM_Net.py:14-39,58-74; modules.py:83-143
+ *   OverlapPatchEmbed                                       core/modules.py:22-40
+ *   Mlp.fc1/fc2, GlobalAttention.qkv/proj, natten qkv/proj  core/modules.py:42-56,235-279,509
+ *   GFT.conv                                                core/modules.py:337
+ * and, with `transposed=1` / lmn_conv_wgrad, their autograd (ATen conv/linear backward).
+ * ------------------------------------------------------------------------------------------ */
+
+/* source (input operand) transforms applied on load, in this order */
+#define LMN_SRC_GELU 1 /* x <- gelu(x)                (exact erf form, nn.GELU default)          */
+#define LMN_SRC_DROP 2 /* x <- x * keep(seed,idx)/(1-p) (same mask as the forward epilogue)      */
+
+typedef struct {
+  const float* ptr;   /* NHWC base, already offset to the slice's first channel                   */
+  const float* scale; /* optional [B][C] per-(image,channel) multiplier (SE gate) or NULL         */
+  int32_t C;          /* channels contributed by this source (multiple of 4)                      */
+  int32_t cstride;    /* floats between consecutive pixels                                        */
+  int32_t flags;      /* LMN_SRC_*                                                                */
+  uint32_t drop_seed; /* dropout stream id for LMN_SRC_DROP                                       */
+  float drop_p;       /* dropout probability for LMN_SRC_DROP                                     */
+  int32_t _pad;
+} lmn_src_t;
+
+/* epilogues; v = accumulator + bias[co] */
+#define LMN_EP_LINEAR 0     /* o = v                                                              */
+#define LMN_EP_AFFINE_ACT 1 /* o = act(v*p0[co] + p1[co])           (BN folded to scale/shift)    */
+#define LMN_EP_DGELU 2      /* o = v * gelu'(aux)                    (Mlp backward through GELU)  */
+#define LMN_EP_BN_BWD1 3    /* zh=(v-p0)*p1; h=p2*zh+p3; o=aux*act'(h); stats+=(o, o*zh)         */
+#define LMN_EP_BN_BWD2 4    /* zh=(v-p0)*p1; o=p2*aux - p3 - zh*p4                                */
+#define LMN_EP_SE_BWD 5     /* o = v; stats[b][co] += v*gelu(aux)    (d gate of the SE block)     */
+
+#define LMN_ACT_NONE 0
+#define LMN_ACT_HSWISH 1 /* nn.Hardswish  core/modules.py:539 */
+#define LMN_ACT_GELU 2   /* nn.GELU       core/modules.py:574,98,134 */
+
+/* what `stats` accumulates (atomicAdd) */
+#define LMN_STATS_NONE 0
+#define LMN_STATS_SUM_SQ 1 /* [2][Cout]: sum v, sum v*v over all pixels (BatchNorm batch statistics) */
+#define LMN_STATS_EP 2     /* defined by the epilogue (BN_BWD1: [2][Cout]; SE_BWD: [B][Cout])        */
+
+typedef struct {
+  int32_t B, Hout, Wout, Hin, Win;
+  int32_t ksize;      /* 1 or 3; padding = ksize/2                                                */
+  int32_t stride;     /* 1 or 2                                                                   */
+  int32_t transposed; /* 0: out(y,x) reads in(y*s + t - pad)                                      */
+                      /* 1: data-gradient form: out(y,x) reads in((y + pad - t)/s) when divisible  */
+  int32_t nsrc;       /* 1..3 sources, concatenated along the reduction (input-channel) axis      */
+  int32_t Cout;
+  lmn_src_t src[3];
+  const float* wpack; /* weights in MFMA fragment order, see lmn_conv_pack                        */
+  const float* bias;  /* [Cout] or NULL                                                           */
+  const float* p0;
+  const float* p1;
+  const float* p2;
+  const float* p3;
+  const float* p4;       /* per-Cout epilogue vectors                                             */
+  const float* aux;      /* epilogue tensor sampled at the output element, or NULL                */
+  const float* residual; /* added after everything else, or NULL                                  */
+  float* out;            /* NULL: nothing is written (statistics-only pass)                       */
+  float* stats;          /* see stats_mode                                                        */
+  int32_t aux_cstride, res_cstride, out_cstride;
+  int32_t epilogue, act, stats_mode;
+  float drop_p;       /* >0: epilogue dropout  o <- o*keep/(1-p) before the residual add          */
+  uint32_t drop_seed; /* (nn.Dropout(0.1), core/modules.py:48,53,55)                              */
+} lmn_conv_args_t;
+
+/* number of floats lmn_conv_pack writes for (ksize, Cout, src channel counts c[nsrc]) */
+int64_t lmn_conv_pack_size(int ksize, int Cout, int nsrc, const int32_t* c);
+/* w: torch layout [Cout][Cin][k][k] (Cin = sum c[]; Linear weights are k=1).
+ * transposed=0 packs for lmn_conv_fwd(args.transposed=0): rows = Cout, reduction = Cin.
+ * transposed=1 packs the data-gradient operator: rows = Cin (single source of Cout channels);
+ *   `c` then lists ONE entry = Cout of the forward conv, `row_off`/`rows` select the slice of
+ *   forward input channels whose gradient is produced (one call per forward source).        */
+int lmn_conv_pack(const float* w, float* wpack, int ksize, int Cout, int Cin, int nsrc, const int32_t* c,
+                  int transposed, int row_off, int rows, lmn_stream_t stream);
+int lmn_conv_fwd(const lmn_conv_args_t* args, lmn_stream_t stream);
+
+/* Weight/bias gradient:  dW[co][ci][ty][tx] += sum_pixels dy[p][co] * src(p*s + t - pad)[ci]
+ * (sources and their on-load transforms exactly as in the forward call), db[co] += sum dy.
+ * dW is the torch-layout gradient [Cout][Cin][k][k] of the forward weight; accumulates
+ * (atomicAdd) -- zero it first.  `dy` has pixel stride dy_cstride; dy_flags/dy_seed/dy_p allow
+ * LMN_SRC_DROP on dy (gradient through the epilogue dropout).                                 */
+typedef struct {
+  int32_t B, Hout, Wout, Hin, Win, ksize, stride, nsrc, Cout;
+  lmn_src_t src[3];
+  const float* dy;
+  int32_t dy_cstride;
+  int32_t dy_flags;
+  uint32_t dy_seed;
+  float dy_p;
+  float* dW;
+  float* db; /* or NULL */
+} lmn_wgrad_args_t;
+int lmn_sizeof_wgrad_args(void);
+int lmn_conv_wgrad(const lmn_wgrad_args_t* args, lmn_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Multi-branch depthwise stencil of ReparamConv (row A2): four depthwise convs 5x5, 3x3, 3x1,
+ * 1x3 (zero pad k/2, no bias), each followed by its own BatchNorm, summed, then GELU
+ * (core/modules.py:548-574, 592-597).  Weight pointers use torch layouts [E][1][kh][kw].
+ * ------------------------------------------------------------------------------------------ */
+/* batch statistics of the four branch outputs: stats[8][E] += (sum y_b, sum y_b^2), b=0..3
+ * in the order large(5x5), square(3x3), ver(3x1), hor(1x3). */
+int lmn_dw_stats(const float* x1, int B, int H, int W, int E, const float* w5, const float* w3, const float* wv,
+                 const float* wh, float* stats, lmn_stream_t stream);
+/* pre = sum_b A_b * conv_b(x1) + bias  expressed as ONE merged 5x5 stencil keff[E][25] + beff[E]
+ * (training: A_b = gamma_b*rstd_b from lmn_dw_stats; eval/deploy: running stats, i.e. exactly
+ * ReparamConv.get_equivalent_kernel_bias, core/modules.py:622-642).  Writes `pre` (the GELU
+ * input) and accumulates gsum[B][E] += sum_hw gelu(pre) for the SE squeeze (modules.py:1030). */
+int lmn_dw_fwd(const float* x1, float* pre, float* gsum, int B, int H, int W, int E, const float* keff,
+               const float* beff, lmn_stream_t stream);
+/* builds keff/beff on the device from the four branch weights and per-branch affine (A_b, shift_b) */
+int lmn_dw_merge(const float* w5, const float* w3, const float* wv, const float* wh, const float* A /*[4][E]*/,
+                 const float* shift /*[4][E]*/, float* keff, float* beff, int E, lmn_stream_t stream);
+/* backward, pass 1: dpre = (u*s[b,e] + dm[b,e]) * gelu'(pre); writes dpre and accumulates
+ * bstats[5][E] += (sum dpre, sum dpre*y_b for the 4 branches).                               */
+int lmn_dw_bwd_stats(const float* x1, const float* pre, const float* u, const float* s, const float* dm,
+                     float* dpre, int B, int H, int W, int E, const float* w5, const float* w3, const float* wv,
+                     const float* wh, float* bstats, lmn_stream_t stream);
+/* backward, pass 2: f_b = cA[b]*dpre + cC[b]*y_b + cD[b] (inside the image), dx1 = sum_b w_b^T * f_b,
+ * dW_b[e][t] += sum_p f_b[p] * x1[p+t]   (dwgrad = [E][40]: 25 + 9 + 3 + 3 taps).             */
+int lmn_dw_bwd(const float* x1, const float* dpre, float* dx1, int B, int H, int W, int E, const float* w5,
+               const float* w3, const float* wv, const float* wh, const float* cA, const float* cC,
+               const float* cD, float* dwgrad, lmn_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * SE gate (core/modules.py:1020-1036): s = hardsigmoid(W2 relu(W1 m + b1) + b2), m = gsum/HW.
+ * ------------------------------------------------------------------------------------------ */
+int lmn_se_fwd(const float* gsum, float inv_hw, const float* w1, const float* b1, const float* w2, const float* b2,
+               float* s, float* hidden, int B, int E, int R, lmn_stream_t stream);
+/* ds[B][E] (= sum_hw u*g) -> dm[B][E] (already divided by HW) and parameter gradients (+=). */
+int lmn_se_bwd(const float* ds, const float* gsum, float inv_hw, const float* w1, const float* b1, const float* w2,
+               const float* b2, const float* hidden, float* dm, float* dw1, float* db1, float* dw2, float* db2,
+               int B, int E, int R, lmn_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Neighborhood attention core (row A7; natten2dqkrpb + softmax + natten2dav fused).
+ * qkv: [B,H,W,3C] with channel = which*C + head*hd + d (the layout natten's module gives:
+ * reshape(B,H,W,3,heads,hd)); out: [B,H,W,C] channel = head*hd + d; rpb: [heads][2K-1][2K-1].
+ * K = 3 (the reference hard-codes kernel_size=3, core/modules.py:509).  scale = hd^-0.5.
+ * ------------------------------------------------------------------------------------------ */
+int lmn_na_fwd(const float* qkv, const float* rpb, float* out, int B, int H, int W, int heads, int hd, float scale,
+               lmn_stream_t stream);
+/* dqkv must be zeroed by the caller (k/v gradients are scattered with atomics); drpb += */
+int lmn_na_bwd(const float* qkv, const float* rpb, const float* dout, float* dqkv, float* drpb, int B, int H,
+               int W, int heads, int hd, float scale, lmn_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Dense global attention of GFT (core/modules.py:267-279): qkv [B,N,3C] (channel = which*C +
+ * head*hd + d), out [B,N,C].  N <= 1024 tokens, hd <= 32.
+ * ------------------------------------------------------------------------------------------ */
+int lmn_gattn_fwd(const float* qkv, float* out, float* lse, int B, int N, int heads, int hd, float scale,
+                  lmn_stream_t stream);
+/* delta: caller workspace [B*heads*N]; dqkv is fully overwritten (no atomics) */
+int lmn_gattn_bwd(const float* qkv, const float* out, const float* dout, const float* lse, float* dqkv, float* delta,
+                  int B, int N, int heads, int hd, float scale, lmn_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * LayerNorm over the channel axis of NHWC rows (core/modules.py:330,333,508,511); eps = 1e-5.
+ * ------------------------------------------------------------------------------------------ */
+int lmn_ln_fwd(const float* x, const float* gamma, const float* beta, float* y, int64_t rows, int C,
+               lmn_stream_t stream);
+/* dx = LN backward (+ dres if not NULL: the residual branch's gradient); dgamma/dbeta += */
+int lmn_ln_bwd(const float* x, const float* gamma, const float* dy, const float* dres, float* dx, float* dgamma,
+               float* dbeta, int64_t rows, int C, lmn_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * BatchNorm(batch stats)+GELU tail of M2Skip/M3Skip.fuse_conv (core/modules.py:96-99,121-123,131-134)
+ * on a stored conv output z:  y = gelu(z*a[c] + b[c]).
+ * ------------------------------------------------------------------------------------------ */
+int lmn_bnact_fwd(const float* z, const float* a, const float* b, float* y, int64_t rows, int C, int act,
+                  lmn_stream_t stream);
+/* pass 1: dh = dy*act'(h); stats[2][C] += (sum dh, sum dh*zhat) ; pass 2: dz = c1*dh - c2 - zhat*c3 */
+int lmn_bnact_bwd_stats(const float* z, const float* dy, const float* mean, const float* rstd, const float* gamma,
+                        const float* beta, float* stats, int64_t rows, int C, int act, lmn_stream_t stream);
+int lmn_bnact_bwd(const float* z, const float* dy, const float* mean, const float* rstd, const float* gamma,
+                  const float* beta, const float* c1, const float* c2, const float* c3, float* dz, int64_t rows,
+                  int C, int act, lmn_stream_t stream);
+
+/* BatchNorm bookkeeping on [C]-vectors (momentum 0.1, unbiased running var; torch semantics).
+ * sums = [2][C] (sum, sumsq) over `count` elements.  Writes mean, rstd (biased var + eps),
+ * A = gamma*rstd, shift = beta - mean*A, and updates running_mean/var in place if not NULL.   */
+int lmn_bn_finalize(const float* sums, float count, const float* gamma, const float* beta, float eps,
+                    float momentum, float* mean, float* rstd, float* A, float* shift, float* running_mean,
+                    float* running_var, int C, lmn_stream_t stream);
+/* BN backward coefficients from bstats = [2][C] (S0 = sum dh, S1 = sum dh*zhat):
+ * dgamma += S1, dbeta += S0, c1 = A, c2 = A*S0/N, c3 = A*S1/N                                   */
+int lmn_bn_bwd_coef(const float* bstats, float count, const float* A, float* dgamma, float* dbeta, float* c1,
+                    float* c2, float* c3, int C, lmn_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Resampling rows: bilinear x2 upsample with align_corners=True (core/LM_Net.py:59-72,
+ * modules.py:94,129) and the exact f x f mean pool of PyramidPool (modules.py:496).
+ * ------------------------------------------------------------------------------------------ */
+int lmn_up2_fwd(const float* x, float* y, int B, int Hin, int Win, int C, int x_cstride, int y_cstride,
+                lmn_stream_t stream);
+int lmn_up2_bwd(const float* dy, float* dx, int B, int Hin, int Win, int C, int dy_cstride, int dx_cstride,
+                lmn_stream_t stream);
+int lmn_avgpool_fwd(const float* x, float* y, int B, int Hout, int Wout, int f, int C, int x_cstride,
+                    int y_cstride, lmn_stream_t stream);
+/* dx = (accumulate ? dx : 0) + dy/(f*f) broadcast over each f x f window */
+int lmn_avgpool_bwd(const float* dy, float* dx, int B, int Hout, int Wout, int f, int C, int dy_cstride,
+                    int dx_cstride, int accumulate, lmn_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Boundary layout rows.  The network input arrives NCHW [B,channel,H,W] (core/LM_Net.py:95) and the
+ * logits leave NCHW [B,n_classes,H,W] (core/LM_Net.py:122-123); inside, everything is NHWC.  The
+ * segmentation head output_layer (1x1 conv, core/LM_Net.py:87) runs on the generic conv with its
+ * rows padded to a multiple of 4, then lmn_nhwc_to_nchw keeps the first n_classes channels.
+ * ------------------------------------------------------------------------------------------ */
+/* y[b,h,w,0:C] = x[b,0:C,h,w]; y[b,h,w,C:y_cstride] = 0 */
+int lmn_nchw_to_nhwc(const float* x, float* y, int B, int C, int H, int W, int y_cstride, lmn_stream_t stream);
+/* y[b,0:C,h,w] = x[b,h,w,0:C]  (x has pixel stride x_cstride) */
+int lmn_nhwc_to_nchw(const float* x, float* y, int B, int C, int H, int W, int x_cstride, lmn_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Small utilities
+ * ------------------------------------------------------------------------------------------ */
+int lmn_fill(float* p, float v, int64_t n, lmn_stream_t stream);
+/* y = a + b (+ c) (+ d); any of c,d may be NULL; y may alias a */
+int lmn_add(const float* a, const float* b, const float* c, const float* d, float* y, int64_t n,
+            lmn_stream_t stream);
+/* out[C] += column sums of x[rows][cstride] (bias gradients) */
+int lmn_colsum(const float* x, float* out, int64_t rows, int C, int cstride, lmn_stream_t stream);
+/* copy a channel slice: y[rows][y_cstride][0:C] = x[rows][x_cstride][0:C] */
+int lmn_copy_slice(const float* x, float* y, int64_t rows, int C, int x_cstride, int y_cstride,
+                   lmn_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LMNET_HIP_H */

@@ -1,0 +1,82 @@
+// Shared device/host helpers for liblmnet_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/lmnet_hip.h"
+
+#define LMN_WAVE 64
+
+extern thread_local char g_lmn_err[256];
+
+#define LMN_REQUIRE(cond, ...)                           \
+  do {                                                   \
+    if (!(cond)) {                                       \
+      snprintf(g_lmn_err, sizeof(g_lmn_err), __VA_ARGS__); \
+      return LMN_E_BADARG;                               \
+    }                                                    \
+  } while (0)
+
+static inline int lmn_launch_status(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    snprintf(g_lmn_err, sizeof(g_lmn_err), "%s: %s", what, hipGetErrorString(e));
+    return (int)e;
+  }
+  return 0;
+}
+
+static inline int lmn_cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// ---------------------------------------------------------------- activations (exact torch forms)
+__device__ __forceinline__ float lmn_gelu(float x) {  // nn.GELU() default (erf form)
+  return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+}
+__device__ __forceinline__ float lmn_dgelu(float x) {
+  const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
+  const float pdf = 0.39894228040143267794f * __expf(-0.5f * x * x);
+  return cdf + x * pdf;
+}
+__device__ __forceinline__ float lmn_hswish(float x) {  // x * relu6(x+3)/6
+  return x * fminf(fmaxf(x + 3.0f, 0.0f), 6.0f) * (1.0f / 6.0f);
+}
+__device__ __forceinline__ float lmn_dhswish(float x) {  // ATen hardswish_backward
+  return x < -3.0f ? 0.0f : (x <= 3.0f ? x * (1.0f / 3.0f) + 0.5f : 1.0f);
+}
+__device__ __forceinline__ float lmn_hsigmoid(float x) { return fminf(fmaxf(x + 3.0f, 0.0f), 6.0f) * (1.0f / 6.0f); }
+__device__ __forceinline__ float lmn_dhsigmoid(float x) { return (x > -3.0f && x < 3.0f) ? (1.0f / 6.0f) : 0.0f; }
+
+__device__ __forceinline__ float lmn_act(float x, int act) {
+  return act == LMN_ACT_HSWISH ? lmn_hswish(x) : (act == LMN_ACT_GELU ? lmn_gelu(x) : x);
+}
+__device__ __forceinline__ float lmn_dact(float x, int act) {
+  return act == LMN_ACT_HSWISH ? lmn_dhswish(x) : (act == LMN_ACT_GELU ? lmn_dgelu(x) : 1.0f);
+}
+
+// ---------------------------------------------------------------- counter-based dropout mask
+// keep(seed, idx) is a pure function of the dropout stream id and the element's linear index in its
+// tensor, so forward and backward regenerate the same mask without storing it.
+__device__ __forceinline__ uint32_t lmn_hash32(uint32_t x) {
+  x ^= x >> 16;
+  x *= 0x7feb352dU;
+  x ^= x >> 15;
+  x *= 0x846ca68bU;
+  x ^= x >> 16;
+  return x;
+}
+// returns 0 or 1/(1-p)
+__device__ __forceinline__ float lmn_drop_scale(uint32_t seed, uint32_t idx, float p, float inv_keep) {
+  const uint32_t h = lmn_hash32(idx * 0x9E3779B9U + seed) ^ lmn_hash32(seed ^ 0x85ebca6bU);
+  const float u = (float)(lmn_hash32(h) >> 8) * (1.0f / 16777216.0f);
+  return u >= p ? inv_keep : 0.0f;
+}
+
+// ---------------------------------------------------------------- wave helpers (64 lanes)
+__device__ __forceinline__ float lmn_wave_sum(float v) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+  return v;
+}

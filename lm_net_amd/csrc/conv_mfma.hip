@@ -1,0 +1,652 @@
+// Dense convolution family on the CDNA4 matrix cores -- forward, data-gradient and weight-gradient.
+//
+// One kernel family serves every nn.Conv2d(k=1|3, stride 1|2) and nn.Linear on the LM-Net path
+// (reference call sites listed in include/lmnet_hip.h).  Design (MI355X-first, not a translation):
+//
+//  * implicit GEMM on v_mfma_f32_16x16x4_f32 (exact fp32, k-ordered fma chain): M = output
+//    channels, N = 16 output pixels ("pixel group"), K = (tap, input channel).  With M on the MFMA
+//    row index each lane ends up holding 4 CONSECUTIVE output channels of ONE pixel, so the epilogue
+//    (bias / BN affine / activation / dropout / residual) and the NHWC store are float4-wide.
+//  * no LDS and no barriers: the B operand (activations) is loaded straight from HBM/L2 as float4
+//    per lane -- lane (q = lane>>4, n = lane&15) loads channels 16t+4q..+3 of pixel n; element j of
+//    that float4 feeds MFMA j of the K16 block, whose k index q therefore means channel 16t+4q+j.
+//    The weights are pre-packed (lmn_conv_pack) in exactly that fragment order, so the A operand is
+//    one coalesced 1 KiB float4 load per (tap, K16 block, cout tile), served by L1/L2.
+//  * a wave owns NPG pixel groups x NCT cout tiles (accumulators in registers, 4 VGPR each) and a
+//    contiguous range of group sets, so per-channel statistics (BatchNorm batch stats, SE gradient)
+//    are reduced in registers first and hit global atomics once per block.
+//  * pixel groups are flattened over one image (never straddle images: the SE scale and the
+//    per-image statistics are wave-uniform).  For the data gradient of a stride-2 conv the groups
+//    enumerate one parity class of the output at a time, so the valid taps are uniform per group.
+#include "common.h"
+
+namespace {
+
+struct ConvParams {
+  lmn_conv_args_t a;
+  int nkb[3];      // K16 blocks per source
+  int kb_off[3];   // first K16 block of each source
+  int NKB;         // total K16 blocks
+  int NCTT;        // total cout tiles
+  int ncls;        // 1 or 4 parity classes
+  int gpi;         // groups per image
+  int ng_c[4];     // groups per class
+  int Hc[4], Wc[4];
+  int total_sets;
+  float inv_keep_ep;      // 1/(1-p) of the epilogue dropout
+  float inv_keep_src[3];
+};
+
+__device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+
+template <int TAPS, int NPG, int NCT>
+__global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams P) {
+  const lmn_conv_args_t& A = P.a;
+  const int lane = threadIdx.x & 63;
+  const int q = lane >> 4, n = lane & 15;
+  const int wave = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int nwaves = gridDim.x * 4;
+  const int ct0 = blockIdx.y * NCT;
+  const int pad = A.ksize >> 1;
+  const int cs = (P.ncls == 4) ? 2 : 1;
+
+  __shared__ float s_stats[2 * NCT * 16];
+  for (int i = threadIdx.x; i < 2 * NCT * 16; i += 256) s_stats[i] = 0.f;
+  __syncthreads();
+
+  // per-lane running statistics for this wave's whole range (per-channel modes)
+  float st0[NCT][4], st1[NCT][4];
+#pragma unroll
+  for (int c = 0; c < NCT; ++c)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) st0[c][r] = st1[c][r] = 0.f;
+
+  const int set_begin = (int)(((int64_t)wave * P.total_sets) / nwaves);
+  const int set_end = (int)(((int64_t)(wave + 1) * P.total_sets) / nwaves);
+  const int total_groups = A.B * P.gpi;
+
+  for (int set = set_begin; set < set_end; ++set) {
+    // ---- decode this wave's NPG pixel groups
+    int gb[NPG], gy[NPG], gx[NPG], gpy[NPG], gpx[NPG];
+    bool gvalid[NPG];
+#pragma unroll
+    for (int g = 0; g < NPG; ++g) {
+      const int gid = set * NPG + g;
+      int b = gid / P.gpi, r = gid - b * P.gpi, c = 0;
+      if (P.ncls == 4) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+          if (c == k && r >= P.ng_c[k]) { r -= P.ng_c[k]; c = k + 1; }
+      }
+      const int Wc = P.Wc[c], HWc = P.Hc[c] * Wc;
+      const int pi = r * 16 + n;
+      const int yc = pi / Wc, xc = pi - yc * Wc;
+      gpy[g] = c >> 1;
+      gpx[g] = c & 1;
+      gb[g] = b;
+      gy[g] = yc * cs + gpy[g];
+      gx[g] = xc * cs + gpx[g];
+      gvalid[g] = (gid < total_groups) && (pi < HWc);
+    }
+
+    f32x4 acc[NPG][NCT];
+#pragma unroll
+    for (int g = 0; g < NPG; ++g)
+#pragma unroll
+      for (int c = 0; c < NCT; ++c) acc[g][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    for (int tap = 0; tap < TAPS; ++tap) {
+      const int ty = (TAPS == 9) ? tap / 3 : 0, tx = (TAPS == 9) ? tap - ty * 3 : 0;
+      int64_t inpix[NPG];
+      bool inb[NPG];
+      bool any = false;
+#pragma unroll
+      for (int g = 0; g < NPG; ++g) {
+        int iy, ix;
+        bool ok = gvalid[g];
+        if (!A.transposed) {
+          iy = gy[g] * A.stride + ty - pad;
+          ix = gx[g] * A.stride + tx - pad;
+        } else {
+          const int ny = gy[g] + pad - ty, nx = gx[g] + pad - tx;
+          if (A.stride == 2) {
+            ok = ok && !((ny | nx) & 1);
+            iy = ny >> 1;
+            ix = nx >> 1;
+          } else {
+            iy = ny;
+            ix = nx;
+          }
+          ok = ok && ny >= 0 && nx >= 0;
+        }
+        ok = ok && iy >= 0 && iy < A.Hin && ix >= 0 && ix < A.Win;
+        inb[g] = ok;
+        inpix[g] = ((int64_t)gb[g] * A.Hin + iy) * A.Win + ix;
+        any = any || ok;
+      }
+      if (__ballot(any) == 0ull) continue;  // wave-uniform: no lane of any group reads this tap
+
+#pragma unroll 1
+      for (int s = 0; s < A.nsrc; ++s) {
+        const lmn_src_t& S = A.src[s];
+        for (int kbs = 0; kbs < P.nkb[s]; ++kbs) {
+          const int ch = kbs * 16 + q * 4;
+          const bool chok = ch < S.C;
+          f32x4 xv[NPG];
+#pragma unroll
+          for (int g = 0; g < NPG; ++g) {
+            f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (inb[g] && chok) {
+              v = ld4(S.ptr + inpix[g] * S.cstride + ch);
+              if (S.flags & LMN_SRC_GELU) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = lmn_gelu(v[j]);
+              }
+              if (S.flags & LMN_SRC_DROP) {
+                const uint32_t idx = (uint32_t)(inpix[g] * S.C + ch);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] *= lmn_drop_scale(S.drop_seed, idx + j, S.drop_p, P.inv_keep_src[s]);
+              }
+              if (S.scale) {
+                const f32x4 sc = ld4(S.scale + (int64_t)gb[g] * S.C + ch);
+                v *= sc;
+              }
+            }
+            xv[g] = v;
+          }
+          const float* wp = P.a.wpack + ((((int64_t)tap * P.NKB + P.kb_off[s] + kbs) * P.NCTT + ct0) * 64 + lane) * 4;
+#pragma unroll
+          for (int c = 0; c < NCT; ++c) {
+            if (ct0 + c < P.NCTT) {
+              const f32x4 wv = ld4(wp + c * 256);
+#pragma unroll
+              for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int g = 0; g < NPG; ++g)
+                  acc[g][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[j], xv[g][j], acc[g][c], 0, 0, 0);
+            }
+          }
+        }
+      }
+    }
+
+    // ---- epilogue: lane holds channels co..co+3 of its pixel, per (g, c)
+#pragma unroll
+    for (int g = 0; g < NPG; ++g) {
+      const int64_t opix = ((int64_t)gb[g] * A.Hout + gy[g]) * A.Wout + gx[g];
+      float sb0[NCT][4];  // per-image statistic (SE_BWD), flushed per group
+#pragma unroll
+      for (int c = 0; c < NCT; ++c) {
+        const int co = (ct0 + c) * 16 + q * 4;
+        const bool cok = (ct0 + c < P.NCTT) && co < A.Cout;
+        f32x4 v = acc[g][c];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) sb0[c][r] = 0.f;
+        if (gvalid[g] && cok) {
+          if (A.bias) v += ld4(A.bias + co);
+          f32x4 o = v;
+          if (A.stats_mode == LMN_STATS_SUM_SQ) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { st0[c][r] += v[r]; st1[c][r] += v[r] * v[r]; }
+          }
+          f32x4 ax = f32x4{0.f, 0.f, 0.f, 0.f};
+          if (A.aux) ax = ld4(A.aux + opix * A.aux_cstride + co);
+          switch (A.epilogue) {
+            case LMN_EP_AFFINE_ACT: {
+              const f32x4 s0 = ld4(A.p0 + co), s1 = ld4(A.p1 + co);
+#pragma unroll
+              for (int r = 0; r < 4; ++r) o[r] = lmn_act(v[r] * s0[r] + s1[r], A.act);
+            } break;
+            case LMN_EP_DGELU: {
+#pragma unroll
+              for (int r = 0; r < 4; ++r) o[r] = v[r] * lmn_dgelu(ax[r]);
+            } break;
+            case LMN_EP_BN_BWD1: {
+              const f32x4 mu = ld4(A.p0 + co), rs = ld4(A.p1 + co), ga = ld4(A.p2 + co), be = ld4(A.p3 + co);
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                const float zh = (v[r] - mu[r]) * rs[r];
+                const float h = ga[r] * zh + be[r];
+                o[r] = ax[r] * lmn_dact(h, A.act);
+                st0[c][r] += o[r];
+                st1[c][r] += o[r] * zh;
+              }
+            } break;
+            case LMN_EP_BN_BWD2: {
+              const f32x4 mu = ld4(A.p0 + co), rs = ld4(A.p1 + co), c1 = ld4(A.p2 + co), c2 = ld4(A.p3 + co),
+                          c3 = ld4(A.p4 + co);
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                const float zh = (v[r] - mu[r]) * rs[r];
+                o[r] = c1[r] * ax[r] - c2[r] - zh * c3[r];
+              }
+            } break;
+            case LMN_EP_SE_BWD: {
+#pragma unroll
+              for (int r = 0; r < 4; ++r) sb0[c][r] = v[r] * lmn_gelu(ax[r]);
+            } break;
+            default: break;
+          }
+          if (A.drop_p > 0.f) {
+            const uint32_t idx = (uint32_t)(opix * A.Cout + co);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[r] *= lmn_drop_scale(A.drop_seed, idx + r, A.drop_p, P.inv_keep_ep);
+          }
+          if (A.residual) o += ld4(A.residual + opix * A.res_cstride + co);
+          if (A.out) *reinterpret_cast<f32x4*>(A.out + opix * A.out_cstride + co) = o;
+        }
+      }
+      if (A.epilogue == LMN_EP_SE_BWD) {
+        // reduce over the 16 pixels of the group (lanes sharing q), one atomic per channel per group
+#pragma unroll
+        for (int c = 0; c < NCT; ++c)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float t = sb0[c][r];
+            t += __shfl_xor(t, 1, 64);
+            t += __shfl_xor(t, 2, 64);
+            t += __shfl_xor(t, 4, 64);
+            t += __shfl_xor(t, 8, 64);
+            const int co = (ct0 + c) * 16 + q * 4 + r;
+            if (n == 0 && (ct0 + c < P.NCTT) && co < A.Cout && (set * NPG + g) < total_groups)
+              atomicAdd(A.stats + (int64_t)gb[g] * A.Cout + co, t);
+          }
+      }
+    }
+  }
+
+  // ---- per-channel statistics: wave shuffle -> LDS -> one global atomic per channel per block
+  const bool chan_stats = (A.stats_mode == LMN_STATS_SUM_SQ) || (A.epilogue == LMN_EP_BN_BWD1);
+  if (chan_stats) {
+#pragma unroll
+    for (int c = 0; c < NCT; ++c)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float a = st0[c][r], b = st1[c][r];
+#pragma unroll
+        for (int m = 1; m <= 8; m <<= 1) {
+          a += __shfl_xor(a, m, 64);
+          b += __shfl_xor(b, m, 64);
+        }
+        if (n == 0) {
+          atomicAdd(&s_stats[c * 16 + q * 4 + r], a);
+          atomicAdd(&s_stats[NCT * 16 + c * 16 + q * 4 + r], b);
+        }
+      }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * NCT * 16; i += 256) {
+      const int which = i / (NCT * 16), cc = i - which * NCT * 16;
+      const int co = ct0 * 16 + cc;
+      if (co < A.Cout) atomicAdd(A.stats + (int64_t)which * A.Cout + co, s_stats[i]);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------ weight packing
+__global__ void conv_pack_kernel(const float* __restrict__ w, float* __restrict__ wp, int taps, int Cout, int Cin,
+                                 int nsrc, int c0, int c1, int c2, int transposed, int row_off, int rows,
+                                 int64_t total) {
+  const int cs[3] = {c0, c1, c2};
+  int nkb[3], kboff[3], cbase[3], NKB = 0, cb = 0;
+  for (int s = 0; s < 3; ++s) {
+    nkb[s] = s < nsrc ? (cs[s] + 15) / 16 : 0;
+    kboff[s] = NKB;
+    cbase[s] = cb;
+    NKB += nkb[s];
+    cb += s < nsrc ? cs[s] : 0;
+  }
+  const int nrows = transposed ? rows : Cout;
+  const int NCTT = (nrows + 15) / 16;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int j = (int)(i & 3);
+    const int lane = (int)((i >> 2) & 63);
+    int64_t t = i >> 8;
+    const int ct = (int)(t % NCTT);
+    t /= NCTT;
+    const int kb = (int)(t % NKB);
+    const int tap = (int)(t / NKB);
+    int s = 0;
+    while (s + 1 < nsrc && kb >= kboff[s + 1]) ++s;
+    const int kk = (kb - kboff[s]) * 16 + (lane >> 4) * 4 + j;  // reduction index inside the source
+    const int row = ct * 16 + (lane & 15);
+    float v = 0.f;
+    if (row < nrows && kk < cs[s]) {
+      if (!transposed) {
+        v = w[((int64_t)row * Cin + cbase[s] + kk) * taps + tap];
+      } else {  // rows = forward input channels, reduction = forward output channels
+        v = w[((int64_t)kk * Cin + row_off + row) * taps + tap];
+      }
+    }
+    wp[i] = v;
+  }
+}
+
+// ------------------------------------------------------------------------------------ weight gradient
+struct WgradParams {
+  lmn_wgrad_args_t a;
+  int ntile_src[3];  // 16-channel tiles per source
+  int ntile_off[3];
+  int cbase[3];
+  int NNTT, NMTT;    // total cin tiles (sum over sources), total cout tiles
+  int Cin;
+  int nsets_n;       // number of cin tile sets
+  int steps_per_img;
+  int64_t total_steps;
+  float inv_keep_src[3];
+  float inv_keep_dy;
+};
+
+template <int TAPS, int NMT, int NNT>
+__global__ __launch_bounds__(256) void wgrad_mfma_kernel(const WgradParams P) {
+  const lmn_wgrad_args_t& A = P.a;
+  const int lane = threadIdx.x & 63;
+  const int q = lane >> 4, n = lane & 15;
+  const int wave = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int nwaves = gridDim.x * 4;
+  const int mset = blockIdx.y / P.nsets_n, nset = blockIdx.y - mset * P.nsets_n;
+  const int mt0 = mset * NMT, nt0 = nset * NNT;
+  const int pad = A.ksize >> 1;
+  const int HWo = A.Hout * A.Wout;
+
+  // which source / channel each of this wave's cin tiles maps to
+  const float* sptr[NNT];
+  const float* sscale[NNT];
+  int sC[NNT], scs[NNT], sflags[NNT], sch[NNT], sgci[NNT];
+  uint32_t sseed[NNT];
+  float sp[NNT], sik[NNT];
+#pragma unroll
+  for (int t = 0; t < NNT; ++t) {
+    const int nt = nt0 + t;
+    int s = 0;
+    while (s + 1 < A.nsrc && nt >= P.ntile_off[s + 1]) ++s;
+    const bool ok = nt < P.NNTT;
+    const int ch = (nt - P.ntile_off[s]) * 16 + n;
+    sptr[t] = A.src[s].ptr;
+    sscale[t] = A.src[s].scale;
+    sC[t] = A.src[s].C;
+    scs[t] = A.src[s].cstride;
+    sflags[t] = A.src[s].flags;
+    sseed[t] = A.src[s].drop_seed;
+    sp[t] = A.src[s].drop_p;
+    sik[t] = P.inv_keep_src[s];
+    sch[t] = (ok && ch < A.src[s].C) ? ch : -1;
+    sgci[t] = P.cbase[s] + ch;
+  }
+
+  f32x4 acc[TAPS][NMT][NNT];
+  f32x4 accb[NMT];
+#pragma unroll
+  for (int tp = 0; tp < TAPS; ++tp)
+#pragma unroll
+    for (int m = 0; m < NMT; ++m)
+#pragma unroll
+      for (int t = 0; t < NNT; ++t) acc[tp][m][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int m = 0; m < NMT; ++m) accb[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int64_t sb = (wave * P.total_steps) / nwaves, se = ((wave + 1) * P.total_steps) / nwaves;
+  for (int64_t step = sb; step < se; ++step) {
+    const int b = (int)(step / P.steps_per_img);
+    const int pi = (int)(step - (int64_t)b * P.steps_per_img) * 4 + q;
+    const bool pok = pi < HWo;
+    const int y = pi / A.Wout, x = pi - y * A.Wout;
+    const int64_t opix = (int64_t)b * HWo + pi;
+    float av[NMT];
+#pragma unroll
+    for (int m = 0; m < NMT; ++m) {
+      const int co = (mt0 + m) * 16 + n;
+      float v = 0.f;
+      if (pok && (mt0 + m) < P.NMTT && co < A.Cout) {
+        v = A.dy[opix * A.dy_cstride + co];
+        if (A.dy_flags & LMN_SRC_DROP) v *= lmn_drop_scale(A.dy_seed, (uint32_t)(opix * A.Cout + co), A.dy_p, P.inv_keep_dy);
+      }
+      av[m] = v;
+    }
+    if (A.db && nset == 0) {
+#pragma unroll
+      for (int m = 0; m < NMT; ++m) accb[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[m], 1.0f, accb[m], 0, 0, 0);
+    }
+#pragma unroll
+    for (int tp = 0; tp < TAPS; ++tp) {
+      const int ty = (TAPS == 9) ? tp / 3 : 0, tx = (TAPS == 9) ? tp % 3 : 0;
+      const int iy = y * A.stride + ty - pad, ix = x * A.stride + tx - pad;
+      const bool ok = pok && iy >= 0 && iy < A.Hin && ix >= 0 && ix < A.Win;
+      const int64_t ipix = ((int64_t)b * A.Hin + iy) * A.Win + ix;
+#pragma unroll
+      for (int t = 0; t < NNT; ++t) {
+        float v = 0.f;
+        if (ok && sch[t] >= 0) {
+          v = sptr[t][ipix * scs[t] + sch[t]];
+          if (sflags[t] & LMN_SRC_GELU) v = lmn_gelu(v);
+          if (sflags[t] & LMN_SRC_DROP) v *= lmn_drop_scale(sseed[t], (uint32_t)(ipix * sC[t] + sch[t]), sp[t], sik[t]);
+          if (sscale[t]) v *= sscale[t][(int64_t)b * sC[t] + sch[t]];
+        }
+#pragma unroll
+        for (int m = 0; m < NMT; ++m) acc[tp][m][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[m], v, acc[tp][m][t], 0, 0, 0);
+      }
+    }
+  }
+
+  // D[m = 4q + r][nn = n]: cout = 16*mtile + 4q + r, cin = tile channel n
+#pragma unroll
+  for (int tp = 0; tp < TAPS; ++tp)
+#pragma unroll
+    for (int m = 0; m < NMT; ++m)
+#pragma unroll
+      for (int t = 0; t < NNT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int co = (mt0 + m) * 16 + q * 4 + r;
+          if ((mt0 + m) < P.NMTT && co < A.Cout && sch[t] >= 0)
+            atomicAdd(A.dW + ((int64_t)co * P.Cin + sgci[t]) * TAPS + tp, acc[tp][m][t][r]);
+        }
+  if (A.db && nset == 0 && n == 0) {
+#pragma unroll
+    for (int m = 0; m < NMT; ++m)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int co = (mt0 + m) * 16 + q * 4 + r;
+        if ((mt0 + m) < P.NMTT && co < A.Cout) atomicAdd(A.db + co, accb[m][r]);
+      }
+  }
+}
+
+template <int TAPS, int NPG, int NCT>
+void launch_conv(const ConvParams& P, int blocks, int chunks, hipStream_t st) {
+  hipLaunchKernelGGL((conv_mfma_kernel<TAPS, NPG, NCT>), dim3(blocks, chunks), dim3(256), 0, st, P);
+}
+
+template <int TAPS>
+void dispatch_conv(const ConvParams& P, int nct, int npg, int blocks, int chunks, hipStream_t st) {
+  switch (nct) {
+    case 1: launch_conv<TAPS, 4, 1>(P, blocks, chunks, st); break;
+    case 2: launch_conv<TAPS, 4, 2>(P, blocks, chunks, st); break;
+    case 3: launch_conv<TAPS, 4, 3>(P, blocks, chunks, st); break;
+    case 4: launch_conv<TAPS, 2, 4>(P, blocks, chunks, st); break;
+    default: launch_conv<TAPS, 2, 6>(P, blocks, chunks, st); break;
+  }
+  (void)npg;
+}
+
+}  // namespace
+
+thread_local char g_lmn_err[256] = {0};
+
+extern "C" {
+
+int lmn_abi_version(void) { return LMN_ABI_VERSION; }
+int lmn_sizeof_conv_args(void) { return (int)sizeof(lmn_conv_args_t); }
+int lmn_sizeof_src(void) { return (int)sizeof(lmn_src_t); }
+int lmn_sizeof_wgrad_args(void) { return (int)sizeof(lmn_wgrad_args_t); }
+const char* lmn_last_error(void) { return g_lmn_err; }
+
+int64_t lmn_conv_pack_size(int ksize, int Cout, int nsrc, const int32_t* c) {
+  int64_t nkb = 0;
+  for (int s = 0; s < nsrc; ++s) nkb += (c[s] + 15) / 16;
+  return (int64_t)ksize * ksize * nkb * ((Cout + 15) / 16) * 256;
+}
+
+int lmn_conv_pack(const float* w, float* wpack, int ksize, int Cout, int Cin, int nsrc, const int32_t* c,
+                  int transposed, int row_off, int rows, lmn_stream_t stream) {
+  LMN_REQUIRE(w && wpack && c, "conv_pack: null pointer");
+  LMN_REQUIRE(ksize == 1 || ksize == 3, "conv_pack: ksize %d", ksize);
+  LMN_REQUIRE(nsrc >= 1 && nsrc <= 3, "conv_pack: nsrc %d", nsrc);
+  int csum = 0;
+  for (int s = 0; s < nsrc; ++s) csum += c[s];
+  if (!transposed) {
+    LMN_REQUIRE(csum == Cin, "conv_pack: sources sum to %d channels, weight has %d", csum, Cin);
+  } else {
+    LMN_REQUIRE(nsrc == 1 && c[0] == Cout, "conv_pack(transposed): one source of Cout=%d channels expected", Cout);
+    LMN_REQUIRE(row_off >= 0 && rows > 0 && row_off + rows <= Cin, "conv_pack(transposed): rows [%d,+%d) of %d", row_off, rows, Cin);
+  }
+  const int nrows = transposed ? rows : Cout;
+  const int64_t total = lmn_conv_pack_size(ksize, nrows, nsrc, c);
+  const int blocks = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
+  hipLaunchKernelGGL(conv_pack_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, wpack, ksize * ksize, Cout,
+                     Cin, nsrc, c[0], nsrc > 1 ? c[1] : 0, nsrc > 2 ? c[2] : 0, transposed, row_off, rows, total);
+  return lmn_launch_status("conv_pack");
+}
+
+int lmn_conv_fwd(const lmn_conv_args_t* args, lmn_stream_t stream) {
+  LMN_REQUIRE(args, "conv_fwd: null args");
+  const lmn_conv_args_t& A = *args;
+  LMN_REQUIRE(A.ksize == 1 || A.ksize == 3, "conv_fwd: ksize %d", A.ksize);
+  LMN_REQUIRE(A.stride == 1 || A.stride == 2, "conv_fwd: stride %d", A.stride);
+  LMN_REQUIRE(A.nsrc >= 1 && A.nsrc <= 3, "conv_fwd: nsrc %d", A.nsrc);
+  LMN_REQUIRE(A.Cout > 0 && A.Cout % 4 == 0, "conv_fwd: Cout %d must be a positive multiple of 4", A.Cout);
+  LMN_REQUIRE(A.B > 0 && A.Hout > 0 && A.Wout > 0 && A.Hin > 0 && A.Win > 0, "conv_fwd: empty tensor");
+  LMN_REQUIRE(A.wpack, "conv_fwd: null packed weights");
+  LMN_REQUIRE(A.out || A.stats, "conv_fwd: neither out nor stats requested");
+  LMN_REQUIRE(!(A.transposed && A.nsrc != 1), "conv_fwd: transposed form takes one source");
+  ConvParams P;
+  P.a = A;
+  P.NKB = 0;
+  for (int s = 0; s < 3; ++s) {
+    P.nkb[s] = P.kb_off[s] = 0;
+    P.inv_keep_src[s] = 1.f;
+  }
+  for (int s = 0; s < A.nsrc; ++s) {
+    LMN_REQUIRE(A.src[s].ptr && A.src[s].C > 0 && A.src[s].C % 4 == 0 && A.src[s].cstride >= A.src[s].C && A.src[s].cstride % 4 == 0,
+                "conv_fwd: source %d: C=%d cstride=%d (need multiples of 4, cstride>=C)", s, A.src[s].C, A.src[s].cstride);
+    P.nkb[s] = (A.src[s].C + 15) / 16;
+    P.kb_off[s] = P.NKB;
+    P.NKB += P.nkb[s];
+    if (A.src[s].flags & LMN_SRC_DROP) {
+      LMN_REQUIRE(A.src[s].drop_p >= 0.f && A.src[s].drop_p < 1.f, "conv_fwd: source dropout p");
+      P.inv_keep_src[s] = 1.f / (1.f - A.src[s].drop_p);
+    }
+  }
+  LMN_REQUIRE(A.drop_p >= 0.f && A.drop_p < 1.f, "conv_fwd: dropout p %f", A.drop_p);
+  P.inv_keep_ep = 1.f / (1.f - A.drop_p);
+  if (A.out) LMN_REQUIRE(A.out_cstride >= A.Cout && A.out_cstride % 4 == 0, "conv_fwd: out_cstride %d", A.out_cstride);
+  if (A.residual) LMN_REQUIRE(A.res_cstride >= A.Cout && A.res_cstride % 4 == 0, "conv_fwd: res_cstride %d", A.res_cstride);
+  if (A.aux) LMN_REQUIRE(A.aux_cstride >= A.Cout && A.aux_cstride % 4 == 0, "conv_fwd: aux_cstride %d", A.aux_cstride);
+  switch (A.epilogue) {
+    case LMN_EP_LINEAR: break;
+    case LMN_EP_AFFINE_ACT: LMN_REQUIRE(A.p0 && A.p1, "conv_fwd: AFFINE_ACT needs p0,p1"); break;
+    case LMN_EP_DGELU: LMN_REQUIRE(A.aux, "conv_fwd: DGELU needs aux"); break;
+    case LMN_EP_BN_BWD1: LMN_REQUIRE(A.aux && A.p0 && A.p1 && A.p2 && A.p3 && A.stats, "conv_fwd: BN_BWD1 operands"); break;
+    case LMN_EP_BN_BWD2: LMN_REQUIRE(A.aux && A.p0 && A.p1 && A.p2 && A.p3 && A.p4, "conv_fwd: BN_BWD2 operands"); break;
+    case LMN_EP_SE_BWD: LMN_REQUIRE(A.aux && A.stats, "conv_fwd: SE_BWD operands"); break;
+    default: LMN_REQUIRE(false, "conv_fwd: epilogue %d", A.epilogue);
+  }
+  if (A.stats_mode == LMN_STATS_SUM_SQ) LMN_REQUIRE(A.stats, "conv_fwd: SUM_SQ needs stats");
+  if (!A.transposed) {
+    LMN_REQUIRE(A.Hout == (A.Hin + 2 * (A.ksize / 2) - A.ksize) / A.stride + 1 && A.Wout == (A.Win + 2 * (A.ksize / 2) - A.ksize) / A.stride + 1,
+                "conv_fwd: out %dx%d inconsistent with in %dx%d k%d s%d", A.Hout, A.Wout, A.Hin, A.Win, A.ksize, A.stride);
+  } else {
+    LMN_REQUIRE(A.Hin == (A.Hout + 2 * (A.ksize / 2) - A.ksize) / A.stride + 1 && A.Win == (A.Wout + 2 * (A.ksize / 2) - A.ksize) / A.stride + 1,
+                "conv_fwd(T): dy %dx%d inconsistent with dx %dx%d k%d s%d", A.Hin, A.Win, A.Hout, A.Wout, A.ksize, A.stride);
+  }
+  P.NCTT = (A.Cout + 15) / 16;
+  P.ncls = (A.transposed && A.stride == 2) ? 4 : 1;
+  P.gpi = 0;
+  for (int c = 0; c < 4; ++c) {
+    P.ng_c[c] = 0;
+    P.Hc[c] = P.Wc[c] = 1;
+  }
+  for (int c = 0; c < P.ncls; ++c) {
+    if (P.ncls == 4) {
+      P.Hc[c] = (A.Hout - (c >> 1) + 1) >> 1;
+      P.Wc[c] = (A.Wout - (c & 1) + 1) >> 1;
+    } else {
+      P.Hc[c] = A.Hout;
+      P.Wc[c] = A.Wout;
+    }
+    if (P.Wc[c] < 1) P.Wc[c] = 1;  // empty class (Hout or Wout == 1): keep divisors sane
+    const int64_t px = (int64_t)((P.ncls == 4) ? ((A.Hout - (c >> 1) + 1) >> 1) * (int64_t)((A.Wout - (c & 1) + 1) >> 1) : (int64_t)A.Hout * A.Wout);
+    P.ng_c[c] = (int)((px + 15) / 16);
+    P.gpi += P.ng_c[c];
+  }
+  const int64_t total_groups = (int64_t)A.B * P.gpi;
+  LMN_REQUIRE(total_groups < (1LL << 30), "conv_fwd: too many pixel groups");
+  int nct = P.NCTT >= 6 ? 6 : (P.NCTT == 5 ? 6 : P.NCTT);
+  const int npg = nct <= 3 ? 4 : 2;
+  const int chunks = (P.NCTT + nct - 1) / nct;
+  P.total_sets = (int)((total_groups + npg - 1) / npg);
+  int blocks = (P.total_sets + 3) / 4;
+  const int maxb = 2048 / chunks > 256 ? 2048 / chunks : 256;
+  if (blocks > maxb) blocks = maxb;
+  if (blocks < 1) blocks = 1;
+  if (A.ksize == 1)
+    dispatch_conv<1>(P, nct, npg, blocks, chunks, (hipStream_t)stream);
+  else
+    dispatch_conv<9>(P, nct, npg, blocks, chunks, (hipStream_t)stream);
+  return lmn_launch_status("conv_fwd");
+}
+
+int lmn_conv_wgrad(const lmn_wgrad_args_t* args, lmn_stream_t stream) {
+  LMN_REQUIRE(args, "conv_wgrad: null args");
+  const lmn_wgrad_args_t& A = *args;
+  LMN_REQUIRE(A.ksize == 1 || A.ksize == 3, "conv_wgrad: ksize %d", A.ksize);
+  LMN_REQUIRE(A.stride == 1 || A.stride == 2, "conv_wgrad: stride %d", A.stride);
+  LMN_REQUIRE(A.nsrc >= 1 && A.nsrc <= 3, "conv_wgrad: nsrc %d", A.nsrc);
+  LMN_REQUIRE(A.dy && A.dW && A.Cout > 0 && A.dy_cstride >= A.Cout, "conv_wgrad: dy/dW/Cout");
+  LMN_REQUIRE(A.B > 0 && A.Hout > 0 && A.Wout > 0, "conv_wgrad: empty tensor");
+  WgradParams P;
+  P.a = A;
+  P.NNTT = 0;
+  P.Cin = 0;
+  for (int s = 0; s < 3; ++s) {
+    P.ntile_src[s] = P.ntile_off[s] = P.cbase[s] = 0;
+    P.inv_keep_src[s] = 1.f;
+  }
+  for (int s = 0; s < A.nsrc; ++s) {
+    LMN_REQUIRE(A.src[s].ptr && A.src[s].C > 0 && A.src[s].cstride >= A.src[s].C, "conv_wgrad: source %d", s);
+    P.ntile_src[s] = (A.src[s].C + 15) / 16;
+    P.ntile_off[s] = P.NNTT;
+    P.cbase[s] = P.Cin;
+    P.NNTT += P.ntile_src[s];
+    P.Cin += A.src[s].C;
+    if (A.src[s].flags & LMN_SRC_DROP) P.inv_keep_src[s] = 1.f / (1.f - A.src[s].drop_p);
+  }
+  P.inv_keep_dy = (A.dy_flags & LMN_SRC_DROP) ? 1.f / (1.f - A.dy_p) : 1.f;
+  P.NMTT = (A.Cout + 15) / 16;
+  P.steps_per_img = (A.Hout * A.Wout + 3) / 4;
+  P.total_steps = (int64_t)A.B * P.steps_per_img;
+  const bool small = (P.NMTT == 1 || P.NNTT == 1);
+  const int NMT = small ? 1 : 2, NNT = small ? 1 : 2;
+  const int msets = (P.NMTT + NMT - 1) / NMT;
+  P.nsets_n = (P.NNTT + NNT - 1) / NNT;
+  const int gy = msets * P.nsets_n;
+  int64_t waves_x = P.total_steps / 8;
+  const int64_t cap = 4096 / gy > 8 ? 4096 / gy : 8;
+  if (waves_x > cap) waves_x = cap;
+  if (waves_x < 1) waves_x = 1;
+  const int blocks = (int)((waves_x + 3) / 4);
+  hipStream_t st = (hipStream_t)stream;
+  if (A.ksize == 1) {
+    if (small)
+      hipLaunchKernelGGL((wgrad_mfma_kernel<1, 1, 1>), dim3(blocks, gy), dim3(256), 0, st, P);
+    else
+      hipLaunchKernelGGL((wgrad_mfma_kernel<1, 2, 2>), dim3(blocks, gy), dim3(256), 0, st, P);
+  } else {
+    if (small)
+      hipLaunchKernelGGL((wgrad_mfma_kernel<9, 1, 1>), dim3(blocks, gy), dim3(256), 0, st, P);
+    else
+      hipLaunchKernelGGL((wgrad_mfma_kernel<9, 2, 2>), dim3(blocks, gy), dim3(256), 0, st, P);
+  }
+  return lmn_launch_status("conv_wgrad");
+}
+
+}  // extern "C"

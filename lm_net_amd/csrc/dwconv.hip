@@ -1,0 +1,423 @@
+// Multi-branch depthwise stencil of ReparamConv (core/modules.py:548-574, 592-597).
+//
+//   pre = sum_b BN_b( dw_b(x1) ),  b in {5x5, 3x3, 3x1, 1x3};   g = GELU(pre)
+//
+// HBM-bound (arithmetic intensity ~1-2 FLOP/B): the job of these kernels is to move each activation
+// byte once.  In NHWC the 4 BatchNorm'd branches collapse to ONE 5x5 per-channel stencil once the
+// per-branch scale A_b = gamma_b * rstd_b is known (lmn_dw_merge) -- in eval/deploy mode that is the
+// reference's own re-parameterisation (modules.py:622-642), in training it needs the batch statistics
+// of every branch first (lmn_dw_stats, a read-only pass).
+//
+// Forward (lmn_dw_fwd, the flagship kernel): a 16x16-pixel x 24-channel tile with a 2-pixel halo is
+// staged in LDS by coalesced 16 B loads (24 fp32 = one 96 B NHWC pixel at level 0, so a halo row is
+// one contiguous 1,920 B span); each thread owns (column, channel pair) and WALKS DOWN the tile:
+// one LDS row = 5 ds_read_b64 feeds 25 packed FMAs into 5 rotating accumulators (register blocking
+// along y), so LDS traffic is 5 reads per output instead of 25, conflict-free (32 lanes x 8 B =
+// one 256 B bank row).  The epilogue stores `pre` once and accumulates the SE squeeze sum_hw GELU(pre).
+//
+// The training-only passes (statistics, and the backward through 4 separately batch-normalised
+// branches) use a simpler direct-stencil form on 8-channel chunks; they are correctness-first.
+#include "common.h"
+
+namespace {
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+constexpr int FW_TH = 16, FW_TW = 16, FW_CCH = 24, FW_NCP = FW_CCH / 2, FW_THREADS = FW_TW * FW_NCP;  // 192
+constexpr int FW_RW = FW_TW + 4, FW_RH = FW_TH + 4;
+
+__global__ __launch_bounds__(FW_THREADS) void dw_fwd_kernel(const float* __restrict__ x1, float* __restrict__ pre,
+                                                            float* __restrict__ gsum, int H, int W, int E,
+                                                            const float* __restrict__ keff,
+                                                            const float* __restrict__ beff, int tiles_x) {
+  __shared__ __attribute__((aligned(16))) float tile[FW_RH * FW_RW * FW_CCH];
+  __shared__ float gs_s[FW_CCH];
+  const int tid = threadIdx.x;
+  const int ty0 = (blockIdx.x / tiles_x) * FW_TH, tx0 = (blockIdx.x % tiles_x) * FW_TW;
+  const int ch0 = blockIdx.y * FW_CCH;
+  const int b = blockIdx.z;
+  const float* xb = x1 + (int64_t)b * H * W * E;
+
+  if (tid < FW_CCH) gs_s[tid] = 0.f;
+  for (int i = tid; i < FW_RH * FW_RW * (FW_CCH / 4); i += FW_THREADS) {
+    const int c4 = i % (FW_CCH / 4), pix = i / (FW_CCH / 4);
+    const int r = pix / FW_RW, c = pix - r * FW_RW;
+    const int gy = ty0 - 2 + r, gx = tx0 - 2 + c;
+    f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (gy >= 0 && gy < H && gx >= 0 && gx < W)
+      v = *reinterpret_cast<const f32x4*>(xb + ((int64_t)gy * W + gx) * E + ch0 + c4 * 4);
+    *reinterpret_cast<f32x4*>(&tile[pix * FW_CCH + c4 * 4]) = v;
+  }
+
+  const int cp = tid % FW_NCP, xx = tid / FW_NCP;
+  const int ch = ch0 + cp * 2;
+  f32x2 w[25];
+#pragma unroll
+  for (int t = 0; t < 25; ++t) w[t] = f32x2{keff[(int64_t)ch * 25 + t], keff[(int64_t)(ch + 1) * 25 + t]};
+  const f32x2 bias = f32x2{beff[ch], beff[ch + 1]};
+  __syncthreads();
+
+  f32x2 acc[5];
+#pragma unroll
+  for (int k = 0; k < 5; ++k) acc[k] = f32x2{0.f, 0.f};
+  f32x2 gs = f32x2{0.f, 0.f};
+  const int gx = tx0 + xx;
+#pragma unroll
+  for (int r = 0; r < FW_RH; ++r) {
+    f32x2 in[5];
+#pragma unroll
+    for (int dx = 0; dx < 5; ++dx) in[dx] = *reinterpret_cast<const f32x2*>(&tile[(r * FW_RW + xx + dx) * FW_CCH + cp * 2]);
+#pragma unroll
+    for (int ky = 0; ky < 5; ++ky) {
+      const int o = r - ky;
+      if (o >= 0 && o < FW_TH) {
+#pragma unroll
+        for (int dx = 0; dx < 5; ++dx) acc[o % 5] += w[ky * 5 + dx] * in[dx];
+      }
+    }
+    const int o = r - 4;
+    if (o >= 0) {
+      const int gy = ty0 + o;
+      const f32x2 p = acc[o % 5] + bias;
+      acc[o % 5] = f32x2{0.f, 0.f};
+      if (gy < H && gx < W) {
+        *reinterpret_cast<f32x2*>(pre + (((int64_t)b * H + gy) * W + gx) * E + ch) = p;
+        gs += f32x2{lmn_gelu(p[0]), lmn_gelu(p[1])};
+      }
+    }
+  }
+  atomicAdd(&gs_s[cp * 2], gs[0]);
+  atomicAdd(&gs_s[cp * 2 + 1], gs[1]);
+  __syncthreads();
+  if (tid < FW_CCH) atomicAdd(gsum + (int64_t)b * E + ch0 + tid, gs_s[tid]);
+}
+
+__global__ void dw_merge_kernel(const float* __restrict__ w5, const float* __restrict__ w3, const float* __restrict__ wv,
+                                const float* __restrict__ wh, const float* __restrict__ A, const float* __restrict__ shift,
+                                float* __restrict__ keff, float* __restrict__ beff, int E) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= E * 25) return;
+  const int e = i / 25, t = i - e * 25, ky = t / 5, kx = t - ky * 5;
+  float v = A[e] * w5[i];
+  if (ky >= 1 && ky <= 3 && kx >= 1 && kx <= 3) v += A[E + e] * w3[e * 9 + (ky - 1) * 3 + (kx - 1)];
+  if (kx == 2 && ky >= 1 && ky <= 3) v += A[2 * E + e] * wv[e * 3 + (ky - 1)];
+  if (ky == 2 && kx >= 1 && kx <= 3) v += A[3 * E + e] * wh[e * 3 + (kx - 1)];
+  keff[i] = v;
+  if (t == 0) beff[e] = shift[e] + shift[E + e] + shift[2 * E + e] + shift[3 * E + e];
+}
+
+// ------------------------------------------------------------------------------------------------
+// direct-stencil training passes: 16x16 tile, 8-channel chunk, 256 threads, thread = (pixel, pair)
+// ------------------------------------------------------------------------------------------------
+constexpr int DT = 16, DC = 8, DNCP = DC / 2;
+
+struct BranchW {  // this thread's channel pair of the four branch kernels
+  f32x2 w5[25], w3[9], wv[3], wh[3];
+};
+
+__device__ __forceinline__ void load_branch_w(BranchW& bw, const float* w5, const float* w3, const float* wv,
+                                              const float* wh, int ch) {
+#pragma unroll
+  for (int t = 0; t < 25; ++t) bw.w5[t] = f32x2{w5[(int64_t)ch * 25 + t], w5[(int64_t)(ch + 1) * 25 + t]};
+#pragma unroll
+  for (int t = 0; t < 9; ++t) bw.w3[t] = f32x2{w3[(int64_t)ch * 9 + t], w3[(int64_t)(ch + 1) * 9 + t]};
+#pragma unroll
+  for (int t = 0; t < 3; ++t) {
+    bw.wv[t] = f32x2{wv[(int64_t)ch * 3 + t], wv[(int64_t)(ch + 1) * 3 + t]};
+    bw.wh[t] = f32x2{wh[(int64_t)ch * 3 + t], wh[(int64_t)(ch + 1) * 3 + t]};
+  }
+}
+
+// stage a (DT+2*halo)^2 x DC window of an NHWC tensor around tile origin (ty0,tx0), zero outside the image
+template <int HALO>
+__device__ __forceinline__ void stage_tile(float* lds, const float* img, int H, int W, int E, int ch0, int ty0, int tx0) {
+  constexpr int R = DT + 2 * HALO;
+  for (int i = threadIdx.x; i < R * R * (DC / 4); i += blockDim.x) {
+    const int c4 = i % (DC / 4), pix = i / (DC / 4);
+    const int r = pix / R, c = pix - r * R;
+    const int gy = ty0 - HALO + r, gx = tx0 - HALO + c;
+    f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (gy >= 0 && gy < H && gx >= 0 && gx < W) v = *reinterpret_cast<const f32x4*>(img + ((int64_t)gy * W + gx) * E + ch0 + c4 * 4);
+    *reinterpret_cast<f32x4*>(&lds[pix * DC + c4 * 4]) = v;
+  }
+}
+
+// the four branch outputs at window position (r,c) (centre) of an LDS image with row length RW
+template <int RW>
+__device__ __forceinline__ void branches_at(const float* lds, int r, int c, int cp, const BranchW& bw, f32x2 y[4]) {
+  y[0] = y[1] = y[2] = y[3] = f32x2{0.f, 0.f};
+#pragma unroll
+  for (int ky = 0; ky < 5; ++ky)
+#pragma unroll
+    for (int kx = 0; kx < 5; ++kx) {
+      const f32x2 v = *reinterpret_cast<const f32x2*>(&lds[((r + ky - 2) * RW + (c + kx - 2)) * DC + cp * 2]);
+      y[0] += bw.w5[ky * 5 + kx] * v;
+      if (ky >= 1 && ky <= 3 && kx >= 1 && kx <= 3) y[1] += bw.w3[(ky - 1) * 3 + (kx - 1)] * v;
+      if (kx == 2 && ky >= 1 && ky <= 3) y[2] += bw.wv[ky - 1] * v;
+      if (ky == 2 && kx >= 1 && kx <= 3) y[3] += bw.wh[kx - 1] * v;
+    }
+}
+
+// MODE 0: forward batch statistics   stats[8][E] += (sum y_b, sum y_b^2)
+// MODE 1: backward pass 1            dpre = (u*s + dm)*gelu'(pre) -> store; stats[5][E] += (sum dpre, sum dpre*y_b)
+template <int MODE>
+__global__ __launch_bounds__(256) void dw_stats_kernel(const float* __restrict__ x1, const float* __restrict__ pre,
+                                                       const float* __restrict__ u, const float* __restrict__ s,
+                                                       const float* __restrict__ dm, float* __restrict__ dpre, int B,
+                                                       int H, int W, int E, const float* __restrict__ w5,
+                                                       const float* __restrict__ w3, const float* __restrict__ wv,
+                                                       const float* __restrict__ wh, float* __restrict__ stats,
+                                                       int tiles_x, int tiles_y) {
+  constexpr int R = DT + 4;
+  constexpr int NS = MODE == 0 ? 8 : 5;
+  __shared__ __attribute__((aligned(16))) float lds[R * R * DC];
+  __shared__ float red[NS * DC];
+  const int tid = threadIdx.x, cp = tid % DNCP;
+  const int ch0 = blockIdx.y * DC, ch = ch0 + cp * 2;
+  BranchW bw;
+  load_branch_w(bw, w5, w3, wv, wh, ch);
+  f32x2 sum[NS];
+#pragma unroll
+  for (int k = 0; k < NS; ++k) sum[k] = f32x2{0.f, 0.f};
+  for (int i = tid; i < NS * DC; i += 256) red[i] = 0.f;
+
+  const int ntiles = B * tiles_x * tiles_y;
+  for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+    const int b = t / (tiles_x * tiles_y), tt = t - b * tiles_x * tiles_y;
+    const int ty0 = (tt / tiles_x) * DT, tx0 = (tt % tiles_x) * DT;
+    __syncthreads();
+    stage_tile<2>(lds, x1 + (int64_t)b * H * W * E, H, W, E, ch0, ty0, tx0);
+    __syncthreads();
+    for (int i = tid; i < DT * DT * DNCP; i += 256) {
+      const int pix = i / DNCP, py = pix / DT, px = pix - py * DT;
+      const int gy = ty0 + py, gx = tx0 + px;
+      if (gy >= H || gx >= W) continue;
+      f32x2 y[4];
+      branches_at<R>(lds, py + 2, px + 2, cp, bw, y);
+      if (MODE == 0) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          sum[k] += y[k];
+          sum[4 + k] += y[k] * y[k];
+        }
+      } else {
+        const int64_t off = (((int64_t)b * H + gy) * W + gx) * E + ch;
+        const f32x2 pv = *reinterpret_cast<const f32x2*>(pre + off);
+        const f32x2 uv = *reinterpret_cast<const f32x2*>(u + off);
+        const f32x2 sv = *reinterpret_cast<const f32x2*>(s + (int64_t)b * E + ch);
+        const f32x2 dv = *reinterpret_cast<const f32x2*>(dm + (int64_t)b * E + ch);
+        f32x2 d;
+        d[0] = (uv[0] * sv[0] + dv[0]) * lmn_dgelu(pv[0]);
+        d[1] = (uv[1] * sv[1] + dv[1]) * lmn_dgelu(pv[1]);
+        *reinterpret_cast<f32x2*>(dpre + off) = d;
+        sum[0] += d;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) sum[1 + k] += d * y[k];
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < NS; ++k) {
+    atomicAdd(&red[k * DC + cp * 2], sum[k][0]);
+    atomicAdd(&red[k * DC + cp * 2 + 1], sum[k][1]);
+  }
+  __syncthreads();
+  for (int i = tid; i < NS * DC; i += 256) atomicAdd(stats + (int64_t)(i / DC) * E + ch0 + (i % DC), red[i]);
+}
+
+// backward pass 2:  f_b = cA_b*dpre + cC_b*y_b + cD_b inside the image (0 outside);
+//   dx1 = sum_b corr^T(f_b, w_b);   dW_b[t] += sum_p f_b[p] * x1[p+t]
+// The four branches are processed one after another through ONE LDS field F; the branch kernels live in
+// LDS (Wl) and only the current branch's taps are pulled into registers, so the 40 persistent
+// weight-gradient accumulators (per channel pair) do not spill.
+template <int KH, int KW, bool FIRST>
+__device__ __forceinline__ void dw_bwd_branch(const float* X, const float* DP, float* F, float* DX, const float* Wl,
+                                              int woff, f32x2 a, f32x2 c, f32x2 d, f32x2 (&gacc)[KH * KW], int cp,
+                                              int tid, int ty0, int tx0, int H, int W) {
+  constexpr int R4 = DT + 8, R2 = DT + 4;
+  constexpr int PH = KH / 2, PW = KW / 2;
+  f32x2 w[KH * KW];
+#pragma unroll
+  for (int t = 0; t < KH * KW; ++t) w[t] = *reinterpret_cast<const f32x2*>(&Wl[(woff + t) * DC + cp * 2]);
+  // phase A: f on the halo-2 region
+  for (int i = tid; i < R2 * R2 * DNCP; i += 256) {
+    const int pix = i / DNCP, r = pix / R2, cc = pix - r * R2;
+    const int gy = ty0 - 2 + r, gx = tx0 - 2 + cc;
+    f32x2 f = f32x2{0.f, 0.f};
+    if (gy >= 0 && gy < H && gx >= 0 && gx < W) {
+      f32x2 y = f32x2{0.f, 0.f};
+      const int xr = r + 2, xc = cc + 2;  // same pixel in X coordinates
+#pragma unroll
+      for (int ky = 0; ky < KH; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < KW; ++kx)
+          y += w[ky * KW + kx] * *reinterpret_cast<const f32x2*>(&X[((xr + ky - PH) * R4 + xc + kx - PW) * DC + cp * 2]);
+      f = a * *reinterpret_cast<const f32x2*>(&DP[pix * DC + cp * 2]) + c * y + d;
+    }
+    *reinterpret_cast<f32x2*>(&F[pix * DC + cp * 2]) = f;
+  }
+  __syncthreads();
+  // phase B: y(p) reads x1(p + t - pad)  =>  dx1(p') += w[t] * f(p' - t + pad);  dW[t] += f(p) * x1(p + t - pad)
+#pragma unroll 1
+  for (int k = 0; k < 4; ++k) {
+    const int i = tid + k * 256;
+    const int pix = i / DNCP, py = pix / DT, px = pix - py * DT;
+    const int fr = py + 2, fc = px + 2;  // F / DP coordinates
+    const int xr = py + 4, xc = px + 4;  // X coordinates
+    const f32x2 fp = *reinterpret_cast<const f32x2*>(&F[(fr * R2 + fc) * DC + cp * 2]);
+    f32x2 acc = f32x2{0.f, 0.f};
+#pragma unroll
+    for (int ky = 0; ky < KH; ++ky)
+#pragma unroll
+      for (int kx = 0; kx < KW; ++kx) {
+        acc += w[ky * KW + kx] * *reinterpret_cast<const f32x2*>(&F[((fr - ky + PH) * R2 + fc - kx + PW) * DC + cp * 2]);
+        gacc[ky * KW + kx] += fp * *reinterpret_cast<const f32x2*>(&X[((xr + ky - PH) * R4 + xc + kx - PW) * DC + cp * 2]);
+      }
+    f32x2* dst = reinterpret_cast<f32x2*>(&DX[pix * DC + cp * 2]);  // owned by this thread: no atomics
+    *dst = FIRST ? acc : (*dst + acc);
+  }
+  __syncthreads();
+}
+
+__global__ __launch_bounds__(256) void dw_bwd_kernel(const float* __restrict__ x1, const float* __restrict__ dpre,
+                                                     float* __restrict__ dx1, int B, int H, int W, int E,
+                                                     const float* __restrict__ w5, const float* __restrict__ w3,
+                                                     const float* __restrict__ wv, const float* __restrict__ wh,
+                                                     const float* __restrict__ cA, const float* __restrict__ cC,
+                                                     const float* __restrict__ cD, float* __restrict__ dwgrad,
+                                                     int tiles_x, int tiles_y) {
+  constexpr int R4 = DT + 8, R2 = DT + 4;
+  __shared__ __attribute__((aligned(16))) float X[R4 * R4 * DC];   // x1, halo 4
+  __shared__ __attribute__((aligned(16))) float DP[R2 * R2 * DC];  // dpre, halo 2
+  __shared__ __attribute__((aligned(16))) float F[R2 * R2 * DC];   // current branch's f_b, halo 2
+  __shared__ __attribute__((aligned(16))) float DX[DT * DT * DC];  // dx1 accumulated over the branches
+  __shared__ __attribute__((aligned(16))) float Wl[40 * DC];       // branch kernels [tap][channel]
+  __shared__ float red[40 * DC];
+  const int tid = threadIdx.x, cp = tid % DNCP;
+  const int ch0 = blockIdx.y * DC, ch = ch0 + cp * 2;
+  for (int i = tid; i < 40 * DC; i += 256) {
+    const int t = i / DC, e = ch0 + (i - t * DC);
+    float v;
+    if (t < 25) v = w5[(int64_t)e * 25 + t];
+    else if (t < 34) v = w3[(int64_t)e * 9 + t - 25];
+    else if (t < 37) v = wv[(int64_t)e * 3 + t - 34];
+    else v = wh[(int64_t)e * 3 + t - 37];
+    Wl[i] = v;
+    red[i] = 0.f;
+  }
+  f32x2 a[4], c[4], d[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    a[k] = f32x2{cA[k * E + ch], cA[k * E + ch + 1]};
+    c[k] = f32x2{cC[k * E + ch], cC[k * E + ch + 1]};
+    d[k] = f32x2{cD[k * E + ch], cD[k * E + ch + 1]};
+  }
+  f32x2 g5[25], g3[9], gv[3], gh[3];
+#pragma unroll
+  for (int t = 0; t < 25; ++t) g5[t] = f32x2{0.f, 0.f};
+#pragma unroll
+  for (int t = 0; t < 9; ++t) g3[t] = f32x2{0.f, 0.f};
+#pragma unroll
+  for (int t = 0; t < 3; ++t) gv[t] = gh[t] = f32x2{0.f, 0.f};
+
+  const int ntiles = B * tiles_x * tiles_y;
+  for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+    const int b = t / (tiles_x * tiles_y), tt = t - b * tiles_x * tiles_y;
+    const int ty0 = (tt / tiles_x) * DT, tx0 = (tt % tiles_x) * DT;
+    __syncthreads();
+    stage_tile<4>(X, x1 + (int64_t)b * H * W * E, H, W, E, ch0, ty0, tx0);
+    stage_tile<2>(DP, dpre + (int64_t)b * H * W * E, H, W, E, ch0, ty0, tx0);
+    __syncthreads();
+    dw_bwd_branch<5, 5, true>(X, DP, F, DX, Wl, 0, a[0], c[0], d[0], g5, cp, tid, ty0, tx0, H, W);
+    dw_bwd_branch<3, 3, false>(X, DP, F, DX, Wl, 25, a[1], c[1], d[1], g3, cp, tid, ty0, tx0, H, W);
+    dw_bwd_branch<3, 1, false>(X, DP, F, DX, Wl, 34, a[2], c[2], d[2], gv, cp, tid, ty0, tx0, H, W);
+    dw_bwd_branch<1, 3, false>(X, DP, F, DX, Wl, 37, a[3], c[3], d[3], gh, cp, tid, ty0, tx0, H, W);
+    for (int i = tid; i < DT * DT * (DC / 4); i += 256) {   // float4 rows of the finished dx1 tile
+      const int c4 = i % (DC / 4), pix = i / (DC / 4), py = pix / DT, px = pix - py * DT;
+      const int gy = ty0 + py, gx = tx0 + px;
+      if (gy < H && gx < W)
+        *reinterpret_cast<f32x4*>(dx1 + (((int64_t)b * H + gy) * W + gx) * E + ch0 + c4 * 4) = *reinterpret_cast<const f32x4*>(&DX[pix * DC + c4 * 4]);
+    }
+  }
+  // weight gradients: [E][40] = 25 (5x5) | 9 (3x3) | 3 (ver) | 3 (hor)
+  __syncthreads();
+#pragma unroll
+  for (int t = 0; t < 25; ++t) { atomicAdd(&red[t * DC + cp * 2], g5[t][0]); atomicAdd(&red[t * DC + cp * 2 + 1], g5[t][1]); }
+#pragma unroll
+  for (int t = 0; t < 9; ++t) { atomicAdd(&red[(25 + t) * DC + cp * 2], g3[t][0]); atomicAdd(&red[(25 + t) * DC + cp * 2 + 1], g3[t][1]); }
+#pragma unroll
+  for (int t = 0; t < 3; ++t) {
+    atomicAdd(&red[(34 + t) * DC + cp * 2], gv[t][0]);
+    atomicAdd(&red[(34 + t) * DC + cp * 2 + 1], gv[t][1]);
+    atomicAdd(&red[(37 + t) * DC + cp * 2], gh[t][0]);
+    atomicAdd(&red[(37 + t) * DC + cp * 2 + 1], gh[t][1]);
+  }
+  __syncthreads();
+  for (int i = tid; i < 40 * DC; i += 256) {
+    const int t = i / DC, cc = i - t * DC;
+    atomicAdd(dwgrad + (int64_t)(ch0 + cc) * 40 + t, red[i]);
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int lmn_dw_fwd(const float* x1, float* pre, float* gsum, int B, int H, int W, int E, const float* keff,
+               const float* beff, lmn_stream_t stream) {
+  LMN_REQUIRE(x1 && pre && gsum && keff && beff, "dw_fwd: null pointer");
+  LMN_REQUIRE(B > 0 && H > 0 && W > 0 && E > 0 && E % FW_CCH == 0, "dw_fwd: E=%d must be a multiple of %d", E, FW_CCH);
+  const int tx = lmn_cdiv(W, FW_TW), ty = lmn_cdiv(H, FW_TH);
+  hipLaunchKernelGGL(dw_fwd_kernel, dim3(tx * ty, E / FW_CCH, B), dim3(FW_THREADS), 0, (hipStream_t)stream, x1, pre,
+                     gsum, H, W, E, keff, beff, tx);
+  return lmn_launch_status("dw_fwd");
+}
+
+int lmn_dw_merge(const float* w5, const float* w3, const float* wv, const float* wh, const float* A, const float* shift,
+                 float* keff, float* beff, int E, lmn_stream_t stream) {
+  LMN_REQUIRE(w5 && w3 && wv && wh && A && shift && keff && beff && E > 0, "dw_merge: bad argument");
+  hipLaunchKernelGGL(dw_merge_kernel, dim3(lmn_cdiv(E * 25, 256)), dim3(256), 0, (hipStream_t)stream, w5, w3, wv, wh,
+                     A, shift, keff, beff, E);
+  return lmn_launch_status("dw_merge");
+}
+
+static int dw_grid_x(int B, int tx, int ty, int chunks) {
+  int64_t n = (int64_t)B * tx * ty;
+  int64_t cap = 2048 / chunks;
+  if (cap < 64) cap = 64;
+  return (int)(n < cap ? n : cap);
+}
+
+int lmn_dw_stats(const float* x1, int B, int H, int W, int E, const float* w5, const float* w3, const float* wv,
+                 const float* wh, float* stats, lmn_stream_t stream) {
+  LMN_REQUIRE(x1 && w5 && w3 && wv && wh && stats, "dw_stats: null pointer");
+  LMN_REQUIRE(B > 0 && H > 0 && W > 0 && E > 0 && E % DC == 0, "dw_stats: E=%d must be a multiple of %d", E, DC);
+  const int tx = lmn_cdiv(W, DT), ty = lmn_cdiv(H, DT);
+  hipLaunchKernelGGL((dw_stats_kernel<0>), dim3(dw_grid_x(B, tx, ty, E / DC), E / DC), dim3(256), 0, (hipStream_t)stream,
+                     x1, nullptr, nullptr, nullptr, nullptr, nullptr, B, H, W, E, w5, w3, wv, wh, stats, tx, ty);
+  return lmn_launch_status("dw_stats");
+}
+
+int lmn_dw_bwd_stats(const float* x1, const float* pre, const float* u, const float* s, const float* dm, float* dpre,
+                     int B, int H, int W, int E, const float* w5, const float* w3, const float* wv, const float* wh,
+                     float* bstats, lmn_stream_t stream) {
+  LMN_REQUIRE(x1 && pre && u && s && dm && dpre && w5 && w3 && wv && wh && bstats, "dw_bwd_stats: null pointer");
+  LMN_REQUIRE(B > 0 && H > 0 && W > 0 && E > 0 && E % DC == 0, "dw_bwd_stats: E=%d must be a multiple of %d", E, DC);
+  const int tx = lmn_cdiv(W, DT), ty = lmn_cdiv(H, DT);
+  hipLaunchKernelGGL((dw_stats_kernel<1>), dim3(dw_grid_x(B, tx, ty, E / DC), E / DC), dim3(256), 0, (hipStream_t)stream,
+                     x1, pre, u, s, dm, dpre, B, H, W, E, w5, w3, wv, wh, bstats, tx, ty);
+  return lmn_launch_status("dw_bwd_stats");
+}
+
+int lmn_dw_bwd(const float* x1, const float* dpre, float* dx1, int B, int H, int W, int E, const float* w5,
+               const float* w3, const float* wv, const float* wh, const float* cA, const float* cC, const float* cD,
+               float* dwgrad, lmn_stream_t stream) {
+  LMN_REQUIRE(x1 && dpre && dx1 && w5 && w3 && wv && wh && cA && cC && cD && dwgrad, "dw_bwd: null pointer");
+  LMN_REQUIRE(B > 0 && H > 0 && W > 0 && E > 0 && E % DC == 0, "dw_bwd: E=%d must be a multiple of %d", E, DC);
+  const int tx = lmn_cdiv(W, DT), ty = lmn_cdiv(H, DT);
+  hipLaunchKernelGGL(dw_bwd_kernel, dim3(dw_grid_x(B, tx, ty, E / DC), E / DC), dim3(256), 0, (hipStream_t)stream, x1,
+                     dpre, dx1, B, H, W, E, w5, w3, wv, wh, cA, cC, cD, dwgrad, tx, ty);
+  return lmn_launch_status("dw_bwd");
+}
+
+}  // extern "C"

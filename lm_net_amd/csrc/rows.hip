@@ -1,0 +1,658 @@
+// Row-wise / element-wise HBM-bound kernels of the LM-Net path: LayerNorm, BatchNorm(+GELU) tails,
+// BatchNorm bookkeeping, SE gate, bilinear x2 resampling, pyramid mean-pool, layout converters and
+// small utilities.  All are float4-vectorised along the NHWC channel axis (every channel count on the
+// path is a multiple of 4) with lanes walking the channel axis first so a wave touches contiguous bytes.
+// Per-channel reductions keep a fixed channel quad per thread, reduce in registers over a grid-stride
+// loop, then LDS atomics, then one global atomic per channel per block (guide: G12).
+#include "common.h"
+
+namespace {
+
+__device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+__device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+
+// ------------------------------------------------------------------------------------ LayerNorm
+// G lanes cooperate on one row; lane j owns float4 slots j, j+G (C/4 <= 2G).
+template <int G>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                     const float* __restrict__ beta, float* __restrict__ y,
+                                                     int64_t rows, int C) {
+  const int C4 = C >> 2;
+  const int j = threadIdx.x % G;
+  const int rpb = 256 / G;
+  const bool has0 = j < C4, has1 = j + G < C4;
+  f32x4 g0 = f32x4{0, 0, 0, 0}, g1 = g0, b0 = g0, b1 = g0;
+  if (has0) { g0 = ld4(gamma + j * 4); b0 = ld4(beta + j * 4); }
+  if (has1) { g1 = ld4(gamma + (j + G) * 4); b1 = ld4(beta + (j + G) * 4); }
+  const float invC = 1.0f / (float)C;
+  const int64_t nit = (rows + (int64_t)gridDim.x * rpb - 1) / ((int64_t)gridDim.x * rpb);
+  for (int64_t it = 0; it < nit; ++it) {
+    const int64_t row = (it * gridDim.x + blockIdx.x) * rpb + threadIdx.x / G;
+    const bool rok = row < rows;  // keep all lanes in the shuffles
+    const float* xr = x + row * C;
+    f32x4 v0 = f32x4{0, 0, 0, 0}, v1 = v0;
+    if (rok && has0) v0 = ld4(xr + j * 4);
+    if (rok && has1) v1 = ld4(xr + (j + G) * 4);
+    float s = v0[0] + v0[1] + v0[2] + v0[3] + v1[0] + v1[1] + v1[2] + v1[3];
+#pragma unroll
+    for (int m = G >> 1; m >= 1; m >>= 1) s += __shfl_xor(s, m, 64);
+    const float mean = s * invC;
+    float q = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if (has0) q += (v0[k] - mean) * (v0[k] - mean);
+      if (has1) q += (v1[k] - mean) * (v1[k] - mean);
+    }
+#pragma unroll
+    for (int m = G >> 1; m >= 1; m >>= 1) q += __shfl_xor(q, m, 64);
+    const float rstd = rsqrtf(q * invC + 1e-5f);
+    if (rok && has0) st4(y + row * C + j * 4, (v0 - mean) * rstd * g0 + b0);
+    if (rok && has1) st4(y + row * C + (j + G) * 4, (v1 - mean) * rstd * g1 + b1);
+  }
+}
+
+template <int G>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                     const float* __restrict__ dy, const float* __restrict__ dres,
+                                                     float* __restrict__ dx, float* __restrict__ dgamma,
+                                                     float* __restrict__ dbeta, int64_t rows, int C) {
+  extern __shared__ float red[];  // [2][C]
+  const int C4 = C >> 2;
+  const int j = threadIdx.x % G;
+  const int rpb = 256 / G;
+  const bool has0 = j < C4, has1 = j + G < C4;
+  for (int i = threadIdx.x; i < 2 * C; i += 256) red[i] = 0.f;
+  __syncthreads();
+  f32x4 g0 = f32x4{0, 0, 0, 0}, g1 = g0;
+  if (has0) g0 = ld4(gamma + j * 4);
+  if (has1) g1 = ld4(gamma + (j + G) * 4);
+  f32x4 ag0 = f32x4{0, 0, 0, 0}, ag1 = ag0, ab0 = ag0, ab1 = ag0;
+  const float invC = 1.0f / (float)C;
+  const int64_t nit = (rows + (int64_t)gridDim.x * rpb - 1) / ((int64_t)gridDim.x * rpb);
+  for (int64_t it = 0; it < nit; ++it) {
+    const int64_t row = (it * gridDim.x + blockIdx.x) * rpb + threadIdx.x / G;
+    const bool rok = row < rows;
+    f32x4 v0 = f32x4{0, 0, 0, 0}, v1 = v0, d0 = v0, d1 = v0;
+    if (rok && has0) { v0 = ld4(x + row * C + j * 4); d0 = ld4(dy + row * C + j * 4); }
+    if (rok && has1) { v1 = ld4(x + row * C + (j + G) * 4); d1 = ld4(dy + row * C + (j + G) * 4); }
+    float s = v0[0] + v0[1] + v0[2] + v0[3] + v1[0] + v1[1] + v1[2] + v1[3];
+#pragma unroll
+    for (int m = G >> 1; m >= 1; m >>= 1) s += __shfl_xor(s, m, 64);
+    const float mean = s * invC;
+    float q = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if (has0) q += (v0[k] - mean) * (v0[k] - mean);
+      if (has1) q += (v1[k] - mean) * (v1[k] - mean);
+    }
+#pragma unroll
+    for (int m = G >> 1; m >= 1; m >>= 1) q += __shfl_xor(q, m, 64);
+    const float rstd = rsqrtf(q * invC + 1e-5f);
+    const f32x4 h0 = (v0 - mean) * rstd, h1 = (v1 - mean) * rstd;
+    const f32x4 t0 = d0 * g0, t1 = d1 * g1;
+    float m1 = 0.f, m2 = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if (has0) { m1 += t0[k]; m2 += t0[k] * h0[k]; }
+      if (has1) { m1 += t1[k]; m2 += t1[k] * h1[k]; }
+    }
+#pragma unroll
+    for (int m = G >> 1; m >= 1; m >>= 1) {
+      m1 += __shfl_xor(m1, m, 64);
+      m2 += __shfl_xor(m2, m, 64);
+    }
+    m1 *= invC;
+    m2 *= invC;
+    if (rok && has0) {
+      f32x4 o = (t0 - m1 - h0 * m2) * rstd;
+      if (dres) o += ld4(dres + row * C + j * 4);
+      st4(dx + row * C + j * 4, o);
+      ag0 += d0 * h0;
+      ab0 += d0;
+    }
+    if (rok && has1) {
+      f32x4 o = (t1 - m1 - h1 * m2) * rstd;
+      if (dres) o += ld4(dres + row * C + (j + G) * 4);
+      st4(dx + row * C + (j + G) * 4, o);
+      ag1 += d1 * h1;
+      ab1 += d1;
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    if (has0) { atomicAdd(&red[j * 4 + k], ag0[k]); atomicAdd(&red[C + j * 4 + k], ab0[k]); }
+    if (has1) { atomicAdd(&red[(j + G) * 4 + k], ag1[k]); atomicAdd(&red[C + (j + G) * 4 + k], ab1[k]); }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < C; i += 256) {
+    atomicAdd(dgamma + i, red[i]);
+    atomicAdd(dbeta + i, red[C + i]);
+  }
+}
+
+// ------------------------------------------------------------------------------------ BN(+act) tails
+__global__ __launch_bounds__(256) void bnact_fwd_kernel(const float* __restrict__ z, const float* __restrict__ a,
+                                                        const float* __restrict__ b, float* __restrict__ y,
+                                                        int64_t n4, int C4, int act) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+    const int c = (int)(i % C4) * 4;
+    const f32x4 v = ld4(z + i * 4), aa = ld4(a + c), bb = ld4(b + c);
+    f32x4 o;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) o[k] = lmn_act(v[k] * aa[k] + bb[k], act);
+    st4(y + i * 4, o);
+  }
+}
+
+// MODE 0: stats[2][C] += (sum dh, sum dh*zhat);  MODE 1: dz = c1*dh - c2 - zhat*c3
+// MODE 2: out[C] += column sums of x (bias gradients); x has pixel stride cstride
+template <int MODE>
+__global__ __launch_bounds__(256) void chan_kernel(const float* __restrict__ z, const float* __restrict__ dy,
+                                                   const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                   const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                   const float* __restrict__ c1, const float* __restrict__ c2,
+                                                   const float* __restrict__ c3, float* __restrict__ out,
+                                                   int64_t rows, int C, int cstride, int act) {
+  extern __shared__ float red[];  // [2][C] (MODE 0), [C] (MODE 2)
+  const int C4 = C >> 2;
+  const int T = (256 / C4) * C4;  // active threads: each keeps a fixed channel quad
+  const int rpb = T / C4;
+  const int tid = threadIdx.x;
+  if (MODE != 1) {
+    for (int i = tid; i < 2 * C; i += 256) red[i] = 0.f;
+    __syncthreads();
+  }
+  f32x4 s0 = f32x4{0, 0, 0, 0}, s1 = s0;
+  if (tid < T) {
+    const int c = (tid % C4) * 4;
+    f32x4 mu = s0, rs = s0, ga = s0, be = s0, k1 = s0, k2 = s0, k3 = s0;
+    if (MODE != 2) { mu = ld4(mean + c); rs = ld4(rstd + c); ga = ld4(gamma + c); be = ld4(beta + c); }
+    if (MODE == 1) { k1 = ld4(c1 + c); k2 = ld4(c2 + c); k3 = ld4(c3 + c); }
+    for (int64_t row = (int64_t)blockIdx.x * rpb + tid / C4; row < rows; row += (int64_t)gridDim.x * rpb) {
+      if (MODE == 2) {
+        s0 += ld4(z + row * cstride + c);
+      } else {
+        const f32x4 v = ld4(z + row * C + c), d = ld4(dy + row * C + c);
+        f32x4 o;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const float zh = (v[k] - mu[k]) * rs[k];
+          const float dh = d[k] * lmn_dact(ga[k] * zh + be[k], act);
+          if (MODE == 0) { s0[k] += dh; s1[k] += dh * zh; }
+          else o[k] = k1[k] * dh - k2[k] - zh * k3[k];
+        }
+        if (MODE == 1) st4(out + row * C + c, o);
+      }
+    }
+    if (MODE != 1) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        atomicAdd(&red[c + k], s0[k]);
+        if (MODE == 0) atomicAdd(&red[C + c + k], s1[k]);
+      }
+    }
+  }
+  if (MODE != 1) {
+    __syncthreads();
+    const int nred = MODE == 0 ? 2 * C : C;
+    for (int i = tid; i < nred; i += 256) atomicAdd(out + i, red[i]);
+  }
+}
+
+__global__ void bn_finalize_kernel(const float* __restrict__ sums, float count, const float* __restrict__ gamma,
+                                   const float* __restrict__ beta, float eps, float momentum, float* mean, float* rstd,
+                                   float* A, float* shift, float* rmean, float* rvar, int C) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const float m = sums[c] / count;
+  float var = sums[C + c] / count - m * m;  // biased
+  var = var > 0.f ? var : 0.f;
+  const float rs = rsqrtf(var + eps);
+  const float a = gamma[c] * rs;
+  if (mean) mean[c] = m;
+  if (rstd) rstd[c] = rs;
+  if (A) A[c] = a;
+  if (shift) shift[c] = beta[c] - m * a;
+  if (rmean) rmean[c] = (1.f - momentum) * rmean[c] + momentum * m;
+  if (rvar) rvar[c] = (1.f - momentum) * rvar[c] + momentum * var * (count > 1.f ? count / (count - 1.f) : 1.f);
+}
+
+__global__ void bn_bwd_coef_kernel(const float* __restrict__ bstats, float count, const float* __restrict__ A,
+                                   float* dgamma, float* dbeta, float* c1, float* c2, float* c3, int C) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const float S0 = bstats[c], S1 = bstats[C + c], a = A[c];
+  if (dgamma) dgamma[c] += S1;
+  if (dbeta) dbeta[c] += S0;
+  c1[c] = a;
+  c2[c] = a * S0 / count;
+  c3[c] = a * S1 / count;
+}
+
+// ------------------------------------------------------------------------------------ SE gate (one block per image)
+__global__ __launch_bounds__(256) void se_fwd_kernel(const float* __restrict__ gsum, float inv_hw,
+                                                     const float* __restrict__ w1, const float* __restrict__ b1,
+                                                     const float* __restrict__ w2, const float* __restrict__ b2,
+                                                     float* __restrict__ s, float* __restrict__ hidden, int E, int R) {
+  extern __shared__ float sm[];  // m[E], h[R]
+  float* m = sm;
+  float* h = sm + E;
+  const int b = blockIdx.x;
+  for (int e = threadIdx.x; e < E; e += 256) m[e] = gsum[(int64_t)b * E + e] * inv_hw;
+  __syncthreads();
+  for (int r = threadIdx.x; r < R; r += 256) {
+    float a = b1[r];
+    for (int e = 0; e < E; ++e) a += w1[(int64_t)r * E + e] * m[e];
+    a = a > 0.f ? a : 0.f;
+    h[r] = a;
+    hidden[(int64_t)b * R + r] = a;
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < E; e += 256) {
+    float a = b2[e];
+    for (int r = 0; r < R; ++r) a += w2[(int64_t)e * R + r] * h[r];
+    s[(int64_t)b * E + e] = lmn_hsigmoid(a);
+  }
+}
+
+__global__ __launch_bounds__(256) void se_bwd_kernel(const float* __restrict__ ds, const float* __restrict__ gsum,
+                                                     float inv_hw, const float* __restrict__ w1,
+                                                     const float* __restrict__ w2, const float* __restrict__ b2,
+                                                     const float* __restrict__ hidden, float* __restrict__ dm,
+                                                     float* dw1, float* db1, float* dw2, float* db2, int E, int R) {
+  extern __shared__ float sm[];  // m[E], dt[E], h[R], da[R]
+  float* m = sm;
+  float* dt = sm + E;
+  float* h = sm + 2 * E;
+  float* da = sm + 2 * E + R;
+  const int b = blockIdx.x;
+  for (int r = threadIdx.x; r < R; r += 256) h[r] = hidden[(int64_t)b * R + r];
+  for (int e = threadIdx.x; e < E; e += 256) m[e] = gsum[(int64_t)b * E + e] * inv_hw;
+  __syncthreads();
+  for (int e = threadIdx.x; e < E; e += 256) {
+    float a = b2[e];
+    for (int r = 0; r < R; ++r) a += w2[(int64_t)e * R + r] * h[r];
+    const float d = ds[(int64_t)b * E + e] * lmn_dhsigmoid(a);
+    dt[e] = d;
+    atomicAdd(db2 + e, d);
+  }
+  __syncthreads();
+  for (int r = threadIdx.x; r < R; r += 256) {
+    float a = 0.f;
+    for (int e = 0; e < E; ++e) a += w2[(int64_t)e * R + r] * dt[e];
+    a = h[r] > 0.f ? a : 0.f;
+    da[r] = a;
+    atomicAdd(db1 + r, a);
+  }
+  for (int i = threadIdx.x; i < E * R; i += 256) {
+    const int e = i / R, r = i - e * R;
+    atomicAdd(dw2 + i, dt[e] * h[r]);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < E * R; i += 256) {
+    const int r = i / E, e = i - r * E;
+    atomicAdd(dw1 + i, da[r] * m[e]);
+  }
+  for (int e = threadIdx.x; e < E; e += 256) {
+    float a = 0.f;
+    for (int r = 0; r < R; ++r) a += w1[(int64_t)r * E + e] * da[r];
+    dm[(int64_t)b * E + e] = a * inv_hw;
+  }
+}
+
+// ------------------------------------------------------------------------------------ bilinear x2, align_corners=True
+// index arithmetic mirrors ATen's upsample_bilinear2d (fp32): src = dst * (in-1)/(out-1)
+__device__ __forceinline__ void up_coord(int dst, int in, float scale, int& i0, int& ip, float& l0, float& l1) {
+  const float r = scale * (float)dst;
+  i0 = (int)r;
+  ip = (i0 < in - 1) ? 1 : 0;
+  l1 = r - (float)i0;
+  l0 = 1.f - l1;
+}
+
+__global__ __launch_bounds__(256) void up2_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int B, int Hin,
+                                                      int Win, int C4, int xcs, int ycs) {
+  const int Hout = 2 * Hin, Wout = 2 * Win;
+  const float sh = (float)(Hin - 1) / (float)(Hout - 1), sw = (float)(Win - 1) / (float)(Wout - 1);
+  const int64_t total = (int64_t)B * Hout * Wout * C4;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int c = (int)(i % C4) * 4;
+    int64_t p = i / C4;
+    const int ox = (int)(p % Wout);
+    p /= Wout;
+    const int oy = (int)(p % Hout);
+    const int b = (int)(p / Hout);
+    int y0, yp, x0, xp;
+    float ly0, ly1, lx0, lx1;
+    up_coord(oy, Hin, sh, y0, yp, ly0, ly1);
+    up_coord(ox, Win, sw, x0, xp, lx0, lx1);
+    const float* base = x + ((int64_t)b * Hin * Win) * xcs + c;
+    const f32x4 v00 = ld4(base + ((int64_t)y0 * Win + x0) * xcs), v01 = ld4(base + ((int64_t)y0 * Win + x0 + xp) * xcs);
+    const f32x4 v10 = ld4(base + ((int64_t)(y0 + yp) * Win + x0) * xcs), v11 = ld4(base + ((int64_t)(y0 + yp) * Win + x0 + xp) * xcs);
+    const f32x4 o = ly0 * (lx0 * v00 + lx1 * v01) + ly1 * (lx0 * v10 + lx1 * v11);
+    st4(y + (((int64_t)b * Hout + oy) * Wout + ox) * ycs + c, o);
+  }
+}
+
+__global__ __launch_bounds__(256) void up2_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, int B,
+                                                      int Hin, int Win, int C4, int dycs, int dxcs) {
+  const int Hout = 2 * Hin, Wout = 2 * Win;
+  const float sh = (float)(Hin - 1) / (float)(Hout - 1), sw = (float)(Win - 1) / (float)(Wout - 1);
+  const int64_t total = (int64_t)B * Hin * Win * C4;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int c = (int)(i % C4) * 4;
+    int64_t p = i / C4;
+    const int ix = (int)(p % Win);
+    p /= Win;
+    const int iy = (int)(p % Hin);
+    const int b = (int)(p / Hin);
+    float wy[8], wx[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int oy = 2 * iy - 3 + k, ox = 2 * ix - 3 + k;
+      wy[k] = wx[k] = 0.f;
+      int i0, ip;
+      float l0, l1;
+      if (oy >= 0 && oy < Hout) {
+        up_coord(oy, Hin, sh, i0, ip, l0, l1);
+        if (i0 == iy) wy[k] += l0;
+        if (i0 + ip == iy) wy[k] += l1;
+      }
+      if (ox >= 0 && ox < Wout) {
+        up_coord(ox, Win, sw, i0, ip, l0, l1);
+        if (i0 == ix) wx[k] += l0;
+        if (i0 + ip == ix) wx[k] += l1;
+      }
+    }
+    f32x4 acc = f32x4{0, 0, 0, 0};
+    const float* base = dy + ((int64_t)b * Hout * Wout) * dycs + c;
+#pragma unroll
+    for (int ky = 0; ky < 8; ++ky) {
+      if (wy[ky] == 0.f) continue;
+      const int oy = 2 * iy - 3 + ky;
+#pragma unroll
+      for (int kx = 0; kx < 8; ++kx) {
+        if (wx[kx] == 0.f) continue;
+        const int ox = 2 * ix - 3 + kx;
+        acc += (wy[ky] * wx[kx]) * ld4(base + ((int64_t)oy * Wout + ox) * dycs);
+      }
+    }
+    st4(dx + (((int64_t)b * Hin + iy) * Win + ix) * dxcs + c, acc);
+  }
+}
+
+// ------------------------------------------------------------------------------------ f x f mean pool
+__global__ __launch_bounds__(256) void avgpool_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int Hout,
+                                                          int Wout, int f, int C, int xcs, int ycs) {
+  extern __shared__ float red[];  // [C]
+  const int C4 = C >> 2;
+  const int T = (256 / C4) * C4, per = T / C4;
+  const int tid = threadIdx.x;
+  const int ox = blockIdx.x % Wout, oy = (blockIdx.x / Wout) % Hout, b = blockIdx.x / (Wout * Hout);
+  for (int i = tid; i < C; i += 256) red[i] = 0.f;
+  __syncthreads();
+  if (tid < T) {
+    const int c = (tid % C4) * 4;
+    f32x4 s = f32x4{0, 0, 0, 0};
+    const int Hin = Hout * f, Win = Wout * f;
+    for (int w = tid / C4; w < f * f; w += per) {
+      const int wy = w / f, wx = w - wy * f;
+      s += ld4(x + (((int64_t)b * Hin + oy * f + wy) * Win + ox * f + wx) * xcs + c);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) atomicAdd(&red[c + k], s[k]);
+  }
+  __syncthreads();
+  const float inv = 1.0f / (float)(f * f);
+  for (int i = tid; i < C; i += 256) y[(((int64_t)b * Hout + oy) * Wout + ox) * ycs + i] = red[i] * inv;
+}
+
+__global__ __launch_bounds__(256) void avgpool_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, int B,
+                                                          int Hout, int Wout, int f, int C4, int dycs, int dxcs,
+                                                          int accumulate) {
+  const int Hin = Hout * f, Win = Wout * f;
+  const float inv = 1.0f / (float)(f * f);
+  const int64_t total = (int64_t)B * Hin * Win * C4;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int c = (int)(i % C4) * 4;
+    int64_t p = i / C4;
+    const int ix = (int)(p % Win);
+    p /= Win;
+    const int iy = (int)(p % Hin);
+    const int b = (int)(p / Hin);
+    f32x4 g = inv * ld4(dy + (((int64_t)b * Hout + iy / f) * Wout + ix / f) * dycs + c);
+    float* o = dx + (((int64_t)b * Hin + iy) * Win + ix) * dxcs + c;
+    if (accumulate) g += ld4(o);
+    st4(o, g);
+  }
+}
+
+// ------------------------------------------------------------------------------------ layout + utilities
+__global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restrict__ x, float* __restrict__ y, int B,
+                                                           int C, int64_t HW, int ycs) {
+  const int64_t total = (int64_t)B * HW;
+  for (int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x; p < total; p += (int64_t)gridDim.x * 256) {
+    const int64_t b = p / HW, hw = p - b * HW;
+    for (int c = 0; c < ycs; ++c) y[p * ycs + c] = c < C ? x[(b * C + c) * HW + hw] : 0.f;
+  }
+}
+__global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const float* __restrict__ x, float* __restrict__ y, int B,
+                                                           int C, int64_t HW, int xcs) {
+  const int64_t total = (int64_t)B * HW;
+  for (int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x; p < total; p += (int64_t)gridDim.x * 256) {
+    const int64_t b = p / HW, hw = p - b * HW;
+    for (int c = 0; c < C; ++c) y[(b * C + c) * HW + hw] = x[p * xcs + c];
+  }
+}
+__global__ __launch_bounds__(256) void fill_kernel(float* __restrict__ p, float v, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) p[i] = v;
+}
+__global__ __launch_bounds__(256) void add_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                  const float* __restrict__ c, const float* __restrict__ d,
+                                                  float* __restrict__ y, int64_t n4) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+    f32x4 v = ld4(a + i * 4) + ld4(b + i * 4);
+    if (c) v += ld4(c + i * 4);
+    if (d) v += ld4(d + i * 4);
+    st4(y + i * 4, v);
+  }
+}
+__global__ __launch_bounds__(256) void copy_slice_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t rows,
+                                                         int C4, int xcs, int ycs) {
+  const int64_t total = rows * C4;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t r = i / C4;
+    const int c = (int)(i - r * C4) * 4;
+    st4(y + r * ycs + c, ld4(x + r * xcs + c));
+  }
+}
+
+inline int grid_for(int64_t work_items, int per_block = 256, int cap = 4096) {
+  int64_t g = (work_items + per_block - 1) / per_block;
+  if (g > cap) g = cap;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+inline int ln_group(int C4) {
+  int g = 1;
+  while (g < C4 && g < 64) g <<= 1;
+  return g;
+}
+
+}  // namespace
+
+extern "C" {
+
+int lmn_ln_fwd(const float* x, const float* gamma, const float* beta, float* y, int64_t rows, int C,
+               lmn_stream_t stream) {
+  LMN_REQUIRE(x && gamma && beta && y && rows > 0, "ln_fwd: bad argument");
+  LMN_REQUIRE(C % 4 == 0 && C >= 4 && C <= 512, "ln_fwd: C=%d (need multiple of 4, <= 512)", C);
+  const int G = ln_group(C / 4);
+  const int grid = grid_for(rows, 256 / G, 2048);
+  hipStream_t st = (hipStream_t)stream;
+#define LN_CASE(g) case g: hipLaunchKernelGGL((ln_fwd_kernel<g>), dim3(grid), dim3(256), 0, st, x, gamma, beta, y, rows, C); break;
+  switch (G) { LN_CASE(1) LN_CASE(2) LN_CASE(4) LN_CASE(8) LN_CASE(16) LN_CASE(32) LN_CASE(64) }
+#undef LN_CASE
+  return lmn_launch_status("ln_fwd");
+}
+
+int lmn_ln_bwd(const float* x, const float* gamma, const float* dy, const float* dres, float* dx, float* dgamma,
+               float* dbeta, int64_t rows, int C, lmn_stream_t stream) {
+  LMN_REQUIRE(x && gamma && dy && dx && dgamma && dbeta && rows > 0, "ln_bwd: bad argument");
+  LMN_REQUIRE(C % 4 == 0 && C >= 4 && C <= 512, "ln_bwd: C=%d", C);
+  const int G = ln_group(C / 4);
+  const int grid = grid_for(rows, 256 / G, 1024);
+  hipStream_t st = (hipStream_t)stream;
+  const size_t sh = 2 * C * sizeof(float);
+#define LN_CASE(g) case g: hipLaunchKernelGGL((ln_bwd_kernel<g>), dim3(grid), dim3(256), sh, st, x, gamma, dy, dres, dx, dgamma, dbeta, rows, C); break;
+  switch (G) { LN_CASE(1) LN_CASE(2) LN_CASE(4) LN_CASE(8) LN_CASE(16) LN_CASE(32) LN_CASE(64) }
+#undef LN_CASE
+  return lmn_launch_status("ln_bwd");
+}
+
+int lmn_bnact_fwd(const float* z, const float* a, const float* b, float* y, int64_t rows, int C, int act,
+                  lmn_stream_t stream) {
+  LMN_REQUIRE(z && a && b && y && rows > 0 && C > 0 && C % 4 == 0, "bnact_fwd: bad argument");
+  const int64_t n4 = rows * (C / 4);
+  hipLaunchKernelGGL(bnact_fwd_kernel, dim3(grid_for(n4)), dim3(256), 0, (hipStream_t)stream, z, a, b, y, n4, C / 4, act);
+  return lmn_launch_status("bnact_fwd");
+}
+
+int lmn_bnact_bwd_stats(const float* z, const float* dy, const float* mean, const float* rstd, const float* gamma,
+                        const float* beta, float* stats, int64_t rows, int C, int act, lmn_stream_t stream) {
+  LMN_REQUIRE(z && dy && mean && rstd && gamma && beta && stats && rows > 0, "bnact_bwd_stats: bad argument");
+  LMN_REQUIRE(C % 4 == 0 && C >= 4 && C <= 1024, "bnact_bwd_stats: C=%d", C);
+  const int rpb = 256 / (C / 4);
+  hipLaunchKernelGGL((chan_kernel<0>), dim3(grid_for(rows, rpb * 8, 1024)), dim3(256), 2 * C * sizeof(float),
+                     (hipStream_t)stream, z, dy, mean, rstd, gamma, beta, nullptr, nullptr, nullptr, stats, rows, C, C, act);
+  return lmn_launch_status("bnact_bwd_stats");
+}
+
+int lmn_bnact_bwd(const float* z, const float* dy, const float* mean, const float* rstd, const float* gamma,
+                  const float* beta, const float* c1, const float* c2, const float* c3, float* dz, int64_t rows, int C,
+                  int act, lmn_stream_t stream) {
+  LMN_REQUIRE(z && dy && mean && rstd && gamma && beta && c1 && c2 && c3 && dz && rows > 0, "bnact_bwd: bad argument");
+  LMN_REQUIRE(C % 4 == 0 && C >= 4 && C <= 1024, "bnact_bwd: C=%d", C);
+  const int rpb = 256 / (C / 4);
+  hipLaunchKernelGGL((chan_kernel<1>), dim3(grid_for(rows, rpb * 4, 4096)), dim3(256), 2 * C * sizeof(float),
+                     (hipStream_t)stream, z, dy, mean, rstd, gamma, beta, c1, c2, c3, dz, rows, C, C, act);
+  return lmn_launch_status("bnact_bwd");
+}
+
+int lmn_colsum(const float* x, float* out, int64_t rows, int C, int cstride, lmn_stream_t stream) {
+  LMN_REQUIRE(x && out && rows > 0 && C % 4 == 0 && C >= 4 && C <= 1024 && cstride >= C && cstride % 4 == 0, "colsum: bad argument");
+  const int rpb = 256 / (C / 4);
+  hipLaunchKernelGGL((chan_kernel<2>), dim3(grid_for(rows, rpb * 8, 1024)), dim3(256), 2 * C * sizeof(float),
+                     (hipStream_t)stream, x, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, out,
+                     rows, C, cstride, 0);
+  return lmn_launch_status("colsum");
+}
+
+int lmn_bn_finalize(const float* sums, float count, const float* gamma, const float* beta, float eps, float momentum,
+                    float* mean, float* rstd, float* A, float* shift, float* running_mean, float* running_var, int C,
+                    lmn_stream_t stream) {
+  LMN_REQUIRE(sums && gamma && beta && C > 0 && count > 0.f, "bn_finalize: bad argument");
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(lmn_cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream, sums, count, gamma,
+                     beta, eps, momentum, mean, rstd, A, shift, running_mean, running_var, C);
+  return lmn_launch_status("bn_finalize");
+}
+
+int lmn_bn_bwd_coef(const float* bstats, float count, const float* A, float* dgamma, float* dbeta, float* c1, float* c2,
+                    float* c3, int C, lmn_stream_t stream) {
+  LMN_REQUIRE(bstats && A && c1 && c2 && c3 && C > 0 && count > 0.f, "bn_bwd_coef: bad argument");
+  hipLaunchKernelGGL(bn_bwd_coef_kernel, dim3(lmn_cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream, bstats, count, A,
+                     dgamma, dbeta, c1, c2, c3, C);
+  return lmn_launch_status("bn_bwd_coef");
+}
+
+int lmn_se_fwd(const float* gsum, float inv_hw, const float* w1, const float* b1, const float* w2, const float* b2,
+               float* s, float* hidden, int B, int E, int R, lmn_stream_t stream) {
+  LMN_REQUIRE(gsum && w1 && b1 && w2 && b2 && s && hidden && B > 0 && E > 0 && R > 0, "se_fwd: bad argument");
+  LMN_REQUIRE((E + R) * sizeof(float) <= 60000, "se_fwd: E=%d too large", E);
+  hipLaunchKernelGGL(se_fwd_kernel, dim3(B), dim3(256), (E + R) * sizeof(float), (hipStream_t)stream, gsum, inv_hw, w1,
+                     b1, w2, b2, s, hidden, E, R);
+  return lmn_launch_status("se_fwd");
+}
+
+int lmn_se_bwd(const float* ds, const float* gsum, float inv_hw, const float* w1, const float* b1, const float* w2,
+               const float* b2, const float* hidden, float* dm, float* dw1, float* db1, float* dw2, float* db2, int B,
+               int E, int R, lmn_stream_t stream) {
+  (void)b1;
+  LMN_REQUIRE(ds && gsum && w1 && w2 && b2 && hidden && dm && dw1 && db1 && dw2 && db2 && B > 0 && E > 0 && R > 0, "se_bwd: bad argument");
+  LMN_REQUIRE((2 * E + 2 * R) * sizeof(float) <= 60000, "se_bwd: E=%d too large", E);
+  hipLaunchKernelGGL(se_bwd_kernel, dim3(B), dim3(256), (2 * E + 2 * R) * sizeof(float), (hipStream_t)stream, ds, gsum,
+                     inv_hw, w1, w2, b2, hidden, dm, dw1, db1, dw2, db2, E, R);
+  return lmn_launch_status("se_bwd");
+}
+
+int lmn_up2_fwd(const float* x, float* y, int B, int Hin, int Win, int C, int x_cstride, int y_cstride,
+                lmn_stream_t stream) {
+  LMN_REQUIRE(x && y && B > 0 && Hin > 0 && Win > 0 && C > 0 && C % 4 == 0 && x_cstride >= C && y_cstride >= C && x_cstride % 4 == 0 && y_cstride % 4 == 0, "up2_fwd: bad argument");
+  const int64_t total = (int64_t)B * 4 * Hin * Win * (C / 4);
+  hipLaunchKernelGGL(up2_fwd_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, y, B, Hin, Win, C / 4,
+                     x_cstride, y_cstride);
+  return lmn_launch_status("up2_fwd");
+}
+
+int lmn_up2_bwd(const float* dy, float* dx, int B, int Hin, int Win, int C, int dy_cstride, int dx_cstride,
+                lmn_stream_t stream) {
+  LMN_REQUIRE(dy && dx && B > 0 && Hin > 0 && Win > 0 && C > 0 && C % 4 == 0 && dy_cstride >= C && dx_cstride >= C && dy_cstride % 4 == 0 && dx_cstride % 4 == 0, "up2_bwd: bad argument");
+  const int64_t total = (int64_t)B * Hin * Win * (C / 4);
+  hipLaunchKernelGGL(up2_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, dy, dx, B, Hin, Win, C / 4,
+                     dy_cstride, dx_cstride);
+  return lmn_launch_status("up2_bwd");
+}
+
+int lmn_avgpool_fwd(const float* x, float* y, int B, int Hout, int Wout, int f, int C, int x_cstride, int y_cstride,
+                    lmn_stream_t stream) {
+  LMN_REQUIRE(x && y && B > 0 && Hout > 0 && Wout > 0 && f >= 1 && C % 4 == 0 && C >= 4 && C <= 1024 && x_cstride >= C && y_cstride >= C && x_cstride % 4 == 0, "avgpool_fwd: bad argument");
+  hipLaunchKernelGGL(avgpool_fwd_kernel, dim3(B * Hout * Wout), dim3(256), C * sizeof(float), (hipStream_t)stream, x, y,
+                     Hout, Wout, f, C, x_cstride, y_cstride);
+  return lmn_launch_status("avgpool_fwd");
+}
+
+int lmn_avgpool_bwd(const float* dy, float* dx, int B, int Hout, int Wout, int f, int C, int dy_cstride, int dx_cstride,
+                    int accumulate, lmn_stream_t stream) {
+  LMN_REQUIRE(dy && dx && B > 0 && Hout > 0 && Wout > 0 && f >= 1 && C % 4 == 0 && C >= 4 && dy_cstride >= C && dx_cstride >= C && dy_cstride % 4 == 0 && dx_cstride % 4 == 0, "avgpool_bwd: bad argument");
+  const int64_t total = (int64_t)B * Hout * f * Wout * f * (C / 4);
+  hipLaunchKernelGGL(avgpool_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, dy, dx, B, Hout, Wout,
+                     f, C / 4, dy_cstride, dx_cstride, accumulate);
+  return lmn_launch_status("avgpool_bwd");
+}
+
+int lmn_nchw_to_nhwc(const float* x, float* y, int B, int C, int H, int W, int y_cstride, lmn_stream_t stream) {
+  LMN_REQUIRE(x && y && B > 0 && C > 0 && H > 0 && W > 0 && y_cstride >= C, "nchw_to_nhwc: bad argument");
+  hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(grid_for((int64_t)B * H * W)), dim3(256), 0, (hipStream_t)stream, x, y, B,
+                     C, (int64_t)H * W, y_cstride);
+  return lmn_launch_status("nchw_to_nhwc");
+}
+
+int lmn_nhwc_to_nchw(const float* x, float* y, int B, int C, int H, int W, int x_cstride, lmn_stream_t stream) {
+  LMN_REQUIRE(x && y && B > 0 && C > 0 && H > 0 && W > 0 && x_cstride >= C, "nhwc_to_nchw: bad argument");
+  hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3(grid_for((int64_t)B * H * W)), dim3(256), 0, (hipStream_t)stream, x, y, B,
+                     C, (int64_t)H * W, x_cstride);
+  return lmn_launch_status("nhwc_to_nchw");
+}
+
+int lmn_fill(float* p, float v, int64_t n, lmn_stream_t stream) {
+  LMN_REQUIRE(p && n >= 0, "fill: bad argument");
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(fill_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, p, v, n);
+  return lmn_launch_status("fill");
+}
+
+int lmn_add(const float* a, const float* b, const float* c, const float* d, float* y, int64_t n, lmn_stream_t stream) {
+  LMN_REQUIRE(a && b && y && n > 0 && n % 4 == 0, "add: bad argument (n must be a multiple of 4)");
+  hipLaunchKernelGGL(add_kernel, dim3(grid_for(n / 4)), dim3(256), 0, (hipStream_t)stream, a, b, c, d, y, n / 4);
+  return lmn_launch_status("add");
+}
+
+int lmn_copy_slice(const float* x, float* y, int64_t rows, int C, int x_cstride, int y_cstride, lmn_stream_t stream) {
+  LMN_REQUIRE(x && y && rows > 0 && C > 0 && C % 4 == 0 && x_cstride >= C && y_cstride >= C && x_cstride % 4 == 0 && y_cstride % 4 == 0, "copy_slice: bad argument");
+  hipLaunchKernelGGL(copy_slice_kernel, dim3(grid_for(rows * (C / 4))), dim3(256), 0, (hipStream_t)stream, x, y, rows,
+                     C / 4, x_cstride, y_cstride);
+  return lmn_launch_status("copy_slice");
+}
+
+}  // extern "C"

@@ -1,0 +1,389 @@
+"""ctypes binding of ``liblmnet_hip.so`` (the C-ABI declared in ``include/lmnet_hip.h``).
+
+PyTorch is plumbing here: it owns device memory and the stream; every arithmetic op of the
+LM-Net path is a hand-written gfx950 kernel behind this boundary.  There is NO fallback: if the
+shared library is missing the import raises, and calling any op with a non-device tensor raises.
+"""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "liblmnet_hip.so")
+
+# ---- constants mirrored from include/lmnet_hip.h
+SRC_GELU, SRC_DROP = 1, 2
+EP_LINEAR, EP_AFFINE_ACT, EP_DGELU, EP_BN_BWD1, EP_BN_BWD2, EP_SE_BWD = 0, 1, 2, 3, 4, 5
+ACT_NONE, ACT_HSWISH, ACT_GELU = 0, 1, 2
+STATS_NONE, STATS_SUM_SQ, STATS_EP = 0, 1, 2
+ABI_VERSION = 1
+
+
+class SrcT(C.Structure):
+    _fields_ = [("ptr", C.c_void_p), ("scale", C.c_void_p), ("C", C.c_int32), ("cstride", C.c_int32),
+                ("flags", C.c_int32), ("drop_seed", C.c_uint32), ("drop_p", C.c_float), ("_pad", C.c_int32)]
+
+
+class ConvArgs(C.Structure):
+    _fields_ = [("B", C.c_int32), ("Hout", C.c_int32), ("Wout", C.c_int32), ("Hin", C.c_int32), ("Win", C.c_int32),
+                ("ksize", C.c_int32), ("stride", C.c_int32), ("transposed", C.c_int32), ("nsrc", C.c_int32),
+                ("Cout", C.c_int32), ("src", SrcT * 3), ("wpack", C.c_void_p), ("bias", C.c_void_p),
+                ("p0", C.c_void_p), ("p1", C.c_void_p), ("p2", C.c_void_p), ("p3", C.c_void_p), ("p4", C.c_void_p),
+                ("aux", C.c_void_p), ("residual", C.c_void_p), ("out", C.c_void_p), ("stats", C.c_void_p),
+                ("aux_cstride", C.c_int32), ("res_cstride", C.c_int32), ("out_cstride", C.c_int32),
+                ("epilogue", C.c_int32), ("act", C.c_int32), ("stats_mode", C.c_int32),
+                ("drop_p", C.c_float), ("drop_seed", C.c_uint32)]
+
+
+class WgradArgs(C.Structure):
+    _fields_ = [("B", C.c_int32), ("Hout", C.c_int32), ("Wout", C.c_int32), ("Hin", C.c_int32), ("Win", C.c_int32),
+                ("ksize", C.c_int32), ("stride", C.c_int32), ("nsrc", C.c_int32), ("Cout", C.c_int32),
+                ("src", SrcT * 3), ("dy", C.c_void_p), ("dy_cstride", C.c_int32), ("dy_flags", C.c_int32),
+                ("dy_seed", C.c_uint32), ("dy_p", C.c_float), ("dW", C.c_void_p), ("db", C.c_void_p)]
+
+
+# every symbol include/lmnet_hip.h declares (the CPU test suite checks the library exports all of them)
+SYMBOLS = [
+    "lmn_abi_version", "lmn_sizeof_conv_args", "lmn_sizeof_src", "lmn_sizeof_wgrad_args", "lmn_last_error",
+    "lmn_conv_pack_size", "lmn_conv_pack", "lmn_conv_fwd", "lmn_conv_wgrad",
+    "lmn_dw_stats", "lmn_dw_fwd", "lmn_dw_merge", "lmn_dw_bwd_stats", "lmn_dw_bwd",
+    "lmn_se_fwd", "lmn_se_bwd", "lmn_na_fwd", "lmn_na_bwd", "lmn_gattn_fwd", "lmn_gattn_bwd",
+    "lmn_ln_fwd", "lmn_ln_bwd", "lmn_bnact_fwd", "lmn_bnact_bwd_stats", "lmn_bnact_bwd",
+    "lmn_bn_finalize", "lmn_bn_bwd_coef", "lmn_up2_fwd", "lmn_up2_bwd", "lmn_avgpool_fwd", "lmn_avgpool_bwd",
+    "lmn_nchw_to_nhwc", "lmn_nhwc_to_nchw", "lmn_fill", "lmn_add", "lmn_colsum", "lmn_copy_slice",
+]
+
+_lib = None
+
+
+def load():
+    """Load the HIP library (once).  Raises if it has not been built -- there is no CPU/torch fallback."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.isfile(LIB_PATH):
+        raise RuntimeError(
+            "lm_net_amd: %s not found. Build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(or `make -C lm_net_amd/csrc`). The LM-Net hot path has no non-HIP fallback." % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name in SYMBOLS:
+        if not hasattr(lib, name):
+            raise RuntimeError("lm_net_amd: %s does not export %s" % (LIB_PATH, name))
+    lib.lmn_last_error.restype = C.c_char_p
+    lib.lmn_conv_pack_size.restype = C.c_int64
+    if lib.lmn_abi_version() != ABI_VERSION:
+        raise RuntimeError("lm_net_amd: ABI version mismatch")
+    if (lib.lmn_sizeof_conv_args() != C.sizeof(ConvArgs) or lib.lmn_sizeof_src() != C.sizeof(SrcT)
+            or lib.lmn_sizeof_wgrad_args() != C.sizeof(WgradArgs)):
+        raise RuntimeError("lm_net_amd: argument struct layout differs between hip.py and lmnet_hip.h")
+    _lib = lib
+    return lib
+
+
+def _check(rc, what):
+    if rc != 0:
+        raise RuntimeError("lm_net_amd.%s failed (code %d): %s" % (what, rc, load().lmn_last_error().decode()))
+
+
+def _p(t):
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError("lm_net_amd: device tensor required (got a CPU tensor); the HIP path has no CPU fallback")
+    if t.dtype != torch.float32:
+        raise RuntimeError("lm_net_amd: fp32 tensor required, got %s" % t.dtype)
+    return C.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _i64(v):
+    return C.c_int64(int(v))
+
+
+def _f(v):
+    return C.c_float(float(v))
+
+
+class V:
+    """A channel slice [off, off+C) of an NHWC tensor ``t`` of shape [..., Ctot] (contiguous)."""
+    __slots__ = ("t", "off", "C")
+
+    def __init__(self, t, off=0, Cn=None):
+        assert t.is_contiguous()
+        self.t, self.off = t, off
+        self.C = t.shape[-1] - off if Cn is None else Cn
+
+    @property
+    def ptr(self):
+        if not self.t.is_cuda or self.t.dtype != torch.float32:
+            raise RuntimeError("lm_net_amd: fp32 device tensor required")
+        return self.t.data_ptr() + 4 * self.off
+
+    @property
+    def cstride(self):
+        return self.t.shape[-1]
+
+
+def _as_view(x):
+    return x if isinstance(x, V) else V(x)
+
+
+def _fill_src(dst, s):
+    """s: V | tensor | dict(view=, scale=, flags=, drop_seed=, drop_p=)"""
+    if isinstance(s, dict):
+        v = _as_view(s["view"])
+        scale = s.get("scale")
+        dst.ptr, dst.C, dst.cstride = v.ptr, v.C, v.cstride
+        dst.scale = scale.data_ptr() if scale is not None else None
+        dst.flags = s.get("flags", 0)
+        dst.drop_seed = s.get("drop_seed", 0)
+        dst.drop_p = s.get("drop_p", 0.0)
+    else:
+        v = _as_view(s)
+        dst.ptr, dst.C, dst.cstride = v.ptr, v.C, v.cstride
+        dst.scale, dst.flags, dst.drop_seed, dst.drop_p = None, 0, 0, 0.0
+    return v.C
+
+
+# ------------------------------------------------------------------------------------------ conv family
+def conv_pack_size(ksize, rows, src_channels):
+    arr = (C.c_int32 * len(src_channels))(*src_channels)
+    return int(load().lmn_conv_pack_size(ksize, rows, len(src_channels), arr))
+
+
+def conv_pack(w, ksize, src_channels, out=None):
+    """Pack a torch-layout weight [Cout, Cin(,k,k)] for the forward operator."""
+    cout, cin = w.shape[0], w.shape[1]
+    n = conv_pack_size(ksize, cout, src_channels)
+    if out is None:
+        out = torch.empty(n, device=w.device, dtype=torch.float32)
+    arr = (C.c_int32 * len(src_channels))(*src_channels)
+    _check(load().lmn_conv_pack(_p(w), _p(out), ksize, cout, cin, len(src_channels), arr, 0, 0, 0, _stream()), "conv_pack")
+    return out
+
+
+def conv_pack_t(w, ksize, row_off=0, rows=None, out=None):
+    """Pack the data-gradient operator of a forward weight [Cout, Cin(,k,k)]: rows = input channels
+    [row_off, row_off+rows), reduction over Cout."""
+    cout, cin = w.shape[0], w.shape[1]
+    rows = cin - row_off if rows is None else rows
+    n = conv_pack_size(ksize, rows, [cout])
+    if out is None:
+        out = torch.empty(n, device=w.device, dtype=torch.float32)
+    arr = (C.c_int32 * 1)(cout)
+    _check(load().lmn_conv_pack(_p(w), _p(out), ksize, cout, cin, 1, arr, 1, row_off, rows, _stream()), "conv_pack_t")
+    return out
+
+
+def conv_fwd(srcs, wpack, out, *, B, Hin, Win, Hout, Wout, Cout, ksize=1, stride=1, transposed=0, bias=None,
+             epilogue=EP_LINEAR, act=ACT_NONE, p=(), aux=None, residual=None, stats=None, stats_mode=STATS_NONE,
+             drop_p=0.0, drop_seed=0):
+    a = ConvArgs()
+    a.B, a.Hout, a.Wout, a.Hin, a.Win = B, Hout, Wout, Hin, Win
+    a.ksize, a.stride, a.transposed, a.nsrc, a.Cout = ksize, stride, transposed, len(srcs), Cout
+    for i, s in enumerate(srcs):
+        _fill_src(a.src[i], s)
+    a.wpack = wpack.data_ptr()
+    a.bias = bias.data_ptr() if bias is not None else None
+    ps = [t.data_ptr() if t is not None else None for t in p] + [None] * (5 - len(p))
+    a.p0, a.p1, a.p2, a.p3, a.p4 = ps
+    if aux is not None:
+        v = _as_view(aux)
+        a.aux, a.aux_cstride = v.ptr, v.cstride
+    if residual is not None:
+        v = _as_view(residual)
+        a.residual, a.res_cstride = v.ptr, v.cstride
+    if out is not None:
+        v = _as_view(out)
+        a.out, a.out_cstride = v.ptr, v.cstride
+    a.stats = stats.data_ptr() if stats is not None else None
+    a.epilogue, a.act, a.stats_mode = epilogue, act, stats_mode
+    a.drop_p, a.drop_seed = drop_p, drop_seed
+    _check(load().lmn_conv_fwd(C.byref(a), _stream()), "conv_fwd")
+
+
+def conv_wgrad(srcs, dy, dW, db, *, B, Hin, Win, Hout, Wout, Cout, ksize=1, stride=1, dy_flags=0, dy_seed=0, dy_p=0.0):
+    a = WgradArgs()
+    a.B, a.Hout, a.Wout, a.Hin, a.Win = B, Hout, Wout, Hin, Win
+    a.ksize, a.stride, a.nsrc, a.Cout = ksize, stride, len(srcs), Cout
+    for i, s in enumerate(srcs):
+        _fill_src(a.src[i], s)
+    v = _as_view(dy)
+    a.dy, a.dy_cstride = v.ptr, v.cstride
+    a.dy_flags, a.dy_seed, a.dy_p = dy_flags, dy_seed, dy_p
+    a.dW = dW.data_ptr()
+    a.db = db.data_ptr() if db is not None else None
+    _check(load().lmn_conv_wgrad(C.byref(a), _stream()), "conv_wgrad")
+
+
+# ------------------------------------------------------------------------------------------ depthwise block
+def dw_stats(x1, w5, w3, wv, wh, stats):
+    B, H, W, E = x1.shape
+    _check(load().lmn_dw_stats(_p(x1), B, H, W, E, _p(w5), _p(w3), _p(wv), _p(wh), _p(stats), _stream()), "dw_stats")
+
+
+def dw_merge(w5, w3, wv, wh, A, shift, keff, beff):
+    _check(load().lmn_dw_merge(_p(w5), _p(w3), _p(wv), _p(wh), _p(A), _p(shift), _p(keff), _p(beff), w5.shape[0],
+                               _stream()), "dw_merge")
+
+
+def dw_fwd(x1, pre, gsum, keff, beff):
+    B, H, W, E = x1.shape
+    _check(load().lmn_dw_fwd(_p(x1), _p(pre), _p(gsum), B, H, W, E, _p(keff), _p(beff), _stream()), "dw_fwd")
+
+
+def dw_bwd_stats(x1, pre, u, s, dm, dpre, w5, w3, wv, wh, bstats):
+    B, H, W, E = x1.shape
+    _check(load().lmn_dw_bwd_stats(_p(x1), _p(pre), _p(u), _p(s), _p(dm), _p(dpre), B, H, W, E, _p(w5), _p(w3), _p(wv),
+                                   _p(wh), _p(bstats), _stream()), "dw_bwd_stats")
+
+
+def dw_bwd(x1, dpre, dx1, w5, w3, wv, wh, cA, cC, cD, dwgrad):
+    B, H, W, E = x1.shape
+    _check(load().lmn_dw_bwd(_p(x1), _p(dpre), _p(dx1), B, H, W, E, _p(w5), _p(w3), _p(wv), _p(wh), _p(cA), _p(cC),
+                             _p(cD), _p(dwgrad), _stream()), "dw_bwd")
+
+
+def se_fwd(gsum, inv_hw, w1, b1, w2, b2, s, hidden):
+    B, E = gsum.shape
+    _check(load().lmn_se_fwd(_p(gsum), _f(inv_hw), _p(w1), _p(b1), _p(w2), _p(b2), _p(s), _p(hidden), B, E, w1.shape[0],
+                             _stream()), "se_fwd")
+
+
+def se_bwd(ds, gsum, inv_hw, w1, b1, w2, b2, hidden, dm, dw1, db1, dw2, db2):
+    B, E = gsum.shape
+    _check(load().lmn_se_bwd(_p(ds), _p(gsum), _f(inv_hw), _p(w1), _p(b1), _p(w2), _p(b2), _p(hidden), _p(dm), _p(dw1),
+                             _p(db1), _p(dw2), _p(db2), B, E, w1.shape[0], _stream()), "se_bwd")
+
+
+# ------------------------------------------------------------------------------------------ attention
+def na_fwd(qkv, rpb, out, heads):
+    B, H, W, C3 = qkv.shape
+    hd = C3 // 3 // heads
+    _check(load().lmn_na_fwd(_p(qkv), _p(rpb), _p(out), B, H, W, heads, hd, _f(hd ** -0.5), _stream()), "na_fwd")
+
+
+def na_bwd(qkv, rpb, dout, dqkv, drpb, heads):
+    B, H, W, C3 = qkv.shape
+    hd = C3 // 3 // heads
+    _check(load().lmn_na_bwd(_p(qkv), _p(rpb), _p(dout), _p(dqkv), _p(drpb), B, H, W, heads, hd, _f(hd ** -0.5),
+                             _stream()), "na_bwd")
+
+
+def gattn_fwd(qkv, out, lse, heads):
+    B, N, C3 = qkv.shape
+    hd = C3 // 3 // heads
+    _check(load().lmn_gattn_fwd(_p(qkv), _p(out), _p(lse), B, N, heads, hd, _f(hd ** -0.5), _stream()), "gattn_fwd")
+
+
+def gattn_bwd(qkv, out, dout, lse, dqkv, delta, heads):
+    B, N, C3 = qkv.shape
+    hd = C3 // 3 // heads
+    _check(load().lmn_gattn_bwd(_p(qkv), _p(out), _p(dout), _p(lse), _p(dqkv), _p(delta), B, N, heads, hd,
+                                _f(hd ** -0.5), _stream()), "gattn_bwd")
+
+
+# ------------------------------------------------------------------------------------------ norms
+def ln_fwd(x, gamma, beta, y):
+    Cn = x.shape[-1]
+    _check(load().lmn_ln_fwd(_p(x), _p(gamma), _p(beta), _p(y), _i64(x.numel() // Cn), Cn, _stream()), "ln_fwd")
+
+
+def ln_bwd(x, gamma, dy, dres, dx, dgamma, dbeta):
+    Cn = x.shape[-1]
+    _check(load().lmn_ln_bwd(_p(x), _p(gamma), _p(dy), _p(dres), _p(dx), _p(dgamma), _p(dbeta), _i64(x.numel() // Cn),
+                             Cn, _stream()), "ln_bwd")
+
+
+def bnact_fwd(z, a, b, y, act):
+    Cn = z.shape[-1]
+    _check(load().lmn_bnact_fwd(_p(z), _p(a), _p(b), _p(y), _i64(z.numel() // Cn), Cn, act, _stream()), "bnact_fwd")
+
+
+def bnact_bwd_stats(z, dy, mean, rstd, gamma, beta, stats, act):
+    Cn = z.shape[-1]
+    _check(load().lmn_bnact_bwd_stats(_p(z), _p(dy), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(stats),
+                                      _i64(z.numel() // Cn), Cn, act, _stream()), "bnact_bwd_stats")
+
+
+def bnact_bwd(z, dy, mean, rstd, gamma, beta, c1, c2, c3, dz, act):
+    Cn = z.shape[-1]
+    _check(load().lmn_bnact_bwd(_p(z), _p(dy), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(c1), _p(c2), _p(c3), _p(dz),
+                                _i64(z.numel() // Cn), Cn, act, _stream()), "bnact_bwd")
+
+
+def bn_finalize(sums, count, gamma, beta, eps, momentum, mean, rstd, A, shift, running_mean, running_var):
+    _check(load().lmn_bn_finalize(_p(sums), _f(count), _p(gamma), _p(beta), _f(eps), _f(momentum), _p(mean), _p(rstd),
+                                  _p(A), _p(shift), _p(running_mean), _p(running_var), gamma.numel(), _stream()),
+           "bn_finalize")
+
+
+def bn_bwd_coef(bstats, count, A, dgamma, dbeta, c1, c2, c3):
+    _check(load().lmn_bn_bwd_coef(_p(bstats), _f(count), _p(A), _p(dgamma), _p(dbeta), _p(c1), _p(c2), _p(c3), A.numel(),
+                                  _stream()), "bn_bwd_coef")
+
+
+# ------------------------------------------------------------------------------------------ resampling / layout / utils
+def up2_fwd(x, y):
+    x, y = _as_view(x), _as_view(y)
+    B, Hin, Win = x.t.shape[:3]
+    _check(load().lmn_up2_fwd(C.c_void_p(x.ptr), C.c_void_p(y.ptr), B, Hin, Win, x.C, x.cstride, y.cstride, _stream()),
+           "up2_fwd")
+
+
+def up2_bwd(dy, dx):
+    dy, dx = _as_view(dy), _as_view(dx)
+    B, Hin, Win = dx.t.shape[:3]
+    _check(load().lmn_up2_bwd(C.c_void_p(dy.ptr), C.c_void_p(dx.ptr), B, Hin, Win, dx.C, dy.cstride, dx.cstride,
+                              _stream()), "up2_bwd")
+
+
+def avgpool_fwd(x, y, f):
+    x, y = _as_view(x), _as_view(y)
+    B, Hout, Wout = y.t.shape[:3]
+    _check(load().lmn_avgpool_fwd(C.c_void_p(x.ptr), C.c_void_p(y.ptr), B, Hout, Wout, f, x.C, x.cstride, y.cstride,
+                                  _stream()), "avgpool_fwd")
+
+
+def avgpool_bwd(dy, dx, f, accumulate):
+    dy, dx = _as_view(dy), _as_view(dx)
+    B, Hout, Wout = dy.t.shape[:3]
+    _check(load().lmn_avgpool_bwd(C.c_void_p(dy.ptr), C.c_void_p(dx.ptr), B, Hout, Wout, f, dx.C, dy.cstride,
+                                  dx.cstride, int(accumulate), _stream()), "avgpool_bwd")
+
+
+def nchw_to_nhwc(x, y):
+    B, Cn, H, W = x.shape
+    _check(load().lmn_nchw_to_nhwc(_p(x), _p(y), B, Cn, H, W, y.shape[-1], _stream()), "nchw_to_nhwc")
+
+
+def nhwc_to_nchw(x, y):
+    B, Cn, H, W = y.shape
+    _check(load().lmn_nhwc_to_nchw(_p(x), _p(y), B, Cn, H, W, x.shape[-1], _stream()), "nhwc_to_nchw")
+
+
+def fill(t, v):
+    _check(load().lmn_fill(_p(t), _f(v), _i64(t.numel()), _stream()), "fill")
+
+
+def add(a, b, c=None, d=None, out=None):
+    out = a if out is None else out
+    _check(load().lmn_add(_p(a), _p(b), _p(c), _p(d), _p(out), _i64(a.numel()), _stream()), "add")
+    return out
+
+
+def colsum(x, out):
+    x = _as_view(x)
+    rows = x.t.numel() // x.cstride
+    _check(load().lmn_colsum(C.c_void_p(x.ptr), _p(out), _i64(rows), x.C, x.cstride, _stream()), "colsum")
+
+
+def copy_slice(x, y):
+    x, y = _as_view(x), _as_view(y)
+    rows = x.t.numel() // x.cstride
+    _check(load().lmn_copy_slice(C.c_void_p(x.ptr), C.c_void_p(y.ptr), _i64(rows), x.C, x.cstride, y.cstride, _stream()),
+           "copy_slice")

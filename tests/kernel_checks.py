@@ -1,0 +1,535 @@
+"""Per-kernel parity checks of the C-ABI (lm_net_amd/hip.py) against plain PyTorch fp64 CPU references
+(and oracle/natten_ref.py for neighborhood attention).  Each check returns a list of
+(name, rel_err, tol) rows; ``tests/test_kernels_gpu.py`` asserts them, ``tools/gpu_kernel_check.py``
+prints them all in one GPU run.  Tolerance for fp32 device arithmetic vs fp64: 1e-4 relative
+(north_star), atomically-reduced sums 2e-4.
+"""
+import math
+
+import torch
+import torch.nn.functional as F
+
+from lm_net_amd import hip
+from oracle import natten_ref
+
+DEV = "cuda"
+TOL = 1e-4
+
+
+def R(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed + 1000 * len(shape) + sum(shape))
+    return (torch.randn(*shape, generator=g, dtype=torch.float64) * scale)
+
+
+def dev(t):
+    return t.to(torch.float32).to(DEV).contiguous()
+
+
+def rel(got, ref):
+    got = got.detach().double().cpu()
+    ref = ref.detach().double().cpu()
+    if got.shape != ref.shape:
+        return float("inf")
+    if not torch.isfinite(got).all():
+        return float("inf")
+    return float((got - ref).abs().max() / (ref.abs().max() + 1e-30))
+
+
+def nhwc(t):  # NCHW fp64 cpu -> NHWC fp32 device
+    return dev(t.permute(0, 2, 3, 1))
+
+
+def nchw(t):  # NHWC device -> NCHW fp64 cpu
+    return t.detach().double().cpu().permute(0, 3, 1, 2)
+
+
+def gelu(x):
+    return 0.5 * x * (1 + torch.erf(x / math.sqrt(2)))
+
+
+# ------------------------------------------------------------------------------------------------ conv forward
+def check_conv_fwd():
+    rows = []
+    cases = [
+        # name, B, H, W, [Cin...], Cout, k, s
+        ("1x1 12->24", 2, 9, 13, [12], 24, 1, 1),
+        ("1x1 4->24 (padded rgb)", 1, 8, 8, [4], 24, 1, 1),
+        ("1x1 96->192", 1, 7, 6, [96], 192, 1, 1),
+        ("1x1 372->1116", 1, 5, 5, [372], 1116, 1, 1),
+        ("1x1 two-src 24+12->12", 2, 6, 7, [24, 12], 12, 1, 1),
+        ("3x3 s1 12->12", 2, 10, 11, [12], 12, 3, 1),
+        ("3x3 s1 48->24", 1, 9, 9, [48], 24, 3, 1),
+        ("3x3 s2 12->24", 2, 12, 10, [12], 24, 3, 2),
+        ("3x3 s2 96->192", 1, 8, 8, [96], 192, 3, 2),
+        ("3x3 s1 cat 24+24+24->24", 1, 8, 9, [24, 24, 24], 24, 3, 1),
+        ("3x3 s1 100->112 (chunks)", 1, 6, 6, [100], 112, 3, 1),
+        ("3x3 s1 372->372", 1, 6, 6, [372], 372, 3, 1),
+    ]
+    for name, B, H, W, cins, cout, k, s in cases:
+        cin = sum(cins)
+        x = R(B, cin, H, W, seed=1)
+        w = R(cout, cin, k, k, seed=2, scale=1.0 / math.sqrt(cin * k * k))
+        b = R(cout, seed=3)
+        ref = F.conv2d(x, w, b, stride=s, padding=k // 2)
+        Ho, Wo = ref.shape[2:]
+        xs, off = [], 0
+        for c in cins:
+            xs.append(nhwc(x[:, off:off + c]))
+            off += c
+        wp = hip.conv_pack(dev(w), k, cins)
+        out = torch.full((B, Ho, Wo, cout), float("nan"), device=DEV)
+        hip.conv_fwd(xs, wp, out, B=B, Hin=H, Win=W, Hout=Ho, Wout=Wo, Cout=cout, ksize=k, stride=s, bias=dev(b))
+        rows.append(("conv_fwd " + name, rel(nchw(out), ref), TOL))
+
+    # sources that are slices of a wider buffer; output into a slice; residual; affine+hardswish; stats
+    B, H, W = 2, 7, 9
+    x = R(B, 36, H, W, seed=5)
+    w = R(24, 24, 3, 3, seed=6, scale=0.1)
+    b = R(24, seed=7)
+    res = R(B, 24, H, W, seed=8)
+    a0, a1 = R(24, seed=9), R(24, seed=10)
+    z = F.conv2d(x[:, 8:32], w, b, padding=1)
+    ref = F.hardswish((z * a0.view(1, -1, 1, 1) + a1.view(1, -1, 1, 1)).float()).double() + res
+    xb = nhwc(x)
+    outb = torch.zeros(B, H, W, 40, device=DEV)
+    stats = torch.zeros(2, 24, device=DEV)
+    wp = hip.conv_pack(dev(w), 3, [24])
+    hip.conv_fwd([hip.V(xb, 8, 24)], wp, hip.V(outb, 12, 24), B=B, Hin=H, Win=W, Hout=H, Wout=W, Cout=24, ksize=3,
+                 bias=dev(b), epilogue=hip.EP_AFFINE_ACT, act=hip.ACT_HSWISH, p=(dev(a0), dev(a1)), residual=nhwc(res),
+                 stats=stats, stats_mode=hip.STATS_SUM_SQ)
+    rows.append(("conv_fwd slice/affine/hswish/residual", rel(nchw(outb[..., 12:36]), ref), TOL))
+    rows.append(("conv_fwd untouched slice stays 0", float(outb[..., :12].abs().max() + outb[..., 36:].abs().max()), 1e-30))
+    sref = torch.stack([z.sum((0, 2, 3)), (z * z).sum((0, 2, 3))])
+    rows.append(("conv_fwd stats sum/sumsq", rel(stats, sref), 2e-4))
+
+    # A3 form: GELU + per-(image,channel) scale on source 0, plain source 1
+    B, H, W = 3, 6, 5
+    pre, xin = R(B, 24, H, W, seed=11), R(B, 12, H, W, seed=12)
+    sc = R(B, 24, seed=13).abs()
+    w = R(12, 36, 1, 1, seed=14, scale=0.2)
+    b = R(12, seed=15)
+    ref = F.conv2d(torch.cat([gelu(pre) * sc.view(B, 24, 1, 1), xin], 1), w, b)
+    wp = hip.conv_pack(dev(w), 1, [24, 12])
+    out = torch.empty(B, H, W, 12, device=DEV)
+    hip.conv_fwd([dict(view=nhwc(pre), scale=dev(sc), flags=hip.SRC_GELU), nhwc(xin)], wp, out, B=B, Hin=H, Win=W,
+                 Hout=H, Wout=W, Cout=12, bias=dev(b))
+    rows.append(("conv_fwd gelu*scale source + plain source", rel(nchw(out), ref), TOL))
+    return rows
+
+
+def check_conv_bwd_data():
+    rows = []
+    cases = [("1x1 24->12", 2, 7, 6, 24, 12, 1, 1), ("3x3 s1 24->36", 2, 8, 9, 24, 36, 3, 1),
+             ("3x3 s2 12->24", 2, 12, 10, 12, 24, 3, 2), ("3x3 s2 48->96 odd", 1, 9, 7, 48, 96, 3, 2),
+             ("3x3 s1 96->96", 1, 6, 6, 96, 96, 3, 1)]
+    for name, B, H, W, cin, cout, k, s in cases:
+        x = R(B, cin, H, W, seed=21).requires_grad_(True)
+        w = R(cout, cin, k, k, seed=22, scale=0.1)
+        y = F.conv2d(x, w, None, stride=s, padding=k // 2)
+        dy = R(*y.shape, seed=23)
+        y.backward(dy)
+        Ho, Wo = y.shape[2:]
+        wpt = hip.conv_pack_t(dev(w), k)
+        dx = torch.full((B, H, W, cin), float("nan"), device=DEV)
+        hip.conv_fwd([nhwc(dy)], wpt, dx, B=B, Hin=Ho, Win=Wo, Hout=H, Wout=W, Cout=cin, ksize=k, stride=s, transposed=1)
+        rows.append(("conv_bwd_data " + name, rel(nchw(dx), x.grad), TOL))
+    # gradient of one source slice of a cat conv (rows [12, 36) of 48 input channels)
+    B, H, W = 1, 6, 7
+    x = R(B, 48, H, W, seed=24).requires_grad_(True)
+    w = R(24, 48, 3, 3, seed=25, scale=0.1)
+    y = F.conv2d(x, w, None, padding=1)
+    dy = R(*y.shape, seed=26)
+    y.backward(dy)
+    wpt = hip.conv_pack_t(dev(w), 3, row_off=12, rows=24)
+    dx = torch.empty(B, H, W, 24, device=DEV)
+    hip.conv_fwd([nhwc(dy)], wpt, dx, B=B, Hin=H, Win=W, Hout=H, Wout=W, Cout=24, ksize=3, transposed=1)
+    rows.append(("conv_bwd_data source slice of cat", rel(nchw(dx), x.grad[:, 12:36]), TOL))
+    return rows
+
+
+def check_conv_wgrad():
+    rows = []
+    cases = [("1x1 12->24", 2, 9, 7, [12], 24, 1, 1), ("1x1 two-src 24+12->12", 2, 6, 7, [24, 12], 12, 1, 1),
+             ("3x3 s1 12->12", 2, 10, 11, [12], 12, 3, 1), ("3x3 s2 24->48", 2, 12, 10, [24], 48, 3, 2),
+             ("3x3 s1 cat 24+24->24", 1, 8, 9, [24, 24], 24, 3, 1), ("3x3 s1 96->96", 1, 7, 7, [96], 96, 3, 1),
+             ("1x1 372->744", 1, 6, 6, [372], 744, 1, 1)]
+    for name, B, H, W, cins, cout, k, s in cases:
+        cin = sum(cins)
+        x = R(B, cin, H, W, seed=31)
+        w = R(cout, cin, k, k, seed=32, scale=0.1).requires_grad_(True)
+        b = R(cout, seed=33).requires_grad_(True)
+        y = F.conv2d(x, w, b, stride=s, padding=k // 2)
+        dy = R(*y.shape, seed=34)
+        y.backward(dy)
+        Ho, Wo = y.shape[2:]
+        xs, off = [], 0
+        for c in cins:
+            xs.append(nhwc(x[:, off:off + c]))
+            off += c
+        dW = torch.zeros(cout, cin, k, k, device=DEV)
+        db = torch.zeros(cout, device=DEV)
+        hip.conv_wgrad(xs, nhwc(dy), dW, db, B=B, Hin=H, Win=W, Hout=Ho, Wout=Wo, Cout=cout, ksize=k, stride=s)
+        rows.append(("conv_wgrad dW " + name, rel(dW, w.grad), 2e-4))
+        rows.append(("conv_wgrad db " + name, rel(db, b.grad), 2e-4))
+    return rows
+
+
+def check_conv_dropout():
+    """Epilogue dropout and its two backward uses regenerate the SAME mask; keep-rate ~ 1-p."""
+    rows = []
+    B, H, W, C = 2, 16, 16, 24
+    x = R(B, C, H, W, seed=41)
+    eye = torch.eye(C, dtype=torch.float64).view(C, C, 1, 1)
+    wp = hip.conv_pack(dev(eye), 1, [C])
+    out = torch.empty(B, H, W, C, device=DEV)
+    hip.conv_fwd([nhwc(x)], wp, out, B=B, Hin=H, Win=W, Hout=H, Wout=W, Cout=C, drop_p=0.1, drop_seed=77)
+    o = nchw(out)
+    keep = (o != 0)
+    rows.append(("dropout keep-rate", abs(float(keep.double().mean()) - 0.9), 0.02))
+    rows.append(("dropout kept values scaled 1/(1-p)", rel(o[keep], (x / 0.9)[keep]), TOL))
+    # the same mask applied on load (LMN_SRC_DROP) to a tensor of ones
+    out2 = torch.empty(B, H, W, C, device=DEV)
+    ones = torch.ones(B, H, W, C, device=DEV)
+    hip.conv_fwd([dict(view=ones, flags=hip.SRC_DROP, drop_seed=77, drop_p=0.1)], wp, out2, B=B, Hin=H, Win=W, Hout=H,
+                 Wout=W, Cout=C)
+    rows.append(("dropout mask identical on load", rel(nchw(out2), keep.double() / 0.9), TOL))
+    return rows
+
+
+# ------------------------------------------------------------------------------------------------ depthwise block
+def _dw_ref(x1, ws, gam, bet, train, rm=None, rv=None):
+    """torch reference of sum_b BN_b(dw_b(x1)) (fp64).  Returns pre and the 4 branch outputs."""
+    E = x1.shape[1]
+    pads = [(2, 2), (1, 1), (1, 0), (0, 1)]
+    ys = [F.conv2d(x1, w, None, padding=p, groups=E) for w, p in zip(ws, pads)]
+    pre = 0
+    for i, y in enumerate(ys):
+        if train:
+            pre = pre + F.batch_norm(y, None, None, gam[i], bet[i], True, 0.1, 1e-5)
+        else:
+            pre = pre + F.batch_norm(y, rm[i], rv[i], gam[i], bet[i], False, 0.1, 1e-5)
+    return pre, ys
+
+
+def check_dw():
+    rows = []
+    for (B, H, W, E) in [(2, 20, 19, 24), (1, 33, 17, 48)]:
+        x1 = R(B, E, H, W, seed=51)
+        ws = [R(E, 1, 5, 5, seed=52, scale=0.2), R(E, 1, 3, 3, seed=53, scale=0.3), R(E, 1, 3, 1, seed=54, scale=0.5),
+              R(E, 1, 1, 3, seed=55, scale=0.5)]
+        gam = [R(E, seed=56 + i).abs() + 0.5 for i in range(4)]
+        bet = [R(E, seed=60 + i) * 0.1 for i in range(4)]
+        x1r = x1.clone().requires_grad_(True)
+        wsr = [w.clone().requires_grad_(True) for w in ws]
+        gr = [g.clone().requires_grad_(True) for g in gam]
+        br = [b.clone().requires_grad_(True) for b in bet]
+        pre_ref, ys = _dw_ref(x1r, wsr, gr, br, True)
+        tag = " E=%d %dx%d" % (E, H, W)
+        # --- stats
+        x1d = nhwc(x1)
+        wd = [dev(w) for w in ws]
+        stats = torch.zeros(8, E, device=DEV)
+        hip.dw_stats(x1d, *wd, stats)
+        sref = torch.stack([y.sum((0, 2, 3)) for y in ys] + [(y * y).sum((0, 2, 3)) for y in ys]).detach()
+        rows.append(("dw_stats" + tag, rel(stats, sref), 2e-4))
+        # --- merge (with the exact fp64 batch stats) + forward
+        N = B * H * W
+        mean = [y.mean((0, 2, 3)).detach() for y in ys]
+        rstd = [1.0 / torch.sqrt(y.var((0, 2, 3), unbiased=False) + 1e-5).detach() for y in ys]
+        A = torch.stack([gam[i] * rstd[i] for i in range(4)])
+        shift = torch.stack([bet[i] - mean[i] * A[i] for i in range(4)])
+        keff, beff = torch.empty(E, 25, device=DEV), torch.empty(E, device=DEV)
+        hip.dw_merge(*wd, dev(A), dev(shift), keff, beff)
+        pre = torch.full((B, H, W, E), float("nan"), device=DEV)
+        gsum = torch.zeros(B, E, device=DEV)
+        hip.dw_fwd(x1d, pre, gsum, keff, beff)
+        rows.append(("dw_fwd pre" + tag, rel(nchw(pre), pre_ref), TOL))
+        rows.append(("dw_fwd gsum" + tag, rel(gsum, gelu(pre_ref).sum((2, 3)).detach()), 2e-4))
+        # --- backward: dpre = (u*s + dm) * gelu'(pre)
+        u = R(B, E, H, W, seed=70)
+        s = R(B, E, seed=71).abs()
+        dm = R(B, E, seed=72) * 0.01
+        pre_l = pre_ref.detach().clone().requires_grad_(True)
+        g = gelu(pre_l)
+        (g * (u * s.view(B, E, 1, 1) + dm.view(B, E, 1, 1))).sum().backward()
+        dpre_ref = pre_l.grad
+        pre_ref.backward(dpre_ref)
+        dpre = torch.full((B, H, W, E), float("nan"), device=DEV)
+        bstats = torch.zeros(5, E, device=DEV)
+        hip.dw_bwd_stats(x1d, nhwc(pre_ref.detach()), nhwc(u), dev(s), dev(dm), dpre, *wd, bstats)
+        rows.append(("dw_bwd_stats dpre" + tag, rel(nchw(dpre), dpre_ref), TOL))
+        bref = torch.stack([dpre_ref.sum((0, 2, 3))] + [(dpre_ref * y.detach()).sum((0, 2, 3)) for y in ys])
+        rows.append(("dw_bwd_stats sums" + tag, rel(bstats, bref), 2e-4))
+        # coefficients (host math in fp64 from the exact sums): f_b = A_b dpre + C_b y_b + D_b
+        S0 = bref[0]
+        cA, cC, cD = [], [], []
+        for i in range(4):
+            T = (bref[1 + i] - mean[i] * S0) * rstd[i]
+            Cb = -A[i] * T * rstd[i] / N
+            cA.append(A[i]); cC.append(Cb); cD.append(-A[i] * S0 / N - Cb * mean[i])
+        dx1 = torch.full((B, H, W, E), float("nan"), device=DEV)
+        dwg = torch.zeros(E, 40, device=DEV)
+        hip.dw_bwd(x1d, nhwc(dpre_ref), dx1, *wd, dev(torch.stack(cA)), dev(torch.stack(cC)), dev(torch.stack(cD)), dwg)
+        rows.append(("dw_bwd dx1" + tag, rel(nchw(dx1), x1r.grad), TOL))
+        dwg = dwg.double().cpu()
+        rows.append(("dw_bwd dW5" + tag, rel(dwg[:, :25], wsr[0].grad.reshape(E, 25)), 2e-4))
+        rows.append(("dw_bwd dW3" + tag, rel(dwg[:, 25:34], wsr[1].grad.reshape(E, 9)), 2e-4))
+        rows.append(("dw_bwd dWv" + tag, rel(dwg[:, 34:37], wsr[2].grad.reshape(E, 3)), 2e-4))
+        rows.append(("dw_bwd dWh" + tag, rel(dwg[:, 37:40], wsr[3].grad.reshape(E, 3)), 2e-4))
+    return rows
+
+
+def check_se():
+    rows = []
+    B, E, Rr, HW = 3, 24, 6, 35
+    gsum = R(B, E, seed=81) * HW * 0.3
+    w1, b1 = R(Rr, E, seed=82, scale=0.4).requires_grad_(True), R(Rr, seed=83).requires_grad_(True)
+    w2, b2 = R(E, Rr, seed=84, scale=0.8).requires_grad_(True), R(E, seed=85).requires_grad_(True)
+    gs = gsum.clone().requires_grad_(True)
+    m = gs / HW
+    h = F.relu(m @ w1.t() + b1)
+    s_ref = F.hardsigmoid((h @ w2.t() + b2).float()).double()
+    # hardsigmoid through float loses autograd in fp64; redo in pure fp64
+    t = h @ w2.t() + b2
+    s_ref = torch.clamp(t + 3, 0, 6) / 6
+    ds = R(B, E, seed=86)
+    (s_ref * ds).sum().backward()
+    s, hid = torch.empty(B, E, device=DEV), torch.empty(B, Rr, device=DEV)
+    hip.se_fwd(dev(gsum), 1.0 / HW, dev(w1), dev(b1), dev(w2), dev(b2), s, hid)
+    rows.append(("se_fwd s", rel(s, s_ref), TOL))
+    dm = torch.empty(B, E, device=DEV)
+    dw1, db1 = torch.zeros(Rr, E, device=DEV), torch.zeros(Rr, device=DEV)
+    dw2, db2 = torch.zeros(E, Rr, device=DEV), torch.zeros(E, device=DEV)
+    hip.se_bwd(dev(ds), dev(gsum), 1.0 / HW, dev(w1), dev(b1), dev(w2), dev(b2), hid, dm, dw1, db1, dw2, db2)
+    rows.append(("se_bwd dm (=d gsum)", rel(dm, gs.grad), TOL))
+    for nm, got, ref in (("dw1", dw1, w1.grad), ("db1", db1, b1.grad), ("dw2", dw2, w2.grad), ("db2", db2, b2.grad)):
+        rows.append(("se_bwd " + nm, rel(got, ref), 2e-4))
+    return rows
+
+
+# ------------------------------------------------------------------------------------------------ attention
+def check_na():
+    rows = []
+    for (B, H, W, hd) in [(2, 7, 9, 1), (1, 6, 5, 2), (2, 5, 8, 4), (1, 9, 6, 8), (1, 3, 3, 2), (1, 3, 17, 1)]:
+        heads, Cn = 12, 12 * hd
+        qkv = R(B, H, W, 3 * Cn, seed=91).requires_grad_(True)
+        rpb = (R(heads, 5, 5, seed=92) * 0.5).requires_grad_(True)
+        q, k, v = qkv.reshape(B, H, W, 3, heads, hd).permute(3, 0, 4, 1, 2, 5).unbind(0)
+        attn = torch.softmax(natten_ref.na2d_qkrpb(q * hd ** -0.5, k, rpb, 3), -1)
+        o_ref = natten_ref.na2d_av(attn, v, 3).permute(0, 2, 3, 1, 4).reshape(B, H, W, Cn)
+        do = R(B, H, W, Cn, seed=93)
+        o_ref.backward(do)
+        tag = " hd=%d %dx%d" % (hd, H, W)
+        if H * W <= 64:
+            bf = natten_ref.na2d_bruteforce(q.detach() * hd ** -0.5, k.detach(), v.detach(), rpb.detach(), 3)
+            rows.append(("na oracle vec==bruteforce" + tag, rel(o_ref, bf.permute(0, 2, 3, 1, 4).reshape(B, H, W, Cn)), 1e-9))
+        out = torch.full((B, H, W, Cn), float("nan"), device=DEV)
+        hip.na_fwd(dev(qkv), dev(rpb), out, heads)
+        rows.append(("na_fwd" + tag, rel(out, o_ref), TOL))
+        dqkv = torch.zeros(B, H, W, 3 * Cn, device=DEV)
+        drpb = torch.zeros(heads, 5, 5, device=DEV)
+        hip.na_bwd(dev(qkv), dev(rpb), dev(do), dqkv, drpb, heads)
+        rows.append(("na_bwd dqkv" + tag, rel(dqkv, qkv.grad), 2e-4))
+        rows.append(("na_bwd drpb" + tag, rel(drpb, rpb.grad), 2e-4))
+    return rows
+
+
+def check_gattn():
+    rows = []
+    for (B, N, heads, hd) in [(2, 70, 12, 31), (1, 484, 12, 31), (1, 130, 3, 8)]:
+        Cn = heads * hd
+        qkv = (R(B, N, 3 * Cn, seed=101) * 0.7).requires_grad_(True)
+        q, k, v = qkv.view(B, N, 3, heads, hd).permute(2, 0, 3, 1, 4).unbind(0)
+        p = torch.softmax((q @ k.transpose(-2, -1)) * hd ** -0.5, -1)
+        o_ref = (p @ v).transpose(1, 2).reshape(B, N, Cn)
+        do = R(B, N, Cn, seed=102)
+        o_ref.backward(do)
+        out = torch.full((B, N, Cn), float("nan"), device=DEV)
+        lse = torch.empty(B, heads, N, device=DEV)
+        hip.gattn_fwd(dev(qkv), out, lse, heads)
+        tag = " N=%d hd=%d" % (N, hd)
+        rows.append(("gattn_fwd" + tag, rel(out, o_ref), TOL))
+        dqkv = torch.full((B, N, 3 * Cn), float("nan"), device=DEV)
+        delta = torch.empty(B, heads, N, device=DEV)
+        hip.gattn_bwd(dev(qkv), out, dev(do), lse, dqkv, delta, heads)
+        rows.append(("gattn_bwd dqkv" + tag, rel(dqkv, qkv.grad), 2e-4))
+    return rows
+
+
+# ------------------------------------------------------------------------------------------------ norms
+def check_ln():
+    rows = []
+    for Cn in (12, 24, 48, 96, 372):
+        n = 531 if Cn < 100 else 77
+        x = R(n, Cn, seed=111).requires_grad_(True)
+        g, b = (R(Cn, seed=112).abs() + 0.5).requires_grad_(True), R(Cn, seed=113).requires_grad_(True)
+        y_ref = F.layer_norm(x, (Cn,), g, b, 1e-5)
+        dy, dres = R(n, Cn, seed=114), R(n, Cn, seed=115)
+        y_ref.backward(dy)
+        y = torch.full((n, Cn), float("nan"), device=DEV)
+        hip.ln_fwd(dev(x), dev(g), dev(b), y)
+        rows.append(("ln_fwd C=%d" % Cn, rel(y, y_ref), TOL))
+        dx = torch.full((n, Cn), float("nan"), device=DEV)
+        dg, db = torch.zeros(Cn, device=DEV), torch.zeros(Cn, device=DEV)
+        hip.ln_bwd(dev(x), dev(g), dev(dy), dev(dres), dx, dg, db)
+        rows.append(("ln_bwd dx(+res) C=%d" % Cn, rel(dx, x.grad + dres), TOL))
+        rows.append(("ln_bwd dgamma C=%d" % Cn, rel(dg, g.grad), 2e-4))
+        rows.append(("ln_bwd dbeta C=%d" % Cn, rel(db, b.grad), 2e-4))
+    return rows
+
+
+def check_bn_tail():
+    """BatchNorm(batch stats)+GELU tail: bn_finalize, bnact_fwd, bnact_bwd_stats, bn_bwd_coef, bnact_bwd, colsum."""
+    rows = []
+    for Cn in (12, 24, 96):
+        n = 403
+        z = (R(n, Cn, seed=121) * 1.3 + 0.2).requires_grad_(True)
+        g, b = (R(Cn, seed=122).abs() + 0.5).requires_grad_(True), R(Cn, seed=123).requires_grad_(True)
+        rm, rv = R(Cn, seed=124) * 0.1, R(Cn, seed=125).abs() + 0.5
+        rm_ref, rv_ref = rm.clone(), rv.clone()
+        h = F.batch_norm(z, rm_ref, rv_ref, g, b, True, 0.1, 1e-5)
+        y_ref = gelu(h)
+        dy = R(n, Cn, seed=126)
+        y_ref.backward(dy)
+        zd = dev(z)
+        sums = torch.zeros(2, Cn, device=DEV)
+        hip.colsum(zd, sums[0])
+        hip.colsum((zd * zd).contiguous(), sums[1])
+        rows.append(("colsum C=%d" % Cn, rel(sums[0], z.detach().sum(0)), 2e-4))
+        mean, rstd, A, shift = (torch.empty(Cn, device=DEV) for _ in range(4))
+        rmd, rvd = dev(rm), dev(rv)
+        hip.bn_finalize(sums, n, dev(g), dev(b), 1e-5, 0.1, mean, rstd, A, shift, rmd, rvd)
+        rows.append(("bn_finalize running_mean C=%d" % Cn, rel(rmd, rm_ref), TOL))
+        rows.append(("bn_finalize running_var C=%d" % Cn, rel(rvd, rv_ref), TOL))
+        y = torch.full((n, Cn), float("nan"), device=DEV)
+        hip.bnact_fwd(zd, A, shift, y, hip.ACT_GELU)
+        rows.append(("bnact_fwd C=%d" % Cn, rel(y, y_ref), TOL))
+        bst = torch.zeros(2, Cn, device=DEV)
+        hip.bnact_bwd_stats(zd, dev(dy), mean, rstd, dev(g), dev(b), bst, hip.ACT_GELU)
+        dg, db = torch.zeros(Cn, device=DEV), torch.zeros(Cn, device=DEV)
+        c1, c2, c3 = (torch.empty(Cn, device=DEV) for _ in range(3))
+        hip.bn_bwd_coef(bst, n, A, dg, db, c1, c2, c3)
+        rows.append(("bn dgamma C=%d" % Cn, rel(dg, g.grad), 2e-4))
+        rows.append(("bn dbeta C=%d" % Cn, rel(db, b.grad), 2e-4))
+        dz = torch.full((n, Cn), float("nan"), device=DEV)
+        hip.bnact_bwd(zd, dev(dy), mean, rstd, dev(g), dev(b), c1, c2, c3, dz, hip.ACT_GELU)
+        rows.append(("bnact_bwd dz C=%d" % Cn, rel(dz, z.grad), 2e-4))
+    return rows
+
+
+def check_conv_bn_epilogues():
+    """expand_conv (1x1 + batch-stat BN + Hardswish) backward through the conv epilogues BN_BWD1/BN_BWD2,
+    and the SE_BWD / DGELU epilogues."""
+    rows = []
+    B, H, W, Cin, E = 2, 9, 8, 12, 24
+    x = R(B, Cin, H, W, seed=131)
+    w, b = R(E, Cin, 1, 1, seed=132, scale=0.4).requires_grad_(True), R(E, seed=133).requires_grad_(True)
+    g, be = (R(E, seed=134).abs() + 0.5).requires_grad_(True), R(E, seed=135).requires_grad_(True)
+    z = F.conv2d(x, w, b)
+    hh = F.batch_norm(z, None, None, g, be, True, 0.1, 1e-5)
+    x1 = hh * torch.clamp(hh + 3, 0, 6) / 6
+    dx1 = R(B, E, H, W, seed=136)
+    zr = z.detach().clone().requires_grad_(True)
+    h2 = F.batch_norm(zr, None, None, g.detach(), be.detach(), True, 0.1, 1e-5)
+    (h2 * torch.clamp(h2 + 3, 0, 6) / 6).backward(dx1)
+    x1.backward(dx1)
+    N = B * H * W
+    mean = z.detach().mean((0, 2, 3))
+    rstd = 1 / torch.sqrt(z.detach().var((0, 2, 3), unbiased=False) + 1e-5)
+    wp = hip.conv_pack(dev(w), 1, [Cin])
+    dh = torch.full((B, H, W, E), float("nan"), device=DEV)
+    st = torch.zeros(2, E, device=DEV)
+    xd = nhwc(x)
+    hip.conv_fwd([xd], wp, dh, B=B, Hin=H, Win=W, Hout=H, Wout=W, Cout=E, bias=dev(b), epilogue=hip.EP_BN_BWD1,
+                 act=hip.ACT_HSWISH, p=(dev(mean), dev(rstd), dev(g), dev(be)), aux=nhwc(dx1), stats=st,
+                 stats_mode=hip.STATS_EP)
+    A = dev(g.detach() * rstd)
+    dg, db_, c1, c2, c3 = (torch.zeros(E, device=DEV) for _ in range(5))
+    hip.bn_bwd_coef(st, N, A, dg, db_, c1, c2, c3)
+    rows.append(("conv BN_BWD1 dgamma", rel(dg, g.grad), 2e-4))
+    rows.append(("conv BN_BWD1 dbeta", rel(db_, be.grad), 2e-4))
+    dz = torch.full((B, H, W, E), float("nan"), device=DEV)
+    hip.conv_fwd([xd], wp, dz, B=B, Hin=H, Win=W, Hout=H, Wout=W, Cout=E, bias=dev(b), epilogue=hip.EP_BN_BWD2,
+                 p=(dev(mean), dev(rstd), c1, c2, c3), aux=dh)
+    rows.append(("conv BN_BWD2 dz", rel(nchw(dz), zr.grad), 2e-4))
+
+    # SE_BWD: o = v, stats[b][c] += v * gelu(aux)
+    pre = R(B, E, H, W, seed=137)
+    dy = R(B, Cin, H, W, seed=138)
+    wpw = R(Cin, E, 1, 1, seed=139, scale=0.3)          # forward pointwise E -> Cin ; data gradient Cin -> E
+    u_ref = F.conv_transpose2d(dy, wpw)
+    ds_ref = (u_ref * gelu(pre)).sum((2, 3))
+    wpt = hip.conv_pack_t(dev(wpw), 1)
+    u = torch.full((B, H, W, E), float("nan"), device=DEV)
+    ds = torch.zeros(B, E, device=DEV)
+    hip.conv_fwd([nhwc(dy)], wpt, u, B=B, Hin=H, Win=W, Hout=H, Wout=W, Cout=E, transposed=1, epilogue=hip.EP_SE_BWD,
+                 aux=nhwc(pre), stats=ds, stats_mode=hip.STATS_EP)
+    rows.append(("conv SE_BWD u", rel(nchw(u), u_ref), TOL))
+    rows.append(("conv SE_BWD ds", rel(ds, ds_ref), 2e-4))
+    # DGELU
+    o = torch.full((B, H, W, E), float("nan"), device=DEV)
+    hip.conv_fwd([nhwc(dy)], wpt, o, B=B, Hin=H, Win=W, Hout=H, Wout=W, Cout=E, transposed=1, epilogue=hip.EP_DGELU,
+                 aux=nhwc(pre))
+    pl = pre.clone().requires_grad_(True)
+    gelu(pl).backward(u_ref)
+    rows.append(("conv DGELU", rel(nchw(o), pl.grad), TOL))
+    return rows
+
+
+# ------------------------------------------------------------------------------------------------ resampling / layout
+def check_resample():
+    rows = []
+    for (B, H, W, Cn) in [(2, 5, 7, 12), (1, 11, 11, 24), (1, 22, 22, 48)]:
+        x = R(B, Cn, H, W, seed=141).requires_grad_(True)
+        y_ref = F.interpolate(x, scale_factor=2, mode="bilinear", align_corners=True)
+        dy = R(*y_ref.shape, seed=142)
+        y_ref.backward(dy)
+        y = torch.full((B, 2 * H, 2 * W, Cn), float("nan"), device=DEV)
+        hip.up2_fwd(nhwc(x), y)
+        rows.append(("up2_fwd %dx%d" % (H, W), rel(nchw(y), y_ref), TOL))
+        dx = torch.full((B, H, W, Cn), float("nan"), device=DEV)
+        hip.up2_bwd(nhwc(dy), dx)
+        rows.append(("up2_bwd %dx%d" % (H, W), rel(nchw(dx), x.grad), TOL))
+    for (B, Ho, Wo, f, Cn) in [(2, 3, 4, 16, 12), (1, 5, 3, 8, 24), (2, 4, 4, 2, 96)]:
+        x = R(B, Cn, Ho * f, Wo * f, seed=143).requires_grad_(True)
+        y_ref = F.adaptive_avg_pool2d(x, (Ho, Wo))
+        dy = R(*y_ref.shape, seed=144)
+        y_ref.backward(dy)
+        buf = torch.zeros(B, Ho, Wo, Cn + 8, device=DEV)
+        hip.avgpool_fwd(nhwc(x), hip.V(buf, 4, Cn), f)
+        rows.append(("avgpool_fwd f=%d (into slice)" % f, rel(nchw(buf[..., 4:4 + Cn]), y_ref), TOL))
+        dybuf = torch.zeros(B, Ho, Wo, Cn + 8, device=DEV)
+        dybuf[..., 4:4 + Cn] = nhwc(dy)
+        base = R(B, Cn, Ho * f, Wo * f, seed=145)
+        dx = nhwc(base).clone()
+        hip.avgpool_bwd(hip.V(dybuf, 4, Cn), dx, f, True)
+        rows.append(("avgpool_bwd f=%d accumulate" % f, rel(nchw(dx), x.grad + base), TOL))
+    return rows
+
+
+def check_layout_utils():
+    rows = []
+    x = R(2, 3, 6, 5, seed=151)
+    y = torch.full((2, 6, 5, 4), float("nan"), device=DEV)
+    hip.nchw_to_nhwc(dev(x), y)
+    rows.append(("nchw_to_nhwc (pad to 4)", rel(y[..., :3], x.permute(0, 2, 3, 1)) + float(y[..., 3].abs().max()), 1e-7))
+    z = R(2, 6, 5, 4, seed=152)
+    o = torch.full((2, 2, 6, 5), float("nan"), device=DEV)
+    hip.nhwc_to_nchw(dev(z), o)
+    rows.append(("nhwc_to_nchw (first 2 ch)", rel(o, z[..., :2].permute(0, 3, 1, 2)), 1e-7))
+    a, b, c = R(1000, seed=153), R(1000, seed=154), R(1000, seed=155)
+    out = torch.empty(1000, device=DEV)
+    hip.add(dev(a), dev(b), dev(c), None, out)
+    rows.append(("add3", rel(out, a + b + c), 1e-6))
+    t = torch.empty(777, device=DEV)
+    hip.fill(t, 2.5)
+    rows.append(("fill", float((t - 2.5).abs().max()), 1e-30))
+    src = R(50, 20, seed=156)
+    dst = torch.zeros(50, 32, device=DEV)
+    hip.copy_slice(hip.V(dev(src), 4, 12), hip.V(dst, 8, 12))
+    rows.append(("copy_slice", rel(dst[:, 8:20], src[:, 4:16]) + float(dst[:, :8].abs().max() + dst[:, 20:].abs().max()), 1e-7))
+    return rows
+
+
+ALL_CHECKS = [check_conv_fwd, check_conv_bwd_data, check_conv_wgrad, check_conv_dropout, check_conv_bn_epilogues,
+              check_dw, check_se, check_na, check_gattn, check_ln, check_bn_tail, check_resample, check_layout_utils]
