@@ -147,8 +147,8 @@ int lmn_conv_wgrad(const lmn_wgrad_args_t* args, lmn_stream_t stream);
  * 1x3 (zero pad k/2, no bias), each followed by its own BatchNorm, summed, then GELU
  * (core/modules.py:548-574, 592-597).  Weight pointers use torch layouts [E][1][kh][kw].
  * ------------------------------------------------------------------------------------------ */
-/* batch statistics of the four branch outputs: stats[8][E] += (sum y_b, sum y_b^2), b=0..3
- * in the order large(5x5), square(3x3), ver(3x1), hor(1x3). */
+/* batch statistics of the four branch outputs: stats[4][2][E] += (sum y_b, sum y_b^2), b=0..3
+ * in the order large(5x5), square(3x3), ver(3x1), hor(1x3); each [2][E] row pair feeds lmn_bn_finalize. */
 int lmn_dw_stats(const float* x1, int B, int H, int W, int E, const float* w5, const float* w3, const float* wv,
                  const float* wh, float* stats, lmn_stream_t stream);
 /* pre = sum_b A_b * conv_b(x1) + bias  expressed as ONE merged 5x5 stencil keff[E][25] + beff[E]
@@ -165,11 +165,17 @@ int lmn_dw_merge(const float* w5, const float* w3, const float* wv, const float*
 int lmn_dw_bwd_stats(const float* x1, const float* pre, const float* u, const float* s, const float* dm,
                      float* dpre, int B, int H, int W, int E, const float* w5, const float* w3, const float* wv,
                      const float* wh, float* bstats, lmn_stream_t stream);
+/* per-branch BatchNorm-backward coefficients from bstats (pass 1) and the forward statistics
+ * mean/rstd/A ([4][E] each): dgamma_b += T_b, dbeta_b += S0, and f_b = cA*dpre + cC*y_b + cD
+ * (batch_stats=0, i.e. eval-mode BN: cC = cD = 0).                                            */
+int lmn_dw_bwd_coef(const float* bstats, const float* mean, const float* rstd, const float* A, float count,
+                    int batch_stats, float* cA, float* cC, float* cD, float* dg0, float* dg1, float* dg2, float* dg3,
+                    float* db0, float* db1, float* db2, float* db3, int E, lmn_stream_t stream);
 /* backward, pass 2: f_b = cA[b]*dpre + cC[b]*y_b + cD[b] (inside the image), dx1 = sum_b w_b^T * f_b,
- * dW_b[e][t] += sum_p f_b[p] * x1[p+t]   (dwgrad = [E][40]: 25 + 9 + 3 + 3 taps).             */
+ * dW_b[e][t] += sum_p f_b[p] * x1[p+t]  into the four torch-layout weight gradients.          */
 int lmn_dw_bwd(const float* x1, const float* dpre, float* dx1, int B, int H, int W, int E, const float* w5,
                const float* w3, const float* wv, const float* wh, const float* cA, const float* cC,
-               const float* cD, float* dwgrad, lmn_stream_t stream);
+               const float* cD, float* dw5, float* dw3, float* dwv, float* dwh, lmn_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * SE gate (core/modules.py:1020-1036): s = hardsigmoid(W2 relu(W1 m + b1) + b2), m = gsum/HW.
@@ -231,10 +237,13 @@ int lmn_bnact_bwd(const float* z, const float* dy, const float* mean, const floa
 int lmn_bn_finalize(const float* sums, float count, const float* gamma, const float* beta, float eps,
                     float momentum, float* mean, float* rstd, float* A, float* shift, float* running_mean,
                     float* running_var, int C, lmn_stream_t stream);
+/* eval-mode BatchNorm (running statistics): mean, rstd, A = gamma*rstd, shift = beta - mean*A */
+int lmn_bn_fold(const float* running_mean, const float* running_var, const float* gamma, const float* beta, float eps,
+                float* mean, float* rstd, float* A, float* shift, int C, lmn_stream_t stream);
 /* BN backward coefficients from bstats = [2][C] (S0 = sum dh, S1 = sum dh*zhat):
- * dgamma += S1, dbeta += S0, c1 = A, c2 = A*S0/N, c3 = A*S1/N                                   */
-int lmn_bn_bwd_coef(const float* bstats, float count, const float* A, float* dgamma, float* dbeta, float* c1,
-                    float* c2, float* c3, int C, lmn_stream_t stream);
+ * dgamma += S1, dbeta += S0, c1 = A, c2 = A*S0/N, c3 = A*S1/N  (batch_stats=0: c2 = c3 = 0)    */
+int lmn_bn_bwd_coef(const float* bstats, float count, int batch_stats, const float* A, float* dgamma, float* dbeta,
+                    float* c1, float* c2, float* c3, int C, lmn_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Resampling rows: bilinear x2 upsample with align_corners=True (core/LM_Net.py:59-72,

@@ -1,0 +1,276 @@
+"""``LM_Net`` -- drop-in replacement of the reference's ``core.LM_Net.LM_Net`` (core/LM_Net.py:5-123).
+
+Same constructor, ``forward(x) -> logits`` and ``structural_reparam()``; same ``state_dict`` keys and
+shapes (766 keys in train form, 510 after deploy), so ``train.py`` runs unchanged with
+``from lm_net_amd import LM_Net`` in place of ``from core.LM_Net import LM_Net``.  The arithmetic runs
+exclusively on the hand-written HIP kernels of ``liblmnet_hip.so``; a CPU tensor or a missing library
+raises -- there is no eager/PyTorch fallback path.
+"""
+import torch
+import torch.nn as nn
+
+from . import hip
+from .engine import Ctx, Engine, GradSlot
+from .hip import V
+from .modules import (GFT, NUM_HEADS, M2Skip, M3Skip, NeighborhoodTransformer, PyramidPool, ReparamConv, _conv, stage)
+
+# backward-completion order of the top-level blocks: the flat gradient buffer is laid out in this
+# order so that a data-parallel bucket (a contiguous slice) is complete as early as possible.
+BACKWARD_ORDER = ["output_layer", "dconv4", "up4", "dconv3", "up3", "dconv2", "up2", "dconv1", "up1",
+                  "natt4", "natt3", "natt2", "natt1", "skip4", "skip3", "skip2", "skip1", "gft",
+                  "down4", "conv4", "down3", "conv3", "down2", "conv2", "down1", "conv1"]
+
+
+class _LMNetFunction(torch.autograd.Function):
+    """The whole network as one autograd node (explicit forward/backward kernel schedules)."""
+
+    @staticmethod
+    def forward(ctx, x, model, *params):
+        cx = Ctx() if model._save_tape else None
+        out = model._forward_impl(x, cx)
+        ctx.model, ctx.cx, ctx.x_req = model, cx, x.requires_grad
+        return out
+
+    @staticmethod
+    def backward(ctx, dlogits):
+        model = ctx.model
+        dx, grads = model._backward_impl(ctx.cx, dlogits.contiguous(), ctx.x_req)
+        ctx.cx = None
+        return (dx, None) + tuple(grads)
+
+
+class LM_Net(nn.Module):
+    def __init__(self, channel, n_classes=2, filters=[12, 24, 48, 96, 192], deep_supervision=False):
+        super().__init__()
+        f = list(filters)
+        assert all(c % NUM_HEADS == 0 for c in f[:4]) and sum(f) % NUM_HEADS == 0, \
+            "filters[0..3] and sum(filters) must be multiples of 12 (12 attention heads)"
+        self.deep_supervision = deep_supervision      # stored, never read (as in the reference)
+        self.filters = f
+        self.channel, self.n_classes = channel, n_classes
+        self.conv1 = stage(channel, f[1], f[0]); self.down1 = nn.Sequential(_conv(f[0], f[1], 3, 2))
+        self.conv2 = stage(f[1], f[2], f[1]);    self.down2 = nn.Sequential(_conv(f[1], f[2], 3, 2))
+        self.conv3 = stage(f[2], f[3], f[2]);    self.down3 = nn.Sequential(_conv(f[2], f[3], 3, 2))
+        self.conv4 = stage(f[3], f[4], f[3]);    self.down4 = nn.Sequential(_conv(f[3], f[4], 3, 2))
+        self.dconv1 = stage(f[3], f[4], f[3])
+        self.dconv2 = stage(f[2], f[3], f[2])
+        self.dconv3 = stage(f[1], f[2], f[1])
+        self.dconv4 = stage(f[0], f[1], f[0])
+        self.pyramidpool = PyramidPool()
+        self.gft = GFT(sum(f), 2, f[4], NUM_HEADS)
+        up = lambda ci, co: nn.Sequential(nn.Upsample(scale_factor=2, mode="bilinear", align_corners=True), _conv(ci, co, 3))
+        self.up1, self.up2, self.up3, self.up4 = up(f[4], f[3]), up(f[3], f[2]), up(f[2], f[1]), up(f[1], f[0])
+        self.skip1 = M2Skip([f[2], f[3]], "bottom")
+        self.skip2 = M3Skip([f[1], f[2], f[3]])
+        self.skip3 = M3Skip([f[0], f[1], f[2]])
+        self.skip4 = M2Skip([f[0], f[1]], "top")
+        self.natt1 = NeighborhoodTransformer(f[3], NUM_HEADS)
+        self.natt2 = NeighborhoodTransformer(f[2], NUM_HEADS)
+        self.natt3 = NeighborhoodTransformer(f[1], NUM_HEADS)
+        self.natt4 = NeighborhoodTransformer(f[0], NUM_HEADS)
+        self.output_layer = nn.Conv2d(f[0], n_classes, 1)
+        self._engine = Engine(self)
+        self._grad_flat = None
+        self._grad_layout = None
+        self._save_tape = False
+        self._keep_taps = False
+        self._taps = None
+        self.grad_ready_hook = None      # ddp.py: called as hook(lo, hi) when flat-grad slice [lo,hi) is enqueued
+
+    # ------------------------------------------------------------------ public API of the reference
+    def structural_reparam(self):
+        for m in list(self.modules()):
+            if hasattr(m, "switch_to_deploy"):
+                m.switch_to_deploy()
+        self._grad_layout = None
+
+    def forward(self, x):
+        if not x.is_cuda:
+            raise RuntimeError("lm_net_amd.LM_Net runs on the HIP device only (input is on %s); there is no CPU path. "
+                               "Move the model and the batch to 'cuda'." % x.device)
+        if x.dim() != 4 or x.shape[1] != self.channel:
+            raise ValueError("expected input [B,%d,H,W], got %s" % (self.channel, tuple(x.shape)))
+        if x.shape[2] % 16 or x.shape[3] % 16 or x.shape[2] < 32 or x.shape[3] < 32:
+            raise ValueError("H and W must be multiples of 16 and >= 32 (got %dx%d)" % (x.shape[2], x.shape[3]))
+        hip.load()
+        params = [p for p in self.parameters()]
+        if params and not params[0].is_cuda:
+            raise RuntimeError("lm_net_amd.LM_Net: parameters are on %s; call model.to('cuda')" % params[0].device)
+        x = x.float().contiguous() if x.dtype != torch.float32 or not x.is_contiguous() else x
+        self._save_tape = torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in params))
+        return _LMNetFunction.apply(x, self, *params)
+
+    # ------------------------------------------------------------------ forward schedule (core/LM_Net.py:95-123)
+    def _forward_impl(self, x, cx):
+        eng = self._engine
+        eng.training = self.training
+        if self.training:
+            eng.step += 1
+            self._bump_num_batches_tracked()
+        B, Cin, H, W = x.shape
+        c4 = (Cin + 3) // 4 * 4
+        xin = torch.empty(B, H, W, c4, device=x.device, dtype=torch.float32)
+        hip.nchw_to_nhwc(x, xin)
+        f = self.filters
+        x1 = eng.stage_fwd(self.conv1, xin, cx)
+        xd1 = torch.empty(B, H // 2, W // 2, f[1], device=x.device); eng.conv3_fwd(self.down1[0], x1, xd1, s=2)
+        x2 = eng.stage_fwd(self.conv2, xd1, cx)
+        xd2 = torch.empty(B, H // 4, W // 4, f[2], device=x.device); eng.conv3_fwd(self.down2[0], x2, xd2, s=2)
+        x3 = eng.stage_fwd(self.conv3, xd2, cx)
+        xd3 = torch.empty(B, H // 8, W // 8, f[3], device=x.device); eng.conv3_fwd(self.down3[0], x3, xd3, s=2)
+        x4 = eng.stage_fwd(self.conv4, xd3, cx)
+        # PyramidPool: mean-pool x1..x4 onto the 1/16 grid, down4 writes x_down4 straight into its slice
+        h, w = H // 16, W // 16
+        catp = torch.empty(B, h, w, sum(f), device=x.device)
+        off = 0
+        for t, fac in ((x1, 16), (x2, 8), (x3, 4), (x4, 2)):
+            hip.avgpool_fwd(t, V(catp, off, t.shape[-1]), fac)
+            off += t.shape[-1]
+        eng.conv3_fwd(self.down4[0], x4, V(catp, off, f[4]), s=2)
+        x5 = eng.gft_fwd(self.gft, catp, cx, tag=0)
+        xs1 = eng.skip_fwd(self.skip1, (x3, x4), cx)
+        xs2 = eng.skip_fwd(self.skip2, (x2, x3, x4), cx)
+        xs3 = eng.skip_fwd(self.skip3, (x1, x2, x3), cx)
+        xs4 = eng.skip_fwd(self.skip4, (x1, x2), cx)
+        x46 = eng.nat_fwd(self.natt1, xs1, cx, tag=2)
+        x37 = eng.nat_fwd(self.natt2, xs2, cx, tag=4)
+        x28 = eng.nat_fwd(self.natt3, xs3, cx, tag=6)
+        x19 = eng.nat_fwd(self.natt4, xs4, cx, tag=8)
+        x6 = eng.stage_fwd(self.dconv1, eng.up_fwd(self.up1, x5, x46, cx), cx)
+        x7 = eng.stage_fwd(self.dconv2, eng.up_fwd(self.up2, x6, x37, cx), cx)
+        x8 = eng.stage_fwd(self.dconv3, eng.up_fwd(self.up3, x7, x28, cx), cx)
+        x9 = eng.stage_fwd(self.dconv4, eng.up_fwd(self.up4, x8, x19, cx), cx)
+        # segmentation head: rows padded to a multiple of 4, then NHWC -> NCHW
+        ncp = (self.n_classes + 3) // 4 * 4
+        wh, bh = self._head_padded(ncp)
+        o4 = torch.empty(B, H, W, ncp, device=x.device)
+        eng.conv([x9], wh, bh, o4, Hin=H, Win=W)
+        logits = torch.empty(B, self.n_classes, H, W, device=x.device)
+        hip.nhwc_to_nchw(o4, logits)
+        if cx is not None:
+            cx.t["act"] = dict(xin=xin, x1=x1, x2=x2, x3=x3, x4=x4, xd1=xd1, xd2=xd2, xd3=xd3, catp=catp, x5=x5, x6=x6,
+                               x7=x7, x8=x8, x9=x9, wh=wh, shape=(B, H, W))
+        self._taps = dict(x1=x1, x2=x2, x3=x3, x4=x4, x5=x5, xs1=xs1, xs2=xs2, xs3=xs3, xs4=xs4, x46=x46, x37=x37,
+                          x28=x28, x19=x19, x6=x6, x7=x7, x8=x8, x9=x9) if self._keep_taps else None
+        return logits
+
+    def _head_padded(self, ncp):
+        w, b = self.output_layer.weight, self.output_layer.bias
+        wp = torch.zeros(ncp, w.shape[1], device=w.device)
+        bp = torch.zeros(ncp, device=w.device)
+        wp[:w.shape[0]].copy_(w.detach().view(w.shape[0], -1))
+        bp[:w.shape[0]].copy_(b.detach())
+        return wp, bp
+
+    def _bump_num_batches_tracked(self):
+        for m in self.modules():
+            if isinstance(m, nn.BatchNorm2d) and m.num_batches_tracked is not None:
+                m.num_batches_tracked += 1
+
+    # ------------------------------------------------------------------ flat gradient buffer
+    def _ensure_grad_layout(self):
+        params = list(self.parameters())
+        key = tuple(id(p) for p in params)
+        if self._grad_layout is not None and self._grad_layout["key"] == key and \
+                self._grad_layout["device"] == params[0].device:
+            return self._grad_layout
+        order, seen = [], set()
+        for name in BACKWARD_ORDER:
+            for p in getattr(self, name).parameters():
+                if id(p) not in seen:
+                    seen.add(id(p)); order.append(p)
+        for p in params:
+            if id(p) not in seen:
+                seen.add(id(p)); order.append(p)
+        offs, pos = {}, 0
+        for p in order:
+            offs[id(p)] = (pos, pos + p.numel())
+            pos += (p.numel() + 3) // 4 * 4            # keep every view 16-byte aligned
+        blocks, lo = {}, 0
+        for name in BACKWARD_ORDER:
+            ps = list(getattr(self, name).parameters())
+            hi = max([offs[id(p)][0] + (p.numel() + 3) // 4 * 4 for p in ps], default=lo)
+            blocks[name] = (lo, hi)
+            lo = hi
+        self._grad_layout = dict(key=key, device=params[0].device, order=order, offs=offs, total=pos, blocks=blocks)
+        return self._grad_layout
+
+    def _new_grads(self):
+        L = self._ensure_grad_layout()
+        flat = torch.zeros(L["total"], device=L["device"], dtype=torch.float32)
+        G = {}
+        for p in L["order"]:
+            a, b = L["offs"][id(p)]
+            G[p] = flat[a:b].view(p.shape)
+        return flat, G
+
+    def _done(self, name):
+        if self.grad_ready_hook is not None:
+            self.grad_ready_hook(*self._grad_layout["blocks"][name])
+
+    # ------------------------------------------------------------------ backward schedule
+    def _backward_impl(self, cx, dlogits, need_dx):
+        if cx is None:
+            raise RuntimeError("backward called on a forward pass that saved no state")
+        eng = self._engine
+        flat, G = self._new_grads()
+        self._grad_flat = flat
+        eng.G = G
+        A = cx.t["act"]
+        B, H, W = A["shape"]
+        f = self.filters
+        dev = dlogits.device
+        # head
+        ncp = A["wh"].shape[0]
+        dy4 = torch.empty(B, H, W, ncp, device=dev)
+        hip.nchw_to_nhwc(dlogits, dy4)
+        dWh, dbh = torch.zeros_like(A["wh"]), torch.zeros(ncp, device=dev)
+        eng.wgrad([A["x9"]], dy4, None, None, Hin=H, Win=W, dW=dWh, db=dbh)
+        G[self.output_layer.weight].copy_(dWh[:self.n_classes].view_as(self.output_layer.weight))
+        G[self.output_layer.bias].copy_(dbh[:self.n_classes])
+        dx9 = torch.empty_like(A["x9"])
+        eng.conv_T(dy4, A["wh"], dx9, Hin=H, Win=W)
+        self._done("output_layer")
+        # decoder
+        dt4 = eng.stage_bwd(self.dconv4, dx9, cx); self._done("dconv4")
+        dx8 = eng.up_bwd(self.up4, dt4, cx, A["x8"].shape); self._done("up4")
+        dt3 = eng.stage_bwd(self.dconv3, dx8, cx); self._done("dconv3")
+        dx7 = eng.up_bwd(self.up3, dt3, cx, A["x7"].shape); self._done("up3")
+        dt2 = eng.stage_bwd(self.dconv2, dx7, cx); self._done("dconv2")
+        dx6 = eng.up_bwd(self.up2, dt2, cx, A["x6"].shape); self._done("up2")
+        dt1 = eng.stage_bwd(self.dconv1, dx6, cx); self._done("dconv1")
+        dx5 = eng.up_bwd(self.up1, dt1, cx, A["x5"].shape); self._done("up1")
+        # neighborhood-attention blocks (their outputs were the residual inputs of up1..4: gradient = dt_k)
+        dxs4 = eng.nat_bwd(self.natt4, dt4, cx); self._done("natt4")
+        dxs3 = eng.nat_bwd(self.natt3, dt3, cx); self._done("natt3")
+        dxs2 = eng.nat_bwd(self.natt2, dt2, cx); self._done("natt2")
+        dxs1 = eng.nat_bwd(self.natt1, dt1, cx); self._done("natt1")
+        # skip fusers: accumulate into the encoder activations' gradients
+        gacc = {id(A[k]): GradSlot() for k in ("x1", "x2", "x3", "x4")}
+        eng.skip_bwd(self.skip4, dxs4, cx, gacc); self._done("skip4")
+        eng.skip_bwd(self.skip3, dxs3, cx, gacc); self._done("skip3")
+        eng.skip_bwd(self.skip2, dxs2, cx, gacc); self._done("skip2")
+        eng.skip_bwd(self.skip1, dxs1, cx, gacc); self._done("skip1")
+        # bottleneck
+        dcat = eng.gft_bwd(self.gft, dx5, cx); self._done("gft")
+        off = 0
+        for k, fac in (("x1", 16), ("x2", 8), ("x3", 4), ("x4", 2)):
+            t = A[k]
+            hip.avgpool_bwd(V(dcat, off, t.shape[-1]), gacc[id(t)].g, fac, True)
+            off += t.shape[-1]
+        g1, g2, g3, g4 = (gacc[id(A[k])].g for k in ("x1", "x2", "x3", "x4"))
+        # encoder (reverse)
+        eng.conv3_bwd(self.down4[0], A["x4"], V(dcat, off, f[4]), s=2, dx=g4, accumulate=True); self._done("down4")
+        dxd3 = eng.stage_bwd(self.conv4, g4, cx); self._done("conv4")
+        eng.conv3_bwd(self.down3[0], A["x3"], dxd3, s=2, dx=g3, accumulate=True); self._done("down3")
+        dxd2 = eng.stage_bwd(self.conv3, g3, cx); self._done("conv3")
+        eng.conv3_bwd(self.down2[0], A["x2"], dxd2, s=2, dx=g2, accumulate=True); self._done("down2")
+        dxd1 = eng.stage_bwd(self.conv2, g2, cx); self._done("conv2")
+        eng.conv3_bwd(self.down1[0], A["x1"], dxd1, s=2, dx=g1, accumulate=True); self._done("down1")
+        dxin = eng.stage_bwd(self.conv1, g1, cx, need_dx=need_dx); self._done("conv1")
+        dx = None
+        if need_dx:
+            dx = torch.empty(B, self.channel, H, W, device=dev)
+            hip.nhwc_to_nchw(dxin, dx)
+        eng.G = None
+        return dx, [G[p] for p in self.parameters()]

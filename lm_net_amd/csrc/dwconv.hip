@@ -158,7 +158,7 @@ __device__ __forceinline__ void branches_at(const float* lds, int r, int c, int 
     }
 }
 
-// MODE 0: forward batch statistics   stats[8][E] += (sum y_b, sum y_b^2)
+// MODE 0: forward batch statistics   stats[4][2][E] += (sum y_b, sum y_b^2)
 // MODE 1: backward pass 1            dpre = (u*s + dm)*gelu'(pre) -> store; stats[5][E] += (sum dpre, sum dpre*y_b)
 template <int MODE>
 __global__ __launch_bounds__(256) void dw_stats_kernel(const float* __restrict__ x1, const float* __restrict__ pre,
@@ -222,7 +222,11 @@ __global__ __launch_bounds__(256) void dw_stats_kernel(const float* __restrict__
     atomicAdd(&red[k * DC + cp * 2 + 1], sum[k][1]);
   }
   __syncthreads();
-  for (int i = tid; i < NS * DC; i += 256) atomicAdd(stats + (int64_t)(i / DC) * E + ch0 + (i % DC), red[i]);
+  for (int i = tid; i < NS * DC; i += 256) {
+    const int k = i / DC;
+    const int row = MODE == 0 ? ((k & 3) * 2 + (k >> 2)) : k;  // MODE 0: [branch][sum|sumsq][E]
+    atomicAdd(stats + (int64_t)row * E + ch0 + (i % DC), red[i]);
+  }
 }
 
 // backward pass 2:  f_b = cA_b*dpre + cC_b*y_b + cD_b inside the image (0 outside);
@@ -284,8 +288,9 @@ __global__ __launch_bounds__(256) void dw_bwd_kernel(const float* __restrict__ x
                                                      const float* __restrict__ w5, const float* __restrict__ w3,
                                                      const float* __restrict__ wv, const float* __restrict__ wh,
                                                      const float* __restrict__ cA, const float* __restrict__ cC,
-                                                     const float* __restrict__ cD, float* __restrict__ dwgrad,
-                                                     int tiles_x, int tiles_y) {
+                                                     const float* __restrict__ cD, float* __restrict__ dw5,
+                                                     float* __restrict__ dw3, float* __restrict__ dwv,
+                                                     float* __restrict__ dwh, int tiles_x, int tiles_y) {
   constexpr int R4 = DT + 8, R2 = DT + 4;
   __shared__ __attribute__((aligned(16))) float X[R4 * R4 * DC];   // x1, halo 4
   __shared__ __attribute__((aligned(16))) float DP[R2 * R2 * DC];  // dpre, halo 2
@@ -354,9 +359,36 @@ __global__ __launch_bounds__(256) void dw_bwd_kernel(const float* __restrict__ x
   }
   __syncthreads();
   for (int i = tid; i < 40 * DC; i += 256) {
-    const int t = i / DC, cc = i - t * DC;
-    atomicAdd(dwgrad + (int64_t)(ch0 + cc) * 40 + t, red[i]);
+    const int t = i / DC, e = ch0 + (i - t * DC);
+    if (t < 25) atomicAdd(dw5 + (int64_t)e * 25 + t, red[i]);
+    else if (t < 34) atomicAdd(dw3 + (int64_t)e * 9 + t - 25, red[i]);
+    else if (t < 37) atomicAdd(dwv + (int64_t)e * 3 + t - 34, red[i]);
+    else atomicAdd(dwh + (int64_t)e * 3 + t - 37, red[i]);
   }
+}
+
+// per-branch BN-backward coefficients from bst[5][E] = (S0 = sum dpre, S1_b = sum dpre*y_b)
+__global__ void dw_bwd_coef_kernel(const float* __restrict__ bst, const float* __restrict__ mean,
+                                   const float* __restrict__ rstd, const float* __restrict__ A, float count,
+                                   int batch_stats, float* __restrict__ cA, float* __restrict__ cC,
+                                   float* __restrict__ cD, float* dg0, float* dg1, float* dg2, float* dg3, float* db0,
+                                   float* db1, float* db2, float* db3, int E) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= 4 * E) return;
+  const int b = i / E, e = i - b * E;
+  float* dgs[4] = {dg0, dg1, dg2, dg3};
+  float* dbs[4] = {db0, db1, db2, db3};
+  const float S0 = bst[e], S1 = bst[(1 + b) * E + e];
+  const float T = (S1 - mean[i] * S0) * rstd[i];  // sum dpre * yhat_b
+  float* dg = b == 0 ? dgs[0] : (b == 1 ? dgs[1] : (b == 2 ? dgs[2] : dgs[3]));
+  float* db = b == 0 ? dbs[0] : (b == 1 ? dbs[1] : (b == 2 ? dbs[2] : dbs[3]));
+  dg[e] += T;
+  db[e] += S0;
+  const float a = A[i];
+  const float c = batch_stats ? -a * T * rstd[i] / count : 0.f;
+  cA[i] = a;
+  cC[i] = c;
+  cD[i] = batch_stats ? (-a * S0 / count - c * mean[i]) : 0.f;
 }
 
 }  // namespace
@@ -409,14 +441,24 @@ int lmn_dw_bwd_stats(const float* x1, const float* pre, const float* u, const fl
   return lmn_launch_status("dw_bwd_stats");
 }
 
+int lmn_dw_bwd_coef(const float* bstats, const float* mean, const float* rstd, const float* A, float count,
+                    int batch_stats, float* cA, float* cC, float* cD, float* dg0, float* dg1, float* dg2, float* dg3,
+                    float* db0, float* db1, float* db2, float* db3, int E, lmn_stream_t stream) {
+  LMN_REQUIRE(bstats && mean && rstd && A && cA && cC && cD && dg0 && dg1 && dg2 && dg3 && db0 && db1 && db2 && db3 && E > 0 && count > 0.f,
+              "dw_bwd_coef: bad argument");
+  hipLaunchKernelGGL(dw_bwd_coef_kernel, dim3(lmn_cdiv(4 * E, 256)), dim3(256), 0, (hipStream_t)stream, bstats, mean, rstd,
+                     A, count, batch_stats, cA, cC, cD, dg0, dg1, dg2, dg3, db0, db1, db2, db3, E);
+  return lmn_launch_status("dw_bwd_coef");
+}
+
 int lmn_dw_bwd(const float* x1, const float* dpre, float* dx1, int B, int H, int W, int E, const float* w5,
                const float* w3, const float* wv, const float* wh, const float* cA, const float* cC, const float* cD,
-               float* dwgrad, lmn_stream_t stream) {
-  LMN_REQUIRE(x1 && dpre && dx1 && w5 && w3 && wv && wh && cA && cC && cD && dwgrad, "dw_bwd: null pointer");
+               float* dw5, float* dw3, float* dwv, float* dwh, lmn_stream_t stream) {
+  LMN_REQUIRE(x1 && dpre && dx1 && w5 && w3 && wv && wh && cA && cC && cD && dw5 && dw3 && dwv && dwh, "dw_bwd: null pointer");
   LMN_REQUIRE(B > 0 && H > 0 && W > 0 && E > 0 && E % DC == 0, "dw_bwd: E=%d must be a multiple of %d", E, DC);
   const int tx = lmn_cdiv(W, DT), ty = lmn_cdiv(H, DT);
   hipLaunchKernelGGL(dw_bwd_kernel, dim3(dw_grid_x(B, tx, ty, E / DC), E / DC), dim3(256), 0, (hipStream_t)stream, x1,
-                     dpre, dx1, B, H, W, E, w5, w3, wv, wh, cA, cC, cD, dwgrad, tx, ty);
+                     dpre, dx1, B, H, W, E, w5, w3, wv, wh, cA, cC, cD, dw5, dw3, dwv, dwh, tx, ty);
   return lmn_launch_status("dw_bwd");
 }
 

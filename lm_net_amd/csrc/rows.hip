@@ -217,16 +217,29 @@ __global__ void bn_finalize_kernel(const float* __restrict__ sums, float count, 
   if (rvar) rvar[c] = (1.f - momentum) * rvar[c] + momentum * var * (count > 1.f ? count / (count - 1.f) : 1.f);
 }
 
-__global__ void bn_bwd_coef_kernel(const float* __restrict__ bstats, float count, const float* __restrict__ A,
-                                   float* dgamma, float* dbeta, float* c1, float* c2, float* c3, int C) {
+__global__ void bn_fold_kernel(const float* __restrict__ rmean, const float* __restrict__ rvar,
+                               const float* __restrict__ gamma, const float* __restrict__ beta, float eps, float* mean,
+                               float* rstd, float* A, float* shift, int C) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const float rs = rsqrtf(rvar[c] + eps), a = gamma[c] * rs;
+  if (mean) mean[c] = rmean[c];
+  if (rstd) rstd[c] = rs;
+  if (A) A[c] = a;
+  if (shift) shift[c] = beta[c] - rmean[c] * a;
+}
+
+__global__ void bn_bwd_coef_kernel(const float* __restrict__ bstats, float count, int batch_stats,
+                                   const float* __restrict__ A, float* dgamma, float* dbeta, float* c1, float* c2,
+                                   float* c3, int C) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
   const float S0 = bstats[c], S1 = bstats[C + c], a = A[c];
   if (dgamma) dgamma[c] += S1;
   if (dbeta) dbeta[c] += S0;
   c1[c] = a;
-  c2[c] = a * S0 / count;
-  c3[c] = a * S1 / count;
+  c2[c] = batch_stats ? a * S0 / count : 0.f;
+  c3[c] = batch_stats ? a * S1 / count : 0.f;
 }
 
 // ------------------------------------------------------------------------------------ SE gate (one block per image)
@@ -558,11 +571,19 @@ int lmn_bn_finalize(const float* sums, float count, const float* gamma, const fl
   return lmn_launch_status("bn_finalize");
 }
 
-int lmn_bn_bwd_coef(const float* bstats, float count, const float* A, float* dgamma, float* dbeta, float* c1, float* c2,
-                    float* c3, int C, lmn_stream_t stream) {
+int lmn_bn_fold(const float* running_mean, const float* running_var, const float* gamma, const float* beta, float eps,
+                float* mean, float* rstd, float* A, float* shift, int C, lmn_stream_t stream) {
+  LMN_REQUIRE(running_mean && running_var && gamma && beta && C > 0, "bn_fold: bad argument");
+  hipLaunchKernelGGL(bn_fold_kernel, dim3(lmn_cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream, running_mean,
+                     running_var, gamma, beta, eps, mean, rstd, A, shift, C);
+  return lmn_launch_status("bn_fold");
+}
+
+int lmn_bn_bwd_coef(const float* bstats, float count, int batch_stats, const float* A, float* dgamma, float* dbeta,
+                    float* c1, float* c2, float* c3, int C, lmn_stream_t stream) {
   LMN_REQUIRE(bstats && A && c1 && c2 && c3 && C > 0 && count > 0.f, "bn_bwd_coef: bad argument");
-  hipLaunchKernelGGL(bn_bwd_coef_kernel, dim3(lmn_cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream, bstats, count, A,
-                     dgamma, dbeta, c1, c2, c3, C);
+  hipLaunchKernelGGL(bn_bwd_coef_kernel, dim3(lmn_cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream, bstats, count,
+                     batch_stats, A, dgamma, dbeta, c1, c2, c3, C);
   return lmn_launch_status("bn_bwd_coef");
 }
 

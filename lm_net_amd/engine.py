@@ -1,0 +1,522 @@
+"""Forward/backward schedule of the LM-Net hot path on the HIP kernels (one process, one stream).
+
+The reference runs this graph as ~400 eager ATen/natten calls forward and ~800 backward
+(core/LM_Net.py:95-123).  Here the whole network is ONE autograd node whose
+forward and backward are explicit kernel schedules over NHWC fp32 activations:
+
+  * every row of SURVEY.md section 8a is a fused HIP kernel (or a short chain) reached through
+    ``hip.py`` -> ``liblmnet_hip.so``; torch only allocates buffers and provides the stream;
+  * torch.cat along channels never materialises: producers write into channel slices of one buffer;
+  * train-mode BatchNorm is two passes (statistics, then apply) with the cheap producer recomputed
+    rather than stored; running statistics are updated by the same finalize kernel;
+  * the backward pass writes every parameter gradient into one flat fp32 buffer laid out in
+    backward-completion order, so data-parallel gradient buckets are contiguous slices that can be
+    all-reduced on a side stream as soon as their last kernel has been enqueued (``ddp.py``).
+"""
+import torch
+
+from . import hip
+from .hip import V
+
+EPS_BN = 1e-5
+
+
+class Ctx:
+    """Saved tensors of one forward pass (the hand-written autograd tape)."""
+
+    def __init__(self):
+        self.t = {}
+
+
+def _E(ref, *shape):
+    return torch.empty(shape, device=ref.device, dtype=torch.float32)
+
+
+def _Z(ref, *shape):
+    return torch.zeros(shape, device=ref.device, dtype=torch.float32)
+
+
+class Engine:
+    def __init__(self, model):
+        self.m = model
+        self.G = None            # param -> gradient view (set per backward)
+        self.training = True
+        self.seed_base = 0x1234567
+        self.step = 0
+        self.bucket_hook = None  # called with a bucket tag as soon as its gradients are enqueued
+
+    # ------------------------------------------------------------------ small helpers
+    def _seed(self, tag):
+        return (self.seed_base + 0x9E3779B1 * (self.step * 64 + tag)) & 0xFFFFFFFF
+
+    @staticmethod
+    def _t(src):
+        v = src["view"] if isinstance(src, dict) else src
+        return v.t if isinstance(v, V) else v
+
+    @staticmethod
+    def _c(src):
+        v = src["view"] if isinstance(src, dict) else src
+        return v.C if isinstance(v, V) else v.shape[-1]
+
+    def conv(self, srcs, w, bias, out, *, Hin, Win, k=1, s=1, wp=None, **kw):
+        """Forward conv of `srcs` (list) with torch-layout weight w [Cout, Cin, k, k] (or [Cout, Cin])."""
+        B = self._t(srcs[0]).shape[0]
+        if wp is None:
+            wp = hip.conv_pack(w, k, [self._c(x) for x in srcs])
+        Hout = (Hin + 2 * (k // 2) - k) // s + 1
+        Wout = (Win + 2 * (k // 2) - k) // s + 1
+        hip.conv_fwd(srcs, wp, out, B=B, Hin=Hin, Win=Win, Hout=Hout, Wout=Wout, Cout=w.shape[0], ksize=k, stride=s,
+                     bias=bias, **kw)
+        return wp
+
+    def conv_T(self, dy, w, out, *, Hin, Win, k=1, s=1, row_off=0, rows=None, B=None, **kw):
+        """Data gradient of a forward conv with weight w whose INPUT was Hin x Win: out = dL/dx (rows slice)."""
+        rows = w.shape[1] - row_off if rows is None else rows
+        wpt = hip.conv_pack_t(w, k, row_off, rows)
+        Ho = (Hin + 2 * (k // 2) - k) // s + 1
+        Wo = (Win + 2 * (k // 2) - k) // s + 1
+        B = self._t(dy).shape[0] if B is None else B
+        hip.conv_fwd([dy], wpt, out, B=B, Hin=Ho, Win=Wo, Hout=Hin, Wout=Win, Cout=rows, ksize=k, stride=s,
+                     transposed=1, **kw)
+
+    def wgrad(self, srcs, dy, w_param, b_param, *, Hin, Win, k=1, s=1, dW=None, db=None, **kw):
+        d = dy.t if isinstance(dy, V) else dy
+        B = d.shape[0]
+        Ho = (Hin + 2 * (k // 2) - k) // s + 1
+        Wo = (Win + 2 * (k // 2) - k) // s + 1
+        dW = self.G[w_param] if dW is None else dW
+        db = (self.G[b_param] if b_param is not None else None) if db is None else db
+        hip.conv_wgrad(srcs, dy, dW, db, B=B, Hin=Hin, Win=Win, Hout=Ho, Wout=Wo, Cout=dW.shape[0], ksize=k, stride=s, **kw)
+
+    def bn_stats(self, bn, sums, count, ref):
+        """(mean, rstd, A, shift) of a BatchNorm from batch sums [2,C] (training) or running stats (eval)."""
+        C = bn.weight.numel()
+        mean, rstd, A, shift = (_E(ref, C) for _ in range(4))
+        if self.training:
+            hip.bn_finalize(sums, count, bn.weight, bn.bias, bn.eps, bn.momentum if bn.momentum is not None else 0.1,
+                            mean, rstd, A, shift, bn.running_mean, bn.running_var)
+        else:
+            hip.bn_fold(bn.running_mean, bn.running_var, bn.weight, bn.bias, bn.eps, mean, rstd, A, shift)
+        return mean, rstd, A, shift
+
+    # ------------------------------------------------------------------ ReparamConv  (rows A1, A2, A3)
+    def reparam_fwd(self, m, x, cx, out=None):
+        """x: NHWC tensor [B,H,W,Cin] (Cin possibly zero-padded to 4).  Returns y [B,H,W,Cout]."""
+        B, H, W, _ = x.shape
+        E, Cout, N = m.cexp, m.cout, B * H * W
+        ec, ebn = m.expand_conv[0], m.expand_conv[1]
+        we = self._w_expand(m, x)
+        wpe = hip.conv_pack(we, 1, [x.shape[-1]])
+        sums1 = None
+        if self.training:
+            sums1 = _Z(x, 2, E)
+            hip.conv_fwd([x], wpe, None, B=B, Hin=H, Win=W, Hout=H, Wout=W, Cout=E, bias=ec.bias, stats=sums1,
+                         stats_mode=hip.STATS_SUM_SQ)
+        mean1, rstd1, A1, sh1 = self.bn_stats(ebn, sums1, N, x)
+        x1 = _E(x, B, H, W, E)
+        hip.conv_fwd([x], wpe, x1, B=B, Hin=H, Win=W, Hout=H, Wout=W, Cout=E, bias=ec.bias, epilogue=hip.EP_AFFINE_ACT,
+                     act=hip.ACT_HSWISH, p=(A1, sh1))
+        # depthwise branches
+        if m.deploy:
+            keff, beff = m.fuse_conv.weight, m.fuse_conv.bias
+            bmean = brstd = bA = None
+        else:
+            brs = m.branches()
+            ws = [b.conv.weight for b in brs]
+            bmean, brstd, bA, bshift = (_E(x, 4, E) for _ in range(4))
+            st2 = None
+            if self.training:
+                st2 = _Z(x, 4, 2, E)
+                hip.dw_stats(x1, *ws, st2)
+            for i, b in enumerate(brs):
+                bn = b.bn
+                if self.training:
+                    hip.bn_finalize(st2[i], N, bn.weight, bn.bias, bn.eps, bn.momentum if bn.momentum is not None else 0.1,
+                                    bmean[i], brstd[i], bA[i], bshift[i], bn.running_mean, bn.running_var)
+                else:
+                    hip.bn_fold(bn.running_mean, bn.running_var, bn.weight, bn.bias, bn.eps, bmean[i], brstd[i], bA[i], bshift[i])
+            keff, beff = _E(x, E, 25), _E(x, E)
+            hip.dw_merge(*ws, bA, bshift, keff, beff)
+        pre = _E(x, B, H, W, E)
+        gsum = _Z(x, B, E)
+        hip.dw_fwd(x1, pre, gsum, keff, beff)
+        se = m.se
+        R = se.fc1.weight.shape[0]
+        sgate, hid = _E(x, B, E), _E(x, B, R)
+        hip.se_fwd(gsum, 1.0 / (H * W), se.fc1.weight, se.fc1.bias, se.fc2.weight, se.fc2.bias, sgate, hid)
+        # pointwise(g*s) + shortcut(x): one conv over two sources
+        wpw, wsc = m.pointwise_conv[0].weight, self._w_shortcut(m, x)
+        wp3 = self._pack2(wpw, wsc, E, x.shape[-1], Cout, x)
+        b3 = hip.add(m.pointwise_conv[0].bias, m.shortcut[0].bias, out=_E(x, Cout))
+        y = _E(x, B, H, W, Cout) if out is None else out
+        hip.conv_fwd([dict(view=pre, scale=sgate, flags=hip.SRC_GELU), x], wp3, y, B=B, Hin=H, Win=W, Hout=H, Wout=W,
+                     Cout=Cout, bias=b3)
+        if cx is not None:
+            cx.t[m] = dict(x=x, x1=x1, pre=pre, gsum=gsum, s=sgate, hid=hid, wpe=wpe, mean1=mean1, rstd1=rstd1, A1=A1,
+                           bmean=bmean, brstd=brstd, bA=bA)
+        return y
+
+    def _w_expand(self, m, x):
+        w = m.expand_conv[0].weight
+        return self._pad_cin(w, x.shape[-1])
+
+    def _w_shortcut(self, m, x):
+        return self._pad_cin(m.shortcut[0].weight, x.shape[-1])
+
+    @staticmethod
+    def _pad_cin(w, cin):
+        """The RGB input is carried as NHWC4 (channel 3 = 0): pad the weight's input axis with zeros
+        (a layout copy of a [Cout,3] weight; no arithmetic)."""
+        if w.shape[1] == cin:
+            return w
+        wp = torch.zeros(w.shape[0], cin, *w.shape[2:], device=w.device, dtype=w.dtype)
+        wp[:, :w.shape[1]].copy_(w.detach())
+        return wp
+
+    @staticmethod
+    def _pack2(w0, w1, c0, c1, cout, ref):
+        """1x1 conv over two sources with separate weights: pack each into its K-block range."""
+        n0 = hip.conv_pack_size(1, cout, [c0])
+        n1 = hip.conv_pack_size(1, cout, [c1])
+        wp = torch.empty(n0 + n1, device=ref.device, dtype=torch.float32)
+        hip.conv_pack(w0, 1, [c0], out=wp[:n0])
+        hip.conv_pack(w1, 1, [c1], out=wp[n0:])
+        return wp
+
+    def reparam_bwd(self, m, dy, cx, need_dx=True):
+        if m.deploy:
+            raise NotImplementedError("backward through a deployed (re-parameterised) ReparamConv is not supported; "
+                                      "deploy form is inference-only, as in the reference")
+        S = cx.t[m]
+        x, x1, pre, sgate = S["x"], S["x1"], S["pre"], S["s"]
+        B, H, W, Cin = x.shape
+        E, Cout, N = m.cexp, m.cout, B * H * W
+        G = self.G
+        pw, sc, ec, ebn, se = m.pointwise_conv[0], m.shortcut[0], m.expand_conv[0], m.expand_conv[1], m.se
+        # ---- A3 backward
+        self.wgrad([dict(view=pre, scale=sgate, flags=hip.SRC_GELU)], dy, pw.weight, pw.bias, Hin=H, Win=W)
+        wsc = self._w_shortcut(m, x)
+        if wsc is sc.weight:
+            self.wgrad([x], dy, sc.weight, sc.bias, Hin=H, Win=W)
+        else:  # padded RGB input: gradient of the padded weight, keep the real columns
+            dWp = torch.zeros_like(wsc)
+            self.wgrad([x], dy, None, None, Hin=H, Win=W, dW=dWp, db=G[sc.bias])
+            G[sc.weight].copy_(dWp[:, :sc.weight.shape[1]])      # un-pad (layout copy)
+        u = _E(x, B, H, W, E)
+        ds = _Z(x, B, E)
+        self.conv_T(dy, pw.weight, u, Hin=H, Win=W, epilogue=hip.EP_SE_BWD, aux=pre, stats=ds, stats_mode=hip.STATS_EP)
+        dx_sc = None
+        if need_dx:
+            dx_sc = _E(x, B, H, W, Cin)
+            self.conv_T(dy, wsc, dx_sc, Hin=H, Win=W)
+        # ---- SE backward
+        dm = _E(x, B, E)
+        hip.se_bwd(ds, S["gsum"], 1.0 / (H * W), se.fc1.weight, se.fc1.bias, se.fc2.weight, se.fc2.bias, S["hid"], dm,
+                   G[se.fc1.weight], G[se.fc1.bias], G[se.fc2.weight], G[se.fc2.bias])
+        # ---- A2 backward
+        brs = m.branches()
+        ws = [b.conv.weight for b in brs]
+        dpre = _E(x, B, H, W, E)
+        bst = _Z(x, 5, E)
+        hip.dw_bwd_stats(x1, pre, u, sgate, dm, dpre, *ws, bst)
+        cA, cC, cD = (_E(x, 4, E) for _ in range(3))
+        hip.dw_bwd_coef(bst, S["bmean"], S["brstd"], S["bA"], N, self.training, cA, cC, cD,
+                        [G[b.bn.weight] for b in brs], [G[b.bn.bias] for b in brs])
+        dx1 = u  # reuse
+        hip.dw_bwd(x1, dpre, dx1, *ws, cA, cC, cD, *[G[w] for w in ws])
+        # ---- A1 backward: Hardswish' and BatchNorm backward fused into the recomputed 1x1 conv
+        wpe = S["wpe"]
+        dh = dpre  # reuse
+        st = _Z(x, 2, E)
+        hip.conv_fwd([x], wpe, dh, B=B, Hin=H, Win=W, Hout=H, Wout=W, Cout=E, bias=ec.bias, epilogue=hip.EP_BN_BWD1,
+                     act=hip.ACT_HSWISH, p=(S["mean1"], S["rstd1"], ebn.weight, ebn.bias), aux=dx1, stats=st,
+                     stats_mode=hip.STATS_EP)
+        c1, c2, c3 = (_E(x, E) for _ in range(3))
+        hip.bn_bwd_coef(st, N, S["A1"], G[ebn.weight], G[ebn.bias], c1, c2, c3, self.training)
+        dz = dh
+        hip.conv_fwd([x], wpe, dz, B=B, Hin=H, Win=W, Hout=H, Wout=W, Cout=E, bias=ec.bias, epilogue=hip.EP_BN_BWD2,
+                     p=(S["mean1"], S["rstd1"], c1, c2, c3), aux=dh)
+        we = self._w_expand(m, x)
+        if we is ec.weight:
+            self.wgrad([x], dz, ec.weight, ec.bias, Hin=H, Win=W)
+        else:
+            dWp = torch.zeros_like(we)
+            self.wgrad([x], dz, None, None, Hin=H, Win=W, dW=dWp, db=G[ec.bias])
+            G[ec.weight].copy_(dWp[:, :ec.weight.shape[1]])      # un-pad (layout copy)
+        if not need_dx:
+            return None
+        dx = _E(x, B, H, W, Cin)
+        self.conv_T(dz, we, dx, Hin=H, Win=W, residual=dx_sc)
+        return dx
+
+    def stage_fwd(self, seq, x, cx):
+        return self.reparam_fwd(seq[1], self.reparam_fwd(seq[0], x, cx), cx)
+
+    def stage_bwd(self, seq, dy, cx, need_dx=True):
+        return self.reparam_bwd(seq[0], self.reparam_bwd(seq[1], dy, cx), cx, need_dx)
+
+    # ------------------------------------------------------------------ plain 3x3 conv rows (A4, parts of A9/A10)
+    def conv3_fwd(self, conv, x, out, s=1, **kw):
+        x_t = x.t if isinstance(x, V) else x
+        H, W = x_t.shape[1:3]
+        self.conv([x], conv.weight, conv.bias, out, Hin=H, Win=W, k=3, s=s, **kw)
+
+    def conv3_bwd(self, conv, x, dy, s=1, dx=None, accumulate=False):
+        """weight/bias grads; if dx is given: dx (+)= data gradient."""
+        x_t = x.t if isinstance(x, V) else x
+        H, W = x_t.shape[1:3]
+        self.wgrad([x], dy, conv.weight, conv.bias, Hin=H, Win=W, k=3, s=s)
+        if dx is not None:
+            self.conv_T(dy, conv.weight, dx, Hin=H, Win=W, k=3, s=s, residual=dx if accumulate else None)
+
+    # ------------------------------------------------------------------ skip fusers (A9)
+    def skip_fwd(self, m, xs_in, cx):
+        """M3Skip(xl, xm, xs) / M2Skip(xl, xs).  All convs write straight into slices of the cat buffer."""
+        three = len(xs_in) == 3
+        bottom = (not three) and m.model_type == "bottom"
+        fconv, fbn = m.fuse_conv[0], m.fuse_conv[1]
+        C = fbn.weight.numel()
+        if three:
+            xl, xm, xsm = xs_in
+            B, H, W, _ = xm.shape
+        elif bottom:
+            xl, xsm = xs_in
+            B, H, W, _ = xsm.shape
+        else:
+            xl, xsm = xs_in
+            B, H, W, _ = xl.shape
+        nb = 3 if three else 2
+        cat = _E(xl, B, H, W, nb * C)
+        up = None
+        self.conv3_fwd(m.convl[0], xl, V(cat, 0, C), s=2 if (three or bottom) else 1)
+        if three:
+            self.conv3_fwd(m.convm[0], xm, V(cat, C, C))
+        if bottom:
+            self.conv3_fwd(m.convs[0], xsm, V(cat, C, C))
+        else:
+            up = _E(xl, B, H, W, xsm.shape[-1])
+            hip.up2_fwd(xsm, up)
+            self.conv3_fwd(m.convs[1], up, V(cat, (nb - 1) * C, C))
+        z = _E(xl, B, H, W, C)
+        sums = _Z(xl, 2, C) if self.training else None
+        self.conv([cat], fconv.weight, fconv.bias, z, Hin=H, Win=W, k=3, stats=sums,
+                  stats_mode=hip.STATS_SUM_SQ if self.training else hip.STATS_NONE)
+        mean, rstd, A, shift = self.bn_stats(fbn, sums, B * H * W, xl)
+        y = _E(xl, B, H, W, C)
+        hip.bnact_fwd(z, A, shift, y, hip.ACT_GELU)
+        if cx is not None:
+            cx.t[m] = dict(xs=xs_in, cat=cat, up=up, z=z, mean=mean, rstd=rstd, A=A)
+        return y
+
+    def skip_bwd(self, m, dy, cx, gacc):
+        """gacc: dict tensor-id -> GradSlot for the encoder activations (accumulated in place)."""
+        S = cx.t[m]
+        xs_in, cat, up, z = S["xs"], S["cat"], S["up"], S["z"]
+        three = len(xs_in) == 3
+        bottom = (not three) and m.model_type == "bottom"
+        fconv, fbn = m.fuse_conv[0], m.fuse_conv[1]
+        C = fbn.weight.numel()
+        B, H, W, _ = z.shape
+        G = self.G
+        st = _Z(z, 2, C)
+        hip.bnact_bwd_stats(z, dy, S["mean"], S["rstd"], fbn.weight, fbn.bias, st, hip.ACT_GELU)
+        c1, c2, c3 = (_E(z, C) for _ in range(3))
+        hip.bn_bwd_coef(st, B * H * W, S["A"], G[fbn.weight], G[fbn.bias], c1, c2, c3, self.training)
+        dz = _E(z, B, H, W, C)
+        hip.bnact_bwd(z, dy, S["mean"], S["rstd"], fbn.weight, fbn.bias, c1, c2, c3, dz, hip.ACT_GELU)
+        self.wgrad([cat], dz, fconv.weight, fconv.bias, Hin=H, Win=W, k=3)
+        nb = 3 if three else 2
+        dcat = _E(z, B, H, W, nb * C)
+        self.conv_T(dz, fconv.weight, dcat, Hin=H, Win=W, k=3)
+        xl = xs_in[0]
+        sl = 2 if (three or bottom) else 1
+        self._acc_conv(m.convl[0], xl, V(dcat, 0, C), sl, gacc)
+        if three:
+            self._acc_conv(m.convm[0], xs_in[1], V(dcat, C, C), 1, gacc)
+        xsm = xs_in[-1]
+        if bottom:
+            self._acc_conv(m.convs[0], xsm, V(dcat, C, C), 1, gacc)
+        else:
+            dup = _E(z, *up.shape)
+            self.conv3_bwd(m.convs[1], up, V(dcat, (nb - 1) * C, C), dx=dup)
+            slot = gacc[id(xsm)]
+            if slot.g is None:
+                slot.g = _E(z, *xsm.shape)
+                hip.up2_bwd(dup, slot.g)
+            else:
+                tmp = _E(z, *xsm.shape)
+                hip.up2_bwd(dup, tmp)
+                hip.add(slot.g, tmp)
+
+    def _acc_conv(self, conv, x, dy, s, gacc):
+        slot = gacc[id(x)]
+        first = slot.g is None
+        if first:
+            slot.g = _E(x, *x.shape)
+        self.conv3_bwd(conv, x, dy, s=s, dx=slot.g, accumulate=not first)
+
+    # ------------------------------------------------------------------ transformer pieces (A6, A7, A8)
+    def _mlp_fwd(self, mlp, n2, a_res, y, tagbase):
+        """y = drop(fc2(drop(gelu(fc1(n2))))) + a_res ; returns a1 (pre-GELU), seeds."""
+        rows_shape = n2.shape[:-1]
+        Cn, Ch = mlp.fc1.weight.shape[1], mlp.fc1.weight.shape[0]
+        n2f, yf, af = n2.view(1, 1, -1, Cn), y.view(1, 1, -1, Cn), a_res.view(1, 1, -1, Cn)
+        npx = n2f.shape[2]
+        a1 = _E(n2, 1, 1, npx, Ch)
+        p = mlp.dropout.p if self.training else 0.0
+        s1, s2 = self._seed(tagbase), self._seed(tagbase + 1)
+        self.conv([n2f], mlp.fc1.weight, mlp.fc1.bias, a1, Hin=1, Win=npx)
+        src = dict(view=a1, flags=hip.SRC_GELU | (hip.SRC_DROP if p > 0 else 0), drop_seed=s1, drop_p=p)
+        self.conv([src], mlp.fc2.weight, mlp.fc2.bias, yf, Hin=1, Win=npx, residual=af, drop_p=p, drop_seed=s2)
+        del rows_shape
+        return a1, (p, s1, s2)
+
+    def _mlp_bwd(self, mlp, n2, a1, dy, drop):
+        """returns dn2; accumulates fc1/fc2 grads.  dy is the gradient of the block output."""
+        p, s1, s2 = drop
+        Cn, Ch = mlp.fc1.weight.shape[1], mlp.fc1.weight.shape[0]
+        n2f, dyf = n2.view(1, 1, -1, Cn), dy.view(1, 1, -1, Cn)
+        npx = n2f.shape[2]
+        dflag = hip.SRC_DROP if p > 0 else 0
+        hsrc = dict(view=a1, flags=hip.SRC_GELU | dflag, drop_seed=s1, drop_p=p)
+        self.wgrad([hsrc], dyf, mlp.fc2.weight, mlp.fc2.bias, Hin=1, Win=npx, dy_flags=dflag, dy_seed=s2, dy_p=p)
+        da1 = _E(n2, 1, 1, npx, Ch)
+        self.conv_T(dict(view=dyf, flags=dflag, drop_seed=s2, drop_p=p), mlp.fc2.weight, da1, Hin=1, Win=npx,
+                    epilogue=hip.EP_DGELU, aux=a1, drop_p=p, drop_seed=s1)
+        self.wgrad([n2f], da1, mlp.fc1.weight, mlp.fc1.bias, Hin=1, Win=npx)
+        dn2 = _E(n2, 1, 1, npx, Cn)
+        self.conv_T(da1, mlp.fc1.weight, dn2, Hin=1, Win=npx)
+        return dn2.view(n2.shape)
+
+    def _lin(self, lin, x, out, **kw):
+        Cn = x.shape[-1]
+        xf = x.view(1, 1, -1, Cn)
+        self.conv([xf], lin.weight, lin.bias, out.view(1, 1, xf.shape[2], -1), Hin=1, Win=xf.shape[2], **kw)
+
+    def _lin_bwd(self, lin, x, dy, dx):
+        Cn, Co = x.shape[-1], dy.shape[-1]
+        xf, dyf = x.view(1, 1, -1, Cn), dy.view(1, 1, -1, Co)
+        npx = xf.shape[2]
+        self.wgrad([xf], dyf, lin.weight, lin.bias, Hin=1, Win=npx)
+        self.conv_T(dyf, lin.weight, dx.view(1, 1, npx, Cn), Hin=1, Win=npx)
+
+    def nat_fwd(self, m, x, cx, tag):
+        B, H, W, C = x.shape
+        heads = m.att1.num_heads
+        e = _E(x, B, H, W, C)
+        self.conv3_fwd(m.patchembedding.patch_embeddings, x, e)
+        n1 = _E(x, B, H, W, C)
+        hip.ln_fwd(e, m.norm1.weight, m.norm1.bias, n1)
+        qkv = _E(x, B, H, W, 3 * C)
+        self._lin(m.att1.qkv, n1, qkv)
+        o = _E(x, B, H, W, C)
+        hip.na_fwd(qkv, m.att1.rpb, o, heads)
+        a = _E(x, B, H, W, C)
+        self._lin(m.att1.proj, o, a, residual=e.view(1, 1, -1, C))
+        n2 = _E(x, B, H, W, C)
+        hip.ln_fwd(a, m.norm2.weight, m.norm2.bias, n2)
+        y = _E(x, B, H, W, C)
+        a1, drop = self._mlp_fwd(m.mlp, n2, a, y, tag)
+        if cx is not None:
+            cx.t[m] = dict(x=x, e=e, n1=n1, qkv=qkv, o=o, a=a, n2=n2, a1=a1, drop=drop)
+        return y
+
+    def nat_bwd(self, m, dy, cx):
+        S = cx.t[m]
+        x, e, n1, qkv, o, a, n2 = S["x"], S["e"], S["n1"], S["qkv"], S["o"], S["a"], S["n2"]
+        B, H, W, C = x.shape
+        G = self.G
+        dn2 = self._mlp_bwd(m.mlp, n2, S["a1"], dy, S["drop"])
+        da = _E(x, B, H, W, C)
+        hip.ln_bwd(a, m.norm2.weight, dn2, dy, da, G[m.norm2.weight], G[m.norm2.bias])
+        do = _E(x, B, H, W, C)
+        self._lin_bwd(m.att1.proj, o, da, do)
+        dqkv = _Z(x, B, H, W, 3 * C)
+        hip.na_bwd(qkv, m.att1.rpb, do, dqkv, G[m.att1.rpb], m.att1.num_heads)
+        dn1 = do
+        self._lin_bwd(m.att1.qkv, n1, dqkv, dn1)
+        de = _E(x, B, H, W, C)
+        hip.ln_bwd(e, m.norm1.weight, dn1, da, de, G[m.norm1.weight], G[m.norm1.bias])
+        dx = _E(x, B, H, W, C)
+        self.conv3_bwd(m.patchembedding.patch_embeddings, x, de, dx=dx)
+        return dx
+
+    def gft_fwd(self, m, catp, cx, tag):
+        B, h, w, C = catp.shape
+        N = h * w
+        heads = m.attention.num_heads
+        e = _E(catp, B, h, w, C)
+        self.conv3_fwd(m.patchembedding.patch_embeddings, catp, e)
+        n1 = _E(catp, B, N, C)
+        hip.ln_fwd(e, m.norm1.weight, m.norm1.bias, n1)
+        qkv = _E(catp, B, N, 3 * C)
+        self._lin(m.attention.qkv, n1, qkv)
+        o = _E(catp, B, N, C)
+        lse = _E(catp, B, heads, N)
+        hip.gattn_fwd(qkv, o, lse, heads)
+        a = _E(catp, B, N, C)
+        self._lin(m.attention.proj, o, a, residual=e.view(1, 1, -1, C))
+        n2 = _E(catp, B, N, C)
+        hip.ln_fwd(a, m.norm2.weight, m.norm2.bias, n2)
+        y = _E(catp, B, N, C)
+        a1, drop = self._mlp_fwd(m.mlp, n2, a, y, tag)
+        cv = m.conv[0]
+        x5 = _E(catp, B, h, w, cv.weight.shape[0])
+        self._lin(cv, y, x5)
+        if cx is not None:
+            cx.t[m] = dict(catp=catp, e=e, n1=n1, qkv=qkv, o=o, lse=lse, a=a, n2=n2, a1=a1, drop=drop, y=y)
+        return x5
+
+    def gft_bwd(self, m, dx5, cx):
+        S = cx.t[m]
+        catp, e, n1, qkv, o, a, n2, y = S["catp"], S["e"], S["n1"], S["qkv"], S["o"], S["a"], S["n2"], S["y"]
+        B, h, w, C = catp.shape
+        N = h * w
+        G = self.G
+        heads = m.attention.num_heads
+        dy = _E(catp, B, N, C)
+        self._lin_bwd(m.conv[0], y, dx5, dy)
+        dn2 = self._mlp_bwd(m.mlp, n2, S["a1"], dy, S["drop"])
+        da = _E(catp, B, N, C)
+        hip.ln_bwd(a, m.norm2.weight, dn2, dy, da, G[m.norm2.weight], G[m.norm2.bias])
+        do = _E(catp, B, N, C)
+        self._lin_bwd(m.attention.proj, o, da, do)
+        dqkv = _E(catp, B, N, 3 * C)
+        delta = _E(catp, B, heads, N)
+        hip.gattn_bwd(qkv, o, do, S["lse"], dqkv, delta, heads)
+        dn1 = do
+        self._lin_bwd(m.attention.qkv, n1, dqkv, dn1)
+        de = _E(catp, B, h, w, C)
+        hip.ln_bwd(e, m.norm1.weight, dn1, da, de, G[m.norm1.weight], G[m.norm1.bias])
+        dcat = _E(catp, B, h, w, C)
+        self.conv3_bwd(m.patchembedding.patch_embeddings, catp, de, dx=dcat)
+        return dcat
+
+    # ------------------------------------------------------------------ decoder up rows (A10)
+    def up_fwd(self, seq, x, skip, cx):
+        """conv3x3(bilinear_x2(x)) + skip"""
+        B, h, w, C = x.shape
+        conv = seq[1]
+        up = _E(x, B, 2 * h, 2 * w, C)
+        hip.up2_fwd(x, up)
+        out = _E(x, B, 2 * h, 2 * w, conv.weight.shape[0])
+        self.conv3_fwd(conv, up, out, residual=skip)
+        if cx is not None:
+            cx.t[seq] = dict(up=up)
+        return out
+
+    def up_bwd(self, seq, dt, cx, xshape):
+        up = cx.t[seq]["up"]
+        dup = _E(dt, *up.shape)
+        self.conv3_bwd(seq[1], up, dt, dx=dup)
+        dx = _E(dt, *xshape)
+        hip.up2_bwd(dup, dx)
+        return dx
+
+
+class GradSlot:
+    __slots__ = ("g",)
+
+    def __init__(self):
+        self.g = None

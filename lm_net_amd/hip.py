@@ -47,10 +47,10 @@ class WgradArgs(C.Structure):
 SYMBOLS = [
     "lmn_abi_version", "lmn_sizeof_conv_args", "lmn_sizeof_src", "lmn_sizeof_wgrad_args", "lmn_last_error",
     "lmn_conv_pack_size", "lmn_conv_pack", "lmn_conv_fwd", "lmn_conv_wgrad",
-    "lmn_dw_stats", "lmn_dw_fwd", "lmn_dw_merge", "lmn_dw_bwd_stats", "lmn_dw_bwd",
+    "lmn_dw_stats", "lmn_dw_fwd", "lmn_dw_merge", "lmn_dw_bwd_stats", "lmn_dw_bwd_coef", "lmn_dw_bwd",
     "lmn_se_fwd", "lmn_se_bwd", "lmn_na_fwd", "lmn_na_bwd", "lmn_gattn_fwd", "lmn_gattn_bwd",
     "lmn_ln_fwd", "lmn_ln_bwd", "lmn_bnact_fwd", "lmn_bnact_bwd_stats", "lmn_bnact_bwd",
-    "lmn_bn_finalize", "lmn_bn_bwd_coef", "lmn_up2_fwd", "lmn_up2_bwd", "lmn_avgpool_fwd", "lmn_avgpool_bwd",
+    "lmn_bn_finalize", "lmn_bn_fold", "lmn_bn_bwd_coef", "lmn_up2_fwd", "lmn_up2_bwd", "lmn_avgpool_fwd", "lmn_avgpool_bwd",
     "lmn_nchw_to_nhwc", "lmn_nhwc_to_nchw", "lmn_fill", "lmn_add", "lmn_colsum", "lmn_copy_slice",
 ]
 
@@ -242,10 +242,16 @@ def dw_bwd_stats(x1, pre, u, s, dm, dpre, w5, w3, wv, wh, bstats):
                                    _p(wh), _p(bstats), _stream()), "dw_bwd_stats")
 
 
-def dw_bwd(x1, dpre, dx1, w5, w3, wv, wh, cA, cC, cD, dwgrad):
+def dw_bwd_coef(bstats, mean, rstd, A, count, batch_stats, cA, cC, cD, dgs, dbs):
+    E = A.shape[-1]
+    _check(load().lmn_dw_bwd_coef(_p(bstats), _p(mean), _p(rstd), _p(A), _f(count), int(batch_stats), _p(cA), _p(cC),
+                                  _p(cD), *[_p(t) for t in dgs], *[_p(t) for t in dbs], E, _stream()), "dw_bwd_coef")
+
+
+def dw_bwd(x1, dpre, dx1, w5, w3, wv, wh, cA, cC, cD, dw5, dw3, dwv, dwh):
     B, H, W, E = x1.shape
     _check(load().lmn_dw_bwd(_p(x1), _p(dpre), _p(dx1), B, H, W, E, _p(w5), _p(w3), _p(wv), _p(wh), _p(cA), _p(cC),
-                             _p(cD), _p(dwgrad), _stream()), "dw_bwd")
+                             _p(cD), _p(dw5), _p(dw3), _p(dwv), _p(dwh), _stream()), "dw_bwd")
 
 
 def se_fwd(gsum, inv_hw, w1, b1, w2, b2, s, hidden):
@@ -322,9 +328,14 @@ def bn_finalize(sums, count, gamma, beta, eps, momentum, mean, rstd, A, shift, r
            "bn_finalize")
 
 
-def bn_bwd_coef(bstats, count, A, dgamma, dbeta, c1, c2, c3):
-    _check(load().lmn_bn_bwd_coef(_p(bstats), _f(count), _p(A), _p(dgamma), _p(dbeta), _p(c1), _p(c2), _p(c3), A.numel(),
-                                  _stream()), "bn_bwd_coef")
+def bn_fold(running_mean, running_var, gamma, beta, eps, mean, rstd, A, shift):
+    _check(load().lmn_bn_fold(_p(running_mean), _p(running_var), _p(gamma), _p(beta), _f(eps), _p(mean), _p(rstd), _p(A),
+                              _p(shift), gamma.numel(), _stream()), "bn_fold")
+
+
+def bn_bwd_coef(bstats, count, A, dgamma, dbeta, c1, c2, c3, batch_stats=True):
+    _check(load().lmn_bn_bwd_coef(_p(bstats), _f(count), int(batch_stats), _p(A), _p(dgamma), _p(dbeta), _p(c1), _p(c2),
+                                  _p(c3), A.numel(), _stream()), "bn_bwd_coef")
 
 
 # ------------------------------------------------------------------------------------------ resampling / layout / utils

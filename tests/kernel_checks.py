@@ -228,9 +228,9 @@ def check_dw():
         # --- stats
         x1d = nhwc(x1)
         wd = [dev(w) for w in ws]
-        stats = torch.zeros(8, E, device=DEV)
+        stats = torch.zeros(4, 2, E, device=DEV)
         hip.dw_stats(x1d, *wd, stats)
-        sref = torch.stack([y.sum((0, 2, 3)) for y in ys] + [(y * y).sum((0, 2, 3)) for y in ys]).detach()
+        sref = torch.stack([torch.stack([y.sum((0, 2, 3)), (y * y).sum((0, 2, 3))]) for y in ys]).detach()
         rows.append(("dw_stats" + tag, rel(stats, sref), 2e-4))
         # --- merge (with the exact fp64 batch stats) + forward
         N = B * H * W
@@ -260,22 +260,20 @@ def check_dw():
         rows.append(("dw_bwd_stats dpre" + tag, rel(nchw(dpre), dpre_ref), TOL))
         bref = torch.stack([dpre_ref.sum((0, 2, 3))] + [(dpre_ref * y.detach()).sum((0, 2, 3)) for y in ys])
         rows.append(("dw_bwd_stats sums" + tag, rel(bstats, bref), 2e-4))
-        # coefficients (host math in fp64 from the exact sums): f_b = A_b dpre + C_b y_b + D_b
-        S0 = bref[0]
-        cA, cC, cD = [], [], []
+        # coefficients from the exact fp64 sums: f_b = A_b dpre + C_b y_b + D_b ; dgamma_b, dbeta_b
+        cA, cC, cD = (torch.empty(4, E, device=DEV) for _ in range(3))
+        dgs = [torch.zeros(E, device=DEV) for _ in range(4)]
+        dbs = [torch.zeros(E, device=DEV) for _ in range(4)]
+        hip.dw_bwd_coef(dev(bref), dev(torch.stack(mean)), dev(torch.stack(rstd)), dev(A), N, True, cA, cC, cD, dgs, dbs)
         for i in range(4):
-            T = (bref[1 + i] - mean[i] * S0) * rstd[i]
-            Cb = -A[i] * T * rstd[i] / N
-            cA.append(A[i]); cC.append(Cb); cD.append(-A[i] * S0 / N - Cb * mean[i])
+            rows.append(("dw_bwd_coef dgamma[%d]" % i + tag, rel(dgs[i], gr[i].grad), 2e-4))
+            rows.append(("dw_bwd_coef dbeta[%d]" % i + tag, rel(dbs[i], br[i].grad), 2e-4))
         dx1 = torch.full((B, H, W, E), float("nan"), device=DEV)
-        dwg = torch.zeros(E, 40, device=DEV)
-        hip.dw_bwd(x1d, nhwc(dpre_ref), dx1, *wd, dev(torch.stack(cA)), dev(torch.stack(cC)), dev(torch.stack(cD)), dwg)
+        dws = [torch.zeros_like(dev(w)) for w in ws]
+        hip.dw_bwd(x1d, nhwc(dpre_ref), dx1, *wd, cA, cC, cD, *dws)
         rows.append(("dw_bwd dx1" + tag, rel(nchw(dx1), x1r.grad), TOL))
-        dwg = dwg.double().cpu()
-        rows.append(("dw_bwd dW5" + tag, rel(dwg[:, :25], wsr[0].grad.reshape(E, 25)), 2e-4))
-        rows.append(("dw_bwd dW3" + tag, rel(dwg[:, 25:34], wsr[1].grad.reshape(E, 9)), 2e-4))
-        rows.append(("dw_bwd dWv" + tag, rel(dwg[:, 34:37], wsr[2].grad.reshape(E, 3)), 2e-4))
-        rows.append(("dw_bwd dWh" + tag, rel(dwg[:, 37:40], wsr[3].grad.reshape(E, 3)), 2e-4))
+        for nm, got, ref in zip(("dW5", "dW3", "dWv", "dWh"), dws, wsr):
+            rows.append(("dw_bwd " + nm + tag, rel(got, ref.grad), 2e-4))
     return rows
 
 
@@ -408,7 +406,7 @@ def check_bn_tail():
         hip.bnact_bwd_stats(zd, dev(dy), mean, rstd, dev(g), dev(b), bst, hip.ACT_GELU)
         dg, db = torch.zeros(Cn, device=DEV), torch.zeros(Cn, device=DEV)
         c1, c2, c3 = (torch.empty(Cn, device=DEV) for _ in range(3))
-        hip.bn_bwd_coef(bst, n, A, dg, db, c1, c2, c3)
+        hip.bn_bwd_coef(bst, n, A, dg, db, c1, c2, c3, True)
         rows.append(("bn dgamma C=%d" % Cn, rel(dg, g.grad), 2e-4))
         rows.append(("bn dbeta C=%d" % Cn, rel(db, b.grad), 2e-4))
         dz = torch.full((n, Cn), float("nan"), device=DEV)
@@ -445,7 +443,7 @@ def check_conv_bn_epilogues():
                  stats_mode=hip.STATS_EP)
     A = dev(g.detach() * rstd)
     dg, db_, c1, c2, c3 = (torch.zeros(E, device=DEV) for _ in range(5))
-    hip.bn_bwd_coef(st, N, A, dg, db_, c1, c2, c3)
+    hip.bn_bwd_coef(st, N, A, dg, db_, c1, c2, c3, True)
     rows.append(("conv BN_BWD1 dgamma", rel(dg, g.grad), 2e-4))
     rows.append(("conv BN_BWD1 dbeta", rel(db_, be.grad), 2e-4))
     dz = torch.full((B, H, W, E), float("nan"), device=DEV)

@@ -34,16 +34,16 @@ def main():
         by = 2 * x1.numel() * 4
         print("dw_fwd      H=%3d E=%3d  %8.1f us  %7.1f GB/s alg (%.1f%% of 8 TB/s)" % (H, E, t * 1e6, by / t / 1e9, by / t / 8e12 * 100))
         w5, w3, wv, wh = (torch.randn(E, 1, a, b, device=dev) for a, b in ((5, 5), (3, 3), (3, 1), (1, 3)))
-        st = torch.zeros(8, E, device=dev)
+        st = torch.zeros(4, 2, E, device=dev)
         t = timeit(lambda: hip.dw_stats(x1, w5, w3, wv, wh, st))
         print("dw_stats    H=%3d E=%3d  %8.1f us  %7.1f GB/s" % (H, E, t * 1e6, x1.numel() * 4 / t / 1e9))
         u, s, dm, dpre, bst = torch.randn_like(x1), torch.rand(B, E, device=dev), torch.zeros(B, E, device=dev), torch.empty_like(x1), torch.zeros(5, E, device=dev)
         t = timeit(lambda: hip.dw_bwd_stats(x1, pre, u, s, dm, dpre, w5, w3, wv, wh, bst))
         print("dw_bwd_stat H=%3d E=%3d  %8.1f us  %7.1f GB/s" % (H, E, t * 1e6, 4 * x1.numel() * 4 / t / 1e9))
         cA = torch.rand(4, E, device=dev)
-        dwg = torch.zeros(E, 40, device=dev)
+        dws = [torch.zeros_like(w) for w in (w5, w3, wv, wh)]
         dx1 = torch.empty_like(x1)
-        t = timeit(lambda: hip.dw_bwd(x1, dpre, dx1, w5, w3, wv, wh, cA, cA, cA, dwg))
+        t = timeit(lambda: hip.dw_bwd(x1, dpre, dx1, w5, w3, wv, wh, cA, cA, cA, *dws))
         print("dw_bwd      H=%3d E=%3d  %8.1f us  %7.1f GB/s" % (H, E, t * 1e6, 3 * x1.numel() * 4 / t / 1e9))
     for (H, C) in [(352, 12), (176, 24), (88, 48), (44, 96)]:
         qkv = torch.randn(B, H, H, 3 * C, device=dev)
