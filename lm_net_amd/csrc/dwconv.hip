@@ -44,17 +44,18 @@ __global__ __launch_bounds__(FW_THREADS) void dw_fwd_kernel(const float* __restr
     const int r = pix / FW_RW, c = pix - r * FW_RW;
     const int gy = ty0 - 2 + r, gx = tx0 - 2 + c;
     f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (gy >= 0 && gy < H && gx >= 0 && gx < W)
+    if (gy >= 0 && gy < H && gx >= 0 && gx < W && ch0 + c4 * 4 < E)
       v = *reinterpret_cast<const f32x4*>(xb + ((int64_t)gy * W + gx) * E + ch0 + c4 * 4);
     *reinterpret_cast<f32x4*>(&tile[pix * FW_CCH + c4 * 4]) = v;
   }
 
   const int cp = tid % FW_NCP, xx = tid / FW_NCP;
   const int ch = ch0 + cp * 2;
+  const bool cok = ch < E;  // E is a multiple of 4: a channel pair is valid as a whole (last chunk may be partial)
   f32x2 w[25];
 #pragma unroll
-  for (int t = 0; t < 25; ++t) w[t] = f32x2{keff[(int64_t)ch * 25 + t], keff[(int64_t)(ch + 1) * 25 + t]};
-  const f32x2 bias = f32x2{beff[ch], beff[ch + 1]};
+  for (int t = 0; t < 25; ++t) w[t] = cok ? f32x2{keff[(int64_t)ch * 25 + t], keff[(int64_t)(ch + 1) * 25 + t]} : f32x2{0.f, 0.f};
+  const f32x2 bias = cok ? f32x2{beff[ch], beff[ch + 1]} : f32x2{0.f, 0.f};
   __syncthreads();
 
   f32x2 acc[5];
@@ -80,7 +81,7 @@ __global__ __launch_bounds__(FW_THREADS) void dw_fwd_kernel(const float* __restr
       const int gy = ty0 + o;
       const f32x2 p = acc[o % 5] + bias;
       acc[o % 5] = f32x2{0.f, 0.f};
-      if (gy < H && gx < W) {
+      if (gy < H && gx < W && cok) {
         *reinterpret_cast<f32x2*>(pre + (((int64_t)b * H + gy) * W + gx) * E + ch) = p;
         gs += f32x2{lmn_gelu(p[0]), lmn_gelu(p[1])};
       }
@@ -89,7 +90,7 @@ __global__ __launch_bounds__(FW_THREADS) void dw_fwd_kernel(const float* __restr
   atomicAdd(&gs_s[cp * 2], gs[0]);
   atomicAdd(&gs_s[cp * 2 + 1], gs[1]);
   __syncthreads();
-  if (tid < FW_CCH) atomicAdd(gsum + (int64_t)b * E + ch0 + tid, gs_s[tid]);
+  if (tid < FW_CCH && ch0 + tid < E) atomicAdd(gsum + (int64_t)b * E + ch0 + tid, gs_s[tid]);
 }
 
 __global__ void dw_merge_kernel(const float* __restrict__ w5, const float* __restrict__ w3, const float* __restrict__ wv,
@@ -116,15 +117,17 @@ struct BranchW {  // this thread's channel pair of the four branch kernels
 };
 
 __device__ __forceinline__ void load_branch_w(BranchW& bw, const float* w5, const float* w3, const float* wv,
-                                              const float* wh, int ch) {
+                                              const float* wh, int ch, int E) {
+  const f32x2 z = f32x2{0.f, 0.f};
+  const bool ok = ch < E;  // partial last chunk: invalid pairs carry zero weights
 #pragma unroll
-  for (int t = 0; t < 25; ++t) bw.w5[t] = f32x2{w5[(int64_t)ch * 25 + t], w5[(int64_t)(ch + 1) * 25 + t]};
+  for (int t = 0; t < 25; ++t) bw.w5[t] = ok ? f32x2{w5[(int64_t)ch * 25 + t], w5[(int64_t)(ch + 1) * 25 + t]} : z;
 #pragma unroll
-  for (int t = 0; t < 9; ++t) bw.w3[t] = f32x2{w3[(int64_t)ch * 9 + t], w3[(int64_t)(ch + 1) * 9 + t]};
+  for (int t = 0; t < 9; ++t) bw.w3[t] = ok ? f32x2{w3[(int64_t)ch * 9 + t], w3[(int64_t)(ch + 1) * 9 + t]} : z;
 #pragma unroll
   for (int t = 0; t < 3; ++t) {
-    bw.wv[t] = f32x2{wv[(int64_t)ch * 3 + t], wv[(int64_t)(ch + 1) * 3 + t]};
-    bw.wh[t] = f32x2{wh[(int64_t)ch * 3 + t], wh[(int64_t)(ch + 1) * 3 + t]};
+    bw.wv[t] = ok ? f32x2{wv[(int64_t)ch * 3 + t], wv[(int64_t)(ch + 1) * 3 + t]} : z;
+    bw.wh[t] = ok ? f32x2{wh[(int64_t)ch * 3 + t], wh[(int64_t)(ch + 1) * 3 + t]} : z;
   }
 }
 
@@ -137,7 +140,8 @@ __device__ __forceinline__ void stage_tile(float* lds, const float* img, int H, 
     const int r = pix / R, c = pix - r * R;
     const int gy = ty0 - HALO + r, gx = tx0 - HALO + c;
     f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (gy >= 0 && gy < H && gx >= 0 && gx < W) v = *reinterpret_cast<const f32x4*>(img + ((int64_t)gy * W + gx) * E + ch0 + c4 * 4);
+    if (gy >= 0 && gy < H && gx >= 0 && gx < W && ch0 + c4 * 4 < E)
+      v = *reinterpret_cast<const f32x4*>(img + ((int64_t)gy * W + gx) * E + ch0 + c4 * 4);
     *reinterpret_cast<f32x4*>(&lds[pix * DC + c4 * 4]) = v;
   }
 }
@@ -174,8 +178,9 @@ __global__ __launch_bounds__(256) void dw_stats_kernel(const float* __restrict__
   __shared__ float red[NS * DC];
   const int tid = threadIdx.x, cp = tid % DNCP;
   const int ch0 = blockIdx.y * DC, ch = ch0 + cp * 2;
+  const bool cok = ch < E;
   BranchW bw;
-  load_branch_w(bw, w5, w3, wv, wh, ch);
+  load_branch_w(bw, w5, w3, wv, wh, ch, E);
   f32x2 sum[NS];
 #pragma unroll
   for (int k = 0; k < NS; ++k) sum[k] = f32x2{0.f, 0.f};
@@ -191,7 +196,7 @@ __global__ __launch_bounds__(256) void dw_stats_kernel(const float* __restrict__
     for (int i = tid; i < DT * DT * DNCP; i += 256) {
       const int pix = i / DNCP, py = pix / DT, px = pix - py * DT;
       const int gy = ty0 + py, gx = tx0 + px;
-      if (gy >= H || gx >= W) continue;
+      if (gy >= H || gx >= W || !cok) continue;
       f32x2 y[4];
       branches_at<R>(lds, py + 2, px + 2, cp, bw, y);
       if (MODE == 0) {
@@ -225,7 +230,7 @@ __global__ __launch_bounds__(256) void dw_stats_kernel(const float* __restrict__
   for (int i = tid; i < NS * DC; i += 256) {
     const int k = i / DC;
     const int row = MODE == 0 ? ((k & 3) * 2 + (k >> 2)) : k;  // MODE 0: [branch][sum|sumsq][E]
-    atomicAdd(stats + (int64_t)row * E + ch0 + (i % DC), red[i]);
+    if (ch0 + (i % DC) < E) atomicAdd(stats + (int64_t)row * E + ch0 + (i % DC), red[i]);
   }
 }
 
@@ -303,19 +308,21 @@ __global__ __launch_bounds__(256) void dw_bwd_kernel(const float* __restrict__ x
   for (int i = tid; i < 40 * DC; i += 256) {
     const int t = i / DC, e = ch0 + (i - t * DC);
     float v;
-    if (t < 25) v = w5[(int64_t)e * 25 + t];
+    if (e >= E) v = 0.f;
+    else if (t < 25) v = w5[(int64_t)e * 25 + t];
     else if (t < 34) v = w3[(int64_t)e * 9 + t - 25];
     else if (t < 37) v = wv[(int64_t)e * 3 + t - 34];
     else v = wh[(int64_t)e * 3 + t - 37];
     Wl[i] = v;
     red[i] = 0.f;
   }
+  const bool cok = ch < E;
   f32x2 a[4], c[4], d[4];
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
-    a[k] = f32x2{cA[k * E + ch], cA[k * E + ch + 1]};
-    c[k] = f32x2{cC[k * E + ch], cC[k * E + ch + 1]};
-    d[k] = f32x2{cD[k * E + ch], cD[k * E + ch + 1]};
+    a[k] = cok ? f32x2{cA[k * E + ch], cA[k * E + ch + 1]} : f32x2{0.f, 0.f};
+    c[k] = cok ? f32x2{cC[k * E + ch], cC[k * E + ch + 1]} : f32x2{0.f, 0.f};
+    d[k] = cok ? f32x2{cD[k * E + ch], cD[k * E + ch + 1]} : f32x2{0.f, 0.f};
   }
   f32x2 g5[25], g3[9], gv[3], gh[3];
 #pragma unroll
@@ -340,7 +347,7 @@ __global__ __launch_bounds__(256) void dw_bwd_kernel(const float* __restrict__ x
     for (int i = tid; i < DT * DT * (DC / 4); i += 256) {   // float4 rows of the finished dx1 tile
       const int c4 = i % (DC / 4), pix = i / (DC / 4), py = pix / DT, px = pix - py * DT;
       const int gy = ty0 + py, gx = tx0 + px;
-      if (gy < H && gx < W)
+      if (gy < H && gx < W && ch0 + c4 * 4 < E)
         *reinterpret_cast<f32x4*>(dx1 + (((int64_t)b * H + gy) * W + gx) * E + ch0 + c4 * 4) = *reinterpret_cast<const f32x4*>(&DX[pix * DC + c4 * 4]);
     }
   }
@@ -360,6 +367,7 @@ __global__ __launch_bounds__(256) void dw_bwd_kernel(const float* __restrict__ x
   __syncthreads();
   for (int i = tid; i < 40 * DC; i += 256) {
     const int t = i / DC, e = ch0 + (i - t * DC);
+    if (e >= E) continue;
     if (t < 25) atomicAdd(dw5 + (int64_t)e * 25 + t, red[i]);
     else if (t < 34) atomicAdd(dw3 + (int64_t)e * 9 + t - 25, red[i]);
     else if (t < 37) atomicAdd(dwv + (int64_t)e * 3 + t - 34, red[i]);
@@ -398,9 +406,9 @@ extern "C" {
 int lmn_dw_fwd(const float* x1, float* pre, float* gsum, int B, int H, int W, int E, const float* keff,
                const float* beff, lmn_stream_t stream) {
   LMN_REQUIRE(x1 && pre && gsum && keff && beff, "dw_fwd: null pointer");
-  LMN_REQUIRE(B > 0 && H > 0 && W > 0 && E > 0 && E % FW_CCH == 0, "dw_fwd: E=%d must be a multiple of %d", E, FW_CCH);
+  LMN_REQUIRE(B > 0 && H > 0 && W > 0 && E > 0 && E % 4 == 0, "dw_fwd: E=%d must be a multiple of 4", E);
   const int tx = lmn_cdiv(W, FW_TW), ty = lmn_cdiv(H, FW_TH);
-  hipLaunchKernelGGL(dw_fwd_kernel, dim3(tx * ty, E / FW_CCH, B), dim3(FW_THREADS), 0, (hipStream_t)stream, x1, pre,
+  hipLaunchKernelGGL(dw_fwd_kernel, dim3(tx * ty, lmn_cdiv(E, FW_CCH), B), dim3(FW_THREADS), 0, (hipStream_t)stream, x1, pre,
                      gsum, H, W, E, keff, beff, tx);
   return lmn_launch_status("dw_fwd");
 }
@@ -423,9 +431,9 @@ static int dw_grid_x(int B, int tx, int ty, int chunks) {
 int lmn_dw_stats(const float* x1, int B, int H, int W, int E, const float* w5, const float* w3, const float* wv,
                  const float* wh, float* stats, lmn_stream_t stream) {
   LMN_REQUIRE(x1 && w5 && w3 && wv && wh && stats, "dw_stats: null pointer");
-  LMN_REQUIRE(B > 0 && H > 0 && W > 0 && E > 0 && E % DC == 0, "dw_stats: E=%d must be a multiple of %d", E, DC);
+  LMN_REQUIRE(B > 0 && H > 0 && W > 0 && E > 0 && E % 4 == 0, "dw_stats: E=%d must be a multiple of 4", E);
   const int tx = lmn_cdiv(W, DT), ty = lmn_cdiv(H, DT);
-  hipLaunchKernelGGL((dw_stats_kernel<0>), dim3(dw_grid_x(B, tx, ty, E / DC), E / DC), dim3(256), 0, (hipStream_t)stream,
+  hipLaunchKernelGGL((dw_stats_kernel<0>), dim3(dw_grid_x(B, tx, ty, lmn_cdiv(E, DC)), lmn_cdiv(E, DC)), dim3(256), 0, (hipStream_t)stream,
                      x1, nullptr, nullptr, nullptr, nullptr, nullptr, B, H, W, E, w5, w3, wv, wh, stats, tx, ty);
   return lmn_launch_status("dw_stats");
 }
@@ -434,9 +442,9 @@ int lmn_dw_bwd_stats(const float* x1, const float* pre, const float* u, const fl
                      int B, int H, int W, int E, const float* w5, const float* w3, const float* wv, const float* wh,
                      float* bstats, lmn_stream_t stream) {
   LMN_REQUIRE(x1 && pre && u && s && dm && dpre && w5 && w3 && wv && wh && bstats, "dw_bwd_stats: null pointer");
-  LMN_REQUIRE(B > 0 && H > 0 && W > 0 && E > 0 && E % DC == 0, "dw_bwd_stats: E=%d must be a multiple of %d", E, DC);
+  LMN_REQUIRE(B > 0 && H > 0 && W > 0 && E > 0 && E % 4 == 0, "dw_bwd_stats: E=%d must be a multiple of 4", E);
   const int tx = lmn_cdiv(W, DT), ty = lmn_cdiv(H, DT);
-  hipLaunchKernelGGL((dw_stats_kernel<1>), dim3(dw_grid_x(B, tx, ty, E / DC), E / DC), dim3(256), 0, (hipStream_t)stream,
+  hipLaunchKernelGGL((dw_stats_kernel<1>), dim3(dw_grid_x(B, tx, ty, lmn_cdiv(E, DC)), lmn_cdiv(E, DC)), dim3(256), 0, (hipStream_t)stream,
                      x1, pre, u, s, dm, dpre, B, H, W, E, w5, w3, wv, wh, bstats, tx, ty);
   return lmn_launch_status("dw_bwd_stats");
 }
@@ -455,9 +463,9 @@ int lmn_dw_bwd(const float* x1, const float* dpre, float* dx1, int B, int H, int
                const float* w3, const float* wv, const float* wh, const float* cA, const float* cC, const float* cD,
                float* dw5, float* dw3, float* dwv, float* dwh, lmn_stream_t stream) {
   LMN_REQUIRE(x1 && dpre && dx1 && w5 && w3 && wv && wh && cA && cC && cD && dw5 && dw3 && dwv && dwh, "dw_bwd: null pointer");
-  LMN_REQUIRE(B > 0 && H > 0 && W > 0 && E > 0 && E % DC == 0, "dw_bwd: E=%d must be a multiple of %d", E, DC);
+  LMN_REQUIRE(B > 0 && H > 0 && W > 0 && E > 0 && E % 4 == 0, "dw_bwd: E=%d must be a multiple of 4", E);
   const int tx = lmn_cdiv(W, DT), ty = lmn_cdiv(H, DT);
-  hipLaunchKernelGGL(dw_bwd_kernel, dim3(dw_grid_x(B, tx, ty, E / DC), E / DC), dim3(256), 0, (hipStream_t)stream, x1,
+  hipLaunchKernelGGL(dw_bwd_kernel, dim3(dw_grid_x(B, tx, ty, lmn_cdiv(E, DC)), lmn_cdiv(E, DC)), dim3(256), 0, (hipStream_t)stream, x1,
                      dpre, dx1, B, H, W, E, w5, w3, wv, wh, cA, cC, cD, dw5, dw3, dwv, dwh, tx, ty);
   return lmn_launch_status("dw_bwd");
 }
