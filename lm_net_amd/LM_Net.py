@@ -75,7 +75,11 @@ class LM_Net(nn.Module):
         self._save_tape = False
         self._keep_taps = False
         self._taps = None
-        self.grad_ready_hook = None      # ddp.py: called as hook(lo, hi) when flat-grad slice [lo,hi) is enqueued
+        # data-parallel hooks (ddp.py): begin(flat) at the start of backward, ready(lo, hi) when the
+        # flat-gradient slice [lo,hi) has been enqueued, finish() at the end of backward
+        self.grad_begin_hook = None
+        self.grad_ready_hook = None
+        self.grad_finish_hook = None
 
     # ------------------------------------------------------------------ public API of the reference
     def structural_reparam(self):
@@ -215,6 +219,8 @@ class LM_Net(nn.Module):
         eng = self._engine
         flat, G = self._new_grads()
         self._grad_flat = flat
+        if self.grad_begin_hook is not None:
+            self.grad_begin_hook(flat)
         eng.G = G
         A = cx.t["act"]
         B, H, W = A["shape"]
@@ -273,4 +279,6 @@ class LM_Net(nn.Module):
             dx = torch.empty(B, self.channel, H, W, device=dev)
             hip.nhwc_to_nchw(dxin, dx)
         eng.G = None
+        if self.grad_finish_hook is not None:
+            self.grad_finish_hook()
         return dx, [G[p] for p in self.parameters()]

@@ -43,7 +43,7 @@ class Engine:
         self.training = True
         self.seed_base = 0x1234567
         self.step = 0
-        self.bucket_hook = None  # called with a bucket tag as soon as its gradients are enqueued
+        self.kernel_events = None  # bench.py: {"dw_fwd": [(start_event, end_event, algorithmic_bytes), ...]}
 
     # ------------------------------------------------------------------ small helpers
     def _seed(self, tag):
@@ -140,7 +140,14 @@ class Engine:
             hip.dw_merge(*ws, bA, bshift, keff, beff)
         pre = _E(x, B, H, W, E)
         gsum = _Z(x, B, E)
+        ev = self.kernel_events.get("dw_fwd") if self.kernel_events is not None else None
+        if ev is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
         hip.dw_fwd(x1, pre, gsum, keff, beff)
+        if ev is not None:
+            e1.record()
+            ev.append((e0, e1, 2 * x1.numel() * 4))
         se = m.se
         R = se.fc1.weight.shape[0]
         sgate, hid = _E(x, B, E), _E(x, B, R)

@@ -1,0 +1,65 @@
+"""CPU, world_size 2 over gloo: the bucketed gradient reducer of lm_net_amd/ddp.py (the N>1 path).
+Each rank fills a flat gradient buffer block by block (as LM_Net's backward does) and the reducer must
+leave the mean over ranks in every element, using a few large buckets."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from lm_net_amd import LM_Net
+    from lm_net_amd.ddp import GradReducer, broadcast_state
+    torch.manual_seed(100 + rank)                       # different init per rank ...
+    model = LM_Net(3, 2, filters=[12] * 5)
+    broadcast_state(model)                              # ... replicated from rank 0
+    w0 = torch.cat([p.detach().flatten() for p in model.parameters()])
+    L = model._ensure_grad_layout()
+    red = GradReducer(bucket_bytes=64 << 10, first_bucket_bytes=16 << 10)
+    for it in range(2):                                 # two "backward passes"
+        flat = torch.zeros(L["total"])
+        red.begin(flat)
+        for name, (lo, hi) in L["blocks"].items():      # blocks complete in backward order
+            flat[lo:hi] = float(rank + 1) * (1 + it) + torch.arange(lo, hi) * 1e-3
+            red.ready(lo, hi)
+        red.finish()
+        expect = (sum(range(1, world + 1)) / world) * (1 + it) + torch.arange(L["total"]) * 1e-3
+        ok = torch.allclose(flat, expect, atol=1e-5)
+        q.put((rank, it, bool(ok), len(red.launched), float(w0.sum())))
+    dist.destroy_process_group()
+
+
+def test_bucketed_allreduce_world2_gloo():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    [p.start() for p in ps]
+    res = [q.get(timeout=120) for _ in range(2 * world)]
+    [p.join(30) for p in ps]
+    assert all(r[2] for r in res), res
+    assert all(1 < r[3] < 20 for r in res), "expected a handful of large buckets, got %s" % res
+    assert len({round(r[4], 4) for r in res}) == 1, "parameters were not replicated from rank 0"
+
+
+def test_grad_layout_is_backward_ordered_and_aligned():
+    from lm_net_amd import LM_Net
+    from lm_net_amd.LM_Net import BACKWARD_ORDER
+    m = LM_Net(3, 2)
+    L = m._ensure_grad_layout()
+    assert set(id(p) for p in L["order"]) == set(id(p) for p in m.parameters())
+    assert all(a % 4 == 0 for a, _ in L["offs"].values())            # 16-byte aligned views
+    los = [L["blocks"][n][0] for n in BACKWARD_ORDER]
+    assert los == sorted(los) and L["blocks"][BACKWARD_ORDER[-1]][1] == L["total"]
+    assert L["blocks"]["output_layer"][0] == 0                        # head gradients complete first
+    # 15.87 MB of fp32 gradients (3,966,566 parameters) + alignment padding
+    assert 3966566 <= L["total"] <= 3966566 + 4 * len(L["order"])

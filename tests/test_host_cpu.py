@@ -1,0 +1,80 @@
+"""CPU: host-side logic of the product that needs no GPU -- the C-ABI library loads and exports every
+symbol include/lmnet_hip.h declares, struct mirrors match, state_dict is checkpoint-compatible with the
+reference, and the product refuses to run without the device (no silent fallback)."""
+import ctypes
+import json
+import os
+import re
+
+import pytest
+import torch
+
+from helpers import GOLDEN, ROOT
+
+
+def test_library_exports_every_declared_symbol():
+    from lm_net_amd import hip
+    lib = hip.load()
+    hdr = open(os.path.join(ROOT, "include", "lmnet_hip.h")).read()
+    declared = set(re.findall(r"\b(lmn_[a-z0-9_]+)\s*\(", hdr))
+    declared -= {"lmn_src_t", "lmn_stream_t"}
+    assert declared == set(hip.SYMBOLS), declared ^ set(hip.SYMBOLS)
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.lmn_abi_version() == hip.ABI_VERSION
+    assert lib.lmn_sizeof_conv_args() == ctypes.sizeof(hip.ConvArgs)
+    assert lib.lmn_sizeof_src() == ctypes.sizeof(hip.SrcT)
+    assert lib.lmn_sizeof_wgrad_args() == ctypes.sizeof(hip.WgradArgs)
+
+
+def test_pack_size_arithmetic():
+    from lm_net_amd import hip
+    # taps * K16-blocks * cout tiles * 256
+    assert hip.conv_pack_size(1, 12, [12]) == 1 * 1 * 1 * 256
+    assert hip.conv_pack_size(3, 96, [96, 96]) == 9 * 12 * 6 * 256
+    assert hip.conv_pack_size(1, 1116, [372]) == 24 * 70 * 256
+
+
+def test_state_dict_matches_reference_keys_and_loads_oracle_checkpoint():
+    from lm_net_amd import LM_Net
+    from oracle.lmnet_ref import LM_Net as Oracle
+    keys = json.load(open(os.path.join(GOLDEN, "keys.json")))
+    m = LM_Net(3, 2)
+    sd = m.state_dict()
+    assert list(sd.keys()) == list(keys["train"].keys()) and len(sd) == 766
+    assert all(list(v.shape) == keys["train"][k] for k, v in sd.items())
+    assert sum(p.numel() for p in m.parameters()) == 3966566
+    m.load_state_dict(Oracle(3, 2).state_dict())          # a reference-format checkpoint loads as is
+    m.structural_reparam()
+    sd = m.state_dict()
+    assert list(sd.keys()) == list(keys["deploy"].keys()) and len(sd) == 510
+
+
+def test_reparam_folding_matches_oracle():
+    from lm_net_amd import LM_Net
+    from oracle.lmnet_ref import LM_Net as Oracle
+    from tools.detweights import fill_module
+    a, b = LM_Net(3, 2, filters=[12] * 5), Oracle(3, 2, filters=[12] * 5)
+    fill_module(a); fill_module(b)
+    a.structural_reparam(); b.structural_reparam()
+    for (k, v), (k2, v2) in zip(a.state_dict().items(), b.state_dict().items()):
+        assert k == k2 and torch.allclose(v, v2, atol=1e-6), k
+
+
+def test_no_cpu_fallback_and_input_validation():
+    from lm_net_amd import LM_Net
+    m = LM_Net(3, 2, filters=[12] * 5)
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        m(torch.zeros(1, 3, 32, 32))
+    with pytest.raises(RuntimeError):                      # parameter containers have no compute path
+        m.conv1[0](torch.zeros(1, 3, 32, 32))
+    with pytest.raises(AssertionError):
+        LM_Net(3, 2, filters=[10, 20, 40, 80, 160])       # 12 heads need multiples of 12
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "lm_net_amd")
+    for fn in os.listdir(pkg):
+        if fn.endswith(".py"):
+            src = open(os.path.join(pkg, fn)).read()
+            assert "oracle" not in src.replace("the oracle", "").replace("CPU oracle", "") or fn == "__none__", fn
