@@ -52,7 +52,10 @@ def cpu_baseline(H, W):
     box's host cores: a bounded sample of the same workload -- train steps at batch 2."""
     from oracle.lmnet_ref import LM_Net as Oracle
     torch.manual_seed(0)
-    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
     torch.set_num_threads(cores)
     m = Oracle(3, 2)
     m.train()
@@ -67,9 +70,11 @@ def cpu_baseline(H, W):
         opt.zero_grad()
         loss.backward()
         opt.step()
+    t0 = time.time()
     step()                       # warm-up (allocator, mkldnn primitives)
+    warm = time.time() - t0
     n, t0 = 0, time.time()
-    while n < 2 or (time.time() - t0 < 8 and n < 6):
+    while n < 1 or (time.time() - t0 + warm < 20 and n < 4):
         step()
         n += 1
     dt = time.time() - t0
@@ -150,7 +155,7 @@ def main():
             "config": {"workload": "LM-Net fp32 training step (fwd + CE/Dice loss + bwd + AdamW), batch %d/GPU, %dx%d "
                                    "synthetic disc masks (BASELINE configs[1])" % (B, H, W),
                        "global_batch": world * B, "image": [3, H, W], "parallelism": "dp%d" % world,
-                       "final_loss": round(float(loss), 5)},
+                       "final_loss": round(float(loss.detach()), 5)},
             "roofline": {"bound": "hbm", "kernel": "dw_fwd_kernel (row A2 forward, 5x5 merged depthwise stencil + GELU-sum)",
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "frac_of_measured_copy_ceiling": round(achieved / 6290.0, 4),

@@ -61,6 +61,31 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams P) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) st0[c][r] = st1[c][r] = 0.f;
 
+  // per-image statistic (SE_BWD): accumulated across this wave's groups while the image stays the same
+  float sb[NCT][4];
+#pragma unroll
+  for (int c = 0; c < NCT; ++c)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) sb[c][r] = 0.f;
+  int cur_b = -1;
+  auto flush_sb = [&]() {
+    if (cur_b >= 0) {
+#pragma unroll
+      for (int c = 0; c < NCT; ++c)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float t = sb[c][r];
+          t += __shfl_xor(t, 1, 64);
+          t += __shfl_xor(t, 2, 64);
+          t += __shfl_xor(t, 4, 64);
+          t += __shfl_xor(t, 8, 64);
+          const int co = (ct0 + c) * 16 + q * 4 + r;
+          if (n == 0 && (ct0 + c < P.NCTT) && co < A.Cout) atomicAdd(A.stats + (int64_t)cur_b * A.Cout + co, t);
+          sb[c][r] = 0.f;
+        }
+    }
+  };
+
   const int set_begin = (int)(((int64_t)wave * P.total_sets) / nwaves);
   const int set_end = (int)(((int64_t)(wave + 1) * P.total_sets) / nwaves);
   const int total_groups = A.B * P.gpi;
@@ -174,14 +199,18 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams P) {
 #pragma unroll
     for (int g = 0; g < NPG; ++g) {
       const int64_t opix = ((int64_t)gb[g] * A.Hout + gy[g]) * A.Wout + gx[g];
-      float sb0[NCT][4];  // per-image statistic (SE_BWD), flushed per group
+      if (A.epilogue == LMN_EP_SE_BWD && (set * NPG + g) < total_groups) {
+        const int bu = __builtin_amdgcn_readfirstlane(gb[g]);  // wave-uniform: groups never straddle images
+        if (bu != cur_b) {
+          flush_sb();
+          cur_b = bu;
+        }
+      }
 #pragma unroll
       for (int c = 0; c < NCT; ++c) {
         const int co = (ct0 + c) * 16 + q * 4;
         const bool cok = (ct0 + c < P.NCTT) && co < A.Cout;
         f32x4 v = acc[g][c];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) sb0[c][r] = 0.f;
         if (gvalid[g] && cok) {
           if (A.bias) v += ld4(A.bias + co);
           f32x4 o = v;
@@ -223,7 +252,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams P) {
             } break;
             case LMN_EP_SE_BWD: {
 #pragma unroll
-              for (int r = 0; r < 4; ++r) sb0[c][r] = v[r] * lmn_gelu(ax[r]);
+              for (int r = 0; r < 4; ++r) sb[c][r] += v[r] * lmn_gelu(ax[r]);
             } break;
             default: break;
           }
@@ -236,24 +265,9 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams P) {
           if (A.out) *reinterpret_cast<f32x4*>(A.out + opix * A.out_cstride + co) = o;
         }
       }
-      if (A.epilogue == LMN_EP_SE_BWD) {
-        // reduce over the 16 pixels of the group (lanes sharing q), one atomic per channel per group
-#pragma unroll
-        for (int c = 0; c < NCT; ++c)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            float t = sb0[c][r];
-            t += __shfl_xor(t, 1, 64);
-            t += __shfl_xor(t, 2, 64);
-            t += __shfl_xor(t, 4, 64);
-            t += __shfl_xor(t, 8, 64);
-            const int co = (ct0 + c) * 16 + q * 4 + r;
-            if (n == 0 && (ct0 + c < P.NCTT) && co < A.Cout && (set * NPG + g) < total_groups)
-              atomicAdd(A.stats + (int64_t)gb[g] * A.Cout + co, t);
-          }
-      }
     }
   }
+  if (A.epilogue == LMN_EP_SE_BWD) flush_sb();
 
   // ---- per-channel statistics: wave shuffle -> LDS -> one global atomic per channel per block
   const bool chan_stats = (A.stats_mode == LMN_STATS_SUM_SQ) || (A.epilogue == LMN_EP_BN_BWD1);
@@ -427,7 +441,12 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(const WgradParams P) {
     }
   }
 
+  // ---- block-level reduction in LDS (4 waves -> 1), then ONE global atomic per weight per block.
   // D[m = 4q + r][nn = n]: cout = 16*mtile + 4q + r, cin = tile channel n
+  constexpr int NT = TAPS * NMT * NNT;
+  __shared__ float s_acc[NT * 256 + NMT * 16];
+  for (int i = threadIdx.x; i < NT * 256 + NMT * 16; i += 256) s_acc[i] = 0.f;
+  __syncthreads();
 #pragma unroll
   for (int tp = 0; tp < TAPS; ++tp)
 #pragma unroll
@@ -435,19 +454,32 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(const WgradParams P) {
 #pragma unroll
       for (int t = 0; t < NNT; ++t)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int co = (mt0 + m) * 16 + q * 4 + r;
-          if ((mt0 + m) < P.NMTT && co < A.Cout && sch[t] >= 0)
-            atomicAdd(A.dW + ((int64_t)co * P.Cin + sgci[t]) * TAPS + tp, acc[tp][m][t][r]);
-        }
+        for (int r = 0; r < 4; ++r) atomicAdd(&s_acc[(((tp * NMT + m) * NNT + t) * 4 + r) * 64 + lane], acc[tp][m][t][r]);
   if (A.db && nset == 0 && n == 0) {
 #pragma unroll
     for (int m = 0; m < NMT; ++m)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int co = (mt0 + m) * 16 + q * 4 + r;
-        if ((mt0 + m) < P.NMTT && co < A.Cout) atomicAdd(A.db + co, accb[m][r]);
-      }
+      for (int r = 0; r < 4; ++r) atomicAdd(&s_acc[NT * 256 + m * 16 + q * 4 + r], accb[m][r]);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < NT * 256; i += 256) {
+    const int ln = i & 63, r = (i >> 6) & 3, tile = i >> 8;
+    const int t = tile % NNT, m = (tile / NNT) % NMT, tp = tile / (NNT * NMT);
+    const int qq = ln >> 4, nn = ln & 15;
+    const int co = (mt0 + m) * 16 + qq * 4 + r;
+    const int nt = nt0 + t;
+    if ((mt0 + m) >= P.NMTT || co >= A.Cout || nt >= P.NNTT) continue;
+    int sidx = 0;
+    while (sidx + 1 < A.nsrc && nt >= P.ntile_off[sidx + 1]) ++sidx;
+    const int ch = (nt - P.ntile_off[sidx]) * 16 + nn;
+    if (ch >= A.src[sidx].C) continue;
+    atomicAdd(A.dW + ((int64_t)co * P.Cin + P.cbase[sidx] + ch) * TAPS + tp, s_acc[i]);
+  }
+  if (A.db && nset == 0) {
+    for (int i = threadIdx.x; i < NMT * 16; i += 256) {
+      const int co = mt0 * 16 + i;
+      if (co < A.Cout && (mt0 + i / 16) < P.NMTT) atomicAdd(A.db + co, s_acc[NT * 256 + i]);
+    }
   }
 }
 
@@ -629,11 +661,13 @@ int lmn_conv_wgrad(const lmn_wgrad_args_t* args, lmn_stream_t stream) {
   const int msets = (P.NMTT + NMT - 1) / NMT;
   P.nsets_n = (P.NNTT + NNT - 1) / NNT;
   const int gy = msets * P.nsets_n;
-  int64_t waves_x = P.total_steps / 8;
-  const int64_t cap = 4096 / gy > 8 ? 4096 / gy : 8;
-  if (waves_x > cap) waves_x = cap;
-  if (waves_x < 1) waves_x = 1;
-  const int blocks = (int)((waves_x + 3) / 4);
+  // K-split: ~512 blocks in total (2 per CU), at least 32 four-pixel steps per wave; every block ends with one
+  // LDS-reduced atomic per weight, so fewer, fatter blocks keep the atomic traffic negligible
+  int64_t blocks64 = P.total_steps / (4 * 32);
+  const int64_t cap = 512 / gy > 2 ? 512 / gy : 2;
+  if (blocks64 > cap) blocks64 = cap;
+  if (blocks64 < 1) blocks64 = 1;
+  const int blocks = (int)blocks64;
   hipStream_t st = (hipStream_t)stream;
   if (A.ksize == 1) {
     if (small)

@@ -144,4 +144,4 @@ def test_dropout_train_mode_is_active_and_consistent():
     assert all(torch.isfinite(p.grad).all() for p in m.parameters())
     m.eval()
     with torch.no_grad():
-        assert (m(x) - m(x)).abs().max() == 0
+        assert (m(x) - m(x)).abs().max() < 1e-5      # eval: no dropout (float-atomic SE sums may differ in the last bits)
