@@ -137,9 +137,13 @@ typedef struct {
   uint32_t dy_seed;
   float dy_p;
   float* dW;
-  float* db; /* or NULL */
+  float* db;        /* or NULL */
+  float* workspace; /* optional scratch for the deterministic two-stage K-split reduction (no atomics);   */
+  int64_t workspace_floats; /* size lmn_conv_wgrad_workspace() asks for; NULL/0 => LDS-reduced atomics   */
 } lmn_wgrad_args_t;
 int lmn_sizeof_wgrad_args(void);
+/* floats of workspace that make lmn_conv_wgrad use the two-stage reduction for this problem (0: not useful) */
+int64_t lmn_conv_wgrad_workspace(const lmn_wgrad_args_t* args);
 int lmn_conv_wgrad(const lmn_wgrad_args_t* args, lmn_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------

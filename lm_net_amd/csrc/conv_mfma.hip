@@ -92,7 +92,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams P) {
 
   for (int set = set_begin; set < set_end; ++set) {
     // ---- decode this wave's NPG pixel groups
-    int gb[NPG], gy[NPG], gx[NPG], gpy[NPG], gpx[NPG];
+    int gb[NPG], gbs[NPG], gy[NPG], gx[NPG], gpy[NPG], gpx[NPG];
     bool gvalid[NPG];
 #pragma unroll
     for (int g = 0; g < NPG; ++g) {
@@ -112,6 +112,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams P) {
       gy[g] = yc * cs + gpy[g];
       gx[g] = xc * cs + gpx[g];
       gvalid[g] = (gid < total_groups) && (pi < HWc);
+      gbs[g] = gid < total_groups ? b : 0;
     }
 
     f32x4 acc[NPG][NCT];
@@ -146,7 +147,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams P) {
         }
         ok = ok && iy >= 0 && iy < A.Hin && ix >= 0 && ix < A.Win;
         inb[g] = ok;
-        inpix[g] = ((int64_t)gb[g] * A.Hin + iy) * A.Win + ix;
+        inpix[g] = ok ? ((int64_t)gb[g] * A.Hin + iy) * A.Win + ix : 0;  // masked lanes read pixel 0 (always mapped)
         any = any || ok;
       }
       if (__ballot(any) == 0ull) continue;  // wave-uniform: no lane of any group reads this tap
@@ -157,28 +158,33 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams P) {
         for (int kbs = 0; kbs < P.nkb[s]; ++kbs) {
           const int ch = kbs * 16 + q * 4;
           const bool chok = ch < S.C;
+          // Loads are UNCONDITIONAL (masked lanes read a safe in-bounds address and are zeroed by a select):
+          // a load under a per-lane branch makes hipcc wait for each one separately (guide, section 5 trap (c)).
+          const int chs = chok ? ch : 0;
           f32x4 xv[NPG];
 #pragma unroll
-          for (int g = 0; g < NPG; ++g) {
-            f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (inb[g] && chok) {
-              v = ld4(S.ptr + inpix[g] * S.cstride + ch);
-              if (S.flags & LMN_SRC_GELU) {
+          for (int g = 0; g < NPG; ++g) xv[g] = ld4(S.ptr + inpix[g] * S.cstride + chs);
+          if (S.flags & LMN_SRC_GELU) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) v[j] = lmn_gelu(v[j]);
-              }
-              if (S.flags & LMN_SRC_DROP) {
-                const uint32_t idx = (uint32_t)(inpix[g] * S.C + ch);
+            for (int g = 0; g < NPG; ++g)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) v[j] *= lmn_drop_scale(S.drop_seed, idx + j, S.drop_p, P.inv_keep_src[s]);
-              }
-              if (S.scale) {
-                const f32x4 sc = ld4(S.scale + (int64_t)gb[g] * S.C + ch);
-                v *= sc;
-              }
-            }
-            xv[g] = v;
+              for (int j = 0; j < 4; ++j) xv[g][j] = lmn_gelu(xv[g][j]);
           }
+          if (S.flags & LMN_SRC_DROP) {
+#pragma unroll
+            for (int g = 0; g < NPG; ++g) {
+              const uint32_t idx = (uint32_t)(inpix[g] * S.C + chs);
+#pragma unroll
+              for (int j = 0; j < 4; ++j) xv[g][j] *= lmn_drop_scale(S.drop_seed, idx + j, S.drop_p, P.inv_keep_src[s]);
+            }
+          }
+          if (S.scale) {
+#pragma unroll
+            for (int g = 0; g < NPG; ++g) xv[g] *= ld4(S.scale + (int64_t)gbs[g] * S.C + chs);
+          }
+#pragma unroll
+          for (int g = 0; g < NPG; ++g)
+            if (!(inb[g] && chok)) xv[g] = f32x4{0.f, 0.f, 0.f, 0.f};
           const float* wp = P.a.wpack + ((((int64_t)tap * P.NKB + P.kb_off[s] + kbs) * P.NCTT + ct0) * 64 + lane) * 4;
 #pragma unroll
           for (int c = 0; c < NCT; ++c) {
@@ -206,64 +212,69 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams P) {
           cur_b = bu;
         }
       }
+      const int64_t opx = gvalid[g] ? opix : 0;  // masked lanes use a safe address; only stores/statistics are predicated
 #pragma unroll
       for (int c = 0; c < NCT; ++c) {
         const int co = (ct0 + c) * 16 + q * 4;
         const bool cok = (ct0 + c < P.NCTT) && co < A.Cout;
+        const bool live = gvalid[g] && cok;
+        const int cos = cok ? co : 0;
         f32x4 v = acc[g][c];
-        if (gvalid[g] && cok) {
-          if (A.bias) v += ld4(A.bias + co);
-          f32x4 o = v;
-          if (A.stats_mode == LMN_STATS_SUM_SQ) {
+        if (A.bias) v += ld4(A.bias + cos);
+        f32x4 o = v;
+        if (A.stats_mode == LMN_STATS_SUM_SQ && live) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) { st0[c][r] += v[r]; st1[c][r] += v[r] * v[r]; }
-          }
-          f32x4 ax = f32x4{0.f, 0.f, 0.f, 0.f};
-          if (A.aux) ax = ld4(A.aux + opix * A.aux_cstride + co);
-          switch (A.epilogue) {
-            case LMN_EP_AFFINE_ACT: {
-              const f32x4 s0 = ld4(A.p0 + co), s1 = ld4(A.p1 + co);
+          for (int r = 0; r < 4; ++r) { st0[c][r] += v[r]; st1[c][r] += v[r] * v[r]; }
+        }
+        f32x4 ax = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (A.aux) ax = ld4(A.aux + opx * A.aux_cstride + cos);
+        switch (A.epilogue) {
+          case LMN_EP_AFFINE_ACT: {
+            const f32x4 s0 = ld4(A.p0 + cos), s1 = ld4(A.p1 + cos);
 #pragma unroll
-              for (int r = 0; r < 4; ++r) o[r] = lmn_act(v[r] * s0[r] + s1[r], A.act);
-            } break;
-            case LMN_EP_DGELU: {
+            for (int r = 0; r < 4; ++r) o[r] = lmn_act(v[r] * s0[r] + s1[r], A.act);
+          } break;
+          case LMN_EP_DGELU: {
 #pragma unroll
-              for (int r = 0; r < 4; ++r) o[r] = v[r] * lmn_dgelu(ax[r]);
-            } break;
-            case LMN_EP_BN_BWD1: {
-              const f32x4 mu = ld4(A.p0 + co), rs = ld4(A.p1 + co), ga = ld4(A.p2 + co), be = ld4(A.p3 + co);
+            for (int r = 0; r < 4; ++r) o[r] = v[r] * lmn_dgelu(ax[r]);
+          } break;
+          case LMN_EP_BN_BWD1: {
+            const f32x4 mu = ld4(A.p0 + cos), rs = ld4(A.p1 + cos), ga = ld4(A.p2 + cos), be = ld4(A.p3 + cos);
 #pragma unroll
-              for (int r = 0; r < 4; ++r) {
-                const float zh = (v[r] - mu[r]) * rs[r];
-                const float h = ga[r] * zh + be[r];
-                o[r] = ax[r] * lmn_dact(h, A.act);
+            for (int r = 0; r < 4; ++r) {
+              const float zh = (v[r] - mu[r]) * rs[r];
+              const float h = ga[r] * zh + be[r];
+              o[r] = ax[r] * lmn_dact(h, A.act);
+              if (live) {
                 st0[c][r] += o[r];
                 st1[c][r] += o[r] * zh;
               }
-            } break;
-            case LMN_EP_BN_BWD2: {
-              const f32x4 mu = ld4(A.p0 + co), rs = ld4(A.p1 + co), c1 = ld4(A.p2 + co), c2 = ld4(A.p3 + co),
-                          c3 = ld4(A.p4 + co);
+            }
+          } break;
+          case LMN_EP_BN_BWD2: {
+            const f32x4 mu = ld4(A.p0 + cos), rs = ld4(A.p1 + cos), c1 = ld4(A.p2 + cos), c2 = ld4(A.p3 + cos),
+                        c3 = ld4(A.p4 + cos);
 #pragma unroll
-              for (int r = 0; r < 4; ++r) {
-                const float zh = (v[r] - mu[r]) * rs[r];
-                o[r] = c1[r] * ax[r] - c2[r] - zh * c3[r];
-              }
-            } break;
-            case LMN_EP_SE_BWD: {
+            for (int r = 0; r < 4; ++r) {
+              const float zh = (v[r] - mu[r]) * rs[r];
+              o[r] = c1[r] * ax[r] - c2[r] - zh * c3[r];
+            }
+          } break;
+          case LMN_EP_SE_BWD: {
+            if (live) {
 #pragma unroll
               for (int r = 0; r < 4; ++r) sb[c][r] += v[r] * lmn_gelu(ax[r]);
-            } break;
-            default: break;
-          }
-          if (A.drop_p > 0.f) {
-            const uint32_t idx = (uint32_t)(opix * A.Cout + co);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) o[r] *= lmn_drop_scale(A.drop_seed, idx + r, A.drop_p, P.inv_keep_ep);
-          }
-          if (A.residual) o += ld4(A.residual + opix * A.res_cstride + co);
-          if (A.out) *reinterpret_cast<f32x4*>(A.out + opix * A.out_cstride + co) = o;
+            }
+          } break;
+          default: break;
         }
+        if (A.drop_p > 0.f) {
+          const uint32_t idx = (uint32_t)(opx * A.Cout + cos);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) o[r] *= lmn_drop_scale(A.drop_seed, idx + r, A.drop_p, P.inv_keep_ep);
+        }
+        if (A.residual) o += ld4(A.residual + opx * A.res_cstride + cos);
+        if (A.out && live) *reinterpret_cast<f32x4*>(A.out + opx * A.out_cstride + cos) = o;
       }
     }
   }
@@ -345,12 +356,13 @@ struct WgradParams {
   int Cin;
   int nsets_n;       // number of cin tile sets
   int steps_per_img;
-  int64_t total_steps;
+  int total_steps;
   float inv_keep_src[3];
   float inv_keep_dy;
+  float* partial;    // two-stage reduction: [gridDim.y][gridDim.x][NT*256 + NMT*16] block partials, or NULL (atomics)
 };
 
-template <int TAPS, int NMT, int NNT>
+template <int TAPS, int NMT, int NNT, int U>
 __global__ __launch_bounds__(256) void wgrad_mfma_kernel(const WgradParams P) {
   const lmn_wgrad_args_t& A = P.a;
   const int lane = threadIdx.x & 63;
@@ -365,7 +377,7 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(const WgradParams P) {
   // which source / channel each of this wave's cin tiles maps to
   const float* sptr[NNT];
   const float* sscale[NNT];
-  int sC[NNT], scs[NNT], sflags[NNT], sch[NNT], sgci[NNT];
+  int sC[NNT], scs[NNT], sflags[NNT], sch[NNT];
   uint32_t sseed[NNT];
   float sp[NNT], sik[NNT];
 #pragma unroll
@@ -384,8 +396,10 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(const WgradParams P) {
     sp[t] = A.src[s].drop_p;
     sik[t] = P.inv_keep_src[s];
     sch[t] = (ok && ch < A.src[s].C) ? ch : -1;
-    sgci[t] = P.cbase[s] + ch;
   }
+  bool mok[NMT];
+#pragma unroll
+  for (int m = 0; m < NMT; ++m) mok[m] = (mt0 + m) < P.NMTT && ((mt0 + m) * 16 + n) < A.Cout;
 
   f32x4 acc[TAPS][NMT][NNT];
   f32x4 accb[NMT];
@@ -398,46 +412,58 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(const WgradParams P) {
 #pragma unroll
   for (int m = 0; m < NMT; ++m) accb[m] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  const int64_t sb = (wave * P.total_steps) / nwaves, se = ((wave + 1) * P.total_steps) / nwaves;
-  for (int64_t step = sb; step < se; ++step) {
-    const int b = (int)(step / P.steps_per_img);
-    const int pi = (int)(step - (int64_t)b * P.steps_per_img) * 4 + q;
-    const bool pok = pi < HWo;
-    const int y = pi / A.Wout, x = pi - y * A.Wout;
-    const int64_t opix = (int64_t)b * HWo + pi;
-    float av[NMT];
+  // contiguous range of 4-pixel K steps per wave; U steps are loaded together (U*(NMT + TAPS*NNT) independent
+  // loads in flight per lane) before their MFMAs issue: the loop is latency-bound otherwise
+  const int sb = (int)(((int64_t)wave * P.total_steps) / nwaves), se = (int)(((int64_t)(wave + 1) * P.total_steps) / nwaves);
+  for (int step0 = sb; step0 < se; step0 += U) {
+    float av[U][NMT], bv[U][TAPS][NNT];
 #pragma unroll
-    for (int m = 0; m < NMT; ++m) {
-      const int co = (mt0 + m) * 16 + n;
-      float v = 0.f;
-      if (pok && (mt0 + m) < P.NMTT && co < A.Cout) {
-        v = A.dy[opix * A.dy_cstride + co];
-        if (A.dy_flags & LMN_SRC_DROP) v *= lmn_drop_scale(A.dy_seed, (uint32_t)(opix * A.Cout + co), A.dy_p, P.inv_keep_dy);
+    for (int u = 0; u < U; ++u) {
+      const int step = step0 + u;
+      const int b = step / P.steps_per_img;
+      const int pi = (step - b * P.steps_per_img) * 4 + q;
+      const bool pok = step < se && pi < HWo;
+      const int y = pi / A.Wout, x = pi - y * A.Wout;
+      const int64_t opix = (int64_t)b * HWo + pi;
+      const int64_t opix_s = pok ? opix : 0;  // masked lanes load a safe address; zeroed by the select below
+#pragma unroll
+      for (int m = 0; m < NMT; ++m) {
+        const int co = mok[m] ? (mt0 + m) * 16 + n : 0;
+        float v = A.dy[opix_s * A.dy_cstride + co];
+        if (A.dy_flags & LMN_SRC_DROP) v *= lmn_drop_scale(A.dy_seed, (uint32_t)(opix_s * A.Cout + co), A.dy_p, P.inv_keep_dy);
+        av[u][m] = (pok && mok[m]) ? v : 0.f;
       }
-      av[m] = v;
-    }
-    if (A.db && nset == 0) {
 #pragma unroll
-      for (int m = 0; m < NMT; ++m) accb[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[m], 1.0f, accb[m], 0, 0, 0);
-    }
+      for (int tp = 0; tp < TAPS; ++tp) {
+        const int ty = (TAPS == 9) ? tp / 3 : 0, tx = (TAPS == 9) ? tp % 3 : 0;
+        const int iy = y * A.stride + ty - pad, ix = x * A.stride + tx - pad;
+        const bool ok = pok && iy >= 0 && iy < A.Hin && ix >= 0 && ix < A.Win;
+        const int64_t ipix = ok ? ((int64_t)b * A.Hin + iy) * A.Win + ix : 0;
+        const int bs = ok ? b : 0;
 #pragma unroll
-    for (int tp = 0; tp < TAPS; ++tp) {
-      const int ty = (TAPS == 9) ? tp / 3 : 0, tx = (TAPS == 9) ? tp % 3 : 0;
-      const int iy = y * A.stride + ty - pad, ix = x * A.stride + tx - pad;
-      const bool ok = pok && iy >= 0 && iy < A.Hin && ix >= 0 && ix < A.Win;
-      const int64_t ipix = ((int64_t)b * A.Hin + iy) * A.Win + ix;
-#pragma unroll
-      for (int t = 0; t < NNT; ++t) {
-        float v = 0.f;
-        if (ok && sch[t] >= 0) {
-          v = sptr[t][ipix * scs[t] + sch[t]];
+        for (int t = 0; t < NNT; ++t) {
+          const int chs = sch[t] >= 0 ? sch[t] : 0;
+          float v = sptr[t][ipix * scs[t] + chs];
           if (sflags[t] & LMN_SRC_GELU) v = lmn_gelu(v);
-          if (sflags[t] & LMN_SRC_DROP) v *= lmn_drop_scale(sseed[t], (uint32_t)(ipix * sC[t] + sch[t]), sp[t], sik[t]);
-          if (sscale[t]) v *= sscale[t][(int64_t)b * sC[t] + sch[t]];
+          if (sflags[t] & LMN_SRC_DROP) v *= lmn_drop_scale(sseed[t], (uint32_t)(ipix * sC[t] + chs), sp[t], sik[t]);
+          if (sscale[t]) v *= sscale[t][(int64_t)bs * sC[t] + chs];
+          bv[u][tp][t] = (ok && sch[t] >= 0) ? v : 0.f;
         }
-#pragma unroll
-        for (int m = 0; m < NMT; ++m) acc[tp][m][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[m], v, acc[tp][m][t], 0, 0, 0);
       }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (A.db && nset == 0) {
+#pragma unroll
+        for (int m = 0; m < NMT; ++m) accb[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u][m], 1.0f, accb[m], 0, 0, 0);
+      }
+#pragma unroll
+      for (int tp = 0; tp < TAPS; ++tp)
+#pragma unroll
+        for (int t = 0; t < NNT; ++t)
+#pragma unroll
+          for (int m = 0; m < NMT; ++m)
+            acc[tp][m][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u][m], bv[u][tp][t], acc[tp][m][t], 0, 0, 0);
     }
   }
 
@@ -462,6 +488,11 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(const WgradParams P) {
       for (int r = 0; r < 4; ++r) atomicAdd(&s_acc[NT * 256 + m * 16 + q * 4 + r], accb[m][r]);
   }
   __syncthreads();
+  if (P.partial) {  // two-stage: plain coalesced stores of this block's partial, summed by wgrad_reduce_kernel
+    float* dst = P.partial + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * (NT * 256 + NMT * 16);
+    for (int i = threadIdx.x; i < NT * 256 + NMT * 16; i += 256) dst[i] = s_acc[i];
+    return;
+  }
   for (int i = threadIdx.x; i < NT * 256; i += 256) {
     const int ln = i & 63, r = (i >> 6) & 3, tile = i >> 8;
     const int t = tile % NNT, m = (tile / NNT) % NMT, tp = tile / (NNT * NMT);
@@ -480,6 +511,46 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(const WgradParams P) {
       const int co = mt0 * 16 + i;
       if (co < A.Cout && (mt0 + i / 16) < P.NMTT) atomicAdd(A.db + co, s_acc[NT * 256 + i]);
     }
+  }
+}
+
+// second stage: dW[co][ci][tap] += sum over the K-split blocks of their partial tiles (fixed order => deterministic).
+// 1024 threads = 64 consecutive elements x 16 K-slices; each thread keeps 8 loads in flight.
+template <int TAPS, int NMT, int NNT>
+__global__ __launch_bounds__(1024) void wgrad_reduce_kernel(const WgradParams P, int nblk) {
+  const lmn_wgrad_args_t& A = P.a;
+  constexpr int NT = TAPS * NMT * NNT, PER = NT * 256 + NMT * 16;
+  __shared__ float red[16][64];
+  const int mset = blockIdx.y / P.nsets_n, nset = blockIdx.y - mset * P.nsets_n;
+  const int mt0 = mset * NMT, nt0 = nset * NNT;
+  const float* src = P.partial + (int64_t)blockIdx.y * nblk * PER;
+  const int e = threadIdx.x & 63, ks = threadIdx.x >> 6;
+  const int i = blockIdx.x * 64 + e;
+  float sum = 0.f;
+  if (i < PER) {
+#pragma unroll 8
+    for (int k = ks; k < nblk; k += 16) sum += src[(int64_t)k * PER + i];
+  }
+  red[ks][e] = sum;
+  __syncthreads();
+  if (ks != 0 || i >= PER) return;
+#pragma unroll
+  for (int k = 1; k < 16; ++k) sum += red[k][e];
+  if (i < NT * 256) {
+    const int ln = i & 63, r = (i >> 6) & 3, tile = i >> 8;
+    const int t = tile % NNT, m = (tile / NNT) % NMT, tp = tile / (NNT * NMT);
+    const int qq = ln >> 4, nn = ln & 15;
+    const int co = (mt0 + m) * 16 + qq * 4 + r;
+    const int nt = nt0 + t;
+    if ((mt0 + m) >= P.NMTT || co >= A.Cout || nt >= P.NNTT) return;
+    int sidx = 0;
+    while (sidx + 1 < A.nsrc && nt >= P.ntile_off[sidx + 1]) ++sidx;
+    const int ch = (nt - P.ntile_off[sidx]) * 16 + nn;
+    if (ch >= A.src[sidx].C) return;
+    A.dW[((int64_t)co * P.Cin + P.cbase[sidx] + ch) * TAPS + tp] += sum;
+  } else if (A.db && nset == 0) {
+    const int j = i - NT * 256, co = mt0 * 16 + j;
+    if (co < A.Cout && (mt0 + j / 16) < P.NMTT) A.db[co] += sum;
   }
 }
 
@@ -510,6 +581,23 @@ int lmn_abi_version(void) { return LMN_ABI_VERSION; }
 int lmn_sizeof_conv_args(void) { return (int)sizeof(lmn_conv_args_t); }
 int lmn_sizeof_src(void) { return (int)sizeof(lmn_src_t); }
 int lmn_sizeof_wgrad_args(void) { return (int)sizeof(lmn_wgrad_args_t); }
+
+int64_t lmn_conv_wgrad_workspace(const lmn_wgrad_args_t* a) {
+  if (!a) return 0;
+  int nntt = 0;
+  for (int s = 0; s < a->nsrc && s < 3; ++s) nntt += (a->src[s].C + 15) / 16;
+  const int nmtt = (a->Cout + 15) / 16;
+  const bool small = (nmtt == 1 || nntt == 1);
+  const int NMT = small ? 1 : 2, NNT = small ? 1 : 2;
+  const int gy = ((nmtt + NMT - 1) / NMT) * ((nntt + NNT - 1) / NNT);
+  const int64_t per = (int64_t)a->ksize * a->ksize * NMT * NNT * 256 + NMT * 16;
+  int64_t blocks = ((int64_t)a->B * ((a->Hout * a->Wout + 3) / 4)) / 64;
+  const int64_t cap = 1024 / gy > 2 ? 1024 / gy : 2;
+  if (blocks > cap) blocks = cap;
+  if (blocks <= 1) return 0;
+  const int64_t need = gy * blocks * per;
+  return need <= (int64_t)(16 << 20) ? need : 0;  // at most 64 MB of partials; larger problems use atomics
+}
 const char* lmn_last_error(void) { return g_lmn_err; }
 
 int64_t lmn_conv_pack_size(int ksize, int Cout, int nsrc, const int32_t* c) {
@@ -655,31 +743,44 @@ int lmn_conv_wgrad(const lmn_wgrad_args_t* args, lmn_stream_t stream) {
   P.inv_keep_dy = (A.dy_flags & LMN_SRC_DROP) ? 1.f / (1.f - A.dy_p) : 1.f;
   P.NMTT = (A.Cout + 15) / 16;
   P.steps_per_img = (A.Hout * A.Wout + 3) / 4;
-  P.total_steps = (int64_t)A.B * P.steps_per_img;
+  LMN_REQUIRE((int64_t)A.B * P.steps_per_img < (1LL << 31), "conv_wgrad: too many pixels");
+  P.total_steps = A.B * P.steps_per_img;
   const bool small = (P.NMTT == 1 || P.NNTT == 1);
   const int NMT = small ? 1 : 2, NNT = small ? 1 : 2;
   const int msets = (P.NMTT + NMT - 1) / NMT;
   P.nsets_n = (P.NNTT + NNT - 1) / NNT;
   const int gy = msets * P.nsets_n;
-  // K-split: ~512 blocks in total (2 per CU), at least 32 four-pixel steps per wave; every block ends with one
-  // LDS-reduced atomic per weight, so fewer, fatter blocks keep the atomic traffic negligible
-  int64_t blocks64 = P.total_steps / (4 * 32);
-  const int64_t cap = 512 / gy > 2 ? 512 / gy : 2;
+  const int taps = A.ksize * A.ksize;
+  const int64_t per = (int64_t)taps * NMT * NNT * 256 + NMT * 16;
+  // K-split: enough blocks to fill the chip (~1024 in total, >= 16 four-pixel steps per wave)
+  int64_t blocks64 = P.total_steps / (4 * 16);
+  const int64_t cap = 1024 / gy > 2 ? 1024 / gy : 2;
   if (blocks64 > cap) blocks64 = cap;
   if (blocks64 < 1) blocks64 = 1;
+  // two-stage reduction when the caller's workspace holds every block partial; else LDS-reduced atomics with fewer blocks
+  P.partial = nullptr;
+  if (A.workspace && blocks64 > 1 && (int64_t)gy * blocks64 * per <= A.workspace_floats) {
+    P.partial = A.workspace;
+  } else if (blocks64 > 512 / gy && 512 / gy >= 2) {
+    blocks64 = 512 / gy;
+  }
   const int blocks = (int)blocks64;
   hipStream_t st = (hipStream_t)stream;
+  const dim3 grid(blocks, gy);
+#define LMN_WG(T, M, N, UU)                                                                                         \
+  do {                                                                                                              \
+    hipLaunchKernelGGL((wgrad_mfma_kernel<T, M, N, UU>), grid, dim3(256), 0, st, P);                                \
+    if (P.partial) {                                                                                                \
+      const int rb = (int)((per + 63) / 64);                                                                        \
+      hipLaunchKernelGGL((wgrad_reduce_kernel<T, M, N>), dim3(rb, gy), dim3(1024), 0, st, P, blocks);               \
+    }                                                                                                               \
+  } while (0)
   if (A.ksize == 1) {
-    if (small)
-      hipLaunchKernelGGL((wgrad_mfma_kernel<1, 1, 1>), dim3(blocks, gy), dim3(256), 0, st, P);
-    else
-      hipLaunchKernelGGL((wgrad_mfma_kernel<1, 2, 2>), dim3(blocks, gy), dim3(256), 0, st, P);
+    if (small) LMN_WG(1, 1, 1, 8); else LMN_WG(1, 2, 2, 4);
   } else {
-    if (small)
-      hipLaunchKernelGGL((wgrad_mfma_kernel<9, 1, 1>), dim3(blocks, gy), dim3(256), 0, st, P);
-    else
-      hipLaunchKernelGGL((wgrad_mfma_kernel<9, 2, 2>), dim3(blocks, gy), dim3(256), 0, st, P);
+    if (small) LMN_WG(9, 1, 1, 4); else LMN_WG(9, 2, 2, 2);
   }
+#undef LMN_WG
   return lmn_launch_status("conv_wgrad");
 }
 

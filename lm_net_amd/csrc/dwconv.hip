@@ -43,9 +43,11 @@ __global__ __launch_bounds__(FW_THREADS) void dw_fwd_kernel(const float* __restr
     const int c4 = i % (FW_CCH / 4), pix = i / (FW_CCH / 4);
     const int r = pix / FW_RW, c = pix - r * FW_RW;
     const int gy = ty0 - 2 + r, gx = tx0 - 2 + c;
-    f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (gy >= 0 && gy < H && gx >= 0 && gx < W && ch0 + c4 * 4 < E)
-      v = *reinterpret_cast<const f32x4*>(xb + ((int64_t)gy * W + gx) * E + ch0 + c4 * 4);
+    // unconditional load from a clamped (in-bounds) address + select: loads under a per-lane branch serialise
+    const bool in = gy >= 0 && gy < H && gx >= 0 && gx < W && ch0 + c4 * 4 < E;
+    const int sy = in ? gy : 0, sx = in ? gx : 0, sc = in ? ch0 + c4 * 4 : 0;
+    f32x4 v = *reinterpret_cast<const f32x4*>(xb + ((int64_t)sy * W + sx) * E + sc);
+    if (!in) v = f32x4{0.f, 0.f, 0.f, 0.f};
     *reinterpret_cast<f32x4*>(&tile[pix * FW_CCH + c4 * 4]) = v;
   }
 
@@ -139,9 +141,10 @@ __device__ __forceinline__ void stage_tile(float* lds, const float* img, int H, 
     const int c4 = i % (DC / 4), pix = i / (DC / 4);
     const int r = pix / R, c = pix - r * R;
     const int gy = ty0 - HALO + r, gx = tx0 - HALO + c;
-    f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (gy >= 0 && gy < H && gx >= 0 && gx < W && ch0 + c4 * 4 < E)
-      v = *reinterpret_cast<const f32x4*>(img + ((int64_t)gy * W + gx) * E + ch0 + c4 * 4);
+    const bool in = gy >= 0 && gy < H && gx >= 0 && gx < W && ch0 + c4 * 4 < E;
+    const int sy = in ? gy : 0, sx = in ? gx : 0, sc = in ? ch0 + c4 * 4 : 0;
+    f32x4 v = *reinterpret_cast<const f32x4*>(img + ((int64_t)sy * W + sx) * E + sc);
+    if (!in) v = f32x4{0.f, 0.f, 0.f, 0.f};
     *reinterpret_cast<f32x4*>(&lds[pix * DC + c4 * 4]) = v;
   }
 }

@@ -40,13 +40,14 @@ class WgradArgs(C.Structure):
     _fields_ = [("B", C.c_int32), ("Hout", C.c_int32), ("Wout", C.c_int32), ("Hin", C.c_int32), ("Win", C.c_int32),
                 ("ksize", C.c_int32), ("stride", C.c_int32), ("nsrc", C.c_int32), ("Cout", C.c_int32),
                 ("src", SrcT * 3), ("dy", C.c_void_p), ("dy_cstride", C.c_int32), ("dy_flags", C.c_int32),
-                ("dy_seed", C.c_uint32), ("dy_p", C.c_float), ("dW", C.c_void_p), ("db", C.c_void_p)]
+                ("dy_seed", C.c_uint32), ("dy_p", C.c_float), ("dW", C.c_void_p), ("db", C.c_void_p),
+                ("workspace", C.c_void_p), ("workspace_floats", C.c_int64)]
 
 
 # every symbol include/lmnet_hip.h declares (the CPU test suite checks the library exports all of them)
 SYMBOLS = [
     "lmn_abi_version", "lmn_sizeof_conv_args", "lmn_sizeof_src", "lmn_sizeof_wgrad_args", "lmn_last_error",
-    "lmn_conv_pack_size", "lmn_conv_pack", "lmn_conv_fwd", "lmn_conv_wgrad",
+    "lmn_conv_pack_size", "lmn_conv_pack", "lmn_conv_fwd", "lmn_conv_wgrad", "lmn_conv_wgrad_workspace",
     "lmn_dw_stats", "lmn_dw_fwd", "lmn_dw_merge", "lmn_dw_bwd_stats", "lmn_dw_bwd_coef", "lmn_dw_bwd",
     "lmn_se_fwd", "lmn_se_bwd", "lmn_na_fwd", "lmn_na_bwd", "lmn_gattn_fwd", "lmn_gattn_bwd",
     "lmn_ln_fwd", "lmn_ln_bwd", "lmn_bnact_fwd", "lmn_bnact_bwd_stats", "lmn_bnact_bwd",
@@ -72,6 +73,7 @@ def load():
             raise RuntimeError("lm_net_amd: %s does not export %s" % (LIB_PATH, name))
     lib.lmn_last_error.restype = C.c_char_p
     lib.lmn_conv_pack_size.restype = C.c_int64
+    lib.lmn_conv_wgrad_workspace.restype = C.c_int64
     if lib.lmn_abi_version() != ABI_VERSION:
         raise RuntimeError("lm_net_amd: ABI version mismatch")
     if (lib.lmn_sizeof_conv_args() != C.sizeof(ConvArgs) or lib.lmn_sizeof_src() != C.sizeof(SrcT)
@@ -217,7 +219,23 @@ def conv_wgrad(srcs, dy, dW, db, *, B, Hin, Win, Hout, Wout, Cout, ksize=1, stri
     a.dy_flags, a.dy_seed, a.dy_p = dy_flags, dy_seed, dy_p
     a.dW = dW.data_ptr()
     a.db = db.data_ptr() if db is not None else None
+    need = int(load().lmn_conv_wgrad_workspace(C.byref(a)))
+    if need > 0:
+        ws = _workspace(dW.device, need)
+        a.workspace, a.workspace_floats = ws.data_ptr(), ws.numel()
     _check(load().lmn_conv_wgrad(C.byref(a), _stream()), "conv_wgrad")
+
+
+_ws_cache = {}
+
+
+def _workspace(device, nfloats):
+    """Grow-only scratch buffer per device (stream-ordered reuse: all users run on the current stream)."""
+    ws = _ws_cache.get(device)
+    if ws is None or ws.numel() < nfloats:
+        ws = torch.empty(max(nfloats, 1 << 20), device=device, dtype=torch.float32)
+        _ws_cache[device] = ws
+    return ws
 
 
 # ------------------------------------------------------------------------------------------ depthwise block
