@@ -121,33 +121,52 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams P) {
 #pragma unroll
       for (int c = 0; c < NCT; ++c) acc[g][c] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+    // input pixel of (group lane, tap) = per-lane base + a wave-uniform tap delta (32-bit index math):
+    //   forward:        in = out*stride + (t - pad)
+    //   data-gradient:  in = out + pad - t            (stride 1)
+    //                   in = out_c + ((parity + pad - t) >> 1), only taps of matching parity   (stride 2)
+    int by[NPG], bx[NPG], bp[NPG], upy[NPG], upx[NPG];
+#pragma unroll
+    for (int g = 0; g < NPG; ++g) {
+      upy[g] = __builtin_amdgcn_readfirstlane(gpy[g]);
+      upx[g] = __builtin_amdgcn_readfirstlane(gpx[g]);
+      if (!A.transposed) {
+        by[g] = gy[g] * A.stride;
+        bx[g] = gx[g] * A.stride;
+      } else if (A.stride == 2) {
+        by[g] = gy[g] >> 1;
+        bx[g] = gx[g] >> 1;
+      } else {
+        by[g] = gy[g];
+        bx[g] = gx[g];
+      }
+      bp[g] = (gbs[g] * A.Hin + by[g]) * A.Win + bx[g];
+    }
     for (int tap = 0; tap < TAPS; ++tap) {
       const int ty = (TAPS == 9) ? tap / 3 : 0, tx = (TAPS == 9) ? tap - ty * 3 : 0;
-      int64_t inpix[NPG];
+      int inpix[NPG];
       bool inb[NPG];
       bool any = false;
 #pragma unroll
       for (int g = 0; g < NPG; ++g) {
-        int iy, ix;
-        bool ok = gvalid[g];
+        int dty, dtx;
+        bool tok = true;
         if (!A.transposed) {
-          iy = gy[g] * A.stride + ty - pad;
-          ix = gx[g] * A.stride + tx - pad;
+          dty = ty - pad;
+          dtx = tx - pad;
+        } else if (A.stride == 2) {
+          const int ey = upy[g] + pad - ty, ex = upx[g] + pad - tx;
+          tok = !((ey | ex) & 1);
+          dty = ey >> 1;
+          dtx = ex >> 1;
         } else {
-          const int ny = gy[g] + pad - ty, nx = gx[g] + pad - tx;
-          if (A.stride == 2) {
-            ok = ok && !((ny | nx) & 1);
-            iy = ny >> 1;
-            ix = nx >> 1;
-          } else {
-            iy = ny;
-            ix = nx;
-          }
-          ok = ok && ny >= 0 && nx >= 0;
+          dty = pad - ty;
+          dtx = pad - tx;
         }
-        ok = ok && iy >= 0 && iy < A.Hin && ix >= 0 && ix < A.Win;
+        const int iy = by[g] + dty, ix = bx[g] + dtx;
+        const bool ok = gvalid[g] && tok && (unsigned)iy < (unsigned)A.Hin && (unsigned)ix < (unsigned)A.Win;
         inb[g] = ok;
-        inpix[g] = ok ? ((int64_t)gb[g] * A.Hin + iy) * A.Win + ix : 0;  // masked lanes read pixel 0 (always mapped)
+        inpix[g] = ok ? bp[g] + dty * A.Win + dtx : 0;  // masked lanes read pixel 0 (always mapped)
         any = any || ok;
       }
       if (__ballot(any) == 0ull) continue;  // wave-uniform: no lane of any group reads this tap
@@ -163,7 +182,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams P) {
           const int chs = chok ? ch : 0;
           f32x4 xv[NPG];
 #pragma unroll
-          for (int g = 0; g < NPG; ++g) xv[g] = ld4(S.ptr + inpix[g] * S.cstride + chs);
+          for (int g = 0; g < NPG; ++g) xv[g] = ld4(S.ptr + (uint32_t)(inpix[g] * S.cstride + chs));
           if (S.flags & LMN_SRC_GELU) {
 #pragma unroll
             for (int g = 0; g < NPG; ++g)
@@ -180,7 +199,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams P) {
           }
           if (S.scale) {
 #pragma unroll
-            for (int g = 0; g < NPG; ++g) xv[g] *= ld4(S.scale + (int64_t)gbs[g] * S.C + chs);
+            for (int g = 0; g < NPG; ++g) xv[g] *= ld4(S.scale + gbs[g] * S.C + chs);
           }
 #pragma unroll
           for (int g = 0; g < NPG; ++g)
@@ -204,7 +223,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams P) {
     // ---- epilogue: lane holds channels co..co+3 of its pixel, per (g, c)
 #pragma unroll
     for (int g = 0; g < NPG; ++g) {
-      const int64_t opix = ((int64_t)gb[g] * A.Hout + gy[g]) * A.Wout + gx[g];
+      const int opix = (gbs[g] * A.Hout + gy[g]) * A.Wout + gx[g];
       if (A.epilogue == LMN_EP_SE_BWD && (set * NPG + g) < total_groups) {
         const int bu = __builtin_amdgcn_readfirstlane(gb[g]);  // wave-uniform: groups never straddle images
         if (bu != cur_b) {
@@ -212,7 +231,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams P) {
           cur_b = bu;
         }
       }
-      const int64_t opx = gvalid[g] ? opix : 0;  // masked lanes use a safe address; only stores/statistics are predicated
+      const uint32_t opx = gvalid[g] ? (uint32_t)opix : 0u;  // masked lanes use a safe address; only stores/statistics are predicated
 #pragma unroll
       for (int c = 0; c < NCT; ++c) {
         const int co = (ct0 + c) * 16 + q * 4;
@@ -360,6 +379,8 @@ struct WgradParams {
   float inv_keep_src[3];
   float inv_keep_dy;
   float* partial;    // two-stage reduction: [gridDim.y][gridDim.x][NT*256 + NMT*16] block partials, or NULL (atomics)
+  // LDS-staged kernel: output-pixel tile TH x TW, its input window XH x XW, LDS pixel strides, tile counts
+  int TH, TW, XH, XW, CSx, CSy, tiles_x, tiles_y, total_tiles;
 };
 
 template <int TAPS, int NMT, int NNT, int U>
@@ -413,10 +434,21 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(const WgradParams P) {
   for (int m = 0; m < NMT; ++m) accb[m] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   // contiguous range of 4-pixel K steps per wave; U steps are loaded together (U*(NMT + TAPS*NNT) independent
-  // loads in flight per lane) before their MFMAs issue: the loop is latency-bound otherwise
+  // loads in flight per lane) before their MFMAs issue.  Index math is 32-bit: per step ONE centre offset per
+  // operand, per tap a wave-uniform delta and two unsigned bounds compares.
   const int sb = (int)(((int64_t)wave * P.total_steps) / nwaves), se = (int)(((int64_t)(wave + 1) * P.total_steps) / nwaves);
+  int tdelta[TAPS];  // (ty - pad) * Win + (tx - pad)
+#pragma unroll
+  for (int tp = 0; tp < TAPS; ++tp) {
+    const int ty = (TAPS == 9) ? tp / 3 : 0, tx = (TAPS == 9) ? tp % 3 : 0;
+    tdelta[tp] = (ty - pad) * A.Win + (tx - pad);
+  }
+  bool any_tf = (A.dy_flags & LMN_SRC_DROP) != 0;
+#pragma unroll
+  for (int t = 0; t < NNT; ++t) any_tf = any_tf || (sflags[t] != 0) || (sscale[t] != nullptr);
   for (int step0 = sb; step0 < se; step0 += U) {
     float av[U][NMT], bv[U][TAPS][NNT];
+    // ---- phase 1: every load of the batch, straight-line (no branch between loads => all in flight together)
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int step = step0 + u;
@@ -424,29 +456,55 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(const WgradParams P) {
       const int pi = (step - b * P.steps_per_img) * 4 + q;
       const bool pok = step < se && pi < HWo;
       const int y = pi / A.Wout, x = pi - y * A.Wout;
-      const int64_t opix = (int64_t)b * HWo + pi;
-      const int64_t opix_s = pok ? opix : 0;  // masked lanes load a safe address; zeroed by the select below
+      const int opix_s = pok ? b * HWo + pi : 0;  // masked lanes load a safe address; zeroed in phase 2
+#pragma unroll
+      for (int m = 0; m < NMT; ++m) av[u][m] = A.dy[(uint32_t)(opix_s * A.dy_cstride + (mok[m] ? (mt0 + m) * 16 + n : 0))];
+      const int cy = y * A.stride, cx = x * A.stride;       // centre tap's input pixel is (cy, cx)
+      const int cpix = (b * A.Hin + cy) * A.Win + cx;
+#pragma unroll
+      for (int tp = 0; tp < TAPS; ++tp) {
+        const int ty = (TAPS == 9) ? tp / 3 : 0, tx = (TAPS == 9) ? tp % 3 : 0;
+        const int iy = cy + ty - pad, ix = cx + tx - pad;
+        const bool ok = pok && (unsigned)iy < (unsigned)A.Hin && (unsigned)ix < (unsigned)A.Win;
+        const int ipix = ok ? cpix + tdelta[tp] : 0;
+#pragma unroll
+        for (int t = 0; t < NNT; ++t) bv[u][tp][t] = sptr[t][(uint32_t)(ipix * scs[t] + (sch[t] >= 0 ? sch[t] : 0))];
+      }
+    }
+    // ---- phase 2: on-load transforms (rare) and masking
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int step = step0 + u;
+      const int b = step / P.steps_per_img;
+      const int pi = (step - b * P.steps_per_img) * 4 + q;
+      const bool pok = step < se && pi < HWo;
+      const int y = pi / A.Wout, x = pi - y * A.Wout;
+      const int opix_s = pok ? b * HWo + pi : 0;
+      const int cy = y * A.stride, cx = x * A.stride;
+      const int cpix = (b * A.Hin + cy) * A.Win + cx;
 #pragma unroll
       for (int m = 0; m < NMT; ++m) {
-        const int co = mok[m] ? (mt0 + m) * 16 + n : 0;
-        float v = A.dy[opix_s * A.dy_cstride + co];
-        if (A.dy_flags & LMN_SRC_DROP) v *= lmn_drop_scale(A.dy_seed, (uint32_t)(opix_s * A.Cout + co), A.dy_p, P.inv_keep_dy);
+        float v = av[u][m];
+        if (any_tf && (A.dy_flags & LMN_SRC_DROP))
+          v *= lmn_drop_scale(A.dy_seed, (uint32_t)(opix_s * A.Cout + (mok[m] ? (mt0 + m) * 16 + n : 0)), A.dy_p, P.inv_keep_dy);
         av[u][m] = (pok && mok[m]) ? v : 0.f;
       }
 #pragma unroll
       for (int tp = 0; tp < TAPS; ++tp) {
         const int ty = (TAPS == 9) ? tp / 3 : 0, tx = (TAPS == 9) ? tp % 3 : 0;
-        const int iy = y * A.stride + ty - pad, ix = x * A.stride + tx - pad;
-        const bool ok = pok && iy >= 0 && iy < A.Hin && ix >= 0 && ix < A.Win;
-        const int64_t ipix = ok ? ((int64_t)b * A.Hin + iy) * A.Win + ix : 0;
+        const int iy = cy + ty - pad, ix = cx + tx - pad;
+        const bool ok = pok && (unsigned)iy < (unsigned)A.Hin && (unsigned)ix < (unsigned)A.Win;
+        const int ipix = ok ? cpix + tdelta[tp] : 0;
         const int bs = ok ? b : 0;
 #pragma unroll
         for (int t = 0; t < NNT; ++t) {
-          const int chs = sch[t] >= 0 ? sch[t] : 0;
-          float v = sptr[t][ipix * scs[t] + chs];
-          if (sflags[t] & LMN_SRC_GELU) v = lmn_gelu(v);
-          if (sflags[t] & LMN_SRC_DROP) v *= lmn_drop_scale(sseed[t], (uint32_t)(ipix * sC[t] + chs), sp[t], sik[t]);
-          if (sscale[t]) v *= sscale[t][(int64_t)bs * sC[t] + chs];
+          float v = bv[u][tp][t];
+          if (any_tf) {
+            const int chs = sch[t] >= 0 ? sch[t] : 0;
+            if (sflags[t] & LMN_SRC_GELU) v = lmn_gelu(v);
+            if (sflags[t] & LMN_SRC_DROP) v *= lmn_drop_scale(sseed[t], (uint32_t)(ipix * sC[t] + chs), sp[t], sik[t]);
+            if (sscale[t]) v *= sscale[t][bs * sC[t] + chs];
+          }
           bv[u][tp][t] = (ok && sch[t] >= 0) ? v : 0.f;
         }
       }
@@ -508,6 +566,167 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(const WgradParams P) {
   }
   if (A.db && nset == 0) {
     for (int i = threadIdx.x; i < NMT * 16; i += 256) {
+      const int co = mt0 * 16 + i;
+      if (co < A.Cout && (mt0 + i / 16) < P.NMTT) atomicAdd(A.db + co, s_acc[NT * 256 + i]);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------ weight gradient, LDS-staged
+// dW[co][ci][tap] = sum_p dy[p][co] * x[p*s + tap - pad][ci]   as an MFMA GEMM with K = pixels.
+// A block walks a contiguous range of output-pixel tiles.  Per tile the input window (with halo) and the dy
+// tile are staged ONCE into LDS by coalesced float4 loads (on-load transforms -- GELU, SE scale, dropout mask
+// -- applied here, once per element); the four waves then split the tile's 4-pixel K steps and read both MFMA
+// operands from LDS as conflict-free ds_read_b32 (lanes along channels; pixel stride = 16 mod 32 banks).
+// One global load per element instead of one per (element, tap): the direct form was bound by the texture
+// addresser (one 4-segment dword load per MFMA).  Accumulators stay in registers across all tiles of the block.
+template <int TAPS, int NMT, int NNT>
+__global__ __launch_bounds__(256, 2) void wgrad_lds_kernel(const WgradParams P) {
+  const lmn_wgrad_args_t& A = P.a;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* XS = smem;                                   // [XH*XW][CSx]  (NNT*16 channels used)
+  float* YS = smem + P.XH * P.XW * P.CSx;             // [TH*TW][CSy]  (NMT*16 channels used)
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int q = lane >> 4, n = lane & 15;
+  const int mset = blockIdx.y / P.nsets_n, nset = blockIdx.y - mset * P.nsets_n;
+  const int mt0 = mset * NMT, nt0 = nset * NNT;
+  const int pad = A.ksize >> 1;
+  const int NP = P.TH * P.TW;
+
+  f32x4 acc[TAPS][NMT][NNT];
+  f32x4 accb[NMT];
+#pragma unroll
+  for (int tp = 0; tp < TAPS; ++tp)
+#pragma unroll
+    for (int m = 0; m < NMT; ++m)
+#pragma unroll
+      for (int t = 0; t < NNT; ++t) acc[tp][m][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int m = 0; m < NMT; ++m) accb[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int t_begin = (int)(((int64_t)blockIdx.x * P.total_tiles) / gridDim.x);
+  const int t_end = (int)(((int64_t)(blockIdx.x + 1) * P.total_tiles) / gridDim.x);
+  for (int tile = t_begin; tile < t_end; ++tile) {
+    const int b = tile / (P.tiles_x * P.tiles_y), tt = tile - b * P.tiles_x * P.tiles_y;
+    const int oy0 = (tt / P.tiles_x) * P.TH, ox0 = (tt % P.tiles_x) * P.TW;
+    const int iy0 = oy0 * A.stride - pad, ix0 = ox0 * A.stride - pad;
+    __syncthreads();  // previous tile's reads are done
+    // ---- stage the input window: float4 items (pixel, cin tile, quad)
+    for (int i = tid; i < P.XH * P.XW * NNT * 4; i += 256) {
+      const int j = i & 3, t = (i >> 2) % NNT, pix = i / (4 * NNT);
+      const int r = pix / P.XW, c = pix - r * P.XW;
+      const int iy = iy0 + r, ix = ix0 + c;
+      const int nt = nt0 + t;
+      int s = 0;
+      while (s + 1 < A.nsrc && nt >= P.ntile_off[s + 1]) ++s;
+      const lmn_src_t& S = A.src[s];
+      const int ch = (nt - P.ntile_off[s]) * 16 + j * 4;
+      const bool ok = nt < P.NNTT && ch < S.C && (unsigned)iy < (unsigned)A.Hin && (unsigned)ix < (unsigned)A.Win;
+      const int gp = ok ? (b * A.Hin + iy) * A.Win + ix : 0;
+      const int chs = ok ? ch : 0;
+      f32x4 v = ld4(S.ptr + (uint32_t)(gp * S.cstride + chs));
+      if (S.flags & LMN_SRC_GELU) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = lmn_gelu(v[k]);
+      }
+      if (S.flags & LMN_SRC_DROP) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] *= lmn_drop_scale(S.drop_seed, (uint32_t)(gp * S.C + chs + k), S.drop_p, P.inv_keep_src[s]);
+      }
+      if (S.scale) v *= ld4(S.scale + (ok ? b : 0) * S.C + chs);
+      if (!ok) v = f32x4{0.f, 0.f, 0.f, 0.f};
+      *reinterpret_cast<f32x4*>(&XS[pix * P.CSx + t * 16 + j * 4]) = v;
+    }
+    // ---- stage the dy tile
+    for (int i = tid; i < NP * NMT * 4; i += 256) {
+      const int j = i & 3, m = (i >> 2) % NMT, pix = i / (4 * NMT);
+      const int r = pix / P.TW, c = pix - r * P.TW;
+      const int oy = oy0 + r, ox = ox0 + c;
+      const int co = (mt0 + m) * 16 + j * 4;
+      const bool ok = (mt0 + m) < P.NMTT && co < A.Cout && oy < A.Hout && ox < A.Wout;
+      const int gp = ok ? (b * A.Hout + oy) * A.Wout + ox : 0;
+      const int cos = ok ? co : 0;
+      f32x4 v = ld4(A.dy + (uint32_t)(gp * A.dy_cstride + cos));
+      if (A.dy_flags & LMN_SRC_DROP) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] *= lmn_drop_scale(A.dy_seed, (uint32_t)(gp * A.Cout + cos + k), A.dy_p, P.inv_keep_dy);
+      }
+      if (!ok) v = f32x4{0.f, 0.f, 0.f, 0.f};
+      *reinterpret_cast<f32x4*>(&YS[pix * P.CSy + m * 16 + j * 4]) = v;
+    }
+    __syncthreads();
+    // ---- MFMA over this wave's K steps (4 consecutive tile pixels each)
+    for (int ks = wv; ks * 4 < NP; ks += 4) {
+      const int pix = ks * 4 + q;
+      const int pr = pix / P.TW, pc = pix - pr * P.TW;
+      const bool pin = pix < NP;
+      float av[NMT];
+#pragma unroll
+      for (int m = 0; m < NMT; ++m) {
+        const float t0 = YS[(pin ? pix : 0) * P.CSy + m * 16 + n];  // unconditional LDS read, masked by select
+        av[m] = pin ? t0 : 0.f;
+      }
+      if (A.db && nset == 0) {
+#pragma unroll
+        for (int m = 0; m < NMT; ++m) accb[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[m], 1.0f, accb[m], 0, 0, 0);
+      }
+      const int xb = pin ? ((pr * A.stride) * P.XW + pc * A.stride) * P.CSx + n : n;
+#pragma unroll
+      for (int tp = 0; tp < TAPS; ++tp) {
+        const int ty = (TAPS == 9) ? tp / 3 : 0, tx = (TAPS == 9) ? tp % 3 : 0;
+        const int off = xb + (ty * P.XW + tx) * P.CSx;
+#pragma unroll
+        for (int t = 0; t < NNT; ++t) {
+          const float braw = XS[off + t * 16];
+          const float bvv = pin ? braw : 0.f;
+#pragma unroll
+          for (int m = 0; m < NMT; ++m) acc[tp][m][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[m], bvv, acc[tp][m][t], 0, 0, 0);
+        }
+      }
+    }
+  }
+
+  // ---- block-level reduction in LDS (4 waves -> 1)
+  constexpr int NT = TAPS * NMT * NNT;
+  __syncthreads();
+  float* s_acc = smem;  // reuse the staging area (>= NT*256 + NMT*16 floats, checked on the host)
+  for (int i = tid; i < NT * 256 + NMT * 16; i += 256) s_acc[i] = 0.f;
+  __syncthreads();
+#pragma unroll
+  for (int tp = 0; tp < TAPS; ++tp)
+#pragma unroll
+    for (int m = 0; m < NMT; ++m)
+#pragma unroll
+      for (int t = 0; t < NNT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) atomicAdd(&s_acc[(((tp * NMT + m) * NNT + t) * 4 + r) * 64 + lane], acc[tp][m][t][r]);
+  if (A.db && nset == 0 && n == 0) {
+#pragma unroll
+    for (int m = 0; m < NMT; ++m)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) atomicAdd(&s_acc[NT * 256 + m * 16 + q * 4 + r], accb[m][r]);
+  }
+  __syncthreads();
+  if (P.partial) {
+    float* dst = P.partial + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * (NT * 256 + NMT * 16);
+    for (int i = tid; i < NT * 256 + NMT * 16; i += 256) dst[i] = s_acc[i];
+    return;
+  }
+  for (int i = tid; i < NT * 256; i += 256) {
+    const int ln = i & 63, r = (i >> 6) & 3, tl = i >> 8;
+    const int t = tl % NNT, m = (tl / NNT) % NMT, tp = tl / (NNT * NMT);
+    const int qq = ln >> 4, nn = ln & 15;
+    const int co = (mt0 + m) * 16 + qq * 4 + r;
+    const int nt = nt0 + t;
+    if ((mt0 + m) >= P.NMTT || co >= A.Cout || nt >= P.NNTT) continue;
+    int sidx = 0;
+    while (sidx + 1 < A.nsrc && nt >= P.ntile_off[sidx + 1]) ++sidx;
+    const int ch = (nt - P.ntile_off[sidx]) * 16 + nn;
+    if (ch >= A.src[sidx].C) continue;
+    atomicAdd(A.dW + ((int64_t)co * P.Cin + P.cbase[sidx] + ch) * TAPS + tp, s_acc[i]);
+  }
+  if (A.db && nset == 0) {
+    for (int i = tid; i < NMT * 16; i += 256) {
       const int co = mt0 * 16 + i;
       if (co < A.Cout && (mt0 + i / 16) < P.NMTT) atomicAdd(A.db + co, s_acc[NT * 256 + i]);
     }
@@ -591,7 +810,13 @@ int64_t lmn_conv_wgrad_workspace(const lmn_wgrad_args_t* a) {
   const int NMT = small ? 1 : 2, NNT = small ? 1 : 2;
   const int gy = ((nmtt + NMT - 1) / NMT) * ((nntt + NNT - 1) / NNT);
   const int64_t per = (int64_t)a->ksize * a->ksize * NMT * NNT * 256 + NMT * 16;
-  int64_t blocks = ((int64_t)a->B * ((a->Hout * a->Wout + 3) / 4)) / 64;
+  const int npmax = a->stride == 2 ? 64 : 256;
+  int TW = a->Wout < (a->ksize == 1 ? npmax : 32) ? a->Wout : (a->ksize == 1 ? npmax : 32);
+  if (a->stride == 2 && TW > 16) TW = 16;
+  int TH = npmax / TW;
+  if (TH > a->Hout) TH = a->Hout;
+  if (TH < 1) TH = 1;
+  int64_t blocks = (int64_t)a->B * ((a->Wout + TW - 1) / TW) * ((a->Hout + TH - 1) / TH);
   const int64_t cap = 1024 / gy > 2 ? 1024 / gy : 2;
   if (blocks > cap) blocks = cap;
   if (blocks <= 1) return 0;
@@ -655,6 +880,14 @@ int lmn_conv_fwd(const lmn_conv_args_t* args, lmn_stream_t stream) {
       LMN_REQUIRE(A.src[s].drop_p >= 0.f && A.src[s].drop_p < 1.f, "conv_fwd: source dropout p");
       P.inv_keep_src[s] = 1.f / (1.f - A.src[s].drop_p);
     }
+  }
+  {  // kernels index with 32-bit element offsets
+    const int64_t lim = (1LL << 31) - 1;
+    for (int s = 0; s < A.nsrc; ++s)
+      LMN_REQUIRE((int64_t)A.B * A.Hin * A.Win * A.src[s].cstride <= lim, "conv_fwd: source %d larger than 2^31 elements", s);
+    const int64_t ocs = A.out_cstride > A.aux_cstride ? A.out_cstride : A.aux_cstride;
+    LMN_REQUIRE((int64_t)A.B * A.Hout * A.Wout * (ocs > A.res_cstride ? ocs : A.res_cstride) <= lim && (int64_t)A.B * A.Hout * A.Wout * A.Cout <= lim,
+                "conv_fwd: output larger than 2^31 elements");
   }
   LMN_REQUIRE(A.drop_p >= 0.f && A.drop_p < 1.f, "conv_fwd: dropout p %f", A.drop_p);
   P.inv_keep_ep = 1.f / (1.f - A.drop_p);
@@ -744,6 +977,9 @@ int lmn_conv_wgrad(const lmn_wgrad_args_t* args, lmn_stream_t stream) {
   P.NMTT = (A.Cout + 15) / 16;
   P.steps_per_img = (A.Hout * A.Wout + 3) / 4;
   LMN_REQUIRE((int64_t)A.B * P.steps_per_img < (1LL << 31), "conv_wgrad: too many pixels");
+  for (int s = 0; s < A.nsrc; ++s)
+    LMN_REQUIRE((int64_t)A.B * A.Hin * A.Win * A.src[s].cstride < (1LL << 31), "conv_wgrad: source %d larger than 2^31 elements", s);
+  LMN_REQUIRE((int64_t)A.B * A.Hout * A.Wout * A.dy_cstride < (1LL << 31), "conv_wgrad: dy larger than 2^31 elements");
   P.total_steps = A.B * P.steps_per_img;
   const bool small = (P.NMTT == 1 || P.NNTT == 1);
   const int NMT = small ? 1 : 2, NNT = small ? 1 : 2;
@@ -752,8 +988,26 @@ int lmn_conv_wgrad(const lmn_wgrad_args_t* args, lmn_stream_t stream) {
   const int gy = msets * P.nsets_n;
   const int taps = A.ksize * A.ksize;
   const int64_t per = (int64_t)taps * NMT * NNT * 256 + NMT * 16;
-  // K-split: enough blocks to fill the chip (~1024 in total, >= 16 four-pixel steps per wave)
-  int64_t blocks64 = P.total_steps / (4 * 16);
+  // ---- tile geometry of the LDS-staged kernel
+  const int npmax = A.stride == 2 ? 64 : 256;
+  P.TW = A.Wout < (A.ksize == 1 ? npmax : 32) ? A.Wout : (A.ksize == 1 ? npmax : 32);
+  if (A.stride == 2 && P.TW > 16) P.TW = 16;
+  P.TH = npmax / P.TW;
+  if (P.TH > A.Hout) P.TH = A.Hout;
+  if (P.TH < 1) P.TH = 1;
+  P.XH = (P.TH - 1) * A.stride + A.ksize;
+  P.XW = (P.TW - 1) * A.stride + A.ksize;
+  // LDS pixel strides: (stride between the 4 pixels of a K step) * CS = 16 mod 32 banks => conflict-free ds_read_b32
+  P.CSy = NMT == 1 ? 16 : 48;
+  P.CSx = A.stride == 1 ? (NNT == 1 ? 16 : 48) : (NNT == 1 ? 24 : 40);
+  P.tiles_x = (A.Wout + P.TW - 1) / P.TW;
+  P.tiles_y = (A.Hout + P.TH - 1) / P.TH;
+  P.total_tiles = A.B * P.tiles_x * P.tiles_y;
+  int64_t lds_floats = (int64_t)P.XH * P.XW * P.CSx + (int64_t)P.TH * P.TW * P.CSy;
+  if (lds_floats < per) lds_floats = per;
+  LMN_REQUIRE(lds_floats * 4 <= 160 * 1024, "conv_wgrad: LDS tile too large (%lld B)", (long long)lds_floats * 4);
+  // K-split: enough blocks to fill the chip (~1024 in total), each walking a contiguous range of tiles
+  int64_t blocks64 = P.total_tiles;
   const int64_t cap = 1024 / gy > 2 ? 1024 / gy : 2;
   if (blocks64 > cap) blocks64 = cap;
   if (blocks64 < 1) blocks64 = 1;
@@ -767,18 +1021,21 @@ int lmn_conv_wgrad(const lmn_wgrad_args_t* args, lmn_stream_t stream) {
   const int blocks = (int)blocks64;
   hipStream_t st = (hipStream_t)stream;
   const dim3 grid(blocks, gy);
-#define LMN_WG(T, M, N, UU)                                                                                         \
+  const size_t shmem = (size_t)lds_floats * 4;
+#define LMN_WG(T, M, N)                                                                                             \
   do {                                                                                                              \
-    hipLaunchKernelGGL((wgrad_mfma_kernel<T, M, N, UU>), grid, dim3(256), 0, st, P);                                \
+    if (shmem > 64 * 1024)                                                                                          \
+      (void)hipFuncSetAttribute((const void*)wgrad_lds_kernel<T, M, N>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem); \
+    hipLaunchKernelGGL((wgrad_lds_kernel<T, M, N>), grid, dim3(256), shmem, st, P);                                 \
     if (P.partial) {                                                                                                \
       const int rb = (int)((per + 63) / 64);                                                                        \
       hipLaunchKernelGGL((wgrad_reduce_kernel<T, M, N>), dim3(rb, gy), dim3(1024), 0, st, P, blocks);               \
     }                                                                                                               \
   } while (0)
   if (A.ksize == 1) {
-    if (small) LMN_WG(1, 1, 1, 8); else LMN_WG(1, 2, 2, 4);
+    if (small) LMN_WG(1, 1, 1); else LMN_WG(1, 2, 2);
   } else {
-    if (small) LMN_WG(9, 1, 1, 4); else LMN_WG(9, 2, 2, 2);
+    if (small) LMN_WG(9, 1, 1); else LMN_WG(9, 2, 2);
   }
 #undef LMN_WG
   return lmn_launch_status("conv_wgrad");
