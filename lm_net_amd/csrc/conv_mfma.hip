@@ -381,6 +381,7 @@ struct WgradParams {
   float* partial;    // two-stage reduction: [gridDim.y][gridDim.x][NT*256 + NMT*16] block partials, or NULL (atomics)
   // LDS-staged kernel: output-pixel tile TH x TW, its input window XH x XW, LDS pixel strides, tile counts
   int TH, TW, XH, XW, CSx, CSy, tiles_x, tiles_y, total_tiles;
+  uint32_t mXW, mTW;  // magic multipliers: n / d == (n * m) >> 32 for n, d < 2^16
 };
 
 template <int TAPS, int NMT, int NNT, int U>
@@ -593,6 +594,28 @@ __global__ __launch_bounds__(256, 2) void wgrad_lds_kernel(const WgradParams P) 
   const int pad = A.ksize >> 1;
   const int NP = P.TH * P.TW;
 
+  // per cin tile of this block: source and channel base (block-uniform, hoisted out of the tile loop)
+  const float* tptr[NNT];
+  const float* tscale[NNT];
+  int tC[NNT], tcs[NNT], tflags[NNT], tch0[NNT];
+  uint32_t tseed[NNT];
+  float tp_[NNT], tik[NNT];
+#pragma unroll
+  for (int t = 0; t < NNT; ++t) {
+    const int nt = nt0 + t;
+    int sidx = 0;
+    while (sidx + 1 < A.nsrc && nt >= P.ntile_off[sidx + 1]) ++sidx;
+    tptr[t] = A.src[sidx].ptr;
+    tscale[t] = A.src[sidx].scale;
+    tC[t] = nt < P.NNTT ? A.src[sidx].C : 0;
+    tcs[t] = A.src[sidx].cstride;
+    tflags[t] = A.src[sidx].flags;
+    tseed[t] = A.src[sidx].drop_seed;
+    tp_[t] = A.src[sidx].drop_p;
+    tik[t] = P.inv_keep_src[sidx];
+    tch0[t] = (nt - P.ntile_off[sidx]) * 16;
+  }
+
   f32x4 acc[TAPS][NMT][NNT];
   f32x4 accb[NMT];
 #pragma unroll
@@ -611,78 +634,83 @@ __global__ __launch_bounds__(256, 2) void wgrad_lds_kernel(const WgradParams P) 
     const int oy0 = (tt / P.tiles_x) * P.TH, ox0 = (tt % P.tiles_x) * P.TW;
     const int iy0 = oy0 * A.stride - pad, ix0 = ox0 * A.stride - pad;
     __syncthreads();  // previous tile's reads are done
-    // ---- stage the input window: float4 items (pixel, cin tile, quad)
-    for (int i = tid; i < P.XH * P.XW * NNT * 4; i += 256) {
-      const int j = i & 3, t = (i >> 2) % NNT, pix = i / (4 * NNT);
-      const int r = pix / P.XW, c = pix - r * P.XW;
-      const int iy = iy0 + r, ix = ix0 + c;
-      const int nt = nt0 + t;
-      int s = 0;
-      while (s + 1 < A.nsrc && nt >= P.ntile_off[s + 1]) ++s;
-      const lmn_src_t& S = A.src[s];
-      const int ch = (nt - P.ntile_off[s]) * 16 + j * 4;
-      const bool ok = nt < P.NNTT && ch < S.C && (unsigned)iy < (unsigned)A.Hin && (unsigned)ix < (unsigned)A.Win;
-      const int gp = ok ? (b * A.Hin + iy) * A.Win + ix : 0;
-      const int chs = ok ? ch : 0;
-      f32x4 v = ld4(S.ptr + (uint32_t)(gp * S.cstride + chs));
-      if (S.flags & LMN_SRC_GELU) {
+    // ---- stage the input window: float4 items (pixel, quad) per cin tile
 #pragma unroll
-        for (int k = 0; k < 4; ++k) v[k] = lmn_gelu(v[k]);
-      }
-      if (S.flags & LMN_SRC_DROP) {
+    for (int t = 0; t < NNT; ++t) {
+      for (int i = tid; i < P.XH * P.XW * 4; i += 256) {
+        const int j = i & 3, pix = i >> 2;
+        const int r = (int)__umulhi((uint32_t)pix, P.mXW), c = pix - r * P.XW;
+        const int iy = iy0 + r, ix = ix0 + c;
+        const int ch = tch0[t] + j * 4;
+        const bool ok = ch < tC[t] && (unsigned)iy < (unsigned)A.Hin && (unsigned)ix < (unsigned)A.Win;
+        const int gp = ok ? (b * A.Hin + iy) * A.Win + ix : 0;
+        const int chs = ok ? ch : 0;
+        f32x4 v = ld4(tptr[t] + (uint32_t)(gp * tcs[t] + chs));
+        if (tflags[t] & LMN_SRC_GELU) {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) v[k] *= lmn_drop_scale(S.drop_seed, (uint32_t)(gp * S.C + chs + k), S.drop_p, P.inv_keep_src[s]);
+          for (int k = 0; k < 4; ++k) v[k] = lmn_gelu(v[k]);
+        }
+        if (tflags[t] & LMN_SRC_DROP) {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) v[k] *= lmn_drop_scale(tseed[t], (uint32_t)(gp * tC[t] + chs + k), tp_[t], tik[t]);
+        }
+        if (tscale[t]) v *= ld4(tscale[t] + (ok ? b : 0) * tC[t] + chs);
+        if (!ok) v = f32x4{0.f, 0.f, 0.f, 0.f};
+        *reinterpret_cast<f32x4*>(&XS[pix * P.CSx + t * 16 + j * 4]) = v;
       }
-      if (S.scale) v *= ld4(S.scale + (ok ? b : 0) * S.C + chs);
-      if (!ok) v = f32x4{0.f, 0.f, 0.f, 0.f};
-      *reinterpret_cast<f32x4*>(&XS[pix * P.CSx + t * 16 + j * 4]) = v;
     }
     // ---- stage the dy tile
-    for (int i = tid; i < NP * NMT * 4; i += 256) {
-      const int j = i & 3, m = (i >> 2) % NMT, pix = i / (4 * NMT);
-      const int r = pix / P.TW, c = pix - r * P.TW;
-      const int oy = oy0 + r, ox = ox0 + c;
-      const int co = (mt0 + m) * 16 + j * 4;
-      const bool ok = (mt0 + m) < P.NMTT && co < A.Cout && oy < A.Hout && ox < A.Wout;
-      const int gp = ok ? (b * A.Hout + oy) * A.Wout + ox : 0;
-      const int cos = ok ? co : 0;
-      f32x4 v = ld4(A.dy + (uint32_t)(gp * A.dy_cstride + cos));
-      if (A.dy_flags & LMN_SRC_DROP) {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) v[k] *= lmn_drop_scale(A.dy_seed, (uint32_t)(gp * A.Cout + cos + k), A.dy_p, P.inv_keep_dy);
+    for (int m = 0; m < NMT; ++m) {
+      for (int i = tid; i < NP * 4; i += 256) {
+        const int j = i & 3, pix = i >> 2;
+        const int r = (int)__umulhi((uint32_t)pix, P.mTW), c = pix - r * P.TW;
+        const int oy = oy0 + r, ox = ox0 + c;
+        const int co = (mt0 + m) * 16 + j * 4;
+        const bool ok = (mt0 + m) < P.NMTT && co < A.Cout && oy < A.Hout && ox < A.Wout;
+        const int gp = ok ? (b * A.Hout + oy) * A.Wout + ox : 0;
+        const int cos = ok ? co : 0;
+        f32x4 v = ld4(A.dy + (uint32_t)(gp * A.dy_cstride + cos));
+        if (A.dy_flags & LMN_SRC_DROP) {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) v[k] *= lmn_drop_scale(A.dy_seed, (uint32_t)(gp * A.Cout + cos + k), A.dy_p, P.inv_keep_dy);
+        }
+        if (!ok) v = f32x4{0.f, 0.f, 0.f, 0.f};
+        *reinterpret_cast<f32x4*>(&YS[pix * P.CSy + m * 16 + j * 4]) = v;
       }
-      if (!ok) v = f32x4{0.f, 0.f, 0.f, 0.f};
-      *reinterpret_cast<f32x4*>(&YS[pix * P.CSy + m * 16 + j * 4]) = v;
     }
     __syncthreads();
-    // ---- MFMA over this wave's K steps (4 consecutive tile pixels each)
+    // ---- MFMA over this wave's K steps (4 consecutive tile pixels each); all LDS reads of a step are issued
+    //      before its MFMAs so their latency overlaps
     for (int ks = wv; ks * 4 < NP; ks += 4) {
       const int pix = ks * 4 + q;
-      const int pr = pix / P.TW, pc = pix - pr * P.TW;
       const bool pin = pix < NP;
-      float av[NMT];
+      const int pixs = pin ? pix : 0;
+      const int pr = (int)__umulhi((uint32_t)pixs, P.mTW), pc = pixs - pr * P.TW;
+      float av[NMT], bvv[TAPS][NNT];
 #pragma unroll
-      for (int m = 0; m < NMT; ++m) {
-        const float t0 = YS[(pin ? pix : 0) * P.CSy + m * 16 + n];  // unconditional LDS read, masked by select
-        av[m] = pin ? t0 : 0.f;
+      for (int m = 0; m < NMT; ++m) av[m] = YS[pixs * P.CSy + m * 16 + n];
+      const int xb = ((pr * A.stride) * P.XW + pc * A.stride) * P.CSx + n;
+#pragma unroll
+      for (int tp = 0; tp < TAPS; ++tp) {
+        const int ty = (TAPS == 9) ? tp / 3 : 0, tx = (TAPS == 9) ? tp % 3 : 0;
+#pragma unroll
+        for (int t = 0; t < NNT; ++t) bvv[tp][t] = XS[xb + (ty * P.XW + tx) * P.CSx + t * 16];
+      }
+      if (!pin) {
+#pragma unroll
+        for (int m = 0; m < NMT; ++m) av[m] = 0.f;
       }
       if (A.db && nset == 0) {
 #pragma unroll
         for (int m = 0; m < NMT; ++m) accb[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[m], 1.0f, accb[m], 0, 0, 0);
       }
-      const int xb = pin ? ((pr * A.stride) * P.XW + pc * A.stride) * P.CSx + n : n;
 #pragma unroll
-      for (int tp = 0; tp < TAPS; ++tp) {
-        const int ty = (TAPS == 9) ? tp / 3 : 0, tx = (TAPS == 9) ? tp % 3 : 0;
-        const int off = xb + (ty * P.XW + tx) * P.CSx;
+      for (int tp = 0; tp < TAPS; ++tp)
 #pragma unroll
-        for (int t = 0; t < NNT; ++t) {
-          const float braw = XS[off + t * 16];
-          const float bvv = pin ? braw : 0.f;
+        for (int t = 0; t < NNT; ++t)
 #pragma unroll
-          for (int m = 0; m < NMT; ++m) acc[tp][m][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[m], bvv, acc[tp][m][t], 0, 0, 0);
-        }
-      }
+          for (int m = 0; m < NMT; ++m) acc[tp][m][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[m], bvv[tp][t], acc[tp][m][t], 0, 0, 0);
     }
   }
 
@@ -1003,6 +1031,9 @@ int lmn_conv_wgrad(const lmn_wgrad_args_t* args, lmn_stream_t stream) {
   P.tiles_x = (A.Wout + P.TW - 1) / P.TW;
   P.tiles_y = (A.Hout + P.TH - 1) / P.TH;
   P.total_tiles = A.B * P.tiles_x * P.tiles_y;
+  LMN_REQUIRE(P.XH * P.XW < 65536 && P.TH * P.TW < 65536, "conv_wgrad: tile too large");
+  P.mXW = (uint32_t)((1ull << 32) / (uint32_t)P.XW + 1);
+  P.mTW = (uint32_t)((1ull << 32) / (uint32_t)P.TW + 1);
   int64_t lds_floats = (int64_t)P.XH * P.XW * P.CSx + (int64_t)P.TH * P.TW * P.CSy;
   if (lds_floats < per) lds_floats = per;
   LMN_REQUIRE(lds_floats * 4 <= 160 * 1024, "conv_wgrad: LDS tile too large (%lld B)", (long long)lds_floats * 4);
