@@ -111,6 +111,14 @@ class LM_Net(nn.Module):
         if self.training:
             eng.step += 1
             self._bump_num_batches_tracked()
+        eng.begin_pass(False, x.device)
+        try:
+            return self._forward_body(x, cx)
+        finally:
+            eng.end_pass()
+
+    def _forward_body(self, x, cx):
+        eng = self._engine
         B, Cin, H, W = x.shape
         c4 = (Cin + 3) // 4 * 4
         xin = torch.empty(B, H, W, c4, device=x.device, dtype=torch.float32)
@@ -167,9 +175,20 @@ class LM_Net(nn.Module):
         return wp, bp
 
     def _bump_num_batches_tracked(self):
-        for m in self.modules():
-            if isinstance(m, nn.BatchNorm2d) and m.num_batches_tracked is not None:
-                m.num_batches_tracked += 1
+        """All 84 `num_batches_tracked` buffers are views of ONE int64 tensor: one increment per step."""
+        bns = [m for m in self.modules() if isinstance(m, nn.BatchNorm2d) and m.num_batches_tracked is not None]
+        if not bns:
+            return
+        flat = getattr(self, "_nbt_flat", None)
+        dev = bns[0].num_batches_tracked.device
+        ok = flat is not None and flat.device == dev and flat.numel() == len(bns) and all(
+            m.num_batches_tracked.data_ptr() == flat.data_ptr() + 8 * i for i, m in enumerate(bns))
+        if not ok:
+            flat = torch.stack([m.num_batches_tracked.detach().to(dev).long() for m in bns]).contiguous()
+            for i, m in enumerate(bns):
+                m.num_batches_tracked.data = flat[i]
+            self._nbt_flat = flat
+        flat += 1
 
     # ------------------------------------------------------------------ flat gradient buffer
     def _ensure_grad_layout(self):
@@ -222,6 +241,18 @@ class LM_Net(nn.Module):
         if self.grad_begin_hook is not None:
             self.grad_begin_hook(flat)
         eng.G = G
+        eng.begin_pass(True, dlogits.device)
+        try:
+            dx = self._backward_body(cx, dlogits, need_dx, G)
+        finally:
+            eng.end_pass()
+            eng.G = None
+        if self.grad_finish_hook is not None:
+            self.grad_finish_hook()
+        return dx, [G[p] for p in self.parameters()]
+
+    def _backward_body(self, cx, dlogits, need_dx, G):
+        eng = self._engine
         A = cx.t["act"]
         B, H, W = A["shape"]
         f = self.filters
@@ -278,7 +309,4 @@ class LM_Net(nn.Module):
         if need_dx:
             dx = torch.empty(B, self.channel, H, W, device=dev)
             hip.nhwc_to_nchw(dxin, dx)
-        eng.G = None
-        if self.grad_finish_hook is not None:
-            self.grad_finish_hook()
-        return dx, [G[p] for p in self.parameters()]
+        return dx

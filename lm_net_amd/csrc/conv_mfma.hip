@@ -294,6 +294,9 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams P) {
         }
         if (A.residual) o += ld4(A.residual + opx * A.res_cstride + cos);
         if (A.out && live) *reinterpret_cast<f32x4*>(A.out + opx * A.out_cstride + cos) = o;
+        // keep each (group, tile) epilogue self-contained: without this the scheduler hoists every iteration's
+        // parameter/aux loads to the top and the live ranges cost >100 VGPRs (occupancy 1)
+        __builtin_amdgcn_sched_barrier(0);
       }
     }
   }
@@ -962,7 +965,7 @@ int lmn_conv_fwd(const lmn_conv_args_t* args, lmn_stream_t stream) {
   const int64_t total_groups = (int64_t)A.B * P.gpi;
   LMN_REQUIRE(total_groups < (1LL << 30), "conv_fwd: too many pixel groups");
   int nct = P.NCTT >= 6 ? 6 : (P.NCTT == 5 ? 6 : P.NCTT);
-  const int npg = nct <= 3 ? 4 : 2;
+  const int npg = nct <= 3 ? 4 : 2;  // must match dispatch_conv
   const int chunks = (P.NCTT + nct - 1) / nct;
   P.total_sets = (int)((total_groups + npg - 1) / npg);
   int blocks = (P.total_sets + 3) / 4;

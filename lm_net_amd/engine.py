@@ -32,8 +32,45 @@ def _E(ref, *shape):
     return torch.empty(shape, device=ref.device, dtype=torch.float32)
 
 
+class ZeroPool:
+    """All small zero-initialised accumulators (BN sums, SE sums, ...) of one forward or backward pass come
+    out of ONE buffer zeroed by ONE memset (their total size is learnt on the first pass)."""
+
+    def __init__(self):
+        self.need = 0
+        self.buf = None
+        self.off = 0
+        self.count = 0
+
+    def begin(self, device):
+        self.buf = torch.zeros(self.need, device=device, dtype=torch.float32) if self.need else None
+        self.off = self.count = 0
+
+    def get(self, device, *shape):
+        n = 1
+        for d in shape:
+            n *= d
+        n4 = (n + 3) // 4 * 4
+        self.count += n4
+        if self.buf is not None and self.off + n4 <= self.buf.numel():
+            v = self.buf[self.off:self.off + n].view(shape)
+            self.off += n4
+            return v
+        return torch.zeros(shape, device=device, dtype=torch.float32)
+
+    def end(self):
+        self.need = max(self.need, self.count)
+        self.buf = None
+
+
+_POOL = [None]
+
+
 def _Z(ref, *shape):
-    return torch.zeros(shape, device=ref.device, dtype=torch.float32)
+    pool = _POOL[0]
+    if pool is None:
+        return torch.zeros(shape, device=ref.device, dtype=torch.float32)
+    return pool.get(ref.device, *shape)
 
 
 class Engine:
@@ -43,9 +80,20 @@ class Engine:
         self.training = True
         self.seed_base = 0x1234567
         self.step = 0
+        self.zpool_fwd, self.zpool_bwd = ZeroPool(), ZeroPool()
         self.kernel_events = None  # bench.py: {"dw_fwd": [(start_event, end_event, algorithmic_bytes), ...]}
 
     # ------------------------------------------------------------------ small helpers
+    def begin_pass(self, backward, device):
+        pool = self.zpool_bwd if backward else self.zpool_fwd
+        pool.begin(device)
+        _POOL[0] = pool
+
+    def end_pass(self):
+        if _POOL[0] is not None:
+            _POOL[0].end()
+        _POOL[0] = None
+
     def _seed(self, tag):
         return (self.seed_base + 0x9E3779B1 * (self.step * 64 + tag)) & 0xFFFFFFFF
 
