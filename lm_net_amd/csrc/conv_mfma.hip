@@ -35,6 +35,10 @@ struct ConvParams {
   int total_sets;
   float inv_keep_ep;      // 1/(1-p) of the epilogue dropout
   float inv_keep_src[3];
+  // LDS-tiled kernel (conv_tile_kernel): output tile TH x TW (TP pixels, NG pixel groups), input window XH x XW,
+  // LDS pixel stride CS floats, CKB K16-blocks per staged chunk
+  int TH, TW, TP, NG, XH, XW, CS, CKB, tiles_x, tiles_y, total_tiles;
+  uint32_t mTW, mXW;
 };
 
 __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
@@ -325,6 +329,235 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams P) {
       const int which = i / (NCT * 16), cc = i - which * NCT * 16;
       const int co = ct0 * 16 + cc;
       if (co < A.Cout) atomicAdd(A.stats + (int64_t)which * A.Cout + co, s_stats[i]);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------ LDS-tiled forward / data-gradient
+// Same arithmetic and operand conventions as conv_mfma_kernel, restructured for latency and registers:
+//   * a block walks a contiguous range of output tiles (<= 128 pixels = 8 pixel groups); per tile and per chunk of
+//     <= 32 input channels the input WINDOW (with its zero-padded halo) is staged once into LDS by coalesced,
+//     unconditional float4 loads with the on-load transforms applied there (once per element, not once per tap);
+//   * each wave owns two pixel groups x NCT cout tiles: the B operand is a conflict-free ds_read_b128 (no bounds
+//     checks in the MFMA loop: padding is already in LDS), the A operand the packed weight fragment from L1/L2;
+//   * ~100 VGPRs instead of 140-256: 4-5 waves per SIMD hide the remaining latency.
+// Used for every case except the data gradient of a stride-2 conv (parity classes; conv_mfma_kernel).
+template <int TAPS, int NCT, int EPI>
+__global__ __launch_bounds__(256) void conv_tile_kernel(const ConvParams P) {
+  const lmn_conv_args_t& A = P.a;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* XS = smem;                       // [XH*XW][CS]
+  float* s_stats = smem + P.XH * P.XW * P.CS;  // [2][NCT*16]
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int q = lane >> 4, n = lane & 15;
+  const int ct0 = blockIdx.y * NCT;
+  const int pad = A.ksize >> 1;
+  constexpr int KS = TAPS == 9 ? 3 : 1;
+
+  for (int i = tid; i < 2 * NCT * 16; i += 256) s_stats[i] = 0.f;
+  float st0[NCT][4], st1[NCT][4];
+#pragma unroll
+  for (int c = 0; c < NCT; ++c)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) st0[c][r] = st1[c][r] = 0.f;
+  int cur_b = -1;  // image whose SE_BWD sums are in st0
+
+  const int t_begin = (int)(((int64_t)blockIdx.x * P.total_tiles) / gridDim.x);
+  const int t_end = (int)(((int64_t)(blockIdx.x + 1) * P.total_tiles) / gridDim.x);
+  for (int tile = t_begin; tile < t_end; ++tile) {
+    const int b = tile / (P.tiles_x * P.tiles_y), tt = tile - b * P.tiles_x * P.tiles_y;
+    const int oy0 = (tt / P.tiles_x) * P.TH, ox0 = (tt % P.tiles_x) * P.TW;
+    // window origin in input coordinates (forward: out*s - pad; data gradient, stride 1: out - pad, taps flipped)
+    const int wy0 = A.transposed ? oy0 - pad : oy0 * A.stride - pad;
+    const int wx0 = A.transposed ? ox0 - pad : ox0 * A.stride - pad;
+
+    if (EPI && A.epilogue == LMN_EP_SE_BWD && b != cur_b) {  // block-uniform: flush the previous image's sums
+      if (cur_b >= 0) {
+#pragma unroll
+        for (int c = 0; c < NCT; ++c)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float t = st0[c][r];
+            t += __shfl_xor(t, 1, 64); t += __shfl_xor(t, 2, 64); t += __shfl_xor(t, 4, 64); t += __shfl_xor(t, 8, 64);
+            const int co = (ct0 + c) * 16 + q * 4 + r;
+            if (n == 0 && (ct0 + c < P.NCTT) && co < A.Cout) atomicAdd(A.stats + cur_b * A.Cout + co, t);
+            st0[c][r] = 0.f;
+          }
+      }
+      cur_b = b;
+    }
+
+    // this wave's two pixel groups: tile pixel -> (row, col), LDS base address, validity
+    int pbase[2], opix[2];
+    bool pvalid[2];
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+      const int i = (wv + 4 * g) * 16 + n;
+      const bool in_t = i < P.TP;
+      const int is = in_t ? i : 0;
+      const int r = (int)__umulhi((uint32_t)is, P.mTW), c = is - r * P.TW;
+      const int oy = oy0 + r, ox = ox0 + c;
+      pvalid[g] = in_t && oy < A.Hout && ox < A.Wout;
+      opix[g] = pvalid[g] ? (b * A.Hout + oy) * A.Wout + ox : 0;
+      const int sr = A.transposed ? r : r * A.stride, sc = A.transposed ? c : c * A.stride;
+      pbase[g] = (sr * P.XW + sc) * P.CS + q * 4;
+    }
+    const bool g1 = (wv + 4) < P.NG;  // wave-uniform: second group exists
+
+    f32x4 acc[2][NCT];
+#pragma unroll
+    for (int g = 0; g < 2; ++g)
+#pragma unroll
+      for (int c = 0; c < NCT; ++c) acc[g][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    for (int s = 0; s < A.nsrc; ++s) {
+      const lmn_src_t& S = A.src[s];
+      for (int kb0 = 0; kb0 < P.nkb[s]; kb0 += P.CKB) {
+        const int nkbc = P.nkb[s] - kb0 < P.CKB ? P.nkb[s] - kb0 : P.CKB;
+        __syncthreads();  // previous chunk / tile fully consumed
+        // ---- stage the window chunk: unconditional float4 loads from clamped addresses, transforms, zero padding
+        const int per_px = nkbc * 4;
+        for (int i = tid; i < P.XH * P.XW * per_px; i += 256) {
+          const int f = i % per_px, pix = i / per_px;
+          const int r = (int)__umulhi((uint32_t)pix, P.mXW), c = pix - r * P.XW;
+          const int iy = wy0 + r, ix = wx0 + c;
+          const int ch = kb0 * 16 + f * 4;
+          const bool ok = ch < S.C && (unsigned)iy < (unsigned)A.Hin && (unsigned)ix < (unsigned)A.Win;
+          const int gp = ok ? (b * A.Hin + iy) * A.Win + ix : 0;
+          const int chs = ok ? ch : 0;
+          f32x4 v = ld4(S.ptr + (uint32_t)(gp * S.cstride + chs));
+          if (S.flags & LMN_SRC_GELU) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] = lmn_gelu(v[k]);
+          }
+          if (S.flags & LMN_SRC_DROP) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] *= lmn_drop_scale(S.drop_seed, (uint32_t)(gp * S.C + chs + k), S.drop_p, P.inv_keep_src[s]);
+          }
+          if (S.scale) v *= ld4(S.scale + b * S.C + chs);
+          if (!ok) v = f32x4{0.f, 0.f, 0.f, 0.f};
+          *reinterpret_cast<f32x4*>(&XS[pix * P.CS + f * 4]) = v;
+        }
+        __syncthreads();
+        // ---- MFMA: taps x K16 blocks of the chunk
+#pragma unroll 1
+        for (int tap = 0; tap < TAPS; ++tap) {
+          const int ty = tap / KS, tx = tap - ty * KS;
+          const int fy = A.transposed ? KS - 1 - ty : ty, fx = A.transposed ? KS - 1 - tx : tx;
+          const int toff = (fy * P.XW + fx) * P.CS;
+          for (int kk = 0; kk < nkbc; ++kk) {
+            const f32x4 x0 = *reinterpret_cast<const f32x4*>(&XS[pbase[0] + toff + kk * 16]);
+            const f32x4 x1 = *reinterpret_cast<const f32x4*>(&XS[pbase[1] + toff + kk * 16]);
+            const float* wp = A.wpack + ((((int64_t)tap * P.NKB + P.kb_off[s] + kb0 + kk) * P.NCTT + ct0) * 64 + lane) * 4;
+#pragma unroll
+            for (int c = 0; c < NCT; ++c) {
+              if (ct0 + c < P.NCTT) {
+                const f32x4 wv4 = ld4(wp + c * 256);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                  acc[0][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv4[j], x0[j], acc[0][c], 0, 0, 0);
+                  if (g1) acc[1][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv4[j], x1[j], acc[1][c], 0, 0, 0);
+                }
+              }
+            }
+          }
+        }
+      }
+    }
+
+    // ---- epilogue (lane holds channels co..co+3 of its pixel)
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+      const uint32_t opx = (uint32_t)opix[g];
+#pragma unroll
+      for (int c = 0; c < NCT; ++c) {
+        const int co = (ct0 + c) * 16 + q * 4;
+        const bool cok = (ct0 + c < P.NCTT) && co < A.Cout;
+        const bool live = pvalid[g] && cok && (g == 0 || g1);
+        const int cos = cok ? co : 0;
+        f32x4 v = acc[g][c];
+        if (A.bias) v += ld4(A.bias + cos);
+        f32x4 o = v;
+        if (EPI && A.stats_mode == LMN_STATS_SUM_SQ && live) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) { st0[c][r] += v[r]; st1[c][r] += v[r] * v[r]; }
+        }
+        if (A.epilogue == LMN_EP_AFFINE_ACT) {
+          const f32x4 s0 = ld4(A.p0 + cos), s1 = ld4(A.p1 + cos);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) o[r] = lmn_act(v[r] * s0[r] + s1[r], A.act);
+        }
+        if (EPI) {
+          f32x4 ax = f32x4{0.f, 0.f, 0.f, 0.f};
+          if (A.aux) ax = ld4(A.aux + opx * A.aux_cstride + cos);
+          switch (A.epilogue) {
+            case LMN_EP_DGELU: {
+#pragma unroll
+              for (int r = 0; r < 4; ++r) o[r] = v[r] * lmn_dgelu(ax[r]);
+            } break;
+            case LMN_EP_BN_BWD1: {
+              const f32x4 mu = ld4(A.p0 + cos), rs = ld4(A.p1 + cos), ga = ld4(A.p2 + cos), be = ld4(A.p3 + cos);
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                const float zh = (v[r] - mu[r]) * rs[r];
+                o[r] = ax[r] * lmn_dact(ga[r] * zh + be[r], A.act);
+                if (live) { st0[c][r] += o[r]; st1[c][r] += o[r] * zh; }
+              }
+            } break;
+            case LMN_EP_BN_BWD2: {
+              const f32x4 mu = ld4(A.p0 + cos), rs = ld4(A.p1 + cos), c1 = ld4(A.p2 + cos), c2 = ld4(A.p3 + cos),
+                          c3 = ld4(A.p4 + cos);
+#pragma unroll
+              for (int r = 0; r < 4; ++r) o[r] = c1[r] * ax[r] - c2[r] - (v[r] - mu[r]) * rs[r] * c3[r];
+            } break;
+            case LMN_EP_SE_BWD: {
+              if (live) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) st0[c][r] += v[r] * lmn_gelu(ax[r]);
+              }
+            } break;
+            default: break;
+          }
+        }
+        if (A.drop_p > 0.f) {
+          const uint32_t idx = opx * A.Cout + cos;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) o[r] *= lmn_drop_scale(A.drop_seed, idx + r, A.drop_p, P.inv_keep_ep);
+        }
+        if (A.residual) o += ld4(A.residual + opx * A.res_cstride + cos);
+        if (A.out && live) *reinterpret_cast<f32x4*>(A.out + opx * A.out_cstride + cos) = o;
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  }
+
+  // ---- statistics: wave shuffle over the 16 pixels -> LDS -> one global atomic per channel per block
+  const bool se = EPI && A.epilogue == LMN_EP_SE_BWD;
+  const bool chan_stats = EPI && ((A.stats_mode == LMN_STATS_SUM_SQ) || (A.epilogue == LMN_EP_BN_BWD1) || se);
+  if (chan_stats) {
+#pragma unroll
+    for (int c = 0; c < NCT; ++c)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float a = st0[c][r], bb = st1[c][r];
+#pragma unroll
+        for (int m = 1; m <= 8; m <<= 1) {
+          a += __shfl_xor(a, m, 64);
+          bb += __shfl_xor(bb, m, 64);
+        }
+        if (n == 0) {
+          atomicAdd(&s_stats[c * 16 + q * 4 + r], a);
+          atomicAdd(&s_stats[NCT * 16 + c * 16 + q * 4 + r], bb);
+        }
+      }
+    __syncthreads();
+    for (int i = tid; i < (se ? 1 : 2) * NCT * 16; i += 256) {
+      const int which = i / (NCT * 16), cc = i - which * NCT * 16;
+      const int co = ct0 * 16 + cc;
+      if (co < A.Cout) {
+        if (se) { if (cur_b >= 0) atomicAdd(A.stats + cur_b * A.Cout + co, s_stats[i]); }
+        else atomicAdd(A.stats + (int64_t)which * A.Cout + co, s_stats[i]);
+      }
     }
   }
 }
@@ -965,17 +1198,74 @@ int lmn_conv_fwd(const lmn_conv_args_t* args, lmn_stream_t stream) {
   const int64_t total_groups = (int64_t)A.B * P.gpi;
   LMN_REQUIRE(total_groups < (1LL << 30), "conv_fwd: too many pixel groups");
   int nct = P.NCTT >= 6 ? 6 : (P.NCTT == 5 ? 6 : P.NCTT);
-  const int npg = nct <= 3 ? 4 : 2;  // must match dispatch_conv
   const int chunks = (P.NCTT + nct - 1) / nct;
+  hipStream_t st = (hipStream_t)stream;
+  if (!(A.transposed && A.stride == 2)) {
+    // ---- LDS-tiled kernel.  1x1: the image is a flat row of H*W pixels.
+    ConvParams T = P;
+    lmn_conv_args_t& a = T.a;
+    if (a.ksize == 1) {
+      a.Wout *= a.Hout; a.Win *= a.Hin; a.Hout = a.Hin = 1;
+    }
+    const int tpmax = (a.stride == 2) ? 64 : 128;
+    if (a.ksize == 1) { T.TW = a.Wout < tpmax ? a.Wout : tpmax; T.TH = 1; }
+    else {
+      T.TW = a.Wout <= 32 ? a.Wout : 16;
+      T.TH = tpmax / T.TW;
+      if (T.TH > a.Hout) T.TH = a.Hout;
+      if (T.TH < 1) T.TH = 1;
+    }
+    T.TP = T.TH * T.TW;
+    T.NG = (T.TP + 15) / 16;
+    LMN_REQUIRE(T.NG <= 8, "conv_fwd: tile of %d pixels", T.TP);
+    const int st_in = a.transposed ? 1 : a.stride;
+    T.XH = (T.TH - 1) * st_in + a.ksize;
+    T.XW = (T.TW - 1) * st_in + a.ksize;
+    int maxkb = 0;
+    for (int s = 0; s < a.nsrc; ++s) maxkb = P.nkb[s] > maxkb ? P.nkb[s] : maxkb;
+    T.CKB = maxkb < 2 ? maxkb : 2;
+    T.CS = T.CKB * 16 + 4;
+    T.tiles_x = (a.Wout + T.TW - 1) / T.TW;
+    T.tiles_y = (a.Hout + T.TH - 1) / T.TH;
+    T.total_tiles = a.B * T.tiles_x * T.tiles_y;
+    T.mTW = (uint32_t)((1ull << 32) / (uint32_t)T.TW + 1);
+    T.mXW = (uint32_t)((1ull << 32) / (uint32_t)T.XW + 1);
+    LMN_REQUIRE(T.XH * T.XW < 65536, "conv_fwd: window too large");
+    const size_t shmem = ((size_t)T.XH * T.XW * T.CS + 2 * nct * 16) * sizeof(float);
+    LMN_REQUIRE(shmem <= 64 * 1024, "conv_fwd: LDS window %zu B", shmem);
+    int blocks = T.total_tiles;
+    const int maxb = 2048 / chunks > 256 ? 2048 / chunks : 256;
+    if (blocks > maxb) blocks = maxb;
+    const bool epi = a.epilogue > LMN_EP_AFFINE_ACT || a.stats_mode != LMN_STATS_NONE;  // EPI=1: statistics / special epilogues
+    const dim3 grid(blocks, chunks);
+#define LMN_CT(TT, NN)                                                                                   \
+  do {                                                                                                   \
+    if (epi) hipLaunchKernelGGL((conv_tile_kernel<TT, NN, 1>), grid, dim3(256), shmem, st, T);           \
+    else hipLaunchKernelGGL((conv_tile_kernel<TT, NN, 0>), grid, dim3(256), shmem, st, T);               \
+  } while (0)
+#define LMN_CTN(TT)                                                                                      \
+  switch (nct) {                                                                                         \
+    case 1: LMN_CT(TT, 1); break;                                                                        \
+    case 2: LMN_CT(TT, 2); break;                                                                        \
+    case 3: LMN_CT(TT, 3); break;                                                                        \
+    case 4: LMN_CT(TT, 4); break;                                                                        \
+    default: LMN_CT(TT, 6); break;                                                                       \
+  }
+    if (a.ksize == 1) { LMN_CTN(1) } else { LMN_CTN(9) }
+#undef LMN_CTN
+#undef LMN_CT
+    return lmn_launch_status("conv_fwd(tile)");
+  }
+  const int npg = nct <= 3 ? 4 : 2;
   P.total_sets = (int)((total_groups + npg - 1) / npg);
   int blocks = (P.total_sets + 3) / 4;
   const int maxb = 2048 / chunks > 256 ? 2048 / chunks : 256;
   if (blocks > maxb) blocks = maxb;
   if (blocks < 1) blocks = 1;
   if (A.ksize == 1)
-    dispatch_conv<1>(P, nct, npg, blocks, chunks, (hipStream_t)stream);
+    dispatch_conv<1>(P, nct, npg, blocks, chunks, st);
   else
-    dispatch_conv<9>(P, nct, npg, blocks, chunks, (hipStream_t)stream);
+    dispatch_conv<9>(P, nct, npg, blocks, chunks, st);
   return lmn_launch_status("conv_fwd");
 }
 
