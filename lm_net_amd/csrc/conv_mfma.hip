@@ -19,6 +19,7 @@
 //    per-image statistics are wave-uniform).  For the data gradient of a stride-2 conv the groups
 //    enumerate one parity class of the output at a time, so the valid taps are uniform per group.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -618,6 +619,7 @@ struct WgradParams {
   // LDS-staged kernel: output-pixel tile TH x TW, its input window XH x XW, LDS pixel strides, tile counts
   int TH, TW, XH, XW, CSx, CSy, tiles_x, tiles_y, total_tiles;
   uint32_t mXW, mTW;  // magic multipliers: n / d == (n * m) >> 32 for n, d < 2^16
+  int dbg;
 };
 
 template <int TAPS, int NMT, int NNT, int U>
@@ -821,8 +823,11 @@ template <int TAPS, int NMT, int NNT>
 __global__ __launch_bounds__(256, 2) void wgrad_lds_kernel(const WgradParams P) {
   const lmn_wgrad_args_t& A = P.a;
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* XS = smem;                                   // [XH*XW][CSx]  (NNT*16 channels used)
-  float* YS = smem + P.XH * P.XW * P.CSx;             // [TH*TW][CSy]  (NMT*16 channels used)
+  // one 16-channel PLANE per cin / cout tile: [tile][pixel][16] -- a K step reads 4 pixels x 16 channels = 64
+  // consecutive floats of one plane (conflict-free ds_read_b32 at stride 1), and no padding is needed
+  const int XP = P.XH * P.XW;
+  float* XS = smem;                                   // [NNT][XH*XW][16]
+  float* YS = smem + NNT * XP * P.CSx;                // [NMT][TH*TW][16]
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int q = lane >> 4, n = lane & 15;
   const int mset = blockIdx.y / P.nsets_n, nset = blockIdx.y - mset * P.nsets_n;
@@ -892,7 +897,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_lds_kernel(const WgradParams P) 
         }
         if (tscale[t]) v *= ld4(tscale[t] + (ok ? b : 0) * tC[t] + chs);
         if (!ok) v = f32x4{0.f, 0.f, 0.f, 0.f};
-        *reinterpret_cast<f32x4*>(&XS[pix * P.CSx + t * 16 + j * 4]) = v;
+        *reinterpret_cast<f32x4*>(&XS[(t * XP + pix) * P.CSx + j * 4]) = v;
       }
     }
     // ---- stage the dy tile
@@ -912,7 +917,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_lds_kernel(const WgradParams P) 
           for (int k = 0; k < 4; ++k) v[k] *= lmn_drop_scale(A.dy_seed, (uint32_t)(gp * A.Cout + cos + k), A.dy_p, P.inv_keep_dy);
         }
         if (!ok) v = f32x4{0.f, 0.f, 0.f, 0.f};
-        *reinterpret_cast<f32x4*>(&YS[pix * P.CSy + m * 16 + j * 4]) = v;
+        *reinterpret_cast<f32x4*>(&YS[(m * NP + pix) * P.CSy + j * 4]) = v;
       }
     }
     __syncthreads();
@@ -925,13 +930,13 @@ __global__ __launch_bounds__(256, 2) void wgrad_lds_kernel(const WgradParams P) 
       const int pr = (int)__umulhi((uint32_t)pixs, P.mTW), pc = pixs - pr * P.TW;
       float av[NMT], bvv[TAPS][NNT];
 #pragma unroll
-      for (int m = 0; m < NMT; ++m) av[m] = YS[pixs * P.CSy + m * 16 + n];
+      for (int m = 0; m < NMT; ++m) av[m] = YS[(m * NP + pixs) * P.CSy + n];
       const int xb = ((pr * A.stride) * P.XW + pc * A.stride) * P.CSx + n;
 #pragma unroll
       for (int tp = 0; tp < TAPS; ++tp) {
         const int ty = (TAPS == 9) ? tp / 3 : 0, tx = (TAPS == 9) ? tp % 3 : 0;
 #pragma unroll
-        for (int t = 0; t < NNT; ++t) bvv[tp][t] = XS[xb + (ty * P.XW + tx) * P.CSx + t * 16];
+        for (int t = 0; t < NNT; ++t) bvv[tp][t] = XS[xb + (t * XP + ty * P.XW + tx) * P.CSx];
       }
       if (!pin) {
 #pragma unroll
@@ -950,27 +955,36 @@ __global__ __launch_bounds__(256, 2) void wgrad_lds_kernel(const WgradParams P) 
     }
   }
 
-  // ---- block-level reduction in LDS (4 waves -> 1)
+  // ---- block-level reduction in LDS (4 waves -> 1): plain stores / read-add-stores in four wave rounds.
+  //      (LDS float atomics cost ~3 cycles per LANE on gfx950 -- measured 180 us for this tail with ds_add_f32.)
   constexpr int NT = TAPS * NMT * NNT;
   __syncthreads();
   float* s_acc = smem;  // reuse the staging area (>= NT*256 + NMT*16 floats, checked on the host)
-  for (int i = tid; i < NT * 256 + NMT * 16; i += 256) s_acc[i] = 0.f;
-  __syncthreads();
+  for (int w = 0; w < 4; ++w) {
+    if (wv == w) {
 #pragma unroll
-  for (int tp = 0; tp < TAPS; ++tp)
+      for (int tp = 0; tp < TAPS; ++tp)
 #pragma unroll
-    for (int m = 0; m < NMT; ++m)
+        for (int m = 0; m < NMT; ++m)
 #pragma unroll
-      for (int t = 0; t < NNT; ++t)
+          for (int t = 0; t < NNT; ++t)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) atomicAdd(&s_acc[(((tp * NMT + m) * NNT + t) * 4 + r) * 64 + lane], acc[tp][m][t][r]);
-  if (A.db && nset == 0 && n == 0) {
+            for (int r = 0; r < 4; ++r) {
+              float* d = &s_acc[(((tp * NMT + m) * NNT + t) * 4 + r) * 64 + lane];
+              *d = (w == 0) ? acc[tp][m][t][r] : *d + acc[tp][m][t][r];
+            }
+      if (n == 0) {  // bias sums live in column 0 of accb (lanes n == 0), rows 4q + r
 #pragma unroll
-    for (int m = 0; m < NMT; ++m)
+        for (int m = 0; m < NMT; ++m)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) atomicAdd(&s_acc[NT * 256 + m * 16 + q * 4 + r], accb[m][r]);
+          for (int r = 0; r < 4; ++r) {
+            float* d = &s_acc[NT * 256 + m * 16 + q * 4 + r];
+            *d = (w == 0) ? accb[m][r] : *d + accb[m][r];
+          }
+      }
+    }
+    __syncthreads();
   }
-  __syncthreads();
   if (P.partial) {
     float* dst = P.partial + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * (NT * 256 + NMT * 16);
     for (int i = tid; i < NT * 256 + NMT * 16; i += 256) dst[i] = s_acc[i];
@@ -1074,7 +1088,7 @@ int64_t lmn_conv_wgrad_workspace(const lmn_wgrad_args_t* a) {
   const int NMT = small ? 1 : 2, NNT = small ? 1 : 2;
   const int gy = ((nmtt + NMT - 1) / NMT) * ((nntt + NNT - 1) / NNT);
   const int64_t per = (int64_t)a->ksize * a->ksize * NMT * NNT * 256 + NMT * 16;
-  const int npmax = a->stride == 2 ? 64 : 256;
+  const int npmax = a->stride == 2 ? 64 : (a->ksize == 1 ? 256 : 128);
   int TW = a->Wout < (a->ksize == 1 ? npmax : 32) ? a->Wout : (a->ksize == 1 ? npmax : 32);
   if (a->stride == 2 && TW > 16) TW = 16;
   int TH = npmax / TW;
@@ -1310,7 +1324,7 @@ int lmn_conv_wgrad(const lmn_wgrad_args_t* args, lmn_stream_t stream) {
   const int taps = A.ksize * A.ksize;
   const int64_t per = (int64_t)taps * NMT * NNT * 256 + NMT * 16;
   // ---- tile geometry of the LDS-staged kernel
-  const int npmax = A.stride == 2 ? 64 : 256;
+  const int npmax = A.stride == 2 ? 64 : (A.ksize == 1 ? 256 : 128);
   P.TW = A.Wout < (A.ksize == 1 ? npmax : 32) ? A.Wout : (A.ksize == 1 ? npmax : 32);
   if (A.stride == 2 && P.TW > 16) P.TW = 16;
   P.TH = npmax / P.TW;
@@ -1318,16 +1332,18 @@ int lmn_conv_wgrad(const lmn_wgrad_args_t* args, lmn_stream_t stream) {
   if (P.TH < 1) P.TH = 1;
   P.XH = (P.TH - 1) * A.stride + A.ksize;
   P.XW = (P.TW - 1) * A.stride + A.ksize;
-  // LDS pixel strides: (stride between the 4 pixels of a K step) * CS = 16 mod 32 banks => conflict-free ds_read_b32
-  P.CSy = NMT == 1 ? 16 : 48;
-  P.CSx = A.stride == 1 ? (NNT == 1 ? 16 : 48) : (NNT == 1 ? 24 : 40);
+  // LDS planes [tile][pixel][CS]: the 4 pixels of a K step are CS*stride floats apart; 16 (stride 1) and 24
+  // (stride 2: 48 = 16 mod 32 banks) keep the two 16-lane halves of a ds_read_b32 group on disjoint banks
+  P.CSy = 16;
+  P.CSx = A.stride == 1 ? 16 : 24;
   P.tiles_x = (A.Wout + P.TW - 1) / P.TW;
   P.tiles_y = (A.Hout + P.TH - 1) / P.TH;
   P.total_tiles = A.B * P.tiles_x * P.tiles_y;
+  P.dbg = 0;
   LMN_REQUIRE(P.XH * P.XW < 65536 && P.TH * P.TW < 65536, "conv_wgrad: tile too large");
   P.mXW = (uint32_t)((1ull << 32) / (uint32_t)P.XW + 1);
   P.mTW = (uint32_t)((1ull << 32) / (uint32_t)P.TW + 1);
-  int64_t lds_floats = (int64_t)P.XH * P.XW * P.CSx + (int64_t)P.TH * P.TW * P.CSy;
+  int64_t lds_floats = (int64_t)NNT * P.XH * P.XW * P.CSx + (int64_t)NMT * P.TH * P.TW * P.CSy;
   if (lds_floats < per) lds_floats = per;
   LMN_REQUIRE(lds_floats * 4 <= 160 * 1024, "conv_wgrad: LDS tile too large (%lld B)", (long long)lds_floats * 4);
   // K-split: enough blocks to fill the chip (~1024 in total), each walking a contiguous range of tiles

@@ -415,11 +415,11 @@ def check_bn_tail():
     return rows
 
 
-def check_conv_bn_epilogues():
+def check_conv_bn_epilogues(B=2, H=9, W=8, tag=""):
     """expand_conv (1x1 + batch-stat BN + Hardswish) backward through the conv epilogues BN_BWD1/BN_BWD2,
     and the SE_BWD / DGELU epilogues."""
     rows = []
-    B, H, W, Cin, E = 2, 9, 8, 12, 24
+    Cin, E = 12, 24
     x = R(B, Cin, H, W, seed=131)
     w, b = R(E, Cin, 1, 1, seed=132, scale=0.4).requires_grad_(True), R(E, seed=133).requires_grad_(True)
     g, be = (R(E, seed=134).abs() + 0.5).requires_grad_(True), R(E, seed=135).requires_grad_(True)
@@ -444,12 +444,13 @@ def check_conv_bn_epilogues():
     A = dev(g.detach() * rstd)
     dg, db_, c1, c2, c3 = (torch.zeros(E, device=DEV) for _ in range(5))
     hip.bn_bwd_coef(st, N, A, dg, db_, c1, c2, c3, True)
-    rows.append(("conv BN_BWD1 dgamma", rel(dg, g.grad), 2e-4))
-    rows.append(("conv BN_BWD1 dbeta", rel(db_, be.grad), 2e-4))
+    rows.append(("conv BN_BWD1 dh" + tag, rel(nchw(dh), (zr.grad * 0 + 1) * 0 + _dh_ref(z, g, be, dx1)), TOL))
+    rows.append(("conv BN_BWD1 dgamma" + tag, rel(dg, g.grad), 2e-4))
+    rows.append(("conv BN_BWD1 dbeta" + tag, rel(db_, be.grad), 2e-4))
     dz = torch.full((B, H, W, E), float("nan"), device=DEV)
     hip.conv_fwd([xd], wp, dz, B=B, Hin=H, Win=W, Hout=H, Wout=W, Cout=E, bias=dev(b), epilogue=hip.EP_BN_BWD2,
                  p=(dev(mean), dev(rstd), c1, c2, c3), aux=dh)
-    rows.append(("conv BN_BWD2 dz", rel(nchw(dz), zr.grad), 2e-4))
+    rows.append(("conv BN_BWD2 dz" + tag, rel(nchw(dz), zr.grad), 2e-4))
 
     # SE_BWD: o = v, stats[b][c] += v * gelu(aux)
     pre = R(B, E, H, W, seed=137)
@@ -462,16 +463,26 @@ def check_conv_bn_epilogues():
     ds = torch.zeros(B, E, device=DEV)
     hip.conv_fwd([nhwc(dy)], wpt, u, B=B, Hin=H, Win=W, Hout=H, Wout=W, Cout=E, transposed=1, epilogue=hip.EP_SE_BWD,
                  aux=nhwc(pre), stats=ds, stats_mode=hip.STATS_EP)
-    rows.append(("conv SE_BWD u", rel(nchw(u), u_ref), TOL))
-    rows.append(("conv SE_BWD ds", rel(ds, ds_ref), 2e-4))
+    rows.append(("conv SE_BWD u" + tag, rel(nchw(u), u_ref), TOL))
+    rows.append(("conv SE_BWD ds" + tag, rel(ds, ds_ref), 2e-4))
     # DGELU
     o = torch.full((B, H, W, E), float("nan"), device=DEV)
     hip.conv_fwd([nhwc(dy)], wpt, o, B=B, Hin=H, Win=W, Hout=H, Wout=W, Cout=E, transposed=1, epilogue=hip.EP_DGELU,
                  aux=nhwc(pre))
     pl = pre.clone().requires_grad_(True)
     gelu(pl).backward(u_ref)
-    rows.append(("conv DGELU", rel(nchw(o), pl.grad), TOL))
+    rows.append(("conv DGELU" + tag, rel(nchw(o), pl.grad), TOL))
     return rows
+
+
+def _dh_ref(z, g, be, dx1):
+    """dL/dh for h = BN(z) (batch stats), x1 = hardswish(h): dx1 * hardswish'(h) in fp64."""
+    zd = z.detach()
+    mean = zd.mean((0, 2, 3), keepdim=True)
+    var = zd.var((0, 2, 3), unbiased=False, keepdim=True)
+    h = (zd - mean) / torch.sqrt(var + 1e-5) * g.detach().view(1, -1, 1, 1) + be.detach().view(1, -1, 1, 1)
+    d = torch.where(h < -3, torch.zeros_like(h), torch.where(h <= 3, h / 3 + 0.5, torch.ones_like(h)))
+    return dx1 * d
 
 
 # ------------------------------------------------------------------------------------------------ resampling / layout
@@ -531,3 +542,57 @@ def check_layout_utils():
 
 ALL_CHECKS = [check_conv_fwd, check_conv_bwd_data, check_conv_wgrad, check_conv_dropout, check_conv_bn_epilogues,
               check_dw, check_se, check_na, check_gattn, check_ln, check_bn_tail, check_resample, check_layout_utils]
+
+
+def check_conv_large():
+    """Full-size feature maps: many tiles per block, several images per block range, K-split reductions."""
+    rows = []
+    B, H, W = 3, 176, 160
+    for (name, cins, cout, k, s) in [("1x1 12->24", [12], 24, 1, 1), ("3x3 12->12", [12], 12, 3, 1),
+                                      ("3x3 s2 12->24", [12], 24, 3, 2), ("3x3 cat 24+12->24", [24, 12], 24, 3, 1)]:
+        cin = sum(cins)
+        x = R(B, cin, H, W, seed=201).requires_grad_(True)
+        w = R(cout, cin, k, k, seed=202, scale=1.0 / math.sqrt(cin * k * k)).requires_grad_(True)
+        b = R(cout, seed=203).requires_grad_(True)
+        y = F.conv2d(x, w, b, stride=s, padding=k // 2)
+        dy = R(*y.shape, seed=204)
+        y.backward(dy)
+        Ho, Wo = y.shape[2:]
+        xs, off = [], 0
+        for c in cins:
+            xs.append(nhwc(x.detach()[:, off:off + c]))
+            off += c
+        wd = dev(w)
+        out = torch.full((B, Ho, Wo, cout), float("nan"), device=DEV)
+        stats = torch.zeros(2, cout, device=DEV)
+        hip.conv_fwd(xs, hip.conv_pack(wd, k, cins), out, B=B, Hin=H, Win=W, Hout=Ho, Wout=Wo, Cout=cout, ksize=k, stride=s,
+                     bias=dev(b), stats=stats, stats_mode=hip.STATS_SUM_SQ)
+        rows.append(("large conv_fwd " + name, rel(nchw(out), y), TOL))
+        yd = y.detach()
+        rows.append(("large conv_fwd stats " + name, rel(stats, torch.stack([yd.sum((0, 2, 3)), (yd * yd).sum((0, 2, 3))])), 2e-4))
+        dW, db = torch.zeros_like(wd), torch.zeros(cout, device=DEV)
+        hip.conv_wgrad(xs, nhwc(dy), dW, db, B=B, Hin=H, Win=W, Hout=Ho, Wout=Wo, Cout=cout, ksize=k, stride=s)
+        rows.append(("large conv_wgrad dW " + name, rel(dW, w.grad), 2e-4))
+        rows.append(("large conv_wgrad db " + name, rel(db, b.grad), 2e-4))
+        if len(cins) == 1:
+            dx = torch.full((B, H, W, cin), float("nan"), device=DEV)
+            hip.conv_fwd([nhwc(dy)], hip.conv_pack_t(wd, k), dx, B=B, Hin=Ho, Win=Wo, Hout=H, Wout=W, Cout=cin, ksize=k,
+                         stride=s, transposed=1)
+            rows.append(("large conv_bwd_data " + name, rel(nchw(dx), x.grad), TOL))
+    # SE_BWD epilogue across several images in one block range
+    E, Cin = 24, 12
+    pre, dyy = R(B, E, H, W, seed=205), R(B, Cin, H, W, seed=206)
+    wpw = R(Cin, E, 1, 1, seed=207, scale=0.3)
+    u_ref = F.conv_transpose2d(dyy, wpw)
+    ds_ref = (u_ref * gelu(pre)).sum((2, 3))
+    u = torch.full((B, H, W, E), float("nan"), device=DEV)
+    ds = torch.zeros(B, E, device=DEV)
+    hip.conv_fwd([nhwc(dyy)], hip.conv_pack_t(dev(wpw), 1), u, B=B, Hin=H, Win=W, Hout=H, Wout=W, Cout=E, transposed=1,
+                 epilogue=hip.EP_SE_BWD, aux=nhwc(pre), stats=ds, stats_mode=hip.STATS_EP)
+    rows.append(("large conv SE_BWD u", rel(nchw(u), u_ref), TOL))
+    rows.append(("large conv SE_BWD ds", rel(ds, ds_ref), 2e-4))
+    rows += check_conv_bn_epilogues(B=2, H=176, W=168, tag=" (large)")
+    return rows
+
+
+ALL_CHECKS.append(check_conv_large)

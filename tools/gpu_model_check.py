@@ -33,6 +33,7 @@ def nodrop(m):
 def main():
     cfg = sys.argv[1] if len(sys.argv) > 1 else "tiny"
     H, W, B = (int(v) for v in sys.argv[2:5]) if len(sys.argv) > 4 else (32, 48, 2)
+    f64 = len(sys.argv) > 5 and sys.argv[5] == "f64"      # oracle in float64: separates GPU error from fp32-CPU noise
     filters = [12] * 5 if cfg == "tiny" else [12, 24, 48, 96, 192]
     ora = Oracle(3, 2, filters=filters)
     fill_module(ora, seed=1)
@@ -43,11 +44,13 @@ def main():
     nodrop(net)
     net._keep_taps = True
     x = det_input((B, 3, H, W), "mc/x")
+    if f64:
+        ora = ora.double()
     worst = 0.0
     for mode in ("eval", "train"):
         ora.train(mode == "train"); net.train(mode == "train")
         taps = {}
-        xo = x.clone().requires_grad_(True)
+        xo = (x.double() if f64 else x.clone()).requires_grad_(True)
         yo = ora(xo, taps)
         xg = x.cuda().requires_grad_(True)
         t0 = time.time()
@@ -59,7 +62,7 @@ def main():
             worst = max(worst, e)
             print("   stage %-4s %.3e %s" % (k, e, "" if e < 1e-4 else "<<<<"))
         Gm = det_input(tuple(yo.shape), "mc/G")
-        (yo * Gm).sum().backward()
+        (yo * (Gm.double() if f64 else Gm)).sum().backward()
         t0 = time.time()
         (yg * Gm.cuda()).sum().backward()
         torch.cuda.synchronize()
