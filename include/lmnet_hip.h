@@ -199,9 +199,10 @@ int lmn_se_bwd(const float* ds, const float* gsum, float inv_hw, const float* w1
  * ------------------------------------------------------------------------------------------ */
 int lmn_na_fwd(const float* qkv, const float* rpb, float* out, int B, int H, int W, int heads, int hd, float scale,
                lmn_stream_t stream);
-/* dqkv must be zeroed by the caller (k/v gradients are scattered with atomics); drpb += */
-int lmn_na_bwd(const float* qkv, const float* rpb, const float* dout, float* dqkv, float* drpb, int B, int H,
-               int W, int heads, int hd, float scale, lmn_stream_t stream);
+/* dqkv is fully overwritten (two gather passes, no atomics, deterministic); drpb +=;
+ * stat: caller workspace of 2*heads floats per pixel ([B*H*W][2][heads]: log-sum-exp and sum_n p_n dp_n) */
+int lmn_na_bwd(const float* qkv, const float* rpb, const float* dout, float* dqkv, float* drpb, float* stat, int B,
+               int H, int W, int heads, int hd, float scale, lmn_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Dense global attention of GFT (core/modules.py:267-279): qkv [B,N,3C] (channel = which*C +

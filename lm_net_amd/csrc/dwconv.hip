@@ -354,27 +354,37 @@ __global__ __launch_bounds__(256) void dw_bwd_kernel(const float* __restrict__ x
         *reinterpret_cast<f32x4*>(dx1 + (((int64_t)b * H + gy) * W + gx) * E + ch0 + c4 * 4) = *reinterpret_cast<const f32x4*>(&DX[pix * DC + c4 * 4]);
     }
   }
-  // weight gradients: [E][40] = 25 (5x5) | 9 (3x3) | 3 (ver) | 3 (hor)
+  // weight gradients: [E][40] = 25 (5x5) | 9 (3x3) | 3 (ver) | 3 (hor).  Lanes sharing a channel pair are 4 apart:
+  // butterfly over lane bits 2..5 (no LDS float atomics: ~3 cycles per lane on gfx950), then one LDS row per wave.
   __syncthreads();
+  float* red4 = X;  // reuse the x1 staging area: [4 waves][40][DC]
+  const int lane = tid & 63, wid = tid >> 6;
+  auto wave_reduce_store = [&](f32x2 v, int t) {
 #pragma unroll
-  for (int t = 0; t < 25; ++t) { atomicAdd(&red[t * DC + cp * 2], g5[t][0]); atomicAdd(&red[t * DC + cp * 2 + 1], g5[t][1]); }
+    for (int m = 4; m <= 32; m <<= 1) {
+      v[0] += __shfl_xor(v[0], m, 64);
+      v[1] += __shfl_xor(v[1], m, 64);
+    }
+    if (lane < DNCP) *reinterpret_cast<f32x2*>(&red4[(wid * 40 + t) * DC + lane * 2]) = v;
+  };
 #pragma unroll
-  for (int t = 0; t < 9; ++t) { atomicAdd(&red[(25 + t) * DC + cp * 2], g3[t][0]); atomicAdd(&red[(25 + t) * DC + cp * 2 + 1], g3[t][1]); }
+  for (int t = 0; t < 25; ++t) wave_reduce_store(g5[t], t);
+#pragma unroll
+  for (int t = 0; t < 9; ++t) wave_reduce_store(g3[t], 25 + t);
 #pragma unroll
   for (int t = 0; t < 3; ++t) {
-    atomicAdd(&red[(34 + t) * DC + cp * 2], gv[t][0]);
-    atomicAdd(&red[(34 + t) * DC + cp * 2 + 1], gv[t][1]);
-    atomicAdd(&red[(37 + t) * DC + cp * 2], gh[t][0]);
-    atomicAdd(&red[(37 + t) * DC + cp * 2 + 1], gh[t][1]);
+    wave_reduce_store(gv[t], 34 + t);
+    wave_reduce_store(gh[t], 37 + t);
   }
   __syncthreads();
   for (int i = tid; i < 40 * DC; i += 256) {
     const int t = i / DC, e = ch0 + (i - t * DC);
     if (e >= E) continue;
-    if (t < 25) atomicAdd(dw5 + (int64_t)e * 25 + t, red[i]);
-    else if (t < 34) atomicAdd(dw3 + (int64_t)e * 9 + t - 25, red[i]);
-    else if (t < 37) atomicAdd(dwv + (int64_t)e * 3 + t - 34, red[i]);
-    else atomicAdd(dwh + (int64_t)e * 3 + t - 37, red[i]);
+    const float v = red4[i] + red4[40 * DC + i] + red4[2 * 40 * DC + i] + red4[3 * 40 * DC + i];
+    if (t < 25) atomicAdd(dw5 + (int64_t)e * 25 + t, v);
+    else if (t < 34) atomicAdd(dw3 + (int64_t)e * 9 + t - 25, v);
+    else if (t < 37) atomicAdd(dwv + (int64_t)e * 3 + t - 34, v);
+    else atomicAdd(dwh + (int64_t)e * 3 + t - 37, v);
   }
 }
 

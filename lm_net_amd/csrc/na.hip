@@ -100,51 +100,41 @@ __global__ __launch_bounds__(256) void na_fwd_kernel(const float* __restrict__ q
   }
 }
 
-// Backward.  One block = an 8x8 query tile x a channel chunk of one image.  The inverse neighbourhood
-// (which queries read key j) is irregular under the clamped-window rule, so dK/dV are SCATTERED from the
-// query side -- but into an LDS image of the tile + 1-pixel halo (ds_add_f32), and only that image is
-// flushed to HBM with global atomics (non-zero entries only): ~(10x10)/(8x8) * 2C adds per pixel instead of 18C.  dQ is owned by
-// its query (plain store), d rpb is reduced per block in LDS.
-constexpr int NB_T = 8, NB_HALO = 2, NB_R = NB_T + 2 * NB_HALO;  // halo 2: a clamped window at the image edge reaches 2 rows back
-
+// Backward in two gather passes -- no atomics on dQ/dK/dV (LDS float atomics cost ~3 cycles per lane on gfx950 and
+// global ones serialise on the 9x fan-in), deterministic:
+//   pass 1 (query-owned): recompute softmax p and dp_n = dO.v_n; dsum = sum_n p_n dp_n; dQ = scale * sum_n ds_n k_n;
+//           store per (pixel, head) the two scalars the key side needs: lse = max + log(sum exp) and dsum; d rpb is
+//           reduced per block in LDS and flushed with one atomic per entry per block.
+//   pass 2 (key-owned): key j gathers from every query i whose clamped window contains j (i within +-2 rows/cols):
+//           p_ij = exp(q_i.k_j + rpb - lse_i), ds_ij = p_ij (dO_i.v_j - dsum_i); dK_j += scale ds_ij q_i; dV_j += p_ij dO_i.
+// Workspace: 2 floats per (pixel, head).
 template <int HD>
-__global__ __launch_bounds__(256) void na_bwd_kernel(const float* __restrict__ qkv, const float* __restrict__ rpb,
-                                                     const float* __restrict__ dout, float* __restrict__ dqkv,
-                                                     float* __restrict__ drpb, const NaGeom g, int cch, int tiles_x,
-                                                     int tiles_y) {
-  extern __shared__ float smem[];  // acc[NB_R*NB_R][2][cch] | s_drpb[heads*25]
-  float* acc = smem;
-  float* s_drpb = smem + NB_R * NB_R * 2 * cch;
-  const int nacc = NB_R * NB_R * 2 * cch;
-  for (int i = threadIdx.x; i < nacc + g.heads * 25; i += 256) smem[i] = 0.f;
+__global__ __launch_bounds__(256) void na_bwd_q_kernel(const float* __restrict__ qkv, const float* __restrict__ rpb,
+                                                       const float* __restrict__ dout, float* __restrict__ dqkv,
+                                                       float* __restrict__ drpb, float* __restrict__ stat,
+                                                       const NaGeom g) {
+  extern __shared__ float s_drpb[];  // [heads][25]
+  for (int i = threadIdx.x; i < g.heads * 25; i += 256) s_drpb[i] = 0.f;
   __syncthreads();
-  const int tile = blockIdx.x % (tiles_x * tiles_y), b = blockIdx.x / (tiles_x * tiles_y);
-  const int ty0 = (tile / tiles_x) * NB_T, tx0 = (tile % tiles_x) * NB_T;
-  const int ch0 = blockIdx.y * cch;
-  const int cch4 = cch >> 2;
-  const int64_t ib = (int64_t)b * g.H * g.W * 3 * g.C;
-  const float* base = qkv + ib;
-  float* dbase = dqkv + ib;
-  const int items = NB_T * NB_T * cch4;
-  const int nit = (items + 255) / 256;
-  for (int it = 0; it < nit; ++it) {
-    int idx = it * 256 + threadIdx.x;
-    bool ok = idx < items;
-    if (!ok) idx = items - 1;  // keep every lane in the shuffles
-    const int c = ch0 + (idx % cch4) * 4;
-    const int pl = idx / cch4;
-    int y = ty0 + pl / NB_T, x = tx0 + pl % NB_T;
-    if (y >= g.H || x >= g.W || c >= g.C) ok = false;
-    y = y < g.H ? y : g.H - 1;
-    x = x < g.W ? x : g.W - 1;
-    const int cc = c < g.C ? c : g.C - 4;
+  const int64_t total = (int64_t)g.B * g.H * g.W * g.C4;
+  const int64_t nit = (total + (int64_t)gridDim.x * 256 - 1) / ((int64_t)gridDim.x * 256);
+  for (int64_t it = 0; it < nit; ++it) {
+    int64_t idx = (it * gridDim.x + blockIdx.x) * 256 + threadIdx.x;
+    const bool ok = idx < total;
+    if (!ok) idx = total - 1;  // keep every lane in the shuffles
+    const int c = (int)(idx % g.C4) * 4;
+    const int64_t pix = idx / g.C4;
+    const int x = (int)(pix % g.W);
+    const int y = (int)((pix / g.W) % g.H);
+    const int b = (int)(pix / ((int64_t)g.W * g.H));
     const int sy = wstart(y, g.H), sx = wstart(x, g.W);
-    const int64_t pix = ((int64_t)b * g.H + y) * g.W + x;
-    const f32x4 q = ld4(base + ((int64_t)y * g.W + x) * 3 * g.C + cc) * g.scale;
-    const f32x4 dO = ld4(dout + pix * g.C + cc);
+    const int64_t ib = (int64_t)b * g.H * g.W * 3 * g.C;
+    const float* base = qkv + ib;
+    const f32x4 q = ld4(base + ((int64_t)y * g.W + x) * 3 * g.C + c) * g.scale;
+    const f32x4 dO = ld4(dout + pix * g.C + c);
     int hidx[4];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) hidx[k] = ((cc + k) / HD) * 25;
+    for (int k = 0; k < 4; ++k) hidx[k] = ((c + k) / HD) * 25;
     f32x4 p[9], dp[9];
     f32x4 mx = f32x4{-3.0e38f, -3.0e38f, -3.0e38f, -3.0e38f};
 #pragma unroll
@@ -153,7 +143,7 @@ __global__ __launch_bounds__(256) void na_bwd_kernel(const float* __restrict__ q
       for (int kj = 0; kj < 3; ++kj) {
         const int ny = sy + ki, nx = sx + kj;
         const int64_t po = ((int64_t)ny * g.W + nx) * 3 * g.C;
-        const f32x4 kk = ld4(base + po + g.C + cc), vv = ld4(base + po + 2 * g.C + cc);
+        const f32x4 kk = ld4(base + po + g.C + c), vv = ld4(base + po + 2 * g.C + c);
         f32x4 s = head_sum<HD>(q * kk);
         const int bo = (ny - y + 2) * 5 + (nx - x + 2);
 #pragma unroll
@@ -178,9 +168,9 @@ __global__ __launch_bounds__(256) void na_bwd_kernel(const float* __restrict__ q
       dsum += p[n] * dp[n];
     }
     f32x4 dq = f32x4{0.f, 0.f, 0.f, 0.f};
-    bool rep[4];  // the lane owning a head's FIRST channel reports that head's rpb gradient
+    bool rep[4];  // the lane owning a head's FIRST channel reports for that head
 #pragma unroll
-    for (int k = 0; k < 4; ++k) rep[k] = ok && ((cc + k) % HD == 0);
+    for (int k = 0; k < 4; ++k) rep[k] = ok && ((c + k) % HD == 0);
 #pragma unroll
     for (int ki = 0; ki < 3; ++ki)
 #pragma unroll
@@ -188,36 +178,83 @@ __global__ __launch_bounds__(256) void na_bwd_kernel(const float* __restrict__ q
         const int n = ki * 3 + kj;
         const int ny = sy + ki, nx = sx + kj;
         const f32x4 ds = p[n] * (dp[n] - dsum);
-        const f32x4 kk = ld4(base + ((int64_t)ny * g.W + nx) * 3 * g.C + g.C + cc);
+        const f32x4 kk = ld4(base + ((int64_t)ny * g.W + nx) * 3 * g.C + g.C + c);
         dq += ds * kk;
-        if (ok) {
-          const f32x4 dk = ds * q;  // q already carries the scale
-          const f32x4 dv = p[n] * dO;
-          float* a = acc + (((ny - ty0 + NB_HALO) * NB_R + (nx - tx0 + NB_HALO)) * 2) * cch + (cc - ch0);
+        const int bo = (ny - y + 2) * 5 + (nx - x + 2);
 #pragma unroll
-          for (int k = 0; k < 4; ++k) {
-            atomicAdd(a + k, dk[k]);
-            atomicAdd(a + cch + k, dv[k]);
-          }
-          const int bo = (ny - y + 2) * 5 + (nx - x + 2);
-#pragma unroll
-          for (int k = 0; k < 4; ++k)
-            if (rep[k]) atomicAdd(&s_drpb[hidx[k] + bo], ds[k]);
-        }
+        for (int k = 0; k < 4; ++k)
+          if (rep[k]) atomicAdd(&s_drpb[hidx[k] + bo], ds[k]);
       }
-    if (ok) *reinterpret_cast<f32x4*>(dbase + ((int64_t)y * g.W + x) * 3 * g.C + cc) = dq * g.scale;
+    if (ok) *reinterpret_cast<f32x4*>(dqkv + ib + ((int64_t)y * g.W + x) * 3 * g.C + c) = dq * g.scale;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      if (rep[k]) {
+        const int h = (c + k) / HD;
+        stat[pix * 2 * g.heads + h] = mx[k] + __logf(den[k]);
+        stat[pix * 2 * g.heads + g.heads + h] = dsum[k];
+      }
   }
   __syncthreads();
-  // flush the tile+halo image of dK, dV
-  for (int i = threadIdx.x; i < nacc; i += 256) {
-    const int cl = i % cch, w = (i / cch) & 1, pp = i / (2 * cch);
-    const int gy = ty0 - NB_HALO + pp / NB_R, gx = tx0 - NB_HALO + pp % NB_R;
-    const float v = acc[i];
-    if (gy >= 0 && gy < g.H && gx >= 0 && gx < g.W && ch0 + cl < g.C && v != 0.f)
-      atomicAdd(dbase + ((int64_t)gy * g.W + gx) * 3 * g.C + (1 + w) * g.C + ch0 + cl, v);
-  }
   for (int i = threadIdx.x; i < g.heads * 25; i += 256)
     if (s_drpb[i] != 0.f) atomicAdd(drpb + i, s_drpb[i]);
+}
+
+template <int HD>
+__global__ __launch_bounds__(256) void na_bwd_kv_kernel(const float* __restrict__ qkv, const float* __restrict__ rpb,
+                                                        const float* __restrict__ dout, float* __restrict__ dqkv,
+                                                        const float* __restrict__ stat, const NaGeom g) {
+  const int64_t total = (int64_t)g.B * g.H * g.W * g.C4;
+  const int64_t nit = (total + (int64_t)gridDim.x * 256 - 1) / ((int64_t)gridDim.x * 256);
+  for (int64_t it = 0; it < nit; ++it) {
+    int64_t idx = (it * gridDim.x + blockIdx.x) * 256 + threadIdx.x;
+    const bool ok = idx < total;
+    if (!ok) idx = total - 1;
+    const int c = (int)(idx % g.C4) * 4;
+    const int64_t pix = idx / g.C4;
+    const int jx = (int)(pix % g.W);
+    const int jy = (int)((pix / g.W) % g.H);
+    const int b = (int)(pix / ((int64_t)g.W * g.H));
+    const int64_t ib = (int64_t)b * g.H * g.W * 3 * g.C;
+    const float* base = qkv + ib;
+    const int64_t kpo = ((int64_t)jy * g.W + jx) * 3 * g.C;
+    const f32x4 kj = ld4(base + kpo + g.C + c), vj = ld4(base + kpo + 2 * g.C + c);
+    int hidx[4], hd_[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { hd_[k] = (c + k) / HD; hidx[k] = hd_[k] * 25; }
+    f32x4 dk = f32x4{0.f, 0.f, 0.f, 0.f}, dv = dk;
+    // queries whose window contains row jy: iy in [jy-2, jy+2] with wstart(iy) <= jy <= wstart(iy)+2 (pixel-uniform
+    // across the lanes of a pixel, so the lane-pair shuffle of hd = 8 stays converged)
+    for (int iy = jy - 2; iy <= jy + 2; ++iy) {
+      if (iy < 0 || iy >= g.H) continue;
+      const int ki = jy - wstart(iy, g.H);
+      if (ki < 0 || ki > 2) continue;
+      for (int ix = jx - 2; ix <= jx + 2; ++ix) {
+        if (ix < 0 || ix >= g.W) continue;
+        const int kx = jx - wstart(ix, g.W);
+        if (kx < 0 || kx > 2) continue;
+        const int64_t ipix = ((int64_t)b * g.H + iy) * g.W + ix;
+        const f32x4 qi = ld4(base + ((int64_t)iy * g.W + ix) * 3 * g.C + c) * g.scale;
+        const f32x4 dOi = ld4(dout + ipix * g.C + c);
+        f32x4 s = head_sum<HD>(qi * kj);
+        const f32x4 dp = head_sum<HD>(dOi * vj);
+        const int bo = (jy - iy + 2) * 5 + (jx - ix + 2);
+        f32x4 pij, ds;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const float lse = stat[ipix * 2 * g.heads + hd_[k]];
+          const float dsm = stat[ipix * 2 * g.heads + g.heads + hd_[k]];
+          pij[k] = __expf(s[k] + rpb[hidx[k] + bo] - lse);
+          ds[k] = pij[k] * (dp[k] - dsm);
+        }
+        dk += ds * qi;   // qi carries the scale
+        dv += pij * dOi;
+      }
+    }
+    if (ok) {
+      *reinterpret_cast<f32x4*>(dqkv + ib + kpo + g.C + c) = dk;
+      *reinterpret_cast<f32x4*>(dqkv + ib + kpo + 2 * g.C + c) = dv;
+    }
+  }
 }
 
 inline int na_grid(int64_t total) {
@@ -250,28 +287,30 @@ int lmn_na_fwd(const float* qkv, const float* rpb, float* out, int B, int H, int
   return lmn_launch_status("na_fwd");
 }
 
-int lmn_na_bwd(const float* qkv, const float* rpb, const float* dout, float* dqkv, float* drpb, int B, int H, int W,
-               int heads, int hd, float scale, lmn_stream_t stream) {
-  LMN_REQUIRE(qkv && rpb && dout && dqkv && drpb, "na_bwd: null pointer");
+int lmn_na_bwd(const float* qkv, const float* rpb, const float* dout, float* dqkv, float* drpb, float* stat, int B,
+               int H, int W, int heads, int hd, float scale, lmn_stream_t stream) {
+  LMN_REQUIRE(qkv && rpb && dout && dqkv && drpb && stat, "na_bwd: null pointer");
   LMN_REQUIRE(B > 0 && H >= 3 && W >= 3, "na_bwd: feature map %dx%d smaller than the 3x3 window", H, W);
   LMN_REQUIRE(hd == 1 || hd == 2 || hd == 4 || hd == 8 || hd == 16, "na_bwd: head_dim %d not in {1,2,4,8,16}", hd);
   LMN_REQUIRE((heads * hd) % 4 == 0 && heads * 25 * sizeof(float) <= 48000, "na_bwd: heads=%d hd=%d", heads, hd);
   NaGeom g{B, H, W, heads * hd, heads * hd / 4, heads, scale};
-  // channel chunk: whole heads, a multiple of 8 channels (lane pairs for hd = 8), at most 24 (48 for hd = 16)
-  int cch = g.C <= 24 ? g.C : (hd == 16 ? 48 : 24);
-  while (g.C % cch) cch += (hd >= 4 ? hd : 4);
-  LMN_REQUIRE(cch % 4 == 0 && (cch % hd == 0 || hd % cch == 0), "na_bwd: channel chunk %d for hd %d", cch, hd);
-  const int tx = lmn_cdiv(W, NB_T), ty = lmn_cdiv(H, NB_T);
-  const dim3 grid(B * tx * ty, g.C / cch);
+  const int grid = na_grid((int64_t)B * H * W * g.C4);
+  const int gq = grid > 2048 ? 2048 : grid;
   hipStream_t st = (hipStream_t)stream;
-  const size_t sh = (size_t)(NB_R * NB_R * 2 * cch + heads * 25) * sizeof(float);
+  const size_t sh = heads * 25 * sizeof(float);
+#define LMN_NA(HDV)                                                                                                  \
+  do {                                                                                                               \
+    hipLaunchKernelGGL((na_bwd_q_kernel<HDV>), dim3(gq), dim3(256), sh, st, qkv, rpb, dout, dqkv, drpb, stat, g);    \
+    hipLaunchKernelGGL((na_bwd_kv_kernel<HDV>), dim3(grid), dim3(256), 0, st, qkv, rpb, dout, dqkv, stat, g);        \
+  } while (0)
   switch (hd) {
-    case 1: hipLaunchKernelGGL((na_bwd_kernel<1>), grid, dim3(256), sh, st, qkv, rpb, dout, dqkv, drpb, g, cch, tx, ty); break;
-    case 2: hipLaunchKernelGGL((na_bwd_kernel<2>), grid, dim3(256), sh, st, qkv, rpb, dout, dqkv, drpb, g, cch, tx, ty); break;
-    case 4: hipLaunchKernelGGL((na_bwd_kernel<4>), grid, dim3(256), sh, st, qkv, rpb, dout, dqkv, drpb, g, cch, tx, ty); break;
-    case 8: hipLaunchKernelGGL((na_bwd_kernel<8>), grid, dim3(256), sh, st, qkv, rpb, dout, dqkv, drpb, g, cch, tx, ty); break;
-    default: hipLaunchKernelGGL((na_bwd_kernel<16>), grid, dim3(256), sh, st, qkv, rpb, dout, dqkv, drpb, g, cch, tx, ty); break;
+    case 1: LMN_NA(1); break;
+    case 2: LMN_NA(2); break;
+    case 4: LMN_NA(4); break;
+    case 8: LMN_NA(8); break;
+    default: LMN_NA(16); break;
   }
+#undef LMN_NA
   return lmn_launch_status("na_bwd");
 }
 

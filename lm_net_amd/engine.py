@@ -487,7 +487,7 @@ class Engine:
         hip.ln_bwd(a, m.norm2.weight, dn2, dy, da, G[m.norm2.weight], G[m.norm2.bias])
         do = _E(x, B, H, W, C)
         self._lin_bwd(m.att1.proj, o, da, do)
-        dqkv = _Z(x, B, H, W, 3 * C)
+        dqkv = _E(x, B, H, W, 3 * C)
         hip.na_bwd(qkv, m.att1.rpb, do, dqkv, G[m.att1.rpb], m.att1.num_heads)
         dn1 = do
         self._lin_bwd(m.att1.qkv, n1, dqkv, dn1)

@@ -291,11 +291,13 @@ def na_fwd(qkv, rpb, out, heads):
     _check(load().lmn_na_fwd(_p(qkv), _p(rpb), _p(out), B, H, W, heads, hd, _f(hd ** -0.5), _stream()), "na_fwd")
 
 
-def na_bwd(qkv, rpb, dout, dqkv, drpb, heads):
+def na_bwd(qkv, rpb, dout, dqkv, drpb, heads, stat=None):
     B, H, W, C3 = qkv.shape
     hd = C3 // 3 // heads
-    _check(load().lmn_na_bwd(_p(qkv), _p(rpb), _p(dout), _p(dqkv), _p(drpb), B, H, W, heads, hd, _f(hd ** -0.5),
-                             _stream()), "na_bwd")
+    if stat is None:
+        stat = torch.empty(B * H * W * 2 * heads, device=qkv.device, dtype=torch.float32)
+    _check(load().lmn_na_bwd(_p(qkv), _p(rpb), _p(dout), _p(dqkv), _p(drpb), _p(stat), B, H, W, heads, hd,
+                             _f(hd ** -0.5), _stream()), "na_bwd")
 
 
 def gattn_fwd(qkv, out, lse, heads):

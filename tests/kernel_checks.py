@@ -324,7 +324,7 @@ def check_na():
         out = torch.full((B, H, W, Cn), float("nan"), device=DEV)
         hip.na_fwd(dev(qkv), dev(rpb), out, heads)
         rows.append(("na_fwd" + tag, rel(out, o_ref), TOL))
-        dqkv = torch.zeros(B, H, W, 3 * Cn, device=DEV)
+        dqkv = torch.full((B, H, W, 3 * Cn), float("nan"), device=DEV)
         drpb = torch.zeros(heads, 5, 5, device=DEV)
         hip.na_bwd(dev(qkv), dev(rpb), dev(do), dqkv, drpb, heads)
         rows.append(("na_bwd dqkv" + tag, rel(dqkv, qkv.grad), 2e-4))

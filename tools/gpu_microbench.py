@@ -52,7 +52,7 @@ def main():
         t = timeit(lambda: hip.na_fwd(qkv, rpb, out, 12))
         by = 4 * B * H * H * C * 4
         print("na_fwd      H=%3d C=%3d  %8.1f us  %7.1f GB/s alg (%.1f%% of 8 TB/s)" % (H, C, t * 1e6, by / t / 1e9, by / t / 8e12 * 100))
-        dq, drpb, do = torch.zeros_like(qkv), torch.zeros_like(rpb), torch.randn_like(out)
+        dq, drpb, do = torch.empty_like(qkv), torch.zeros_like(rpb), torch.randn_like(out)
         t = timeit(lambda: hip.na_bwd(qkv, rpb, do, dq, drpb, 12))
         print("na_bwd      H=%3d C=%3d  %8.1f us  %7.1f GB/s alg" % (H, C, t * 1e6, 7 * B * H * H * C * 4 / t / 1e9))
     convs = [("1x1 12->24 L0", 352, [12], 24, 1, 1), ("1x1 24+12->12 L0", 352, [24, 12], 12, 1, 1), ("3x3 12->12 L0", 352, [12], 12, 3, 1),
