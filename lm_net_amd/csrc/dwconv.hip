@@ -23,24 +23,38 @@ namespace {
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-constexpr int FW_TH = 16, FW_TW = 16, FW_CCH = 24, FW_NCP = FW_CCH / 2, FW_THREADS = FW_TW * FW_NCP;  // 192
+constexpr int FW_TH = 16, FW_TW = 16;
 constexpr int FW_RW = FW_TW + 4, FW_RH = FW_TH + 4;
 
-__global__ __launch_bounds__(FW_THREADS) void dw_fwd_kernel(const float* __restrict__ x1, float* __restrict__ pre,
-                                                            float* __restrict__ gsum, int H, int W, int E,
-                                                            const float* __restrict__ keff,
-                                                            const float* __restrict__ beff, int tiles_x) {
-  __shared__ __attribute__((aligned(16))) float tile[FW_RH * FW_RW * FW_CCH];
-  __shared__ float gs_s[FW_CCH];
+// XCD-aware block order (guide T1, bijective form): consecutive LOGICAL tiles run on the same XCD, so the 2-pixel
+// halos shared by neighbouring tiles hit that XCD's L2 instead of being re-fetched from HBM by another XCD.
+__device__ __forceinline__ int xcd_swizzle(int bid, int nwg) {
+  const int qd = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+  return (xcd < r ? xcd * (qd + 1) : r * (qd + 1) + (xcd - r) * qd) + (bid >> 3);
+}
+
+// CCH = channels per block: 24 (E = 24: a pixel is 96 B, rows are contiguous), 48 (E = 48) or 32 (E % 32 == 0:
+// 128-B-aligned chunks) -- a chunk must cover whole cache lines or HBM fetches double (PMC: 2.7x at E = 48 with 24).
+template <int CCH>
+__global__ __launch_bounds__(FW_TW * CCH / 2) void dw_fwd_kernel(const float* __restrict__ x1, float* __restrict__ pre,
+                                                                  float* __restrict__ gsum, int H, int W, int E,
+                                                                  const float* __restrict__ keff,
+                                                                  const float* __restrict__ beff, int tiles_x,
+                                                                  int tiles, int chunks) {
+  constexpr int NCP = CCH / 2, THREADS = FW_TW * NCP;
+  extern __shared__ __attribute__((aligned(16))) float tile[];  // [FW_RH*FW_RW][CCH] | gs_s[CCH]
+  float* gs_s = tile + FW_RH * FW_RW * CCH;
   const int tid = threadIdx.x;
-  const int ty0 = (blockIdx.x / tiles_x) * FW_TH, tx0 = (blockIdx.x % tiles_x) * FW_TW;
-  const int ch0 = blockIdx.y * FW_CCH;
-  const int b = blockIdx.z;
+  const int lid = xcd_swizzle(blockIdx.x, gridDim.x);  // logical block: tile fastest, then chunk, then image
+  const int t = lid % tiles, cb = lid / tiles;
+  const int ty0 = (t / tiles_x) * FW_TH, tx0 = (t % tiles_x) * FW_TW;
+  const int ch0 = (cb % chunks) * CCH;
+  const int b = cb / chunks;
   const float* xb = x1 + (int64_t)b * H * W * E;
 
-  if (tid < FW_CCH) gs_s[tid] = 0.f;
-  for (int i = tid; i < FW_RH * FW_RW * (FW_CCH / 4); i += FW_THREADS) {
-    const int c4 = i % (FW_CCH / 4), pix = i / (FW_CCH / 4);
+  if (tid < CCH) gs_s[tid] = 0.f;
+  for (int i = tid; i < FW_RH * FW_RW * (CCH / 4); i += THREADS) {
+    const int c4 = i % (CCH / 4), pix = i / (CCH / 4);
     const int r = pix / FW_RW, c = pix - r * FW_RW;
     const int gy = ty0 - 2 + r, gx = tx0 - 2 + c;
     // unconditional load from a clamped (in-bounds) address + select: loads under a per-lane branch serialise
@@ -48,15 +62,15 @@ __global__ __launch_bounds__(FW_THREADS) void dw_fwd_kernel(const float* __restr
     const int sy = in ? gy : 0, sx = in ? gx : 0, sc = in ? ch0 + c4 * 4 : 0;
     f32x4 v = *reinterpret_cast<const f32x4*>(xb + ((int64_t)sy * W + sx) * E + sc);
     if (!in) v = f32x4{0.f, 0.f, 0.f, 0.f};
-    *reinterpret_cast<f32x4*>(&tile[pix * FW_CCH + c4 * 4]) = v;
+    *reinterpret_cast<f32x4*>(&tile[pix * CCH + c4 * 4]) = v;
   }
 
-  const int cp = tid % FW_NCP, xx = tid / FW_NCP;
+  const int cp = tid % NCP, xx = tid / NCP;
   const int ch = ch0 + cp * 2;
   const bool cok = ch < E;  // E is a multiple of 4: a channel pair is valid as a whole (last chunk may be partial)
   f32x2 w[25];
 #pragma unroll
-  for (int t = 0; t < 25; ++t) w[t] = cok ? f32x2{keff[(int64_t)ch * 25 + t], keff[(int64_t)(ch + 1) * 25 + t]} : f32x2{0.f, 0.f};
+  for (int k = 0; k < 25; ++k) w[k] = cok ? f32x2{keff[(int64_t)ch * 25 + k], keff[(int64_t)(ch + 1) * 25 + k]} : f32x2{0.f, 0.f};
   const f32x2 bias = cok ? f32x2{beff[ch], beff[ch + 1]} : f32x2{0.f, 0.f};
   __syncthreads();
 
@@ -69,7 +83,7 @@ __global__ __launch_bounds__(FW_THREADS) void dw_fwd_kernel(const float* __restr
   for (int r = 0; r < FW_RH; ++r) {
     f32x2 in[5];
 #pragma unroll
-    for (int dx = 0; dx < 5; ++dx) in[dx] = *reinterpret_cast<const f32x2*>(&tile[(r * FW_RW + xx + dx) * FW_CCH + cp * 2]);
+    for (int dx = 0; dx < 5; ++dx) in[dx] = *reinterpret_cast<const f32x2*>(&tile[(r * FW_RW + xx + dx) * CCH + cp * 2]);
 #pragma unroll
     for (int ky = 0; ky < 5; ++ky) {
       const int o = r - ky;
@@ -89,10 +103,12 @@ __global__ __launch_bounds__(FW_THREADS) void dw_fwd_kernel(const float* __restr
       }
     }
   }
+  // SE squeeze: lanes sharing a channel pair are NCP apart -> LDS row per thread column would need atomics; the sums
+  // are only 2 floats per thread, so a few ds_add_f32 per thread are acceptable here
   atomicAdd(&gs_s[cp * 2], gs[0]);
   atomicAdd(&gs_s[cp * 2 + 1], gs[1]);
   __syncthreads();
-  if (tid < FW_CCH && ch0 + tid < E) atomicAdd(gsum + (int64_t)b * E + ch0 + tid, gs_s[tid]);
+  if (tid < CCH && ch0 + tid < E) atomicAdd(gsum + (int64_t)b * E + ch0 + tid, gs_s[tid]);
 }
 
 __global__ void dw_merge_kernel(const float* __restrict__ w5, const float* __restrict__ w3, const float* __restrict__ wv,
@@ -421,8 +437,19 @@ int lmn_dw_fwd(const float* x1, float* pre, float* gsum, int B, int H, int W, in
   LMN_REQUIRE(x1 && pre && gsum && keff && beff, "dw_fwd: null pointer");
   LMN_REQUIRE(B > 0 && H > 0 && W > 0 && E > 0 && E % 4 == 0, "dw_fwd: E=%d must be a multiple of 4", E);
   const int tx = lmn_cdiv(W, FW_TW), ty = lmn_cdiv(H, FW_TH);
-  hipLaunchKernelGGL(dw_fwd_kernel, dim3(tx * ty, lmn_cdiv(E, FW_CCH), B), dim3(FW_THREADS), 0, (hipStream_t)stream, x1, pre,
-                     gsum, H, W, E, keff, beff, tx);
+  const int cch = (E % 32 == 0) ? 32 : (E == 48 ? 48 : 24);
+  const int chunks = lmn_cdiv(E, cch);
+  const int grid = tx * ty * chunks * B;
+  const size_t sh = (size_t)(FW_RH * FW_RW * cch + cch) * sizeof(float);
+  hipStream_t st = (hipStream_t)stream;
+  if (cch == 24) {
+    hipLaunchKernelGGL((dw_fwd_kernel<24>), dim3(grid), dim3(FW_TW * 12), sh, st, x1, pre, gsum, H, W, E, keff, beff, tx, tx * ty, chunks);
+  } else if (cch == 32) {
+    hipLaunchKernelGGL((dw_fwd_kernel<32>), dim3(grid), dim3(FW_TW * 16), sh, st, x1, pre, gsum, H, W, E, keff, beff, tx, tx * ty, chunks);
+  } else {
+    (void)hipFuncSetAttribute((const void*)dw_fwd_kernel<48>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+    hipLaunchKernelGGL((dw_fwd_kernel<48>), dim3(grid), dim3(FW_TW * 24), sh, st, x1, pre, gsum, H, W, E, keff, beff, tx, tx * ty, chunks);
+  }
   return lmn_launch_status("dw_fwd");
 }
 

@@ -43,41 +43,72 @@ __device__ __forceinline__ int wstart(int i, int L) {
   return s > L - 3 ? L - 3 : s;
 }
 
+// XCD-aware block order (guide T1, bijective): consecutive logical tiles share an XCD and therefore an L2.
+__device__ __forceinline__ int xcd_swizzle(int bid, int nwg) {
+  const int qd = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+  return (xcd < r ? xcd * (qd + 1) : r * (qd + 1) + (xcd - r) * qd) + (bid >> 3);
+}
+
+// Forward.  One block = a T x T query tile x a channel chunk of one image.  The k and v rows the tile's clamped
+// 3x3 windows can touch ((T+2)^2 pixels; the origin follows the clamping at the image border) are staged ONCE in
+// LDS by coalesced float4 loads, so the 9x neighbour re-use never leaves the CU: measured HBM fetch of the
+// direct-from-L1 form was 4.4x the algorithmic bytes (rocprof FETCH_SIZE), this form reads (T+2)^2/T^2.
 template <int HD>
 __global__ __launch_bounds__(256) void na_fwd_kernel(const float* __restrict__ qkv, const float* __restrict__ rpb,
-                                                     float* __restrict__ out, const NaGeom g) {
-  const int64_t total = (int64_t)g.B * g.H * g.W * g.C4;
-  const int64_t nit = (total + (int64_t)gridDim.x * 256 - 1) / ((int64_t)gridDim.x * 256);
-  for (int64_t it = 0; it < nit; ++it) {
-    int64_t idx = (it * gridDim.x + blockIdx.x) * 256 + threadIdx.x;
-    const bool ok = idx < total;
-    if (!ok) idx = total - 1;  // keep every lane in the shuffles
-    const int c = (int)(idx % g.C4) * 4;
-    const int64_t pix = idx / g.C4;
-    const int x = (int)(pix % g.W);
-    const int y = (int)((pix / g.W) % g.H);
-    const int b = (int)(pix / ((int64_t)g.W * g.H));
+                                                     float* __restrict__ out, const NaGeom g, int T, int cch,
+                                                     int tiles_x, int tiles, int chunks) {
+  extern __shared__ __attribute__((aligned(16))) float KV[];  // [(T+2)^2][2][cch]
+  const int R = T + 2;
+  const int lid = xcd_swizzle(blockIdx.x, gridDim.x);
+  const int t = lid % tiles, cb = lid / tiles;
+  const int ty0 = (t / tiles_x) * T, tx0 = (t % tiles_x) * T;
+  const int ch0 = (cb % chunks) * cch, b = cb / chunks;
+  const int rlo = max(0, min(ty0 - 1, g.H - 3)), clo = max(0, min(tx0 - 1, g.W - 3));
+  const int cch4 = cch >> 2;
+  const float* base = qkv + (int64_t)b * g.H * g.W * 3 * g.C;
+  for (int i = threadIdx.x; i < R * R * 2 * cch4; i += 256) {
+    const int c4 = i % cch4, w = (i / cch4) & 1, pix = i / (2 * cch4);
+    const int gy = rlo + pix / R, gx = clo + pix % R;
+    const bool in = gy < g.H && gx < g.W && ch0 + c4 * 4 < g.C;
+    const int sy = in ? gy : 0, sx = in ? gx : 0, sc = in ? ch0 + c4 * 4 : 0;
+    f32x4 v = ld4(base + ((int64_t)sy * g.W + sx) * 3 * g.C + (1 + w) * g.C + sc);
+    if (!in) v = f32x4{0.f, 0.f, 0.f, 0.f};
+    *reinterpret_cast<f32x4*>(&KV[(pix * 2 + w) * cch + c4 * 4]) = v;
+  }
+  __syncthreads();
+  const int items = T * T * cch4;
+  const int nit = (items + 255) / 256;
+  for (int it = 0; it < nit; ++it) {
+    int idx = it * 256 + threadIdx.x;
+    bool ok = idx < items;
+    if (!ok) idx = items - 1;  // keep every lane in the shuffles
+    const int cl = (idx % cch4) * 4, pl = idx / cch4;
+    int y = ty0 + pl / T, x = tx0 + pl % T;
+    const int c = ch0 + cl;
+    if (y >= g.H || x >= g.W || c >= g.C) ok = false;
+    y = y < g.H ? y : g.H - 1;
+    x = x < g.W ? x : g.W - 1;
+    const int cc = c < g.C ? c : g.C - 4, ccl = cc - ch0;
     const int sy = wstart(y, g.H), sx = wstart(x, g.W);
-    const float* base = qkv + (int64_t)b * g.H * g.W * 3 * g.C;
-    const f32x4 q = ld4(base + ((int64_t)y * g.W + x) * 3 * g.C + c) * g.scale;
+    const f32x4 q = ld4(base + ((int64_t)y * g.W + x) * 3 * g.C + cc) * g.scale;
     int hidx[4];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) hidx[k] = ((c + k) / HD) * 25;
+    for (int k = 0; k < 4; ++k) hidx[k] = ((cc + k) / HD) * 25;
+    const float* kv0 = KV + (((sy - rlo) * R + (sx - clo)) * 2) * cch + ccl;
     f32x4 l[9];
     f32x4 mx = f32x4{-3.0e38f, -3.0e38f, -3.0e38f, -3.0e38f};
 #pragma unroll
     for (int ki = 0; ki < 3; ++ki)
 #pragma unroll
       for (int kj = 0; kj < 3; ++kj) {
-        const int ny = sy + ki, nx = sx + kj;
-        const f32x4 kk = ld4(base + ((int64_t)ny * g.W + nx) * 3 * g.C + g.C + c);
-        f32x4 s = head_sum<HD>(q * kk);
-        const int bo = (ny - y + 2) * 5 + (nx - x + 2);
+        const f32x4 kk = *reinterpret_cast<const f32x4*>(kv0 + ((ki * R + kj) * 2) * cch);
+        f32x4 sc = head_sum<HD>(q * kk);
+        const int bo = (sy + ki - y + 2) * 5 + (sx + kj - x + 2);
 #pragma unroll
-        for (int k = 0; k < 4; ++k) s[k] += rpb[hidx[k] + bo];
-        l[ki * 3 + kj] = s;
+        for (int k = 0; k < 4; ++k) sc[k] += rpb[hidx[k] + bo];
+        l[ki * 3 + kj] = sc;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) mx[k] = fmaxf(mx[k], s[k]);
+        for (int k = 0; k < 4; ++k) mx[k] = fmaxf(mx[k], sc[k]);
       }
     f32x4 den = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -90,13 +121,10 @@ __global__ __launch_bounds__(256) void na_fwd_kernel(const float* __restrict__ q
 #pragma unroll
     for (int ki = 0; ki < 3; ++ki)
 #pragma unroll
-      for (int kj = 0; kj < 3; ++kj) {
-        const f32x4 vv = ld4(base + ((int64_t)(sy + ki) * g.W + sx + kj) * 3 * g.C + 2 * g.C + c);
-        o += l[ki * 3 + kj] * vv;
-      }
+      for (int kj = 0; kj < 3; ++kj) o += l[ki * 3 + kj] * *reinterpret_cast<const f32x4*>(kv0 + ((ki * R + kj) * 2 + 1) * cch);
 #pragma unroll
     for (int k = 0; k < 4; ++k) o[k] = o[k] / den[k];
-    if (ok) *reinterpret_cast<f32x4*>(out + pix * g.C + c) = o;
+    if (ok) *reinterpret_cast<f32x4*>(out + (((int64_t)b * g.H + y) * g.W + x) * g.C + cc) = o;
   }
 }
 
@@ -274,16 +302,24 @@ int lmn_na_fwd(const float* qkv, const float* rpb, float* out, int B, int H, int
   LMN_REQUIRE(hd == 1 || hd == 2 || hd == 4 || hd == 8 || hd == 16, "na_fwd: head_dim %d not in {1,2,4,8,16}", hd);
   LMN_REQUIRE((heads * hd) % 4 == 0, "na_fwd: C=%d must be a multiple of 4", heads * hd);
   NaGeom g{B, H, W, heads * hd, heads * hd / 4, heads, scale};
-  LMN_REQUIRE(hd < 8 || (g.C4 % (hd / 4)) == 0, "na_fwd: geometry");
-  const int grid = na_grid((int64_t)B * H * W * g.C4);
+  // channel chunk: whole heads and whole lane pairs; tile 16x16 while the k/v window fits 64 KB of LDS, else 8x8
+  int cch = g.C <= 48 ? g.C : 48;
+  while (g.C % cch || cch % (hd > 4 ? hd : 4)) cch -= 4;
+  LMN_REQUIRE(cch >= 4 && cch % hd == 0, "na_fwd: channel chunk %d for hd %d", cch, hd);
+  const int T = (18 * 18 * 2 * cch * 4 <= 48 * 1024) ? 16 : 8;
+  const int tx = lmn_cdiv(W, T), ty = lmn_cdiv(H, T), chunks = g.C / cch;
+  const int grid = tx * ty * chunks * B;
+  const size_t sh = (size_t)(T + 2) * (T + 2) * 2 * cch * sizeof(float);
   hipStream_t st = (hipStream_t)stream;
+#define LMN_NAF(HDV) hipLaunchKernelGGL((na_fwd_kernel<HDV>), dim3(grid), dim3(256), sh, st, qkv, rpb, out, g, T, cch, tx, tx * ty, chunks)
   switch (hd) {
-    case 1: hipLaunchKernelGGL((na_fwd_kernel<1>), dim3(grid), dim3(256), 0, st, qkv, rpb, out, g); break;
-    case 2: hipLaunchKernelGGL((na_fwd_kernel<2>), dim3(grid), dim3(256), 0, st, qkv, rpb, out, g); break;
-    case 4: hipLaunchKernelGGL((na_fwd_kernel<4>), dim3(grid), dim3(256), 0, st, qkv, rpb, out, g); break;
-    case 8: hipLaunchKernelGGL((na_fwd_kernel<8>), dim3(grid), dim3(256), 0, st, qkv, rpb, out, g); break;
-    default: hipLaunchKernelGGL((na_fwd_kernel<16>), dim3(grid), dim3(256), 0, st, qkv, rpb, out, g); break;
+    case 1: LMN_NAF(1); break;
+    case 2: LMN_NAF(2); break;
+    case 4: LMN_NAF(4); break;
+    case 8: LMN_NAF(8); break;
+    default: LMN_NAF(16); break;
   }
+#undef LMN_NAF
   return lmn_launch_status("na_fwd");
 }
 
