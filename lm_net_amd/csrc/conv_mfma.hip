@@ -858,7 +858,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_lds_kernel(const WgradParams P) 
   }
 
   f32x4 acc[TAPS][NMT][NNT];
-  f32x4 accb[NMT];
+  float bsum[NMT];  // bias gradient: running sum of this lane's dy values (pixel q of every K step, channel n)
 #pragma unroll
   for (int tp = 0; tp < TAPS; ++tp)
 #pragma unroll
@@ -866,7 +866,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_lds_kernel(const WgradParams P) 
 #pragma unroll
       for (int t = 0; t < NNT; ++t) acc[tp][m][t] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-  for (int m = 0; m < NMT; ++m) accb[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int m = 0; m < NMT; ++m) bsum[m] = 0.f;
 
   const int t_begin = (int)(((int64_t)blockIdx.x * P.total_tiles) / gridDim.x);
   const int t_end = (int)(((int64_t)(blockIdx.x + 1) * P.total_tiles) / gridDim.x);
@@ -942,10 +942,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_lds_kernel(const WgradParams P) 
 #pragma unroll
         for (int m = 0; m < NMT; ++m) av[m] = 0.f;
       }
-      if (A.db && nset == 0) {
 #pragma unroll
-        for (int m = 0; m < NMT; ++m) accb[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[m], 1.0f, accb[m], 0, 0, 0);
-      }
+      for (int m = 0; m < NMT; ++m) bsum[m] += av[m];
 #pragma unroll
       for (int tp = 0; tp < TAPS; ++tp)
 #pragma unroll
@@ -973,14 +971,15 @@ __global__ __launch_bounds__(256, 2) void wgrad_lds_kernel(const WgradParams P) 
               float* d = &s_acc[(((tp * NMT + m) * NNT + t) * 4 + r) * 64 + lane];
               *d = (w == 0) ? acc[tp][m][t][r] : *d + acc[tp][m][t][r];
             }
-      if (n == 0) {  // bias sums live in column 0 of accb (lanes n == 0), rows 4q + r
 #pragma unroll
-        for (int m = 0; m < NMT; ++m)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            float* d = &s_acc[NT * 256 + m * 16 + q * 4 + r];
-            *d = (w == 0) ? accb[m][r] : *d + accb[m][r];
-          }
+      for (int m = 0; m < NMT; ++m) {  // bias: sum the 4 pixel lanes (q) of channel n
+        float v = bsum[m];
+        v += __shfl_xor(v, 16, 64);
+        v += __shfl_xor(v, 32, 64);
+        if (q == 0) {
+          float* d = &s_acc[NT * 256 + m * 16 + n];
+          *d = (w == 0) ? v : *d + v;
+        }
       }
     }
     __syncthreads();
@@ -1238,7 +1237,9 @@ int lmn_conv_fwd(const lmn_conv_args_t* args, lmn_stream_t stream) {
     int maxkb = 0;
     for (int s = 0; s < a.nsrc; ++s) maxkb = P.nkb[s] > maxkb ? P.nkb[s] : maxkb;
     T.CKB = maxkb < 2 ? maxkb : 2;
-    T.CS = T.CKB * 16 + 4;
+    // LDS pixel stride: conflict-free ds_read_b128 for 16 pixels st_in apart (brute-forced over the b128 lane groups):
+    // +8 floats at unit stride, +4 at stride 2 (PMC: 0.5 conflict cycles per LDS cycle with +4 at unit stride)
+    T.CS = T.CKB * 16 + (st_in == 1 ? 8 : 4);
     T.tiles_x = (a.Wout + T.TW - 1) / T.TW;
     T.tiles_y = (a.Hout + T.TH - 1) / T.TH;
     T.total_tiles = a.B * T.tiles_x * T.tiles_y;
