@@ -97,10 +97,10 @@ class DistributedLMNet(torch.nn.Module):
     """``model = DistributedLMNet(LM_Net(...).cuda())`` -- the data-parallel wrapper.  ``forward`` is the
     wrapped model's; gradients are averaged across ranks by the time ``loss.backward()`` returns."""
 
-    def __init__(self, model, process_group=None, bucket_bytes=4 << 20):
+    def __init__(self, model, process_group=None, bucket_bytes=4 << 20, first_bucket_bytes=1 << 20):
         super().__init__()
         self.module = model
-        self.reducer = GradReducer(process_group, bucket_bytes)
+        self.reducer = GradReducer(process_group, bucket_bytes, first_bucket_bytes)
         broadcast_state(model, 0, process_group)
         model.grad_begin_hook = self.reducer.begin
         model.grad_ready_hook = self.reducer.ready

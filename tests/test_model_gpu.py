@@ -148,3 +148,42 @@ def test_dropout_train_mode_is_active_and_consistent():
     m.eval()
     with torch.no_grad():
         assert (m(x) - m(x)).abs().max() < 1e-5      # eval: no dropout (float-atomic SE sums may differ in the last bits)
+
+
+def test_eval_512x512_vs_oracle():
+    """BASELINE configs[4] resolution (512x512; GFT runs on 1024 tokens): eval forward against the CPU oracle."""
+    from oracle.lmnet_ref import LM_Net as Oracle
+    ora = Oracle(3, 2)
+    fill_module(ora, 7)
+    ora.eval()
+    m = _net(seed=7)
+    m.eval()
+    x = det_input((1, 3, 512, 512), "t512/x")
+    with torch.no_grad():
+        yo = ora(x)
+        yg = m(x.cuda())
+    assert rel_err(yg, yo) < TOL
+    assert (yg.argmax(1).cpu() != yo.argmax(1)).float().mean() < 1e-4
+
+
+def test_non_square_and_odd_tile_sizes_vs_oracle():
+    """H, W only need to be multiples of 16: 48x80 exercises partial tiles at every level (3x5 .. 48x80)."""
+    from oracle.lmnet_ref import LM_Net as Oracle
+    ora = Oracle(3, 2)
+    fill_module(ora, 9)
+    no_dropout(ora)
+    m = _net(seed=9)
+    x = det_input((3, 3, 48, 80), "odd/x")
+    ora.train(); m.train()
+    xo = x.clone().requires_grad_(True)
+    xg = x.cuda().requires_grad_(True)
+    yo, yg = ora(xo), m(xg)
+    assert rel_err(yg, yo) < TOL
+    G = det_input(tuple(yo.shape), "odd/G")
+    (yo * G).sum().backward()
+    (yg * G.cuda()).sum().backward()
+    assert rel_err(xg.grad, xo.grad) < 2e-3
+    gmax = max(float(p.grad.abs().max()) for p in ora.parameters())
+    for (k, po), (_, pg) in zip(ora.named_parameters(), m.named_parameters()):
+        err = float((pg.grad.cpu() - po.grad).abs().max())
+        assert err < 2e-3 * float(po.grad.abs().max()) or err < 5e-5 * gmax, (k, err)
