@@ -563,6 +563,233 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(const ConvParams P) {
   }
 }
 
+// M-split variant for wide layers (Cout >= 64): the four waves of a block own DIFFERENT cout tiles (wave w: tiles
+// ct0 + w + 4i, i < NCW) and ALL pixel groups of the tile, instead of different pixel groups and all cout tiles.
+// Each weight fragment is then fetched by exactly one wave of the block (the N-split form pulls every fragment
+// through L1 four times; at Cout = 372 that stream, not the MFMAs, set the pace) and feeds 8 x 4 MFMAs; the pixel
+// operand comes from LDS, where re-reading it per wave is cheap.
+template <int TAPS, int NCW, int EPI>
+__global__ __launch_bounds__(256) void conv_tileM_kernel(const ConvParams P) {
+  constexpr int NCT = 4 * NCW;  // cout tiles per block
+  const lmn_conv_args_t& A = P.a;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* XS = smem;                       // [XH*XW][CS]
+  float* s_stats = smem + P.XH * P.XW * P.CS;  // [2][NCT*16]
+  constexpr int NGM = 8;                       // pixel groups per tile (all owned by every wave)
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int q = lane >> 4, n = lane & 15;
+  const int ct0 = blockIdx.y * NCT;
+  const int pad = A.ksize >> 1;
+  constexpr int KS = TAPS == 9 ? 3 : 1;
+
+  for (int i = tid; i < 2 * NCT * 16; i += 256) s_stats[i] = 0.f;
+  float st0[NCW][4], st1[NCW][4];
+#pragma unroll
+  for (int c = 0; c < NCW; ++c)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) st0[c][r] = st1[c][r] = 0.f;
+  int cur_b = -1;  // image whose SE_BWD sums are in st0
+
+  const int t_begin = (int)(((int64_t)blockIdx.x * P.total_tiles) / gridDim.x);
+  const int t_end = (int)(((int64_t)(blockIdx.x + 1) * P.total_tiles) / gridDim.x);
+  for (int tile = t_begin; tile < t_end; ++tile) {
+    const int b = tile / (P.tiles_x * P.tiles_y), tt = tile - b * P.tiles_x * P.tiles_y;
+    const int oy0 = (tt / P.tiles_x) * P.TH, ox0 = (tt % P.tiles_x) * P.TW;
+    // window origin in input coordinates (forward: out*s - pad; data gradient, stride 1: out - pad, taps flipped)
+    const int wy0 = A.transposed ? oy0 - pad : oy0 * A.stride - pad;
+    const int wx0 = A.transposed ? ox0 - pad : ox0 * A.stride - pad;
+
+    if (EPI && A.epilogue == LMN_EP_SE_BWD && b != cur_b) {  // block-uniform: flush the previous image's sums
+      if (cur_b >= 0) {
+#pragma unroll
+        for (int c = 0; c < NCW; ++c)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float t = st0[c][r];
+            t += __shfl_xor(t, 1, 64); t += __shfl_xor(t, 2, 64); t += __shfl_xor(t, 4, 64); t += __shfl_xor(t, 8, 64);
+            const int ctc = ct0 + wv + 4 * c;
+            const int co = ctc * 16 + q * 4 + r;
+            if (n == 0 && ctc < P.NCTT && co < A.Cout) atomicAdd(A.stats + cur_b * A.Cout + co, t);
+            st0[c][r] = 0.f;
+          }
+      }
+      cur_b = b;
+    }
+
+    // this wave's two pixel groups: tile pixel -> (row, col), LDS base address, validity
+    int pbase[NGM], opix[NGM];
+    bool pvalid[NGM];
+#pragma unroll
+    for (int g = 0; g < NGM; ++g) {
+      const int i = g * 16 + n;
+      const bool in_t = i < P.TP;
+      const int is = in_t ? i : 0;
+      const int r = (int)__umulhi((uint32_t)is, P.mTW), c = is - r * P.TW;
+      const int oy = oy0 + r, ox = ox0 + c;
+      pvalid[g] = in_t && oy < A.Hout && ox < A.Wout;
+      opix[g] = pvalid[g] ? (b * A.Hout + oy) * A.Wout + ox : 0;
+      const int sr = A.transposed ? r : r * A.stride, sc = A.transposed ? c : c * A.stride;
+      pbase[g] = (sr * P.XW + sc) * P.CS + q * 4;
+    }
+    f32x4 acc[NGM][NCW];
+#pragma unroll
+    for (int g = 0; g < NGM; ++g)
+#pragma unroll
+      for (int c = 0; c < NCW; ++c) acc[g][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    for (int s = 0; s < A.nsrc; ++s) {
+      const lmn_src_t& S = A.src[s];
+      for (int kb0 = 0; kb0 < P.nkb[s]; kb0 += P.CKB) {
+        const int nkbc = P.nkb[s] - kb0 < P.CKB ? P.nkb[s] - kb0 : P.CKB;
+        __syncthreads();  // previous chunk / tile fully consumed
+        // ---- stage the window chunk: unconditional float4 loads from clamped addresses, transforms, zero padding
+        const int per_px = nkbc * 4;
+        for (int i = tid; i < P.XH * P.XW * per_px; i += 256) {
+          const int f = i % per_px, pix = i / per_px;
+          const int r = (int)__umulhi((uint32_t)pix, P.mXW), c = pix - r * P.XW;
+          const int iy = wy0 + r, ix = wx0 + c;
+          const int ch = kb0 * 16 + f * 4;
+          const bool ok = ch < S.C && (unsigned)iy < (unsigned)A.Hin && (unsigned)ix < (unsigned)A.Win;
+          const int gp = ok ? (b * A.Hin + iy) * A.Win + ix : 0;
+          const int chs = ok ? ch : 0;
+          f32x4 v = ld4(S.ptr + (uint32_t)(gp * S.cstride + chs));
+          if (S.flags & LMN_SRC_GELU) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] = lmn_gelu(v[k]);
+          }
+          if (S.flags & LMN_SRC_DROP) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] *= lmn_drop_scale(S.drop_seed, (uint32_t)(gp * S.C + chs + k), S.drop_p, P.inv_keep_src[s]);
+          }
+          if (S.scale) v *= ld4(S.scale + b * S.C + chs);
+          if (!ok) v = f32x4{0.f, 0.f, 0.f, 0.f};
+          *reinterpret_cast<f32x4*>(&XS[pix * P.CS + f * 4]) = v;
+        }
+        __syncthreads();
+        // ---- MFMA: taps x K16 blocks of the chunk
+#pragma unroll 1
+        for (int tap = 0; tap < TAPS; ++tap) {
+          const int ty = tap / KS, tx = tap - ty * KS;
+          const int fy = A.transposed ? KS - 1 - ty : ty, fx = A.transposed ? KS - 1 - tx : tx;
+          const int toff = (fy * P.XW + fx) * P.CS;
+          for (int kk = 0; kk < nkbc; ++kk) {
+            const float* wp = A.wpack + ((((int64_t)tap * P.NKB + P.kb_off[s] + kb0 + kk) * P.NCTT + ct0 + wv) * 64 + lane) * 4;
+            f32x4 wv4[NCW];
+#pragma unroll
+            for (int c = 0; c < NCW; ++c) wv4[c] = ld4(wp + (ct0 + wv + 4 * c < P.NCTT ? c * 4 * 256 : 0));
+#pragma unroll
+            for (int g = 0; g < NGM; ++g) {
+              if (g < P.NG) {
+                const f32x4 xg = *reinterpret_cast<const f32x4*>(&XS[pbase[g] + toff + kk * 16]);
+#pragma unroll
+                for (int c = 0; c < NCW; ++c)
+#pragma unroll
+                  for (int j = 0; j < 4; ++j) acc[g][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv4[c][j], xg[j], acc[g][c], 0, 0, 0);
+              }
+            }
+          }
+        }
+      }
+    }
+
+    // ---- epilogue (lane holds channels co..co+3 of its pixel)
+#pragma unroll
+    for (int g = 0; g < NGM; ++g) {
+      const uint32_t opx = (uint32_t)opix[g];
+#pragma unroll
+      for (int c = 0; c < NCW; ++c) {
+        const int ctc = ct0 + wv + 4 * c;
+        const int co = ctc * 16 + q * 4;
+        const bool cok = ctc < P.NCTT && co < A.Cout;
+        const bool live = pvalid[g] && cok && g < P.NG;
+        const int cos = cok ? co : 0;
+        f32x4 v = acc[g][c];
+        if (A.bias) v += ld4(A.bias + cos);
+        f32x4 o = v;
+        if (EPI && A.stats_mode == LMN_STATS_SUM_SQ && live) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) { st0[c][r] += v[r]; st1[c][r] += v[r] * v[r]; }
+        }
+        if (A.epilogue == LMN_EP_AFFINE_ACT) {
+          const f32x4 s0 = ld4(A.p0 + cos), s1 = ld4(A.p1 + cos);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) o[r] = lmn_act(v[r] * s0[r] + s1[r], A.act);
+        }
+        if (EPI) {
+          f32x4 ax = f32x4{0.f, 0.f, 0.f, 0.f};
+          if (A.aux) ax = ld4(A.aux + opx * A.aux_cstride + cos);
+          switch (A.epilogue) {
+            case LMN_EP_DGELU: {
+#pragma unroll
+              for (int r = 0; r < 4; ++r) o[r] = v[r] * lmn_dgelu(ax[r]);
+            } break;
+            case LMN_EP_BN_BWD1: {
+              const f32x4 mu = ld4(A.p0 + cos), rs = ld4(A.p1 + cos), ga = ld4(A.p2 + cos), be = ld4(A.p3 + cos);
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                const float zh = (v[r] - mu[r]) * rs[r];
+                o[r] = ax[r] * lmn_dact(ga[r] * zh + be[r], A.act);
+                if (live) { st0[c][r] += o[r]; st1[c][r] += o[r] * zh; }
+              }
+            } break;
+            case LMN_EP_BN_BWD2: {
+              const f32x4 mu = ld4(A.p0 + cos), rs = ld4(A.p1 + cos), c1 = ld4(A.p2 + cos), c2 = ld4(A.p3 + cos),
+                          c3 = ld4(A.p4 + cos);
+#pragma unroll
+              for (int r = 0; r < 4; ++r) o[r] = c1[r] * ax[r] - c2[r] - (v[r] - mu[r]) * rs[r] * c3[r];
+            } break;
+            case LMN_EP_SE_BWD: {
+              if (live) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) st0[c][r] += v[r] * lmn_gelu(ax[r]);
+              }
+            } break;
+            default: break;
+          }
+        }
+        if (A.drop_p > 0.f) {
+          const uint32_t idx = opx * A.Cout + cos;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) o[r] *= lmn_drop_scale(A.drop_seed, idx + r, A.drop_p, P.inv_keep_ep);
+        }
+        if (A.residual) o += ld4(A.residual + opx * A.res_cstride + cos);
+        if (A.out && live) *reinterpret_cast<f32x4*>(A.out + opx * A.out_cstride + cos) = o;
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  }
+
+  // ---- statistics: wave shuffle over the 16 pixels -> LDS -> one global atomic per channel per block
+  const bool se = EPI && A.epilogue == LMN_EP_SE_BWD;
+  const bool chan_stats = EPI && ((A.stats_mode == LMN_STATS_SUM_SQ) || (A.epilogue == LMN_EP_BN_BWD1) || se);
+  if (chan_stats) {
+#pragma unroll
+    for (int c = 0; c < NCW; ++c)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float a = st0[c][r], bb = st1[c][r];
+#pragma unroll
+        for (int m = 1; m <= 8; m <<= 1) {
+          a += __shfl_xor(a, m, 64);
+          bb += __shfl_xor(bb, m, 64);
+        }
+        if (n == 0) {  // each (tile, channel) is owned by exactly one wave: plain stores
+          s_stats[(wv + 4 * c) * 16 + q * 4 + r] = a;
+          s_stats[NCT * 16 + (wv + 4 * c) * 16 + q * 4 + r] = bb;
+        }
+      }
+    __syncthreads();
+    for (int i = tid; i < (se ? 1 : 2) * NCT * 16; i += 256) {
+      const int which = i / (NCT * 16), cc = i - which * NCT * 16;
+      const int co = ct0 * 16 + cc;
+      if (co < A.Cout) {
+        if (se) { if (cur_b >= 0) atomicAdd(A.stats + cur_b * A.Cout + co, s_stats[i]); }
+        else atomicAdd(A.stats + (int64_t)which * A.Cout + co, s_stats[i]);
+      }
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------ weight packing
 __global__ void conv_pack_kernel(const float* __restrict__ w, float* __restrict__ wp, int taps, int Cout, int Cin,
                                  int nsrc, int c0, int c1, int c2, int transposed, int row_off, int rows,
@@ -1221,12 +1448,41 @@ int lmn_conv_fwd(const lmn_conv_args_t* args, lmn_stream_t stream) {
       a.Wout *= a.Hout; a.Win *= a.Hin; a.Hout = a.Hin = 1;
     }
     const int tpmax = (a.stride == 2) ? 64 : 128;
+    int ncw = 0;  // > 0: M-split kernel with ncw cout tiles per wave
     if (a.ksize == 1) { T.TW = a.Wout < tpmax ? a.Wout : tpmax; T.TH = 1; }
     else {
       T.TW = a.Wout <= 32 ? a.Wout : 16;
       T.TH = tpmax / T.TW;
       if (T.TH > a.Hout) T.TH = a.Hout;
       if (T.TH < 1) T.TH = 1;
+    }
+    if (P.NCTT >= 4) {
+      // Wide layer -> M-split kernel.  Wide layers sit on the small feature maps, where a 128-pixel tile times a
+      // few cout chunks can leave most of the 256 CUs idle: pick (tile pixels, cout tiles per wave) by a cost model
+      // -- rounds of 256 blocks x per-block MFMA work (+ staging, inflated by the halo for short 3x3 tiles).
+      float best = 1e30f;
+      int bTW = T.TW, bTH = T.TH;
+      for (int cand = 0; cand < 16; ++cand) {
+        int tw, th;
+        if (a.ksize == 1) {
+          if (cand > 2) break;
+          tw = tpmax >> cand; th = 1;
+          if (tw > a.Wout) { if (cand) continue; tw = a.Wout; }
+          if (tw < 16) continue;
+        } else {
+          tw = T.TW; th = T.TH - cand;
+          if (th < 1) break;
+        }
+        const int ng = (tw * th + 15) / 16;
+        const long tiles = (long)a.B * ((a.Wout + tw - 1) / tw) * ((a.Hout + th - 1) / th);
+        for (int w = 1; w <= 2; ++w) {
+          const long blk = tiles * ((P.NCTT + 4 * w - 1) / (4 * w));
+          const float halo = a.ksize == 1 ? 1.f : (float)(th + 2) / th;
+          const float cost = (float)((blk + 255) / 256) * (ng * (w + 0.3f * halo) + 1.f);
+          if (cost < best * 0.999f) { best = cost; bTW = tw; bTH = th; ncw = w; }
+        }
+      }
+      T.TW = bTW; T.TH = bTH;
     }
     T.TP = T.TH * T.TW;
     T.NG = (T.TP + 15) / 16;
@@ -1252,6 +1508,23 @@ int lmn_conv_fwd(const lmn_conv_args_t* args, lmn_stream_t stream) {
     const int maxb = 2048 / chunks > 256 ? 2048 / chunks : 256;
     if (blocks > maxb) blocks = maxb;
     const bool epi = a.epilogue > LMN_EP_AFFINE_ACT || a.stats_mode != LMN_STATS_NONE;  // EPI=1: statistics / special epilogues
+    if (ncw) {
+      const int mchunks = (P.NCTT + 4 * ncw - 1) / (4 * ncw);
+      int mblocks = T.total_tiles;
+      const int mmax = 2048 / mchunks > 256 ? 2048 / mchunks : 256;
+      if (mblocks > mmax) mblocks = mmax;
+      const dim3 mgrid(mblocks, mchunks);
+      const size_t msh = ((size_t)T.XH * T.XW * T.CS + 2 * 4 * ncw * 16) * sizeof(float);
+#define LMN_CM(TT, NN)                                                                                   \
+  do {                                                                                                   \
+    if (epi) hipLaunchKernelGGL((conv_tileM_kernel<TT, NN, 1>), mgrid, dim3(256), msh, st, T);           \
+    else hipLaunchKernelGGL((conv_tileM_kernel<TT, NN, 0>), mgrid, dim3(256), msh, st, T);               \
+  } while (0)
+      if (a.ksize == 1) { if (ncw == 2) LMN_CM(1, 2); else LMN_CM(1, 1); }
+      else { if (ncw == 2) LMN_CM(9, 2); else LMN_CM(9, 1); }
+#undef LMN_CM
+      return lmn_launch_status("conv_fwd(tileM)");
+    }
     const dim3 grid(blocks, chunks);
 #define LMN_CT(TT, NN)                                                                                   \
   do {                                                                                                   \
@@ -1262,9 +1535,7 @@ int lmn_conv_fwd(const lmn_conv_args_t* args, lmn_stream_t stream) {
   switch (nct) {                                                                                         \
     case 1: LMN_CT(TT, 1); break;                                                                        \
     case 2: LMN_CT(TT, 2); break;                                                                        \
-    case 3: LMN_CT(TT, 3); break;                                                                        \
-    case 4: LMN_CT(TT, 4); break;                                                                        \
-    default: LMN_CT(TT, 6); break;                                                                       \
+    default: LMN_CT(TT, 3); break;                                                                       \
   }
     if (a.ksize == 1) { LMN_CTN(1) } else { LMN_CTN(9) }
 #undef LMN_CTN
