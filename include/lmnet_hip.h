@@ -121,6 +121,22 @@ int64_t lmn_conv_pack_size(int ksize, int Cout, int nsrc, const int32_t* c);
  *   forward input channels whose gradient is produced (one call per forward source).        */
 int lmn_conv_pack(const float* w, float* wpack, int ksize, int Cout, int Cin, int nsrc, const int32_t* c,
                   int transposed, int row_off, int rows, lmn_stream_t stream);
+/* The same packing for MANY weights in one launch (weights change every optimizer step, so a training step
+ * re-packs every dense weight of the net: one launch instead of ~190).  `jobs_dev` is a DEVICE array of njobs
+ * descriptors sorted by first_block, where job j owns blocks [first_block_j, first_block_j + ceil(total_j/1024))
+ * and total_j = lmn_conv_pack_size(...); total_blocks = the sum.  Field meaning as in lmn_conv_pack.            */
+typedef struct {
+  const float* w;
+  float* wpack;
+  int64_t total;       /* floats written = lmn_conv_pack_size(ksize, rows, nsrc, c) */
+  int64_t first_block;
+  int32_t ksize, Cout, Cin, nsrc;
+  int32_t c[3];
+  int32_t transposed, row_off, rows;
+  int32_t _pad[2];
+} lmn_pack_job_t;
+int lmn_sizeof_pack_job(void);
+int lmn_conv_pack_batch(const lmn_pack_job_t* jobs_dev, int njobs, int64_t total_blocks, lmn_stream_t stream);
 int lmn_conv_fwd(const lmn_conv_args_t* args, lmn_stream_t stream);
 
 /* Weight/bias gradient:  dW[co][ci][ty][tx] += sum_pixels dy[p][co] * src(p*s + t - pad)[ci]

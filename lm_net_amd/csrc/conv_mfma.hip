@@ -673,10 +673,11 @@ __global__ __launch_bounds__(256) void conv_tileM_kernel(const ConvParams P) {
           const int fy = A.transposed ? KS - 1 - ty : ty, fx = A.transposed ? KS - 1 - tx : tx;
           const int toff = (fy * P.XW + fx) * P.CS;
           for (int kk = 0; kk < nkbc; ++kk) {
-            const float* wp = A.wpack + ((((int64_t)tap * P.NKB + P.kb_off[s] + kb0 + kk) * P.NCTT + ct0 + wv) * 64 + lane) * 4;
+            // cout tiles past the end (last chunk) read the last real tile: loads stay unconditional and in bounds
+            const float* wp = A.wpack + ((((int64_t)tap * P.NKB + P.kb_off[s] + kb0 + kk) * P.NCTT) * 64 + lane) * 4;
             f32x4 wv4[NCW];
 #pragma unroll
-            for (int c = 0; c < NCW; ++c) wv4[c] = ld4(wp + (ct0 + wv + 4 * c < P.NCTT ? c * 4 * 256 : 0));
+            for (int c = 0; c < NCW; ++c) wv4[c] = ld4(wp + min(ct0 + wv + 4 * c, P.NCTT - 1) * 256);
 #pragma unroll
             for (int g = 0; g < NGM; ++g) {
               if (g < P.NG) {
@@ -791,41 +792,69 @@ __global__ __launch_bounds__(256) void conv_tileM_kernel(const ConvParams P) {
 }
 
 // ------------------------------------------------------------------------------------ weight packing
-__global__ void conv_pack_kernel(const float* __restrict__ w, float* __restrict__ wp, int taps, int Cout, int Cin,
-                                 int nsrc, int c0, int c1, int c2, int transposed, int row_off, int rows,
-                                 int64_t total) {
-  const int cs[3] = {c0, c1, c2};
+struct PackGeom {
+  int taps, Cout, Cin, nsrc, cs[3], transposed, row_off, rows;
+};
+
+// One element i of the packed stream [tap][K16 block][cout tile][64 lanes][4].
+__device__ __forceinline__ float pack_element(const float* __restrict__ w, const PackGeom& g, int64_t i) {
   int nkb[3], kboff[3], cbase[3], NKB = 0, cb = 0;
+#pragma unroll
   for (int s = 0; s < 3; ++s) {
-    nkb[s] = s < nsrc ? (cs[s] + 15) / 16 : 0;
+    nkb[s] = s < g.nsrc ? (g.cs[s] + 15) / 16 : 0;
     kboff[s] = NKB;
     cbase[s] = cb;
     NKB += nkb[s];
-    cb += s < nsrc ? cs[s] : 0;
+    cb += s < g.nsrc ? g.cs[s] : 0;
   }
-  const int nrows = transposed ? rows : Cout;
+  const int nrows = g.transposed ? g.rows : g.Cout;
   const int NCTT = (nrows + 15) / 16;
-  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    const int j = (int)(i & 3);
-    const int lane = (int)((i >> 2) & 63);
-    int64_t t = i >> 8;
-    const int ct = (int)(t % NCTT);
-    t /= NCTT;
-    const int kb = (int)(t % NKB);
-    const int tap = (int)(t / NKB);
-    int s = 0;
-    while (s + 1 < nsrc && kb >= kboff[s + 1]) ++s;
-    const int kk = (kb - kboff[s]) * 16 + (lane >> 4) * 4 + j;  // reduction index inside the source
-    const int row = ct * 16 + (lane & 15);
-    float v = 0.f;
-    if (row < nrows && kk < cs[s]) {
-      if (!transposed) {
-        v = w[((int64_t)row * Cin + cbase[s] + kk) * taps + tap];
-      } else {  // rows = forward input channels, reduction = forward output channels
-        v = w[((int64_t)kk * Cin + row_off + row) * taps + tap];
-      }
+  const int j = (int)(i & 3);
+  const int lane = (int)((i >> 2) & 63);
+  int64_t t = i >> 8;
+  const int ct = (int)(t % NCTT);
+  t /= NCTT;
+  const int kb = (int)(t % NKB);
+  const int tap = (int)(t / NKB);
+  int s = 0;
+  while (s + 1 < g.nsrc && kb >= kboff[s + 1]) ++s;
+  const int kk = (kb - kboff[s]) * 16 + (lane >> 4) * 4 + j;  // reduction index inside the source
+  const int row = ct * 16 + (lane & 15);
+  float v = 0.f;
+  if (row < nrows && kk < g.cs[s]) {
+    if (!g.transposed) {
+      v = w[((int64_t)row * g.Cin + cbase[s] + kk) * g.taps + tap];
+    } else {  // rows = forward input channels, reduction = forward output channels
+      v = w[((int64_t)kk * g.Cin + g.row_off + row) * g.taps + tap];
     }
-    wp[i] = v;
+  }
+  return v;
+}
+
+__global__ void conv_pack_kernel(const float* __restrict__ w, float* __restrict__ wp, const PackGeom g, int64_t total) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x)
+    wp[i] = pack_element(w, g, i);
+}
+
+// All weights of a pass in ONE launch: block b finds its job by bisection over the jobs' first-block table, then
+// packs 1024 consecutive elements of it.  (192 separate pack launches cost ~1 ms per training step.)
+__global__ __launch_bounds__(256) void conv_pack_batch_kernel(const lmn_pack_job_t* __restrict__ jobs, int njobs) {
+  int lo = 0, hi = njobs - 1;
+  const int64_t b = blockIdx.x;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (jobs[mid].first_block <= b) lo = mid; else hi = mid - 1;
+  }
+  const lmn_pack_job_t J = jobs[lo];
+  PackGeom g;
+  g.taps = J.ksize * J.ksize; g.Cout = J.Cout; g.Cin = J.Cin; g.nsrc = J.nsrc;
+  g.cs[0] = J.c[0]; g.cs[1] = J.c[1]; g.cs[2] = J.c[2];
+  g.transposed = J.transposed; g.row_off = J.row_off; g.rows = J.rows;
+  const int64_t base = (b - J.first_block) * 1024;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int64_t i = base + r * 256 + threadIdx.x;
+    if (i < J.total) J.wpack[i] = pack_element(J.w, g, i);
   }
 }
 
@@ -1304,6 +1333,7 @@ int lmn_abi_version(void) { return LMN_ABI_VERSION; }
 int lmn_sizeof_conv_args(void) { return (int)sizeof(lmn_conv_args_t); }
 int lmn_sizeof_src(void) { return (int)sizeof(lmn_src_t); }
 int lmn_sizeof_wgrad_args(void) { return (int)sizeof(lmn_wgrad_args_t); }
+int lmn_sizeof_pack_job(void) { return (int)sizeof(lmn_pack_job_t); }
 
 int64_t lmn_conv_wgrad_workspace(const lmn_wgrad_args_t* a) {
   if (!a) return 0;
@@ -1351,9 +1381,18 @@ int lmn_conv_pack(const float* w, float* wpack, int ksize, int Cout, int Cin, in
   const int nrows = transposed ? rows : Cout;
   const int64_t total = lmn_conv_pack_size(ksize, nrows, nsrc, c);
   const int blocks = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
-  hipLaunchKernelGGL(conv_pack_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, wpack, ksize * ksize, Cout,
-                     Cin, nsrc, c[0], nsrc > 1 ? c[1] : 0, nsrc > 2 ? c[2] : 0, transposed, row_off, rows, total);
+  PackGeom g;
+  g.taps = ksize * ksize; g.Cout = Cout; g.Cin = Cin; g.nsrc = nsrc;
+  g.cs[0] = c[0]; g.cs[1] = nsrc > 1 ? c[1] : 0; g.cs[2] = nsrc > 2 ? c[2] : 0;
+  g.transposed = transposed; g.row_off = row_off; g.rows = rows;
+  hipLaunchKernelGGL(conv_pack_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, wpack, g, total);
   return lmn_launch_status("conv_pack");
+}
+
+int lmn_conv_pack_batch(const lmn_pack_job_t* jobs_dev, int njobs, int64_t total_blocks, lmn_stream_t stream) {
+  LMN_REQUIRE(jobs_dev && njobs > 0 && total_blocks > 0 && total_blocks < (1LL << 31), "conv_pack_batch: bad job table");
+  hipLaunchKernelGGL(conv_pack_batch_kernel, dim3((unsigned)total_blocks), dim3(256), 0, (hipStream_t)stream, jobs_dev, njobs);
+  return lmn_launch_status("conv_pack_batch");
 }
 
 int lmn_conv_fwd(const lmn_conv_args_t* args, lmn_stream_t stream) {
@@ -1468,7 +1507,7 @@ int lmn_conv_fwd(const lmn_conv_args_t* args, lmn_stream_t stream) {
           if (cand > 2) break;
           tw = tpmax >> cand; th = 1;
           if (tw > a.Wout) { if (cand) continue; tw = a.Wout; }
-          if (tw < 16) continue;
+          if (cand && tw < 16) continue;
         } else {
           tw = T.TW; th = T.TH - cand;
           if (th < 1) break;
@@ -1483,6 +1522,7 @@ int lmn_conv_fwd(const lmn_conv_args_t* args, lmn_stream_t stream) {
         }
       }
       T.TW = bTW; T.TH = bTH;
+      LMN_REQUIRE(ncw > 0, "conv_fwd: no tile candidate");
     }
     T.TP = T.TH * T.TW;
     T.NG = (T.TP + 15) / 16;

@@ -81,6 +81,7 @@ class Engine:
         self.seed_base = 0x1234567
         self.step = 0
         self.zpool_fwd, self.zpool_bwd = ZeroPool(), ZeroPool()
+        self.packs_fwd, self.packs_bwd = hip.PackPlan(), hip.PackPlan()
         self.kernel_events = None  # bench.py: {"dw_fwd": [(start_event, end_event, algorithmic_bytes), ...]}
 
     # ------------------------------------------------------------------ small helpers
@@ -88,11 +89,15 @@ class Engine:
         pool = self.zpool_bwd if backward else self.zpool_fwd
         pool.begin(device)
         _POOL[0] = pool
+        plan = self.packs_bwd if backward else self.packs_fwd
+        plan.refresh()            # all persistent weights of this pass re-packed in one launch
+        hip._PLAN[0] = plan
 
     def end_pass(self):
         if _POOL[0] is not None:
             _POOL[0].end()
         _POOL[0] = None
+        hip._PLAN[0] = None
 
     def _seed(self, tag):
         return (self.seed_base + 0x9E3779B1 * (self.step * 64 + tag)) & 0xFFFFFFFF
@@ -234,9 +239,14 @@ class Engine:
         """1x1 conv over two sources with separate weights: pack each into its K-block range."""
         n0 = hip.conv_pack_size(1, cout, [c0])
         n1 = hip.conv_pack_size(1, cout, [c1])
-        wp = torch.empty(n0 + n1, device=ref.device, dtype=torch.float32)
-        hip.conv_pack(w0, 1, [c0], out=wp[:n0])
-        hip.conv_pack(w1, 1, [c1], out=wp[n0:])
+        plan = hip._PLAN[0]
+        own = plan is not None and isinstance(w0, torch.nn.Parameter) and isinstance(w1, torch.nn.Parameter)
+        if own:
+            wp = plan.buffer(("pack2", w0.data_ptr(), w1.data_ptr()), n0 + n1, ref.device)
+        else:
+            wp = torch.empty(n0 + n1, device=ref.device, dtype=torch.float32)
+        hip.conv_pack(w0, 1, [c0], out=wp[:n0], persistent=own)
+        hip.conv_pack(w1, 1, [c1], out=wp[n0:], persistent=own)
         return wp
 
     def reparam_bwd(self, m, dy, cx, need_dx=True):

@@ -47,7 +47,7 @@ class WgradArgs(C.Structure):
 # every symbol include/lmnet_hip.h declares (the CPU test suite checks the library exports all of them)
 SYMBOLS = [
     "lmn_abi_version", "lmn_sizeof_conv_args", "lmn_sizeof_src", "lmn_sizeof_wgrad_args", "lmn_last_error",
-    "lmn_conv_pack_size", "lmn_conv_pack", "lmn_conv_fwd", "lmn_conv_wgrad", "lmn_conv_wgrad_workspace",
+    "lmn_conv_pack_size", "lmn_conv_pack", "lmn_conv_pack_batch", "lmn_sizeof_pack_job", "lmn_conv_fwd", "lmn_conv_wgrad", "lmn_conv_wgrad_workspace",
     "lmn_dw_stats", "lmn_dw_fwd", "lmn_dw_merge", "lmn_dw_bwd_stats", "lmn_dw_bwd_coef", "lmn_dw_bwd",
     "lmn_se_fwd", "lmn_se_bwd", "lmn_na_fwd", "lmn_na_bwd", "lmn_gattn_fwd", "lmn_gattn_bwd",
     "lmn_ln_fwd", "lmn_ln_bwd", "lmn_bnact_fwd", "lmn_bnact_bwd_stats", "lmn_bnact_bwd",
@@ -157,14 +157,96 @@ def conv_pack_size(ksize, rows, src_channels):
     return int(load().lmn_conv_pack_size(ksize, rows, len(src_channels), arr))
 
 
-def conv_pack(w, ksize, src_channels, out=None):
-    """Pack a torch-layout weight [Cout, Cin(,k,k)] for the forward operator."""
+class PackJob(C.Structure):
+    """Mirror of lmn_pack_job_t."""
+    _fields_ = [("w", C.c_void_p), ("wpack", C.c_void_p), ("total", C.c_int64), ("first_block", C.c_int64),
+                ("ksize", C.c_int32), ("Cout", C.c_int32), ("Cin", C.c_int32), ("nsrc", C.c_int32),
+                ("c", C.c_int32 * 3), ("transposed", C.c_int32), ("row_off", C.c_int32), ("rows", C.c_int32),
+                ("_pad", C.c_int32 * 2)]
+
+
+class PackPlan:
+    """Packed forms of the PERSISTENT weights (nn.Parameter storage) used by one pass (forward or backward).
+
+    The first pass runs every pack as its own launch and records it; later passes re-pack all recorded jobs
+    with ONE ``lmn_conv_pack_batch`` launch in ``refresh()`` and ``conv_pack``/``conv_pack_t`` then only look
+    their buffer up.  Jobs hold a reference to the weight tensor; if a parameter's storage moved
+    (``model.to(...)``) the plan is dropped and re-recorded."""
+
+    def __init__(self):
+        self.jobs = {}        # key -> [weight tensor, packed tensor, PackJob fields]
+        self.buffers = {}     # key -> plan-owned buffer that several jobs pack slices of
+        self.table = None     # device copy of the job array
+        self.blocks = 0
+        self.fresh = False
+
+    def refresh(self):
+        self.fresh = False
+        if not self.jobs:
+            return
+        if any(j[0].data_ptr() != j[2]["w"] for j in self.jobs.values()):
+            self.jobs, self.buffers, self.table = {}, {}, None
+            return
+        if self.table is None:
+            arr = (PackJob * len(self.jobs))()
+            blk = 0
+            for i, (wt, out, f) in enumerate(self.jobs.values()):
+                a = arr[i]
+                a.w, a.wpack, a.total, a.first_block = f["w"], out.data_ptr(), out.numel(), blk
+                a.ksize, a.Cout, a.Cin, a.nsrc = f["ksize"], f["Cout"], f["Cin"], len(f["c"])
+                for k, cc in enumerate(f["c"]):
+                    a.c[k] = cc
+                a.transposed, a.row_off, a.rows = f["transposed"], f["row_off"], f["rows"]
+                blk += (out.numel() + 1023) // 1024
+            if C.sizeof(PackJob) != load().lmn_sizeof_pack_job():
+                raise RuntimeError("lm_net_amd: lmn_pack_job_t layout differs between hip.py and lmnet_hip.h")
+            dev = next(iter(self.jobs.values()))[1].device
+            host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
+            self.table, self.blocks = host.to(dev), blk
+        _check(load().lmn_conv_pack_batch(C.c_void_p(self.table.data_ptr()), len(self.jobs), _i64(self.blocks), _stream()),
+               "conv_pack_batch")
+        self.fresh = True
+
+    def buffer(self, key, n, device):
+        b = self.buffers.get(key)
+        if b is None or b.numel() != n or b.device != device:
+            b = self.buffers[key] = torch.empty(n, device=device, dtype=torch.float32)
+        return b
+
+    def lookup(self, key):
+        j = self.jobs.get(key) if self.fresh else None
+        return j[1] if j is not None else None
+
+    def record(self, key, w, out, fields):
+        self.jobs[key] = [w, out, fields]
+        self.table = None     # rebuilt by the next refresh()
+
+
+_PLAN = [None]                # the plan of the pass in flight (set by engine.begin_pass)
+
+
+def _planned(w, out, persistent):
+    return _PLAN[0] is not None and (out is None or persistent) and isinstance(w, torch.nn.Parameter)
+
+
+def conv_pack(w, ksize, src_channels, out=None, persistent=False):
+    """Pack a torch-layout weight [Cout, Cin(,k,k)] for the forward operator.  ``persistent``: ``out`` is a
+    slice of a ``PackPlan.buffer`` (so the job may be recorded and replayed by the plan)."""
     cout, cin = w.shape[0], w.shape[1]
+    planned = _planned(w, out, persistent)
+    if planned:
+        key = (w.data_ptr(), ksize, tuple(src_channels), 0, 0, 0, out.data_ptr() if out is not None else 0)
+        hit = _PLAN[0].lookup(key)
+        if hit is not None:
+            return hit
     n = conv_pack_size(ksize, cout, src_channels)
     if out is None:
         out = torch.empty(n, device=w.device, dtype=torch.float32)
     arr = (C.c_int32 * len(src_channels))(*src_channels)
     _check(load().lmn_conv_pack(_p(w), _p(out), ksize, cout, cin, len(src_channels), arr, 0, 0, 0, _stream()), "conv_pack")
+    if planned:
+        _PLAN[0].record(key, w, out, dict(w=w.data_ptr(), ksize=ksize, Cout=cout, Cin=cin, c=list(src_channels),
+                                          transposed=0, row_off=0, rows=0))
     return out
 
 
@@ -173,11 +255,20 @@ def conv_pack_t(w, ksize, row_off=0, rows=None, out=None):
     [row_off, row_off+rows), reduction over Cout."""
     cout, cin = w.shape[0], w.shape[1]
     rows = cin - row_off if rows is None else rows
+    planned = _planned(w, out, False)
+    if planned:
+        key = (w.data_ptr(), ksize, (cout,), 1, row_off, rows)
+        hit = _PLAN[0].lookup(key)
+        if hit is not None:
+            return hit
     n = conv_pack_size(ksize, rows, [cout])
     if out is None:
         out = torch.empty(n, device=w.device, dtype=torch.float32)
     arr = (C.c_int32 * 1)(cout)
     _check(load().lmn_conv_pack(_p(w), _p(out), ksize, cout, cin, 1, arr, 1, row_off, rows, _stream()), "conv_pack_t")
+    if planned:
+        _PLAN[0].record(key, w, out, dict(w=w.data_ptr(), ksize=ksize, Cout=cout, Cin=cin, c=[cout],
+                                          transposed=1, row_off=row_off, rows=rows))
     return out
 
 

@@ -64,6 +64,11 @@ def check_conv_fwd():
         ("3x3 s1 cat 24+24+24->24", 1, 8, 9, [24, 24, 24], 24, 3, 1),
         ("3x3 s1 100->112 (chunks)", 1, 6, 6, [100], 112, 3, 1),
         ("3x3 s1 372->372", 1, 6, 6, [372], 372, 3, 1),
+        ("1x1 64->64 on 2x3 map", 1, 2, 3, [64], 64, 1, 1),
+        ("1x1 32->72 on 1x1 map", 2, 1, 1, [32], 72, 1, 1),
+        ("3x3 s1 64->80 on 2x3 map", 1, 2, 3, [64], 80, 3, 1),
+        ("3x3 s1 48->144 22x22", 2, 22, 22, [48], 144, 3, 1),
+        ("1x1 96->288 44x44", 1, 44, 44, [96], 288, 1, 1),
     ]
     for name, B, H, W, cins, cout, k, s in cases:
         cin = sum(cins)
