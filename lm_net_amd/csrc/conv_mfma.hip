@@ -49,7 +49,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams P) {
   const lmn_conv_args_t& A = P.a;
   const int lane = threadIdx.x & 63;
   const int q = lane >> 4, n = lane & 15;
-  const int wave = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int wave = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int nwaves = gridDim.x * 4;
   const int ct0 = blockIdx.y * NCT;
   const int pad = A.ksize >> 1;
@@ -349,7 +349,8 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(const ConvParams P) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* XS = smem;                       // [XH*XW][CS]
   float* s_stats = smem + P.XH * P.XW * P.CS;  // [2][NCT*16]
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave index as an SGPR: branches on it stay scalar
   const int q = lane >> 4, n = lane & 15;
   const int ct0 = blockIdx.y * NCT;
   const int pad = A.ksize >> 1;
@@ -449,15 +450,17 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(const ConvParams P) {
           for (int kk = 0; kk < nkbc; ++kk) {
             const f32x4 x0 = *reinterpret_cast<const f32x4*>(&XS[pbase[0] + toff + kk * 16]);
             const f32x4 x1 = *reinterpret_cast<const f32x4*>(&XS[pbase[1] + toff + kk * 16]);
-            const float* wp = A.wpack + ((((int64_t)tap * P.NKB + P.kb_off[s] + kb0 + kk) * P.NCTT + ct0) * 64 + lane) * 4;
+            const float* wp = A.wpack + ((((int64_t)tap * P.NKB + P.kb_off[s] + kb0 + kk) * P.NCTT) * 64 + lane) * 4;
 #pragma unroll
             for (int c = 0; c < NCT; ++c) {
-              if (ct0 + c < P.NCTT) {
-                const f32x4 wv4 = ld4(wp + c * 256);
+              {  // cout tiles past the end re-read the last real tile (results dropped in the epilogue)
+                const f32x4 wv4 = ld4(wp + min(ct0 + c, P.NCTT - 1) * 256);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
+                  // both groups unconditionally (a missing second group reads pixel 0 and is dropped in the epilogue):
+                  // a branch around an MFMA makes the accumulators bounce between VGPRs and AGPRs every iteration
                   acc[0][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv4[j], x0[j], acc[0][c], 0, 0, 0);
-                  if (g1) acc[1][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv4[j], x1[j], acc[1][c], 0, 0, 0);
+                  acc[1][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv4[j], x1[j], acc[1][c], 0, 0, 0);
                 }
               }
             }
@@ -576,7 +579,8 @@ __global__ __launch_bounds__(256) void conv_tileM_kernel(const ConvParams P) {
   float* XS = smem;                       // [XH*XW][CS]
   float* s_stats = smem + P.XH * P.XW * P.CS;  // [2][NCT*16]
   constexpr int NGM = 8;                       // pixel groups per tile (all owned by every wave)
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave index as an SGPR: branches on it stay scalar
   const int q = lane >> 4, n = lane & 15;
   const int ct0 = blockIdx.y * NCT;
   const int pad = A.ksize >> 1;
@@ -883,7 +887,7 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(const WgradParams P) {
   const lmn_wgrad_args_t& A = P.a;
   const int lane = threadIdx.x & 63;
   const int q = lane >> 4, n = lane & 15;
-  const int wave = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int wave = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int nwaves = gridDim.x * 4;
   const int mset = blockIdx.y / P.nsets_n, nset = blockIdx.y - mset * P.nsets_n;
   const int mt0 = mset * NMT, nt0 = nset * NNT;
@@ -1084,7 +1088,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_lds_kernel(const WgradParams P) 
   const int XP = P.XH * P.XW;
   float* XS = smem;                                   // [NNT][XH*XW][16]
   float* YS = smem + NNT * XP * P.CSx;                // [NMT][TH*TW][16]
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave index as an SGPR: branches on it stay scalar
   const int q = lane >> 4, n = lane & 15;
   const int mset = blockIdx.y / P.nsets_n, nset = blockIdx.y - mset * P.nsets_n;
   const int mt0 = mset * NMT, nt0 = nset * NNT;
