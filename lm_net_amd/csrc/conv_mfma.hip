@@ -355,6 +355,10 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(const ConvParams P) {
   const int ct0 = blockIdx.y * NCT;
   const int pad = A.ksize >> 1;
   constexpr int KS = TAPS == 9 ? 3 : 1;
+  const float* wlane = A.wpack + lane * 4;
+  int wtile[NCT];  // cout tiles past the end re-read the last real tile (results dropped in the epilogue)
+#pragma unroll
+  for (int c = 0; c < NCT; ++c) wtile[c] = min(ct0 + c, P.NCTT - 1) * 256;
 
   for (int i = tid; i < 2 * NCT * 16; i += 256) s_stats[i] = 0.f;
   float st0[NCT][4], st1[NCT][4];
@@ -416,6 +420,13 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(const ConvParams P) {
       const lmn_src_t& S = A.src[s];
       for (int kb0 = 0; kb0 < P.nkb[s]; kb0 += P.CKB) {
         const int nkbc = P.nkb[s] - kb0 < P.CKB ? P.nkb[s] - kb0 : P.CKB;
+        const int ksh = nkbc - 1, niter = TAPS * nkbc;  // step it = (tap, kk): tap = it >> ksh, kk = it & ksh (nkbc is 1 or 2)
+        f32x4 wcur[NCT];
+        {
+          const float* wp = wlane + ((int64_t)(P.kb_off[s] + kb0) * P.NCTT) * 256;
+#pragma unroll
+          for (int c = 0; c < NCT; ++c) wcur[c] = ld4(wp + wtile[c]);
+        }
         __syncthreads();  // previous chunk / tile fully consumed
         // ---- stage the window chunk: unconditional float4 loads from clamped addresses, transforms, zero padding
         const int per_px = nkbc * 4;
@@ -441,30 +452,35 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(const ConvParams P) {
           *reinterpret_cast<f32x4*>(&XS[pix * P.CS + f * 4]) = v;
         }
         __syncthreads();
-        // ---- MFMA: taps x K16 blocks of the chunk
-#pragma unroll 1
-        for (int tap = 0; tap < TAPS; ++tap) {
+        // ---- MFMA: taps x K16 blocks of the chunk; the packed weights of step it+1 are fetched while step it runs
+        //      (the first fetch was issued before the staging loop), so no L2 latency is exposed inside the loop
+        for (int it = 0; it < niter; ++it) {
+          const int itn = it + 1 < niter ? it + 1 : it;
+          f32x4 wnext[NCT];
+          {
+            const int tapn = itn >> ksh, kkn = itn & ksh;
+            const float* wp = wlane + (((int64_t)tapn * P.NKB + P.kb_off[s] + kb0 + kkn) * P.NCTT) * 256;
+#pragma unroll
+            for (int c = 0; c < NCT; ++c) wnext[c] = ld4(wp + wtile[c]);
+          }
+          const int tap = it >> ksh, kk = it & ksh;
           const int ty = tap / KS, tx = tap - ty * KS;
           const int fy = A.transposed ? KS - 1 - ty : ty, fx = A.transposed ? KS - 1 - tx : tx;
           const int toff = (fy * P.XW + fx) * P.CS;
-          for (int kk = 0; kk < nkbc; ++kk) {
-            const f32x4 x0 = *reinterpret_cast<const f32x4*>(&XS[pbase[0] + toff + kk * 16]);
-            const f32x4 x1 = *reinterpret_cast<const f32x4*>(&XS[pbase[1] + toff + kk * 16]);
-            const float* wp = A.wpack + ((((int64_t)tap * P.NKB + P.kb_off[s] + kb0 + kk) * P.NCTT) * 64 + lane) * 4;
+          const f32x4 x0 = *reinterpret_cast<const f32x4*>(&XS[pbase[0] + toff + kk * 16]);
+          const f32x4 x1 = *reinterpret_cast<const f32x4*>(&XS[pbase[1] + toff + kk * 16]);
 #pragma unroll
-            for (int c = 0; c < NCT; ++c) {
-              {  // cout tiles past the end re-read the last real tile (results dropped in the epilogue)
-                const f32x4 wv4 = ld4(wp + min(ct0 + c, P.NCTT - 1) * 256);
+          for (int c = 0; c < NCT; ++c) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                  // both groups unconditionally (a missing second group reads pixel 0 and is dropped in the epilogue):
-                  // a branch around an MFMA makes the accumulators bounce between VGPRs and AGPRs every iteration
-                  acc[0][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv4[j], x0[j], acc[0][c], 0, 0, 0);
-                  acc[1][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv4[j], x1[j], acc[1][c], 0, 0, 0);
-                }
-              }
+            for (int j = 0; j < 4; ++j) {
+              // both groups unconditionally (a missing second group reads pixel 0 and is dropped in the epilogue):
+              // a branch around an MFMA makes the accumulators bounce between VGPRs and AGPRs every iteration
+              acc[0][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(wcur[c][j], x0[j], acc[0][c], 0, 0, 0);
+              acc[1][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(wcur[c][j], x1[j], acc[1][c], 0, 0, 0);
             }
           }
+#pragma unroll
+          for (int c = 0; c < NCT; ++c) wcur[c] = wnext[c];
         }
       }
     }
@@ -585,6 +601,10 @@ __global__ __launch_bounds__(256) void conv_tileM_kernel(const ConvParams P) {
   const int ct0 = blockIdx.y * NCT;
   const int pad = A.ksize >> 1;
   constexpr int KS = TAPS == 9 ? 3 : 1;
+  const float* wlane = A.wpack + lane * 4;
+  int wtile[NCW];  // cout tiles past the end (last chunk) re-read the last real tile: loads stay unconditional, in bounds
+#pragma unroll
+  for (int c = 0; c < NCW; ++c) wtile[c] = min(ct0 + wv + 4 * c, P.NCTT - 1) * 256;
 
   for (int i = tid; i < 2 * NCT * 16; i += 256) s_stats[i] = 0.f;
   float st0[NCW][4], st1[NCW][4];
@@ -645,6 +665,13 @@ __global__ __launch_bounds__(256) void conv_tileM_kernel(const ConvParams P) {
       const lmn_src_t& S = A.src[s];
       for (int kb0 = 0; kb0 < P.nkb[s]; kb0 += P.CKB) {
         const int nkbc = P.nkb[s] - kb0 < P.CKB ? P.nkb[s] - kb0 : P.CKB;
+        const int ksh = nkbc - 1, niter = TAPS * nkbc;  // step it = (tap, kk): tap = it >> ksh, kk = it & ksh (nkbc is 1 or 2)
+        f32x4 wcur[NCW];
+        {
+          const float* wp = wlane + ((int64_t)(P.kb_off[s] + kb0) * P.NCTT) * 256;
+#pragma unroll
+          for (int c = 0; c < NCW; ++c) wcur[c] = ld4(wp + wtile[c]);
+        }
         __syncthreads();  // previous chunk / tile fully consumed
         // ---- stage the window chunk: unconditional float4 loads from clamped addresses, transforms, zero padding
         const int per_px = nkbc * 4;
@@ -670,29 +697,33 @@ __global__ __launch_bounds__(256) void conv_tileM_kernel(const ConvParams P) {
           *reinterpret_cast<f32x4*>(&XS[pix * P.CS + f * 4]) = v;
         }
         __syncthreads();
-        // ---- MFMA: taps x K16 blocks of the chunk
-#pragma unroll 1
-        for (int tap = 0; tap < TAPS; ++tap) {
+        // ---- MFMA: taps x K16 blocks of the chunk; weights of step it+1 are fetched while step it runs (the first
+        //      fetch was issued before the staging loop)
+        for (int it = 0; it < niter; ++it) {
+          const int itn = it + 1 < niter ? it + 1 : it;
+          f32x4 wnext[NCW];
+          {
+            const int tapn = itn >> ksh, kkn = itn & ksh;
+            const float* wp = wlane + (((int64_t)tapn * P.NKB + P.kb_off[s] + kb0 + kkn) * P.NCTT) * 256;
+#pragma unroll
+            for (int c = 0; c < NCW; ++c) wnext[c] = ld4(wp + wtile[c]);
+          }
+          const int tap = it >> ksh, kk = it & ksh;
           const int ty = tap / KS, tx = tap - ty * KS;
           const int fy = A.transposed ? KS - 1 - ty : ty, fx = A.transposed ? KS - 1 - tx : tx;
           const int toff = (fy * P.XW + fx) * P.CS;
-          for (int kk = 0; kk < nkbc; ++kk) {
-            // cout tiles past the end (last chunk) read the last real tile: loads stay unconditional and in bounds
-            const float* wp = A.wpack + ((((int64_t)tap * P.NKB + P.kb_off[s] + kb0 + kk) * P.NCTT) * 64 + lane) * 4;
-            f32x4 wv4[NCW];
 #pragma unroll
-            for (int c = 0; c < NCW; ++c) wv4[c] = ld4(wp + min(ct0 + wv + 4 * c, P.NCTT - 1) * 256);
+          for (int g = 0; g < NGM; ++g) {
+            if (g < P.NG) {
+              const f32x4 xg = *reinterpret_cast<const f32x4*>(&XS[pbase[g] + toff + kk * 16]);
 #pragma unroll
-            for (int g = 0; g < NGM; ++g) {
-              if (g < P.NG) {
-                const f32x4 xg = *reinterpret_cast<const f32x4*>(&XS[pbase[g] + toff + kk * 16]);
+              for (int c = 0; c < NCW; ++c)
 #pragma unroll
-                for (int c = 0; c < NCW; ++c)
-#pragma unroll
-                  for (int j = 0; j < 4; ++j) acc[g][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv4[c][j], xg[j], acc[g][c], 0, 0, 0);
-              }
+                for (int j = 0; j < 4; ++j) acc[g][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(wcur[c][j], xg[j], acc[g][c], 0, 0, 0);
             }
           }
+#pragma unroll
+          for (int c = 0; c < NCW; ++c) wcur[c] = wnext[c];
         }
       }
     }
