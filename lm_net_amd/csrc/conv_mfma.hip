@@ -1172,11 +1172,18 @@ __global__ __launch_bounds__(256, 2) void wgrad_lds_kernel(const WgradParams P) 
     for (int t = 0; t < NNT; ++t) {
       for (int i = tid; i < P.XH * P.XW * 4; i += 256) {
         const int j = i & 3, pix = i >> 2;
-        const int r = (int)__umulhi((uint32_t)pix, P.mXW), c = pix - r * P.XW;
-        const int iy = iy0 + r, ix = ix0 + c;
         const int ch = tch0[t] + j * 4;
-        const bool ok = ch < tC[t] && (unsigned)iy < (unsigned)A.Hin && (unsigned)ix < (unsigned)A.Win;
-        const int gp = ok ? (b * A.Hin + iy) * A.Win + ix : 0;
+        bool ok;
+        int gp;
+        if constexpr (TAPS == 1) {  // 1x1: the image is one flat row (host), the window is the tile itself
+          ok = ch < tC[t] && ox0 + pix < A.Wout;
+          gp = ok ? b * A.Wout + ox0 + pix : 0;
+        } else {
+          const int r = (int)__umulhi((uint32_t)pix, P.mXW), c = pix - r * P.XW;
+          const int iy = iy0 + r, ix = ix0 + c;
+          ok = ch < tC[t] && (unsigned)iy < (unsigned)A.Hin && (unsigned)ix < (unsigned)A.Win;
+          gp = ok ? (b * A.Hin + iy) * A.Win + ix : 0;
+        }
         const int chs = ok ? ch : 0;
         f32x4 v = ld4(tptr[t] + (uint32_t)(gp * tcs[t] + chs));
         if (tflags[t] & LMN_SRC_GELU) {
@@ -1197,11 +1204,18 @@ __global__ __launch_bounds__(256, 2) void wgrad_lds_kernel(const WgradParams P) 
     for (int m = 0; m < NMT; ++m) {
       for (int i = tid; i < NP * 4; i += 256) {
         const int j = i & 3, pix = i >> 2;
-        const int r = (int)__umulhi((uint32_t)pix, P.mTW), c = pix - r * P.TW;
-        const int oy = oy0 + r, ox = ox0 + c;
         const int co = (mt0 + m) * 16 + j * 4;
-        const bool ok = (mt0 + m) < P.NMTT && co < A.Cout && oy < A.Hout && ox < A.Wout;
-        const int gp = ok ? (b * A.Hout + oy) * A.Wout + ox : 0;
+        bool ok;
+        int gp;
+        if constexpr (TAPS == 1) {
+          ok = (mt0 + m) < P.NMTT && co < A.Cout && ox0 + pix < A.Wout;
+          gp = ok ? b * A.Wout + ox0 + pix : 0;
+        } else {
+          const int r = (int)__umulhi((uint32_t)pix, P.mTW), c = pix - r * P.TW;
+          const int oy = oy0 + r, ox = ox0 + c;
+          ok = (mt0 + m) < P.NMTT && co < A.Cout && oy < A.Hout && ox < A.Wout;
+          gp = ok ? (b * A.Hout + oy) * A.Wout + ox : 0;
+        }
         const int cos = ok ? co : 0;
         f32x4 v = ld4(A.dy + (uint32_t)(gp * A.dy_cstride + cos));
         if (A.dy_flags & LMN_SRC_DROP) {
@@ -1219,11 +1233,16 @@ __global__ __launch_bounds__(256, 2) void wgrad_lds_kernel(const WgradParams P) 
       const int pix = ks * 4 + q;
       const bool pin = pix < NP;
       const int pixs = pin ? pix : 0;
-      const int pr = (int)__umulhi((uint32_t)pixs, P.mTW), pc = pixs - pr * P.TW;
       float av[NMT], bvv[TAPS][NNT];
 #pragma unroll
       for (int m = 0; m < NMT; ++m) av[m] = YS[(m * NP + pixs) * P.CSy + n];
-      const int xb = ((pr * A.stride) * P.XW + pc * A.stride) * P.CSx + n;
+      int xb;
+      if constexpr (TAPS == 1) {
+        xb = pixs * P.CSx + n;
+      } else {
+        const int pr = (int)__umulhi((uint32_t)pixs, P.mTW), pc = pixs - pr * P.TW;
+        xb = ((pr * A.stride) * P.XW + pc * A.stride) * P.CSx + n;
+      }
 #pragma unroll
       for (int tp = 0; tp < TAPS; ++tp) {
         const int ty = (TAPS == 9) ? tp / 3 : 0, tx = (TAPS == 9) ? tp % 3 : 0;
@@ -1293,6 +1312,169 @@ __global__ __launch_bounds__(256, 2) void wgrad_lds_kernel(const WgradParams P) 
     const int ch = (nt - P.ntile_off[sidx]) * 16 + nn;
     if (ch >= A.src[sidx].C) continue;
     atomicAdd(A.dW + ((int64_t)co * P.Cin + P.cbase[sidx] + ch) * TAPS + tp, s_acc[i]);
+  }
+  if (A.db && nset == 0) {
+    for (int i = tid; i < NMT * 16; i += 256) {
+      const int co = mt0 * 16 + i;
+      if (co < A.Cout && (mt0 + i / 16) < P.NMTT) atomicAdd(A.db + co, s_acc[NT * 256 + i]);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------ weight gradient, 1x1 direct
+// 1x1 / stride 1: both operands of a K step (4 pixels x 16 channels) are 4 x 64 contiguous bytes in NHWC, so
+// a lane's MFMA operand IS one dword of global memory -- no LDS staging, no barriers in the main loop.  Every wave
+// owns a contiguous range of K steps and keeps U steps (U * (NMT + NNT) loads) in flight.  The pixel index is flat
+// over the batch; the image index (needed only for the per-image SE scale) is tracked per batch of steps.
+template <int NMT, int NNT>
+__global__ __launch_bounds__(256) void wgrad_1x1_kernel(const WgradParams P) {
+  constexpr int U = 8;
+  const lmn_wgrad_args_t& A = P.a;
+  const int lane = threadIdx.x & 63;
+  const int q = lane >> 4, n = lane & 15;
+  const int wvb = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wave = blockIdx.x * 4 + wvb, nwaves = gridDim.x * 4;
+  const int mset = blockIdx.y / P.nsets_n, nset = blockIdx.y - mset * P.nsets_n;
+  const int mt0 = mset * NMT, nt0 = nset * NNT;
+  const int HW = A.Hout * A.Wout;
+  const int NPX = A.B * HW;
+
+  const float* sptr[NNT];
+  const float* sscale[NNT];
+  int sC[NNT], scs[NNT], sflags[NNT], sch[NNT];
+  uint32_t sseed[NNT];
+  float sp[NNT], sik[NNT];
+  bool any_tf = (A.dy_flags & LMN_SRC_DROP) != 0;
+#pragma unroll
+  for (int t = 0; t < NNT; ++t) {
+    const int nt = nt0 + t;
+    int s = 0;
+    while (s + 1 < A.nsrc && nt >= P.ntile_off[s + 1]) ++s;
+    const int ch = (nt - P.ntile_off[s]) * 16 + n;
+    sptr[t] = A.src[s].ptr;
+    sscale[t] = A.src[s].scale;
+    sC[t] = A.src[s].C;
+    scs[t] = A.src[s].cstride;
+    sflags[t] = A.src[s].flags;
+    sseed[t] = A.src[s].drop_seed;
+    sp[t] = A.src[s].drop_p;
+    sik[t] = P.inv_keep_src[s];
+    sch[t] = (nt < P.NNTT && ch < A.src[s].C) ? ch : -1;
+    any_tf = any_tf || sflags[t] != 0 || sscale[t] != nullptr;
+  }
+  int mco[NMT];  // this lane's cout per tile, or -1
+#pragma unroll
+  for (int m = 0; m < NMT; ++m) mco[m] = ((mt0 + m) < P.NMTT && (mt0 + m) * 16 + n < A.Cout) ? (mt0 + m) * 16 + n : -1;
+
+  f32x4 acc[NMT][NNT];
+  float bsum[NMT];
+#pragma unroll
+  for (int m = 0; m < NMT; ++m) {
+    bsum[m] = 0.f;
+#pragma unroll
+    for (int t = 0; t < NNT; ++t) acc[m][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+
+  const int total_steps = (NPX + 3) >> 2;
+  const int sb = (int)(((int64_t)wave * total_steps) / nwaves), se = (int)(((int64_t)(wave + 1) * total_steps) / nwaves);
+  for (int step0 = sb; step0 < se; step0 += U) {
+    float av[U][NMT], bv[U][NNT];
+    // ---- all loads of the batch, straight-line from clamped addresses
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int px = (step0 + u) * 4 + q;
+      const bool ok = step0 + u < se && px < NPX;
+      const int ps = ok ? px : 0;
+#pragma unroll
+      for (int m = 0; m < NMT; ++m) av[u][m] = A.dy[(uint32_t)(ps * A.dy_cstride + (mco[m] >= 0 ? mco[m] : 0))];
+#pragma unroll
+      for (int t = 0; t < NNT; ++t) bv[u][t] = sptr[t][(uint32_t)(ps * scs[t] + (sch[t] >= 0 ? sch[t] : 0))];
+    }
+    // ---- on-load transforms (wave-uniform flags) and masking
+    int b0 = 0;
+    if (any_tf) b0 = (step0 * 4) / HW;  // image of the batch's first pixel (scalar); a batch spans <= 2 images (HW >= 4U)
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int px = (step0 + u) * 4 + q;
+      const bool ok = step0 + u < se && px < NPX;
+      const int ps = ok ? px : 0;
+#pragma unroll
+      for (int m = 0; m < NMT; ++m) {
+        float v = av[u][m];
+        if (A.dy_flags & LMN_SRC_DROP) v *= lmn_drop_scale(A.dy_seed, (uint32_t)(ps * A.Cout + (mco[m] >= 0 ? mco[m] : 0)), A.dy_p, P.inv_keep_dy);
+        av[u][m] = (ok && mco[m] >= 0) ? v : 0.f;
+      }
+#pragma unroll
+      for (int t = 0; t < NNT; ++t) {
+        float v = bv[u][t];
+        if (any_tf) {
+          const int chs = sch[t] >= 0 ? sch[t] : 0;
+          if (sflags[t] & LMN_SRC_GELU) v = lmn_gelu(v);
+          if (sflags[t] & LMN_SRC_DROP) v *= lmn_drop_scale(sseed[t], (uint32_t)(ps * sC[t] + chs), sp[t], sik[t]);
+          if (sscale[t]) {
+            const int bi = b0 + (ps >= (b0 + 1) * HW ? 1 : 0);
+            v *= sscale[t][bi * sC[t] + chs];
+          }
+        }
+        bv[u][t] = (ok && sch[t] >= 0) ? v : 0.f;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+#pragma unroll
+      for (int m = 0; m < NMT; ++m) bsum[m] += av[u][m];
+#pragma unroll
+      for (int t = 0; t < NNT; ++t)
+#pragma unroll
+        for (int m = 0; m < NMT; ++m) acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u][m], bv[u][t], acc[m][t], 0, 0, 0);
+    }
+  }
+
+  // ---- block-level reduction in LDS (4 waves -> 1), plain stores in four wave rounds; layout as wgrad_lds_kernel
+  constexpr int NT = NMT * NNT;
+  __shared__ float s_acc[NT * 256 + NMT * 16];
+  for (int w = 0; w < 4; ++w) {
+    if (wvb == w) {
+#pragma unroll
+      for (int m = 0; m < NMT; ++m)
+#pragma unroll
+        for (int t = 0; t < NNT; ++t)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float* d = &s_acc[((m * NNT + t) * 4 + r) * 64 + lane];
+            *d = (w == 0) ? acc[m][t][r] : *d + acc[m][t][r];
+          }
+#pragma unroll
+      for (int m = 0; m < NMT; ++m) {
+        float v = bsum[m];
+        v += __shfl_xor(v, 16, 64);
+        v += __shfl_xor(v, 32, 64);
+        if (q == 0) {
+          float* d = &s_acc[NT * 256 + m * 16 + n];
+          *d = (w == 0) ? v : *d + v;
+        }
+      }
+    }
+    __syncthreads();
+  }
+  const int tid = threadIdx.x;
+  if (P.partial) {
+    float* dst = P.partial + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * (NT * 256 + NMT * 16);
+    for (int i = tid; i < NT * 256 + NMT * 16; i += 256) dst[i] = s_acc[i];
+    return;
+  }
+  for (int i = tid; i < NT * 256; i += 256) {
+    const int ln = i & 63, r = (i >> 6) & 3, tl = i >> 8;
+    const int t = tl % NNT, m = tl / NNT;
+    const int qq = ln >> 4, nn = ln & 15;
+    const int co = (mt0 + m) * 16 + qq * 4 + r;
+    const int nt = nt0 + t;
+    if ((mt0 + m) >= P.NMTT || co >= A.Cout || nt >= P.NNTT) continue;
+    int sidx = 0;
+    while (sidx + 1 < A.nsrc && nt >= P.ntile_off[sidx + 1]) ++sidx;
+    const int ch = (nt - P.ntile_off[sidx]) * 16 + nn;
+    if (ch >= A.src[sidx].C) continue;
+    atomicAdd(A.dW + ((int64_t)co * P.Cin + P.cbase[sidx] + ch), s_acc[i]);
   }
   if (A.db && nset == 0) {
     for (int i = tid; i < NMT * 16; i += 256) {
@@ -1376,21 +1558,11 @@ int64_t lmn_conv_wgrad_workspace(const lmn_wgrad_args_t* a) {
   int nntt = 0;
   for (int s = 0; s < a->nsrc && s < 3; ++s) nntt += (a->src[s].C + 15) / 16;
   const int nmtt = (a->Cout + 15) / 16;
-  const bool small = (nmtt == 1 || nntt == 1);
-  const int NMT = small ? 1 : 2, NNT = small ? 1 : 2;
+  const int NMT = nmtt == 1 ? 1 : 2, NNT = nntt == 1 ? 1 : 2;
   const int gy = ((nmtt + NMT - 1) / NMT) * ((nntt + NNT - 1) / NNT);
   const int64_t per = (int64_t)a->ksize * a->ksize * NMT * NNT * 256 + NMT * 16;
-  const int npmax = a->stride == 2 ? 64 : (a->ksize == 1 ? 256 : 128);
-  int TW = a->Wout < (a->ksize == 1 ? npmax : 32) ? a->Wout : (a->ksize == 1 ? npmax : 32);
-  if (a->stride == 2 && TW > 16) TW = 16;
-  int TH = npmax / TW;
-  if (TH > a->Hout) TH = a->Hout;
-  if (TH < 1) TH = 1;
-  int64_t blocks = (int64_t)a->B * ((a->Wout + TW - 1) / TW) * ((a->Hout + TH - 1) / TH);
-  const int64_t cap = 1024 / gy > 2 ? 1024 / gy : 2;
-  if (blocks > cap) blocks = cap;
-  if (blocks <= 1) return 0;
-  const int64_t need = gy * blocks * per;
+  const int64_t cap = 1024 / gy > 2 ? 1024 / gy : 2;  // upper bound of the K-split block count (see lmn_conv_wgrad)
+  const int64_t need = gy * cap * per;
   return need <= (int64_t)(16 << 20) ? need : 0;  // at most 64 MB of partials; larger problems use atomics
 }
 const char* lmn_last_error(void) { return g_lmn_err; }
@@ -1664,28 +1836,32 @@ int lmn_conv_wgrad(const lmn_wgrad_args_t* args, lmn_stream_t stream) {
     LMN_REQUIRE((int64_t)A.B * A.Hin * A.Win * A.src[s].cstride < (1LL << 31), "conv_wgrad: source %d larger than 2^31 elements", s);
   LMN_REQUIRE((int64_t)A.B * A.Hout * A.Wout * A.dy_cstride < (1LL << 31), "conv_wgrad: dy larger than 2^31 elements");
   P.total_steps = A.B * P.steps_per_img;
-  const bool small = (P.NMTT == 1 || P.NNTT == 1);
-  const int NMT = small ? 1 : 2, NNT = small ? 1 : 2;
+  if (A.ksize == 1 && A.stride == 1) {  // 1x1: every image is one flat row of H*W pixels (all tiles full)
+    P.a.Wout = A.Hout * A.Wout; P.a.Hout = 1;
+    P.a.Win = A.Hin * A.Win; P.a.Hin = 1;
+  }
+  const int NMT = P.NMTT == 1 ? 1 : 2, NNT = P.NNTT == 1 ? 1 : 2;  // cout x cin tiles per block
   const int msets = (P.NMTT + NMT - 1) / NMT;
   P.nsets_n = (P.NNTT + NNT - 1) / NNT;
   const int gy = msets * P.nsets_n;
   const int taps = A.ksize * A.ksize;
   const int64_t per = (int64_t)taps * NMT * NNT * 256 + NMT * 16;
   // ---- tile geometry of the LDS-staged kernel
-  const int npmax = A.stride == 2 ? 64 : (A.ksize == 1 ? 256 : 128);
-  P.TW = A.Wout < (A.ksize == 1 ? npmax : 32) ? A.Wout : (A.ksize == 1 ? npmax : 32);
-  if (A.stride == 2 && P.TW > 16) P.TW = 16;
+  const lmn_wgrad_args_t& G = P.a;  // (flattened) geometry
+  const int npmax = G.stride == 2 ? 64 : (G.ksize == 1 ? 256 : 128);
+  P.TW = G.Wout < (G.ksize == 1 ? npmax : 32) ? G.Wout : (G.ksize == 1 ? npmax : 32);
+  if (G.stride == 2 && P.TW > 16) P.TW = 16;
   P.TH = npmax / P.TW;
-  if (P.TH > A.Hout) P.TH = A.Hout;
+  if (P.TH > G.Hout) P.TH = G.Hout;
   if (P.TH < 1) P.TH = 1;
-  P.XH = (P.TH - 1) * A.stride + A.ksize;
-  P.XW = (P.TW - 1) * A.stride + A.ksize;
+  P.XH = (P.TH - 1) * G.stride + G.ksize;
+  P.XW = (P.TW - 1) * G.stride + G.ksize;
   // LDS planes [tile][pixel][CS]: the 4 pixels of a K step are CS*stride floats apart; 16 (stride 1) and 24
   // (stride 2: 48 = 16 mod 32 banks) keep the two 16-lane halves of a ds_read_b32 group on disjoint banks
   P.CSy = 16;
   P.CSx = A.stride == 1 ? 16 : 24;
-  P.tiles_x = (A.Wout + P.TW - 1) / P.TW;
-  P.tiles_y = (A.Hout + P.TH - 1) / P.TH;
+  P.tiles_x = (G.Wout + P.TW - 1) / P.TW;
+  P.tiles_y = (G.Hout + P.TH - 1) / P.TH;
   P.total_tiles = A.B * P.tiles_x * P.tiles_y;
   P.dbg = 0;
   LMN_REQUIRE(P.XH * P.XW < 65536 && P.TH * P.TW < 65536, "conv_wgrad: tile too large");
@@ -1720,11 +1896,40 @@ int lmn_conv_wgrad(const lmn_wgrad_args_t* args, lmn_stream_t stream) {
       hipLaunchKernelGGL((wgrad_reduce_kernel<T, M, N>), dim3(rb, gy), dim3(1024), 0, st, P, blocks);               \
     }                                                                                                               \
   } while (0)
-  if (A.ksize == 1) {
-    if (small) LMN_WG(1, 1, 1); else LMN_WG(1, 2, 2);
-  } else {
-    if (small) LMN_WG(9, 1, 1); else LMN_WG(9, 2, 2);
+  if (A.ksize == 1 && A.stride == 1 && (int64_t)G.Hout * G.Wout >= 32) {
+    // direct (no LDS) kernel: K steps split over ~1024*4/gy waves, at least 16 steps per wave
+    const int64_t steps = ((int64_t)A.B * G.Hout * G.Wout + 3) / 4;
+    int64_t nb = (steps + 63) / 64;  // >= 16 steps per wave
+    if (nb > cap) nb = cap;
+    if (nb < 1) nb = 1;
+    P.partial = nullptr;
+    if (A.workspace && nb > 1 && (int64_t)gy * nb * per <= A.workspace_floats) P.partial = A.workspace;
+    else if (nb > 512 / gy && 512 / gy >= 2) nb = 512 / gy;
+    const dim3 dgrid((unsigned)nb, gy);
+#define LMN_WD(M, N)                                                                                               \
+  do {                                                                                                              \
+    hipLaunchKernelGGL((wgrad_1x1_kernel<M, N>), dgrid, dim3(256), 0, st, P);                                       \
+    if (P.partial) {                                                                                                \
+      const int rb = (int)((per + 63) / 64);                                                                        \
+      hipLaunchKernelGGL((wgrad_reduce_kernel<1, M, N>), dim3(rb, gy), dim3(1024), 0, st, P, (int)nb);              \
+    }                                                                                                               \
+  } while (0)
+    if (NMT == 1 && NNT == 1) LMN_WD(1, 1);
+    else if (NMT == 1) LMN_WD(1, 2);
+    else if (NNT == 1) LMN_WD(2, 1);
+    else LMN_WD(2, 2);
+#undef LMN_WD
+    return lmn_launch_status("conv_wgrad(1x1)");
   }
+#define LMN_WGS(T)                                                   \
+  do {                                                               \
+    if (NMT == 1 && NNT == 1) LMN_WG(T, 1, 1);                       \
+    else if (NMT == 1) LMN_WG(T, 1, 2);                              \
+    else if (NNT == 1) LMN_WG(T, 2, 1);                              \
+    else LMN_WG(T, 2, 2);                                            \
+  } while (0)
+  if (A.ksize == 1) LMN_WGS(1); else LMN_WGS(9);
+#undef LMN_WGS
 #undef LMN_WG
   return lmn_launch_status("conv_wgrad");
 }
