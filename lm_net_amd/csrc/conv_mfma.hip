@@ -1553,12 +1553,22 @@ int lmn_sizeof_src(void) { return (int)sizeof(lmn_src_t); }
 int lmn_sizeof_wgrad_args(void) { return (int)sizeof(lmn_wgrad_args_t); }
 int lmn_sizeof_pack_job(void) { return (int)sizeof(lmn_pack_job_t); }
 
+// cout x cin 16-channel tiles per block.  The direct 1x1 kernel holds up to 4 accumulator tiles in any shape (a
+// one-tile-wide side is read exactly once); the LDS-staged kernel is instantiated for 1 or 2 tiles per side.
+static void wgrad_tile_shape(const lmn_wgrad_args_t& a, int nmtt, int nntt, int* NMT, int* NNT) {
+  const bool direct = a.ksize == 1 && a.stride == 1 && (int64_t)a.Hout * a.Wout >= 32;
+  if (direct && nntt == 1) { *NMT = nmtt < 4 ? nmtt : 4; *NNT = 1; }
+  else if (direct && nmtt == 1) { *NMT = 1; *NNT = nntt < 4 ? nntt : 4; }
+  else { *NMT = nmtt == 1 ? 1 : 2; *NNT = nntt == 1 ? 1 : 2; }
+}
+
 int64_t lmn_conv_wgrad_workspace(const lmn_wgrad_args_t* a) {
   if (!a) return 0;
   int nntt = 0;
   for (int s = 0; s < a->nsrc && s < 3; ++s) nntt += (a->src[s].C + 15) / 16;
   const int nmtt = (a->Cout + 15) / 16;
-  const int NMT = nmtt == 1 ? 1 : 2, NNT = nntt == 1 ? 1 : 2;
+  int NMT, NNT;
+  wgrad_tile_shape(*a, nmtt, nntt, &NMT, &NNT);
   const int gy = ((nmtt + NMT - 1) / NMT) * ((nntt + NNT - 1) / NNT);
   const int64_t per = (int64_t)a->ksize * a->ksize * NMT * NNT * 256 + NMT * 16;
   const int64_t cap = 1024 / gy > 2 ? 1024 / gy : 2;  // upper bound of the K-split block count (see lmn_conv_wgrad)
@@ -1840,7 +1850,8 @@ int lmn_conv_wgrad(const lmn_wgrad_args_t* args, lmn_stream_t stream) {
     P.a.Wout = A.Hout * A.Wout; P.a.Hout = 1;
     P.a.Win = A.Hin * A.Win; P.a.Hin = 1;
   }
-  const int NMT = P.NMTT == 1 ? 1 : 2, NNT = P.NNTT == 1 ? 1 : 2;  // cout x cin tiles per block
+  int NMT, NNT;  // cout x cin tiles per block
+  wgrad_tile_shape(A, P.NMTT, P.NNTT, &NMT, &NNT);
   const int msets = (P.NMTT + NMT - 1) / NMT;
   P.nsets_n = (P.NNTT + NNT - 1) / NNT;
   const int gy = msets * P.nsets_n;
@@ -1914,10 +1925,16 @@ int lmn_conv_wgrad(const lmn_wgrad_args_t* args, lmn_stream_t stream) {
       hipLaunchKernelGGL((wgrad_reduce_kernel<1, M, N>), dim3(rb, gy), dim3(1024), 0, st, P, (int)nb);              \
     }                                                                                                               \
   } while (0)
-    if (NMT == 1 && NNT == 1) LMN_WD(1, 1);
-    else if (NMT == 1) LMN_WD(1, 2);
-    else if (NNT == 1) LMN_WD(2, 1);
-    else LMN_WD(2, 2);
+    switch (NMT * 8 + NNT) {
+      case 1 * 8 + 1: LMN_WD(1, 1); break;
+      case 1 * 8 + 2: LMN_WD(1, 2); break;
+      case 1 * 8 + 3: LMN_WD(1, 3); break;
+      case 1 * 8 + 4: LMN_WD(1, 4); break;
+      case 2 * 8 + 1: LMN_WD(2, 1); break;
+      case 3 * 8 + 1: LMN_WD(3, 1); break;
+      case 4 * 8 + 1: LMN_WD(4, 1); break;
+      default: LMN_WD(2, 2); break;
+    }
 #undef LMN_WD
     return lmn_launch_status("conv_wgrad(1x1)");
   }
