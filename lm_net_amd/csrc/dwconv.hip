@@ -530,6 +530,299 @@ __global__ __launch_bounds__(256) void dw_bwd_kernel(const float* __restrict__ x
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// backward pass 2, strip-walking form (replaces dw_bwd_kernel on the hot path).
+//
+// VALU-bound work (per pixel and channel: 40 FMAs for the four y_b, 40 for dx1, 40 for the weight gradients), so
+// the layout is chosen to make every FMA a packed v_pk_fma_f32 with NO per-FMA LDS operand:
+//   * a WAVE owns one channel pair; its 64 LANES are 64 adjacent columns [xs-2, xs+62) of a strip.  All weights
+//     and BN coefficients of the pair are wave-uniform, i.e. live in SGPRs and feed v_pk_fma_f32 directly;
+//   * the wave walks down the rows of a segment.  One x1 row (5 ds_read_b64: columns x-2..x+2) feeds the rotating
+//     accumulators of the four branch outputs y_b; two steps later row q = r-2 is complete, f_b(q) = a_b*dpre +
+//     c_b*y_b + d_b follows, its +-1/+-2 column neighbours come from DPP wave shifts (no LDS), and it is scattered
+//     into 5 rotating dx1-row accumulators; the weight gradients pair the thread's own f history (registers) with a
+//     re-read of x1 row r-4;
+//   * x1 / dpre rows are staged (and dx1 rows drained) through LDS by the whole block in batches of 5 rows with
+//     coalesced 16 B accesses; LDS pixel stride 10 floats (2*odd) makes the 64-column b64 reads conflict-free.
+// Valid dx1 columns are lanes 2..61 (60 per strip); f on lanes 0,1,62,63 is halo.  Rows: x1 rows [ys-4, ye+4).
+constexpr int SW_NW = 4, SW_CH = 2 * SW_NW, SW_CS = SW_CH + 2;
+constexpr int SW_XC = 68, SW_FC = 64, SW_R = 5, SW_XR = 10, SW_OC = 60;
+
+// (scalar temporaries on purpose: __builtin_bit_cast on a vector ELEMENT made hipcc 7.2 shift element 0 only and
+//  broadcast it -- checked in the ISA)
+__device__ __forceinline__ float dpp_wave_shr1(float a) {   // lane l gets lane l-1, lane 0 gets 0
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(a), 0x138, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float dpp_wave_shl1(float a) {   // lane l gets lane l+1, lane 63 gets 0
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(a), 0x130, 0xF, 0xF, true));
+}
+__device__ __forceinline__ f32x2 lane_from_left(f32x2 v) {   // result[l] = v[l-1]
+  const float a0 = v.x, a1 = v.y;
+  f32x2 r;
+  r.x = dpp_wave_shr1(a0);
+  r.y = dpp_wave_shr1(a1);
+  return r;
+}
+__device__ __forceinline__ f32x2 lane_from_right(f32x2 v) {  // result[l] = v[l+1]
+  const float a0 = v.x, a1 = v.y;
+  f32x2 r;
+  r.x = dpp_wave_shl1(a0);
+  r.y = dpp_wave_shl1(a1);
+  return r;
+}
+
+struct SwState {
+  f32x2 a5[5], a3[5], av[5], ah[5];          // y_b accumulators, slot = row index mod 5
+  f32x2 h5[5], h3[5], hv[5], hh[5];          // own-pixel f_b history (masked), slot = row index mod 5
+  f32x2 dxa[5];                              // dx1 row accumulators, slot = row index mod 5
+  f32x2 g5[25], g3[9], gv[3], gh[3];         // weight-gradient accumulators
+};
+
+// One row step.  P = step index mod 5 (compile time, so every slot below is a fixed register).
+template <int P>
+__device__ __forceinline__ void sw_step(SwState& S, const BranchW& bw, const f32x2 (&ca)[4], const f32x2 (&cc)[4],
+                                        const f32x2 (&cd)[4], const float* XS, const float* DPS, float* OUT, int j,
+                                        int lane, int wv, bool frow_in, bool col_in, bool own, bool dx_row, bool dw_ok) {
+  const f32x2 z2 = f32x2{0.f, 0.f};
+  // ---- x1 row j: columns x-2 .. x+2
+  const float* xr = XS + ((j % SW_XR) * SW_XC + lane) * SW_CS + wv * 2;
+  f32x2 in[5];
+#pragma unroll
+  for (int d = 0; d < 5; ++d) in[d] = *reinterpret_cast<const f32x2*>(xr + d * SW_CS);
+#pragma unroll
+  for (int ky = 0; ky < 5; ++ky)
+#pragma unroll
+    for (int d = 0; d < 5; ++d) S.a5[(P - ky + 7) % 5] += bw.w5[ky * 5 + d] * in[d];
+#pragma unroll
+  for (int ky = 0; ky < 3; ++ky) {
+#pragma unroll
+    for (int d = 0; d < 3; ++d) S.a3[(P - ky + 6) % 5] += bw.w3[ky * 3 + d] * in[1 + d];
+    S.av[(P - ky + 6) % 5] += bw.wv[ky] * in[2];
+  }
+#pragma unroll
+  for (int d = 0; d < 3; ++d) S.ah[P] += bw.wh[d] * in[1 + d];
+  // ---- row q = j-2 is complete: f_b
+  constexpr int Q = (P + 3) % 5;
+  const f32x2 dp = *reinterpret_cast<const f32x2*>(DPS + (P * SW_FC + lane) * SW_CS + wv * 2);
+  const bool fin = frow_in && col_in;
+  f32x2 f5 = cc[0] * S.a5[Q] + (ca[0] * dp + cd[0]);
+  f32x2 f3 = cc[1] * S.a3[Q] + (ca[1] * dp + cd[1]);
+  f32x2 fv = cc[2] * S.av[Q] + (ca[2] * dp + cd[2]);
+  f32x2 fh = cc[3] * S.ah[Q] + (ca[3] * dp + cd[3]);
+  if (!fin) f5 = f3 = fv = fh = z2;
+  S.a5[Q] = S.a3[Q] = S.av[Q] = S.ah[Q] = z2;
+  S.h5[Q] = own ? f5 : z2;
+  S.h3[Q] = own ? f3 : z2;
+  S.hv[Q] = own ? fv : z2;
+  S.hh[Q] = own ? fh : z2;
+  // ---- dx1: f row q feeds dx rows q-2..q+2; column neighbours by DPP.  sh[k][l] = f[l + 2 - k]
+  {
+    f32x2 sh[5];
+    sh[2] = f5;
+    sh[1] = lane_from_right(f5);
+    sh[0] = lane_from_right(sh[1]);
+    sh[3] = lane_from_left(f5);
+    sh[4] = lane_from_left(sh[3]);
+#pragma unroll
+    for (int ky = 0; ky < 5; ++ky)
+#pragma unroll
+      for (int kx = 0; kx < 5; ++kx) S.dxa[(P + ky + 1) % 5] += bw.w5[ky * 5 + kx] * sh[kx];
+    f32x2 s3[3];
+    s3[1] = f3;
+    s3[0] = lane_from_right(f3);
+    s3[2] = lane_from_left(f3);
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) S.dxa[(P + ky + 2) % 5] += bw.w3[ky * 3 + kx] * s3[kx];
+      S.dxa[(P + ky + 2) % 5] += bw.wv[ky] * fv;
+    }
+    S.dxa[Q] += bw.wh[0] * lane_from_right(fh) + bw.wh[1] * fh + bw.wh[2] * lane_from_left(fh);
+  }
+  // ---- dx row j-4 is complete
+  constexpr int D = (P + 1) % 5;
+  if (dx_row) *reinterpret_cast<f32x2*>(OUT + (P * SW_FC + lane) * SW_CS + wv * 2) = S.dxa[D];
+  S.dxa[D] = z2;
+  // ---- weight gradients: x1 row j-4 (re-read) against the own-pixel f history
+  if (dw_ok) {
+    const float* x2 = XS + (((j + SW_XR - 4) % SW_XR) * SW_XC + lane) * SW_CS + wv * 2;
+    f32x2 i2[5];
+#pragma unroll
+    for (int d = 0; d < 5; ++d) i2[d] = *reinterpret_cast<const f32x2*>(x2 + d * SW_CS);
+#pragma unroll
+    for (int ky = 0; ky < 5; ++ky)
+#pragma unroll
+      for (int kx = 0; kx < 5; ++kx) S.g5[ky * 5 + kx] += S.h5[(P + 8 - ky) % 5] * i2[kx];
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) S.g3[ky * 3 + kx] += S.h3[(P + 7 - ky) % 5] * i2[1 + kx];
+      S.gv[ky] += S.hv[(P + 7 - ky) % 5] * i2[2];
+    }
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) S.gh[kx] += S.hh[D] * i2[1 + kx];
+  }
+}
+
+__global__ __launch_bounds__(256) void dw_bwd_strip_kernel(
+    const float* __restrict__ x1, const float* __restrict__ dpre, float* __restrict__ dx1, int B, int H, int W, int E,
+    const float* __restrict__ w5, const float* __restrict__ w3, const float* __restrict__ wvv,
+    const float* __restrict__ whh, const float* __restrict__ cA, const float* __restrict__ cC,
+    const float* __restrict__ cD, float* __restrict__ dw5, float* __restrict__ dw3, float* __restrict__ dwv,
+    float* __restrict__ dwh, int strips, int segs, int seg_rows, int chunks) {
+  __shared__ __attribute__((aligned(16))) float XS[SW_XR * SW_XC * SW_CS];
+  __shared__ __attribute__((aligned(16))) float DPS[SW_R * SW_FC * SW_CS];
+  __shared__ __attribute__((aligned(16))) float OUT[SW_R * SW_FC * SW_CS];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  // logical block id: channel chunk fastest (siblings share the x1 / dpre cache lines -> same XCD, same L2)
+  int lid = xcd_swizzle(blockIdx.x, gridDim.x);
+  const int chunk = lid % chunks; lid /= chunks;
+  const int strip = lid % strips; lid /= strips;
+  const int seg = lid % segs;
+  const int b = lid / segs;
+  const int ch0 = chunk * SW_CH;
+  const int ch = ch0 + wv * 2;
+  const bool cok = ch < E;                      // wave-uniform: pairs past E (partial last chunk) compute on zeros
+  const int chs = cok ? ch : 0;
+  BranchW bw;
+  load_branch_w(bw, w5, w3, wvv, whh, chs, E);
+  f32x2 ca[4], cc[4], cd[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    ca[k] = f32x2{cA[k * E + chs], cA[k * E + chs + 1]};
+    cc[k] = f32x2{cC[k * E + chs], cC[k * E + chs + 1]};
+    cd[k] = f32x2{cD[k * E + chs], cD[k * E + chs + 1]};
+  }
+  const int ys = seg * seg_rows, ye = min(ys + seg_rows, H);
+  const int xs = strip * SW_OC;
+  const int cx = xs - 2 + lane;
+  const bool col_in = cx >= 0 && cx < W;
+  const bool own_col = lane >= 2 && lane < 2 + SW_OC && cx < W;
+  const float* xb = x1 + (int64_t)b * H * W * E;
+  const float* db = dpre + (int64_t)b * H * W * E;
+  float* ob = dx1 + (int64_t)b * H * W * E;
+
+  SwState S;
+  const f32x2 z2 = f32x2{0.f, 0.f};
+#pragma unroll
+  for (int k = 0; k < 5; ++k) S.a5[k] = S.a3[k] = S.av[k] = S.ah[k] = S.h5[k] = S.h3[k] = S.hv[k] = S.hh[k] = S.dxa[k] = z2;
+#pragma unroll
+  for (int k = 0; k < 25; ++k) S.g5[k] = z2;
+#pragma unroll
+  for (int k = 0; k < 9; ++k) S.g3[k] = z2;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) S.gv[k] = S.gh[k] = z2;
+
+  // step j: x1 row (ys-4+j) enters; f row (ys-6+j); finished dx row (ys-8+j); weight-gradient products of x1 row
+  // (ys-8+j).  The last own f row (ye-1) still meets x1 row ye+1 => rows + 10 steps (the last two only feed dW).
+  const int nsteps = (ye - ys) + 10;
+  const int ndx = (ye - ys) + 8;  // steps that finish a dx row: 8 <= j < ndx
+  for (int j0 = 0; j0 < nsteps; j0 += SW_R) {
+    __syncthreads();  // previous batch computed: OUT holds its dx rows, XS/DPS slots are free
+    // ---- drain the dx rows of the previous batch (steps j0-5 .. j0-1 => image rows ys-8+j)
+    if (j0 >= 8 + SW_R - 4) {  // some step of the previous batch had j >= 8
+      for (int i = tid; i < SW_R * SW_OC * 2; i += 256) {
+        const int k4 = i & 1, pc = i >> 1;
+        const int rr = pc / SW_OC, c = pc - rr * SW_OC;
+        const int jj = j0 - SW_R + rr;
+        const int gy = ys - 8 + jj, gx = xs + c;
+        if (jj >= 8 && jj < ndx && gx < W && ch0 + k4 * 4 < E)
+          *reinterpret_cast<f32x4*>(ob + ((int64_t)gy * W + gx) * E + ch0 + k4 * 4) =
+              f32x4{OUT[(rr * SW_FC + c + 2) * SW_CS + k4 * 4], OUT[(rr * SW_FC + c + 2) * SW_CS + k4 * 4 + 1],
+                    OUT[(rr * SW_FC + c + 2) * SW_CS + k4 * 4 + 2], OUT[(rr * SW_FC + c + 2) * SW_CS + k4 * 4 + 3]};
+      }
+    }
+    // ---- stage x1 rows of this batch (image rows ys-4+j, columns xs-4 .. xs+63) into the ring
+    for (int i = tid; i < SW_R * SW_XC * 2; i += 256) {
+      const int k4 = i & 1, pc = i >> 1;
+      const int rr = pc / SW_XC, c = pc - rr * SW_XC;
+      const int jj = j0 + rr;
+      const int gy = ys - 4 + jj, gx = xs - 4 + c;
+      const bool in = jj < nsteps && gy >= 0 && gy < H && gx >= 0 && gx < W && ch0 + k4 * 4 < E;
+      const int sy = in ? gy : 0, sx = in ? gx : 0, sc = in ? ch0 + k4 * 4 : 0;
+      f32x4 v = *reinterpret_cast<const f32x4*>(xb + ((int64_t)sy * W + sx) * E + sc);
+      if (!in) v = f32x4{0.f, 0.f, 0.f, 0.f};
+      float* d = &XS[((jj % SW_XR) * SW_XC + c) * SW_CS + k4 * 4];
+      *reinterpret_cast<f32x2*>(d) = f32x2{v[0], v[1]};
+      *reinterpret_cast<f32x2*>(d + 2) = f32x2{v[2], v[3]};
+    }
+    // ---- stage dpre rows (image rows ys-6+j, columns xs-2 .. xs+61)
+    for (int i = tid; i < SW_R * SW_FC * 2; i += 256) {
+      const int k4 = i & 1, pc = i >> 1;
+      const int rr = pc / SW_FC, c = pc - rr * SW_FC;
+      const int jj = j0 + rr;
+      const int gy = ys - 6 + jj, gx = xs - 2 + c;
+      const bool in = jj < nsteps && gy >= 0 && gy < H && gx >= 0 && gx < W && ch0 + k4 * 4 < E;
+      const int sy = in ? gy : 0, sx = in ? gx : 0, sc = in ? ch0 + k4 * 4 : 0;
+      f32x4 v = *reinterpret_cast<const f32x4*>(db + ((int64_t)sy * W + sx) * E + sc);
+      if (!in) v = f32x4{0.f, 0.f, 0.f, 0.f};
+      float* d = &DPS[(rr * SW_FC + c) * SW_CS + k4 * 4];
+      *reinterpret_cast<f32x2*>(d) = f32x2{v[0], v[1]};
+      *reinterpret_cast<f32x2*>(d + 2) = f32x2{v[2], v[3]};
+    }
+    __syncthreads();
+    // ---- five row steps (fixed register slots per phase)
+#define LMN_SW_STEP(PH)                                                                                       \
+    {                                                                                                         \
+      const int j = j0 + PH;                                                                                  \
+      if (j < nsteps) {                                                                                       \
+        const int fy = ys - 6 + j;                                                                            \
+        const bool frow_in = j >= 4 && fy >= 0 && fy < H;                                                     \
+        const bool own = own_col && fy >= ys && fy < ye;                                                      \
+        sw_step<PH>(S, bw, ca, cc, cd, XS, DPS, OUT, j, lane, wv, frow_in, col_in, own, j >= 8 && j < ndx, j >= 4);      \
+      }                                                                                                       \
+    }
+    LMN_SW_STEP(0) LMN_SW_STEP(1) LMN_SW_STEP(2) LMN_SW_STEP(3) LMN_SW_STEP(4)
+#undef LMN_SW_STEP
+  }
+  __syncthreads();
+  {  // drain the dx rows of the last batch
+    const int j0 = ((nsteps + SW_R - 1) / SW_R) * SW_R;
+    for (int i = tid; i < SW_R * SW_OC * 2; i += 256) {
+      const int k4 = i & 1, pc = i >> 1;
+      const int rr = pc / SW_OC, c = pc - rr * SW_OC;
+      const int jj = j0 - SW_R + rr;
+      const int gy = ys - 8 + jj, gx = xs + c;
+      if (jj >= 8 && jj < ndx && gx < W && ch0 + k4 * 4 < E)
+        *reinterpret_cast<f32x4*>(ob + ((int64_t)gy * W + gx) * E + ch0 + k4 * 4) =
+            f32x4{OUT[(rr * SW_FC + c + 2) * SW_CS + k4 * 4], OUT[(rr * SW_FC + c + 2) * SW_CS + k4 * 4 + 1],
+                  OUT[(rr * SW_FC + c + 2) * SW_CS + k4 * 4 + 2], OUT[(rr * SW_FC + c + 2) * SW_CS + k4 * 4 + 3]};
+    }
+  }
+  // ---- weight gradients: butterfly over the 64 columns, one LDS row per wave, then one atomic per (tap, channel)
+  __syncthreads();
+  float* red = XS;  // [4 waves][40 taps][2]
+  auto wave_sum_store = [&](f32x2 v, int t) {
+#pragma unroll
+    for (int m = 1; m <= 32; m <<= 1) {
+      v[0] += __shfl_xor(v[0], m, 64);
+      v[1] += __shfl_xor(v[1], m, 64);
+    }
+    if (lane == 0) *reinterpret_cast<f32x2*>(&red[(wv * 40 + t) * 2]) = v;
+  };
+#pragma unroll
+  for (int t = 0; t < 25; ++t) wave_sum_store(S.g5[t], t);
+#pragma unroll
+  for (int t = 0; t < 9; ++t) wave_sum_store(S.g3[t], 25 + t);
+#pragma unroll
+  for (int t = 0; t < 3; ++t) {
+    wave_sum_store(S.gv[t], 34 + t);
+    wave_sum_store(S.gh[t], 37 + t);
+  }
+  __syncthreads();
+  for (int i = tid; i < SW_NW * 40 * 2; i += 256) {
+    const int k = i & 1, t = (i >> 1) % 40, w = i / 80;
+    const int e = ch0 + w * 2 + k;
+    if (e >= E) continue;
+    const float v = red[i];
+    if (t < 25) atomicAdd(dw5 + (int64_t)e * 25 + t, v);
+    else if (t < 34) atomicAdd(dw3 + (int64_t)e * 9 + t - 25, v);
+    else if (t < 37) atomicAdd(dwv + (int64_t)e * 3 + t - 34, v);
+    else atomicAdd(dwh + (int64_t)e * 3 + t - 37, v);
+  }
+}
+
 // per-branch BN-backward coefficients from bst[5][E] = (S0 = sum dpre, S1_b = sum dpre*y_b)
 __global__ void dw_bwd_coef_kernel(const float* __restrict__ bst, const float* __restrict__ mean,
                                    const float* __restrict__ rstd, const float* __restrict__ A, float count,
@@ -648,9 +941,17 @@ int lmn_dw_bwd(const float* x1, const float* dpre, float* dx1, int B, int H, int
                float* dw5, float* dw3, float* dwv, float* dwh, lmn_stream_t stream) {
   LMN_REQUIRE(x1 && dpre && dx1 && w5 && w3 && wv && wh && cA && cC && cD && dw5 && dw3 && dwv && dwh, "dw_bwd: null pointer");
   LMN_REQUIRE(B > 0 && H > 0 && W > 0 && E > 0 && E % 4 == 0, "dw_bwd: E=%d must be a multiple of 4", E);
-  const int tx = lmn_cdiv(W, DT), ty = lmn_cdiv(H, DT);
-  hipLaunchKernelGGL(dw_bwd_kernel, dim3(dw_grid_x(B, tx, ty, lmn_cdiv(E, DC)), lmn_cdiv(E, DC)), dim3(256), 0, (hipStream_t)stream, x1,
-                     dpre, dx1, B, H, W, E, w5, w3, wv, wh, cA, cC, cD, dw5, dw3, dwv, dwh, tx, ty);
+  // strip-walking kernel: blocks = B x strips(60 columns) x row segments x 8-channel chunks.  Segments add 8 halo
+  // rows each, so they are as long as possible while the grid still has ~3 blocks per CU.
+  const int strips = lmn_cdiv(W, SW_OC), chunks = lmn_cdiv(E, SW_CH);
+  int segs = 1;
+  while ((int64_t)B * strips * chunks * segs < 768 && lmn_cdiv(H, segs * 2) >= 16) segs *= 2;
+  const int seg_rows = lmn_cdiv(H, segs);
+  segs = lmn_cdiv(H, seg_rows);
+  const int64_t nblk = (int64_t)B * strips * chunks * segs;
+  LMN_REQUIRE(nblk < (1LL << 31), "dw_bwd: grid too large");
+  hipLaunchKernelGGL(dw_bwd_strip_kernel, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, x1, dpre, dx1, B, H, W, E, w5,
+                     w3, wv, wh, cA, cC, cD, dw5, dw3, dwv, dwh, strips, segs, seg_rows, chunks);
   return lmn_launch_status("dw_bwd");
 }
 
