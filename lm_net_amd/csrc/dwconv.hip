@@ -693,6 +693,9 @@ __global__ __launch_bounds__(256) void dw_bwd_strip_kernel(
     ca[k] = f32x2{cA[k * E + chs], cA[k * E + chs + 1]};
     cc[k] = f32x2{cC[k * E + chs], cC[k * E + chs + 1]};
     cd[k] = f32x2{cD[k * E + chs], cD[k * E + chs + 1]};
+    // the 80 weight SGPRs already fill the scalar file: keep the 24 coefficient floats in VGPRs (otherwise the
+    // allocator spills weights to VGPR lanes and every use costs v_readlane x2 + s_nop)
+    asm volatile("" : "+v"(ca[k].x), "+v"(ca[k].y), "+v"(cc[k].x), "+v"(cc[k].y), "+v"(cd[k].x), "+v"(cd[k].y));
   }
   const int ys = seg * seg_rows, ye = min(ys + seg_rows, H);
   const int xs = strip * SW_OC;
@@ -793,13 +796,15 @@ __global__ __launch_bounds__(256) void dw_bwd_strip_kernel(
   // ---- weight gradients: butterfly over the 64 columns, one LDS row per wave, then one atomic per (tap, channel)
   __syncthreads();
   float* red = XS;  // [4 waves][40 taps][2]
-  auto wave_sum_store = [&](f32x2 v, int t) {
-#pragma unroll
-    for (int m = 1; m <= 32; m <<= 1) {
-      v[0] += __shfl_xor(v[0], m, 64);
-      v[1] += __shfl_xor(v[1], m, 64);
-    }
-    if (lane == 0) *reinterpret_cast<f32x2*>(&red[(wv * 40 + t) * 2]) = v;
+  auto wave_sum_store = [&](f32x2 v, int t) {  // DPP reduction: total lands in lane 63 (no LDS round trips)
+    float a = v.x, c = v.y;
+#define LMN_DPP_ADD(CTRL)                                                                               \
+    a += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(a), CTRL, 0xF, 0xF, true));       \
+    c += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(c), CTRL, 0xF, 0xF, true));
+    LMN_DPP_ADD(0x111) LMN_DPP_ADD(0x112) LMN_DPP_ADD(0x114) LMN_DPP_ADD(0x118)  // row_shr 1, 2, 4, 8
+    LMN_DPP_ADD(0x142) LMN_DPP_ADD(0x143)                                        // row_bcast 15, 31
+#undef LMN_DPP_ADD
+    if (lane == 63) *reinterpret_cast<f32x2*>(&red[(wv * 40 + t) * 2]) = f32x2{a, c};
   };
 #pragma unroll
   for (int t = 0; t < 25; ++t) wave_sum_store(S.g5[t], t);
