@@ -141,17 +141,25 @@ __global__ __launch_bounds__(256) void na_bwd_q_kernel(const float* __restrict__
                                                        const float* __restrict__ dout, float* __restrict__ dqkv,
                                                        float* __restrict__ drpb, float* __restrict__ stat,
                                                        const NaGeom g) {
-  extern __shared__ float s_drpb[];  // [heads][25]
+  extern __shared__ float s_drpb[];  // [heads][25] | per-thread interior bins [256][36]
+  float* s_bins = s_drpb + g.heads * 25;
   for (int i = threadIdx.x; i < g.heads * 25; i += 256) s_drpb[i] = 0.f;
   __syncthreads();
-  const int64_t total = (int64_t)g.B * g.H * g.W * g.C4;
-  const int64_t nit = (total + (int64_t)gridDim.x * 256 - 1) / ((int64_t)gridDim.x * 256);
+  // A thread keeps ONE channel quad for the whole kernel (quad = tid % C4, pixel slot = tid / C4), so the rpb
+  // gradient of interior pixels -- whose 9 neighbours always hit the same 9 bins -- accumulates in 36 registers.
+  // (Per-pixel LDS atomics on 9 shared bins serialise the whole block: 554 us at 352x352, 12 heads.)
+  const int PB = 256 / g.C4;                       // pixels per block iteration
+  const int c = (threadIdx.x % g.C4) * 4;
+  const int slot = threadIdx.x / g.C4;
+  const int64_t npix = (int64_t)g.B * g.H * g.W;
+  const int64_t nit = (npix + (int64_t)gridDim.x * PB - 1) / ((int64_t)gridDim.x * PB);
+  f32x4 bins[9];
+#pragma unroll
+  for (int n = 0; n < 9; ++n) bins[n] = f32x4{0.f, 0.f, 0.f, 0.f};
   for (int64_t it = 0; it < nit; ++it) {
-    int64_t idx = (it * gridDim.x + blockIdx.x) * 256 + threadIdx.x;
-    const bool ok = idx < total;
-    if (!ok) idx = total - 1;  // keep every lane in the shuffles
-    const int c = (int)(idx % g.C4) * 4;
-    const int64_t pix = idx / g.C4;
+    int64_t pix = (it * gridDim.x + blockIdx.x) * PB + slot;
+    const bool ok = slot < PB && pix < npix;
+    if (!ok) pix = npix - 1;  // keep every lane in the shuffles
     const int x = (int)(pix % g.W);
     const int y = (int)((pix / g.W) % g.H);
     const int b = (int)(pix / ((int64_t)g.W * g.H));
@@ -199,6 +207,10 @@ __global__ __launch_bounds__(256) void na_bwd_q_kernel(const float* __restrict__
     bool rep[4];  // the lane owning a head's FIRST channel reports for that head
 #pragma unroll
     for (int k = 0; k < 4; ++k) rep[k] = ok && ((c + k) % HD == 0);
+    const bool inter = sy == y - 1 && sx == x - 1;  // unclamped window: neighbour n always lands in bin (ki+1, kj+1)
+    f32x4 rm;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) rm[k] = (rep[k] && inter) ? 1.f : 0.f;
 #pragma unroll
     for (int ki = 0; ki < 3; ++ki)
 #pragma unroll
@@ -208,10 +220,13 @@ __global__ __launch_bounds__(256) void na_bwd_q_kernel(const float* __restrict__
         const f32x4 ds = p[n] * (dp[n] - dsum);
         const f32x4 kk = ld4(base + ((int64_t)ny * g.W + nx) * 3 * g.C + g.C + c);
         dq += ds * kk;
-        const int bo = (ny - y + 2) * 5 + (nx - x + 2);
+        bins[n] += ds * rm;
+        if (!inter) {  // border pixels (the clamped window shifts the bins): rare, through LDS atomics
+          const int bo = (ny - y + 2) * 5 + (nx - x + 2);
 #pragma unroll
-        for (int k = 0; k < 4; ++k)
-          if (rep[k]) atomicAdd(&s_drpb[hidx[k] + bo], ds[k]);
+          for (int k = 0; k < 4; ++k)
+            if (rep[k]) atomicAdd(&s_drpb[hidx[k] + bo], ds[k]);
+        }
       }
     if (ok) *reinterpret_cast<f32x4*>(dqkv + ib + ((int64_t)y * g.W + x) * 3 * g.C + c) = dq * g.scale;
 #pragma unroll
@@ -221,6 +236,21 @@ __global__ __launch_bounds__(256) void na_bwd_q_kernel(const float* __restrict__
         stat[pix * 2 * g.heads + h] = mx[k] + __logf(den[k]);
         stat[pix * 2 * g.heads + g.heads + h] = dsum[k];
       }
+  }
+  // interior bins: park per thread, then one thread per (quad, neighbour, component) sums its PB pixel slots
+#pragma unroll
+  for (int n = 0; n < 9; ++n)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) s_bins[threadIdx.x * 36 + n * 4 + k] = bins[n][k];
+  __syncthreads();
+  for (int o = threadIdx.x; o < g.C4 * 36; o += 256) {
+    const int qd = o / 36, nk = o - qd * 36;
+    const int n = nk >> 2, k = nk & 3;
+    const int ch = qd * 4 + k;
+    if (ch % HD != 0) continue;
+    float v = 0.f;
+    for (int sl = 0; sl < PB; ++sl) v += s_bins[(sl * g.C4 + qd) * 36 + nk];
+    atomicAdd(&s_drpb[(ch / HD) * 25 + (n / 3 + 1) * 5 + (n % 3 + 1)], v);
   }
   __syncthreads();
   for (int i = threadIdx.x; i < g.heads * 25; i += 256)
@@ -333,7 +363,7 @@ int lmn_na_bwd(const float* qkv, const float* rpb, const float* dout, float* dqk
   const int grid = na_grid((int64_t)B * H * W * g.C4);
   const int gq = grid > 2048 ? 2048 : grid;
   hipStream_t st = (hipStream_t)stream;
-  const size_t sh = heads * 25 * sizeof(float);
+  const size_t sh = (heads * 25 + 256 * 36) * sizeof(float);
 #define LMN_NA(HDV)                                                                                                  \
   do {                                                                                                               \
     hipLaunchKernelGGL((na_bwd_q_kernel<HDV>), dim3(gq), dim3(256), sh, st, qkv, rpb, dout, dqkv, drpb, stat, g);    \
