@@ -58,6 +58,8 @@ __global__ __launch_bounds__(256) void na_fwd_kernel(const float* __restrict__ q
                                                      float* __restrict__ out, const NaGeom g, int T, int cch,
                                                      int tiles_x, int tiles, int chunks) {
   extern __shared__ __attribute__((aligned(16))) float KV[];  // [(T+2)^2][2][cch]
+  __shared__ float s_rpb[16 * 25];  // the bias table: per-lane gathers from LDS, not 36 global gathers per pixel
+  for (int i = threadIdx.x; i < g.heads * 25; i += 256) s_rpb[i] = rpb[i];
   const int R = T + 2;
   const int lid = xcd_swizzle(blockIdx.x, gridDim.x);
   const int t = lid % tiles, cb = lid / tiles;
@@ -105,7 +107,7 @@ __global__ __launch_bounds__(256) void na_fwd_kernel(const float* __restrict__ q
         f32x4 sc = head_sum<HD>(q * kk);
         const int bo = (sy + ki - y + 2) * 5 + (sx + kj - x + 2);
 #pragma unroll
-        for (int k = 0; k < 4; ++k) sc[k] += rpb[hidx[k] + bo];
+        for (int k = 0; k < 4; ++k) sc[k] += s_rpb[hidx[k] + bo];
         l[ki * 3 + kj] = sc;
 #pragma unroll
         for (int k = 0; k < 4; ++k) mx[k] = fmaxf(mx[k], sc[k]);
@@ -123,7 +125,7 @@ __global__ __launch_bounds__(256) void na_fwd_kernel(const float* __restrict__ q
 #pragma unroll
       for (int kj = 0; kj < 3; ++kj) o += l[ki * 3 + kj] * *reinterpret_cast<const f32x4*>(kv0 + ((ki * R + kj) * 2 + 1) * cch);
 #pragma unroll
-    for (int k = 0; k < 4; ++k) o[k] = o[k] / den[k];
+    for (int k = 0; k < 4; ++k) o[k] = o[k] * __builtin_amdgcn_rcpf(den[k]);  // v_rcp_f32: 1 ulp
     if (ok) *reinterpret_cast<f32x4*>(out + (((int64_t)b * g.H + y) * g.W + x) * g.C + cc) = o;
   }
 }
@@ -143,7 +145,8 @@ __global__ __launch_bounds__(256) void na_bwd_q_kernel(const float* __restrict__
                                                        const NaGeom g) {
   extern __shared__ float s_drpb[];  // [heads][25] | per-thread interior bins [256][36]
   float* s_bins = s_drpb + g.heads * 25;
-  for (int i = threadIdx.x; i < g.heads * 25; i += 256) s_drpb[i] = 0.f;
+  float* s_rpb = s_bins + 256 * 36;  // [heads][25] copy of the bias table
+  for (int i = threadIdx.x; i < g.heads * 25; i += 256) { s_drpb[i] = 0.f; s_rpb[i] = rpb[i]; }
   __syncthreads();
   // A thread keeps ONE channel quad for the whole kernel (quad = tid % C4, pixel slot = tid / C4), so the rpb
   // gradient of interior pixels -- whose 9 neighbours always hit the same 9 bins -- accumulates in 36 registers.
@@ -183,7 +186,7 @@ __global__ __launch_bounds__(256) void na_bwd_q_kernel(const float* __restrict__
         f32x4 s = head_sum<HD>(q * kk);
         const int bo = (ny - y + 2) * 5 + (nx - x + 2);
 #pragma unroll
-        for (int k = 0; k < 4; ++k) s[k] += rpb[hidx[k] + bo];
+        for (int k = 0; k < 4; ++k) s[k] += s_rpb[hidx[k] + bo];
         p[ki * 3 + kj] = s;
         dp[ki * 3 + kj] = head_sum<HD>(dO * vv);
 #pragma unroll
@@ -197,10 +200,13 @@ __global__ __launch_bounds__(256) void na_bwd_q_kernel(const float* __restrict__
       den += p[n];
     }
     f32x4 dsum = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 rden;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) rden[k] = __builtin_amdgcn_rcpf(den[k]);  // v_rcp_f32 (1 ulp) instead of 36 IEEE divisions
 #pragma unroll
     for (int n = 0; n < 9; ++n) {
 #pragma unroll
-      for (int k = 0; k < 4; ++k) p[n][k] = p[n][k] / den[k];
+      for (int k = 0; k < 4; ++k) p[n][k] = p[n][k] * rden[k];
       dsum += p[n] * dp[n];
     }
     f32x4 dq = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -331,6 +337,7 @@ int lmn_na_fwd(const float* qkv, const float* rpb, float* out, int B, int H, int
   LMN_REQUIRE(B > 0 && H >= 3 && W >= 3, "na_fwd: feature map %dx%d smaller than the 3x3 window", H, W);
   LMN_REQUIRE(hd == 1 || hd == 2 || hd == 4 || hd == 8 || hd == 16, "na_fwd: head_dim %d not in {1,2,4,8,16}", hd);
   LMN_REQUIRE((heads * hd) % 4 == 0, "na_fwd: C=%d must be a multiple of 4", heads * hd);
+  LMN_REQUIRE(heads <= 16, "na_fwd: %d heads (the LDS bias table holds 16)", heads);
   NaGeom g{B, H, W, heads * hd, heads * hd / 4, heads, scale};
   // channel chunk: whole heads and whole lane pairs; tile 16x16 while the k/v window fits 64 KB of LDS, else 8x8
   int cch = g.C <= 48 ? g.C : 48;
@@ -363,7 +370,7 @@ int lmn_na_bwd(const float* qkv, const float* rpb, const float* dout, float* dqk
   const int grid = na_grid((int64_t)B * H * W * g.C4);
   const int gq = grid > 2048 ? 2048 : grid;
   hipStream_t st = (hipStream_t)stream;
-  const size_t sh = (heads * 25 + 256 * 36) * sizeof(float);
+  const size_t sh = (2 * heads * 25 + 256 * 36) * sizeof(float);
 #define LMN_NA(HDV)                                                                                                  \
   do {                                                                                                               \
     hipLaunchKernelGGL((na_bwd_q_kernel<HDV>), dim3(gq), dim3(256), sh, st, qkv, rpb, dout, dqkv, drpb, stat, g);    \

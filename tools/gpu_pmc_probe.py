@@ -41,3 +41,11 @@ if what == "dw":
         hip.dw_fwd(x1, pre, gsum, keff, beff)
         hip.dw_bwd(x1, pre, dx1, w5, w3, wv, wh, cA, cA, cA, *dws)
 torch.cuda.synchronize()
+if what == "na":
+    for (H, C) in [(352, 12), (176, 24)]:
+        qkv = torch.randn(B, H, H, 3 * C, device=dev); rpb = torch.randn(12, 5, 5, device=dev)
+        out = torch.empty(B, H, H, C, device=dev); dq, drpb, do = torch.empty_like(qkv), torch.zeros_like(rpb), torch.randn_like(out)
+        for _ in range(2):
+            hip.na_fwd(qkv, rpb, out, 12)
+            hip.na_bwd(qkv, rpb, do, dq, drpb, 12)
+    torch.cuda.synchronize()
