@@ -1167,63 +1167,78 @@ __global__ __launch_bounds__(256, 2) void wgrad_lds_kernel(const WgradParams P) 
     const int oy0 = (tt / P.tiles_x) * P.TH, ox0 = (tt % P.tiles_x) * P.TW;
     const int iy0 = oy0 * A.stride - pad, ix0 = ox0 * A.stride - pad;
     __syncthreads();  // previous tile's reads are done
-    // ---- stage the input window: float4 items (pixel, quad) per cin tile
+    // ---- stage the input window: float4 items (pixel, quad); the pixel geometry is shared by the block's cin
+    //      tiles, whose loads are issued together before any is consumed
+    for (int i = tid; i < P.XH * P.XW * 4; i += 256) {
+      const int j = i & 3, pix = i >> 2;
+      bool inb;
+      int gp;
+      if constexpr (TAPS == 1) {  // 1x1: the image is one flat row (host), the window is the tile itself
+        inb = ox0 + pix < A.Wout;
+        gp = inb ? b * A.Wout + ox0 + pix : 0;
+      } else {
+        const int r = (int)__umulhi((uint32_t)pix, P.mXW), c = pix - r * P.XW;
+        const int iy = iy0 + r, ix = ix0 + c;
+        inb = (unsigned)iy < (unsigned)A.Hin && (unsigned)ix < (unsigned)A.Win;
+        gp = inb ? (b * A.Hin + iy) * A.Win + ix : 0;
+      }
+      f32x4 v[NNT];
 #pragma unroll
-    for (int t = 0; t < NNT; ++t) {
-      for (int i = tid; i < P.XH * P.XW * 4; i += 256) {
-        const int j = i & 3, pix = i >> 2;
+      for (int t = 0; t < NNT; ++t) {
         const int ch = tch0[t] + j * 4;
-        bool ok;
-        int gp;
-        if constexpr (TAPS == 1) {  // 1x1: the image is one flat row (host), the window is the tile itself
-          ok = ch < tC[t] && ox0 + pix < A.Wout;
-          gp = ok ? b * A.Wout + ox0 + pix : 0;
-        } else {
-          const int r = (int)__umulhi((uint32_t)pix, P.mXW), c = pix - r * P.XW;
-          const int iy = iy0 + r, ix = ix0 + c;
-          ok = ch < tC[t] && (unsigned)iy < (unsigned)A.Hin && (unsigned)ix < (unsigned)A.Win;
-          gp = ok ? (b * A.Hin + iy) * A.Win + ix : 0;
-        }
-        const int chs = ok ? ch : 0;
-        f32x4 v = ld4(tptr[t] + (uint32_t)(gp * tcs[t] + chs));
+        v[t] = ld4(tptr[t] + (uint32_t)(gp * tcs[t] + (ch < tC[t] ? ch : 0)));
+      }
+#pragma unroll
+      for (int t = 0; t < NNT; ++t) {
+        const int ch = tch0[t] + j * 4;
+        const bool ok = inb && ch < tC[t];
+        const int chs = ch < tC[t] ? ch : 0;
+        f32x4 w = v[t];
         if (tflags[t] & LMN_SRC_GELU) {
 #pragma unroll
-          for (int k = 0; k < 4; ++k) v[k] = lmn_gelu(v[k]);
+          for (int k = 0; k < 4; ++k) w[k] = lmn_gelu(w[k]);
         }
         if (tflags[t] & LMN_SRC_DROP) {
 #pragma unroll
-          for (int k = 0; k < 4; ++k) v[k] *= lmn_drop_scale(tseed[t], (uint32_t)(gp * tC[t] + chs + k), tp_[t], tik[t]);
+          for (int k = 0; k < 4; ++k) w[k] *= lmn_drop_scale(tseed[t], (uint32_t)(gp * tC[t] + chs + k), tp_[t], tik[t]);
         }
-        if (tscale[t]) v *= ld4(tscale[t] + (ok ? b : 0) * tC[t] + chs);
-        if (!ok) v = f32x4{0.f, 0.f, 0.f, 0.f};
-        *reinterpret_cast<f32x4*>(&XS[(t * XP + pix) * P.CSx + j * 4]) = v;
+        if (tscale[t]) w *= ld4(tscale[t] + (inb ? b : 0) * tC[t] + chs);
+        if (!ok) w = f32x4{0.f, 0.f, 0.f, 0.f};
+        *reinterpret_cast<f32x4*>(&XS[(t * XP + pix) * P.CSx + j * 4]) = w;
       }
     }
-    // ---- stage the dy tile
+    // ---- stage the dy tile (same pattern over the block's cout tiles)
+    for (int i = tid; i < NP * 4; i += 256) {
+      const int j = i & 3, pix = i >> 2;
+      bool inb;
+      int gp;
+      if constexpr (TAPS == 1) {
+        inb = ox0 + pix < A.Wout;
+        gp = inb ? b * A.Wout + ox0 + pix : 0;
+      } else {
+        const int r = (int)__umulhi((uint32_t)pix, P.mTW), c = pix - r * P.TW;
+        const int oy = oy0 + r, ox = ox0 + c;
+        inb = oy < A.Hout && ox < A.Wout;
+        gp = inb ? (b * A.Hout + oy) * A.Wout + ox : 0;
+      }
+      f32x4 v[NMT];
+      int cosv[NMT];
 #pragma unroll
-    for (int m = 0; m < NMT; ++m) {
-      for (int i = tid; i < NP * 4; i += 256) {
-        const int j = i & 3, pix = i >> 2;
+      for (int m = 0; m < NMT; ++m) {
         const int co = (mt0 + m) * 16 + j * 4;
-        bool ok;
-        int gp;
-        if constexpr (TAPS == 1) {
-          ok = (mt0 + m) < P.NMTT && co < A.Cout && ox0 + pix < A.Wout;
-          gp = ok ? b * A.Wout + ox0 + pix : 0;
-        } else {
-          const int r = (int)__umulhi((uint32_t)pix, P.mTW), c = pix - r * P.TW;
-          const int oy = oy0 + r, ox = ox0 + c;
-          ok = (mt0 + m) < P.NMTT && co < A.Cout && oy < A.Hout && ox < A.Wout;
-          gp = ok ? (b * A.Hout + oy) * A.Wout + ox : 0;
-        }
-        const int cos = ok ? co : 0;
-        f32x4 v = ld4(A.dy + (uint32_t)(gp * A.dy_cstride + cos));
+        cosv[m] = ((mt0 + m) < P.NMTT && co < A.Cout) ? co : -1;
+        v[m] = ld4(A.dy + (uint32_t)(gp * A.dy_cstride + (cosv[m] >= 0 ? cosv[m] : 0)));
+      }
+#pragma unroll
+      for (int m = 0; m < NMT; ++m) {
+        const int cos = cosv[m] >= 0 ? cosv[m] : 0;
+        f32x4 w = v[m];
         if (A.dy_flags & LMN_SRC_DROP) {
 #pragma unroll
-          for (int k = 0; k < 4; ++k) v[k] *= lmn_drop_scale(A.dy_seed, (uint32_t)(gp * A.Cout + cos + k), A.dy_p, P.inv_keep_dy);
+          for (int k = 0; k < 4; ++k) w[k] *= lmn_drop_scale(A.dy_seed, (uint32_t)(gp * A.Cout + cos + k), A.dy_p, P.inv_keep_dy);
         }
-        if (!ok) v = f32x4{0.f, 0.f, 0.f, 0.f};
-        *reinterpret_cast<f32x4*>(&YS[(m * NP + pix) * P.CSy + j * 4]) = v;
+        if (!(inb && cosv[m] >= 0)) w = f32x4{0.f, 0.f, 0.f, 0.f};
+        *reinterpret_cast<f32x4*>(&YS[(m * NP + pix) * P.CSy + j * 4]) = w;
       }
     }
     __syncthreads();
@@ -1559,7 +1574,7 @@ static void wgrad_tile_shape(const lmn_wgrad_args_t& a, int nmtt, int nntt, int*
   const bool direct = a.ksize == 1 && a.stride == 1 && (int64_t)a.Hout * a.Wout >= 32;
   if (direct && nntt == 1) { *NMT = nmtt < 4 ? nmtt : 4; *NNT = 1; }
   else if (direct && nmtt == 1) { *NMT = 1; *NNT = nntt < 4 ? nntt : 4; }
-  else { *NMT = nmtt == 1 ? 1 : 2; *NNT = nntt == 1 ? 1 : 2; }
+  else { const bool small = nmtt == 1 || nntt == 1; *NMT = small ? 1 : 2; *NNT = small ? 1 : 2; }  // (1,2)/(2,1) measured slower here
 }
 
 int64_t lmn_conv_wgrad_workspace(const lmn_wgrad_args_t* a) {
