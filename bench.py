@@ -108,7 +108,8 @@ def main():
     net = LM_Net(3, 2).to(dev)
     model = DistributedLMNet(net) if world > 1 else net
     model.train()
-    opt = torch.optim.AdamW(net.parameters(), lr=1e-3, weight_decay=1e-4)
+    from lm_net_amd.optim import FusedAdamW
+    opt = FusedAdamW(net, lr=1e-3, weight_decay=1e-4)     # torch.optim.AdamW semantics, one launch per step
     B, H, W = args.batch, args.size, args.size
     x, y = make_batch(B, H, W, dev, 1234 + rank)          # rank-offset data seed (train.py:42)
     cw = torch.tensor([1.0, 4.0], device=dev)

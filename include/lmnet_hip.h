@@ -294,6 +294,11 @@ int lmn_nhwc_to_nchw(const float* x, float* y, int B, int C, int H, int W, int x
 /* ------------------------------------------------------------------------------------------
  * Small utilities
  * ------------------------------------------------------------------------------------------ */
+/* One AdamW step over flat buffers of n floats (n % 4 == 0): replaces torch.optim.AdamW.step() of
+ * train.py:156 when parameters and gradients live in the flat layout of lm_net_amd.LM_Net.
+ * bias_corr1 = 1 - beta1^t, bias_corr2 = 1 - beta2^t (t = step count, from the host). */
+int lmn_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+                   float eps, float weight_decay, float bias_corr1, float bias_corr2, lmn_stream_t stream);
 int lmn_fill(float* p, float v, int64_t n, lmn_stream_t stream);
 /* y = a + b (+ c) (+ d); any of c,d may be NULL; y may alias a */
 int lmn_add(const float* a, const float* b, const float* c, const float* d, float* y, int64_t n,

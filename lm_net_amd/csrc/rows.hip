@@ -493,6 +493,28 @@ inline int ln_group(int C4) {
   return g;
 }
 
+// AdamW over the flat parameter / gradient buffers (torch.optim.AdamW, amsgrad=False, maximize=False):
+//   p *= 1 - lr*wd;  m = b1 m + (1-b1) g;  v = b2 v + (1-b2) g^2;  p -= (lr/bc1) * m / (sqrt(v)/sqrt(bc2) + eps)
+__global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                             float* __restrict__ v, int64_t n4, float lr, float b1, float b2, float eps, float wd,
+                             float inv_bc1, float inv_sqrt_bc2) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+    f32x4 pp = reinterpret_cast<f32x4*>(p)[i], mm = reinterpret_cast<f32x4*>(m)[i], vv = reinterpret_cast<f32x4*>(v)[i];
+    const f32x4 gg = reinterpret_cast<const f32x4*>(g)[i];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      float x = pp[k] * (1.f - lr * wd);
+      mm[k] = b1 * mm[k] + (1.f - b1) * gg[k];
+      vv[k] = b2 * vv[k] + (1.f - b2) * gg[k] * gg[k];
+      const float denom = sqrtf(vv[k]) * inv_sqrt_bc2 + eps;
+      pp[k] = x - (lr * inv_bc1) * (mm[k] / denom);
+    }
+    reinterpret_cast<f32x4*>(p)[i] = pp;
+    reinterpret_cast<f32x4*>(m)[i] = mm;
+    reinterpret_cast<f32x4*>(v)[i] = vv;
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -654,6 +676,15 @@ int lmn_nhwc_to_nchw(const float* x, float* y, int B, int C, int H, int W, int x
   hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3(grid_for((int64_t)B * H * W)), dim3(256), 0, (hipStream_t)stream, x, y, B,
                      C, (int64_t)H * W, x_cstride);
   return lmn_launch_status("nhwc_to_nchw");
+}
+
+int lmn_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+                   float eps, float weight_decay, float bias_corr1, float bias_corr2, lmn_stream_t stream) {
+  LMN_REQUIRE(p && g && m && v && n > 0 && n % 4 == 0, "adamw_step: bad argument (n must be a multiple of 4)");
+  LMN_REQUIRE(bias_corr1 > 0.f && bias_corr2 > 0.f, "adamw_step: bias corrections must be positive");
+  hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n / 4)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n / 4, lr, beta1,
+                     beta2, eps, weight_decay, 1.f / bias_corr1, 1.f / sqrtf(bias_corr2));
+  return lmn_launch_status("adamw_step");
 }
 
 int lmn_fill(float* p, float v, int64_t n, lmn_stream_t stream) {

@@ -52,7 +52,7 @@ SYMBOLS = [
     "lmn_se_fwd", "lmn_se_bwd", "lmn_na_fwd", "lmn_na_bwd", "lmn_gattn_fwd", "lmn_gattn_bwd",
     "lmn_ln_fwd", "lmn_ln_bwd", "lmn_bnact_fwd", "lmn_bnact_bwd_stats", "lmn_bnact_bwd",
     "lmn_bn_finalize", "lmn_bn_fold", "lmn_bn_bwd_coef", "lmn_up2_fwd", "lmn_up2_bwd", "lmn_avgpool_fwd", "lmn_avgpool_bwd",
-    "lmn_nchw_to_nhwc", "lmn_nhwc_to_nchw", "lmn_fill", "lmn_add", "lmn_colsum", "lmn_copy_slice",
+    "lmn_nchw_to_nhwc", "lmn_nhwc_to_nchw", "lmn_adamw_step", "lmn_fill", "lmn_add", "lmn_colsum", "lmn_copy_slice",
 ]
 
 _lib = None
@@ -486,6 +486,11 @@ def nchw_to_nhwc(x, y):
 def nhwc_to_nchw(x, y):
     B, Cn, H, W = y.shape
     _check(load().lmn_nhwc_to_nchw(_p(x), _p(y), B, Cn, H, W, x.shape[-1], _stream()), "nhwc_to_nchw")
+
+
+def adamw_step(p, g, m, v, lr, beta1, beta2, eps, weight_decay, bias_corr1, bias_corr2):
+    _check(load().lmn_adamw_step(_p(p), _p(g), _p(m), _p(v), _i64(p.numel()), _f(lr), _f(beta1), _f(beta2), _f(eps),
+                                 _f(weight_decay), _f(bias_corr1), _f(bias_corr2), _stream()), "adamw_step")
 
 
 def fill(t, v):

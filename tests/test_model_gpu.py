@@ -187,3 +187,44 @@ def test_non_square_and_odd_tile_sizes_vs_oracle():
     for (k, po), (_, pg) in zip(ora.named_parameters(), m.named_parameters()):
         err = float((pg.grad.cpu() - po.grad).abs().max())
         assert err < 2e-3 * float(po.grad.abs().max()) or err < 5e-5 * gmax, (k, err)
+
+
+def test_fused_adamw_matches_torch_adamw_and_exchanges_state():
+    """lm_net_amd.optim.FusedAdamW (one kernel over the flat buffers) against torch.optim.AdamW -- the reference's
+    optimizer (train.py:156) -- on the same model, data and loss: parameters after 3 steps, then a state_dict
+    hand-over from the torch optimizer and one more step."""
+    from lm_net_amd.optim import FusedAdamW
+    a, b = _net(seed=3), _net(seed=3)       # dropout off (helpers.no_dropout): both models see identical graphs
+    a.train(); b.train()
+    oa = torch.optim.AdamW(a.parameters(), lr=1e-3, weight_decay=1e-4)
+    ob = FusedAdamW(b, lr=1e-3, weight_decay=1e-4)
+    x = det_input((2, 3, 64, 64), "adamw/x").cuda()
+    G = det_input((2, 2, 64, 64), "adamw/G").cuda()
+
+    def run(m, o, n, ref=None, oref=None):
+        """n training steps of model m; the torch optimizer `oref` of model `ref` is fed the SAME gradient values
+        (Adam's m/sqrt(v) turns the last-bit noise of two separate backward passes into O(lr) differences)."""
+        for _ in range(n):
+            o.zero_grad(set_to_none=True)
+            (m(x) * G).sum().backward()
+            if ref is not None:
+                for pr, pm in zip(ref.parameters(), m.parameters()):
+                    pr.grad = pm.grad.detach().clone()
+                oref.step()
+            o.step()
+
+    run(b, ob, 3, a, oa)
+    for (n1, p1), (_, p2) in zip(a.named_parameters(), b.named_parameters()):
+        assert rel_err(p2, p1) < 2e-6, n1
+    # hand the torch optimizer's state to a fresh fused optimizer on a copy of model a, continue both
+    c = _net(seed=3)
+    c.load_state_dict(a.state_dict())
+    c.train()
+    oc = FusedAdamW(c, lr=1e-3, weight_decay=1e-4)
+    oc.load_state_dict(oa.state_dict())
+    assert oc.step_count == 3
+    run(c, oc, 1, a, oa)
+    for (n1, p1), (_, p2) in zip(a.named_parameters(), c.named_parameters()):
+        assert rel_err(p2, p1) < 2e-6, n1
+    sd = oc.state_dict()
+    assert set(sd["state"][0]) == {"step", "exp_avg", "exp_avg_sq"} and float(sd["state"][0]["step"]) == 4.0
