@@ -831,6 +831,141 @@ __global__ __launch_bounds__(256) void dw_bwd_strip_kernel(
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Forward in the same strip-walking form (flagship HBM-bound kernel of row A2): wave = channel pair, lanes = 64
+// adjacent output columns, the merged 5x5 kernel of the pair in SGPRs.  Per row step: 5 ds_read_b64 + 25 packed
+// FMAs into 5 rotating row accumulators; the finished row gets bias + GELU-sum and leaves through LDS as coalesced
+// 16 B stores.  No halo recompute along x (68 staged columns for 64 outputs), 4 halo rows per row segment.
+constexpr int FS_XR = 2 * SW_R;  // x1 ring: the batch being consumed + the batch being committed
+
+template <int P>
+__device__ __forceinline__ void fs_step(f32x2 (&acc)[5], f32x2& gs, const f32x2 (&w)[25], f32x2 bias, const float* XS,
+                                        float* OUT, int j, int lane, int wv, bool row_out, bool cvalid) {
+  const float* xr = XS + ((j % FS_XR) * SW_XC + lane) * SW_CS + wv * 2;
+  f32x2 in[5];
+#pragma unroll
+  for (int d = 0; d < 5; ++d) in[d] = *reinterpret_cast<const f32x2*>(xr + d * SW_CS);
+#pragma unroll
+  for (int ky = 0; ky < 5; ++ky)
+#pragma unroll
+    for (int d = 0; d < 5; ++d) acc[(P - ky + 5) % 5] += w[ky * 5 + d] * in[d];
+  constexpr int D = (P + 1) % 5;  // output row j-4 is complete
+  if (row_out) {
+    const f32x2 pv = acc[D] + bias;
+    *reinterpret_cast<f32x2*>(OUT + (P * SW_FC + lane) * SW_CS + wv * 2) = pv;
+    const float m = cvalid ? 1.f : 0.f;
+    gs += f32x2{lmn_gelu(pv[0]), lmn_gelu(pv[1])} * m;
+  }
+  acc[D] = f32x2{0.f, 0.f};
+}
+
+__global__ __launch_bounds__(256) void dw_fwd_strip_kernel(const float* __restrict__ x1, float* __restrict__ pre,
+                                                            float* __restrict__ gsum, int H, int W, int E,
+                                                            const float* __restrict__ keff,
+                                                            const float* __restrict__ beff, int strips, int segs,
+                                                            int seg_rows, int chunks) {
+  __shared__ __attribute__((aligned(16))) float XS[FS_XR * SW_XC * SW_CS];
+  __shared__ __attribute__((aligned(16))) float OUT[SW_R * SW_FC * SW_CS];
+  __shared__ float gs_s[SW_CH];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int lid = xcd_swizzle(blockIdx.x, gridDim.x);  // channel chunk fastest: siblings share cache lines and an L2
+  const int chunk = lid % chunks; lid /= chunks;
+  const int strip = lid % strips; lid /= strips;
+  const int seg = lid % segs;
+  const int b = lid / segs;
+  const int ch0 = chunk * SW_CH, ch = ch0 + wv * 2;
+  const bool cok = ch < E;
+  const int chs = cok ? ch : 0;
+  f32x2 w[25];
+#pragma unroll
+  for (int t = 0; t < 25; ++t) w[t] = f32x2{keff[(int64_t)chs * 25 + t], keff[(int64_t)(chs + 1) * 25 + t]};
+  const f32x2 bias = f32x2{beff[chs], beff[chs + 1]};
+  const int ys = seg * seg_rows, ye = min(ys + seg_rows, H);
+  const int xs = strip * SW_FC;
+  const bool cvalid = cok && xs + lane < W;
+  const float* xb = x1 + (int64_t)b * H * W * E;
+  float* ob = pre + (int64_t)b * H * W * E;
+  const int nsteps = (ye - ys) + 4;  // x1 row (ys-2+j) enters at step j; output row (ys+j-4) completes
+
+  constexpr int NX = (SW_R * SW_XC * 2 + 255) / 256;
+  f32x4 px[NX];
+  auto fetch = [&](int j0) {
+#pragma unroll
+    for (int k = 0; k < NX; ++k) {
+      const int i = tid + k * 256;
+      const int k4 = i & 1, pc = i >> 1;
+      const int rr = pc / SW_XC, c = pc - rr * SW_XC;
+      const int gy = ys - 2 + j0 + rr, gx = xs - 2 + c;
+      const bool in = i < SW_R * SW_XC * 2 && gx >= 0 && gx < W && ch0 + k4 * 4 < E && gy >= 0 && gy < H;
+      px[k] = *reinterpret_cast<const f32x4*>(xb + (in ? ((int64_t)gy * W + gx) * E + ch0 + k4 * 4 : 0));
+      if (!in) px[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  };
+  auto commit = [&](int j0) {
+#pragma unroll
+    for (int k = 0; k < NX; ++k) {
+      const int i = tid + k * 256;
+      if (i < SW_R * SW_XC * 2) {
+        const int k4 = i & 1, pc = i >> 1;
+        const int rr = pc / SW_XC, c = pc - rr * SW_XC;
+        float* d = &XS[(((j0 + rr) % FS_XR) * SW_XC + c) * SW_CS + k4 * 4];
+        *reinterpret_cast<f32x2*>(d) = f32x2{px[k][0], px[k][1]};
+        *reinterpret_cast<f32x2*>(d + 2) = f32x2{px[k][2], px[k][3]};
+      }
+    }
+  };
+  auto drain = [&](int j0) {  // output rows finished by steps j0 .. j0+4 (image rows ys+j-4)
+    for (int i = tid; i < SW_R * SW_FC * 2; i += 256) {
+      const int k4 = i & 1, pc = i >> 1;
+      const int rr = pc / SW_FC, c = pc - rr * SW_FC;
+      const int jj = j0 + rr;
+      const int gy = ys + jj - 4, gx = xs + c;
+      if (jj >= 4 && jj < nsteps && gx < W && ch0 + k4 * 4 < E) {
+        const float* o = &OUT[(rr * SW_FC + c) * SW_CS + k4 * 4];
+        const f32x2 lo = *reinterpret_cast<const f32x2*>(o), hi = *reinterpret_cast<const f32x2*>(o + 2);
+        *reinterpret_cast<f32x4*>(ob + ((int64_t)gy * W + gx) * E + ch0 + k4 * 4) = f32x4{lo[0], lo[1], hi[0], hi[1]};
+      }
+    }
+  };
+
+  f32x2 acc[5];
+#pragma unroll
+  for (int k = 0; k < 5; ++k) acc[k] = f32x2{0.f, 0.f};
+  f32x2 gs = f32x2{0.f, 0.f};
+  if (tid < SW_CH) gs_s[tid] = 0.f;
+  fetch(0);
+  commit(0);
+  __syncthreads();
+  for (int j0 = 0; j0 < nsteps; j0 += SW_R) {
+    if (j0 + SW_R < nsteps) fetch(j0 + SW_R);  // next batch in flight during the five steps
+#define LMN_FS_STEP(PH)                                                                         \
+    {                                                                                           \
+      const int j = j0 + PH;                                                                    \
+      if (j < nsteps) fs_step<PH>(acc, gs, w, bias, XS, OUT, j, lane, wv, j >= 4, cvalid);      \
+    }
+    LMN_FS_STEP(0) LMN_FS_STEP(1) LMN_FS_STEP(2) LMN_FS_STEP(3) LMN_FS_STEP(4)
+#undef LMN_FS_STEP
+    __syncthreads();  // OUT complete; the other half of the ring is free
+    drain(j0);
+    if (j0 + SW_R < nsteps) commit(j0 + SW_R);
+    __syncthreads();
+  }
+  // SE squeeze: wave total by DPP (lands in lane 63), one global atomic per channel per block
+  {
+    float a = gs.x, c = gs.y;
+#define LMN_DPP_ADD(CTRL)                                                                               \
+    a += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(a), CTRL, 0xF, 0xF, true));       \
+    c += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(c), CTRL, 0xF, 0xF, true));
+    LMN_DPP_ADD(0x111) LMN_DPP_ADD(0x112) LMN_DPP_ADD(0x114) LMN_DPP_ADD(0x118) LMN_DPP_ADD(0x142) LMN_DPP_ADD(0x143)
+#undef LMN_DPP_ADD
+    if (lane == 63 && cok) {
+      atomicAdd(gsum + (int64_t)b * E + ch, a);
+      atomicAdd(gsum + (int64_t)b * E + ch + 1, c);
+    }
+  }
+}
+
 // per-branch BN-backward coefficients from bst[5][E] = (S0 = sum dpre, S1_b = sum dpre*y_b)
 __global__ void dw_bwd_coef_kernel(const float* __restrict__ bst, const float* __restrict__ mean,
                                    const float* __restrict__ rstd, const float* __restrict__ A, float count,
@@ -885,20 +1020,16 @@ int lmn_dw_fwd(const float* x1, float* pre, float* gsum, int B, int H, int W, in
                const float* beff, lmn_stream_t stream) {
   LMN_REQUIRE(x1 && pre && gsum && keff && beff, "dw_fwd: null pointer");
   LMN_REQUIRE(B > 0 && H > 0 && W > 0 && E > 0 && E % 4 == 0, "dw_fwd: E=%d must be a multiple of 4", E);
-  const int tx = lmn_cdiv(W, FW_TW), ty = lmn_cdiv(H, FW_TH);
-  const int cch = (E % 32 == 0) ? 32 : 24;  // (48-channel chunks measured slower at E = 48: 384 threads, 77 KB LDS)
-  const int chunks = lmn_cdiv(E, cch);
-  const int grid = tx * ty * chunks * B;
-  const size_t sh = (size_t)(FW_RH * FW_RW * cch + cch) * sizeof(float);
-  hipStream_t st = (hipStream_t)stream;
-  if (cch == 24) {
-    hipLaunchKernelGGL((dw_fwd_kernel<24>), dim3(grid), dim3(FW_TW * 12), sh, st, x1, pre, gsum, H, W, E, keff, beff, tx, tx * ty, chunks);
-  } else if (cch == 32) {
-    hipLaunchKernelGGL((dw_fwd_kernel<32>), dim3(grid), dim3(FW_TW * 16), sh, st, x1, pre, gsum, H, W, E, keff, beff, tx, tx * ty, chunks);
-  } else {
-    (void)hipFuncSetAttribute((const void*)dw_fwd_kernel<48>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
-    hipLaunchKernelGGL((dw_fwd_kernel<48>), dim3(grid), dim3(FW_TW * 24), sh, st, x1, pre, gsum, H, W, E, keff, beff, tx, tx * ty, chunks);
-  }
+  // strip-walking kernel: blocks = B x strips(64 columns) x row segments x 8-channel chunks
+  const int strips = lmn_cdiv(W, SW_FC), chunks = lmn_cdiv(E, SW_CH);
+  int segs = 1;
+  while ((int64_t)B * strips * chunks * segs < 1536 && lmn_cdiv(H, segs * 2) >= 16) segs *= 2;
+  const int seg_rows = lmn_cdiv(H, segs);
+  segs = lmn_cdiv(H, seg_rows);
+  const int64_t nblk = (int64_t)B * strips * chunks * segs;
+  LMN_REQUIRE(nblk < (1LL << 31), "dw_fwd: grid too large");
+  hipLaunchKernelGGL(dw_fwd_strip_kernel, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, x1, pre, gsum, H, W, E, keff,
+                     beff, strips, segs, seg_rows, chunks);
   return lmn_launch_status("dw_fwd");
 }
 
