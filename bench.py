@@ -112,11 +112,12 @@ def main():
     opt = FusedAdamW(net, lr=1e-3, weight_decay=1e-4)     # torch.optim.AdamW semantics, one launch per step
     B, H, W = args.batch, args.size, args.size
     x, y = make_batch(B, H, W, dev, 1234 + rank)          # rank-offset data seed (train.py:42)
-    cw = torch.tensor([1.0, 4.0], device=dev)
+    from lm_net_amd.loss import SegLoss
+    crit = SegLoss(ce_weight=(1.0, 4.0), dice_weight=(1.0, 4.0), label_smoothing=0.001).to(dev)   # fused CE + Dice
 
     def step():
         out = model(x)
-        loss = F.cross_entropy(out, y, weight=cw, label_smoothing=0.001) + dice_loss(out, y)
+        loss = crit(out, y)
         opt.zero_grad(set_to_none=True)
         loss.backward()
         opt.step()

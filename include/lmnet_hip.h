@@ -294,6 +294,21 @@ int lmn_nhwc_to_nchw(const float* x, float* y, int B, int C, int H, int W, int x
 /* ------------------------------------------------------------------------------------------
  * Small utilities
  * ------------------------------------------------------------------------------------------ */
+/* Segmentation loss around the path on NCHW logits [B][C][HW], int64 labels [B][HW]:
+ *   loss = CrossEntropyLoss(weight=w_ce, label_smoothing)(logits, target)            (train.py:157)
+ *        + DiceLoss(C)(logits, target, weight=w_dice)  -- softmax, one-hot, per class
+ *          1 - (2*sum(p*t) + smooth)/(sum(p^2) + sum(t^2) + smooth), weighted, / C   (utils/loss.py:170-206),
+ * as called in utils/train_eval_utils.py:141.  `sums` [3+3C] and `coef` [3+2C] are device workspaces the
+ * backward re-uses; `loss` [1] stays on the device (no host sync).  C in {2,3,4,8}.
+ * lmn_segloss_bwd writes dlogits = gscale[0] * dloss/dlogits (gscale NULL = 1).                                 */
+int lmn_segloss_fwd(const float* logits, const int64_t* target, const float* w_ce, const float* w_dice, int B, int C,
+                    int64_t HW, float label_smoothing, float smooth, float* sums, float* coef, float* loss,
+                    lmn_stream_t stream);
+int lmn_segloss_bwd(const float* logits, const int64_t* target, const float* w_ce, const float* coef, const float* gscale,
+                    int B, int C, int64_t HW, float* dlogits, lmn_stream_t stream);
+/* On-device confusion matrix (row N2): counts[t*C + p] += #pixels with label t and argmax(logits) = p.  Dice and IoU
+ * follow as 2TP/(2TP+FP+FN), TP/(TP+FP+FN) (utils/train_eval_utils.py:78-95).  C in {2,3,4}.                   */
+int lmn_confusion(const float* logits, const int64_t* target, int B, int C, int64_t HW, float* counts, lmn_stream_t stream);
 /* One AdamW step over flat buffers of n floats (n % 4 == 0): replaces torch.optim.AdamW.step() of
  * train.py:156 when parameters and gradients live in the flat layout of lm_net_amd.LM_Net.
  * bias_corr1 = 1 - beta1^t, bias_corr2 = 1 - beta2^t (t = step count, from the host). */

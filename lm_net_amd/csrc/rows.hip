@@ -515,6 +515,168 @@ __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Segmentation loss around the path: CrossEntropyLoss(weight, label_smoothing) (train.py:157) +
+// DiceLoss (utils/loss.py:170-206) on NCHW logits [B,C,HW], C in {2,3,4,8}.  Pass 1 reduces the 3 + 3C batch
+// sums, a one-block kernel turns them into the scalar loss and the backward coefficients, pass 2 writes dlogits.
+//   sums: [0] sum w_y   [1] sum w_y*(-log p_y)   [2] sum_i sum_c w_c*(-log p_c)
+//         [3+c] sum p_c*t_c   [3+C+c] sum p_c^2   [3+2C+c] sum t_c
+
+
+template <int C>
+__device__ __forceinline__ void loss_softmax(const float* __restrict__ lg, int64_t hw, int64_t i, float (&p)[C], float& lse) {
+  float z[C], mx = -3.0e38f;
+#pragma unroll
+  for (int c = 0; c < C; ++c) { z[c] = lg[c * hw + i]; mx = fmaxf(mx, z[c]); }
+  float den = 0.f;
+#pragma unroll
+  for (int c = 0; c < C; ++c) { p[c] = __expf(z[c] - mx); den += p[c]; }
+  const float r = 1.f / den;
+  lse = mx + __logf(den);
+#pragma unroll
+  for (int c = 0; c < C; ++c) { p[c] *= r; z[c] = z[c]; }
+}
+
+template <int C>
+__global__ __launch_bounds__(256) void segloss_sums_kernel(const float* __restrict__ logits, const int64_t* __restrict__ target,
+                                                           const float* __restrict__ wce, int B, int64_t hw,
+                                                           float* __restrict__ sums) {
+  constexpr int NS = 3 + 3 * C;
+  float acc[NS];
+#pragma unroll
+  for (int k = 0; k < NS; ++k) acc[k] = 0.f;
+  float w[C];
+#pragma unroll
+  for (int c = 0; c < C; ++c) w[c] = wce[c];
+  const int64_t total = (int64_t)B * hw;
+  for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t b = idx / hw, i = idx - b * hw;
+    const float* lg = logits + b * C * hw;
+    float p[C], lse;
+    loss_softmax<C>(lg, hw, i, p, lse);
+    const int y = (int)target[idx];
+    float sm = 0.f;
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      const float nlp = lse - lg[c * hw + i];  // -log p_c
+      const float t = (c == y) ? 1.f : 0.f;
+      sm += w[c] * nlp;
+      acc[0] += t * w[c];
+      acc[1] += t * w[c] * nlp;
+      acc[3 + c] += p[c] * t;
+      acc[3 + C + c] += p[c] * p[c];
+      acc[3 + 2 * C + c] += t;
+    }
+    acc[2] += sm;
+  }
+  __shared__ float red[4][NS];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < NS; ++k) {
+    float v = acc[k];
+#pragma unroll
+    for (int m = 1; m <= 32; m <<= 1) v += __shfl_xor(v, m, 64);
+    if (lane == 0) red[wv][k] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < NS) atomicAdd(sums + threadIdx.x, red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
+// coef: [0] (1-eps)/S_w  [1] (eps/C)/S_w  [2] sum_c w_c   [3+c] a_c  [3+C+c] b_c   with dL_dice/dp_c = a_c*t_c + b_c*p_c
+__global__ void segloss_finish_kernel(const float* __restrict__ sums, const float* __restrict__ wce,
+                                      const float* __restrict__ wdice, int C, float eps_ls, float smooth,
+                                      float* __restrict__ loss, float* __restrict__ coef) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const float Sw = sums[0];
+  float l = ((1.f - eps_ls) * sums[1] + (eps_ls / C) * sums[2]) / Sw;
+  float wsum = 0.f;
+  for (int c = 0; c < C; ++c) {
+    const float I = sums[3 + c], Z = sums[3 + C + c], Y = sums[3 + 2 * C + c];
+    const float num = 2.f * I + smooth, den = Z + Y + smooth;
+    l += wdice[c] * (1.f - num / den) / C;
+    coef[3 + c] = wdice[c] / C * (-2.f / den);
+    coef[3 + C + c] = wdice[c] / C * (2.f * num / (den * den));
+    wsum += wce[c];
+  }
+  coef[0] = (1.f - eps_ls) / Sw;
+  coef[1] = (eps_ls / C) / Sw;
+  coef[2] = wsum;
+  loss[0] = l;
+}
+
+template <int C>
+__global__ __launch_bounds__(256) void segloss_bwd_kernel(const float* __restrict__ logits, const int64_t* __restrict__ target,
+                                                          const float* __restrict__ wce, const float* __restrict__ coef,
+                                                          const float* __restrict__ gscale, int B, int64_t hw,
+                                                          float* __restrict__ dlogits) {
+  float w[C], a[C], bq[C];
+#pragma unroll
+  for (int c = 0; c < C; ++c) { w[c] = wce[c]; a[c] = coef[3 + c]; bq[c] = coef[3 + C + c]; }
+  const float k_nll = coef[0], k_sm = coef[1], wsum = coef[2];
+  const float gs = gscale ? gscale[0] : 1.f;
+  const int64_t total = (int64_t)B * hw;
+  for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t b = idx / hw, i = idx - b * hw;
+    const float* lg = logits + b * C * hw;
+    float p[C], lse;
+    loss_softmax<C>(lg, hw, i, p, lse);
+    const int y = (int)target[idx];
+    float wy = 0.f;
+#pragma unroll
+    for (int c = 0; c < C; ++c) wy = (c == y) ? w[c] : wy;
+    float g[C], gp = 0.f;  // dice: dL/dp_c, then through the softmax Jacobian
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      g[c] = a[c] * ((c == y) ? 1.f : 0.f) + bq[c] * p[c];
+      gp += g[c] * p[c];
+    }
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      const float t = (c == y) ? 1.f : 0.f;
+      const float dce = k_nll * wy * (p[c] - t) + k_sm * (p[c] * wsum - w[c]);
+      dlogits[b * C * hw + c * hw + i] = gs * (dce + p[c] * (g[c] - gp));
+    }
+  }
+}
+
+// Confusion matrix of argmax(logits) against the labels: counts[t*C + p] += 1 (float counts are
+// exact up to 2^24 per launch per cell; the host accumulates in int64/double).
+template <int C>
+__global__ __launch_bounds__(256) void confusion_kernel(const float* __restrict__ logits, const int64_t* __restrict__ target,
+                                                        int B, int64_t hw, float* __restrict__ counts) {
+  __shared__ float sc[C * C];
+  for (int i = threadIdx.x; i < C * C; i += 256) sc[i] = 0.f;
+  __syncthreads();
+  int cnt[C * C];
+#pragma unroll
+  for (int k = 0; k < C * C; ++k) cnt[k] = 0;
+  const int64_t total = (int64_t)B * hw;
+  for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t b = idx / hw, i = idx - b * hw;
+    const float* lg = logits + b * C * hw;
+    int best = 0;
+    float bv = lg[i];
+#pragma unroll
+    for (int c = 1; c < C; ++c) {
+      const float v = lg[c * hw + i];
+      if (v > bv) { bv = v; best = c; }  // first maximum wins, as torch.argmax
+    }
+    const int y = (int)target[idx];
+#pragma unroll
+    for (int k = 0; k < C * C; ++k) cnt[k] += (k == y * C + best) ? 1 : 0;
+  }
+#pragma unroll
+  for (int k = 0; k < C * C; ++k) {
+    int v = cnt[k];
+#pragma unroll
+    for (int m = 1; m <= 32; m <<= 1) v += __shfl_xor(v, m, 64);
+    if ((threadIdx.x & 63) == 0 && v) atomicAdd(&sc[k], (float)v);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < C * C; i += 256)
+    if (sc[i] != 0.f) atomicAdd(counts + i, sc[i]);
+}
+
 }  // namespace
 
 extern "C" {
@@ -676,6 +838,53 @@ int lmn_nhwc_to_nchw(const float* x, float* y, int B, int C, int H, int W, int x
   hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3(grid_for((int64_t)B * H * W)), dim3(256), 0, (hipStream_t)stream, x, y, B,
                      C, (int64_t)H * W, x_cstride);
   return lmn_launch_status("nhwc_to_nchw");
+}
+
+int lmn_segloss_fwd(const float* logits, const int64_t* target, const float* w_ce, const float* w_dice, int B, int C,
+                    int64_t HW, float label_smoothing, float smooth, float* sums, float* coef, float* loss,
+                    lmn_stream_t stream) {
+  LMN_REQUIRE(logits && target && w_ce && w_dice && sums && coef && loss, "segloss_fwd: null pointer");
+  LMN_REQUIRE(B > 0 && HW > 0 && (C == 2 || C == 3 || C == 4 || C == 8), "segloss_fwd: C=%d not in {2,3,4,8}", C);
+  hipStream_t st = (hipStream_t)stream;
+  const int grid = grid_for((int64_t)B * HW) > 1024 ? 1024 : grid_for((int64_t)B * HW);
+  hipLaunchKernelGGL(fill_kernel, dim3(1), dim3(64), 0, st, sums, 0.f, (int64_t)(3 + 3 * C));
+  switch (C) {
+    case 2: hipLaunchKernelGGL((segloss_sums_kernel<2>), dim3(grid), dim3(256), 0, st, logits, target, w_ce, B, HW, sums); break;
+    case 3: hipLaunchKernelGGL((segloss_sums_kernel<3>), dim3(grid), dim3(256), 0, st, logits, target, w_ce, B, HW, sums); break;
+    case 4: hipLaunchKernelGGL((segloss_sums_kernel<4>), dim3(grid), dim3(256), 0, st, logits, target, w_ce, B, HW, sums); break;
+    default: hipLaunchKernelGGL((segloss_sums_kernel<8>), dim3(grid), dim3(256), 0, st, logits, target, w_ce, B, HW, sums); break;
+  }
+  hipLaunchKernelGGL(segloss_finish_kernel, dim3(1), dim3(64), 0, st, sums, w_ce, w_dice, C, label_smoothing, smooth, loss, coef);
+  return lmn_launch_status("segloss_fwd");
+}
+
+int lmn_segloss_bwd(const float* logits, const int64_t* target, const float* w_ce, const float* coef, const float* gscale,
+                    int B, int C, int64_t HW, float* dlogits, lmn_stream_t stream) {
+  LMN_REQUIRE(logits && target && w_ce && coef && dlogits, "segloss_bwd: null pointer");
+  LMN_REQUIRE(B > 0 && HW > 0 && (C == 2 || C == 3 || C == 4 || C == 8), "segloss_bwd: C=%d not in {2,3,4,8}", C);
+  hipStream_t st = (hipStream_t)stream;
+  const int grid = grid_for((int64_t)B * HW);
+  switch (C) {
+    case 2: hipLaunchKernelGGL((segloss_bwd_kernel<2>), dim3(grid), dim3(256), 0, st, logits, target, w_ce, coef, gscale, B, HW, dlogits); break;
+    case 3: hipLaunchKernelGGL((segloss_bwd_kernel<3>), dim3(grid), dim3(256), 0, st, logits, target, w_ce, coef, gscale, B, HW, dlogits); break;
+    case 4: hipLaunchKernelGGL((segloss_bwd_kernel<4>), dim3(grid), dim3(256), 0, st, logits, target, w_ce, coef, gscale, B, HW, dlogits); break;
+    default: hipLaunchKernelGGL((segloss_bwd_kernel<8>), dim3(grid), dim3(256), 0, st, logits, target, w_ce, coef, gscale, B, HW, dlogits); break;
+  }
+  return lmn_launch_status("segloss_bwd");
+}
+
+int lmn_confusion(const float* logits, const int64_t* target, int B, int C, int64_t HW, float* counts, lmn_stream_t stream) {
+  LMN_REQUIRE(logits && target && counts, "confusion: null pointer");
+  LMN_REQUIRE(B > 0 && HW > 0 && (C == 2 || C == 3 || C == 4), "confusion: C=%d not in {2,3,4}", C);
+  LMN_REQUIRE((int64_t)B * HW < (1LL << 24) * 64, "confusion: more than 2^30 pixels per call");
+  hipStream_t st = (hipStream_t)stream;
+  const int grid = grid_for((int64_t)B * HW) > 512 ? 512 : grid_for((int64_t)B * HW);
+  switch (C) {
+    case 2: hipLaunchKernelGGL((confusion_kernel<2>), dim3(grid), dim3(256), 0, st, logits, target, B, HW, counts); break;
+    case 3: hipLaunchKernelGGL((confusion_kernel<3>), dim3(grid), dim3(256), 0, st, logits, target, B, HW, counts); break;
+    default: hipLaunchKernelGGL((confusion_kernel<4>), dim3(grid), dim3(256), 0, st, logits, target, B, HW, counts); break;
+  }
+  return lmn_launch_status("confusion");
 }
 
 int lmn_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,

@@ -52,7 +52,7 @@ SYMBOLS = [
     "lmn_se_fwd", "lmn_se_bwd", "lmn_na_fwd", "lmn_na_bwd", "lmn_gattn_fwd", "lmn_gattn_bwd",
     "lmn_ln_fwd", "lmn_ln_bwd", "lmn_bnact_fwd", "lmn_bnact_bwd_stats", "lmn_bnact_bwd",
     "lmn_bn_finalize", "lmn_bn_fold", "lmn_bn_bwd_coef", "lmn_up2_fwd", "lmn_up2_bwd", "lmn_avgpool_fwd", "lmn_avgpool_bwd",
-    "lmn_nchw_to_nhwc", "lmn_nhwc_to_nchw", "lmn_adamw_step", "lmn_fill", "lmn_add", "lmn_colsum", "lmn_copy_slice",
+    "lmn_nchw_to_nhwc", "lmn_nhwc_to_nchw", "lmn_adamw_step", "lmn_segloss_fwd", "lmn_segloss_bwd", "lmn_confusion", "lmn_fill", "lmn_add", "lmn_colsum", "lmn_copy_slice",
 ]
 
 _lib = None
@@ -486,6 +486,34 @@ def nchw_to_nhwc(x, y):
 def nhwc_to_nchw(x, y):
     B, Cn, H, W = y.shape
     _check(load().lmn_nhwc_to_nchw(_p(x), _p(y), B, Cn, H, W, x.shape[-1], _stream()), "nhwc_to_nchw")
+
+
+def _pl(t):
+    if t is None:
+        return None
+    if not t.is_cuda or t.dtype != torch.int64 or not t.is_contiguous():
+        raise RuntimeError("lm_net_amd: contiguous int64 device tensor required for labels")
+    return C.c_void_p(t.data_ptr())
+
+
+def segloss_fwd(logits, target, w_ce, w_dice, label_smoothing, smooth, sums, coef, loss):
+    B, Cn = logits.shape[0], logits.shape[1]
+    hw = logits.numel() // (B * Cn)
+    _check(load().lmn_segloss_fwd(_p(logits), _pl(target), _p(w_ce), _p(w_dice), B, Cn, _i64(hw), _f(label_smoothing),
+                                  _f(smooth), _p(sums), _p(coef), _p(loss), _stream()), "segloss_fwd")
+
+
+def segloss_bwd(logits, target, w_ce, coef, gscale, dlogits):
+    B, Cn = logits.shape[0], logits.shape[1]
+    hw = logits.numel() // (B * Cn)
+    _check(load().lmn_segloss_bwd(_p(logits), _pl(target), _p(w_ce), _p(coef), _p(gscale), B, Cn, _i64(hw), _p(dlogits),
+                                  _stream()), "segloss_bwd")
+
+
+def confusion(logits, target, counts):
+    B, Cn = logits.shape[0], logits.shape[1]
+    hw = logits.numel() // (B * Cn)
+    _check(load().lmn_confusion(_p(logits), _pl(target), B, Cn, _i64(hw), _p(counts), _stream()), "confusion")
 
 
 def adamw_step(p, g, m, v, lr, beta1, beta2, eps, weight_decay, bias_corr1, bias_corr2):

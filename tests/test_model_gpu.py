@@ -228,3 +228,46 @@ def test_fused_adamw_matches_torch_adamw_and_exchanges_state():
         assert rel_err(p2, p1) < 2e-6, n1
     sd = oc.state_dict()
     assert set(sd["state"][0]) == {"step", "exp_avg", "exp_avg_sq"} and float(sd["state"][0]["step"]) == 4.0
+
+
+def _ref_loss(logits, target, eps=1e-3):
+    """torch restatement of utils/train_eval_utils.py:141 (CE weight [1,4] + label smoothing, DiceLoss weight [1,4])."""
+    import torch.nn.functional as F
+    ce = F.cross_entropy(logits, target, weight=torch.tensor([1.0, 4.0], device=logits.device, dtype=logits.dtype),
+                         label_smoothing=eps)
+    p = torch.softmax(logits, dim=1)
+    dl = 0.0
+    for i, w in enumerate((1.0, 4.0)):
+        t = (target == i).to(logits.dtype)
+        dl = dl + (1 - (2 * (p[:, i] * t).sum() + 1e-5) / ((p[:, i] ** 2).sum() + (t * t).sum() + 1e-5)) * w
+    return ce + dl / 2
+
+
+def test_fused_seg_loss_matches_torch_ce_plus_dice():
+    from lm_net_amd.loss import SegLoss
+    lg = (det_input((3, 2, 40, 56), "loss/lg") * 3).cuda()
+    y = disc_labels(3, 40, 56).cuda()
+    l64 = lg.double().requires_grad_(True)
+    ref = _ref_loss(l64, y)
+    ref.backward()
+    l32 = lg.clone().requires_grad_(True)
+    out = SegLoss(label_smoothing=1e-3).cuda()(l32, y)
+    (out * 1.5).backward()
+    assert abs(float(out) - float(ref)) < 2e-6 * max(1.0, abs(float(ref)))
+    assert rel_err(l32.grad, 1.5 * l64.grad) < 1e-5
+    # the reference's call shape: labels.unsqueeze(1).float() for the Dice term
+    out2 = SegLoss(label_smoothing=1e-3).cuda()(lg, y.unsqueeze(1).float())
+    assert abs(float(out2) - float(ref)) < 2e-6 * max(1.0, abs(float(ref)))
+
+
+def test_on_device_confusion_dice_iou():
+    from lm_net_amd.metrics import ConfusionMeter
+    lg = det_input((2, 2, 64, 48), "metric/lg").cuda()
+    y = disc_labels(2, 64, 48).cuda()
+    m = ConfusionMeter(2)
+    m.update(lg[:1], y[:1])
+    m.update(lg[1:], y[1:])
+    r = m.compute()
+    d, i = dice_iou(lg.argmax(1).cpu(), y.cpu())
+    assert abs(r["dice"][1] - d) < 1e-12 and abs(r["iou"][1] - i) < 1e-12
+    assert sum(map(sum, r["confusion"])) == 2 * 64 * 48
