@@ -87,6 +87,8 @@ class LM_Net(nn.Module):
             if hasattr(m, "switch_to_deploy"):
                 m.switch_to_deploy()
         self._grad_layout = None
+        self.__dict__["_param_cache"] = None
+        self.__dict__["_bn_cache"] = None
 
     def forward(self, x):
         if not x.is_cuda:
@@ -97,12 +99,20 @@ class LM_Net(nn.Module):
         if x.shape[2] % 16 or x.shape[3] % 16 or x.shape[2] < 32 or x.shape[3] < 32:
             raise ValueError("H and W must be multiples of 16 and >= 32 (got %dx%d)" % (x.shape[2], x.shape[3]))
         hip.load()
-        params = [p for p in self.parameters()]
+        params = self._param_list()
         if params and not params[0].is_cuda:
             raise RuntimeError("lm_net_amd.LM_Net: parameters are on %s; call model.to('cuda')" % params[0].device)
         x = x.float().contiguous() if x.dtype != torch.float32 or not x.is_contiguous() else x
         self._save_tape = torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in params))
         return _LMNetFunction.apply(x, self, *params)
+
+    def _param_list(self):
+        """model.parameters() as a cached list (walking 300 sub-modules costs ~1.5 ms per call); the Parameter
+        objects are stable -- only structural_reparam() changes the set, and it drops the cache."""
+        c = self.__dict__.get("_param_cache")
+        if c is None:
+            c = self.__dict__["_param_cache"] = list(self.parameters())
+        return c
 
     # ------------------------------------------------------------------ forward schedule (core/LM_Net.py:95-123)
     def _forward_impl(self, x, cx):
@@ -176,7 +186,10 @@ class LM_Net(nn.Module):
 
     def _bump_num_batches_tracked(self):
         """All 84 `num_batches_tracked` buffers are views of ONE int64 tensor: one increment per step."""
-        bns = [m for m in self.modules() if isinstance(m, nn.BatchNorm2d) and m.num_batches_tracked is not None]
+        bns = self.__dict__.get("_bn_cache")
+        if bns is None:
+            bns = self.__dict__["_bn_cache"] = [m for m in self.modules()
+                                                if isinstance(m, nn.BatchNorm2d) and m.num_batches_tracked is not None]
         if not bns:
             return
         flat = getattr(self, "_nbt_flat", None)
@@ -192,7 +205,7 @@ class LM_Net(nn.Module):
 
     # ------------------------------------------------------------------ flat gradient buffer
     def _ensure_grad_layout(self):
-        params = list(self.parameters())
+        params = self._param_list()
         key = tuple(id(p) for p in params)
         if self._grad_layout is not None and self._grad_layout["key"] == key and \
                 self._grad_layout["device"] == params[0].device:
@@ -249,7 +262,7 @@ class LM_Net(nn.Module):
             eng.G = None
         if self.grad_finish_hook is not None:
             self.grad_finish_hook()
-        return dx, [G[p] for p in self.parameters()]
+        return dx, [G[p] for p in self._param_list()]
 
     def _backward_body(self, cx, dlogits, need_dx, G):
         eng = self._engine

@@ -89,6 +89,8 @@ class Engine:
         pool = self.zpool_bwd if backward else self.zpool_fwd
         pool.begin(device)
         _POOL[0] = pool
+        hip._STREAM[0] = None
+        hip._STREAM[0] = hip._stream()          # one stream lookup per pass instead of one per launch
         plan = self.packs_bwd if backward else self.packs_fwd
         plan.refresh()            # all persistent weights of this pass re-packed in one launch
         hip._PLAN[0] = plan
@@ -98,6 +100,7 @@ class Engine:
             _POOL[0].end()
         _POOL[0] = None
         hip._PLAN[0] = None
+        hip._STREAM[0] = None
 
     def _seed(self, tag):
         return (self.seed_base + 0x9E3779B1 * (self.step * 64 + tag)) & 0xFFFFFFFF

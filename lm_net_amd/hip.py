@@ -98,8 +98,11 @@ def _p(t):
     return C.c_void_p(t.data_ptr())
 
 
+_STREAM = [None]   # stream handle of the pass in flight (engine.begin_pass): torch.cuda.current_stream() costs ~3 us
+
+
 def _stream():
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    return _STREAM[0] if _STREAM[0] is not None else C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
 def _i64(v):
