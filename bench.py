@@ -39,6 +39,16 @@ def dice_loss(logits, target, weight=(1.0, 4.0), smooth=1e-5):
     return loss / n
 
 
+def pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel`, measured by separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this
+    very command and committed under profiles/ (a PMC pass cannot run inside the timed loop)."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")) as f:
+            return round(json.load(f)["kernels"][kernel]["hbm_bytes_per_launch"])
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def make_batch(B, H, W, device, seed):
     from tools.detweights import disc_labels
     g = torch.Generator().manual_seed(seed)
@@ -156,11 +166,15 @@ def main():
                                    "synthetic disc masks (BASELINE configs[1])" % (B, H, W),
                        "global_batch": world * B, "image": [3, H, W], "parallelism": "dp%d" % world,
                        "final_loss": round(float(loss.detach()), 5)},
-            "roofline": {"bound": "hbm", "kernel": "dw_fwd_kernel (row A2 forward, 5x5 merged depthwise stencil + GELU-sum)",
+            "roofline": {"bound": "hbm", "kernel": "dw_fwd_strip_kernel (row A2 forward, 5x5 merged depthwise stencil + GELU-sum)",
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "frac_of_measured_copy_ceiling": round(achieved / 6290.0, 4),
-                         "launches": len(ev), "avg_us": round(kt / max(len(ev), 1) * 1e6, 2), "traffic": None,
-                         "algorithmic_bytes": "2*E*H*W*B*4 per launch (read x1 once, write pre once)"},
+                         "launches": len(ev), "avg_us": round(kt / max(len(ev), 1) * 1e6, 2),
+                         "traffic": pmc_traffic("dw_fwd_strip_kernel") if (B, H, W) == (8, 352, 352) else None,
+                         "algorithmic_bytes_per_launch": round(kb / max(len(ev), 1)),
+                         "algorithmic_bytes": "2*E*H*W*B*4 per launch (read x1 once, write pre once), averaged over "
+                                              "the 16 launches per step (four resolutions); traffic = HBM bytes per launch "
+                                              "from the committed rocprofv3 PMC passes (profiles/r01_pmc_hbm_traffic.json)"},
         }
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(H, W)
