@@ -267,6 +267,9 @@ template <int HD>
 __global__ __launch_bounds__(256) void na_bwd_kv_kernel(const float* __restrict__ qkv, const float* __restrict__ rpb,
                                                         const float* __restrict__ dout, float* __restrict__ dqkv,
                                                         const float* __restrict__ stat, const NaGeom g) {
+  __shared__ float s_rpb[16 * 25];  // bias table (per-lane gathers from LDS instead of global)
+  for (int i = threadIdx.x; i < g.heads * 25; i += 256) s_rpb[i] = rpb[i];
+  __syncthreads();
   const int64_t total = (int64_t)g.B * g.H * g.W * g.C4;
   const int64_t nit = (total + (int64_t)gridDim.x * 256 - 1) / ((int64_t)gridDim.x * 256);
   for (int64_t it = 0; it < nit; ++it) {
@@ -302,13 +305,27 @@ __global__ __launch_bounds__(256) void na_bwd_kv_kernel(const float* __restrict_
         f32x4 s = head_sum<HD>(qi * kj);
         const f32x4 dp = head_sum<HD>(dOi * vj);
         const int bo = (jy - iy + 2) * 5 + (jx - ix + 2);
+        // the query's (lse, dsum) of this quad's heads: hd = 1 -> 4 consecutive heads = one float4 each (the per-head
+        // scalar gathers were 8 of the 12 loads per candidate and kept the texture addresser saturated)
+        f32x4 lse4, dsm4;
+        const float* sp = stat + ipix * 2 * g.heads;
+        if constexpr (HD == 1) {
+          lse4 = ld4(sp + hd_[0]);
+          dsm4 = ld4(sp + g.heads + hd_[0]);
+        } else if constexpr (HD == 2) {
+          const float2 a = *reinterpret_cast<const float2*>(sp + hd_[0]), bq = *reinterpret_cast<const float2*>(sp + g.heads + hd_[0]);
+          lse4 = f32x4{a.x, a.x, a.y, a.y};
+          dsm4 = f32x4{bq.x, bq.x, bq.y, bq.y};
+        } else {
+          const float a = sp[hd_[0]], bq = sp[g.heads + hd_[0]];
+          lse4 = f32x4{a, a, a, a};
+          dsm4 = f32x4{bq, bq, bq, bq};
+        }
         f32x4 pij, ds;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-          const float lse = stat[ipix * 2 * g.heads + hd_[k]];
-          const float dsm = stat[ipix * 2 * g.heads + g.heads + hd_[k]];
-          pij[k] = __expf(s[k] + rpb[hidx[k] + bo] - lse);
-          ds[k] = pij[k] * (dp[k] - dsm);
+          pij[k] = __expf(s[k] + s_rpb[hidx[k] + bo] - lse4[k]);
+          ds[k] = pij[k] * (dp[k] - dsm4[k]);
         }
         dk += ds * qi;   // qi carries the scale
         dv += pij * dOi;
@@ -365,7 +382,7 @@ int lmn_na_bwd(const float* qkv, const float* rpb, const float* dout, float* dqk
   LMN_REQUIRE(qkv && rpb && dout && dqkv && drpb && stat, "na_bwd: null pointer");
   LMN_REQUIRE(B > 0 && H >= 3 && W >= 3, "na_bwd: feature map %dx%d smaller than the 3x3 window", H, W);
   LMN_REQUIRE(hd == 1 || hd == 2 || hd == 4 || hd == 8 || hd == 16, "na_bwd: head_dim %d not in {1,2,4,8,16}", hd);
-  LMN_REQUIRE((heads * hd) % 4 == 0 && heads * 25 * sizeof(float) <= 48000, "na_bwd: heads=%d hd=%d", heads, hd);
+  LMN_REQUIRE((heads * hd) % 4 == 0 && heads <= 16, "na_bwd: heads=%d hd=%d (C %% 4 == 0, at most 16 heads)", heads, hd);
   NaGeom g{B, H, W, heads * hd, heads * hd / 4, heads, scale};
   const int grid = na_grid((int64_t)B * H * W * g.C4);
   const int gq = grid > 2048 ? 2048 : grid;
