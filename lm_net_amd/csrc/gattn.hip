@@ -1,7 +1,7 @@
 // Dense multi-head self-attention of the GFT bottleneck (core/modules.py:267-279): N = (H/16)*(W/16)
 // tokens (484 at 352x352, 1024 at 512x512), 12 heads, head_dim = 31.  < 2 % of the step's FLOPs, so a
-// compact flash-style VALU kernel: one thread per query row (q, running max/sum and the output row in
-// registers), keys/values streamed through LDS in 64-key chunks and read as broadcasts.  The backward
+// compact flash-style VALU kernel: four lanes per query row (each owns 8 of the 32 padded dims: q, the output
+// slice and the running max/sum in registers), keys/values streamed through LDS in 64-key chunks.  The backward
 // is the standard two-sweep form (query-owned dq; key-owned dk, dv) -- no atomics, deterministic.
 #include "common.h"
 
@@ -9,6 +9,11 @@ namespace {
 
 constexpr int GA_D = 32;    // padded head_dim
 constexpr int GA_KC = 64;   // keys (or queries) per LDS chunk
+constexpr int GA_P = 4;     // lanes per row: each owns GA_D / GA_P = 8 consecutive dims
+constexpr int GA_DP = GA_D / GA_P;
+constexpr int GA_ROWS = 256 / GA_P;  // rows (queries or keys) per block
+
+typedef float f32x4g __attribute__((ext_vector_type(4)));
 
 struct GaGeom {
   int B, N, heads, hd, C;
@@ -25,18 +30,38 @@ __device__ __forceinline__ void stage_rows(float* lds, const float* base, int64_
   }
 }
 
+// sum over the 4 lanes of a row (lanes 4k..4k+3): two DPP quad permutes, no LDS
+__device__ __forceinline__ float quad_sum(float v) {
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, true));  // quad_perm [1,0,3,2]
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, true));  // quad_perm [2,3,0,1]
+  return v;
+}
+
+// this lane's 8-dim slice of LDS row r
+__device__ __forceinline__ void row_slice(const float* lds, int r, int part, float (&x)[GA_DP]) {
+  const f32x4g a = *reinterpret_cast<const f32x4g*>(lds + r * GA_D + part * GA_DP);
+  const f32x4g c = *reinterpret_cast<const f32x4g*>(lds + r * GA_D + part * GA_DP + 4);
+  x[0] = a[0]; x[1] = a[1]; x[2] = a[2]; x[3] = a[3];
+  x[4] = c[0]; x[5] = c[1]; x[6] = c[2]; x[7] = c[3];
+}
+
+// The row (query or key) a thread works on is shared by 4 lanes that split head_dim: 4x the waves of the
+// one-thread-per-row form (484 tokens x 12 heads x 8 images is only 726 waves of rows -- less than one per SIMD),
+// a quarter of the registers, and the dot products close with two DPP adds.
 __global__ __launch_bounds__(256) void gattn_fwd_kernel(const float* __restrict__ qkv, float* __restrict__ out,
                                                         float* __restrict__ lse, const GaGeom g) {
-  __shared__ float Ks[GA_KC * GA_D], Vs[GA_KC * GA_D];
+  __shared__ __attribute__((aligned(16))) float Ks[GA_KC * GA_D], Vs[GA_KC * GA_D];
   const int h = blockIdx.y, b = blockIdx.z;
-  const int i = blockIdx.x * 256 + threadIdx.x;
+  const int part = threadIdx.x & (GA_P - 1);
+  const int i = blockIdx.x * GA_ROWS + (threadIdx.x >> 2);
   const bool ok = i < g.N;
   const int64_t rs = 3 * g.C;
   const float* qb = qkv + (int64_t)b * g.N * rs + h * g.hd;
-  float q[GA_D], o[GA_D];
+  float q[GA_DP], o[GA_DP];
 #pragma unroll
-  for (int d = 0; d < GA_D; ++d) {
-    q[d] = (ok && d < g.hd) ? qb[(int64_t)i * rs + d] * g.scale : 0.f;
+  for (int d = 0; d < GA_DP; ++d) {
+    const int dd = part * GA_DP + d;
+    q[d] = (ok && dd < g.hd) ? qb[(int64_t)i * rs + dd] * g.scale : 0.f;
     o[d] = 0.f;
   }
   float m = -3.0e38f, l = 0.f;
@@ -47,14 +72,18 @@ __global__ __launch_bounds__(256) void gattn_fwd_kernel(const float* __restrict_
     __syncthreads();
     const int kn = g.N - k0 < GA_KC ? g.N - k0 : GA_KC;
     for (int j = 0; j < kn; ++j) {
+      float kk[GA_DP], vv[GA_DP];
+      row_slice(Ks, j, part, kk);
+      row_slice(Vs, j, part, vv);
       float s = 0.f;
 #pragma unroll
-      for (int d = 0; d < GA_D; ++d) s += q[d] * Ks[j * GA_D + d];
+      for (int d = 0; d < GA_DP; ++d) s += q[d] * kk[d];
+      s = quad_sum(s);
       const float mn = fmaxf(m, s);
-      const float corr = __expf(m - mn), p = __expf(s - mn);
-      l = l * corr + p;
+      const float corr = __expf(m - mn), pj = __expf(s - mn);
+      l = l * corr + pj;
 #pragma unroll
-      for (int d = 0; d < GA_D; ++d) o[d] = o[d] * corr + p * Vs[j * GA_D + d];
+      for (int d = 0; d < GA_DP; ++d) o[d] = o[d] * corr + pj * vv[d];
       m = mn;
     }
   }
@@ -62,9 +91,9 @@ __global__ __launch_bounds__(256) void gattn_fwd_kernel(const float* __restrict_
     const float inv = 1.0f / l;
     float* ob = out + ((int64_t)b * g.N + i) * g.C + h * g.hd;
 #pragma unroll
-    for (int d = 0; d < GA_D; ++d)
-      if (d < g.hd) ob[d] = o[d] * inv;
-    lse[((int64_t)b * g.heads + h) * g.N + i] = m + __logf(l);
+    for (int d = 0; d < GA_DP; ++d)
+      if (part * GA_DP + d < g.hd) ob[part * GA_DP + d] = o[d] * inv;
+    if (part == 0) lse[((int64_t)b * g.heads + h) * g.N + i] = m + __logf(l);
   }
 }
 
@@ -73,23 +102,26 @@ __global__ __launch_bounds__(256) void gattn_bwd_q_kernel(const float* __restric
                                                           const float* __restrict__ dout, const float* __restrict__ lse,
                                                           float* __restrict__ dqkv, float* __restrict__ delta,
                                                           const GaGeom g) {
-  __shared__ float Ks[GA_KC * GA_D], Vs[GA_KC * GA_D];
+  __shared__ __attribute__((aligned(16))) float Ks[GA_KC * GA_D], Vs[GA_KC * GA_D];
   const int h = blockIdx.y, b = blockIdx.z;
-  const int i = blockIdx.x * 256 + threadIdx.x;
+  const int part = threadIdx.x & (GA_P - 1);
+  const int i = blockIdx.x * GA_ROWS + (threadIdx.x >> 2);
   const bool ok = i < g.N;
   const int64_t rs = 3 * g.C;
   const float* qb = qkv + (int64_t)b * g.N * rs + h * g.hd;
-  float q[GA_D], dO[GA_D], dq[GA_D];
+  float q[GA_DP], dO[GA_DP], dq[GA_DP];
   float dl = 0.f;
 #pragma unroll
-  for (int d = 0; d < GA_D; ++d) {
-    const bool dk = ok && d < g.hd;
-    q[d] = dk ? qb[(int64_t)i * rs + d] * g.scale : 0.f;
-    dO[d] = dk ? dout[((int64_t)b * g.N + i) * g.C + h * g.hd + d] : 0.f;
-    const float ov = dk ? out[((int64_t)b * g.N + i) * g.C + h * g.hd + d] : 0.f;
+  for (int d = 0; d < GA_DP; ++d) {
+    const int dd = part * GA_DP + d;
+    const bool dk = ok && dd < g.hd;
+    q[d] = dk ? qb[(int64_t)i * rs + dd] * g.scale : 0.f;
+    dO[d] = dk ? dout[((int64_t)b * g.N + i) * g.C + h * g.hd + dd] : 0.f;
+    const float ov = dk ? out[((int64_t)b * g.N + i) * g.C + h * g.hd + dd] : 0.f;
     dl += dO[d] * ov;
     dq[d] = 0.f;
   }
+  dl = quad_sum(dl);
   const float L = ok ? lse[((int64_t)b * g.heads + h) * g.N + i] : 0.f;
   for (int k0 = 0; k0 < g.N; k0 += GA_KC) {
     __syncthreads();
@@ -98,23 +130,28 @@ __global__ __launch_bounds__(256) void gattn_bwd_q_kernel(const float* __restric
     __syncthreads();
     const int kn = g.N - k0 < GA_KC ? g.N - k0 : GA_KC;
     for (int j = 0; j < kn; ++j) {
+      float kk[GA_DP], vv[GA_DP];
+      row_slice(Ks, j, part, kk);
+      row_slice(Vs, j, part, vv);
       float s = 0.f, dp = 0.f;
 #pragma unroll
-      for (int d = 0; d < GA_D; ++d) {
-        s += q[d] * Ks[j * GA_D + d];
-        dp += dO[d] * Vs[j * GA_D + d];
+      for (int d = 0; d < GA_DP; ++d) {
+        s += q[d] * kk[d];
+        dp += dO[d] * vv[d];
       }
+      s = quad_sum(s);
+      dp = quad_sum(dp);
       const float ds = __expf(s - L) * (dp - dl);
 #pragma unroll
-      for (int d = 0; d < GA_D; ++d) dq[d] += ds * Ks[j * GA_D + d];
+      for (int d = 0; d < GA_DP; ++d) dq[d] += ds * kk[d];
     }
   }
   if (ok) {
     float* dqb = dqkv + ((int64_t)b * g.N + i) * rs + h * g.hd;
 #pragma unroll
-    for (int d = 0; d < GA_D; ++d)
-      if (d < g.hd) dqb[d] = dq[d] * g.scale;
-    delta[((int64_t)b * g.heads + h) * g.N + i] = dl;
+    for (int d = 0; d < GA_DP; ++d)
+      if (part * GA_DP + d < g.hd) dqb[part * GA_DP + d] = dq[d] * g.scale;
+    if (part == 0) delta[((int64_t)b * g.heads + h) * g.N + i] = dl;
   }
 }
 
@@ -122,18 +159,21 @@ __global__ __launch_bounds__(256) void gattn_bwd_q_kernel(const float* __restric
 __global__ __launch_bounds__(256) void gattn_bwd_kv_kernel(const float* __restrict__ qkv, const float* __restrict__ dout,
                                                            const float* __restrict__ lse, const float* __restrict__ delta,
                                                            float* __restrict__ dqkv, const GaGeom g) {
-  __shared__ float Qs[GA_KC * GA_D], Ds[GA_KC * GA_D], Ls[GA_KC], Dl[GA_KC];
+  __shared__ __attribute__((aligned(16))) float Qs[GA_KC * GA_D], Ds[GA_KC * GA_D];
+  __shared__ float Ls[GA_KC], Dl[GA_KC];
   const int h = blockIdx.y, b = blockIdx.z;
-  const int j = blockIdx.x * 256 + threadIdx.x;
+  const int part = threadIdx.x & (GA_P - 1);
+  const int j = blockIdx.x * GA_ROWS + (threadIdx.x >> 2);
   const bool ok = j < g.N;
   const int64_t rs = 3 * g.C;
   const float* qb = qkv + (int64_t)b * g.N * rs + h * g.hd;
-  float k[GA_D], v[GA_D], dk[GA_D], dv[GA_D];
+  float k[GA_DP], v[GA_DP], dk[GA_DP], dv[GA_DP];
 #pragma unroll
-  for (int d = 0; d < GA_D; ++d) {
-    const bool dok = ok && d < g.hd;
-    k[d] = dok ? qb[(int64_t)j * rs + g.C + d] : 0.f;
-    v[d] = dok ? qb[(int64_t)j * rs + 2 * g.C + d] : 0.f;
+  for (int d = 0; d < GA_DP; ++d) {
+    const int dd = part * GA_DP + d;
+    const bool dok = ok && dd < g.hd;
+    k[d] = dok ? qb[(int64_t)j * rs + g.C + dd] : 0.f;
+    v[d] = dok ? qb[(int64_t)j * rs + 2 * g.C + dd] : 0.f;
     dk[d] = dv[d] = 0.f;
   }
   const float* dob = dout + (int64_t)b * g.N * g.C + h * g.hd;
@@ -149,28 +189,33 @@ __global__ __launch_bounds__(256) void gattn_bwd_kv_kernel(const float* __restri
     __syncthreads();
     const int qn = g.N - i0 < GA_KC ? g.N - i0 : GA_KC;
     for (int i = 0; i < qn; ++i) {
+      float qq[GA_DP], dd[GA_DP];
+      row_slice(Qs, i, part, qq);
+      row_slice(Ds, i, part, dd);
       float s = 0.f, dp = 0.f;
 #pragma unroll
-      for (int d = 0; d < GA_D; ++d) {
-        s += Qs[i * GA_D + d] * k[d];
-        dp += Ds[i * GA_D + d] * v[d];
+      for (int d = 0; d < GA_DP; ++d) {
+        s += qq[d] * k[d];
+        dp += dd[d] * v[d];
       }
-      const float p = __expf(s * g.scale - Ls[i]);
-      const float ds = p * (dp - Dl[i]);
+      s = quad_sum(s);
+      dp = quad_sum(dp);
+      const float pij = __expf(s * g.scale - Ls[i]);
+      const float ds = pij * (dp - Dl[i]);
 #pragma unroll
-      for (int d = 0; d < GA_D; ++d) {
-        dv[d] += p * Ds[i * GA_D + d];
-        dk[d] += ds * Qs[i * GA_D + d];
+      for (int d = 0; d < GA_DP; ++d) {
+        dv[d] += pij * dd[d];
+        dk[d] += ds * qq[d];
       }
     }
   }
   if (ok) {
     float* db = dqkv + ((int64_t)b * g.N + j) * rs + h * g.hd;
 #pragma unroll
-    for (int d = 0; d < GA_D; ++d)
-      if (d < g.hd) {
-        db[g.C + d] = dk[d] * g.scale;
-        db[2 * g.C + d] = dv[d];
+    for (int d = 0; d < GA_DP; ++d)
+      if (part * GA_DP + d < g.hd) {
+        db[g.C + part * GA_DP + d] = dk[d] * g.scale;
+        db[2 * g.C + part * GA_DP + d] = dv[d];
       }
   }
 }
@@ -184,7 +229,7 @@ int lmn_gattn_fwd(const float* qkv, float* out, float* lse, int B, int N, int he
   LMN_REQUIRE(qkv && out && lse && B > 0 && N > 0 && heads > 0, "gattn_fwd: bad argument");
   LMN_REQUIRE(hd >= 1 && hd <= GA_D, "gattn_fwd: head_dim %d > %d", hd, GA_D);
   GaGeom g{B, N, heads, hd, heads * hd, scale};
-  hipLaunchKernelGGL(gattn_fwd_kernel, dim3(lmn_cdiv(N, 256), heads, B), dim3(256), 0, (hipStream_t)stream, qkv, out, lse, g);
+  hipLaunchKernelGGL(gattn_fwd_kernel, dim3(lmn_cdiv(N, GA_ROWS), heads, B), dim3(256), 0, (hipStream_t)stream, qkv, out, lse, g);
   return lmn_launch_status("gattn_fwd");
 }
 
@@ -193,7 +238,7 @@ int lmn_gattn_bwd(const float* qkv, const float* out, const float* dout, const f
   LMN_REQUIRE(qkv && out && dout && lse && dqkv && delta && B > 0 && N > 0 && heads > 0, "gattn_bwd: bad argument");
   LMN_REQUIRE(hd >= 1 && hd <= GA_D, "gattn_bwd: head_dim %d > %d", hd, GA_D);
   GaGeom g{B, N, heads, hd, heads * hd, scale};
-  const dim3 grid(lmn_cdiv(N, 256), heads, B);
+  const dim3 grid(lmn_cdiv(N, GA_ROWS), heads, B);
   hipLaunchKernelGGL(gattn_bwd_q_kernel, grid, dim3(256), 0, (hipStream_t)stream, qkv, out, dout, lse, dqkv, delta, g);
   hipLaunchKernelGGL(gattn_bwd_kv_kernel, grid, dim3(256), 0, (hipStream_t)stream, qkv, dout, lse, delta, dqkv, g);
   return lmn_launch_status("gattn_bwd");
