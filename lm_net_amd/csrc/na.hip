@@ -267,9 +267,8 @@ template <int HD>
 __global__ __launch_bounds__(256) void na_bwd_kv_kernel(const float* __restrict__ qkv, const float* __restrict__ rpb,
                                                         const float* __restrict__ dout, float* __restrict__ dqkv,
                                                         const float* __restrict__ stat, const NaGeom g) {
-  __shared__ float s_rpb[16 * 25];  // bias table (per-lane gathers from LDS instead of global)
-  for (int i = threadIdx.x; i < g.heads * 25; i += 256) s_rpb[i] = rpb[i];
-  __syncthreads();
+  // (the bias table stays in global memory here: with 12 heads x 25 entries gathered per lane the LDS copy was
+  //  slower than the L1-resident table -- 25-word head stride = bank conflicts)
   const int64_t total = (int64_t)g.B * g.H * g.W * g.C4;
   const int64_t nit = (total + (int64_t)gridDim.x * 256 - 1) / ((int64_t)gridDim.x * 256);
   for (int64_t it = 0; it < nit; ++it) {
@@ -324,7 +323,7 @@ __global__ __launch_bounds__(256) void na_bwd_kv_kernel(const float* __restrict_
         f32x4 pij, ds;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-          pij[k] = __expf(s[k] + s_rpb[hidx[k] + bo] - lse4[k]);
+          pij[k] = __expf(s[k] + rpb[hidx[k] + bo] - lse4[k]);
           ds[k] = pij[k] * (dp[k] - dsm4[k]);
         }
         dk += ds * qi;   // qi carries the scale
