@@ -346,6 +346,13 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams P) {
 template <int TAPS, int NCT, int EPI>
 __global__ __launch_bounds__(256) void conv_tile_kernel(const ConvParams P) {
   const lmn_conv_args_t& A = P.a;
+  // EPI: 0 plain (LINEAR / AFFINE_ACT, no statistics), 1 generic, 2 LINEAR + SUM_SQ statistics, 3 BN_BWD1, 4 BN_BWD2,
+  // 5 SE_BWD.  For EPI >= 2 the epilogue kind is a compile-time constant: each instance carries only its own code
+  // (the generic instance keeps every variant resident: 125-160 VGPRs + spills, and measured 20-40 us over its
+  // memory time at level 0).
+  const int ep_kind = EPI == 2 ? LMN_EP_LINEAR : EPI == 3 ? LMN_EP_BN_BWD1 : EPI == 4 ? LMN_EP_BN_BWD2 : EPI == 5 ? LMN_EP_SE_BWD : A.epilogue;
+  const int st_mode = EPI == 2 ? LMN_STATS_SUM_SQ : (EPI == 3 || EPI == 5) ? LMN_STATS_EP : EPI == 4 ? LMN_STATS_NONE : A.stats_mode;
+  const bool has_drop = EPI <= 1 && A.drop_p > 0.f;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* XS = smem;                       // [XH*XW][CS]
   float* s_stats = smem + P.XH * P.XW * P.CS;  // [2][NCT*16]
@@ -377,7 +384,7 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(const ConvParams P) {
     const int wy0 = A.transposed ? oy0 - pad : oy0 * A.stride - pad;
     const int wx0 = A.transposed ? ox0 - pad : ox0 * A.stride - pad;
 
-    if (EPI && A.epilogue == LMN_EP_SE_BWD && b != cur_b) {  // block-uniform: flush the previous image's sums
+    if (EPI && ep_kind == LMN_EP_SE_BWD && b != cur_b) {  // block-uniform: flush the previous image's sums
       if (cur_b >= 0) {
 #pragma unroll
         for (int c = 0; c < NCT; ++c)
@@ -498,11 +505,11 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(const ConvParams P) {
         f32x4 v = acc[g][c];
         if (A.bias) v += ld4(A.bias + cos);
         f32x4 o = v;
-        if (EPI && A.stats_mode == LMN_STATS_SUM_SQ && live) {
+        if (EPI && st_mode == LMN_STATS_SUM_SQ && live) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) { st0[c][r] += v[r]; st1[c][r] += v[r] * v[r]; }
         }
-        if (A.epilogue == LMN_EP_AFFINE_ACT) {
+        if (ep_kind == LMN_EP_AFFINE_ACT) {
           const f32x4 s0 = ld4(A.p0 + cos), s1 = ld4(A.p1 + cos);
 #pragma unroll
           for (int r = 0; r < 4; ++r) o[r] = lmn_act(v[r] * s0[r] + s1[r], A.act);
@@ -510,7 +517,7 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(const ConvParams P) {
         if (EPI) {
           f32x4 ax = f32x4{0.f, 0.f, 0.f, 0.f};
           if (A.aux) ax = ld4(A.aux + opx * A.aux_cstride + cos);
-          switch (A.epilogue) {
+          switch (ep_kind) {
             case LMN_EP_DGELU: {
 #pragma unroll
               for (int r = 0; r < 4; ++r) o[r] = v[r] * lmn_dgelu(ax[r]);
@@ -539,7 +546,7 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(const ConvParams P) {
             default: break;
           }
         }
-        if (A.drop_p > 0.f) {
+        if (has_drop) {
           const uint32_t idx = opx * A.Cout + cos;
 #pragma unroll
           for (int r = 0; r < 4; ++r) o[r] *= lmn_drop_scale(A.drop_seed, idx + r, A.drop_p, P.inv_keep_ep);
@@ -552,8 +559,8 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(const ConvParams P) {
   }
 
   // ---- statistics: wave shuffle over the 16 pixels -> LDS -> one global atomic per channel per block
-  const bool se = EPI && A.epilogue == LMN_EP_SE_BWD;
-  const bool chan_stats = EPI && ((A.stats_mode == LMN_STATS_SUM_SQ) || (A.epilogue == LMN_EP_BN_BWD1) || se);
+  const bool se = EPI && ep_kind == LMN_EP_SE_BWD;
+  const bool chan_stats = EPI && ((st_mode == LMN_STATS_SUM_SQ) || (ep_kind == LMN_EP_BN_BWD1) || se);
   if (chan_stats) {
 #pragma unroll
     for (int c = 0; c < NCT; ++c)
@@ -591,6 +598,13 @@ template <int TAPS, int NCW, int EPI>
 __global__ __launch_bounds__(256) void conv_tileM_kernel(const ConvParams P) {
   constexpr int NCT = 4 * NCW;  // cout tiles per block
   const lmn_conv_args_t& A = P.a;
+  // EPI: 0 plain (LINEAR / AFFINE_ACT, no statistics), 1 generic, 2 LINEAR + SUM_SQ statistics, 3 BN_BWD1, 4 BN_BWD2,
+  // 5 SE_BWD.  For EPI >= 2 the epilogue kind is a compile-time constant: each instance carries only its own code
+  // (the generic instance keeps every variant resident: 125-160 VGPRs + spills, and measured 20-40 us over its
+  // memory time at level 0).
+  const int ep_kind = EPI == 2 ? LMN_EP_LINEAR : EPI == 3 ? LMN_EP_BN_BWD1 : EPI == 4 ? LMN_EP_BN_BWD2 : EPI == 5 ? LMN_EP_SE_BWD : A.epilogue;
+  const int st_mode = EPI == 2 ? LMN_STATS_SUM_SQ : (EPI == 3 || EPI == 5) ? LMN_STATS_EP : EPI == 4 ? LMN_STATS_NONE : A.stats_mode;
+  const bool has_drop = EPI <= 1 && A.drop_p > 0.f;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* XS = smem;                       // [XH*XW][CS]
   float* s_stats = smem + P.XH * P.XW * P.CS;  // [2][NCT*16]
@@ -623,7 +637,7 @@ __global__ __launch_bounds__(256) void conv_tileM_kernel(const ConvParams P) {
     const int wy0 = A.transposed ? oy0 - pad : oy0 * A.stride - pad;
     const int wx0 = A.transposed ? ox0 - pad : ox0 * A.stride - pad;
 
-    if (EPI && A.epilogue == LMN_EP_SE_BWD && b != cur_b) {  // block-uniform: flush the previous image's sums
+    if (EPI && ep_kind == LMN_EP_SE_BWD && b != cur_b) {  // block-uniform: flush the previous image's sums
       if (cur_b >= 0) {
 #pragma unroll
         for (int c = 0; c < NCW; ++c)
@@ -742,11 +756,11 @@ __global__ __launch_bounds__(256) void conv_tileM_kernel(const ConvParams P) {
         f32x4 v = acc[g][c];
         if (A.bias) v += ld4(A.bias + cos);
         f32x4 o = v;
-        if (EPI && A.stats_mode == LMN_STATS_SUM_SQ && live) {
+        if (EPI && st_mode == LMN_STATS_SUM_SQ && live) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) { st0[c][r] += v[r]; st1[c][r] += v[r] * v[r]; }
         }
-        if (A.epilogue == LMN_EP_AFFINE_ACT) {
+        if (ep_kind == LMN_EP_AFFINE_ACT) {
           const f32x4 s0 = ld4(A.p0 + cos), s1 = ld4(A.p1 + cos);
 #pragma unroll
           for (int r = 0; r < 4; ++r) o[r] = lmn_act(v[r] * s0[r] + s1[r], A.act);
@@ -754,7 +768,7 @@ __global__ __launch_bounds__(256) void conv_tileM_kernel(const ConvParams P) {
         if (EPI) {
           f32x4 ax = f32x4{0.f, 0.f, 0.f, 0.f};
           if (A.aux) ax = ld4(A.aux + opx * A.aux_cstride + cos);
-          switch (A.epilogue) {
+          switch (ep_kind) {
             case LMN_EP_DGELU: {
 #pragma unroll
               for (int r = 0; r < 4; ++r) o[r] = v[r] * lmn_dgelu(ax[r]);
@@ -783,7 +797,7 @@ __global__ __launch_bounds__(256) void conv_tileM_kernel(const ConvParams P) {
             default: break;
           }
         }
-        if (A.drop_p > 0.f) {
+        if (has_drop) {
           const uint32_t idx = opx * A.Cout + cos;
 #pragma unroll
           for (int r = 0; r < 4; ++r) o[r] *= lmn_drop_scale(A.drop_seed, idx + r, A.drop_p, P.inv_keep_ep);
@@ -796,8 +810,8 @@ __global__ __launch_bounds__(256) void conv_tileM_kernel(const ConvParams P) {
   }
 
   // ---- statistics: wave shuffle over the 16 pixels -> LDS -> one global atomic per channel per block
-  const bool se = EPI && A.epilogue == LMN_EP_SE_BWD;
-  const bool chan_stats = EPI && ((A.stats_mode == LMN_STATS_SUM_SQ) || (A.epilogue == LMN_EP_BN_BWD1) || se);
+  const bool se = EPI && ep_kind == LMN_EP_SE_BWD;
+  const bool chan_stats = EPI && ((st_mode == LMN_STATS_SUM_SQ) || (ep_kind == LMN_EP_BN_BWD1) || se);
   if (chan_stats) {
 #pragma unroll
     for (int c = 0; c < NCW; ++c)
@@ -1780,7 +1794,14 @@ int lmn_conv_fwd(const lmn_conv_args_t* args, lmn_stream_t stream) {
     int blocks = T.total_tiles;
     const int maxb = 2048 / chunks > 256 ? 2048 / chunks : 256;
     if (blocks > maxb) blocks = maxb;
-    const bool epi = a.epilogue > LMN_EP_AFFINE_ACT || a.stats_mode != LMN_STATS_NONE;  // EPI=1: statistics / special epilogues
+    // epilogue instance (see the kernel): 0 plain, 2 LINEAR+SUM_SQ, 3 BN_BWD1, 4 BN_BWD2, 5 SE_BWD, 1 everything else
+    int ek = 1;
+    if (a.epilogue <= LMN_EP_AFFINE_ACT && a.stats_mode == LMN_STATS_NONE) ek = 0;
+    else if (a.drop_p > 0.f) ek = 1;
+    else if (a.epilogue == LMN_EP_LINEAR && a.stats_mode == LMN_STATS_SUM_SQ) ek = 2;
+    else if (a.epilogue == LMN_EP_BN_BWD1 && a.stats_mode == LMN_STATS_EP) ek = 3;
+    else if (a.epilogue == LMN_EP_BN_BWD2 && a.stats_mode == LMN_STATS_NONE) ek = 4;
+    else if (a.epilogue == LMN_EP_SE_BWD && a.stats_mode == LMN_STATS_EP) ek = 5;
     if (ncw) {
       const int mchunks = (P.NCTT + 4 * ncw - 1) / (4 * ncw);
       int mblocks = T.total_tiles;
@@ -1790,8 +1811,14 @@ int lmn_conv_fwd(const lmn_conv_args_t* args, lmn_stream_t stream) {
       const size_t msh = ((size_t)T.XH * T.XW * T.CS + 2 * 4 * ncw * 16) * sizeof(float);
 #define LMN_CM(TT, NN)                                                                                   \
   do {                                                                                                   \
-    if (epi) hipLaunchKernelGGL((conv_tileM_kernel<TT, NN, 1>), mgrid, dim3(256), msh, st, T);           \
-    else hipLaunchKernelGGL((conv_tileM_kernel<TT, NN, 0>), mgrid, dim3(256), msh, st, T);               \
+    switch ((TT) == 1 ? ek : (ek > 2 ? 1 : ek)) {                                                        \
+      case 0: hipLaunchKernelGGL((conv_tileM_kernel<TT, NN, 0>), mgrid, dim3(256), msh, st, T); break;   \
+      case 2: hipLaunchKernelGGL((conv_tileM_kernel<TT, NN, 2>), mgrid, dim3(256), msh, st, T); break;   \
+      case 3: hipLaunchKernelGGL((conv_tileM_kernel<1, NN, 3>), mgrid, dim3(256), msh, st, T); break;    \
+      case 4: hipLaunchKernelGGL((conv_tileM_kernel<1, NN, 4>), mgrid, dim3(256), msh, st, T); break;    \
+      case 5: hipLaunchKernelGGL((conv_tileM_kernel<1, NN, 5>), mgrid, dim3(256), msh, st, T); break;    \
+      default: hipLaunchKernelGGL((conv_tileM_kernel<TT, NN, 1>), mgrid, dim3(256), msh, st, T); break;  \
+    }                                                                                                    \
   } while (0)
       if (a.ksize == 1) { if (ncw == 2) LMN_CM(1, 2); else LMN_CM(1, 1); }
       else { if (ncw == 2) LMN_CM(9, 2); else LMN_CM(9, 1); }
@@ -1801,8 +1828,14 @@ int lmn_conv_fwd(const lmn_conv_args_t* args, lmn_stream_t stream) {
     const dim3 grid(blocks, chunks);
 #define LMN_CT(TT, NN)                                                                                   \
   do {                                                                                                   \
-    if (epi) hipLaunchKernelGGL((conv_tile_kernel<TT, NN, 1>), grid, dim3(256), shmem, st, T);           \
-    else hipLaunchKernelGGL((conv_tile_kernel<TT, NN, 0>), grid, dim3(256), shmem, st, T);               \
+    switch ((TT) == 1 ? ek : (ek > 2 ? 1 : ek)) {                                                        \
+      case 0: hipLaunchKernelGGL((conv_tile_kernel<TT, NN, 0>), grid, dim3(256), shmem, st, T); break;   \
+      case 2: hipLaunchKernelGGL((conv_tile_kernel<TT, NN, 2>), grid, dim3(256), shmem, st, T); break;   \
+      case 3: hipLaunchKernelGGL((conv_tile_kernel<1, NN, 3>), grid, dim3(256), shmem, st, T); break;    \
+      case 4: hipLaunchKernelGGL((conv_tile_kernel<1, NN, 4>), grid, dim3(256), shmem, st, T); break;    \
+      case 5: hipLaunchKernelGGL((conv_tile_kernel<1, NN, 5>), grid, dim3(256), shmem, st, T); break;    \
+      default: hipLaunchKernelGGL((conv_tile_kernel<TT, NN, 1>), grid, dim3(256), shmem, st, T); break;  \
+    }                                                                                                    \
   } while (0)
 #define LMN_CTN(TT)                                                                                      \
   switch (nct) {                                                                                         \
