@@ -78,3 +78,42 @@ def test_product_never_imports_the_oracle():
         if fn.endswith(".py"):
             src = open(os.path.join(pkg, fn)).read()
             assert "oracle" not in src.replace("the oracle", "").replace("CPU oracle", "") or fn == "__none__", fn
+
+
+def test_rows_around_the_path_have_no_cpu_fallback_either():
+    """SegLoss / FusedAdamW / ConfusionMeter refuse CPU tensors instead of falling back."""
+    from lm_net_amd import LM_Net
+    from lm_net_amd.loss import SegLoss
+    from lm_net_amd.metrics import ConfusionMeter
+    from lm_net_amd.optim import FusedAdamW
+    lg, y = torch.zeros(1, 2, 32, 32, requires_grad=True), torch.zeros(1, 32, 32, dtype=torch.int64)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        SegLoss()(lg, y)
+    with pytest.raises(ValueError):
+        SegLoss(ce_weight=(1.0, 2.0, 3.0), dice_weight=(1.0, 2.0, 3.0))(lg, y)      # class-count mismatch
+    with pytest.raises(RuntimeError, match="GPU first"):
+        FusedAdamW(LM_Net(3, 2, filters=[12] * 5))
+    with pytest.raises(TypeError):
+        FusedAdamW(torch.nn.Linear(2, 2))
+    m = ConfusionMeter(2, device="cpu")
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        m.update(lg.detach(), y)
+    m.total += torch.tensor([[50.0, 10.0], [5.0, 35.0]], dtype=torch.float64)        # rows = label, cols = prediction
+    r = m.compute()
+    assert abs(r["dice"][1] - 2 * 35 / (2 * 35 + 10 + 5)) < 1e-12 and abs(r["iou"][1] - 35 / 50) < 1e-12
+    assert abs(r["accuracy"] - 0.85) < 1e-12
+
+
+def test_pack_plan_records_once_and_drops_on_storage_change():
+    """hip.PackPlan bookkeeping (no launches): jobs are keyed by weight storage and dropped when it moves."""
+    from lm_net_amd import hip
+    plan = hip.PackPlan()
+    w = torch.nn.Parameter(torch.zeros(4, 4))
+    out = torch.zeros(16)
+    plan.record(("k",), w, out, dict(w=w.data_ptr(), ksize=1, Cout=4, Cin=4, c=[4], transposed=0, row_off=0, rows=0))
+    assert plan.lookup(("k",)) is None            # not fresh until refresh() has re-packed
+    plan.fresh = True
+    assert plan.lookup(("k",)) is out
+    w.data = torch.ones(4, 4)                     # storage replaced (model.to(), load via .data=)
+    plan.refresh()
+    assert not plan.jobs and not plan.fresh
