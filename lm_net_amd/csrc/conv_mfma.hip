@@ -1936,7 +1936,9 @@ int lmn_conv_wgrad(const lmn_wgrad_args_t* args, lmn_stream_t stream) {
   if (blocks64 < 1) blocks64 = 1;
   // two-stage reduction when the caller's workspace holds every block partial; else LDS-reduced atomics with fewer blocks
   P.partial = nullptr;
-  if (A.workspace && blocks64 > 1 && (int64_t)gy * blocks64 * per <= A.workspace_floats) {
+  // (up to 48 K-split blocks add their LDS-reduced tile straight into dW: 48 atomics per address do not contend, and
+  //  the separate reduction launch costs more than it saves on the small feature maps)
+  if (A.workspace && blocks64 > 48 && (int64_t)gy * blocks64 * per <= A.workspace_floats) {
     P.partial = A.workspace;
   } else if (blocks64 > 512 / gy && 512 / gy >= 2) {
     blocks64 = 512 / gy;
@@ -1962,7 +1964,7 @@ int lmn_conv_wgrad(const lmn_wgrad_args_t* args, lmn_stream_t stream) {
     if (nb > cap) nb = cap;
     if (nb < 1) nb = 1;
     P.partial = nullptr;
-    if (A.workspace && nb > 1 && (int64_t)gy * nb * per <= A.workspace_floats) P.partial = A.workspace;
+    if (A.workspace && nb > 48 && (int64_t)gy * nb * per <= A.workspace_floats) P.partial = A.workspace;
     else if (nb > 512 / gy && 512 / gy >= 2) nb = 512 / gy;
     const dim3 dgrid((unsigned)nb, gy);
 #define LMN_WD(M, N)                                                                                               \
