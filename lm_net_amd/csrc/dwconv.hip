@@ -1014,6 +1014,25 @@ static int launch_dw_walk_stats(const float* x1, const float* pre, const float* 
 }
 
 
+// Row segments of the strip kernels: every segment re-walks `halo` extra rows, and the grid runs in rounds of
+// occ blocks per CU x 256 CUs -- pick the segment count that minimises rounds x (rows + halo) (e.g. level 0 of the
+// backward kernel: 8 segments = 3 rounds x 54 row steps, 7 segments = 2 rounds x 61).
+static int strip_segments(int64_t blocks_per_seg, int H, int halo, int occ, int* seg_rows) {
+  int best = 1;
+  int64_t best_cost = -1;
+  for (int sg = 1; sg <= H; ++sg) {
+    const int rows = lmn_cdiv(H, sg);
+    if (sg > 1 && rows < 8) break;
+    const int nseg = lmn_cdiv(H, rows);
+    if (nseg != sg) continue;  // same partition as a smaller count
+    const int64_t rounds = (blocks_per_seg * nseg + (int64_t)occ * 256 - 1) / ((int64_t)occ * 256);
+    const int64_t cost = rounds * (rows + halo);
+    if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = sg; }
+  }
+  *seg_rows = lmn_cdiv(H, best);
+  return lmn_cdiv(H, *seg_rows);
+}
+
 extern "C" {
 
 int lmn_dw_fwd(const float* x1, float* pre, float* gsum, int B, int H, int W, int E, const float* keff,
@@ -1022,10 +1041,8 @@ int lmn_dw_fwd(const float* x1, float* pre, float* gsum, int B, int H, int W, in
   LMN_REQUIRE(B > 0 && H > 0 && W > 0 && E > 0 && E % 4 == 0, "dw_fwd: E=%d must be a multiple of 4", E);
   // strip-walking kernel: blocks = B x strips(64 columns) x row segments x 8-channel chunks
   const int strips = lmn_cdiv(W, SW_FC), chunks = lmn_cdiv(E, SW_CH);
-  int segs = 1;
-  while ((int64_t)B * strips * chunks * segs < 1536 && lmn_cdiv(H, segs * 2) >= 16) segs *= 2;
-  const int seg_rows = lmn_cdiv(H, segs);
-  segs = lmn_cdiv(H, seg_rows);
+  int seg_rows;
+  const int segs = strip_segments((int64_t)B * strips * chunks, H, 4, 4, &seg_rows);   // 40 KB LDS: 4 blocks per CU
   const int64_t nblk = (int64_t)B * strips * chunks * segs;
   LMN_REQUIRE(nblk < (1LL << 31), "dw_fwd: grid too large");
   hipLaunchKernelGGL(dw_fwd_strip_kernel, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, x1, pre, gsum, H, W, E, keff,
@@ -1080,13 +1097,10 @@ int lmn_dw_bwd(const float* x1, const float* dpre, float* dx1, int B, int H, int
                float* dw5, float* dw3, float* dwv, float* dwh, lmn_stream_t stream) {
   LMN_REQUIRE(x1 && dpre && dx1 && w5 && w3 && wv && wh && cA && cC && cD && dw5 && dw3 && dwv && dwh, "dw_bwd: null pointer");
   LMN_REQUIRE(B > 0 && H > 0 && W > 0 && E > 0 && E % 4 == 0, "dw_bwd: E=%d must be a multiple of 4", E);
-  // strip-walking kernel: blocks = B x strips(60 columns) x row segments x 8-channel chunks.  Segments add 8 halo
-  // rows each, so they are as long as possible while the grid still has ~3 blocks per CU.
+  // strip-walking kernel: blocks = B x strips(60 columns) x row segments x 8-channel chunks (segments: strip_segments)
   const int strips = lmn_cdiv(W, SW_OC), chunks = lmn_cdiv(E, SW_CH);
-  int segs = 1;
-  while ((int64_t)B * strips * chunks * segs < 768 && lmn_cdiv(H, segs * 2) >= 16) segs *= 2;
-  const int seg_rows = lmn_cdiv(H, segs);
-  segs = lmn_cdiv(H, seg_rows);
+  int seg_rows;
+  const int segs = strip_segments((int64_t)B * strips * chunks, H, 10, 2, &seg_rows);  // 242 VGPRs: 2 blocks per CU
   const int64_t nblk = (int64_t)B * strips * chunks * segs;
   LMN_REQUIRE(nblk < (1LL << 31), "dw_bwd: grid too large");
   hipLaunchKernelGGL(dw_bwd_strip_kernel, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, x1, dpre, dx1, B, H, W, E, w5,
