@@ -1792,7 +1792,7 @@ int lmn_conv_fwd(const lmn_conv_args_t* args, lmn_stream_t stream) {
     const size_t shmem = ((size_t)T.XH * T.XW * T.CS + 2 * nct * 16) * sizeof(float);
     LMN_REQUIRE(shmem <= 64 * 1024, "conv_fwd: LDS window %zu B", shmem);
     int blocks = T.total_tiles;
-    const int maxb = 2048 / chunks > 256 ? 2048 / chunks : 256;
+    const int maxb = 1280 / chunks > 256 ? 1280 / chunks : 256;  // ~5 resident blocks per CU: one round of persistent blocks
     if (blocks > maxb) blocks = maxb;
     // epilogue instance (see the kernel): 0 plain, 2 LINEAR+SUM_SQ, 3 BN_BWD1, 4 BN_BWD2, 5 SE_BWD, 1 everything else
     int ek = 1;
