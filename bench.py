@@ -99,6 +99,9 @@ def main():
     ap.add_argument("--batch", type=int, default=8, help="images per GPU")
     ap.add_argument("--size", type=int, default=352)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--graphs", action="store_true",
+                    help="replay the step as two hipGraphs (wins when the host is the bottleneck, e.g. batch 1; at batch 8 "
+                         "the step is GPU-bound and host launches measured 7 %% faster than the replay)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -118,6 +121,8 @@ def main():
     net = LM_Net(3, 2).to(dev)
     model = DistributedLMNet(net) if world > 1 else net
     model.train()
+    if args.graphs:
+        net.enable_graphs()     # forward / backward as two hipGraph replays per step (captured during the warm-up)
     from lm_net_amd.optim import FusedAdamW
     opt = FusedAdamW(net, lr=1e-3, weight_decay=1e-4)     # torch.optim.AdamW semantics, one launch per step
     B, H, W = args.batch, args.size, args.size
@@ -133,9 +138,11 @@ def main():
         opt.step()
         return loss
 
-    for _ in range(args.warmup):
+    for _ in range(max(args.warmup, 3 if args.graphs else 0)):   # graph capture happens on the 3rd step of a shape
         step()
-    # dominant-kernel timing (HIP events on the launch stream, inside the timed region)
+    # dominant-kernel timing: HIP events on the launch stream around every dw_fwd launch -- inside the timed region
+    # when kernels are launched from the host; in graph mode (no host code runs during a replay) over 5 extra
+    # host-launched steps right after the timed region, same process, same buffers
     net._engine.kernel_events = {"dw_fwd": []}
     torch.cuda.synchronize()
     if world > 1:
@@ -151,6 +158,12 @@ def main():
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+    if net.use_graphs:
+        net.use_graphs = False
+        for _ in range(5):
+            step()
+        torch.cuda.synchronize()
+        net.use_graphs = True
     ev = net._engine.kernel_events["dw_fwd"]
     net._engine.kernel_events = None
     if rank == 0:
@@ -165,6 +178,7 @@ def main():
             "config": {"workload": "LM-Net fp32 training step (fwd + CE/Dice loss + bwd + AdamW), batch %d/GPU, %dx%d "
                                    "synthetic disc masks (BASELINE configs[1])" % (B, H, W),
                        "global_batch": world * B, "image": [3, H, W], "parallelism": "dp%d" % world,
+                       "launch": "hipGraph replay (fwd + bwd graphs per step)" if args.graphs else "host",
                        "final_loss": round(float(loss.detach()), 5)},
             "roofline": {"bound": "hbm", "kernel": "dw_fwd_strip_kernel (row A2 forward, 5x5 merged depthwise stencil + GELU-sum)",
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",

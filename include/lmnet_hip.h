@@ -33,7 +33,7 @@ extern "C" {
 
 typedef void* lmn_stream_t; /* hipStream_t */
 
-#define LMN_ABI_VERSION 1
+#define LMN_ABI_VERSION 2
 #define LMN_E_BADARG (-1)
 #define LMN_E_UNSUPPORTED (-2)
 
@@ -110,6 +110,8 @@ typedef struct {
   int32_t epilogue, act, stats_mode;
   float drop_p;       /* >0: epilogue dropout  o <- o*keep/(1-p) before the residual add          */
   uint32_t drop_seed; /* (nn.Dropout(0.1), core/modules.py:48,53,55)                              */
+  const uint32_t* seed_ctr; /* optional DEVICE word added to every dropout seed of this call: lets a captured */
+                            /* hipGraph draw a new mask per replay (the host bumps the word once per step)    */
 } lmn_conv_args_t;
 
 /* number of floats lmn_conv_pack writes for (ksize, Cout, src channel counts c[nsrc]) */
@@ -156,6 +158,7 @@ typedef struct {
   float* db;        /* or NULL */
   float* workspace; /* optional scratch for the deterministic two-stage K-split reduction (no atomics);   */
   int64_t workspace_floats; /* size lmn_conv_wgrad_workspace() asks for; NULL/0 => LDS-reduced atomics   */
+  const uint32_t* seed_ctr; /* as in lmn_conv_args_t: device word added to the dropout seeds of this call   */
 } lmn_wgrad_args_t;
 int lmn_sizeof_wgrad_args(void);
 /* floats of workspace that make lmn_conv_wgrad use the two-stage reduction for this problem (0: not useful) */

@@ -39,6 +39,46 @@ class _LMNetFunction(torch.autograd.Function):
         return (dx, None) + tuple(grads)
 
 
+class _GraphedStep:
+    """One captured training step for a fixed input shape: forward and backward hipGraphs sharing a memory pool."""
+
+    def __init__(self):
+        self.fwd = self.bwd = None
+        self.x = self.out = self.dlogits = None
+        self.cx = None
+        self.flat = None          # static flat gradient buffer (views = the returned gradients)
+        self.grads = None
+        self.warm = 0
+
+
+class _LMNetGraphFunction(torch.autograd.Function):
+    """The captured step as an autograd node: forward = replay of the forward graph on a static input copy,
+    backward = replay of the backward graph on a static copy of dlogits."""
+
+    @staticmethod
+    def forward(ctx, x, model, gs, *params):
+        gs.x.copy_(x)
+        gs.fwd.replay()
+        ctx.model, ctx.gs = model, gs
+        return gs.out.clone()
+
+    @staticmethod
+    def backward(ctx, dlogits):
+        model, gs = ctx.model, ctx.gs
+        gs.dlogits.copy_(dlogits)
+        gs.bwd.replay()
+        model._grad_flat = gs.flat
+        if model.grad_begin_hook is not None:       # data parallel: one bucketed all-reduce pass after the replay
+            model.grad_begin_hook(gs.flat)
+            model.grad_ready_hook(0, gs.flat.numel())
+            model.grad_finish_hook()
+        grads = gs.grads
+        p0 = model._param_list()[0]
+        if p0.grad is not None and p0.grad.data_ptr() == grads[0].data_ptr():
+            grads = [g.clone() for g in grads]      # accumulation into .grad that aliases the static buffer
+        return (None, None, None) + tuple(grads)
+
+
 class LM_Net(nn.Module):
     def __init__(self, channel, n_classes=2, filters=[12, 24, 48, 96, 192], deep_supervision=False):
         super().__init__()
@@ -75,6 +115,8 @@ class LM_Net(nn.Module):
         self._save_tape = False
         self._keep_taps = False
         self._taps = None
+        self.use_graphs = False   # capture the training step into hipGraphs (see enable_graphs)
+        self._graphs = {}
         # data-parallel hooks (ddp.py): begin(flat) at the start of backward, ready(lo, hi) when the
         # flat-gradient slice [lo,hi) has been enqueued, finish() at the end of backward
         self.grad_begin_hook = None
@@ -104,7 +146,62 @@ class LM_Net(nn.Module):
             raise RuntimeError("lm_net_amd.LM_Net: parameters are on %s; call model.to('cuda')" % params[0].device)
         x = x.float().contiguous() if x.dtype != torch.float32 or not x.is_contiguous() else x
         self._save_tape = torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in params))
+        if self.use_graphs and self.training and self._save_tape and not x.requires_grad and not self._keep_taps:
+            gs = self._graph_for(x)
+            if gs is not None:
+                return _LMNetGraphFunction.apply(x, self, gs, *params)
         return _LMNetFunction.apply(x, self, *params)
+
+    # ------------------------------------------------------------------ hipGraph capture of the training step
+    def enable_graphs(self, on=True):
+        """Run training steps as two hipGraph replays (forward, backward) per input shape instead of ~1700 launches:
+        the step at batch 8 / 352x352 carries ~8 ms of per-launch cost.  The first two steps of a shape run eagerly
+        (warm-up: workspaces, pack plans, allocator), the third is captured.  Contract while enabled: fixed parameter
+        storage, `zero_grad(set_to_none=True)` semantics (returned gradients are views of one static buffer; they
+        are cloned if a `.grad` still aliases it), data-parallel gradients are all-reduced after the backward
+        replay instead of bucket by bucket inside it.  Dropout draws a new mask per replay from a device-side
+        counter."""
+        self.use_graphs = bool(on)
+        if not on:
+            self._graphs = {}
+            self._engine.seed_ctr = None
+        return self
+
+    def _graph_for(self, x):
+        key = (tuple(x.shape), x.device)
+        gs = self._graphs.get(key)
+        if gs is None:
+            gs = self._graphs[key] = _GraphedStep()
+        if gs.fwd is not None:
+            return gs
+        gs.warm += 1
+        if gs.warm <= 2:
+            return None                      # eager warm-up steps
+        eng = self._engine
+        if eng.seed_ctr is None:
+            eng.seed_ctr = torch.zeros(1, device=x.device, dtype=torch.int32)
+        params = self._param_list()
+        gs.x = x.clone()
+        # (no extra warm-up pass here: the two eager steps already sized the workspaces / pack plans / zero pools, and
+        #  another training-mode forward would update the BatchNorm running statistics once too often)
+        torch.cuda.synchronize(x.device)
+        hooks = (self.grad_begin_hook, self.grad_ready_hook, self.grad_finish_hook)
+        self.grad_begin_hook = self.grad_ready_hook = self.grad_finish_hook = None   # no collectives inside the capture
+        eng.capturing = True
+        try:
+            gs.fwd = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gs.fwd):
+                gs.cx = Ctx()
+                gs.out = self._forward_impl(gs.x, gs.cx)
+            gs.dlogits = torch.zeros_like(gs.out)
+            gs.bwd = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gs.bwd, pool=gs.fwd.pool()):
+                _, grads = self._backward_impl(gs.cx, gs.dlogits, False)
+            gs.flat, gs.grads = self._grad_flat, grads
+        finally:
+            eng.capturing = False
+            self.grad_begin_hook, self.grad_ready_hook, self.grad_finish_hook = hooks
+        return gs
 
     def _param_list(self):
         """model.parameters() as a cached list (walking 300 sub-modules costs ~1.5 ms per call); the Parameter
@@ -120,6 +217,8 @@ class LM_Net(nn.Module):
         eng.training = self.training
         if self.training:
             eng.step += 1
+            if eng.seed_ctr is not None:
+                eng.seed_ctr += 0x2545F49          # odd increment: a fresh dropout stream per step, also under replay
             self._bump_num_batches_tracked()
         eng.begin_pass(False, x.device)
         try:
@@ -242,6 +341,7 @@ class LM_Net(nn.Module):
 
     def _done(self, name):
         if self.grad_ready_hook is not None:
+            self._engine.join_side(self._grad_flat.device)    # the block's weight gradients run on the side stream
             self.grad_ready_hook(*self._grad_layout["blocks"][name])
 
     # ------------------------------------------------------------------ backward schedule
@@ -257,6 +357,7 @@ class LM_Net(nn.Module):
         eng.begin_pass(True, dlogits.device)
         try:
             dx = self._backward_body(cx, dlogits, need_dx, G)
+            eng.join_side(dlogits.device)
         finally:
             eng.end_pass()
             eng.G = None

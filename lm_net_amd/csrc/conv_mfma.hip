@@ -47,6 +47,7 @@ __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<
 template <int TAPS, int NPG, int NCT>
 __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams P) {
   const lmn_conv_args_t& A = P.a;
+  const uint32_t soff = A.seed_ctr ? *A.seed_ctr : 0u;  // device-side dropout stream offset (graph replays: one bump per step)
   const int lane = threadIdx.x & 63;
   const int q = lane >> 4, n = lane & 15;
   const int wave = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -199,7 +200,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams P) {
             for (int g = 0; g < NPG; ++g) {
               const uint32_t idx = (uint32_t)(inpix[g] * S.C + chs);
 #pragma unroll
-              for (int j = 0; j < 4; ++j) xv[g][j] *= lmn_drop_scale(S.drop_seed, idx + j, S.drop_p, P.inv_keep_src[s]);
+              for (int j = 0; j < 4; ++j) xv[g][j] *= lmn_drop_scale(S.drop_seed + soff, idx + j, S.drop_p, P.inv_keep_src[s]);
             }
           }
           if (S.scale) {
@@ -295,7 +296,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams P) {
         if (A.drop_p > 0.f) {
           const uint32_t idx = (uint32_t)(opx * A.Cout + cos);
 #pragma unroll
-          for (int r = 0; r < 4; ++r) o[r] *= lmn_drop_scale(A.drop_seed, idx + r, A.drop_p, P.inv_keep_ep);
+          for (int r = 0; r < 4; ++r) o[r] *= lmn_drop_scale(A.drop_seed + soff, idx + r, A.drop_p, P.inv_keep_ep);
         }
         if (A.residual) o += ld4(A.residual + opx * A.res_cstride + cos);
         if (A.out && live) *reinterpret_cast<f32x4*>(A.out + opx * A.out_cstride + cos) = o;
@@ -346,6 +347,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams P) {
 template <int TAPS, int NCT, int EPI>
 __global__ __launch_bounds__(256) void conv_tile_kernel(const ConvParams P) {
   const lmn_conv_args_t& A = P.a;
+  const uint32_t soff = A.seed_ctr ? *A.seed_ctr : 0u;  // device-side dropout stream offset (graph replays: one bump per step)
   // EPI: 0 plain (LINEAR / AFFINE_ACT, no statistics), 1 generic, 2 LINEAR + SUM_SQ statistics, 3 BN_BWD1, 4 BN_BWD2,
   // 5 SE_BWD.  For EPI >= 2 the epilogue kind is a compile-time constant: each instance carries only its own code
   // (the generic instance keeps every variant resident: 125-160 VGPRs + spills, and measured 20-40 us over its
@@ -452,7 +454,7 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(const ConvParams P) {
           }
           if (S.flags & LMN_SRC_DROP) {
 #pragma unroll
-            for (int k = 0; k < 4; ++k) v[k] *= lmn_drop_scale(S.drop_seed, (uint32_t)(gp * S.C + chs + k), S.drop_p, P.inv_keep_src[s]);
+            for (int k = 0; k < 4; ++k) v[k] *= lmn_drop_scale(S.drop_seed + soff, (uint32_t)(gp * S.C + chs + k), S.drop_p, P.inv_keep_src[s]);
           }
           if (S.scale) v *= ld4(S.scale + b * S.C + chs);
           if (!ok) v = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -549,7 +551,7 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(const ConvParams P) {
         if (has_drop) {
           const uint32_t idx = opx * A.Cout + cos;
 #pragma unroll
-          for (int r = 0; r < 4; ++r) o[r] *= lmn_drop_scale(A.drop_seed, idx + r, A.drop_p, P.inv_keep_ep);
+          for (int r = 0; r < 4; ++r) o[r] *= lmn_drop_scale(A.drop_seed + soff, idx + r, A.drop_p, P.inv_keep_ep);
         }
         if (A.residual) o += ld4(A.residual + opx * A.res_cstride + cos);
         if (A.out && live) *reinterpret_cast<f32x4*>(A.out + opx * A.out_cstride + cos) = o;
@@ -598,6 +600,7 @@ template <int TAPS, int NCW, int EPI>
 __global__ __launch_bounds__(256) void conv_tileM_kernel(const ConvParams P) {
   constexpr int NCT = 4 * NCW;  // cout tiles per block
   const lmn_conv_args_t& A = P.a;
+  const uint32_t soff = A.seed_ctr ? *A.seed_ctr : 0u;  // device-side dropout stream offset (graph replays: one bump per step)
   // EPI: 0 plain (LINEAR / AFFINE_ACT, no statistics), 1 generic, 2 LINEAR + SUM_SQ statistics, 3 BN_BWD1, 4 BN_BWD2,
   // 5 SE_BWD.  For EPI >= 2 the epilogue kind is a compile-time constant: each instance carries only its own code
   // (the generic instance keeps every variant resident: 125-160 VGPRs + spills, and measured 20-40 us over its
@@ -704,7 +707,7 @@ __global__ __launch_bounds__(256) void conv_tileM_kernel(const ConvParams P) {
           }
           if (S.flags & LMN_SRC_DROP) {
 #pragma unroll
-            for (int k = 0; k < 4; ++k) v[k] *= lmn_drop_scale(S.drop_seed, (uint32_t)(gp * S.C + chs + k), S.drop_p, P.inv_keep_src[s]);
+            for (int k = 0; k < 4; ++k) v[k] *= lmn_drop_scale(S.drop_seed + soff, (uint32_t)(gp * S.C + chs + k), S.drop_p, P.inv_keep_src[s]);
           }
           if (S.scale) v *= ld4(S.scale + b * S.C + chs);
           if (!ok) v = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -800,7 +803,7 @@ __global__ __launch_bounds__(256) void conv_tileM_kernel(const ConvParams P) {
         if (has_drop) {
           const uint32_t idx = opx * A.Cout + cos;
 #pragma unroll
-          for (int r = 0; r < 4; ++r) o[r] *= lmn_drop_scale(A.drop_seed, idx + r, A.drop_p, P.inv_keep_ep);
+          for (int r = 0; r < 4; ++r) o[r] *= lmn_drop_scale(A.drop_seed + soff, idx + r, A.drop_p, P.inv_keep_ep);
         }
         if (A.residual) o += ld4(A.residual + opx * A.res_cstride + cos);
         if (A.out && live) *reinterpret_cast<f32x4*>(A.out + opx * A.out_cstride + cos) = o;
@@ -930,6 +933,7 @@ struct WgradParams {
 template <int TAPS, int NMT, int NNT, int U>
 __global__ __launch_bounds__(256) void wgrad_mfma_kernel(const WgradParams P) {
   const lmn_wgrad_args_t& A = P.a;
+  const uint32_t soff = A.seed_ctr ? *A.seed_ctr : 0u;  // device-side dropout stream offset (graph replays: one bump per step)
   const int lane = threadIdx.x & 63;
   const int q = lane >> 4, n = lane & 15;
   const int wave = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -957,7 +961,7 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(const WgradParams P) {
     sC[t] = A.src[s].C;
     scs[t] = A.src[s].cstride;
     sflags[t] = A.src[s].flags;
-    sseed[t] = A.src[s].drop_seed;
+    sseed[t] = A.src[s].drop_seed + soff;
     sp[t] = A.src[s].drop_p;
     sik[t] = P.inv_keep_src[s];
     sch[t] = (ok && ch < A.src[s].C) ? ch : -1;
@@ -1030,7 +1034,7 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(const WgradParams P) {
       for (int m = 0; m < NMT; ++m) {
         float v = av[u][m];
         if (any_tf && (A.dy_flags & LMN_SRC_DROP))
-          v *= lmn_drop_scale(A.dy_seed, (uint32_t)(opix_s * A.Cout + (mok[m] ? (mt0 + m) * 16 + n : 0)), A.dy_p, P.inv_keep_dy);
+          v *= lmn_drop_scale(A.dy_seed + soff, (uint32_t)(opix_s * A.Cout + (mok[m] ? (mt0 + m) * 16 + n : 0)), A.dy_p, P.inv_keep_dy);
         av[u][m] = (pok && mok[m]) ? v : 0.f;
       }
 #pragma unroll
@@ -1127,6 +1131,7 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(const WgradParams P) {
 template <int TAPS, int NMT, int NNT>
 __global__ __launch_bounds__(256, 2) void wgrad_lds_kernel(const WgradParams P) {
   const lmn_wgrad_args_t& A = P.a;
+  const uint32_t soff = A.seed_ctr ? *A.seed_ctr : 0u;  // device-side dropout stream offset (graph replays: one bump per step)
   extern __shared__ __attribute__((aligned(16))) float smem[];
   // one 16-channel PLANE per cin / cout tile: [tile][pixel][16] -- a K step reads 4 pixels x 16 channels = 64
   // consecutive floats of one plane (conflict-free ds_read_b32 at stride 1), and no padding is needed
@@ -1157,7 +1162,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_lds_kernel(const WgradParams P) 
     tC[t] = nt < P.NNTT ? A.src[sidx].C : 0;
     tcs[t] = A.src[sidx].cstride;
     tflags[t] = A.src[sidx].flags;
-    tseed[t] = A.src[sidx].drop_seed;
+    tseed[t] = A.src[sidx].drop_seed + soff;
     tp_[t] = A.src[sidx].drop_p;
     tik[t] = P.inv_keep_src[sidx];
     tch0[t] = (nt - P.ntile_off[sidx]) * 16;
@@ -1249,7 +1254,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_lds_kernel(const WgradParams P) 
         f32x4 w = v[m];
         if (A.dy_flags & LMN_SRC_DROP) {
 #pragma unroll
-          for (int k = 0; k < 4; ++k) w[k] *= lmn_drop_scale(A.dy_seed, (uint32_t)(gp * A.Cout + cos + k), A.dy_p, P.inv_keep_dy);
+          for (int k = 0; k < 4; ++k) w[k] *= lmn_drop_scale(A.dy_seed + soff, (uint32_t)(gp * A.Cout + cos + k), A.dy_p, P.inv_keep_dy);
         }
         if (!(inb && cosv[m] >= 0)) w = f32x4{0.f, 0.f, 0.f, 0.f};
         *reinterpret_cast<f32x4*>(&YS[(m * NP + pix) * P.CSy + j * 4]) = w;
@@ -1359,6 +1364,7 @@ template <int NMT, int NNT>
 __global__ __launch_bounds__(256) void wgrad_1x1_kernel(const WgradParams P) {
   constexpr int U = 8;
   const lmn_wgrad_args_t& A = P.a;
+  const uint32_t soff = A.seed_ctr ? *A.seed_ctr : 0u;  // device-side dropout stream offset (graph replays: one bump per step)
   const int lane = threadIdx.x & 63;
   const int q = lane >> 4, n = lane & 15;
   const int wvb = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -1385,7 +1391,7 @@ __global__ __launch_bounds__(256) void wgrad_1x1_kernel(const WgradParams P) {
     sC[t] = A.src[s].C;
     scs[t] = A.src[s].cstride;
     sflags[t] = A.src[s].flags;
-    sseed[t] = A.src[s].drop_seed;
+    sseed[t] = A.src[s].drop_seed + soff;
     sp[t] = A.src[s].drop_p;
     sik[t] = P.inv_keep_src[s];
     sch[t] = (nt < P.NNTT && ch < A.src[s].C) ? ch : -1;
@@ -1430,7 +1436,7 @@ __global__ __launch_bounds__(256) void wgrad_1x1_kernel(const WgradParams P) {
 #pragma unroll
       for (int m = 0; m < NMT; ++m) {
         float v = av[u][m];
-        if (A.dy_flags & LMN_SRC_DROP) v *= lmn_drop_scale(A.dy_seed, (uint32_t)(ps * A.Cout + (mco[m] >= 0 ? mco[m] : 0)), A.dy_p, P.inv_keep_dy);
+        if (A.dy_flags & LMN_SRC_DROP) v *= lmn_drop_scale(A.dy_seed + soff, (uint32_t)(ps * A.Cout + (mco[m] >= 0 ? mco[m] : 0)), A.dy_p, P.inv_keep_dy);
         av[u][m] = (ok && mco[m] >= 0) ? v : 0.f;
       }
 #pragma unroll

@@ -80,6 +80,11 @@ class Engine:
         self.training = True
         self.seed_base = 0x1234567
         self.step = 0
+        self.seed_ctr = None      # int32[1] device tensor while a hipGraph of the pass is captured / replayed
+        self.overlap_wgrad = True # weight gradients on a side stream (see wgrad)
+        self.capturing = False
+        self.side = None
+        self.side_busy = False
         self.zpool_fwd, self.zpool_bwd = ZeroPool(), ZeroPool()
         self.packs_fwd, self.packs_bwd = hip.PackPlan(), hip.PackPlan()
         self.kernel_events = None  # bench.py: {"dw_fwd": [(start_event, end_event, algorithmic_bytes), ...]}
@@ -91,6 +96,7 @@ class Engine:
         _POOL[0] = pool
         hip._STREAM[0] = None
         hip._STREAM[0] = hip._stream()          # one stream lookup per pass instead of one per launch
+        hip._SEED_CTR[0] = self.seed_ctr
         plan = self.packs_bwd if backward else self.packs_fwd
         plan.refresh()            # all persistent weights of this pass re-packed in one launch
         hip._PLAN[0] = plan
@@ -101,8 +107,11 @@ class Engine:
         _POOL[0] = None
         hip._PLAN[0] = None
         hip._STREAM[0] = None
+        hip._SEED_CTR[0] = None
 
     def _seed(self, tag):
+        if self.seed_ctr is not None:   # graph mode: the step-dependent part lives in device memory (hip._SEED_CTR)
+            return (self.seed_base + 0x9E3779B1 * tag) & 0xFFFFFFFF
         return (self.seed_base + 0x9E3779B1 * (self.step * 64 + tag)) & 0xFFFFFFFF
 
     @staticmethod
@@ -141,9 +150,45 @@ class Engine:
         B = d.shape[0]
         Ho = (Hin + 2 * (k // 2) - k) // s + 1
         Wo = (Win + 2 * (k // 2) - k) // s + 1
+        explicit = dW is not None                      # caller reads the result on the main stream right away
         dW = self.G[w_param] if dW is None else dW
         db = (self.G[b_param] if b_param is not None else None) if db is None else db
-        hip.conv_wgrad(srcs, dy, dW, db, B=B, Hin=Hin, Win=Win, Hout=Ho, Wout=Wo, Cout=dW.shape[0], ksize=k, stride=s, **kw)
+        if not self.overlap_wgrad or self.capturing:
+            hip.conv_wgrad(srcs, dy, dW, db, B=B, Hin=Hin, Win=Win, Hout=Ho, Wout=Wo, Cout=dW.shape[0], ksize=k, stride=s, **kw)
+            return
+        # Weight gradients feed nothing downstream in the backward chain: they run on a side stream and overlap the
+        # data-gradient chain on the main stream (at batch 8 most kernels of levels 2-4 cannot fill 256 CUs alone).
+        # Order: side waits for everything enqueued on main so far; inputs are marked as in use on the side stream so
+        # the caching allocator does not recycle them early; main joins the side stream at the end of backward
+        # (and before every data-parallel bucket hand-over).
+        main = torch.cuda.current_stream(d.device)
+        side = self._side_stream(d.device)
+        side.wait_stream(main)
+        saved = hip._STREAM[0]
+        hip._STREAM[0] = hip.C.c_void_p(side.cuda_stream)
+        try:
+            hip.conv_wgrad(srcs, dy, dW, db, B=B, Hin=Hin, Win=Win, Hout=Ho, Wout=Wo, Cout=dW.shape[0], ksize=k, stride=s, **kw)
+        finally:
+            hip._STREAM[0] = saved
+        d.record_stream(side)
+        for src in srcs:
+            self._t(src).record_stream(side)
+            if isinstance(src, dict) and src.get("scale") is not None:
+                src["scale"].record_stream(side)
+        self.side_busy = True
+        if explicit:
+            self.join_side(d.device)
+
+    def _side_stream(self, device):
+        if self.side is None or self.side.device != device:
+            self.side = torch.cuda.Stream(device=device)
+        return self.side
+
+    def join_side(self, device):
+        """Make the main stream wait for the weight-gradient stream."""
+        if self.side is not None and self.side_busy:
+            torch.cuda.current_stream(device).wait_stream(self.side)
+            self.side_busy = False
 
     def bn_stats(self, bn, sums, count, ref):
         """(mean, rstd, A, shift) of a BatchNorm from batch sums [2,C] (training) or running stats (eval)."""

@@ -17,7 +17,7 @@ SRC_GELU, SRC_DROP = 1, 2
 EP_LINEAR, EP_AFFINE_ACT, EP_DGELU, EP_BN_BWD1, EP_BN_BWD2, EP_SE_BWD = 0, 1, 2, 3, 4, 5
 ACT_NONE, ACT_HSWISH, ACT_GELU = 0, 1, 2
 STATS_NONE, STATS_SUM_SQ, STATS_EP = 0, 1, 2
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 
 class SrcT(C.Structure):
@@ -33,7 +33,7 @@ class ConvArgs(C.Structure):
                 ("aux", C.c_void_p), ("residual", C.c_void_p), ("out", C.c_void_p), ("stats", C.c_void_p),
                 ("aux_cstride", C.c_int32), ("res_cstride", C.c_int32), ("out_cstride", C.c_int32),
                 ("epilogue", C.c_int32), ("act", C.c_int32), ("stats_mode", C.c_int32),
-                ("drop_p", C.c_float), ("drop_seed", C.c_uint32)]
+                ("drop_p", C.c_float), ("drop_seed", C.c_uint32), ("seed_ctr", C.c_void_p)]
 
 
 class WgradArgs(C.Structure):
@@ -41,7 +41,7 @@ class WgradArgs(C.Structure):
                 ("ksize", C.c_int32), ("stride", C.c_int32), ("nsrc", C.c_int32), ("Cout", C.c_int32),
                 ("src", SrcT * 3), ("dy", C.c_void_p), ("dy_cstride", C.c_int32), ("dy_flags", C.c_int32),
                 ("dy_seed", C.c_uint32), ("dy_p", C.c_float), ("dW", C.c_void_p), ("db", C.c_void_p),
-                ("workspace", C.c_void_p), ("workspace_floats", C.c_int64)]
+                ("workspace", C.c_void_p), ("workspace_floats", C.c_int64), ("seed_ctr", C.c_void_p)]
 
 
 # every symbol include/lmnet_hip.h declares (the CPU test suite checks the library exports all of them)
@@ -98,6 +98,7 @@ def _p(t):
     return C.c_void_p(t.data_ptr())
 
 
+_SEED_CTR = [None]  # device int32[1] added to every dropout seed (graph mode: bumped once per step), or None
 _STREAM = [None]   # stream handle of the pass in flight (engine.begin_pass): torch.cuda.current_stream() costs ~3 us
 
 
@@ -299,6 +300,7 @@ def conv_fwd(srcs, wpack, out, *, B, Hin, Win, Hout, Wout, Cout, ksize=1, stride
     a.stats = stats.data_ptr() if stats is not None else None
     a.epilogue, a.act, a.stats_mode = epilogue, act, stats_mode
     a.drop_p, a.drop_seed = drop_p, drop_seed
+    a.seed_ctr = _SEED_CTR[0].data_ptr() if _SEED_CTR[0] is not None else None
     _check(load().lmn_conv_fwd(C.byref(a), _stream()), "conv_fwd")
 
 
@@ -317,6 +319,7 @@ def conv_wgrad(srcs, dy, dW, db, *, B, Hin, Win, Hout, Wout, Cout, ksize=1, stri
     if need > 0:
         ws = _workspace(dW.device, need)
         a.workspace, a.workspace_floats = ws.data_ptr(), ws.numel()
+    a.seed_ctr = _SEED_CTR[0].data_ptr() if _SEED_CTR[0] is not None else None
     _check(load().lmn_conv_wgrad(C.byref(a), _stream()), "conv_wgrad")
 
 
