@@ -85,6 +85,8 @@ class Engine:
         self.capturing = False
         self.side = None
         self.side_busy = False
+        self.side_rr = 0
+        self.n_side = 1
         self.zpool_fwd, self.zpool_bwd = ZeroPool(), ZeroPool()
         self.packs_fwd, self.packs_bwd = hip.PackPlan(), hip.PackPlan()
         self.kernel_events = None  # bench.py: {"dw_fwd": [(start_event, end_event, algorithmic_bytes), ...]}
@@ -180,14 +182,18 @@ class Engine:
             self.join_side(d.device)
 
     def _side_stream(self, device):
-        if self.side is None or self.side.device != device:
-            self.side = torch.cuda.Stream(device=device)
-        return self.side
+        """Weight-gradient streams, used round-robin (gradients of different layers are independent of each other)."""
+        if self.side is None or self.side[0].device != device:
+            self.side = [torch.cuda.Stream(device=device) for _ in range(self.n_side)]
+        self.side_rr = (self.side_rr + 1) % len(self.side)
+        return self.side[self.side_rr]
 
     def join_side(self, device):
-        """Make the main stream wait for the weight-gradient stream."""
+        """Make the main stream wait for the weight-gradient streams."""
         if self.side is not None and self.side_busy:
-            torch.cuda.current_stream(device).wait_stream(self.side)
+            main = torch.cuda.current_stream(device)
+            for s in self.side:
+                main.wait_stream(s)
             self.side_busy = False
 
     def bn_stats(self, bn, sums, count, ref):

@@ -327,11 +327,14 @@ _ws_cache = {}
 
 
 def _workspace(device, nfloats):
-    """Grow-only scratch buffer per device (stream-ordered reuse: all users run on the current stream)."""
-    ws = _ws_cache.get(device)
+    """Scratch buffer of the weight-gradient K-split reduction, one per (device, launch stream): users of one
+    stream reuse it in stream order.  Allocated once at the library's cap (lmn_conv_wgrad_workspace never asks for
+    more than 16 M floats), so it is never re-allocated under kernels still in flight on another stream."""
+    key = (device, _STREAM[0].value if _STREAM[0] is not None else 0)
+    ws = _ws_cache.get(key)
     if ws is None or ws.numel() < nfloats:
-        ws = torch.empty(max(nfloats, 1 << 20), device=device, dtype=torch.float32)
-        _ws_cache[device] = ws
+        ws = torch.empty(max(nfloats, 16 << 20), device=device, dtype=torch.float32)
+        _ws_cache[key] = ws
     return ws
 
 
