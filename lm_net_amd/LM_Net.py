@@ -382,26 +382,53 @@ class LM_Net(nn.Module):
         dx9 = torch.empty_like(A["x9"])
         eng.conv_T(dy4, A["wh"], dx9, Hin=H, Win=W)
         self._done("output_layer")
-        # decoder
+        gacc = {id(A[k]): GradSlot() for k in ("x1", "x2", "x3", "x4")}
+        main = torch.cuda.current_stream(dev)
+        fork = eng.branch_overlap and not eng.capturing
+        bst = eng.branch_stream(dev) if fork else None
+
+        def branch(nat, skip, dt):
+            """Backward of one neighborhood-attention block and its skip fuser.  Their only input is dt (the decoder
+            stage gradient) and nothing on the decoder chain waits for them, so they run on the branch stream while
+            the main stream continues with the coarser decoder stages (few of those kernels fill 256 CUs alone)."""
+            if not fork:
+                return nat, skip, dt
+            bst.wait_stream(main)
+            dt.record_stream(bst)
+            with eng.on_stream(bst):
+                dxs = eng.nat_bwd(nat, dt, cx)
+                eng.skip_bwd(skip, dxs, cx, gacc)
+                eng.join_side(dev)                       # this chain's weight gradients
+            return None
+
+        # decoder (the branch work of level k is forked as soon as dt_k exists)
         dt4 = eng.stage_bwd(self.dconv4, dx9, cx); self._done("dconv4")
+        p4 = branch(self.natt4, self.skip4, dt4)
         dx8 = eng.up_bwd(self.up4, dt4, cx, A["x8"].shape); self._done("up4")
         dt3 = eng.stage_bwd(self.dconv3, dx8, cx); self._done("dconv3")
+        p3 = branch(self.natt3, self.skip3, dt3)
         dx7 = eng.up_bwd(self.up3, dt3, cx, A["x7"].shape); self._done("up3")
         dt2 = eng.stage_bwd(self.dconv2, dx7, cx); self._done("dconv2")
+        p2 = branch(self.natt2, self.skip2, dt2)
         dx6 = eng.up_bwd(self.up2, dt2, cx, A["x6"].shape); self._done("up2")
         dt1 = eng.stage_bwd(self.dconv1, dx6, cx); self._done("dconv1")
+        p1 = branch(self.natt1, self.skip1, dt1)
         dx5 = eng.up_bwd(self.up1, dt1, cx, A["x5"].shape); self._done("up1")
-        # neighborhood-attention blocks (their outputs were the residual inputs of up1..4: gradient = dt_k)
-        dxs4 = eng.nat_bwd(self.natt4, dt4, cx); self._done("natt4")
-        dxs3 = eng.nat_bwd(self.natt3, dt3, cx); self._done("natt3")
-        dxs2 = eng.nat_bwd(self.natt2, dt2, cx); self._done("natt2")
-        dxs1 = eng.nat_bwd(self.natt1, dt1, cx); self._done("natt1")
-        # skip fusers: accumulate into the encoder activations' gradients
-        gacc = {id(A[k]): GradSlot() for k in ("x1", "x2", "x3", "x4")}
-        eng.skip_bwd(self.skip4, dxs4, cx, gacc); self._done("skip4")
-        eng.skip_bwd(self.skip3, dxs3, cx, gacc); self._done("skip3")
-        eng.skip_bwd(self.skip2, dxs2, cx, gacc); self._done("skip2")
-        eng.skip_bwd(self.skip1, dxs1, cx, gacc); self._done("skip1")
+        if fork:
+            main.wait_stream(bst)                        # join: the encoder gradients in gacc are complete
+            for slot in gacc.values():
+                if slot.g is not None:
+                    slot.g.record_stream(main)
+            for name in ("natt4", "natt3", "natt2", "natt1", "skip4", "skip3", "skip2", "skip1"):
+                self._done(name)
+        else:
+            # neighborhood-attention blocks (their outputs were the residual inputs of up1..4: gradient = dt_k)
+            dxs = [eng.nat_bwd(p[0], p[2], cx) for p in (p4, p3, p2, p1)]
+            for k, name in enumerate(("natt4", "natt3", "natt2", "natt1")):
+                self._done(name)
+            # skip fusers: accumulate into the encoder activations' gradients
+            for k, (p, name) in enumerate(zip((p4, p3, p2, p1), ("skip4", "skip3", "skip2", "skip1"))):
+                eng.skip_bwd(p[1], dxs[k], cx, gacc); self._done(name)
         # bottleneck
         dcat = eng.gft_bwd(self.gft, dx5, cx); self._done("gft")
         off = 0

@@ -13,6 +13,8 @@ forward and backward are explicit kernel schedules over NHWC fp32 activations:
     backward-completion order, so data-parallel gradient buckets are contiguous slices that can be
     all-reduced on a side stream as soon as their last kernel has been enqueued (``ddp.py``).
 """
+import contextlib
+
 import torch
 
 from . import hip
@@ -83,10 +85,9 @@ class Engine:
         self.seed_ctr = None      # int32[1] device tensor while a hipGraph of the pass is captured / replayed
         self.overlap_wgrad = True # weight gradients on a side stream (see wgrad)
         self.capturing = False
-        self.side = None
-        self.side_busy = False
-        self.side_rr = 0
-        self.n_side = 1
+        self.sides = {}           # issuing stream handle -> [weight-gradient stream, busy]
+        self.branch = None        # second compute stream of the backward schedule (LM_Net._backward_body)
+        self.branch_overlap = True
         self.zpool_fwd, self.zpool_bwd = ZeroPool(), ZeroPool()
         self.packs_fwd, self.packs_bwd = hip.PackPlan(), hip.PackPlan()
         self.kernel_events = None  # bench.py: {"dw_fwd": [(start_event, end_event, algorithmic_bytes), ...]}
@@ -164,7 +165,7 @@ class Engine:
         # the caching allocator does not recycle them early; main joins the side stream at the end of backward
         # (and before every data-parallel bucket hand-over).
         main = torch.cuda.current_stream(d.device)
-        side = self._side_stream(d.device)
+        side = self._side_stream(main)
         side.wait_stream(main)
         saved = hip._STREAM[0]
         hip._STREAM[0] = hip.C.c_void_p(side.cuda_stream)
@@ -177,24 +178,42 @@ class Engine:
             self._t(src).record_stream(side)
             if isinstance(src, dict) and src.get("scale") is not None:
                 src["scale"].record_stream(side)
-        self.side_busy = True
         if explicit:
             self.join_side(d.device)
 
-    def _side_stream(self, device):
-        """Weight-gradient streams, used round-robin (gradients of different layers are independent of each other)."""
-        if self.side is None or self.side[0].device != device:
-            self.side = [torch.cuda.Stream(device=device) for _ in range(self.n_side)]
-        self.side_rr = (self.side_rr + 1) % len(self.side)
-        return self.side[self.side_rr]
+    def _side_stream(self, issuing):
+        """The weight-gradient stream paired with the issuing stream (main, or the branch stream of LM_Net's
+        backward): each chain joins only its own weight gradients."""
+        key = issuing.cuda_stream
+        ent = self.sides.get(key)
+        if ent is None:
+            ent = self.sides[key] = [torch.cuda.Stream(device=issuing.device), False]
+        ent[1] = True
+        return ent[0]
 
     def join_side(self, device):
-        """Make the main stream wait for the weight-gradient streams."""
-        if self.side is not None and self.side_busy:
-            main = torch.cuda.current_stream(device)
-            for s in self.side:
-                main.wait_stream(s)
-            self.side_busy = False
+        """Make the current stream wait for its weight-gradient stream."""
+        cur = torch.cuda.current_stream(device)
+        ent = self.sides.get(cur.cuda_stream)
+        if ent is not None and ent[1]:
+            cur.wait_stream(ent[0])
+            ent[1] = False
+
+    @contextlib.contextmanager
+    def on_stream(self, s):
+        """Launch everything inside the block on stream `s` (torch allocations and the C-ABI calls alike)."""
+        prev = hip._STREAM[0]
+        with torch.cuda.stream(s):
+            hip._STREAM[0] = hip.C.c_void_p(s.cuda_stream)
+            try:
+                yield
+            finally:
+                hip._STREAM[0] = prev
+
+    def branch_stream(self, device):
+        if self.branch is None or self.branch.device != device:
+            self.branch = torch.cuda.Stream(device=device)
+        return self.branch
 
     def bn_stats(self, bn, sums, count, ref):
         """(mean, rstd, A, shift) of a BatchNorm from batch sums [2,C] (training) or running stats (eval)."""
