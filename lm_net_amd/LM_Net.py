@@ -233,13 +233,44 @@ class LM_Net(nn.Module):
         xin = torch.empty(B, H, W, c4, device=x.device, dtype=torch.float32)
         hip.nchw_to_nhwc(x, xin)
         f = self.filters
+        main = torch.cuda.current_stream(x.device)
+        fork = eng.branch_overlap and not eng.capturing
+        bst = eng.branch_stream(x.device) if fork else None
+
+        def chain(skip, nat, xs_in, tag):
+            """Skip fuser + neighborhood-attention block of one level: needs only encoder outputs and is needed
+            only by the decoder stage of its level, so it runs on the branch stream as soon as its inputs exist
+            (level 0 -- the heavy one -- right after conv2) while the main stream goes down the encoder and
+            through the GFT bottleneck, whose small feature maps cannot fill the GPU."""
+            if not fork:
+                xs = eng.skip_fwd(skip, xs_in, cx)
+                return eng.nat_fwd(nat, xs, cx, tag=tag), None, xs
+            bst.wait_stream(main)
+            with eng.on_stream(bst):
+                xs = eng.skip_fwd(skip, xs_in, cx)
+                out = eng.nat_fwd(nat, xs, cx, tag=tag)
+            ev = torch.cuda.Event()
+            ev.record(bst)
+            return out, ev, xs
+
+        def need(res):
+            out, ev, _ = res
+            if ev is not None:
+                main.wait_event(ev)
+                out.record_stream(main)
+            return out
+
         x1 = eng.stage_fwd(self.conv1, xin, cx)
         xd1 = torch.empty(B, H // 2, W // 2, f[1], device=x.device); eng.conv3_fwd(self.down1[0], x1, xd1, s=2)
         x2 = eng.stage_fwd(self.conv2, xd1, cx)
+        r4 = chain(self.skip4, self.natt4, (x1, x2), 8) if fork else None
         xd2 = torch.empty(B, H // 4, W // 4, f[2], device=x.device); eng.conv3_fwd(self.down2[0], x2, xd2, s=2)
         x3 = eng.stage_fwd(self.conv3, xd2, cx)
+        r3 = chain(self.skip3, self.natt3, (x1, x2, x3), 6) if fork else None
         xd3 = torch.empty(B, H // 8, W // 8, f[3], device=x.device); eng.conv3_fwd(self.down3[0], x3, xd3, s=2)
         x4 = eng.stage_fwd(self.conv4, xd3, cx)
+        r1 = chain(self.skip1, self.natt1, (x3, x4), 2) if fork else None
+        r2 = chain(self.skip2, self.natt2, (x2, x3, x4), 4) if fork else None
         # PyramidPool: mean-pool x1..x4 onto the 1/16 grid, down4 writes x_down4 straight into its slice
         h, w = H // 16, W // 16
         catp = torch.empty(B, h, w, sum(f), device=x.device)
@@ -249,18 +280,21 @@ class LM_Net(nn.Module):
             off += t.shape[-1]
         eng.conv3_fwd(self.down4[0], x4, V(catp, off, f[4]), s=2)
         x5 = eng.gft_fwd(self.gft, catp, cx, tag=0)
-        xs1 = eng.skip_fwd(self.skip1, (x3, x4), cx)
-        xs2 = eng.skip_fwd(self.skip2, (x2, x3, x4), cx)
-        xs3 = eng.skip_fwd(self.skip3, (x1, x2, x3), cx)
-        xs4 = eng.skip_fwd(self.skip4, (x1, x2), cx)
-        x46 = eng.nat_fwd(self.natt1, xs1, cx, tag=2)
-        x37 = eng.nat_fwd(self.natt2, xs2, cx, tag=4)
-        x28 = eng.nat_fwd(self.natt3, xs3, cx, tag=6)
-        x19 = eng.nat_fwd(self.natt4, xs4, cx, tag=8)
+        if not fork:    # the reference's order (core/LM_Net.py:107-116)
+            r1 = chain(self.skip1, self.natt1, (x3, x4), 2)
+            r2 = chain(self.skip2, self.natt2, (x2, x3, x4), 4)
+            r3 = chain(self.skip3, self.natt3, (x1, x2, x3), 6)
+            r4 = chain(self.skip4, self.natt4, (x1, x2), 8)
+        x46 = need(r1)
         x6 = eng.stage_fwd(self.dconv1, eng.up_fwd(self.up1, x5, x46, cx), cx)
+        x37 = need(r2)
         x7 = eng.stage_fwd(self.dconv2, eng.up_fwd(self.up2, x6, x37, cx), cx)
+        x28 = need(r3)
         x8 = eng.stage_fwd(self.dconv3, eng.up_fwd(self.up3, x7, x28, cx), cx)
+        x19 = need(r4)
         x9 = eng.stage_fwd(self.dconv4, eng.up_fwd(self.up4, x8, x19, cx), cx)
+        if fork:
+            main.wait_stream(bst)
         # segmentation head: rows padded to a multiple of 4, then NHWC -> NCHW
         ncp = (self.n_classes + 3) // 4 * 4
         wh, bh = self._head_padded(ncp)
@@ -271,7 +305,7 @@ class LM_Net(nn.Module):
         if cx is not None:
             cx.t["act"] = dict(xin=xin, x1=x1, x2=x2, x3=x3, x4=x4, xd1=xd1, xd2=xd2, xd3=xd3, catp=catp, x5=x5, x6=x6,
                                x7=x7, x8=x8, x9=x9, wh=wh, shape=(B, H, W))
-        self._taps = dict(x1=x1, x2=x2, x3=x3, x4=x4, x5=x5, xs1=xs1, xs2=xs2, xs3=xs3, xs4=xs4, x46=x46, x37=x37,
+        self._taps = dict(x1=x1, x2=x2, x3=x3, x4=x4, x5=x5, xs1=r1[2], xs2=r2[2], xs3=r3[2], xs4=r4[2], x46=x46, x37=x37,
                           x28=x28, x19=x19, x6=x6, x7=x7, x8=x8, x9=x9) if self._keep_taps else None
         return logits
 
