@@ -449,6 +449,7 @@ class LM_Net(nn.Module):
         p1 = branch(self.natt1, self.skip1, dt1)
         dx5 = eng.up_bwd(self.up1, dt1, cx, A["x5"].shape); self._done("up1")
         if fork:
+            dcat = eng.gft_bwd(self.gft, dx5, cx)        # independent of the branch chains: before the join
             main.wait_stream(bst)                        # join: the encoder gradients in gacc are complete
             for slot in gacc.values():
                 if slot.g is not None:
@@ -464,7 +465,9 @@ class LM_Net(nn.Module):
             for k, (p, name) in enumerate(zip((p4, p3, p2, p1), ("skip4", "skip3", "skip2", "skip1"))):
                 eng.skip_bwd(p[1], dxs[k], cx, gacc); self._done(name)
         # bottleneck
-        dcat = eng.gft_bwd(self.gft, dx5, cx); self._done("gft")
+        if not fork:
+            dcat = eng.gft_bwd(self.gft, dx5, cx)
+        self._done("gft")
         off = 0
         for k, fac in (("x1", 16), ("x2", 8), ("x3", 4), ("x4", 2)):
             t = A[k]
