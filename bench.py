@@ -109,9 +109,11 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        # RCCL ("nccl") over xGMI; LMNET_BENCH_BACKEND=gloo only to exercise this code path with several ranks on ONE GPU
+        dist.init_process_group(os.environ.get("LMNET_BENCH_BACKEND", "nccl"), rank=rank, world_size=world)
     if args.gpus != world and rank == 0 and world > 1:
         print("warning: --gpus %d but WORLD_SIZE %d" % (args.gpus, world), file=sys.stderr)
+    local = local % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 

@@ -375,8 +375,11 @@ class LM_Net(nn.Module):
 
     def _done(self, name):
         if self.grad_ready_hook is not None:
-            self._engine.join_side(self._grad_flat.device)    # the block's weight gradients run on the side stream
-            self.grad_ready_hook(*self._grad_layout["blocks"][name])
+            # the block's weight gradients run on the side stream of the current stream: the collective waits for
+            # that stream, the compute chain does not (it joins once, at the end of backward)
+            ent = self._engine.sides.get(torch.cuda.current_stream(self._grad_flat.device).cuda_stream) \
+                if self._grad_flat.is_cuda else None
+            self.grad_ready_hook(*self._grad_layout["blocks"][name], [ent[0]] if ent is not None else [])
 
     # ------------------------------------------------------------------ backward schedule
     def _backward_impl(self, cx, dlogits, need_dx):

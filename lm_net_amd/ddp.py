@@ -33,19 +33,26 @@ class GradReducer:
         self.pending_lo = self.pending_hi = 0
         self.works = []
         self.launched = []            # (lo, hi) of every bucket launched in the current backward
+        self.also_wait = []           # producer streams besides the current one (model's weight-gradient stream)
         self.stream = None
 
     def begin(self, flat):
         self.flat = flat
         self.pending_lo = self.pending_hi = 0
         self.works, self.launched = [], []
+        self.also_wait = []
         if flat.is_cuda and self.stream is None:
             self.stream = torch.cuda.Stream(device=flat.device)
 
-    def ready(self, lo, hi):
-        """Gradients of flat[lo:hi) have been enqueued on the current stream.  Blocks arrive in order."""
+    def ready(self, lo, hi, streams=()):
+        """Gradients of flat[lo:hi) have been enqueued on the current stream (and on `streams`: the weight-gradient
+        side stream of the model -- the collective waits for them, the compute stream does not).  Blocks arrive in
+        order."""
         if self.world == 1 or hi <= lo:
             return
+        for s in streams:
+            if s not in self.also_wait:
+                self.also_wait.append(s)
         assert lo == self.pending_hi, "blocks must be reported contiguously in backward order"
         self.pending_hi = hi
         cap = self.first_bucket_bytes if not self.launched else self.bucket_bytes
@@ -60,6 +67,8 @@ class GradReducer:
         avg = dist.ReduceOp.AVG if (self.flat.is_cuda and dist.get_backend(self.pg) == "nccl") else dist.ReduceOp.SUM
         if self.flat.is_cuda:
             self.stream.wait_stream(torch.cuda.current_stream(self.flat.device))
+            for s in self.also_wait:
+                self.stream.wait_stream(s)
             with torch.cuda.stream(self.stream):
                 dist.all_reduce(chunk, op=avg, group=self.pg)
                 if avg == dist.ReduceOp.SUM:
