@@ -275,3 +275,50 @@ def test_on_device_confusion_dice_iou():
     d, i = dice_iou(lg.argmax(1).cpu(), y.cpu())
     assert abs(r["dice"][1] - d) < 1e-12 and abs(r["iou"][1] - i) < 1e-12
     assert sum(map(sum, r["confusion"])) == 2 * 64 * 48
+
+
+def test_graph_mode_matches_host_launches_and_redraws_dropout():
+    """LM_Net.enable_graphs(): the training step as two hipGraph replays (forward, backward) per input shape.
+    Same losses as host launches over 6 steps (steps 3+ are replays), BatchNorm running statistics advance once
+    per step, and with dropout on two consecutive replays draw different masks (device-side stream counter)."""
+    from lm_net_amd.loss import SegLoss
+    from lm_net_amd.optim import FusedAdamW
+    x = det_input((2, 3, 64, 96), "graph/x").cuda()
+    y = disc_labels(2, 64, 96).cuda()
+    crit = SegLoss(label_smoothing=1e-3).cuda()
+
+    def run(m, n):
+        opt = FusedAdamW(m, lr=1e-3, weight_decay=1e-4)
+        out = []
+        for _ in range(n):
+            loss = crit(m(x), y)
+            opt.zero_grad(set_to_none=True)
+            loss.backward()
+            opt.step()
+            out.append(float(loss.detach()))
+        return out
+
+    a, b = _net(seed=11).train(), _net(seed=11).train()
+    b.enable_graphs()
+    la, lb = run(a, 6), run(b, 6)
+    assert sum(g.fwd is not None for g in b._graphs.values()) == 1
+    # (Adam turns the last-bit noise of two runs into O(lr) parameter differences: 2e-3 on the loss after six steps;
+    #  a wrong gradient or a stale buffer in the replay shows up at the 1e-1 level)
+    assert max(abs(u - v) / abs(u) for u, v in zip(la, lb)) < 2e-3, (la, lb)
+    nb = [m for m in b.modules() if isinstance(m, torch.nn.BatchNorm2d)][0]
+    na_ = [m for m in a.modules() if isinstance(m, torch.nn.BatchNorm2d)][0]
+    assert int(nb.num_batches_tracked) == int(na_.num_batches_tracked) == 6
+    assert rel_err(nb.running_mean, na_.running_mean) < 5e-2     # six Adam steps apart in the last bits of the gradients
+    # dropout on (a fresh model keeps nn.Dropout(0.1) of the Mlp blocks): replays must not repeat the mask
+    from lm_net_amd import LM_Net
+    c = LM_Net(3, 2)
+    fill_module(c, 11)
+    c = c.cuda().train().enable_graphs()
+    outs = []
+    for _ in range(5):
+        o = c(x)
+        o.sum().backward()
+        outs.append(o.detach().clone())
+        for p in c.parameters():
+            p.grad = None
+    assert float((outs[3] - outs[4]).abs().max()) > 1e-3
