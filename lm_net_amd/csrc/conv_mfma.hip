@@ -930,196 +930,6 @@ struct WgradParams {
   int dbg;
 };
 
-template <int TAPS, int NMT, int NNT, int U>
-__global__ __launch_bounds__(256) void wgrad_mfma_kernel(const WgradParams P) {
-  const lmn_wgrad_args_t& A = P.a;
-  const uint32_t soff = A.seed_ctr ? *A.seed_ctr : 0u;  // device-side dropout stream offset (graph replays: one bump per step)
-  const int lane = threadIdx.x & 63;
-  const int q = lane >> 4, n = lane & 15;
-  const int wave = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int nwaves = gridDim.x * 4;
-  const int mset = blockIdx.y / P.nsets_n, nset = blockIdx.y - mset * P.nsets_n;
-  const int mt0 = mset * NMT, nt0 = nset * NNT;
-  const int pad = A.ksize >> 1;
-  const int HWo = A.Hout * A.Wout;
-
-  // which source / channel each of this wave's cin tiles maps to
-  const float* sptr[NNT];
-  const float* sscale[NNT];
-  int sC[NNT], scs[NNT], sflags[NNT], sch[NNT];
-  uint32_t sseed[NNT];
-  float sp[NNT], sik[NNT];
-#pragma unroll
-  for (int t = 0; t < NNT; ++t) {
-    const int nt = nt0 + t;
-    int s = 0;
-    while (s + 1 < A.nsrc && nt >= P.ntile_off[s + 1]) ++s;
-    const bool ok = nt < P.NNTT;
-    const int ch = (nt - P.ntile_off[s]) * 16 + n;
-    sptr[t] = A.src[s].ptr;
-    sscale[t] = A.src[s].scale;
-    sC[t] = A.src[s].C;
-    scs[t] = A.src[s].cstride;
-    sflags[t] = A.src[s].flags;
-    sseed[t] = A.src[s].drop_seed + soff;
-    sp[t] = A.src[s].drop_p;
-    sik[t] = P.inv_keep_src[s];
-    sch[t] = (ok && ch < A.src[s].C) ? ch : -1;
-  }
-  bool mok[NMT];
-#pragma unroll
-  for (int m = 0; m < NMT; ++m) mok[m] = (mt0 + m) < P.NMTT && ((mt0 + m) * 16 + n) < A.Cout;
-
-  f32x4 acc[TAPS][NMT][NNT];
-  f32x4 accb[NMT];
-#pragma unroll
-  for (int tp = 0; tp < TAPS; ++tp)
-#pragma unroll
-    for (int m = 0; m < NMT; ++m)
-#pragma unroll
-      for (int t = 0; t < NNT; ++t) acc[tp][m][t] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-  for (int m = 0; m < NMT; ++m) accb[m] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  // contiguous range of 4-pixel K steps per wave; U steps are loaded together (U*(NMT + TAPS*NNT) independent
-  // loads in flight per lane) before their MFMAs issue.  Index math is 32-bit: per step ONE centre offset per
-  // operand, per tap a wave-uniform delta and two unsigned bounds compares.
-  const int sb = (int)(((int64_t)wave * P.total_steps) / nwaves), se = (int)(((int64_t)(wave + 1) * P.total_steps) / nwaves);
-  int tdelta[TAPS];  // (ty - pad) * Win + (tx - pad)
-#pragma unroll
-  for (int tp = 0; tp < TAPS; ++tp) {
-    const int ty = (TAPS == 9) ? tp / 3 : 0, tx = (TAPS == 9) ? tp % 3 : 0;
-    tdelta[tp] = (ty - pad) * A.Win + (tx - pad);
-  }
-  bool any_tf = (A.dy_flags & LMN_SRC_DROP) != 0;
-#pragma unroll
-  for (int t = 0; t < NNT; ++t) any_tf = any_tf || (sflags[t] != 0) || (sscale[t] != nullptr);
-  for (int step0 = sb; step0 < se; step0 += U) {
-    float av[U][NMT], bv[U][TAPS][NNT];
-    // ---- phase 1: every load of the batch, straight-line (no branch between loads => all in flight together)
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int step = step0 + u;
-      const int b = step / P.steps_per_img;
-      const int pi = (step - b * P.steps_per_img) * 4 + q;
-      const bool pok = step < se && pi < HWo;
-      const int y = pi / A.Wout, x = pi - y * A.Wout;
-      const int opix_s = pok ? b * HWo + pi : 0;  // masked lanes load a safe address; zeroed in phase 2
-#pragma unroll
-      for (int m = 0; m < NMT; ++m) av[u][m] = A.dy[(uint32_t)(opix_s * A.dy_cstride + (mok[m] ? (mt0 + m) * 16 + n : 0))];
-      const int cy = y * A.stride, cx = x * A.stride;       // centre tap's input pixel is (cy, cx)
-      const int cpix = (b * A.Hin + cy) * A.Win + cx;
-#pragma unroll
-      for (int tp = 0; tp < TAPS; ++tp) {
-        const int ty = (TAPS == 9) ? tp / 3 : 0, tx = (TAPS == 9) ? tp % 3 : 0;
-        const int iy = cy + ty - pad, ix = cx + tx - pad;
-        const bool ok = pok && (unsigned)iy < (unsigned)A.Hin && (unsigned)ix < (unsigned)A.Win;
-        const int ipix = ok ? cpix + tdelta[tp] : 0;
-#pragma unroll
-        for (int t = 0; t < NNT; ++t) bv[u][tp][t] = sptr[t][(uint32_t)(ipix * scs[t] + (sch[t] >= 0 ? sch[t] : 0))];
-      }
-    }
-    // ---- phase 2: on-load transforms (rare) and masking
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int step = step0 + u;
-      const int b = step / P.steps_per_img;
-      const int pi = (step - b * P.steps_per_img) * 4 + q;
-      const bool pok = step < se && pi < HWo;
-      const int y = pi / A.Wout, x = pi - y * A.Wout;
-      const int opix_s = pok ? b * HWo + pi : 0;
-      const int cy = y * A.stride, cx = x * A.stride;
-      const int cpix = (b * A.Hin + cy) * A.Win + cx;
-#pragma unroll
-      for (int m = 0; m < NMT; ++m) {
-        float v = av[u][m];
-        if (any_tf && (A.dy_flags & LMN_SRC_DROP))
-          v *= lmn_drop_scale(A.dy_seed + soff, (uint32_t)(opix_s * A.Cout + (mok[m] ? (mt0 + m) * 16 + n : 0)), A.dy_p, P.inv_keep_dy);
-        av[u][m] = (pok && mok[m]) ? v : 0.f;
-      }
-#pragma unroll
-      for (int tp = 0; tp < TAPS; ++tp) {
-        const int ty = (TAPS == 9) ? tp / 3 : 0, tx = (TAPS == 9) ? tp % 3 : 0;
-        const int iy = cy + ty - pad, ix = cx + tx - pad;
-        const bool ok = pok && (unsigned)iy < (unsigned)A.Hin && (unsigned)ix < (unsigned)A.Win;
-        const int ipix = ok ? cpix + tdelta[tp] : 0;
-        const int bs = ok ? b : 0;
-#pragma unroll
-        for (int t = 0; t < NNT; ++t) {
-          float v = bv[u][tp][t];
-          if (any_tf) {
-            const int chs = sch[t] >= 0 ? sch[t] : 0;
-            if (sflags[t] & LMN_SRC_GELU) v = lmn_gelu(v);
-            if (sflags[t] & LMN_SRC_DROP) v *= lmn_drop_scale(sseed[t], (uint32_t)(ipix * sC[t] + chs), sp[t], sik[t]);
-            if (sscale[t]) v *= sscale[t][bs * sC[t] + chs];
-          }
-          bv[u][tp][t] = (ok && sch[t] >= 0) ? v : 0.f;
-        }
-      }
-    }
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      if (A.db && nset == 0) {
-#pragma unroll
-        for (int m = 0; m < NMT; ++m) accb[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u][m], 1.0f, accb[m], 0, 0, 0);
-      }
-#pragma unroll
-      for (int tp = 0; tp < TAPS; ++tp)
-#pragma unroll
-        for (int t = 0; t < NNT; ++t)
-#pragma unroll
-          for (int m = 0; m < NMT; ++m)
-            acc[tp][m][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u][m], bv[u][tp][t], acc[tp][m][t], 0, 0, 0);
-    }
-  }
-
-  // ---- block-level reduction in LDS (4 waves -> 1), then ONE global atomic per weight per block.
-  // D[m = 4q + r][nn = n]: cout = 16*mtile + 4q + r, cin = tile channel n
-  constexpr int NT = TAPS * NMT * NNT;
-  __shared__ float s_acc[NT * 256 + NMT * 16];
-  for (int i = threadIdx.x; i < NT * 256 + NMT * 16; i += 256) s_acc[i] = 0.f;
-  __syncthreads();
-#pragma unroll
-  for (int tp = 0; tp < TAPS; ++tp)
-#pragma unroll
-    for (int m = 0; m < NMT; ++m)
-#pragma unroll
-      for (int t = 0; t < NNT; ++t)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) atomicAdd(&s_acc[(((tp * NMT + m) * NNT + t) * 4 + r) * 64 + lane], acc[tp][m][t][r]);
-  if (A.db && nset == 0 && n == 0) {
-#pragma unroll
-    for (int m = 0; m < NMT; ++m)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) atomicAdd(&s_acc[NT * 256 + m * 16 + q * 4 + r], accb[m][r]);
-  }
-  __syncthreads();
-  if (P.partial) {  // two-stage: plain coalesced stores of this block's partial, summed by wgrad_reduce_kernel
-    float* dst = P.partial + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * (NT * 256 + NMT * 16);
-    for (int i = threadIdx.x; i < NT * 256 + NMT * 16; i += 256) dst[i] = s_acc[i];
-    return;
-  }
-  for (int i = threadIdx.x; i < NT * 256; i += 256) {
-    const int ln = i & 63, r = (i >> 6) & 3, tile = i >> 8;
-    const int t = tile % NNT, m = (tile / NNT) % NMT, tp = tile / (NNT * NMT);
-    const int qq = ln >> 4, nn = ln & 15;
-    const int co = (mt0 + m) * 16 + qq * 4 + r;
-    const int nt = nt0 + t;
-    if ((mt0 + m) >= P.NMTT || co >= A.Cout || nt >= P.NNTT) continue;
-    int sidx = 0;
-    while (sidx + 1 < A.nsrc && nt >= P.ntile_off[sidx + 1]) ++sidx;
-    const int ch = (nt - P.ntile_off[sidx]) * 16 + nn;
-    if (ch >= A.src[sidx].C) continue;
-    atomicAdd(A.dW + ((int64_t)co * P.Cin + P.cbase[sidx] + ch) * TAPS + tp, s_acc[i]);
-  }
-  if (A.db && nset == 0) {
-    for (int i = threadIdx.x; i < NMT * 16; i += 256) {
-      const int co = mt0 * 16 + i;
-      if (co < A.Cout && (mt0 + i / 16) < P.NMTT) atomicAdd(A.db + co, s_acc[NT * 256 + i]);
-    }
-  }
-}
-
 // ------------------------------------------------------------------------------------ weight gradient, LDS-staged
 // dW[co][ci][tap] = sum_p dy[p][co] * x[p*s + tap - pad][ci]   as an MFMA GEMM with K = pixels.
 // A block walks a contiguous range of output-pixel tiles.  Per tile the input window (with halo) and the dy

@@ -8,15 +8,13 @@
 // reference's own re-parameterisation (modules.py:622-642), in training it needs the batch statistics
 // of every branch first (lmn_dw_stats, a read-only pass).
 //
-// Forward (lmn_dw_fwd, the flagship kernel): a 16x16-pixel x 24-channel tile with a 2-pixel halo is
-// staged in LDS by coalesced 16 B loads (24 fp32 = one 96 B NHWC pixel at level 0, so a halo row is
-// one contiguous 1,920 B span); each thread owns (column, channel pair) and WALKS DOWN the tile:
-// one LDS row = 5 ds_read_b64 feeds 25 packed FMAs into 5 rotating accumulators (register blocking
-// along y), so LDS traffic is 5 reads per output instead of 25, conflict-free (32 lanes x 8 B =
-// one 256 B bank row).  The epilogue stores `pre` once and accumulates the SE squeeze sum_hw GELU(pre).
-//
-// The training-only passes (statistics, and the backward through 4 separately batch-normalised
-// branches) use a simpler direct-stencil form on 8-channel chunks; they are correctness-first.
+// Forward (lmn_dw_fwd, the flagship kernel), backward pass 2 (lmn_dw_bwd): STRIP-WALKING form -- a wave owns one
+// channel pair, its 64 lanes are 64 adjacent columns, the pair's stencil weights live in SGPRs and feed
+// v_pk_fma_f32 directly; the wave walks down the rows of a segment: one x1 row (5 ds_read_b64: columns x-2..x+2)
+// feeds rotating row accumulators (register blocking along y); rows are staged / drained through LDS in batches by
+// the whole block with coalesced 16 B accesses (LDS pixel stride 10 floats = conflict-free for 64 columns).
+// The statistics passes (lmn_dw_stats, lmn_dw_bwd_stats) use the older 16x16-tile walking form: thread = (column,
+// channel pair) with the weights in VGPRs, persistent blocks (the strip form measured slower there).
 #include "common.h"
 
 namespace {
@@ -31,87 +29,6 @@ constexpr int FW_RW = FW_TW + 4, FW_RH = FW_TH + 4;
 __device__ __forceinline__ int xcd_swizzle(int bid, int nwg) {
   const int qd = nwg >> 3, r = nwg & 7, xcd = bid & 7;
   return (xcd < r ? xcd * (qd + 1) : r * (qd + 1) + (xcd - r) * qd) + (bid >> 3);
-}
-
-// CCH = channels per block: 24 (E = 24: a pixel is 96 B, rows are contiguous), 48 (E = 48) or 32 (E % 32 == 0:
-// 128-B-aligned chunks) -- a chunk must cover whole cache lines or HBM fetches double (PMC: 2.7x at E = 48 with 24).
-template <int CCH>
-__global__ __launch_bounds__(FW_TW * CCH / 2) void dw_fwd_kernel(const float* __restrict__ x1, float* __restrict__ pre,
-                                                                  float* __restrict__ gsum, int H, int W, int E,
-                                                                  const float* __restrict__ keff,
-                                                                  const float* __restrict__ beff, int tiles_x,
-                                                                  int tiles, int chunks) {
-  constexpr int NCP = CCH / 2, THREADS = FW_TW * NCP;
-  extern __shared__ __attribute__((aligned(16))) float tile[];  // [FW_RH*FW_RW][CCH] | gs_s[CCH]
-  float* gs_s = tile + FW_RH * FW_RW * CCH;
-  const int tid = threadIdx.x;
-  // logical block: channel chunk fastest (the chunks of one tile share 128-B lines of every pixel: neighbours in
-  // the swizzled order run on the same XCD at the same time, so the second chunk hits L2 -- PMC: 2.15x the
-  // algorithmic fetch at E = 48 with the tile-fastest order), then tile, then image
-  const int lid = xcd_swizzle(blockIdx.x, gridDim.x);
-  const int ck = lid % chunks, tb = lid / chunks;
-  const int t = tb % tiles, b = tb / tiles;
-  const int ty0 = (t / tiles_x) * FW_TH, tx0 = (t % tiles_x) * FW_TW;
-  const int ch0 = ck * CCH;
-  const float* xb = x1 + (int64_t)b * H * W * E;
-
-  if (tid < CCH) gs_s[tid] = 0.f;
-  for (int i = tid; i < FW_RH * FW_RW * (CCH / 4); i += THREADS) {
-    const int c4 = i % (CCH / 4), pix = i / (CCH / 4);
-    const int r = pix / FW_RW, c = pix - r * FW_RW;
-    const int gy = ty0 - 2 + r, gx = tx0 - 2 + c;
-    // unconditional load from a clamped (in-bounds) address + select: loads under a per-lane branch serialise
-    const bool in = gy >= 0 && gy < H && gx >= 0 && gx < W && ch0 + c4 * 4 < E;
-    const int sy = in ? gy : 0, sx = in ? gx : 0, sc = in ? ch0 + c4 * 4 : 0;
-    f32x4 v = *reinterpret_cast<const f32x4*>(xb + ((int64_t)sy * W + sx) * E + sc);
-    if (!in) v = f32x4{0.f, 0.f, 0.f, 0.f};
-    *reinterpret_cast<f32x4*>(&tile[pix * CCH + c4 * 4]) = v;
-  }
-
-  const int cp = tid % NCP, xx = tid / NCP;
-  const int ch = ch0 + cp * 2;
-  const bool cok = ch < E;  // E is a multiple of 4: a channel pair is valid as a whole (last chunk may be partial)
-  f32x2 w[25];
-#pragma unroll
-  for (int k = 0; k < 25; ++k) w[k] = cok ? f32x2{keff[(int64_t)ch * 25 + k], keff[(int64_t)(ch + 1) * 25 + k]} : f32x2{0.f, 0.f};
-  const f32x2 bias = cok ? f32x2{beff[ch], beff[ch + 1]} : f32x2{0.f, 0.f};
-  __syncthreads();
-
-  f32x2 acc[5];
-#pragma unroll
-  for (int k = 0; k < 5; ++k) acc[k] = f32x2{0.f, 0.f};
-  f32x2 gs = f32x2{0.f, 0.f};
-  const int gx = tx0 + xx;
-#pragma unroll
-  for (int r = 0; r < FW_RH; ++r) {
-    f32x2 in[5];
-#pragma unroll
-    for (int dx = 0; dx < 5; ++dx) in[dx] = *reinterpret_cast<const f32x2*>(&tile[(r * FW_RW + xx + dx) * CCH + cp * 2]);
-#pragma unroll
-    for (int ky = 0; ky < 5; ++ky) {
-      const int o = r - ky;
-      if (o >= 0 && o < FW_TH) {
-#pragma unroll
-        for (int dx = 0; dx < 5; ++dx) acc[o % 5] += w[ky * 5 + dx] * in[dx];
-      }
-    }
-    const int o = r - 4;
-    if (o >= 0) {
-      const int gy = ty0 + o;
-      const f32x2 p = acc[o % 5] + bias;
-      acc[o % 5] = f32x2{0.f, 0.f};
-      if (gy < H && gx < W && cok) {
-        *reinterpret_cast<f32x2*>(pre + (((int64_t)b * H + gy) * W + gx) * E + ch) = p;
-        gs += f32x2{lmn_gelu(p[0]), lmn_gelu(p[1])};
-      }
-    }
-  }
-  // SE squeeze: lanes sharing a channel pair are NCP apart -> LDS row per thread column would need atomics; the sums
-  // are only 2 floats per thread, so a few ds_add_f32 per thread are acceptable here
-  atomicAdd(&gs_s[cp * 2], gs[0]);
-  atomicAdd(&gs_s[cp * 2 + 1], gs[1]);
-  __syncthreads();
-  if (tid < CCH && ch0 + tid < E) atomicAdd(gsum + (int64_t)b * E + ch0 + tid, gs_s[tid]);
 }
 
 struct BranchW {  // this thread's channel pair of the four branch kernels
@@ -273,268 +190,9 @@ __global__ void dw_merge_kernel(const float* __restrict__ w5, const float* __res
   if (t == 0) beff[e] = shift[e] + shift[E + e] + shift[2 * E + e] + shift[3 * E + e];
 }
 
-// ------------------------------------------------------------------------------------------------
-// direct-stencil training passes: 16x16 tile, 8-channel chunk, 256 threads, thread = (pixel, pair)
-// ------------------------------------------------------------------------------------------------
-constexpr int DT = 16, DC = 8, DNCP = DC / 2;
-
-// stage a (DT+2*halo)^2 x DC window of an NHWC tensor around tile origin (ty0,tx0), zero outside the image
-template <int HALO>
-__device__ __forceinline__ void stage_tile(float* lds, const float* img, int H, int W, int E, int ch0, int ty0, int tx0) {
-  constexpr int R = DT + 2 * HALO;
-  for (int i = threadIdx.x; i < R * R * (DC / 4); i += blockDim.x) {
-    const int c4 = i % (DC / 4), pix = i / (DC / 4);
-    const int r = pix / R, c = pix - r * R;
-    const int gy = ty0 - HALO + r, gx = tx0 - HALO + c;
-    const bool in = gy >= 0 && gy < H && gx >= 0 && gx < W && ch0 + c4 * 4 < E;
-    const int sy = in ? gy : 0, sx = in ? gx : 0, sc = in ? ch0 + c4 * 4 : 0;
-    f32x4 v = *reinterpret_cast<const f32x4*>(img + ((int64_t)sy * W + sx) * E + sc);
-    if (!in) v = f32x4{0.f, 0.f, 0.f, 0.f};
-    *reinterpret_cast<f32x4*>(&lds[pix * DC + c4 * 4]) = v;
-  }
-}
-
-// the four branch outputs at window position (r,c) (centre) of an LDS image with row length RW
-template <int RW>
-__device__ __forceinline__ void branches_at(const float* lds, int r, int c, int cp, const BranchW& bw, f32x2 y[4]) {
-  y[0] = y[1] = y[2] = y[3] = f32x2{0.f, 0.f};
-#pragma unroll
-  for (int ky = 0; ky < 5; ++ky)
-#pragma unroll
-    for (int kx = 0; kx < 5; ++kx) {
-      const f32x2 v = *reinterpret_cast<const f32x2*>(&lds[((r + ky - 2) * RW + (c + kx - 2)) * DC + cp * 2]);
-      y[0] += bw.w5[ky * 5 + kx] * v;
-      if (ky >= 1 && ky <= 3 && kx >= 1 && kx <= 3) y[1] += bw.w3[(ky - 1) * 3 + (kx - 1)] * v;
-      if (kx == 2 && ky >= 1 && ky <= 3) y[2] += bw.wv[ky - 1] * v;
-      if (ky == 2 && kx >= 1 && kx <= 3) y[3] += bw.wh[kx - 1] * v;
-    }
-}
-
-// MODE 0: forward batch statistics   stats[4][2][E] += (sum y_b, sum y_b^2)
-// MODE 1: backward pass 1            dpre = (u*s + dm)*gelu'(pre) -> store; stats[5][E] += (sum dpre, sum dpre*y_b)
-template <int MODE>
-__global__ __launch_bounds__(256) void dw_stats_kernel(const float* __restrict__ x1, const float* __restrict__ pre,
-                                                       const float* __restrict__ u, const float* __restrict__ s,
-                                                       const float* __restrict__ dm, float* __restrict__ dpre, int B,
-                                                       int H, int W, int E, const float* __restrict__ w5,
-                                                       const float* __restrict__ w3, const float* __restrict__ wv,
-                                                       const float* __restrict__ wh, float* __restrict__ stats,
-                                                       int tiles_x, int tiles_y) {
-  constexpr int R = DT + 4;
-  constexpr int NS = MODE == 0 ? 8 : 5;
-  __shared__ __attribute__((aligned(16))) float lds[R * R * DC];
-  __shared__ float red[NS * DC];
-  const int tid = threadIdx.x, cp = tid % DNCP;
-  const int ch0 = blockIdx.y * DC, ch = ch0 + cp * 2;
-  const bool cok = ch < E;
-  BranchW bw;
-  load_branch_w(bw, w5, w3, wv, wh, ch, E);
-  f32x2 sum[NS];
-#pragma unroll
-  for (int k = 0; k < NS; ++k) sum[k] = f32x2{0.f, 0.f};
-  for (int i = tid; i < NS * DC; i += 256) red[i] = 0.f;
-
-  const int ntiles = B * tiles_x * tiles_y;
-  for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
-    const int b = t / (tiles_x * tiles_y), tt = t - b * tiles_x * tiles_y;
-    const int ty0 = (tt / tiles_x) * DT, tx0 = (tt % tiles_x) * DT;
-    __syncthreads();
-    stage_tile<2>(lds, x1 + (int64_t)b * H * W * E, H, W, E, ch0, ty0, tx0);
-    __syncthreads();
-    for (int i = tid; i < DT * DT * DNCP; i += 256) {
-      const int pix = i / DNCP, py = pix / DT, px = pix - py * DT;
-      const int gy = ty0 + py, gx = tx0 + px;
-      if (gy >= H || gx >= W || !cok) continue;
-      f32x2 y[4];
-      branches_at<R>(lds, py + 2, px + 2, cp, bw, y);
-      if (MODE == 0) {
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          sum[k] += y[k];
-          sum[4 + k] += y[k] * y[k];
-        }
-      } else {
-        const int64_t off = (((int64_t)b * H + gy) * W + gx) * E + ch;
-        const f32x2 pv = *reinterpret_cast<const f32x2*>(pre + off);
-        const f32x2 uv = *reinterpret_cast<const f32x2*>(u + off);
-        const f32x2 sv = *reinterpret_cast<const f32x2*>(s + (int64_t)b * E + ch);
-        const f32x2 dv = *reinterpret_cast<const f32x2*>(dm + (int64_t)b * E + ch);
-        f32x2 d;
-        d[0] = (uv[0] * sv[0] + dv[0]) * lmn_dgelu(pv[0]);
-        d[1] = (uv[1] * sv[1] + dv[1]) * lmn_dgelu(pv[1]);
-        *reinterpret_cast<f32x2*>(dpre + off) = d;
-        sum[0] += d;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) sum[1 + k] += d * y[k];
-      }
-    }
-  }
-#pragma unroll
-  for (int k = 0; k < NS; ++k) {
-    atomicAdd(&red[k * DC + cp * 2], sum[k][0]);
-    atomicAdd(&red[k * DC + cp * 2 + 1], sum[k][1]);
-  }
-  __syncthreads();
-  for (int i = tid; i < NS * DC; i += 256) {
-    const int k = i / DC;
-    const int row = MODE == 0 ? ((k & 3) * 2 + (k >> 2)) : k;  // MODE 0: [branch][sum|sumsq][E]
-    if (ch0 + (i % DC) < E) atomicAdd(stats + (int64_t)row * E + ch0 + (i % DC), red[i]);
-  }
-}
-
-// backward pass 2:  f_b = cA_b*dpre + cC_b*y_b + cD_b inside the image (0 outside);
-//   dx1 = sum_b corr^T(f_b, w_b);   dW_b[t] += sum_p f_b[p] * x1[p+t]
-// The four branches are processed one after another through ONE LDS field F; the branch kernels live in
-// LDS (Wl) and only the current branch's taps are pulled into registers, so the 40 persistent
-// weight-gradient accumulators (per channel pair) do not spill.
-template <int KH, int KW, bool FIRST>
-__device__ __forceinline__ void dw_bwd_branch(const float* X, const float* DP, float* F, float* DX, const float* Wl,
-                                              int woff, f32x2 a, f32x2 c, f32x2 d, f32x2 (&gacc)[KH * KW], int cp,
-                                              int tid, int ty0, int tx0, int H, int W) {
-  constexpr int R4 = DT + 8, R2 = DT + 4;
-  constexpr int PH = KH / 2, PW = KW / 2;
-  f32x2 w[KH * KW];
-#pragma unroll
-  for (int t = 0; t < KH * KW; ++t) w[t] = *reinterpret_cast<const f32x2*>(&Wl[(woff + t) * DC + cp * 2]);
-  // phase A: f on the halo-2 region
-  for (int i = tid; i < R2 * R2 * DNCP; i += 256) {
-    const int pix = i / DNCP, r = pix / R2, cc = pix - r * R2;
-    const int gy = ty0 - 2 + r, gx = tx0 - 2 + cc;
-    f32x2 f = f32x2{0.f, 0.f};
-    if (gy >= 0 && gy < H && gx >= 0 && gx < W) {
-      f32x2 y = f32x2{0.f, 0.f};
-      const int xr = r + 2, xc = cc + 2;  // same pixel in X coordinates
-#pragma unroll
-      for (int ky = 0; ky < KH; ++ky)
-#pragma unroll
-        for (int kx = 0; kx < KW; ++kx)
-          y += w[ky * KW + kx] * *reinterpret_cast<const f32x2*>(&X[((xr + ky - PH) * R4 + xc + kx - PW) * DC + cp * 2]);
-      f = a * *reinterpret_cast<const f32x2*>(&DP[pix * DC + cp * 2]) + c * y + d;
-    }
-    *reinterpret_cast<f32x2*>(&F[pix * DC + cp * 2]) = f;
-  }
-  __syncthreads();
-  // phase B: y(p) reads x1(p + t - pad)  =>  dx1(p') += w[t] * f(p' - t + pad);  dW[t] += f(p) * x1(p + t - pad)
-#pragma unroll 1
-  for (int k = 0; k < 4; ++k) {
-    const int i = tid + k * 256;
-    const int pix = i / DNCP, py = pix / DT, px = pix - py * DT;
-    const int fr = py + 2, fc = px + 2;  // F / DP coordinates
-    const int xr = py + 4, xc = px + 4;  // X coordinates
-    const f32x2 fp = *reinterpret_cast<const f32x2*>(&F[(fr * R2 + fc) * DC + cp * 2]);
-    f32x2 acc = f32x2{0.f, 0.f};
-#pragma unroll
-    for (int ky = 0; ky < KH; ++ky)
-#pragma unroll
-      for (int kx = 0; kx < KW; ++kx) {
-        acc += w[ky * KW + kx] * *reinterpret_cast<const f32x2*>(&F[((fr - ky + PH) * R2 + fc - kx + PW) * DC + cp * 2]);
-        gacc[ky * KW + kx] += fp * *reinterpret_cast<const f32x2*>(&X[((xr + ky - PH) * R4 + xc + kx - PW) * DC + cp * 2]);
-      }
-    f32x2* dst = reinterpret_cast<f32x2*>(&DX[pix * DC + cp * 2]);  // owned by this thread: no atomics
-    *dst = FIRST ? acc : (*dst + acc);
-  }
-  __syncthreads();
-}
-
-__global__ __launch_bounds__(256) void dw_bwd_kernel(const float* __restrict__ x1, const float* __restrict__ dpre,
-                                                     float* __restrict__ dx1, int B, int H, int W, int E,
-                                                     const float* __restrict__ w5, const float* __restrict__ w3,
-                                                     const float* __restrict__ wv, const float* __restrict__ wh,
-                                                     const float* __restrict__ cA, const float* __restrict__ cC,
-                                                     const float* __restrict__ cD, float* __restrict__ dw5,
-                                                     float* __restrict__ dw3, float* __restrict__ dwv,
-                                                     float* __restrict__ dwh, int tiles_x, int tiles_y) {
-  constexpr int R4 = DT + 8, R2 = DT + 4;
-  __shared__ __attribute__((aligned(16))) float X[R4 * R4 * DC];   // x1, halo 4
-  __shared__ __attribute__((aligned(16))) float DP[R2 * R2 * DC];  // dpre, halo 2
-  __shared__ __attribute__((aligned(16))) float F[R2 * R2 * DC];   // current branch's f_b, halo 2
-  __shared__ __attribute__((aligned(16))) float DX[DT * DT * DC];  // dx1 accumulated over the branches
-  __shared__ __attribute__((aligned(16))) float Wl[40 * DC];       // branch kernels [tap][channel]
-  __shared__ float red[40 * DC];
-  const int tid = threadIdx.x, cp = tid % DNCP;
-  const int ch0 = blockIdx.y * DC, ch = ch0 + cp * 2;
-  for (int i = tid; i < 40 * DC; i += 256) {
-    const int t = i / DC, e = ch0 + (i - t * DC);
-    float v;
-    if (e >= E) v = 0.f;
-    else if (t < 25) v = w5[(int64_t)e * 25 + t];
-    else if (t < 34) v = w3[(int64_t)e * 9 + t - 25];
-    else if (t < 37) v = wv[(int64_t)e * 3 + t - 34];
-    else v = wh[(int64_t)e * 3 + t - 37];
-    Wl[i] = v;
-    red[i] = 0.f;
-  }
-  const bool cok = ch < E;
-  f32x2 a[4], c[4], d[4];
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    a[k] = cok ? f32x2{cA[k * E + ch], cA[k * E + ch + 1]} : f32x2{0.f, 0.f};
-    c[k] = cok ? f32x2{cC[k * E + ch], cC[k * E + ch + 1]} : f32x2{0.f, 0.f};
-    d[k] = cok ? f32x2{cD[k * E + ch], cD[k * E + ch + 1]} : f32x2{0.f, 0.f};
-  }
-  f32x2 g5[25], g3[9], gv[3], gh[3];
-#pragma unroll
-  for (int t = 0; t < 25; ++t) g5[t] = f32x2{0.f, 0.f};
-#pragma unroll
-  for (int t = 0; t < 9; ++t) g3[t] = f32x2{0.f, 0.f};
-#pragma unroll
-  for (int t = 0; t < 3; ++t) gv[t] = gh[t] = f32x2{0.f, 0.f};
-
-  const int ntiles = B * tiles_x * tiles_y;
-  for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
-    const int b = t / (tiles_x * tiles_y), tt = t - b * tiles_x * tiles_y;
-    const int ty0 = (tt / tiles_x) * DT, tx0 = (tt % tiles_x) * DT;
-    __syncthreads();
-    stage_tile<4>(X, x1 + (int64_t)b * H * W * E, H, W, E, ch0, ty0, tx0);
-    stage_tile<2>(DP, dpre + (int64_t)b * H * W * E, H, W, E, ch0, ty0, tx0);
-    __syncthreads();
-    dw_bwd_branch<5, 5, true>(X, DP, F, DX, Wl, 0, a[0], c[0], d[0], g5, cp, tid, ty0, tx0, H, W);
-    dw_bwd_branch<3, 3, false>(X, DP, F, DX, Wl, 25, a[1], c[1], d[1], g3, cp, tid, ty0, tx0, H, W);
-    dw_bwd_branch<3, 1, false>(X, DP, F, DX, Wl, 34, a[2], c[2], d[2], gv, cp, tid, ty0, tx0, H, W);
-    dw_bwd_branch<1, 3, false>(X, DP, F, DX, Wl, 37, a[3], c[3], d[3], gh, cp, tid, ty0, tx0, H, W);
-    for (int i = tid; i < DT * DT * (DC / 4); i += 256) {   // float4 rows of the finished dx1 tile
-      const int c4 = i % (DC / 4), pix = i / (DC / 4), py = pix / DT, px = pix - py * DT;
-      const int gy = ty0 + py, gx = tx0 + px;
-      if (gy < H && gx < W && ch0 + c4 * 4 < E)
-        *reinterpret_cast<f32x4*>(dx1 + (((int64_t)b * H + gy) * W + gx) * E + ch0 + c4 * 4) = *reinterpret_cast<const f32x4*>(&DX[pix * DC + c4 * 4]);
-    }
-  }
-  // weight gradients: [E][40] = 25 (5x5) | 9 (3x3) | 3 (ver) | 3 (hor).  Lanes sharing a channel pair are 4 apart:
-  // butterfly over lane bits 2..5 (no LDS float atomics: ~3 cycles per lane on gfx950), then one LDS row per wave.
-  __syncthreads();
-  float* red4 = X;  // reuse the x1 staging area: [4 waves][40][DC]
-  const int lane = tid & 63, wid = tid >> 6;
-  auto wave_reduce_store = [&](f32x2 v, int t) {
-#pragma unroll
-    for (int m = 4; m <= 32; m <<= 1) {
-      v[0] += __shfl_xor(v[0], m, 64);
-      v[1] += __shfl_xor(v[1], m, 64);
-    }
-    if (lane < DNCP) *reinterpret_cast<f32x2*>(&red4[(wid * 40 + t) * DC + lane * 2]) = v;
-  };
-#pragma unroll
-  for (int t = 0; t < 25; ++t) wave_reduce_store(g5[t], t);
-#pragma unroll
-  for (int t = 0; t < 9; ++t) wave_reduce_store(g3[t], 25 + t);
-#pragma unroll
-  for (int t = 0; t < 3; ++t) {
-    wave_reduce_store(gv[t], 34 + t);
-    wave_reduce_store(gh[t], 37 + t);
-  }
-  __syncthreads();
-  for (int i = tid; i < 40 * DC; i += 256) {
-    const int t = i / DC, e = ch0 + (i - t * DC);
-    if (e >= E) continue;
-    const float v = red4[i] + red4[40 * DC + i] + red4[2 * 40 * DC + i] + red4[3 * 40 * DC + i];
-    if (t < 25) atomicAdd(dw5 + (int64_t)e * 25 + t, v);
-    else if (t < 34) atomicAdd(dw3 + (int64_t)e * 9 + t - 25, v);
-    else if (t < 37) atomicAdd(dwv + (int64_t)e * 3 + t - 34, v);
-    else atomicAdd(dwh + (int64_t)e * 3 + t - 37, v);
-  }
-}
-
 // ---------------------------------------------------------------------------------------------------------------
-// backward pass 2, strip-walking form (replaces dw_bwd_kernel on the hot path).
+// backward pass 2, strip-walking form:  f_b = cA_b*dpre + cC_b*y_b + cD_b inside the image (0 outside);
+//   dx1 = sum_b corr^T(f_b, w_b);   dW_b[t] += sum_p f_b[p] * x1[p+t]
 //
 // VALU-bound work (per pixel and channel: 40 FMAs for the four y_b, 40 for dx1, 40 for the weight gradients), so
 // the layout is chosen to make every FMA a packed v_pk_fma_f32 with NO per-FMA LDS operand:
