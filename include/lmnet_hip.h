@@ -181,6 +181,15 @@ int lmn_dw_stats(const float* x1, int B, int H, int W, int E, const float* w5, c
 int lmn_dw_fwd(const float* x1, float* pre, float* gsum, int B, int H, int W, int E, const float* keff,
                const float* beff, lmn_stream_t stream);
 /* builds keff/beff on the device from the four branch weights and per-branch affine (A_b, shift_b) */
+/* Training forward between lmn_dw_stats and lmn_dw_fwd, one launch: finalise the four branch BatchNorms from the
+ * batch sums `stats` [4][2][E] (mean/rstd/A [4][E] out, running statistics updated with `momentum`, unbiased variance
+ * -- nn.BatchNorm2d in training mode, core/modules.py:548-572) and merge the branches into keff [E][25], beff [E]
+ * (get_equivalent_kernel_bias, core/modules.py:622-642).  gamma/beta/running_* are host arrays of 4 device pointers
+ * (branch order 5x5, 3x3, 3x1, 1x3); eps/momentum host arrays of 4 floats.                                        */
+int lmn_dw_finalize_merge(const float* stats, float count, const float* const* gamma, const float* const* beta,
+                          float* const* running_mean, float* const* running_var, const float* eps, const float* momentum,
+                          const float* w5, const float* w3, const float* wv, const float* wh, float* mean, float* rstd,
+                          float* A, float* keff, float* beff, int E, lmn_stream_t stream);
 int lmn_dw_merge(const float* w5, const float* w3, const float* wv, const float* wh, const float* A /*[4][E]*/,
                  const float* shift /*[4][E]*/, float* keff, float* beff, int E, lmn_stream_t stream);
 /* backward, pass 1: dpre = (u*s[b,e] + dm[b,e]) * gelu'(pre); writes dpre and accumulates

@@ -624,6 +624,52 @@ __global__ __launch_bounds__(256) void dw_fwd_strip_kernel(const float* __restri
   }
 }
 
+// Training forward, between the statistics pass and lmn_dw_fwd: finalise the four branch BatchNorms from their
+// batch sums (mean, rstd, A = gamma*rstd, running statistics with momentum -- nn.BatchNorm2d semantics, unbiased
+// running variance) AND merge the branches into the effective 5x5 kernel, in ONE launch instead of 4 + 1.
+// One block per channel: threads 0..3 finalise branch b, then 25 threads write the taps.
+struct DwBnPtrs {
+  const float* gamma[4];
+  const float* beta[4];
+  float* rmean[4];
+  float* rvar[4];
+};
+
+__global__ __launch_bounds__(64) void dw_finalize_merge_kernel(
+    const float* __restrict__ stats, float count, const DwBnPtrs bn, float eps0, float eps1, float eps2, float eps3,
+    float mom0, float mom1, float mom2, float mom3, const float* __restrict__ w5, const float* __restrict__ w3,
+    const float* __restrict__ wv, const float* __restrict__ wh, float* __restrict__ mean, float* __restrict__ rstd,
+    float* __restrict__ A, float* __restrict__ keff, float* __restrict__ beff, int E) {
+  __shared__ float sA[4], sS[4];
+  const int e = blockIdx.x, t = threadIdx.x;
+  if (t < 4) {
+    const float eps = t == 0 ? eps0 : t == 1 ? eps1 : t == 2 ? eps2 : eps3;
+    const float mom = t == 0 ? mom0 : t == 1 ? mom1 : t == 2 ? mom2 : mom3;
+    const float m = stats[(t * 2) * E + e] / count;
+    float var = stats[(t * 2 + 1) * E + e] / count - m * m;  // biased
+    var = var > 0.f ? var : 0.f;
+    const float rs = rsqrtf(var + eps);
+    const float a = bn.gamma[t][e] * rs;
+    mean[t * E + e] = m;
+    rstd[t * E + e] = rs;
+    A[t * E + e] = a;
+    sA[t] = a;
+    sS[t] = bn.beta[t][e] - m * a;
+    bn.rmean[t][e] = (1.f - mom) * bn.rmean[t][e] + mom * m;
+    bn.rvar[t][e] = (1.f - mom) * bn.rvar[t][e] + mom * var * (count > 1.f ? count / (count - 1.f) : 1.f);
+  }
+  __syncthreads();
+  if (t < 25) {
+    const int ky = t / 5, kx = t - ky * 5;
+    float v = sA[0] * w5[e * 25 + t];
+    if (ky >= 1 && ky <= 3 && kx >= 1 && kx <= 3) v += sA[1] * w3[e * 9 + (ky - 1) * 3 + (kx - 1)];
+    if (kx == 2 && ky >= 1 && ky <= 3) v += sA[2] * wv[e * 3 + (ky - 1)];
+    if (ky == 2 && kx >= 1 && kx <= 3) v += sA[3] * wh[e * 3 + (kx - 1)];
+    keff[e * 25 + t] = v;
+    if (t == 0) beff[e] = sS[0] + sS[1] + sS[2] + sS[3];
+  }
+}
+
 // per-branch BN-backward coefficients from bst[5][E] = (S0 = sum dpre, S1_b = sum dpre*y_b)
 __global__ void dw_bwd_coef_kernel(const float* __restrict__ bst, const float* __restrict__ mean,
                                    const float* __restrict__ rstd, const float* __restrict__ A, float count,
@@ -706,6 +752,24 @@ int lmn_dw_fwd(const float* x1, float* pre, float* gsum, int B, int H, int W, in
   hipLaunchKernelGGL(dw_fwd_strip_kernel, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, x1, pre, gsum, H, W, E, keff,
                      beff, strips, segs, seg_rows, chunks);
   return lmn_launch_status("dw_fwd");
+}
+
+int lmn_dw_finalize_merge(const float* stats, float count, const float* const* gamma, const float* const* beta,
+                          float* const* running_mean, float* const* running_var, const float* eps, const float* momentum,
+                          const float* w5, const float* w3, const float* wv, const float* wh, float* mean, float* rstd,
+                          float* A, float* keff, float* beff, int E, lmn_stream_t stream) {
+  LMN_REQUIRE(stats && gamma && beta && running_mean && running_var && eps && momentum && w5 && w3 && wv && wh && mean &&
+                  rstd && A && keff && beff && E > 0 && count > 0.f,
+              "dw_finalize_merge: bad argument");
+  DwBnPtrs bn;
+  for (int b = 0; b < 4; ++b) {
+    LMN_REQUIRE(gamma[b] && beta[b] && running_mean[b] && running_var[b], "dw_finalize_merge: null BatchNorm tensor %d", b);
+    bn.gamma[b] = gamma[b]; bn.beta[b] = beta[b]; bn.rmean[b] = running_mean[b]; bn.rvar[b] = running_var[b];
+  }
+  hipLaunchKernelGGL(dw_finalize_merge_kernel, dim3(E), dim3(64), 0, (hipStream_t)stream, stats, count, bn, eps[0], eps[1],
+                     eps[2], eps[3], momentum[0], momentum[1], momentum[2], momentum[3], w5, w3, wv, wh, mean, rstd, A, keff,
+                     beff, E);
+  return lmn_launch_status("dw_finalize_merge");
 }
 
 int lmn_dw_merge(const float* w5, const float* w3, const float* wv, const float* wh, const float* A, const float* shift,

@@ -255,15 +255,14 @@ class Engine:
             if self.training:
                 st2 = _Z(x, 4, 2, E)
                 hip.dw_stats(x1, *ws, st2)
-            for i, b in enumerate(brs):
-                bn = b.bn
-                if self.training:
-                    hip.bn_finalize(st2[i], N, bn.weight, bn.bias, bn.eps, bn.momentum if bn.momentum is not None else 0.1,
-                                    bmean[i], brstd[i], bA[i], bshift[i], bn.running_mean, bn.running_var)
-                else:
-                    hip.bn_fold(bn.running_mean, bn.running_var, bn.weight, bn.bias, bn.eps, bmean[i], brstd[i], bA[i], bshift[i])
             keff, beff = _E(x, E, 25), _E(x, E)
-            hip.dw_merge(*ws, bA, bshift, keff, beff)
+            if self.training:   # the four finalizes and the merge in one launch
+                hip.dw_finalize_merge(st2, N, [b.bn for b in brs], ws, bmean, brstd, bA, keff, beff)
+            else:
+                for i, b in enumerate(brs):
+                    bn = b.bn
+                    hip.bn_fold(bn.running_mean, bn.running_var, bn.weight, bn.bias, bn.eps, bmean[i], brstd[i], bA[i], bshift[i])
+                hip.dw_merge(*ws, bA, bshift, keff, beff)
         pre = _E(x, B, H, W, E)
         gsum = _Z(x, B, E)
         ev = self.kernel_events.get("dw_fwd") if self.kernel_events is not None else None

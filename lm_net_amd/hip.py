@@ -48,7 +48,7 @@ class WgradArgs(C.Structure):
 SYMBOLS = [
     "lmn_abi_version", "lmn_sizeof_conv_args", "lmn_sizeof_src", "lmn_sizeof_wgrad_args", "lmn_last_error",
     "lmn_conv_pack_size", "lmn_conv_pack", "lmn_conv_pack_batch", "lmn_sizeof_pack_job", "lmn_conv_fwd", "lmn_conv_wgrad", "lmn_conv_wgrad_workspace",
-    "lmn_dw_stats", "lmn_dw_fwd", "lmn_dw_merge", "lmn_dw_bwd_stats", "lmn_dw_bwd_coef", "lmn_dw_bwd",
+    "lmn_dw_stats", "lmn_dw_fwd", "lmn_dw_merge", "lmn_dw_finalize_merge", "lmn_dw_bwd_stats", "lmn_dw_bwd_coef", "lmn_dw_bwd",
     "lmn_se_fwd", "lmn_se_bwd", "lmn_na_fwd", "lmn_na_bwd", "lmn_gattn_fwd", "lmn_gattn_bwd",
     "lmn_ln_fwd", "lmn_ln_bwd", "lmn_bnact_fwd", "lmn_bnact_bwd_stats", "lmn_bnact_bwd",
     "lmn_bn_finalize", "lmn_bn_fold", "lmn_bn_bwd_coef", "lmn_up2_fwd", "lmn_up2_bwd", "lmn_avgpool_fwd", "lmn_avgpool_bwd",
@@ -352,6 +352,19 @@ def dw_merge(w5, w3, wv, wh, A, shift, keff, beff):
 def dw_fwd(x1, pre, gsum, keff, beff):
     B, H, W, E = x1.shape
     _check(load().lmn_dw_fwd(_p(x1), _p(pre), _p(gsum), B, H, W, E, _p(keff), _p(beff), _stream()), "dw_fwd")
+
+
+def dw_finalize_merge(stats, count, bns, ws, mean, rstd, A, keff, beff):
+    """bns: the four BatchNorm2d modules (branch order 5x5, 3x3, 3x1, 1x3); ws: the four depthwise weights."""
+    P4 = C.c_void_p * 4
+    F4 = C.c_float * 4
+    E = mean.shape[-1]
+    _check(load().lmn_dw_finalize_merge(
+        _p(stats), _f(count), P4(*[b.weight.data_ptr() for b in bns]), P4(*[b.bias.data_ptr() for b in bns]),
+        P4(*[b.running_mean.data_ptr() for b in bns]), P4(*[b.running_var.data_ptr() for b in bns]),
+        F4(*[b.eps for b in bns]), F4(*[(b.momentum if b.momentum is not None else 0.1) for b in bns]),
+        _p(ws[0]), _p(ws[1]), _p(ws[2]), _p(ws[3]), _p(mean), _p(rstd), _p(A), _p(keff), _p(beff), E, _stream()),
+        "dw_finalize_merge")
 
 
 def dw_bwd_stats(x1, pre, u, s, dm, dpre, w5, w3, wv, wh, bstats):
