@@ -13,8 +13,9 @@
 // v_pk_fma_f32 directly; the wave walks down the rows of a segment: one x1 row (5 ds_read_b64: columns x-2..x+2)
 // feeds rotating row accumulators (register blocking along y); rows are staged / drained through LDS in batches by
 // the whole block with coalesced 16 B accesses (LDS pixel stride 10 floats = conflict-free for 64 columns).
-// The statistics passes (lmn_dw_stats, lmn_dw_bwd_stats) use the older 16x16-tile walking form: thread = (column,
-// channel pair) with the weights in VGPRs, persistent blocks (the strip form measured slower there).
+// The forward statistics pass (lmn_dw_stats) uses the same strip form; the backward statistics pass
+// (lmn_dw_bwd_stats: three more E-channel tensors through LDS) measured equal-to-slower in it and keeps the older
+// 16x16-tile walking form: thread = (column, channel pair), weights in VGPRs, persistent blocks.
 #include "common.h"
 
 namespace {
@@ -591,7 +592,6 @@ __global__ __launch_bounds__(256) void dw_fwd_strip_kernel(const float* __restri
 #pragma unroll
   for (int k = 0; k < 5; ++k) acc[k] = f32x2{0.f, 0.f};
   f32x2 gs = f32x2{0.f, 0.f};
-  if (tid < SW_CH) gs_s[tid] = 0.f;
   fetch(0);
   commit(0);
   __syncthreads();
@@ -609,7 +609,7 @@ __global__ __launch_bounds__(256) void dw_fwd_strip_kernel(const float* __restri
     if (j0 + SW_R < nsteps) commit(j0 + SW_R);
     __syncthreads();
   }
-  // SE squeeze: wave total by DPP (lands in lane 63), one global atomic per channel per block
+  // SE squeeze: wave total by DPP (lands in lane 63), parked in LDS
   {
     float a = gs.x, c = gs.y;
 #define LMN_DPP_ADD(CTRL)                                                                               \
@@ -617,10 +617,207 @@ __global__ __launch_bounds__(256) void dw_fwd_strip_kernel(const float* __restri
     c += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(c), CTRL, 0xF, 0xF, true));
     LMN_DPP_ADD(0x111) LMN_DPP_ADD(0x112) LMN_DPP_ADD(0x114) LMN_DPP_ADD(0x118) LMN_DPP_ADD(0x142) LMN_DPP_ADD(0x143)
 #undef LMN_DPP_ADD
-    if (lane == 63 && cok) {
-      atomicAdd(gsum + (int64_t)b * E + ch, a);
-      atomicAdd(gsum + (int64_t)b * E + ch + 1, c);
+    if (lane == 63) { gs_s[wv * 2] = a; gs_s[wv * 2 + 1] = c; }
+  }
+  __syncthreads();  // the block's 8 channel sums leave as ONE atomic instruction (single-lane atomics per wave queue up in L2)
+  if (tid < SW_CH && ch0 + tid < E) atomicAdd(gsum + (int64_t)b * E + ch0 + tid, gs_s[tid]);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Statistics passes in the strip-walking form (layout of dw_fwd_strip_kernel; the 5x5 kernel of the channel pair in
+// SGPRs, the three small kernels in VGPRs -- 80 weight floats do not fit the scalar file):
+//   MODE 0: forward batch statistics   stats[4][2][E] += (sum y_b, sum y_b^2)
+//   MODE 1: backward pass 1            dpre = (u*s + dm)*gelu'(pre) -> store; stats[5][E] += (sum dpre, sum dpre*y_b)
+// Sums stay in registers for the whole segment; wave totals by DPP, parked in LDS, ONE atomic instruction per block
+// (a first version issued 16 single-lane atomics per wave: 73 k atomic instructions on 192 addresses = 170 us).
+template <int P, int MODE>
+__device__ __forceinline__ void ss_step(f32x2 (&a5)[5], f32x2 (&a3)[5], f32x2 (&av)[5], f32x2 (&ah)[5],
+                                        f32x2 (&sum)[MODE == 0 ? 8 : 5], const BranchW& bw, const float* XS, const float* PS,
+                                        const float* US, float* OUT, int j, int lane, int wv, bool row_out, bool valid,
+                                        f32x2 sv, f32x2 dv) {
+  const f32x2 z2 = f32x2{0.f, 0.f};
+  const float* xr = XS + ((j % FS_XR) * SW_XC + lane) * SW_CS + wv * 2;
+  f32x2 in[5];
+#pragma unroll
+  for (int d = 0; d < 5; ++d) in[d] = *reinterpret_cast<const f32x2*>(xr + d * SW_CS);
+#pragma unroll
+  for (int ky = 0; ky < 5; ++ky)
+#pragma unroll
+    for (int d = 0; d < 5; ++d) a5[(P - ky + 5) % 5] += bw.w5[ky * 5 + d] * in[d];
+#pragma unroll
+  for (int ky = 0; ky < 3; ++ky) {
+#pragma unroll
+    for (int d = 0; d < 3; ++d) a3[(P + 4 - ky) % 5] += bw.w3[ky * 3 + d] * in[1 + d];
+    av[(P + 4 - ky) % 5] += bw.wv[ky] * in[2];
+  }
+#pragma unroll
+  for (int d = 0; d < 3; ++d) ah[(P + 3) % 5] += bw.wh[d] * in[1 + d];
+  constexpr int D = (P + 1) % 5;  // output row j-4 is complete in every branch
+  if (row_out) {
+    const float m = valid ? 1.f : 0.f;
+    const f32x2 y5 = a5[D] * m, y3 = a3[D] * m, yv = av[D] * m, yh = ah[D] * m;
+    if (MODE == 0) {
+      sum[0] += y5; sum[1] += y3; sum[2] += yv; sum[3] += yh;
+      sum[4] += y5 * y5; sum[5] += y3 * y3; sum[6] += yv * yv; sum[7] += yh * yh;
+    } else {
+      const int o = (P * SW_FC + lane) * SW_CS + wv * 2;
+      const f32x2 pv = *reinterpret_cast<const f32x2*>(PS + o), uv = *reinterpret_cast<const f32x2*>(US + o);
+      f32x2 d;
+      d[0] = (uv[0] * sv[0] + dv[0]) * lmn_dgelu(pv[0]);
+      d[1] = (uv[1] * sv[1] + dv[1]) * lmn_dgelu(pv[1]);
+      *reinterpret_cast<f32x2*>(OUT + o) = d;
+      d *= m;
+      sum[0] += d; sum[1] += d * y5; sum[2] += d * y3; sum[3] += d * yv; sum[4] += d * yh;
     }
+  }
+  a5[D] = a3[D] = av[D] = ah[D] = z2;
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256) void dw_stats_strip_kernel(
+    const float* __restrict__ x1, const float* __restrict__ pre, const float* __restrict__ u,
+    const float* __restrict__ sgate, const float* __restrict__ dm, float* __restrict__ dpre, int H, int W, int E,
+    const float* __restrict__ w5, const float* __restrict__ w3, const float* __restrict__ wvv,
+    const float* __restrict__ whh, float* __restrict__ stats, int strips, int segs, int seg_rows, int chunks) {
+  constexpr int NS = MODE == 0 ? 8 : 5;
+  constexpr int NAUX = MODE == 1 ? SW_R * SW_FC * SW_CS : 4;
+  __shared__ __attribute__((aligned(16))) float XS[FS_XR * SW_XC * SW_CS];
+  __shared__ __attribute__((aligned(16))) float PS[NAUX], US[NAUX], OUT[NAUX];
+  __shared__ float red[NS * SW_CH];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int lid = xcd_swizzle(blockIdx.x, gridDim.x);
+  const int chunk = lid % chunks; lid /= chunks;
+  const int strip = lid % strips; lid /= strips;
+  const int seg = lid % segs;
+  const int b = lid / segs;
+  const int ch0 = chunk * SW_CH, ch = ch0 + wv * 2;
+  const bool cok = ch < E;
+  const int chs = cok ? ch : 0;
+  BranchW bw;
+  load_branch_w(bw, w5, w3, wvv, whh, chs, E);
+#pragma unroll
+  for (int k = 0; k < 9; ++k) asm volatile("" : "+v"(bw.w3[k].x), "+v"(bw.w3[k].y));
+#pragma unroll
+  for (int k = 0; k < 3; ++k) asm volatile("" : "+v"(bw.wv[k].x), "+v"(bw.wv[k].y), "+v"(bw.wh[k].x), "+v"(bw.wh[k].y));
+  f32x2 sv = f32x2{0.f, 0.f}, dv = f32x2{0.f, 0.f};
+  if (MODE == 1) {
+    sv = f32x2{sgate[(int64_t)b * E + chs], sgate[(int64_t)b * E + chs + 1]};
+    dv = f32x2{dm[(int64_t)b * E + chs], dm[(int64_t)b * E + chs + 1]};
+  }
+  const int ys = seg * seg_rows, ye = min(ys + seg_rows, H);
+  const int xs = strip * SW_FC;
+  const bool cvalid = cok && xs + lane < W;
+  const int64_t ib = (int64_t)b * H * W * E;
+  const float* xb = x1 + ib;
+  const int nsteps = (ye - ys) + 4;  // x1 row (ys-2+j) enters at step j; output row (ys+j-4) completes
+
+  constexpr int NX = (SW_R * SW_XC * 2 + 255) / 256, ND = (SW_R * SW_FC * 2 + 255) / 256;
+  f32x4 px[NX], pp[MODE == 1 ? ND : 1], pu[MODE == 1 ? ND : 1];
+  auto fetch = [&](int j0) {
+#pragma unroll
+    for (int k = 0; k < NX; ++k) {
+      const int i = tid + k * 256;
+      const int k4 = i & 1, pc = i >> 1;
+      const int rr = pc / SW_XC, c = pc - rr * SW_XC;
+      const int gy = ys - 2 + j0 + rr, gx = xs - 2 + c;
+      const bool in = i < SW_R * SW_XC * 2 && gx >= 0 && gx < W && ch0 + k4 * 4 < E && gy >= 0 && gy < H;
+      px[k] = *reinterpret_cast<const f32x4*>(xb + (in ? ((int64_t)gy * W + gx) * E + ch0 + k4 * 4 : 0));
+      if (!in) px[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    if (MODE == 1) {
+#pragma unroll
+      for (int k = 0; k < ND; ++k) {  // pre / u rows of the OUTPUT rows of batch j0: image rows ys-4+j0+rr
+        const int i = tid + k * 256;
+        const int k4 = i & 1, pc = i >> 1;
+        const int rr = pc / SW_FC, c = pc - rr * SW_FC;
+        const int gy = ys - 4 + j0 + rr, gx = xs + c;
+        const bool in = i < SW_R * SW_FC * 2 && gx < W && ch0 + k4 * 4 < E && gy >= ys && gy < ye;
+        const int64_t off = in ? ib + ((int64_t)gy * W + gx) * E + ch0 + k4 * 4 : 0;
+        pp[k] = *reinterpret_cast<const f32x4*>(pre + off);
+        pu[k] = *reinterpret_cast<const f32x4*>(u + off);
+        if (!in) pp[k] = pu[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+    }
+  };
+  auto commit = [&](int j0) {
+#pragma unroll
+    for (int k = 0; k < NX; ++k) {
+      const int i = tid + k * 256;
+      if (i < SW_R * SW_XC * 2) {
+        const int k4 = i & 1, pc = i >> 1;
+        const int rr = pc / SW_XC, c = pc - rr * SW_XC;
+        float* d = &XS[(((j0 + rr) % FS_XR) * SW_XC + c) * SW_CS + k4 * 4];
+        *reinterpret_cast<f32x2*>(d) = f32x2{px[k][0], px[k][1]};
+        *reinterpret_cast<f32x2*>(d + 2) = f32x2{px[k][2], px[k][3]};
+      }
+    }
+    if (MODE == 1) {
+#pragma unroll
+      for (int k = 0; k < ND; ++k) {
+        const int i = tid + k * 256;
+        if (i < SW_R * SW_FC * 2) {
+          const int o = (i >> 1) * SW_CS + (i & 1) * 4;
+          *reinterpret_cast<f32x2*>(&PS[o]) = f32x2{pp[k][0], pp[k][1]};
+          *reinterpret_cast<f32x2*>(&PS[o + 2]) = f32x2{pp[k][2], pp[k][3]};
+          *reinterpret_cast<f32x2*>(&US[o]) = f32x2{pu[k][0], pu[k][1]};
+          *reinterpret_cast<f32x2*>(&US[o + 2]) = f32x2{pu[k][2], pu[k][3]};
+        }
+      }
+    }
+  };
+  auto drain = [&](int j0) {  // MODE 1: dpre rows finished by steps j0 .. j0+4 (image rows ys+j-4)
+    for (int i = tid; i < SW_R * SW_FC * 2; i += 256) {
+      const int k4 = i & 1, pc = i >> 1;
+      const int rr = pc / SW_FC, c = pc - rr * SW_FC;
+      const int jj = j0 + rr;
+      const int gy = ys + jj - 4, gx = xs + c;
+      if (jj >= 4 && jj < nsteps && gx < W && ch0 + k4 * 4 < E) {
+        const float* o = &OUT[(rr * SW_FC + c) * SW_CS + k4 * 4];
+        const f32x2 lo = *reinterpret_cast<const f32x2*>(o), hi = *reinterpret_cast<const f32x2*>(o + 2);
+        *reinterpret_cast<f32x4*>(dpre + ib + ((int64_t)gy * W + gx) * E + ch0 + k4 * 4) = f32x4{lo[0], lo[1], hi[0], hi[1]};
+      }
+    }
+  };
+
+  const f32x2 z2 = f32x2{0.f, 0.f};
+  f32x2 a5[5], a3[5], av[5], ah[5], sum[NS];
+#pragma unroll
+  for (int k = 0; k < 5; ++k) a5[k] = a3[k] = av[k] = ah[k] = z2;
+#pragma unroll
+  for (int k = 0; k < NS; ++k) sum[k] = z2;
+  fetch(0);
+  commit(0);
+  __syncthreads();
+  for (int j0 = 0; j0 < nsteps; j0 += SW_R) {
+    if (j0 + SW_R < nsteps) fetch(j0 + SW_R);
+#define LMN_SS_STEP(PH)                                                                                          \
+    {                                                                                                            \
+      const int j = j0 + PH;                                                                                     \
+      if (j < nsteps) ss_step<PH, MODE>(a5, a3, av, ah, sum, bw, XS, PS, US, OUT, j, lane, wv, j >= 4, cvalid, sv, dv); \
+    }
+    LMN_SS_STEP(0) LMN_SS_STEP(1) LMN_SS_STEP(2) LMN_SS_STEP(3) LMN_SS_STEP(4)
+#undef LMN_SS_STEP
+    __syncthreads();
+    if (MODE == 1) drain(j0);
+    if (j0 + SW_R < nsteps) commit(j0 + SW_R);
+    __syncthreads();
+  }
+#pragma unroll
+  for (int k = 0; k < NS; ++k) {
+    float a = sum[k].x, c = sum[k].y;
+#define LMN_DPP_ADD(CTRL)                                                                               \
+    a += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(a), CTRL, 0xF, 0xF, true));       \
+    c += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(c), CTRL, 0xF, 0xF, true));
+    LMN_DPP_ADD(0x111) LMN_DPP_ADD(0x112) LMN_DPP_ADD(0x114) LMN_DPP_ADD(0x118) LMN_DPP_ADD(0x142) LMN_DPP_ADD(0x143)
+#undef LMN_DPP_ADD
+    if (lane == 63) { red[k * SW_CH + wv * 2] = a; red[k * SW_CH + wv * 2 + 1] = c; }
+  }
+  __syncthreads();
+  if (tid < NS * SW_CH) {
+    const int k = tid / SW_CH, cc = tid - k * SW_CH;
+    const int row = MODE == 0 ? ((k & 3) * 2 + (k >> 2)) : k;  // MODE 0: [branch][sum|sumsq][E]
+    if (ch0 + cc < E) atomicAdd(stats + (int64_t)row * E + ch0 + cc, red[tid]);
   }
 }
 
@@ -696,6 +893,39 @@ __global__ void dw_bwd_coef_kernel(const float* __restrict__ bst, const float* _
 
 }  // namespace
 
+// Row segments of the strip kernels: every segment re-walks `halo` extra rows, and the grid runs in rounds of
+// occ blocks per CU x 256 CUs -- pick the segment count that minimises rounds x (rows + halo) (e.g. level 0 of the
+// backward kernel: 8 segments = 3 rounds x 54 row steps, 7 segments = 2 rounds x 61).
+static int strip_segments(int64_t blocks_per_seg, int H, int halo, int occ, int* seg_rows) {
+  int best = 1;
+  int64_t best_cost = -1;
+  for (int sg = 1; sg <= H; ++sg) {
+    const int rows = lmn_cdiv(H, sg);
+    if (sg > 1 && rows < 8) break;
+    const int nseg = lmn_cdiv(H, rows);
+    if (nseg != sg) continue;  // same partition as a smaller count
+    const int64_t rounds = (blocks_per_seg * nseg + (int64_t)occ * 256 - 1) / ((int64_t)occ * 256);
+    const int64_t cost = rounds * (rows + halo);
+    if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = sg; }
+  }
+  *seg_rows = lmn_cdiv(H, best);
+  return lmn_cdiv(H, *seg_rows);
+}
+
+template <int MODE>
+static int launch_dw_strip_stats(const float* x1, const float* pre, const float* u, const float* s, const float* dm,
+                                 float* dpre, int B, int H, int W, int E, const float* w5, const float* w3,
+                                 const float* wv, const float* wh, float* stats, hipStream_t st) {
+  const int strips = lmn_cdiv(W, SW_FC), chunks = lmn_cdiv(E, SW_CH);
+  int seg_rows;
+  const int segs = strip_segments((int64_t)B * strips * chunks, H, 4, MODE == 0 ? 3 : 2, &seg_rows);
+  const int64_t nblk = (int64_t)B * strips * chunks * segs;
+  if (nblk >= (1LL << 31)) return -1;
+  hipLaunchKernelGGL((dw_stats_strip_kernel<MODE>), dim3((unsigned)nblk), dim3(256), 0, st, x1, pre, u, s, dm, dpre, H, W, E,
+                     w5, w3, wv, wh, stats, strips, segs, seg_rows, chunks);
+  return 0;
+}
+
 template <int MODE>
 static int launch_dw_walk_stats(const float* x1, const float* pre, const float* u, const float* s, const float* dm,
                                 float* dpre, int B, int H, int W, int E, const float* w5, const float* w3,
@@ -717,25 +947,6 @@ static int launch_dw_walk_stats(const float* x1, const float* pre, const float* 
   return 0;
 }
 
-
-// Row segments of the strip kernels: every segment re-walks `halo` extra rows, and the grid runs in rounds of
-// occ blocks per CU x 256 CUs -- pick the segment count that minimises rounds x (rows + halo) (e.g. level 0 of the
-// backward kernel: 8 segments = 3 rounds x 54 row steps, 7 segments = 2 rounds x 61).
-static int strip_segments(int64_t blocks_per_seg, int H, int halo, int occ, int* seg_rows) {
-  int best = 1;
-  int64_t best_cost = -1;
-  for (int sg = 1; sg <= H; ++sg) {
-    const int rows = lmn_cdiv(H, sg);
-    if (sg > 1 && rows < 8) break;
-    const int nseg = lmn_cdiv(H, rows);
-    if (nseg != sg) continue;  // same partition as a smaller count
-    const int64_t rounds = (blocks_per_seg * nseg + (int64_t)occ * 256 - 1) / ((int64_t)occ * 256);
-    const int64_t cost = rounds * (rows + halo);
-    if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = sg; }
-  }
-  *seg_rows = lmn_cdiv(H, best);
-  return lmn_cdiv(H, *seg_rows);
-}
 
 extern "C" {
 
@@ -791,7 +1002,7 @@ int lmn_dw_stats(const float* x1, int B, int H, int W, int E, const float* w5, c
                  const float* wh, float* stats, lmn_stream_t stream) {
   LMN_REQUIRE(x1 && w5 && w3 && wv && wh && stats, "dw_stats: null pointer");
   LMN_REQUIRE(B > 0 && H > 0 && W > 0 && E > 0 && E % 4 == 0, "dw_stats: E=%d must be a multiple of 4", E);
-  launch_dw_walk_stats<0>(x1, nullptr, nullptr, nullptr, nullptr, nullptr, B, H, W, E, w5, w3, wv, wh, stats, (hipStream_t)stream);
+  launch_dw_strip_stats<0>(x1, nullptr, nullptr, nullptr, nullptr, nullptr, B, H, W, E, w5, w3, wv, wh, stats, (hipStream_t)stream);
   return lmn_launch_status("dw_stats");
 }
 
