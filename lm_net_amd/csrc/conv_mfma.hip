@@ -1416,7 +1416,7 @@ int64_t lmn_conv_wgrad_workspace(const lmn_wgrad_args_t* a) {
   wgrad_tile_shape(*a, nmtt, nntt, &NMT, &NNT);
   const int gy = ((nmtt + NMT - 1) / NMT) * ((nntt + NNT - 1) / NNT);
   const int64_t per = (int64_t)a->ksize * a->ksize * NMT * NNT * 256 + NMT * 16;
-  const int64_t cap = 1024 / gy > 2 ? 1024 / gy : 2;  // upper bound of the K-split block count (see lmn_conv_wgrad)
+  const int64_t cap = 512 / gy > 2 ? 512 / gy : 2;  // upper bound of the K-split block count (see lmn_conv_wgrad)
   const int64_t need = gy * cap * per;
   return need <= (int64_t)(16 << 20) ? need : 0;  // at most 64 MB of partials; larger problems use atomics
 }
@@ -1747,7 +1747,7 @@ int lmn_conv_wgrad(const lmn_wgrad_args_t* args, lmn_stream_t stream) {
   LMN_REQUIRE(lds_floats * 4 <= 160 * 1024, "conv_wgrad: LDS tile too large (%lld B)", (long long)lds_floats * 4);
   // K-split: enough blocks to fill the chip (~1024 in total), each walking a contiguous range of tiles
   int64_t blocks64 = P.total_tiles;
-  const int64_t cap = 1024 / gy > 2 ? 1024 / gy : 2;
+  const int64_t cap = 512 / gy > 2 ? 512 / gy : 2;
   if (blocks64 > cap) blocks64 = cap;
   if (blocks64 < 1) blocks64 = 1;
   // two-stage reduction when the caller's workspace holds every block partial; else LDS-reduced atomics with fewer blocks

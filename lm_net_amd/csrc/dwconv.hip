@@ -13,17 +13,12 @@
 // v_pk_fma_f32 directly; the wave walks down the rows of a segment: one x1 row (5 ds_read_b64: columns x-2..x+2)
 // feeds rotating row accumulators (register blocking along y); rows are staged / drained through LDS in batches by
 // the whole block with coalesced 16 B accesses (LDS pixel stride 10 floats = conflict-free for 64 columns).
-// The forward statistics pass (lmn_dw_stats) uses the same strip form; the backward statistics pass
-// (lmn_dw_bwd_stats: three more E-channel tensors through LDS) measured equal-to-slower in it and keeps the older
-// 16x16-tile walking form: thread = (column, channel pair), weights in VGPRs, persistent blocks.
+// Both statistics passes (lmn_dw_stats, lmn_dw_bwd_stats) use the same strip form.
 #include "common.h"
 
 namespace {
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
-
-constexpr int FW_TH = 16, FW_TW = 16;
-constexpr int FW_RW = FW_TW + 4, FW_RH = FW_TH + 4;
 
 // XCD-aware block order (guide T1, bijective form): consecutive LOGICAL tiles run on the same XCD, so the 2-pixel
 // halos shared by neighbouring tiles hit that XCD's L2 instead of being re-fetched from HBM by another XCD.
@@ -48,132 +43,6 @@ __device__ __forceinline__ void load_branch_w(BranchW& bw, const float* w5, cons
   for (int t = 0; t < 3; ++t) {
     bw.wv[t] = ok ? f32x2{wv[(int64_t)ch * 3 + t], wv[(int64_t)(ch + 1) * 3 + t]} : z;
     bw.wh[t] = ok ? f32x2{wh[(int64_t)ch * 3 + t], wh[(int64_t)(ch + 1) * 3 + t]} : z;
-  }
-}
-
-// Statistics passes in the same walking form as dw_fwd_kernel (one LDS row = 5 ds_read_b64 per thread feeds all four
-// branch stencils: 40 packed FMAs into 4 x 5 rotating accumulators), instead of 40 LDS reads per output.
-//   MODE 0: forward batch statistics   stats[4][2][E] += (sum y_b, sum y_b^2)
-//   MODE 1: backward pass 1            dpre = (u*s + dm) * gelu'(pre) -> store; stats[5][E] += (sum dpre, sum dpre*y_b)
-template <int CCH, int MODE>
-__global__ __launch_bounds__(FW_TW * CCH / 2) void dw_walk_stats_kernel(
-    const float* __restrict__ x1, const float* __restrict__ pre, const float* __restrict__ u,
-    const float* __restrict__ sgate, const float* __restrict__ dm, float* __restrict__ dpre, int H, int W, int E,
-    const float* __restrict__ w5, const float* __restrict__ w3, const float* __restrict__ wvv,
-    const float* __restrict__ whh, float* __restrict__ stats, int tiles_x, int tiles, int chunks) {
-  constexpr int NCP = CCH / 2, THREADS = FW_TW * NCP;
-  constexpr int NS = MODE == 0 ? 8 : 5;
-  extern __shared__ __attribute__((aligned(16))) float tile[];  // [FW_RH*FW_RW][CCH], reused as [THREADS][NS*2]
-  const int tid = threadIdx.x;
-  const int ch0 = blockIdx.y * CCH;
-  const int cp = tid % NCP, xx = tid / NCP;
-  const int ch = ch0 + cp * 2;
-  const bool cok = ch < E;
-  BranchW bw;
-  load_branch_w(bw, w5, w3, wvv, whh, ch, E);
-  const f32x2 z2 = f32x2{0.f, 0.f};
-  f32x2 sum[NS];
-#pragma unroll
-  for (int k = 0; k < NS; ++k) sum[k] = z2;
-  // persistent over a contiguous range of (image, tile) pairs: sums stay in registers, one atomic set per block.
-  // XCD-aware: logical block ids that are neighbours share an XCD, so their ranges (and halos) share an L2.
-  const int lb = xcd_swizzle(blockIdx.x, gridDim.x);
-  const int nt_all = tiles * chunks;  // `chunks` carries the batch size B here
-  const int t_begin = (int)(((int64_t)lb * nt_all) / gridDim.x), t_end = (int)(((int64_t)(lb + 1) * nt_all) / gridDim.x);
-  for (int tt = t_begin; tt < t_end; ++tt) {
-  const int b = tt / tiles, t = tt - b * tiles;
-  const int ty0 = (t / tiles_x) * FW_TH, tx0 = (t % tiles_x) * FW_TW;
-  const float* xb = x1 + (int64_t)b * H * W * E;
-  __syncthreads();  // previous tile fully consumed
-  for (int i = tid; i < FW_RH * FW_RW * (CCH / 4); i += THREADS) {
-    const int c4 = i % (CCH / 4), pix = i / (CCH / 4);
-    const int r = pix / FW_RW, c = pix - r * FW_RW;
-    const int gy = ty0 - 2 + r, gx = tx0 - 2 + c;
-    const bool in = gy >= 0 && gy < H && gx >= 0 && gx < W && ch0 + c4 * 4 < E;
-    const int sy = in ? gy : 0, sx = in ? gx : 0, sc = in ? ch0 + c4 * 4 : 0;
-    f32x4 v = *reinterpret_cast<const f32x4*>(xb + ((int64_t)sy * W + sx) * E + sc);
-    if (!in) v = f32x4{0.f, 0.f, 0.f, 0.f};
-    *reinterpret_cast<f32x4*>(&tile[pix * CCH + c4 * 4]) = v;
-  }
-  f32x2 sv = f32x2{0.f, 0.f}, dv = f32x2{0.f, 0.f};
-  if (MODE == 1 && cok) {
-    sv = *reinterpret_cast<const f32x2*>(sgate + (int64_t)b * E + ch);
-    dv = *reinterpret_cast<const f32x2*>(dm + (int64_t)b * E + ch);
-  }
-  __syncthreads();
-
-  f32x2 a5[5], a3[5], av[5], ah[5];
-#pragma unroll
-  for (int k = 0; k < 5; ++k) a5[k] = a3[k] = av[k] = ah[k] = z2;
-  const int gx = tx0 + xx;
-#pragma unroll
-  for (int r = 0; r < FW_RH; ++r) {
-    f32x2 in[5];
-#pragma unroll
-    for (int dx = 0; dx < 5; ++dx) in[dx] = *reinterpret_cast<const f32x2*>(&tile[(r * FW_RW + xx + dx) * CCH + cp * 2]);
-    // 5x5: output row o = r - ky
-#pragma unroll
-    for (int ky = 0; ky < 5; ++ky) {
-      const int o = r - ky;
-      if (o >= 0 && o < FW_TH) {
-#pragma unroll
-        for (int dx = 0; dx < 5; ++dx) a5[o % 5] += bw.w5[ky * 5 + dx] * in[dx];
-      }
-    }
-    // 3x3 and 3x1: output row o = r - 1 - ky3 (window rows o-1..o+1 are halo rows o+1..o+3)
-#pragma unroll
-    for (int ky = 0; ky < 3; ++ky) {
-      const int o = r - 1 - ky;
-      if (o >= 0 && o < FW_TH) {
-#pragma unroll
-        for (int dx = 0; dx < 3; ++dx) a3[o % 5] += bw.w3[ky * 3 + dx] * in[1 + dx];
-        av[o % 5] += bw.wv[ky] * in[2];
-      }
-    }
-    // 1x3: output row o = r - 2
-    {
-      const int o = r - 2;
-      if (o >= 0 && o < FW_TH) {
-#pragma unroll
-        for (int dx = 0; dx < 3; ++dx) ah[o % 5] += bw.wh[dx] * in[1 + dx];
-      }
-    }
-    const int o = r - 4;  // every branch of output row o is complete
-    if (o >= 0) {
-      const int gy = ty0 + o;
-      const f32x2 y5 = a5[o % 5], y3 = a3[o % 5], yv = av[o % 5], yh = ah[o % 5];
-      a5[o % 5] = a3[o % 5] = av[o % 5] = ah[o % 5] = z2;
-      if (gy < H && gx < W && cok) {
-        if (MODE == 0) {
-          sum[0] += y5; sum[1] += y3; sum[2] += yv; sum[3] += yh;
-          sum[4] += y5 * y5; sum[5] += y3 * y3; sum[6] += yv * yv; sum[7] += yh * yh;
-        } else {
-          const int64_t off = (((int64_t)b * H + gy) * W + gx) * E + ch;
-          const f32x2 pv = *reinterpret_cast<const f32x2*>(pre + off);
-          const f32x2 uv = *reinterpret_cast<const f32x2*>(u + off);
-          f32x2 d;
-          d[0] = (uv[0] * sv[0] + dv[0]) * lmn_dgelu(pv[0]);
-          d[1] = (uv[1] * sv[1] + dv[1]) * lmn_dgelu(pv[1]);
-          *reinterpret_cast<f32x2*>(dpre + off) = d;
-          sum[0] += d; sum[1] += d * y5; sum[2] += d * y3; sum[3] += d * yv; sum[4] += d * yh;
-        }
-      }
-    }
-  }
-  }  // tiles
-  // block reduction without LDS atomics: every thread parks its sums, then one thread per (sum, channel) adds the
-  // 16 columns; one global atomic per (sum, channel) per block
-  __syncthreads();
-#pragma unroll
-  for (int k = 0; k < NS; ++k) *reinterpret_cast<f32x2*>(&tile[(tid * NS + k) * 2]) = sum[k];
-  __syncthreads();
-  for (int i = tid; i < NS * CCH; i += THREADS) {
-    const int k = i / CCH, cc = i - k * CCH;     // channel cc of the chunk: pair cc/2, component cc&1
-    float v = 0.f;
-#pragma unroll
-    for (int x = 0; x < FW_TW; ++x) v += tile[((x * NCP + (cc >> 1)) * NS + k) * 2 + (cc & 1)];
-    const int row = MODE == 0 ? ((k & 3) * 2 + (k >> 2)) : k;  // MODE 0: [branch][sum|sumsq][E]
-    if (ch0 + cc < E) atomicAdd(stats + (int64_t)row * E + ch0 + cc, v);
   }
 }
 
@@ -926,27 +795,6 @@ static int launch_dw_strip_stats(const float* x1, const float* pre, const float*
   return 0;
 }
 
-template <int MODE>
-static int launch_dw_walk_stats(const float* x1, const float* pre, const float* u, const float* s, const float* dm,
-                                float* dpre, int B, int H, int W, int E, const float* w5, const float* w3,
-                                const float* wv, const float* wh, float* stats, hipStream_t st) {
-  const int tx = lmn_cdiv(W, FW_TW), ty = lmn_cdiv(H, FW_TH);
-  const int cch = (E % 32 == 0) ? 32 : 24;
-  const int chunks = lmn_cdiv(E, cch);
-  int gx = tx * ty * B;                      // persistent blocks: ~1024 in total
-  const int cap = 1024 / chunks > 64 ? 1024 / chunks : 64;
-  if (gx > cap) gx = cap;
-  const dim3 grid(gx, chunks);
-  const size_t sh = (size_t)FW_RH * FW_RW * cch * sizeof(float);  // >= THREADS * 16 floats of reduction scratch
-  if (cch == 24)
-    hipLaunchKernelGGL((dw_walk_stats_kernel<24, MODE>), grid, dim3(FW_TW * 12), sh, st, x1, pre, u, s, dm, dpre, H,
-                       W, E, w5, w3, wv, wh, stats, tx, tx * ty, B);
-  else
-    hipLaunchKernelGGL((dw_walk_stats_kernel<32, MODE>), grid, dim3(FW_TW * 16), sh, st, x1, pre, u, s, dm, dpre, H,
-                       W, E, w5, w3, wv, wh, stats, tx, tx * ty, B);
-  return 0;
-}
-
 
 extern "C" {
 
@@ -991,13 +839,6 @@ int lmn_dw_merge(const float* w5, const float* w3, const float* wv, const float*
   return lmn_launch_status("dw_merge");
 }
 
-static int dw_grid_x(int B, int tx, int ty, int chunks) {
-  int64_t n = (int64_t)B * tx * ty;
-  int64_t cap = 2048 / chunks;
-  if (cap < 64) cap = 64;
-  return (int)(n < cap ? n : cap);
-}
-
 int lmn_dw_stats(const float* x1, int B, int H, int W, int E, const float* w5, const float* w3, const float* wv,
                  const float* wh, float* stats, lmn_stream_t stream) {
   LMN_REQUIRE(x1 && w5 && w3 && wv && wh && stats, "dw_stats: null pointer");
@@ -1011,7 +852,7 @@ int lmn_dw_bwd_stats(const float* x1, const float* pre, const float* u, const fl
                      float* bstats, lmn_stream_t stream) {
   LMN_REQUIRE(x1 && pre && u && s && dm && dpre && w5 && w3 && wv && wh && bstats, "dw_bwd_stats: null pointer");
   LMN_REQUIRE(B > 0 && H > 0 && W > 0 && E > 0 && E % 4 == 0, "dw_bwd_stats: E=%d must be a multiple of 4", E);
-  launch_dw_walk_stats<1>(x1, pre, u, s, dm, dpre, B, H, W, E, w5, w3, wv, wh, bstats, (hipStream_t)stream);
+  launch_dw_strip_stats<1>(x1, pre, u, s, dm, dpre, B, H, W, E, w5, w3, wv, wh, bstats, (hipStream_t)stream);
   return lmn_launch_status("dw_bwd_stats");
 }
 
