@@ -20,6 +20,23 @@ namespace {
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
+// Raw buffer access (bounds-checked by the descriptor: out-of-range loads return 0, stores are dropped).
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef __amdgpu_buffer_rsrc_t BufRsrc;
+__device__ __forceinline__ BufRsrc make_rsrc(const float* base, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, (int)bytes, 0x00020000);
+}
+// byte_off: per-lane offset (range-checked); soff: wave-uniform offset added to the address
+__device__ __forceinline__ f32x4 buf_load4(BufRsrc r, unsigned byte_off, int soff = 0) {
+  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_off, soff, 0));
+}
+__device__ __forceinline__ void buf_store4(BufRsrc r, unsigned byte_off, f32x4 v) {
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, (int)byte_off, 0, 0);
+}
+__device__ __forceinline__ void buf_store4(BufRsrc r, unsigned byte_off, int soff, f32x4 v) {
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, (int)byte_off, soff, 0);
+}
+
 // XCD-aware block order (guide T1, bijective form): consecutive LOGICAL tiles run on the same XCD, so the 2-pixel
 // halos shared by neighbouring tiles hit that XCD's L2 instead of being re-fetched from HBM by another XCD.
 __device__ __forceinline__ int xcd_swizzle(int bid, int nwg) {
@@ -416,43 +433,61 @@ __global__ __launch_bounds__(256) void dw_fwd_strip_kernel(const float* __restri
   float* ob = pre + (int64_t)b * H * W * E;
   const int nsteps = (ye - ys) + 4;  // x1 row (ys-2+j) enters at step j; output row (ys+j-4) completes
 
-  constexpr int NX = (SW_R * SW_XC * 2 + 255) / 256;
-  f32x4 px[NX];
-  auto fetch = [&](int j0) {
+  // Staging geometry is fixed per thread: byte offsets into the image (loads) / the row segment (stores) and LDS
+  // indices are computed ONCE; a batch only adds its wave-uniform row offset.  Bounds are the buffer descriptor's job:
+  // columns / channels outside the tensor carry an offset beyond num_records for good, rows above the image wrap
+  // negative, rows below it (or below the segment, for stores) exceed num_records -- loads return 0, stores are dropped.
+  constexpr int NX = (SW_R * SW_XC * 2 + 255) / 256, ND = (SW_R * SW_FC * 2 + 255) / 256;
+  constexpr unsigned OOB = 0x80000000u;
+  const int rowb = W * E * 4;  // bytes per image row (host: (H+8)*W*E*4 < 2^30)
+  const BufRsrc rin = make_rsrc(xb, (unsigned)H * rowb);
+  const BufRsrc rout = make_rsrc(ob + (int64_t)ys * W * E, (unsigned)(ye - ys) * rowb);
+  unsigned fo[NX], so[ND];
+  int li[NX], lo[ND];
 #pragma unroll
-    for (int k = 0; k < NX; ++k) {
-      const int i = tid + k * 256;
-      const int k4 = i & 1, pc = i >> 1;
-      const int rr = pc / SW_XC, c = pc - rr * SW_XC;
-      const int gy = ys - 2 + j0 + rr, gx = xs - 2 + c;
-      const bool in = i < SW_R * SW_XC * 2 && gx >= 0 && gx < W && ch0 + k4 * 4 < E && gy >= 0 && gy < H;
-      px[k] = *reinterpret_cast<const f32x4*>(xb + (in ? ((int64_t)gy * W + gx) * E + ch0 + k4 * 4 : 0));
-      if (!in) px[k] = f32x4{0.f, 0.f, 0.f, 0.f};
-    }
+  for (int k = 0; k < NX; ++k) {
+    const int i = tid + k * 256;
+    const int k4 = i & 1, pc = i >> 1;
+    const int rr = pc / SW_XC, c = pc - rr * SW_XC;
+    const int gx = xs - 2 + c;
+    const bool ok = i < SW_R * SW_XC * 2 && gx >= 0 && gx < W && ch0 + k4 * 4 < E;
+    fo[k] = ok ? (unsigned)(((rr - 2) * W + gx) * E + ch0 + k4 * 4) * 4u : OOB;
+    li[k] = (rr * SW_XC + c) * SW_CS + k4 * 4;
+  }
+#pragma unroll
+  for (int k = 0; k < ND; ++k) {
+    const int i = tid + k * 256;
+    const int k4 = i & 1, pc = i >> 1;
+    const int rr = pc / SW_FC, c = pc - rr * SW_FC;
+    const bool ok = i < SW_R * SW_FC * 2 && xs + c < W && ch0 + k4 * 4 < E;
+    so[k] = ok ? (unsigned)(((rr - 4) * W + xs + c) * E + ch0 + k4 * 4) * 4u : OOB;
+    lo[k] = (rr * SW_FC + c) * SW_CS + k4 * 4;
+  }
+  f32x4 px[NX];
+  auto fetch = [&](int j0) {  // x1 rows ys-2+j0 .. +4
+    const unsigned base = (unsigned)((ys + j0) * rowb);
+#pragma unroll
+    for (int k = 0; k < NX; ++k) px[k] = buf_load4(rin, fo[k] + base);  // OOB + base stays >= 2^31
   };
   auto commit = [&](int j0) {
+    float* ring = XS + (j0 % FS_XR) * (SW_XC * SW_CS);
 #pragma unroll
     for (int k = 0; k < NX; ++k) {
-      const int i = tid + k * 256;
-      if (i < SW_R * SW_XC * 2) {
-        const int k4 = i & 1, pc = i >> 1;
-        const int rr = pc / SW_XC, c = pc - rr * SW_XC;
-        float* d = &XS[(((j0 + rr) % FS_XR) * SW_XC + c) * SW_CS + k4 * 4];
+      if (k * 256 + 255 < SW_R * SW_XC * 2 || tid + k * 256 < SW_R * SW_XC * 2) {
+        float* d = ring + li[k];
         *reinterpret_cast<f32x2*>(d) = f32x2{px[k][0], px[k][1]};
         *reinterpret_cast<f32x2*>(d + 2) = f32x2{px[k][2], px[k][3]};
       }
     }
   };
-  auto drain = [&](int j0) {  // output rows finished by steps j0 .. j0+4 (image rows ys+j-4)
-    for (int i = tid; i < SW_R * SW_FC * 2; i += 256) {
-      const int k4 = i & 1, pc = i >> 1;
-      const int rr = pc / SW_FC, c = pc - rr * SW_FC;
-      const int jj = j0 + rr;
-      const int gy = ys + jj - 4, gx = xs + c;
-      if (jj >= 4 && jj < nsteps && gx < W && ch0 + k4 * 4 < E) {
-        const float* o = &OUT[(rr * SW_FC + c) * SW_CS + k4 * 4];
-        const f32x2 lo = *reinterpret_cast<const f32x2*>(o), hi = *reinterpret_cast<const f32x2*>(o + 2);
-        *reinterpret_cast<f32x4*>(ob + ((int64_t)gy * W + gx) * E + ch0 + k4 * 4) = f32x4{lo[0], lo[1], hi[0], hi[1]};
+  auto drain = [&](int j0) {  // output rows ys+j0-4 .. ys+j0 (rows outside the segment fall off the descriptor)
+    const unsigned base = (unsigned)(j0 * rowb);
+#pragma unroll
+    for (int k = 0; k < ND; ++k) {
+      if (k * 256 + 255 < SW_R * SW_FC * 2 || tid + k * 256 < SW_R * SW_FC * 2) {
+        const float* o = &OUT[lo[k]];
+        const f32x2 a = *reinterpret_cast<const f32x2*>(o), c = *reinterpret_cast<const f32x2*>(o + 2);
+        buf_store4(rout, so[k] + base, f32x4{a[0], a[1], c[0], c[1]});
       }
     }
   };
@@ -581,42 +616,58 @@ __global__ __launch_bounds__(256) void dw_stats_strip_kernel(
   const float* xb = x1 + ib;
   const int nsteps = (ye - ys) + 4;  // x1 row (ys-2+j) enters at step j; output row (ys+j-4) completes
 
+  // staging geometry fixed per thread, bounds by buffer descriptors (see dw_fwd_strip_kernel)
   constexpr int NX = (SW_R * SW_XC * 2 + 255) / 256, ND = (SW_R * SW_FC * 2 + 255) / 256;
-  f32x4 px[NX], pp[MODE == 1 ? ND : 1], pu[MODE == 1 ? ND : 1];
-  auto fetch = [&](int j0) {
+  constexpr unsigned OOB = 0x80000000u;
+  const int rowb = W * E * 4;
+  const int64_t sb = ib + (int64_t)ys * W * E;  // first element of the row segment
+  const BufRsrc rin = make_rsrc(xb, (unsigned)H * rowb);
+  const BufRsrc rpre = make_rsrc(MODE == 1 ? pre + sb : xb, MODE == 1 ? (unsigned)(ye - ys) * rowb : 0u);
+  const BufRsrc ru = make_rsrc(MODE == 1 ? u + sb : xb, MODE == 1 ? (unsigned)(ye - ys) * rowb : 0u);
+  const BufRsrc rout = make_rsrc(MODE == 1 ? dpre + sb : xb, MODE == 1 ? (unsigned)(ye - ys) * rowb : 0u);
+  unsigned fo[NX], so[MODE == 1 ? ND : 1];
+  int li[NX], lo[MODE == 1 ? ND : 1];
 #pragma unroll
-    for (int k = 0; k < NX; ++k) {
+  for (int k = 0; k < NX; ++k) {
+    const int i = tid + k * 256;
+    const int k4 = i & 1, pc = i >> 1;
+    const int rr = pc / SW_XC, c = pc - rr * SW_XC;
+    const int gx = xs - 2 + c;
+    const bool ok = i < SW_R * SW_XC * 2 && gx >= 0 && gx < W && ch0 + k4 * 4 < E;
+    fo[k] = ok ? (unsigned)(((rr - 2) * W + gx) * E + ch0 + k4 * 4) * 4u : OOB;
+    li[k] = (rr * SW_XC + c) * SW_CS + k4 * 4;
+  }
+  if (MODE == 1) {
+#pragma unroll
+    for (int k = 0; k < ND; ++k) {
       const int i = tid + k * 256;
       const int k4 = i & 1, pc = i >> 1;
-      const int rr = pc / SW_XC, c = pc - rr * SW_XC;
-      const int gy = ys - 2 + j0 + rr, gx = xs - 2 + c;
-      const bool in = i < SW_R * SW_XC * 2 && gx >= 0 && gx < W && ch0 + k4 * 4 < E && gy >= 0 && gy < H;
-      px[k] = *reinterpret_cast<const f32x4*>(xb + (in ? ((int64_t)gy * W + gx) * E + ch0 + k4 * 4 : 0));
-      if (!in) px[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+      const int rr = pc / SW_FC, c = pc - rr * SW_FC;
+      const bool ok = i < SW_R * SW_FC * 2 && xs + c < W && ch0 + k4 * 4 < E;
+      so[k] = ok ? (unsigned)(((rr - 4) * W + xs + c) * E + ch0 + k4 * 4) * 4u : OOB;
+      lo[k] = (rr * SW_FC + c) * SW_CS + k4 * 4;
     }
-    if (MODE == 1) {
+  }
+  f32x4 px[NX], pp[MODE == 1 ? ND : 1], pu[MODE == 1 ? ND : 1];
+  auto fetch = [&](int j0) {
+    const unsigned base = (unsigned)((ys + j0) * rowb);
 #pragma unroll
-      for (int k = 0; k < ND; ++k) {  // pre / u rows of the OUTPUT rows of batch j0: image rows ys-4+j0+rr
-        const int i = tid + k * 256;
-        const int k4 = i & 1, pc = i >> 1;
-        const int rr = pc / SW_FC, c = pc - rr * SW_FC;
-        const int gy = ys - 4 + j0 + rr, gx = xs + c;
-        const bool in = i < SW_R * SW_FC * 2 && gx < W && ch0 + k4 * 4 < E && gy >= ys && gy < ye;
-        const int64_t off = in ? ib + ((int64_t)gy * W + gx) * E + ch0 + k4 * 4 : 0;
-        pp[k] = *reinterpret_cast<const f32x4*>(pre + off);
-        pu[k] = *reinterpret_cast<const f32x4*>(u + off);
-        if (!in) pp[k] = pu[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int k = 0; k < NX; ++k) px[k] = buf_load4(rin, fo[k] + base);
+    if (MODE == 1) {  // pre / u rows of the OUTPUT rows of batch j0: segment rows j0-4+rr
+      const unsigned sbase = (unsigned)(j0 * rowb);
+#pragma unroll
+      for (int k = 0; k < ND; ++k) {
+        pp[k] = buf_load4(rpre, so[k] + sbase);
+        pu[k] = buf_load4(ru, so[k] + sbase);
       }
     }
   };
   auto commit = [&](int j0) {
+    float* ring = XS + (j0 % FS_XR) * (SW_XC * SW_CS);
 #pragma unroll
     for (int k = 0; k < NX; ++k) {
-      const int i = tid + k * 256;
-      if (i < SW_R * SW_XC * 2) {
-        const int k4 = i & 1, pc = i >> 1;
-        const int rr = pc / SW_XC, c = pc - rr * SW_XC;
-        float* d = &XS[(((j0 + rr) % FS_XR) * SW_XC + c) * SW_CS + k4 * 4];
+      if (k * 256 + 255 < SW_R * SW_XC * 2 || tid + k * 256 < SW_R * SW_XC * 2) {
+        float* d = ring + li[k];
         *reinterpret_cast<f32x2*>(d) = f32x2{px[k][0], px[k][1]};
         *reinterpret_cast<f32x2*>(d + 2) = f32x2{px[k][2], px[k][3]};
       }
@@ -624,9 +675,8 @@ __global__ __launch_bounds__(256) void dw_stats_strip_kernel(
     if (MODE == 1) {
 #pragma unroll
       for (int k = 0; k < ND; ++k) {
-        const int i = tid + k * 256;
-        if (i < SW_R * SW_FC * 2) {
-          const int o = (i >> 1) * SW_CS + (i & 1) * 4;
+        if (k * 256 + 255 < SW_R * SW_FC * 2 || tid + k * 256 < SW_R * SW_FC * 2) {
+          const int o = lo[k];
           *reinterpret_cast<f32x2*>(&PS[o]) = f32x2{pp[k][0], pp[k][1]};
           *reinterpret_cast<f32x2*>(&PS[o + 2]) = f32x2{pp[k][2], pp[k][3]};
           *reinterpret_cast<f32x2*>(&US[o]) = f32x2{pu[k][0], pu[k][1]};
@@ -635,16 +685,14 @@ __global__ __launch_bounds__(256) void dw_stats_strip_kernel(
       }
     }
   };
-  auto drain = [&](int j0) {  // MODE 1: dpre rows finished by steps j0 .. j0+4 (image rows ys+j-4)
-    for (int i = tid; i < SW_R * SW_FC * 2; i += 256) {
-      const int k4 = i & 1, pc = i >> 1;
-      const int rr = pc / SW_FC, c = pc - rr * SW_FC;
-      const int jj = j0 + rr;
-      const int gy = ys + jj - 4, gx = xs + c;
-      if (jj >= 4 && jj < nsteps && gx < W && ch0 + k4 * 4 < E) {
-        const float* o = &OUT[(rr * SW_FC + c) * SW_CS + k4 * 4];
-        const f32x2 lo = *reinterpret_cast<const f32x2*>(o), hi = *reinterpret_cast<const f32x2*>(o + 2);
-        *reinterpret_cast<f32x4*>(dpre + ib + ((int64_t)gy * W + gx) * E + ch0 + k4 * 4) = f32x4{lo[0], lo[1], hi[0], hi[1]};
+  auto drain = [&](int j0) {  // MODE 1: dpre rows finished by steps j0 .. j0+4 (segment rows j0-4+rr)
+    const unsigned sbase = (unsigned)(j0 * rowb);
+#pragma unroll
+    for (int k = 0; k < (MODE == 1 ? ND : 0); ++k) {
+      if (k * 256 + 255 < SW_R * SW_FC * 2 || tid + k * 256 < SW_R * SW_FC * 2) {
+        const float* o = &OUT[lo[k]];
+        const f32x2 a = *reinterpret_cast<const f32x2*>(o), c = *reinterpret_cast<const f32x2*>(o + 2);
+        buf_store4(rout, so[k] + sbase, f32x4{a[0], a[1], c[0], c[1]});
       }
     }
   };
@@ -785,6 +833,7 @@ template <int MODE>
 static int launch_dw_strip_stats(const float* x1, const float* pre, const float* u, const float* s, const float* dm,
                                  float* dpre, int B, int H, int W, int E, const float* w5, const float* w3,
                                  const float* wv, const float* wh, float* stats, hipStream_t st) {
+  LMN_REQUIRE((int64_t)(H + 8) * W * E * 4 < (1LL << 30), "dw statistics: one image (%d x %d x %d) must stay below 1 GiB", H, W, E);
   const int strips = lmn_cdiv(W, SW_FC), chunks = lmn_cdiv(E, SW_CH);
   int seg_rows;
   const int segs = strip_segments((int64_t)B * strips * chunks, H, 4, MODE == 0 ? 3 : 2, &seg_rows);
@@ -802,6 +851,7 @@ int lmn_dw_fwd(const float* x1, float* pre, float* gsum, int B, int H, int W, in
                const float* beff, lmn_stream_t stream) {
   LMN_REQUIRE(x1 && pre && gsum && keff && beff, "dw_fwd: null pointer");
   LMN_REQUIRE(B > 0 && H > 0 && W > 0 && E > 0 && E % 4 == 0, "dw_fwd: E=%d must be a multiple of 4", E);
+  LMN_REQUIRE((int64_t)(H + 8) * W * E * 4 < (1LL << 30), "dw_fwd: one image (%d x %d x %d) must stay below 1 GiB", H, W, E);
   // strip-walking kernel: blocks = B x strips(64 columns) x row segments x 8-channel chunks
   const int strips = lmn_cdiv(W, SW_FC), chunks = lmn_cdiv(E, SW_CH);
   int seg_rows;

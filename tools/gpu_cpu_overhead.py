@@ -15,6 +15,8 @@ crit = SegLoss(label_smoothing=0.001).to(dev)
 import sys as _s
 BS, HW = (1, 64) if len(_s.argv) > 1 and _s.argv[1] == "tiny" else (8, 352)
 x, y = make_batch(BS, HW, HW, dev, 1234)
+if "serial" in _s.argv:
+    net._engine.branch_overlap = net._engine.overlap_wgrad = False
 
 
 def step():
@@ -36,7 +38,7 @@ t1 = time.perf_counter()
 torch.cuda.synchronize()
 t2 = time.perf_counter()
 print("enqueue %.2f ms/step, finish %.2f ms/step" % ((t1 - t0) / n * 1e3, (t2 - t0) / n * 1e3))
-raise SystemExit(0)
+if os.environ.get("LMN_CPROFILE") is None: raise SystemExit(0)
 import cProfile, pstats
 pr = cProfile.Profile(); pr.enable()
 for _ in range(3):
