@@ -269,48 +269,80 @@ __global__ __launch_bounds__(256) void dw_bwd_strip_kernel(
   // (ys-8+j).  The last own f row (ye-1) still meets x1 row ye+1 => rows + 10 steps (the last two only feed dW).
   const int nsteps = (ye - ys) + 10;
   const int ndx = (ye - ys) + 8;  // steps that finish a dx row: 8 <= j < ndx
-  for (int j0 = 0; j0 < nsteps; j0 += SW_R) {
-    __syncthreads();  // previous batch computed: OUT holds its dx rows, XS/DPS slots are free
-    // ---- drain the dx rows of the previous batch (steps j0-5 .. j0-1 => image rows ys-8+j)
-    if (j0 >= 8 + SW_R - 4) {  // some step of the previous batch had j >= 8
-      for (int i = tid; i < SW_R * SW_OC * 2; i += 256) {
+  // Staging: bounds are the buffer descriptors' job (columns / channels outside the tensor get an offset beyond
+  // num_records, rows above the image wrap negative, rows below it exceed num_records: loads return 0, stores are
+  // dropped), offsets are 32-bit, and ALL loads of a batch are issued before the first LDS write (one exposed
+  // memory latency per batch instead of six).
+  constexpr unsigned OOB = 0x80000000u;
+  constexpr int NXB = (SW_R * SW_XC * 2 + 255) / 256, NDB = (SW_R * SW_FC * 2 + 255) / 256, NOB = (SW_R * SW_OC * 2 + 255) / 256;
+  const int rowb = W * E * 4;  // bytes per image row (host: (H+16)*W*E*4 < 2^30)
+  const BufRsrc rx = make_rsrc(xb, (unsigned)H * rowb);
+  const BufRsrc rd = make_rsrc(db, (unsigned)H * rowb);
+  const BufRsrc ro = make_rsrc(ob + (int64_t)ys * W * E, (unsigned)(ye - ys) * rowb);
+  auto drain = [&](int jb) {  // dx rows of the batch that started at step jb: segment rows jb-8+rr
+    int tv = tid;
+    asm volatile("" : "+v"(tv));  // keep the index math inside the batch (hoisted, it costs accumulator registers)
+#pragma unroll
+    for (int k = 0; k < NOB; ++k) {
+      const int i = tv + k * 256;
+      if (k * 256 + 255 < SW_R * SW_OC * 2 || i < SW_R * SW_OC * 2) {
         const int k4 = i & 1, pc = i >> 1;
         const int rr = pc / SW_OC, c = pc - rr * SW_OC;
-        const int jj = j0 - SW_R + rr;
-        const int gy = ys - 8 + jj, gx = xs + c;
-        if (jj >= 8 && jj < ndx && gx < W && ch0 + k4 * 4 < E)
-          *reinterpret_cast<f32x4*>(ob + ((int64_t)gy * W + gx) * E + ch0 + k4 * 4) =
-              f32x4{OUT[(rr * SW_FC + c + 2) * SW_CS + k4 * 4], OUT[(rr * SW_FC + c + 2) * SW_CS + k4 * 4 + 1],
-                    OUT[(rr * SW_FC + c + 2) * SW_CS + k4 * 4 + 2], OUT[(rr * SW_FC + c + 2) * SW_CS + k4 * 4 + 3]};
+        const bool ok = xs + c < W && ch0 + k4 * 4 < E;
+        const unsigned off = ok ? (unsigned)(((jb - 8 + rr) * W + xs + c) * E + ch0 + k4 * 4) * 4u : OOB;
+        const float* o = &OUT[(rr * SW_FC + c + 2) * SW_CS + k4 * 4];
+        const f32x2 a = *reinterpret_cast<const f32x2*>(o), d = *reinterpret_cast<const f32x2*>(o + 2);
+        buf_store4(ro, off, f32x4{a[0], a[1], d[0], d[1]});
       }
     }
-    // ---- stage x1 rows of this batch (image rows ys-4+j, columns xs-4 .. xs+63) into the ring
-    for (int i = tid; i < SW_R * SW_XC * 2; i += 256) {
-      const int k4 = i & 1, pc = i >> 1;
-      const int rr = pc / SW_XC, c = pc - rr * SW_XC;
-      const int jj = j0 + rr;
-      const int gy = ys - 4 + jj, gx = xs - 4 + c;
-      const bool in = jj < nsteps && gy >= 0 && gy < H && gx >= 0 && gx < W && ch0 + k4 * 4 < E;
-      const int sy = in ? gy : 0, sx = in ? gx : 0, sc = in ? ch0 + k4 * 4 : 0;
-      f32x4 v = *reinterpret_cast<const f32x4*>(xb + ((int64_t)sy * W + sx) * E + sc);
-      if (!in) v = f32x4{0.f, 0.f, 0.f, 0.f};
-      float* d = &XS[((jj % SW_XR) * SW_XC + c) * SW_CS + k4 * 4];
-      *reinterpret_cast<f32x2*>(d) = f32x2{v[0], v[1]};
-      *reinterpret_cast<f32x2*>(d + 2) = f32x2{v[2], v[3]};
-    }
-    // ---- stage dpre rows (image rows ys-6+j, columns xs-2 .. xs+61)
-    for (int i = tid; i < SW_R * SW_FC * 2; i += 256) {
-      const int k4 = i & 1, pc = i >> 1;
-      const int rr = pc / SW_FC, c = pc - rr * SW_FC;
-      const int jj = j0 + rr;
-      const int gy = ys - 6 + jj, gx = xs - 2 + c;
-      const bool in = jj < nsteps && gy >= 0 && gy < H && gx >= 0 && gx < W && ch0 + k4 * 4 < E;
-      const int sy = in ? gy : 0, sx = in ? gx : 0, sc = in ? ch0 + k4 * 4 : 0;
-      f32x4 v = *reinterpret_cast<const f32x4*>(db + ((int64_t)sy * W + sx) * E + sc);
-      if (!in) v = f32x4{0.f, 0.f, 0.f, 0.f};
-      float* d = &DPS[(rr * SW_FC + c) * SW_CS + k4 * 4];
-      *reinterpret_cast<f32x2*>(d) = f32x2{v[0], v[1]};
-      *reinterpret_cast<f32x2*>(d + 2) = f32x2{v[2], v[3]};
+  };
+  for (int j0 = 0; j0 < nsteps; j0 += SW_R) {
+    __syncthreads();  // previous batch computed: OUT holds its dx rows, XS/DPS slots are free
+    // ---- stage x1 rows (image rows ys-4+j, columns xs-4 .. xs+63) and dpre rows (rows ys-6+j, columns xs-2 .. xs+61)
+    {
+      int tv = tid;
+      asm volatile("" : "+v"(tv));
+      f32x4 vx[NXB];
+      int lx[NXB];
+#pragma unroll
+      for (int k = 0; k < NXB; ++k) {
+        const int i = tv + k * 256;
+        const int k4 = i & 1, pc = i >> 1;
+        const int rr = pc / SW_XC, c = pc - rr * SW_XC;
+        const int gx = xs - 4 + c;
+        const bool ok = i < SW_R * SW_XC * 2 && gx >= 0 && gx < W && ch0 + k4 * 4 < E;
+        const unsigned off = ok ? (unsigned)(((ys - 4 + j0 + rr) * W + gx) * E + ch0 + k4 * 4) * 4u : OOB;
+        vx[k] = buf_load4(rx, off);
+        lx[k] = (((j0 + rr) % SW_XR) * SW_XC + c) * SW_CS + k4 * 4;
+      }
+      f32x4 vd[NDB];
+      int ld[NDB];
+#pragma unroll
+      for (int k = 0; k < NDB; ++k) {
+        const int i = tv + k * 256;
+        const int k4 = i & 1, pc = i >> 1;
+        const int rr = pc / SW_FC, c = pc - rr * SW_FC;
+        const int gx = xs - 2 + c;
+        const bool ok = i < SW_R * SW_FC * 2 && gx >= 0 && gx < W && ch0 + k4 * 4 < E;
+        const unsigned off = ok ? (unsigned)(((ys - 6 + j0 + rr) * W + gx) * E + ch0 + k4 * 4) * 4u : OOB;
+        vd[k] = buf_load4(rd, off);
+        ld[k] = (rr * SW_FC + c) * SW_CS + k4 * 4;
+      }
+      if (j0 >= 8 + SW_R - 4) drain(j0 - SW_R);  // dx rows of the previous batch leave while the loads are in flight
+#pragma unroll
+      for (int k = 0; k < NXB; ++k) {
+        if (k * 256 + 255 < SW_R * SW_XC * 2 || tv + k * 256 < SW_R * SW_XC * 2) {
+          *reinterpret_cast<f32x2*>(&XS[lx[k]]) = f32x2{vx[k][0], vx[k][1]};
+          *reinterpret_cast<f32x2*>(&XS[lx[k] + 2]) = f32x2{vx[k][2], vx[k][3]};
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < NDB; ++k) {
+        if (k * 256 + 255 < SW_R * SW_FC * 2 || tv + k * 256 < SW_R * SW_FC * 2) {
+          *reinterpret_cast<f32x2*>(&DPS[ld[k]]) = f32x2{vd[k][0], vd[k][1]};
+          *reinterpret_cast<f32x2*>(&DPS[ld[k] + 2]) = f32x2{vd[k][2], vd[k][3]};
+        }
+      }
     }
     __syncthreads();
     // ---- five row steps (fixed register slots per phase)
@@ -328,19 +360,7 @@ __global__ __launch_bounds__(256) void dw_bwd_strip_kernel(
 #undef LMN_SW_STEP
   }
   __syncthreads();
-  {  // drain the dx rows of the last batch
-    const int j0 = ((nsteps + SW_R - 1) / SW_R) * SW_R;
-    for (int i = tid; i < SW_R * SW_OC * 2; i += 256) {
-      const int k4 = i & 1, pc = i >> 1;
-      const int rr = pc / SW_OC, c = pc - rr * SW_OC;
-      const int jj = j0 - SW_R + rr;
-      const int gy = ys - 8 + jj, gx = xs + c;
-      if (jj >= 8 && jj < ndx && gx < W && ch0 + k4 * 4 < E)
-        *reinterpret_cast<f32x4*>(ob + ((int64_t)gy * W + gx) * E + ch0 + k4 * 4) =
-            f32x4{OUT[(rr * SW_FC + c + 2) * SW_CS + k4 * 4], OUT[(rr * SW_FC + c + 2) * SW_CS + k4 * 4 + 1],
-                  OUT[(rr * SW_FC + c + 2) * SW_CS + k4 * 4 + 2], OUT[(rr * SW_FC + c + 2) * SW_CS + k4 * 4 + 3]};
-    }
-  }
+  drain(((nsteps + SW_R - 1) / SW_R) * SW_R - SW_R);  // dx rows of the last batch
   // ---- weight gradients: butterfly over the 64 columns, one LDS row per wave, then one atomic per (tap, channel)
   __syncthreads();
   float* red = XS;  // [4 waves][40 taps][2]
@@ -921,6 +941,7 @@ int lmn_dw_bwd(const float* x1, const float* dpre, float* dx1, int B, int H, int
                float* dw5, float* dw3, float* dwv, float* dwh, lmn_stream_t stream) {
   LMN_REQUIRE(x1 && dpre && dx1 && w5 && w3 && wv && wh && cA && cC && cD && dw5 && dw3 && dwv && dwh, "dw_bwd: null pointer");
   LMN_REQUIRE(B > 0 && H > 0 && W > 0 && E > 0 && E % 4 == 0, "dw_bwd: E=%d must be a multiple of 4", E);
+  LMN_REQUIRE((int64_t)(H + 16) * W * E * 4 < (1LL << 30), "dw_bwd: one image (%d x %d x %d) must stay below 1 GiB", H, W, E);
   // strip-walking kernel: blocks = B x strips(60 columns) x row segments x 8-channel chunks (segments: strip_segments)
   const int strips = lmn_cdiv(W, SW_OC), chunks = lmn_cdiv(E, SW_CH);
   int seg_rows;
