@@ -996,78 +996,108 @@ __global__ __launch_bounds__(256, 2) void wgrad_lds_kernel(const WgradParams P) 
     const int oy0 = (tt / P.tiles_x) * P.TH, ox0 = (tt % P.tiles_x) * P.TW;
     const int iy0 = oy0 * A.stride - pad, ix0 = ox0 * A.stride - pad;
     __syncthreads();  // previous tile's reads are done
-    // ---- stage the input window: float4 items (pixel, quad); the pixel geometry is shared by the block's cin
-    //      tiles, whose loads are issued together before any is consumed
-    for (int i = tid; i < P.XH * P.XW * 4; i += 256) {
-      const int j = i & 3, pix = i >> 2;
-      bool inb;
-      int gp;
-      if constexpr (TAPS == 1) {  // 1x1: the image is one flat row (host), the window is the tile itself
-        inb = ox0 + pix < A.Wout;
-        gp = inb ? b * A.Wout + ox0 + pix : 0;
-      } else {
-        const int r = (int)__umulhi((uint32_t)pix, P.mXW), c = pix - r * P.XW;
-        const int iy = iy0 + r, ix = ix0 + c;
-        inb = (unsigned)iy < (unsigned)A.Hin && (unsigned)ix < (unsigned)A.Win;
-        gp = inb ? (b * A.Hin + iy) * A.Win + ix : 0;
-      }
-      f32x4 v[NNT];
+    // ---- stage the input window and the dy tile: float4 items (pixel, quad).  ALL global loads of a round (up to
+    //      UX x 256 window items and UY x 256 dy items -- normally the whole tile) are issued before the first one is
+    //      consumed: one exposed memory latency per tile instead of one per 256 items (the K loop of a tile is
+    //      shorter than two such latencies).
+    constexpr int UX = (TAPS == 9 && NMT * NNT == 4) ? 3 : 4, UY = 2;
+    const int NXI = P.XH * P.XW * 4, NYI = NP * 4;
+    for (int rd = 0; rd * (UX * 256) < NXI || rd * (UY * 256) < NYI; ++rd) {
+      f32x4 vx[UX][NNT], vy[UY][NMT];
+      int gpx[UX], gpy[UY];  // global pixel index, -1 = outside the image
 #pragma unroll
-      for (int t = 0; t < NNT; ++t) {
-        const int ch = tch0[t] + j * 4;
-        v[t] = ld4(tptr[t] + (uint32_t)(gp * tcs[t] + (ch < tC[t] ? ch : 0)));
-      }
-#pragma unroll
-      for (int t = 0; t < NNT; ++t) {
-        const int ch = tch0[t] + j * 4;
-        const bool ok = inb && ch < tC[t];
-        const int chs = ch < tC[t] ? ch : 0;
-        f32x4 w = v[t];
-        if (tflags[t] & LMN_SRC_GELU) {
-#pragma unroll
-          for (int k = 0; k < 4; ++k) w[k] = lmn_gelu(w[k]);
+      for (int u = 0; u < UX; ++u) {
+        const int i = rd * (UX * 256) + u * 256 + tid;
+        const int j = i & 3, pix = i >> 2;
+        bool inb;
+        int gp;
+        if constexpr (TAPS == 1) {  // 1x1: the image is one flat row (host), the window is the tile itself
+          inb = i < NXI && ox0 + pix < A.Wout;
+          gp = inb ? b * A.Wout + ox0 + pix : 0;
+        } else {
+          const int r = (int)__umulhi((uint32_t)pix, P.mXW), c = pix - r * P.XW;
+          const int iy = iy0 + r, ix = ix0 + c;
+          inb = i < NXI && (unsigned)iy < (unsigned)A.Hin && (unsigned)ix < (unsigned)A.Win;
+          gp = inb ? (b * A.Hin + iy) * A.Win + ix : 0;
         }
-        if (tflags[t] & LMN_SRC_DROP) {
+        gpx[u] = inb ? gp : -1;
 #pragma unroll
-          for (int k = 0; k < 4; ++k) w[k] *= lmn_drop_scale(tseed[t], (uint32_t)(gp * tC[t] + chs + k), tp_[t], tik[t]);
+        for (int t = 0; t < NNT; ++t) {
+          const int ch = tch0[t] + j * 4;
+          vx[u][t] = ld4(tptr[t] + (uint32_t)(gp * tcs[t] + (ch < tC[t] ? ch : 0)));
         }
-        if (tscale[t]) w *= ld4(tscale[t] + (inb ? b : 0) * tC[t] + chs);
-        if (!ok) w = f32x4{0.f, 0.f, 0.f, 0.f};
-        *reinterpret_cast<f32x4*>(&XS[(t * XP + pix) * P.CSx + j * 4]) = w;
-      }
-    }
-    // ---- stage the dy tile (same pattern over the block's cout tiles)
-    for (int i = tid; i < NP * 4; i += 256) {
-      const int j = i & 3, pix = i >> 2;
-      bool inb;
-      int gp;
-      if constexpr (TAPS == 1) {
-        inb = ox0 + pix < A.Wout;
-        gp = inb ? b * A.Wout + ox0 + pix : 0;
-      } else {
-        const int r = (int)__umulhi((uint32_t)pix, P.mTW), c = pix - r * P.TW;
-        const int oy = oy0 + r, ox = ox0 + c;
-        inb = oy < A.Hout && ox < A.Wout;
-        gp = inb ? (b * A.Hout + oy) * A.Wout + ox : 0;
-      }
-      f32x4 v[NMT];
-      int cosv[NMT];
-#pragma unroll
-      for (int m = 0; m < NMT; ++m) {
-        const int co = (mt0 + m) * 16 + j * 4;
-        cosv[m] = ((mt0 + m) < P.NMTT && co < A.Cout) ? co : -1;
-        v[m] = ld4(A.dy + (uint32_t)(gp * A.dy_cstride + (cosv[m] >= 0 ? cosv[m] : 0)));
       }
 #pragma unroll
-      for (int m = 0; m < NMT; ++m) {
-        const int cos = cosv[m] >= 0 ? cosv[m] : 0;
-        f32x4 w = v[m];
-        if (A.dy_flags & LMN_SRC_DROP) {
-#pragma unroll
-          for (int k = 0; k < 4; ++k) w[k] *= lmn_drop_scale(A.dy_seed + soff, (uint32_t)(gp * A.Cout + cos + k), A.dy_p, P.inv_keep_dy);
+      for (int u = 0; u < UY; ++u) {
+        const int i = rd * (UY * 256) + u * 256 + tid;
+        const int j = i & 3, pix = i >> 2;
+        bool inb;
+        int gp;
+        if constexpr (TAPS == 1) {
+          inb = i < NYI && ox0 + pix < A.Wout;
+          gp = inb ? b * A.Wout + ox0 + pix : 0;
+        } else {
+          const int r = (int)__umulhi((uint32_t)pix, P.mTW), c = pix - r * P.TW;
+          const int oy = oy0 + r, ox = ox0 + c;
+          inb = i < NYI && oy < A.Hout && ox < A.Wout;
+          gp = inb ? (b * A.Hout + oy) * A.Wout + ox : 0;
         }
-        if (!(inb && cosv[m] >= 0)) w = f32x4{0.f, 0.f, 0.f, 0.f};
-        *reinterpret_cast<f32x4*>(&YS[(m * NP + pix) * P.CSy + j * 4]) = w;
+        gpy[u] = inb ? gp : -1;
+#pragma unroll
+        for (int m = 0; m < NMT; ++m) {
+          const int co = (mt0 + m) * 16 + j * 4;
+          const bool cok = (mt0 + m) < P.NMTT && co < A.Cout;
+          vy[u][m] = ld4(A.dy + (uint32_t)(gp * A.dy_cstride + (cok ? co : 0)));
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < UX; ++u) {
+        const int i = rd * (UX * 256) + u * 256 + tid;
+        if (i < NXI) {
+          const int j = i & 3, pix = i >> 2;
+          const bool inb = gpx[u] >= 0;
+          const int gp = inb ? gpx[u] : 0;
+#pragma unroll
+          for (int t = 0; t < NNT; ++t) {
+            const int ch = tch0[t] + j * 4;
+            const bool ok = inb && ch < tC[t];
+            const int chs = ch < tC[t] ? ch : 0;
+            f32x4 w = vx[u][t];
+            if (tflags[t] & LMN_SRC_GELU) {
+#pragma unroll
+              for (int k = 0; k < 4; ++k) w[k] = lmn_gelu(w[k]);
+            }
+            if (tflags[t] & LMN_SRC_DROP) {
+#pragma unroll
+              for (int k = 0; k < 4; ++k) w[k] *= lmn_drop_scale(tseed[t], (uint32_t)(gp * tC[t] + chs + k), tp_[t], tik[t]);
+            }
+            if (tscale[t]) w *= ld4(tscale[t] + (inb ? b : 0) * tC[t] + chs);
+            if (!ok) w = f32x4{0.f, 0.f, 0.f, 0.f};
+            *reinterpret_cast<f32x4*>(&XS[(t * XP + pix) * P.CSx + j * 4]) = w;
+          }
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < UY; ++u) {
+        const int i = rd * (UY * 256) + u * 256 + tid;
+        if (i < NYI) {
+          const int j = i & 3, pix = i >> 2;
+          const bool inb = gpy[u] >= 0;
+          const int gp = inb ? gpy[u] : 0;
+#pragma unroll
+          for (int m = 0; m < NMT; ++m) {
+            const int co = (mt0 + m) * 16 + j * 4;
+            const bool cok = (mt0 + m) < P.NMTT && co < A.Cout;
+            const int cos = cok ? co : 0;
+            f32x4 w = vy[u][m];
+            if (A.dy_flags & LMN_SRC_DROP) {
+#pragma unroll
+              for (int k = 0; k < 4; ++k) w[k] *= lmn_drop_scale(A.dy_seed + soff, (uint32_t)(gp * A.Cout + cos + k), A.dy_p, P.inv_keep_dy);
+            }
+            if (!(inb && cok)) w = f32x4{0.f, 0.f, 0.f, 0.f};
+            *reinterpret_cast<f32x4*>(&YS[(m * NP + pix) * P.CSy + j * 4]) = w;
+          }
+        }
       }
     }
     __syncthreads();
@@ -1677,6 +1707,13 @@ int lmn_conv_fwd(const lmn_conv_args_t* args, lmn_stream_t stream) {
   return lmn_launch_status("conv_fwd");
 }
 
+// K-split blocks either add their LDS-reduced tile straight into dW with atomics or write it to the workspace for a
+// second (reduction) launch.  Scattered float atomics retire at ~40 per microsecond chip-wide (measured: 4.6 M of
+// them made a 114 us tail on the 192->96 3x3 layer), the reduction launch costs ~6-10 us: atomics only for small totals.
+static bool wgrad_two_stage(int64_t gy, int64_t blocks, int64_t per) {
+  return blocks > 48 || gy * blocks * per > 256 * 1024;
+}
+
 int lmn_conv_wgrad(const lmn_wgrad_args_t* args, lmn_stream_t stream) {
   LMN_REQUIRE(args, "conv_wgrad: null args");
   const lmn_wgrad_args_t& A = *args;
@@ -1752,9 +1789,7 @@ int lmn_conv_wgrad(const lmn_wgrad_args_t* args, lmn_stream_t stream) {
   if (blocks64 < 1) blocks64 = 1;
   // two-stage reduction when the caller's workspace holds every block partial; else LDS-reduced atomics with fewer blocks
   P.partial = nullptr;
-  // (up to 48 K-split blocks add their LDS-reduced tile straight into dW: 48 atomics per address do not contend, and
-  //  the separate reduction launch costs more than it saves on the small feature maps)
-  if (A.workspace && blocks64 > 48 && (int64_t)gy * blocks64 * per <= A.workspace_floats) {
+  if (A.workspace && wgrad_two_stage(gy, blocks64, per) && (int64_t)gy * blocks64 * per <= A.workspace_floats) {
     P.partial = A.workspace;
   } else if (blocks64 > 512 / gy && 512 / gy >= 2) {
     blocks64 = 512 / gy;
@@ -1780,7 +1815,7 @@ int lmn_conv_wgrad(const lmn_wgrad_args_t* args, lmn_stream_t stream) {
     if (nb > cap) nb = cap;
     if (nb < 1) nb = 1;
     P.partial = nullptr;
-    if (A.workspace && nb > 48 && (int64_t)gy * nb * per <= A.workspace_floats) P.partial = A.workspace;
+    if (A.workspace && wgrad_two_stage(gy, nb, per) && (int64_t)gy * nb * per <= A.workspace_floats) P.partial = A.workspace;
     else if (nb > 512 / gy && 512 / gy >= 2) nb = 512 / gy;
     const dim3 dgrid((unsigned)nb, gy);
 #define LMN_WD(M, N)                                                                                               \
