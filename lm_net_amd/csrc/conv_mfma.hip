@@ -1708,7 +1708,7 @@ int lmn_conv_fwd(const lmn_conv_args_t* args, lmn_stream_t stream) {
 }
 
 // K-split blocks either add their LDS-reduced tile straight into dW with atomics or write it to the workspace for a
-// second (reduction) launch.  Scattered float atomics retire at ~40 per microsecond chip-wide (measured: 4.6 M of
+// second (reduction) launch.  Scattered float atomics retire at ~40 per nanosecond chip-wide (measured: 4.6 M of
 // them made a 114 us tail on the 192->96 3x3 layer), the reduction launch costs ~6-10 us: atomics only for small totals.
 static bool wgrad_two_stage(int64_t gy, int64_t blocks, int64_t per) {
   return blocks > 48 || gy * blocks * per > 256 * 1024;
