@@ -591,7 +591,7 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(const ConvParams P) {
   }
 }
 
-// M-split variant for wide layers (Cout >= 64): the four waves of a block own DIFFERENT cout tiles (wave w: tiles
+// M-split variant for wide layers (Cout > 80): the four waves of a block own DIFFERENT cout tiles (wave w: tiles
 // ct0 + w + 4i, i < NCW) and ALL pixel groups of the tile, instead of different pixel groups and all cout tiles.
 // Each weight fragment is then fetched by exactly one wave of the block (the N-split form pulls every fragment
 // through L1 four times; at Cout = 372 that stream, not the MFMAs, set the pace) and feeds 8 x 4 MFMAs; the pixel
@@ -1581,6 +1581,10 @@ int lmn_conv_fwd(const lmn_conv_args_t* args, lmn_stream_t stream) {
     }
     const int tpmax = (a.stride == 2) ? 64 : 128;
     int ncw = 0;  // > 0: M-split kernel with ncw cout tiles per wave
+    // M-split from 6 cout tiles: 5 tiles split 2+1+1+1 over the four waves (24->72 3x3 at 176x176: 242 us, N-split 185 us)
+    constexpr int msplit_min = 6;
+    int tnct = nct, tchunks = chunks;  // N-split form: cout tiles per block (<= 3), cout chunks (grid.y)
+    if (P.NCTT > 3) { tnct = 3; tchunks = (P.NCTT + 2) / 3; }
     if (a.ksize == 1) { T.TW = a.Wout < tpmax ? a.Wout : tpmax; T.TH = 1; }
     else {
       T.TW = a.Wout <= 32 ? a.Wout : 16;
@@ -1588,7 +1592,7 @@ int lmn_conv_fwd(const lmn_conv_args_t* args, lmn_stream_t stream) {
       if (T.TH > a.Hout) T.TH = a.Hout;
       if (T.TH < 1) T.TH = 1;
     }
-    if (P.NCTT >= 4) {
+    if (P.NCTT >= msplit_min) {
       // Wide layer -> M-split kernel.  Wide layers sit on the small feature maps, where a 128-pixel tile times a
       // few cout chunks can leave most of the 256 CUs idle: pick (tile pixels, cout tiles per wave) by a cost model
       // -- rounds of 256 blocks x per-block MFMA work (+ staging, inflated by the halo for short 3x3 tiles).
@@ -1635,10 +1639,10 @@ int lmn_conv_fwd(const lmn_conv_args_t* args, lmn_stream_t stream) {
     T.mTW = (uint32_t)((1ull << 32) / (uint32_t)T.TW + 1);
     T.mXW = (uint32_t)((1ull << 32) / (uint32_t)T.XW + 1);
     LMN_REQUIRE(T.XH * T.XW < 65536, "conv_fwd: window too large");
-    const size_t shmem = ((size_t)T.XH * T.XW * T.CS + 2 * nct * 16) * sizeof(float);
+    const size_t shmem = ((size_t)T.XH * T.XW * T.CS + 2 * tnct * 16) * sizeof(float);
     LMN_REQUIRE(shmem <= 64 * 1024, "conv_fwd: LDS window %zu B", shmem);
     int blocks = T.total_tiles;
-    const int maxb = 1280 / chunks > 256 ? 1280 / chunks : 256;  // ~5 resident blocks per CU: one round of persistent blocks
+    const int maxb = 1280 / tchunks > 256 ? 1280 / tchunks : 256;  // ~5 resident blocks per CU: one round of persistent blocks
     if (blocks > maxb) blocks = maxb;
     // epilogue instance (see the kernel): 0 plain, 2 LINEAR+SUM_SQ, 3 BN_BWD1, 4 BN_BWD2, 5 SE_BWD, 1 everything else
     int ek = 1;
@@ -1671,7 +1675,7 @@ int lmn_conv_fwd(const lmn_conv_args_t* args, lmn_stream_t stream) {
 #undef LMN_CM
       return lmn_launch_status("conv_fwd(tileM)");
     }
-    const dim3 grid(blocks, chunks);
+    const dim3 grid(blocks, tchunks);
 #define LMN_CT(TT, NN)                                                                                   \
   do {                                                                                                   \
     switch ((TT) == 1 ? ek : (ek > 2 ? 1 : ek)) {                                                        \
@@ -1684,7 +1688,7 @@ int lmn_conv_fwd(const lmn_conv_args_t* args, lmn_stream_t stream) {
     }                                                                                                    \
   } while (0)
 #define LMN_CTN(TT)                                                                                      \
-  switch (nct) {                                                                                         \
+  switch (tnct) {                                                                                         \
     case 1: LMN_CT(TT, 1); break;                                                                        \
     case 2: LMN_CT(TT, 2); break;                                                                        \
     default: LMN_CT(TT, 3); break;                                                                       \

@@ -31,6 +31,10 @@ if what in ("conv", "wgrad"):
     conv_case(176, [48], 24, 3, 1, f, g)
     conv_case(44, [192], 96, 3, 1, f, g)
     conv_case(22, [372], 372, 3, 1, f, g)
+if what == "conv72":
+    conv_case(176, [24], 72, 3, 1, True, False)
+    conv_case(176, [24, 24, 24], 24, 3, 1, True, False)
+    conv_case(88, [24], 80, 1, 1, True, False)
 if what == "dw":
     H, E = 352, 24
     x1 = torch.randn(B, H, H, E, device=dev); pre = torch.empty_like(x1); gsum = torch.zeros(B, E, device=dev)
