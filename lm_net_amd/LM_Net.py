@@ -129,6 +129,7 @@ class LM_Net(nn.Module):
             if hasattr(m, "switch_to_deploy"):
                 m.switch_to_deploy()
         self._grad_layout = None
+        self._graphs = {}
         self.__dict__["_param_cache"] = None
         self.__dict__["_bn_cache"] = None
 
@@ -150,11 +151,16 @@ class LM_Net(nn.Module):
             gs = self._graph_for(x)
             if gs is not None:
                 return _LMNetGraphFunction.apply(x, self, gs, *params)
+        if self.use_graphs and not self.training and not self._save_tape and not self._keep_taps:
+            out = self._infer_replay(x)
+            if out is not None:
+                return out
         return _LMNetFunction.apply(x, self, *params)
 
     # ------------------------------------------------------------------ hipGraph capture of the training step
     def enable_graphs(self, on=True):
-        """Run training steps as two hipGraph replays (forward, backward) per input shape instead of ~1700 launches:
+        """Run training steps as two hipGraph replays (forward, backward) per input shape instead of ~1700 launches
+        (and eval / no-grad forwards as one replay, see _infer_replay):
         the step at batch 8 / 352x352 carries ~8 ms of per-launch cost.  The first two steps of a shape run eagerly
         (warm-up: workspaces, pack plans, allocator), the third is captured.  Contract while enabled: fixed parameter
         storage, `zero_grad(set_to_none=True)` semantics (returned gradients are views of one static buffer; they
@@ -166,6 +172,33 @@ class LM_Net(nn.Module):
             self._graphs = {}
             self._engine.seed_ctr = None
         return self
+
+    def _infer_replay(self, x):
+        """Eval / no-grad forward of a fixed input shape as ONE hipGraph replay (the
+        launch-minimal inference schedule).  Two eager calls of a shape warm the workspaces up, the third is captured;
+        weight packing and BatchNorm folding are kernels inside the graph, so parameter / running-stat updates between
+        calls are honoured; `structural_reparam()` drops the graphs.  Returns None while warming up."""
+        key = ("infer", tuple(x.shape), x.device)
+        gs = self._graphs.get(key)
+        if gs is None:
+            gs = self._graphs[key] = _GraphedStep()
+        if gs.fwd is None:
+            gs.warm += 1
+            if gs.warm <= 2:
+                return None
+            eng = self._engine
+            gs.x = x.clone()
+            torch.cuda.synchronize(x.device)
+            eng.capturing = True
+            try:
+                gs.fwd = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(gs.fwd):
+                    gs.out = self._forward_impl(gs.x, Ctx())
+            finally:
+                eng.capturing = False
+        gs.x.copy_(x)
+        gs.fwd.replay()
+        return gs.out.clone()
 
     def _graph_for(self, x):
         key = (tuple(x.shape), x.device)

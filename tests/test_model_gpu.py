@@ -322,3 +322,33 @@ def test_graph_mode_matches_host_launches_and_redraws_dropout():
         for p in c.parameters():
             p.grad = None
     assert float((outs[3] - outs[4]).abs().max()) > 1e-3
+
+
+def test_inference_graph_replay_matches_eager_and_follows_the_weights():
+    """Eval forward as one hipGraph replay per input shape: same logits as host launches, a
+    parameter update between calls is honoured by the replay (packing / BN folding are kernels inside the graph),
+    and structural_reparam() drops the captured graphs."""
+    x = det_input((2, 3, 64, 96), "igraph/x").cuda()
+    m = _net(seed=5).eval()
+    with torch.no_grad():
+        y0 = m(x)
+        m.enable_graphs()
+        ys = [m(x) for _ in range(4)]                       # 2 eager warm-ups, capture, replay
+        assert sum(g.fwd is not None for g in m._graphs.values()) == 1
+        for y in ys:
+            assert rel_err(y, y0) < 1e-5
+        x2 = det_input((2, 3, 64, 96), "igraph/x2").cuda()
+        m.enable_graphs(False)
+        y2 = m(x2)
+        m.enable_graphs()
+        m._graphs = {}
+        for _ in range(3):
+            m(x)
+        assert rel_err(m(x2), y2) < 1e-5                     # new input through the static buffer
+        m.output_layer.weight.mul_(2.0)                      # in-place update of a parameter the graph reads
+        m.output_layer.bias.mul_(2.0)
+        assert rel_err(m(x2), 2.0 * y2) < 1e-5
+        m.structural_reparam()
+        assert m._graphs == {}
+        yd = m(x2)
+        assert rel_err(yd, 2.0 * y2) < 1e-4
