@@ -321,6 +321,15 @@ int lmn_segloss_bwd(const float* logits, const int64_t* target, const float* w_c
 /* On-device confusion matrix (row N2): counts[t*C + p] += #pixels with label t and argmax(logits) = p.  Dice and IoU
  * follow as 2TP/(2TP+FP+FN), TP/(TP+FP+FN) (utils/train_eval_utils.py:78-95).  C in {2,3,4}.                   */
 int lmn_confusion(const float* logits, const int64_t* target, int B, int C, int64_t HW, float* counts, lmn_stream_t stream);
+/* Device-side input pipeline (row N4): uint8 HWC images [B,Hs,Ws,3] (channel order untouched, as cv2.imread hands it
+ * over) and grayscale masks [B,Hs,Ws] -> normalised fp32 NCHW images [B,3,H,W] and int64 labels [B,H,W].
+ * Replaces, for data already in HBM, A.Resize + A.Normalize + ToTensorV2 (dataset/data_loading.py:203-206), the mask
+ * threshold (:237) and the two flips of the training transform (:213-214): cv2.resize INTER_LINEAR semantics on uint8
+ * (11-bit fixed-point coefficients, rounded back to uint8), INTER_NEAREST for masks, (v - mean*255)/(std*255).
+ * flips (device, [B], may be NULL): bit 0 horizontal, bit 1 vertical.  mean / std: HOST arrays of 3 doubles (A.Normalize
+ * arguments, max_pixel_value 255).  Either images/out or masks/labels may be NULL.                                   */
+int lmn_preprocess_u8(const uint8_t* images, const uint8_t* masks, const uint8_t* flips, int B, int Hs, int Ws, int H,
+                      int W, const double* mean, const double* std, float* out, int64_t* labels, lmn_stream_t stream);
 /* One AdamW step over flat buffers of n floats (n % 4 == 0): replaces torch.optim.AdamW.step() of
  * train.py:156 when parameters and gradients live in the flat layout of lm_net_amd.LM_Net.
  * bias_corr1 = 1 - beta1^t, bias_corr2 = 1 - beta2^t (t = step count, from the host). */

@@ -639,6 +639,67 @@ __global__ __launch_bounds__(256) void segloss_bwd_kernel(const float* __restric
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Input pipeline on the device: the validation transform of dataset/data_loading.py:203-206
+// (A.Resize -> A.Normalize -> ToTensorV2) plus the two flips of the training transform (:213-214), for a batch of
+// uint8 HWC images and grayscale masks already in HBM.
+//   image: cv2.resize(INTER_LINEAR) on uint8 -- half-pixel centres, 11-bit fixed-point coefficients, result rounded
+//          back to uint8 -- then (v - mean*255) * (1/(std*255)) with numpy's float32/float64 promotion;
+//   mask:  cv2.threshold(127, 1, THRESH_BINARY) (data_loading.py:237) and INTER_NEAREST (floor(dst*scale));
+//   flips: bit 0 of flips[b] = horizontal, bit 1 = vertical (applied after the resize, before Normalize).
+struct PrepGeom {
+  int B, Hs, Ws, H, W;
+  double m255[3], inv[3];
+};
+
+__device__ __forceinline__ void prep_axis(int d, int n_dst, int n_src, bool clamp_frac, int& s0, int& s1, int& a0, int& a1) {
+  const double scale = (double)n_src / (double)n_dst;
+  float f = (float)((d + 0.5) * scale - 0.5);
+  int s = (int)floorf(f);
+  f -= (float)s;
+  if (clamp_frac) {  // columns: cv2 zeroes the fraction at the borders; rows are clamped instead
+    if (s < 0) { s = 0; f = 0.f; }
+    if (s >= n_src - 1) { s = n_src - 1; f = 0.f; }
+  }
+  a0 = (int)rintf((1.f - f) * 2048.f);  // saturate_cast<short>: round half to even
+  a1 = (int)rintf(f * 2048.f);
+  s0 = min(max(s, 0), n_src - 1);
+  s1 = min(max(s + 1, 0), n_src - 1);
+}
+
+__global__ __launch_bounds__(256) void preprocess_u8_kernel(const uint8_t* __restrict__ img, const uint8_t* __restrict__ mask,
+                                                            const uint8_t* __restrict__ flips, float* __restrict__ out,
+                                                            int64_t* __restrict__ labels, const PrepGeom g) {
+  const int64_t n = (int64_t)g.B * g.H * g.W;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const int x = (int)(i % g.W), y = (int)((i / g.W) % g.H), b = (int)(i / ((int64_t)g.W * g.H));
+    const int fl = flips ? flips[b] : 0;
+    const int rx = (fl & 1) ? g.W - 1 - x : x, ry = (fl & 2) ? g.H - 1 - y : y;  // pixel of the resized image
+    if (img) {
+      int x0, x1, ax0, ax1, y0, y1, ay0, ay1;
+      prep_axis(rx, g.W, g.Ws, true, x0, x1, ax0, ax1);
+      prep_axis(ry, g.H, g.Hs, false, y0, y1, ay0, ay1);
+      const uint8_t* r0 = img + ((int64_t)b * g.Hs + y0) * g.Ws * 3;
+      const uint8_t* r1 = img + ((int64_t)b * g.Hs + y1) * g.Ws * 3;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const int h0 = r0[x0 * 3 + c] * ax0 + r0[x1 * 3 + c] * ax1;  // horizontal pass, scale 2^11
+        const int h1 = r1[x0 * 3 + c] * ax0 + r1[x1 * 3 + c] * ax1;
+        int v = (((ay0 * (h0 >> 4)) >> 16) + ((ay1 * (h1 >> 4)) >> 16) + 2) >> 2;  // cv2 VResizeLinear<uchar>
+        v = min(max(v, 0), 255);
+        const float t = (float)((double)v - g.m255[c]);     // numpy: float32 array -= float64 mean
+        out[(((int64_t)b * 3 + c) * g.H + y) * g.W + x] = (float)((double)t * g.inv[c]);
+      }
+    }
+    if (mask) {
+      const int sx = min((int)floor(rx * ((double)g.Ws / g.W)), g.Ws - 1);
+      const int sy = min((int)floor(ry * ((double)g.Hs / g.H)), g.Hs - 1);
+      labels[i] = mask[((int64_t)b * g.Hs + sy) * g.Ws + sx] > 127 ? 1 : 0;
+    }
+  }
+}
+
+
 // Confusion matrix of argmax(logits) against the labels: counts[t*C + p] += 1 (float counts are
 // exact up to 2^24 per launch per cell; the host accumulates in int64/double).
 template <int C>
@@ -885,6 +946,27 @@ int lmn_confusion(const float* logits, const int64_t* target, int B, int C, int6
     default: hipLaunchKernelGGL((confusion_kernel<4>), dim3(grid), dim3(256), 0, st, logits, target, B, HW, counts); break;
   }
   return lmn_launch_status("confusion");
+}
+
+int lmn_preprocess_u8(const uint8_t* images, const uint8_t* masks, const uint8_t* flips, int B, int Hs, int Ws, int H,
+                      int W, const double* mean, const double* std, float* out, int64_t* labels, lmn_stream_t stream) {
+  LMN_REQUIRE((images && out && mean && std) || (masks && labels), "preprocess_u8: nothing to do");
+  LMN_REQUIRE(!images || (out && mean && std), "preprocess_u8: images need out, mean and std");
+  LMN_REQUIRE(!masks || labels, "preprocess_u8: masks need labels");
+  LMN_REQUIRE(B > 0 && Hs > 0 && Ws > 0 && H > 0 && W > 0, "preprocess_u8: empty tensor");
+  LMN_REQUIRE(Hs < 32768 && Ws < 32768 && H < 32768 && W < 32768, "preprocess_u8: side above 32767");
+  PrepGeom g{B, Hs, Ws, H, W, {0, 0, 0}, {1, 1, 1}};
+  if (images) {
+    for (int c = 0; c < 3; ++c) {
+      LMN_REQUIRE(std[c] > 0.0, "preprocess_u8: std[%d] must be positive", c);
+      g.m255[c] = mean[c] * 255.0;          // albumentations: mean * max_pixel_value, reciprocal(std * max_pixel_value)
+      g.inv[c] = 1.0 / (std[c] * 255.0);
+    }
+  }
+  const int64_t n = (int64_t)B * H * W;
+  hipLaunchKernelGGL(preprocess_u8_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, images ? images : nullptr,
+                     masks ? masks : nullptr, flips, images ? out : nullptr, masks ? labels : nullptr, g);
+  return lmn_launch_status("preprocess_u8");
 }
 
 int lmn_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,

@@ -52,7 +52,7 @@ SYMBOLS = [
     "lmn_se_fwd", "lmn_se_bwd", "lmn_na_fwd", "lmn_na_bwd", "lmn_gattn_fwd", "lmn_gattn_bwd",
     "lmn_ln_fwd", "lmn_ln_bwd", "lmn_bnact_fwd", "lmn_bnact_bwd_stats", "lmn_bnact_bwd",
     "lmn_bn_finalize", "lmn_bn_fold", "lmn_bn_bwd_coef", "lmn_up2_fwd", "lmn_up2_bwd", "lmn_avgpool_fwd", "lmn_avgpool_bwd",
-    "lmn_nchw_to_nhwc", "lmn_nhwc_to_nchw", "lmn_adamw_step", "lmn_segloss_fwd", "lmn_segloss_bwd", "lmn_confusion", "lmn_fill", "lmn_add", "lmn_colsum", "lmn_copy_slice",
+    "lmn_nchw_to_nhwc", "lmn_nhwc_to_nchw", "lmn_adamw_step", "lmn_segloss_fwd", "lmn_segloss_bwd", "lmn_confusion", "lmn_preprocess_u8", "lmn_fill", "lmn_add", "lmn_colsum", "lmn_copy_slice",
 ]
 
 _lib = None
@@ -536,6 +536,23 @@ def confusion(logits, target, counts):
     B, Cn = logits.shape[0], logits.shape[1]
     hw = logits.numel() // (B * Cn)
     _check(load().lmn_confusion(_p(logits), _pl(target), B, Cn, _i64(hw), _p(counts), _stream()), "confusion")
+
+
+def preprocess_u8(images, masks, flips, out, labels, mean, std):
+    """uint8 HWC images [B,Hs,Ws,3] / masks [B,Hs,Ws] -> fp32 NCHW `out` [B,3,H,W] / int64 `labels` [B,H,W]."""
+    def raw(t, dt):
+        if t is None:
+            return None
+        if not t.is_cuda or t.dtype != dt or not t.is_contiguous():
+            raise RuntimeError("lm_net_amd.preprocess_u8: contiguous %s device tensor required" % dt)
+        return C.c_void_p(t.data_ptr())
+    ref = images if images is not None else masks
+    B, Hs, Ws = ref.shape[0], ref.shape[1], ref.shape[2]
+    dst = out if out is not None else labels
+    H, W = dst.shape[-2], dst.shape[-1]
+    m3, s3 = (C.c_double * 3)(*[float(v) for v in mean]), (C.c_double * 3)(*[float(v) for v in std])
+    _check(load().lmn_preprocess_u8(raw(images, torch.uint8), raw(masks, torch.uint8), raw(flips, torch.uint8), B, Hs, Ws,
+                                    H, W, m3, s3, _p(out), raw(labels, torch.int64), _stream()), "preprocess_u8")
 
 
 def adamw_step(p, g, m, v, lr, beta1, beta2, eps, weight_decay, bias_corr1, bias_corr2):
