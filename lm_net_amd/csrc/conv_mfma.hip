@@ -1362,25 +1362,27 @@ __global__ __launch_bounds__(256) void wgrad_1x1_kernel(const WgradParams P) {
 // second stage: dW[co][ci][tap] += sum over the K-split blocks of their partial tiles (fixed order => deterministic).
 // 1024 threads = 64 consecutive elements x 16 K-slices; each thread keeps 8 loads in flight.
 template <int TAPS, int NMT, int NNT>
-__global__ __launch_bounds__(1024) void wgrad_reduce_kernel(const WgradParams P, int nblk) {
+__global__ __launch_bounds__(1024) void wgrad_reduce_kernel(const WgradParams P, int nblk, int ksl) {
+  // a block sums epb = 1024 / ksl elements over the nblk partials in ksl slices (ksl = 1 .. 16, a power of two sized to
+  // nblk on the host: with 2-3 partials, 16 slices left 13 of 16 waves idle and the grid 4x too large)
   const lmn_wgrad_args_t& A = P.a;
   constexpr int NT = TAPS * NMT * NNT, PER = NT * 256 + NMT * 16;
-  __shared__ float red[16][64];
+  __shared__ float red[1024];
   const int mset = blockIdx.y / P.nsets_n, nset = blockIdx.y - mset * P.nsets_n;
   const int mt0 = mset * NMT, nt0 = nset * NNT;
   const float* src = P.partial + (int64_t)blockIdx.y * nblk * PER;
-  const int e = threadIdx.x & 63, ks = threadIdx.x >> 6;
-  const int i = blockIdx.x * 64 + e;
+  const int epb = 1024 / ksl;
+  const int e = threadIdx.x & (epb - 1), ks = threadIdx.x / epb;
+  const int i = blockIdx.x * epb + e;
   float sum = 0.f;
   if (i < PER) {
-#pragma unroll 8
-    for (int k = ks; k < nblk; k += 16) sum += src[(int64_t)k * PER + i];
+#pragma unroll 4
+    for (int k = ks; k < nblk; k += ksl) sum += src[(int64_t)k * PER + i];
   }
-  red[ks][e] = sum;
+  red[threadIdx.x] = sum;
   __syncthreads();
   if (ks != 0 || i >= PER) return;
-#pragma unroll
-  for (int k = 1; k < 16; ++k) sum += red[k][e];
+  for (int k = 1; k < ksl; ++k) sum += red[k * epb + e];
   if (i < NT * 256) {
     const int ln = i & 63, r = (i >> 6) & 3, tile = i >> 8;
     const int t = tile % NNT, m = (tile / NNT) % NMT, tp = tile / (NNT * NMT);
@@ -1711,6 +1713,12 @@ int lmn_conv_fwd(const lmn_conv_args_t* args, lmn_stream_t stream) {
   return lmn_launch_status("conv_fwd");
 }
 
+static int reduce_slices(int nblk) {  // k-slices of the reduction kernel: ~4 partials per slice, at most 16
+  int k = 1;
+  while (k < 16 && k * 4 < nblk) k <<= 1;
+  return k;
+}
+
 // K-split blocks either add their LDS-reduced tile straight into dW with atomics or write it to the workspace for a
 // second (reduction) launch.  Scattered float atomics retire at ~40 per nanosecond chip-wide (measured: 4.6 M of
 // them made a 114 us tail on the 192->96 3x3 layer), the reduction launch costs ~6-10 us: atomics only for small totals.
@@ -1808,8 +1816,9 @@ int lmn_conv_wgrad(const lmn_wgrad_args_t* args, lmn_stream_t stream) {
       (void)hipFuncSetAttribute((const void*)wgrad_lds_kernel<T, M, N>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem); \
     hipLaunchKernelGGL((wgrad_lds_kernel<T, M, N>), grid, dim3(256), shmem, st, P);                                 \
     if (P.partial) {                                                                                                \
-      const int rb = (int)((per + 63) / 64);                                                                        \
-      hipLaunchKernelGGL((wgrad_reduce_kernel<T, M, N>), dim3(rb, gy), dim3(1024), 0, st, P, blocks);               \
+      const int ksl = reduce_slices(blocks);                                                                        \
+      const int rb = (int)((per + 1024 / ksl - 1) / (1024 / ksl));                                                  \
+      hipLaunchKernelGGL((wgrad_reduce_kernel<T, M, N>), dim3(rb, gy), dim3(1024), 0, st, P, blocks, ksl);          \
     }                                                                                                               \
   } while (0)
   if (A.ksize == 1 && A.stride == 1 && (int64_t)G.Hout * G.Wout >= 32) {
@@ -1826,8 +1835,9 @@ int lmn_conv_wgrad(const lmn_wgrad_args_t* args, lmn_stream_t stream) {
   do {                                                                                                              \
     hipLaunchKernelGGL((wgrad_1x1_kernel<M, N>), dgrid, dim3(256), 0, st, P);                                       \
     if (P.partial) {                                                                                                \
-      const int rb = (int)((per + 63) / 64);                                                                        \
-      hipLaunchKernelGGL((wgrad_reduce_kernel<1, M, N>), dim3(rb, gy), dim3(1024), 0, st, P, (int)nb);              \
+      const int ksl = reduce_slices((int)nb);                                                                       \
+      const int rb = (int)((per + 1024 / ksl - 1) / (1024 / ksl));                                                  \
+      hipLaunchKernelGGL((wgrad_reduce_kernel<1, M, N>), dim3(rb, gy), dim3(1024), 0, st, P, (int)nb, ksl);         \
     }                                                                                                               \
   } while (0)
     switch (NMT * 8 + NNT) {
