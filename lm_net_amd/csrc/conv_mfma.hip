@@ -343,8 +343,12 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams P) {
 //   * each wave owns two pixel groups x NCT cout tiles: the B operand is a conflict-free ds_read_b128 (no bounds
 //     checks in the MFMA loop: padding is already in LDS), the A operand the packed weight fragment from L1/L2;
 //   * ~100 VGPRs instead of 140-256: 4-5 waves per SIMD hide the remaining latency.
-// Used for every case except the data gradient of a stride-2 conv (parity classes; conv_mfma_kernel).
-template <int TAPS, int NCT, int EPI>
+// Used for every case of the model; conv_mfma_kernel stays as the fallback for stride-2 data gradients the S2T form does not take.
+// S2T: data gradient of a stride-2 3x3 conv (pad 1).  Output pixels of parity class (py, px) = blockIdx.z form a
+// stride-1 problem over dy with a 1x1 / 1x2 / 2x1 / 2x2 sub-kernel: in = out_c + ((parity + pad - t) >> 1) for the taps of
+// matching parity.  The tile walks CLASS coordinates, the window is TH+1 x TW+1 pixels of dy, outputs land at
+// (2*yc + py, 2*xc + px).
+template <int TAPS, int NCT, int EPI, bool S2T = false>
 __global__ __launch_bounds__(256) void conv_tile_kernel(const ConvParams P) {
   const lmn_conv_args_t& A = P.a;
   const uint32_t soff = A.seed_ctr ? *A.seed_ctr : 0u;  // device-side dropout stream offset (graph replays: one bump per step)
@@ -364,6 +368,21 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(const ConvParams P) {
   const int ct0 = blockIdx.y * NCT;
   const int pad = A.ksize >> 1;
   constexpr int KS = TAPS == 9 ? 3 : 1;
+  // S2T: this class's taps (weight tap index, window offset in pixels)
+  const int cpy = S2T ? (int)(blockIdx.z >> 1) : 0, cpx = S2T ? (int)(blockIdx.z & 1) : 0;
+  int s2_wt[4], s2_off[4], s2_n = 0;
+  if constexpr (S2T) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) s2_wt[k] = s2_off[k] = 0;
+    for (int ty = 0; ty < 3; ++ty)
+      for (int tx = 0; tx < 3; ++tx) {
+        const int ey = cpy + 1 - ty, ex = cpx + 1 - tx;
+        if ((ey | ex) & 1) continue;
+        s2_wt[s2_n] = ty * 3 + tx;
+        s2_off[s2_n] = (ey >> 1) * P.XW + (ex >> 1);
+        ++s2_n;
+      }
+  }
   const float* wlane = A.wpack + lane * 4;
   int wtile[NCT];  // cout tiles past the end re-read the last real tile (results dropped in the epilogue)
 #pragma unroll
@@ -383,8 +402,8 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(const ConvParams P) {
     const int b = tile / (P.tiles_x * P.tiles_y), tt = tile - b * P.tiles_x * P.tiles_y;
     const int oy0 = (tt / P.tiles_x) * P.TH, ox0 = (tt % P.tiles_x) * P.TW;
     // window origin in input coordinates (forward: out*s - pad; data gradient, stride 1: out - pad, taps flipped)
-    const int wy0 = A.transposed ? oy0 - pad : oy0 * A.stride - pad;
-    const int wx0 = A.transposed ? ox0 - pad : ox0 * A.stride - pad;
+    const int wy0 = S2T ? oy0 : (A.transposed ? oy0 - pad : oy0 * A.stride - pad);
+    const int wx0 = S2T ? ox0 : (A.transposed ? ox0 - pad : ox0 * A.stride - pad);
 
     if (EPI && ep_kind == LMN_EP_SE_BWD && b != cur_b) {  // block-uniform: flush the previous image's sums
       if (cur_b >= 0) {
@@ -411,10 +430,10 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(const ConvParams P) {
       const bool in_t = i < P.TP;
       const int is = in_t ? i : 0;
       const int r = (int)__umulhi((uint32_t)is, P.mTW), c = is - r * P.TW;
-      const int oy = oy0 + r, ox = ox0 + c;
+      const int oy = S2T ? 2 * (oy0 + r) + cpy : oy0 + r, ox = S2T ? 2 * (ox0 + c) + cpx : ox0 + c;
       pvalid[g] = in_t && oy < A.Hout && ox < A.Wout;
       opix[g] = pvalid[g] ? (b * A.Hout + oy) * A.Wout + ox : 0;
-      const int sr = A.transposed ? r : r * A.stride, sc = A.transposed ? c : c * A.stride;
+      const int sr = (S2T || A.transposed) ? r : r * A.stride, sc = (S2T || A.transposed) ? c : c * A.stride;
       pbase[g] = (sr * P.XW + sc) * P.CS + q * 4;
     }
     const bool g1 = (wv + 4) < P.NG;  // wave-uniform: second group exists
@@ -429,10 +448,10 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(const ConvParams P) {
       const lmn_src_t& S = A.src[s];
       for (int kb0 = 0; kb0 < P.nkb[s]; kb0 += P.CKB) {
         const int nkbc = P.nkb[s] - kb0 < P.CKB ? P.nkb[s] - kb0 : P.CKB;
-        const int ksh = nkbc - 1, niter = TAPS * nkbc;  // step it = (tap, kk): tap = it >> ksh, kk = it & ksh (nkbc is 1 or 2)
+        const int ksh = nkbc - 1, niter = (S2T ? s2_n : TAPS) * nkbc;  // step it = (tap, kk): tap = it >> ksh, kk = it & ksh (nkbc is 1 or 2)
         f32x4 wcur[NCT];
         {
-          const float* wp = wlane + ((int64_t)(P.kb_off[s] + kb0) * P.NCTT) * 256;
+          const float* wp = wlane + (((int64_t)(S2T ? s2_wt[0] : 0) * P.NKB + P.kb_off[s] + kb0) * P.NCTT) * 256;
 #pragma unroll
           for (int c = 0; c < NCT; ++c) wcur[c] = ld4(wp + wtile[c]);
         }
@@ -467,7 +486,8 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(const ConvParams P) {
           const int itn = it + 1 < niter ? it + 1 : it;
           f32x4 wnext[NCT];
           {
-            const int tapn = itn >> ksh, kkn = itn & ksh;
+            const int tapi = itn >> ksh, kkn = itn & ksh;
+            const int tapn = S2T ? s2_wt[tapi & 3] : tapi;
             const float* wp = wlane + (((int64_t)tapn * P.NKB + P.kb_off[s] + kb0 + kkn) * P.NCTT) * 256;
 #pragma unroll
             for (int c = 0; c < NCT; ++c) wnext[c] = ld4(wp + wtile[c]);
@@ -475,7 +495,7 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(const ConvParams P) {
           const int tap = it >> ksh, kk = it & ksh;
           const int ty = tap / KS, tx = tap - ty * KS;
           const int fy = A.transposed ? KS - 1 - ty : ty, fx = A.transposed ? KS - 1 - tx : tx;
-          const int toff = (fy * P.XW + fx) * P.CS;
+          const int toff = S2T ? s2_off[tap & 3] * P.CS : (fy * P.XW + fx) * P.CS;
           const f32x4 x0 = *reinterpret_cast<const f32x4*>(&XS[pbase[0] + toff + kk * 16]);
           const f32x4 x1 = *reinterpret_cast<const f32x4*>(&XS[pbase[1] + toff + kk * 16]);
 #pragma unroll
@@ -1574,14 +1594,17 @@ int lmn_conv_fwd(const lmn_conv_args_t* args, lmn_stream_t stream) {
   int nct = P.NCTT >= 6 ? 6 : (P.NCTT == 5 ? 6 : P.NCTT);
   const int chunks = (P.NCTT + nct - 1) / nct;
   hipStream_t st = (hipStream_t)stream;
-  if (!(A.transposed && A.stride == 2)) {
+  // data gradient of a stride-2 3x3 conv: four parity classes in grid.z of the tile kernel (S2T)
+  const bool s2t = A.transposed && A.stride == 2 && A.ksize == 3 && !(A.epilogue == LMN_EP_SE_BWD);
+  if (!(A.transposed && A.stride == 2) || s2t) {
     // ---- LDS-tiled kernel.  1x1: the image is a flat row of H*W pixels.
     ConvParams T = P;
     lmn_conv_args_t& a = T.a;
     if (a.ksize == 1) {
       a.Wout *= a.Hout; a.Win *= a.Hin; a.Hout = a.Hin = 1;
     }
-    const int tpmax = (a.stride == 2) ? 64 : 128;
+    const int tpmax = (a.stride == 2 && !s2t) ? 64 : 128;
+    const int gW = s2t ? (a.Wout + 1) / 2 : a.Wout, gH = s2t ? (a.Hout + 1) / 2 : a.Hout;  // tiled grid (S2T: class coordinates)
     int ncw = 0;  // > 0: M-split kernel with ncw cout tiles per wave
     // M-split from 6 cout tiles: 5 tiles split 2+1+1+1 over the four waves (24->72 3x3 at 176x176: 242 us, N-split 185 us)
     constexpr int msplit_min = 6;
@@ -1589,12 +1612,12 @@ int lmn_conv_fwd(const lmn_conv_args_t* args, lmn_stream_t stream) {
     if (P.NCTT > 3) { tnct = 3; tchunks = (P.NCTT + 2) / 3; }
     if (a.ksize == 1) { T.TW = a.Wout < tpmax ? a.Wout : tpmax; T.TH = 1; }
     else {
-      T.TW = a.Wout <= 32 ? a.Wout : 16;
+      T.TW = gW <= 32 ? gW : 16;
       T.TH = tpmax / T.TW;
-      if (T.TH > a.Hout) T.TH = a.Hout;
+      if (T.TH > gH) T.TH = gH;
       if (T.TH < 1) T.TH = 1;
     }
-    if (P.NCTT >= msplit_min) {
+    if (P.NCTT >= msplit_min && !s2t) {
       // Wide layer -> M-split kernel.  Wide layers sit on the small feature maps, where a 128-pixel tile times a
       // few cout chunks can leave most of the 256 CUs idle: pick (tile pixels, cout tiles per wave) by a cost model
       // -- rounds of 256 blocks x per-block MFMA work (+ staging, inflated by the halo for short 3x3 tiles).
@@ -1627,16 +1650,16 @@ int lmn_conv_fwd(const lmn_conv_args_t* args, lmn_stream_t stream) {
     T.NG = (T.TP + 15) / 16;
     LMN_REQUIRE(T.NG <= 8, "conv_fwd: tile of %d pixels", T.TP);
     const int st_in = a.transposed ? 1 : a.stride;
-    T.XH = (T.TH - 1) * st_in + a.ksize;
-    T.XW = (T.TW - 1) * st_in + a.ksize;
+    T.XH = s2t ? T.TH + 1 : (T.TH - 1) * st_in + a.ksize;
+    T.XW = s2t ? T.TW + 1 : (T.TW - 1) * st_in + a.ksize;
     int maxkb = 0;
     for (int s = 0; s < a.nsrc; ++s) maxkb = P.nkb[s] > maxkb ? P.nkb[s] : maxkb;
     T.CKB = maxkb < 2 ? maxkb : 2;
     // LDS pixel stride: conflict-free ds_read_b128 for 16 pixels st_in apart (brute-forced over the b128 lane groups):
     // +8 floats at unit stride, +4 at stride 2 (PMC: 0.5 conflict cycles per LDS cycle with +4 at unit stride)
     T.CS = T.CKB * 16 + (st_in == 1 ? 8 : 4);
-    T.tiles_x = (a.Wout + T.TW - 1) / T.TW;
-    T.tiles_y = (a.Hout + T.TH - 1) / T.TH;
+    T.tiles_x = (gW + T.TW - 1) / T.TW;
+    T.tiles_y = (gH + T.TH - 1) / T.TH;
     T.total_tiles = a.B * T.tiles_x * T.tiles_y;
     T.mTW = (uint32_t)((1ull << 32) / (uint32_t)T.TW + 1);
     T.mXW = (uint32_t)((1ull << 32) / (uint32_t)T.XW + 1);
@@ -1644,7 +1667,8 @@ int lmn_conv_fwd(const lmn_conv_args_t* args, lmn_stream_t stream) {
     const size_t shmem = ((size_t)T.XH * T.XW * T.CS + 2 * tnct * 16) * sizeof(float);
     LMN_REQUIRE(shmem <= 64 * 1024, "conv_fwd: LDS window %zu B", shmem);
     int blocks = T.total_tiles;
-    const int maxb = 1280 / tchunks > 256 ? 1280 / tchunks : 256;  // ~5 resident blocks per CU: one round of persistent blocks
+    int maxb = 1280 / tchunks > 256 ? 1280 / tchunks : 256;  // ~5 resident blocks per CU: one round of persistent blocks
+    if (s2t) maxb = 320 / tchunks > 64 ? 320 / tchunks : 64;          // x 4 classes in grid.z
     if (blocks > maxb) blocks = maxb;
     // epilogue instance (see the kernel): 0 plain, 2 LINEAR+SUM_SQ, 3 BN_BWD1, 4 BN_BWD2, 5 SE_BWD, 1 everything else
     int ek = 1;
@@ -1676,6 +1700,21 @@ int lmn_conv_fwd(const lmn_conv_args_t* args, lmn_stream_t stream) {
       else { if (ncw == 2) LMN_CM(9, 2); else LMN_CM(9, 1); }
 #undef LMN_CM
       return lmn_launch_status("conv_fwd(tileM)");
+    }
+    if (s2t) {
+      const dim3 zgrid(blocks, tchunks, 4);
+#define LMN_CZ(NN)                                                                                            \
+  do {                                                                                                        \
+    if (ek == 0) hipLaunchKernelGGL((conv_tile_kernel<9, NN, 0, true>), zgrid, dim3(256), shmem, st, T);      \
+    else hipLaunchKernelGGL((conv_tile_kernel<9, NN, 1, true>), zgrid, dim3(256), shmem, st, T);              \
+  } while (0)
+      switch (tnct) {
+        case 1: LMN_CZ(1); break;
+        case 2: LMN_CZ(2); break;
+        default: LMN_CZ(3); break;
+      }
+#undef LMN_CZ
+      return lmn_launch_status("conv_fwd(tile, stride-2 data gradient)");
     }
     const dim3 grid(blocks, tchunks);
 #define LMN_CT(TT, NN)                                                                                   \

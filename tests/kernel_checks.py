@@ -126,7 +126,8 @@ def check_conv_bwd_data():
     rows = []
     cases = [("1x1 24->12", 2, 7, 6, 24, 12, 1, 1), ("3x3 s1 24->36", 2, 8, 9, 24, 36, 3, 1),
              ("3x3 s2 12->24", 2, 12, 10, 12, 24, 3, 2), ("3x3 s2 48->96 odd", 1, 9, 7, 48, 96, 3, 2),
-             ("3x3 s1 96->96", 1, 6, 6, 96, 96, 3, 1)]
+             ("3x3 s1 96->96", 1, 6, 6, 96, 96, 3, 1), ("3x3 s2 12->24 multi-tile", 2, 64, 80, 12, 24, 3, 2),
+             ("3x3 s2 96->192 two cout chunks", 2, 22, 38, 96, 192, 3, 2), ("3x3 s2 24->48 odd wide", 1, 35, 71, 24, 48, 3, 2)]
     for name, B, H, W, cin, cout, k, s in cases:
         x = R(B, cin, H, W, seed=21).requires_grad_(True)
         w = R(cout, cin, k, k, seed=22, scale=0.1)
