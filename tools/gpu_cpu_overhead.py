@@ -44,5 +44,5 @@ pr = cProfile.Profile(); pr.enable()
 for _ in range(3):
     step()
 pr.disable(); torch.cuda.synchronize()
-pstats.Stats(pr).sort_stats("tottime").print_stats(28)
+pstats.Stats(pr).sort_stats("tottime").print_stats(45)
 pstats.Stats(pr).sort_stats("cumtime").print_stats(30)
