@@ -44,306 +44,15 @@ struct ConvParams {
 
 __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 
-template <int TAPS, int NPG, int NCT>
-__global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams P) {
-  const lmn_conv_args_t& A = P.a;
-  const uint32_t soff = A.seed_ctr ? *A.seed_ctr : 0u;  // device-side dropout stream offset (graph replays: one bump per step)
-  const int lane = threadIdx.x & 63;
-  const int q = lane >> 4, n = lane & 15;
-  const int wave = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int nwaves = gridDim.x * 4;
-  const int ct0 = blockIdx.y * NCT;
-  const int pad = A.ksize >> 1;
-  const int cs = (P.ncls == 4) ? 2 : 1;
-
-  __shared__ float s_stats[2 * NCT * 16];
-  for (int i = threadIdx.x; i < 2 * NCT * 16; i += 256) s_stats[i] = 0.f;
-  __syncthreads();
-
-  // per-lane running statistics for this wave's whole range (per-channel modes)
-  float st0[NCT][4], st1[NCT][4];
-#pragma unroll
-  for (int c = 0; c < NCT; ++c)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) st0[c][r] = st1[c][r] = 0.f;
-
-  // per-image statistic (SE_BWD): accumulated across this wave's groups while the image stays the same
-  float sb[NCT][4];
-#pragma unroll
-  for (int c = 0; c < NCT; ++c)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) sb[c][r] = 0.f;
-  int cur_b = -1;
-  auto flush_sb = [&]() {
-    if (cur_b >= 0) {
-#pragma unroll
-      for (int c = 0; c < NCT; ++c)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          float t = sb[c][r];
-          t += __shfl_xor(t, 1, 64);
-          t += __shfl_xor(t, 2, 64);
-          t += __shfl_xor(t, 4, 64);
-          t += __shfl_xor(t, 8, 64);
-          const int co = (ct0 + c) * 16 + q * 4 + r;
-          if (n == 0 && (ct0 + c < P.NCTT) && co < A.Cout) atomicAdd(A.stats + (int64_t)cur_b * A.Cout + co, t);
-          sb[c][r] = 0.f;
-        }
-    }
-  };
-
-  const int set_begin = (int)(((int64_t)wave * P.total_sets) / nwaves);
-  const int set_end = (int)(((int64_t)(wave + 1) * P.total_sets) / nwaves);
-  const int total_groups = A.B * P.gpi;
-
-  for (int set = set_begin; set < set_end; ++set) {
-    // ---- decode this wave's NPG pixel groups
-    int gb[NPG], gbs[NPG], gy[NPG], gx[NPG], gpy[NPG], gpx[NPG];
-    bool gvalid[NPG];
-#pragma unroll
-    for (int g = 0; g < NPG; ++g) {
-      const int gid = set * NPG + g;
-      int b = gid / P.gpi, r = gid - b * P.gpi, c = 0;
-      if (P.ncls == 4) {
-#pragma unroll
-        for (int k = 0; k < 3; ++k)
-          if (c == k && r >= P.ng_c[k]) { r -= P.ng_c[k]; c = k + 1; }
-      }
-      const int Wc = P.Wc[c], HWc = P.Hc[c] * Wc;
-      const int pi = r * 16 + n;
-      const int yc = pi / Wc, xc = pi - yc * Wc;
-      gpy[g] = c >> 1;
-      gpx[g] = c & 1;
-      gb[g] = b;
-      gy[g] = yc * cs + gpy[g];
-      gx[g] = xc * cs + gpx[g];
-      gvalid[g] = (gid < total_groups) && (pi < HWc);
-      gbs[g] = gid < total_groups ? b : 0;
-    }
-
-    f32x4 acc[NPG][NCT];
-#pragma unroll
-    for (int g = 0; g < NPG; ++g)
-#pragma unroll
-      for (int c = 0; c < NCT; ++c) acc[g][c] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    // input pixel of (group lane, tap) = per-lane base + a wave-uniform tap delta (32-bit index math):
-    //   forward:        in = out*stride + (t - pad)
-    //   data-gradient:  in = out + pad - t            (stride 1)
-    //                   in = out_c + ((parity + pad - t) >> 1), only taps of matching parity   (stride 2)
-    int by[NPG], bx[NPG], bp[NPG], upy[NPG], upx[NPG];
-#pragma unroll
-    for (int g = 0; g < NPG; ++g) {
-      upy[g] = __builtin_amdgcn_readfirstlane(gpy[g]);
-      upx[g] = __builtin_amdgcn_readfirstlane(gpx[g]);
-      if (!A.transposed) {
-        by[g] = gy[g] * A.stride;
-        bx[g] = gx[g] * A.stride;
-      } else if (A.stride == 2) {
-        by[g] = gy[g] >> 1;
-        bx[g] = gx[g] >> 1;
-      } else {
-        by[g] = gy[g];
-        bx[g] = gx[g];
-      }
-      bp[g] = (gbs[g] * A.Hin + by[g]) * A.Win + bx[g];
-    }
-    for (int tap = 0; tap < TAPS; ++tap) {
-      const int ty = (TAPS == 9) ? tap / 3 : 0, tx = (TAPS == 9) ? tap - ty * 3 : 0;
-      int inpix[NPG];
-      bool inb[NPG];
-      bool any = false;
-#pragma unroll
-      for (int g = 0; g < NPG; ++g) {
-        int dty, dtx;
-        bool tok = true;
-        if (!A.transposed) {
-          dty = ty - pad;
-          dtx = tx - pad;
-        } else if (A.stride == 2) {
-          const int ey = upy[g] + pad - ty, ex = upx[g] + pad - tx;
-          tok = !((ey | ex) & 1);
-          dty = ey >> 1;
-          dtx = ex >> 1;
-        } else {
-          dty = pad - ty;
-          dtx = pad - tx;
-        }
-        const int iy = by[g] + dty, ix = bx[g] + dtx;
-        const bool ok = gvalid[g] && tok && (unsigned)iy < (unsigned)A.Hin && (unsigned)ix < (unsigned)A.Win;
-        inb[g] = ok;
-        inpix[g] = ok ? bp[g] + dty * A.Win + dtx : 0;  // masked lanes read pixel 0 (always mapped)
-        any = any || ok;
-      }
-      if (__ballot(any) == 0ull) continue;  // wave-uniform: no lane of any group reads this tap
-
-#pragma unroll 1
-      for (int s = 0; s < A.nsrc; ++s) {
-        const lmn_src_t& S = A.src[s];
-        for (int kbs = 0; kbs < P.nkb[s]; ++kbs) {
-          const int ch = kbs * 16 + q * 4;
-          const bool chok = ch < S.C;
-          // Loads are UNCONDITIONAL (masked lanes read a safe in-bounds address and are zeroed by a select):
-          // a load under a per-lane branch makes hipcc wait for each one separately (guide, section 5 trap (c)).
-          const int chs = chok ? ch : 0;
-          f32x4 xv[NPG];
-#pragma unroll
-          for (int g = 0; g < NPG; ++g) xv[g] = ld4(S.ptr + (uint32_t)(inpix[g] * S.cstride + chs));
-          if (S.flags & LMN_SRC_GELU) {
-#pragma unroll
-            for (int g = 0; g < NPG; ++g)
-#pragma unroll
-              for (int j = 0; j < 4; ++j) xv[g][j] = lmn_gelu(xv[g][j]);
-          }
-          if (S.flags & LMN_SRC_DROP) {
-#pragma unroll
-            for (int g = 0; g < NPG; ++g) {
-              const uint32_t idx = (uint32_t)(inpix[g] * S.C + chs);
-#pragma unroll
-              for (int j = 0; j < 4; ++j) xv[g][j] *= lmn_drop_scale(S.drop_seed + soff, idx + j, S.drop_p, P.inv_keep_src[s]);
-            }
-          }
-          if (S.scale) {
-#pragma unroll
-            for (int g = 0; g < NPG; ++g) xv[g] *= ld4(S.scale + gbs[g] * S.C + chs);
-          }
-#pragma unroll
-          for (int g = 0; g < NPG; ++g)
-            if (!(inb[g] && chok)) xv[g] = f32x4{0.f, 0.f, 0.f, 0.f};
-          const float* wp = P.a.wpack + ((((int64_t)tap * P.NKB + P.kb_off[s] + kbs) * P.NCTT + ct0) * 64 + lane) * 4;
-#pragma unroll
-          for (int c = 0; c < NCT; ++c) {
-            if (ct0 + c < P.NCTT) {
-              const f32x4 wv = ld4(wp + c * 256);
-#pragma unroll
-              for (int j = 0; j < 4; ++j)
-#pragma unroll
-                for (int g = 0; g < NPG; ++g)
-                  acc[g][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[j], xv[g][j], acc[g][c], 0, 0, 0);
-            }
-          }
-        }
-      }
-    }
-
-    // ---- epilogue: lane holds channels co..co+3 of its pixel, per (g, c)
-#pragma unroll
-    for (int g = 0; g < NPG; ++g) {
-      const int opix = (gbs[g] * A.Hout + gy[g]) * A.Wout + gx[g];
-      if (A.epilogue == LMN_EP_SE_BWD && (set * NPG + g) < total_groups) {
-        const int bu = __builtin_amdgcn_readfirstlane(gb[g]);  // wave-uniform: groups never straddle images
-        if (bu != cur_b) {
-          flush_sb();
-          cur_b = bu;
-        }
-      }
-      const uint32_t opx = gvalid[g] ? (uint32_t)opix : 0u;  // masked lanes use a safe address; only stores/statistics are predicated
-#pragma unroll
-      for (int c = 0; c < NCT; ++c) {
-        const int co = (ct0 + c) * 16 + q * 4;
-        const bool cok = (ct0 + c < P.NCTT) && co < A.Cout;
-        const bool live = gvalid[g] && cok;
-        const int cos = cok ? co : 0;
-        f32x4 v = acc[g][c];
-        if (A.bias) v += ld4(A.bias + cos);
-        f32x4 o = v;
-        if (A.stats_mode == LMN_STATS_SUM_SQ && live) {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) { st0[c][r] += v[r]; st1[c][r] += v[r] * v[r]; }
-        }
-        f32x4 ax = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (A.aux) ax = ld4(A.aux + opx * A.aux_cstride + cos);
-        switch (A.epilogue) {
-          case LMN_EP_AFFINE_ACT: {
-            const f32x4 s0 = ld4(A.p0 + cos), s1 = ld4(A.p1 + cos);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) o[r] = lmn_act(v[r] * s0[r] + s1[r], A.act);
-          } break;
-          case LMN_EP_DGELU: {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) o[r] = v[r] * lmn_dgelu(ax[r]);
-          } break;
-          case LMN_EP_BN_BWD1: {
-            const f32x4 mu = ld4(A.p0 + cos), rs = ld4(A.p1 + cos), ga = ld4(A.p2 + cos), be = ld4(A.p3 + cos);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              const float zh = (v[r] - mu[r]) * rs[r];
-              const float h = ga[r] * zh + be[r];
-              o[r] = ax[r] * lmn_dact(h, A.act);
-              if (live) {
-                st0[c][r] += o[r];
-                st1[c][r] += o[r] * zh;
-              }
-            }
-          } break;
-          case LMN_EP_BN_BWD2: {
-            const f32x4 mu = ld4(A.p0 + cos), rs = ld4(A.p1 + cos), c1 = ld4(A.p2 + cos), c2 = ld4(A.p3 + cos),
-                        c3 = ld4(A.p4 + cos);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              const float zh = (v[r] - mu[r]) * rs[r];
-              o[r] = c1[r] * ax[r] - c2[r] - zh * c3[r];
-            }
-          } break;
-          case LMN_EP_SE_BWD: {
-            if (live) {
-#pragma unroll
-              for (int r = 0; r < 4; ++r) sb[c][r] += v[r] * lmn_gelu(ax[r]);
-            }
-          } break;
-          default: break;
-        }
-        if (A.drop_p > 0.f) {
-          const uint32_t idx = (uint32_t)(opx * A.Cout + cos);
-#pragma unroll
-          for (int r = 0; r < 4; ++r) o[r] *= lmn_drop_scale(A.drop_seed + soff, idx + r, A.drop_p, P.inv_keep_ep);
-        }
-        if (A.residual) o += ld4(A.residual + opx * A.res_cstride + cos);
-        if (A.out && live) *reinterpret_cast<f32x4*>(A.out + opx * A.out_cstride + cos) = o;
-        // keep each (group, tile) epilogue self-contained: without this the scheduler hoists every iteration's
-        // parameter/aux loads to the top and the live ranges cost >100 VGPRs (occupancy 1)
-        __builtin_amdgcn_sched_barrier(0);
-      }
-    }
-  }
-  if (A.epilogue == LMN_EP_SE_BWD) flush_sb();
-
-  // ---- per-channel statistics: wave shuffle -> LDS -> one global atomic per channel per block
-  const bool chan_stats = (A.stats_mode == LMN_STATS_SUM_SQ) || (A.epilogue == LMN_EP_BN_BWD1);
-  if (chan_stats) {
-#pragma unroll
-    for (int c = 0; c < NCT; ++c)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        float a = st0[c][r], b = st1[c][r];
-#pragma unroll
-        for (int m = 1; m <= 8; m <<= 1) {
-          a += __shfl_xor(a, m, 64);
-          b += __shfl_xor(b, m, 64);
-        }
-        if (n == 0) {
-          atomicAdd(&s_stats[c * 16 + q * 4 + r], a);
-          atomicAdd(&s_stats[NCT * 16 + c * 16 + q * 4 + r], b);
-        }
-      }
-    __syncthreads();
-    for (int i = threadIdx.x; i < 2 * NCT * 16; i += 256) {
-      const int which = i / (NCT * 16), cc = i - which * NCT * 16;
-      const int co = ct0 * 16 + cc;
-      if (co < A.Cout) atomicAdd(A.stats + (int64_t)which * A.Cout + co, s_stats[i]);
-    }
-  }
-}
-
 // ------------------------------------------------------------------------------------ LDS-tiled forward / data-gradient
-// Same arithmetic and operand conventions as conv_mfma_kernel, restructured for latency and registers:
+// Implicit-GEMM convolution on v_mfma_f32_16x16x4_f32 (M = cout tile: a lane holds 4 consecutive output channels of one
+// pixel), structured for latency and registers:
 //   * a block walks a contiguous range of output tiles (<= 128 pixels = 8 pixel groups); per tile and per chunk of
 //     <= 32 input channels the input WINDOW (with its zero-padded halo) is staged once into LDS by coalesced,
 //     unconditional float4 loads with the on-load transforms applied there (once per element, not once per tap);
 //   * each wave owns two pixel groups x NCT cout tiles: the B operand is a conflict-free ds_read_b128 (no bounds
 //     checks in the MFMA loop: padding is already in LDS), the A operand the packed weight fragment from L1/L2;
 //   * ~100 VGPRs instead of 140-256: 4-5 waves per SIMD hide the remaining latency.
-// Used for every case of the model; conv_mfma_kernel stays as the fallback for stride-2 data gradients the S2T form does not take.
 // S2T: data gradient of a stride-2 3x3 conv (pad 1).  Output pixels of parity class (py, px) = blockIdx.z form a
 // stride-1 problem over dy with a 1x1 / 1x2 / 2x1 / 2x2 sub-kernel: in = out_c + ((parity + pad - t) >> 1) for the taps of
 // matching parity.  The tile walks CLASS coordinates, the window is TH+1 x TW+1 pixels of dy, outputs land at
@@ -477,7 +186,10 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(const ConvParams P) {
           }
           if (S.scale) v *= ld4(S.scale + b * S.C + chs);
           if (!ok) v = f32x4{0.f, 0.f, 0.f, 0.f};
-          *reinterpret_cast<f32x4*>(&XS[pix * P.CS + f * 4]) = v;
+          {  // blocked K layout: channel 4*fl + r of its K16 block sits at position 4*r + fl (MFMA j reads channel 4j + q)
+            float* d = &XS[pix * P.CS + (f >> 2) * 16 + (f & 3)];
+            d[0] = v[0]; d[4] = v[1]; d[8] = v[2]; d[12] = v[3];
+          }
         }
         __syncthreads();
         // ---- MFMA: taps x K16 blocks of the chunk; the packed weights of step it+1 are fetched while step it runs
@@ -498,14 +210,16 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(const ConvParams P) {
           const int toff = S2T ? s2_off[tap & 3] * P.CS : (fy * P.XW + fx) * P.CS;
           const f32x4 x0 = *reinterpret_cast<const f32x4*>(&XS[pbase[0] + toff + kk * 16]);
           const f32x4 x1 = *reinterpret_cast<const f32x4*>(&XS[pbase[1] + toff + kk * 16]);
+          const int nj = (S.C - (kb0 + kk) * 16 + 3) >> 2;  // K slices of this block that hold channels (wave-uniform)
 #pragma unroll
-          for (int c = 0; c < NCT; ++c) {
+          for (int j = 0; j < 4; ++j) {
+            if (j == 0 || j < nj) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-              // both groups unconditionally (a missing second group reads pixel 0 and is dropped in the epilogue):
-              // a branch around an MFMA makes the accumulators bounce between VGPRs and AGPRs every iteration
-              acc[0][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(wcur[c][j], x0[j], acc[0][c], 0, 0, 0);
-              acc[1][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(wcur[c][j], x1[j], acc[1][c], 0, 0, 0);
+              for (int c = 0; c < NCT; ++c) {
+                // both groups unconditionally (a missing second group reads pixel 0 and is dropped in the epilogue)
+                acc[0][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(wcur[c][j], x0[j], acc[0][c], 0, 0, 0);
+                acc[1][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(wcur[c][j], x1[j], acc[1][c], 0, 0, 0);
+              }
             }
           }
 #pragma unroll
@@ -731,7 +445,10 @@ __global__ __launch_bounds__(256) void conv_tileM_kernel(const ConvParams P) {
           }
           if (S.scale) v *= ld4(S.scale + b * S.C + chs);
           if (!ok) v = f32x4{0.f, 0.f, 0.f, 0.f};
-          *reinterpret_cast<f32x4*>(&XS[pix * P.CS + f * 4]) = v;
+          {  // blocked K layout: channel 4*fl + r of its K16 block sits at position 4*r + fl (MFMA j reads channel 4j + q)
+            float* d = &XS[pix * P.CS + (f >> 2) * 16 + (f & 3)];
+            d[0] = v[0]; d[4] = v[1]; d[8] = v[2]; d[12] = v[3];
+          }
         }
         __syncthreads();
         // ---- MFMA: taps x K16 blocks of the chunk; weights of step it+1 are fetched while step it runs (the first
@@ -749,6 +466,7 @@ __global__ __launch_bounds__(256) void conv_tileM_kernel(const ConvParams P) {
           const int ty = tap / KS, tx = tap - ty * KS;
           const int fy = A.transposed ? KS - 1 - ty : ty, fx = A.transposed ? KS - 1 - tx : tx;
           const int toff = (fy * P.XW + fx) * P.CS;
+          // (no zero-slice skipping here: wide layers have few partial K16 blocks, and the branch cost this loop its schedule)
 #pragma unroll
           for (int g = 0; g < NGM; ++g) {
             if (g < P.NG) {
@@ -890,7 +608,9 @@ __device__ __forceinline__ float pack_element(const float* __restrict__ w, const
   const int tap = (int)(t / NKB);
   int s = 0;
   while (s + 1 < g.nsrc && kb >= kboff[s + 1]) ++s;
-  const int kk = (kb - kboff[s]) * 16 + (lane >> 4) * 4 + j;  // reduction index inside the source
+  // MFMA j of a K16 block covers channels 4j .. 4j+3 (k slot = lane >> 4): a source whose last block holds fewer than
+  // 16 channels leaves whole MFMAs zero, which the kernels skip (12 channels: 3 of 4)
+  const int kk = (kb - kboff[s]) * 16 + j * 4 + (lane >> 4);  // reduction index inside the source
   const int row = ct * 16 + (lane & 15);
   float v = 0.f;
   if (row < nrows && kk < g.cs[s]) {
@@ -1421,23 +1141,6 @@ __global__ __launch_bounds__(1024) void wgrad_reduce_kernel(const WgradParams P,
   }
 }
 
-template <int TAPS, int NPG, int NCT>
-void launch_conv(const ConvParams& P, int blocks, int chunks, hipStream_t st) {
-  hipLaunchKernelGGL((conv_mfma_kernel<TAPS, NPG, NCT>), dim3(blocks, chunks), dim3(256), 0, st, P);
-}
-
-template <int TAPS>
-void dispatch_conv(const ConvParams& P, int nct, int npg, int blocks, int chunks, hipStream_t st) {
-  switch (nct) {
-    case 1: launch_conv<TAPS, 4, 1>(P, blocks, chunks, st); break;
-    case 2: launch_conv<TAPS, 4, 2>(P, blocks, chunks, st); break;
-    case 3: launch_conv<TAPS, 4, 3>(P, blocks, chunks, st); break;
-    case 4: launch_conv<TAPS, 2, 4>(P, blocks, chunks, st); break;
-    default: launch_conv<TAPS, 2, 6>(P, blocks, chunks, st); break;
-  }
-  (void)npg;
-}
-
 }  // namespace
 
 thread_local char g_lmn_err[256] = {0};
@@ -1739,17 +1442,8 @@ int lmn_conv_fwd(const lmn_conv_args_t* args, lmn_stream_t stream) {
 #undef LMN_CT
     return lmn_launch_status("conv_fwd(tile)");
   }
-  const int npg = nct <= 3 ? 4 : 2;
-  P.total_sets = (int)((total_groups + npg - 1) / npg);
-  int blocks = (P.total_sets + 3) / 4;
-  const int maxb = 2048 / chunks > 256 ? 2048 / chunks : 256;
-  if (blocks > maxb) blocks = maxb;
-  if (blocks < 1) blocks = 1;
-  if (A.ksize == 1)
-    dispatch_conv<1>(P, nct, npg, blocks, chunks, st);
-  else
-    dispatch_conv<9>(P, nct, npg, blocks, chunks, st);
-  return lmn_launch_status("conv_fwd");
+  LMN_REQUIRE(false, "conv_fwd: the data gradient of a stride-2 conv is implemented for 3x3 kernels (got ksize %d, epilogue %d)", A.ksize, A.epilogue);
+  return -1;
 }
 
 static int reduce_slices(int nblk) {  // k-slices of the reduction kernel: ~4 partials per slice, at most 16
