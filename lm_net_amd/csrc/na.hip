@@ -264,6 +264,154 @@ __global__ __launch_bounds__(256) void na_bwd_q_kernel(const float* __restrict__
 }
 
 template <int HD>
+__global__ __launch_bounds__(256) void na_bwd_q_tile_kernel(const float* __restrict__ qkv, const float* __restrict__ rpb,
+                                                            const float* __restrict__ dout, float* __restrict__ dqkv,
+                                                            float* __restrict__ drpb, float* __restrict__ stat,
+                                                            const NaGeom g, int TH, int TW, int tiles_x, int tiles_img,
+                                                            int total_tiles) {
+  // Query pass for C <= 24 (levels 0-1) with the k/v window of a TH x TW query tile staged in LDS, as the forward
+  // does: the direct form is bound by the L1 address path (PMC: TA busy 78 % of the kernel, 49 cache accesses per wave
+  // load -- 21 pixels x 48 B at a 144 B stride).  Persistent blocks walk tiles; a thread keeps its channel quad, so
+  // the interior rpb bins stay in registers across tiles and are flushed once (the parking area reuses the window).
+  extern __shared__ __attribute__((aligned(16))) float s_drpb[];  // [heads][25] | rpb copy [heads][25] (padded to 16 B) | KV window / bins
+  const int ntab = (g.heads * 25 + 3) & ~3;
+  float* s_rpb = s_drpb + ntab;
+  float* KV = s_rpb + ntab;   // [(TH+2)*(TW+2)][2][C]
+  float* s_bins = KV;         // [256][36] after the last tile
+  const int RW = TW + 2, RH = TH + 2;
+  for (int i = threadIdx.x; i < g.heads * 25; i += 256) { s_drpb[i] = 0.f; s_rpb[i] = rpb[i]; }
+  __syncthreads();
+  // A thread keeps ONE channel quad for the whole kernel (quad = tid % C4, pixel slot = tid / C4), so the rpb
+  // gradient of interior pixels -- whose 9 neighbours always hit the same 9 bins -- accumulates in 36 registers.
+  // (Per-pixel LDS atomics on 9 shared bins serialise the whole block: 554 us at 352x352, 12 heads.)
+  const int PB = 256 / g.C4;                       // pixels per block iteration
+  const int c = (threadIdx.x % g.C4) * 4;
+  const int slot = threadIdx.x / g.C4;
+  const int npx = TH * TW;
+  f32x4 bins[9];
+#pragma unroll
+  for (int n = 0; n < 9; ++n) bins[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int tile = blockIdx.x; tile < total_tiles; tile += gridDim.x) {
+   const int b = tile / tiles_img, tt = tile - b * tiles_img;
+   const int ty0 = (tt / tiles_x) * TH, tx0 = (tt % tiles_x) * TW;
+   const int rlo = max(0, min(ty0 - 1, g.H - 3)), clo = max(0, min(tx0 - 1, g.W - 3));
+   const int64_t ib = (int64_t)b * g.H * g.W * 3 * g.C;
+   const float* base = qkv + ib;
+   __syncthreads();  // the previous tile's window is consumed
+   for (int i = threadIdx.x; i < RH * RW * 2 * g.C4; i += 256) {
+     const int c4 = i % g.C4, w = (i / g.C4) & 1, wp = i / (2 * g.C4);
+     const int gy = rlo + wp / RW, gx = clo + wp % RW;
+     const bool in = gy < g.H && gx < g.W;
+     f32x4 v = ld4(base + ((int64_t)(in ? gy : 0) * g.W + (in ? gx : 0)) * 3 * g.C + (1 + w) * g.C + c4 * 4);
+     if (!in) v = f32x4{0.f, 0.f, 0.f, 0.f};
+     *reinterpret_cast<f32x4*>(&KV[(wp * 2 + w) * g.C + c4 * 4]) = v;
+   }
+   __syncthreads();
+   for (int p0 = 0; p0 < npx; p0 += PB) {
+    const int pl = p0 + slot;
+    int y = ty0 + pl / TW, x = tx0 + pl % TW;
+    const bool ok = slot < PB && pl < npx && y < g.H && x < g.W;
+    if (!ok) { y = ty0; x = tx0; }  // a safe pixel of this tile; nothing of it is stored or counted
+    const int64_t pix = ((int64_t)b * g.H + y) * g.W + x;
+    const int sy = wstart(y, g.H), sx = wstart(x, g.W);
+    const float* kv0 = KV + (((sy - rlo) * RW + (sx - clo)) * 2) * g.C + c;
+    const f32x4 q = ld4(base + ((int64_t)y * g.W + x) * 3 * g.C + c) * g.scale;
+    const f32x4 dO = ld4(dout + pix * g.C + c);
+    int hidx[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) hidx[k] = ((c + k) / HD) * 25;
+    f32x4 p[9], dp[9];
+    f32x4 mx = f32x4{-3.0e38f, -3.0e38f, -3.0e38f, -3.0e38f};
+#pragma unroll
+    for (int ki = 0; ki < 3; ++ki)
+#pragma unroll
+      for (int kj = 0; kj < 3; ++kj) {
+        const int ny = sy + ki, nx = sx + kj;
+        const float* kvn = kv0 + ((ki * RW + kj) * 2) * g.C;
+        const f32x4 kk = *reinterpret_cast<const f32x4*>(kvn), vv = *reinterpret_cast<const f32x4*>(kvn + g.C);
+        f32x4 s = head_sum<HD>(q * kk);
+        const int bo = (ny - y + 2) * 5 + (nx - x + 2);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) s[k] += s_rpb[hidx[k] + bo];
+        p[ki * 3 + kj] = s;
+        dp[ki * 3 + kj] = head_sum<HD>(dO * vv);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) mx[k] = fmaxf(mx[k], s[k]);
+      }
+    f32x4 den = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int n = 0; n < 9; ++n) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) p[n][k] = __expf(p[n][k] - mx[k]);
+      den += p[n];
+    }
+    f32x4 dsum = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 rden;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) rden[k] = __builtin_amdgcn_rcpf(den[k]);  // v_rcp_f32 (1 ulp) instead of 36 IEEE divisions
+#pragma unroll
+    for (int n = 0; n < 9; ++n) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) p[n][k] = p[n][k] * rden[k];
+      dsum += p[n] * dp[n];
+    }
+    f32x4 dq = f32x4{0.f, 0.f, 0.f, 0.f};
+    bool rep[4];  // the lane owning a head's FIRST channel reports for that head
+#pragma unroll
+    for (int k = 0; k < 4; ++k) rep[k] = ok && ((c + k) % HD == 0);
+    const bool inter = sy == y - 1 && sx == x - 1;  // unclamped window: neighbour n always lands in bin (ki+1, kj+1)
+    f32x4 rm;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) rm[k] = (rep[k] && inter) ? 1.f : 0.f;
+#pragma unroll
+    for (int ki = 0; ki < 3; ++ki)
+#pragma unroll
+      for (int kj = 0; kj < 3; ++kj) {
+        const int n = ki * 3 + kj;
+        const int ny = sy + ki, nx = sx + kj;
+        const f32x4 ds = p[n] * (dp[n] - dsum);
+        const f32x4 kk = *reinterpret_cast<const f32x4*>(kv0 + ((ki * RW + kj) * 2) * g.C);
+        dq += ds * kk;
+        bins[n] += ds * rm;
+        if (!inter) {  // border pixels (the clamped window shifts the bins): rare, through LDS atomics
+          const int bo = (ny - y + 2) * 5 + (nx - x + 2);
+#pragma unroll
+          for (int k = 0; k < 4; ++k)
+            if (rep[k]) atomicAdd(&s_drpb[hidx[k] + bo], ds[k]);
+        }
+      }
+    if (ok) *reinterpret_cast<f32x4*>(dqkv + ib + ((int64_t)y * g.W + x) * 3 * g.C + c) = dq * g.scale;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      if (rep[k]) {
+        const int h = (c + k) / HD;
+        stat[pix * 2 * g.heads + h] = mx[k] + __logf(den[k]);
+        stat[pix * 2 * g.heads + g.heads + h] = dsum[k];
+      }
+   }
+  }
+  __syncthreads();  // every window read is done: the parking area reuses that memory
+  // interior bins: park per thread, then one thread per (quad, neighbour, component) sums its PB pixel slots
+#pragma unroll
+  for (int n = 0; n < 9; ++n)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) s_bins[threadIdx.x * 36 + n * 4 + k] = bins[n][k];
+  __syncthreads();
+  for (int o = threadIdx.x; o < g.C4 * 36; o += 256) {
+    const int qd = o / 36, nk = o - qd * 36;
+    const int n = nk >> 2, k = nk & 3;
+    const int ch = qd * 4 + k;
+    if (ch % HD != 0) continue;
+    float v = 0.f;
+    for (int sl = 0; sl < PB; ++sl) v += s_bins[(sl * g.C4 + qd) * 36 + nk];
+    atomicAdd(&s_drpb[(ch / HD) * 25 + (n / 3 + 1) * 5 + (n % 3 + 1)], v);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < g.heads * 25; i += 256)
+    if (s_drpb[i] != 0.f) atomicAdd(drpb + i, s_drpb[i]);
+}
+
+template <int HD>
 __global__ __launch_bounds__(256) void na_bwd_kv_kernel(const float* __restrict__ qkv, const float* __restrict__ rpb,
                                                         const float* __restrict__ dout, float* __restrict__ dqkv,
                                                         const float* __restrict__ stat, const NaGeom g) {
@@ -403,14 +551,30 @@ int lmn_na_bwd(const float* qkv, const float* rpb, const float* dout, float* dqk
     hipLaunchKernelGGL((na_bwd_q_kernel<HDV>), dim3(gq), dim3(256), sh, st, qkv, rpb, dout, dqkv, drpb, stat, g);    \
     hipLaunchKernelGGL((na_bwd_kv_kernel<HDV>), dim3(grid), dim3(256), 0, st, qkv, rpb, dout, dqkv, stat, g);        \
   } while (0)
+  // C <= 24 (levels 0-1): query pass with the k/v window in LDS; tile sizes are whole multiples of the 256/C4 pixels a
+  // block handles per iteration (15x17 = 3 x 85, 12x14 = 4 x 42)
+#define LMN_NAT(HDV)                                                                                                 \
+  do {                                                                                                               \
+    const int TH = g.C4 == 3 ? 15 : 12, TW = g.C4 == 3 ? 17 : 14;                                                    \
+    const int tx = lmn_cdiv(W, TW), ty = lmn_cdiv(H, TH), total = tx * ty * B;                                       \
+    const int ntab = (heads * 25 + 3) & ~3;                                                                          \
+    const int win = (TH + 2) * (TW + 2) * 2 * g.C;                                                                   \
+    const size_t tsh = (size_t)(2 * ntab + (win > 256 * 36 ? win : 256 * 36)) * sizeof(float);                       \
+    const int gt = total > 1024 ? 1024 : total;                                                                      \
+    hipLaunchKernelGGL((na_bwd_q_tile_kernel<HDV>), dim3(gt), dim3(256), tsh, st, qkv, rpb, dout, dqkv, drpb, stat, g, TH, TW, \
+                       tx, tx * ty, total);                                                                          \
+    hipLaunchKernelGGL((na_bwd_kv_kernel<HDV>), dim3(grid), dim3(256), 0, st, qkv, rpb, dout, dqkv, stat, g);        \
+  } while (0)
+  const bool tiled = (g.C4 == 3 || g.C4 == 6) && hd <= 2 && H >= 16 && W >= 16;
   switch (hd) {
-    case 1: LMN_NA(1); break;
-    case 2: LMN_NA(2); break;
+    case 1: if (tiled) LMN_NAT(1); else LMN_NA(1); break;
+    case 2: if (tiled) LMN_NAT(2); else LMN_NA(2); break;
     case 4: LMN_NA(4); break;
     case 8: LMN_NA(8); break;
     default: LMN_NA(16); break;
   }
 #undef LMN_NA
+#undef LMN_NAT
   return lmn_launch_status("na_bwd");
 }
 

@@ -314,7 +314,8 @@ def check_se():
 # ------------------------------------------------------------------------------------------------ attention
 def check_na():
     rows = []
-    for (B, H, W, hd) in [(2, 7, 9, 1), (1, 6, 5, 2), (2, 5, 8, 4), (1, 9, 6, 8), (1, 3, 3, 2), (1, 3, 17, 1)]:
+    for (B, H, W, hd) in [(2, 7, 9, 1), (1, 6, 5, 2), (2, 5, 8, 4), (1, 9, 6, 8), (1, 3, 3, 2), (1, 3, 17, 1),
+                          (2, 37, 41, 1), (1, 16, 52, 2), (2, 31, 18, 2), (1, 48, 33, 1)]:  # LDS-tiled query pass (C <= 24, maps >= 16)
         heads, Cn = 12, 12 * hd
         qkv = R(B, H, W, 3 * Cn, seed=91).requires_grad_(True)
         rpb = (R(heads, 5, 5, seed=92) * 0.5).requires_grad_(True)
