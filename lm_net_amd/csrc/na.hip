@@ -502,6 +502,112 @@ inline int na_grid(int64_t total) {
   return (int)(gsz < 1 ? 1 : gsz);
 }
 
+template <int HD>
+__global__ __launch_bounds__(256) void na_bwd_kv_tile_kernel(const float* __restrict__ qkv, const float* __restrict__ rpb,
+                                                             const float* __restrict__ dout, float* __restrict__ dqkv,
+                                                             const float* __restrict__ stat, const NaGeom g, int T,
+                                                             int tiles_x, int tiles_img) {
+  // Key pass for C <= 24 with the strided operands of the 3x3 query neighbourhood -- q (48..96 B of a 144..288 B
+  // pixel) and the per-head lse / dsum -- of a T x T key tile staged in LDS ([pixel][C + 2*heads], window T+2 squared);
+  // dO is contiguous per pixel and stays a global load.  Keys within 3 pixels of the border (clamped windows: up to 25
+  // candidate queries) keep the direct path.
+  extern __shared__ __attribute__((aligned(16))) float QS[];
+  const int PS = g.C + 2 * g.heads, RW = T + 2;
+  const int tile = blockIdx.x;
+  const int b = tile / tiles_img, tt = tile - b * tiles_img;
+  const int ty0 = (tt / tiles_x) * T, tx0 = (tt % tiles_x) * T;
+  const int64_t ib = (int64_t)b * g.H * g.W * 3 * g.C;
+  const float* base = qkv + ib;
+  {
+    const int qf = g.C4, sf = g.heads / 2, per = qf + sf;  // float4 items per window pixel
+    for (int i = threadIdx.x; i < RW * RW * per; i += 256) {
+      const int f = i % per, wp = i / per;
+      const int gy = ty0 - 1 + wp / RW, gx = tx0 - 1 + wp % RW;
+      const bool in = gy >= 0 && gy < g.H && gx >= 0 && gx < g.W;
+      const int64_t ipix = ((int64_t)b * g.H + (in ? gy : 0)) * g.W + (in ? gx : 0);
+      f32x4 v = f < qf ? ld4(base + ((int64_t)(in ? gy : 0) * g.W + (in ? gx : 0)) * 3 * g.C + f * 4)
+                       : ld4(stat + ipix * 2 * g.heads + (f - qf) * 4);
+      if (!in) v = f32x4{0.f, 0.f, 0.f, 0.f};
+      *reinterpret_cast<f32x4*>(&QS[wp * PS + f * 4]) = v;
+    }
+  }
+  __syncthreads();
+  const int items = T * T * g.C4;
+  for (int it0 = 0; it0 < items; it0 += 256) {
+    int idx = it0 + threadIdx.x;
+    bool ok = idx < items;
+    if (!ok) idx = 0;
+    const int c = (idx % g.C4) * 4;
+    const int pl = idx / g.C4;
+    int jy = ty0 + pl / T, jx = tx0 + pl % T;
+    if (jy >= g.H || jx >= g.W) { ok = false; jy = ty0; jx = tx0; }
+    const int64_t kpo = ((int64_t)jy * g.W + jx) * 3 * g.C;
+    const f32x4 kj = ld4(base + kpo + g.C + c), vj = ld4(base + kpo + 2 * g.C + c);
+    int hidx[4], hd_[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { hd_[k] = (c + k) / HD; hidx[k] = hd_[k] * 25; }
+    f32x4 dk = f32x4{0.f, 0.f, 0.f, 0.f}, dv = dk;
+    auto candidate = [&](int iy, int ix, bool lds) {
+      const int64_t ipix = ((int64_t)b * g.H + iy) * g.W + ix;
+      const float* wq = QS + ((iy - ty0 + 1) * RW + (ix - tx0 + 1)) * PS;
+      const f32x4 qi = (lds ? *reinterpret_cast<const f32x4*>(wq + c) : ld4(base + ((int64_t)iy * g.W + ix) * 3 * g.C + c)) * g.scale;
+      const f32x4 dOi = ld4(dout + ipix * g.C + c);
+      f32x4 lse4, dsm4;
+      const float* sp = lds ? wq + g.C : stat + ipix * 2 * g.heads;
+      if constexpr (HD == 1) {
+        lse4 = ld4(sp + hd_[0]);
+        dsm4 = ld4(sp + g.heads + hd_[0]);
+      } else if constexpr (HD == 2) {
+        const float2 a = *reinterpret_cast<const float2*>(sp + hd_[0]), bq = *reinterpret_cast<const float2*>(sp + g.heads + hd_[0]);
+        lse4 = f32x4{a.x, a.x, a.y, a.y};
+        dsm4 = f32x4{bq.x, bq.x, bq.y, bq.y};
+      } else {
+        const float a = sp[hd_[0]], bq = sp[g.heads + hd_[0]];
+        lse4 = f32x4{a, a, a, a};
+        dsm4 = f32x4{bq, bq, bq, bq};
+      }
+      const f32x4 s = head_sum<HD>(qi * kj);
+      const f32x4 dp = head_sum<HD>(dOi * vj);
+      const int bo = (jy - iy + 2) * 5 + (jx - ix + 2);
+      f32x4 pij, ds;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        pij[k] = __expf(s[k] + rpb[hidx[k] + bo] - lse4[k]);
+        ds[k] = pij[k] * (dp[k] - dsm4[k]);
+      }
+      dk += ds * qi;   // qi carries the scale
+      dv += pij * dOi;
+    };
+    // Interior keys (99 % of them): the queries that see key j are exactly its 3x3 neighbourhood, all with unclamped
+    // windows -- a fixed, fully unrolled candidate set whose 36 loads can be issued together.  The generic loop with
+    // its per-candidate window tests (16 of 25 candidates fail them) is kept for keys within 3 pixels of the border.
+    // (The test is pixel-uniform, so the lane pairs of hd >= 8 stay converged in head_sum.)
+    // (queries 2 pixels away see key j only through a CLAMPED window, i.e. when they sit on the border: j in [3, L-4])
+    if (jy >= 3 && jy <= g.H - 4 && jx >= 3 && jx <= g.W - 4) {
+#pragma unroll
+      for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+        for (int dx = -1; dx <= 1; ++dx) candidate(jy + dy, jx + dx, true);
+    } else {
+      for (int iy = jy - 2; iy <= jy + 2; ++iy) {
+        if (iy < 0 || iy >= g.H) continue;
+        const int ki = jy - wstart(iy, g.H);
+        if (ki < 0 || ki > 2) continue;
+        for (int ix = jx - 2; ix <= jx + 2; ++ix) {
+          if (ix < 0 || ix >= g.W) continue;
+          const int kx = jx - wstart(ix, g.W);
+          if (kx < 0 || kx > 2) continue;
+          candidate(iy, ix, false);
+        }
+      }
+    }
+    if (ok) {
+      *reinterpret_cast<f32x4*>(dqkv + ib + kpo + g.C + c) = dk;
+      *reinterpret_cast<f32x4*>(dqkv + ib + kpo + 2 * g.C + c) = dv;
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -563,9 +669,17 @@ int lmn_na_bwd(const float* qkv, const float* rpb, const float* dout, float* dqk
     const int gt = total > 1024 ? 1024 : total;                                                                      \
     hipLaunchKernelGGL((na_bwd_q_tile_kernel<HDV>), dim3(gt), dim3(256), tsh, st, qkv, rpb, dout, dqkv, drpb, stat, g, TH, TW, \
                        tx, tx * ty, total);                                                                          \
-    hipLaunchKernelGGL((na_bwd_kv_kernel<HDV>), dim3(grid), dim3(256), 0, st, qkv, rpb, dout, dqkv, stat, g);        \
+    if (g.C4 == 3) {  /* key pass in LDS form only at C = 12 (measured: 208 -> 181 us; at C = 24 it is slower, 71 -> 97 us) */ \
+      const int KT = 16;  /* key tile: window (KT+2)^2 x (C + 2*heads) floats of LDS */                              \
+      const int kx = lmn_cdiv(W, KT), ky = lmn_cdiv(H, KT);                                                          \
+      const size_t ksh = (size_t)(KT + 2) * (KT + 2) * (g.C + 2 * heads) * sizeof(float);                            \
+      hipLaunchKernelGGL((na_bwd_kv_tile_kernel<HDV>), dim3(kx * ky * B), dim3(256), ksh, st, qkv, rpb, dout, dqkv, stat, g, KT, \
+                         kx, kx * ky);                                                                               \
+    } else {                                                                                                         \
+      hipLaunchKernelGGL((na_bwd_kv_kernel<HDV>), dim3(grid), dim3(256), 0, st, qkv, rpb, dout, dqkv, stat, g);      \
+    }                                                                                                                \
   } while (0)
-  const bool tiled = (g.C4 == 3 || g.C4 == 6) && hd <= 2 && H >= 16 && W >= 16;
+  const bool tiled = (g.C4 == 3 || g.C4 == 6) && hd <= 2 && heads % 2 == 0 && H >= 16 && W >= 16;
   switch (hd) {
     case 1: if (tiled) LMN_NAT(1); else LMN_NA(1); break;
     case 2: if (tiled) LMN_NAT(2); else LMN_NA(2); break;
