@@ -1523,7 +1523,9 @@ int lmn_conv_wgrad(const lmn_wgrad_args_t* args, lmn_stream_t stream) {
   const int64_t per = (int64_t)taps * NMT * NNT * 256 + NMT * 16;
   // ---- tile geometry of the LDS-staged kernel
   const lmn_wgrad_args_t& G = P.a;  // (flattened) geometry
-  const int npmax = G.stride == 2 ? 64 : (G.ksize == 1 ? 256 : 128);
+  // tile pixels: 256 for the 1x1 form, for one-tile blocks and on the small maps (fewer barriers and less halo per pixel:
+  // -5..10 %), 128 where a 2x2-tile block would need 76 KB of LDS for it (+3 % there)
+  const int npmax = G.stride == 2 ? 64 : ((G.ksize == 1 || NMT * NNT == 1 || G.Wout <= 32) ? 256 : 128);
   P.TW = G.Wout < (G.ksize == 1 ? npmax : 32) ? G.Wout : (G.ksize == 1 ? npmax : 32);
   if (G.stride == 2 && P.TW > 16) P.TW = 16;
   P.TH = npmax / P.TW;
