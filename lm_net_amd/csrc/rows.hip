@@ -56,13 +56,11 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ x
                                                      const float* __restrict__ dy, const float* __restrict__ dres,
                                                      float* __restrict__ dx, float* __restrict__ dgamma,
                                                      float* __restrict__ dbeta, int64_t rows, int C) {
-  extern __shared__ float red[];  // [2][C]
+  extern __shared__ float red[];  // [4 waves][2][C]
   const int C4 = C >> 2;
   const int j = threadIdx.x % G;
   const int rpb = 256 / G;
   const bool has0 = j < C4, has1 = j + G < C4;
-  for (int i = threadIdx.x; i < 2 * C; i += 256) red[i] = 0.f;
-  __syncthreads();
   f32x4 g0 = f32x4{0, 0, 0, 0}, g1 = g0;
   if (has0) g0 = ld4(gamma + j * 4);
   if (has1) g1 = ld4(gamma + (j + G) * 4);
@@ -118,15 +116,31 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ x
       ab1 += d1;
     }
   }
+  // dgamma / dbeta: the row slots of a wave (lanes with equal j differ in the lane bits >= log2 G) fold by shuffles,
+  // the four waves through plain LDS stores, then ONE global atomic per channel per block.  (Per-thread LDS float
+  // atomics on 2C shared addresses plus ~1000 same-address global atomics per channel put a ~40 us floor under
+  // every call, whatever the size of the tensor.)
 #pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    if (has0) { atomicAdd(&red[j * 4 + k], ag0[k]); atomicAdd(&red[C + j * 4 + k], ab0[k]); }
-    if (has1) { atomicAdd(&red[(j + G) * 4 + k], ag1[k]); atomicAdd(&red[C + (j + G) * 4 + k], ab1[k]); }
+  for (int m = G; m < 64; m <<= 1) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      ag0[k] += __shfl_xor(ag0[k], m, 64); ab0[k] += __shfl_xor(ab0[k], m, 64);
+      ag1[k] += __shfl_xor(ag1[k], m, 64); ab1[k] += __shfl_xor(ab1[k], m, 64);
+    }
+  }
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  float* wred = red + wv * 2 * C;  // [4 waves][2][C]
+  if (lane < G) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if (has0) { wred[j * 4 + k] = ag0[k]; wred[C + j * 4 + k] = ab0[k]; }
+      if (has1) { wred[(j + G) * 4 + k] = ag1[k]; wred[C + (j + G) * 4 + k] = ab1[k]; }
+    }
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < C; i += 256) {
-    atomicAdd(dgamma + i, red[i]);
-    atomicAdd(dbeta + i, red[C + i]);
+  for (int i = threadIdx.x; i < 2 * C; i += 256) {
+    const float v = red[i] + red[2 * C + i] + red[4 * C + i] + red[6 * C + i];
+    atomicAdd((i < C ? dgamma : dbeta - C) + i, v);
   }
 }
 
@@ -760,9 +774,11 @@ int lmn_ln_bwd(const float* x, const float* gamma, const float* dy, const float*
   LMN_REQUIRE(x && gamma && dy && dx && dgamma && dbeta && rows > 0, "ln_bwd: bad argument");
   LMN_REQUIRE(C % 4 == 0 && C >= 4 && C <= 512, "ln_bwd: C=%d", C);
   const int G = ln_group(C / 4);
-  const int grid = grid_for(rows, 256 / G, 1024);
+  // every block ends with one global atomic per channel: ~40 ns per block on the same address, so the grid is kept to
+  // what the tensor needs for bandwidth (level 0: 143 MB -> 1024 blocks; the coarser maps: 512)
+  const int grid = grid_for(rows, 256 / G, C <= 12 ? 1024 : 512);
   hipStream_t st = (hipStream_t)stream;
-  const size_t sh = 2 * C * sizeof(float);
+  const size_t sh = 8 * C * sizeof(float);
 #define LN_CASE(g) case g: hipLaunchKernelGGL((ln_bwd_kernel<g>), dim3(grid), dim3(256), sh, st, x, gamma, dy, dres, dx, dgamma, dbeta, rows, C); break;
   switch (G) { LN_CASE(1) LN_CASE(2) LN_CASE(4) LN_CASE(8) LN_CASE(16) LN_CASE(32) LN_CASE(64) }
 #undef LN_CASE
