@@ -33,7 +33,7 @@ extern "C" {
 
 typedef void* lmn_stream_t; /* hipStream_t */
 
-#define LMN_ABI_VERSION 2
+#define LMN_ABI_VERSION 3
 #define LMN_E_BADARG (-1)
 #define LMN_E_UNSUPPORTED (-2)
 
@@ -112,6 +112,8 @@ typedef struct {
   uint32_t drop_seed; /* (nn.Dropout(0.1), core/modules.py:48,53,55)                              */
   const uint32_t* seed_ctr; /* optional DEVICE word added to every dropout seed of this call: lets a captured */
                             /* hipGraph draw a new mask per replay (the host bumps the word once per step)    */
+  const float* bias2;       /* second [Cout] bias or NULL: one conv over two sources stands for two biased    */
+                            /* convs (pointwise_conv + shortcut, core/modules.py:597-599)                     */
 } lmn_conv_args_t;
 
 /* number of floats lmn_conv_pack writes for (ksize, Cout, src channel counts c[nsrc]) */

@@ -240,6 +240,7 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(const ConvParams P) {
         const int cos = cok ? co : 0;
         f32x4 v = acc[g][c];
         if (A.bias) v += ld4(A.bias + cos);
+        if (A.bias2) v += ld4(A.bias2 + cos);
         f32x4 o = v;
         if (EPI && st_mode == LMN_STATS_SUM_SQ && live) {
 #pragma unroll
@@ -496,6 +497,7 @@ __global__ __launch_bounds__(256) void conv_tileM_kernel(const ConvParams P) {
         const int cos = cok ? co : 0;
         f32x4 v = acc[g][c];
         if (A.bias) v += ld4(A.bias + cos);
+        if (A.bias2) v += ld4(A.bias2 + cos);
         f32x4 o = v;
         if (EPI && st_mode == LMN_STATS_SUM_SQ && live) {
 #pragma unroll

@@ -280,10 +280,9 @@ class Engine:
         # pointwise(g*s) + shortcut(x): one conv over two sources
         wpw, wsc = m.pointwise_conv[0].weight, self._w_shortcut(m, x)
         wp3 = self._pack2(wpw, wsc, E, x.shape[-1], Cout, x)
-        b3 = hip.add(m.pointwise_conv[0].bias, m.shortcut[0].bias, out=_E(x, Cout))
         y = _E(x, B, H, W, Cout) if out is None else out
         hip.conv_fwd([dict(view=pre, scale=sgate, flags=hip.SRC_GELU), x], wp3, y, B=B, Hin=H, Win=W, Hout=H, Wout=W,
-                     Cout=Cout, bias=b3)
+                     Cout=Cout, bias=m.pointwise_conv[0].bias, bias2=m.shortcut[0].bias)
         if cx is not None:
             cx.t[m] = dict(x=x, x1=x1, pre=pre, gsum=gsum, s=sgate, hid=hid, wpe=wpe, mean1=mean1, rstd1=rstd1, A1=A1,
                            bmean=bmean, brstd=brstd, bA=bA)

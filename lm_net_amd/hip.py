@@ -17,7 +17,7 @@ SRC_GELU, SRC_DROP = 1, 2
 EP_LINEAR, EP_AFFINE_ACT, EP_DGELU, EP_BN_BWD1, EP_BN_BWD2, EP_SE_BWD = 0, 1, 2, 3, 4, 5
 ACT_NONE, ACT_HSWISH, ACT_GELU = 0, 1, 2
 STATS_NONE, STATS_SUM_SQ, STATS_EP = 0, 1, 2
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 
 class SrcT(C.Structure):
@@ -33,7 +33,7 @@ class ConvArgs(C.Structure):
                 ("aux", C.c_void_p), ("residual", C.c_void_p), ("out", C.c_void_p), ("stats", C.c_void_p),
                 ("aux_cstride", C.c_int32), ("res_cstride", C.c_int32), ("out_cstride", C.c_int32),
                 ("epilogue", C.c_int32), ("act", C.c_int32), ("stats_mode", C.c_int32),
-                ("drop_p", C.c_float), ("drop_seed", C.c_uint32), ("seed_ctr", C.c_void_p)]
+                ("drop_p", C.c_float), ("drop_seed", C.c_uint32), ("seed_ctr", C.c_void_p), ("bias2", C.c_void_p)]
 
 
 class WgradArgs(C.Structure):
@@ -276,7 +276,7 @@ def conv_pack_t(w, ksize, row_off=0, rows=None, out=None):
     return out
 
 
-def conv_fwd(srcs, wpack, out, *, B, Hin, Win, Hout, Wout, Cout, ksize=1, stride=1, transposed=0, bias=None,
+def conv_fwd(srcs, wpack, out, *, B, Hin, Win, Hout, Wout, Cout, ksize=1, stride=1, transposed=0, bias=None, bias2=None,
              epilogue=EP_LINEAR, act=ACT_NONE, p=(), aux=None, residual=None, stats=None, stats_mode=STATS_NONE,
              drop_p=0.0, drop_seed=0):
     a = ConvArgs()
@@ -286,6 +286,7 @@ def conv_fwd(srcs, wpack, out, *, B, Hin, Win, Hout, Wout, Cout, ksize=1, stride
         _fill_src(a.src[i], s)
     a.wpack = wpack.data_ptr()
     a.bias = bias.data_ptr() if bias is not None else None
+    a.bias2 = bias2.data_ptr() if bias2 is not None else None
     ps = [t.data_ptr() if t is not None else None for t in p] + [None] * (5 - len(p))
     a.p0, a.p1, a.p2, a.p3, a.p4 = ps
     if aux is not None:

@@ -119,6 +119,10 @@ def check_conv_fwd():
     hip.conv_fwd([dict(view=nhwc(pre), scale=dev(sc), flags=hip.SRC_GELU), nhwc(xin)], wp, out, B=B, Hin=H, Win=W,
                  Hout=H, Wout=W, Cout=12, bias=dev(b))
     rows.append(("conv_fwd gelu*scale source + plain source", rel(nchw(out), ref), TOL))
+    b2 = R(12, seed=77)
+    hip.conv_fwd([dict(view=nhwc(pre), scale=dev(sc), flags=hip.SRC_GELU), nhwc(xin)], wp, out, B=B, Hin=H, Win=W,
+                 Hout=H, Wout=W, Cout=12, bias=dev(b), bias2=dev(b2))
+    rows.append(("conv_fwd two biases (pointwise + shortcut)", rel(nchw(out), ref + b2.view(1, -1, 1, 1)), TOL))
     return rows
 
 
