@@ -161,6 +161,11 @@ typedef struct {
   float* workspace; /* optional scratch for the deterministic two-stage K-split reduction (no atomics);   */
   int64_t workspace_floats; /* size lmn_conv_wgrad_workspace() asks for; NULL/0 => LDS-reduced atomics   */
   const uint32_t* seed_ctr; /* as in lmn_conv_args_t: device word added to the dropout seeds of this call   */
+  float* dW_src[3]; /* optional: gradient of the weight slice of source s as its OWN tensor [Cout][C_s][k][k]    */
+                    /* (one pass over dy for convs that were fused over several sources in the forward, e.g.   */
+                    /* pointwise_conv + shortcut); NULL entries fall back to the columns of dW (may be NULL if */
+                    /* every source has its own tensor)                                                        */
+  float* db2;       /* optional second bias gradient receiving the same sum as db                              */
 } lmn_wgrad_args_t;
 int lmn_sizeof_wgrad_args(void);
 /* floats of workspace that make lmn_conv_wgrad use the two-stage reduction for this problem (0: not useful) */

@@ -672,6 +672,14 @@ struct WgradParams {
   int dbg;
 };
 
+// first element (tap 0) of dW[co][ch of source sidx]: the source's own gradient tensor if the caller gave one,
+// else its column range of the concatenated dW
+__device__ __forceinline__ float* wgrad_dst(const WgradParams& P, int co, int sidx, int ch, int taps) {
+  float* own = P.a.dW_src[sidx];
+  return own ? own + ((int64_t)co * P.a.src[sidx].C + ch) * taps
+             : P.a.dW + ((int64_t)co * P.Cin + P.cbase[sidx] + ch) * taps;
+}
+
 // ------------------------------------------------------------------------------------ weight gradient, LDS-staged
 // dW[co][ci][tap] = sum_p dy[p][co] * x[p*s + tap - pad][ci]   as an MFMA GEMM with K = pixels.
 // A block walks a contiguous range of output-pixel tiles.  Per tile the input window (with halo) and the dy
@@ -927,12 +935,15 @@ __global__ __launch_bounds__(256, 2) void wgrad_lds_kernel(const WgradParams P) 
     while (sidx + 1 < A.nsrc && nt >= P.ntile_off[sidx + 1]) ++sidx;
     const int ch = (nt - P.ntile_off[sidx]) * 16 + nn;
     if (ch >= A.src[sidx].C) continue;
-    atomicAdd(A.dW + ((int64_t)co * P.Cin + P.cbase[sidx] + ch) * TAPS + tp, s_acc[i]);
+    atomicAdd(wgrad_dst(P, co, sidx, ch, TAPS) + tp, s_acc[i]);
   }
   if (A.db && nset == 0) {
     for (int i = tid; i < NMT * 16; i += 256) {
       const int co = mt0 * 16 + i;
-      if (co < A.Cout && (mt0 + i / 16) < P.NMTT) atomicAdd(A.db + co, s_acc[NT * 256 + i]);
+      if (co < A.Cout && (mt0 + i / 16) < P.NMTT) {
+        atomicAdd(A.db + co, s_acc[NT * 256 + i]);
+        if (A.db2) atomicAdd(A.db2 + co, s_acc[NT * 256 + i]);
+      }
     }
   }
 }
@@ -1109,12 +1120,15 @@ __global__ __launch_bounds__(256) void wgrad_1x1_kernel(const WgradParams P) {
     while (sidx + 1 < A.nsrc && nt >= P.ntile_off[sidx + 1]) ++sidx;
     const int ch = (nt - P.ntile_off[sidx]) * 16 + nn;
     if (ch >= A.src[sidx].C) continue;
-    atomicAdd(A.dW + ((int64_t)co * P.Cin + P.cbase[sidx] + ch), s_acc[i]);
+    atomicAdd(wgrad_dst(P, co, sidx, ch, 1), s_acc[i]);
   }
   if (A.db && nset == 0) {
     for (int i = tid; i < NMT * 16; i += 256) {
       const int co = mt0 * 16 + i;
-      if (co < A.Cout && (mt0 + i / 16) < P.NMTT) atomicAdd(A.db + co, s_acc[NT * 256 + i]);
+      if (co < A.Cout && (mt0 + i / 16) < P.NMTT) {
+        atomicAdd(A.db + co, s_acc[NT * 256 + i]);
+        if (A.db2) atomicAdd(A.db2 + co, s_acc[NT * 256 + i]);
+      }
     }
   }
 }
@@ -1154,10 +1168,13 @@ __global__ __launch_bounds__(1024) void wgrad_reduce_kernel(const WgradParams P,
     while (sidx + 1 < A.nsrc && nt >= P.ntile_off[sidx + 1]) ++sidx;
     const int ch = (nt - P.ntile_off[sidx]) * 16 + nn;
     if (ch >= A.src[sidx].C) return;
-    A.dW[((int64_t)co * P.Cin + P.cbase[sidx] + ch) * TAPS + tp] += sum;
+    wgrad_dst(P, co, sidx, ch, TAPS)[tp] += sum;
   } else if (A.db && nset == 0) {
     const int j = i - NT * 256, co = mt0 * 16 + j;
-    if (co < A.Cout && (mt0 + j / 16) < P.NMTT) A.db[co] += sum;
+    if (co < A.Cout && (mt0 + j / 16) < P.NMTT) {
+      A.db[co] += sum;
+      if (A.db2) A.db2[co] += sum;
+    }
   }
 }
 
@@ -1485,7 +1502,9 @@ int lmn_conv_wgrad(const lmn_wgrad_args_t* args, lmn_stream_t stream) {
   LMN_REQUIRE(A.ksize == 1 || A.ksize == 3, "conv_wgrad: ksize %d", A.ksize);
   LMN_REQUIRE(A.stride == 1 || A.stride == 2, "conv_wgrad: stride %d", A.stride);
   LMN_REQUIRE(A.nsrc >= 1 && A.nsrc <= 3, "conv_wgrad: nsrc %d", A.nsrc);
-  LMN_REQUIRE(A.dy && A.dW && A.Cout > 0 && A.dy_cstride >= A.Cout, "conv_wgrad: dy/dW/Cout");
+  LMN_REQUIRE(A.dy && A.Cout > 0 && A.dy_cstride >= A.Cout, "conv_wgrad: dy/Cout");
+  for (int s = 0; s < A.nsrc && s < 3; ++s) LMN_REQUIRE(A.dW || A.dW_src[s], "conv_wgrad: no gradient tensor for source %d", s);
+  LMN_REQUIRE(!A.db2 || A.db, "conv_wgrad: db2 without db");
   LMN_REQUIRE(A.B > 0 && A.Hout > 0 && A.Wout > 0, "conv_wgrad: empty tensor");
   WgradParams P;
   P.a = A;

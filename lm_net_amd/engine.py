@@ -154,10 +154,12 @@ class Engine:
         Ho = (Hin + 2 * (k // 2) - k) // s + 1
         Wo = (Win + 2 * (k // 2) - k) // s + 1
         explicit = dW is not None                      # caller reads the result on the main stream right away
-        dW = self.G[w_param] if dW is None else dW
+        if dW is None and w_param is not None:
+            dW = self.G[w_param]
         db = (self.G[b_param] if b_param is not None else None) if db is None else db
+        cout = dW.shape[0] if dW is not None else kw["dW_src"][0].shape[0]
         if not self.overlap_wgrad or self.capturing:
-            hip.conv_wgrad(srcs, dy, dW, db, B=B, Hin=Hin, Win=Win, Hout=Ho, Wout=Wo, Cout=dW.shape[0], ksize=k, stride=s, **kw)
+            hip.conv_wgrad(srcs, dy, dW, db, B=B, Hin=Hin, Win=Win, Hout=Ho, Wout=Wo, Cout=cout, ksize=k, stride=s, **kw)
             return
         # Weight gradients feed nothing downstream in the backward chain: they run on a side stream and overlap the
         # data-gradient chain on the main stream (at batch 8 most kernels of levels 2-4 cannot fill 256 CUs alone).
@@ -170,7 +172,7 @@ class Engine:
         saved = hip._STREAM[0]
         hip._STREAM[0] = hip.C.c_void_p(side.cuda_stream)
         try:
-            hip.conv_wgrad(srcs, dy, dW, db, B=B, Hin=Hin, Win=Win, Hout=Ho, Wout=Wo, Cout=dW.shape[0], ksize=k, stride=s, **kw)
+            hip.conv_wgrad(srcs, dy, dW, db, B=B, Hin=Hin, Win=Win, Hout=Ho, Wout=Wo, Cout=cout, ksize=k, stride=s, **kw)
         finally:
             hip._STREAM[0] = saved
         d.record_stream(side)
@@ -331,11 +333,12 @@ class Engine:
         G = self.G
         pw, sc, ec, ebn, se = m.pointwise_conv[0], m.shortcut[0], m.expand_conv[0], m.expand_conv[1], m.se
         # ---- A3 backward
-        self.wgrad([dict(view=pre, scale=sgate, flags=hip.SRC_GELU)], dy, pw.weight, pw.bias, Hin=H, Win=W)
         wsc = self._w_shortcut(m, x)
-        if wsc is sc.weight:
-            self.wgrad([x], dy, sc.weight, sc.bias, Hin=H, Win=W)
+        if wsc is sc.weight:  # one pass over dy for both convs (they were one conv over two sources in the forward)
+            self.wgrad([dict(view=pre, scale=sgate, flags=hip.SRC_GELU), x], dy, None, pw.bias, Hin=H, Win=W,
+                       dW_src=[G[pw.weight], G[sc.weight]], db2=G[sc.bias])
         else:  # padded RGB input: gradient of the padded weight, keep the real columns
+            self.wgrad([dict(view=pre, scale=sgate, flags=hip.SRC_GELU)], dy, pw.weight, pw.bias, Hin=H, Win=W)
             dWp = torch.zeros_like(wsc)
             self.wgrad([x], dy, None, None, Hin=H, Win=W, dW=dWp, db=G[sc.bias])
             G[sc.weight].copy_(dWp[:, :sc.weight.shape[1]])      # un-pad (layout copy)

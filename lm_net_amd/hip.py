@@ -41,7 +41,8 @@ class WgradArgs(C.Structure):
                 ("ksize", C.c_int32), ("stride", C.c_int32), ("nsrc", C.c_int32), ("Cout", C.c_int32),
                 ("src", SrcT * 3), ("dy", C.c_void_p), ("dy_cstride", C.c_int32), ("dy_flags", C.c_int32),
                 ("dy_seed", C.c_uint32), ("dy_p", C.c_float), ("dW", C.c_void_p), ("db", C.c_void_p),
-                ("workspace", C.c_void_p), ("workspace_floats", C.c_int64), ("seed_ctr", C.c_void_p)]
+                ("workspace", C.c_void_p), ("workspace_floats", C.c_int64), ("seed_ctr", C.c_void_p),
+                ("dW_src", C.c_void_p * 3), ("db2", C.c_void_p)]
 
 
 # every symbol include/lmnet_hip.h declares (the CPU test suite checks the library exports all of them)
@@ -305,7 +306,9 @@ def conv_fwd(srcs, wpack, out, *, B, Hin, Win, Hout, Wout, Cout, ksize=1, stride
     _check(load().lmn_conv_fwd(C.byref(a), _stream()), "conv_fwd")
 
 
-def conv_wgrad(srcs, dy, dW, db, *, B, Hin, Win, Hout, Wout, Cout, ksize=1, stride=1, dy_flags=0, dy_seed=0, dy_p=0.0):
+def conv_wgrad(srcs, dy, dW, db, *, B, Hin, Win, Hout, Wout, Cout, ksize=1, stride=1, dy_flags=0, dy_seed=0, dy_p=0.0,
+               dW_src=None, db2=None):
+    """dW_src: optional list (one entry per source, None = use the columns of dW) of per-source gradient tensors."""
     a = WgradArgs()
     a.B, a.Hout, a.Wout, a.Hin, a.Win = B, Hout, Wout, Hin, Win
     a.ksize, a.stride, a.nsrc, a.Cout = ksize, stride, len(srcs), Cout
@@ -314,11 +317,15 @@ def conv_wgrad(srcs, dy, dW, db, *, B, Hin, Win, Hout, Wout, Cout, ksize=1, stri
     v = _as_view(dy)
     a.dy, a.dy_cstride = v.ptr, v.cstride
     a.dy_flags, a.dy_seed, a.dy_p = dy_flags, dy_seed, dy_p
-    a.dW = dW.data_ptr()
+    a.dW = dW.data_ptr() if dW is not None else None
     a.db = db.data_ptr() if db is not None else None
+    a.db2 = db2.data_ptr() if db2 is not None else None
+    if dW_src is not None:
+        for i, t in enumerate(dW_src):
+            a.dW_src[i] = t.data_ptr() if t is not None else None
     need = int(load().lmn_conv_wgrad_workspace(C.byref(a)))
     if need > 0:
-        ws = _workspace(dW.device, need)
+        ws = _workspace(v.t.device, need)
         a.workspace, a.workspace_floats = ws.data_ptr(), ws.numel()
     a.seed_ctr = _SEED_CTR[0].data_ptr() if _SEED_CTR[0] is not None else None
     _check(load().lmn_conv_wgrad(C.byref(a), _stream()), "conv_wgrad")

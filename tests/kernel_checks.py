@@ -181,6 +181,30 @@ def check_conv_wgrad():
         hip.conv_wgrad(xs, nhwc(dy), dW, db, B=B, Hin=H, Win=W, Hout=Ho, Wout=Wo, Cout=cout, ksize=k, stride=s)
         rows.append(("conv_wgrad dW " + name, rel(dW, w.grad), 2e-4))
         rows.append(("conv_wgrad db " + name, rel(db, b.grad), 2e-4))
+        if len(cins) > 1:  # per-source gradient tensors + second bias gradient (pointwise + shortcut in one pass)
+            parts = [torch.zeros(cout, c, k, k, device=DEV) for c in cins]
+            db1, db2 = torch.zeros(cout, device=DEV), torch.zeros(cout, device=DEV)
+            hip.conv_wgrad(xs, nhwc(dy), None, db1, B=B, Hin=H, Win=W, Hout=Ho, Wout=Wo, Cout=cout, ksize=k, stride=s,
+                           dW_src=parts, db2=db2)
+            off = 0
+            for i, c in enumerate(cins):
+                rows.append(("conv_wgrad per-source dW[%d] %s" % (i, name), rel(parts[i], w.grad[:, off:off + c]), 2e-4))
+                off += c
+            rows.append(("conv_wgrad db2 " + name, rel(db2, b.grad), 2e-4))
+    # large two-source 1x1 (two-stage reduction path) with per-source outputs
+    B, H, W, cins, cout = 2, 64, 48, [24, 12], 12
+    x = R(B, 36, H, W, seed=41)
+    w = R(cout, 36, 1, 1, seed=42, scale=0.1).requires_grad_(True)
+    y = F.conv2d(x, w)
+    dy = R(*y.shape, seed=43)
+    y.backward(dy)
+    parts = [torch.zeros(cout, c, 1, 1, device=DEV) for c in cins]
+    db1, db2 = torch.zeros(cout, device=DEV), torch.zeros(cout, device=DEV)
+    hip.conv_wgrad([nhwc(x[:, :24]), nhwc(x[:, 24:])], nhwc(dy), None, db1, B=B, Hin=H, Win=W, Hout=H, Wout=W, Cout=cout,
+                   dW_src=parts, db2=db2)
+    rows.append(("conv_wgrad per-source large dW[0]", rel(parts[0], w.grad[:, :24]), 2e-4))
+    rows.append(("conv_wgrad per-source large dW[1]", rel(parts[1], w.grad[:, 24:]), 2e-4))
+    rows.append(("conv_wgrad per-source large db/db2", rel(db1 + db2, 2 * dy.sum((0, 2, 3))), 2e-4))
     return rows
 
 
