@@ -114,6 +114,10 @@ typedef struct {
                             /* hipGraph draw a new mask per replay (the host bumps the word once per step)    */
   const float* bias2;       /* second [Cout] bias or NULL: one conv over two sources stands for two biased    */
                             /* convs (pointwise_conv + shortcut, core/modules.py:597-599)                     */
+  int32_t stats_rep;        /* > 1 (SUM_SQ and BN_BWD1 statistics only): `stats` holds stats_rep slices of     */
+  int32_t _pad0;            /* [2][Cout]; block b adds into slice b % stats_rep (1280 blocks adding to the same */
+                            /* 2 cache lines cost 15-20 us of same-address atomics); the consumers              */
+                            /* (lmn_bn_finalize / lmn_bn_bwd_coef, argument nrep) sum the slices                */
 } lmn_conv_args_t;
 
 /* number of floats lmn_conv_pack writes for (ksize, Cout, src channel counts c[nsrc]) */
@@ -274,16 +278,16 @@ int lmn_bnact_bwd(const float* z, const float* dy, const float* mean, const floa
 /* BatchNorm bookkeeping on [C]-vectors (momentum 0.1, unbiased running var; torch semantics).
  * sums = [2][C] (sum, sumsq) over `count` elements.  Writes mean, rstd (biased var + eps),
  * A = gamma*rstd, shift = beta - mean*A, and updates running_mean/var in place if not NULL.   */
-int lmn_bn_finalize(const float* sums, float count, const float* gamma, const float* beta, float eps,
+int lmn_bn_finalize(const float* sums, int nrep, float count, const float* gamma, const float* beta, float eps,
                     float momentum, float* mean, float* rstd, float* A, float* shift, float* running_mean,
-                    float* running_var, int C, lmn_stream_t stream);
+                    float* running_var, int C, lmn_stream_t stream);  /* sums: nrep slices of [2][C] (nrep >= 1) */
 /* eval-mode BatchNorm (running statistics): mean, rstd, A = gamma*rstd, shift = beta - mean*A */
 int lmn_bn_fold(const float* running_mean, const float* running_var, const float* gamma, const float* beta, float eps,
                 float* mean, float* rstd, float* A, float* shift, int C, lmn_stream_t stream);
 /* BN backward coefficients from bstats = [2][C] (S0 = sum dh, S1 = sum dh*zhat):
  * dgamma += S1, dbeta += S0, c1 = A, c2 = A*S0/N, c3 = A*S1/N  (batch_stats=0: c2 = c3 = 0)    */
-int lmn_bn_bwd_coef(const float* bstats, float count, int batch_stats, const float* A, float* dgamma, float* dbeta,
-                    float* c1, float* c2, float* c3, int C, lmn_stream_t stream);
+int lmn_bn_bwd_coef(const float* bstats, int nrep, float count, int batch_stats, const float* A, float* dgamma,
+                    float* dbeta, float* c1, float* c2, float* c3, int C, lmn_stream_t stream);  /* bstats: nrep slices */
 
 /* ------------------------------------------------------------------------------------------
  * Resampling rows: bilinear x2 upsample with align_corners=True (core/LM_Net.py:59-72,

@@ -320,7 +320,7 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(const ConvParams P) {
       const int co = ct0 * 16 + cc;
       if (co < A.Cout) {
         if (se) { if (cur_b >= 0) atomicAdd(A.stats + cur_b * A.Cout + co, s_stats[i]); }
-        else atomicAdd(A.stats + (int64_t)which * A.Cout + co, s_stats[i]);
+        else atomicAdd(A.stats + (A.stats_rep > 1 ? (int64_t)(blockIdx.x % A.stats_rep) * 2 * A.Cout : 0) + (int64_t)which * A.Cout + co, s_stats[i]);
       }
     }
   }
@@ -577,7 +577,7 @@ __global__ __launch_bounds__(256) void conv_tileM_kernel(const ConvParams P) {
       const int co = ct0 * 16 + cc;
       if (co < A.Cout) {
         if (se) { if (cur_b >= 0) atomicAdd(A.stats + cur_b * A.Cout + co, s_stats[i]); }
-        else atomicAdd(A.stats + (int64_t)which * A.Cout + co, s_stats[i]);
+        else atomicAdd(A.stats + (A.stats_rep > 1 ? (int64_t)(blockIdx.x % A.stats_rep) * 2 * A.Cout : 0) + (int64_t)which * A.Cout + co, s_stats[i]);
       }
     }
   }

@@ -213,13 +213,15 @@ __global__ __launch_bounds__(256) void chan_kernel(const float* __restrict__ z, 
   }
 }
 
-__global__ void bn_finalize_kernel(const float* __restrict__ sums, float count, const float* __restrict__ gamma,
+__global__ void bn_finalize_kernel(const float* __restrict__ sums, int nrep, float count, const float* __restrict__ gamma,
                                    const float* __restrict__ beta, float eps, float momentum, float* mean, float* rstd,
                                    float* A, float* shift, float* rmean, float* rvar, int C) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
-  const float m = sums[c] / count;
-  float var = sums[C + c] / count - m * m;  // biased
+  float s0 = 0.f, s1 = 0.f;
+  for (int r = 0; r < nrep; ++r) { s0 += sums[r * 2 * C + c]; s1 += sums[r * 2 * C + C + c]; }
+  const float m = s0 / count;
+  float var = s1 / count - m * m;  // biased
   var = var > 0.f ? var : 0.f;
   const float rs = rsqrtf(var + eps);
   const float a = gamma[c] * rs;
@@ -243,12 +245,14 @@ __global__ void bn_fold_kernel(const float* __restrict__ rmean, const float* __r
   if (shift) shift[c] = beta[c] - rmean[c] * a;
 }
 
-__global__ void bn_bwd_coef_kernel(const float* __restrict__ bstats, float count, int batch_stats,
+__global__ void bn_bwd_coef_kernel(const float* __restrict__ bstats, int nrep, float count, int batch_stats,
                                    const float* __restrict__ A, float* dgamma, float* dbeta, float* c1, float* c2,
                                    float* c3, int C) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
-  const float S0 = bstats[c], S1 = bstats[C + c], a = A[c];
+  float S0 = 0.f, S1 = 0.f;
+  for (int r = 0; r < nrep; ++r) { S0 += bstats[r * 2 * C + c]; S1 += bstats[r * 2 * C + C + c]; }
+  const float a = A[c];
   if (dgamma) dgamma[c] += S1;
   if (dbeta) dbeta[c] += S0;
   c1[c] = a;
@@ -823,11 +827,11 @@ int lmn_colsum(const float* x, float* out, int64_t rows, int C, int cstride, lmn
   return lmn_launch_status("colsum");
 }
 
-int lmn_bn_finalize(const float* sums, float count, const float* gamma, const float* beta, float eps, float momentum,
-                    float* mean, float* rstd, float* A, float* shift, float* running_mean, float* running_var, int C,
-                    lmn_stream_t stream) {
-  LMN_REQUIRE(sums && gamma && beta && C > 0 && count > 0.f, "bn_finalize: bad argument");
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3(lmn_cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream, sums, count, gamma,
+int lmn_bn_finalize(const float* sums, int nrep, float count, const float* gamma, const float* beta, float eps,
+                    float momentum, float* mean, float* rstd, float* A, float* shift, float* running_mean,
+                    float* running_var, int C, lmn_stream_t stream) {
+  LMN_REQUIRE(sums && nrep >= 1 && gamma && beta && C > 0 && count > 0.f, "bn_finalize: bad argument");
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(lmn_cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream, sums, nrep, count, gamma,
                      beta, eps, momentum, mean, rstd, A, shift, running_mean, running_var, C);
   return lmn_launch_status("bn_finalize");
 }
@@ -840,10 +844,10 @@ int lmn_bn_fold(const float* running_mean, const float* running_var, const float
   return lmn_launch_status("bn_fold");
 }
 
-int lmn_bn_bwd_coef(const float* bstats, float count, int batch_stats, const float* A, float* dgamma, float* dbeta,
-                    float* c1, float* c2, float* c3, int C, lmn_stream_t stream) {
-  LMN_REQUIRE(bstats && A && c1 && c2 && c3 && C > 0 && count > 0.f, "bn_bwd_coef: bad argument");
-  hipLaunchKernelGGL(bn_bwd_coef_kernel, dim3(lmn_cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream, bstats, count,
+int lmn_bn_bwd_coef(const float* bstats, int nrep, float count, int batch_stats, const float* A, float* dgamma,
+                    float* dbeta, float* c1, float* c2, float* c3, int C, lmn_stream_t stream) {
+  LMN_REQUIRE(bstats && nrep >= 1 && A && c1 && c2 && c3 && C > 0 && count > 0.f, "bn_bwd_coef: bad argument");
+  hipLaunchKernelGGL(bn_bwd_coef_kernel, dim3(lmn_cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream, bstats, nrep, count,
                      batch_stats, A, dgamma, dbeta, c1, c2, c3, C);
   return lmn_launch_status("bn_bwd_coef");
 }

@@ -75,6 +75,11 @@ def _Z(ref, *shape):
     return pool.get(ref.device, *shape)
 
 
+# slices of the conv statistics buffers: a conv's ~1280 blocks add into slice (block % STATS_REP) instead of all into the
+# same two cache lines; lmn_bn_finalize / lmn_bn_bwd_coef sum the slices
+STATS_REP = 16
+
+
 class Engine:
     def __init__(self, model):
         self.m = model
@@ -238,9 +243,9 @@ class Engine:
         wpe = hip.conv_pack(we, 1, [x.shape[-1]])
         sums1 = None
         if self.training:
-            sums1 = _Z(x, 2, E)
+            sums1 = _Z(x, STATS_REP, 2, E)
             hip.conv_fwd([x], wpe, None, B=B, Hin=H, Win=W, Hout=H, Wout=W, Cout=E, bias=ec.bias, stats=sums1,
-                         stats_mode=hip.STATS_SUM_SQ)
+                         stats_mode=hip.STATS_SUM_SQ, stats_rep=STATS_REP)
         mean1, rstd1, A1, sh1 = self.bn_stats(ebn, sums1, N, x)
         x1 = _E(x, B, H, W, E)
         hip.conv_fwd([x], wpe, x1, B=B, Hin=H, Win=W, Hout=H, Wout=W, Cout=E, bias=ec.bias, epilogue=hip.EP_AFFINE_ACT,
@@ -367,10 +372,10 @@ class Engine:
         # ---- A1 backward: Hardswish' and BatchNorm backward fused into the recomputed 1x1 conv
         wpe = S["wpe"]
         dh = dpre  # reuse
-        st = _Z(x, 2, E)
+        st = _Z(x, STATS_REP, 2, E)
         hip.conv_fwd([x], wpe, dh, B=B, Hin=H, Win=W, Hout=H, Wout=W, Cout=E, bias=ec.bias, epilogue=hip.EP_BN_BWD1,
                      act=hip.ACT_HSWISH, p=(S["mean1"], S["rstd1"], ebn.weight, ebn.bias), aux=dx1, stats=st,
-                     stats_mode=hip.STATS_EP)
+                     stats_mode=hip.STATS_EP, stats_rep=STATS_REP)
         c1, c2, c3 = (_E(x, E) for _ in range(3))
         hip.bn_bwd_coef(st, N, S["A1"], G[ebn.weight], G[ebn.bias], c1, c2, c3, self.training)
         dz = dh

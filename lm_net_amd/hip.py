@@ -33,7 +33,8 @@ class ConvArgs(C.Structure):
                 ("aux", C.c_void_p), ("residual", C.c_void_p), ("out", C.c_void_p), ("stats", C.c_void_p),
                 ("aux_cstride", C.c_int32), ("res_cstride", C.c_int32), ("out_cstride", C.c_int32),
                 ("epilogue", C.c_int32), ("act", C.c_int32), ("stats_mode", C.c_int32),
-                ("drop_p", C.c_float), ("drop_seed", C.c_uint32), ("seed_ctr", C.c_void_p), ("bias2", C.c_void_p)]
+                ("drop_p", C.c_float), ("drop_seed", C.c_uint32), ("seed_ctr", C.c_void_p), ("bias2", C.c_void_p),
+                ("stats_rep", C.c_int32), ("_pad0", C.c_int32)]
 
 
 class WgradArgs(C.Structure):
@@ -279,7 +280,7 @@ def conv_pack_t(w, ksize, row_off=0, rows=None, out=None):
 
 def conv_fwd(srcs, wpack, out, *, B, Hin, Win, Hout, Wout, Cout, ksize=1, stride=1, transposed=0, bias=None, bias2=None,
              epilogue=EP_LINEAR, act=ACT_NONE, p=(), aux=None, residual=None, stats=None, stats_mode=STATS_NONE,
-             drop_p=0.0, drop_seed=0):
+             drop_p=0.0, drop_seed=0, stats_rep=1):
     a = ConvArgs()
     a.B, a.Hout, a.Wout, a.Hin, a.Win = B, Hout, Wout, Hin, Win
     a.ksize, a.stride, a.transposed, a.nsrc, a.Cout = ksize, stride, transposed, len(srcs), Cout
@@ -300,6 +301,7 @@ def conv_fwd(srcs, wpack, out, *, B, Hin, Win, Hout, Wout, Cout, ksize=1, stride
         v = _as_view(out)
         a.out, a.out_cstride = v.ptr, v.cstride
     a.stats = stats.data_ptr() if stats is not None else None
+    a.stats_rep = stats_rep
     a.epilogue, a.act, a.stats_mode = epilogue, act, stats_mode
     a.drop_p, a.drop_seed = drop_p, drop_seed
     a.seed_ctr = _SEED_CTR[0].data_ptr() if _SEED_CTR[0] is not None else None
@@ -464,7 +466,8 @@ def bnact_bwd(z, dy, mean, rstd, gamma, beta, c1, c2, c3, dz, act):
 
 
 def bn_finalize(sums, count, gamma, beta, eps, momentum, mean, rstd, A, shift, running_mean, running_var):
-    _check(load().lmn_bn_finalize(_p(sums), _f(count), _p(gamma), _p(beta), _f(eps), _f(momentum), _p(mean), _p(rstd),
+    nrep = sums.shape[0] if sums.dim() == 3 else 1      # [nrep][2][C] slices (conv_fwd(stats_rep=nrep)) or [2][C]
+    _check(load().lmn_bn_finalize(_p(sums), nrep, _f(count), _p(gamma), _p(beta), _f(eps), _f(momentum), _p(mean), _p(rstd),
                                   _p(A), _p(shift), _p(running_mean), _p(running_var), gamma.numel(), _stream()),
            "bn_finalize")
 
@@ -475,7 +478,8 @@ def bn_fold(running_mean, running_var, gamma, beta, eps, mean, rstd, A, shift):
 
 
 def bn_bwd_coef(bstats, count, A, dgamma, dbeta, c1, c2, c3, batch_stats=True):
-    _check(load().lmn_bn_bwd_coef(_p(bstats), _f(count), int(batch_stats), _p(A), _p(dgamma), _p(dbeta), _p(c1), _p(c2),
+    nrep = bstats.shape[0] if bstats.dim() == 3 else 1
+    _check(load().lmn_bn_bwd_coef(_p(bstats), nrep, _f(count), int(batch_stats), _p(A), _p(dgamma), _p(dbeta), _p(c1), _p(c2),
                                   _p(c3), A.numel(), _stream()), "bn_bwd_coef")
 
 

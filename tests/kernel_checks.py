@@ -106,6 +106,15 @@ def check_conv_fwd():
     rows.append(("conv_fwd untouched slice stays 0", float(outb[..., :12].abs().max() + outb[..., 36:].abs().max()), 1e-30))
     sref = torch.stack([z.sum((0, 2, 3)), (z * z).sum((0, 2, 3))])
     rows.append(("conv_fwd stats sum/sumsq", rel(stats, sref), 2e-4))
+    srep = torch.zeros(4, 2, 24, device=DEV)        # statistics in 4 slices (block % 4), summed by the consumer
+    hip.conv_fwd([hip.V(xb, 8, 24)], wp, hip.V(outb, 12, 24), B=B, Hin=H, Win=W, Hout=H, Wout=W, Cout=24, ksize=3,
+                 bias=dev(b), epilogue=hip.EP_AFFINE_ACT, act=hip.ACT_HSWISH, p=(dev(a0), dev(a1)), residual=nhwc(res),
+                 stats=srep, stats_mode=hip.STATS_SUM_SQ, stats_rep=4)
+    rows.append(("conv_fwd stats in 4 slices", rel(srep.sum(0), sref), 2e-4))
+    mean_r, rstd_r = torch.empty(24, device=DEV), torch.empty(24, device=DEV)
+    hip.bn_finalize(srep, B * H * W, torch.ones(24, device=DEV), torch.zeros(24, device=DEV), 1e-5, 0.1, mean_r, rstd_r,
+                    None, None, None, None)
+    rows.append(("bn_finalize over slices: mean", rel(mean_r, sref[0] / (B * H * W)), 2e-4))
 
     # A3 form: GELU + per-(image,channel) scale on source 0, plain source 1
     B, H, W = 3, 6, 5
