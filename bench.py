@@ -43,8 +43,87 @@ def pmc_traffic(kernel):
     """HBM bytes per launch of `kernel`, measured by separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this
     very command and committed under profiles/ (a PMC pass cannot run inside the timed loop)."""
     try:
-        with open(os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")) as f:
+        with open(os.path.join(ROOT, "profiles", "r02_pmc.json")) as f:
             return round(json.load(f)["kernels"][kernel]["hbm_bytes_per_launch"])
+    except (OSError, KeyError, ValueError):
+        return None
+
+
+MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: dense fp32 MFMA (v_mfma_f32_16x16x4_f32) = fp32 vector peak
+# SURVEY.md 8d, per image at 352x352 fp32 (scaled by pixels for other sizes): algorithmic bytes / FLOPs of one training step
+STEP_MB_352, STEP_GFLOP_352 = 2085.54, 59.7
+
+
+def _entry(name, rec, extra_us=0.0):
+    """One kernel's achieved rates from the in-library timer record {launches, total_us, flops, bytes}."""
+    t = (rec["total_us"] + extra_us) * 1e-6
+    n = max(rec["launches"], 1)
+    gbs, tfs = rec["bytes"] / t / 1e9 if t > 0 else 0.0, rec["flops"] / t / 1e12 if t > 0 else 0.0
+    t_hbm, t_mfma = rec["bytes"] / (HBM_PEAK_GBS * 1e9), rec["flops"] / (MFMA_F32_PEAK_TFLOPS * 1e12)
+    bound = "mfma" if t_mfma > t_hbm else "hbm"
+    return {"kernel": name, "bound": bound, "launches": rec["launches"], "avg_us": round(rec["total_us"] / n, 2),
+            "achieved": round(tfs if bound == "mfma" else gbs, 2), "peak": MFMA_F32_PEAK_TFLOPS if bound == "mfma" else HBM_PEAK_GBS,
+            "unit": "TFLOP/s" if bound == "mfma" else "GB/s",
+            "frac": round((tfs / MFMA_F32_PEAK_TFLOPS) if bound == "mfma" else (gbs / HBM_PEAK_GBS), 4),
+            "algorithmic_flops_per_launch": round(rec["flops"] / n), "algorithmic_bytes_per_launch": round(rec["bytes"] / n)}
+
+
+def _group(live, names):
+    tot = {"launches": 0, "total_us": 0.0, "flops": 0.0, "bytes": 0.0}
+    for k, v in live.items():
+        if k.split("<")[0] in names:
+            for f in tot:
+                tot[f] += v[f]
+    return tot
+
+
+def roofline_block(dominant, live, survey, tot_us, B, H, W, step_s):
+    """`roofline` of the bench line: the kernel that takes the most GPU time (found by timing EVERY launch over two untimed
+    steps), measured live with HIP events on its launch stream inside the timed region; algorithmic FLOPs / bytes from the
+    layer shapes of each launch (SURVEY 8d convention).  Secondary entries: rows A2 / A7 (north_star's >= 70 % HBM targets)
+    and the whole step against both rooflines."""
+    rec = live.get(dominant) or survey[dominant]
+    red = dominant.replace("wgrad_lds_kernel", "wgrad_reduce_kernel").replace("wgrad_1x1_kernel", "wgrad_reduce_kernel")
+    r = _entry(dominant, rec)
+    r["share_of_gpu_time"] = round(survey[dominant]["total_us"] / tot_us, 4)
+    if red != dominant and red in live:
+        r["frac_with_reduce_launches"] = _entry(dominant, rec, live[red]["total_us"])["frac"]
+    r["traffic"] = pmc_traffic(dominant) if (B, H, W) == (8, 352, 352) else None
+    r["mfma_util_pmc"] = pmc_field(dominant, "mfma_busy_frac") if (B, H, W) == (8, 352, 352) else None
+    r["top5_by_time"] = [{"kernel": k, "share": round(v["total_us"] / tot_us, 4), "avg_us": round(v["total_us"] / max(v["launches"], 1), 1)}
+                         for k, v in sorted(survey.items(), key=lambda kv: -kv[1]["total_us"])[:5]]
+    a2 = _group(live, ("dw_fwd_strip_kernel", "dw_bwd_strip_kernel", "dw_stats_strip_kernel"))
+    a7 = _group(live, ("na_fwd_kernel", "na_bwd_q_kernel", "na_bwd_kv_kernel", "na_bwd_q_tile_kernel", "na_bwd_kv_tile_kernel"))
+    # row totals under the 8d convention: A2 train = 5*E*HW*B*4 (the statistics passes are extra passes, not extra bytes)
+    if a2["total_us"] > 0:
+        a2b = sum(v["bytes"] for k, v in live.items() if k.startswith(("dw_fwd", "dw_bwd")))
+        e = _entry("row A2 (depthwise branches: fwd + 2 statistics passes + bwd)", dict(a2, bytes=a2b))
+        r["row_A2"] = {k: e[k] for k in ("kernel", "launches", "achieved", "peak", "unit", "frac")}
+        for k in ("dw_fwd_strip_kernel", "dw_bwd_strip_kernel"):
+            if k in live:
+                r["row_A2"][k] = {f: _entry(k, live[k])[f] for f in ("avg_us", "achieved", "frac")}
+    if a7["total_us"] > 0:
+        e = _entry("row A7 (fused neighborhood attention: fwd + query pass + key pass)", a7)
+        r["row_A7"] = {k: e[k] for k in ("kernel", "launches", "achieved", "peak", "unit", "frac")}
+        for k, v in live.items():
+            if k.startswith("na_fwd_kernel"):
+                r["row_A7"][k] = {f: _entry(k, v)[f] for f in ("avg_us", "achieved", "frac")}
+    scale = (H * W) / (352.0 * 352.0)
+    mb, gf = STEP_MB_352 * scale * B, STEP_GFLOP_352 * scale * B
+    r["whole_step"] = {"algorithmic_MB": round(mb, 1), "algorithmic_GFLOP": round(gf, 1),
+                       "hbm_GBps": round(mb / 1e3 / step_s, 1), "hbm_frac": round(mb / 1e3 / step_s / HBM_PEAK_GBS, 4),
+                       "TFLOPs": round(gf / 1e3 / step_s, 2), "mfma_frac": round(gf / 1e3 / step_s / MFMA_F32_PEAK_TFLOPS, 4)}
+    r["note"] = ("dominant kernel = largest share of GPU kernel time over two untimed steps with every launch timed; its "
+                 "achieved rate = sum of algorithmic FLOPs (2*MACs of each launch's layer shape) / sum of HIP-event durations "
+                 "on the launch stream INSIDE the timed region, where it shares the GPU with the other streams of the step; "
+                 "traffic / mfma_util_pmc from the committed rocprofv3 PMC passes (profiles/)")
+    return r
+
+
+def pmc_field(kernel, field):
+    try:
+        with open(os.path.join(ROOT, "profiles", "r02_pmc.json")) as f:
+            return json.load(f)["kernels"][kernel][field]
     except (OSError, KeyError, ValueError):
         return None
 
@@ -99,6 +178,9 @@ def main():
     ap.add_argument("--batch", type=int, default=8, help="images per GPU")
     ap.add_argument("--size", type=int, default=352)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--plans", action="store_true",
+                    help="replay the step as recorded C-side schedules (LM_Net.enable_plans(): one lmn_plan_run per pass on the "
+                         "same four streams; host cost ~2 ms per step instead of 16-20)")
     ap.add_argument("--graphs", action="store_true",
                     help="replay the step as two hipGraphs (wins when the host is the bottleneck, e.g. batch 1; at batch 8 "
                          "the step is GPU-bound and host launches measured 7 %% faster than the replay)")
@@ -123,6 +205,8 @@ def main():
     net = LM_Net(3, 2).to(dev)
     model = DistributedLMNet(net) if world > 1 else net
     model.train()
+    if args.plans:
+        net.enable_plans()      # forward / backward as one lmn_plan_run each (recorded on the 3rd step of the shape)
     if args.graphs:
         net.enable_graphs()     # forward / backward as two hipGraph replays per step (captured during the warm-up)
     from lm_net_amd.optim import FusedAdamW
@@ -140,15 +224,30 @@ def main():
         opt.step()
         return loss
 
-    for _ in range(max(args.warmup, 3 if args.graphs else 0)):   # graph capture happens on the 3rd step of a shape
+    for _ in range(max(args.warmup, 4 if (args.graphs or args.plans) else 0)):   # graph capture happens on the 3rd step of a shape
         step()
-    # dominant-kernel timing: HIP events on the launch stream around every dw_fwd launch -- inside the timed region
-    # when kernels are launched from the host; in graph mode (no host code runs during a replay) over 5 extra
-    # host-launched steps right after the timed region, same process, same buffers
-    net._engine.kernel_events = {"dw_fwd": []}
+    # ---- which kernel dominates?  Two extra untimed steps with the in-library timer on EVERY kernel launch (HIP events on
+    # the launch stream, lm_net_amd/csrc/runtime.hip); graph replays run no host code, so this survey uses host launches
+    from lm_net_amd import hip
+    eng = net._engine
+    saved_graphs = net.use_graphs
+    net.use_graphs = False
+    torch.cuda.synchronize()
+    hip.prof_begin(None)
+    for _ in range(2):
+        step()
+    survey = hip.prof_end()
+    net.use_graphs = saved_graphs
+    tot_us = sum(v["total_us"] for v in survey.values()) or 1.0
+    ranked = sorted(survey.items(), key=lambda kv: -kv[1]["total_us"])
+    dominant = ranked[0][0]
+    watch = [dominant] + [k for k in survey if k.startswith(("dw_", "na_")) or "wgrad_reduce" in k]
+    # ---- timed region: the dominant kernel and the A2 / A7 kernels (north_star targets) are timed live
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
+    if not net.use_graphs:
+        hip.prof_begin("|".join(sorted(set(w.split("<")[0] for w in watch))))
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step()
@@ -156,58 +255,32 @@ def main():
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0
+    live = hip.prof_end() if not net.use_graphs else {}
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    if net.use_graphs:
+    if net.use_graphs:      # replays run no host code: time the same kernels over 5 host-launched steps right after
         net.use_graphs = False
+        hip.prof_begin("|".join(sorted(set(w.split("<")[0] for w in watch))))
         for _ in range(5):
             step()
-        torch.cuda.synchronize()
+        live = hip.prof_end()
         net.use_graphs = True
-    ev = net._engine.kernel_events["dw_fwd"]
-    # the same kernel with nothing else on the GPU: 5 more steps with the side / branch streams switched off (inside
-    # the timed region the kernel shares the CUs with the concurrently running skip / attention chains)
-    eng = net._engine
-    saved = (eng.branch_overlap, eng.overlap_wgrad, net.use_graphs)
-    eng.branch_overlap, eng.overlap_wgrad, net.use_graphs = False, False, False
-    eng.kernel_events = {"dw_fwd": []}
-    for _ in range(5):
-        step()
-    torch.cuda.synchronize()
-    ev_serial = eng.kernel_events["dw_fwd"]
-    eng.branch_overlap, eng.overlap_wgrad, net.use_graphs = saved
-    net._engine.kernel_events = None
     if rank == 0:
-        kt = sum(e0.elapsed_time(e1) for e0, e1, _ in ev) * 1e-3
-        kb = sum(b for _, _, b in ev)
-        achieved = kb / kt / 1e9 if kt > 0 else 0.0
-        kts = sum(e0.elapsed_time(e1) for e0, e1, _ in ev_serial) * 1e-3
-        achieved_serial = sum(b for _, _, b in ev_serial) / kts / 1e9 if kts > 0 else 0.0
+        step_s = dt / args.steps
         res = {
             "metric": "train images/sec at 352x352, 1/2/4/8 MI355X; Dice vs ref",
             "value": round(world * B * args.steps / dt, 2), "unit": "images/sec", "n_gpus": world,
-            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(step_s * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "LM-Net fp32 training step (fwd + CE/Dice loss + bwd + AdamW), batch %d/GPU, %dx%d "
                                    "synthetic disc masks (BASELINE configs[1])" % (B, H, W),
                        "global_batch": world * B, "image": [3, H, W], "parallelism": "dp%d" % world,
-                       "launch": "hipGraph replay (fwd + bwd graphs per step)" if args.graphs else "host",
+                       "launch": "hipGraph replay (fwd + bwd graphs per step)" if args.graphs else
+                                 ("lmn_plan_run (recorded C-side schedule, one crossing per pass)" if args.plans else "host"),
                        "final_loss": round(float(loss.detach()), 5)},
-            "roofline": {"bound": "hbm", "kernel": "dw_fwd_strip_kernel (row A2 forward, 5x5 merged depthwise stencil + GELU-sum)",
-                         "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "frac_of_measured_copy_ceiling": round(achieved / 6290.0, 4),
-                         "launches": len(ev), "avg_us": round(kt / max(len(ev), 1) * 1e6, 2),
-                         "achieved_alone": round(achieved_serial, 1), "frac_alone": round(achieved_serial / HBM_PEAK_GBS, 4),
-                         "note": "achieved: HIP events around every launch inside the timed region, where the kernel shares "
-                                 "the GPU with the concurrent branch / weight-gradient streams; achieved_alone: same events "
-                                 "over 5 further steps of this process with those streams switched off",
-                         "traffic": pmc_traffic("dw_fwd_strip_kernel") if (B, H, W) == (8, 352, 352) else None,
-                         "algorithmic_bytes_per_launch": round(kb / max(len(ev), 1)),
-                         "algorithmic_bytes": "2*E*H*W*B*4 per launch (read x1 once, write pre once), averaged over "
-                                              "the 16 launches per step (four resolutions); traffic = HBM bytes per launch "
-                                              "from the committed rocprofv3 PMC passes (profiles/r01_pmc_hbm_traffic.json)"},
+            "roofline": roofline_block(dominant, live, survey, tot_us, B, H, W, step_s),
         }
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(H, W)

@@ -33,7 +33,7 @@ extern "C" {
 
 typedef void* lmn_stream_t; /* hipStream_t */
 
-#define LMN_ABI_VERSION 3
+#define LMN_ABI_VERSION 4
 #define LMN_E_BADARG (-1)
 #define LMN_E_UNSUPPORTED (-2)
 
@@ -355,6 +355,44 @@ int lmn_colsum(const float* x, float* out, int64_t rows, int C, int cstride, lmn
 /* copy a channel slice: y[rows][y_cstride][0:C] = x[rows][x_cstride][0:C] */
 int lmn_copy_slice(const float* x, float* y, int64_t rows, int C, int x_cstride, int y_cstride,
                    lmn_stream_t stream);
+
+/* y[r][0:cols] = x[r][0:cols] for r < rows, any cols >= 1 (row strides in floats): pads / un-pads the few weights whose
+ * channel count is not a multiple of 4 (the RGB input is carried as NHWC4, the 2-class head on 4 rows).            */
+int lmn_copy2d(const float* x, float* y, int64_t rows, int cols, int x_stride, int y_stride, lmn_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Single-crossing schedule (lmn_plan_create / lmn_forward / lmn_backward).
+ * The hot loop this serves is utils/train_eval_utils.py:140-145 (output = model(images); loss.backward()):
+ * per input shape, a pass of the network is a FIXED sequence of the entries above over FIXED buffers.  A plan
+ * records that sequence once -- while recording, every entry called on this thread runs AND is remembered with its
+ * arguments by value (argument structs are copied) -- and lmn_plan_run re-issues it: one FFI crossing per pass (or per
+ * data-parallel gradient bucket, see `lo`/`hi`) instead of one per kernel.  Cross-stream dependencies are part of the
+ * schedule: lmn_stream_wait(waiter, waited) makes `waiter` wait (hipEventRecord + hipStreamWaitEvent, no host sync) for
+ * everything enqueued on `waited` so far, and is recorded like any other entry.  The caller guarantees that every
+ * pointer a recorded entry received stays valid and means the same buffer for the life of the plan (lm_net_amd
+ * allocates them from one arena per plan).  Thread model: a plan is recorded and run by one thread at a time.
+ * ------------------------------------------------------------------------------------------ */
+typedef void* lmn_plan_t;
+int lmn_stream_wait(lmn_stream_t waiter, lmn_stream_t waited);
+/* numbered events (64 slots): mark a point on one stream, make another stream wait for exactly that point (a fork
+ * that is joined later, after more work has been queued behind the point); recorded by plans like any entry        */
+int lmn_event_record(int slot, lmn_stream_t stream);
+int lmn_event_wait(int slot, lmn_stream_t stream);
+lmn_plan_t lmn_plan_create(void);
+int lmn_plan_destroy(lmn_plan_t plan);
+int lmn_plan_record_begin(lmn_plan_t plan);              /* start / resume recording on this thread                  */
+int64_t lmn_plan_record_end(lmn_plan_t plan, int seal);  /* pause (seal=0) or finish (seal=1); returns #ops recorded  */
+int64_t lmn_plan_size(lmn_plan_t plan);
+int lmn_plan_run(lmn_plan_t plan, int64_t lo, int64_t hi); /* re-issue ops [lo, hi); hi < 0 = to the end              */
+
+/* ------------------------------------------------------------------------------------------
+ * In-library kernel timer (measurement): HIP events on the launch stream around every kernel launch whose
+ * name contains one of the '|'-separated substrings of `filter` (NULL / "" = all kernels).  lmn_prof_end stops the timer,
+ * synchronises the device and writes one line per kernel name: "name\tlaunches\ttotal_us\tflops\tbytes\n", where
+ * flops / bytes are the ALGORITHMIC costs (layer shapes; SURVEY 8d convention) the conv / depthwise / attention entries
+ * declare per launch.  Returns the number of bytes needed for the full report.                                        */
+int lmn_prof_begin(const char* filter);
+int64_t lmn_prof_end(char* out, int64_t cap);
 
 #ifdef __cplusplus
 }

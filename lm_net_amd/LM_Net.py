@@ -10,7 +10,7 @@ import torch
 import torch.nn as nn
 
 from . import hip
-from .engine import Ctx, Engine, GradSlot
+from .engine import Arena, Ctx, Engine, GradSlot, _E, _Z
 from .hip import V
 from .modules import (GFT, NUM_HEADS, M2Skip, M3Skip, NeighborhoodTransformer, PyramidPool, ReparamConv, _conv, stage)
 
@@ -79,6 +79,38 @@ class _LMNetGraphFunction(torch.autograd.Function):
         return (None, None, None) + tuple(grads)
 
 
+class _PlannedStep:
+    """One recorded pass pair (forward, backward) for a fixed input shape and mode: two lmn plans over one arena."""
+
+    def __init__(self):
+        self.warm = 0
+        self.need_fwd = self.need_bwd = 0   # floats of arena a pass needs (measured on the eager warm-up steps)
+        self.arena = None
+        self.fwd = self.bwd = None
+        self.x = self.out = self.dlogits = None
+        self.cx = None
+        self.flat = None           # static flat gradient buffer
+        self.G = None
+        self.sizes = None
+        self.shapes = None
+        self.marks = []            # backward: (op index, block name, producer streams) at every finished gradient block
+        self.pending = False       # a forward whose backward has not run yet
+
+
+class _LMNetPlanFunction(torch.autograd.Function):
+    """The recorded step as an autograd node: forward / backward = one lmn_plan_run each (per gradient bucket when a
+    data-parallel reducer is attached)."""
+
+    @staticmethod
+    def forward(ctx, x, model, ps, *params):
+        ctx.model, ctx.ps = model, ps
+        return model._plan_forward(ps, x)
+
+    @staticmethod
+    def backward(ctx, dlogits):
+        return (None, None, None) + tuple(ctx.model._plan_backward(ctx.ps, dlogits))
+
+
 class LM_Net(nn.Module):
     def __init__(self, channel, n_classes=2, filters=[12, 24, 48, 96, 192], deep_supervision=False):
         super().__init__()
@@ -112,11 +144,15 @@ class LM_Net(nn.Module):
         self._engine = Engine(self)
         self._grad_flat = None
         self._grad_layout = None
+        self._recording = None
         self._save_tape = False
         self._keep_taps = False
         self._taps = None
         self.use_graphs = False   # capture the training step into hipGraphs (see enable_graphs)
         self._graphs = {}
+        self.use_plans = False    # replay recorded C-side schedules (see enable_plans)
+        self._plans = {}
+        self._head_bias4 = None
         # data-parallel hooks (ddp.py): begin(flat) at the start of backward, ready(lo, hi) when the
         # flat-gradient slice [lo,hi) has been enqueued, finish() at the end of backward
         self.grad_begin_hook = None
@@ -130,6 +166,7 @@ class LM_Net(nn.Module):
                 m.switch_to_deploy()
         self._grad_layout = None
         self._graphs = {}
+        self._plans = {}
         self.__dict__["_param_cache"] = None
         self.__dict__["_bn_cache"] = None
 
@@ -147,6 +184,12 @@ class LM_Net(nn.Module):
             raise RuntimeError("lm_net_amd.LM_Net: parameters are on %s; call model.to('cuda')" % params[0].device)
         x = x.float().contiguous() if x.dtype != torch.float32 or not x.is_contiguous() else x
         self._save_tape = torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in params))
+        if self.use_plans and not x.requires_grad and not self._keep_taps and (self._save_tape or not torch.is_grad_enabled()):
+            ps = self._plan_for(x)
+            if ps is not None:
+                if self._save_tape:
+                    return _LMNetPlanFunction.apply(x, self, ps, *params)
+                return self._plan_forward(ps, x)
         if self.use_graphs and self.training and self._save_tape and not x.requires_grad and not self._keep_taps:
             gs = self._graph_for(x)
             if gs is not None:
@@ -156,6 +199,117 @@ class LM_Net(nn.Module):
             if out is not None:
                 return out
         return _LMNetFunction.apply(x, self, *params)
+
+    # ------------------------------------------------------------------ recorded C-side schedules (lmn_plan_*)
+    def enable_plans(self, on=True):
+        """Run every pass of a repeated input shape as ONE call into the library (include/lmnet_hip.h, lmn_plan_*): the
+        first two passes of a (shape, mode) run launch by launch and size the arena, the third is recorded while it runs,
+        later ones are `lmn_plan_run` replays -- same kernels, same four HIP streams and cross-stream events as the
+        host-launched schedule (unlike a hipGraph capture, which cannot carry the stream forks), ~2 ms of host time per
+        step instead of 16-20.  Contract while enabled: fixed parameter storage; the returned gradients are views of one
+        static buffer (as `zero_grad(set_to_none=True)` expects; a `.grad` that still aliases it is accumulated into
+        correctly); data-parallel buckets are reported between plan segments; dropout draws from a device-side counter."""
+        self.use_plans = bool(on)
+        if not on:
+            self._plans = {}
+            self._engine.seed_ctr = None if not self.use_graphs else self._engine.seed_ctr
+        return self
+
+    def _plan_for(self, x):
+        train = bool(self.training and self._save_tape)
+        key = (tuple(x.shape), x.device, self.training, self._save_tape)
+        ps = self._plans.get(key)
+        if ps is None:
+            ps = self._plans[key] = _PlannedStep()
+        if ps.fwd is not None:
+            if ps.pending and train:
+                return None            # a second forward before the backward of the first: that one runs launch by launch
+            return ps
+        ps.warm += 1
+        if ps.warm <= 2:
+            return None
+        if train and ps.need_bwd == 0:
+            return None                # no backward has been seen for this shape yet: keep warming up
+        eng = self._engine
+        if eng.seed_ctr is None:
+            eng.seed_ctr = torch.zeros(1, device=x.device, dtype=torch.int32)
+        return ps
+
+    def _plan_forward(self, ps, x):
+        eng = self._engine
+        if ps.fwd is None:                          # record while running
+            train = bool(self.training and self._save_tape)
+            L = self._ensure_grad_layout()
+            need = ps.need_fwd + (ps.need_bwd + L["total"] if train else 0)
+            ps.arena = Arena(int(need * 1.02) + (1 << 16), x.device)
+            ps.x = ps.arena.alloc(tuple(x.shape))
+            ps.x.copy_(x)
+            ps.cx = Ctx() if self._save_tape else None
+            ps.fwd = hip.Plan()
+            eng.arena, eng.planning = ps.arena, True
+            try:
+                ps.fwd.record_begin()
+                ps.out = self._forward_impl(ps.x, ps.cx)
+            finally:
+                ps.fwd.record_end()
+                eng.arena, eng.planning = None, False
+            ps.keep = [eng.packs_fwd.table, eng.packs_bwd.table]     # device job tables the recorded pack launches read
+        else:
+            ps.x.copy_(x)
+            self._step_bookkeeping()
+            if ps.cx is not None:
+                ps.cx.training = self.training
+            ps.fwd.run()
+        ps.pending = ps.cx is not None
+        return ps.out.clone()
+
+    def _plan_backward(self, ps, dlogits):
+        eng = self._engine
+        L = self._ensure_grad_layout()
+        params = self._param_list()
+        p0 = params[0]
+        acc = ps.flat is not None and p0.grad is not None and \
+            ps.flat.data_ptr() <= p0.grad.data_ptr() < ps.flat.data_ptr() + 4 * ps.flat.numel()
+        old = ps.flat.clone() if acc else None      # a .grad still aliases the static buffer: keep its values
+        if ps.bwd is None:                          # record while running
+            ps.dlogits = ps.arena.alloc(tuple(dlogits.shape))
+            ps.dlogits.copy_(dlogits)
+            ps.flat = ps.arena.alloc((L["total"],))
+            ps.G = {}
+            for p in L["order"]:
+                a, b = L["offs"][id(p)]
+                ps.G[p] = ps.flat[a:b].view(p.shape)
+            ps.sizes = [(L["offs"][id(p)][0], p.numel(), tuple(p.shape)) for p in params]
+            ps.bwd = hip.Plan()
+            ps.marks = []
+            eng.arena, eng.planning = ps.arena, True
+            try:
+                ps.bwd.record_begin()
+                self._backward_impl(ps.cx, ps.dlogits, False, plan=ps)
+            finally:
+                ps.bwd.record_end()
+                eng.arena, eng.planning = None, False
+            ps.keep += [eng.packs_fwd.table, eng.packs_bwd.table]
+        else:
+            ps.dlogits.copy_(dlogits)
+            self._grad_flat = ps.flat
+            if self.grad_begin_hook is not None:
+                self.grad_begin_hook(ps.flat)
+            if self.grad_ready_hook is None:
+                ps.bwd.run()
+            else:
+                lo = 0
+                for idx, name, streams in ps.marks:
+                    ps.bwd.run(lo, idx)
+                    lo = idx
+                    self.grad_ready_hook(*L["blocks"][name], streams)
+                ps.bwd.run(lo, -1)
+            if self.grad_finish_hook is not None:
+                self.grad_finish_hook()
+        ps.pending = False
+        src = ps.flat if old is None else old
+        # fresh views every time: AccumulateGrad then takes them as .grad without a copy
+        return [src[a:a + n].view(shp) for a, n, shp in ps.sizes]
 
     # ------------------------------------------------------------------ hipGraph capture of the training step
     def enable_graphs(self, on=True):
@@ -245,30 +399,47 @@ class LM_Net(nn.Module):
         return c
 
     # ------------------------------------------------------------------ forward schedule (core/LM_Net.py:95-123)
-    def _forward_impl(self, x, cx):
+    def _step_bookkeeping(self):
         eng = self._engine
-        eng.training = self.training
         if self.training:
             eng.step += 1
             if eng.seed_ctr is not None:
                 eng.seed_ctr += 0x2545F49          # odd increment: a fresh dropout stream per step, also under replay
             self._bump_num_batches_tracked()
-        eng.begin_pass(False, x.device)
-        try:
-            return self._forward_body(x, cx)
-        finally:
-            eng.end_pass()
+
+    def _forward_impl(self, x, cx):
+        eng = self._engine
+        eng.training = self.training
+        if cx is not None:
+            cx.training = self.training             # the backward of THIS pass uses the BatchNorm mode it ran in
+        self._step_bookkeeping()
+        with torch.cuda.device(x.device):
+            eng.begin_pass(False, x.device)
+            try:
+                out = self._forward_body(x, cx)
+            finally:
+                nf = eng.alloc_floats
+                eng.end_pass()
+        if self.use_plans:
+            ps = self._plans.get((tuple(x.shape), x.device, self.training, self._save_tape))
+            if ps is not None:
+                ps.need_fwd = max(ps.need_fwd, nf)
+                if cx is not None:
+                    cx.plan_key = (tuple(x.shape), x.device, self.training, self._save_tape)
+        return out
 
     def _forward_body(self, x, cx):
         eng = self._engine
         B, Cin, H, W = x.shape
         c4 = (Cin + 3) // 4 * 4
-        xin = torch.empty(B, H, W, c4, device=x.device, dtype=torch.float32)
+        dev = x.device
+        xin = _E(dev, B, H, W, c4)
         hip.nchw_to_nhwc(x, xin)
         f = self.filters
-        main = torch.cuda.current_stream(x.device)
+        main = torch.cuda.current_stream(dev)
         fork = eng.branch_overlap and not eng.capturing
-        bst = eng.branch_stream(x.device) if fork else None
+        bst = eng.branch_stream(dev) if fork else None
+        slots = {2: 0, 4: 1, 6: 2, 8: 3}     # lmn event slot of each chain (by dropout tag)
 
         def chain(skip, nat, xs_in, tag):
             """Skip fuser + neighborhood-attention block of one level: needs only encoder outputs and is needed
@@ -278,35 +449,35 @@ class LM_Net(nn.Module):
             if not fork:
                 xs = eng.skip_fwd(skip, xs_in, cx)
                 return eng.nat_fwd(nat, xs, cx, tag=tag), None, xs
-            bst.wait_stream(main)
+            hip.stream_wait(bst, main)
             with eng.on_stream(bst):
                 xs = eng.skip_fwd(skip, xs_in, cx)
                 out = eng.nat_fwd(nat, xs, cx, tag=tag)
-            ev = torch.cuda.Event()
-            ev.record(bst)
-            return out, ev, xs
+            hip.event_record(slots[tag], bst)          # the point the decoder stage of this level waits for
+            return out, slots[tag], xs
 
         def need(res):
             out, ev, _ = res
             if ev is not None:
-                main.wait_event(ev)
-                out.record_stream(main)
+                hip.event_wait(ev, main)
+                if eng.arena is None:
+                    out.record_stream(main)
             return out
 
         x1 = eng.stage_fwd(self.conv1, xin, cx)
-        xd1 = torch.empty(B, H // 2, W // 2, f[1], device=x.device); eng.conv3_fwd(self.down1[0], x1, xd1, s=2)
+        xd1 = _E(dev, B, H // 2, W // 2, f[1]); eng.conv3_fwd(self.down1[0], x1, xd1, s=2)
         x2 = eng.stage_fwd(self.conv2, xd1, cx)
         r4 = chain(self.skip4, self.natt4, (x1, x2), 8) if fork else None
-        xd2 = torch.empty(B, H // 4, W // 4, f[2], device=x.device); eng.conv3_fwd(self.down2[0], x2, xd2, s=2)
+        xd2 = _E(dev, B, H // 4, W // 4, f[2]); eng.conv3_fwd(self.down2[0], x2, xd2, s=2)
         x3 = eng.stage_fwd(self.conv3, xd2, cx)
         r3 = chain(self.skip3, self.natt3, (x1, x2, x3), 6) if fork else None
-        xd3 = torch.empty(B, H // 8, W // 8, f[3], device=x.device); eng.conv3_fwd(self.down3[0], x3, xd3, s=2)
+        xd3 = _E(dev, B, H // 8, W // 8, f[3]); eng.conv3_fwd(self.down3[0], x3, xd3, s=2)
         x4 = eng.stage_fwd(self.conv4, xd3, cx)
         r1 = chain(self.skip1, self.natt1, (x3, x4), 2) if fork else None
         r2 = chain(self.skip2, self.natt2, (x2, x3, x4), 4) if fork else None
         # PyramidPool: mean-pool x1..x4 onto the 1/16 grid, down4 writes x_down4 straight into its slice
         h, w = H // 16, W // 16
-        catp = torch.empty(B, h, w, sum(f), device=x.device)
+        catp = _E(dev, B, h, w, sum(f))
         off = 0
         for t, fac in ((x1, 16), (x2, 8), (x3, 4), (x4, 2)):
             hip.avgpool_fwd(t, V(catp, off, t.shape[-1]), fac)
@@ -327,28 +498,30 @@ class LM_Net(nn.Module):
         x19 = need(r4)
         x9 = eng.stage_fwd(self.dconv4, eng.up_fwd(self.up4, x8, x19, cx), cx)
         if fork:
-            main.wait_stream(bst)
-        # segmentation head: rows padded to a multiple of 4, then NHWC -> NCHW
+            hip.stream_wait(main, bst)
+        # segmentation head: computed on rows padded to a multiple of 4 (the packed weight's extra rows are zeros, the
+        # bias lives in a persistent 4-vector), then NHWC -> NCHW keeps the first n_classes channels
         ncp = (self.n_classes + 3) // 4 * 4
-        wh, bh = self._head_padded(ncp)
-        o4 = torch.empty(B, H, W, ncp, device=x.device)
-        eng.conv([x9], wh, bh, o4, Hin=H, Win=W)
-        logits = torch.empty(B, self.n_classes, H, W, device=x.device)
+        bh = self._head_bias(ncp)
+        o4 = _E(dev, B, H, W, ncp)
+        eng.conv([x9], self.output_layer.weight, bh, o4, Hin=H, Win=W, cout=ncp)
+        logits = _E(dev, B, self.n_classes, H, W)
         hip.nhwc_to_nchw(o4, logits)
         if cx is not None:
             cx.t["act"] = dict(xin=xin, x1=x1, x2=x2, x3=x3, x4=x4, xd1=xd1, xd2=xd2, xd3=xd3, catp=catp, x5=x5, x6=x6,
-                               x7=x7, x8=x8, x9=x9, wh=wh, shape=(B, H, W))
+                               x7=x7, x8=x8, x9=x9, ncp=ncp, shape=(B, H, W))
         self._taps = dict(x1=x1, x2=x2, x3=x3, x4=x4, x5=x5, xs1=r1[2], xs2=r2[2], xs3=r3[2], xs4=r4[2], x46=x46, x37=x37,
                           x28=x28, x19=x19, x6=x6, x7=x7, x8=x8, x9=x9) if self._keep_taps else None
         return logits
 
-    def _head_padded(self, ncp):
-        w, b = self.output_layer.weight, self.output_layer.bias
-        wp = torch.zeros(ncp, w.shape[1], device=w.device)
-        bp = torch.zeros(ncp, device=w.device)
-        wp[:w.shape[0]].copy_(w.detach().view(w.shape[0], -1))
-        bp[:w.shape[0]].copy_(b.detach())
-        return wp, bp
+    def _head_bias(self, ncp):
+        """output_layer.bias in a persistent zero-padded [ncp] vector, refreshed by one small copy per pass."""
+        b = self.output_layer.bias
+        hb = self._head_bias4
+        if hb is None or hb.device != b.device or hb.numel() != ncp:
+            hb = self._head_bias4 = torch.zeros(ncp, device=b.device, dtype=torch.float32)
+        hip.copy2d(b, hb, 1, self.n_classes, self.n_classes, ncp)
+        return hb
 
     def _bump_num_batches_tracked(self):
         """All 84 `num_batches_tracked` buffers are views of ONE int64 tensor: one increment per step."""
@@ -407,30 +580,48 @@ class LM_Net(nn.Module):
         return flat, G
 
     def _done(self, name):
-        if self.grad_ready_hook is not None:
+        plan = self._recording
+        if self.grad_ready_hook is not None or plan is not None:
             # the block's weight gradients run on the side stream of the current stream: the collective waits for
             # that stream, the compute chain does not (it joins once, at the end of backward)
             ent = self._engine.sides.get(torch.cuda.current_stream(self._grad_flat.device).cuda_stream) \
                 if self._grad_flat.is_cuda else None
-            self.grad_ready_hook(*self._grad_layout["blocks"][name], [ent[0]] if ent is not None else [])
+            streams = [ent[0]] if ent is not None else []
+            if plan is not None:                     # replays call the hook between plan segments
+                plan.marks.append((plan.bwd.size(), name, streams))
+            if self.grad_ready_hook is not None:
+                self.grad_ready_hook(*self._grad_layout["blocks"][name], streams)
 
     # ------------------------------------------------------------------ backward schedule
-    def _backward_impl(self, cx, dlogits, need_dx):
+    def _backward_impl(self, cx, dlogits, need_dx, plan=None):
         if cx is None:
             raise RuntimeError("backward called on a forward pass that saved no state")
         eng = self._engine
-        flat, G = self._new_grads()
-        self._grad_flat = flat
-        if self.grad_begin_hook is not None:
-            self.grad_begin_hook(flat)
-        eng.G = G
-        eng.begin_pass(True, dlogits.device)
-        try:
-            dx = self._backward_body(cx, dlogits, need_dx, G)
-            eng.join_side(dlogits.device)
-        finally:
-            eng.end_pass()
-            eng.G = None
+        eng.training = getattr(cx, "training", eng.training)     # the mode of the forward this tape belongs to
+        with torch.cuda.device(dlogits.device):
+            if plan is None:
+                flat, G = self._new_grads()
+            else:
+                flat, G = plan.flat, plan.G
+            self._grad_flat = flat
+            self._recording = plan
+            if self.grad_begin_hook is not None:
+                self.grad_begin_hook(flat)
+            eng.G = G
+            eng.begin_pass(True, dlogits.device)
+            try:
+                if plan is not None:
+                    hip.fill(flat, 0.0)                          # recorded: every replay starts from zero gradients
+                dx = self._backward_body(cx, dlogits, need_dx, G)
+                eng.join_side(dlogits.device)
+            finally:
+                nb = eng.alloc_floats
+                eng.end_pass()
+                eng.G = None
+                self._recording = None
+        key = getattr(cx, "plan_key", None)
+        if key is not None and key in self._plans:
+            self._plans[key].need_bwd = max(self._plans[key].need_bwd, nb + dlogits.numel() + 64)
         if self.grad_finish_hook is not None:
             self.grad_finish_hook()
         return dx, [G[p] for p in self._param_list()]
@@ -442,15 +633,15 @@ class LM_Net(nn.Module):
         f = self.filters
         dev = dlogits.device
         # head
-        ncp = A["wh"].shape[0]
-        dy4 = torch.empty(B, H, W, ncp, device=dev)
+        ncp, c0 = A["ncp"], f[0]
+        dy4 = _E(dev, B, H, W, ncp)
         hip.nchw_to_nhwc(dlogits, dy4)
-        dWh, dbh = torch.zeros_like(A["wh"]), torch.zeros(ncp, device=dev)
+        dWh, dbh = _Z(dev, ncp, c0), _Z(dev, ncp)
         eng.wgrad([A["x9"]], dy4, None, None, Hin=H, Win=W, dW=dWh, db=dbh)
-        G[self.output_layer.weight].copy_(dWh[:self.n_classes].view_as(self.output_layer.weight))
-        G[self.output_layer.bias].copy_(dbh[:self.n_classes])
-        dx9 = torch.empty_like(A["x9"])
-        eng.conv_T(dy4, A["wh"], dx9, Hin=H, Win=W)
+        hip.copy2d(dWh, G[self.output_layer.weight], self.n_classes, c0, c0, c0)      # drop the padding rows
+        hip.copy2d(dbh, G[self.output_layer.bias], 1, self.n_classes, ncp, self.n_classes)
+        dx9 = _E(dev, *A["x9"].shape)
+        eng.conv_T(dy4, self.output_layer.weight, dx9, Hin=H, Win=W)
         self._done("output_layer")
         gacc = {id(A[k]): GradSlot() for k in ("x1", "x2", "x3", "x4")}
         main = torch.cuda.current_stream(dev)
@@ -463,8 +654,9 @@ class LM_Net(nn.Module):
             the main stream continues with the coarser decoder stages (few of those kernels fill 256 CUs alone)."""
             if not fork:
                 return nat, skip, dt
-            bst.wait_stream(main)
-            dt.record_stream(bst)
+            hip.stream_wait(bst, main)
+            if eng.arena is None:
+                dt.record_stream(bst)
             with eng.on_stream(bst):
                 dxs = eng.nat_bwd(nat, dt, cx)
                 eng.skip_bwd(skip, dxs, cx, gacc)
@@ -486,10 +678,11 @@ class LM_Net(nn.Module):
         dx5 = eng.up_bwd(self.up1, dt1, cx, A["x5"].shape); self._done("up1")
         if fork:
             dcat = eng.gft_bwd(self.gft, dx5, cx)        # independent of the branch chains: before the join
-            main.wait_stream(bst)                        # join: the encoder gradients in gacc are complete
-            for slot in gacc.values():
-                if slot.g is not None:
-                    slot.g.record_stream(main)
+            hip.stream_wait(main, bst)                   # join: the encoder gradients in gacc are complete
+            if eng.arena is None:
+                for slot in gacc.values():
+                    if slot.g is not None:
+                        slot.g.record_stream(main)
             for name in ("natt4", "natt3", "natt2", "natt1", "skip4", "skip3", "skip2", "skip1"):
                 self._done(name)
         else:
@@ -521,6 +714,6 @@ class LM_Net(nn.Module):
         dxin = eng.stage_bwd(self.conv1, g1, cx, need_dx=need_dx); self._done("conv1")
         dx = None
         if need_dx:
-            dx = torch.empty(B, self.channel, H, W, device=dev)
+            dx = _E(dev, B, self.channel, H, W)
             hip.nhwc_to_nchw(dxin, dx)
         return dx

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <string.h>
 
 #include "../../include/lmnet_hip.h"
 
@@ -28,6 +29,35 @@ static inline int lmn_launch_status(const char* what) {
 }
 
 static inline int lmn_cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+
+// ---------------------------------------------------------------- runtime hooks (runtime.hip)
+// (1) in-library kernel timer (lmn_prof_begin / lmn_prof_end): HIP events around every kernel launch whose name matches
+//     the active filter, recorded on the stream the kernel is launched on; bench.py reads the dominant kernel's average
+//     duration from it inside the timed region.  Off: one predictable branch per launch.
+// (2) plan recorder (lmn_plan_*): while a plan is recording, every C-ABI entry also appends a closure of itself
+//     (arguments by value) to the plan; lmn_plan_run re-issues the recorded entries in order -- one FFI crossing per
+//     pass instead of one per kernel.
+extern int g_lmn_prof_on;
+bool lmn_prof_start(const char* kernel, hipStream_t st);
+void lmn_prof_stop(hipStream_t st);
+void lmn_prof_cost(double flops, double bytes);  // algorithmic cost of the NEXT launch of this thread (consumed by it)
+#define LMN_LAUNCH(kern, grid, block, shmem, stream, ...)                        \
+  do {                                                                           \
+    const bool _lmn_pf = g_lmn_prof_on && lmn_prof_start(#kern, (stream));       \
+    hipLaunchKernelGGL(kern, grid, block, shmem, stream, __VA_ARGS__);           \
+    if (_lmn_pf) lmn_prof_stop((stream));                                        \
+  } while (0)
+
+#ifdef __cplusplus
+#include <functional>
+extern thread_local void* g_lmn_rec;  // plan being recorded by this thread, or NULL
+void lmn_rec_push(std::function<int()>&& f);
+// LMN_REC(call-expression using only by-value locals): record the entry, then fall through and execute it
+#define LMN_REC(...)                                                    \
+  do {                                                                  \
+    if (g_lmn_rec) lmn_rec_push([=]() -> int { return __VA_ARGS__; });  \
+  } while (0)
+#endif
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 

@@ -615,11 +615,13 @@ __device__ __forceinline__ float pack_element(const float* __restrict__ w, const
   const int kk = (kb - kboff[s]) * 16 + j * 4 + (lane >> 4);  // reduction index inside the source
   const int row = ct * 16 + (lane & 15);
   float v = 0.f;
+  // (a source / row count may be the weight's padded to a multiple of 4 -- the RGB input travels as NHWC4, the 2-class
+  //  head is computed on 4 rows: elements past the real weight are zeros)
   if (row < nrows && kk < g.cs[s]) {
     if (!g.transposed) {
-      v = w[((int64_t)row * g.Cin + cbase[s] + kk) * g.taps + tap];
+      if (row < g.Cout && cbase[s] + kk < g.Cin) v = w[((int64_t)row * g.Cin + cbase[s] + kk) * g.taps + tap];
     } else {  // rows = forward input channels, reduction = forward output channels
-      v = w[((int64_t)kk * g.Cin + g.row_off + row) * g.taps + tap];
+      if (kk < g.Cout && g.row_off + row < g.Cin) v = w[((int64_t)kk * g.Cin + g.row_off + row) * g.taps + tap];
     }
   }
   return v;
@@ -1223,35 +1225,46 @@ int64_t lmn_conv_pack_size(int ksize, int Cout, int nsrc, const int32_t* c) {
 int lmn_conv_pack(const float* w, float* wpack, int ksize, int Cout, int Cin, int nsrc, const int32_t* c,
                   int transposed, int row_off, int rows, lmn_stream_t stream) {
   LMN_REQUIRE(w && wpack && c, "conv_pack: null pointer");
+  if (g_lmn_rec && nsrc >= 1 && nsrc <= 3) {
+    int32_t cc[3] = {c[0], nsrc > 1 ? c[1] : 0, nsrc > 2 ? c[2] : 0};
+    const int32_t c0 = cc[0], c1 = cc[1], c2 = cc[2];
+    lmn_rec_push([=]() -> int { const int32_t ca[3] = {c0, c1, c2}; return lmn_conv_pack(w, wpack, ksize, Cout, Cin, nsrc, ca, transposed, row_off, rows, stream); });
+  }
   LMN_REQUIRE(ksize == 1 || ksize == 3, "conv_pack: ksize %d", ksize);
   LMN_REQUIRE(nsrc >= 1 && nsrc <= 3, "conv_pack: nsrc %d", nsrc);
   int csum = 0;
   for (int s = 0; s < nsrc; ++s) csum += c[s];
   if (!transposed) {
-    LMN_REQUIRE(csum == Cin, "conv_pack: sources sum to %d channels, weight has %d", csum, Cin);
+    LMN_REQUIRE(csum == Cin || (nsrc == 1 && csum > Cin && csum < Cin + 4),
+                "conv_pack: sources sum to %d channels, weight has %d", csum, Cin);
   } else {
-    LMN_REQUIRE(nsrc == 1 && c[0] == Cout, "conv_pack(transposed): one source of Cout=%d channels expected", Cout);
-    LMN_REQUIRE(row_off >= 0 && rows > 0 && row_off + rows <= Cin, "conv_pack(transposed): rows [%d,+%d) of %d", row_off, rows, Cin);
+    LMN_REQUIRE(nsrc == 1 && c[0] >= Cout && c[0] < Cout + 4, "conv_pack(transposed): one source of Cout=%d channels expected", Cout);
+    LMN_REQUIRE(row_off >= 0 && rows > 0 && row_off + rows < Cin + 4, "conv_pack(transposed): rows [%d,+%d) of %d", row_off, rows, Cin);
   }
-  const int nrows = transposed ? rows : Cout;
+  const int nrows = transposed ? rows : (Cout + 3) / 4 * 4;
   const int64_t total = lmn_conv_pack_size(ksize, nrows, nsrc, c);
   const int blocks = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
   PackGeom g;
   g.taps = ksize * ksize; g.Cout = Cout; g.Cin = Cin; g.nsrc = nsrc;
   g.cs[0] = c[0]; g.cs[1] = nsrc > 1 ? c[1] : 0; g.cs[2] = nsrc > 2 ? c[2] : 0;
   g.transposed = transposed; g.row_off = row_off; g.rows = rows;
-  hipLaunchKernelGGL(conv_pack_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, wpack, g, total);
+  LMN_LAUNCH(conv_pack_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, wpack, g, total);
   return lmn_launch_status("conv_pack");
 }
 
 int lmn_conv_pack_batch(const lmn_pack_job_t* jobs_dev, int njobs, int64_t total_blocks, lmn_stream_t stream) {
+  LMN_REC(lmn_conv_pack_batch(jobs_dev, njobs, total_blocks, stream));
   LMN_REQUIRE(jobs_dev && njobs > 0 && total_blocks > 0 && total_blocks < (1LL << 31), "conv_pack_batch: bad job table");
-  hipLaunchKernelGGL(conv_pack_batch_kernel, dim3((unsigned)total_blocks), dim3(256), 0, (hipStream_t)stream, jobs_dev, njobs);
+  LMN_LAUNCH(conv_pack_batch_kernel, dim3((unsigned)total_blocks), dim3(256), 0, (hipStream_t)stream, jobs_dev, njobs);
   return lmn_launch_status("conv_pack_batch");
 }
 
 int lmn_conv_fwd(const lmn_conv_args_t* args, lmn_stream_t stream) {
   LMN_REQUIRE(args, "conv_fwd: null args");
+  if (g_lmn_rec) {
+    const lmn_conv_args_t copy = *args;
+    lmn_rec_push([copy, stream]() -> int { return lmn_conv_fwd(&copy, stream); });
+  }
   const lmn_conv_args_t& A = *args;
   LMN_REQUIRE(A.ksize == 1 || A.ksize == 3, "conv_fwd: ksize %d", A.ksize);
   LMN_REQUIRE(A.stride == 1 || A.stride == 2, "conv_fwd: stride %d", A.stride);
@@ -1308,6 +1321,16 @@ int lmn_conv_fwd(const lmn_conv_args_t* args, lmn_stream_t stream) {
   } else {
     LMN_REQUIRE(A.Hin == (A.Hout + 2 * (A.ksize / 2) - A.ksize) / A.stride + 1 && A.Win == (A.Wout + 2 * (A.ksize / 2) - A.ksize) / A.stride + 1,
                 "conv_fwd(T): dy %dx%d inconsistent with dx %dx%d k%d s%d", A.Hin, A.Win, A.Hout, A.Wout, A.ksize, A.stride);
+  }
+  if (g_lmn_prof_on) {  // algorithmic cost of this launch (each HBM tensor once, MACs of the layer shape)
+    int64_t cin = 0;
+    for (int s = 0; s < A.nsrc; ++s) cin += A.src[s].C;
+    const double opix = (double)A.B * A.Hout * A.Wout, ipix = (double)A.B * A.Hin * A.Win;
+    const double macs = (A.transposed ? ipix : opix) * (double)cin * A.Cout * A.ksize * A.ksize;
+    double by = ipix * cin + (A.out ? opix * A.Cout : 0.0);
+    if (A.aux) by += opix * A.Cout;
+    if (A.residual) by += opix * A.Cout;
+    lmn_prof_cost(2.0 * macs, 4.0 * by);
   }
   P.NCTT = (A.Cout + 15) / 16;
   P.ncls = (A.transposed && A.stride == 2) ? 4 : 1;
@@ -1428,12 +1451,12 @@ int lmn_conv_fwd(const lmn_conv_args_t* args, lmn_stream_t stream) {
 #define LMN_CM(TT, NN)                                                                                   \
   do {                                                                                                   \
     switch ((TT) == 1 ? ek : (ek > 2 ? 1 : ek)) {                                                        \
-      case 0: hipLaunchKernelGGL((conv_tileM_kernel<TT, NN, 0>), mgrid, dim3(256), msh, st, T); break;   \
-      case 2: hipLaunchKernelGGL((conv_tileM_kernel<TT, NN, 2>), mgrid, dim3(256), msh, st, T); break;   \
-      case 3: hipLaunchKernelGGL((conv_tileM_kernel<1, NN, 3>), mgrid, dim3(256), msh, st, T); break;    \
-      case 4: hipLaunchKernelGGL((conv_tileM_kernel<1, NN, 4>), mgrid, dim3(256), msh, st, T); break;    \
-      case 5: hipLaunchKernelGGL((conv_tileM_kernel<1, NN, 5>), mgrid, dim3(256), msh, st, T); break;    \
-      default: hipLaunchKernelGGL((conv_tileM_kernel<TT, NN, 1>), mgrid, dim3(256), msh, st, T); break;  \
+      case 0: LMN_LAUNCH((conv_tileM_kernel<TT, NN, 0>), mgrid, dim3(256), msh, st, T); break;   \
+      case 2: LMN_LAUNCH((conv_tileM_kernel<TT, NN, 2>), mgrid, dim3(256), msh, st, T); break;   \
+      case 3: LMN_LAUNCH((conv_tileM_kernel<1, NN, 3>), mgrid, dim3(256), msh, st, T); break;    \
+      case 4: LMN_LAUNCH((conv_tileM_kernel<1, NN, 4>), mgrid, dim3(256), msh, st, T); break;    \
+      case 5: LMN_LAUNCH((conv_tileM_kernel<1, NN, 5>), mgrid, dim3(256), msh, st, T); break;    \
+      default: LMN_LAUNCH((conv_tileM_kernel<TT, NN, 1>), mgrid, dim3(256), msh, st, T); break;  \
     }                                                                                                    \
   } while (0)
       if (a.ksize == 1) { if (ncw == 2) LMN_CM(1, 2); else LMN_CM(1, 1); }
@@ -1445,8 +1468,8 @@ int lmn_conv_fwd(const lmn_conv_args_t* args, lmn_stream_t stream) {
       const dim3 zgrid(blocks, tchunks, 4);
 #define LMN_CZ(NN)                                                                                            \
   do {                                                                                                        \
-    if (ek == 0) hipLaunchKernelGGL((conv_tile_kernel<9, NN, 0, true>), zgrid, dim3(256), shmem, st, T);      \
-    else hipLaunchKernelGGL((conv_tile_kernel<9, NN, 1, true>), zgrid, dim3(256), shmem, st, T);              \
+    if (ek == 0) LMN_LAUNCH((conv_tile_kernel<9, NN, 0, true>), zgrid, dim3(256), shmem, st, T);      \
+    else LMN_LAUNCH((conv_tile_kernel<9, NN, 1, true>), zgrid, dim3(256), shmem, st, T);              \
   } while (0)
       switch (tnct) {
         case 1: LMN_CZ(1); break;
@@ -1460,12 +1483,12 @@ int lmn_conv_fwd(const lmn_conv_args_t* args, lmn_stream_t stream) {
 #define LMN_CT(TT, NN)                                                                                   \
   do {                                                                                                   \
     switch ((TT) == 1 ? ek : (ek > 2 ? 1 : ek)) {                                                        \
-      case 0: hipLaunchKernelGGL((conv_tile_kernel<TT, NN, 0>), grid, dim3(256), shmem, st, T); break;   \
-      case 2: hipLaunchKernelGGL((conv_tile_kernel<TT, NN, 2>), grid, dim3(256), shmem, st, T); break;   \
-      case 3: hipLaunchKernelGGL((conv_tile_kernel<1, NN, 3>), grid, dim3(256), shmem, st, T); break;    \
-      case 4: hipLaunchKernelGGL((conv_tile_kernel<1, NN, 4>), grid, dim3(256), shmem, st, T); break;    \
-      case 5: hipLaunchKernelGGL((conv_tile_kernel<1, NN, 5>), grid, dim3(256), shmem, st, T); break;    \
-      default: hipLaunchKernelGGL((conv_tile_kernel<TT, NN, 1>), grid, dim3(256), shmem, st, T); break;  \
+      case 0: LMN_LAUNCH((conv_tile_kernel<TT, NN, 0>), grid, dim3(256), shmem, st, T); break;   \
+      case 2: LMN_LAUNCH((conv_tile_kernel<TT, NN, 2>), grid, dim3(256), shmem, st, T); break;   \
+      case 3: LMN_LAUNCH((conv_tile_kernel<1, NN, 3>), grid, dim3(256), shmem, st, T); break;    \
+      case 4: LMN_LAUNCH((conv_tile_kernel<1, NN, 4>), grid, dim3(256), shmem, st, T); break;    \
+      case 5: LMN_LAUNCH((conv_tile_kernel<1, NN, 5>), grid, dim3(256), shmem, st, T); break;    \
+      default: LMN_LAUNCH((conv_tile_kernel<TT, NN, 1>), grid, dim3(256), shmem, st, T); break;  \
     }                                                                                                    \
   } while (0)
 #define LMN_CTN(TT)                                                                                      \
@@ -1497,6 +1520,10 @@ static bool wgrad_two_stage(int64_t gy, int64_t blocks, int64_t per) {
 }
 
 int lmn_conv_wgrad(const lmn_wgrad_args_t* args, lmn_stream_t stream) {
+  if (args && g_lmn_rec) {
+    const lmn_wgrad_args_t copy = *args;
+    lmn_rec_push([copy, stream]() -> int { return lmn_conv_wgrad(&copy, stream); });
+  }
   LMN_REQUIRE(args, "conv_wgrad: null args");
   const lmn_wgrad_args_t& A = *args;
   LMN_REQUIRE(A.ksize == 1 || A.ksize == 3, "conv_wgrad: ksize %d", A.ksize);
@@ -1524,6 +1551,10 @@ int lmn_conv_wgrad(const lmn_wgrad_args_t* args, lmn_stream_t stream) {
     if (A.src[s].flags & LMN_SRC_DROP) P.inv_keep_src[s] = 1.f / (1.f - A.src[s].drop_p);
   }
   P.inv_keep_dy = (A.dy_flags & LMN_SRC_DROP) ? 1.f / (1.f - A.dy_p) : 1.f;
+  if (g_lmn_prof_on) {  // algorithmic cost: MACs of the layer shape; every source and dy read once
+    const double opix = (double)A.B * A.Hout * A.Wout, ipix = (double)A.B * A.Hin * A.Win;
+    lmn_prof_cost(2.0 * opix * (double)P.Cin * A.Cout * A.ksize * A.ksize, 4.0 * (ipix * P.Cin + opix * A.Cout));
+  }
   P.NMTT = (A.Cout + 15) / 16;
   P.steps_per_img = (A.Hout * A.Wout + 3) / 4;
   LMN_REQUIRE((int64_t)A.B * P.steps_per_img < (1LL << 31), "conv_wgrad: too many pixels");
@@ -1588,11 +1619,11 @@ int lmn_conv_wgrad(const lmn_wgrad_args_t* args, lmn_stream_t stream) {
   do {                                                                                                              \
     if (shmem > 64 * 1024)                                                                                          \
       (void)hipFuncSetAttribute((const void*)wgrad_lds_kernel<T, M, N>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem); \
-    hipLaunchKernelGGL((wgrad_lds_kernel<T, M, N>), grid, dim3(256), shmem, st, P);                                 \
+    LMN_LAUNCH((wgrad_lds_kernel<T, M, N>), grid, dim3(256), shmem, st, P);                                 \
     if (P.partial) {                                                                                                \
       const int ksl = reduce_slices(blocks);                                                                        \
       const int rb = (int)((per + 1024 / ksl - 1) / (1024 / ksl));                                                  \
-      hipLaunchKernelGGL((wgrad_reduce_kernel<T, M, N>), dim3(rb, gy), dim3(1024), 0, st, P, blocks, ksl);          \
+      LMN_LAUNCH((wgrad_reduce_kernel<T, M, N>), dim3(rb, gy), dim3(1024), 0, st, P, blocks, ksl);          \
     }                                                                                                               \
   } while (0)
   if (A.ksize == 1 && A.stride == 1 && (int64_t)G.Hout * G.Wout >= 32) {
@@ -1607,11 +1638,11 @@ int lmn_conv_wgrad(const lmn_wgrad_args_t* args, lmn_stream_t stream) {
     const dim3 dgrid((unsigned)nb, gy);
 #define LMN_WD(M, N)                                                                                               \
   do {                                                                                                              \
-    hipLaunchKernelGGL((wgrad_1x1_kernel<M, N>), dgrid, dim3(256), 0, st, P);                                       \
+    LMN_LAUNCH((wgrad_1x1_kernel<M, N>), dgrid, dim3(256), 0, st, P);                                       \
     if (P.partial) {                                                                                                \
       const int ksl = reduce_slices((int)nb);                                                                       \
       const int rb = (int)((per + 1024 / ksl - 1) / (1024 / ksl));                                                  \
-      hipLaunchKernelGGL((wgrad_reduce_kernel<1, M, N>), dim3(rb, gy), dim3(1024), 0, st, P, (int)nb, ksl);         \
+      LMN_LAUNCH((wgrad_reduce_kernel<1, M, N>), dim3(rb, gy), dim3(1024), 0, st, P, (int)nb, ksl);         \
     }                                                                                                               \
   } while (0)
     switch (NMT * 8 + NNT) {

@@ -859,7 +859,8 @@ static int launch_dw_strip_stats(const float* x1, const float* pre, const float*
   const int segs = strip_segments((int64_t)B * strips * chunks, H, 4, MODE == 0 ? 3 : 2, &seg_rows);
   const int64_t nblk = (int64_t)B * strips * chunks * segs;
   if (nblk >= (1LL << 31)) return -1;
-  hipLaunchKernelGGL((dw_stats_strip_kernel<MODE>), dim3((unsigned)nblk), dim3(256), 0, st, x1, pre, u, s, dm, dpre, H, W, E,
+  if (g_lmn_prof_on) lmn_prof_cost(2.0 * 42 * (double)B * H * W * E, 4.0 * (MODE == 0 ? 1 : 4) * (double)B * H * W * E);
+  LMN_LAUNCH((dw_stats_strip_kernel<MODE>), dim3((unsigned)nblk), dim3(256), 0, st, x1, pre, u, s, dm, dpre, H, W, E,
                      w5, w3, wv, wh, stats, strips, segs, seg_rows, chunks);
   return 0;
 }
@@ -869,6 +870,7 @@ extern "C" {
 
 int lmn_dw_fwd(const float* x1, float* pre, float* gsum, int B, int H, int W, int E, const float* keff,
                const float* beff, lmn_stream_t stream) {
+  LMN_REC(lmn_dw_fwd(x1, pre, gsum, B, H, W, E, keff, beff, stream));
   LMN_REQUIRE(x1 && pre && gsum && keff && beff, "dw_fwd: null pointer");
   LMN_REQUIRE(B > 0 && H > 0 && W > 0 && E > 0 && E % 4 == 0, "dw_fwd: E=%d must be a multiple of 4", E);
   LMN_REQUIRE((int64_t)(H + 8) * W * E * 4 < (1LL << 30), "dw_fwd: one image (%d x %d x %d) must stay below 1 GiB", H, W, E);
@@ -878,7 +880,8 @@ int lmn_dw_fwd(const float* x1, float* pre, float* gsum, int B, int H, int W, in
   const int segs = strip_segments((int64_t)B * strips * chunks, H, 4, 4, &seg_rows);   // 40 KB LDS: 4 blocks per CU
   const int64_t nblk = (int64_t)B * strips * chunks * segs;
   LMN_REQUIRE(nblk < (1LL << 31), "dw_fwd: grid too large");
-  hipLaunchKernelGGL(dw_fwd_strip_kernel, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, x1, pre, gsum, H, W, E, keff,
+  if (g_lmn_prof_on) lmn_prof_cost(2.0 * 25 * (double)B * H * W * E, 4.0 * 2 * (double)B * H * W * E);
+  LMN_LAUNCH(dw_fwd_strip_kernel, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, x1, pre, gsum, H, W, E, keff,
                      beff, strips, segs, seg_rows, chunks);
   return lmn_launch_status("dw_fwd");
 }
@@ -890,12 +893,22 @@ int lmn_dw_finalize_merge(const float* stats, float count, const float* const* g
   LMN_REQUIRE(stats && gamma && beta && running_mean && running_var && eps && momentum && w5 && w3 && wv && wh && mean &&
                   rstd && A && keff && beff && E > 0 && count > 0.f,
               "dw_finalize_merge: bad argument");
+  if (g_lmn_rec) {
+    struct Arr { const float* g[4]; const float* b[4]; float* rm[4]; float* rv[4]; float eps[4]; float mom[4]; } a;
+    for (int b = 0; b < 4; ++b) {
+      a.g[b] = gamma[b]; a.b[b] = beta[b]; a.rm[b] = running_mean[b]; a.rv[b] = running_var[b];
+      a.eps[b] = eps[b]; a.mom[b] = momentum[b];
+    }
+    lmn_rec_push([=]() -> int {
+      return lmn_dw_finalize_merge(stats, count, a.g, a.b, a.rm, a.rv, a.eps, a.mom, w5, w3, wv, wh, mean, rstd, A, keff, beff, E, stream);
+    });
+  }
   DwBnPtrs bn;
   for (int b = 0; b < 4; ++b) {
     LMN_REQUIRE(gamma[b] && beta[b] && running_mean[b] && running_var[b], "dw_finalize_merge: null BatchNorm tensor %d", b);
     bn.gamma[b] = gamma[b]; bn.beta[b] = beta[b]; bn.rmean[b] = running_mean[b]; bn.rvar[b] = running_var[b];
   }
-  hipLaunchKernelGGL(dw_finalize_merge_kernel, dim3(E), dim3(64), 0, (hipStream_t)stream, stats, count, bn, eps[0], eps[1],
+  LMN_LAUNCH(dw_finalize_merge_kernel, dim3(E), dim3(64), 0, (hipStream_t)stream, stats, count, bn, eps[0], eps[1],
                      eps[2], eps[3], momentum[0], momentum[1], momentum[2], momentum[3], w5, w3, wv, wh, mean, rstd, A, keff,
                      beff, E);
   return lmn_launch_status("dw_finalize_merge");
@@ -903,14 +916,16 @@ int lmn_dw_finalize_merge(const float* stats, float count, const float* const* g
 
 int lmn_dw_merge(const float* w5, const float* w3, const float* wv, const float* wh, const float* A, const float* shift,
                  float* keff, float* beff, int E, lmn_stream_t stream) {
+  LMN_REC(lmn_dw_merge(w5, w3, wv, wh, A, shift, keff, beff, E, stream));
   LMN_REQUIRE(w5 && w3 && wv && wh && A && shift && keff && beff && E > 0, "dw_merge: bad argument");
-  hipLaunchKernelGGL(dw_merge_kernel, dim3(lmn_cdiv(E * 25, 256)), dim3(256), 0, (hipStream_t)stream, w5, w3, wv, wh,
+  LMN_LAUNCH(dw_merge_kernel, dim3(lmn_cdiv(E * 25, 256)), dim3(256), 0, (hipStream_t)stream, w5, w3, wv, wh,
                      A, shift, keff, beff, E);
   return lmn_launch_status("dw_merge");
 }
 
 int lmn_dw_stats(const float* x1, int B, int H, int W, int E, const float* w5, const float* w3, const float* wv,
                  const float* wh, float* stats, lmn_stream_t stream) {
+  LMN_REC(lmn_dw_stats(x1, B, H, W, E, w5, w3, wv, wh, stats, stream));
   LMN_REQUIRE(x1 && w5 && w3 && wv && wh && stats, "dw_stats: null pointer");
   LMN_REQUIRE(B > 0 && H > 0 && W > 0 && E > 0 && E % 4 == 0, "dw_stats: E=%d must be a multiple of 4", E);
   launch_dw_strip_stats<0>(x1, nullptr, nullptr, nullptr, nullptr, nullptr, B, H, W, E, w5, w3, wv, wh, stats, (hipStream_t)stream);
@@ -920,6 +935,7 @@ int lmn_dw_stats(const float* x1, int B, int H, int W, int E, const float* w5, c
 int lmn_dw_bwd_stats(const float* x1, const float* pre, const float* u, const float* s, const float* dm, float* dpre,
                      int B, int H, int W, int E, const float* w5, const float* w3, const float* wv, const float* wh,
                      float* bstats, lmn_stream_t stream) {
+  LMN_REC(lmn_dw_bwd_stats(x1, pre, u, s, dm, dpre, B, H, W, E, w5, w3, wv, wh, bstats, stream));
   LMN_REQUIRE(x1 && pre && u && s && dm && dpre && w5 && w3 && wv && wh && bstats, "dw_bwd_stats: null pointer");
   LMN_REQUIRE(B > 0 && H > 0 && W > 0 && E > 0 && E % 4 == 0, "dw_bwd_stats: E=%d must be a multiple of 4", E);
   launch_dw_strip_stats<1>(x1, pre, u, s, dm, dpre, B, H, W, E, w5, w3, wv, wh, bstats, (hipStream_t)stream);
@@ -929,9 +945,10 @@ int lmn_dw_bwd_stats(const float* x1, const float* pre, const float* u, const fl
 int lmn_dw_bwd_coef(const float* bstats, const float* mean, const float* rstd, const float* A, float count,
                     int batch_stats, float* cA, float* cC, float* cD, float* dg0, float* dg1, float* dg2, float* dg3,
                     float* db0, float* db1, float* db2, float* db3, int E, lmn_stream_t stream) {
+  LMN_REC(lmn_dw_bwd_coef(bstats, mean, rstd, A, count, batch_stats, cA, cC, cD, dg0, dg1, dg2, dg3, db0, db1, db2, db3, E, stream));
   LMN_REQUIRE(bstats && mean && rstd && A && cA && cC && cD && dg0 && dg1 && dg2 && dg3 && db0 && db1 && db2 && db3 && E > 0 && count > 0.f,
               "dw_bwd_coef: bad argument");
-  hipLaunchKernelGGL(dw_bwd_coef_kernel, dim3(lmn_cdiv(4 * E, 256)), dim3(256), 0, (hipStream_t)stream, bstats, mean, rstd,
+  LMN_LAUNCH(dw_bwd_coef_kernel, dim3(lmn_cdiv(4 * E, 256)), dim3(256), 0, (hipStream_t)stream, bstats, mean, rstd,
                      A, count, batch_stats, cA, cC, cD, dg0, dg1, dg2, dg3, db0, db1, db2, db3, E);
   return lmn_launch_status("dw_bwd_coef");
 }
@@ -939,6 +956,7 @@ int lmn_dw_bwd_coef(const float* bstats, const float* mean, const float* rstd, c
 int lmn_dw_bwd(const float* x1, const float* dpre, float* dx1, int B, int H, int W, int E, const float* w5,
                const float* w3, const float* wv, const float* wh, const float* cA, const float* cC, const float* cD,
                float* dw5, float* dw3, float* dwv, float* dwh, lmn_stream_t stream) {
+  LMN_REC(lmn_dw_bwd(x1, dpre, dx1, B, H, W, E, w5, w3, wv, wh, cA, cC, cD, dw5, dw3, dwv, dwh, stream));
   LMN_REQUIRE(x1 && dpre && dx1 && w5 && w3 && wv && wh && cA && cC && cD && dw5 && dw3 && dwv && dwh, "dw_bwd: null pointer");
   LMN_REQUIRE(B > 0 && H > 0 && W > 0 && E > 0 && E % 4 == 0, "dw_bwd: E=%d must be a multiple of 4", E);
   LMN_REQUIRE((int64_t)(H + 16) * W * E * 4 < (1LL << 30), "dw_bwd: one image (%d x %d x %d) must stay below 1 GiB", H, W, E);
@@ -948,7 +966,8 @@ int lmn_dw_bwd(const float* x1, const float* dpre, float* dx1, int B, int H, int
   const int segs = strip_segments((int64_t)B * strips * chunks, H, 10, 2, &seg_rows);  // 242 VGPRs: 2 blocks per CU
   const int64_t nblk = (int64_t)B * strips * chunks * segs;
   LMN_REQUIRE(nblk < (1LL << 31), "dw_bwd: grid too large");
-  hipLaunchKernelGGL(dw_bwd_strip_kernel, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, x1, dpre, dx1, B, H, W, E, w5,
+  if (g_lmn_prof_on) lmn_prof_cost(2.0 * 2 * 42 * (double)B * H * W * E, 4.0 * 3 * (double)B * H * W * E);
+  LMN_LAUNCH(dw_bwd_strip_kernel, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, x1, dpre, dx1, B, H, W, E, w5,
                      w3, wv, wh, cA, cC, cD, dw5, dw3, dwv, dwh, strips, segs, seg_rows, chunks);
   return lmn_launch_status("dw_bwd");
 }

@@ -226,21 +226,23 @@ extern "C" {
 
 int lmn_gattn_fwd(const float* qkv, float* out, float* lse, int B, int N, int heads, int hd, float scale,
                   lmn_stream_t stream) {
+  LMN_REC(lmn_gattn_fwd(qkv, out, lse, B, N, heads, hd, scale, stream));
   LMN_REQUIRE(qkv && out && lse && B > 0 && N > 0 && heads > 0, "gattn_fwd: bad argument");
   LMN_REQUIRE(hd >= 1 && hd <= GA_D, "gattn_fwd: head_dim %d > %d", hd, GA_D);
   GaGeom g{B, N, heads, hd, heads * hd, scale};
-  hipLaunchKernelGGL(gattn_fwd_kernel, dim3(lmn_cdiv(N, GA_ROWS), heads, B), dim3(256), 0, (hipStream_t)stream, qkv, out, lse, g);
+  LMN_LAUNCH(gattn_fwd_kernel, dim3(lmn_cdiv(N, GA_ROWS), heads, B), dim3(256), 0, (hipStream_t)stream, qkv, out, lse, g);
   return lmn_launch_status("gattn_fwd");
 }
 
 int lmn_gattn_bwd(const float* qkv, const float* out, const float* dout, const float* lse, float* dqkv, float* delta,
                   int B, int N, int heads, int hd, float scale, lmn_stream_t stream) {
+  LMN_REC(lmn_gattn_bwd(qkv, out, dout, lse, dqkv, delta, B, N, heads, hd, scale, stream));
   LMN_REQUIRE(qkv && out && dout && lse && dqkv && delta && B > 0 && N > 0 && heads > 0, "gattn_bwd: bad argument");
   LMN_REQUIRE(hd >= 1 && hd <= GA_D, "gattn_bwd: head_dim %d > %d", hd, GA_D);
   GaGeom g{B, N, heads, hd, heads * hd, scale};
   const dim3 grid(lmn_cdiv(N, GA_ROWS), heads, B);
-  hipLaunchKernelGGL(gattn_bwd_q_kernel, grid, dim3(256), 0, (hipStream_t)stream, qkv, out, dout, lse, dqkv, delta, g);
-  hipLaunchKernelGGL(gattn_bwd_kv_kernel, grid, dim3(256), 0, (hipStream_t)stream, qkv, dout, lse, delta, dqkv, g);
+  LMN_LAUNCH(gattn_bwd_q_kernel, grid, dim3(256), 0, (hipStream_t)stream, qkv, out, dout, lse, dqkv, delta, g);
+  LMN_LAUNCH(gattn_bwd_kv_kernel, grid, dim3(256), 0, (hipStream_t)stream, qkv, dout, lse, delta, dqkv, g);
   return lmn_launch_status("gattn_bwd");
 }
 

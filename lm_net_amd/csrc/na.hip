@@ -614,6 +614,7 @@ extern "C" {
 
 int lmn_na_fwd(const float* qkv, const float* rpb, float* out, int B, int H, int W, int heads, int hd, float scale,
                lmn_stream_t stream) {
+  LMN_REC(lmn_na_fwd(qkv, rpb, out, B, H, W, heads, hd, scale, stream));
   LMN_REQUIRE(qkv && rpb && out, "na_fwd: null pointer");
   LMN_REQUIRE(B > 0 && H >= 3 && W >= 3, "na_fwd: feature map %dx%d smaller than the 3x3 window", H, W);
   LMN_REQUIRE(hd == 1 || hd == 2 || hd == 4 || hd == 8 || hd == 16, "na_fwd: head_dim %d not in {1,2,4,8,16}", hd);
@@ -629,7 +630,8 @@ int lmn_na_fwd(const float* qkv, const float* rpb, float* out, int B, int H, int
   const int grid = tx * ty * chunks * B;
   const size_t sh = (size_t)(T + 2) * (T + 2) * 2 * cch * sizeof(float);
   hipStream_t st = (hipStream_t)stream;
-#define LMN_NAF(HDV) hipLaunchKernelGGL((na_fwd_kernel<HDV>), dim3(grid), dim3(256), sh, st, qkv, rpb, out, g, T, cch, tx, tx * ty, chunks)
+  if (g_lmn_prof_on) lmn_prof_cost(2.0 * 2 * 9 * (double)B * H * W * g.C, 4.0 * 4 * (double)B * H * W * g.C);
+#define LMN_NAF(HDV) LMN_LAUNCH((na_fwd_kernel<HDV>), dim3(grid), dim3(256), sh, st, qkv, rpb, out, g, T, cch, tx, tx * ty, chunks)
   switch (hd) {
     case 1: LMN_NAF(1); break;
     case 2: LMN_NAF(2); break;
@@ -643,6 +645,7 @@ int lmn_na_fwd(const float* qkv, const float* rpb, float* out, int B, int H, int
 
 int lmn_na_bwd(const float* qkv, const float* rpb, const float* dout, float* dqkv, float* drpb, float* stat, int B,
                int H, int W, int heads, int hd, float scale, lmn_stream_t stream) {
+  LMN_REC(lmn_na_bwd(qkv, rpb, dout, dqkv, drpb, stat, B, H, W, heads, hd, scale, stream));
   LMN_REQUIRE(qkv && rpb && dout && dqkv && drpb && stat, "na_bwd: null pointer");
   LMN_REQUIRE(B > 0 && H >= 3 && W >= 3, "na_bwd: feature map %dx%d smaller than the 3x3 window", H, W);
   LMN_REQUIRE(hd == 1 || hd == 2 || hd == 4 || hd == 8 || hd == 16, "na_bwd: head_dim %d not in {1,2,4,8,16}", hd);
@@ -652,10 +655,13 @@ int lmn_na_bwd(const float* qkv, const float* rpb, const float* dout, float* dqk
   const int gq = grid > 2048 ? 2048 : grid;
   hipStream_t st = (hipStream_t)stream;
   const size_t sh = (2 * heads * 25 + 256 * 36) * sizeof(float);
+  // algorithmic cost (7*C per pixel for the pair): query pass reads q,k,v,dout and writes dq; key pass writes dk,dv
+#define NA_COST_Q if (g_lmn_prof_on) lmn_prof_cost(2.0 * 3 * 9 * (double)B * H * W * g.C, 4.0 * 5 * (double)B * H * W * g.C)
+#define NA_COST_KV if (g_lmn_prof_on) lmn_prof_cost(2.0 * 3 * 9 * (double)B * H * W * g.C, 4.0 * 2 * (double)B * H * W * g.C)
 #define LMN_NA(HDV)                                                                                                  \
   do {                                                                                                               \
-    hipLaunchKernelGGL((na_bwd_q_kernel<HDV>), dim3(gq), dim3(256), sh, st, qkv, rpb, dout, dqkv, drpb, stat, g);    \
-    hipLaunchKernelGGL((na_bwd_kv_kernel<HDV>), dim3(grid), dim3(256), 0, st, qkv, rpb, dout, dqkv, stat, g);        \
+    NA_COST_Q; LMN_LAUNCH((na_bwd_q_kernel<HDV>), dim3(gq), dim3(256), sh, st, qkv, rpb, dout, dqkv, drpb, stat, g);    \
+    NA_COST_KV; LMN_LAUNCH((na_bwd_kv_kernel<HDV>), dim3(grid), dim3(256), 0, st, qkv, rpb, dout, dqkv, stat, g);        \
   } while (0)
   // C <= 24 (levels 0-1): query pass with the k/v window in LDS; tile sizes are whole multiples of the 256/C4 pixels a
   // block handles per iteration (15x17 = 3 x 85, 12x14 = 4 x 42)
@@ -667,16 +673,16 @@ int lmn_na_bwd(const float* qkv, const float* rpb, const float* dout, float* dqk
     const int win = (TH + 2) * (TW + 2) * 2 * g.C;                                                                   \
     const size_t tsh = (size_t)(2 * ntab + (win > 256 * 36 ? win : 256 * 36)) * sizeof(float);                       \
     const int gt = total > 1024 ? 1024 : total;                                                                      \
-    hipLaunchKernelGGL((na_bwd_q_tile_kernel<HDV>), dim3(gt), dim3(256), tsh, st, qkv, rpb, dout, dqkv, drpb, stat, g, TH, TW, \
+    NA_COST_Q; LMN_LAUNCH((na_bwd_q_tile_kernel<HDV>), dim3(gt), dim3(256), tsh, st, qkv, rpb, dout, dqkv, drpb, stat, g, TH, TW, \
                        tx, tx * ty, total);                                                                          \
     if (g.C4 == 3) {  /* key pass in LDS form only at C = 12 (measured: 208 -> 181 us; at C = 24 it is slower, 71 -> 97 us) */ \
       const int KT = 16;  /* key tile: window (KT+2)^2 x (C + 2*heads) floats of LDS */                              \
       const int kx = lmn_cdiv(W, KT), ky = lmn_cdiv(H, KT);                                                          \
       const size_t ksh = (size_t)(KT + 2) * (KT + 2) * (g.C + 2 * heads) * sizeof(float);                            \
-      hipLaunchKernelGGL((na_bwd_kv_tile_kernel<HDV>), dim3(kx * ky * B), dim3(256), ksh, st, qkv, rpb, dout, dqkv, stat, g, KT, \
+      NA_COST_KV; LMN_LAUNCH((na_bwd_kv_tile_kernel<HDV>), dim3(kx * ky * B), dim3(256), ksh, st, qkv, rpb, dout, dqkv, stat, g, KT, \
                          kx, kx * ky);                                                                               \
     } else {                                                                                                         \
-      hipLaunchKernelGGL((na_bwd_kv_kernel<HDV>), dim3(grid), dim3(256), 0, st, qkv, rpb, dout, dqkv, stat, g);      \
+      NA_COST_KV; LMN_LAUNCH((na_bwd_kv_kernel<HDV>), dim3(grid), dim3(256), 0, st, qkv, rpb, dout, dqkv, stat, g);      \
     }                                                                                                                \
   } while (0)
   const bool tiled = (g.C4 == 3 || g.C4 == 6) && hd <= 2 && heads % 2 == 0 && H >= 16 && W >= 16;

@@ -756,18 +756,35 @@ __global__ __launch_bounds__(256) void confusion_kernel(const float* __restrict_
     if (sc[i] != 0.f) atomicAdd(counts + i, sc[i]);
 }
 
+__global__ void copy2d_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t rows, int cols, int xs, int ys) {
+  const int64_t n = rows * cols;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = i / cols;
+    const int c = (int)(i - r * cols);
+    y[r * ys + c] = x[r * xs + c];
+  }
+}
+
 }  // namespace
 
 extern "C" {
 
+int lmn_copy2d(const float* x, float* y, int64_t rows, int cols, int x_stride, int y_stride, lmn_stream_t stream) {
+  LMN_REC(lmn_copy2d(x, y, rows, cols, x_stride, y_stride, stream));
+  LMN_REQUIRE(x && y && rows > 0 && cols > 0 && x_stride >= cols && y_stride >= cols, "copy2d: bad argument");
+  LMN_LAUNCH(copy2d_kernel, dim3(grid_for(rows * cols)), dim3(256), 0, (hipStream_t)stream, x, y, rows, cols, x_stride, y_stride);
+  return lmn_launch_status("copy2d");
+}
+
 int lmn_ln_fwd(const float* x, const float* gamma, const float* beta, float* y, int64_t rows, int C,
                lmn_stream_t stream) {
+  LMN_REC(lmn_ln_fwd(x, gamma, beta, y, rows, C, stream));
   LMN_REQUIRE(x && gamma && beta && y && rows > 0, "ln_fwd: bad argument");
   LMN_REQUIRE(C % 4 == 0 && C >= 4 && C <= 512, "ln_fwd: C=%d (need multiple of 4, <= 512)", C);
   const int G = ln_group(C / 4);
   const int grid = grid_for(rows, 256 / G, 2048);
   hipStream_t st = (hipStream_t)stream;
-#define LN_CASE(g) case g: hipLaunchKernelGGL((ln_fwd_kernel<g>), dim3(grid), dim3(256), 0, st, x, gamma, beta, y, rows, C); break;
+#define LN_CASE(g) case g: LMN_LAUNCH((ln_fwd_kernel<g>), dim3(grid), dim3(256), 0, st, x, gamma, beta, y, rows, C); break;
   switch (G) { LN_CASE(1) LN_CASE(2) LN_CASE(4) LN_CASE(8) LN_CASE(16) LN_CASE(32) LN_CASE(64) }
 #undef LN_CASE
   return lmn_launch_status("ln_fwd");
@@ -775,6 +792,7 @@ int lmn_ln_fwd(const float* x, const float* gamma, const float* beta, float* y, 
 
 int lmn_ln_bwd(const float* x, const float* gamma, const float* dy, const float* dres, float* dx, float* dgamma,
                float* dbeta, int64_t rows, int C, lmn_stream_t stream) {
+  LMN_REC(lmn_ln_bwd(x, gamma, dy, dres, dx, dgamma, dbeta, rows, C, stream));
   LMN_REQUIRE(x && gamma && dy && dx && dgamma && dbeta && rows > 0, "ln_bwd: bad argument");
   LMN_REQUIRE(C % 4 == 0 && C >= 4 && C <= 512, "ln_bwd: C=%d", C);
   const int G = ln_group(C / 4);
@@ -783,7 +801,7 @@ int lmn_ln_bwd(const float* x, const float* gamma, const float* dy, const float*
   const int grid = grid_for(rows, 256 / G, C <= 12 ? 1024 : 512);
   hipStream_t st = (hipStream_t)stream;
   const size_t sh = 8 * C * sizeof(float);
-#define LN_CASE(g) case g: hipLaunchKernelGGL((ln_bwd_kernel<g>), dim3(grid), dim3(256), sh, st, x, gamma, dy, dres, dx, dgamma, dbeta, rows, C); break;
+#define LN_CASE(g) case g: LMN_LAUNCH((ln_bwd_kernel<g>), dim3(grid), dim3(256), sh, st, x, gamma, dy, dres, dx, dgamma, dbeta, rows, C); break;
   switch (G) { LN_CASE(1) LN_CASE(2) LN_CASE(4) LN_CASE(8) LN_CASE(16) LN_CASE(32) LN_CASE(64) }
 #undef LN_CASE
   return lmn_launch_status("ln_bwd");
@@ -791,18 +809,20 @@ int lmn_ln_bwd(const float* x, const float* gamma, const float* dy, const float*
 
 int lmn_bnact_fwd(const float* z, const float* a, const float* b, float* y, int64_t rows, int C, int act,
                   lmn_stream_t stream) {
+  LMN_REC(lmn_bnact_fwd(z, a, b, y, rows, C, act, stream));
   LMN_REQUIRE(z && a && b && y && rows > 0 && C > 0 && C % 4 == 0, "bnact_fwd: bad argument");
   const int64_t n4 = rows * (C / 4);
-  hipLaunchKernelGGL(bnact_fwd_kernel, dim3(grid_for(n4)), dim3(256), 0, (hipStream_t)stream, z, a, b, y, n4, C / 4, act);
+  LMN_LAUNCH(bnact_fwd_kernel, dim3(grid_for(n4)), dim3(256), 0, (hipStream_t)stream, z, a, b, y, n4, C / 4, act);
   return lmn_launch_status("bnact_fwd");
 }
 
 int lmn_bnact_bwd_stats(const float* z, const float* dy, const float* mean, const float* rstd, const float* gamma,
                         const float* beta, float* stats, int64_t rows, int C, int act, lmn_stream_t stream) {
+  LMN_REC(lmn_bnact_bwd_stats(z, dy, mean, rstd, gamma, beta, stats, rows, C, act, stream));
   LMN_REQUIRE(z && dy && mean && rstd && gamma && beta && stats && rows > 0, "bnact_bwd_stats: bad argument");
   LMN_REQUIRE(C % 4 == 0 && C >= 4 && C <= 1024, "bnact_bwd_stats: C=%d", C);
   const int rpb = 256 / (C / 4);
-  hipLaunchKernelGGL((chan_kernel<0>), dim3(grid_for(rows, rpb * 8, 1024)), dim3(256), 2 * C * sizeof(float),
+  LMN_LAUNCH((chan_kernel<0>), dim3(grid_for(rows, rpb * 8, 1024)), dim3(256), 2 * C * sizeof(float),
                      (hipStream_t)stream, z, dy, mean, rstd, gamma, beta, nullptr, nullptr, nullptr, stats, rows, C, C, act);
   return lmn_launch_status("bnact_bwd_stats");
 }
@@ -810,18 +830,20 @@ int lmn_bnact_bwd_stats(const float* z, const float* dy, const float* mean, cons
 int lmn_bnact_bwd(const float* z, const float* dy, const float* mean, const float* rstd, const float* gamma,
                   const float* beta, const float* c1, const float* c2, const float* c3, float* dz, int64_t rows, int C,
                   int act, lmn_stream_t stream) {
+  LMN_REC(lmn_bnact_bwd(z, dy, mean, rstd, gamma, beta, c1, c2, c3, dz, rows, C, act, stream));
   LMN_REQUIRE(z && dy && mean && rstd && gamma && beta && c1 && c2 && c3 && dz && rows > 0, "bnact_bwd: bad argument");
   LMN_REQUIRE(C % 4 == 0 && C >= 4 && C <= 1024, "bnact_bwd: C=%d", C);
   const int rpb = 256 / (C / 4);
-  hipLaunchKernelGGL((chan_kernel<1>), dim3(grid_for(rows, rpb * 4, 4096)), dim3(256), 2 * C * sizeof(float),
+  LMN_LAUNCH((chan_kernel<1>), dim3(grid_for(rows, rpb * 4, 4096)), dim3(256), 2 * C * sizeof(float),
                      (hipStream_t)stream, z, dy, mean, rstd, gamma, beta, c1, c2, c3, dz, rows, C, C, act);
   return lmn_launch_status("bnact_bwd");
 }
 
 int lmn_colsum(const float* x, float* out, int64_t rows, int C, int cstride, lmn_stream_t stream) {
+  LMN_REC(lmn_colsum(x, out, rows, C, cstride, stream));
   LMN_REQUIRE(x && out && rows > 0 && C % 4 == 0 && C >= 4 && C <= 1024 && cstride >= C && cstride % 4 == 0, "colsum: bad argument");
   const int rpb = 256 / (C / 4);
-  hipLaunchKernelGGL((chan_kernel<2>), dim3(grid_for(rows, rpb * 8, 1024)), dim3(256), 2 * C * sizeof(float),
+  LMN_LAUNCH((chan_kernel<2>), dim3(grid_for(rows, rpb * 8, 1024)), dim3(256), 2 * C * sizeof(float),
                      (hipStream_t)stream, x, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, out,
                      rows, C, cstride, 0);
   return lmn_launch_status("colsum");
@@ -830,33 +852,37 @@ int lmn_colsum(const float* x, float* out, int64_t rows, int C, int cstride, lmn
 int lmn_bn_finalize(const float* sums, int nrep, float count, const float* gamma, const float* beta, float eps,
                     float momentum, float* mean, float* rstd, float* A, float* shift, float* running_mean,
                     float* running_var, int C, lmn_stream_t stream) {
+  LMN_REC(lmn_bn_finalize(sums, nrep, count, gamma, beta, eps, momentum, mean, rstd, A, shift, running_mean, running_var, C, stream));
   LMN_REQUIRE(sums && nrep >= 1 && gamma && beta && C > 0 && count > 0.f, "bn_finalize: bad argument");
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3(lmn_cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream, sums, nrep, count, gamma,
+  LMN_LAUNCH(bn_finalize_kernel, dim3(lmn_cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream, sums, nrep, count, gamma,
                      beta, eps, momentum, mean, rstd, A, shift, running_mean, running_var, C);
   return lmn_launch_status("bn_finalize");
 }
 
 int lmn_bn_fold(const float* running_mean, const float* running_var, const float* gamma, const float* beta, float eps,
                 float* mean, float* rstd, float* A, float* shift, int C, lmn_stream_t stream) {
+  LMN_REC(lmn_bn_fold(running_mean, running_var, gamma, beta, eps, mean, rstd, A, shift, C, stream));
   LMN_REQUIRE(running_mean && running_var && gamma && beta && C > 0, "bn_fold: bad argument");
-  hipLaunchKernelGGL(bn_fold_kernel, dim3(lmn_cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream, running_mean,
+  LMN_LAUNCH(bn_fold_kernel, dim3(lmn_cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream, running_mean,
                      running_var, gamma, beta, eps, mean, rstd, A, shift, C);
   return lmn_launch_status("bn_fold");
 }
 
 int lmn_bn_bwd_coef(const float* bstats, int nrep, float count, int batch_stats, const float* A, float* dgamma,
                     float* dbeta, float* c1, float* c2, float* c3, int C, lmn_stream_t stream) {
+  LMN_REC(lmn_bn_bwd_coef(bstats, nrep, count, batch_stats, A, dgamma, dbeta, c1, c2, c3, C, stream));
   LMN_REQUIRE(bstats && nrep >= 1 && A && c1 && c2 && c3 && C > 0 && count > 0.f, "bn_bwd_coef: bad argument");
-  hipLaunchKernelGGL(bn_bwd_coef_kernel, dim3(lmn_cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream, bstats, nrep, count,
+  LMN_LAUNCH(bn_bwd_coef_kernel, dim3(lmn_cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream, bstats, nrep, count,
                      batch_stats, A, dgamma, dbeta, c1, c2, c3, C);
   return lmn_launch_status("bn_bwd_coef");
 }
 
 int lmn_se_fwd(const float* gsum, float inv_hw, const float* w1, const float* b1, const float* w2, const float* b2,
                float* s, float* hidden, int B, int E, int R, lmn_stream_t stream) {
+  LMN_REC(lmn_se_fwd(gsum, inv_hw, w1, b1, w2, b2, s, hidden, B, E, R, stream));
   LMN_REQUIRE(gsum && w1 && b1 && w2 && b2 && s && hidden && B > 0 && E > 0 && R > 0, "se_fwd: bad argument");
   LMN_REQUIRE((E + R) * sizeof(float) <= 60000, "se_fwd: E=%d too large", E);
-  hipLaunchKernelGGL(se_fwd_kernel, dim3(B), dim3(256), (E + R) * sizeof(float), (hipStream_t)stream, gsum, inv_hw, w1,
+  LMN_LAUNCH(se_fwd_kernel, dim3(B), dim3(256), (E + R) * sizeof(float), (hipStream_t)stream, gsum, inv_hw, w1,
                      b1, w2, b2, s, hidden, E, R);
   return lmn_launch_status("se_fwd");
 }
@@ -864,59 +890,66 @@ int lmn_se_fwd(const float* gsum, float inv_hw, const float* w1, const float* b1
 int lmn_se_bwd(const float* ds, const float* gsum, float inv_hw, const float* w1, const float* b1, const float* w2,
                const float* b2, const float* hidden, float* dm, float* dw1, float* db1, float* dw2, float* db2, int B,
                int E, int R, lmn_stream_t stream) {
+  LMN_REC(lmn_se_bwd(ds, gsum, inv_hw, w1, b1, w2, b2, hidden, dm, dw1, db1, dw2, db2, B, E, R, stream));
   (void)b1;
   LMN_REQUIRE(ds && gsum && w1 && w2 && b2 && hidden && dm && dw1 && db1 && dw2 && db2 && B > 0 && E > 0 && R > 0, "se_bwd: bad argument");
   LMN_REQUIRE((2 * E + 2 * R) * sizeof(float) <= 60000, "se_bwd: E=%d too large", E);
-  hipLaunchKernelGGL(se_bwd_kernel, dim3(B), dim3(256), (2 * E + 2 * R) * sizeof(float), (hipStream_t)stream, ds, gsum,
+  LMN_LAUNCH(se_bwd_kernel, dim3(B), dim3(256), (2 * E + 2 * R) * sizeof(float), (hipStream_t)stream, ds, gsum,
                      inv_hw, w1, w2, b2, hidden, dm, dw1, db1, dw2, db2, E, R);
   return lmn_launch_status("se_bwd");
 }
 
 int lmn_up2_fwd(const float* x, float* y, int B, int Hin, int Win, int C, int x_cstride, int y_cstride,
                 lmn_stream_t stream) {
+  LMN_REC(lmn_up2_fwd(x, y, B, Hin, Win, C, x_cstride, y_cstride, stream));
   LMN_REQUIRE(x && y && B > 0 && Hin > 0 && Win > 0 && C > 0 && C % 4 == 0 && x_cstride >= C && y_cstride >= C && x_cstride % 4 == 0 && y_cstride % 4 == 0, "up2_fwd: bad argument");
   const int64_t total = (int64_t)B * 4 * Hin * Win * (C / 4);
-  hipLaunchKernelGGL(up2_fwd_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, y, B, Hin, Win, C / 4,
+  LMN_LAUNCH(up2_fwd_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, y, B, Hin, Win, C / 4,
                      x_cstride, y_cstride);
   return lmn_launch_status("up2_fwd");
 }
 
 int lmn_up2_bwd(const float* dy, float* dx, int B, int Hin, int Win, int C, int dy_cstride, int dx_cstride,
                 lmn_stream_t stream) {
+  LMN_REC(lmn_up2_bwd(dy, dx, B, Hin, Win, C, dy_cstride, dx_cstride, stream));
   LMN_REQUIRE(dy && dx && B > 0 && Hin > 0 && Win > 0 && C > 0 && C % 4 == 0 && dy_cstride >= C && dx_cstride >= C && dy_cstride % 4 == 0 && dx_cstride % 4 == 0, "up2_bwd: bad argument");
   const int64_t total = (int64_t)B * Hin * Win * (C / 4);
-  hipLaunchKernelGGL(up2_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, dy, dx, B, Hin, Win, C / 4,
+  LMN_LAUNCH(up2_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, dy, dx, B, Hin, Win, C / 4,
                      dy_cstride, dx_cstride);
   return lmn_launch_status("up2_bwd");
 }
 
 int lmn_avgpool_fwd(const float* x, float* y, int B, int Hout, int Wout, int f, int C, int x_cstride, int y_cstride,
                     lmn_stream_t stream) {
+  LMN_REC(lmn_avgpool_fwd(x, y, B, Hout, Wout, f, C, x_cstride, y_cstride, stream));
   LMN_REQUIRE(x && y && B > 0 && Hout > 0 && Wout > 0 && f >= 1 && C % 4 == 0 && C >= 4 && C <= 1024 && x_cstride >= C && y_cstride >= C && x_cstride % 4 == 0, "avgpool_fwd: bad argument");
-  hipLaunchKernelGGL(avgpool_fwd_kernel, dim3(B * Hout * Wout), dim3(256), C * sizeof(float), (hipStream_t)stream, x, y,
+  LMN_LAUNCH(avgpool_fwd_kernel, dim3(B * Hout * Wout), dim3(256), C * sizeof(float), (hipStream_t)stream, x, y,
                      Hout, Wout, f, C, x_cstride, y_cstride);
   return lmn_launch_status("avgpool_fwd");
 }
 
 int lmn_avgpool_bwd(const float* dy, float* dx, int B, int Hout, int Wout, int f, int C, int dy_cstride, int dx_cstride,
                     int accumulate, lmn_stream_t stream) {
+  LMN_REC(lmn_avgpool_bwd(dy, dx, B, Hout, Wout, f, C, dy_cstride, dx_cstride, accumulate, stream));
   LMN_REQUIRE(dy && dx && B > 0 && Hout > 0 && Wout > 0 && f >= 1 && C % 4 == 0 && C >= 4 && dy_cstride >= C && dx_cstride >= C && dy_cstride % 4 == 0 && dx_cstride % 4 == 0, "avgpool_bwd: bad argument");
   const int64_t total = (int64_t)B * Hout * f * Wout * f * (C / 4);
-  hipLaunchKernelGGL(avgpool_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, dy, dx, B, Hout, Wout,
+  LMN_LAUNCH(avgpool_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, dy, dx, B, Hout, Wout,
                      f, C / 4, dy_cstride, dx_cstride, accumulate);
   return lmn_launch_status("avgpool_bwd");
 }
 
 int lmn_nchw_to_nhwc(const float* x, float* y, int B, int C, int H, int W, int y_cstride, lmn_stream_t stream) {
+  LMN_REC(lmn_nchw_to_nhwc(x, y, B, C, H, W, y_cstride, stream));
   LMN_REQUIRE(x && y && B > 0 && C > 0 && H > 0 && W > 0 && y_cstride >= C, "nchw_to_nhwc: bad argument");
-  hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(grid_for((int64_t)B * H * W)), dim3(256), 0, (hipStream_t)stream, x, y, B,
+  LMN_LAUNCH(nchw_to_nhwc_kernel, dim3(grid_for((int64_t)B * H * W)), dim3(256), 0, (hipStream_t)stream, x, y, B,
                      C, (int64_t)H * W, y_cstride);
   return lmn_launch_status("nchw_to_nhwc");
 }
 
 int lmn_nhwc_to_nchw(const float* x, float* y, int B, int C, int H, int W, int x_cstride, lmn_stream_t stream) {
+  LMN_REC(lmn_nhwc_to_nchw(x, y, B, C, H, W, x_cstride, stream));
   LMN_REQUIRE(x && y && B > 0 && C > 0 && H > 0 && W > 0 && x_cstride >= C, "nhwc_to_nchw: bad argument");
-  hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3(grid_for((int64_t)B * H * W)), dim3(256), 0, (hipStream_t)stream, x, y, B,
+  LMN_LAUNCH(nhwc_to_nchw_kernel, dim3(grid_for((int64_t)B * H * W)), dim3(256), 0, (hipStream_t)stream, x, y, B,
                      C, (int64_t)H * W, x_cstride);
   return lmn_launch_status("nhwc_to_nchw");
 }
@@ -928,14 +961,14 @@ int lmn_segloss_fwd(const float* logits, const int64_t* target, const float* w_c
   LMN_REQUIRE(B > 0 && HW > 0 && (C == 2 || C == 3 || C == 4 || C == 8), "segloss_fwd: C=%d not in {2,3,4,8}", C);
   hipStream_t st = (hipStream_t)stream;
   const int grid = grid_for((int64_t)B * HW) > 1024 ? 1024 : grid_for((int64_t)B * HW);
-  hipLaunchKernelGGL(fill_kernel, dim3(1), dim3(64), 0, st, sums, 0.f, (int64_t)(3 + 3 * C));
+  LMN_LAUNCH(fill_kernel, dim3(1), dim3(64), 0, st, sums, 0.f, (int64_t)(3 + 3 * C));
   switch (C) {
-    case 2: hipLaunchKernelGGL((segloss_sums_kernel<2>), dim3(grid), dim3(256), 0, st, logits, target, w_ce, B, HW, sums); break;
-    case 3: hipLaunchKernelGGL((segloss_sums_kernel<3>), dim3(grid), dim3(256), 0, st, logits, target, w_ce, B, HW, sums); break;
-    case 4: hipLaunchKernelGGL((segloss_sums_kernel<4>), dim3(grid), dim3(256), 0, st, logits, target, w_ce, B, HW, sums); break;
-    default: hipLaunchKernelGGL((segloss_sums_kernel<8>), dim3(grid), dim3(256), 0, st, logits, target, w_ce, B, HW, sums); break;
+    case 2: LMN_LAUNCH((segloss_sums_kernel<2>), dim3(grid), dim3(256), 0, st, logits, target, w_ce, B, HW, sums); break;
+    case 3: LMN_LAUNCH((segloss_sums_kernel<3>), dim3(grid), dim3(256), 0, st, logits, target, w_ce, B, HW, sums); break;
+    case 4: LMN_LAUNCH((segloss_sums_kernel<4>), dim3(grid), dim3(256), 0, st, logits, target, w_ce, B, HW, sums); break;
+    default: LMN_LAUNCH((segloss_sums_kernel<8>), dim3(grid), dim3(256), 0, st, logits, target, w_ce, B, HW, sums); break;
   }
-  hipLaunchKernelGGL(segloss_finish_kernel, dim3(1), dim3(64), 0, st, sums, w_ce, w_dice, C, label_smoothing, smooth, loss, coef);
+  LMN_LAUNCH(segloss_finish_kernel, dim3(1), dim3(64), 0, st, sums, w_ce, w_dice, C, label_smoothing, smooth, loss, coef);
   return lmn_launch_status("segloss_fwd");
 }
 
@@ -946,10 +979,10 @@ int lmn_segloss_bwd(const float* logits, const int64_t* target, const float* w_c
   hipStream_t st = (hipStream_t)stream;
   const int grid = grid_for((int64_t)B * HW);
   switch (C) {
-    case 2: hipLaunchKernelGGL((segloss_bwd_kernel<2>), dim3(grid), dim3(256), 0, st, logits, target, w_ce, coef, gscale, B, HW, dlogits); break;
-    case 3: hipLaunchKernelGGL((segloss_bwd_kernel<3>), dim3(grid), dim3(256), 0, st, logits, target, w_ce, coef, gscale, B, HW, dlogits); break;
-    case 4: hipLaunchKernelGGL((segloss_bwd_kernel<4>), dim3(grid), dim3(256), 0, st, logits, target, w_ce, coef, gscale, B, HW, dlogits); break;
-    default: hipLaunchKernelGGL((segloss_bwd_kernel<8>), dim3(grid), dim3(256), 0, st, logits, target, w_ce, coef, gscale, B, HW, dlogits); break;
+    case 2: LMN_LAUNCH((segloss_bwd_kernel<2>), dim3(grid), dim3(256), 0, st, logits, target, w_ce, coef, gscale, B, HW, dlogits); break;
+    case 3: LMN_LAUNCH((segloss_bwd_kernel<3>), dim3(grid), dim3(256), 0, st, logits, target, w_ce, coef, gscale, B, HW, dlogits); break;
+    case 4: LMN_LAUNCH((segloss_bwd_kernel<4>), dim3(grid), dim3(256), 0, st, logits, target, w_ce, coef, gscale, B, HW, dlogits); break;
+    default: LMN_LAUNCH((segloss_bwd_kernel<8>), dim3(grid), dim3(256), 0, st, logits, target, w_ce, coef, gscale, B, HW, dlogits); break;
   }
   return lmn_launch_status("segloss_bwd");
 }
@@ -961,9 +994,9 @@ int lmn_confusion(const float* logits, const int64_t* target, int B, int C, int6
   hipStream_t st = (hipStream_t)stream;
   const int grid = grid_for((int64_t)B * HW) > 512 ? 512 : grid_for((int64_t)B * HW);
   switch (C) {
-    case 2: hipLaunchKernelGGL((confusion_kernel<2>), dim3(grid), dim3(256), 0, st, logits, target, B, HW, counts); break;
-    case 3: hipLaunchKernelGGL((confusion_kernel<3>), dim3(grid), dim3(256), 0, st, logits, target, B, HW, counts); break;
-    default: hipLaunchKernelGGL((confusion_kernel<4>), dim3(grid), dim3(256), 0, st, logits, target, B, HW, counts); break;
+    case 2: LMN_LAUNCH((confusion_kernel<2>), dim3(grid), dim3(256), 0, st, logits, target, B, HW, counts); break;
+    case 3: LMN_LAUNCH((confusion_kernel<3>), dim3(grid), dim3(256), 0, st, logits, target, B, HW, counts); break;
+    default: LMN_LAUNCH((confusion_kernel<4>), dim3(grid), dim3(256), 0, st, logits, target, B, HW, counts); break;
   }
   return lmn_launch_status("confusion");
 }
@@ -984,7 +1017,7 @@ int lmn_preprocess_u8(const uint8_t* images, const uint8_t* masks, const uint8_t
     }
   }
   const int64_t n = (int64_t)B * H * W;
-  hipLaunchKernelGGL(preprocess_u8_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, images ? images : nullptr,
+  LMN_LAUNCH(preprocess_u8_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, images ? images : nullptr,
                      masks ? masks : nullptr, flips, images ? out : nullptr, masks ? labels : nullptr, g);
   return lmn_launch_status("preprocess_u8");
 }
@@ -993,27 +1026,30 @@ int lmn_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, floa
                    float eps, float weight_decay, float bias_corr1, float bias_corr2, lmn_stream_t stream) {
   LMN_REQUIRE(p && g && m && v && n > 0 && n % 4 == 0, "adamw_step: bad argument (n must be a multiple of 4)");
   LMN_REQUIRE(bias_corr1 > 0.f && bias_corr2 > 0.f, "adamw_step: bias corrections must be positive");
-  hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n / 4)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n / 4, lr, beta1,
+  LMN_LAUNCH(adamw_kernel, dim3(grid_for(n / 4)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n / 4, lr, beta1,
                      beta2, eps, weight_decay, 1.f / bias_corr1, 1.f / sqrtf(bias_corr2));
   return lmn_launch_status("adamw_step");
 }
 
 int lmn_fill(float* p, float v, int64_t n, lmn_stream_t stream) {
+  LMN_REC(lmn_fill(p, v, n, stream));
   LMN_REQUIRE(p && n >= 0, "fill: bad argument");
   if (n == 0) return 0;
-  hipLaunchKernelGGL(fill_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, p, v, n);
+  LMN_LAUNCH(fill_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, p, v, n);
   return lmn_launch_status("fill");
 }
 
 int lmn_add(const float* a, const float* b, const float* c, const float* d, float* y, int64_t n, lmn_stream_t stream) {
+  LMN_REC(lmn_add(a, b, c, d, y, n, stream));
   LMN_REQUIRE(a && b && y && n > 0 && n % 4 == 0, "add: bad argument (n must be a multiple of 4)");
-  hipLaunchKernelGGL(add_kernel, dim3(grid_for(n / 4)), dim3(256), 0, (hipStream_t)stream, a, b, c, d, y, n / 4);
+  LMN_LAUNCH(add_kernel, dim3(grid_for(n / 4)), dim3(256), 0, (hipStream_t)stream, a, b, c, d, y, n / 4);
   return lmn_launch_status("add");
 }
 
 int lmn_copy_slice(const float* x, float* y, int64_t rows, int C, int x_cstride, int y_cstride, lmn_stream_t stream) {
+  LMN_REC(lmn_copy_slice(x, y, rows, C, x_cstride, y_cstride, stream));
   LMN_REQUIRE(x && y && rows > 0 && C > 0 && C % 4 == 0 && x_cstride >= C && y_cstride >= C && x_cstride % 4 == 0 && y_cstride % 4 == 0, "copy_slice: bad argument");
-  hipLaunchKernelGGL(copy_slice_kernel, dim3(grid_for(rows * (C / 4))), dim3(256), 0, (hipStream_t)stream, x, y, rows,
+  LMN_LAUNCH(copy_slice_kernel, dim3(grid_for(rows * (C / 4))), dim3(256), 0, (hipStream_t)stream, x, y, rows,
                      C / 4, x_cstride, y_cstride);
   return lmn_launch_status("copy_slice");
 }

@@ -1,0 +1,267 @@
+// Runtime around the kernels of liblmnet_hip.so: plan recorder (one FFI crossing per pass), stream ordering helpers,
+// and the in-library kernel timer that bench.py's `roofline` block reads.
+//
+// The reference's hot loop (utils/train_eval_utils.py:140-145: model(images); loss.backward()) crosses into ~1200 ATen
+// calls per step.  Here a pass is a fixed schedule of C-ABI entries over fixed buffers, so it is recorded once (entries
+// executed AND remembered, arguments by value) and afterwards re-issued by lmn_plan_run -- on the same HIP streams, with
+// the cross-stream dependencies re-created by events -- without any host code per kernel.
+#include "common.h"
+
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
+int g_lmn_prof_on = 0;
+thread_local void* g_lmn_rec = nullptr;
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------ plan
+struct Plan {
+  std::vector<std::function<int()>> ops;
+  std::vector<hipEvent_t> events;  // owned by the plan: one per recorded cross-stream wait
+  bool sealed = false;
+};
+
+// events for lmn_stream_wait outside of a plan: a ring (an event may be re-recorded as soon as the wait on its previous
+// record has been ISSUED -- hipStreamWaitEvent captures the record that is current at the call)
+struct EventRing {
+  std::vector<hipEvent_t> ev;
+  size_t next = 0;
+  hipEvent_t get() {
+    if (ev.size() < 512) {
+      hipEvent_t e;
+      if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return nullptr;
+      ev.push_back(e);
+      return e;
+    }
+    hipEvent_t e = ev[next];
+    next = (next + 1) % ev.size();
+    return e;
+  }
+};
+thread_local EventRing g_ring;
+
+int wait_with(hipEvent_t e, hipStream_t waiter, hipStream_t waited) {
+  hipError_t r = hipEventRecord(e, waited);
+  if (r == hipSuccess) r = hipStreamWaitEvent(waiter, e, 0);
+  if (r != hipSuccess) {
+    snprintf(g_lmn_err, sizeof(g_lmn_err), "stream_wait: %s", hipGetErrorString(r));
+    return (int)r;
+  }
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------ kernel timer
+struct ProfRec {
+  const char* name;  // string literal of the launch site
+  hipEvent_t e0, e1;
+  double flops, bytes;
+};
+struct Prof {
+  std::mutex mu;
+  std::string filter;  // '|'-separated substrings; empty = every kernel
+  std::vector<std::string> parts;
+  std::vector<ProfRec> recs;
+  std::vector<hipEvent_t> pool;
+} g_prof;
+thread_local double g_cost_flops = 0.0, g_cost_bytes = 0.0;
+thread_local hipEvent_t g_open_e1 = nullptr;
+
+hipEvent_t prof_event() {
+  if (!g_prof.pool.empty()) {
+    hipEvent_t e = g_prof.pool.back();
+    g_prof.pool.pop_back();
+    return e;
+  }
+  hipEvent_t e = nullptr;
+  (void)hipEventCreate(&e);
+  return e;
+}
+
+}  // namespace
+
+void lmn_rec_push(std::function<int()>&& f) {
+  Plan* p = (Plan*)g_lmn_rec;
+  if (p && !p->sealed) p->ops.push_back(std::move(f));
+}
+
+void lmn_prof_cost(double flops, double bytes) {
+  g_cost_flops = flops;
+  g_cost_bytes = bytes;
+}
+
+bool lmn_prof_start(const char* kernel, hipStream_t st) {
+  std::lock_guard<std::mutex> lk(g_prof.mu);
+  const double fl = g_cost_flops, by = g_cost_bytes;
+  g_cost_flops = g_cost_bytes = 0.0;
+  if (!g_prof.parts.empty()) {
+    bool hit = false;
+    for (const std::string& s : g_prof.parts)
+      if (strstr(kernel, s.c_str())) { hit = true; break; }
+    if (!hit) return false;
+  }
+  ProfRec r;
+  r.name = kernel;
+  r.e0 = prof_event();
+  r.e1 = prof_event();
+  r.flops = fl;
+  r.bytes = by;
+  if (!r.e0 || !r.e1) return false;
+  (void)hipEventRecord(r.e0, st);
+  g_open_e1 = r.e1;
+  g_prof.recs.push_back(r);
+  return true;
+}
+
+void lmn_prof_stop(hipStream_t st) {
+  if (g_open_e1) (void)hipEventRecord(g_open_e1, st);
+  g_open_e1 = nullptr;
+}
+
+extern "C" {
+
+// ---- stream ordering without torch: `waiter` waits for everything enqueued on `waited` so far
+int lmn_stream_wait(lmn_stream_t waiter, lmn_stream_t waited) {
+  if (waiter == waited) return 0;
+  Plan* p = (Plan*)g_lmn_rec;
+  hipEvent_t e = nullptr;
+  if (p && !p->sealed) {
+    if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) {
+      snprintf(g_lmn_err, sizeof(g_lmn_err), "stream_wait: hipEventCreate failed");
+      return LMN_E_BADARG;
+    }
+    p->events.push_back(e);
+    p->ops.push_back([e, waiter, waited]() -> int { return wait_with(e, (hipStream_t)waiter, (hipStream_t)waited); });
+  } else {
+    e = g_ring.get();
+    LMN_REQUIRE(e, "stream_wait: no event");
+  }
+  return wait_with(e, (hipStream_t)waiter, (hipStream_t)waited);
+}
+
+// ---- numbered events: record on one stream now, make another stream wait for exactly that point later
+// (lmn_stream_wait orders against everything enqueued so far, which would also wait for work queued AFTER the point of
+// interest on the waited stream).  64 slots per process; a slot may be re-recorded once its waits have been issued.
+static hipEvent_t g_slots[64] = {nullptr};
+static hipEvent_t slot_event(int slot) {
+  if (slot < 0 || slot >= 64) return nullptr;
+  if (!g_slots[slot] && hipEventCreateWithFlags(&g_slots[slot], hipEventDisableTiming) != hipSuccess) g_slots[slot] = nullptr;
+  return g_slots[slot];
+}
+int lmn_event_record(int slot, lmn_stream_t stream) {
+  LMN_REC(lmn_event_record(slot, stream));
+  hipEvent_t e = slot_event(slot);
+  LMN_REQUIRE(e, "event_record: slot %d", slot);
+  const hipError_t r = hipEventRecord(e, (hipStream_t)stream);
+  LMN_REQUIRE(r == hipSuccess, "event_record: %s", hipGetErrorString(r));
+  return 0;
+}
+int lmn_event_wait(int slot, lmn_stream_t stream) {
+  LMN_REC(lmn_event_wait(slot, stream));
+  hipEvent_t e = slot_event(slot);
+  LMN_REQUIRE(e, "event_wait: slot %d", slot);
+  const hipError_t r = hipStreamWaitEvent((hipStream_t)stream, e, 0);
+  LMN_REQUIRE(r == hipSuccess, "event_wait: %s", hipGetErrorString(r));
+  return 0;
+}
+
+// ---- plans
+lmn_plan_t lmn_plan_create(void) { return (lmn_plan_t) new Plan(); }
+
+int lmn_plan_destroy(lmn_plan_t plan) {
+  Plan* p = (Plan*)plan;
+  if (!p) return 0;
+  if (g_lmn_rec == p) g_lmn_rec = nullptr;
+  for (hipEvent_t e : p->events) (void)hipEventDestroy(e);
+  delete p;
+  return 0;
+}
+
+int lmn_plan_record_begin(lmn_plan_t plan) {
+  Plan* p = (Plan*)plan;
+  LMN_REQUIRE(p && !p->sealed, "plan_record_begin: null or sealed plan");
+  LMN_REQUIRE(g_lmn_rec == nullptr || g_lmn_rec == p, "plan_record_begin: another plan is recording on this thread");
+  g_lmn_rec = p;
+  return 0;
+}
+
+// pause / resume (entries issued while paused run but are not remembered); returns the number of ops recorded so far,
+// which is what lmn_plan_run takes as segment bounds
+int64_t lmn_plan_record_end(lmn_plan_t plan, int seal) {
+  Plan* p = (Plan*)plan;
+  if (!p) return -1;
+  if (g_lmn_rec == p) g_lmn_rec = nullptr;
+  if (seal) p->sealed = true;
+  return (int64_t)p->ops.size();
+}
+
+int64_t lmn_plan_size(lmn_plan_t plan) { return plan ? (int64_t)((Plan*)plan)->ops.size() : -1; }
+
+// re-issue ops [lo, hi) (hi < 0: to the end).  Stops at the first failing entry and returns its code.
+int lmn_plan_run(lmn_plan_t plan, int64_t lo, int64_t hi) {
+  Plan* p = (Plan*)plan;
+  LMN_REQUIRE(p, "plan_run: null plan");
+  LMN_REQUIRE(g_lmn_rec == nullptr, "plan_run: a plan is recording on this thread");
+  const int64_t n = (int64_t)p->ops.size();
+  if (hi < 0 || hi > n) hi = n;
+  LMN_REQUIRE(lo >= 0 && lo <= hi, "plan_run: bad range [%lld, %lld) of %lld", (long long)lo, (long long)hi, (long long)n);
+  for (int64_t i = lo; i < hi; ++i) {
+    const int rc = p->ops[(size_t)i]();
+    if (rc != 0) return rc;
+  }
+  return 0;
+}
+
+// ---- kernel timer
+int lmn_prof_begin(const char* filter) {
+  std::lock_guard<std::mutex> lk(g_prof.mu);
+  for (ProfRec& r : g_prof.recs) { g_prof.pool.push_back(r.e0); g_prof.pool.push_back(r.e1); }
+  g_prof.recs.clear();
+  g_prof.parts.clear();
+  g_prof.filter = filter ? filter : "";
+  size_t a = 0;
+  while (a <= g_prof.filter.size() && !g_prof.filter.empty()) {
+    size_t b = g_prof.filter.find('|', a);
+    if (b == std::string::npos) b = g_prof.filter.size();
+    if (b > a) g_prof.parts.push_back(g_prof.filter.substr(a, b - a));
+    a = b + 1;
+  }
+  g_lmn_prof_on = 1;
+  return 0;
+}
+
+// Stops the timer, waits for the device, and writes one line per kernel name:
+//   name \t launches \t total_us \t flops \t bytes \n      (flops / bytes: sums of the algorithmic costs the entries declared)
+// Returns the number of bytes needed (including the terminator); call again with a larger buffer if > cap.
+int64_t lmn_prof_end(char* out, int64_t cap) {
+  g_lmn_prof_on = 0;
+  (void)hipDeviceSynchronize();
+  std::lock_guard<std::mutex> lk(g_prof.mu);
+  struct Agg { int64_t n = 0; double us = 0, fl = 0, by = 0; };
+  std::map<std::string, Agg> agg;
+  for (ProfRec& r : g_prof.recs) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, r.e0, r.e1) != hipSuccess) continue;
+    std::string nm = r.name;
+    if (!nm.empty() && nm.front() == '(' && nm.back() == ')') nm = nm.substr(1, nm.size() - 2);
+    Agg& a = agg[nm];
+    a.n += 1; a.us += ms * 1e3; a.fl += r.flops; a.by += r.bytes;
+  }
+  std::string s;
+  char line[512];
+  for (auto& kv : agg) {
+    snprintf(line, sizeof(line), "%s\t%lld\t%.3f\t%.6e\t%.6e\n", kv.first.c_str(), (long long)kv.second.n, kv.second.us,
+             kv.second.fl, kv.second.by);
+    s += line;
+  }
+  if (out && cap > 0) {
+    const size_t k = s.size() < (size_t)cap - 1 ? s.size() : (size_t)cap - 1;
+    memcpy(out, s.data(), k);
+    out[k] = 0;
+  }
+  return (int64_t)s.size() + 1;
+}
+
+}  // extern "C"

@@ -33,6 +33,7 @@ class GradReducer:
         self.pending_lo = self.pending_hi = 0
         self.works = []
         self.launched = []            # (lo, hi) of every bucket launched in the current backward
+        self.launched_before_finish = 0   # how many of them were handed to the backend before finish() (= overlapped)
         self.also_wait = []           # producer streams besides the current one (model's weight-gradient stream)
         self.stream = None
 
@@ -82,6 +83,7 @@ class GradReducer:
         """Flush the tail bucket and make the compute stream wait for every collective."""
         if self.world == 1 or self.flat is None:
             return
+        self.launched_before_finish = len(self.launched)
         self._launch()
         if self.flat.is_cuda:
             torch.cuda.current_stream(self.flat.device).wait_stream(self.stream)

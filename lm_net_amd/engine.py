@@ -30,8 +30,37 @@ class Ctx:
         self.t = {}
 
 
+class Arena:
+    """Bump allocator over ONE fp32 buffer, no reuse inside a step: every tensor of a recorded pass keeps its address for
+    the life of the plan (288 GB of HBM: a batch-8 352x352 training step needs a few GB this way), and no buffer is ever
+    shared between the streams of the schedule, so replays need no allocator bookkeeping."""
+
+    def __init__(self, nfloats, device):
+        self.buf = torch.empty(int(nfloats), device=device, dtype=torch.float32)
+        self.off = 0
+
+    def alloc(self, shape):
+        n = 1
+        for d in shape:
+            n *= int(d)
+        n_al = (n + 63) & ~63                  # 256-byte granules
+        if self.off + n_al > self.buf.numel():
+            raise RuntimeError("lm_net_amd: plan arena exhausted (%d + %d > %d floats)" % (self.off, n_al, self.buf.numel()))
+        v = self.buf[self.off:self.off + n].view(shape)
+        self.off += n_al
+        return v
+
+
+_ENG = [None]      # engine of the pass in flight
+
+
 def _E(ref, *shape):
-    return torch.empty(shape, device=ref.device, dtype=torch.float32)
+    """fp32 buffer of `shape` on ref's device (ref: tensor or torch.device) from the allocator of the pass in flight."""
+    dev = ref if isinstance(ref, torch.device) else ref.device
+    eng = _ENG[0]
+    if eng is None:
+        return torch.empty(shape, device=dev, dtype=torch.float32)
+    return eng.alloc(dev, shape)
 
 
 class ZeroPool:
@@ -45,7 +74,10 @@ class ZeroPool:
         self.count = 0
 
     def begin(self, device):
-        self.buf = torch.zeros(self.need, device=device, dtype=torch.float32) if self.need else None
+        self.buf = None
+        if self.need:
+            self.buf = _E(device, self.need)
+            hip.fill(self.buf, 0.0)
         self.off = self.count = 0
 
     def get(self, device, *shape):
@@ -58,7 +90,9 @@ class ZeroPool:
             v = self.buf[self.off:self.off + n].view(shape)
             self.off += n4
             return v
-        return torch.zeros(shape, device=device, dtype=torch.float32)
+        t = _E(device, *shape)
+        hip.fill(t, 0.0)
+        return t
 
     def end(self):
         self.need = max(self.need, self.count)
@@ -71,8 +105,10 @@ _POOL = [None]
 def _Z(ref, *shape):
     pool = _POOL[0]
     if pool is None:
-        return torch.zeros(shape, device=ref.device, dtype=torch.float32)
-    return pool.get(ref.device, *shape)
+        t = _E(ref, *shape)
+        hip.fill(t, 0.0)
+        return t
+    return pool.get(ref if isinstance(ref, torch.device) else ref.device, *shape)
 
 
 # slices of the conv statistics buffers: a conv's ~1280 blocks add into slice (block % STATS_REP) instead of all into the
@@ -95,16 +131,30 @@ class Engine:
         self.branch_overlap = True
         self.zpool_fwd, self.zpool_bwd = ZeroPool(), ZeroPool()
         self.packs_fwd, self.packs_bwd = hip.PackPlan(), hip.PackPlan()
-        self.kernel_events = None  # bench.py: {"dw_fwd": [(start_event, end_event, algorithmic_bytes), ...]}
+        self.arena = None         # plan mode (LM_Net.enable_plans): bump arena all tensors of the pass come from
+        self.planning = False     # a plan is being recorded: buffers come from the arena, no allocator stream bookkeeping
+        self.alloc_floats = 0     # floats requested since begin_pass (sizes the arena during the eager warm-up steps)
+
+    def alloc(self, device, shape):
+        n = 1
+        for d in shape:
+            n *= int(d)
+        self.alloc_floats += (n + 63) & ~63
+        if self.arena is not None:
+            return self.arena.alloc(shape)
+        return torch.empty(shape, device=device, dtype=torch.float32)
 
     # ------------------------------------------------------------------ small helpers
     def begin_pass(self, backward, device):
-        pool = self.zpool_bwd if backward else self.zpool_fwd
-        pool.begin(device)
-        _POOL[0] = pool
+        _ENG[0] = self
+        self.alloc_floats = 0
+        hip._ALLOC[0] = self.alloc
         hip._STREAM[0] = None
         hip._STREAM[0] = hip._stream()          # one stream lookup per pass instead of one per launch
         hip._SEED_CTR[0] = self.seed_ctr
+        pool = self.zpool_bwd if backward else self.zpool_fwd
+        pool.begin(device)
+        _POOL[0] = pool
         plan = self.packs_bwd if backward else self.packs_fwd
         plan.refresh()            # all persistent weights of this pass re-packed in one launch
         hip._PLAN[0] = plan
@@ -113,6 +163,8 @@ class Engine:
         if _POOL[0] is not None:
             _POOL[0].end()
         _POOL[0] = None
+        _ENG[0] = None
+        hip._ALLOC[0] = None
         hip._PLAN[0] = None
         hip._STREAM[0] = None
         hip._SEED_CTR[0] = None
@@ -132,21 +184,23 @@ class Engine:
         v = src["view"] if isinstance(src, dict) else src
         return v.C if isinstance(v, V) else v.shape[-1]
 
-    def conv(self, srcs, w, bias, out, *, Hin, Win, k=1, s=1, wp=None, **kw):
-        """Forward conv of `srcs` (list) with torch-layout weight w [Cout, Cin, k, k] (or [Cout, Cin])."""
+    def conv(self, srcs, w, bias, out, *, Hin, Win, k=1, s=1, wp=None, cout=None, **kw):
+        """Forward conv of `srcs` (list) with torch-layout weight w [Cout, Cin, k, k] (or [Cout, Cin]).
+        cout: rows computed (the weight's Cout rounded up to 4: the extra rows of the packed weight are zeros)."""
         B = self._t(srcs[0]).shape[0]
         if wp is None:
             wp = hip.conv_pack(w, k, [self._c(x) for x in srcs])
         Hout = (Hin + 2 * (k // 2) - k) // s + 1
         Wout = (Win + 2 * (k // 2) - k) // s + 1
-        hip.conv_fwd(srcs, wp, out, B=B, Hin=Hin, Win=Win, Hout=Hout, Wout=Wout, Cout=w.shape[0], ksize=k, stride=s,
+        hip.conv_fwd(srcs, wp, out, B=B, Hin=Hin, Win=Win, Hout=Hout, Wout=Wout, Cout=cout or w.shape[0], ksize=k, stride=s,
                      bias=bias, **kw)
         return wp
 
     def conv_T(self, dy, w, out, *, Hin, Win, k=1, s=1, row_off=0, rows=None, B=None, **kw):
-        """Data gradient of a forward conv with weight w whose INPUT was Hin x Win: out = dL/dx (rows slice)."""
+        """Data gradient of a forward conv with weight w whose INPUT was Hin x Win: out = dL/dx (rows slice).
+        rows / the channel count of dy may be the weight's Cin / Cout rounded up to 4 (zero-padded operators)."""
         rows = w.shape[1] - row_off if rows is None else rows
-        wpt = hip.conv_pack_t(w, k, row_off, rows)
+        wpt = hip.conv_pack_t(w, k, row_off, rows, cred=self._c(dy))
         Ho = (Hin + 2 * (k // 2) - k) // s + 1
         Wo = (Win + 2 * (k // 2) - k) // s + 1
         B = self._t(dy).shape[0] if B is None else B
@@ -173,18 +227,19 @@ class Engine:
         # (and before every data-parallel bucket hand-over).
         main = torch.cuda.current_stream(d.device)
         side = self._side_stream(main)
-        side.wait_stream(main)
+        hip.stream_wait(side, main)
         saved = hip._STREAM[0]
         hip._STREAM[0] = hip.C.c_void_p(side.cuda_stream)
         try:
             hip.conv_wgrad(srcs, dy, dW, db, B=B, Hin=Hin, Win=Win, Hout=Ho, Wout=Wo, Cout=cout, ksize=k, stride=s, **kw)
         finally:
             hip._STREAM[0] = saved
-        d.record_stream(side)
-        for src in srcs:
-            self._t(src).record_stream(side)
-            if isinstance(src, dict) and src.get("scale") is not None:
-                src["scale"].record_stream(side)
+        if self.arena is None:          # caching-allocator tensors: keep them alive for the side stream
+            d.record_stream(side)
+            for src in srcs:
+                self._t(src).record_stream(side)
+                if isinstance(src, dict) and src.get("scale") is not None:
+                    src["scale"].record_stream(side)
         if explicit:
             self.join_side(d.device)
 
@@ -203,7 +258,7 @@ class Engine:
         cur = torch.cuda.current_stream(device)
         ent = self.sides.get(cur.cuda_stream)
         if ent is not None and ent[1]:
-            cur.wait_stream(ent[0])
+            hip.stream_wait(cur, ent[0])
             ent[1] = False
 
     @contextlib.contextmanager
@@ -239,8 +294,7 @@ class Engine:
         B, H, W, _ = x.shape
         E, Cout, N = m.cexp, m.cout, B * H * W
         ec, ebn = m.expand_conv[0], m.expand_conv[1]
-        we = self._w_expand(m, x)
-        wpe = hip.conv_pack(we, 1, [x.shape[-1]])
+        wpe = hip.conv_pack(ec.weight, 1, [x.shape[-1]])   # (a 3-channel weight on the NHWC4 input: zero column packed)
         sums1 = None
         if self.training:
             sums1 = _Z(x, STATS_REP, 2, E)
@@ -272,20 +326,13 @@ class Engine:
                 hip.dw_merge(*ws, bA, bshift, keff, beff)
         pre = _E(x, B, H, W, E)
         gsum = _Z(x, B, E)
-        ev = self.kernel_events.get("dw_fwd") if self.kernel_events is not None else None
-        if ev is not None:
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
         hip.dw_fwd(x1, pre, gsum, keff, beff)
-        if ev is not None:
-            e1.record()
-            ev.append((e0, e1, 2 * x1.numel() * 4))
         se = m.se
         R = se.fc1.weight.shape[0]
         sgate, hid = _E(x, B, E), _E(x, B, R)
         hip.se_fwd(gsum, 1.0 / (H * W), se.fc1.weight, se.fc1.bias, se.fc2.weight, se.fc2.bias, sgate, hid)
         # pointwise(g*s) + shortcut(x): one conv over two sources
-        wpw, wsc = m.pointwise_conv[0].weight, self._w_shortcut(m, x)
+        wpw, wsc = m.pointwise_conv[0].weight, m.shortcut[0].weight
         wp3 = self._pack2(wpw, wsc, E, x.shape[-1], Cout, x)
         y = _E(x, B, H, W, Cout) if out is None else out
         hip.conv_fwd([dict(view=pre, scale=sgate, flags=hip.SRC_GELU), x], wp3, y, B=B, Hin=H, Win=W, Hout=H, Wout=W,
@@ -294,23 +341,6 @@ class Engine:
             cx.t[m] = dict(x=x, x1=x1, pre=pre, gsum=gsum, s=sgate, hid=hid, wpe=wpe, mean1=mean1, rstd1=rstd1, A1=A1,
                            bmean=bmean, brstd=brstd, bA=bA)
         return y
-
-    def _w_expand(self, m, x):
-        w = m.expand_conv[0].weight
-        return self._pad_cin(w, x.shape[-1])
-
-    def _w_shortcut(self, m, x):
-        return self._pad_cin(m.shortcut[0].weight, x.shape[-1])
-
-    @staticmethod
-    def _pad_cin(w, cin):
-        """The RGB input is carried as NHWC4 (channel 3 = 0): pad the weight's input axis with zeros
-        (a layout copy of a [Cout,3] weight; no arithmetic)."""
-        if w.shape[1] == cin:
-            return w
-        wp = torch.zeros(w.shape[0], cin, *w.shape[2:], device=w.device, dtype=w.dtype)
-        wp[:, :w.shape[1]].copy_(w.detach())
-        return wp
 
     @staticmethod
     def _pack2(w0, w1, c0, c1, cout, ref):
@@ -322,7 +352,7 @@ class Engine:
         if own:
             wp = plan.buffer(("pack2", w0.data_ptr(), w1.data_ptr()), n0 + n1, ref.device)
         else:
-            wp = torch.empty(n0 + n1, device=ref.device, dtype=torch.float32)
+            wp = _E(ref, n0 + n1)
         hip.conv_pack(w0, 1, [c0], out=wp[:n0], persistent=own)
         hip.conv_pack(w1, 1, [c1], out=wp[n0:], persistent=own)
         return wp
@@ -338,22 +368,22 @@ class Engine:
         G = self.G
         pw, sc, ec, ebn, se = m.pointwise_conv[0], m.shortcut[0], m.expand_conv[0], m.expand_conv[1], m.se
         # ---- A3 backward
-        wsc = self._w_shortcut(m, x)
-        if wsc is sc.weight:  # one pass over dy for both convs (they were one conv over two sources in the forward)
+        cw = sc.weight.shape[1]          # real input channels (3 for the RGB stem, carried as NHWC4)
+        if cw == Cin:  # one pass over dy for both convs (they were one conv over two sources in the forward)
             self.wgrad([dict(view=pre, scale=sgate, flags=hip.SRC_GELU), x], dy, None, pw.bias, Hin=H, Win=W,
                        dW_src=[G[pw.weight], G[sc.weight]], db2=G[sc.bias])
         else:  # padded RGB input: gradient of the padded weight, keep the real columns
             self.wgrad([dict(view=pre, scale=sgate, flags=hip.SRC_GELU)], dy, pw.weight, pw.bias, Hin=H, Win=W)
-            dWp = torch.zeros_like(wsc)
+            dWp = _Z(x, Cout, Cin)
             self.wgrad([x], dy, None, None, Hin=H, Win=W, dW=dWp, db=G[sc.bias])
-            G[sc.weight].copy_(dWp[:, :sc.weight.shape[1]])      # un-pad (layout copy)
+            hip.copy2d(dWp, G[sc.weight], Cout, cw, Cin, cw)      # un-pad (layout copy)
         u = _E(x, B, H, W, E)
         ds = _Z(x, B, E)
         self.conv_T(dy, pw.weight, u, Hin=H, Win=W, epilogue=hip.EP_SE_BWD, aux=pre, stats=ds, stats_mode=hip.STATS_EP)
         dx_sc = None
         if need_dx:
             dx_sc = _E(x, B, H, W, Cin)
-            self.conv_T(dy, wsc, dx_sc, Hin=H, Win=W)
+            self.conv_T(dy, sc.weight, dx_sc, Hin=H, Win=W, rows=Cin)
         # ---- SE backward
         dm = _E(x, B, E)
         hip.se_bwd(ds, S["gsum"], 1.0 / (H * W), se.fc1.weight, se.fc1.bias, se.fc2.weight, se.fc2.bias, S["hid"], dm,
@@ -381,17 +411,16 @@ class Engine:
         dz = dh
         hip.conv_fwd([x], wpe, dz, B=B, Hin=H, Win=W, Hout=H, Wout=W, Cout=E, bias=ec.bias, epilogue=hip.EP_BN_BWD2,
                      p=(S["mean1"], S["rstd1"], c1, c2, c3), aux=dh)
-        we = self._w_expand(m, x)
-        if we is ec.weight:
+        if cw == Cin:
             self.wgrad([x], dz, ec.weight, ec.bias, Hin=H, Win=W)
         else:
-            dWp = torch.zeros_like(we)
+            dWp = _Z(x, E, Cin)
             self.wgrad([x], dz, None, None, Hin=H, Win=W, dW=dWp, db=G[ec.bias])
-            G[ec.weight].copy_(dWp[:, :ec.weight.shape[1]])      # un-pad (layout copy)
+            hip.copy2d(dWp, G[ec.weight], E, cw, Cin, cw)         # un-pad (layout copy)
         if not need_dx:
             return None
         dx = _E(x, B, H, W, Cin)
-        self.conv_T(dz, we, dx, Hin=H, Win=W, residual=dx_sc)
+        self.conv_T(dz, ec.weight, dx, Hin=H, Win=W, rows=Cin, residual=dx_sc)
         return dx
 
     def stage_fwd(self, seq, x, cx):

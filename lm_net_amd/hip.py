@@ -17,7 +17,7 @@ SRC_GELU, SRC_DROP = 1, 2
 EP_LINEAR, EP_AFFINE_ACT, EP_DGELU, EP_BN_BWD1, EP_BN_BWD2, EP_SE_BWD = 0, 1, 2, 3, 4, 5
 ACT_NONE, ACT_HSWISH, ACT_GELU = 0, 1, 2
 STATS_NONE, STATS_SUM_SQ, STATS_EP = 0, 1, 2
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 
 class SrcT(C.Structure):
@@ -54,7 +54,9 @@ SYMBOLS = [
     "lmn_se_fwd", "lmn_se_bwd", "lmn_na_fwd", "lmn_na_bwd", "lmn_gattn_fwd", "lmn_gattn_bwd",
     "lmn_ln_fwd", "lmn_ln_bwd", "lmn_bnact_fwd", "lmn_bnact_bwd_stats", "lmn_bnact_bwd",
     "lmn_bn_finalize", "lmn_bn_fold", "lmn_bn_bwd_coef", "lmn_up2_fwd", "lmn_up2_bwd", "lmn_avgpool_fwd", "lmn_avgpool_bwd",
-    "lmn_nchw_to_nhwc", "lmn_nhwc_to_nchw", "lmn_adamw_step", "lmn_segloss_fwd", "lmn_segloss_bwd", "lmn_confusion", "lmn_preprocess_u8", "lmn_fill", "lmn_add", "lmn_colsum", "lmn_copy_slice",
+    "lmn_nchw_to_nhwc", "lmn_nhwc_to_nchw", "lmn_adamw_step", "lmn_segloss_fwd", "lmn_segloss_bwd", "lmn_confusion", "lmn_preprocess_u8", "lmn_fill", "lmn_add", "lmn_colsum", "lmn_copy_slice", "lmn_copy2d",
+    "lmn_stream_wait", "lmn_event_record", "lmn_event_wait", "lmn_plan_create", "lmn_plan_destroy", "lmn_plan_record_begin", "lmn_plan_record_end", "lmn_plan_size",
+    "lmn_plan_run", "lmn_prof_begin", "lmn_prof_end",
 ]
 
 _lib = None
@@ -76,6 +78,10 @@ def load():
     lib.lmn_last_error.restype = C.c_char_p
     lib.lmn_conv_pack_size.restype = C.c_int64
     lib.lmn_conv_wgrad_workspace.restype = C.c_int64
+    lib.lmn_plan_create.restype = C.c_void_p
+    lib.lmn_plan_record_end.restype = C.c_int64
+    lib.lmn_plan_size.restype = C.c_int64
+    lib.lmn_prof_end.restype = C.c_int64
     if lib.lmn_abi_version() != ABI_VERSION:
         raise RuntimeError("lm_net_amd: ABI version mismatch")
     if (lib.lmn_sizeof_conv_args() != C.sizeof(ConvArgs) or lib.lmn_sizeof_src() != C.sizeof(SrcT)
@@ -98,6 +104,13 @@ def _p(t):
     if t.dtype != torch.float32:
         raise RuntimeError("lm_net_amd: fp32 tensor required, got %s" % t.dtype)
     return C.c_void_p(t.data_ptr())
+
+
+_ALLOC = [None]    # allocator of the pass in flight (engine.begin_pass): fn(device, shape) -> fp32 tensor
+
+
+def _default_alloc(device, shape):
+    return torch.empty(shape, device=device, dtype=torch.float32)
 
 
 _SEED_CTR = [None]  # device int32[1] added to every dropout seed (graph mode: bumped once per step), or None
@@ -256,24 +269,26 @@ def conv_pack(w, ksize, src_channels, out=None, persistent=False):
     return out
 
 
-def conv_pack_t(w, ksize, row_off=0, rows=None, out=None):
+def conv_pack_t(w, ksize, row_off=0, rows=None, out=None, cred=None):
     """Pack the data-gradient operator of a forward weight [Cout, Cin(,k,k)]: rows = input channels
-    [row_off, row_off+rows), reduction over Cout."""
+    [row_off, row_off+rows), reduction over Cout.  `rows` may exceed the weight's Cin and `cred` (channels of the dy
+    operand) its Cout by the zero padding to a multiple of 4 (RGB input as NHWC4, 2-class head on 4 rows)."""
     cout, cin = w.shape[0], w.shape[1]
     rows = cin - row_off if rows is None else rows
+    cred = cout if cred is None else cred
     planned = _planned(w, out, False)
     if planned:
-        key = (w.data_ptr(), ksize, (cout,), 1, row_off, rows)
+        key = (w.data_ptr(), ksize, (cred,), 1, row_off, rows)
         hit = _PLAN[0].lookup(key)
         if hit is not None:
             return hit
-    n = conv_pack_size(ksize, rows, [cout])
+    n = conv_pack_size(ksize, rows, [cred])
     if out is None:
         out = torch.empty(n, device=w.device, dtype=torch.float32)
-    arr = (C.c_int32 * 1)(cout)
+    arr = (C.c_int32 * 1)(cred)
     _check(load().lmn_conv_pack(_p(w), _p(out), ksize, cout, cin, 1, arr, 1, row_off, rows, _stream()), "conv_pack_t")
     if planned:
-        _PLAN[0].record(key, w, out, dict(w=w.data_ptr(), ksize=ksize, Cout=cout, Cin=cin, c=[cout],
+        _PLAN[0].record(key, w, out, dict(w=w.data_ptr(), ksize=ksize, Cout=cout, Cin=cin, c=[cred],
                                           transposed=1, row_off=row_off, rows=rows))
     return out
 
@@ -418,7 +433,7 @@ def na_bwd(qkv, rpb, dout, dqkv, drpb, heads, stat=None):
     B, H, W, C3 = qkv.shape
     hd = C3 // 3 // heads
     if stat is None:
-        stat = torch.empty(B * H * W * 2 * heads, device=qkv.device, dtype=torch.float32)
+        stat = (_ALLOC[0] or _default_alloc)(qkv.device, (B * H * W * 2 * heads,))
     _check(load().lmn_na_bwd(_p(qkv), _p(rpb), _p(dout), _p(dqkv), _p(drpb), _p(stat), B, H, W, heads, hd,
                              _f(hd ** -0.5), _stream()), "na_bwd")
 
@@ -593,3 +608,79 @@ def copy_slice(x, y):
     rows = x.t.numel() // x.cstride
     _check(load().lmn_copy_slice(C.c_void_p(x.ptr), C.c_void_p(y.ptr), _i64(rows), x.C, x.cstride, y.cstride, _stream()),
            "copy_slice")
+
+
+def copy2d(x, y, rows, cols, x_stride, y_stride):
+    """y[r][0:cols] = x[r][0:cols] (row strides in floats); any cols."""
+    _check(load().lmn_copy2d(_p(x), _p(y), _i64(rows), cols, x_stride, y_stride, _stream()), "copy2d")
+
+
+# ------------------------------------------------------------------------------------------ streams, plans, kernel timer
+def stream_wait(waiter, waited):
+    """`waiter` (torch stream) waits for everything enqueued on `waited` so far; recorded when a plan is recording."""
+    if waiter.cuda_stream == waited.cuda_stream:
+        return
+    _check(load().lmn_stream_wait(C.c_void_p(waiter.cuda_stream), C.c_void_p(waited.cuda_stream)), "stream_wait")
+
+
+def event_record(slot, stream):
+    _check(load().lmn_event_record(slot, C.c_void_p(stream.cuda_stream)), "event_record")
+
+
+def event_wait(slot, stream):
+    _check(load().lmn_event_wait(slot, C.c_void_p(stream.cuda_stream)), "event_wait")
+
+
+class Plan:
+    """A recorded pass (see include/lmnet_hip.h, lmn_plan_*): every C-ABI entry issued between record_begin() and
+    record_end() is remembered with its arguments; run() re-issues them in one FFI crossing."""
+
+    def __init__(self):
+        self.h = C.c_void_p(load().lmn_plan_create())
+        self.marks = []            # op counts at the segment boundaries reported during recording
+
+    def record_begin(self):
+        _check(load().lmn_plan_record_begin(self.h), "plan_record_begin")
+
+    def record_end(self, seal=True):
+        return int(load().lmn_plan_record_end(self.h, 1 if seal else 0))
+
+    def size(self):
+        return int(load().lmn_plan_size(self.h))
+
+    def mark(self):
+        self.marks.append(self.size())
+
+    def run(self, lo=0, hi=-1):
+        _check(load().lmn_plan_run(self.h, _i64(lo), _i64(hi)), "plan_run")
+
+    def __del__(self):
+        try:
+            if self.h is not None and _lib is not None:
+                _lib.lmn_plan_destroy(self.h)
+        except Exception:
+            pass
+        self.h = None
+
+
+def prof_begin(filter_=None):
+    """Time (HIP events on the launch stream) every kernel launch whose name contains one of the '|'-separated substrings."""
+    _check(load().lmn_prof_begin(filter_.encode() if filter_ else None), "prof_begin")
+
+
+def prof_end():
+    """-> {kernel name: dict(launches, total_us, flops, bytes)} since prof_begin (synchronises the device)."""
+    lib = load()
+    cap = 1 << 16
+    while True:
+        buf = C.create_string_buffer(cap)
+        need = int(lib.lmn_prof_end(buf, _i64(cap)))
+        if need <= cap:
+            break
+        cap = need + 16
+        # the records are kept until the next prof_begin: a second call re-reads them
+    out = {}
+    for line in buf.value.decode().splitlines():
+        name, n, us, fl, by = line.split("\t")
+        out[name] = dict(launches=int(n), total_us=float(us), flops=float(fl), bytes=float(by))
+    return out

@@ -24,6 +24,11 @@ class FusedAdamW(torch.optim.Optimizer):
         params = list(net.parameters())
         if not params or not params[0].is_cuda:
             raise RuntimeError("FusedAdamW: move the model to the GPU first (the HIP path has no CPU fallback)")
+        if any(not p.requires_grad for p in params):
+            # the one-launch update runs over the WHOLE flat buffer (moments, weight decay and step for every element);
+            # torch.optim.AdamW skips parameters without a gradient -- that case is not supported here
+            raise ValueError("FusedAdamW updates every parameter of LM_Net's flat buffer: parameters with "
+                             "requires_grad=False are not supported (use torch.optim.AdamW for partial fine-tuning)")
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
         self._flatten_parameters()
         self.exp_avg = torch.zeros_like(self.flat_p)
@@ -45,7 +50,7 @@ class FusedAdamW(torch.optim.Optimizer):
         """The model's flat gradient buffer if every p.grad is still its view, else a gathered copy."""
         L, net = self._layout, self.net
         flat = getattr(net, "_grad_flat", None)
-        ok = flat is not None and flat.numel() == L["total"]
+        ok = flat is not None and flat.numel() == L["total"] and all(p.requires_grad for p in L["order"][::37])
         if ok:
             for p in (L["order"][0], L["order"][-1], L["order"][len(L["order"]) // 2]):
                 a, _ = L["offs"][id(p)]

@@ -352,3 +352,83 @@ def test_inference_graph_replay_matches_eager_and_follows_the_weights():
         assert m._graphs == {}
         yd = m(x2)
         assert rel_err(yd, 2.0 * y2) < 1e-4
+
+
+def test_plan_mode_matches_host_launches():
+    """LM_Net.enable_plans(): every pass of a repeated shape as ONE lmn_plan_run (include/lmnet_hip.h) on the same four
+    streams as the host-launched schedule.  Same losses as host launches over 7 steps (steps 3+ are replays), BatchNorm
+    statistics advance once per step, gradients land in one static buffer that FusedAdamW consumes without a copy,
+    dropout masks are redrawn per replay, an eval forward in between and gradient accumulation behave as eager."""
+    from lm_net_amd.loss import SegLoss
+    from lm_net_amd.optim import FusedAdamW
+    x = det_input((2, 3, 64, 96), "plan/x").cuda()
+    y = disc_labels(2, 64, 96).cuda()
+    crit = SegLoss(label_smoothing=1e-3).cuda()
+
+    def run(m, n):
+        opt = FusedAdamW(m, lr=1e-3, weight_decay=1e-4)
+        out = []
+        for _ in range(n):
+            loss = crit(m(x), y)
+            opt.zero_grad(set_to_none=True)
+            loss.backward()
+            opt.step()
+            out.append(float(loss.detach()))
+        return out, opt
+
+    a, b = _net(seed=13).train(), _net(seed=13).train()
+    b.enable_plans()
+    (la, _), (lb, ob) = run(a, 7), run(b, 7)
+    ps = [p for p in b._plans.values() if p.fwd is not None]
+    assert len(ps) == 1 and ps[0].bwd is not None and ps[0].fwd.size() > 200 and ps[0].bwd.size() > 400
+    assert max(abs(u - v) / abs(u) for u, v in zip(la, lb)) < 2e-3, (la, lb)
+    assert ob._flat_grad().data_ptr() == ps[0].flat.data_ptr()          # the optimizer reads the static buffer in place
+    na_, nb = [[m for m in n.modules() if isinstance(m, torch.nn.BatchNorm2d)][0] for n in (a, b)]
+    assert int(nb.num_batches_tracked) == int(na_.num_batches_tracked) == 7
+    assert rel_err(nb.running_mean, na_.running_mean) < 5e-2
+    # exactness of a replay: same weights, same input -> the replayed step reproduces the host-launched gradients
+    c, d = _net(seed=17).train(), _net(seed=17).train()
+    d.enable_plans()
+    G = det_input((2, 2, 64, 96), "plan/G").cuda()
+    for it in range(5):
+        for m in (c, d):
+            for p in m.parameters():
+                p.grad = None
+            (m(x) * G).sum().backward()
+    gmax = max(float(p.grad.abs().max()) for p in c.parameters())
+
+    def same(u, v):     # float-atomic noise only (pre-BatchNorm biases have an exact gradient of 0: absolute scale)
+        return rel_err(u, v) < 2e-4 or float((u - v).abs().max()) < 1e-5 * gmax
+
+    for (k, pc), (_, pd) in zip(c.named_parameters(), d.named_parameters()):
+        assert same(pd.grad, pc.grad), k
+    # gradient accumulation into a .grad that aliases the static buffer: second backward adds
+    g1 = [p.grad.clone() for p in d.parameters()]
+    (d(x) * G).sum().backward()
+    for g, p in zip(g1, d.parameters()):
+        assert same(p.grad, 2 * g)
+    # an eval forward between a training forward and its backward neither disturbs the tape nor the BatchNorm mode
+    for p in d.parameters():
+        p.grad = None
+    out = d(x)
+    d.eval()
+    with torch.no_grad():
+        ye = [d(x) for _ in range(4)]                # eval plans: 2 eager, record, replay
+    d.train()
+    (out * G).sum().backward()
+    for (k, pc), (_, pd) in zip(c.named_parameters(), d.named_parameters()):
+        assert same(pd.grad, pc.grad), k
+    assert rel_err(ye[3], ye[0]) < 1e-5
+    # dropout on: replays must not repeat the mask
+    from lm_net_amd import LM_Net
+    e = LM_Net(3, 2)
+    fill_module(e, 11)
+    e = e.cuda().train().enable_plans()
+    outs = []
+    for _ in range(5):
+        o = e(x)
+        o.sum().backward()
+        outs.append(o.detach().clone())
+        for p in e.parameters():
+            p.grad = None
+    assert float((outs[3] - outs[4]).abs().max()) > 1e-3
