@@ -178,6 +178,9 @@ def main():
     ap.add_argument("--batch", type=int, default=8, help="images per GPU")
     ap.add_argument("--size", type=int, default=352)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"],
+                    help="arithmetic of the dense contractions: f32 (BASELINE configs[1], the headline) or bf16 matrix-core operands "
+                         "with fp32 accumulation / statistics / master weights (BASELINE configs[2]; run with --batch 64)")
     ap.add_argument("--plans", action="store_true",
                     help="replay the step as recorded C-side schedules (LM_Net.enable_plans(): one lmn_plan_run per pass on the "
                          "same four streams; host cost ~2 ms per step instead of 16-20)")
@@ -203,6 +206,7 @@ def main():
     from lm_net_amd.ddp import DistributedLMNet
     torch.manual_seed(1234)
     net = LM_Net(3, 2).to(dev)
+    net.compute_dtype = "bf16" if args.dtype == "bf16" else "fp32"
     model = DistributedLMNet(net) if world > 1 else net
     model.train()
     if args.plans:
@@ -273,9 +277,11 @@ def main():
             "metric": "train images/sec at 352x352, 1/2/4/8 MI355X; Dice vs ref",
             "value": round(world * B * args.steps / dt, 2), "unit": "images/sec", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(step_s * 1e3, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "LM-Net fp32 training step (fwd + CE/Dice loss + bwd + AdamW), batch %d/GPU, %dx%d "
-                                   "synthetic disc masks (BASELINE configs[1])" % (B, H, W),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": "LM-Net %s training step (fwd + CE/Dice loss + bwd + AdamW), batch %d/GPU, %dx%d "
+                                   "synthetic disc masks (BASELINE configs[%d])" % (
+                                       "fp32" if args.dtype == "f32" else "bf16 mixed-precision (bf16 MFMA operands, fp32 accumulate / "
+                                       "statistics / master weights)", B, H, W, 1 if args.dtype == "f32" else 2),
                        "global_batch": world * B, "image": [3, H, W], "parallelism": "dp%d" % world,
                        "launch": "hipGraph replay (fwd + bwd graphs per step)" if args.graphs else
                                  ("lmn_plan_run (recorded C-side schedule, one crossing per pass)" if args.plans else "host"),

@@ -34,6 +34,10 @@ extern "C" {
 typedef void* lmn_stream_t; /* hipStream_t */
 
 #define LMN_ABI_VERSION 4
+/* arithmetic type of the matrix-core operands of a dense contraction (accumulators, epilogues, statistics: fp32) */
+#define LMN_F32 0  /* v_mfma_f32_16x16x4_f32: exact fp32 (k-ordered fma chain)                                  */
+#define LMN_BF16 1 /* v_mfma_f32_16x16x16_bf16: operands rounded to bf16 (RNE) when staged / packed -- the mixed- */
+                   /* precision path (reference: torch.cuda.amp.autocast, utils/train_eval_utils.py:130-138)      */
 #define LMN_E_BADARG (-1)
 #define LMN_E_UNSUPPORTED (-2)
 
@@ -115,9 +119,10 @@ typedef struct {
   const float* bias2;       /* second [Cout] bias or NULL: one conv over two sources stands for two biased    */
                             /* convs (pointwise_conv + shortcut, core/modules.py:597-599)                     */
   int32_t stats_rep;        /* > 1 (SUM_SQ and BN_BWD1 statistics only): `stats` holds stats_rep slices of     */
-  int32_t _pad0;            /* [2][Cout]; block b adds into slice b % stats_rep (1280 blocks adding to the same */
+  int32_t mma_dtype;        /* [2][Cout]; block b adds into slice b % stats_rep (1280 blocks adding to the same */
                             /* 2 cache lines cost 15-20 us of same-address atomics); the consumers              */
                             /* (lmn_bn_finalize / lmn_bn_bwd_coef, argument nrep) sum the slices                */
+                            /* mma_dtype: LMN_F32 | LMN_BF16 -- `wpack` must have been packed with the same dtype */
 } lmn_conv_args_t;
 
 /* number of floats lmn_conv_pack writes for (ksize, Cout, src channel counts c[nsrc]) */
@@ -128,7 +133,8 @@ int64_t lmn_conv_pack_size(int ksize, int Cout, int nsrc, const int32_t* c);
  *   `c` then lists ONE entry = Cout of the forward conv, `row_off`/`rows` select the slice of
  *   forward input channels whose gradient is produced (one call per forward source).        */
 int lmn_conv_pack(const float* w, float* wpack, int ksize, int Cout, int Cin, int nsrc, const int32_t* c,
-                  int transposed, int row_off, int rows, lmn_stream_t stream);
+                  int transposed, int row_off, int rows, int dtype /* LMN_F32 | LMN_BF16: half the bytes */,
+                  lmn_stream_t stream);
 /* The same packing for MANY weights in one launch (weights change every optimizer step, so a training step
  * re-packs every dense weight of the net: one launch instead of ~190).  `jobs_dev` is a DEVICE array of njobs
  * descriptors sorted by first_block, where job j owns blocks [first_block_j, first_block_j + ceil(total_j/1024))
@@ -141,7 +147,8 @@ typedef struct {
   int32_t ksize, Cout, Cin, nsrc;
   int32_t c[3];
   int32_t transposed, row_off, rows;
-  int32_t _pad[2];
+  int32_t dtype; /* LMN_F32 | LMN_BF16 */
+  int32_t _pad;
 } lmn_pack_job_t;
 int lmn_sizeof_pack_job(void);
 int lmn_conv_pack_batch(const lmn_pack_job_t* jobs_dev, int njobs, int64_t total_blocks, lmn_stream_t stream);
@@ -170,6 +177,8 @@ typedef struct {
                     /* pointwise_conv + shortcut); NULL entries fall back to the columns of dW (may be NULL if */
                     /* every source has its own tensor)                                                        */
   float* db2;       /* optional second bias gradient receiving the same sum as db                              */
+  int32_t mma_dtype; /* LMN_F32 | LMN_BF16: operand type of the pixel-reduction MFMAs (accumulators fp32)                */
+  int32_t _pad;
 } lmn_wgrad_args_t;
 int lmn_sizeof_wgrad_args(void);
 /* floats of workspace that make lmn_conv_wgrad use the two-stage reduction for this problem (0: not useful) */

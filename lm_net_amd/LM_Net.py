@@ -150,6 +150,10 @@ class LM_Net(nn.Module):
         self._taps = None
         self.use_graphs = False   # capture the training step into hipGraphs (see enable_graphs)
         self._graphs = {}
+        # arithmetic of the dense contractions: None = follow torch.autocast (bf16 / fp16 autocast -> bf16 matrix-core
+        # operands, else fp32), or "fp32" / "bf16" to pin it (custom autograd nodes are opaque to autocast, so the module
+        # reads the autocast state itself: the reference's AMP branch, utils/train_eval_utils.py:130-138, keeps working)
+        self.compute_dtype = None
         self.use_plans = False    # replay recorded C-side schedules (see enable_plans)
         self._plans = {}
         self._head_bias4 = None
@@ -183,6 +187,7 @@ class LM_Net(nn.Module):
         if params and not params[0].is_cuda:
             raise RuntimeError("lm_net_amd.LM_Net: parameters are on %s; call model.to('cuda')" % params[0].device)
         x = x.float().contiguous() if x.dtype != torch.float32 or not x.is_contiguous() else x
+        self._engine.mma = self._mma_mode()
         self._save_tape = torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in params))
         if self.use_plans and not x.requires_grad and not self._keep_taps and (self._save_tape or not torch.is_grad_enabled()):
             ps = self._plan_for(x)
@@ -199,6 +204,17 @@ class LM_Net(nn.Module):
             if out is not None:
                 return out
         return _LMNetFunction.apply(x, self, *params)
+
+    def _mma_mode(self):
+        cd = self.compute_dtype
+        if cd is None:
+            amp = torch.is_autocast_enabled() and torch.get_autocast_dtype('cuda') in (torch.bfloat16, torch.float16)
+            return hip.BF16 if amp else hip.F32
+        if cd in ("bf16", "bfloat16", torch.bfloat16):
+            return hip.BF16
+        if cd in ("fp32", "f32", "float32", torch.float32):
+            return hip.F32
+        raise ValueError("LM_Net.compute_dtype must be None, 'fp32' or 'bf16' (got %r)" % (cd,))
 
     # ------------------------------------------------------------------ recorded C-side schedules (lmn_plan_*)
     def enable_plans(self, on=True):
@@ -217,7 +233,7 @@ class LM_Net(nn.Module):
 
     def _plan_for(self, x):
         train = bool(self.training and self._save_tape)
-        key = (tuple(x.shape), x.device, self.training, self._save_tape)
+        key = (tuple(x.shape), x.device, self.training, self._save_tape, self._engine.mma)
         ps = self._plans.get(key)
         if ps is None:
             ps = self._plans[key] = _PlannedStep()
@@ -259,6 +275,7 @@ class LM_Net(nn.Module):
             self._step_bookkeeping()
             if ps.cx is not None:
                 ps.cx.training = self.training
+                ps.cx.mma = eng.mma
             ps.fwd.run()
         ps.pending = ps.cx is not None
         return ps.out.clone()
@@ -332,7 +349,7 @@ class LM_Net(nn.Module):
         launch-minimal inference schedule).  Two eager calls of a shape warm the workspaces up, the third is captured;
         weight packing and BatchNorm folding are kernels inside the graph, so parameter / running-stat updates between
         calls are honoured; `structural_reparam()` drops the graphs.  Returns None while warming up."""
-        key = ("infer", tuple(x.shape), x.device)
+        key = ("infer", tuple(x.shape), x.device, self._engine.mma)
         gs = self._graphs.get(key)
         if gs is None:
             gs = self._graphs[key] = _GraphedStep()
@@ -355,7 +372,7 @@ class LM_Net(nn.Module):
         return gs.out.clone()
 
     def _graph_for(self, x):
-        key = (tuple(x.shape), x.device)
+        key = (tuple(x.shape), x.device, self._engine.mma)
         gs = self._graphs.get(key)
         if gs is None:
             gs = self._graphs[key] = _GraphedStep()
@@ -412,6 +429,7 @@ class LM_Net(nn.Module):
         eng.training = self.training
         if cx is not None:
             cx.training = self.training             # the backward of THIS pass uses the BatchNorm mode it ran in
+            cx.mma = eng.mma                        # ... and the same matrix-core operand type
         self._step_bookkeeping()
         with torch.cuda.device(x.device):
             eng.begin_pass(False, x.device)
@@ -421,11 +439,12 @@ class LM_Net(nn.Module):
                 nf = eng.alloc_floats
                 eng.end_pass()
         if self.use_plans:
-            ps = self._plans.get((tuple(x.shape), x.device, self.training, self._save_tape))
+            key = (tuple(x.shape), x.device, self.training, self._save_tape, eng.mma)
+            ps = self._plans.get(key)
             if ps is not None:
                 ps.need_fwd = max(ps.need_fwd, nf)
                 if cx is not None:
-                    cx.plan_key = (tuple(x.shape), x.device, self.training, self._save_tape)
+                    cx.plan_key = key
         return out
 
     def _forward_body(self, x, cx):
@@ -598,6 +617,7 @@ class LM_Net(nn.Module):
             raise RuntimeError("backward called on a forward pass that saved no state")
         eng = self._engine
         eng.training = getattr(cx, "training", eng.training)     # the mode of the forward this tape belongs to
+        eng.mma = getattr(cx, "mma", eng.mma)
         with torch.cuda.device(dlogits.device):
             if plan is None:
                 flat, G = self._new_grads()

@@ -44,6 +44,27 @@ struct ConvParams {
 
 __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 
+// ---- bf16 operand forms (mixed-precision path: bf16 MFMA operands, fp32 accumulators / epilogues / statistics)
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pk_bf16(float a, float b) {  // one v_cvt_pk_bf16_f32 (round to nearest even, NaN kept)
+  const f32x2_t t = {a, b};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(t, bf16x2_t));
+}
+__device__ __forceinline__ uint2 pk4_bf16(f32x4 v) { return uint2{pk_bf16(v[0], v[1]), pk_bf16(v[2], v[3])}; }
+// MFMA operand fragment of one K16 block: fp32 path = 4 floats (one per v_mfma_f32_16x16x4_f32, blocked channel order),
+// bf16 path = 4 bf16 (channels 4q..4q+3 of the lane's row, ONE v_mfma_f32_16x16x16_bf16)
+template <bool BF> struct Frag { typedef f32x4 type; };
+template <> struct Frag<true> { typedef uint2 type; };
+template <bool BF> __device__ __forceinline__ typename Frag<BF>::type ldfrag(const float* p) {
+  if constexpr (BF) return *reinterpret_cast<const uint2*>(p);
+  else return *reinterpret_cast<const f32x4*>(p);
+}
+__device__ __forceinline__ f32x4 mfma_bf16(uint2 a, uint2 b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s16x4, a), __builtin_bit_cast(s16x4, b), c, 0, 0, 0);
+}
+
 // ------------------------------------------------------------------------------------ LDS-tiled forward / data-gradient
 // Implicit-GEMM convolution on v_mfma_f32_16x16x4_f32 (M = cout tile: a lane holds 4 consecutive output channels of one
 // pixel), structured for latency and registers:
@@ -57,8 +78,13 @@ __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<
 // stride-1 problem over dy with a 1x1 / 1x2 / 2x1 / 2x2 sub-kernel: in = out_c + ((parity + pad - t) >> 1) for the taps of
 // matching parity.  The tile walks CLASS coordinates, the window is TH+1 x TW+1 pixels of dy, outputs land at
 // (2*yc + py, 2*xc + px).
-template <int TAPS, int NCT, int EPI, bool S2T = false>
+template <int TAPS, int NCT, int EPI, bool S2T = false, bool BF = false>
 __global__ __launch_bounds__(256) void conv_tile_kernel(const ConvParams P) {
+  // BF: operands rounded to bf16 when they are staged / packed, v_mfma_f32_16x16x16_bf16 (8x the fp32 MFMA rate), the LDS
+  // window holds 4-bf16 fragments (pixel stride P.CS dwords = 8 per K16 block + 4: conflict-free ds_read_b64)
+  typedef typename Frag<BF>::type wfrag;
+  constexpr int WT = BF ? 128 : 256;   // floats per packed weight fragment tile (64 lanes x 8 or 16 bytes)
+  constexpr int KD = BF ? 8 : 16;      // LDS dwords per K16 block of a pixel
   const lmn_conv_args_t& A = P.a;
   const uint32_t soff = A.seed_ctr ? *A.seed_ctr : 0u;  // device-side dropout stream offset (graph replays: one bump per step)
   // EPI: 0 plain (LINEAR / AFFINE_ACT, no statistics), 1 generic, 2 LINEAR + SUM_SQ statistics, 3 BN_BWD1, 4 BN_BWD2,
@@ -92,10 +118,10 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(const ConvParams P) {
         ++s2_n;
       }
   }
-  const float* wlane = A.wpack + lane * 4;
+  const float* wlane = A.wpack + lane * (BF ? 2 : 4);
   int wtile[NCT];  // cout tiles past the end re-read the last real tile (results dropped in the epilogue)
 #pragma unroll
-  for (int c = 0; c < NCT; ++c) wtile[c] = min(ct0 + c, P.NCTT - 1) * 256;
+  for (int c = 0; c < NCT; ++c) wtile[c] = min(ct0 + c, P.NCTT - 1) * WT;
 
   for (int i = tid; i < 2 * NCT * 16; i += 256) s_stats[i] = 0.f;
   float st0[NCT][4], st1[NCT][4];
@@ -143,7 +169,7 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(const ConvParams P) {
       pvalid[g] = in_t && oy < A.Hout && ox < A.Wout;
       opix[g] = pvalid[g] ? (b * A.Hout + oy) * A.Wout + ox : 0;
       const int sr = (S2T || A.transposed) ? r : r * A.stride, sc = (S2T || A.transposed) ? c : c * A.stride;
-      pbase[g] = (sr * P.XW + sc) * P.CS + q * 4;
+      pbase[g] = (sr * P.XW + sc) * P.CS + q * (BF ? 2 : 4);
     }
     const bool g1 = (wv + 4) < P.NG;  // wave-uniform: second group exists
 
@@ -158,11 +184,11 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(const ConvParams P) {
       for (int kb0 = 0; kb0 < P.nkb[s]; kb0 += P.CKB) {
         const int nkbc = P.nkb[s] - kb0 < P.CKB ? P.nkb[s] - kb0 : P.CKB;
         const int ksh = nkbc - 1, niter = (S2T ? s2_n : TAPS) * nkbc;  // step it = (tap, kk): tap = it >> ksh, kk = it & ksh (nkbc is 1 or 2)
-        f32x4 wcur[NCT];
+        wfrag wcur[NCT];
         {
-          const float* wp = wlane + (((int64_t)(S2T ? s2_wt[0] : 0) * P.NKB + P.kb_off[s] + kb0) * P.NCTT) * 256;
+          const float* wp = wlane + (((int64_t)(S2T ? s2_wt[0] : 0) * P.NKB + P.kb_off[s] + kb0) * P.NCTT) * WT;
 #pragma unroll
-          for (int c = 0; c < NCT; ++c) wcur[c] = ld4(wp + wtile[c]);
+          for (int c = 0; c < NCT; ++c) wcur[c] = ldfrag<BF>(wp + wtile[c]);
         }
         __syncthreads();  // previous chunk / tile fully consumed
         // ---- stage the window chunk: unconditional float4 loads from clamped addresses, transforms, zero padding
@@ -186,7 +212,9 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(const ConvParams P) {
           }
           if (S.scale) v *= ld4(S.scale + b * S.C + chs);
           if (!ok) v = f32x4{0.f, 0.f, 0.f, 0.f};
-          {  // blocked K layout: channel 4*fl + r of its K16 block sits at position 4*r + fl (MFMA j reads channel 4j + q)
+          if constexpr (BF) {  // natural channel order, 4 bf16 = one 8-byte fragment slot
+            *reinterpret_cast<uint2*>(&XS[pix * P.CS + f * 2]) = pk4_bf16(v);
+          } else {  // blocked K layout: channel 4*fl + r of its K16 block sits at position 4*r + fl (MFMA j reads channel 4j + q)
             float* d = &XS[pix * P.CS + (f >> 2) * 16 + (f & 3)];
             d[0] = v[0]; d[4] = v[1]; d[8] = v[2]; d[12] = v[3];
           }
@@ -196,20 +224,27 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(const ConvParams P) {
         //      (the first fetch was issued before the staging loop), so no L2 latency is exposed inside the loop
         for (int it = 0; it < niter; ++it) {
           const int itn = it + 1 < niter ? it + 1 : it;
-          f32x4 wnext[NCT];
+          wfrag wnext[NCT];
           {
             const int tapi = itn >> ksh, kkn = itn & ksh;
             const int tapn = S2T ? s2_wt[tapi & 3] : tapi;
-            const float* wp = wlane + (((int64_t)tapn * P.NKB + P.kb_off[s] + kb0 + kkn) * P.NCTT) * 256;
+            const float* wp = wlane + (((int64_t)tapn * P.NKB + P.kb_off[s] + kb0 + kkn) * P.NCTT) * WT;
 #pragma unroll
-            for (int c = 0; c < NCT; ++c) wnext[c] = ld4(wp + wtile[c]);
+            for (int c = 0; c < NCT; ++c) wnext[c] = ldfrag<BF>(wp + wtile[c]);
           }
           const int tap = it >> ksh, kk = it & ksh;
           const int ty = tap / KS, tx = tap - ty * KS;
           const int fy = A.transposed ? KS - 1 - ty : ty, fx = A.transposed ? KS - 1 - tx : tx;
           const int toff = S2T ? s2_off[tap & 3] * P.CS : (fy * P.XW + fx) * P.CS;
-          const f32x4 x0 = *reinterpret_cast<const f32x4*>(&XS[pbase[0] + toff + kk * 16]);
-          const f32x4 x1 = *reinterpret_cast<const f32x4*>(&XS[pbase[1] + toff + kk * 16]);
+          const wfrag x0 = ldfrag<BF>(&XS[pbase[0] + toff + kk * KD]);
+          const wfrag x1 = ldfrag<BF>(&XS[pbase[1] + toff + kk * KD]);
+          if constexpr (BF) {
+#pragma unroll
+            for (int c = 0; c < NCT; ++c) {
+              acc[0][c] = mfma_bf16(wcur[c], x0, acc[0][c]);
+              acc[1][c] = mfma_bf16(wcur[c], x1, acc[1][c]);
+            }
+          } else {
           const int nj = (S.C - (kb0 + kk) * 16 + 3) >> 2;  // K slices of this block that hold channels (wave-uniform)
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
@@ -221,6 +256,7 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(const ConvParams P) {
                 acc[1][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(wcur[c][j], x1[j], acc[1][c], 0, 0, 0);
               }
             }
+          }
           }
 #pragma unroll
           for (int c = 0; c < NCT; ++c) wcur[c] = wnext[c];
@@ -331,8 +367,11 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(const ConvParams P) {
 // Each weight fragment is then fetched by exactly one wave of the block (the N-split form pulls every fragment
 // through L1 four times; at Cout = 372 that stream, not the MFMAs, set the pace) and feeds 8 x 4 MFMAs; the pixel
 // operand comes from LDS, where re-reading it per wave is cheap.
-template <int TAPS, int NCW, int EPI>
+template <int TAPS, int NCW, int EPI, bool BF = false>
 __global__ __launch_bounds__(256) void conv_tileM_kernel(const ConvParams P) {
+  typedef typename Frag<BF>::type wfrag;  // (bf16 operand form: see conv_tile_kernel)
+  constexpr int WT = BF ? 128 : 256;
+  constexpr int KD = BF ? 8 : 16;
   constexpr int NCT = 4 * NCW;  // cout tiles per block
   const lmn_conv_args_t& A = P.a;
   const uint32_t soff = A.seed_ctr ? *A.seed_ctr : 0u;  // device-side dropout stream offset (graph replays: one bump per step)
@@ -353,10 +392,10 @@ __global__ __launch_bounds__(256) void conv_tileM_kernel(const ConvParams P) {
   const int ct0 = blockIdx.y * NCT;
   const int pad = A.ksize >> 1;
   constexpr int KS = TAPS == 9 ? 3 : 1;
-  const float* wlane = A.wpack + lane * 4;
+  const float* wlane = A.wpack + lane * (BF ? 2 : 4);
   int wtile[NCW];  // cout tiles past the end (last chunk) re-read the last real tile: loads stay unconditional, in bounds
 #pragma unroll
-  for (int c = 0; c < NCW; ++c) wtile[c] = min(ct0 + wv + 4 * c, P.NCTT - 1) * 256;
+  for (int c = 0; c < NCW; ++c) wtile[c] = min(ct0 + wv + 4 * c, P.NCTT - 1) * WT;
 
   for (int i = tid; i < 2 * NCT * 16; i += 256) s_stats[i] = 0.f;
   float st0[NCW][4], st1[NCW][4];
@@ -405,7 +444,7 @@ __global__ __launch_bounds__(256) void conv_tileM_kernel(const ConvParams P) {
       pvalid[g] = in_t && oy < A.Hout && ox < A.Wout;
       opix[g] = pvalid[g] ? (b * A.Hout + oy) * A.Wout + ox : 0;
       const int sr = A.transposed ? r : r * A.stride, sc = A.transposed ? c : c * A.stride;
-      pbase[g] = (sr * P.XW + sc) * P.CS + q * 4;
+      pbase[g] = (sr * P.XW + sc) * P.CS + q * (BF ? 2 : 4);
     }
     f32x4 acc[NGM][NCW];
 #pragma unroll
@@ -418,11 +457,11 @@ __global__ __launch_bounds__(256) void conv_tileM_kernel(const ConvParams P) {
       for (int kb0 = 0; kb0 < P.nkb[s]; kb0 += P.CKB) {
         const int nkbc = P.nkb[s] - kb0 < P.CKB ? P.nkb[s] - kb0 : P.CKB;
         const int ksh = nkbc - 1, niter = TAPS * nkbc;  // step it = (tap, kk): tap = it >> ksh, kk = it & ksh (nkbc is 1 or 2)
-        f32x4 wcur[NCW];
+        wfrag wcur[NCW];
         {
-          const float* wp = wlane + ((int64_t)(P.kb_off[s] + kb0) * P.NCTT) * 256;
+          const float* wp = wlane + ((int64_t)(P.kb_off[s] + kb0) * P.NCTT) * WT;
 #pragma unroll
-          for (int c = 0; c < NCW; ++c) wcur[c] = ld4(wp + wtile[c]);
+          for (int c = 0; c < NCW; ++c) wcur[c] = ldfrag<BF>(wp + wtile[c]);
         }
         __syncthreads();  // previous chunk / tile fully consumed
         // ---- stage the window chunk: unconditional float4 loads from clamped addresses, transforms, zero padding
@@ -446,7 +485,9 @@ __global__ __launch_bounds__(256) void conv_tileM_kernel(const ConvParams P) {
           }
           if (S.scale) v *= ld4(S.scale + b * S.C + chs);
           if (!ok) v = f32x4{0.f, 0.f, 0.f, 0.f};
-          {  // blocked K layout: channel 4*fl + r of its K16 block sits at position 4*r + fl (MFMA j reads channel 4j + q)
+          if constexpr (BF) {  // natural channel order, 4 bf16 = one 8-byte fragment slot
+            *reinterpret_cast<uint2*>(&XS[pix * P.CS + f * 2]) = pk4_bf16(v);
+          } else {  // blocked K layout: channel 4*fl + r of its K16 block sits at position 4*r + fl (MFMA j reads channel 4j + q)
             float* d = &XS[pix * P.CS + (f >> 2) * 16 + (f & 3)];
             d[0] = v[0]; d[4] = v[1]; d[8] = v[2]; d[12] = v[3];
           }
@@ -456,12 +497,12 @@ __global__ __launch_bounds__(256) void conv_tileM_kernel(const ConvParams P) {
         //      fetch was issued before the staging loop)
         for (int it = 0; it < niter; ++it) {
           const int itn = it + 1 < niter ? it + 1 : it;
-          f32x4 wnext[NCW];
+          wfrag wnext[NCW];
           {
             const int tapn = itn >> ksh, kkn = itn & ksh;
-            const float* wp = wlane + (((int64_t)tapn * P.NKB + P.kb_off[s] + kb0 + kkn) * P.NCTT) * 256;
+            const float* wp = wlane + (((int64_t)tapn * P.NKB + P.kb_off[s] + kb0 + kkn) * P.NCTT) * WT;
 #pragma unroll
-            for (int c = 0; c < NCW; ++c) wnext[c] = ld4(wp + wtile[c]);
+            for (int c = 0; c < NCW; ++c) wnext[c] = ldfrag<BF>(wp + wtile[c]);
           }
           const int tap = it >> ksh, kk = it & ksh;
           const int ty = tap / KS, tx = tap - ty * KS;
@@ -471,11 +512,16 @@ __global__ __launch_bounds__(256) void conv_tileM_kernel(const ConvParams P) {
 #pragma unroll
           for (int g = 0; g < NGM; ++g) {
             if (g < P.NG) {
-              const f32x4 xg = *reinterpret_cast<const f32x4*>(&XS[pbase[g] + toff + kk * 16]);
+              const wfrag xg = ldfrag<BF>(&XS[pbase[g] + toff + kk * KD]);
+              if constexpr (BF) {
+#pragma unroll
+                for (int c = 0; c < NCW; ++c) acc[g][c] = mfma_bf16(wcur[c], xg, acc[g][c]);
+              } else {
 #pragma unroll
               for (int c = 0; c < NCW; ++c)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) acc[g][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(wcur[c][j], xg[j], acc[g][c], 0, 0, 0);
+              }
             }
           }
 #pragma unroll
@@ -586,6 +632,7 @@ __global__ __launch_bounds__(256) void conv_tileM_kernel(const ConvParams P) {
 // ------------------------------------------------------------------------------------ weight packing
 struct PackGeom {
   int taps, Cout, Cin, nsrc, cs[3], transposed, row_off, rows;
+  int bf16;  // 1: fragment order of v_mfma_f32_16x16x16_bf16 (lane (q, n) holds channels 4q..4q+3), elements stored as bf16
 };
 
 // One element i of the packed stream [tap][K16 block][cout tile][64 lanes][4].
@@ -612,7 +659,7 @@ __device__ __forceinline__ float pack_element(const float* __restrict__ w, const
   while (s + 1 < g.nsrc && kb >= kboff[s + 1]) ++s;
   // MFMA j of a K16 block covers channels 4j .. 4j+3 (k slot = lane >> 4): a source whose last block holds fewer than
   // 16 channels leaves whole MFMAs zero, which the kernels skip (12 channels: 3 of 4)
-  const int kk = (kb - kboff[s]) * 16 + j * 4 + (lane >> 4);  // reduction index inside the source
+  const int kk = (kb - kboff[s]) * 16 + (g.bf16 ? (lane >> 4) * 4 + j : j * 4 + (lane >> 4));  // reduction index inside the source
   const int row = ct * 16 + (lane & 15);
   float v = 0.f;
   // (a source / row count may be the weight's padded to a multiple of 4 -- the RGB input travels as NHWC4, the 2-class
@@ -627,9 +674,14 @@ __device__ __forceinline__ float pack_element(const float* __restrict__ w, const
   return v;
 }
 
+__device__ __forceinline__ void pack_store(float* __restrict__ wp, int64_t i, float v, int bf16) {
+  if (bf16) reinterpret_cast<__bf16*>(wp)[i] = (__bf16)v;
+  else wp[i] = v;
+}
+
 __global__ void conv_pack_kernel(const float* __restrict__ w, float* __restrict__ wp, const PackGeom g, int64_t total) {
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x)
-    wp[i] = pack_element(w, g, i);
+    pack_store(wp, i, pack_element(w, g, i), g.bf16);
 }
 
 // All weights of a pass in ONE launch: block b finds its job by bisection over the jobs' first-block table, then
@@ -646,11 +698,12 @@ __global__ __launch_bounds__(256) void conv_pack_batch_kernel(const lmn_pack_job
   g.taps = J.ksize * J.ksize; g.Cout = J.Cout; g.Cin = J.Cin; g.nsrc = J.nsrc;
   g.cs[0] = J.c[0]; g.cs[1] = J.c[1]; g.cs[2] = J.c[2];
   g.transposed = J.transposed; g.row_off = J.row_off; g.rows = J.rows;
+  g.bf16 = J.dtype == LMN_BF16;
   const int64_t base = (b - J.first_block) * 1024;
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int64_t i = base + r * 256 + threadIdx.x;
-    if (i < J.total) J.wpack[i] = pack_element(J.w, g, i);
+    if (i < J.total) pack_store(J.wpack, i, pack_element(J.w, g, i), g.bf16);
   }
 }
 
@@ -690,7 +743,10 @@ __device__ __forceinline__ float* wgrad_dst(const WgradParams& P, int co, int si
 // operands from LDS as conflict-free ds_read_b32 (lanes along channels; pixel stride = 16 mod 32 banks).
 // One global load per element instead of one per (element, tap): the direct form was bound by the texture
 // addresser (one 4-segment dword load per MFMA).  Accumulators stay in registers across all tiles of the block.
-template <int TAPS, int NMT, int NNT>
+// BF: operands rounded to bf16 when staged ([tile][pixel][16 bf16] planes, pixel stride CS dwords), a K step is 16 pixels
+// = ONE v_mfma_f32_16x16x16_bf16 per (tap, cout tile, cin tile): lane (q, n) gathers pixels 4q..4q+3 of channel n with
+// four ds_read_u16 per operand (the same LDS instruction count per pixel as the fp32 form, an eighth of its MFMA time).
+template <int TAPS, int NMT, int NNT, bool BF = false>
 __global__ __launch_bounds__(256, 2) void wgrad_lds_kernel(const WgradParams P) {
   const lmn_wgrad_args_t& A = P.a;
   const uint32_t soff = A.seed_ctr ? *A.seed_ctr : 0u;  // device-side dropout stream offset (graph replays: one bump per step)
@@ -825,7 +881,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_lds_kernel(const WgradParams P) 
             }
             if (tscale[t]) w *= ld4(tscale[t] + (inb ? b : 0) * tC[t] + chs);
             if (!ok) w = f32x4{0.f, 0.f, 0.f, 0.f};
-            *reinterpret_cast<f32x4*>(&XS[(t * XP + pix) * P.CSx + j * 4]) = w;
+            if constexpr (BF) *reinterpret_cast<uint2*>(&XS[(t * XP + pix) * P.CSx + j * 2]) = pk4_bf16(w);
+            else *reinterpret_cast<f32x4*>(&XS[(t * XP + pix) * P.CSx + j * 4]) = w;
           }
         }
       }
@@ -847,12 +904,62 @@ __global__ __launch_bounds__(256, 2) void wgrad_lds_kernel(const WgradParams P) 
               for (int k = 0; k < 4; ++k) w[k] *= lmn_drop_scale(A.dy_seed + soff, (uint32_t)(gp * A.Cout + cos + k), A.dy_p, P.inv_keep_dy);
             }
             if (!(inb && cok)) w = f32x4{0.f, 0.f, 0.f, 0.f};
-            *reinterpret_cast<f32x4*>(&YS[(m * NP + pix) * P.CSy + j * 4]) = w;
+            if constexpr (BF) *reinterpret_cast<uint2*>(&YS[(m * NP + pix) * P.CSy + j * 2]) = pk4_bf16(w);
+            else *reinterpret_cast<f32x4*>(&YS[(m * NP + pix) * P.CSy + j * 4]) = w;
           }
         }
       }
     }
     __syncthreads();
+    if constexpr (BF) {
+      // ---- bf16: K steps of 16 consecutive tile pixels; lane (q, n) owns pixels 4q..4q+3 of the step, channel n
+      const uint16_t* XH16 = reinterpret_cast<const uint16_t*>(XS);
+      const uint16_t* YH16 = reinterpret_cast<const uint16_t*>(YS);
+      for (int ks = wv; ks * 16 < NP; ks += 4) {
+        int xb[4];
+        bool pin[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int pix = ks * 16 + q * 4 + j;
+          pin[j] = pix < NP;
+          const int pixs = pin[j] ? pix : 0;
+          if constexpr (TAPS == 1) {
+            xb[j] = pixs * P.CSx * 2 + n;
+          } else {
+            const int pr = (int)__umulhi((uint32_t)pixs, P.mTW), pc = pixs - pr * P.TW;
+            xb[j] = ((pr * A.stride) * P.XW + pc * A.stride) * P.CSx * 2 + n;
+          }
+        }
+        uint2 av[NMT], bvv[TAPS][NNT];
+#pragma unroll
+        for (int m = 0; m < NMT; ++m) {
+          uint32_t h[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int pixs = pin[j] ? ks * 16 + q * 4 + j : 0;
+            h[j] = pin[j] ? (uint32_t)YH16[(m * NP + pixs) * P.CSy * 2 + n] : 0u;
+            bsum[m] += __builtin_bit_cast(float, h[j] << 16);
+          }
+          av[m] = uint2{h[0] | (h[1] << 16), h[2] | (h[3] << 16)};
+        }
+#pragma unroll
+        for (int tp = 0; tp < TAPS; ++tp) {
+          const int ty = (TAPS == 9) ? tp / 3 : 0, tx = (TAPS == 9) ? tp % 3 : 0;
+#pragma unroll
+          for (int t = 0; t < NNT; ++t) {
+            const int toff = (t * XP + ty * P.XW + tx) * P.CSx * 2;
+            const uint32_t h0 = XH16[xb[0] + toff], h1 = XH16[xb[1] + toff], h2 = XH16[xb[2] + toff], h3 = XH16[xb[3] + toff];
+            bvv[tp][t] = uint2{h0 | (h1 << 16), h2 | (h3 << 16)};
+          }
+        }
+#pragma unroll
+        for (int tp = 0; tp < TAPS; ++tp)
+#pragma unroll
+          for (int t = 0; t < NNT; ++t)
+#pragma unroll
+            for (int m = 0; m < NMT; ++m) acc[tp][m][t] = mfma_bf16(av[m], bvv[tp][t], acc[tp][m][t]);
+      }
+    } else
     // ---- MFMA over this wave's K steps (4 consecutive tile pixels each); all LDS reads of a step are issued
     //      before its MFMAs so their latency overlaps
     for (int ks = wv; ks * 4 < NP; ks += 4) {
@@ -955,7 +1062,9 @@ __global__ __launch_bounds__(256, 2) void wgrad_lds_kernel(const WgradParams P) 
 // a lane's MFMA operand IS one dword of global memory -- no LDS staging, no barriers in the main loop.  Every wave
 // owns a contiguous range of K steps and keeps U steps (U * (NMT + NNT) loads) in flight.  The pixel index is flat
 // over the batch; the image index (needed only for the per-image SE scale) is tracked per batch of steps.
-template <int NMT, int NNT>
+// BF: the U = 8 four-pixel steps of a batch form two 16-pixel K steps; a lane packs its four loaded values (pixels
+// 4q..4q+3 of one K16 step, i.e. step 4h + q, pixel j) into one bf16 fragment: 2 instead of 8 MFMAs per tile and batch.
+template <int NMT, int NNT, bool BF = false>
 __global__ __launch_bounds__(256) void wgrad_1x1_kernel(const WgradParams P) {
   constexpr int U = 8;
   const lmn_wgrad_args_t& A = P.a;
@@ -1019,8 +1128,9 @@ __global__ __launch_bounds__(256) void wgrad_1x1_kernel(const WgradParams P) {
     // ---- all loads of the batch, straight-line from clamped addresses
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const int px = (step0 + u) * 4 + q;
-      const bool ok = step0 + u < se && px < NPX;
+      // fp32: lane (q, n) holds pixel q of four-pixel step u; bf16: pixel (u & 3) of lane group q in 16-pixel step u >> 2
+      const int px = BF ? step0 * 4 + (u >> 2) * 16 + q * 4 + (u & 3) : (step0 + u) * 4 + q;
+      const bool ok = (BF ? px < se * 4 : step0 + u < se) && px < NPX;
       const int ps = ok ? px : 0;
 #pragma unroll
       for (int m = 0; m < NMT; ++m) av[u][m] = A.dy[(uint32_t)(ps * A.dy_cstride + (mco[m] >= 0 ? mco[m] : 0))];
@@ -1046,8 +1156,8 @@ __global__ __launch_bounds__(256) void wgrad_1x1_kernel(const WgradParams P) {
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const int px = (step0 + u) * 4 + q;
-      const bool ok = step0 + u < se && px < NPX;
+      const int px = BF ? step0 * 4 + (u >> 2) * 16 + q * 4 + (u & 3) : (step0 + u) * 4 + q;
+      const bool ok = (BF ? px < se * 4 : step0 + u < se) && px < NPX;
       const int ps = ok ? px : 0;
 #pragma unroll
       for (int m = 0; m < NMT; ++m) {
@@ -1067,6 +1177,23 @@ __global__ __launch_bounds__(256) void wgrad_1x1_kernel(const WgradParams P) {
         bv[u][t] = (ok && sch[t] >= 0) ? v : 0.f;
       }
     }
+    if constexpr (BF) {
+#pragma unroll
+      for (int h = 0; h < U / 4; ++h) {
+        uint2 af[NMT], bf[NNT];
+#pragma unroll
+        for (int m = 0; m < NMT; ++m) {
+          bsum[m] += (av[4 * h][m] + av[4 * h + 1][m]) + (av[4 * h + 2][m] + av[4 * h + 3][m]);
+          af[m] = uint2{pk_bf16(av[4 * h][m], av[4 * h + 1][m]), pk_bf16(av[4 * h + 2][m], av[4 * h + 3][m])};
+        }
+#pragma unroll
+        for (int t = 0; t < NNT; ++t) bf[t] = uint2{pk_bf16(bv[4 * h][t], bv[4 * h + 1][t]), pk_bf16(bv[4 * h + 2][t], bv[4 * h + 3][t])};
+#pragma unroll
+        for (int t = 0; t < NNT; ++t)
+#pragma unroll
+          for (int m = 0; m < NMT; ++m) acc[m][t] = mfma_bf16(af[m], bf[t], acc[m][t]);
+      }
+    } else {
 #pragma unroll
     for (int u = 0; u < U; ++u) {
 #pragma unroll
@@ -1075,6 +1202,7 @@ __global__ __launch_bounds__(256) void wgrad_1x1_kernel(const WgradParams P) {
       for (int t = 0; t < NNT; ++t)
 #pragma unroll
         for (int m = 0; m < NMT; ++m) acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u][m], bv[u][t], acc[m][t], 0, 0, 0);
+    }
     }
   }
 
@@ -1223,12 +1351,13 @@ int64_t lmn_conv_pack_size(int ksize, int Cout, int nsrc, const int32_t* c) {
 }
 
 int lmn_conv_pack(const float* w, float* wpack, int ksize, int Cout, int Cin, int nsrc, const int32_t* c,
-                  int transposed, int row_off, int rows, lmn_stream_t stream) {
+                  int transposed, int row_off, int rows, int dtype, lmn_stream_t stream) {
   LMN_REQUIRE(w && wpack && c, "conv_pack: null pointer");
+  LMN_REQUIRE(dtype == LMN_F32 || dtype == LMN_BF16, "conv_pack: dtype %d", dtype);
   if (g_lmn_rec && nsrc >= 1 && nsrc <= 3) {
     int32_t cc[3] = {c[0], nsrc > 1 ? c[1] : 0, nsrc > 2 ? c[2] : 0};
     const int32_t c0 = cc[0], c1 = cc[1], c2 = cc[2];
-    lmn_rec_push([=]() -> int { const int32_t ca[3] = {c0, c1, c2}; return lmn_conv_pack(w, wpack, ksize, Cout, Cin, nsrc, ca, transposed, row_off, rows, stream); });
+    lmn_rec_push([=]() -> int { const int32_t ca[3] = {c0, c1, c2}; return lmn_conv_pack(w, wpack, ksize, Cout, Cin, nsrc, ca, transposed, row_off, rows, dtype, stream); });
   }
   LMN_REQUIRE(ksize == 1 || ksize == 3, "conv_pack: ksize %d", ksize);
   LMN_REQUIRE(nsrc >= 1 && nsrc <= 3, "conv_pack: nsrc %d", nsrc);
@@ -1248,6 +1377,7 @@ int lmn_conv_pack(const float* w, float* wpack, int ksize, int Cout, int Cin, in
   g.taps = ksize * ksize; g.Cout = Cout; g.Cin = Cin; g.nsrc = nsrc;
   g.cs[0] = c[0]; g.cs[1] = nsrc > 1 ? c[1] : 0; g.cs[2] = nsrc > 2 ? c[2] : 0;
   g.transposed = transposed; g.row_off = row_off; g.rows = rows;
+  g.bf16 = dtype == LMN_BF16;
   LMN_LAUNCH(conv_pack_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, wpack, g, total);
   return lmn_launch_status("conv_pack");
 }
@@ -1270,6 +1400,7 @@ int lmn_conv_fwd(const lmn_conv_args_t* args, lmn_stream_t stream) {
   LMN_REQUIRE(A.stride == 1 || A.stride == 2, "conv_fwd: stride %d", A.stride);
   LMN_REQUIRE(A.nsrc >= 1 && A.nsrc <= 3, "conv_fwd: nsrc %d", A.nsrc);
   LMN_REQUIRE(A.Cout > 0 && A.Cout % 4 == 0, "conv_fwd: Cout %d must be a positive multiple of 4", A.Cout);
+  LMN_REQUIRE(A.mma_dtype == LMN_F32 || A.mma_dtype == LMN_BF16, "conv_fwd: mma_dtype %d", A.mma_dtype);
   LMN_REQUIRE(A.B > 0 && A.Hout > 0 && A.Wout > 0 && A.Hin > 0 && A.Win > 0, "conv_fwd: empty tensor");
   LMN_REQUIRE(A.wpack, "conv_fwd: null packed weights");
   LMN_REQUIRE(A.out || A.stats, "conv_fwd: neither out nor stats requested");
@@ -1421,6 +1552,8 @@ int lmn_conv_fwd(const lmn_conv_args_t* args, lmn_stream_t stream) {
     // LDS pixel stride: conflict-free ds_read_b128 for 16 pixels st_in apart (brute-forced over the b128 lane groups):
     // +8 floats at unit stride, +4 at stride 2 (PMC: 0.5 conflict cycles per LDS cycle with +4 at unit stride)
     T.CS = T.CKB * 16 + (st_in == 1 ? 8 : 4);
+    const bool bf = a.mma_dtype == LMN_BF16;
+    if (bf) T.CS = T.CKB * 8 + 4;  // dwords: 8 per K16 block of 4-bf16 fragments, +4: conflict-free ds_read_b64 (brute-forced)
     T.tiles_x = (gW + T.TW - 1) / T.TW;
     T.tiles_y = (gH + T.TH - 1) / T.TH;
     T.total_tiles = a.B * T.tiles_x * T.tiles_y;
@@ -1448,54 +1581,61 @@ int lmn_conv_fwd(const lmn_conv_args_t* args, lmn_stream_t stream) {
       if (mblocks > mmax) mblocks = mmax;
       const dim3 mgrid(mblocks, mchunks);
       const size_t msh = ((size_t)T.XH * T.XW * T.CS + 2 * 4 * ncw * 16) * sizeof(float);
-#define LMN_CM(TT, NN)                                                                                   \
+#define LMN_CM(TT, NN, BFV)                                                                              \
   do {                                                                                                   \
     switch ((TT) == 1 ? ek : (ek > 2 ? 1 : ek)) {                                                        \
-      case 0: LMN_LAUNCH((conv_tileM_kernel<TT, NN, 0>), mgrid, dim3(256), msh, st, T); break;   \
-      case 2: LMN_LAUNCH((conv_tileM_kernel<TT, NN, 2>), mgrid, dim3(256), msh, st, T); break;   \
-      case 3: LMN_LAUNCH((conv_tileM_kernel<1, NN, 3>), mgrid, dim3(256), msh, st, T); break;    \
-      case 4: LMN_LAUNCH((conv_tileM_kernel<1, NN, 4>), mgrid, dim3(256), msh, st, T); break;    \
-      case 5: LMN_LAUNCH((conv_tileM_kernel<1, NN, 5>), mgrid, dim3(256), msh, st, T); break;    \
-      default: LMN_LAUNCH((conv_tileM_kernel<TT, NN, 1>), mgrid, dim3(256), msh, st, T); break;  \
+      case 0: LMN_LAUNCH((conv_tileM_kernel<TT, NN, 0, BFV>), mgrid, dim3(256), msh, st, T); break;   \
+      case 2: LMN_LAUNCH((conv_tileM_kernel<TT, NN, 2, BFV>), mgrid, dim3(256), msh, st, T); break;   \
+      case 3: LMN_LAUNCH((conv_tileM_kernel<1, NN, 3, BFV>), mgrid, dim3(256), msh, st, T); break;    \
+      case 4: LMN_LAUNCH((conv_tileM_kernel<1, NN, 4, BFV>), mgrid, dim3(256), msh, st, T); break;    \
+      case 5: LMN_LAUNCH((conv_tileM_kernel<1, NN, 5, BFV>), mgrid, dim3(256), msh, st, T); break;    \
+      default: LMN_LAUNCH((conv_tileM_kernel<TT, NN, 1, BFV>), mgrid, dim3(256), msh, st, T); break;  \
     }                                                                                                    \
   } while (0)
-      if (a.ksize == 1) { if (ncw == 2) LMN_CM(1, 2); else LMN_CM(1, 1); }
-      else { if (ncw == 2) LMN_CM(9, 2); else LMN_CM(9, 1); }
+#define LMN_CMB(TT, NN) do { if (bf) LMN_CM(TT, NN, true); else LMN_CM(TT, NN, false); } while (0)
+      if (a.ksize == 1) { if (ncw == 2) LMN_CMB(1, 2); else LMN_CMB(1, 1); }
+      else { if (ncw == 2) LMN_CMB(9, 2); else LMN_CMB(9, 1); }
+#undef LMN_CMB
 #undef LMN_CM
       return lmn_launch_status("conv_fwd(tileM)");
     }
     if (s2t) {
       const dim3 zgrid(blocks, tchunks, 4);
-#define LMN_CZ(NN)                                                                                            \
+#define LMN_CZ(NN, BFV)                                                                                       \
   do {                                                                                                        \
-    if (ek == 0) LMN_LAUNCH((conv_tile_kernel<9, NN, 0, true>), zgrid, dim3(256), shmem, st, T);      \
-    else LMN_LAUNCH((conv_tile_kernel<9, NN, 1, true>), zgrid, dim3(256), shmem, st, T);              \
+    if (ek == 0) LMN_LAUNCH((conv_tile_kernel<9, NN, 0, true, BFV>), zgrid, dim3(256), shmem, st, T); \
+    else LMN_LAUNCH((conv_tile_kernel<9, NN, 1, true, BFV>), zgrid, dim3(256), shmem, st, T);         \
   } while (0)
+#define LMN_CZB(NN) do { if (bf) LMN_CZ(NN, true); else LMN_CZ(NN, false); } while (0)
       switch (tnct) {
-        case 1: LMN_CZ(1); break;
-        case 2: LMN_CZ(2); break;
-        default: LMN_CZ(3); break;
+        case 1: LMN_CZB(1); break;
+        case 2: LMN_CZB(2); break;
+        default: LMN_CZB(3); break;
       }
+#undef LMN_CZB
 #undef LMN_CZ
       return lmn_launch_status("conv_fwd(tile, stride-2 data gradient)");
     }
     const dim3 grid(blocks, tchunks);
-#define LMN_CT(TT, NN)                                                                                   \
+#define LMN_CT(TT, NN, BFV)                                                                              \
   do {                                                                                                   \
     switch ((TT) == 1 ? ek : (ek > 2 ? 1 : ek)) {                                                        \
-      case 0: LMN_LAUNCH((conv_tile_kernel<TT, NN, 0>), grid, dim3(256), shmem, st, T); break;   \
-      case 2: LMN_LAUNCH((conv_tile_kernel<TT, NN, 2>), grid, dim3(256), shmem, st, T); break;   \
-      case 3: LMN_LAUNCH((conv_tile_kernel<1, NN, 3>), grid, dim3(256), shmem, st, T); break;    \
-      case 4: LMN_LAUNCH((conv_tile_kernel<1, NN, 4>), grid, dim3(256), shmem, st, T); break;    \
-      case 5: LMN_LAUNCH((conv_tile_kernel<1, NN, 5>), grid, dim3(256), shmem, st, T); break;    \
-      default: LMN_LAUNCH((conv_tile_kernel<TT, NN, 1>), grid, dim3(256), shmem, st, T); break;  \
+      case 0: LMN_LAUNCH((conv_tile_kernel<TT, NN, 0, false, BFV>), grid, dim3(256), shmem, st, T); break;   \
+      case 2: LMN_LAUNCH((conv_tile_kernel<TT, NN, 2, false, BFV>), grid, dim3(256), shmem, st, T); break;   \
+      case 3: LMN_LAUNCH((conv_tile_kernel<1, NN, 3, false, BFV>), grid, dim3(256), shmem, st, T); break;    \
+      case 4: LMN_LAUNCH((conv_tile_kernel<1, NN, 4, false, BFV>), grid, dim3(256), shmem, st, T); break;    \
+      case 5: LMN_LAUNCH((conv_tile_kernel<1, NN, 5, false, BFV>), grid, dim3(256), shmem, st, T); break;    \
+      default: LMN_LAUNCH((conv_tile_kernel<TT, NN, 1, false, BFV>), grid, dim3(256), shmem, st, T); break;  \
     }                                                                                                    \
   } while (0)
 #define LMN_CTN(TT)                                                                                      \
-  switch (tnct) {                                                                                         \
-    case 1: LMN_CT(TT, 1); break;                                                                        \
-    case 2: LMN_CT(TT, 2); break;                                                                        \
-    default: LMN_CT(TT, 3); break;                                                                       \
+  switch (tnct * 2 + (bf ? 1 : 0)) {                                                                     \
+    case 2: LMN_CT(TT, 1, false); break;                                                                 \
+    case 3: LMN_CT(TT, 1, true); break;                                                                  \
+    case 4: LMN_CT(TT, 2, false); break;                                                                 \
+    case 5: LMN_CT(TT, 2, true); break;                                                                  \
+    case 7: LMN_CT(TT, 3, true); break;                                                                  \
+    default: LMN_CT(TT, 3, false); break;                                                                \
   }
     if (a.ksize == 1) { LMN_CTN(1) } else { LMN_CTN(9) }
 #undef LMN_CTN
@@ -1533,6 +1673,7 @@ int lmn_conv_wgrad(const lmn_wgrad_args_t* args, lmn_stream_t stream) {
   for (int s = 0; s < A.nsrc && s < 3; ++s) LMN_REQUIRE(A.dW || A.dW_src[s], "conv_wgrad: no gradient tensor for source %d", s);
   LMN_REQUIRE(!A.db2 || A.db, "conv_wgrad: db2 without db");
   LMN_REQUIRE(A.B > 0 && A.Hout > 0 && A.Wout > 0, "conv_wgrad: empty tensor");
+  LMN_REQUIRE(A.mma_dtype == LMN_F32 || A.mma_dtype == LMN_BF16, "conv_wgrad: mma_dtype %d", A.mma_dtype);
   WgradParams P;
   P.a = A;
   P.NNTT = 0;
@@ -1589,6 +1730,9 @@ int lmn_conv_wgrad(const lmn_wgrad_args_t* args, lmn_stream_t stream) {
   // (stride 2: 48 = 16 mod 32 banks) keep the two 16-lane halves of a ds_read_b32 group on disjoint banks
   P.CSy = 16;
   P.CSx = A.stride == 1 ? 16 : 24;
+  const bool bf = A.mma_dtype == LMN_BF16;
+  // bf16 planes: 16 bf16 = 8 dwords per pixel, +4: the lane groups q (pixels 4 apart) read disjoint bank ranges
+  if (bf) P.CSy = P.CSx = 12;
   P.tiles_x = (G.Wout + P.TW - 1) / P.TW;
   P.tiles_y = (G.Hout + P.TH - 1) / P.TH;
   P.total_tiles = A.B * P.tiles_x * P.tiles_y;
@@ -1617,9 +1761,12 @@ int lmn_conv_wgrad(const lmn_wgrad_args_t* args, lmn_stream_t stream) {
   const size_t shmem = (size_t)lds_floats * 4;
 #define LMN_WG(T, M, N)                                                                                             \
   do {                                                                                                              \
-    if (shmem > 64 * 1024)                                                                                          \
-      (void)hipFuncSetAttribute((const void*)wgrad_lds_kernel<T, M, N>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem); \
-    LMN_LAUNCH((wgrad_lds_kernel<T, M, N>), grid, dim3(256), shmem, st, P);                                 \
+    if (shmem > 64 * 1024) {                                                                                        \
+      (void)hipFuncSetAttribute((const void*)wgrad_lds_kernel<T, M, N, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem); \
+      (void)hipFuncSetAttribute((const void*)wgrad_lds_kernel<T, M, N, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem); \
+    }                                                                                                               \
+    if (bf) LMN_LAUNCH((wgrad_lds_kernel<T, M, N, true>), grid, dim3(256), shmem, st, P);                   \
+    else LMN_LAUNCH((wgrad_lds_kernel<T, M, N, false>), grid, dim3(256), shmem, st, P);                     \
     if (P.partial) {                                                                                                \
       const int ksl = reduce_slices(blocks);                                                                        \
       const int rb = (int)((per + 1024 / ksl - 1) / (1024 / ksl));                                                  \
@@ -1638,7 +1785,8 @@ int lmn_conv_wgrad(const lmn_wgrad_args_t* args, lmn_stream_t stream) {
     const dim3 dgrid((unsigned)nb, gy);
 #define LMN_WD(M, N)                                                                                               \
   do {                                                                                                              \
-    LMN_LAUNCH((wgrad_1x1_kernel<M, N>), dgrid, dim3(256), 0, st, P);                                       \
+    if (bf) LMN_LAUNCH((wgrad_1x1_kernel<M, N, true>), dgrid, dim3(256), 0, st, P);                         \
+    else LMN_LAUNCH((wgrad_1x1_kernel<M, N, false>), dgrid, dim3(256), 0, st, P);                           \
     if (P.partial) {                                                                                                \
       const int ksl = reduce_slices((int)nb);                                                                       \
       const int rb = (int)((per + 1024 / ksl - 1) / (1024 / ksl));                                                  \

@@ -131,6 +131,7 @@ class Engine:
         self.branch_overlap = True
         self.zpool_fwd, self.zpool_bwd = ZeroPool(), ZeroPool()
         self.packs_fwd, self.packs_bwd = hip.PackPlan(), hip.PackPlan()
+        self.mma = hip.F32        # matrix-core operand type of the dense contractions of the pass (hip.F32 | hip.BF16)
         self.arena = None         # plan mode (LM_Net.enable_plans): bump arena all tensors of the pass come from
         self.planning = False     # a plan is being recorded: buffers come from the arena, no allocator stream bookkeeping
         self.alloc_floats = 0     # floats requested since begin_pass (sizes the arena during the eager warm-up steps)
@@ -152,6 +153,7 @@ class Engine:
         hip._STREAM[0] = None
         hip._STREAM[0] = hip._stream()          # one stream lookup per pass instead of one per launch
         hip._SEED_CTR[0] = self.seed_ctr
+        hip._MMA[0] = self.mma
         pool = self.zpool_bwd if backward else self.zpool_fwd
         pool.begin(device)
         _POOL[0] = pool
@@ -164,6 +166,7 @@ class Engine:
             _POOL[0].end()
         _POOL[0] = None
         _ENG[0] = None
+        hip._MMA[0] = hip.F32
         hip._ALLOC[0] = None
         hip._PLAN[0] = None
         hip._STREAM[0] = None
@@ -350,11 +353,12 @@ class Engine:
         plan = hip._PLAN[0]
         own = plan is not None and isinstance(w0, torch.nn.Parameter) and isinstance(w1, torch.nn.Parameter)
         if own:
-            wp = plan.buffer(("pack2", w0.data_ptr(), w1.data_ptr()), n0 + n1, ref.device)
+            wp = plan.buffer(("pack2", w0.data_ptr(), w1.data_ptr(), hip._MMA[0]), n0 + n1, ref.device)
         else:
             wp = _E(ref, n0 + n1)
-        hip.conv_pack(w0, 1, [c0], out=wp[:n0], persistent=own)
-        hip.conv_pack(w1, 1, [c1], out=wp[n0:], persistent=own)
+        h = 2 if hip._MMA[0] == hip.BF16 else 1      # bf16 fragments take half the space: source 1 starts at n0 / 2
+        hip.conv_pack(w0, 1, [c0], out=wp[:n0 // h], persistent=own)
+        hip.conv_pack(w1, 1, [c1], out=wp[n0 // h:(n0 + n1) // h], persistent=own)
         return wp
 
     def reparam_bwd(self, m, dy, cx, need_dx=True):

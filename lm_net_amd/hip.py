@@ -17,6 +17,8 @@ SRC_GELU, SRC_DROP = 1, 2
 EP_LINEAR, EP_AFFINE_ACT, EP_DGELU, EP_BN_BWD1, EP_BN_BWD2, EP_SE_BWD = 0, 1, 2, 3, 4, 5
 ACT_NONE, ACT_HSWISH, ACT_GELU = 0, 1, 2
 STATS_NONE, STATS_SUM_SQ, STATS_EP = 0, 1, 2
+F32, BF16 = 0, 1            # matrix-core operand type of the dense contractions (LMN_F32 / LMN_BF16)
+_MMA = [F32]                # ... of the pass in flight (engine.begin_pass)
 ABI_VERSION = 4
 
 
@@ -34,7 +36,7 @@ class ConvArgs(C.Structure):
                 ("aux_cstride", C.c_int32), ("res_cstride", C.c_int32), ("out_cstride", C.c_int32),
                 ("epilogue", C.c_int32), ("act", C.c_int32), ("stats_mode", C.c_int32),
                 ("drop_p", C.c_float), ("drop_seed", C.c_uint32), ("seed_ctr", C.c_void_p), ("bias2", C.c_void_p),
-                ("stats_rep", C.c_int32), ("_pad0", C.c_int32)]
+                ("stats_rep", C.c_int32), ("mma_dtype", C.c_int32)]
 
 
 class WgradArgs(C.Structure):
@@ -43,7 +45,7 @@ class WgradArgs(C.Structure):
                 ("src", SrcT * 3), ("dy", C.c_void_p), ("dy_cstride", C.c_int32), ("dy_flags", C.c_int32),
                 ("dy_seed", C.c_uint32), ("dy_p", C.c_float), ("dW", C.c_void_p), ("db", C.c_void_p),
                 ("workspace", C.c_void_p), ("workspace_floats", C.c_int64), ("seed_ctr", C.c_void_p),
-                ("dW_src", C.c_void_p * 3), ("db2", C.c_void_p)]
+                ("dW_src", C.c_void_p * 3), ("db2", C.c_void_p), ("mma_dtype", C.c_int32), ("_pad", C.c_int32)]
 
 
 # every symbol include/lmnet_hip.h declares (the CPU test suite checks the library exports all of them)
@@ -181,7 +183,7 @@ class PackJob(C.Structure):
     _fields_ = [("w", C.c_void_p), ("wpack", C.c_void_p), ("total", C.c_int64), ("first_block", C.c_int64),
                 ("ksize", C.c_int32), ("Cout", C.c_int32), ("Cin", C.c_int32), ("nsrc", C.c_int32),
                 ("c", C.c_int32 * 3), ("transposed", C.c_int32), ("row_off", C.c_int32), ("rows", C.c_int32),
-                ("_pad", C.c_int32 * 2)]
+                ("dtype", C.c_int32), ("_pad", C.c_int32)]
 
 
 class PackPlan:
@@ -216,6 +218,7 @@ class PackPlan:
                 for k, cc in enumerate(f["c"]):
                     a.c[k] = cc
                 a.transposed, a.row_off, a.rows = f["transposed"], f["row_off"], f["rows"]
+                a.dtype = f.get("dtype", F32)
                 blk += (out.numel() + 1023) // 1024
             if C.sizeof(PackJob) != load().lmn_sizeof_pack_job():
                 raise RuntimeError("lm_net_amd: lmn_pack_job_t layout differs between hip.py and lmnet_hip.h")
@@ -253,19 +256,20 @@ def conv_pack(w, ksize, src_channels, out=None, persistent=False):
     slice of a ``PackPlan.buffer`` (so the job may be recorded and replayed by the plan)."""
     cout, cin = w.shape[0], w.shape[1]
     planned = _planned(w, out, persistent)
+    dt = _MMA[0]
     if planned:
-        key = (w.data_ptr(), ksize, tuple(src_channels), 0, 0, 0, out.data_ptr() if out is not None else 0)
+        key = (w.data_ptr(), ksize, tuple(src_channels), 0, 0, 0, out.data_ptr() if out is not None else 0, dt)
         hit = _PLAN[0].lookup(key)
         if hit is not None:
             return hit
-    n = conv_pack_size(ksize, cout, src_channels)
+    n = conv_pack_size(ksize, cout, src_channels)      # floats of the fp32 form (the bf16 form fills the first half)
     if out is None:
         out = torch.empty(n, device=w.device, dtype=torch.float32)
     arr = (C.c_int32 * len(src_channels))(*src_channels)
-    _check(load().lmn_conv_pack(_p(w), _p(out), ksize, cout, cin, len(src_channels), arr, 0, 0, 0, _stream()), "conv_pack")
+    _check(load().lmn_conv_pack(_p(w), _p(out), ksize, cout, cin, len(src_channels), arr, 0, 0, 0, dt, _stream()), "conv_pack")
     if planned:
         _PLAN[0].record(key, w, out, dict(w=w.data_ptr(), ksize=ksize, Cout=cout, Cin=cin, c=list(src_channels),
-                                          transposed=0, row_off=0, rows=0))
+                                          transposed=0, row_off=0, rows=0, dtype=dt))
     return out
 
 
@@ -277,8 +281,9 @@ def conv_pack_t(w, ksize, row_off=0, rows=None, out=None, cred=None):
     rows = cin - row_off if rows is None else rows
     cred = cout if cred is None else cred
     planned = _planned(w, out, False)
+    dt = _MMA[0]
     if planned:
-        key = (w.data_ptr(), ksize, (cred,), 1, row_off, rows)
+        key = (w.data_ptr(), ksize, (cred,), 1, row_off, rows, dt)
         hit = _PLAN[0].lookup(key)
         if hit is not None:
             return hit
@@ -286,10 +291,10 @@ def conv_pack_t(w, ksize, row_off=0, rows=None, out=None, cred=None):
     if out is None:
         out = torch.empty(n, device=w.device, dtype=torch.float32)
     arr = (C.c_int32 * 1)(cred)
-    _check(load().lmn_conv_pack(_p(w), _p(out), ksize, cout, cin, 1, arr, 1, row_off, rows, _stream()), "conv_pack_t")
+    _check(load().lmn_conv_pack(_p(w), _p(out), ksize, cout, cin, 1, arr, 1, row_off, rows, dt, _stream()), "conv_pack_t")
     if planned:
         _PLAN[0].record(key, w, out, dict(w=w.data_ptr(), ksize=ksize, Cout=cout, Cin=cin, c=[cred],
-                                          transposed=1, row_off=row_off, rows=rows))
+                                          transposed=1, row_off=row_off, rows=rows, dtype=dt))
     return out
 
 
@@ -319,6 +324,7 @@ def conv_fwd(srcs, wpack, out, *, B, Hin, Win, Hout, Wout, Cout, ksize=1, stride
     a.stats_rep = stats_rep
     a.epilogue, a.act, a.stats_mode = epilogue, act, stats_mode
     a.drop_p, a.drop_seed = drop_p, drop_seed
+    a.mma_dtype = _MMA[0]
     a.seed_ctr = _SEED_CTR[0].data_ptr() if _SEED_CTR[0] is not None else None
     _check(load().lmn_conv_fwd(C.byref(a), _stream()), "conv_fwd")
 
@@ -337,6 +343,7 @@ def conv_wgrad(srcs, dy, dW, db, *, B, Hin, Win, Hout, Wout, Cout, ksize=1, stri
     a.dW = dW.data_ptr() if dW is not None else None
     a.db = db.data_ptr() if db is not None else None
     a.db2 = db2.data_ptr() if db2 is not None else None
+    a.mma_dtype = _MMA[0]
     if dW_src is not None:
         for i, t in enumerate(dW_src):
             a.dW_src[i] = t.data_ptr() if t is not None else None

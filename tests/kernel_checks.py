@@ -16,9 +16,13 @@ DEV = "cuda"
 TOL = 1e-4
 
 
+_ROUND16 = [False]   # check_conv_bf16: draw bf16-representable test data (every bf16 product is then exact in fp32)
+
+
 def R(*shape, seed=0, scale=1.0):
     g = torch.Generator().manual_seed(seed + 1000 * len(shape) + sum(shape))
-    return (torch.randn(*shape, generator=g, dtype=torch.float64) * scale)
+    t = torch.randn(*shape, generator=g, dtype=torch.float64) * scale
+    return t.to(torch.bfloat16).double() if _ROUND16[0] else t
 
 
 def dev(t):
@@ -640,3 +644,63 @@ def check_conv_large():
 
 
 ALL_CHECKS.append(check_conv_large)
+
+
+# ------------------------------------------------------------------------------------------------ bf16 matrix-core operands
+def check_conv_bf16():
+    """Mixed-precision form of the dense contractions (LMN_BF16: operands rounded to bf16 when staged / packed,
+    v_mfma_f32_16x16x16_bf16, fp32 accumulation and epilogues).
+    (a) EXACTNESS of the wiring: with bf16-representable inputs and weights every product is exact in fp32, so the result
+        must match the fp64 reference to fp32 accumulation noise (1e-5) -- a fragment-order or packing bug cannot hide
+        behind a rounding tolerance;
+    (b) the fp32 checks of the conv family re-run with bf16 operands at the rounding tolerance 1e-2 (two operands rounded
+        to 8 significant bits: 2^-8 per product, averaged over the reduction)."""
+    rows = []
+    hip._MMA[0] = hip.BF16
+    try:
+        r16 = lambda t: t.to(torch.bfloat16).double()
+        cases = [("1x1 12->24", 2, 9, 13, [12], 24, 1, 1), ("1x1 4->24 (padded rgb)", 1, 8, 8, [4], 24, 1, 1),
+                 ("1x1 two-src 24+12->12", 2, 6, 7, [24, 12], 12, 1, 1), ("1x1 372->1116", 1, 5, 5, [372], 1116, 1, 1),
+                 ("3x3 s1 12->12", 2, 10, 11, [12], 12, 3, 1), ("3x3 s2 12->24", 2, 12, 10, [12], 24, 3, 2),
+                 ("3x3 s1 cat 24+24+24->24", 1, 8, 9, [24, 24, 24], 24, 3, 1), ("3x3 s1 100->112 (chunks)", 1, 6, 6, [100], 112, 3, 1),
+                 ("3x3 s1 48->144 22x22", 2, 22, 22, [48], 144, 3, 1), ("1x1 96->288 44x44", 1, 44, 44, [96], 288, 1, 1)]
+        for name, B, H, W, cins, cout, k, s in cases:
+            cin = sum(cins)
+            x = r16(R(B, cin, H, W, seed=1))
+            w = r16(R(cout, cin, k, k, seed=2, scale=1.0 / math.sqrt(cin * k * k)))
+            b = R(cout, seed=3)
+            ref = F.conv2d(x, w, b, stride=s, padding=k // 2)
+            Ho, Wo = ref.shape[2:]
+            xs, off = [], 0
+            for c in cins:
+                xs.append(nhwc(x[:, off:off + c]))
+                off += c
+            wp = hip.conv_pack(dev(w), k, cins)
+            out = torch.full((B, Ho, Wo, cout), float("nan"), device=DEV)
+            hip.conv_fwd(xs, wp, out, B=B, Hin=H, Win=W, Hout=Ho, Wout=Wo, Cout=cout, ksize=k, stride=s, bias=dev(b))
+            rows.append(("bf16 exact conv_fwd " + name, rel(nchw(out), ref), 1e-5))
+            # data gradient (transposed operator) of the same layer, single source only
+            if len(cins) == 1:
+                dy = r16(R(B, cout, Ho, Wo, seed=4))
+                dref = torch.nn.grad.conv2d_input((B, cin, H, W), w, dy, stride=s, padding=k // 2)
+                wpt = hip.conv_pack_t(dev(w), k)
+                dx = torch.full((B, H, W, cin), float("nan"), device=DEV)
+                hip.conv_fwd([nhwc(dy)], wpt, dx, B=B, Hin=Ho, Win=Wo, Hout=H, Wout=W, Cout=cin, ksize=k, stride=s,
+                             transposed=1)
+                rows.append(("bf16 exact conv_bwd_data " + name, rel(nchw(dx), dref), 1e-5))
+        _ROUND16[0] = True       # bf16-representable operands: the weight-gradient kernels must be exact as well
+        try:
+            for fn in (check_conv_wgrad, check_conv_bwd_data):
+                for n, e, t in fn():
+                    rows.append(("bf16 exact " + n, e, t))
+        finally:
+            _ROUND16[0] = False
+        for fn in (check_conv_fwd, check_conv_bwd_data, check_conv_bn_epilogues, check_conv_dropout, check_conv_wgrad):
+            for n, e, t in fn():
+                rows.append(("bf16 " + n, e, max(t, 1e-2) if t > 1e-20 else t))
+    finally:
+        hip._MMA[0] = hip.F32
+    return rows
+
+
+ALL_CHECKS.append(check_conv_bf16)
