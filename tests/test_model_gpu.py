@@ -484,6 +484,8 @@ def test_bf16_mixed_precision_path():
             assert rel_err(v, g["state/" + k]) < 1e-2, k
     # Dice / IoU on the 352x352 fixture (BASELINE configs[0] shape)
     g3 = load_golden("default_352.npz")
+    m = _net()                                           # (fresh BatchNorm running statistics)
+    m.compute_dtype = "bf16"
     m.eval()
     x3 = det_input((1, 3, 352, 352), "d352/x").cuda()
     with torch.no_grad():
