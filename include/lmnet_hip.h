@@ -87,7 +87,7 @@ typedef struct {
 
 /* what `stats` accumulates (atomicAdd) */
 #define LMN_STATS_NONE 0
-#define LMN_STATS_SUM_SQ 1 /* [2][Cout]: sum v, sum v*v over all pixels (BatchNorm batch statistics) */
+#define LMN_STATS_SUM_SQ 1 /* [2][Cout]: sum d, sum d*d over all pixels, d = v - p4[co] (p4 NULL: d = v): BatchNorm batch statistics */
 #define LMN_STATS_EP 2     /* defined by the epilogue (BN_BWD1: [2][Cout]; SE_BWD: [B][Cout])        */
 
 typedef struct {
@@ -289,7 +289,11 @@ int lmn_bnact_bwd(const float* z, const float* dy, const float* mean, const floa
  * A = gamma*rstd, shift = beta - mean*A, and updates running_mean/var in place if not NULL.   */
 int lmn_bn_finalize(const float* sums, int nrep, float count, const float* gamma, const float* beta, float eps,
                     float momentum, float* mean, float* rstd, float* A, float* shift, float* running_mean,
-                    float* running_var, int C, lmn_stream_t stream);  /* sums: nrep slices of [2][C] (nrep >= 1) */
+                    float* running_var, const float* about, int C, lmn_stream_t stream);
+/* sums: nrep slices of [2][C] (nrep >= 1), added in double.  about (or NULL): the sums were taken ABOUT about[c] -- sum(v - about),
+ * sum((v - about)^2), which is what lmn_conv_fwd(stats_mode=LMN_STATS_SUM_SQ, p4=about) accumulates -- so that the single-pass
+ * variance E[d^2] - E[d]^2 cancels numbers of the size of the variance, not of the squared mean (torch: Welford).  It may alias
+ * running_mean (read before the in-place update).                                                                              */
 /* eval-mode BatchNorm (running statistics): mean, rstd, A = gamma*rstd, shift = beta - mean*A */
 int lmn_bn_fold(const float* running_mean, const float* running_var, const float* gamma, const float* beta, float eps,
                 float* mean, float* rstd, float* A, float* shift, int C, lmn_stream_t stream);

@@ -603,9 +603,9 @@ class LM_Net(nn.Module):
         if self.grad_ready_hook is not None or plan is not None:
             # the block's weight gradients run on the side stream of the current stream: the collective waits for
             # that stream, the compute chain does not (it joins once, at the end of backward)
-            ent = self._engine.sides.get(torch.cuda.current_stream(self._grad_flat.device).cuda_stream) \
-                if self._grad_flat.is_cuda else None
-            streams = [ent[0]] if ent is not None else []
+            cur = torch.cuda.current_stream(self._grad_flat.device) if self._grad_flat.is_cuda else None
+            ent = self._engine.sides.get(cur.cuda_stream) if cur is not None else None
+            streams = ([cur] if cur is not None else []) + ([ent[0]] if ent is not None else [])
             if plan is not None:                     # replays call the hook between plan segments
                 plan.marks.append((plan.bwd.size(), name, streams))
             if self.grad_ready_hook is not None:
@@ -683,6 +683,19 @@ class LM_Net(nn.Module):
                 eng.join_side(dev)                       # this chain's weight gradients
             return None
 
+        # The flat gradient buffer lists natt4..1 before skip4..1 (BACKWARD_ORDER) and a data-parallel bucket is a
+        # contiguous prefix: blocks are reported as soon as every block before them is enqueued too.  The branch stream
+        # runs natt_k + skip_k per level, so after level 4..1 are all forked the whole natt/skip range is complete on
+        # the BRANCH stream -- it is handed to the reducer from there (the collective waits for the branch stream and its
+        # weight-gradient stream only), while the main stream goes on with the GFT backward.
+        def branch_blocks_done():
+            if not fork or (self.grad_ready_hook is None and self._recording is None):
+                return False
+            with eng.on_stream(bst):
+                for name in ("natt4", "natt3", "natt2", "natt1", "skip4", "skip3", "skip2", "skip1"):
+                    self._done(name)
+            return True
+
         # decoder (the branch work of level k is forked as soon as dt_k exists)
         dt4 = eng.stage_bwd(self.dconv4, dx9, cx); self._done("dconv4")
         p4 = branch(self.natt4, self.skip4, dt4)
@@ -697,14 +710,16 @@ class LM_Net(nn.Module):
         p1 = branch(self.natt1, self.skip1, dt1)
         dx5 = eng.up_bwd(self.up1, dt1, cx, A["x5"].shape); self._done("up1")
         if fork:
+            reported = branch_blocks_done()              # natt* / skip*: complete on the branch stream from here on
             dcat = eng.gft_bwd(self.gft, dx5, cx)        # independent of the branch chains: before the join
             hip.stream_wait(main, bst)                   # join: the encoder gradients in gacc are complete
             if eng.arena is None:
                 for slot in gacc.values():
                     if slot.g is not None:
                         slot.g.record_stream(main)
-            for name in ("natt4", "natt3", "natt2", "natt1", "skip4", "skip3", "skip2", "skip1"):
-                self._done(name)
+            if not reported:
+                for name in ("natt4", "natt3", "natt2", "natt1", "skip4", "skip3", "skip2", "skip1"):
+                    self._done(name)
         else:
             # neighborhood-attention blocks (their outputs were the residual inputs of up1..4: gradient = dt_k)
             dxs = [eng.nat_bwd(p[0], p[2], cx) for p in (p4, p3, p2, p1)]

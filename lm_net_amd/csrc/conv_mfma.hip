@@ -279,8 +279,11 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(const ConvParams P) {
         if (A.bias2) v += ld4(A.bias2 + cos);
         f32x4 o = v;
         if (EPI && st_mode == LMN_STATS_SUM_SQ && live) {
+          // sums about p4[co] when given (the BatchNorm's running mean): E[x^2] - E[x]^2 then subtracts numbers of the
+          // size of the variance, not of the squared mean
+          const f32x4 sh = A.p4 ? ld4(A.p4 + cos) : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-          for (int r = 0; r < 4; ++r) { st0[c][r] += v[r]; st1[c][r] += v[r] * v[r]; }
+          for (int r = 0; r < 4; ++r) { const float d = v[r] - sh[r]; st0[c][r] += d; st1[c][r] += d * d; }
         }
         if (ep_kind == LMN_EP_AFFINE_ACT) {
           const f32x4 s0 = ld4(A.p0 + cos), s1 = ld4(A.p1 + cos);
@@ -546,8 +549,11 @@ __global__ __launch_bounds__(256) void conv_tileM_kernel(const ConvParams P) {
         if (A.bias2) v += ld4(A.bias2 + cos);
         f32x4 o = v;
         if (EPI && st_mode == LMN_STATS_SUM_SQ && live) {
+          // sums about p4[co] when given (the BatchNorm's running mean): E[x^2] - E[x]^2 then subtracts numbers of the
+          // size of the variance, not of the squared mean
+          const f32x4 sh = A.p4 ? ld4(A.p4 + cos) : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-          for (int r = 0; r < 4; ++r) { st0[c][r] += v[r]; st1[c][r] += v[r] * v[r]; }
+          for (int r = 0; r < 4; ++r) { const float d = v[r] - sh[r]; st0[c][r] += d; st1[c][r] += d * d; }
         }
         if (ep_kind == LMN_EP_AFFINE_ACT) {
           const f32x4 s0 = ld4(A.p0 + cos), s1 = ld4(A.p1 + cos);

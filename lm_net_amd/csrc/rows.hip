@@ -215,14 +215,17 @@ __global__ __launch_bounds__(256) void chan_kernel(const float* __restrict__ z, 
 
 __global__ void bn_finalize_kernel(const float* __restrict__ sums, int nrep, float count, const float* __restrict__ gamma,
                                    const float* __restrict__ beta, float eps, float momentum, float* mean, float* rstd,
-                                   float* A, float* shift, float* rmean, float* rvar, int C) {
+                                   float* A, float* shift, float* rmean, float* rvar, const float* about, int C) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
-  float s0 = 0.f, s1 = 0.f;
-  for (int r = 0; r < nrep; ++r) { s0 += sums[r * 2 * C + c]; s1 += sums[r * 2 * C + C + c]; }
-  const float m = s0 / count;
-  float var = s1 / count - m * m;  // biased
+  // the slices are summed in double; the sums were taken about about[c] (NULL: about 0), so the subtraction below
+  // cancels numbers of the size of the variance instead of the squared mean (torch uses Welford for the same reason)
+  double s0 = 0.0, s1 = 0.0;
+  for (int r = 0; r < nrep; ++r) { s0 += (double)sums[r * 2 * C + c]; s1 += (double)sums[r * 2 * C + C + c]; }
+  const double md = s0 / (double)count;
+  float var = (float)(s1 / (double)count - md * md);  // biased
   var = var > 0.f ? var : 0.f;
+  const float m = (float)md + (about ? about[c] : 0.f);
   const float rs = rsqrtf(var + eps);
   const float a = gamma[c] * rs;
   if (mean) mean[c] = m;
@@ -851,11 +854,11 @@ int lmn_colsum(const float* x, float* out, int64_t rows, int C, int cstride, lmn
 
 int lmn_bn_finalize(const float* sums, int nrep, float count, const float* gamma, const float* beta, float eps,
                     float momentum, float* mean, float* rstd, float* A, float* shift, float* running_mean,
-                    float* running_var, int C, lmn_stream_t stream) {
-  LMN_REC(lmn_bn_finalize(sums, nrep, count, gamma, beta, eps, momentum, mean, rstd, A, shift, running_mean, running_var, C, stream));
+                    float* running_var, const float* about, int C, lmn_stream_t stream) {
+  LMN_REC(lmn_bn_finalize(sums, nrep, count, gamma, beta, eps, momentum, mean, rstd, A, shift, running_mean, running_var, about, C, stream));
   LMN_REQUIRE(sums && nrep >= 1 && gamma && beta && C > 0 && count > 0.f, "bn_finalize: bad argument");
   LMN_LAUNCH(bn_finalize_kernel, dim3(lmn_cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream, sums, nrep, count, gamma,
-                     beta, eps, momentum, mean, rstd, A, shift, running_mean, running_var, C);
+                     beta, eps, momentum, mean, rstd, A, shift, running_mean, running_var, about, C);
   return lmn_launch_status("bn_finalize");
 }
 

@@ -281,12 +281,13 @@ class Engine:
         return self.branch
 
     def bn_stats(self, bn, sums, count, ref):
-        """(mean, rstd, A, shift) of a BatchNorm from batch sums [2,C] (training) or running stats (eval)."""
+        """(mean, rstd, A, shift) of a BatchNorm from batch sums [2,C] (training; taken about the running mean, see
+        lmn_bn_finalize) or running stats (eval)."""
         C = bn.weight.numel()
         mean, rstd, A, shift = (_E(ref, C) for _ in range(4))
         if self.training:
             hip.bn_finalize(sums, count, bn.weight, bn.bias, bn.eps, bn.momentum if bn.momentum is not None else 0.1,
-                            mean, rstd, A, shift, bn.running_mean, bn.running_var)
+                            mean, rstd, A, shift, bn.running_mean, bn.running_var, about=bn.running_mean)
         else:
             hip.bn_fold(bn.running_mean, bn.running_var, bn.weight, bn.bias, bn.eps, mean, rstd, A, shift)
         return mean, rstd, A, shift
@@ -302,7 +303,7 @@ class Engine:
         if self.training:
             sums1 = _Z(x, STATS_REP, 2, E)
             hip.conv_fwd([x], wpe, None, B=B, Hin=H, Win=W, Hout=H, Wout=W, Cout=E, bias=ec.bias, stats=sums1,
-                         stats_mode=hip.STATS_SUM_SQ, stats_rep=STATS_REP)
+                         stats_mode=hip.STATS_SUM_SQ, stats_rep=STATS_REP, p=(None, None, None, None, ebn.running_mean))
         mean1, rstd1, A1, sh1 = self.bn_stats(ebn, sums1, N, x)
         x1 = _E(x, B, H, W, E)
         hip.conv_fwd([x], wpe, x1, B=B, Hin=H, Win=W, Hout=H, Wout=W, Cout=E, bias=ec.bias, epilogue=hip.EP_AFFINE_ACT,
@@ -478,7 +479,8 @@ class Engine:
         z = _E(xl, B, H, W, C)
         sums = _Z(xl, 2, C) if self.training else None
         self.conv([cat], fconv.weight, fconv.bias, z, Hin=H, Win=W, k=3, stats=sums,
-                  stats_mode=hip.STATS_SUM_SQ if self.training else hip.STATS_NONE)
+                  stats_mode=hip.STATS_SUM_SQ if self.training else hip.STATS_NONE,
+                  p=(None, None, None, None, fbn.running_mean) if self.training else ())
         mean, rstd, A, shift = self.bn_stats(fbn, sums, B * H * W, xl)
         y = _E(xl, B, H, W, C)
         hip.bnact_fwd(z, A, shift, y, hip.ACT_GELU)

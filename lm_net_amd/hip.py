@@ -487,10 +487,11 @@ def bnact_bwd(z, dy, mean, rstd, gamma, beta, c1, c2, c3, dz, act):
                                 _i64(z.numel() // Cn), Cn, act, _stream()), "bnact_bwd")
 
 
-def bn_finalize(sums, count, gamma, beta, eps, momentum, mean, rstd, A, shift, running_mean, running_var):
+def bn_finalize(sums, count, gamma, beta, eps, momentum, mean, rstd, A, shift, running_mean, running_var, about=None):
+    """about: the per-channel value the sums were taken about (conv_fwd(..., p=(None,)*4 + (about,))), or None."""
     nrep = sums.shape[0] if sums.dim() == 3 else 1      # [nrep][2][C] slices (conv_fwd(stats_rep=nrep)) or [2][C]
     _check(load().lmn_bn_finalize(_p(sums), nrep, _f(count), _p(gamma), _p(beta), _f(eps), _f(momentum), _p(mean), _p(rstd),
-                                  _p(A), _p(shift), _p(running_mean), _p(running_var), gamma.numel(), _stream()),
+                                  _p(A), _p(shift), _p(running_mean), _p(running_var), _p(about), gamma.numel(), _stream()),
            "bn_finalize")
 
 

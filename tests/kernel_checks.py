@@ -703,4 +703,35 @@ def check_conv_bf16():
     return rows
 
 
+def check_bn_shifted_stats():
+    """Batch variance when |mean| >> std (a large conv bias: |mean| / std ~ 1e3).  The conv epilogue sums about the
+    BatchNorm's running mean (lmn_conv_fwd p4 / lmn_bn_finalize `about`), so E[d^2] - E[d]^2 does not cancel the squared
+    mean; the un-shifted single-pass form loses the variance entirely in fp32 at this ratio."""
+    rows = []
+    B, H, W, cin, cout = 2, 40, 36, 12, 24
+    x = R(B, cin, H, W, seed=91)
+    w = R(cout, cin, 1, 1, seed=92, scale=0.05)
+    b = R(cout, seed=93) * 300.0 + 500.0
+    z = F.conv2d(x, w, b)
+    mean_ref, var_ref = z.mean((0, 2, 3)), z.var((0, 2, 3), unbiased=False)
+    about = dev(b + R(cout, seed=94) * 0.3)                      # a running mean close to (not equal to) the batch mean
+    wp = hip.conv_pack(dev(w), 1, [cin])
+    for tag, ab in (("about running mean", about), ("about 0 (old form)", None)):
+        sums = torch.zeros(16, 2, cout, device=DEV)
+        hip.conv_fwd([nhwc(x)], wp, None, B=B, Hin=H, Win=W, Hout=H, Wout=W, Cout=cout, bias=dev(b), stats=sums,
+                     stats_mode=hip.STATS_SUM_SQ, stats_rep=16, p=(None, None, None, None, ab))
+        mean, rstd = torch.empty(cout, device=DEV), torch.empty(cout, device=DEV)
+        hip.bn_finalize(sums, B * H * W, torch.ones(cout, device=DEV), torch.zeros(cout, device=DEV), 0.0, 0.1, mean, rstd,
+                        None, None, None, None, about=ab)
+        var = 1.0 / (rstd.double().cpu() ** 2)
+        e = float(((var - var_ref).abs() / var_ref).max())
+        if ab is not None:
+            rows.append(("BN variance at |mean|/std ~ 1e3, sums " + tag, e, 1e-3))
+            rows.append(("BN mean at |mean|/std ~ 1e3", rel(mean, mean_ref), 1e-6))
+        else:
+            rows.append(("(for contrast) un-shifted variance error %.1e is > 10x worse" % e, 0.0 if e > 1e-2 else 1.0, 0.5))
+    return rows
+
+
 ALL_CHECKS.append(check_conv_bf16)
+ALL_CHECKS.append(check_bn_shifted_stats)

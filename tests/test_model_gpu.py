@@ -495,3 +495,32 @@ def test_bf16_mixed_precision_path():
     dice, iou = dice_iou(pred, disc_labels(1, 352, 352))
     assert abs(dice - float(g3["dice"][0])) < 2e-3 and abs(iou - float(g3["iou"][0])) < 2e-3
     assert abs(int(pred.sum()) - int(g3["pred_sum"][0])) < 124         # < 0.1 % of the argmax decisions flip
+
+
+def test_loss_and_metrics_vs_reference_classes():
+    """Rows N1 / N2 pinned to the REAL reference: tests/golden/loss_metrics.npz holds the value and logits-gradient of
+    nn.CrossEntropyLoss(weight=[1,4], label_smoothing=1e-3) + utils/loss.py::DiceLoss(2)(..., weight=[1,4]) exactly as
+    utils/train_eval_utils.py:141 calls them (float64), and the confusion matrix / Dice / mean Dice / mIoU / accuracy of
+    utils/train_eval_utils.py::Evaluator on argmax(logits) (tools/make_golden_loss.py imports both classes)."""
+    from lm_net_amd.loss import SegLoss
+    from lm_net_amd.metrics import ConfusionMeter
+    g = load_golden("loss_metrics.npz")
+    for tag in ("a", "b"):
+        B, H, W, scale = g[tag + "/meta"]
+        B, H, W = int(B), int(H), int(W)
+        lg = (det_input((B, 2, H, W), "loss/%s" % tag) * float(scale)).cuda().requires_grad_(True)
+        y = disc_labels(B, H, W, seed=77).cuda()
+        loss = SegLoss(ce_weight=(1.0, 4.0), dice_weight=(1.0, 4.0), label_smoothing=0.001).cuda()(lg, y)
+        loss.backward()
+        ref = float(g[tag + "/loss"][0])
+        assert abs(float(loss.detach()) - ref) < 2e-6 * max(1.0, abs(ref)), (tag, float(loss.detach()), ref)
+        assert rel_err(lg.grad, g[tag + "/dlogits"]) < 1e-5, tag
+        m = ConfusionMeter(2)
+        m.update(lg.detach(), y)
+        r = m.compute()
+        conf = torch.tensor(r["confusion"], dtype=torch.float64)
+        assert torch.equal(conf, torch.from_numpy(g[tag + "/confusion"]))          # integer counts: exact
+        assert abs(r["dice"][1] - float(g[tag + "/dice_fg"][0])) < 1e-12           # Evaluator.Dice (foreground class)
+        assert abs(sum(r["dice"]) / 2 - float(g[tag + "/mean_dice"][0])) < 1e-12   # Evaluator.Mean_Dice
+        assert abs(sum(r["iou"]) / 2 - float(g[tag + "/miou"][0])) < 1e-12         # Mean_Intersection_over_Union
+        assert abs(r["accuracy"] - float(g[tag + "/acc"][0])) < 1e-12
