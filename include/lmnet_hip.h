@@ -11,7 +11,13 @@
  * Each entry cites the reference code whose arithmetic it replaces.
  *
  * Conventions
- *   - all tensors are fp32 device pointers; activations are NHWC ("pixel-major"): element
+ *   - parameters, statistics, gradients of parameters and workspaces are fp32 device pointers.  ACTIVATION tensors
+ *     (`const void*` / `void*` arguments, lmn_src_t.ptr, aux / residual / out / dy of the conv family) are stored
+ *     as fp32 or bf16: every activation tensor of ONE call has the storage type named by its `act_dtype` argument
+ *     (LMN_F32 | LMN_BF16; all arithmetic, accumulation and statistics are fp32 either way).  Strides and offsets
+ *     are in ELEMENTS.  The network input and the logits are fp32 NCHW; lmn_nchw_to_nhwc / lmn_nhwc_to_nchw are
+ *     the converters at that boundary.
+ *   - activations are NHWC ("pixel-major"): element
  *     (b,y,x,c) of a tensor with pixel stride `cstride` lives at ((b*H+y)*W+x)*cstride + c.
  *     A pointer may address a channel slice of a wider buffer (cstride > C) -- this is how
  *     torch.cat along channels (core/modules.py:104,139,497) is expressed without a copy.
@@ -33,7 +39,7 @@ extern "C" {
 
 typedef void* lmn_stream_t; /* hipStream_t */
 
-#define LMN_ABI_VERSION 4
+#define LMN_ABI_VERSION 5
 /* arithmetic type of the matrix-core operands of a dense contraction (accumulators, epilogues, statistics: fp32) */
 #define LMN_F32 0  /* v_mfma_f32_16x16x4_f32: exact fp32 (k-ordered fma chain)                                  */
 #define LMN_BF16 1 /* v_mfma_f32_16x16x16_bf16: operands rounded to bf16 (RNE) when staged / packed -- the mixed- */
@@ -63,7 +69,7 @@ const char* lmn_last_error(void);
 #define LMN_SRC_DROP 2 /* x <- x * keep(seed,idx)/(1-p) (same mask as the forward epilogue)      */
 
 typedef struct {
-  const float* ptr;   /* NHWC base, already offset to the slice's first channel                   */
+  const void* ptr;    /* NHWC base (act_dtype of the call), already offset to the slice's first channel */
   const float* scale; /* optional [B][C] per-(image,channel) multiplier (SE gate) or NULL         */
   int32_t C;          /* channels contributed by this source (multiple of 4)                      */
   int32_t cstride;    /* floats between consecutive pixels                                        */
@@ -106,9 +112,9 @@ typedef struct {
   const float* p2;
   const float* p3;
   const float* p4;       /* per-Cout epilogue vectors                                             */
-  const float* aux;      /* epilogue tensor sampled at the output element, or NULL                */
-  const float* residual; /* added after everything else, or NULL                                  */
-  float* out;            /* NULL: nothing is written (statistics-only pass)                       */
+  const void* aux;       /* epilogue ACTIVATION tensor sampled at the output element, or NULL     */
+  const void* residual;  /* activation tensor added after everything else, or NULL                */
+  void* out;             /* activation tensor; NULL: nothing is written (statistics-only pass)    */
   float* stats;          /* see stats_mode                                                        */
   int32_t aux_cstride, res_cstride, out_cstride;
   int32_t epilogue, act, stats_mode;
@@ -123,6 +129,8 @@ typedef struct {
                             /* 2 cache lines cost 15-20 us of same-address atomics); the consumers              */
                             /* (lmn_bn_finalize / lmn_bn_bwd_coef, argument nrep) sum the slices                */
                             /* mma_dtype: LMN_F32 | LMN_BF16 -- `wpack` must have been packed with the same dtype */
+  int32_t act_dtype;        /* storage of src[].ptr / aux / residual / out: LMN_F32, or LMN_BF16 (needs mma_dtype   */
+  int32_t _pad1;            /* LMN_BF16)                                                                             */
 } lmn_conv_args_t;
 
 /* number of floats lmn_conv_pack writes for (ksize, Cout, src channel counts c[nsrc]) */
@@ -162,7 +170,7 @@ int lmn_conv_fwd(const lmn_conv_args_t* args, lmn_stream_t stream);
 typedef struct {
   int32_t B, Hout, Wout, Hin, Win, ksize, stride, nsrc, Cout;
   lmn_src_t src[3];
-  const float* dy;
+  const void* dy;   /* activation tensor (act_dtype) */
   int32_t dy_cstride;
   int32_t dy_flags;
   uint32_t dy_seed;
@@ -178,7 +186,7 @@ typedef struct {
                     /* every source has its own tensor)                                                        */
   float* db2;       /* optional second bias gradient receiving the same sum as db                              */
   int32_t mma_dtype; /* LMN_F32 | LMN_BF16: operand type of the pixel-reduction MFMAs (accumulators fp32)                */
-  int32_t _pad;
+  int32_t act_dtype; /* storage of src[].ptr and dy                                                                      */
 } lmn_wgrad_args_t;
 int lmn_sizeof_wgrad_args(void);
 /* floats of workspace that make lmn_conv_wgrad use the two-stage reduction for this problem (0: not useful) */
@@ -192,14 +200,14 @@ int lmn_conv_wgrad(const lmn_wgrad_args_t* args, lmn_stream_t stream);
  * ------------------------------------------------------------------------------------------ */
 /* batch statistics of the four branch outputs: stats[4][2][E] += (sum y_b, sum y_b^2), b=0..3
  * in the order large(5x5), square(3x3), ver(3x1), hor(1x3); each [2][E] row pair feeds lmn_bn_finalize. */
-int lmn_dw_stats(const float* x1, int B, int H, int W, int E, const float* w5, const float* w3, const float* wv,
-                 const float* wh, float* stats, lmn_stream_t stream);
+int lmn_dw_stats(const void* x1, int B, int H, int W, int E, const float* w5, const float* w3, const float* wv,
+                 const float* wh, float* stats, int act_dtype, lmn_stream_t stream);
 /* pre = sum_b A_b * conv_b(x1) + bias  expressed as ONE merged 5x5 stencil keff[E][25] + beff[E]
  * (training: A_b = gamma_b*rstd_b from lmn_dw_stats; eval/deploy: running stats, i.e. exactly
  * ReparamConv.get_equivalent_kernel_bias, core/modules.py:622-642).  Writes `pre` (the GELU
  * input) and accumulates gsum[B][E] += sum_hw gelu(pre) for the SE squeeze (modules.py:1030). */
-int lmn_dw_fwd(const float* x1, float* pre, float* gsum, int B, int H, int W, int E, const float* keff,
-               const float* beff, lmn_stream_t stream);
+int lmn_dw_fwd(const void* x1, void* pre, float* gsum, int B, int H, int W, int E, const float* keff,
+               const float* beff, int act_dtype, lmn_stream_t stream);
 /* builds keff/beff on the device from the four branch weights and per-branch affine (A_b, shift_b) */
 /* Training forward between lmn_dw_stats and lmn_dw_fwd, one launch: finalise the four branch BatchNorms from the
  * batch sums `stats` [4][2][E] (mean/rstd/A [4][E] out, running statistics updated with `momentum`, unbiased variance
@@ -214,9 +222,9 @@ int lmn_dw_merge(const float* w5, const float* w3, const float* wv, const float*
                  const float* shift /*[4][E]*/, float* keff, float* beff, int E, lmn_stream_t stream);
 /* backward, pass 1: dpre = (u*s[b,e] + dm[b,e]) * gelu'(pre); writes dpre and accumulates
  * bstats[5][E] += (sum dpre, sum dpre*y_b for the 4 branches).                               */
-int lmn_dw_bwd_stats(const float* x1, const float* pre, const float* u, const float* s, const float* dm,
-                     float* dpre, int B, int H, int W, int E, const float* w5, const float* w3, const float* wv,
-                     const float* wh, float* bstats, lmn_stream_t stream);
+int lmn_dw_bwd_stats(const void* x1, const void* pre, const void* u, const float* s, const float* dm,
+                     void* dpre, int B, int H, int W, int E, const float* w5, const float* w3, const float* wv,
+                     const float* wh, float* bstats, int act_dtype, lmn_stream_t stream);
 /* per-branch BatchNorm-backward coefficients from bstats (pass 1) and the forward statistics
  * mean/rstd/A ([4][E] each): dgamma_b += T_b, dbeta_b += S0, and f_b = cA*dpre + cC*y_b + cD
  * (batch_stats=0, i.e. eval-mode BN: cC = cD = 0).                                            */
@@ -225,9 +233,9 @@ int lmn_dw_bwd_coef(const float* bstats, const float* mean, const float* rstd, c
                     float* db0, float* db1, float* db2, float* db3, int E, lmn_stream_t stream);
 /* backward, pass 2: f_b = cA[b]*dpre + cC[b]*y_b + cD[b] (inside the image), dx1 = sum_b w_b^T * f_b,
  * dW_b[e][t] += sum_p f_b[p] * x1[p+t]  into the four torch-layout weight gradients.          */
-int lmn_dw_bwd(const float* x1, const float* dpre, float* dx1, int B, int H, int W, int E, const float* w5,
+int lmn_dw_bwd(const void* x1, const void* dpre, void* dx1, int B, int H, int W, int E, const float* w5,
                const float* w3, const float* wv, const float* wh, const float* cA, const float* cC,
-               const float* cD, float* dw5, float* dw3, float* dwv, float* dwh, lmn_stream_t stream);
+               const float* cD, float* dw5, float* dw3, float* dwv, float* dwh, int act_dtype, lmn_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * SE gate (core/modules.py:1020-1036): s = hardsigmoid(W2 relu(W1 m + b1) + b2), m = gsum/HW.
@@ -245,44 +253,44 @@ int lmn_se_bwd(const float* ds, const float* gsum, float inv_hw, const float* w1
  * reshape(B,H,W,3,heads,hd)); out: [B,H,W,C] channel = head*hd + d; rpb: [heads][2K-1][2K-1].
  * K = 3 (the reference hard-codes kernel_size=3, core/modules.py:509).  scale = hd^-0.5.
  * ------------------------------------------------------------------------------------------ */
-int lmn_na_fwd(const float* qkv, const float* rpb, float* out, int B, int H, int W, int heads, int hd, float scale,
-               lmn_stream_t stream);
+int lmn_na_fwd(const void* qkv, const float* rpb, void* out, int B, int H, int W, int heads, int hd, float scale,
+               int act_dtype, lmn_stream_t stream);
 /* dqkv is fully overwritten (two gather passes, no atomics, deterministic); drpb +=;
  * stat: caller workspace of 2*heads floats per pixel ([B*H*W][2][heads]: log-sum-exp and sum_n p_n dp_n) */
-int lmn_na_bwd(const float* qkv, const float* rpb, const float* dout, float* dqkv, float* drpb, float* stat, int B,
-               int H, int W, int heads, int hd, float scale, lmn_stream_t stream);
+int lmn_na_bwd(const void* qkv, const float* rpb, const void* dout, void* dqkv, float* drpb, float* stat, int B,
+               int H, int W, int heads, int hd, float scale, int act_dtype, lmn_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Dense global attention of GFT (core/modules.py:267-279): qkv [B,N,3C] (channel = which*C +
  * head*hd + d), out [B,N,C].  N <= 1024 tokens, hd <= 32.
  * ------------------------------------------------------------------------------------------ */
-int lmn_gattn_fwd(const float* qkv, float* out, float* lse, int B, int N, int heads, int hd, float scale,
+int lmn_gattn_fwd(const void* qkv, void* out, float* lse, int B, int N, int heads, int hd, float scale, int act_dtype,
                   lmn_stream_t stream);
 /* delta: caller workspace [B*heads*N]; dqkv is fully overwritten (no atomics) */
-int lmn_gattn_bwd(const float* qkv, const float* out, const float* dout, const float* lse, float* dqkv, float* delta,
-                  int B, int N, int heads, int hd, float scale, lmn_stream_t stream);
+int lmn_gattn_bwd(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, float* delta,
+                  int B, int N, int heads, int hd, float scale, int act_dtype, lmn_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * LayerNorm over the channel axis of NHWC rows (core/modules.py:330,333,508,511); eps = 1e-5.
  * ------------------------------------------------------------------------------------------ */
-int lmn_ln_fwd(const float* x, const float* gamma, const float* beta, float* y, int64_t rows, int C,
+int lmn_ln_fwd(const void* x, const float* gamma, const float* beta, void* y, int64_t rows, int C, int act_dtype,
                lmn_stream_t stream);
 /* dx = LN backward (+ dres if not NULL: the residual branch's gradient); dgamma/dbeta += */
-int lmn_ln_bwd(const float* x, const float* gamma, const float* dy, const float* dres, float* dx, float* dgamma,
-               float* dbeta, int64_t rows, int C, lmn_stream_t stream);
+int lmn_ln_bwd(const void* x, const float* gamma, const void* dy, const void* dres, void* dx, float* dgamma,
+               float* dbeta, int64_t rows, int C, int act_dtype, lmn_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * BatchNorm(batch stats)+GELU tail of M2Skip/M3Skip.fuse_conv (core/modules.py:96-99,121-123,131-134)
  * on a stored conv output z:  y = gelu(z*a[c] + b[c]).
  * ------------------------------------------------------------------------------------------ */
-int lmn_bnact_fwd(const float* z, const float* a, const float* b, float* y, int64_t rows, int C, int act,
+int lmn_bnact_fwd(const void* z, const float* a, const float* b, void* y, int64_t rows, int C, int act, int act_dtype,
                   lmn_stream_t stream);
 /* pass 1: dh = dy*act'(h); stats[2][C] += (sum dh, sum dh*zhat) ; pass 2: dz = c1*dh - c2 - zhat*c3 */
-int lmn_bnact_bwd_stats(const float* z, const float* dy, const float* mean, const float* rstd, const float* gamma,
-                        const float* beta, float* stats, int64_t rows, int C, int act, lmn_stream_t stream);
-int lmn_bnact_bwd(const float* z, const float* dy, const float* mean, const float* rstd, const float* gamma,
-                  const float* beta, const float* c1, const float* c2, const float* c3, float* dz, int64_t rows,
-                  int C, int act, lmn_stream_t stream);
+int lmn_bnact_bwd_stats(const void* z, const void* dy, const float* mean, const float* rstd, const float* gamma,
+                        const float* beta, float* stats, int64_t rows, int C, int act, int act_dtype, lmn_stream_t stream);
+int lmn_bnact_bwd(const void* z, const void* dy, const float* mean, const float* rstd, const float* gamma,
+                  const float* beta, const float* c1, const float* c2, const float* c3, void* dz, int64_t rows,
+                  int C, int act, int act_dtype, lmn_stream_t stream);
 
 /* BatchNorm bookkeeping on [C]-vectors (momentum 0.1, unbiased running var; torch semantics).
  * sums = [2][C] (sum, sumsq) over `count` elements.  Writes mean, rstd (biased var + eps),
@@ -306,15 +314,15 @@ int lmn_bn_bwd_coef(const float* bstats, int nrep, float count, int batch_stats,
  * Resampling rows: bilinear x2 upsample with align_corners=True (core/LM_Net.py:59-72,
  * modules.py:94,129) and the exact f x f mean pool of PyramidPool (modules.py:496).
  * ------------------------------------------------------------------------------------------ */
-int lmn_up2_fwd(const float* x, float* y, int B, int Hin, int Win, int C, int x_cstride, int y_cstride,
+int lmn_up2_fwd(const void* x, void* y, int B, int Hin, int Win, int C, int x_cstride, int y_cstride, int act_dtype,
                 lmn_stream_t stream);
-int lmn_up2_bwd(const float* dy, float* dx, int B, int Hin, int Win, int C, int dy_cstride, int dx_cstride,
+int lmn_up2_bwd(const void* dy, void* dx, int B, int Hin, int Win, int C, int dy_cstride, int dx_cstride, int act_dtype,
                 lmn_stream_t stream);
-int lmn_avgpool_fwd(const float* x, float* y, int B, int Hout, int Wout, int f, int C, int x_cstride,
-                    int y_cstride, lmn_stream_t stream);
+int lmn_avgpool_fwd(const void* x, void* y, int B, int Hout, int Wout, int f, int C, int x_cstride,
+                    int y_cstride, int act_dtype, lmn_stream_t stream);
 /* dx = (accumulate ? dx : 0) + dy/(f*f) broadcast over each f x f window */
-int lmn_avgpool_bwd(const float* dy, float* dx, int B, int Hout, int Wout, int f, int C, int dy_cstride,
-                    int dx_cstride, int accumulate, lmn_stream_t stream);
+int lmn_avgpool_bwd(const void* dy, void* dx, int B, int Hout, int Wout, int f, int C, int dy_cstride,
+                    int dx_cstride, int accumulate, int act_dtype, lmn_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Boundary layout rows.  The network input arrives NCHW [B,channel,H,W] (core/LM_Net.py:95) and the
@@ -323,9 +331,9 @@ int lmn_avgpool_bwd(const float* dy, float* dx, int B, int Hout, int Wout, int f
  * rows padded to a multiple of 4, then lmn_nhwc_to_nchw keeps the first n_classes channels.
  * ------------------------------------------------------------------------------------------ */
 /* y[b,h,w,0:C] = x[b,0:C,h,w]; y[b,h,w,C:y_cstride] = 0 */
-int lmn_nchw_to_nhwc(const float* x, float* y, int B, int C, int H, int W, int y_cstride, lmn_stream_t stream);
+int lmn_nchw_to_nhwc(const float* x, void* y, int B, int C, int H, int W, int y_cstride, int act_dtype, lmn_stream_t stream);
 /* y[b,0:C,h,w] = x[b,h,w,0:C]  (x has pixel stride x_cstride) */
-int lmn_nhwc_to_nchw(const float* x, float* y, int B, int C, int H, int W, int x_cstride, lmn_stream_t stream);
+int lmn_nhwc_to_nchw(const void* x, float* y, int B, int C, int H, int W, int x_cstride, int act_dtype, lmn_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Small utilities
@@ -361,12 +369,12 @@ int lmn_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, floa
                    float eps, float weight_decay, float bias_corr1, float bias_corr2, lmn_stream_t stream);
 int lmn_fill(float* p, float v, int64_t n, lmn_stream_t stream);
 /* y = a + b (+ c) (+ d); any of c,d may be NULL; y may alias a */
-int lmn_add(const float* a, const float* b, const float* c, const float* d, float* y, int64_t n,
+int lmn_add(const void* a, const void* b, const void* c, const void* d, void* y, int64_t n, int act_dtype,
             lmn_stream_t stream);
 /* out[C] += column sums of x[rows][cstride] (bias gradients) */
-int lmn_colsum(const float* x, float* out, int64_t rows, int C, int cstride, lmn_stream_t stream);
+int lmn_colsum(const void* x, float* out, int64_t rows, int C, int cstride, int act_dtype, lmn_stream_t stream);
 /* copy a channel slice: y[rows][y_cstride][0:C] = x[rows][x_cstride][0:C] */
-int lmn_copy_slice(const float* x, float* y, int64_t rows, int C, int x_cstride, int y_cstride,
+int lmn_copy_slice(const void* x, void* y, int64_t rows, int C, int x_cstride, int y_cstride, int act_dtype,
                    lmn_stream_t stream);
 
 /* y[r][0:cols] = x[r][0:cols] for r < rows, any cols >= 1 (row strides in floats): pads / un-pads the few weights whose

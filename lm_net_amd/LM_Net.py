@@ -10,7 +10,7 @@ import torch
 import torch.nn as nn
 
 from . import hip
-from .engine import Arena, Ctx, Engine, GradSlot, _E, _Z
+from .engine import Arena, Ctx, Engine, GradSlot, _A, _E, _Z
 from .hip import V
 from .modules import (GFT, NUM_HEADS, M2Skip, M3Skip, NeighborhoodTransformer, PyramidPool, ReparamConv, _conv, stage)
 
@@ -150,9 +150,13 @@ class LM_Net(nn.Module):
         self._taps = None
         self.use_graphs = False   # capture the training step into hipGraphs (see enable_graphs)
         self._graphs = {}
-        # arithmetic of the dense contractions: None = follow torch.autocast (bf16 / fp16 autocast -> bf16 matrix-core
-        # operands, else fp32), or "fp32" / "bf16" to pin it (custom autograd nodes are opaque to autocast, so the module
-        # reads the autocast state itself: the reference's AMP branch, utils/train_eval_utils.py:130-138, keeps working)
+        # precision of the pass: None = follow torch.autocast (bf16 / fp16 autocast -> "bf16", else "fp32"), or pinned:
+        #   "fp32"      fp32 activations, exact fp32 MFMA                     (BASELINE configs[1], the default)
+        #   "bf16"      bf16 ACTIVATION STORAGE + bf16 MFMA operands; fp32 accumulators, BatchNorm / LayerNorm / softmax
+        #               statistics, master weights and weight gradients     (BASELINE configs[2])
+        #   "bf16-mma"  fp32 activation storage, bf16 MFMA operands only
+        # (custom autograd nodes are opaque to autocast, so the module reads the autocast state itself: the reference's
+        #  AMP branch, utils/train_eval_utils.py:130-138, keeps working)
         self.compute_dtype = None
         self.use_plans = False    # replay recorded C-side schedules (see enable_plans)
         self._plans = {}
@@ -187,7 +191,7 @@ class LM_Net(nn.Module):
         if params and not params[0].is_cuda:
             raise RuntimeError("lm_net_amd.LM_Net: parameters are on %s; call model.to('cuda')" % params[0].device)
         x = x.float().contiguous() if x.dtype != torch.float32 or not x.is_contiguous() else x
-        self._engine.mma = self._mma_mode()
+        self._engine.mma, self._engine.act_dtype = self._precision()
         self._save_tape = torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in params))
         if self.use_plans and not x.requires_grad and not self._keep_taps and (self._save_tape or not torch.is_grad_enabled()):
             ps = self._plan_for(x)
@@ -205,16 +209,19 @@ class LM_Net(nn.Module):
                 return out
         return _LMNetFunction.apply(x, self, *params)
 
-    def _mma_mode(self):
+    def _precision(self):
+        """(matrix-core operand type, activation storage type) of the next pass."""
         cd = self.compute_dtype
         if cd is None:
             amp = torch.is_autocast_enabled() and torch.get_autocast_dtype('cuda') in (torch.bfloat16, torch.float16)
-            return hip.BF16 if amp else hip.F32
-        if cd in ("bf16", "bfloat16", torch.bfloat16):
-            return hip.BF16
+            cd = "bf16" if amp else "fp32"
+        if cd in ("bf16", "bfloat16", torch.bfloat16):       # bf16 activation storage + bf16 MFMA operands
+            return hip.BF16, torch.bfloat16
+        if cd in ("bf16-mma", "bf16_mma"):                   # fp32 activation storage, bf16 MFMA operands only
+            return hip.BF16, torch.float32
         if cd in ("fp32", "f32", "float32", torch.float32):
-            return hip.F32
-        raise ValueError("LM_Net.compute_dtype must be None, 'fp32' or 'bf16' (got %r)" % (cd,))
+            return hip.F32, torch.float32
+        raise ValueError("LM_Net.compute_dtype must be None, 'fp32', 'bf16' or 'bf16-mma' (got %r)" % (cd,))
 
     # ------------------------------------------------------------------ recorded C-side schedules (lmn_plan_*)
     def enable_plans(self, on=True):
@@ -233,7 +240,7 @@ class LM_Net(nn.Module):
 
     def _plan_for(self, x):
         train = bool(self.training and self._save_tape)
-        key = (tuple(x.shape), x.device, self.training, self._save_tape, self._engine.mma)
+        key = (tuple(x.shape), x.device, self.training, self._save_tape, self._engine.pm())
         ps = self._plans.get(key)
         if ps is None:
             ps = self._plans[key] = _PlannedStep()
@@ -275,7 +282,7 @@ class LM_Net(nn.Module):
             self._step_bookkeeping()
             if ps.cx is not None:
                 ps.cx.training = self.training
-                ps.cx.mma = eng.mma
+                ps.cx.mma, ps.cx.act_dtype = eng.mma, eng.act_dtype
             ps.fwd.run()
         ps.pending = ps.cx is not None
         return ps.out.clone()
@@ -349,7 +356,7 @@ class LM_Net(nn.Module):
         launch-minimal inference schedule).  Two eager calls of a shape warm the workspaces up, the third is captured;
         weight packing and BatchNorm folding are kernels inside the graph, so parameter / running-stat updates between
         calls are honoured; `structural_reparam()` drops the graphs.  Returns None while warming up."""
-        key = ("infer", tuple(x.shape), x.device, self._engine.mma)
+        key = ("infer", tuple(x.shape), x.device, self._engine.pm())
         gs = self._graphs.get(key)
         if gs is None:
             gs = self._graphs[key] = _GraphedStep()
@@ -372,7 +379,7 @@ class LM_Net(nn.Module):
         return gs.out.clone()
 
     def _graph_for(self, x):
-        key = (tuple(x.shape), x.device, self._engine.mma)
+        key = (tuple(x.shape), x.device, self._engine.pm())
         gs = self._graphs.get(key)
         if gs is None:
             gs = self._graphs[key] = _GraphedStep()
@@ -429,7 +436,7 @@ class LM_Net(nn.Module):
         eng.training = self.training
         if cx is not None:
             cx.training = self.training             # the backward of THIS pass uses the BatchNorm mode it ran in
-            cx.mma = eng.mma                        # ... and the same matrix-core operand type
+            cx.mma, cx.act_dtype = eng.mma, eng.act_dtype   # ... and the same arithmetic / storage types
         self._step_bookkeeping()
         with torch.cuda.device(x.device):
             eng.begin_pass(False, x.device)
@@ -439,7 +446,7 @@ class LM_Net(nn.Module):
                 nf = eng.alloc_floats
                 eng.end_pass()
         if self.use_plans:
-            key = (tuple(x.shape), x.device, self.training, self._save_tape, eng.mma)
+            key = (tuple(x.shape), x.device, self.training, self._save_tape, eng.pm())
             ps = self._plans.get(key)
             if ps is not None:
                 ps.need_fwd = max(ps.need_fwd, nf)
@@ -452,7 +459,7 @@ class LM_Net(nn.Module):
         B, Cin, H, W = x.shape
         c4 = (Cin + 3) // 4 * 4
         dev = x.device
-        xin = _E(dev, B, H, W, c4)
+        xin = _A(dev, B, H, W, c4)
         hip.nchw_to_nhwc(x, xin)
         f = self.filters
         main = torch.cuda.current_stream(dev)
@@ -484,19 +491,19 @@ class LM_Net(nn.Module):
             return out
 
         x1 = eng.stage_fwd(self.conv1, xin, cx)
-        xd1 = _E(dev, B, H // 2, W // 2, f[1]); eng.conv3_fwd(self.down1[0], x1, xd1, s=2)
+        xd1 = _A(dev, B, H // 2, W // 2, f[1]); eng.conv3_fwd(self.down1[0], x1, xd1, s=2)
         x2 = eng.stage_fwd(self.conv2, xd1, cx)
         r4 = chain(self.skip4, self.natt4, (x1, x2), 8) if fork else None
-        xd2 = _E(dev, B, H // 4, W // 4, f[2]); eng.conv3_fwd(self.down2[0], x2, xd2, s=2)
+        xd2 = _A(dev, B, H // 4, W // 4, f[2]); eng.conv3_fwd(self.down2[0], x2, xd2, s=2)
         x3 = eng.stage_fwd(self.conv3, xd2, cx)
         r3 = chain(self.skip3, self.natt3, (x1, x2, x3), 6) if fork else None
-        xd3 = _E(dev, B, H // 8, W // 8, f[3]); eng.conv3_fwd(self.down3[0], x3, xd3, s=2)
+        xd3 = _A(dev, B, H // 8, W // 8, f[3]); eng.conv3_fwd(self.down3[0], x3, xd3, s=2)
         x4 = eng.stage_fwd(self.conv4, xd3, cx)
         r1 = chain(self.skip1, self.natt1, (x3, x4), 2) if fork else None
         r2 = chain(self.skip2, self.natt2, (x2, x3, x4), 4) if fork else None
         # PyramidPool: mean-pool x1..x4 onto the 1/16 grid, down4 writes x_down4 straight into its slice
         h, w = H // 16, W // 16
-        catp = _E(dev, B, h, w, sum(f))
+        catp = _A(dev, B, h, w, sum(f))
         off = 0
         for t, fac in ((x1, 16), (x2, 8), (x3, 4), (x4, 2)):
             hip.avgpool_fwd(t, V(catp, off, t.shape[-1]), fac)
@@ -522,7 +529,7 @@ class LM_Net(nn.Module):
         # bias lives in a persistent 4-vector), then NHWC -> NCHW keeps the first n_classes channels
         ncp = (self.n_classes + 3) // 4 * 4
         bh = self._head_bias(ncp)
-        o4 = _E(dev, B, H, W, ncp)
+        o4 = _A(dev, B, H, W, ncp)
         eng.conv([x9], self.output_layer.weight, bh, o4, Hin=H, Win=W, cout=ncp)
         logits = _E(dev, B, self.n_classes, H, W)
         hip.nhwc_to_nchw(o4, logits)
@@ -617,7 +624,7 @@ class LM_Net(nn.Module):
             raise RuntimeError("backward called on a forward pass that saved no state")
         eng = self._engine
         eng.training = getattr(cx, "training", eng.training)     # the mode of the forward this tape belongs to
-        eng.mma = getattr(cx, "mma", eng.mma)
+        eng.mma, eng.act_dtype = getattr(cx, "mma", eng.mma), getattr(cx, "act_dtype", eng.act_dtype)
         with torch.cuda.device(dlogits.device):
             if plan is None:
                 flat, G = self._new_grads()
@@ -654,13 +661,13 @@ class LM_Net(nn.Module):
         dev = dlogits.device
         # head
         ncp, c0 = A["ncp"], f[0]
-        dy4 = _E(dev, B, H, W, ncp)
+        dy4 = _A(dev, B, H, W, ncp)
         hip.nchw_to_nhwc(dlogits, dy4)
         dWh, dbh = _Z(dev, ncp, c0), _Z(dev, ncp)
         eng.wgrad([A["x9"]], dy4, None, None, Hin=H, Win=W, dW=dWh, db=dbh)
         hip.copy2d(dWh, G[self.output_layer.weight], self.n_classes, c0, c0, c0)      # drop the padding rows
         hip.copy2d(dbh, G[self.output_layer.bias], 1, self.n_classes, ncp, self.n_classes)
-        dx9 = _E(dev, *A["x9"].shape)
+        dx9 = _A(dev, *A["x9"].shape)
         eng.conv_T(dy4, self.output_layer.weight, dx9, Hin=H, Win=W)
         self._done("output_layer")
         gacc = {id(A[k]): GradSlot() for k in ("x1", "x2", "x3", "x4")}

@@ -61,6 +61,40 @@ void lmn_rec_push(std::function<int()>&& f);
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// ---------------------------------------------------------------- activation storage: fp32 or bf16
+// Every activation tensor of a call has ONE storage type (lmn act_dtype: LMN_F32 | LMN_BF16); kernels are templated on it
+// and do all arithmetic in fp32: ld4 / st4 move 4 consecutive channels (16 B or 8 B per lane), conversion is one
+// v_cvt_pk_bf16_f32 per pair on the way out (round to nearest even) and a shift on the way in.
+typedef __bf16 lmn_bf16;
+typedef __bf16 lmn_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float lmn_f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t lmn_pk_bf16(float a, float b) {
+  const lmn_f32x2 t = {a, b};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(t, lmn_bf16x2));
+}
+__device__ __forceinline__ float lmn_bf16_lo(uint32_t u) { return __builtin_bit_cast(float, u << 16); }
+__device__ __forceinline__ float lmn_bf16_hi(uint32_t u) { return __builtin_bit_cast(float, u & 0xFFFF0000u); }
+__device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+__device__ __forceinline__ f32x4 ld4(const lmn_bf16* p) {
+  const uint2 r = *reinterpret_cast<const uint2*>(p);
+  return f32x4{lmn_bf16_lo(r.x), lmn_bf16_hi(r.x), lmn_bf16_lo(r.y), lmn_bf16_hi(r.y)};
+}
+__device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+__device__ __forceinline__ void st4(lmn_bf16* p, f32x4 v) {
+  *reinterpret_cast<uint2*>(p) = uint2{lmn_pk_bf16(v[0], v[1]), lmn_pk_bf16(v[2], v[3])};
+}
+__device__ __forceinline__ float ld1(const float* p) { return *p; }
+__device__ __forceinline__ float ld1(const lmn_bf16* p) { return lmn_bf16_lo((uint32_t)*reinterpret_cast<const uint16_t*>(p)); }
+__device__ __forceinline__ void st1(float* p, float v) { *p = v; }
+__device__ __forceinline__ void st1(lmn_bf16* p, float v) { *p = (lmn_bf16)v; }
+// host side: run `...` once with T = the storage type named by dt
+#define LMN_ACT_DISPATCH(dt, ...)                      \
+  do {                                                 \
+    if ((dt) == LMN_BF16) { typedef lmn_bf16 T; __VA_ARGS__; } \
+    else { typedef float T; __VA_ARGS__; }             \
+  } while (0)
+#define LMN_REQUIRE_DT(dt, what) LMN_REQUIRE((dt) == LMN_F32 || (dt) == LMN_BF16, what ": act_dtype %d", (int)(dt))
+
 // ---------------------------------------------------------------- activations
 // erf: Abramowitz & Stegun 7.1.26 (|abs error| <= 1.5e-7 over the whole line), branch-free: the libm erff has two
 // branches that a wave almost always takes both of (~45 instructions per element against ~13 here).  The

@@ -42,7 +42,10 @@ struct ConvParams {
   uint32_t mTW, mXW;
 };
 
-__device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+// precision mode of a conv-family kernel instance: 0 = fp32 storage + fp32 MFMA, 1 = fp32 storage + bf16 MFMA operands,
+// 2 = bf16 storage + bf16 MFMA operands (accumulators / epilogues / statistics are fp32 in every mode)
+template <int PM> struct ActT { typedef float type; };
+template <> struct ActT<2> { typedef lmn_bf16 type; };
 
 // ---- bf16 operand forms (mixed-precision path: bf16 MFMA operands, fp32 accumulators / epilogues / statistics)
 typedef short s16x4 __attribute__((ext_vector_type(4)));
@@ -78,8 +81,10 @@ __device__ __forceinline__ f32x4 mfma_bf16(uint2 a, uint2 b, f32x4 c) {
 // stride-1 problem over dy with a 1x1 / 1x2 / 2x1 / 2x2 sub-kernel: in = out_c + ((parity + pad - t) >> 1) for the taps of
 // matching parity.  The tile walks CLASS coordinates, the window is TH+1 x TW+1 pixels of dy, outputs land at
 // (2*yc + py, 2*xc + px).
-template <int TAPS, int NCT, int EPI, bool S2T = false, bool BF = false>
+template <int TAPS, int NCT, int EPI, bool S2T = false, int PM = 0>
 __global__ __launch_bounds__(256) void conv_tile_kernel(const ConvParams P) {
+  constexpr bool BF = PM >= 1;
+  typedef typename ActT<PM>::type TA;   // activation storage type
   // BF: operands rounded to bf16 when they are staged / packed, v_mfma_f32_16x16x16_bf16 (8x the fp32 MFMA rate), the LDS
   // window holds 4-bf16 fragments (pixel stride P.CS dwords = 8 per K16 block + 4: conflict-free ds_read_b64)
   typedef typename Frag<BF>::type wfrag;
@@ -201,7 +206,7 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(const ConvParams P) {
           const bool ok = ch < S.C && (unsigned)iy < (unsigned)A.Hin && (unsigned)ix < (unsigned)A.Win;
           const int gp = ok ? (b * A.Hin + iy) * A.Win + ix : 0;
           const int chs = ok ? ch : 0;
-          f32x4 v = ld4(S.ptr + (uint32_t)(gp * S.cstride + chs));
+          f32x4 v = ld4((const TA*)S.ptr + (uint32_t)(gp * S.cstride + chs));
           if (S.flags & LMN_SRC_GELU) {
 #pragma unroll
             for (int k = 0; k < 4; ++k) v[k] = lmn_gelu(v[k]);
@@ -292,7 +297,7 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(const ConvParams P) {
         }
         if (EPI) {
           f32x4 ax = f32x4{0.f, 0.f, 0.f, 0.f};
-          if (A.aux) ax = ld4(A.aux + opx * A.aux_cstride + cos);
+          if (A.aux) ax = ld4((const TA*)A.aux + opx * A.aux_cstride + cos);
           switch (ep_kind) {
             case LMN_EP_DGELU: {
 #pragma unroll
@@ -327,8 +332,8 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(const ConvParams P) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) o[r] *= lmn_drop_scale(A.drop_seed + soff, idx + r, A.drop_p, P.inv_keep_ep);
         }
-        if (A.residual) o += ld4(A.residual + opx * A.res_cstride + cos);
-        if (A.out && live) *reinterpret_cast<f32x4*>(A.out + opx * A.out_cstride + cos) = o;
+        if (A.residual) o += ld4((const TA*)A.residual + opx * A.res_cstride + cos);
+        if (A.out && live) st4((TA*)A.out + opx * A.out_cstride + cos, o);
         __builtin_amdgcn_sched_barrier(0);
       }
     }
@@ -370,8 +375,10 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(const ConvParams P) {
 // Each weight fragment is then fetched by exactly one wave of the block (the N-split form pulls every fragment
 // through L1 four times; at Cout = 372 that stream, not the MFMAs, set the pace) and feeds 8 x 4 MFMAs; the pixel
 // operand comes from LDS, where re-reading it per wave is cheap.
-template <int TAPS, int NCW, int EPI, bool BF = false>
+template <int TAPS, int NCW, int EPI, int PM = 0>
 __global__ __launch_bounds__(256) void conv_tileM_kernel(const ConvParams P) {
+  constexpr bool BF = PM >= 1;
+  typedef typename ActT<PM>::type TA;
   typedef typename Frag<BF>::type wfrag;  // (bf16 operand form: see conv_tile_kernel)
   constexpr int WT = BF ? 128 : 256;
   constexpr int KD = BF ? 8 : 16;
@@ -477,7 +484,7 @@ __global__ __launch_bounds__(256) void conv_tileM_kernel(const ConvParams P) {
           const bool ok = ch < S.C && (unsigned)iy < (unsigned)A.Hin && (unsigned)ix < (unsigned)A.Win;
           const int gp = ok ? (b * A.Hin + iy) * A.Win + ix : 0;
           const int chs = ok ? ch : 0;
-          f32x4 v = ld4(S.ptr + (uint32_t)(gp * S.cstride + chs));
+          f32x4 v = ld4((const TA*)S.ptr + (uint32_t)(gp * S.cstride + chs));
           if (S.flags & LMN_SRC_GELU) {
 #pragma unroll
             for (int k = 0; k < 4; ++k) v[k] = lmn_gelu(v[k]);
@@ -562,7 +569,7 @@ __global__ __launch_bounds__(256) void conv_tileM_kernel(const ConvParams P) {
         }
         if (EPI) {
           f32x4 ax = f32x4{0.f, 0.f, 0.f, 0.f};
-          if (A.aux) ax = ld4(A.aux + opx * A.aux_cstride + cos);
+          if (A.aux) ax = ld4((const TA*)A.aux + opx * A.aux_cstride + cos);
           switch (ep_kind) {
             case LMN_EP_DGELU: {
 #pragma unroll
@@ -597,8 +604,8 @@ __global__ __launch_bounds__(256) void conv_tileM_kernel(const ConvParams P) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) o[r] *= lmn_drop_scale(A.drop_seed + soff, idx + r, A.drop_p, P.inv_keep_ep);
         }
-        if (A.residual) o += ld4(A.residual + opx * A.res_cstride + cos);
-        if (A.out && live) *reinterpret_cast<f32x4*>(A.out + opx * A.out_cstride + cos) = o;
+        if (A.residual) o += ld4((const TA*)A.residual + opx * A.res_cstride + cos);
+        if (A.out && live) st4((TA*)A.out + opx * A.out_cstride + cos, o);
         __builtin_amdgcn_sched_barrier(0);
       }
     }
@@ -752,8 +759,10 @@ __device__ __forceinline__ float* wgrad_dst(const WgradParams& P, int co, int si
 // BF: operands rounded to bf16 when staged ([tile][pixel][16 bf16] planes, pixel stride CS dwords), a K step is 16 pixels
 // = ONE v_mfma_f32_16x16x16_bf16 per (tap, cout tile, cin tile): lane (q, n) gathers pixels 4q..4q+3 of channel n with
 // four ds_read_u16 per operand (the same LDS instruction count per pixel as the fp32 form, an eighth of its MFMA time).
-template <int TAPS, int NMT, int NNT, bool BF = false>
+template <int TAPS, int NMT, int NNT, int PM = 0>
 __global__ __launch_bounds__(256, 2) void wgrad_lds_kernel(const WgradParams P) {
+  constexpr bool BF = PM >= 1;
+  typedef typename ActT<PM>::type TA;
   const lmn_wgrad_args_t& A = P.a;
   const uint32_t soff = A.seed_ctr ? *A.seed_ctr : 0u;  // device-side dropout stream offset (graph replays: one bump per step)
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -771,7 +780,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_lds_kernel(const WgradParams P) 
   const int NP = P.TH * P.TW;
 
   // per cin tile of this block: source and channel base (block-uniform, hoisted out of the tile loop)
-  const float* tptr[NNT];
+  const TA* tptr[NNT];
   const float* tscale[NNT];
   int tC[NNT], tcs[NNT], tflags[NNT], tch0[NNT];
   uint32_t tseed[NNT];
@@ -781,7 +790,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_lds_kernel(const WgradParams P) 
     const int nt = nt0 + t;
     int sidx = 0;
     while (sidx + 1 < A.nsrc && nt >= P.ntile_off[sidx + 1]) ++sidx;
-    tptr[t] = A.src[sidx].ptr;
+    tptr[t] = (const TA*)A.src[sidx].ptr;
     tscale[t] = A.src[sidx].scale;
     tC[t] = nt < P.NNTT ? A.src[sidx].C : 0;
     tcs[t] = A.src[sidx].cstride;
@@ -861,7 +870,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_lds_kernel(const WgradParams P) 
         for (int m = 0; m < NMT; ++m) {
           const int co = (mt0 + m) * 16 + j * 4;
           const bool cok = (mt0 + m) < P.NMTT && co < A.Cout;
-          vy[u][m] = ld4(A.dy + (uint32_t)(gp * A.dy_cstride + (cok ? co : 0)));
+          vy[u][m] = ld4((const TA*)A.dy + (uint32_t)(gp * A.dy_cstride + (cok ? co : 0)));
         }
       }
 #pragma unroll
@@ -1070,8 +1079,10 @@ __global__ __launch_bounds__(256, 2) void wgrad_lds_kernel(const WgradParams P) 
 // over the batch; the image index (needed only for the per-image SE scale) is tracked per batch of steps.
 // BF: the U = 8 four-pixel steps of a batch form two 16-pixel K steps; a lane packs its four loaded values (pixels
 // 4q..4q+3 of one K16 step, i.e. step 4h + q, pixel j) into one bf16 fragment: 2 instead of 8 MFMAs per tile and batch.
-template <int NMT, int NNT, bool BF = false>
+template <int NMT, int NNT, int PM = 0>
 __global__ __launch_bounds__(256) void wgrad_1x1_kernel(const WgradParams P) {
+  constexpr bool BF = PM >= 1;
+  typedef typename ActT<PM>::type TA;
   constexpr int U = 8;
   const lmn_wgrad_args_t& A = P.a;
   const uint32_t soff = A.seed_ctr ? *A.seed_ctr : 0u;  // device-side dropout stream offset (graph replays: one bump per step)
@@ -1084,7 +1095,7 @@ __global__ __launch_bounds__(256) void wgrad_1x1_kernel(const WgradParams P) {
   const int HW = A.Hout * A.Wout;
   const int NPX = A.B * HW;
 
-  const float* sptr[NNT];
+  const TA* sptr[NNT];
   const float* sscale[NNT];
   int sC[NNT], scs[NNT], sflags[NNT], sch[NNT];
   uint32_t sseed[NNT];
@@ -1096,7 +1107,7 @@ __global__ __launch_bounds__(256) void wgrad_1x1_kernel(const WgradParams P) {
     int s = 0;
     while (s + 1 < A.nsrc && nt >= P.ntile_off[s + 1]) ++s;
     const int ch = (nt - P.ntile_off[s]) * 16 + n;
-    sptr[t] = A.src[s].ptr;
+    sptr[t] = (const TA*)A.src[s].ptr;
     sscale[t] = A.src[s].scale;
     sC[t] = A.src[s].C;
     scs[t] = A.src[s].cstride;
@@ -1139,9 +1150,9 @@ __global__ __launch_bounds__(256) void wgrad_1x1_kernel(const WgradParams P) {
       const bool ok = (BF ? px < se * 4 : step0 + u < se) && px < NPX;
       const int ps = ok ? px : 0;
 #pragma unroll
-      for (int m = 0; m < NMT; ++m) av[u][m] = A.dy[(uint32_t)(ps * A.dy_cstride + (mco[m] >= 0 ? mco[m] : 0))];
+      for (int m = 0; m < NMT; ++m) av[u][m] = ld1((const TA*)A.dy + (uint32_t)(ps * A.dy_cstride + (mco[m] >= 0 ? mco[m] : 0)));
 #pragma unroll
-      for (int t = 0; t < NNT; ++t) bv[u][t] = sptr[t][(uint32_t)(ps * scs[t] + (sch[t] >= 0 ? sch[t] : 0))];
+      for (int t = 0; t < NNT; ++t) bv[u][t] = ld1(sptr[t] + (uint32_t)(ps * scs[t] + (sch[t] >= 0 ? sch[t] : 0)));
     }
     // ---- on-load transforms (wave-uniform flags) and masking
     int b0 = 0;
@@ -1407,6 +1418,8 @@ int lmn_conv_fwd(const lmn_conv_args_t* args, lmn_stream_t stream) {
   LMN_REQUIRE(A.nsrc >= 1 && A.nsrc <= 3, "conv_fwd: nsrc %d", A.nsrc);
   LMN_REQUIRE(A.Cout > 0 && A.Cout % 4 == 0, "conv_fwd: Cout %d must be a positive multiple of 4", A.Cout);
   LMN_REQUIRE(A.mma_dtype == LMN_F32 || A.mma_dtype == LMN_BF16, "conv_fwd: mma_dtype %d", A.mma_dtype);
+  LMN_REQUIRE(A.act_dtype == LMN_F32 || (A.act_dtype == LMN_BF16 && A.mma_dtype == LMN_BF16),
+              "conv_fwd: act_dtype %d with mma_dtype %d (bf16 storage needs bf16 matrix-core operands)", A.act_dtype, A.mma_dtype);
   LMN_REQUIRE(A.B > 0 && A.Hout > 0 && A.Wout > 0 && A.Hin > 0 && A.Win > 0, "conv_fwd: empty tensor");
   LMN_REQUIRE(A.wpack, "conv_fwd: null packed weights");
   LMN_REQUIRE(A.out || A.stats, "conv_fwd: neither out nor stats requested");
@@ -1467,7 +1480,7 @@ int lmn_conv_fwd(const lmn_conv_args_t* args, lmn_stream_t stream) {
     double by = ipix * cin + (A.out ? opix * A.Cout : 0.0);
     if (A.aux) by += opix * A.Cout;
     if (A.residual) by += opix * A.Cout;
-    lmn_prof_cost(2.0 * macs, 4.0 * by);
+    lmn_prof_cost(2.0 * macs, (A.act_dtype == LMN_BF16 ? 2.0 : 4.0) * by);
   }
   P.NCTT = (A.Cout + 15) / 16;
   P.ncls = (A.transposed && A.stride == 2) ? 4 : 1;
@@ -1559,6 +1572,7 @@ int lmn_conv_fwd(const lmn_conv_args_t* args, lmn_stream_t stream) {
     // +8 floats at unit stride, +4 at stride 2 (PMC: 0.5 conflict cycles per LDS cycle with +4 at unit stride)
     T.CS = T.CKB * 16 + (st_in == 1 ? 8 : 4);
     const bool bf = a.mma_dtype == LMN_BF16;
+    const int pm = bf ? (a.act_dtype == LMN_BF16 ? 2 : 1) : 0;
     if (bf) T.CS = T.CKB * 8 + 4;  // dwords: 8 per K16 block of 4-bf16 fragments, +4: conflict-free ds_read_b64 (brute-forced)
     T.tiles_x = (gW + T.TW - 1) / T.TW;
     T.tiles_y = (gH + T.TH - 1) / T.TH;
@@ -1598,7 +1612,7 @@ int lmn_conv_fwd(const lmn_conv_args_t* args, lmn_stream_t stream) {
       default: LMN_LAUNCH((conv_tileM_kernel<TT, NN, 1, BFV>), mgrid, dim3(256), msh, st, T); break;  \
     }                                                                                                    \
   } while (0)
-#define LMN_CMB(TT, NN) do { if (bf) LMN_CM(TT, NN, true); else LMN_CM(TT, NN, false); } while (0)
+#define LMN_CMB(TT, NN) do { if (pm == 2) LMN_CM(TT, NN, 2); else if (pm == 1) LMN_CM(TT, NN, 1); else LMN_CM(TT, NN, 0); } while (0)
       if (a.ksize == 1) { if (ncw == 2) LMN_CMB(1, 2); else LMN_CMB(1, 1); }
       else { if (ncw == 2) LMN_CMB(9, 2); else LMN_CMB(9, 1); }
 #undef LMN_CMB
@@ -1612,7 +1626,7 @@ int lmn_conv_fwd(const lmn_conv_args_t* args, lmn_stream_t stream) {
     if (ek == 0) LMN_LAUNCH((conv_tile_kernel<9, NN, 0, true, BFV>), zgrid, dim3(256), shmem, st, T); \
     else LMN_LAUNCH((conv_tile_kernel<9, NN, 1, true, BFV>), zgrid, dim3(256), shmem, st, T);         \
   } while (0)
-#define LMN_CZB(NN) do { if (bf) LMN_CZ(NN, true); else LMN_CZ(NN, false); } while (0)
+#define LMN_CZB(NN) do { if (pm == 2) LMN_CZ(NN, 2); else if (pm == 1) LMN_CZ(NN, 1); else LMN_CZ(NN, 0); } while (0)
       switch (tnct) {
         case 1: LMN_CZB(1); break;
         case 2: LMN_CZB(2); break;
@@ -1635,13 +1649,16 @@ int lmn_conv_fwd(const lmn_conv_args_t* args, lmn_stream_t stream) {
     }                                                                                                    \
   } while (0)
 #define LMN_CTN(TT)                                                                                      \
-  switch (tnct * 2 + (bf ? 1 : 0)) {                                                                     \
-    case 2: LMN_CT(TT, 1, false); break;                                                                 \
-    case 3: LMN_CT(TT, 1, true); break;                                                                  \
-    case 4: LMN_CT(TT, 2, false); break;                                                                 \
-    case 5: LMN_CT(TT, 2, true); break;                                                                  \
-    case 7: LMN_CT(TT, 3, true); break;                                                                  \
-    default: LMN_CT(TT, 3, false); break;                                                                \
+  switch ((tnct > 3 ? 3 : tnct) * 4 + pm) {                                                              \
+    case 4: LMN_CT(TT, 1, 0); break;                                                                     \
+    case 5: LMN_CT(TT, 1, 1); break;                                                                     \
+    case 6: LMN_CT(TT, 1, 2); break;                                                                     \
+    case 8: LMN_CT(TT, 2, 0); break;                                                                     \
+    case 9: LMN_CT(TT, 2, 1); break;                                                                     \
+    case 10: LMN_CT(TT, 2, 2); break;                                                                    \
+    case 13: LMN_CT(TT, 3, 1); break;                                                                    \
+    case 14: LMN_CT(TT, 3, 2); break;                                                                    \
+    default: LMN_CT(TT, 3, 0); break;                                                                    \
   }
     if (a.ksize == 1) { LMN_CTN(1) } else { LMN_CTN(9) }
 #undef LMN_CTN
@@ -1680,6 +1697,8 @@ int lmn_conv_wgrad(const lmn_wgrad_args_t* args, lmn_stream_t stream) {
   LMN_REQUIRE(!A.db2 || A.db, "conv_wgrad: db2 without db");
   LMN_REQUIRE(A.B > 0 && A.Hout > 0 && A.Wout > 0, "conv_wgrad: empty tensor");
   LMN_REQUIRE(A.mma_dtype == LMN_F32 || A.mma_dtype == LMN_BF16, "conv_wgrad: mma_dtype %d", A.mma_dtype);
+  LMN_REQUIRE(A.act_dtype == LMN_F32 || (A.act_dtype == LMN_BF16 && A.mma_dtype == LMN_BF16),
+              "conv_wgrad: act_dtype %d with mma_dtype %d", A.act_dtype, A.mma_dtype);
   WgradParams P;
   P.a = A;
   P.NNTT = 0;
@@ -1700,7 +1719,7 @@ int lmn_conv_wgrad(const lmn_wgrad_args_t* args, lmn_stream_t stream) {
   P.inv_keep_dy = (A.dy_flags & LMN_SRC_DROP) ? 1.f / (1.f - A.dy_p) : 1.f;
   if (g_lmn_prof_on) {  // algorithmic cost: MACs of the layer shape; every source and dy read once
     const double opix = (double)A.B * A.Hout * A.Wout, ipix = (double)A.B * A.Hin * A.Win;
-    lmn_prof_cost(2.0 * opix * (double)P.Cin * A.Cout * A.ksize * A.ksize, 4.0 * (ipix * P.Cin + opix * A.Cout));
+    lmn_prof_cost(2.0 * opix * (double)P.Cin * A.Cout * A.ksize * A.ksize, (A.act_dtype == LMN_BF16 ? 2.0 : 4.0) * (ipix * P.Cin + opix * A.Cout));
   }
   P.NMTT = (A.Cout + 15) / 16;
   P.steps_per_img = (A.Hout * A.Wout + 3) / 4;
@@ -1737,6 +1756,7 @@ int lmn_conv_wgrad(const lmn_wgrad_args_t* args, lmn_stream_t stream) {
   P.CSy = 16;
   P.CSx = A.stride == 1 ? 16 : 24;
   const bool bf = A.mma_dtype == LMN_BF16;
+  const int pm = bf ? (A.act_dtype == LMN_BF16 ? 2 : 1) : 0;
   // bf16 planes: 16 bf16 = 8 dwords per pixel, +4: the lane groups q (pixels 4 apart) read disjoint bank ranges
   if (bf) P.CSy = P.CSx = 12;
   P.tiles_x = (G.Wout + P.TW - 1) / P.TW;
@@ -1768,11 +1788,13 @@ int lmn_conv_wgrad(const lmn_wgrad_args_t* args, lmn_stream_t stream) {
 #define LMN_WG(T, M, N)                                                                                             \
   do {                                                                                                              \
     if (shmem > 64 * 1024) {                                                                                        \
-      (void)hipFuncSetAttribute((const void*)wgrad_lds_kernel<T, M, N, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem); \
-      (void)hipFuncSetAttribute((const void*)wgrad_lds_kernel<T, M, N, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem); \
+      (void)hipFuncSetAttribute((const void*)wgrad_lds_kernel<T, M, N, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem); \
+      (void)hipFuncSetAttribute((const void*)wgrad_lds_kernel<T, M, N, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem); \
+      (void)hipFuncSetAttribute((const void*)wgrad_lds_kernel<T, M, N, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem); \
     }                                                                                                               \
-    if (bf) LMN_LAUNCH((wgrad_lds_kernel<T, M, N, true>), grid, dim3(256), shmem, st, P);                   \
-    else LMN_LAUNCH((wgrad_lds_kernel<T, M, N, false>), grid, dim3(256), shmem, st, P);                     \
+    if (pm == 2) LMN_LAUNCH((wgrad_lds_kernel<T, M, N, 2>), grid, dim3(256), shmem, st, P);                 \
+    else if (pm == 1) LMN_LAUNCH((wgrad_lds_kernel<T, M, N, 1>), grid, dim3(256), shmem, st, P);            \
+    else LMN_LAUNCH((wgrad_lds_kernel<T, M, N, 0>), grid, dim3(256), shmem, st, P);                         \
     if (P.partial) {                                                                                                \
       const int ksl = reduce_slices(blocks);                                                                        \
       const int rb = (int)((per + 1024 / ksl - 1) / (1024 / ksl));                                                  \
@@ -1791,8 +1813,9 @@ int lmn_conv_wgrad(const lmn_wgrad_args_t* args, lmn_stream_t stream) {
     const dim3 dgrid((unsigned)nb, gy);
 #define LMN_WD(M, N)                                                                                               \
   do {                                                                                                              \
-    if (bf) LMN_LAUNCH((wgrad_1x1_kernel<M, N, true>), dgrid, dim3(256), 0, st, P);                         \
-    else LMN_LAUNCH((wgrad_1x1_kernel<M, N, false>), dgrid, dim3(256), 0, st, P);                           \
+    if (pm == 2) LMN_LAUNCH((wgrad_1x1_kernel<M, N, 2>), dgrid, dim3(256), 0, st, P);                       \
+    else if (pm == 1) LMN_LAUNCH((wgrad_1x1_kernel<M, N, 1>), dgrid, dim3(256), 0, st, P);                  \
+    else LMN_LAUNCH((wgrad_1x1_kernel<M, N, 0>), dgrid, dim3(256), 0, st, P);                               \
     if (P.partial) {                                                                                                \
       const int ksl = reduce_slices((int)nb);                                                                       \
       const int rb = (int)((per + 1024 / ksl - 1) / (1024 / ksl));                                                  \

@@ -23,18 +23,25 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 // Raw buffer access (bounds-checked by the descriptor: out-of-range loads return 0, stores are dropped).
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef __amdgpu_buffer_rsrc_t BufRsrc;
-__device__ __forceinline__ BufRsrc make_rsrc(const float* base, unsigned bytes) {
-  return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, (int)bytes, 0x00020000);
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ BufRsrc make_rsrc(const void* base, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
 }
-// byte_off: per-lane offset (range-checked); soff: wave-uniform offset added to the address
-__device__ __forceinline__ f32x4 buf_load4(BufRsrc r, unsigned byte_off, int soff = 0) {
-  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_off, soff, 0));
+// 4 consecutive channels of storage type TA (16 B of fp32 / 8 B of bf16) at a per-lane byte offset (range-checked)
+template <typename TA> __device__ __forceinline__ f32x4 buf_load4(BufRsrc r, unsigned byte_off) {
+  if constexpr (sizeof(TA) == 4) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_off, 0, 0));
+  } else {
+    const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(r, (int)byte_off, 0, 0);
+    return f32x4{lmn_bf16_lo(v.x), lmn_bf16_hi(v.x), lmn_bf16_lo(v.y), lmn_bf16_hi(v.y)};
+  }
 }
-__device__ __forceinline__ void buf_store4(BufRsrc r, unsigned byte_off, f32x4 v) {
-  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, (int)byte_off, 0, 0);
-}
-__device__ __forceinline__ void buf_store4(BufRsrc r, unsigned byte_off, int soff, f32x4 v) {
-  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, (int)byte_off, soff, 0);
+template <typename TA> __device__ __forceinline__ void buf_store4(BufRsrc r, unsigned byte_off, f32x4 v) {
+  if constexpr (sizeof(TA) == 4) {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, (int)byte_off, 0, 0);
+  } else {
+    __builtin_amdgcn_raw_buffer_store_b64(u32x2{lmn_pk_bf16(v[0], v[1]), lmn_pk_bf16(v[2], v[3])}, r, (int)byte_off, 0, 0);
+  }
 }
 
 // XCD-aware block order (guide T1, bijective form): consecutive LOGICAL tiles run on the same XCD, so the 2-pixel
@@ -212,8 +219,9 @@ __device__ __forceinline__ void sw_step(SwState& S, const BranchW& bw, const f32
   }
 }
 
+template <typename TA>
 __global__ __launch_bounds__(256) void dw_bwd_strip_kernel(
-    const float* __restrict__ x1, const float* __restrict__ dpre, float* __restrict__ dx1, int B, int H, int W, int E,
+    const TA* __restrict__ x1, const TA* __restrict__ dpre, TA* __restrict__ dx1, int B, int H, int W, int E,
     const float* __restrict__ w5, const float* __restrict__ w3, const float* __restrict__ wvv,
     const float* __restrict__ whh, const float* __restrict__ cA, const float* __restrict__ cC,
     const float* __restrict__ cD, float* __restrict__ dw5, float* __restrict__ dw3, float* __restrict__ dwv,
@@ -250,9 +258,9 @@ __global__ __launch_bounds__(256) void dw_bwd_strip_kernel(
   const int cx = xs - 2 + lane;
   const bool col_in = cx >= 0 && cx < W;
   const bool own_col = lane >= 2 && lane < 2 + SW_OC && cx < W;
-  const float* xb = x1 + (int64_t)b * H * W * E;
-  const float* db = dpre + (int64_t)b * H * W * E;
-  float* ob = dx1 + (int64_t)b * H * W * E;
+  const TA* xb = x1 + (int64_t)b * H * W * E;
+  const TA* db = dpre + (int64_t)b * H * W * E;
+  TA* ob = dx1 + (int64_t)b * H * W * E;
 
   SwState S;
   const f32x2 z2 = f32x2{0.f, 0.f};
@@ -275,7 +283,8 @@ __global__ __launch_bounds__(256) void dw_bwd_strip_kernel(
   // memory latency per batch instead of six).
   constexpr unsigned OOB = 0x80000000u;
   constexpr int NXB = (SW_R * SW_XC * 2 + 255) / 256, NDB = (SW_R * SW_FC * 2 + 255) / 256, NOB = (SW_R * SW_OC * 2 + 255) / 256;
-  const int rowb = W * E * 4;  // bytes per image row (host: (H+16)*W*E*4 < 2^30)
+  constexpr unsigned ES = sizeof(TA);
+  const int rowb = W * E * (int)ES;  // bytes per image row (host: (H+16)*W*E*4 < 2^30)
   const BufRsrc rx = make_rsrc(xb, (unsigned)H * rowb);
   const BufRsrc rd = make_rsrc(db, (unsigned)H * rowb);
   const BufRsrc ro = make_rsrc(ob + (int64_t)ys * W * E, (unsigned)(ye - ys) * rowb);
@@ -289,10 +298,10 @@ __global__ __launch_bounds__(256) void dw_bwd_strip_kernel(
         const int k4 = i & 1, pc = i >> 1;
         const int rr = pc / SW_OC, c = pc - rr * SW_OC;
         const bool ok = xs + c < W && ch0 + k4 * 4 < E;
-        const unsigned off = ok ? (unsigned)(((jb - 8 + rr) * W + xs + c) * E + ch0 + k4 * 4) * 4u : OOB;
+        const unsigned off = ok ? (unsigned)(((jb - 8 + rr) * W + xs + c) * E + ch0 + k4 * 4) * ES : OOB;
         const float* o = &OUT[(rr * SW_FC + c + 2) * SW_CS + k4 * 4];
         const f32x2 a = *reinterpret_cast<const f32x2*>(o), d = *reinterpret_cast<const f32x2*>(o + 2);
-        buf_store4(ro, off, f32x4{a[0], a[1], d[0], d[1]});
+        buf_store4<TA>(ro, off, f32x4{a[0], a[1], d[0], d[1]});
       }
     }
   };
@@ -311,8 +320,8 @@ __global__ __launch_bounds__(256) void dw_bwd_strip_kernel(
         const int rr = pc / SW_XC, c = pc - rr * SW_XC;
         const int gx = xs - 4 + c;
         const bool ok = i < SW_R * SW_XC * 2 && gx >= 0 && gx < W && ch0 + k4 * 4 < E;
-        const unsigned off = ok ? (unsigned)(((ys - 4 + j0 + rr) * W + gx) * E + ch0 + k4 * 4) * 4u : OOB;
-        vx[k] = buf_load4(rx, off);
+        const unsigned off = ok ? (unsigned)(((ys - 4 + j0 + rr) * W + gx) * E + ch0 + k4 * 4) * ES : OOB;
+        vx[k] = buf_load4<TA>(rx, off);
         lx[k] = (((j0 + rr) % SW_XR) * SW_XC + c) * SW_CS + k4 * 4;
       }
       f32x4 vd[NDB];
@@ -324,8 +333,8 @@ __global__ __launch_bounds__(256) void dw_bwd_strip_kernel(
         const int rr = pc / SW_FC, c = pc - rr * SW_FC;
         const int gx = xs - 2 + c;
         const bool ok = i < SW_R * SW_FC * 2 && gx >= 0 && gx < W && ch0 + k4 * 4 < E;
-        const unsigned off = ok ? (unsigned)(((ys - 6 + j0 + rr) * W + gx) * E + ch0 + k4 * 4) * 4u : OOB;
-        vd[k] = buf_load4(rd, off);
+        const unsigned off = ok ? (unsigned)(((ys - 6 + j0 + rr) * W + gx) * E + ch0 + k4 * 4) * ES : OOB;
+        vd[k] = buf_load4<TA>(rd, off);
         ld[k] = (rr * SW_FC + c) * SW_CS + k4 * 4;
       }
       if (j0 >= 8 + SW_R - 4) drain(j0 - SW_R);  // dx rows of the previous batch leave while the loads are in flight
@@ -424,7 +433,8 @@ __device__ __forceinline__ void fs_step(f32x2 (&acc)[5], f32x2& gs, const f32x2 
   acc[D] = f32x2{0.f, 0.f};
 }
 
-__global__ __launch_bounds__(256) void dw_fwd_strip_kernel(const float* __restrict__ x1, float* __restrict__ pre,
+template <typename TA>
+__global__ __launch_bounds__(256) void dw_fwd_strip_kernel(const TA* __restrict__ x1, TA* __restrict__ pre,
                                                             float* __restrict__ gsum, int H, int W, int E,
                                                             const float* __restrict__ keff,
                                                             const float* __restrict__ beff, int strips, int segs,
@@ -449,8 +459,8 @@ __global__ __launch_bounds__(256) void dw_fwd_strip_kernel(const float* __restri
   const int ys = seg * seg_rows, ye = min(ys + seg_rows, H);
   const int xs = strip * SW_FC;
   const bool cvalid = cok && xs + lane < W;
-  const float* xb = x1 + (int64_t)b * H * W * E;
-  float* ob = pre + (int64_t)b * H * W * E;
+  const TA* xb = x1 + (int64_t)b * H * W * E;
+  TA* ob = pre + (int64_t)b * H * W * E;
   const int nsteps = (ye - ys) + 4;  // x1 row (ys-2+j) enters at step j; output row (ys+j-4) completes
 
   // Staging geometry is fixed per thread: byte offsets into the image (loads) / the row segment (stores) and LDS
@@ -459,7 +469,8 @@ __global__ __launch_bounds__(256) void dw_fwd_strip_kernel(const float* __restri
   // negative, rows below it (or below the segment, for stores) exceed num_records -- loads return 0, stores are dropped.
   constexpr int NX = (SW_R * SW_XC * 2 + 255) / 256, ND = (SW_R * SW_FC * 2 + 255) / 256;
   constexpr unsigned OOB = 0x80000000u;
-  const int rowb = W * E * 4;  // bytes per image row (host: (H+8)*W*E*4 < 2^30)
+  constexpr unsigned ES = sizeof(TA);
+  const int rowb = W * E * (int)ES;  // bytes per image row (host: (H+8)*W*E*4 < 2^30)
   const BufRsrc rin = make_rsrc(xb, (unsigned)H * rowb);
   const BufRsrc rout = make_rsrc(ob + (int64_t)ys * W * E, (unsigned)(ye - ys) * rowb);
   unsigned fo[NX], so[ND];
@@ -471,7 +482,7 @@ __global__ __launch_bounds__(256) void dw_fwd_strip_kernel(const float* __restri
     const int rr = pc / SW_XC, c = pc - rr * SW_XC;
     const int gx = xs - 2 + c;
     const bool ok = i < SW_R * SW_XC * 2 && gx >= 0 && gx < W && ch0 + k4 * 4 < E;
-    fo[k] = ok ? (unsigned)(((rr - 2) * W + gx) * E + ch0 + k4 * 4) * 4u : OOB;
+    fo[k] = ok ? (unsigned)(((rr - 2) * W + gx) * E + ch0 + k4 * 4) * ES : OOB;
     li[k] = (rr * SW_XC + c) * SW_CS + k4 * 4;
   }
 #pragma unroll
@@ -480,14 +491,14 @@ __global__ __launch_bounds__(256) void dw_fwd_strip_kernel(const float* __restri
     const int k4 = i & 1, pc = i >> 1;
     const int rr = pc / SW_FC, c = pc - rr * SW_FC;
     const bool ok = i < SW_R * SW_FC * 2 && xs + c < W && ch0 + k4 * 4 < E;
-    so[k] = ok ? (unsigned)(((rr - 4) * W + xs + c) * E + ch0 + k4 * 4) * 4u : OOB;
+    so[k] = ok ? (unsigned)(((rr - 4) * W + xs + c) * E + ch0 + k4 * 4) * ES : OOB;
     lo[k] = (rr * SW_FC + c) * SW_CS + k4 * 4;
   }
   f32x4 px[NX];
   auto fetch = [&](int j0) {  // x1 rows ys-2+j0 .. +4
     const unsigned base = (unsigned)((ys + j0) * rowb);
 #pragma unroll
-    for (int k = 0; k < NX; ++k) px[k] = buf_load4(rin, fo[k] + base);  // OOB + base stays >= 2^31
+    for (int k = 0; k < NX; ++k) px[k] = buf_load4<TA>(rin, fo[k] + base);  // OOB + base stays >= 2^31
   };
   auto commit = [&](int j0) {
     float* ring = XS + (j0 % FS_XR) * (SW_XC * SW_CS);
@@ -507,7 +518,7 @@ __global__ __launch_bounds__(256) void dw_fwd_strip_kernel(const float* __restri
       if (k * 256 + 255 < SW_R * SW_FC * 2 || tid + k * 256 < SW_R * SW_FC * 2) {
         const float* o = &OUT[lo[k]];
         const f32x2 a = *reinterpret_cast<const f32x2*>(o), c = *reinterpret_cast<const f32x2*>(o + 2);
-        buf_store4(rout, so[k] + base, f32x4{a[0], a[1], c[0], c[1]});
+        buf_store4<TA>(rout, so[k] + base, f32x4{a[0], a[1], c[0], c[1]});
       }
     }
   };
@@ -597,10 +608,10 @@ __device__ __forceinline__ void ss_step(f32x2 (&a5)[5], f32x2 (&a3)[5], f32x2 (&
   a5[D] = a3[D] = av[D] = ah[D] = z2;
 }
 
-template <int MODE>
+template <int MODE, typename TA>
 __global__ __launch_bounds__(256) void dw_stats_strip_kernel(
-    const float* __restrict__ x1, const float* __restrict__ pre, const float* __restrict__ u,
-    const float* __restrict__ sgate, const float* __restrict__ dm, float* __restrict__ dpre, int H, int W, int E,
+    const TA* __restrict__ x1, const TA* __restrict__ pre, const TA* __restrict__ u,
+    const float* __restrict__ sgate, const float* __restrict__ dm, TA* __restrict__ dpre, int H, int W, int E,
     const float* __restrict__ w5, const float* __restrict__ w3, const float* __restrict__ wvv,
     const float* __restrict__ whh, float* __restrict__ stats, int strips, int segs, int seg_rows, int chunks) {
   constexpr int NS = MODE == 0 ? 8 : 5;
@@ -633,13 +644,14 @@ __global__ __launch_bounds__(256) void dw_stats_strip_kernel(
   const int xs = strip * SW_FC;
   const bool cvalid = cok && xs + lane < W;
   const int64_t ib = (int64_t)b * H * W * E;
-  const float* xb = x1 + ib;
+  const TA* xb = x1 + ib;
   const int nsteps = (ye - ys) + 4;  // x1 row (ys-2+j) enters at step j; output row (ys+j-4) completes
 
   // staging geometry fixed per thread, bounds by buffer descriptors (see dw_fwd_strip_kernel)
   constexpr int NX = (SW_R * SW_XC * 2 + 255) / 256, ND = (SW_R * SW_FC * 2 + 255) / 256;
   constexpr unsigned OOB = 0x80000000u;
-  const int rowb = W * E * 4;
+  constexpr unsigned ES = sizeof(TA);
+  const int rowb = W * E * (int)ES;
   const int64_t sb = ib + (int64_t)ys * W * E;  // first element of the row segment
   const BufRsrc rin = make_rsrc(xb, (unsigned)H * rowb);
   const BufRsrc rpre = make_rsrc(MODE == 1 ? pre + sb : xb, MODE == 1 ? (unsigned)(ye - ys) * rowb : 0u);
@@ -654,7 +666,7 @@ __global__ __launch_bounds__(256) void dw_stats_strip_kernel(
     const int rr = pc / SW_XC, c = pc - rr * SW_XC;
     const int gx = xs - 2 + c;
     const bool ok = i < SW_R * SW_XC * 2 && gx >= 0 && gx < W && ch0 + k4 * 4 < E;
-    fo[k] = ok ? (unsigned)(((rr - 2) * W + gx) * E + ch0 + k4 * 4) * 4u : OOB;
+    fo[k] = ok ? (unsigned)(((rr - 2) * W + gx) * E + ch0 + k4 * 4) * ES : OOB;
     li[k] = (rr * SW_XC + c) * SW_CS + k4 * 4;
   }
   if (MODE == 1) {
@@ -664,7 +676,7 @@ __global__ __launch_bounds__(256) void dw_stats_strip_kernel(
       const int k4 = i & 1, pc = i >> 1;
       const int rr = pc / SW_FC, c = pc - rr * SW_FC;
       const bool ok = i < SW_R * SW_FC * 2 && xs + c < W && ch0 + k4 * 4 < E;
-      so[k] = ok ? (unsigned)(((rr - 4) * W + xs + c) * E + ch0 + k4 * 4) * 4u : OOB;
+      so[k] = ok ? (unsigned)(((rr - 4) * W + xs + c) * E + ch0 + k4 * 4) * ES : OOB;
       lo[k] = (rr * SW_FC + c) * SW_CS + k4 * 4;
     }
   }
@@ -672,13 +684,13 @@ __global__ __launch_bounds__(256) void dw_stats_strip_kernel(
   auto fetch = [&](int j0) {
     const unsigned base = (unsigned)((ys + j0) * rowb);
 #pragma unroll
-    for (int k = 0; k < NX; ++k) px[k] = buf_load4(rin, fo[k] + base);
+    for (int k = 0; k < NX; ++k) px[k] = buf_load4<TA>(rin, fo[k] + base);
     if (MODE == 1) {  // pre / u rows of the OUTPUT rows of batch j0: segment rows j0-4+rr
       const unsigned sbase = (unsigned)(j0 * rowb);
 #pragma unroll
       for (int k = 0; k < ND; ++k) {
-        pp[k] = buf_load4(rpre, so[k] + sbase);
-        pu[k] = buf_load4(ru, so[k] + sbase);
+        pp[k] = buf_load4<TA>(rpre, so[k] + sbase);
+        pu[k] = buf_load4<TA>(ru, so[k] + sbase);
       }
     }
   };
@@ -712,7 +724,7 @@ __global__ __launch_bounds__(256) void dw_stats_strip_kernel(
       if (k * 256 + 255 < SW_R * SW_FC * 2 || tid + k * 256 < SW_R * SW_FC * 2) {
         const float* o = &OUT[lo[k]];
         const f32x2 a = *reinterpret_cast<const f32x2*>(o), c = *reinterpret_cast<const f32x2*>(o + 2);
-        buf_store4(rout, so[k] + sbase, f32x4{a[0], a[1], c[0], c[1]});
+        buf_store4<TA>(rout, so[k] + sbase, f32x4{a[0], a[1], c[0], c[1]});
       }
     }
   };
@@ -850,27 +862,28 @@ static int strip_segments(int64_t blocks_per_seg, int H, int halo, int occ, int*
 }
 
 template <int MODE>
-static int launch_dw_strip_stats(const float* x1, const float* pre, const float* u, const float* s, const float* dm,
-                                 float* dpre, int B, int H, int W, int E, const float* w5, const float* w3,
-                                 const float* wv, const float* wh, float* stats, hipStream_t st) {
+static int launch_dw_strip_stats(const void* x1, const void* pre, const void* u, const float* s, const float* dm,
+                                 void* dpre, int B, int H, int W, int E, const float* w5, const float* w3,
+                                 const float* wv, const float* wh, float* stats, int act_dtype, hipStream_t st) {
   LMN_REQUIRE((int64_t)(H + 8) * W * E * 4 < (1LL << 30), "dw statistics: one image (%d x %d x %d) must stay below 1 GiB", H, W, E);
   const int strips = lmn_cdiv(W, SW_FC), chunks = lmn_cdiv(E, SW_CH);
   int seg_rows;
   const int segs = strip_segments((int64_t)B * strips * chunks, H, 4, MODE == 0 ? 3 : 2, &seg_rows);
   const int64_t nblk = (int64_t)B * strips * chunks * segs;
   if (nblk >= (1LL << 31)) return -1;
-  if (g_lmn_prof_on) lmn_prof_cost(2.0 * 42 * (double)B * H * W * E, 4.0 * (MODE == 0 ? 1 : 4) * (double)B * H * W * E);
-  LMN_LAUNCH((dw_stats_strip_kernel<MODE>), dim3((unsigned)nblk), dim3(256), 0, st, x1, pre, u, s, dm, dpre, H, W, E,
-                     w5, w3, wv, wh, stats, strips, segs, seg_rows, chunks);
+  if (g_lmn_prof_on) lmn_prof_cost(2.0 * 42 * (double)B * H * W * E, (act_dtype == LMN_BF16 ? 2.0 : 4.0) * (MODE == 0 ? 1 : 4) * (double)B * H * W * E);
+  LMN_ACT_DISPATCH(act_dtype, LMN_LAUNCH((dw_stats_strip_kernel<MODE, T>), dim3((unsigned)nblk), dim3(256), 0, st, (const T*)x1, (const T*)pre, (const T*)u, s, dm, (T*)dpre, H, W, E,
+                     w5, w3, wv, wh, stats, strips, segs, seg_rows, chunks));
   return 0;
 }
 
 
 extern "C" {
 
-int lmn_dw_fwd(const float* x1, float* pre, float* gsum, int B, int H, int W, int E, const float* keff,
-               const float* beff, lmn_stream_t stream) {
-  LMN_REC(lmn_dw_fwd(x1, pre, gsum, B, H, W, E, keff, beff, stream));
+int lmn_dw_fwd(const void* x1, void* pre, float* gsum, int B, int H, int W, int E, const float* keff,
+               const float* beff, int act_dtype, lmn_stream_t stream) {
+  LMN_REC(lmn_dw_fwd(x1, pre, gsum, B, H, W, E, keff, beff, act_dtype, stream));
+  LMN_REQUIRE_DT(act_dtype, "dw_fwd");
   LMN_REQUIRE(x1 && pre && gsum && keff && beff, "dw_fwd: null pointer");
   LMN_REQUIRE(B > 0 && H > 0 && W > 0 && E > 0 && E % 4 == 0, "dw_fwd: E=%d must be a multiple of 4", E);
   LMN_REQUIRE((int64_t)(H + 8) * W * E * 4 < (1LL << 30), "dw_fwd: one image (%d x %d x %d) must stay below 1 GiB", H, W, E);
@@ -880,9 +893,9 @@ int lmn_dw_fwd(const float* x1, float* pre, float* gsum, int B, int H, int W, in
   const int segs = strip_segments((int64_t)B * strips * chunks, H, 4, 4, &seg_rows);   // 40 KB LDS: 4 blocks per CU
   const int64_t nblk = (int64_t)B * strips * chunks * segs;
   LMN_REQUIRE(nblk < (1LL << 31), "dw_fwd: grid too large");
-  if (g_lmn_prof_on) lmn_prof_cost(2.0 * 25 * (double)B * H * W * E, 4.0 * 2 * (double)B * H * W * E);
-  LMN_LAUNCH(dw_fwd_strip_kernel, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, x1, pre, gsum, H, W, E, keff,
-                     beff, strips, segs, seg_rows, chunks);
+  if (g_lmn_prof_on) lmn_prof_cost(2.0 * 25 * (double)B * H * W * E, (act_dtype == LMN_BF16 ? 2.0 : 4.0) * 2 * (double)B * H * W * E);
+  LMN_ACT_DISPATCH(act_dtype, LMN_LAUNCH((dw_fwd_strip_kernel<T>), dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, (const T*)x1, (T*)pre, gsum, H, W, E, keff,
+                     beff, strips, segs, seg_rows, chunks));
   return lmn_launch_status("dw_fwd");
 }
 
@@ -923,22 +936,24 @@ int lmn_dw_merge(const float* w5, const float* w3, const float* wv, const float*
   return lmn_launch_status("dw_merge");
 }
 
-int lmn_dw_stats(const float* x1, int B, int H, int W, int E, const float* w5, const float* w3, const float* wv,
-                 const float* wh, float* stats, lmn_stream_t stream) {
-  LMN_REC(lmn_dw_stats(x1, B, H, W, E, w5, w3, wv, wh, stats, stream));
+int lmn_dw_stats(const void* x1, int B, int H, int W, int E, const float* w5, const float* w3, const float* wv,
+                 const float* wh, float* stats, int act_dtype, lmn_stream_t stream) {
+  LMN_REC(lmn_dw_stats(x1, B, H, W, E, w5, w3, wv, wh, stats, act_dtype, stream));
+  LMN_REQUIRE_DT(act_dtype, "dw_stats");
   LMN_REQUIRE(x1 && w5 && w3 && wv && wh && stats, "dw_stats: null pointer");
   LMN_REQUIRE(B > 0 && H > 0 && W > 0 && E > 0 && E % 4 == 0, "dw_stats: E=%d must be a multiple of 4", E);
-  launch_dw_strip_stats<0>(x1, nullptr, nullptr, nullptr, nullptr, nullptr, B, H, W, E, w5, w3, wv, wh, stats, (hipStream_t)stream);
+  launch_dw_strip_stats<0>(x1, nullptr, nullptr, nullptr, nullptr, nullptr, B, H, W, E, w5, w3, wv, wh, stats, act_dtype, (hipStream_t)stream);
   return lmn_launch_status("dw_stats");
 }
 
-int lmn_dw_bwd_stats(const float* x1, const float* pre, const float* u, const float* s, const float* dm, float* dpre,
+int lmn_dw_bwd_stats(const void* x1, const void* pre, const void* u, const float* s, const float* dm, void* dpre,
                      int B, int H, int W, int E, const float* w5, const float* w3, const float* wv, const float* wh,
-                     float* bstats, lmn_stream_t stream) {
-  LMN_REC(lmn_dw_bwd_stats(x1, pre, u, s, dm, dpre, B, H, W, E, w5, w3, wv, wh, bstats, stream));
+                     float* bstats, int act_dtype, lmn_stream_t stream) {
+  LMN_REC(lmn_dw_bwd_stats(x1, pre, u, s, dm, dpre, B, H, W, E, w5, w3, wv, wh, bstats, act_dtype, stream));
+  LMN_REQUIRE_DT(act_dtype, "dw_bwd_stats");
   LMN_REQUIRE(x1 && pre && u && s && dm && dpre && w5 && w3 && wv && wh && bstats, "dw_bwd_stats: null pointer");
   LMN_REQUIRE(B > 0 && H > 0 && W > 0 && E > 0 && E % 4 == 0, "dw_bwd_stats: E=%d must be a multiple of 4", E);
-  launch_dw_strip_stats<1>(x1, pre, u, s, dm, dpre, B, H, W, E, w5, w3, wv, wh, bstats, (hipStream_t)stream);
+  launch_dw_strip_stats<1>(x1, pre, u, s, dm, dpre, B, H, W, E, w5, w3, wv, wh, bstats, act_dtype, (hipStream_t)stream);
   return lmn_launch_status("dw_bwd_stats");
 }
 
@@ -953,10 +968,11 @@ int lmn_dw_bwd_coef(const float* bstats, const float* mean, const float* rstd, c
   return lmn_launch_status("dw_bwd_coef");
 }
 
-int lmn_dw_bwd(const float* x1, const float* dpre, float* dx1, int B, int H, int W, int E, const float* w5,
+int lmn_dw_bwd(const void* x1, const void* dpre, void* dx1, int B, int H, int W, int E, const float* w5,
                const float* w3, const float* wv, const float* wh, const float* cA, const float* cC, const float* cD,
-               float* dw5, float* dw3, float* dwv, float* dwh, lmn_stream_t stream) {
-  LMN_REC(lmn_dw_bwd(x1, dpre, dx1, B, H, W, E, w5, w3, wv, wh, cA, cC, cD, dw5, dw3, dwv, dwh, stream));
+               float* dw5, float* dw3, float* dwv, float* dwh, int act_dtype, lmn_stream_t stream) {
+  LMN_REC(lmn_dw_bwd(x1, dpre, dx1, B, H, W, E, w5, w3, wv, wh, cA, cC, cD, dw5, dw3, dwv, dwh, act_dtype, stream));
+  LMN_REQUIRE_DT(act_dtype, "dw_bwd");
   LMN_REQUIRE(x1 && dpre && dx1 && w5 && w3 && wv && wh && cA && cC && cD && dw5 && dw3 && dwv && dwh, "dw_bwd: null pointer");
   LMN_REQUIRE(B > 0 && H > 0 && W > 0 && E > 0 && E % 4 == 0, "dw_bwd: E=%d must be a multiple of 4", E);
   LMN_REQUIRE((int64_t)(H + 16) * W * E * 4 < (1LL << 30), "dw_bwd: one image (%d x %d x %d) must stay below 1 GiB", H, W, E);
@@ -966,9 +982,9 @@ int lmn_dw_bwd(const float* x1, const float* dpre, float* dx1, int B, int H, int
   const int segs = strip_segments((int64_t)B * strips * chunks, H, 10, 2, &seg_rows);  // 242 VGPRs: 2 blocks per CU
   const int64_t nblk = (int64_t)B * strips * chunks * segs;
   LMN_REQUIRE(nblk < (1LL << 31), "dw_bwd: grid too large");
-  if (g_lmn_prof_on) lmn_prof_cost(2.0 * 2 * 42 * (double)B * H * W * E, 4.0 * 3 * (double)B * H * W * E);
-  LMN_LAUNCH(dw_bwd_strip_kernel, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, x1, dpre, dx1, B, H, W, E, w5,
-                     w3, wv, wh, cA, cC, cD, dw5, dw3, dwv, dwh, strips, segs, seg_rows, chunks);
+  if (g_lmn_prof_on) lmn_prof_cost(2.0 * 2 * 42 * (double)B * H * W * E, (act_dtype == LMN_BF16 ? 2.0 : 4.0) * 3 * (double)B * H * W * E);
+  LMN_ACT_DISPATCH(act_dtype, LMN_LAUNCH((dw_bwd_strip_kernel<T>), dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, (const T*)x1, (const T*)dpre, (T*)dx1, B, H, W, E, w5,
+                     w3, wv, wh, cA, cC, cD, dw5, dw3, dwv, dwh, strips, segs, seg_rows, chunks));
   return lmn_launch_status("dw_bwd");
 }
 

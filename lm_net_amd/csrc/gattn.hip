@@ -21,11 +21,12 @@ struct GaGeom {
 };
 
 // copy rows [r0, r0+GA_KC) of one (b, head, which) slab into LDS as [GA_KC][GA_D] (zero padded)
-__device__ __forceinline__ void stage_rows(float* lds, const float* base, int64_t row_stride, int r0, int N, int hd) {
+template <typename TA>
+__device__ __forceinline__ void stage_rows(float* lds, const TA* base, int64_t row_stride, int r0, int N, int hd) {
   for (int i = threadIdx.x; i < GA_KC * GA_D; i += blockDim.x) {
     const int r = i / GA_D, d = i - r * GA_D;
     float v = 0.f;
-    if (r0 + r < N && d < hd) v = base[(int64_t)(r0 + r) * row_stride + d];
+    if (r0 + r < N && d < hd) v = ld1(base + (int64_t)(r0 + r) * row_stride + d);
     lds[i] = v;
   }
 }
@@ -48,7 +49,8 @@ __device__ __forceinline__ void row_slice(const float* lds, int r, int part, flo
 // The row (query or key) a thread works on is shared by 4 lanes that split head_dim: 4x the waves of the
 // one-thread-per-row form (484 tokens x 12 heads x 8 images is only 726 waves of rows -- less than one per SIMD),
 // a quarter of the registers, and the dot products close with two DPP adds.
-__global__ __launch_bounds__(256) void gattn_fwd_kernel(const float* __restrict__ qkv, float* __restrict__ out,
+template <typename TA>
+__global__ __launch_bounds__(256) void gattn_fwd_kernel(const TA* __restrict__ qkv, TA* __restrict__ out,
                                                         float* __restrict__ lse, const GaGeom g) {
   __shared__ __attribute__((aligned(16))) float Ks[GA_KC * GA_D], Vs[GA_KC * GA_D];
   const int h = blockIdx.y, b = blockIdx.z;
@@ -56,12 +58,12 @@ __global__ __launch_bounds__(256) void gattn_fwd_kernel(const float* __restrict_
   const int i = blockIdx.x * GA_ROWS + (threadIdx.x >> 2);
   const bool ok = i < g.N;
   const int64_t rs = 3 * g.C;
-  const float* qb = qkv + (int64_t)b * g.N * rs + h * g.hd;
+  const TA* qb = qkv + (int64_t)b * g.N * rs + h * g.hd;
   float q[GA_DP], o[GA_DP];
 #pragma unroll
   for (int d = 0; d < GA_DP; ++d) {
     const int dd = part * GA_DP + d;
-    q[d] = (ok && dd < g.hd) ? qb[(int64_t)i * rs + dd] * g.scale : 0.f;
+    q[d] = (ok && dd < g.hd) ? ld1(qb + (int64_t)i * rs + dd) * g.scale : 0.f;
     o[d] = 0.f;
   }
   float m = -3.0e38f, l = 0.f;
@@ -89,18 +91,19 @@ __global__ __launch_bounds__(256) void gattn_fwd_kernel(const float* __restrict_
   }
   if (ok) {
     const float inv = 1.0f / l;
-    float* ob = out + ((int64_t)b * g.N + i) * g.C + h * g.hd;
+    TA* ob = out + ((int64_t)b * g.N + i) * g.C + h * g.hd;
 #pragma unroll
     for (int d = 0; d < GA_DP; ++d)
-      if (part * GA_DP + d < g.hd) ob[part * GA_DP + d] = o[d] * inv;
+      if (part * GA_DP + d < g.hd) st1(ob + part * GA_DP + d, o[d] * inv);
     if (part == 0) lse[((int64_t)b * g.heads + h) * g.N + i] = m + __logf(l);
   }
 }
 
 // sweep A: query-owned.  delta_i = do_i . o_i ;  dq_i = scale * sum_j p_ij (dp_ij - delta_i) k_j
-__global__ __launch_bounds__(256) void gattn_bwd_q_kernel(const float* __restrict__ qkv, const float* __restrict__ out,
-                                                          const float* __restrict__ dout, const float* __restrict__ lse,
-                                                          float* __restrict__ dqkv, float* __restrict__ delta,
+template <typename TA>
+__global__ __launch_bounds__(256) void gattn_bwd_q_kernel(const TA* __restrict__ qkv, const TA* __restrict__ out,
+                                                          const TA* __restrict__ dout, const float* __restrict__ lse,
+                                                          TA* __restrict__ dqkv, float* __restrict__ delta,
                                                           const GaGeom g) {
   __shared__ __attribute__((aligned(16))) float Ks[GA_KC * GA_D], Vs[GA_KC * GA_D];
   const int h = blockIdx.y, b = blockIdx.z;
@@ -108,16 +111,16 @@ __global__ __launch_bounds__(256) void gattn_bwd_q_kernel(const float* __restric
   const int i = blockIdx.x * GA_ROWS + (threadIdx.x >> 2);
   const bool ok = i < g.N;
   const int64_t rs = 3 * g.C;
-  const float* qb = qkv + (int64_t)b * g.N * rs + h * g.hd;
+  const TA* qb = qkv + (int64_t)b * g.N * rs + h * g.hd;
   float q[GA_DP], dO[GA_DP], dq[GA_DP];
   float dl = 0.f;
 #pragma unroll
   for (int d = 0; d < GA_DP; ++d) {
     const int dd = part * GA_DP + d;
     const bool dk = ok && dd < g.hd;
-    q[d] = dk ? qb[(int64_t)i * rs + dd] * g.scale : 0.f;
-    dO[d] = dk ? dout[((int64_t)b * g.N + i) * g.C + h * g.hd + dd] : 0.f;
-    const float ov = dk ? out[((int64_t)b * g.N + i) * g.C + h * g.hd + dd] : 0.f;
+    q[d] = dk ? ld1(qb + (int64_t)i * rs + dd) * g.scale : 0.f;
+    dO[d] = dk ? ld1(dout + ((int64_t)b * g.N + i) * g.C + h * g.hd + dd) : 0.f;
+    const float ov = dk ? ld1(out + ((int64_t)b * g.N + i) * g.C + h * g.hd + dd) : 0.f;
     dl += dO[d] * ov;
     dq[d] = 0.f;
   }
@@ -147,18 +150,19 @@ __global__ __launch_bounds__(256) void gattn_bwd_q_kernel(const float* __restric
     }
   }
   if (ok) {
-    float* dqb = dqkv + ((int64_t)b * g.N + i) * rs + h * g.hd;
+    TA* dqb = dqkv + ((int64_t)b * g.N + i) * rs + h * g.hd;
 #pragma unroll
     for (int d = 0; d < GA_DP; ++d)
-      if (part * GA_DP + d < g.hd) dqb[part * GA_DP + d] = dq[d] * g.scale;
+      if (part * GA_DP + d < g.hd) st1(dqb + part * GA_DP + d, dq[d] * g.scale);
     if (part == 0) delta[((int64_t)b * g.heads + h) * g.N + i] = dl;
   }
 }
 
 // sweep B: key-owned.  dv_j = sum_i p_ij do_i ;  dk_j = scale * sum_i p_ij (dp_ij - delta_i) q_i
-__global__ __launch_bounds__(256) void gattn_bwd_kv_kernel(const float* __restrict__ qkv, const float* __restrict__ dout,
+template <typename TA>
+__global__ __launch_bounds__(256) void gattn_bwd_kv_kernel(const TA* __restrict__ qkv, const TA* __restrict__ dout,
                                                            const float* __restrict__ lse, const float* __restrict__ delta,
-                                                           float* __restrict__ dqkv, const GaGeom g) {
+                                                           TA* __restrict__ dqkv, const GaGeom g) {
   __shared__ __attribute__((aligned(16))) float Qs[GA_KC * GA_D], Ds[GA_KC * GA_D];
   __shared__ float Ls[GA_KC], Dl[GA_KC];
   const int h = blockIdx.y, b = blockIdx.z;
@@ -166,17 +170,17 @@ __global__ __launch_bounds__(256) void gattn_bwd_kv_kernel(const float* __restri
   const int j = blockIdx.x * GA_ROWS + (threadIdx.x >> 2);
   const bool ok = j < g.N;
   const int64_t rs = 3 * g.C;
-  const float* qb = qkv + (int64_t)b * g.N * rs + h * g.hd;
+  const TA* qb = qkv + (int64_t)b * g.N * rs + h * g.hd;
   float k[GA_DP], v[GA_DP], dk[GA_DP], dv[GA_DP];
 #pragma unroll
   for (int d = 0; d < GA_DP; ++d) {
     const int dd = part * GA_DP + d;
     const bool dok = ok && dd < g.hd;
-    k[d] = dok ? qb[(int64_t)j * rs + g.C + dd] : 0.f;
-    v[d] = dok ? qb[(int64_t)j * rs + 2 * g.C + dd] : 0.f;
+    k[d] = dok ? ld1(qb + (int64_t)j * rs + g.C + dd) : 0.f;
+    v[d] = dok ? ld1(qb + (int64_t)j * rs + 2 * g.C + dd) : 0.f;
     dk[d] = dv[d] = 0.f;
   }
-  const float* dob = dout + (int64_t)b * g.N * g.C + h * g.hd;
+  const TA* dob = dout + (int64_t)b * g.N * g.C + h * g.hd;
   for (int i0 = 0; i0 < g.N; i0 += GA_KC) {
     __syncthreads();
     stage_rows(Qs, qb, rs, i0, g.N, g.hd);
@@ -210,12 +214,12 @@ __global__ __launch_bounds__(256) void gattn_bwd_kv_kernel(const float* __restri
     }
   }
   if (ok) {
-    float* db = dqkv + ((int64_t)b * g.N + j) * rs + h * g.hd;
+    TA* db = dqkv + ((int64_t)b * g.N + j) * rs + h * g.hd;
 #pragma unroll
     for (int d = 0; d < GA_DP; ++d)
       if (part * GA_DP + d < g.hd) {
-        db[g.C + part * GA_DP + d] = dk[d] * g.scale;
-        db[2 * g.C + part * GA_DP + d] = dv[d];
+        st1(db + g.C + part * GA_DP + d, dk[d] * g.scale);
+        st1(db + 2 * g.C + part * GA_DP + d, dv[d]);
       }
   }
 }
@@ -224,25 +228,27 @@ __global__ __launch_bounds__(256) void gattn_bwd_kv_kernel(const float* __restri
 
 extern "C" {
 
-int lmn_gattn_fwd(const float* qkv, float* out, float* lse, int B, int N, int heads, int hd, float scale,
+int lmn_gattn_fwd(const void* qkv, void* out, float* lse, int B, int N, int heads, int hd, float scale, int act_dtype,
                   lmn_stream_t stream) {
-  LMN_REC(lmn_gattn_fwd(qkv, out, lse, B, N, heads, hd, scale, stream));
+  LMN_REC(lmn_gattn_fwd(qkv, out, lse, B, N, heads, hd, scale, act_dtype, stream));
+  LMN_REQUIRE_DT(act_dtype, "gattn_fwd");
   LMN_REQUIRE(qkv && out && lse && B > 0 && N > 0 && heads > 0, "gattn_fwd: bad argument");
   LMN_REQUIRE(hd >= 1 && hd <= GA_D, "gattn_fwd: head_dim %d > %d", hd, GA_D);
   GaGeom g{B, N, heads, hd, heads * hd, scale};
-  LMN_LAUNCH(gattn_fwd_kernel, dim3(lmn_cdiv(N, GA_ROWS), heads, B), dim3(256), 0, (hipStream_t)stream, qkv, out, lse, g);
+  LMN_ACT_DISPATCH(act_dtype, LMN_LAUNCH((gattn_fwd_kernel<T>), dim3(lmn_cdiv(N, GA_ROWS), heads, B), dim3(256), 0, (hipStream_t)stream, (const T*)qkv, (T*)out, lse, g));
   return lmn_launch_status("gattn_fwd");
 }
 
-int lmn_gattn_bwd(const float* qkv, const float* out, const float* dout, const float* lse, float* dqkv, float* delta,
-                  int B, int N, int heads, int hd, float scale, lmn_stream_t stream) {
-  LMN_REC(lmn_gattn_bwd(qkv, out, dout, lse, dqkv, delta, B, N, heads, hd, scale, stream));
+int lmn_gattn_bwd(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, float* delta,
+                  int B, int N, int heads, int hd, float scale, int act_dtype, lmn_stream_t stream) {
+  LMN_REC(lmn_gattn_bwd(qkv, out, dout, lse, dqkv, delta, B, N, heads, hd, scale, act_dtype, stream));
+  LMN_REQUIRE_DT(act_dtype, "gattn_bwd");
   LMN_REQUIRE(qkv && out && dout && lse && dqkv && delta && B > 0 && N > 0 && heads > 0, "gattn_bwd: bad argument");
   LMN_REQUIRE(hd >= 1 && hd <= GA_D, "gattn_bwd: head_dim %d > %d", hd, GA_D);
   GaGeom g{B, N, heads, hd, heads * hd, scale};
   const dim3 grid(lmn_cdiv(N, GA_ROWS), heads, B);
-  LMN_LAUNCH(gattn_bwd_q_kernel, grid, dim3(256), 0, (hipStream_t)stream, qkv, out, dout, lse, dqkv, delta, g);
-  LMN_LAUNCH(gattn_bwd_kv_kernel, grid, dim3(256), 0, (hipStream_t)stream, qkv, dout, lse, delta, dqkv, g);
+  LMN_ACT_DISPATCH(act_dtype, LMN_LAUNCH((gattn_bwd_q_kernel<T>), grid, dim3(256), 0, (hipStream_t)stream, (const T*)qkv, (const T*)out, (const T*)dout, lse, (T*)dqkv, delta, g);
+                   LMN_LAUNCH((gattn_bwd_kv_kernel<T>), grid, dim3(256), 0, (hipStream_t)stream, (const T*)qkv, (const T*)dout, lse, delta, (T*)dqkv, g));
   return lmn_launch_status("gattn_bwd");
 }
 

@@ -12,7 +12,6 @@
 
 namespace {
 
-__device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 
 // per-component head sums of a float4 of products (replicated inside each head)
 template <int HD>
@@ -53,9 +52,9 @@ __device__ __forceinline__ int xcd_swizzle(int bid, int nwg) {
 // 3x3 windows can touch ((T+2)^2 pixels; the origin follows the clamping at the image border) are staged ONCE in
 // LDS by coalesced float4 loads, so the 9x neighbour re-use never leaves the CU: measured HBM fetch of the
 // direct-from-L1 form was 4.4x the algorithmic bytes (rocprof FETCH_SIZE), this form reads (T+2)^2/T^2.
-template <int HD>
-__global__ __launch_bounds__(256) void na_fwd_kernel(const float* __restrict__ qkv, const float* __restrict__ rpb,
-                                                     float* __restrict__ out, const NaGeom g, int T, int cch,
+template <int HD, typename TA>
+__global__ __launch_bounds__(256) void na_fwd_kernel(const TA* __restrict__ qkv, const float* __restrict__ rpb,
+                                                     TA* __restrict__ out, const NaGeom g, int T, int cch,
                                                      int tiles_x, int tiles, int chunks) {
   extern __shared__ __attribute__((aligned(16))) float KV[];  // [(T+2)^2][2][cch]
   __shared__ float s_rpb[16 * 25];  // the bias table: per-lane gathers from LDS, not 36 global gathers per pixel
@@ -67,7 +66,7 @@ __global__ __launch_bounds__(256) void na_fwd_kernel(const float* __restrict__ q
   const int ch0 = (cb % chunks) * cch, b = cb / chunks;
   const int rlo = max(0, min(ty0 - 1, g.H - 3)), clo = max(0, min(tx0 - 1, g.W - 3));
   const int cch4 = cch >> 2;
-  const float* base = qkv + (int64_t)b * g.H * g.W * 3 * g.C;
+  const TA* base = qkv + (int64_t)b * g.H * g.W * 3 * g.C;
   for (int i = threadIdx.x; i < R * R * 2 * cch4; i += 256) {
     const int c4 = i % cch4, w = (i / cch4) & 1, pix = i / (2 * cch4);
     const int gy = rlo + pix / R, gx = clo + pix % R;
@@ -126,7 +125,7 @@ __global__ __launch_bounds__(256) void na_fwd_kernel(const float* __restrict__ q
       for (int kj = 0; kj < 3; ++kj) o += l[ki * 3 + kj] * *reinterpret_cast<const f32x4*>(kv0 + ((ki * R + kj) * 2 + 1) * cch);
 #pragma unroll
     for (int k = 0; k < 4; ++k) o[k] = o[k] * __builtin_amdgcn_rcpf(den[k]);  // v_rcp_f32: 1 ulp
-    if (ok) *reinterpret_cast<f32x4*>(out + (((int64_t)b * g.H + y) * g.W + x) * g.C + cc) = o;
+    if (ok) st4(out + (((int64_t)b * g.H + y) * g.W + x) * g.C + cc, o);
   }
 }
 
@@ -138,9 +137,9 @@ __global__ __launch_bounds__(256) void na_fwd_kernel(const float* __restrict__ q
 //   pass 2 (key-owned): key j gathers from every query i whose clamped window contains j (i within +-2 rows/cols):
 //           p_ij = exp(q_i.k_j + rpb - lse_i), ds_ij = p_ij (dO_i.v_j - dsum_i); dK_j += scale ds_ij q_i; dV_j += p_ij dO_i.
 // Workspace: 2 floats per (pixel, head).
-template <int HD>
-__global__ __launch_bounds__(256) void na_bwd_q_kernel(const float* __restrict__ qkv, const float* __restrict__ rpb,
-                                                       const float* __restrict__ dout, float* __restrict__ dqkv,
+template <int HD, typename TA>
+__global__ __launch_bounds__(256) void na_bwd_q_kernel(const TA* __restrict__ qkv, const float* __restrict__ rpb,
+                                                       const TA* __restrict__ dout, TA* __restrict__ dqkv,
                                                        float* __restrict__ drpb, float* __restrict__ stat,
                                                        const NaGeom g) {
   extern __shared__ float s_drpb[];  // [heads][25] | per-thread interior bins [256][36]
@@ -168,7 +167,7 @@ __global__ __launch_bounds__(256) void na_bwd_q_kernel(const float* __restrict__
     const int b = (int)(pix / ((int64_t)g.W * g.H));
     const int sy = wstart(y, g.H), sx = wstart(x, g.W);
     const int64_t ib = (int64_t)b * g.H * g.W * 3 * g.C;
-    const float* base = qkv + ib;
+    const TA* base = qkv + ib;
     const f32x4 q = ld4(base + ((int64_t)y * g.W + x) * 3 * g.C + c) * g.scale;
     const f32x4 dO = ld4(dout + pix * g.C + c);
     int hidx[4];
@@ -234,7 +233,7 @@ __global__ __launch_bounds__(256) void na_bwd_q_kernel(const float* __restrict__
             if (rep[k]) atomicAdd(&s_drpb[hidx[k] + bo], ds[k]);
         }
       }
-    if (ok) *reinterpret_cast<f32x4*>(dqkv + ib + ((int64_t)y * g.W + x) * 3 * g.C + c) = dq * g.scale;
+    if (ok) st4(dqkv + ib + ((int64_t)y * g.W + x) * 3 * g.C + c, dq * g.scale);
 #pragma unroll
     for (int k = 0; k < 4; ++k)
       if (rep[k]) {
@@ -263,9 +262,9 @@ __global__ __launch_bounds__(256) void na_bwd_q_kernel(const float* __restrict__
     if (s_drpb[i] != 0.f) atomicAdd(drpb + i, s_drpb[i]);
 }
 
-template <int HD>
-__global__ __launch_bounds__(256) void na_bwd_q_tile_kernel(const float* __restrict__ qkv, const float* __restrict__ rpb,
-                                                            const float* __restrict__ dout, float* __restrict__ dqkv,
+template <int HD, typename TA>
+__global__ __launch_bounds__(256) void na_bwd_q_tile_kernel(const TA* __restrict__ qkv, const float* __restrict__ rpb,
+                                                            const TA* __restrict__ dout, TA* __restrict__ dqkv,
                                                             float* __restrict__ drpb, float* __restrict__ stat,
                                                             const NaGeom g, int TH, int TW, int tiles_x, int tiles_img,
                                                             int total_tiles) {
@@ -296,7 +295,7 @@ __global__ __launch_bounds__(256) void na_bwd_q_tile_kernel(const float* __restr
    const int ty0 = (tt / tiles_x) * TH, tx0 = (tt % tiles_x) * TW;
    const int rlo = max(0, min(ty0 - 1, g.H - 3)), clo = max(0, min(tx0 - 1, g.W - 3));
    const int64_t ib = (int64_t)b * g.H * g.W * 3 * g.C;
-   const float* base = qkv + ib;
+   const TA* base = qkv + ib;
    __syncthreads();  // the previous tile's window is consumed
    for (int i = threadIdx.x; i < RH * RW * 2 * g.C4; i += 256) {
      const int c4 = i % g.C4, w = (i / g.C4) & 1, wp = i / (2 * g.C4);
@@ -380,7 +379,7 @@ __global__ __launch_bounds__(256) void na_bwd_q_tile_kernel(const float* __restr
             if (rep[k]) atomicAdd(&s_drpb[hidx[k] + bo], ds[k]);
         }
       }
-    if (ok) *reinterpret_cast<f32x4*>(dqkv + ib + ((int64_t)y * g.W + x) * 3 * g.C + c) = dq * g.scale;
+    if (ok) st4(dqkv + ib + ((int64_t)y * g.W + x) * 3 * g.C + c, dq * g.scale);
 #pragma unroll
     for (int k = 0; k < 4; ++k)
       if (rep[k]) {
@@ -411,9 +410,9 @@ __global__ __launch_bounds__(256) void na_bwd_q_tile_kernel(const float* __restr
     if (s_drpb[i] != 0.f) atomicAdd(drpb + i, s_drpb[i]);
 }
 
-template <int HD>
-__global__ __launch_bounds__(256) void na_bwd_kv_kernel(const float* __restrict__ qkv, const float* __restrict__ rpb,
-                                                        const float* __restrict__ dout, float* __restrict__ dqkv,
+template <int HD, typename TA>
+__global__ __launch_bounds__(256) void na_bwd_kv_kernel(const TA* __restrict__ qkv, const float* __restrict__ rpb,
+                                                        const TA* __restrict__ dout, TA* __restrict__ dqkv,
                                                         const float* __restrict__ stat, const NaGeom g) {
   // (the bias table stays in global memory here: with 12 heads x 25 entries gathered per lane the LDS copy was
   //  slower than the L1-resident table -- 25-word head stride = bank conflicts)
@@ -429,7 +428,7 @@ __global__ __launch_bounds__(256) void na_bwd_kv_kernel(const float* __restrict_
     const int jy = (int)((pix / g.W) % g.H);
     const int b = (int)(pix / ((int64_t)g.W * g.H));
     const int64_t ib = (int64_t)b * g.H * g.W * 3 * g.C;
-    const float* base = qkv + ib;
+    const TA* base = qkv + ib;
     const int64_t kpo = ((int64_t)jy * g.W + jx) * 3 * g.C;
     const f32x4 kj = ld4(base + kpo + g.C + c), vj = ld4(base + kpo + 2 * g.C + c);
     int hidx[4], hd_[4];
@@ -490,8 +489,8 @@ __global__ __launch_bounds__(256) void na_bwd_kv_kernel(const float* __restrict_
       }
     }
     if (ok) {
-      *reinterpret_cast<f32x4*>(dqkv + ib + kpo + g.C + c) = dk;
-      *reinterpret_cast<f32x4*>(dqkv + ib + kpo + 2 * g.C + c) = dv;
+      st4(dqkv + ib + kpo + g.C + c, dk);
+      st4(dqkv + ib + kpo + 2 * g.C + c, dv);
     }
   }
 }
@@ -502,9 +501,9 @@ inline int na_grid(int64_t total) {
   return (int)(gsz < 1 ? 1 : gsz);
 }
 
-template <int HD>
-__global__ __launch_bounds__(256) void na_bwd_kv_tile_kernel(const float* __restrict__ qkv, const float* __restrict__ rpb,
-                                                             const float* __restrict__ dout, float* __restrict__ dqkv,
+template <int HD, typename TA>
+__global__ __launch_bounds__(256) void na_bwd_kv_tile_kernel(const TA* __restrict__ qkv, const float* __restrict__ rpb,
+                                                             const TA* __restrict__ dout, TA* __restrict__ dqkv,
                                                              const float* __restrict__ stat, const NaGeom g, int T,
                                                              int tiles_x, int tiles_img) {
   // Key pass for C <= 24 with the strided operands of the 3x3 query neighbourhood -- q (48..96 B of a 144..288 B
@@ -517,7 +516,7 @@ __global__ __launch_bounds__(256) void na_bwd_kv_tile_kernel(const float* __rest
   const int b = tile / tiles_img, tt = tile - b * tiles_img;
   const int ty0 = (tt / tiles_x) * T, tx0 = (tt % tiles_x) * T;
   const int64_t ib = (int64_t)b * g.H * g.W * 3 * g.C;
-  const float* base = qkv + ib;
+  const TA* base = qkv + ib;
   {
     const int qf = g.C4, sf = g.heads / 2, per = qf + sf;  // float4 items per window pixel
     for (int i = threadIdx.x; i < RW * RW * per; i += 256) {
@@ -602,8 +601,8 @@ __global__ __launch_bounds__(256) void na_bwd_kv_tile_kernel(const float* __rest
       }
     }
     if (ok) {
-      *reinterpret_cast<f32x4*>(dqkv + ib + kpo + g.C + c) = dk;
-      *reinterpret_cast<f32x4*>(dqkv + ib + kpo + 2 * g.C + c) = dv;
+      st4(dqkv + ib + kpo + g.C + c, dk);
+      st4(dqkv + ib + kpo + 2 * g.C + c, dv);
     }
   }
 }
@@ -612,9 +611,10 @@ __global__ __launch_bounds__(256) void na_bwd_kv_tile_kernel(const float* __rest
 
 extern "C" {
 
-int lmn_na_fwd(const float* qkv, const float* rpb, float* out, int B, int H, int W, int heads, int hd, float scale,
-               lmn_stream_t stream) {
-  LMN_REC(lmn_na_fwd(qkv, rpb, out, B, H, W, heads, hd, scale, stream));
+int lmn_na_fwd(const void* qkv, const float* rpb, void* out, int B, int H, int W, int heads, int hd, float scale,
+               int act_dtype, lmn_stream_t stream) {
+  LMN_REC(lmn_na_fwd(qkv, rpb, out, B, H, W, heads, hd, scale, act_dtype, stream));
+  LMN_REQUIRE_DT(act_dtype, "na_fwd");
   LMN_REQUIRE(qkv && rpb && out, "na_fwd: null pointer");
   LMN_REQUIRE(B > 0 && H >= 3 && W >= 3, "na_fwd: feature map %dx%d smaller than the 3x3 window", H, W);
   LMN_REQUIRE(hd == 1 || hd == 2 || hd == 4 || hd == 8 || hd == 16, "na_fwd: head_dim %d not in {1,2,4,8,16}", hd);
@@ -625,27 +625,30 @@ int lmn_na_fwd(const float* qkv, const float* rpb, float* out, int B, int H, int
   int cch = g.C <= 48 ? g.C : 48;
   while (g.C % cch || cch % (hd > 4 ? hd : 4)) cch -= 4;
   LMN_REQUIRE(cch >= 4 && cch % hd == 0, "na_fwd: channel chunk %d for hd %d", cch, hd);
-  const int T = (18 * 18 * 2 * cch * 4 <= 48 * 1024) ? 16 : 8;
-  const int tx = lmn_cdiv(W, T), ty = lmn_cdiv(H, T), chunks = g.C / cch;
+  const int TS = (18 * 18 * 2 * cch * 4 <= 48 * 1024) ? 16 : 8;
+  const int tx = lmn_cdiv(W, TS), ty = lmn_cdiv(H, TS), chunks = g.C / cch;
   const int grid = tx * ty * chunks * B;
-  const size_t sh = (size_t)(T + 2) * (T + 2) * 2 * cch * sizeof(float);
+  const size_t sh = (size_t)(TS + 2) * (TS + 2) * 2 * cch * sizeof(float);
   hipStream_t st = (hipStream_t)stream;
-  if (g_lmn_prof_on) lmn_prof_cost(2.0 * 2 * 9 * (double)B * H * W * g.C, 4.0 * 4 * (double)B * H * W * g.C);
-#define LMN_NAF(HDV) LMN_LAUNCH((na_fwd_kernel<HDV>), dim3(grid), dim3(256), sh, st, qkv, rpb, out, g, T, cch, tx, tx * ty, chunks)
-  switch (hd) {
+  if (g_lmn_prof_on) lmn_prof_cost(2.0 * 2 * 9 * (double)B * H * W * g.C, (act_dtype == LMN_BF16 ? 2.0 : 4.0) * 4 * (double)B * H * W * g.C);
+#define LMN_NAF(HDV) LMN_LAUNCH((na_fwd_kernel<HDV, T>), dim3(grid), dim3(256), sh, st, (const T*)qkv, rpb, (T*)out, g, TS, cch, tx, tx * ty, chunks)
+  LMN_ACT_DISPATCH(act_dtype, switch (hd) {
     case 1: LMN_NAF(1); break;
     case 2: LMN_NAF(2); break;
     case 4: LMN_NAF(4); break;
     case 8: LMN_NAF(8); break;
     default: LMN_NAF(16); break;
-  }
+  });
 #undef LMN_NAF
   return lmn_launch_status("na_fwd");
 }
 
-int lmn_na_bwd(const float* qkv, const float* rpb, const float* dout, float* dqkv, float* drpb, float* stat, int B,
-               int H, int W, int heads, int hd, float scale, lmn_stream_t stream) {
-  LMN_REC(lmn_na_bwd(qkv, rpb, dout, dqkv, drpb, stat, B, H, W, heads, hd, scale, stream));
+int lmn_na_bwd(const void* qkv_, const float* rpb, const void* dout_, void* dqkv_, float* drpb, float* stat, int B,
+               int H, int W, int heads, int hd, float scale, int act_dtype, lmn_stream_t stream) {
+  LMN_REC(lmn_na_bwd(qkv_, rpb, dout_, dqkv_, drpb, stat, B, H, W, heads, hd, scale, act_dtype, stream));
+  LMN_REQUIRE_DT(act_dtype, "na_bwd");
+  const void *qkv = qkv_, *dout = dout_;
+  void* dqkv = dqkv_;
   LMN_REQUIRE(qkv && rpb && dout && dqkv && drpb && stat, "na_bwd: null pointer");
   LMN_REQUIRE(B > 0 && H >= 3 && W >= 3, "na_bwd: feature map %dx%d smaller than the 3x3 window", H, W);
   LMN_REQUIRE(hd == 1 || hd == 2 || hd == 4 || hd == 8 || hd == 16, "na_bwd: head_dim %d not in {1,2,4,8,16}", hd);
@@ -656,12 +659,12 @@ int lmn_na_bwd(const float* qkv, const float* rpb, const float* dout, float* dqk
   hipStream_t st = (hipStream_t)stream;
   const size_t sh = (2 * heads * 25 + 256 * 36) * sizeof(float);
   // algorithmic cost (7*C per pixel for the pair): query pass reads q,k,v,dout and writes dq; key pass writes dk,dv
-#define NA_COST_Q if (g_lmn_prof_on) lmn_prof_cost(2.0 * 3 * 9 * (double)B * H * W * g.C, 4.0 * 5 * (double)B * H * W * g.C)
-#define NA_COST_KV if (g_lmn_prof_on) lmn_prof_cost(2.0 * 3 * 9 * (double)B * H * W * g.C, 4.0 * 2 * (double)B * H * W * g.C)
+#define NA_COST_Q if (g_lmn_prof_on) lmn_prof_cost(2.0 * 3 * 9 * (double)B * H * W * g.C, (act_dtype == LMN_BF16 ? 2.0 : 4.0) * 5 * (double)B * H * W * g.C)
+#define NA_COST_KV if (g_lmn_prof_on) lmn_prof_cost(2.0 * 3 * 9 * (double)B * H * W * g.C, (act_dtype == LMN_BF16 ? 2.0 : 4.0) * 2 * (double)B * H * W * g.C)
 #define LMN_NA(HDV)                                                                                                  \
   do {                                                                                                               \
-    NA_COST_Q; LMN_LAUNCH((na_bwd_q_kernel<HDV>), dim3(gq), dim3(256), sh, st, qkv, rpb, dout, dqkv, drpb, stat, g);    \
-    NA_COST_KV; LMN_LAUNCH((na_bwd_kv_kernel<HDV>), dim3(grid), dim3(256), 0, st, qkv, rpb, dout, dqkv, stat, g);        \
+    NA_COST_Q; LMN_LAUNCH((na_bwd_q_kernel<HDV, T>), dim3(gq), dim3(256), sh, st, (const T*)qkv, rpb, (const T*)dout, (T*)dqkv, drpb, stat, g);    \
+    NA_COST_KV; LMN_LAUNCH((na_bwd_kv_kernel<HDV, T>), dim3(grid), dim3(256), 0, st, (const T*)qkv, rpb, (const T*)dout, (T*)dqkv, stat, g);        \
   } while (0)
   // C <= 24 (levels 0-1): query pass with the k/v window in LDS; tile sizes are whole multiples of the 256/C4 pixels a
   // block handles per iteration (15x17 = 3 x 85, 12x14 = 4 x 42)
@@ -673,26 +676,26 @@ int lmn_na_bwd(const float* qkv, const float* rpb, const float* dout, float* dqk
     const int win = (TH + 2) * (TW + 2) * 2 * g.C;                                                                   \
     const size_t tsh = (size_t)(2 * ntab + (win > 256 * 36 ? win : 256 * 36)) * sizeof(float);                       \
     const int gt = total > 1024 ? 1024 : total;                                                                      \
-    NA_COST_Q; LMN_LAUNCH((na_bwd_q_tile_kernel<HDV>), dim3(gt), dim3(256), tsh, st, qkv, rpb, dout, dqkv, drpb, stat, g, TH, TW, \
+    NA_COST_Q; LMN_LAUNCH((na_bwd_q_tile_kernel<HDV, T>), dim3(gt), dim3(256), tsh, st, (const T*)qkv, rpb, (const T*)dout, (T*)dqkv, drpb, stat, g, TH, TW, \
                        tx, tx * ty, total);                                                                          \
     if (g.C4 == 3) {  /* key pass in LDS form only at C = 12 (measured: 208 -> 181 us; at C = 24 it is slower, 71 -> 97 us) */ \
       const int KT = 16;  /* key tile: window (KT+2)^2 x (C + 2*heads) floats of LDS */                              \
       const int kx = lmn_cdiv(W, KT), ky = lmn_cdiv(H, KT);                                                          \
       const size_t ksh = (size_t)(KT + 2) * (KT + 2) * (g.C + 2 * heads) * sizeof(float);                            \
-      NA_COST_KV; LMN_LAUNCH((na_bwd_kv_tile_kernel<HDV>), dim3(kx * ky * B), dim3(256), ksh, st, qkv, rpb, dout, dqkv, stat, g, KT, \
+      NA_COST_KV; LMN_LAUNCH((na_bwd_kv_tile_kernel<HDV, T>), dim3(kx * ky * B), dim3(256), ksh, st, (const T*)qkv, rpb, (const T*)dout, (T*)dqkv, stat, g, KT, \
                          kx, kx * ky);                                                                               \
     } else {                                                                                                         \
-      NA_COST_KV; LMN_LAUNCH((na_bwd_kv_kernel<HDV>), dim3(grid), dim3(256), 0, st, qkv, rpb, dout, dqkv, stat, g);      \
+      NA_COST_KV; LMN_LAUNCH((na_bwd_kv_kernel<HDV, T>), dim3(grid), dim3(256), 0, st, (const T*)qkv, rpb, (const T*)dout, (T*)dqkv, stat, g);      \
     }                                                                                                                \
   } while (0)
   const bool tiled = (g.C4 == 3 || g.C4 == 6) && hd <= 2 && heads % 2 == 0 && H >= 16 && W >= 16;
-  switch (hd) {
+  LMN_ACT_DISPATCH(act_dtype, switch (hd) {
     case 1: if (tiled) LMN_NAT(1); else LMN_NA(1); break;
     case 2: if (tiled) LMN_NAT(2); else LMN_NA(2); break;
     case 4: LMN_NA(4); break;
     case 8: LMN_NA(8); break;
     default: LMN_NA(16); break;
-  }
+  });
 #undef LMN_NA
 #undef LMN_NAT
   return lmn_launch_status("na_bwd");

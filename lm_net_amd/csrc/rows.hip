@@ -8,14 +8,12 @@
 
 namespace {
 
-__device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
-__device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
 
 // ------------------------------------------------------------------------------------ LayerNorm
 // G lanes cooperate on one row; lane j owns float4 slots j, j+G (C/4 <= 2G).
-template <int G>
-__global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
-                                                     const float* __restrict__ beta, float* __restrict__ y,
+template <int G, typename T>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, const float* __restrict__ gamma,
+                                                     const float* __restrict__ beta, T* __restrict__ y,
                                                      int64_t rows, int C) {
   const int C4 = C >> 2;
   const int j = threadIdx.x % G;
@@ -29,7 +27,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
   for (int64_t it = 0; it < nit; ++it) {
     const int64_t row = (it * gridDim.x + blockIdx.x) * rpb + threadIdx.x / G;
     const bool rok = row < rows;  // keep all lanes in the shuffles
-    const float* xr = x + row * C;
+    const T* xr = x + row * C;
     f32x4 v0 = f32x4{0, 0, 0, 0}, v1 = v0;
     if (rok && has0) v0 = ld4(xr + j * 4);
     if (rok && has1) v1 = ld4(xr + (j + G) * 4);
@@ -51,10 +49,10 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
   }
 }
 
-template <int G>
-__global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
-                                                     const float* __restrict__ dy, const float* __restrict__ dres,
-                                                     float* __restrict__ dx, float* __restrict__ dgamma,
+template <int G, typename T>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ x, const float* __restrict__ gamma,
+                                                     const T* __restrict__ dy, const T* __restrict__ dres,
+                                                     T* __restrict__ dx, float* __restrict__ dgamma,
                                                      float* __restrict__ dbeta, int64_t rows, int C) {
   extern __shared__ float red[];  // [4 waves][2][C]
   const int C4 = C >> 2;
@@ -145,8 +143,9 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ x
 }
 
 // ------------------------------------------------------------------------------------ BN(+act) tails
-__global__ __launch_bounds__(256) void bnact_fwd_kernel(const float* __restrict__ z, const float* __restrict__ a,
-                                                        const float* __restrict__ b, float* __restrict__ y,
+template <typename T>
+__global__ __launch_bounds__(256) void bnact_fwd_kernel(const T* __restrict__ z, const float* __restrict__ a,
+                                                        const float* __restrict__ b, T* __restrict__ y,
                                                         int64_t n4, int C4, int act) {
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
     const int c = (int)(i % C4) * 4;
@@ -160,24 +159,26 @@ __global__ __launch_bounds__(256) void bnact_fwd_kernel(const float* __restrict_
 
 // MODE 0: stats[2][C] += (sum dh, sum dh*zhat);  MODE 1: dz = c1*dh - c2 - zhat*c3
 // MODE 2: out[C] += column sums of x (bias gradients); x has pixel stride cstride
-template <int MODE>
-__global__ __launch_bounds__(256) void chan_kernel(const float* __restrict__ z, const float* __restrict__ dy,
+template <int MODE, typename T>
+__global__ __launch_bounds__(256) void chan_kernel(const T* __restrict__ z, const T* __restrict__ dy,
                                                    const float* __restrict__ mean, const float* __restrict__ rstd,
                                                    const float* __restrict__ gamma, const float* __restrict__ beta,
                                                    const float* __restrict__ c1, const float* __restrict__ c2,
-                                                   const float* __restrict__ c3, float* __restrict__ out,
+                                                   const float* __restrict__ c3, void* __restrict__ out_,
                                                    int64_t rows, int C, int cstride, int act) {
+  float* out = reinterpret_cast<float*>(out_);   // MODE 0 / 2: fp32 statistics; MODE 1: the activation tensor dz
+  T* out_act = reinterpret_cast<T*>(out_);
   extern __shared__ float red[];  // [2][C] (MODE 0), [C] (MODE 2)
   const int C4 = C >> 2;
-  const int T = (256 / C4) * C4;  // active threads: each keeps a fixed channel quad
-  const int rpb = T / C4;
+  const int NTH = (256 / C4) * C4;  // active threads: each keeps a fixed channel quad
+  const int rpb = NTH / C4;
   const int tid = threadIdx.x;
   if (MODE != 1) {
     for (int i = tid; i < 2 * C; i += 256) red[i] = 0.f;
     __syncthreads();
   }
   f32x4 s0 = f32x4{0, 0, 0, 0}, s1 = s0;
-  if (tid < T) {
+  if (tid < NTH) {
     const int c = (tid % C4) * 4;
     f32x4 mu = s0, rs = s0, ga = s0, be = s0, k1 = s0, k2 = s0, k3 = s0;
     if (MODE != 2) { mu = ld4(mean + c); rs = ld4(rstd + c); ga = ld4(gamma + c); be = ld4(beta + c); }
@@ -195,7 +196,7 @@ __global__ __launch_bounds__(256) void chan_kernel(const float* __restrict__ z, 
           if (MODE == 0) { s0[k] += dh; s1[k] += dh * zh; }
           else o[k] = k1[k] * dh - k2[k] - zh * k3[k];
         }
-        if (MODE == 1) st4(out + row * C + c, o);
+        if (MODE == 1) st4(out_act + row * C + c, o);
       }
     }
     if (MODE != 1) {
@@ -344,7 +345,8 @@ __device__ __forceinline__ void up_coord(int dst, int in, float scale, int& i0, 
   l0 = 1.f - l1;
 }
 
-__global__ __launch_bounds__(256) void up2_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int B, int Hin,
+template <typename T>
+__global__ __launch_bounds__(256) void up2_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, int B, int Hin,
                                                       int Win, int C4, int xcs, int ycs) {
   const int Hout = 2 * Hin, Wout = 2 * Win;
   const float sh = (float)(Hin - 1) / (float)(Hout - 1), sw = (float)(Win - 1) / (float)(Wout - 1);
@@ -360,7 +362,7 @@ __global__ __launch_bounds__(256) void up2_fwd_kernel(const float* __restrict__ 
     float ly0, ly1, lx0, lx1;
     up_coord(oy, Hin, sh, y0, yp, ly0, ly1);
     up_coord(ox, Win, sw, x0, xp, lx0, lx1);
-    const float* base = x + ((int64_t)b * Hin * Win) * xcs + c;
+    const T* base = x + ((int64_t)b * Hin * Win) * xcs + c;
     const f32x4 v00 = ld4(base + ((int64_t)y0 * Win + x0) * xcs), v01 = ld4(base + ((int64_t)y0 * Win + x0 + xp) * xcs);
     const f32x4 v10 = ld4(base + ((int64_t)(y0 + yp) * Win + x0) * xcs), v11 = ld4(base + ((int64_t)(y0 + yp) * Win + x0 + xp) * xcs);
     const f32x4 o = ly0 * (lx0 * v00 + lx1 * v01) + ly1 * (lx0 * v10 + lx1 * v11);
@@ -368,7 +370,8 @@ __global__ __launch_bounds__(256) void up2_fwd_kernel(const float* __restrict__ 
   }
 }
 
-__global__ __launch_bounds__(256) void up2_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, int B,
+template <typename T>
+__global__ __launch_bounds__(256) void up2_bwd_kernel(const T* __restrict__ dy, T* __restrict__ dx, int B,
                                                       int Hin, int Win, int C4, int dycs, int dxcs) {
   const int Hout = 2 * Hin, Wout = 2 * Win;
   const float sh = (float)(Hin - 1) / (float)(Hout - 1), sw = (float)(Win - 1) / (float)(Wout - 1);
@@ -399,7 +402,7 @@ __global__ __launch_bounds__(256) void up2_bwd_kernel(const float* __restrict__ 
       }
     }
     f32x4 acc = f32x4{0, 0, 0, 0};
-    const float* base = dy + ((int64_t)b * Hout * Wout) * dycs + c;
+    const T* base = dy + ((int64_t)b * Hout * Wout) * dycs + c;
 #pragma unroll
     for (int ky = 0; ky < 8; ++ky) {
       if (wy[ky] == 0.f) continue;
@@ -416,16 +419,17 @@ __global__ __launch_bounds__(256) void up2_bwd_kernel(const float* __restrict__ 
 }
 
 // ------------------------------------------------------------------------------------ f x f mean pool
-__global__ __launch_bounds__(256) void avgpool_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int Hout,
+template <typename T>
+__global__ __launch_bounds__(256) void avgpool_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, int Hout,
                                                           int Wout, int f, int C, int xcs, int ycs) {
   extern __shared__ float red[];  // [C]
   const int C4 = C >> 2;
-  const int T = (256 / C4) * C4, per = T / C4;
+  const int NTH = (256 / C4) * C4, per = NTH / C4;
   const int tid = threadIdx.x;
   const int ox = blockIdx.x % Wout, oy = (blockIdx.x / Wout) % Hout, b = blockIdx.x / (Wout * Hout);
   for (int i = tid; i < C; i += 256) red[i] = 0.f;
   __syncthreads();
-  if (tid < T) {
+  if (tid < NTH) {
     const int c = (tid % C4) * 4;
     f32x4 s = f32x4{0, 0, 0, 0};
     const int Hin = Hout * f, Win = Wout * f;
@@ -438,10 +442,11 @@ __global__ __launch_bounds__(256) void avgpool_fwd_kernel(const float* __restric
   }
   __syncthreads();
   const float inv = 1.0f / (float)(f * f);
-  for (int i = tid; i < C; i += 256) y[(((int64_t)b * Hout + oy) * Wout + ox) * ycs + i] = red[i] * inv;
+  for (int i = tid; i < C; i += 256) st1(y + (((int64_t)b * Hout + oy) * Wout + ox) * ycs + i, red[i] * inv);
 }
 
-__global__ __launch_bounds__(256) void avgpool_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, int B,
+template <typename T>
+__global__ __launch_bounds__(256) void avgpool_bwd_kernel(const T* __restrict__ dy, T* __restrict__ dx, int B,
                                                           int Hout, int Wout, int f, int C4, int dycs, int dxcs,
                                                           int accumulate) {
   const int Hin = Hout * f, Win = Wout * f;
@@ -455,35 +460,38 @@ __global__ __launch_bounds__(256) void avgpool_bwd_kernel(const float* __restric
     const int iy = (int)(p % Hin);
     const int b = (int)(p / Hin);
     f32x4 g = inv * ld4(dy + (((int64_t)b * Hout + iy / f) * Wout + ix / f) * dycs + c);
-    float* o = dx + (((int64_t)b * Hin + iy) * Win + ix) * dxcs + c;
+    T* o = dx + (((int64_t)b * Hin + iy) * Win + ix) * dxcs + c;
     if (accumulate) g += ld4(o);
     st4(o, g);
   }
 }
 
 // ------------------------------------------------------------------------------------ layout + utilities
-__global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restrict__ x, float* __restrict__ y, int B,
+template <typename T>
+__global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restrict__ x, T* __restrict__ y, int B,
                                                            int C, int64_t HW, int ycs) {
   const int64_t total = (int64_t)B * HW;
   for (int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x; p < total; p += (int64_t)gridDim.x * 256) {
     const int64_t b = p / HW, hw = p - b * HW;
-    for (int c = 0; c < ycs; ++c) y[p * ycs + c] = c < C ? x[(b * C + c) * HW + hw] : 0.f;
+    for (int c = 0; c < ycs; ++c) st1(y + p * ycs + c, c < C ? x[(b * C + c) * HW + hw] : 0.f);
   }
 }
-__global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const float* __restrict__ x, float* __restrict__ y, int B,
+template <typename T>
+__global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const T* __restrict__ x, float* __restrict__ y, int B,
                                                            int C, int64_t HW, int xcs) {
   const int64_t total = (int64_t)B * HW;
   for (int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x; p < total; p += (int64_t)gridDim.x * 256) {
     const int64_t b = p / HW, hw = p - b * HW;
-    for (int c = 0; c < C; ++c) y[(b * C + c) * HW + hw] = x[p * xcs + c];
+    for (int c = 0; c < C; ++c) y[(b * C + c) * HW + hw] = ld1(x + p * xcs + c);
   }
 }
 __global__ __launch_bounds__(256) void fill_kernel(float* __restrict__ p, float v, int64_t n) {
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) p[i] = v;
 }
-__global__ __launch_bounds__(256) void add_kernel(const float* __restrict__ a, const float* __restrict__ b,
-                                                  const float* __restrict__ c, const float* __restrict__ d,
-                                                  float* __restrict__ y, int64_t n4) {
+template <typename T>
+__global__ __launch_bounds__(256) void add_kernel(const T* __restrict__ a, const T* __restrict__ b,
+                                                  const T* __restrict__ c, const T* __restrict__ d,
+                                                  T* __restrict__ y, int64_t n4) {
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
     f32x4 v = ld4(a + i * 4) + ld4(b + i * 4);
     if (c) v += ld4(c + i * 4);
@@ -491,7 +499,8 @@ __global__ __launch_bounds__(256) void add_kernel(const float* __restrict__ a, c
     st4(y + i * 4, v);
   }
 }
-__global__ __launch_bounds__(256) void copy_slice_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t rows,
+template <typename T>
+__global__ __launch_bounds__(256) void copy_slice_kernel(const T* __restrict__ x, T* __restrict__ y, int64_t rows,
                                                          int C4, int xcs, int ycs) {
   const int64_t total = rows * C4;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
@@ -779,23 +788,25 @@ int lmn_copy2d(const float* x, float* y, int64_t rows, int cols, int x_stride, i
   return lmn_launch_status("copy2d");
 }
 
-int lmn_ln_fwd(const float* x, const float* gamma, const float* beta, float* y, int64_t rows, int C,
+int lmn_ln_fwd(const void* x, const float* gamma, const float* beta, void* y, int64_t rows, int C, int act_dtype,
                lmn_stream_t stream) {
-  LMN_REC(lmn_ln_fwd(x, gamma, beta, y, rows, C, stream));
+  LMN_REC(lmn_ln_fwd(x, gamma, beta, y, rows, C, act_dtype, stream));
+  LMN_REQUIRE_DT(act_dtype, "ln_fwd");
   LMN_REQUIRE(x && gamma && beta && y && rows > 0, "ln_fwd: bad argument");
   LMN_REQUIRE(C % 4 == 0 && C >= 4 && C <= 512, "ln_fwd: C=%d (need multiple of 4, <= 512)", C);
   const int G = ln_group(C / 4);
   const int grid = grid_for(rows, 256 / G, 2048);
   hipStream_t st = (hipStream_t)stream;
-#define LN_CASE(g) case g: LMN_LAUNCH((ln_fwd_kernel<g>), dim3(grid), dim3(256), 0, st, x, gamma, beta, y, rows, C); break;
-  switch (G) { LN_CASE(1) LN_CASE(2) LN_CASE(4) LN_CASE(8) LN_CASE(16) LN_CASE(32) LN_CASE(64) }
+#define LN_CASE(g) case g: LMN_LAUNCH((ln_fwd_kernel<g, T>), dim3(grid), dim3(256), 0, st, (const T*)x, gamma, beta, (T*)y, rows, C); break;
+  LMN_ACT_DISPATCH(act_dtype, switch (G) { LN_CASE(1) LN_CASE(2) LN_CASE(4) LN_CASE(8) LN_CASE(16) LN_CASE(32) LN_CASE(64) });
 #undef LN_CASE
   return lmn_launch_status("ln_fwd");
 }
 
-int lmn_ln_bwd(const float* x, const float* gamma, const float* dy, const float* dres, float* dx, float* dgamma,
-               float* dbeta, int64_t rows, int C, lmn_stream_t stream) {
-  LMN_REC(lmn_ln_bwd(x, gamma, dy, dres, dx, dgamma, dbeta, rows, C, stream));
+int lmn_ln_bwd(const void* x, const float* gamma, const void* dy, const void* dres, void* dx, float* dgamma,
+               float* dbeta, int64_t rows, int C, int act_dtype, lmn_stream_t stream) {
+  LMN_REC(lmn_ln_bwd(x, gamma, dy, dres, dx, dgamma, dbeta, rows, C, act_dtype, stream));
+  LMN_REQUIRE_DT(act_dtype, "ln_bwd");
   LMN_REQUIRE(x && gamma && dy && dx && dgamma && dbeta && rows > 0, "ln_bwd: bad argument");
   LMN_REQUIRE(C % 4 == 0 && C >= 4 && C <= 512, "ln_bwd: C=%d", C);
   const int G = ln_group(C / 4);
@@ -804,51 +815,55 @@ int lmn_ln_bwd(const float* x, const float* gamma, const float* dy, const float*
   const int grid = grid_for(rows, 256 / G, C <= 12 ? 1024 : 512);
   hipStream_t st = (hipStream_t)stream;
   const size_t sh = 8 * C * sizeof(float);
-#define LN_CASE(g) case g: LMN_LAUNCH((ln_bwd_kernel<g>), dim3(grid), dim3(256), sh, st, x, gamma, dy, dres, dx, dgamma, dbeta, rows, C); break;
-  switch (G) { LN_CASE(1) LN_CASE(2) LN_CASE(4) LN_CASE(8) LN_CASE(16) LN_CASE(32) LN_CASE(64) }
+#define LN_CASE(g) case g: LMN_LAUNCH((ln_bwd_kernel<g, T>), dim3(grid), dim3(256), sh, st, (const T*)x, gamma, (const T*)dy, (const T*)dres, (T*)dx, dgamma, dbeta, rows, C); break;
+  LMN_ACT_DISPATCH(act_dtype, switch (G) { LN_CASE(1) LN_CASE(2) LN_CASE(4) LN_CASE(8) LN_CASE(16) LN_CASE(32) LN_CASE(64) });
 #undef LN_CASE
   return lmn_launch_status("ln_bwd");
 }
 
-int lmn_bnact_fwd(const float* z, const float* a, const float* b, float* y, int64_t rows, int C, int act,
+int lmn_bnact_fwd(const void* z, const float* a, const float* b, void* y, int64_t rows, int C, int act, int act_dtype,
                   lmn_stream_t stream) {
-  LMN_REC(lmn_bnact_fwd(z, a, b, y, rows, C, act, stream));
+  LMN_REC(lmn_bnact_fwd(z, a, b, y, rows, C, act, act_dtype, stream));
+  LMN_REQUIRE_DT(act_dtype, "bnact_fwd");
   LMN_REQUIRE(z && a && b && y && rows > 0 && C > 0 && C % 4 == 0, "bnact_fwd: bad argument");
   const int64_t n4 = rows * (C / 4);
-  LMN_LAUNCH(bnact_fwd_kernel, dim3(grid_for(n4)), dim3(256), 0, (hipStream_t)stream, z, a, b, y, n4, C / 4, act);
+  LMN_ACT_DISPATCH(act_dtype, LMN_LAUNCH((bnact_fwd_kernel<T>), dim3(grid_for(n4)), dim3(256), 0, (hipStream_t)stream, (const T*)z, a, b, (T*)y, n4, C / 4, act));
   return lmn_launch_status("bnact_fwd");
 }
 
-int lmn_bnact_bwd_stats(const float* z, const float* dy, const float* mean, const float* rstd, const float* gamma,
-                        const float* beta, float* stats, int64_t rows, int C, int act, lmn_stream_t stream) {
-  LMN_REC(lmn_bnact_bwd_stats(z, dy, mean, rstd, gamma, beta, stats, rows, C, act, stream));
+int lmn_bnact_bwd_stats(const void* z, const void* dy, const float* mean, const float* rstd, const float* gamma,
+                        const float* beta, float* stats, int64_t rows, int C, int act, int act_dtype, lmn_stream_t stream) {
+  LMN_REC(lmn_bnact_bwd_stats(z, dy, mean, rstd, gamma, beta, stats, rows, C, act, act_dtype, stream));
+  LMN_REQUIRE_DT(act_dtype, "bnact_bwd_stats");
   LMN_REQUIRE(z && dy && mean && rstd && gamma && beta && stats && rows > 0, "bnact_bwd_stats: bad argument");
   LMN_REQUIRE(C % 4 == 0 && C >= 4 && C <= 1024, "bnact_bwd_stats: C=%d", C);
   const int rpb = 256 / (C / 4);
-  LMN_LAUNCH((chan_kernel<0>), dim3(grid_for(rows, rpb * 8, 1024)), dim3(256), 2 * C * sizeof(float),
-                     (hipStream_t)stream, z, dy, mean, rstd, gamma, beta, nullptr, nullptr, nullptr, stats, rows, C, C, act);
+  LMN_ACT_DISPATCH(act_dtype, LMN_LAUNCH((chan_kernel<0, T>), dim3(grid_for(rows, rpb * 8, 1024)), dim3(256), 2 * C * sizeof(float),
+                     (hipStream_t)stream, (const T*)z, (const T*)dy, mean, rstd, gamma, beta, nullptr, nullptr, nullptr, (void*)stats, rows, C, C, act));
   return lmn_launch_status("bnact_bwd_stats");
 }
 
-int lmn_bnact_bwd(const float* z, const float* dy, const float* mean, const float* rstd, const float* gamma,
-                  const float* beta, const float* c1, const float* c2, const float* c3, float* dz, int64_t rows, int C,
-                  int act, lmn_stream_t stream) {
-  LMN_REC(lmn_bnact_bwd(z, dy, mean, rstd, gamma, beta, c1, c2, c3, dz, rows, C, act, stream));
+int lmn_bnact_bwd(const void* z, const void* dy, const float* mean, const float* rstd, const float* gamma,
+                  const float* beta, const float* c1, const float* c2, const float* c3, void* dz, int64_t rows, int C,
+                  int act, int act_dtype, lmn_stream_t stream) {
+  LMN_REC(lmn_bnact_bwd(z, dy, mean, rstd, gamma, beta, c1, c2, c3, dz, rows, C, act, act_dtype, stream));
+  LMN_REQUIRE_DT(act_dtype, "bnact_bwd");
   LMN_REQUIRE(z && dy && mean && rstd && gamma && beta && c1 && c2 && c3 && dz && rows > 0, "bnact_bwd: bad argument");
   LMN_REQUIRE(C % 4 == 0 && C >= 4 && C <= 1024, "bnact_bwd: C=%d", C);
   const int rpb = 256 / (C / 4);
-  LMN_LAUNCH((chan_kernel<1>), dim3(grid_for(rows, rpb * 4, 4096)), dim3(256), 2 * C * sizeof(float),
-                     (hipStream_t)stream, z, dy, mean, rstd, gamma, beta, c1, c2, c3, dz, rows, C, C, act);
+  LMN_ACT_DISPATCH(act_dtype, LMN_LAUNCH((chan_kernel<1, T>), dim3(grid_for(rows, rpb * 4, 4096)), dim3(256), 2 * C * sizeof(float),
+                     (hipStream_t)stream, (const T*)z, (const T*)dy, mean, rstd, gamma, beta, c1, c2, c3, dz, rows, C, C, act));
   return lmn_launch_status("bnact_bwd");
 }
 
-int lmn_colsum(const float* x, float* out, int64_t rows, int C, int cstride, lmn_stream_t stream) {
-  LMN_REC(lmn_colsum(x, out, rows, C, cstride, stream));
+int lmn_colsum(const void* x, float* out, int64_t rows, int C, int cstride, int act_dtype, lmn_stream_t stream) {
+  LMN_REC(lmn_colsum(x, out, rows, C, cstride, act_dtype, stream));
+  LMN_REQUIRE_DT(act_dtype, "colsum");
   LMN_REQUIRE(x && out && rows > 0 && C % 4 == 0 && C >= 4 && C <= 1024 && cstride >= C && cstride % 4 == 0, "colsum: bad argument");
   const int rpb = 256 / (C / 4);
-  LMN_LAUNCH((chan_kernel<2>), dim3(grid_for(rows, rpb * 8, 1024)), dim3(256), 2 * C * sizeof(float),
-                     (hipStream_t)stream, x, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, out,
-                     rows, C, cstride, 0);
+  LMN_ACT_DISPATCH(act_dtype, LMN_LAUNCH((chan_kernel<2, T>), dim3(grid_for(rows, rpb * 8, 1024)), dim3(256), 2 * C * sizeof(float),
+                     (hipStream_t)stream, (const T*)x, (const T*)nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, (void*)out,
+                     rows, C, cstride, 0));
   return lmn_launch_status("colsum");
 }
 
@@ -902,58 +917,64 @@ int lmn_se_bwd(const float* ds, const float* gsum, float inv_hw, const float* w1
   return lmn_launch_status("se_bwd");
 }
 
-int lmn_up2_fwd(const float* x, float* y, int B, int Hin, int Win, int C, int x_cstride, int y_cstride,
+int lmn_up2_fwd(const void* x, void* y, int B, int Hin, int Win, int C, int x_cstride, int y_cstride, int act_dtype,
                 lmn_stream_t stream) {
-  LMN_REC(lmn_up2_fwd(x, y, B, Hin, Win, C, x_cstride, y_cstride, stream));
+  LMN_REC(lmn_up2_fwd(x, y, B, Hin, Win, C, x_cstride, y_cstride, act_dtype, stream));
+  LMN_REQUIRE_DT(act_dtype, "up2_fwd");
   LMN_REQUIRE(x && y && B > 0 && Hin > 0 && Win > 0 && C > 0 && C % 4 == 0 && x_cstride >= C && y_cstride >= C && x_cstride % 4 == 0 && y_cstride % 4 == 0, "up2_fwd: bad argument");
   const int64_t total = (int64_t)B * 4 * Hin * Win * (C / 4);
-  LMN_LAUNCH(up2_fwd_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, y, B, Hin, Win, C / 4,
-                     x_cstride, y_cstride);
+  LMN_ACT_DISPATCH(act_dtype, LMN_LAUNCH((up2_fwd_kernel<T>), dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, (const T*)x, (T*)y, B, Hin, Win, C / 4,
+                     x_cstride, y_cstride));
   return lmn_launch_status("up2_fwd");
 }
 
-int lmn_up2_bwd(const float* dy, float* dx, int B, int Hin, int Win, int C, int dy_cstride, int dx_cstride,
+int lmn_up2_bwd(const void* dy, void* dx, int B, int Hin, int Win, int C, int dy_cstride, int dx_cstride, int act_dtype,
                 lmn_stream_t stream) {
-  LMN_REC(lmn_up2_bwd(dy, dx, B, Hin, Win, C, dy_cstride, dx_cstride, stream));
+  LMN_REC(lmn_up2_bwd(dy, dx, B, Hin, Win, C, dy_cstride, dx_cstride, act_dtype, stream));
+  LMN_REQUIRE_DT(act_dtype, "up2_bwd");
   LMN_REQUIRE(dy && dx && B > 0 && Hin > 0 && Win > 0 && C > 0 && C % 4 == 0 && dy_cstride >= C && dx_cstride >= C && dy_cstride % 4 == 0 && dx_cstride % 4 == 0, "up2_bwd: bad argument");
   const int64_t total = (int64_t)B * Hin * Win * (C / 4);
-  LMN_LAUNCH(up2_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, dy, dx, B, Hin, Win, C / 4,
-                     dy_cstride, dx_cstride);
+  LMN_ACT_DISPATCH(act_dtype, LMN_LAUNCH((up2_bwd_kernel<T>), dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, (const T*)dy, (T*)dx, B, Hin, Win, C / 4,
+                     dy_cstride, dx_cstride));
   return lmn_launch_status("up2_bwd");
 }
 
-int lmn_avgpool_fwd(const float* x, float* y, int B, int Hout, int Wout, int f, int C, int x_cstride, int y_cstride,
-                    lmn_stream_t stream) {
-  LMN_REC(lmn_avgpool_fwd(x, y, B, Hout, Wout, f, C, x_cstride, y_cstride, stream));
+int lmn_avgpool_fwd(const void* x, void* y, int B, int Hout, int Wout, int f, int C, int x_cstride, int y_cstride,
+                    int act_dtype, lmn_stream_t stream) {
+  LMN_REC(lmn_avgpool_fwd(x, y, B, Hout, Wout, f, C, x_cstride, y_cstride, act_dtype, stream));
+  LMN_REQUIRE_DT(act_dtype, "avgpool_fwd");
   LMN_REQUIRE(x && y && B > 0 && Hout > 0 && Wout > 0 && f >= 1 && C % 4 == 0 && C >= 4 && C <= 1024 && x_cstride >= C && y_cstride >= C && x_cstride % 4 == 0, "avgpool_fwd: bad argument");
-  LMN_LAUNCH(avgpool_fwd_kernel, dim3(B * Hout * Wout), dim3(256), C * sizeof(float), (hipStream_t)stream, x, y,
-                     Hout, Wout, f, C, x_cstride, y_cstride);
+  LMN_ACT_DISPATCH(act_dtype, LMN_LAUNCH((avgpool_fwd_kernel<T>), dim3(B * Hout * Wout), dim3(256), C * sizeof(float), (hipStream_t)stream, (const T*)x, (T*)y,
+                     Hout, Wout, f, C, x_cstride, y_cstride));
   return lmn_launch_status("avgpool_fwd");
 }
 
-int lmn_avgpool_bwd(const float* dy, float* dx, int B, int Hout, int Wout, int f, int C, int dy_cstride, int dx_cstride,
-                    int accumulate, lmn_stream_t stream) {
-  LMN_REC(lmn_avgpool_bwd(dy, dx, B, Hout, Wout, f, C, dy_cstride, dx_cstride, accumulate, stream));
+int lmn_avgpool_bwd(const void* dy, void* dx, int B, int Hout, int Wout, int f, int C, int dy_cstride, int dx_cstride,
+                    int accumulate, int act_dtype, lmn_stream_t stream) {
+  LMN_REC(lmn_avgpool_bwd(dy, dx, B, Hout, Wout, f, C, dy_cstride, dx_cstride, accumulate, act_dtype, stream));
+  LMN_REQUIRE_DT(act_dtype, "avgpool_bwd");
   LMN_REQUIRE(dy && dx && B > 0 && Hout > 0 && Wout > 0 && f >= 1 && C % 4 == 0 && C >= 4 && dy_cstride >= C && dx_cstride >= C && dy_cstride % 4 == 0 && dx_cstride % 4 == 0, "avgpool_bwd: bad argument");
   const int64_t total = (int64_t)B * Hout * f * Wout * f * (C / 4);
-  LMN_LAUNCH(avgpool_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, dy, dx, B, Hout, Wout,
-                     f, C / 4, dy_cstride, dx_cstride, accumulate);
+  LMN_ACT_DISPATCH(act_dtype, LMN_LAUNCH((avgpool_bwd_kernel<T>), dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, (const T*)dy, (T*)dx, B, Hout, Wout,
+                     f, C / 4, dy_cstride, dx_cstride, accumulate));
   return lmn_launch_status("avgpool_bwd");
 }
 
-int lmn_nchw_to_nhwc(const float* x, float* y, int B, int C, int H, int W, int y_cstride, lmn_stream_t stream) {
-  LMN_REC(lmn_nchw_to_nhwc(x, y, B, C, H, W, y_cstride, stream));
+int lmn_nchw_to_nhwc(const float* x, void* y, int B, int C, int H, int W, int y_cstride, int act_dtype, lmn_stream_t stream) {
+  LMN_REC(lmn_nchw_to_nhwc(x, y, B, C, H, W, y_cstride, act_dtype, stream));
+  LMN_REQUIRE_DT(act_dtype, "nchw_to_nhwc");
   LMN_REQUIRE(x && y && B > 0 && C > 0 && H > 0 && W > 0 && y_cstride >= C, "nchw_to_nhwc: bad argument");
-  LMN_LAUNCH(nchw_to_nhwc_kernel, dim3(grid_for((int64_t)B * H * W)), dim3(256), 0, (hipStream_t)stream, x, y, B,
-                     C, (int64_t)H * W, y_cstride);
+  LMN_ACT_DISPATCH(act_dtype, LMN_LAUNCH((nchw_to_nhwc_kernel<T>), dim3(grid_for((int64_t)B * H * W)), dim3(256), 0, (hipStream_t)stream, x, (T*)y, B,
+                     C, (int64_t)H * W, y_cstride));
   return lmn_launch_status("nchw_to_nhwc");
 }
 
-int lmn_nhwc_to_nchw(const float* x, float* y, int B, int C, int H, int W, int x_cstride, lmn_stream_t stream) {
-  LMN_REC(lmn_nhwc_to_nchw(x, y, B, C, H, W, x_cstride, stream));
+int lmn_nhwc_to_nchw(const void* x, float* y, int B, int C, int H, int W, int x_cstride, int act_dtype, lmn_stream_t stream) {
+  LMN_REC(lmn_nhwc_to_nchw(x, y, B, C, H, W, x_cstride, act_dtype, stream));
+  LMN_REQUIRE_DT(act_dtype, "nhwc_to_nchw");
   LMN_REQUIRE(x && y && B > 0 && C > 0 && H > 0 && W > 0 && x_cstride >= C, "nhwc_to_nchw: bad argument");
-  LMN_LAUNCH(nhwc_to_nchw_kernel, dim3(grid_for((int64_t)B * H * W)), dim3(256), 0, (hipStream_t)stream, x, y, B,
-                     C, (int64_t)H * W, x_cstride);
+  LMN_ACT_DISPATCH(act_dtype, LMN_LAUNCH((nhwc_to_nchw_kernel<T>), dim3(grid_for((int64_t)B * H * W)), dim3(256), 0, (hipStream_t)stream, (const T*)x, y, B,
+                     C, (int64_t)H * W, x_cstride));
   return lmn_launch_status("nhwc_to_nchw");
 }
 
@@ -1042,18 +1063,20 @@ int lmn_fill(float* p, float v, int64_t n, lmn_stream_t stream) {
   return lmn_launch_status("fill");
 }
 
-int lmn_add(const float* a, const float* b, const float* c, const float* d, float* y, int64_t n, lmn_stream_t stream) {
-  LMN_REC(lmn_add(a, b, c, d, y, n, stream));
+int lmn_add(const void* a, const void* b, const void* c, const void* d, void* y, int64_t n, int act_dtype, lmn_stream_t stream) {
+  LMN_REC(lmn_add(a, b, c, d, y, n, act_dtype, stream));
+  LMN_REQUIRE_DT(act_dtype, "add");
   LMN_REQUIRE(a && b && y && n > 0 && n % 4 == 0, "add: bad argument (n must be a multiple of 4)");
-  LMN_LAUNCH(add_kernel, dim3(grid_for(n / 4)), dim3(256), 0, (hipStream_t)stream, a, b, c, d, y, n / 4);
+  LMN_ACT_DISPATCH(act_dtype, LMN_LAUNCH((add_kernel<T>), dim3(grid_for(n / 4)), dim3(256), 0, (hipStream_t)stream, (const T*)a, (const T*)b, (const T*)c, (const T*)d, (T*)y, n / 4));
   return lmn_launch_status("add");
 }
 
-int lmn_copy_slice(const float* x, float* y, int64_t rows, int C, int x_cstride, int y_cstride, lmn_stream_t stream) {
-  LMN_REC(lmn_copy_slice(x, y, rows, C, x_cstride, y_cstride, stream));
+int lmn_copy_slice(const void* x, void* y, int64_t rows, int C, int x_cstride, int y_cstride, int act_dtype, lmn_stream_t stream) {
+  LMN_REC(lmn_copy_slice(x, y, rows, C, x_cstride, y_cstride, act_dtype, stream));
+  LMN_REQUIRE_DT(act_dtype, "copy_slice");
   LMN_REQUIRE(x && y && rows > 0 && C > 0 && C % 4 == 0 && x_cstride >= C && y_cstride >= C && x_cstride % 4 == 0 && y_cstride % 4 == 0, "copy_slice: bad argument");
-  LMN_LAUNCH(copy_slice_kernel, dim3(grid_for(rows * (C / 4))), dim3(256), 0, (hipStream_t)stream, x, y, rows,
-                     C / 4, x_cstride, y_cstride);
+  LMN_ACT_DISPATCH(act_dtype, LMN_LAUNCH((copy_slice_kernel<T>), dim3(grid_for(rows * (C / 4))), dim3(256), 0, (hipStream_t)stream, (const T*)x, (T*)y, rows,
+                     C / 4, x_cstride, y_cstride));
   return lmn_launch_status("copy_slice");
 }
 

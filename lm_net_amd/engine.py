@@ -39,14 +39,16 @@ class Arena:
         self.buf = torch.empty(int(nfloats), device=device, dtype=torch.float32)
         self.off = 0
 
-    def alloc(self, shape):
+    def alloc(self, shape, dtype=torch.float32):
         n = 1
         for d in shape:
             n *= int(d)
-        n_al = (n + 63) & ~63                  # 256-byte granules
+        nf = n if dtype == torch.float32 else (n + 1) // 2      # floats covering n elements
+        n_al = (nf + 63) & ~63                 # 256-byte granules
         if self.off + n_al > self.buf.numel():
             raise RuntimeError("lm_net_amd: plan arena exhausted (%d + %d > %d floats)" % (self.off, n_al, self.buf.numel()))
-        v = self.buf[self.off:self.off + n].view(shape)
+        v = self.buf[self.off:self.off + nf]
+        v = v.view(shape) if dtype == torch.float32 else v.view(dtype)[:n].view(shape)
         self.off += n_al
         return v
 
@@ -55,12 +57,22 @@ _ENG = [None]      # engine of the pass in flight
 
 
 def _E(ref, *shape):
-    """fp32 buffer of `shape` on ref's device (ref: tensor or torch.device) from the allocator of the pass in flight."""
+    """fp32 buffer of `shape` on ref's device (ref: tensor or torch.device) from the allocator of the pass in flight:
+    per-channel vectors, statistics, packed weights, workspaces and the fp32 tensors at the module boundary."""
     dev = ref if isinstance(ref, torch.device) else ref.device
     eng = _ENG[0]
     if eng is None:
         return torch.empty(shape, device=dev, dtype=torch.float32)
     return eng.alloc(dev, shape)
+
+
+def _A(ref, *shape):
+    """ACTIVATION tensor of `shape`: stored in the pass's activation type (fp32, or bf16 in the mixed-precision mode)."""
+    dev = ref if isinstance(ref, torch.device) else ref.device
+    eng = _ENG[0]
+    if eng is None:
+        return torch.empty(shape, device=dev, dtype=torch.float32)
+    return eng.alloc(dev, shape, eng.act_dtype)
 
 
 class ZeroPool:
@@ -132,18 +144,23 @@ class Engine:
         self.zpool_fwd, self.zpool_bwd = ZeroPool(), ZeroPool()
         self.packs_fwd, self.packs_bwd = hip.PackPlan(), hip.PackPlan()
         self.mma = hip.F32        # matrix-core operand type of the dense contractions of the pass (hip.F32 | hip.BF16)
+        self.act_dtype = torch.float32   # storage of the activation tensors of the pass (bf16 needs mma = BF16)
         self.arena = None         # plan mode (LM_Net.enable_plans): bump arena all tensors of the pass come from
         self.planning = False     # a plan is being recorded: buffers come from the arena, no allocator stream bookkeeping
         self.alloc_floats = 0     # floats requested since begin_pass (sizes the arena during the eager warm-up steps)
 
-    def alloc(self, device, shape):
+    def pm(self):
+        """precision mode of the pass: 0 fp32, 1 bf16 MFMA operands on fp32 storage, 2 bf16 storage + bf16 operands."""
+        return 0 if self.mma == hip.F32 else (2 if self.act_dtype == torch.bfloat16 else 1)
+
+    def alloc(self, device, shape, dtype=torch.float32):
         n = 1
         for d in shape:
             n *= int(d)
-        self.alloc_floats += (n + 63) & ~63
+        self.alloc_floats += ((n if dtype == torch.float32 else (n + 1) // 2) + 63) & ~63
         if self.arena is not None:
-            return self.arena.alloc(shape)
-        return torch.empty(shape, device=device, dtype=torch.float32)
+            return self.arena.alloc(shape, dtype)
+        return torch.empty(shape, device=device, dtype=dtype)
 
     # ------------------------------------------------------------------ small helpers
     def begin_pass(self, backward, device):
@@ -305,7 +322,7 @@ class Engine:
             hip.conv_fwd([x], wpe, None, B=B, Hin=H, Win=W, Hout=H, Wout=W, Cout=E, bias=ec.bias, stats=sums1,
                          stats_mode=hip.STATS_SUM_SQ, stats_rep=STATS_REP, p=(None, None, None, None, ebn.running_mean))
         mean1, rstd1, A1, sh1 = self.bn_stats(ebn, sums1, N, x)
-        x1 = _E(x, B, H, W, E)
+        x1 = _A(x, B, H, W, E)
         hip.conv_fwd([x], wpe, x1, B=B, Hin=H, Win=W, Hout=H, Wout=W, Cout=E, bias=ec.bias, epilogue=hip.EP_AFFINE_ACT,
                      act=hip.ACT_HSWISH, p=(A1, sh1))
         # depthwise branches
@@ -328,7 +345,7 @@ class Engine:
                     bn = b.bn
                     hip.bn_fold(bn.running_mean, bn.running_var, bn.weight, bn.bias, bn.eps, bmean[i], brstd[i], bA[i], bshift[i])
                 hip.dw_merge(*ws, bA, bshift, keff, beff)
-        pre = _E(x, B, H, W, E)
+        pre = _A(x, B, H, W, E)
         gsum = _Z(x, B, E)
         hip.dw_fwd(x1, pre, gsum, keff, beff)
         se = m.se
@@ -338,7 +355,7 @@ class Engine:
         # pointwise(g*s) + shortcut(x): one conv over two sources
         wpw, wsc = m.pointwise_conv[0].weight, m.shortcut[0].weight
         wp3 = self._pack2(wpw, wsc, E, x.shape[-1], Cout, x)
-        y = _E(x, B, H, W, Cout) if out is None else out
+        y = _A(x, B, H, W, Cout) if out is None else out
         hip.conv_fwd([dict(view=pre, scale=sgate, flags=hip.SRC_GELU), x], wp3, y, B=B, Hin=H, Win=W, Hout=H, Wout=W,
                      Cout=Cout, bias=m.pointwise_conv[0].bias, bias2=m.shortcut[0].bias)
         if cx is not None:
@@ -382,12 +399,12 @@ class Engine:
             dWp = _Z(x, Cout, Cin)
             self.wgrad([x], dy, None, None, Hin=H, Win=W, dW=dWp, db=G[sc.bias])
             hip.copy2d(dWp, G[sc.weight], Cout, cw, Cin, cw)      # un-pad (layout copy)
-        u = _E(x, B, H, W, E)
+        u = _A(x, B, H, W, E)
         ds = _Z(x, B, E)
         self.conv_T(dy, pw.weight, u, Hin=H, Win=W, epilogue=hip.EP_SE_BWD, aux=pre, stats=ds, stats_mode=hip.STATS_EP)
         dx_sc = None
         if need_dx:
-            dx_sc = _E(x, B, H, W, Cin)
+            dx_sc = _A(x, B, H, W, Cin)
             self.conv_T(dy, sc.weight, dx_sc, Hin=H, Win=W, rows=Cin)
         # ---- SE backward
         dm = _E(x, B, E)
@@ -396,7 +413,7 @@ class Engine:
         # ---- A2 backward
         brs = m.branches()
         ws = [b.conv.weight for b in brs]
-        dpre = _E(x, B, H, W, E)
+        dpre = _A(x, B, H, W, E)
         bst = _Z(x, 5, E)
         hip.dw_bwd_stats(x1, pre, u, sgate, dm, dpre, *ws, bst)
         cA, cC, cD = (_E(x, 4, E) for _ in range(3))
@@ -424,7 +441,7 @@ class Engine:
             hip.copy2d(dWp, G[ec.weight], E, cw, Cin, cw)         # un-pad (layout copy)
         if not need_dx:
             return None
-        dx = _E(x, B, H, W, Cin)
+        dx = _A(x, B, H, W, Cin)
         self.conv_T(dz, ec.weight, dx, Hin=H, Win=W, rows=Cin, residual=dx_sc)
         return dx
 
@@ -465,7 +482,7 @@ class Engine:
             xl, xsm = xs_in
             B, H, W, _ = xl.shape
         nb = 3 if three else 2
-        cat = _E(xl, B, H, W, nb * C)
+        cat = _A(xl, B, H, W, nb * C)
         up = None
         self.conv3_fwd(m.convl[0], xl, V(cat, 0, C), s=2 if (three or bottom) else 1)
         if three:
@@ -473,16 +490,16 @@ class Engine:
         if bottom:
             self.conv3_fwd(m.convs[0], xsm, V(cat, C, C))
         else:
-            up = _E(xl, B, H, W, xsm.shape[-1])
+            up = _A(xl, B, H, W, xsm.shape[-1])
             hip.up2_fwd(xsm, up)
             self.conv3_fwd(m.convs[1], up, V(cat, (nb - 1) * C, C))
-        z = _E(xl, B, H, W, C)
+        z = _A(xl, B, H, W, C)
         sums = _Z(xl, 2, C) if self.training else None
         self.conv([cat], fconv.weight, fconv.bias, z, Hin=H, Win=W, k=3, stats=sums,
                   stats_mode=hip.STATS_SUM_SQ if self.training else hip.STATS_NONE,
                   p=(None, None, None, None, fbn.running_mean) if self.training else ())
         mean, rstd, A, shift = self.bn_stats(fbn, sums, B * H * W, xl)
-        y = _E(xl, B, H, W, C)
+        y = _A(xl, B, H, W, C)
         hip.bnact_fwd(z, A, shift, y, hip.ACT_GELU)
         if cx is not None:
             cx.t[m] = dict(xs=xs_in, cat=cat, up=up, z=z, mean=mean, rstd=rstd, A=A)
@@ -502,11 +519,11 @@ class Engine:
         hip.bnact_bwd_stats(z, dy, S["mean"], S["rstd"], fbn.weight, fbn.bias, st, hip.ACT_GELU)
         c1, c2, c3 = (_E(z, C) for _ in range(3))
         hip.bn_bwd_coef(st, B * H * W, S["A"], G[fbn.weight], G[fbn.bias], c1, c2, c3, self.training)
-        dz = _E(z, B, H, W, C)
+        dz = _A(z, B, H, W, C)
         hip.bnact_bwd(z, dy, S["mean"], S["rstd"], fbn.weight, fbn.bias, c1, c2, c3, dz, hip.ACT_GELU)
         self.wgrad([cat], dz, fconv.weight, fconv.bias, Hin=H, Win=W, k=3)
         nb = 3 if three else 2
-        dcat = _E(z, B, H, W, nb * C)
+        dcat = _A(z, B, H, W, nb * C)
         self.conv_T(dz, fconv.weight, dcat, Hin=H, Win=W, k=3)
         xl = xs_in[0]
         sl = 2 if (three or bottom) else 1
@@ -517,14 +534,14 @@ class Engine:
         if bottom:
             self._acc_conv(m.convs[0], xsm, V(dcat, C, C), 1, gacc)
         else:
-            dup = _E(z, *up.shape)
+            dup = _A(z, *up.shape)
             self.conv3_bwd(m.convs[1], up, V(dcat, (nb - 1) * C, C), dx=dup)
             slot = gacc[id(xsm)]
             if slot.g is None:
-                slot.g = _E(z, *xsm.shape)
+                slot.g = _A(z, *xsm.shape)
                 hip.up2_bwd(dup, slot.g)
             else:
-                tmp = _E(z, *xsm.shape)
+                tmp = _A(z, *xsm.shape)
                 hip.up2_bwd(dup, tmp)
                 hip.add(slot.g, tmp)
 
@@ -532,7 +549,7 @@ class Engine:
         slot = gacc[id(x)]
         first = slot.g is None
         if first:
-            slot.g = _E(x, *x.shape)
+            slot.g = _A(x, *x.shape)
         self.conv3_bwd(conv, x, dy, s=s, dx=slot.g, accumulate=not first)
 
     # ------------------------------------------------------------------ transformer pieces (A6, A7, A8)
@@ -542,7 +559,7 @@ class Engine:
         Cn, Ch = mlp.fc1.weight.shape[1], mlp.fc1.weight.shape[0]
         n2f, yf, af = n2.view(1, 1, -1, Cn), y.view(1, 1, -1, Cn), a_res.view(1, 1, -1, Cn)
         npx = n2f.shape[2]
-        a1 = _E(n2, 1, 1, npx, Ch)
+        a1 = _A(n2, 1, 1, npx, Ch)
         p = mlp.dropout.p if self.training else 0.0
         s1, s2 = self._seed(tagbase), self._seed(tagbase + 1)
         self.conv([n2f], mlp.fc1.weight, mlp.fc1.bias, a1, Hin=1, Win=npx)
@@ -560,11 +577,11 @@ class Engine:
         dflag = hip.SRC_DROP if p > 0 else 0
         hsrc = dict(view=a1, flags=hip.SRC_GELU | dflag, drop_seed=s1, drop_p=p)
         self.wgrad([hsrc], dyf, mlp.fc2.weight, mlp.fc2.bias, Hin=1, Win=npx, dy_flags=dflag, dy_seed=s2, dy_p=p)
-        da1 = _E(n2, 1, 1, npx, Ch)
+        da1 = _A(n2, 1, 1, npx, Ch)
         self.conv_T(dict(view=dyf, flags=dflag, drop_seed=s2, drop_p=p), mlp.fc2.weight, da1, Hin=1, Win=npx,
                     epilogue=hip.EP_DGELU, aux=a1, drop_p=p, drop_seed=s1)
         self.wgrad([n2f], da1, mlp.fc1.weight, mlp.fc1.bias, Hin=1, Win=npx)
-        dn2 = _E(n2, 1, 1, npx, Cn)
+        dn2 = _A(n2, 1, 1, npx, Cn)
         self.conv_T(da1, mlp.fc1.weight, dn2, Hin=1, Win=npx)
         return dn2.view(n2.shape)
 
@@ -583,19 +600,19 @@ class Engine:
     def nat_fwd(self, m, x, cx, tag):
         B, H, W, C = x.shape
         heads = m.att1.num_heads
-        e = _E(x, B, H, W, C)
+        e = _A(x, B, H, W, C)
         self.conv3_fwd(m.patchembedding.patch_embeddings, x, e)
-        n1 = _E(x, B, H, W, C)
+        n1 = _A(x, B, H, W, C)
         hip.ln_fwd(e, m.norm1.weight, m.norm1.bias, n1)
-        qkv = _E(x, B, H, W, 3 * C)
+        qkv = _A(x, B, H, W, 3 * C)
         self._lin(m.att1.qkv, n1, qkv)
-        o = _E(x, B, H, W, C)
+        o = _A(x, B, H, W, C)
         hip.na_fwd(qkv, m.att1.rpb, o, heads)
-        a = _E(x, B, H, W, C)
+        a = _A(x, B, H, W, C)
         self._lin(m.att1.proj, o, a, residual=e.view(1, 1, -1, C))
-        n2 = _E(x, B, H, W, C)
+        n2 = _A(x, B, H, W, C)
         hip.ln_fwd(a, m.norm2.weight, m.norm2.bias, n2)
-        y = _E(x, B, H, W, C)
+        y = _A(x, B, H, W, C)
         a1, drop = self._mlp_fwd(m.mlp, n2, a, y, tag)
         if cx is not None:
             cx.t[m] = dict(x=x, e=e, n1=n1, qkv=qkv, o=o, a=a, n2=n2, a1=a1, drop=drop)
@@ -607,17 +624,17 @@ class Engine:
         B, H, W, C = x.shape
         G = self.G
         dn2 = self._mlp_bwd(m.mlp, n2, S["a1"], dy, S["drop"])
-        da = _E(x, B, H, W, C)
+        da = _A(x, B, H, W, C)
         hip.ln_bwd(a, m.norm2.weight, dn2, dy, da, G[m.norm2.weight], G[m.norm2.bias])
-        do = _E(x, B, H, W, C)
+        do = _A(x, B, H, W, C)
         self._lin_bwd(m.att1.proj, o, da, do)
-        dqkv = _E(x, B, H, W, 3 * C)
+        dqkv = _A(x, B, H, W, 3 * C)
         hip.na_bwd(qkv, m.att1.rpb, do, dqkv, G[m.att1.rpb], m.att1.num_heads)
         dn1 = do
         self._lin_bwd(m.att1.qkv, n1, dqkv, dn1)
-        de = _E(x, B, H, W, C)
+        de = _A(x, B, H, W, C)
         hip.ln_bwd(e, m.norm1.weight, dn1, da, de, G[m.norm1.weight], G[m.norm1.bias])
-        dx = _E(x, B, H, W, C)
+        dx = _A(x, B, H, W, C)
         self.conv3_bwd(m.patchembedding.patch_embeddings, x, de, dx=dx)
         return dx
 
@@ -625,23 +642,23 @@ class Engine:
         B, h, w, C = catp.shape
         N = h * w
         heads = m.attention.num_heads
-        e = _E(catp, B, h, w, C)
+        e = _A(catp, B, h, w, C)
         self.conv3_fwd(m.patchembedding.patch_embeddings, catp, e)
-        n1 = _E(catp, B, N, C)
+        n1 = _A(catp, B, N, C)
         hip.ln_fwd(e, m.norm1.weight, m.norm1.bias, n1)
-        qkv = _E(catp, B, N, 3 * C)
+        qkv = _A(catp, B, N, 3 * C)
         self._lin(m.attention.qkv, n1, qkv)
-        o = _E(catp, B, N, C)
+        o = _A(catp, B, N, C)
         lse = _E(catp, B, heads, N)
         hip.gattn_fwd(qkv, o, lse, heads)
-        a = _E(catp, B, N, C)
+        a = _A(catp, B, N, C)
         self._lin(m.attention.proj, o, a, residual=e.view(1, 1, -1, C))
-        n2 = _E(catp, B, N, C)
+        n2 = _A(catp, B, N, C)
         hip.ln_fwd(a, m.norm2.weight, m.norm2.bias, n2)
-        y = _E(catp, B, N, C)
+        y = _A(catp, B, N, C)
         a1, drop = self._mlp_fwd(m.mlp, n2, a, y, tag)
         cv = m.conv[0]
-        x5 = _E(catp, B, h, w, cv.weight.shape[0])
+        x5 = _A(catp, B, h, w, cv.weight.shape[0])
         self._lin(cv, y, x5)
         if cx is not None:
             cx.t[m] = dict(catp=catp, e=e, n1=n1, qkv=qkv, o=o, lse=lse, a=a, n2=n2, a1=a1, drop=drop, y=y)
@@ -654,21 +671,21 @@ class Engine:
         N = h * w
         G = self.G
         heads = m.attention.num_heads
-        dy = _E(catp, B, N, C)
+        dy = _A(catp, B, N, C)
         self._lin_bwd(m.conv[0], y, dx5, dy)
         dn2 = self._mlp_bwd(m.mlp, n2, S["a1"], dy, S["drop"])
-        da = _E(catp, B, N, C)
+        da = _A(catp, B, N, C)
         hip.ln_bwd(a, m.norm2.weight, dn2, dy, da, G[m.norm2.weight], G[m.norm2.bias])
-        do = _E(catp, B, N, C)
+        do = _A(catp, B, N, C)
         self._lin_bwd(m.attention.proj, o, da, do)
-        dqkv = _E(catp, B, N, 3 * C)
+        dqkv = _A(catp, B, N, 3 * C)
         delta = _E(catp, B, heads, N)
         hip.gattn_bwd(qkv, o, do, S["lse"], dqkv, delta, heads)
         dn1 = do
         self._lin_bwd(m.attention.qkv, n1, dqkv, dn1)
-        de = _E(catp, B, h, w, C)
+        de = _A(catp, B, h, w, C)
         hip.ln_bwd(e, m.norm1.weight, dn1, da, de, G[m.norm1.weight], G[m.norm1.bias])
-        dcat = _E(catp, B, h, w, C)
+        dcat = _A(catp, B, h, w, C)
         self.conv3_bwd(m.patchembedding.patch_embeddings, catp, de, dx=dcat)
         return dcat
 
@@ -677,9 +694,9 @@ class Engine:
         """conv3x3(bilinear_x2(x)) + skip"""
         B, h, w, C = x.shape
         conv = seq[1]
-        up = _E(x, B, 2 * h, 2 * w, C)
+        up = _A(x, B, 2 * h, 2 * w, C)
         hip.up2_fwd(x, up)
-        out = _E(x, B, 2 * h, 2 * w, conv.weight.shape[0])
+        out = _A(x, B, 2 * h, 2 * w, conv.weight.shape[0])
         self.conv3_fwd(conv, up, out, residual=skip)
         if cx is not None:
             cx.t[seq] = dict(up=up)
@@ -687,9 +704,9 @@ class Engine:
 
     def up_bwd(self, seq, dt, cx, xshape):
         up = cx.t[seq]["up"]
-        dup = _E(dt, *up.shape)
+        dup = _A(dt, *up.shape)
         self.conv3_bwd(seq[1], up, dt, dx=dup)
-        dx = _E(dt, *xshape)
+        dx = _A(dt, *xshape)
         hip.up2_bwd(dup, dx)
         return dx
 

@@ -19,7 +19,7 @@ ACT_NONE, ACT_HSWISH, ACT_GELU = 0, 1, 2
 STATS_NONE, STATS_SUM_SQ, STATS_EP = 0, 1, 2
 F32, BF16 = 0, 1            # matrix-core operand type of the dense contractions (LMN_F32 / LMN_BF16)
 _MMA = [F32]                # ... of the pass in flight (engine.begin_pass)
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 
 class SrcT(C.Structure):
@@ -36,7 +36,7 @@ class ConvArgs(C.Structure):
                 ("aux_cstride", C.c_int32), ("res_cstride", C.c_int32), ("out_cstride", C.c_int32),
                 ("epilogue", C.c_int32), ("act", C.c_int32), ("stats_mode", C.c_int32),
                 ("drop_p", C.c_float), ("drop_seed", C.c_uint32), ("seed_ctr", C.c_void_p), ("bias2", C.c_void_p),
-                ("stats_rep", C.c_int32), ("mma_dtype", C.c_int32)]
+                ("stats_rep", C.c_int32), ("mma_dtype", C.c_int32), ("act_dtype", C.c_int32), ("_pad1", C.c_int32)]
 
 
 class WgradArgs(C.Structure):
@@ -45,7 +45,7 @@ class WgradArgs(C.Structure):
                 ("src", SrcT * 3), ("dy", C.c_void_p), ("dy_cstride", C.c_int32), ("dy_flags", C.c_int32),
                 ("dy_seed", C.c_uint32), ("dy_p", C.c_float), ("dW", C.c_void_p), ("db", C.c_void_p),
                 ("workspace", C.c_void_p), ("workspace_floats", C.c_int64), ("seed_ctr", C.c_void_p),
-                ("dW_src", C.c_void_p * 3), ("db2", C.c_void_p), ("mma_dtype", C.c_int32), ("_pad", C.c_int32)]
+                ("dW_src", C.c_void_p * 3), ("db2", C.c_void_p), ("mma_dtype", C.c_int32), ("act_dtype", C.c_int32)]
 
 
 # every symbol include/lmnet_hip.h declares (the CPU test suite checks the library exports all of them)
@@ -99,6 +99,7 @@ def _check(rc, what):
 
 
 def _p(t):
+    """fp32 device pointer (parameters, statistics, workspaces, fp32 boundary tensors)."""
     if t is None:
         return None
     if not t.is_cuda:
@@ -106,6 +107,31 @@ def _p(t):
     if t.dtype != torch.float32:
         raise RuntimeError("lm_net_amd: fp32 tensor required, got %s" % t.dtype)
     return C.c_void_p(t.data_ptr())
+
+
+def _pa(t):
+    """activation pointer: fp32 or bf16 storage (the call's act_dtype says which, see _dt)."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError("lm_net_amd: device tensor required (got a CPU tensor); the HIP path has no CPU fallback")
+    if t.dtype not in (torch.float32, torch.bfloat16):
+        raise RuntimeError("lm_net_amd: fp32 or bf16 activation tensor required, got %s" % t.dtype)
+    return C.c_void_p(t.data_ptr())
+
+
+def _dt(*ts):
+    """act_dtype of a call: the storage type shared by all of its activation tensors."""
+    d = None
+    for t in ts:
+        if t is None:
+            continue
+        t = t.t if isinstance(t, V) else t
+        if d is None:
+            d = t.dtype
+        elif t.dtype != d:
+            raise RuntimeError("lm_net_amd: activation tensors of one call must share a storage type (%s vs %s)" % (d, t.dtype))
+    return BF16 if d == torch.bfloat16 else F32
 
 
 _ALLOC = [None]    # allocator of the pass in flight (engine.begin_pass): fn(device, shape) -> fp32 tensor
@@ -142,9 +168,9 @@ class V:
 
     @property
     def ptr(self):
-        if not self.t.is_cuda or self.t.dtype != torch.float32:
-            raise RuntimeError("lm_net_amd: fp32 device tensor required")
-        return self.t.data_ptr() + 4 * self.off
+        if not self.t.is_cuda or self.t.dtype not in (torch.float32, torch.bfloat16):
+            raise RuntimeError("lm_net_amd: fp32 or bf16 device tensor required")
+        return self.t.data_ptr() + self.t.element_size() * self.off
 
     @property
     def cstride(self):
@@ -325,6 +351,7 @@ def conv_fwd(srcs, wpack, out, *, B, Hin, Win, Hout, Wout, Cout, ksize=1, stride
     a.epilogue, a.act, a.stats_mode = epilogue, act, stats_mode
     a.drop_p, a.drop_seed = drop_p, drop_seed
     a.mma_dtype = _MMA[0]
+    a.act_dtype = _dt(*[(s["view"] if isinstance(s, dict) else s) for s in srcs], aux, residual, out)
     a.seed_ctr = _SEED_CTR[0].data_ptr() if _SEED_CTR[0] is not None else None
     _check(load().lmn_conv_fwd(C.byref(a), _stream()), "conv_fwd")
 
@@ -344,6 +371,7 @@ def conv_wgrad(srcs, dy, dW, db, *, B, Hin, Win, Hout, Wout, Cout, ksize=1, stri
     a.db = db.data_ptr() if db is not None else None
     a.db2 = db2.data_ptr() if db2 is not None else None
     a.mma_dtype = _MMA[0]
+    a.act_dtype = _dt(*[(s["view"] if isinstance(s, dict) else s) for s in srcs], dy)
     if dW_src is not None:
         for i, t in enumerate(dW_src):
             a.dW_src[i] = t.data_ptr() if t is not None else None
@@ -373,7 +401,7 @@ def _workspace(device, nfloats):
 # ------------------------------------------------------------------------------------------ depthwise block
 def dw_stats(x1, w5, w3, wv, wh, stats):
     B, H, W, E = x1.shape
-    _check(load().lmn_dw_stats(_p(x1), B, H, W, E, _p(w5), _p(w3), _p(wv), _p(wh), _p(stats), _stream()), "dw_stats")
+    _check(load().lmn_dw_stats(_pa(x1), B, H, W, E, _p(w5), _p(w3), _p(wv), _p(wh), _p(stats), _dt(x1), _stream()), "dw_stats")
 
 
 def dw_merge(w5, w3, wv, wh, A, shift, keff, beff):
@@ -383,7 +411,7 @@ def dw_merge(w5, w3, wv, wh, A, shift, keff, beff):
 
 def dw_fwd(x1, pre, gsum, keff, beff):
     B, H, W, E = x1.shape
-    _check(load().lmn_dw_fwd(_p(x1), _p(pre), _p(gsum), B, H, W, E, _p(keff), _p(beff), _stream()), "dw_fwd")
+    _check(load().lmn_dw_fwd(_pa(x1), _pa(pre), _p(gsum), B, H, W, E, _p(keff), _p(beff), _dt(x1, pre), _stream()), "dw_fwd")
 
 
 def dw_finalize_merge(stats, count, bns, ws, mean, rstd, A, keff, beff):
@@ -401,8 +429,8 @@ def dw_finalize_merge(stats, count, bns, ws, mean, rstd, A, keff, beff):
 
 def dw_bwd_stats(x1, pre, u, s, dm, dpre, w5, w3, wv, wh, bstats):
     B, H, W, E = x1.shape
-    _check(load().lmn_dw_bwd_stats(_p(x1), _p(pre), _p(u), _p(s), _p(dm), _p(dpre), B, H, W, E, _p(w5), _p(w3), _p(wv),
-                                   _p(wh), _p(bstats), _stream()), "dw_bwd_stats")
+    _check(load().lmn_dw_bwd_stats(_pa(x1), _pa(pre), _pa(u), _p(s), _p(dm), _pa(dpre), B, H, W, E, _p(w5), _p(w3), _p(wv),
+                                   _p(wh), _p(bstats), _dt(x1, pre, u, dpre), _stream()), "dw_bwd_stats")
 
 
 def dw_bwd_coef(bstats, mean, rstd, A, count, batch_stats, cA, cC, cD, dgs, dbs):
@@ -413,8 +441,8 @@ def dw_bwd_coef(bstats, mean, rstd, A, count, batch_stats, cA, cC, cD, dgs, dbs)
 
 def dw_bwd(x1, dpre, dx1, w5, w3, wv, wh, cA, cC, cD, dw5, dw3, dwv, dwh):
     B, H, W, E = x1.shape
-    _check(load().lmn_dw_bwd(_p(x1), _p(dpre), _p(dx1), B, H, W, E, _p(w5), _p(w3), _p(wv), _p(wh), _p(cA), _p(cC),
-                             _p(cD), _p(dw5), _p(dw3), _p(dwv), _p(dwh), _stream()), "dw_bwd")
+    _check(load().lmn_dw_bwd(_pa(x1), _pa(dpre), _pa(dx1), B, H, W, E, _p(w5), _p(w3), _p(wv), _p(wh), _p(cA), _p(cC),
+                             _p(cD), _p(dw5), _p(dw3), _p(dwv), _p(dwh), _dt(x1, dpre, dx1), _stream()), "dw_bwd")
 
 
 def se_fwd(gsum, inv_hw, w1, b1, w2, b2, s, hidden):
@@ -433,7 +461,7 @@ def se_bwd(ds, gsum, inv_hw, w1, b1, w2, b2, hidden, dm, dw1, db1, dw2, db2):
 def na_fwd(qkv, rpb, out, heads):
     B, H, W, C3 = qkv.shape
     hd = C3 // 3 // heads
-    _check(load().lmn_na_fwd(_p(qkv), _p(rpb), _p(out), B, H, W, heads, hd, _f(hd ** -0.5), _stream()), "na_fwd")
+    _check(load().lmn_na_fwd(_pa(qkv), _p(rpb), _pa(out), B, H, W, heads, hd, _f(hd ** -0.5), _dt(qkv, out), _stream()), "na_fwd")
 
 
 def na_bwd(qkv, rpb, dout, dqkv, drpb, heads, stat=None):
@@ -441,50 +469,50 @@ def na_bwd(qkv, rpb, dout, dqkv, drpb, heads, stat=None):
     hd = C3 // 3 // heads
     if stat is None:
         stat = (_ALLOC[0] or _default_alloc)(qkv.device, (B * H * W * 2 * heads,))
-    _check(load().lmn_na_bwd(_p(qkv), _p(rpb), _p(dout), _p(dqkv), _p(drpb), _p(stat), B, H, W, heads, hd,
-                             _f(hd ** -0.5), _stream()), "na_bwd")
+    _check(load().lmn_na_bwd(_pa(qkv), _p(rpb), _pa(dout), _pa(dqkv), _p(drpb), _p(stat), B, H, W, heads, hd,
+                             _f(hd ** -0.5), _dt(qkv, dout, dqkv), _stream()), "na_bwd")
 
 
 def gattn_fwd(qkv, out, lse, heads):
     B, N, C3 = qkv.shape
     hd = C3 // 3 // heads
-    _check(load().lmn_gattn_fwd(_p(qkv), _p(out), _p(lse), B, N, heads, hd, _f(hd ** -0.5), _stream()), "gattn_fwd")
+    _check(load().lmn_gattn_fwd(_pa(qkv), _pa(out), _p(lse), B, N, heads, hd, _f(hd ** -0.5), _dt(qkv, out), _stream()), "gattn_fwd")
 
 
 def gattn_bwd(qkv, out, dout, lse, dqkv, delta, heads):
     B, N, C3 = qkv.shape
     hd = C3 // 3 // heads
-    _check(load().lmn_gattn_bwd(_p(qkv), _p(out), _p(dout), _p(lse), _p(dqkv), _p(delta), B, N, heads, hd,
-                                _f(hd ** -0.5), _stream()), "gattn_bwd")
+    _check(load().lmn_gattn_bwd(_pa(qkv), _pa(out), _pa(dout), _p(lse), _pa(dqkv), _p(delta), B, N, heads, hd,
+                                _f(hd ** -0.5), _dt(qkv, out, dout, dqkv), _stream()), "gattn_bwd")
 
 
 # ------------------------------------------------------------------------------------------ norms
 def ln_fwd(x, gamma, beta, y):
     Cn = x.shape[-1]
-    _check(load().lmn_ln_fwd(_p(x), _p(gamma), _p(beta), _p(y), _i64(x.numel() // Cn), Cn, _stream()), "ln_fwd")
+    _check(load().lmn_ln_fwd(_pa(x), _p(gamma), _p(beta), _pa(y), _i64(x.numel() // Cn), Cn, _dt(x, y), _stream()), "ln_fwd")
 
 
 def ln_bwd(x, gamma, dy, dres, dx, dgamma, dbeta):
     Cn = x.shape[-1]
-    _check(load().lmn_ln_bwd(_p(x), _p(gamma), _p(dy), _p(dres), _p(dx), _p(dgamma), _p(dbeta), _i64(x.numel() // Cn),
-                             Cn, _stream()), "ln_bwd")
+    _check(load().lmn_ln_bwd(_pa(x), _p(gamma), _pa(dy), _pa(dres), _pa(dx), _p(dgamma), _p(dbeta), _i64(x.numel() // Cn),
+                             Cn, _dt(x, dy, dres, dx), _stream()), "ln_bwd")
 
 
 def bnact_fwd(z, a, b, y, act):
     Cn = z.shape[-1]
-    _check(load().lmn_bnact_fwd(_p(z), _p(a), _p(b), _p(y), _i64(z.numel() // Cn), Cn, act, _stream()), "bnact_fwd")
+    _check(load().lmn_bnact_fwd(_pa(z), _p(a), _p(b), _pa(y), _i64(z.numel() // Cn), Cn, act, _dt(z, y), _stream()), "bnact_fwd")
 
 
 def bnact_bwd_stats(z, dy, mean, rstd, gamma, beta, stats, act):
     Cn = z.shape[-1]
-    _check(load().lmn_bnact_bwd_stats(_p(z), _p(dy), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(stats),
-                                      _i64(z.numel() // Cn), Cn, act, _stream()), "bnact_bwd_stats")
+    _check(load().lmn_bnact_bwd_stats(_pa(z), _pa(dy), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(stats),
+                                      _i64(z.numel() // Cn), Cn, act, _dt(z, dy), _stream()), "bnact_bwd_stats")
 
 
 def bnact_bwd(z, dy, mean, rstd, gamma, beta, c1, c2, c3, dz, act):
     Cn = z.shape[-1]
-    _check(load().lmn_bnact_bwd(_p(z), _p(dy), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(c1), _p(c2), _p(c3), _p(dz),
-                                _i64(z.numel() // Cn), Cn, act, _stream()), "bnact_bwd")
+    _check(load().lmn_bnact_bwd(_pa(z), _pa(dy), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(c1), _p(c2), _p(c3), _pa(dz),
+                                _i64(z.numel() // Cn), Cn, act, _dt(z, dy, dz), _stream()), "bnact_bwd")
 
 
 def bn_finalize(sums, count, gamma, beta, eps, momentum, mean, rstd, A, shift, running_mean, running_var, about=None):
@@ -510,39 +538,39 @@ def bn_bwd_coef(bstats, count, A, dgamma, dbeta, c1, c2, c3, batch_stats=True):
 def up2_fwd(x, y):
     x, y = _as_view(x), _as_view(y)
     B, Hin, Win = x.t.shape[:3]
-    _check(load().lmn_up2_fwd(C.c_void_p(x.ptr), C.c_void_p(y.ptr), B, Hin, Win, x.C, x.cstride, y.cstride, _stream()),
-           "up2_fwd")
+    _check(load().lmn_up2_fwd(C.c_void_p(x.ptr), C.c_void_p(y.ptr), B, Hin, Win, x.C, x.cstride, y.cstride, _dt(x, y),
+                              _stream()), "up2_fwd")
 
 
 def up2_bwd(dy, dx):
     dy, dx = _as_view(dy), _as_view(dx)
     B, Hin, Win = dx.t.shape[:3]
     _check(load().lmn_up2_bwd(C.c_void_p(dy.ptr), C.c_void_p(dx.ptr), B, Hin, Win, dx.C, dy.cstride, dx.cstride,
-                              _stream()), "up2_bwd")
+                              _dt(dy, dx), _stream()), "up2_bwd")
 
 
 def avgpool_fwd(x, y, f):
     x, y = _as_view(x), _as_view(y)
     B, Hout, Wout = y.t.shape[:3]
     _check(load().lmn_avgpool_fwd(C.c_void_p(x.ptr), C.c_void_p(y.ptr), B, Hout, Wout, f, x.C, x.cstride, y.cstride,
-                                  _stream()), "avgpool_fwd")
+                                  _dt(x, y), _stream()), "avgpool_fwd")
 
 
 def avgpool_bwd(dy, dx, f, accumulate):
     dy, dx = _as_view(dy), _as_view(dx)
     B, Hout, Wout = dy.t.shape[:3]
     _check(load().lmn_avgpool_bwd(C.c_void_p(dy.ptr), C.c_void_p(dx.ptr), B, Hout, Wout, f, dx.C, dy.cstride,
-                                  dx.cstride, int(accumulate), _stream()), "avgpool_bwd")
+                                  dx.cstride, int(accumulate), _dt(dy, dx), _stream()), "avgpool_bwd")
 
 
 def nchw_to_nhwc(x, y):
     B, Cn, H, W = x.shape
-    _check(load().lmn_nchw_to_nhwc(_p(x), _p(y), B, Cn, H, W, y.shape[-1], _stream()), "nchw_to_nhwc")
+    _check(load().lmn_nchw_to_nhwc(_p(x), _pa(y), B, Cn, H, W, y.shape[-1], _dt(y), _stream()), "nchw_to_nhwc")
 
 
 def nhwc_to_nchw(x, y):
     B, Cn, H, W = y.shape
-    _check(load().lmn_nhwc_to_nchw(_p(x), _p(y), B, Cn, H, W, x.shape[-1], _stream()), "nhwc_to_nchw")
+    _check(load().lmn_nhwc_to_nchw(_pa(x), _p(y), B, Cn, H, W, x.shape[-1], _dt(x), _stream()), "nhwc_to_nchw")
 
 
 def _pl(t):
@@ -601,21 +629,21 @@ def fill(t, v):
 
 def add(a, b, c=None, d=None, out=None):
     out = a if out is None else out
-    _check(load().lmn_add(_p(a), _p(b), _p(c), _p(d), _p(out), _i64(a.numel()), _stream()), "add")
+    _check(load().lmn_add(_pa(a), _pa(b), _pa(c), _pa(d), _pa(out), _i64(a.numel()), _dt(a, b, c, d, out), _stream()), "add")
     return out
 
 
 def colsum(x, out):
     x = _as_view(x)
     rows = x.t.numel() // x.cstride
-    _check(load().lmn_colsum(C.c_void_p(x.ptr), _p(out), _i64(rows), x.C, x.cstride, _stream()), "colsum")
+    _check(load().lmn_colsum(C.c_void_p(x.ptr), _p(out), _i64(rows), x.C, x.cstride, _dt(x), _stream()), "colsum")
 
 
 def copy_slice(x, y):
     x, y = _as_view(x), _as_view(y)
     rows = x.t.numel() // x.cstride
-    _check(load().lmn_copy_slice(C.c_void_p(x.ptr), C.c_void_p(y.ptr), _i64(rows), x.C, x.cstride, y.cstride, _stream()),
-           "copy_slice")
+    _check(load().lmn_copy_slice(C.c_void_p(x.ptr), C.c_void_p(y.ptr), _i64(rows), x.C, x.cstride, y.cstride, _dt(x, y),
+                                 _stream()), "copy_slice")
 
 
 def copy2d(x, y, rows, cols, x_stride, y_stride):

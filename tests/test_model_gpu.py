@@ -434,63 +434,74 @@ def test_plan_mode_matches_host_launches():
     assert float((outs[3] - outs[4]).abs().max()) > 1e-3
 
 
-def test_bf16_mixed_precision_path():
-    """BASELINE configs[2] arithmetic (row X1): every dense contraction (conv / linear forward, data gradient, weight
-    gradient) on v_mfma_f32_16x16x16_bf16 with operands rounded to bf16 when staged, fp32 accumulators, epilogues,
-    BatchNorm / LayerNorm / softmax statistics and master weights.  Selected by `compute_dtype = "bf16"` or by running the
-    module under torch.autocast (the reference's AMP branch, utils/train_eval_utils.py:130-138).
+@pytest.mark.parametrize("mode", ["bf16", "bf16-mma"])
+def test_bf16_mixed_precision_path(mode):
+    """BASELINE configs[2] arithmetic (row X1).  mode "bf16": every activation tensor STORED as bf16 (half the HBM bytes of
+    every row) and every dense contraction (conv / linear forward, data gradient, weight gradient) on
+    v_mfma_f32_16x16x16_bf16; accumulators, epilogues, BatchNorm / LayerNorm / softmax statistics, master weights and
+    weight gradients stay fp32.  mode "bf16-mma": fp32 storage, bf16 matrix-core operands only.  "bf16" is what running
+    the module under torch.autocast selects (the reference's AMP branch, utils/train_eval_utils.py:130-138).
     Stated bf16 tolerances against the fp32 goldens of the REAL reference = 2x the measured distances
-    (tools/gpu_bf16_probe.py: logits 1.7e-2 of their range / 7e-3 in L2; input gradient 4.6e-2 in L2; parameter gradients
-    4.6e-2 median, 0.16 worst in L2 -- the BatchNorm gammas of the expand convs, sums of dh*zhat with heavy cancellation;
-    running statistics 4e-3; Dice / IoU of the 352x352 fixture +6e-4 / +4e-4: 31 of 123,904 argmax decisions flip, so
-    "identical to 4 decimals" holds for the fp32 path only)."""
+    (tools/gpu_bf16_probe.py, "bf16" / "bf16-mma": logits 2.0e-2 / 1.7e-2 of their range, 8.0e-3 / 6.9e-3 in L2; input
+    gradient 4.9e-2 / 4.6e-2 in L2; parameter gradients 4.9e-2 / 4.4e-2 median, 0.19 / 0.16 worst in L2 -- the BatchNorm
+    gammas of the expand convs, sums of dh*zhat with heavy cancellation; running statistics 4e-3; Dice / IoU of the 352x352
+    fixture +8e-4 / +5e-4: ~30 of 123,904 argmax decisions flip, so "identical to 4 decimals" holds for fp32 only)."""
     def l2(a, b):
         a, b = torch.as_tensor(a).detach().double().cpu(), torch.as_tensor(b).detach().double().cpu()
         return float((a - b).norm() / (b.norm() + 1e-30))
 
     g = load_golden("default_64x96.npz")
     m = _net()
-    m.compute_dtype = "bf16"
+    m.compute_dtype = mode
     m.eval()
     x = det_input((2, 3, 64, 96), "d64/x").cuda()
     with torch.no_grad():
         y = m(x)
-    assert 2e-4 < rel_err(y, g["logits"]) < 4e-2 and l2(y, g["logits"]) < 1.5e-2      # bf16 operands are really in use
-    m.compute_dtype = None                               # follow autocast
-    with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
-        ya = m(x)
-    with torch.no_grad():
-        yf = m(x)
-    # autocast selects the same path (float-atomic SE sums differ in the last bits between two runs, which flips a few
-    # bf16 roundings downstream: 2e-3, against the 1.7e-2 distance to the fp32 path) ...
-    assert float((ya - y).abs().max()) < 2e-3 * float(y.abs().max()) and rel_err(ya, g["logits"]) > 2e-4
-    assert rel_err(yf, g["logits"]) < TOL                                      # ... and outside of it the fp32 one
-    m.compute_dtype = "bf16"
+    assert y.dtype == torch.float32                      # logits leave the module as fp32 NCHW in every mode
+    assert 2e-4 < rel_err(y, g["logits"]) < 4e-2 and l2(y, g["logits"]) < 1.6e-2      # bf16 arithmetic is really in use
+    if mode == "bf16":
+        m.compute_dtype = None                           # follow autocast
+        with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+            ya = m(x)
+        with torch.no_grad():
+            yf = m(x)
+        # autocast selects the same path (float-atomic SE sums differ in the last bits between two runs, which flips a
+        # few bf16 roundings downstream: 4e-3, against the 2e-2 distance to the fp32 path) ...
+        assert float((ya - y).abs().max()) < 4e-3 * float(y.abs().max()) and rel_err(ya, g["logits"]) > 2e-4
+        assert rel_err(yf, g["logits"]) < TOL                                  # ... and outside of it the fp32 one
+        m.compute_dtype = mode
     m.train()
     xg = x.clone().requires_grad_(True)
     yt = m(xg)
-    assert rel_err(yt, g["train_logits"]) < 5e-2 and l2(yt, g["train_logits"]) < 2.5e-2
+    assert rel_err(yt, g["train_logits"]) < 5e-2 and l2(yt, g["train_logits"]) < 3e-2
     (yt * det_input(tuple(yt.shape), "d64/G").cuda()).sum().backward()
     assert l2(xg.grad, g["train_grad_input"]) < 0.1
     errs = []
     for k, p in m.named_parameters():
+        assert p.grad.dtype == torch.float32
         if is_pre_bn_bias(k) or "grad/" + k not in g:
             continue
         errs.append((l2(p.grad, g["grad/" + k]), k))
     errs.sort()
-    assert errs[len(errs) // 2][0] < 0.1 and errs[-1][0] < 0.35, (errs[len(errs) // 2], errs[-1])
+    assert errs[len(errs) // 2][0] < 0.1 and errs[-1][0] < 0.4, (errs[len(errs) // 2], errs[-1])
     for k, v in m.state_dict().items():
         if "running_" in k:
             assert rel_err(v, g["state/" + k]) < 1e-2, k
+    # stage activations are stored as bf16 in "bf16" mode
+    m.eval()
+    m._keep_taps = True
+    with torch.no_grad():
+        m(x)
+    assert m._taps["x1"].dtype == (torch.bfloat16 if mode == "bf16" else torch.float32)
     # Dice / IoU on the 352x352 fixture (BASELINE configs[0] shape)
     g3 = load_golden("default_352.npz")
     m = _net()                                           # (fresh BatchNorm running statistics)
-    m.compute_dtype = "bf16"
+    m.compute_dtype = mode
     m.eval()
     x3 = det_input((1, 3, 352, 352), "d352/x").cuda()
     with torch.no_grad():
         y3 = m(x3)
-    assert rel_err(y3, g3["logits"]) < 4e-2
+    assert rel_err(y3, g3["logits"]) < 5e-2
     pred = y3.argmax(1).cpu()
     dice, iou = dice_iou(pred, disc_labels(1, 352, 352))
     assert abs(dice - float(g3["dice"][0])) < 2e-3 and abs(iou - float(g3["iou"][0])) < 2e-3

@@ -14,7 +14,7 @@ def l2(a, b):
 
 g = load_golden("default_64x96.npz")
 m = LM_Net(3, 2); fill_module(m, 0); no_dropout(m); m = m.cuda()
-for mode in ("fp32", "bf16"):
+for mode in ("fp32", "bf16-mma", "bf16"):
     m.compute_dtype = mode
     m.eval()
     x = det_input((2, 3, 64, 96), "d64/x").cuda()
@@ -40,7 +40,7 @@ for mode in ("fp32", "bf16"):
         pass
     fill_module(m, 0); m = m.cuda()
 g3 = load_golden("default_352.npz")
-for mode in ("fp32", "bf16"):
+for mode in ("fp32", "bf16-mma", "bf16"):
     m.compute_dtype = mode
     m.eval()
     x3 = det_input((1, 3, 352, 352), "d352/x").cuda()
