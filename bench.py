@@ -181,9 +181,10 @@ def main():
     ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"],
                     help="arithmetic of the dense contractions: f32 (BASELINE configs[1], the headline) or bf16 matrix-core operands "
                          "with fp32 accumulation / statistics / master weights (BASELINE configs[2]; run with --batch 64)")
-    ap.add_argument("--plans", action="store_true",
-                    help="replay the step as recorded C-side schedules (LM_Net.enable_plans(): one lmn_plan_run per pass on the "
-                         "same four streams; host cost ~2 ms per step instead of 16-20)")
+    ap.add_argument("--plans", dest="plans", action="store_true", default=True,
+                    help="(default) replay the step as recorded C-side schedules (LM_Net.enable_plans(): one lmn_plan_run per "
+                         "pass on the same four streams; host cost ~2 ms per step instead of 16-20)")
+    ap.add_argument("--no-plans", dest="plans", action="store_false", help="launch every kernel from the host (Python)")
     ap.add_argument("--graphs", action="store_true",
                     help="replay the step as two hipGraphs (wins when the host is the bottleneck, e.g. batch 1; at batch 8 "
                          "the step is GPU-bound and host launches measured 7 %% faster than the replay)")
@@ -209,6 +210,8 @@ def main():
     net.compute_dtype = "bf16" if args.dtype == "bf16" else "fp32"
     model = DistributedLMNet(net) if world > 1 else net
     model.train()
+    if args.graphs:
+        args.plans = False
     if args.plans:
         net.enable_plans()      # forward / backward as one lmn_plan_run each (recorded on the 3rd step of the shape)
     if args.graphs:

@@ -17,7 +17,7 @@ def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, plans=False):
     try:
         os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
         dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -33,6 +33,12 @@ def _worker(rank, world, port, q):
                 m.p = 0.0
         x = det_input((2, 3, 32, 48), "ddp/x%d" % rank).cuda()   # rank-specific shard of the batch
         model = DistributedLMNet(net, bucket_bytes=64 << 10, first_bucket_bytes=16 << 10)       # ... replicated from rank 0 here
+        if plans:       # recorded C-side schedules: the reducer is fed between plan segments (LM_Net._plan_backward)
+            net.enable_plans()
+            for _ in range(4):      # 2 warm-up passes, the recording pass, one replay: the checks below run on replays
+                model(x).square().mean().backward()
+                net.zero_grad(set_to_none=True)
+            assert any(p.bwd is not None for p in net._plans.values()), "no plan was recorded"
         # local (un-reduced) gradients: run once with the hooks detached
         hooks = (net.grad_begin_hook, net.grad_ready_hook, net.grad_finish_hook)
         net.grad_begin_hook = net.grad_ready_hook = net.grad_finish_hook = None
@@ -61,11 +67,12 @@ def _worker(rank, world, port, q):
         q.put((rank, repr(e), None, None))
 
 
-def test_two_rank_training_step_on_one_gpu():
+@pytest.mark.parametrize("plans", [False, True])
+def test_two_rank_training_step_on_one_gpu(plans):
     world, port = 2, _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    ps = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    ps = [ctx.Process(target=_worker, args=(r, world, port, q, plans)) for r in range(world)]
     [p.start() for p in ps]
     res = [q.get(timeout=240) for _ in range(world)]
     [p.join(60) for p in ps]
