@@ -77,15 +77,19 @@ def _group(live, names):
     return tot
 
 
-def roofline_block(dominant, live, survey, tot_us, B, H, W, step_s):
+def roofline_block(dominant, live, survey, tot_us, B, H, W, step_s, alone):
     """`roofline` of the bench line: the kernel that takes the most GPU time (found by timing EVERY launch over two untimed
     steps), measured live with HIP events on its launch stream inside the timed region; algorithmic FLOPs / bytes from the
     layer shapes of each launch (SURVEY 8d convention).  Secondary entries: rows A2 / A7 (north_star's >= 70 % HBM targets)
     and the whole step against both rooflines."""
     rec = live.get(dominant) or survey[dominant]
-    red = dominant.replace("wgrad_lds_kernel", "wgrad_reduce_kernel").replace("wgrad_1x1_kernel", "wgrad_reduce_kernel")
+    red = dominant.replace("wgrad_lds_kernel", "wgrad_reduce_kernel").replace("wgrad_1x1_kernel<", "wgrad_reduce_kernel<1, ")
+    red = red.rsplit(",", 1)[0] + ">" if red != dominant else red        # (the reduce kernel has no precision-mode argument)
     r = _entry(dominant, rec)
     r["share_of_gpu_time"] = round(survey[dominant]["total_us"] / tot_us, 4)
+    if dominant in alone:
+        ea = _entry(dominant, alone[dominant])
+        r["achieved_alone"], r["frac_alone"], r["avg_us_alone"] = ea["achieved"], ea["frac"], ea["avg_us"]
     if red != dominant and red in live:
         r["frac_with_reduce_launches"] = _entry(dominant, rec, live[red]["total_us"])["frac"]
     r["traffic"] = pmc_traffic(dominant) if (B, H, W) == (8, 352, 352) else None
@@ -94,28 +98,49 @@ def roofline_block(dominant, live, survey, tot_us, B, H, W, step_s):
                          for k, v in sorted(survey.items(), key=lambda kv: -kv[1]["total_us"])[:5]]
     a2 = _group(live, ("dw_fwd_strip_kernel", "dw_bwd_strip_kernel", "dw_stats_strip_kernel"))
     a7 = _group(live, ("na_fwd_kernel", "na_bwd_q_kernel", "na_bwd_kv_kernel", "na_bwd_q_tile_kernel", "na_bwd_kv_tile_kernel"))
+    pm = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc.json"))).get("whole_step") if os.path.isfile(
+        os.path.join(ROOT, "profiles", "r02_pmc.json")) else None
     # row totals under the 8d convention: A2 train = 5*E*HW*B*4 (the statistics passes are extra passes, not extra bytes)
+    A2K = ("dw_fwd_strip_kernel", "dw_bwd_strip_kernel", "dw_stats_strip_kernel")
+    A7K = ("na_fwd_kernel", "na_bwd_q_kernel", "na_bwd_kv_kernel", "na_bwd_q_tile_kernel", "na_bwd_kv_tile_kernel")
+
+    def a2_bytes(d):   # 8d convention: A2 train = 5*E*HW*B*4 = the bytes of fwd + bwd (the statistics passes add time, not bytes)
+        return sum(v["bytes"] for k, v in d.items() if k.startswith(("dw_fwd", "dw_bwd")))
+
     if a2["total_us"] > 0:
-        a2b = sum(v["bytes"] for k, v in live.items() if k.startswith(("dw_fwd", "dw_bwd")))
-        e = _entry("row A2 (depthwise branches: fwd + 2 statistics passes + bwd)", dict(a2, bytes=a2b))
+        e = _entry("row A2 (depthwise branches: fwd + 2 statistics passes + bwd)", dict(a2, bytes=a2_bytes(live)))
         r["row_A2"] = {k: e[k] for k in ("kernel", "launches", "achieved", "peak", "unit", "frac")}
-        for k in ("dw_fwd_strip_kernel", "dw_bwd_strip_kernel"):
-            if k in live:
-                r["row_A2"][k] = {f: _entry(k, live[k])[f] for f in ("avg_us", "achieved", "frac")}
+        al = _group(alone, A2K)
+        if al["total_us"] > 0:
+            r["row_A2"]["frac_alone"] = _entry("", dict(al, bytes=a2_bytes(alone)))["frac"]
+        for k, v in live.items():
+            if k.startswith(("dw_fwd_strip_kernel", "dw_bwd_strip_kernel")):
+                r["row_A2"][k] = {f: _entry(k, v)[f] for f in ("avg_us", "achieved", "frac")}
+                if k in alone:
+                    r["row_A2"][k]["frac_alone"] = _entry(k, alone[k])["frac"]
     if a7["total_us"] > 0:
         e = _entry("row A7 (fused neighborhood attention: fwd + query pass + key pass)", a7)
         r["row_A7"] = {k: e[k] for k in ("kernel", "launches", "achieved", "peak", "unit", "frac")}
+        al = _group(alone, A7K)
+        if al["total_us"] > 0:
+            r["row_A7"]["frac_alone"] = _entry("", al)["frac"]
         for k, v in live.items():
             if k.startswith("na_fwd_kernel"):
                 r["row_A7"][k] = {f: _entry(k, v)[f] for f in ("avg_us", "achieved", "frac")}
+                if k in alone:
+                    r["row_A7"][k]["frac_alone"] = _entry(k, alone[k])["frac"]
     scale = (H * W) / (352.0 * 352.0)
     mb, gf = STEP_MB_352 * scale * B, STEP_GFLOP_352 * scale * B
     r["whole_step"] = {"algorithmic_MB": round(mb, 1), "algorithmic_GFLOP": round(gf, 1),
                        "hbm_GBps": round(mb / 1e3 / step_s, 1), "hbm_frac": round(mb / 1e3 / step_s / HBM_PEAK_GBS, 4),
                        "TFLOPs": round(gf / 1e3 / step_s, 2), "mfma_frac": round(gf / 1e3 / step_s / MFMA_F32_PEAK_TFLOPS, 4)}
+    if pm and (B, H, W) == (8, 352, 352):
+        r["whole_step"]["hbm_traffic_MB_pmc"] = pm["hbm_total_MB"]            # FETCH_SIZE x2 + WRITE_SIZE over one step
+        r["whole_step"]["mfma_busy_ms_per_simd_pmc"] = pm["mfma_busy_ms_per_simd_at_2p4GHz"]
     r["note"] = ("dominant kernel = largest share of GPU kernel time over two untimed steps with every launch timed; its "
                  "achieved rate = sum of algorithmic FLOPs (2*MACs of each launch's layer shape) / sum of HIP-event durations "
-                 "on the launch stream INSIDE the timed region, where it shares the GPU with the other streams of the step; "
+                 "on the launch stream INSIDE the timed region, where it shares the GPU with the other streams of the step "
+                 "(*_alone: the same events over 3 further steps of this process with the extra streams switched off); "
                  "traffic / mfma_util_pmc from the committed rocprofv3 PMC passes (profiles/)")
     return r
 
@@ -274,6 +299,18 @@ def main():
             step()
         live = hip.prof_end()
         net.use_graphs = True
+    # the same kernels with nothing else on the GPU: 3 more steps launched from the host with the branch / weight-gradient
+    # streams switched off (inside the timed region a kernel shares the CUs with the other streams of the step)
+    eng = net._engine
+    saved = (eng.branch_overlap, eng.overlap_wgrad, net.use_graphs, net.use_plans)
+    eng.branch_overlap, eng.overlap_wgrad, net.use_graphs, net.use_plans = False, False, False, False
+    for _ in range(2):
+        step()
+    hip.prof_begin("|".join(sorted(set(w.split("<")[0] for w in watch))))
+    for _ in range(3):
+        step()
+    alone = hip.prof_end()
+    eng.branch_overlap, eng.overlap_wgrad, net.use_graphs, net.use_plans = saved
     if rank == 0:
         step_s = dt / args.steps
         res = {
@@ -289,7 +326,7 @@ def main():
                        "launch": "hipGraph replay (fwd + bwd graphs per step)" if args.graphs else
                                  ("lmn_plan_run (recorded C-side schedule, one crossing per pass)" if args.plans else "host"),
                        "final_loss": round(float(loss.detach()), 5)},
-            "roofline": roofline_block(dominant, live, survey, tot_us, B, H, W, step_s),
+            "roofline": roofline_block(dominant, live, survey, tot_us, B, H, W, step_s, alone),
         }
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(H, W)
