@@ -83,8 +83,8 @@ typedef struct {
 #define LMN_EP_LINEAR 0     /* o = v                                                              */
 #define LMN_EP_AFFINE_ACT 1 /* o = act(v*p0[co] + p1[co])           (BN folded to scale/shift)    */
 #define LMN_EP_DGELU 2      /* o = v * gelu'(aux)                    (Mlp backward through GELU)  */
-#define LMN_EP_BN_BWD1 3    /* zh=(v-p0)*p1; h=p2*zh+p3; o=aux*act'(h); stats+=(o, o*zh)         */
-#define LMN_EP_BN_BWD2 4    /* zh=(v-p0)*p1; o=p2*aux - p3 - zh*p4                                */
+#define LMN_EP_BN_BWD1 3    /* zh=(v-p0)*p1; h=p2*zh+p3; o=aux*act'(h); stats+=(o, o*zh); out may be NULL (statistics only) */
+#define LMN_EP_BN_BWD2 4    /* zh=(v-p0)*p1; dh = p5 ? aux*act'(p5*zh+p6) : aux; o=p2*dh - p3 - zh*p4 */
 #define LMN_EP_SE_BWD 5     /* o = v; stats[b][co] += v*gelu(aux)    (d gate of the SE block)     */
 
 #define LMN_ACT_NONE 0
@@ -131,6 +131,8 @@ typedef struct {
                             /* mma_dtype: LMN_F32 | LMN_BF16 -- `wpack` must have been packed with the same dtype */
   int32_t act_dtype;        /* storage of src[].ptr / aux / residual / out: LMN_F32, or LMN_BF16 (needs mma_dtype   */
   int32_t _pad1;            /* LMN_BF16)                                                                             */
+  const float* p5;          /* BN_BWD2 only: BatchNorm gamma / beta when `aux` is the gradient w.r.t. the ACTIVATED   */
+  const float* p6;          /* output (the activation derivative is then applied here and dh is never written)        */
 } lmn_conv_args_t;
 
 /* number of floats lmn_conv_pack writes for (ksize, Cout, src channel counts c[nsrc]) */

@@ -319,8 +319,17 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(const ConvParams P) {
             case LMN_EP_BN_BWD2: {
               const f32x4 mu = ld4(A.p0 + cos), rs = ld4(A.p1 + cos), c1 = ld4(A.p2 + cos), c2 = ld4(A.p3 + cos),
                           c3 = ld4(A.p4 + cos);
+              if (A.p5) {  // aux is the gradient w.r.t. the ACTIVATED output: dh = aux * act'(gamma*zh + beta) formed here
+                const f32x4 ga = ld4(A.p5 + cos), be = ld4(A.p6 + cos);
 #pragma unroll
-              for (int r = 0; r < 4; ++r) o[r] = c1[r] * ax[r] - c2[r] - (v[r] - mu[r]) * rs[r] * c3[r];
+                for (int r = 0; r < 4; ++r) {
+                  const float zh = (v[r] - mu[r]) * rs[r];
+                  o[r] = c1[r] * (ax[r] * lmn_dact(ga[r] * zh + be[r], A.act)) - c2[r] - zh * c3[r];
+                }
+              } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[r] = c1[r] * ax[r] - c2[r] - (v[r] - mu[r]) * rs[r] * c3[r];
+              }
             } break;
             case LMN_EP_SE_BWD: {
               if (live) {
@@ -594,8 +603,17 @@ __global__ __launch_bounds__(256) void conv_tileM_kernel(const ConvParams P) {
             case LMN_EP_BN_BWD2: {
               const f32x4 mu = ld4(A.p0 + cos), rs = ld4(A.p1 + cos), c1 = ld4(A.p2 + cos), c2 = ld4(A.p3 + cos),
                           c3 = ld4(A.p4 + cos);
+              if (A.p5) {  // aux is the gradient w.r.t. the ACTIVATED output: dh = aux * act'(gamma*zh + beta) formed here
+                const f32x4 ga = ld4(A.p5 + cos), be = ld4(A.p6 + cos);
 #pragma unroll
-              for (int r = 0; r < 4; ++r) o[r] = c1[r] * ax[r] - c2[r] - (v[r] - mu[r]) * rs[r] * c3[r];
+                for (int r = 0; r < 4; ++r) {
+                  const float zh = (v[r] - mu[r]) * rs[r];
+                  o[r] = c1[r] * (ax[r] * lmn_dact(ga[r] * zh + be[r], A.act)) - c2[r] - zh * c3[r];
+                }
+              } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[r] = c1[r] * ax[r] - c2[r] - (v[r] - mu[r]) * rs[r] * c3[r];
+              }
             } break;
             case LMN_EP_SE_BWD: {
               if (live) {
@@ -1467,7 +1485,7 @@ int lmn_conv_fwd(const lmn_conv_args_t* args, lmn_stream_t stream) {
     case LMN_EP_AFFINE_ACT: LMN_REQUIRE(A.p0 && A.p1, "conv_fwd: AFFINE_ACT needs p0,p1"); break;
     case LMN_EP_DGELU: LMN_REQUIRE(A.aux, "conv_fwd: DGELU needs aux"); break;
     case LMN_EP_BN_BWD1: LMN_REQUIRE(A.aux && A.p0 && A.p1 && A.p2 && A.p3 && A.stats, "conv_fwd: BN_BWD1 operands"); break;
-    case LMN_EP_BN_BWD2: LMN_REQUIRE(A.aux && A.p0 && A.p1 && A.p2 && A.p3 && A.p4, "conv_fwd: BN_BWD2 operands"); break;
+    case LMN_EP_BN_BWD2: LMN_REQUIRE(A.aux && A.p0 && A.p1 && A.p2 && A.p3 && A.p4 && (!A.p5 == !A.p6), "conv_fwd: BN_BWD2 operands"); break;
     case LMN_EP_SE_BWD: LMN_REQUIRE(A.aux && A.stats, "conv_fwd: SE_BWD operands"); break;
     default: LMN_REQUIRE(false, "conv_fwd: epilogue %d", A.epilogue);
   }

@@ -423,16 +423,17 @@ class Engine:
         hip.dw_bwd(x1, dpre, dx1, *ws, cA, cC, cD, *[G[w] for w in ws])
         # ---- A1 backward: Hardswish' and BatchNorm backward fused into the recomputed 1x1 conv
         wpe = S["wpe"]
-        dh = dpre  # reuse
+        # pass 1 is statistics only (dh = dx1 * hswish'(h) is not written); pass 2 forms dh again from dx1 and turns it into
+        # dz in the same epilogue: one E-wide write and one E-wide read fewer than writing dh in between
         st = _Z(x, STATS_REP, 2, E)
-        hip.conv_fwd([x], wpe, dh, B=B, Hin=H, Win=W, Hout=H, Wout=W, Cout=E, bias=ec.bias, epilogue=hip.EP_BN_BWD1,
+        hip.conv_fwd([x], wpe, None, B=B, Hin=H, Win=W, Hout=H, Wout=W, Cout=E, bias=ec.bias, epilogue=hip.EP_BN_BWD1,
                      act=hip.ACT_HSWISH, p=(S["mean1"], S["rstd1"], ebn.weight, ebn.bias), aux=dx1, stats=st,
                      stats_mode=hip.STATS_EP, stats_rep=STATS_REP)
         c1, c2, c3 = (_E(x, E) for _ in range(3))
         hip.bn_bwd_coef(st, N, S["A1"], G[ebn.weight], G[ebn.bias], c1, c2, c3, self.training)
-        dz = dh
+        dz = dpre  # reuse
         hip.conv_fwd([x], wpe, dz, B=B, Hin=H, Win=W, Hout=H, Wout=W, Cout=E, bias=ec.bias, epilogue=hip.EP_BN_BWD2,
-                     p=(S["mean1"], S["rstd1"], c1, c2, c3), aux=dh)
+                     act=hip.ACT_HSWISH, p=(S["mean1"], S["rstd1"], c1, c2, c3, ebn.weight, ebn.bias), aux=dx1)
         if cw == Cin:
             self.wgrad([x], dz, ec.weight, ec.bias, Hin=H, Win=W)
         else:

@@ -36,7 +36,8 @@ class ConvArgs(C.Structure):
                 ("aux_cstride", C.c_int32), ("res_cstride", C.c_int32), ("out_cstride", C.c_int32),
                 ("epilogue", C.c_int32), ("act", C.c_int32), ("stats_mode", C.c_int32),
                 ("drop_p", C.c_float), ("drop_seed", C.c_uint32), ("seed_ctr", C.c_void_p), ("bias2", C.c_void_p),
-                ("stats_rep", C.c_int32), ("mma_dtype", C.c_int32), ("act_dtype", C.c_int32), ("_pad1", C.c_int32)]
+                ("stats_rep", C.c_int32), ("mma_dtype", C.c_int32), ("act_dtype", C.c_int32), ("_pad1", C.c_int32),
+                ("p5", C.c_void_p), ("p6", C.c_void_p)]
 
 
 class WgradArgs(C.Structure):
@@ -335,8 +336,8 @@ def conv_fwd(srcs, wpack, out, *, B, Hin, Win, Hout, Wout, Cout, ksize=1, stride
     a.wpack = wpack.data_ptr()
     a.bias = bias.data_ptr() if bias is not None else None
     a.bias2 = bias2.data_ptr() if bias2 is not None else None
-    ps = [t.data_ptr() if t is not None else None for t in p] + [None] * (5 - len(p))
-    a.p0, a.p1, a.p2, a.p3, a.p4 = ps
+    ps = [t.data_ptr() if t is not None else None for t in p] + [None] * (7 - len(p))
+    a.p0, a.p1, a.p2, a.p3, a.p4, a.p5, a.p6 = ps
     if aux is not None:
         v = _as_view(aux)
         a.aux, a.aux_cstride = v.ptr, v.cstride

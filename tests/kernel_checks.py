@@ -499,6 +499,16 @@ def check_conv_bn_epilogues(B=2, H=9, W=8, tag=""):
     hip.conv_fwd([xd], wp, dz, B=B, Hin=H, Win=W, Hout=H, Wout=W, Cout=E, bias=dev(b), epilogue=hip.EP_BN_BWD2,
                  p=(dev(mean), dev(rstd), c1, c2, c3), aux=dh)
     rows.append(("conv BN_BWD2 dz" + tag, rel(nchw(dz), zr.grad), 2e-4))
+    # the forms the engine uses: pass 1 statistics only (no dh), pass 2 forms dh from dx1 itself (p5 / p6 = gamma / beta)
+    st2 = torch.zeros(2, E, device=DEV)
+    hip.conv_fwd([xd], wp, None, B=B, Hin=H, Win=W, Hout=H, Wout=W, Cout=E, bias=dev(b), epilogue=hip.EP_BN_BWD1,
+                 act=hip.ACT_HSWISH, p=(dev(mean), dev(rstd), dev(g), dev(be)), aux=nhwc(dx1), stats=st2,
+                 stats_mode=hip.STATS_EP)
+    rows.append(("conv BN_BWD1 statistics-only pass" + tag, rel(st2, st), 2e-5))
+    dz2 = torch.full((B, H, W, E), float("nan"), device=DEV)
+    hip.conv_fwd([xd], wp, dz2, B=B, Hin=H, Win=W, Hout=H, Wout=W, Cout=E, bias=dev(b), epilogue=hip.EP_BN_BWD2,
+                 act=hip.ACT_HSWISH, p=(dev(mean), dev(rstd), c1, c2, c3, dev(g), dev(be)), aux=nhwc(dx1))
+    rows.append(("conv BN_BWD2 with the activation derivative fused (dz from dx1)" + tag, rel(nchw(dz2), zr.grad), 2e-4))
 
     # SE_BWD: o = v, stats[b][c] += v * gelu(aux)
     pre = R(B, E, H, W, seed=137)

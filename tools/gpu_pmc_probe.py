@@ -31,6 +31,10 @@ if what in ("conv", "wgrad"):
     conv_case(176, [48], 24, 3, 1, f, g)
     conv_case(44, [192], 96, 3, 1, f, g)
     conv_case(22, [372], 372, 3, 1, f, g)
+if what == "conv1":     # the HBM-side 1x1 layers of level 0 / 1
+    conv_case(352, [12], 24, 1, 1, True, False)
+    conv_case(352, [24, 12], 12, 1, 1, True, False)
+    conv_case(176, [24], 48, 1, 1, True, False)
 if what == "conv72":
     conv_case(176, [24], 72, 3, 1, True, False)
     conv_case(176, [24, 24, 24], 24, 3, 1, True, False)
