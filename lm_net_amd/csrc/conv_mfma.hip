@@ -1305,6 +1305,210 @@ __global__ __launch_bounds__(256) void wgrad_1x1_kernel(const WgradParams P) {
   }
 }
 
+// ------------------------------------------------------------------------------------ weight gradient, 1x1, wave-staged
+// Same job and same block / K-split geometry as wgrad_1x1_kernel, different data path.  The direct form feeds every MFMA
+// operand with ONE dword (or one bf16) per lane straight from global memory: 256 B (128 B) per wave instruction, and the
+// kernel runs at the pace of its vector-memory instructions (1.1 TB/s over the step's 1x1 weight gradients).  Here a wave
+// moves a CHUNK of 16 pixels x 16 channels per tile with ONE 16-byte (8-byte) load per lane -- 1 KiB per wave instruction,
+// whole 64-byte runs per pixel -- applies the on-load transforms once per element, parks the chunk in a WAVE-PRIVATE LDS
+// slice ([pixel][16 channels] fp32: conflict-free ds_write_b128 / ds_read_b32) and reads the MFMA operands back in the
+// (pixel = k, channel = row / column) form.  No block barrier in the main loop; the loads of chunk c+1 are in flight while
+// chunk c is multiplied.
+template <int NMT, int NNT, int PM>
+__global__ __launch_bounds__(256) void wgrad_1x1w_kernel(const WgradParams P) {
+  constexpr bool BF = PM >= 1;
+  typedef typename ActT<PM>::type TA;
+  constexpr int NTT = NMT + NNT;              // staged tiles per chunk: dy tiles first, then source tiles
+  const lmn_wgrad_args_t& A = P.a;
+  const uint32_t soff = A.seed_ctr ? *A.seed_ctr : 0u;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int lane = threadIdx.x & 63;
+  const int q = lane >> 4, n = lane & 15;
+  const int wvb = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  float* WS = smem + wvb * (NTT * 256);       // this wave's slice: NTT tiles x [16 px][16 ch]
+  const int wave = blockIdx.x * 4 + wvb, nwaves = gridDim.x * 4;
+  const int mset = blockIdx.y / P.nsets_n, nset = blockIdx.y - mset * P.nsets_n;
+  const int mt0 = mset * NMT, nt0 = nset * NNT;
+  const int HW = A.Hout * A.Wout;
+  const int NPX = A.B * HW;
+  // staging role of this lane: pixel lp of the chunk, channel quad lq of every tile
+  const int lp = lane >> 2, lq = lane & 3;
+
+  const TA* sptr[NNT];
+  const float* sscale[NNT];
+  int sC[NNT], scs[NNT], sflags[NNT], sch4[NNT];
+  uint32_t sseed[NNT];
+  float sp[NNT], sik[NNT];
+#pragma unroll
+  for (int t = 0; t < NNT; ++t) {
+    const int nt = nt0 + t;
+    int s = 0;
+    while (s + 1 < A.nsrc && nt >= P.ntile_off[s + 1]) ++s;
+    const int ch = (nt - P.ntile_off[s]) * 16 + lq * 4;
+    sptr[t] = (const TA*)A.src[s].ptr;
+    sscale[t] = A.src[s].scale;
+    sC[t] = A.src[s].C;
+    scs[t] = A.src[s].cstride;
+    sflags[t] = A.src[s].flags;
+    sseed[t] = A.src[s].drop_seed + soff;
+    sp[t] = A.src[s].drop_p;
+    sik[t] = P.inv_keep_src[s];
+    sch4[t] = (nt < P.NNTT && ch < A.src[s].C) ? ch : -1;   // first channel of this lane's quad, or -1
+  }
+  int mco4[NMT];
+#pragma unroll
+  for (int m = 0; m < NMT; ++m) mco4[m] = ((mt0 + m) < P.NMTT && (mt0 + m) * 16 + lq * 4 < A.Cout) ? (mt0 + m) * 16 + lq * 4 : -1;
+
+  f32x4 acc[NMT][NNT];
+  float bsum[NMT];
+#pragma unroll
+  for (int m = 0; m < NMT; ++m) {
+    bsum[m] = 0.f;
+#pragma unroll
+    for (int t = 0; t < NNT; ++t) acc[m][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+
+  // this wave's pixels: whole chunks of 16
+  const int total_chunks = (NPX + 15) >> 4;
+  const int cb = (int)(((int64_t)wave * total_chunks) / nwaves), ce = (int)(((int64_t)(wave + 1) * total_chunks) / nwaves);
+  f32x4 stg[NTT];
+  auto chunk_load = [&](int c) {
+    const int px = c * 16 + lp;
+    const int ps = px < NPX ? px : 0;
+#pragma unroll
+    for (int m = 0; m < NMT; ++m) stg[m] = ld4((const TA*)A.dy + (uint32_t)(ps * A.dy_cstride + (mco4[m] >= 0 ? mco4[m] : 0)));
+#pragma unroll
+    for (int t = 0; t < NNT; ++t) stg[NMT + t] = ld4(sptr[t] + (uint32_t)(ps * scs[t] + (sch4[t] >= 0 ? sch4[t] : 0)));
+  };
+  auto chunk_put = [&](int c) {   // transforms, masking, LDS
+    const int px = c * 16 + lp;
+    const bool ok = px < NPX;
+    const int ps = ok ? px : 0;
+#pragma unroll
+    for (int m = 0; m < NMT; ++m) {
+      f32x4 v = stg[m];
+      if (A.dy_flags & LMN_SRC_DROP) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] *= lmn_drop_scale(A.dy_seed + soff, (uint32_t)(ps * A.Cout + (mco4[m] >= 0 ? mco4[m] : 0) + k), A.dy_p, P.inv_keep_dy);
+      }
+      if (!(ok && mco4[m] >= 0)) v = f32x4{0.f, 0.f, 0.f, 0.f};
+      *reinterpret_cast<f32x4*>(&WS[m * 256 + lp * 16 + lq * 4]) = v;
+    }
+#pragma unroll
+    for (int t = 0; t < NNT; ++t) {
+      f32x4 v = stg[NMT + t];
+      const int chs = sch4[t] >= 0 ? sch4[t] : 0;
+      if (sflags[t] & LMN_SRC_GELU) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = lmn_gelu(v[k]);
+      }
+      if (sflags[t] & LMN_SRC_DROP) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] *= lmn_drop_scale(sseed[t], (uint32_t)(ps * sC[t] + chs + k), sp[t], sik[t]);
+      }
+      if (sscale[t]) v *= ld4(sscale[t] + (ps / HW) * sC[t] + chs);
+      if (!(ok && sch4[t] >= 0)) v = f32x4{0.f, 0.f, 0.f, 0.f};
+      *reinterpret_cast<f32x4*>(&WS[(NMT + t) * 256 + lp * 16 + lq * 4]) = v;
+    }
+  };
+  if (cb < ce) chunk_load(cb);
+  for (int c = cb; c < ce; ++c) {
+    chunk_put(c);                       // (LDS operations of one wave execute in order: the previous chunk's reads are done)
+    if (c + 1 < ce) chunk_load(c + 1);  // in flight during the MFMAs below
+    if constexpr (BF) {                 // one K16 step: lane (q, n) owns pixels 4q..4q+3, channel n
+      uint2 af[NMT], bf_[NNT];
+#pragma unroll
+      for (int m = 0; m < NMT; ++m) {
+        const float a0 = WS[m * 256 + (4 * q) * 16 + n], a1 = WS[m * 256 + (4 * q + 1) * 16 + n];
+        const float a2 = WS[m * 256 + (4 * q + 2) * 16 + n], a3 = WS[m * 256 + (4 * q + 3) * 16 + n];
+        bsum[m] += (a0 + a1) + (a2 + a3);
+        af[m] = uint2{pk_bf16(a0, a1), pk_bf16(a2, a3)};
+      }
+#pragma unroll
+      for (int t = 0; t < NNT; ++t) {
+        const float* b = &WS[(NMT + t) * 256 + (4 * q) * 16 + n];
+        bf_[t] = uint2{pk_bf16(b[0], b[16]), pk_bf16(b[32], b[48])};
+      }
+#pragma unroll
+      for (int t = 0; t < NNT; ++t)
+#pragma unroll
+        for (int m = 0; m < NMT; ++m) acc[m][t] = mfma_bf16(af[m], bf_[t], acc[m][t]);
+    } else {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {     // four K4 steps: lane (q, n) owns pixel 4k + q, channel n
+        float av[NMT], bv[NNT];
+#pragma unroll
+        for (int m = 0; m < NMT; ++m) av[m] = WS[m * 256 + (4 * k + q) * 16 + n];
+#pragma unroll
+        for (int t = 0; t < NNT; ++t) bv[t] = WS[(NMT + t) * 256 + (4 * k + q) * 16 + n];
+#pragma unroll
+        for (int m = 0; m < NMT; ++m) bsum[m] += av[m];
+#pragma unroll
+        for (int t = 0; t < NNT; ++t)
+#pragma unroll
+          for (int m = 0; m < NMT; ++m) acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[m], bv[t], acc[m][t], 0, 0, 0);
+      }
+    }
+  }
+
+  // ---- block-level reduction in LDS (4 waves -> 1), plain stores in four wave rounds; layout as wgrad_lds_kernel
+  constexpr int NT = NMT * NNT;
+  __syncthreads();                      // every wave is done with its staging slice
+  float* s_acc = smem;                  // reuse (host sizes the allocation to max(staging, NT*256 + NMT*16) floats)
+  for (int w = 0; w < 4; ++w) {
+    if (wvb == w) {
+#pragma unroll
+      for (int m = 0; m < NMT; ++m)
+#pragma unroll
+        for (int t = 0; t < NNT; ++t)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float* d = &s_acc[((m * NNT + t) * 4 + r) * 64 + lane];
+            *d = (w == 0) ? acc[m][t][r] : *d + acc[m][t][r];
+          }
+#pragma unroll
+      for (int m = 0; m < NMT; ++m) {
+        float v = bsum[m];
+        v += __shfl_xor(v, 16, 64);
+        v += __shfl_xor(v, 32, 64);
+        if (q == 0) {
+          float* d = &s_acc[NT * 256 + m * 16 + n];
+          *d = (w == 0) ? v : *d + v;
+        }
+      }
+    }
+    __syncthreads();
+  }
+  const int tid = threadIdx.x;
+  if (P.partial) {
+    float* dst = P.partial + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * (NT * 256 + NMT * 16);
+    for (int i = tid; i < NT * 256 + NMT * 16; i += 256) dst[i] = s_acc[i];
+    return;
+  }
+  for (int i = tid; i < NT * 256; i += 256) {
+    const int ln = i & 63, r = (i >> 6) & 3, tl = i >> 8;
+    const int t = tl % NNT, m = tl / NNT;
+    const int qq = ln >> 4, nn = ln & 15;
+    const int co = (mt0 + m) * 16 + qq * 4 + r;
+    const int nt = nt0 + t;
+    if ((mt0 + m) >= P.NMTT || co >= A.Cout || nt >= P.NNTT) continue;
+    int sidx = 0;
+    while (sidx + 1 < A.nsrc && nt >= P.ntile_off[sidx + 1]) ++sidx;
+    const int ch = (nt - P.ntile_off[sidx]) * 16 + nn;
+    if (ch >= A.src[sidx].C) continue;
+    atomicAdd(wgrad_dst(P, co, sidx, ch, 1), s_acc[i]);
+  }
+  if (A.db && nset == 0) {
+    for (int i = tid; i < NMT * 16; i += 256) {
+      const int co = mt0 * 16 + i;
+      if (co < A.Cout && (mt0 + i / 16) < P.NMTT) {
+        atomicAdd(A.db + co, s_acc[NT * 256 + i]);
+        if (A.db2) atomicAdd(A.db2 + co, s_acc[NT * 256 + i]);
+      }
+    }
+  }
+}
+
 // second stage: dW[co][ci][tap] += sum over the K-split blocks of their partial tiles (fixed order => deterministic).
 // 1024 threads = 64 consecutive elements x 16 K-slices; each thread keeps 8 loads in flight.
 template <int TAPS, int NMT, int NNT>
@@ -1366,9 +1570,25 @@ int lmn_sizeof_pack_job(void) { return (int)sizeof(lmn_pack_job_t); }
 // one-tile-wide side is read exactly once); the LDS-staged kernel is instantiated for 1 or 2 tiles per side.
 static void wgrad_tile_shape(const lmn_wgrad_args_t& a, int nmtt, int nntt, int* NMT, int* NNT) {
   const bool direct = a.ksize == 1 && a.stride == 1 && (int64_t)a.Hout * a.Wout >= 32;
-  if (direct && nntt == 1) { *NMT = nmtt < 4 ? nmtt : 4; *NNT = 1; }
-  else if (direct && nmtt == 1) { *NMT = 1; *NNT = nntt < 4 ? nntt : 4; }
-  else { const bool small = nmtt == 1 || nntt == 1; *NMT = small ? 1 : 2; *NNT = small ? 1 : 2; }  // (1,2)/(2,1) measured slower here
+  if (direct) {
+    // 1x1: a block of (M x N) tiles reads its M dy tiles and N source tiles once per pixel; the grid's tile sets re-read
+    // dy ceil(nntt/N) times and the sources ceil(nmtt/M) times: take the instantiated shape with the fewest bytes per
+    // pixel (ties: fewer accumulator tiles)
+    static const int shapes[][2] = {{1, 1}, {1, 2}, {1, 3}, {1, 4}, {2, 1}, {3, 1}, {4, 1}, {2, 2}, {2, 3}, {3, 2}, {2, 4}, {4, 2}};
+    int cin = 0;
+    for (int s = 0; s < a.nsrc && s < 3; ++s) cin += a.src[s].C;
+    long best = -1;
+    for (const auto& sh : shapes) {
+      const int M = sh[0], N = sh[1];
+      if (M > nmtt && M > 1) continue;
+      if (N > nntt && N > 1) continue;
+      const long cost = ((long)((nmtt + M - 1) / M) * cin + (long)((nntt + N - 1) / N) * a.Cout) * 64 + M * N;
+      if (best < 0 || cost < best) { best = cost; *NMT = M; *NNT = N; }
+    }
+    return;
+  }
+  const bool small = nmtt == 1 || nntt == 1;
+  *NMT = small ? 1 : 2; *NNT = small ? 1 : 2;  // LDS-staged kernel: (1,2)/(2,1) measured slower here
 }
 
 int64_t lmn_conv_wgrad_workspace(const lmn_wgrad_args_t* a) {
@@ -1839,11 +2059,37 @@ int lmn_conv_wgrad(const lmn_wgrad_args_t* args, lmn_stream_t stream) {
     if (A.workspace && wgrad_two_stage(gy, nb, per) && (int64_t)gy * nb * per <= A.workspace_floats) P.partial = A.workspace;
     else if (nb > 512 / gy && 512 / gy >= 2) nb = 512 / gy;
     const dim3 dgrid((unsigned)nb, gy);
+    // data path: wave-staged chunks (wgrad_1x1w_kernel) except for bf16-stored operands without on-load transforms in
+    // one of the direct kernel's shapes, where one 2-byte load per lane and MFMA operand is faster (measured, level 0:
+    // 28 vs 40 us; with transforms 70 vs 63 us; fp32 storage: wave-staged -19 % over the 13 probe layers)
+    bool any_tf = (A.dy_flags & LMN_SRC_DROP) != 0;
+    for (int s = 0; s < A.nsrc; ++s) any_tf = any_tf || A.src[s].flags != 0 || A.src[s].scale != nullptr;
+    const bool old_shape = (NMT == 1 && NNT <= 4) || (NNT == 1 && NMT <= 4) || (NMT == 2 && NNT == 2);
+    const bool wave_staged = !(pm == 2 && !any_tf && old_shape);
 #define LMN_WD(M, N)                                                                                               \
   do {                                                                                                              \
-    if (pm == 2) LMN_LAUNCH((wgrad_1x1_kernel<M, N, 2>), dgrid, dim3(256), 0, st, P);                       \
+    if (wave_staged) {                                                                                              \
+      const int64_t stf = 4 * (M + N) * 256, rdf = (int64_t)M * N * 256 + M * 16;                                   \
+      const size_t wsh = (size_t)(stf > rdf ? stf : rdf) * 4;                                                       \
+      if (pm == 2) LMN_LAUNCH((wgrad_1x1w_kernel<M, N, 2>), dgrid, dim3(256), wsh, st, P);                  \
+      else if (pm == 1) LMN_LAUNCH((wgrad_1x1w_kernel<M, N, 1>), dgrid, dim3(256), wsh, st, P);             \
+      else LMN_LAUNCH((wgrad_1x1w_kernel<M, N, 0>), dgrid, dim3(256), wsh, st, P);                          \
+    } else if (pm == 2) LMN_LAUNCH((wgrad_1x1_kernel<M, N, 2>), dgrid, dim3(256), 0, st, P);                \
     else if (pm == 1) LMN_LAUNCH((wgrad_1x1_kernel<M, N, 1>), dgrid, dim3(256), 0, st, P);                  \
     else LMN_LAUNCH((wgrad_1x1_kernel<M, N, 0>), dgrid, dim3(256), 0, st, P);                               \
+    if (P.partial) {                                                                                                \
+      const int ksl = reduce_slices((int)nb);                                                                       \
+      const int rb = (int)((per + 1024 / ksl - 1) / (1024 / ksl));                                                  \
+      LMN_LAUNCH((wgrad_reduce_kernel<1, M, N>), dim3(rb, gy), dim3(1024), 0, st, P, (int)nb, ksl);         \
+    }                                                                                                               \
+  } while (0)
+#define LMN_WW(M, N)                                                                                               \
+  do {                                                                                                              \
+    const int64_t stf = 4 * (M + N) * 256, rdf = (int64_t)M * N * 256 + M * 16;                                     \
+    const size_t wsh = (size_t)(stf > rdf ? stf : rdf) * 4;                                                         \
+    if (pm == 2) LMN_LAUNCH((wgrad_1x1w_kernel<M, N, 2>), dgrid, dim3(256), wsh, st, P);                    \
+    else if (pm == 1) LMN_LAUNCH((wgrad_1x1w_kernel<M, N, 1>), dgrid, dim3(256), wsh, st, P);               \
+    else LMN_LAUNCH((wgrad_1x1w_kernel<M, N, 0>), dgrid, dim3(256), wsh, st, P);                            \
     if (P.partial) {                                                                                                \
       const int ksl = reduce_slices((int)nb);                                                                       \
       const int rb = (int)((per + 1024 / ksl - 1) / (1024 / ksl));                                                  \
@@ -1858,8 +2104,13 @@ int lmn_conv_wgrad(const lmn_wgrad_args_t* args, lmn_stream_t stream) {
       case 2 * 8 + 1: LMN_WD(2, 1); break;
       case 3 * 8 + 1: LMN_WD(3, 1); break;
       case 4 * 8 + 1: LMN_WD(4, 1); break;
-      default: LMN_WD(2, 2); break;
+      case 2 * 8 + 2: LMN_WD(2, 2); break;
+      case 2 * 8 + 3: LMN_WW(2, 3); break;
+      case 3 * 8 + 2: LMN_WW(3, 2); break;
+      case 2 * 8 + 4: LMN_WW(2, 4); break;
+      default: LMN_WW(4, 2); break;
     }
+#undef LMN_WW
 #undef LMN_WD
     return lmn_launch_status("conv_wgrad(1x1)");
   }
