@@ -784,8 +784,24 @@ __device__ __forceinline__ float* wgrad_dst(const WgradParams& P, int co, int si
 // BF: operands rounded to bf16 when staged ([tile][pixel][16 bf16] planes, pixel stride CS dwords), a K step is 16 pixels
 // = ONE v_mfma_f32_16x16x16_bf16 per (tap, cout tile, cin tile): lane (q, n) gathers pixels 4q..4q+3 of channel n with
 // four ds_read_u16 per operand (the same LDS instruction count per pixel as the fp32 form, an eighth of its MFMA time).
-template <int TAPS, int NMT, int NNT, int PM = 0>
-__global__ __launch_bounds__(256, 2) void wgrad_lds_kernel(const WgradParams P) {
+#ifdef LMN_WG_TIMING
+// phase clocks of wgrad_lds_kernel (debug builds only): per block {commit + barriers, K loop, tail, total} in shader cycles
+__device__ unsigned long long g_wg_timing[4096 * 6];
+#define LMN_TCLK() __builtin_amdgcn_s_memtime()
+#endif
+// V == 1 (3x3 stride 1, one-tile and 2 x 2-tile blocks; the host checks that a tile's items fit the register arrays):
+//  * the global loads of tile i+1 are issued BEFORE the K loop of tile i and committed to LDS after it: the memory
+//    latency of a tile (the K loop of a tile is 2-4 us, a loaded-chip HBM round trip is of that order) hides behind MFMAs
+//    of the same block instead of only behind those of the CU's other blocks;
+//  * 2 x 2-tile blocks: wave w owns output tile (w / 2, w % 2) with all 9 taps and walks ALL K steps, instead of all four
+//    tiles and every fourth K step.  36 accumulator VGPRs instead of 144 (which is what makes room for the prefetch
+//    registers and a third resident block per CU), and no cross-wave reduction at the end.
+template <int TAPS, int NMT, int NNT, int PM = 0, int V = 0>
+__global__ __launch_bounds__(256, V == 1 ? 3 : 2) void wgrad_lds_kernel(const WgradParams P) {
+  static_assert(V == 0 || (TAPS == 9 && (NMT * NNT == 4 || NMT * NNT == 1)), "V1: 3x3, 1 or 4 tiles");
+  constexpr bool PF = V == 1;                  // cross-tile prefetch
+  constexpr bool TS = V == 1 && NMT * NNT == 4;  // one output tile per wave
+  constexpr int AM = TS ? 1 : NMT, AN = TS ? 1 : NNT;
   constexpr bool BF = PM >= 1;
   typedef typename ActT<PM>::type TA;
   const lmn_wgrad_args_t& A = P.a;
@@ -799,6 +815,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_lds_kernel(const WgradParams P) 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave index as an SGPR: branches on it stay scalar
   const int q = lane >> 4, n = lane & 15;
+  const int m_w = TS ? wv / NNT : 0, t_w = TS ? wv % NNT : 0;  // TS: this wave's tile
   const int mset = blockIdx.y / P.nsets_n, nset = blockIdx.y - mset * P.nsets_n;
   const int mt0 = mset * NMT, nt0 = nset * NNT;
   const int pad = A.ksize >> 1;
@@ -826,136 +843,215 @@ __global__ __launch_bounds__(256, 2) void wgrad_lds_kernel(const WgradParams P) 
     tch0[t] = (nt - P.ntile_off[sidx]) * 16;
   }
 
-  f32x4 acc[TAPS][NMT][NNT];
-  float bsum[NMT];  // bias gradient: running sum of this lane's dy values (pixel q of every K step, channel n)
+  f32x4 acc[TAPS][AM][AN];
+  float bsum[AM];  // bias gradient: running sum of this lane's dy values (pixel q of every K step, channel n)
 #pragma unroll
   for (int tp = 0; tp < TAPS; ++tp)
 #pragma unroll
-    for (int m = 0; m < NMT; ++m)
+    for (int m = 0; m < AM; ++m)
 #pragma unroll
-      for (int t = 0; t < NNT; ++t) acc[tp][m][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int t = 0; t < AN; ++t) acc[tp][m][t] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-  for (int m = 0; m < NMT; ++m) bsum[m] = 0.f;
+  for (int m = 0; m < AM; ++m) bsum[m] = 0.f;
 
   const int t_begin = (int)(((int64_t)blockIdx.x * P.total_tiles) / gridDim.x);
   const int t_end = (int)(((int64_t)(blockIdx.x + 1) * P.total_tiles) / gridDim.x);
-  for (int tile = t_begin; tile < t_end; ++tile) {
+  // ---- staging of the input window and the dy tile: float4 items (pixel, quad).  ALL global loads of a round (up to
+  //      UX x 256 window items and UY x 256 dy items -- normally the whole tile) are issued before the first one is
+  //      consumed: one exposed memory latency per tile instead of one per 256 items.
+  constexpr int UX = PF ? (NMT * NNT == 1 ? 6 : 4) : ((TAPS == 9 && NMT * NNT == 4) ? 3 : 4), UY = PF ? (NMT * NNT == 1 ? 4 : 2) : 2;
+  const int NXI = P.XH * P.XW * 4, NYI = NP * 4;
+  f32x4 vx[UX][NNT], vy[UY][NMT];
+  int gpx[UX], gpy[UY];  // global pixel index, -1 = outside the image
+  auto issue = [&](int tile, int rd) __attribute__((always_inline)) {
     const int b = tile / (P.tiles_x * P.tiles_y), tt = tile - b * P.tiles_x * P.tiles_y;
     const int oy0 = (tt / P.tiles_x) * P.TH, ox0 = (tt % P.tiles_x) * P.TW;
     const int iy0 = oy0 * A.stride - pad, ix0 = ox0 * A.stride - pad;
-    __syncthreads();  // previous tile's reads are done
-    // ---- stage the input window and the dy tile: float4 items (pixel, quad).  ALL global loads of a round (up to
-    //      UX x 256 window items and UY x 256 dy items -- normally the whole tile) are issued before the first one is
-    //      consumed: one exposed memory latency per tile instead of one per 256 items (the K loop of a tile is
-    //      shorter than two such latencies).
-    constexpr int UX = (TAPS == 9 && NMT * NNT == 4) ? 3 : 4, UY = 2;
-    const int NXI = P.XH * P.XW * 4, NYI = NP * 4;
-    for (int rd = 0; rd * (UX * 256) < NXI || rd * (UY * 256) < NYI; ++rd) {
-      f32x4 vx[UX][NNT], vy[UY][NMT];
-      int gpx[UX], gpy[UY];  // global pixel index, -1 = outside the image
+    (void)iy0; (void)ix0; (void)oy0;
 #pragma unroll
-      for (int u = 0; u < UX; ++u) {
-        const int i = rd * (UX * 256) + u * 256 + tid;
+    for (int u = 0; u < UX; ++u) {
+      const int i = rd * (UX * 256) + u * 256 + tid;
+      const int j = i & 3, pix = i >> 2;
+      bool inb;
+      int gp;
+      if constexpr (TAPS == 1) {  // 1x1: the image is one flat row (host), the window is the tile itself
+        inb = i < NXI && ox0 + pix < A.Wout;
+        gp = inb ? b * A.Wout + ox0 + pix : 0;
+      } else {
+        const int r = (int)__umulhi((uint32_t)pix, P.mXW), c = pix - r * P.XW;
+        const int iy = iy0 + r, ix = ix0 + c;
+        inb = i < NXI && (unsigned)iy < (unsigned)A.Hin && (unsigned)ix < (unsigned)A.Win;
+        gp = inb ? (b * A.Hin + iy) * A.Win + ix : 0;
+      }
+      gpx[u] = inb ? gp : -1;
+#pragma unroll
+    for (int t = 0; t < NNT; ++t) {
+        const int ch = tch0[t] + j * 4;
+        vx[u][t] = ld4(tptr[t] + (uint32_t)(gp * tcs[t] + (ch < tC[t] ? ch : 0)));
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < UY; ++u) {
+      const int i = rd * (UY * 256) + u * 256 + tid;
+      const int j = i & 3, pix = i >> 2;
+      bool inb;
+      int gp;
+      if constexpr (TAPS == 1) {
+        inb = i < NYI && ox0 + pix < A.Wout;
+        gp = inb ? b * A.Wout + ox0 + pix : 0;
+      } else {
+        const int r = (int)__umulhi((uint32_t)pix, P.mTW), c = pix - r * P.TW;
+        const int oy = oy0 + r, ox = ox0 + c;
+        inb = i < NYI && oy < A.Hout && ox < A.Wout;
+        gp = inb ? (b * A.Hout + oy) * A.Wout + ox : 0;
+      }
+      gpy[u] = inb ? gp : -1;
+#pragma unroll
+    for (int m = 0; m < NMT; ++m) {
+        const int co = (mt0 + m) * 16 + j * 4;
+        const bool cok = (mt0 + m) < P.NMTT && co < A.Cout;
+        vy[u][m] = ld4((const TA*)A.dy + (uint32_t)(gp * A.dy_cstride + (cok ? co : 0)));
+      }
+    }
+  };
+  auto commit = [&](int tile, int rd) __attribute__((always_inline)) {
+    const int b = tile / (P.tiles_x * P.tiles_y);
+#pragma unroll
+    for (int u = 0; u < UX; ++u) {
+      const int i = rd * (UX * 256) + u * 256 + tid;
+      if (i < NXI) {
         const int j = i & 3, pix = i >> 2;
-        bool inb;
-        int gp;
-        if constexpr (TAPS == 1) {  // 1x1: the image is one flat row (host), the window is the tile itself
-          inb = i < NXI && ox0 + pix < A.Wout;
-          gp = inb ? b * A.Wout + ox0 + pix : 0;
-        } else {
-          const int r = (int)__umulhi((uint32_t)pix, P.mXW), c = pix - r * P.XW;
-          const int iy = iy0 + r, ix = ix0 + c;
-          inb = i < NXI && (unsigned)iy < (unsigned)A.Hin && (unsigned)ix < (unsigned)A.Win;
-          gp = inb ? (b * A.Hin + iy) * A.Win + ix : 0;
-        }
-        gpx[u] = inb ? gp : -1;
+        const bool inb = gpx[u] >= 0;
+        const int gp = inb ? gpx[u] : 0;
 #pragma unroll
         for (int t = 0; t < NNT; ++t) {
           const int ch = tch0[t] + j * 4;
-          vx[u][t] = ld4(tptr[t] + (uint32_t)(gp * tcs[t] + (ch < tC[t] ? ch : 0)));
+          const bool ok = inb && ch < tC[t];
+          const int chs = ch < tC[t] ? ch : 0;
+          f32x4 w = vx[u][t];
+          if (tflags[t] & LMN_SRC_GELU) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) w[k] = lmn_gelu(w[k]);
+          }
+          if (tflags[t] & LMN_SRC_DROP) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) w[k] *= lmn_drop_scale(tseed[t], (uint32_t)(gp * tC[t] + chs + k), tp_[t], tik[t]);
+          }
+          if (tscale[t]) w *= ld4(tscale[t] + (inb ? b : 0) * tC[t] + chs);
+          if (!ok) w = f32x4{0.f, 0.f, 0.f, 0.f};
+          if constexpr (BF) *reinterpret_cast<uint2*>(&XS[(t * XP + pix) * P.CSx + j * 2]) = pk4_bf16(w);
+          else *reinterpret_cast<f32x4*>(&XS[(t * XP + pix) * P.CSx + j * 4]) = w;
         }
       }
+    }
 #pragma unroll
-      for (int u = 0; u < UY; ++u) {
-        const int i = rd * (UY * 256) + u * 256 + tid;
+    for (int u = 0; u < UY; ++u) {
+      const int i = rd * (UY * 256) + u * 256 + tid;
+      if (i < NYI) {
         const int j = i & 3, pix = i >> 2;
-        bool inb;
-        int gp;
-        if constexpr (TAPS == 1) {
-          inb = i < NYI && ox0 + pix < A.Wout;
-          gp = inb ? b * A.Wout + ox0 + pix : 0;
-        } else {
-          const int r = (int)__umulhi((uint32_t)pix, P.mTW), c = pix - r * P.TW;
-          const int oy = oy0 + r, ox = ox0 + c;
-          inb = i < NYI && oy < A.Hout && ox < A.Wout;
-          gp = inb ? (b * A.Hout + oy) * A.Wout + ox : 0;
-        }
-        gpy[u] = inb ? gp : -1;
+        const bool inb = gpy[u] >= 0;
+        const int gp = inb ? gpy[u] : 0;
 #pragma unroll
         for (int m = 0; m < NMT; ++m) {
           const int co = (mt0 + m) * 16 + j * 4;
           const bool cok = (mt0 + m) < P.NMTT && co < A.Cout;
-          vy[u][m] = ld4((const TA*)A.dy + (uint32_t)(gp * A.dy_cstride + (cok ? co : 0)));
-        }
-      }
+          const int cos = cok ? co : 0;
+          f32x4 w = vy[u][m];
+          if (A.dy_flags & LMN_SRC_DROP) {
 #pragma unroll
-      for (int u = 0; u < UX; ++u) {
-        const int i = rd * (UX * 256) + u * 256 + tid;
-        if (i < NXI) {
-          const int j = i & 3, pix = i >> 2;
-          const bool inb = gpx[u] >= 0;
-          const int gp = inb ? gpx[u] : 0;
-#pragma unroll
-          for (int t = 0; t < NNT; ++t) {
-            const int ch = tch0[t] + j * 4;
-            const bool ok = inb && ch < tC[t];
-            const int chs = ch < tC[t] ? ch : 0;
-            f32x4 w = vx[u][t];
-            if (tflags[t] & LMN_SRC_GELU) {
-#pragma unroll
-              for (int k = 0; k < 4; ++k) w[k] = lmn_gelu(w[k]);
-            }
-            if (tflags[t] & LMN_SRC_DROP) {
-#pragma unroll
-              for (int k = 0; k < 4; ++k) w[k] *= lmn_drop_scale(tseed[t], (uint32_t)(gp * tC[t] + chs + k), tp_[t], tik[t]);
-            }
-            if (tscale[t]) w *= ld4(tscale[t] + (inb ? b : 0) * tC[t] + chs);
-            if (!ok) w = f32x4{0.f, 0.f, 0.f, 0.f};
-            if constexpr (BF) *reinterpret_cast<uint2*>(&XS[(t * XP + pix) * P.CSx + j * 2]) = pk4_bf16(w);
-            else *reinterpret_cast<f32x4*>(&XS[(t * XP + pix) * P.CSx + j * 4]) = w;
+            for (int k = 0; k < 4; ++k) w[k] *= lmn_drop_scale(A.dy_seed + soff, (uint32_t)(gp * A.Cout + cos + k), A.dy_p, P.inv_keep_dy);
           }
-        }
-      }
-#pragma unroll
-      for (int u = 0; u < UY; ++u) {
-        const int i = rd * (UY * 256) + u * 256 + tid;
-        if (i < NYI) {
-          const int j = i & 3, pix = i >> 2;
-          const bool inb = gpy[u] >= 0;
-          const int gp = inb ? gpy[u] : 0;
-#pragma unroll
-          for (int m = 0; m < NMT; ++m) {
-            const int co = (mt0 + m) * 16 + j * 4;
-            const bool cok = (mt0 + m) < P.NMTT && co < A.Cout;
-            const int cos = cok ? co : 0;
-            f32x4 w = vy[u][m];
-            if (A.dy_flags & LMN_SRC_DROP) {
-#pragma unroll
-              for (int k = 0; k < 4; ++k) w[k] *= lmn_drop_scale(A.dy_seed + soff, (uint32_t)(gp * A.Cout + cos + k), A.dy_p, P.inv_keep_dy);
-            }
-            if (!(inb && cok)) w = f32x4{0.f, 0.f, 0.f, 0.f};
-            if constexpr (BF) *reinterpret_cast<uint2*>(&YS[(m * NP + pix) * P.CSy + j * 2]) = pk4_bf16(w);
-            else *reinterpret_cast<f32x4*>(&YS[(m * NP + pix) * P.CSy + j * 4]) = w;
-          }
+          if (!(inb && cok)) w = f32x4{0.f, 0.f, 0.f, 0.f};
+          if constexpr (BF) *reinterpret_cast<uint2*>(&YS[(m * NP + pix) * P.CSy + j * 2]) = pk4_bf16(w);
+          else *reinterpret_cast<f32x4*>(&YS[(m * NP + pix) * P.CSy + j * 4]) = w;
         }
       }
     }
+  };
+#ifdef LMN_WG_TIMING
+  unsigned long long tk0 = LMN_TCLK(), tk_s1 = 0, tk_s2 = 0, tk_s3 = 0, tk_a, tk_b;
+#endif
+  if constexpr (PF) {
+    if (t_begin < t_end) issue(t_begin, 0);
+  }
+  for (int tile = t_begin; tile < t_end; ++tile) {
+#ifdef LMN_WG_TIMING
+    tk_a = LMN_TCLK();
+#endif
+    __syncthreads();  // previous tile's reads are done
+#ifdef LMN_WG_TIMING
+    tk_b = LMN_TCLK(); tk_s1 += tk_b - tk_a; tk_a = tk_b;
+#endif
+    if constexpr (PF) {
+      commit(tile, 0);
+    } else {
+      for (int rd = 0; rd * (UX * 256) < NXI || rd * (UY * 256) < NYI; ++rd) {
+        issue(tile, rd);
+        commit(tile, rd);
+      }
+    }
+#ifdef LMN_WG_TIMING
+    __builtin_amdgcn_s_waitcnt(0);
+    tk_b = LMN_TCLK(); tk_s2 += tk_b - tk_a; tk_a = tk_b;
+#endif
     __syncthreads();
-    if constexpr (BF) {
+    if constexpr (PF) {
+      if (tile + 1 < t_end) issue(tile + 1, 0);
+    }
+#ifdef LMN_WG_TIMING
+    tk_b = LMN_TCLK(); tk_s3 += tk_b - tk_a;
+#endif
+    if constexpr (PF) {
+      // ---- V1 K loops.  The host guarantees TW == 32 and XW == 34 (stride 1, maps >= 32 wide) and one accumulator tile
+      //      per wave: a K step lies in ONE tile row, its row / column are scalar shifts of the step index, and the nine
+      //      tap reads are immediate offsets from one lane address -- 3 VALU per step beside the MFMAs (the general form
+      //      below spends ~35 on index math, which on 3-wave SIMDs competes with the MFMA issue slots).
+      constexpr int XWC = 34, CS = BF ? 12 : 16;
+      const int K0 = TS ? 0 : wv, KSTEP = TS ? 1 : 4;
+      if constexpr (BF) {
+        const uint16_t* xw = reinterpret_cast<const uint16_t*>(XS) + (t_w * XP + q * 4) * (CS * 2) + n;
+        const uint16_t* yw = reinterpret_cast<const uint16_t*>(YS) + (m_w * NP + q * 4) * (CS * 2) + n;
+        for (int ks = K0; ks * 16 < NP; ks += KSTEP) {
+          const int pix0 = ks * 16, pr = pix0 >> 5, pc0 = pix0 & 31;
+          const uint16_t* xp = xw + (pr * XWC + pc0) * (CS * 2);
+          const uint16_t* yp = yw + pix0 * (CS * 2);
+          uint32_t h[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            h[j] = yp[j * CS * 2];
+            bsum[0] += __builtin_bit_cast(float, h[j] << 16);
+          }
+          const uint2 av = uint2{h[0] | (h[1] << 16), h[2] | (h[3] << 16)};
+          uint2 bv[9];
+#pragma unroll
+          for (int tp = 0; tp < 9; ++tp) {
+            const uint16_t* xt = xp + ((tp / 3) * XWC + tp % 3) * (CS * 2);
+            const uint32_t h0 = xt[0], h1 = xt[CS * 2], h2 = xt[2 * CS * 2], h3 = xt[3 * CS * 2];
+            bv[tp] = uint2{h0 | (h1 << 16), h2 | (h3 << 16)};
+          }
+#pragma unroll
+          for (int tp = 0; tp < 9; ++tp) acc[tp][0][0] = mfma_bf16(av, bv[tp], acc[tp][0][0]);
+        }
+      } else {
+        const float* xw = XS + (t_w * XP + q) * CS + n;
+        const float* yw = YS + (m_w * NP + q) * CS + n;
+        for (int ks = K0; ks * 4 < NP; ks += KSTEP) {
+          const int pix0 = ks * 4, pr = pix0 >> 5, pc0 = pix0 & 31;
+          const float* xp = xw + (pr * XWC + pc0) * CS;
+          const float av = yw[pix0 * CS];
+          float bv[9];
+#pragma unroll
+          for (int tp = 0; tp < 9; ++tp) bv[tp] = xp[((tp / 3) * XWC + tp % 3) * CS];
+          bsum[0] += av;
+#pragma unroll
+          for (int tp = 0; tp < 9; ++tp) acc[tp][0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv[tp], acc[tp][0][0], 0, 0, 0);
+        }
+      }
+    } else if constexpr (BF) {
       // ---- bf16: K steps of 16 consecutive tile pixels; lane (q, n) owns pixels 4q..4q+3 of the step, channel n
       const uint16_t* XH16 = reinterpret_cast<const uint16_t*>(XS);
       const uint16_t* YH16 = reinterpret_cast<const uint16_t*>(YS);
-      for (int ks = wv; ks * 16 < NP; ks += 4) {
+      for (int ks = TS ? 0 : wv; ks * 16 < NP; ks += TS ? 1 : 4) {
         int xb[4];
         bool pin[4];
 #pragma unroll
@@ -970,14 +1066,14 @@ __global__ __launch_bounds__(256, 2) void wgrad_lds_kernel(const WgradParams P) 
             xb[j] = ((pr * A.stride) * P.XW + pc * A.stride) * P.CSx * 2 + n;
           }
         }
-        uint2 av[NMT], bvv[TAPS][NNT];
+        uint2 av[AM], bvv[TAPS][AN];
 #pragma unroll
-        for (int m = 0; m < NMT; ++m) {
+        for (int m = 0; m < AM; ++m) {
           uint32_t h[4];
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
             const int pixs = pin[j] ? ks * 16 + q * 4 + j : 0;
-            h[j] = pin[j] ? (uint32_t)YH16[(m * NP + pixs) * P.CSy * 2 + n] : 0u;
+            h[j] = pin[j] ? (uint32_t)YH16[((TS ? m_w : m) * NP + pixs) * P.CSy * 2 + n] : 0u;
             bsum[m] += __builtin_bit_cast(float, h[j] << 16);
           }
           av[m] = uint2{h[0] | (h[1] << 16), h[2] | (h[3] << 16)};
@@ -986,8 +1082,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_lds_kernel(const WgradParams P) 
         for (int tp = 0; tp < TAPS; ++tp) {
           const int ty = (TAPS == 9) ? tp / 3 : 0, tx = (TAPS == 9) ? tp % 3 : 0;
 #pragma unroll
-          for (int t = 0; t < NNT; ++t) {
-            const int toff = (t * XP + ty * P.XW + tx) * P.CSx * 2;
+          for (int t = 0; t < AN; ++t) {
+            const int toff = ((TS ? t_w : t) * XP + ty * P.XW + tx) * P.CSx * 2;
             const uint32_t h0 = XH16[xb[0] + toff], h1 = XH16[xb[1] + toff], h2 = XH16[xb[2] + toff], h3 = XH16[xb[3] + toff];
             bvv[tp][t] = uint2{h0 | (h1 << 16), h2 | (h3 << 16)};
           }
@@ -995,20 +1091,20 @@ __global__ __launch_bounds__(256, 2) void wgrad_lds_kernel(const WgradParams P) 
 #pragma unroll
         for (int tp = 0; tp < TAPS; ++tp)
 #pragma unroll
-          for (int t = 0; t < NNT; ++t)
+          for (int t = 0; t < AN; ++t)
 #pragma unroll
-            for (int m = 0; m < NMT; ++m) acc[tp][m][t] = mfma_bf16(av[m], bvv[tp][t], acc[tp][m][t]);
+            for (int m = 0; m < AM; ++m) acc[tp][m][t] = mfma_bf16(av[m], bvv[tp][t], acc[tp][m][t]);
       }
     } else
     // ---- MFMA over this wave's K steps (4 consecutive tile pixels each); all LDS reads of a step are issued
     //      before its MFMAs so their latency overlaps
-    for (int ks = wv; ks * 4 < NP; ks += 4) {
+    for (int ks = TS ? 0 : wv; ks * 4 < NP; ks += TS ? 1 : 4) {
       const int pix = ks * 4 + q;
       const bool pin = pix < NP;
       const int pixs = pin ? pix : 0;
-      float av[NMT], bvv[TAPS][NNT];
+      float av[AM], bvv[TAPS][AN];
 #pragma unroll
-      for (int m = 0; m < NMT; ++m) av[m] = YS[(m * NP + pixs) * P.CSy + n];
+      for (int m = 0; m < AM; ++m) av[m] = YS[((TS ? m_w : m) * NP + pixs) * P.CSy + n];
       int xb;
       if constexpr (TAPS == 1) {
         xb = pixs * P.CSx + n;
@@ -1020,26 +1116,75 @@ __global__ __launch_bounds__(256, 2) void wgrad_lds_kernel(const WgradParams P) 
       for (int tp = 0; tp < TAPS; ++tp) {
         const int ty = (TAPS == 9) ? tp / 3 : 0, tx = (TAPS == 9) ? tp % 3 : 0;
 #pragma unroll
-        for (int t = 0; t < NNT; ++t) bvv[tp][t] = XS[xb + (t * XP + ty * P.XW + tx) * P.CSx];
+        for (int t = 0; t < AN; ++t) bvv[tp][t] = XS[xb + ((TS ? t_w : t) * XP + ty * P.XW + tx) * P.CSx];
       }
       if (!pin) {
 #pragma unroll
-        for (int m = 0; m < NMT; ++m) av[m] = 0.f;
+        for (int m = 0; m < AM; ++m) av[m] = 0.f;
       }
 #pragma unroll
-      for (int m = 0; m < NMT; ++m) bsum[m] += av[m];
+      for (int m = 0; m < AM; ++m) bsum[m] += av[m];
 #pragma unroll
       for (int tp = 0; tp < TAPS; ++tp)
 #pragma unroll
-        for (int t = 0; t < NNT; ++t)
+        for (int t = 0; t < AN; ++t)
 #pragma unroll
-          for (int m = 0; m < NMT; ++m) acc[tp][m][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[m], bvv[tp][t], acc[tp][m][t], 0, 0, 0);
+          for (int m = 0; m < AM; ++m) acc[tp][m][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[m], bvv[tp][t], acc[tp][m][t], 0, 0, 0);
     }
   }
 
+#ifdef LMN_WG_TIMING
+  {
+    const unsigned long long tk_e = LMN_TCLK();
+    const int bid = blockIdx.y * gridDim.x + blockIdx.x;
+    if (tid == 0 && bid < 4096) {
+      g_wg_timing[bid * 6 + 0] = tk_s1;
+      g_wg_timing[bid * 6 + 1] = tk_s2;
+      g_wg_timing[bid * 6 + 2] = tk_s3;
+      g_wg_timing[bid * 6 + 3] = tk_e - tk0 - tk_s1 - tk_s2 - tk_s3;
+      g_wg_timing[bid * 6 + 4] = tk0;
+      g_wg_timing[bid * 6 + 5] = tk_e;
+    }
+  }
+#endif
   // ---- block-level reduction in LDS (4 waves -> 1): plain stores / read-add-stores in four wave rounds.
   //      (LDS float atomics cost ~3 cycles per LANE on gfx950 -- measured 180 us for this tail with ds_add_f32.)
   constexpr int NT = TAPS * NMT * NNT;
+  if constexpr (TS) {
+    // every wave holds the finished sums of ITS tile: straight to the block partial (coalesced, the layout of the
+    // LDS-reduced form: [tap][m][t][r][lane], then the bias sums) or to dW
+    float* dst = P.partial ? P.partial + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * (NT * 256 + NMT * 16) : nullptr;
+    const int nt = nt0 + t_w;
+    int sidx = 0;
+    while (sidx + 1 < A.nsrc && nt >= P.ntile_off[sidx + 1]) ++sidx;
+    const int ch = (nt - P.ntile_off[sidx]) * 16 + n;
+#pragma unroll
+    for (int tp = 0; tp < TAPS; ++tp)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        if (dst) {
+          dst[(((tp * NMT + m_w) * NNT + t_w) * 4 + r) * 64 + lane] = acc[tp][0][0][r];
+        } else {
+          const int co = (mt0 + m_w) * 16 + q * 4 + r;
+          if ((mt0 + m_w) < P.NMTT && co < A.Cout && nt < P.NNTT && ch < A.src[sidx].C)
+            atomicAdd(wgrad_dst(P, co, sidx, ch, TAPS) + tp, acc[tp][0][0][r]);
+        }
+      }
+    if (t_w == 0) {
+      float v = bsum[0];
+      v += __shfl_xor(v, 16, 64);
+      v += __shfl_xor(v, 32, 64);
+      if (q == 0) {
+        const int co = (mt0 + m_w) * 16 + n;
+        if (dst) dst[NT * 256 + m_w * 16 + n] = v;
+        else if (A.db && nset == 0 && co < A.Cout && (mt0 + m_w) < P.NMTT) {
+          atomicAdd(A.db + co, v);
+          if (A.db2) atomicAdd(A.db2 + co, v);
+        }
+      }
+    }
+    return;
+  }
   __syncthreads();
   float* s_acc = smem;  // reuse the staging area (>= NT*256 + NMT*16 floats, checked on the host)
   for (int w = 0; w < 4; ++w) {
@@ -1591,6 +1736,20 @@ static void wgrad_tile_shape(const lmn_wgrad_args_t& a, int nmtt, int nntt, int*
   *NMT = small ? 1 : 2; *NNT = small ? 1 : 2;  // LDS-staged kernel: (1,2)/(2,1) measured slower here
 }
 
+// 3x3 stride-1 layers run wgrad_lds_kernel<.., V = 1> (cross-tile prefetch, tile-split waves): ~140 VGPRs and <= 42 KB of
+// LDS per block, so THREE blocks are resident per CU and the K-split aims at 768 blocks instead of 512.
+static int wgrad_v1_env() {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("LMN_WGRAD_V1"); v = e ? atoi(e) : 1; }
+  return v;
+}
+static bool wgrad_v1(const lmn_wgrad_args_t& a) { return a.ksize == 3 && a.stride == 1 && wgrad_v1_env() != 0; }
+static int wgrad_blocks_total(const lmn_wgrad_args_t& a) {
+  static int c = -1;
+  if (c < 0) { const char* e = getenv("LMN_WGRAD_CAP"); c = e ? atoi(e) : 768; }
+  return wgrad_v1(a) ? c : 512;
+}
+
 int64_t lmn_conv_wgrad_workspace(const lmn_wgrad_args_t* a) {
   if (!a) return 0;
   int nntt = 0;
@@ -1600,11 +1759,17 @@ int64_t lmn_conv_wgrad_workspace(const lmn_wgrad_args_t* a) {
   wgrad_tile_shape(*a, nmtt, nntt, &NMT, &NNT);
   const int gy = ((nmtt + NMT - 1) / NMT) * ((nntt + NNT - 1) / NNT);
   const int64_t per = (int64_t)a->ksize * a->ksize * NMT * NNT * 256 + NMT * 16;
-  const int64_t cap = 512 / gy > 2 ? 512 / gy : 2;  // upper bound of the K-split block count (see lmn_conv_wgrad)
+  const int btot = wgrad_blocks_total(*a);
+  const int64_t cap = btot / gy > 2 ? btot / gy : 2;  // upper bound of the K-split block count (see lmn_conv_wgrad)
   const int64_t need = gy * cap * per;
   return need <= (int64_t)(16 << 20) ? need : 0;  // at most 64 MB of partials; larger problems use atomics
 }
 const char* lmn_last_error(void) { return g_lmn_err; }
+#ifdef LMN_WG_TIMING
+int lmn_wg_timing(unsigned long long* out, int n) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wg_timing), sizeof(unsigned long long) * n);
+}
+#endif
 
 int64_t lmn_conv_pack_size(int ksize, int Cout, int nsrc, const int32_t* c) {
   int64_t nkb = 0;
@@ -1991,7 +2156,8 @@ int lmn_conv_wgrad(const lmn_wgrad_args_t* args, lmn_stream_t stream) {
   const lmn_wgrad_args_t& G = P.a;  // (flattened) geometry
   // tile pixels: 256 for the 1x1 form, for one-tile blocks and on the small maps (fewer barriers and less halo per pixel:
   // -5..10 %), 128 where a 2x2-tile block would need 76 KB of LDS for it (+3 % there)
-  const int npmax = G.stride == 2 ? 64 : ((G.ksize == 1 || NMT * NNT == 1 || G.Wout <= 32) ? 256 : 128);
+  const bool v1c = wgrad_v1(A) && G.Wout >= 32 && (NMT * NNT == 4 || NMT * NNT == 1);  // V1 candidate (item counts checked below)
+  const int npmax = G.stride == 2 ? 64 : ((G.ksize == 1 || NMT * NNT == 1 || (G.Wout <= 32 && !v1c)) ? 256 : 128);
   P.TW = G.Wout < (G.ksize == 1 ? npmax : 32) ? G.Wout : (G.ksize == 1 ? npmax : 32);
   if (G.stride == 2 && P.TW > 16) P.TW = 16;
   P.TH = npmax / P.TW;
@@ -2019,7 +2185,11 @@ int lmn_conv_wgrad(const lmn_wgrad_args_t* args, lmn_stream_t stream) {
   LMN_REQUIRE(lds_floats * 4 <= 160 * 1024, "conv_wgrad: LDS tile too large (%lld B)", (long long)lds_floats * 4);
   // K-split: enough blocks to fill the chip (~1024 in total), each walking a contiguous range of tiles
   int64_t blocks64 = P.total_tiles;
-  const int64_t cap = 512 / gy > 2 ? 512 / gy : 2;
+  // V1: the whole tile's float4 items in the prefetch registers (6 + 4 per thread for one-tile, 4 + 2 for 2 x 2-tile blocks)
+  const bool v1 = v1c && P.TW == 32 && P.XW == 34 && P.CSx == P.CSy &&
+                  P.XH * P.XW * 4 <= (NMT * NNT == 1 ? 6 : 4) * 256 && P.TH * P.TW * 4 <= (NMT * NNT == 1 ? 4 : 2) * 256;
+  const int btot = v1 ? wgrad_blocks_total(A) : 512;
+  const int64_t cap = btot / gy > 2 ? btot / gy : 2;
   if (blocks64 > cap) blocks64 = cap;
   if (blocks64 < 1) blocks64 = 1;
   // two-stage reduction when the caller's workspace holds every block partial; else LDS-reduced atomics with fewer blocks
@@ -2027,7 +2197,7 @@ int lmn_conv_wgrad(const lmn_wgrad_args_t* args, lmn_stream_t stream) {
   if (A.workspace && wgrad_two_stage(gy, blocks64, per) && (int64_t)gy * blocks64 * per <= A.workspace_floats) {
     P.partial = A.workspace;
   } else if (blocks64 > 512 / gy && 512 / gy >= 2) {
-    blocks64 = 512 / gy;
+    blocks64 = 512 / gy;  // atomics: fewer blocks
   }
   const int blocks = (int)blocks64;
   hipStream_t st = (hipStream_t)stream;
@@ -2040,9 +2210,23 @@ int lmn_conv_wgrad(const lmn_wgrad_args_t* args, lmn_stream_t stream) {
       (void)hipFuncSetAttribute((const void*)wgrad_lds_kernel<T, M, N, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem); \
       (void)hipFuncSetAttribute((const void*)wgrad_lds_kernel<T, M, N, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem); \
     }                                                                                                               \
+    if constexpr (T == 9 && (M * N == 4 || M * N == 1)) {                                                           \
+      if (v1) {                                                                                                     \
+        if (shmem > 64 * 1024) {                                                                                    \
+          (void)hipFuncSetAttribute((const void*)wgrad_lds_kernel<T, M, N, 0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem); \
+          (void)hipFuncSetAttribute((const void*)wgrad_lds_kernel<T, M, N, 1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem); \
+          (void)hipFuncSetAttribute((const void*)wgrad_lds_kernel<T, M, N, 2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem); \
+        }                                                                                                           \
+        if (pm == 2) LMN_LAUNCH((wgrad_lds_kernel<T, M, N, 2, 1>), grid, dim3(256), shmem, st, P);          \
+        else if (pm == 1) LMN_LAUNCH((wgrad_lds_kernel<T, M, N, 1, 1>), grid, dim3(256), shmem, st, P);     \
+        else LMN_LAUNCH((wgrad_lds_kernel<T, M, N, 0, 1>), grid, dim3(256), shmem, st, P);                  \
+        goto wg_reduce_##T##M##N;                                                                                   \
+      }                                                                                                             \
+    }                                                                                                               \
     if (pm == 2) LMN_LAUNCH((wgrad_lds_kernel<T, M, N, 2>), grid, dim3(256), shmem, st, P);                 \
     else if (pm == 1) LMN_LAUNCH((wgrad_lds_kernel<T, M, N, 1>), grid, dim3(256), shmem, st, P);            \
     else LMN_LAUNCH((wgrad_lds_kernel<T, M, N, 0>), grid, dim3(256), shmem, st, P);                         \
+  wg_reduce_##T##M##N:                                                                                              \
     if (P.partial) {                                                                                                \
       const int ksl = reduce_slices(blocks);                                                                        \
       const int rb = (int)((per + 1024 / ksl - 1) / (1024 / ksl));                                                  \

@@ -35,6 +35,11 @@ if what == "conv1":     # the HBM-side 1x1 layers of level 0 / 1
     conv_case(352, [12], 24, 1, 1, True, False)
     conv_case(352, [24, 12], 12, 1, 1, True, False)
     conv_case(176, [24], 48, 1, 1, True, False)
+if what == "wg3":       # 3x3 weight gradients: one-tile and 2x2-tile blocks
+    conv_case(352, [12], 12, 3, 1, False, True)
+    conv_case(176, [24], 24, 3, 1, False, True)
+    conv_case(176, [48], 24, 3, 1, False, True)
+    conv_case(88, [96], 48, 3, 1, False, True)
 if what == "conv72":
     conv_case(176, [24], 72, 3, 1, True, False)
     conv_case(176, [24, 24, 24], 24, 3, 1, True, False)
