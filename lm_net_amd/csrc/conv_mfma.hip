@@ -784,24 +784,8 @@ __device__ __forceinline__ float* wgrad_dst(const WgradParams& P, int co, int si
 // BF: operands rounded to bf16 when staged ([tile][pixel][16 bf16] planes, pixel stride CS dwords), a K step is 16 pixels
 // = ONE v_mfma_f32_16x16x16_bf16 per (tap, cout tile, cin tile): lane (q, n) gathers pixels 4q..4q+3 of channel n with
 // four ds_read_u16 per operand (the same LDS instruction count per pixel as the fp32 form, an eighth of its MFMA time).
-#ifdef LMN_WG_TIMING
-// phase clocks of wgrad_lds_kernel (debug builds only): per block {commit + barriers, K loop, tail, total} in shader cycles
-__device__ unsigned long long g_wg_timing[4096 * 6];
-#define LMN_TCLK() __builtin_amdgcn_s_memtime()
-#endif
-// V == 1 (3x3 stride 1, one-tile and 2 x 2-tile blocks; the host checks that a tile's items fit the register arrays):
-//  * the global loads of tile i+1 are issued BEFORE the K loop of tile i and committed to LDS after it: the memory
-//    latency of a tile (the K loop of a tile is 2-4 us, a loaded-chip HBM round trip is of that order) hides behind MFMAs
-//    of the same block instead of only behind those of the CU's other blocks;
-//  * 2 x 2-tile blocks: wave w owns output tile (w / 2, w % 2) with all 9 taps and walks ALL K steps, instead of all four
-//    tiles and every fourth K step.  36 accumulator VGPRs instead of 144 (which is what makes room for the prefetch
-//    registers and a third resident block per CU), and no cross-wave reduction at the end.
-template <int TAPS, int NMT, int NNT, int PM = 0, int V = 0>
-__global__ __launch_bounds__(256, V == 1 ? 3 : 2) void wgrad_lds_kernel(const WgradParams P) {
-  static_assert(V == 0 || (TAPS == 9 && (NMT * NNT == 4 || NMT * NNT == 1)), "V1: 3x3, 1 or 4 tiles");
-  constexpr bool PF = V == 1;                  // cross-tile prefetch
-  constexpr bool TS = V == 1 && NMT * NNT == 4;  // one output tile per wave
-  constexpr int AM = TS ? 1 : NMT, AN = TS ? 1 : NNT;
+template <int TAPS, int NMT, int NNT, int PM = 0>
+__global__ __launch_bounds__(256, 2) void wgrad_lds_kernel(const WgradParams P) {
   constexpr bool BF = PM >= 1;
   typedef typename ActT<PM>::type TA;
   const lmn_wgrad_args_t& A = P.a;
@@ -815,7 +799,6 @@ __global__ __launch_bounds__(256, V == 1 ? 3 : 2) void wgrad_lds_kernel(const Wg
   const int tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave index as an SGPR: branches on it stay scalar
   const int q = lane >> 4, n = lane & 15;
-  const int m_w = TS ? wv / NNT : 0, t_w = TS ? wv % NNT : 0;  // TS: this wave's tile
   const int mset = blockIdx.y / P.nsets_n, nset = blockIdx.y - mset * P.nsets_n;
   const int mt0 = mset * NMT, nt0 = nset * NNT;
   const int pad = A.ksize >> 1;
@@ -843,215 +826,136 @@ __global__ __launch_bounds__(256, V == 1 ? 3 : 2) void wgrad_lds_kernel(const Wg
     tch0[t] = (nt - P.ntile_off[sidx]) * 16;
   }
 
-  f32x4 acc[TAPS][AM][AN];
-  float bsum[AM];  // bias gradient: running sum of this lane's dy values (pixel q of every K step, channel n)
+  f32x4 acc[TAPS][NMT][NNT];
+  float bsum[NMT];  // bias gradient: running sum of this lane's dy values (pixel q of every K step, channel n)
 #pragma unroll
   for (int tp = 0; tp < TAPS; ++tp)
 #pragma unroll
-    for (int m = 0; m < AM; ++m)
+    for (int m = 0; m < NMT; ++m)
 #pragma unroll
-      for (int t = 0; t < AN; ++t) acc[tp][m][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int t = 0; t < NNT; ++t) acc[tp][m][t] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-  for (int m = 0; m < AM; ++m) bsum[m] = 0.f;
+  for (int m = 0; m < NMT; ++m) bsum[m] = 0.f;
 
   const int t_begin = (int)(((int64_t)blockIdx.x * P.total_tiles) / gridDim.x);
   const int t_end = (int)(((int64_t)(blockIdx.x + 1) * P.total_tiles) / gridDim.x);
-  // ---- staging of the input window and the dy tile: float4 items (pixel, quad).  ALL global loads of a round (up to
-  //      UX x 256 window items and UY x 256 dy items -- normally the whole tile) are issued before the first one is
-  //      consumed: one exposed memory latency per tile instead of one per 256 items.
-  constexpr int UX = PF ? (NMT * NNT == 1 ? 6 : 4) : ((TAPS == 9 && NMT * NNT == 4) ? 3 : 4), UY = PF ? (NMT * NNT == 1 ? 4 : 2) : 2;
-  const int NXI = P.XH * P.XW * 4, NYI = NP * 4;
-  f32x4 vx[UX][NNT], vy[UY][NMT];
-  int gpx[UX], gpy[UY];  // global pixel index, -1 = outside the image
-  auto issue = [&](int tile, int rd) __attribute__((always_inline)) {
+  for (int tile = t_begin; tile < t_end; ++tile) {
     const int b = tile / (P.tiles_x * P.tiles_y), tt = tile - b * P.tiles_x * P.tiles_y;
     const int oy0 = (tt / P.tiles_x) * P.TH, ox0 = (tt % P.tiles_x) * P.TW;
     const int iy0 = oy0 * A.stride - pad, ix0 = ox0 * A.stride - pad;
-    (void)iy0; (void)ix0; (void)oy0;
+    __syncthreads();  // previous tile's reads are done
+    // ---- stage the input window and the dy tile: float4 items (pixel, quad).  ALL global loads of a round (up to
+    //      UX x 256 window items and UY x 256 dy items -- normally the whole tile) are issued before the first one is
+    //      consumed: one exposed memory latency per tile instead of one per 256 items (the K loop of a tile is
+    //      shorter than two such latencies).
+    constexpr int UX = (TAPS == 9 && NMT * NNT == 4) ? 3 : 4, UY = 2;
+    const int NXI = P.XH * P.XW * 4, NYI = NP * 4;
+    for (int rd = 0; rd * (UX * 256) < NXI || rd * (UY * 256) < NYI; ++rd) {
+      f32x4 vx[UX][NNT], vy[UY][NMT];
+      int gpx[UX], gpy[UY];  // global pixel index, -1 = outside the image
 #pragma unroll
-    for (int u = 0; u < UX; ++u) {
-      const int i = rd * (UX * 256) + u * 256 + tid;
-      const int j = i & 3, pix = i >> 2;
-      bool inb;
-      int gp;
-      if constexpr (TAPS == 1) {  // 1x1: the image is one flat row (host), the window is the tile itself
-        inb = i < NXI && ox0 + pix < A.Wout;
-        gp = inb ? b * A.Wout + ox0 + pix : 0;
-      } else {
-        const int r = (int)__umulhi((uint32_t)pix, P.mXW), c = pix - r * P.XW;
-        const int iy = iy0 + r, ix = ix0 + c;
-        inb = i < NXI && (unsigned)iy < (unsigned)A.Hin && (unsigned)ix < (unsigned)A.Win;
-        gp = inb ? (b * A.Hin + iy) * A.Win + ix : 0;
-      }
-      gpx[u] = inb ? gp : -1;
-#pragma unroll
-    for (int t = 0; t < NNT; ++t) {
-        const int ch = tch0[t] + j * 4;
-        vx[u][t] = ld4(tptr[t] + (uint32_t)(gp * tcs[t] + (ch < tC[t] ? ch : 0)));
-      }
-    }
-#pragma unroll
-    for (int u = 0; u < UY; ++u) {
-      const int i = rd * (UY * 256) + u * 256 + tid;
-      const int j = i & 3, pix = i >> 2;
-      bool inb;
-      int gp;
-      if constexpr (TAPS == 1) {
-        inb = i < NYI && ox0 + pix < A.Wout;
-        gp = inb ? b * A.Wout + ox0 + pix : 0;
-      } else {
-        const int r = (int)__umulhi((uint32_t)pix, P.mTW), c = pix - r * P.TW;
-        const int oy = oy0 + r, ox = ox0 + c;
-        inb = i < NYI && oy < A.Hout && ox < A.Wout;
-        gp = inb ? (b * A.Hout + oy) * A.Wout + ox : 0;
-      }
-      gpy[u] = inb ? gp : -1;
-#pragma unroll
-    for (int m = 0; m < NMT; ++m) {
-        const int co = (mt0 + m) * 16 + j * 4;
-        const bool cok = (mt0 + m) < P.NMTT && co < A.Cout;
-        vy[u][m] = ld4((const TA*)A.dy + (uint32_t)(gp * A.dy_cstride + (cok ? co : 0)));
-      }
-    }
-  };
-  auto commit = [&](int tile, int rd) __attribute__((always_inline)) {
-    const int b = tile / (P.tiles_x * P.tiles_y);
-#pragma unroll
-    for (int u = 0; u < UX; ++u) {
-      const int i = rd * (UX * 256) + u * 256 + tid;
-      if (i < NXI) {
+      for (int u = 0; u < UX; ++u) {
+        const int i = rd * (UX * 256) + u * 256 + tid;
         const int j = i & 3, pix = i >> 2;
-        const bool inb = gpx[u] >= 0;
-        const int gp = inb ? gpx[u] : 0;
+        bool inb;
+        int gp;
+        if constexpr (TAPS == 1) {  // 1x1: the image is one flat row (host), the window is the tile itself
+          inb = i < NXI && ox0 + pix < A.Wout;
+          gp = inb ? b * A.Wout + ox0 + pix : 0;
+        } else {
+          const int r = (int)__umulhi((uint32_t)pix, P.mXW), c = pix - r * P.XW;
+          const int iy = iy0 + r, ix = ix0 + c;
+          inb = i < NXI && (unsigned)iy < (unsigned)A.Hin && (unsigned)ix < (unsigned)A.Win;
+          gp = inb ? (b * A.Hin + iy) * A.Win + ix : 0;
+        }
+        gpx[u] = inb ? gp : -1;
 #pragma unroll
         for (int t = 0; t < NNT; ++t) {
           const int ch = tch0[t] + j * 4;
-          const bool ok = inb && ch < tC[t];
-          const int chs = ch < tC[t] ? ch : 0;
-          f32x4 w = vx[u][t];
-          if (tflags[t] & LMN_SRC_GELU) {
-#pragma unroll
-            for (int k = 0; k < 4; ++k) w[k] = lmn_gelu(w[k]);
-          }
-          if (tflags[t] & LMN_SRC_DROP) {
-#pragma unroll
-            for (int k = 0; k < 4; ++k) w[k] *= lmn_drop_scale(tseed[t], (uint32_t)(gp * tC[t] + chs + k), tp_[t], tik[t]);
-          }
-          if (tscale[t]) w *= ld4(tscale[t] + (inb ? b : 0) * tC[t] + chs);
-          if (!ok) w = f32x4{0.f, 0.f, 0.f, 0.f};
-          if constexpr (BF) *reinterpret_cast<uint2*>(&XS[(t * XP + pix) * P.CSx + j * 2]) = pk4_bf16(w);
-          else *reinterpret_cast<f32x4*>(&XS[(t * XP + pix) * P.CSx + j * 4]) = w;
+          vx[u][t] = ld4(tptr[t] + (uint32_t)(gp * tcs[t] + (ch < tC[t] ? ch : 0)));
         }
       }
-    }
 #pragma unroll
-    for (int u = 0; u < UY; ++u) {
-      const int i = rd * (UY * 256) + u * 256 + tid;
-      if (i < NYI) {
+      for (int u = 0; u < UY; ++u) {
+        const int i = rd * (UY * 256) + u * 256 + tid;
         const int j = i & 3, pix = i >> 2;
-        const bool inb = gpy[u] >= 0;
-        const int gp = inb ? gpy[u] : 0;
+        bool inb;
+        int gp;
+        if constexpr (TAPS == 1) {
+          inb = i < NYI && ox0 + pix < A.Wout;
+          gp = inb ? b * A.Wout + ox0 + pix : 0;
+        } else {
+          const int r = (int)__umulhi((uint32_t)pix, P.mTW), c = pix - r * P.TW;
+          const int oy = oy0 + r, ox = ox0 + c;
+          inb = i < NYI && oy < A.Hout && ox < A.Wout;
+          gp = inb ? (b * A.Hout + oy) * A.Wout + ox : 0;
+        }
+        gpy[u] = inb ? gp : -1;
 #pragma unroll
         for (int m = 0; m < NMT; ++m) {
           const int co = (mt0 + m) * 16 + j * 4;
           const bool cok = (mt0 + m) < P.NMTT && co < A.Cout;
-          const int cos = cok ? co : 0;
-          f32x4 w = vy[u][m];
-          if (A.dy_flags & LMN_SRC_DROP) {
+          vy[u][m] = ld4((const TA*)A.dy + (uint32_t)(gp * A.dy_cstride + (cok ? co : 0)));
+        }
+      }
 #pragma unroll
-            for (int k = 0; k < 4; ++k) w[k] *= lmn_drop_scale(A.dy_seed + soff, (uint32_t)(gp * A.Cout + cos + k), A.dy_p, P.inv_keep_dy);
+      for (int u = 0; u < UX; ++u) {
+        const int i = rd * (UX * 256) + u * 256 + tid;
+        if (i < NXI) {
+          const int j = i & 3, pix = i >> 2;
+          const bool inb = gpx[u] >= 0;
+          const int gp = inb ? gpx[u] : 0;
+#pragma unroll
+          for (int t = 0; t < NNT; ++t) {
+            const int ch = tch0[t] + j * 4;
+            const bool ok = inb && ch < tC[t];
+            const int chs = ch < tC[t] ? ch : 0;
+            f32x4 w = vx[u][t];
+            if (tflags[t] & LMN_SRC_GELU) {
+#pragma unroll
+              for (int k = 0; k < 4; ++k) w[k] = lmn_gelu(w[k]);
+            }
+            if (tflags[t] & LMN_SRC_DROP) {
+#pragma unroll
+              for (int k = 0; k < 4; ++k) w[k] *= lmn_drop_scale(tseed[t], (uint32_t)(gp * tC[t] + chs + k), tp_[t], tik[t]);
+            }
+            if (tscale[t]) w *= ld4(tscale[t] + (inb ? b : 0) * tC[t] + chs);
+            if (!ok) w = f32x4{0.f, 0.f, 0.f, 0.f};
+            if constexpr (BF) *reinterpret_cast<uint2*>(&XS[(t * XP + pix) * P.CSx + j * 2]) = pk4_bf16(w);
+            else *reinterpret_cast<f32x4*>(&XS[(t * XP + pix) * P.CSx + j * 4]) = w;
           }
-          if (!(inb && cok)) w = f32x4{0.f, 0.f, 0.f, 0.f};
-          if constexpr (BF) *reinterpret_cast<uint2*>(&YS[(m * NP + pix) * P.CSy + j * 2]) = pk4_bf16(w);
-          else *reinterpret_cast<f32x4*>(&YS[(m * NP + pix) * P.CSy + j * 4]) = w;
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < UY; ++u) {
+        const int i = rd * (UY * 256) + u * 256 + tid;
+        if (i < NYI) {
+          const int j = i & 3, pix = i >> 2;
+          const bool inb = gpy[u] >= 0;
+          const int gp = inb ? gpy[u] : 0;
+#pragma unroll
+          for (int m = 0; m < NMT; ++m) {
+            const int co = (mt0 + m) * 16 + j * 4;
+            const bool cok = (mt0 + m) < P.NMTT && co < A.Cout;
+            const int cos = cok ? co : 0;
+            f32x4 w = vy[u][m];
+            if (A.dy_flags & LMN_SRC_DROP) {
+#pragma unroll
+              for (int k = 0; k < 4; ++k) w[k] *= lmn_drop_scale(A.dy_seed + soff, (uint32_t)(gp * A.Cout + cos + k), A.dy_p, P.inv_keep_dy);
+            }
+            if (!(inb && cok)) w = f32x4{0.f, 0.f, 0.f, 0.f};
+            if constexpr (BF) *reinterpret_cast<uint2*>(&YS[(m * NP + pix) * P.CSy + j * 2]) = pk4_bf16(w);
+            else *reinterpret_cast<f32x4*>(&YS[(m * NP + pix) * P.CSy + j * 4]) = w;
+          }
         }
       }
     }
-  };
-#ifdef LMN_WG_TIMING
-  unsigned long long tk0 = LMN_TCLK(), tk_s1 = 0, tk_s2 = 0, tk_s3 = 0, tk_a, tk_b;
-#endif
-  if constexpr (PF) {
-    if (t_begin < t_end) issue(t_begin, 0);
-  }
-  for (int tile = t_begin; tile < t_end; ++tile) {
-#ifdef LMN_WG_TIMING
-    tk_a = LMN_TCLK();
-#endif
-    __syncthreads();  // previous tile's reads are done
-#ifdef LMN_WG_TIMING
-    tk_b = LMN_TCLK(); tk_s1 += tk_b - tk_a; tk_a = tk_b;
-#endif
-    if constexpr (PF) {
-      commit(tile, 0);
-    } else {
-      for (int rd = 0; rd * (UX * 256) < NXI || rd * (UY * 256) < NYI; ++rd) {
-        issue(tile, rd);
-        commit(tile, rd);
-      }
-    }
-#ifdef LMN_WG_TIMING
-    __builtin_amdgcn_s_waitcnt(0);
-    tk_b = LMN_TCLK(); tk_s2 += tk_b - tk_a; tk_a = tk_b;
-#endif
     __syncthreads();
-    if constexpr (PF) {
-      if (tile + 1 < t_end) issue(tile + 1, 0);
-    }
-#ifdef LMN_WG_TIMING
-    tk_b = LMN_TCLK(); tk_s3 += tk_b - tk_a;
-#endif
-    if constexpr (PF) {
-      // ---- V1 K loops.  The host guarantees TW == 32 and XW == 34 (stride 1, maps >= 32 wide) and one accumulator tile
-      //      per wave: a K step lies in ONE tile row, its row / column are scalar shifts of the step index, and the nine
-      //      tap reads are immediate offsets from one lane address -- 3 VALU per step beside the MFMAs (the general form
-      //      below spends ~35 on index math, which on 3-wave SIMDs competes with the MFMA issue slots).
-      constexpr int XWC = 34, CS = BF ? 12 : 16;
-      const int K0 = TS ? 0 : wv, KSTEP = TS ? 1 : 4;
-      if constexpr (BF) {
-        const uint16_t* xw = reinterpret_cast<const uint16_t*>(XS) + (t_w * XP + q * 4) * (CS * 2) + n;
-        const uint16_t* yw = reinterpret_cast<const uint16_t*>(YS) + (m_w * NP + q * 4) * (CS * 2) + n;
-        for (int ks = K0; ks * 16 < NP; ks += KSTEP) {
-          const int pix0 = ks * 16, pr = pix0 >> 5, pc0 = pix0 & 31;
-          const uint16_t* xp = xw + (pr * XWC + pc0) * (CS * 2);
-          const uint16_t* yp = yw + pix0 * (CS * 2);
-          uint32_t h[4];
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            h[j] = yp[j * CS * 2];
-            bsum[0] += __builtin_bit_cast(float, h[j] << 16);
-          }
-          const uint2 av = uint2{h[0] | (h[1] << 16), h[2] | (h[3] << 16)};
-          uint2 bv[9];
-#pragma unroll
-          for (int tp = 0; tp < 9; ++tp) {
-            const uint16_t* xt = xp + ((tp / 3) * XWC + tp % 3) * (CS * 2);
-            const uint32_t h0 = xt[0], h1 = xt[CS * 2], h2 = xt[2 * CS * 2], h3 = xt[3 * CS * 2];
-            bv[tp] = uint2{h0 | (h1 << 16), h2 | (h3 << 16)};
-          }
-#pragma unroll
-          for (int tp = 0; tp < 9; ++tp) acc[tp][0][0] = mfma_bf16(av, bv[tp], acc[tp][0][0]);
-        }
-      } else {
-        const float* xw = XS + (t_w * XP + q) * CS + n;
-        const float* yw = YS + (m_w * NP + q) * CS + n;
-        for (int ks = K0; ks * 4 < NP; ks += KSTEP) {
-          const int pix0 = ks * 4, pr = pix0 >> 5, pc0 = pix0 & 31;
-          const float* xp = xw + (pr * XWC + pc0) * CS;
-          const float av = yw[pix0 * CS];
-          float bv[9];
-#pragma unroll
-          for (int tp = 0; tp < 9; ++tp) bv[tp] = xp[((tp / 3) * XWC + tp % 3) * CS];
-          bsum[0] += av;
-#pragma unroll
-          for (int tp = 0; tp < 9; ++tp) acc[tp][0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv[tp], acc[tp][0][0], 0, 0, 0);
-        }
-      }
-    } else if constexpr (BF) {
+    if constexpr (BF) {
       // ---- bf16: K steps of 16 consecutive tile pixels; lane (q, n) owns pixels 4q..4q+3 of the step, channel n
       const uint16_t* XH16 = reinterpret_cast<const uint16_t*>(XS);
       const uint16_t* YH16 = reinterpret_cast<const uint16_t*>(YS);
-      for (int ks = TS ? 0 : wv; ks * 16 < NP; ks += TS ? 1 : 4) {
+      for (int ks = wv; ks * 16 < NP; ks += 4) {
         int xb[4];
         bool pin[4];
 #pragma unroll
@@ -1066,14 +970,14 @@ __global__ __launch_bounds__(256, V == 1 ? 3 : 2) void wgrad_lds_kernel(const Wg
             xb[j] = ((pr * A.stride) * P.XW + pc * A.stride) * P.CSx * 2 + n;
           }
         }
-        uint2 av[AM], bvv[TAPS][AN];
+        uint2 av[NMT], bvv[TAPS][NNT];
 #pragma unroll
-        for (int m = 0; m < AM; ++m) {
+        for (int m = 0; m < NMT; ++m) {
           uint32_t h[4];
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
             const int pixs = pin[j] ? ks * 16 + q * 4 + j : 0;
-            h[j] = pin[j] ? (uint32_t)YH16[((TS ? m_w : m) * NP + pixs) * P.CSy * 2 + n] : 0u;
+            h[j] = pin[j] ? (uint32_t)YH16[(m * NP + pixs) * P.CSy * 2 + n] : 0u;
             bsum[m] += __builtin_bit_cast(float, h[j] << 16);
           }
           av[m] = uint2{h[0] | (h[1] << 16), h[2] | (h[3] << 16)};
@@ -1082,8 +986,8 @@ __global__ __launch_bounds__(256, V == 1 ? 3 : 2) void wgrad_lds_kernel(const Wg
         for (int tp = 0; tp < TAPS; ++tp) {
           const int ty = (TAPS == 9) ? tp / 3 : 0, tx = (TAPS == 9) ? tp % 3 : 0;
 #pragma unroll
-          for (int t = 0; t < AN; ++t) {
-            const int toff = ((TS ? t_w : t) * XP + ty * P.XW + tx) * P.CSx * 2;
+          for (int t = 0; t < NNT; ++t) {
+            const int toff = (t * XP + ty * P.XW + tx) * P.CSx * 2;
             const uint32_t h0 = XH16[xb[0] + toff], h1 = XH16[xb[1] + toff], h2 = XH16[xb[2] + toff], h3 = XH16[xb[3] + toff];
             bvv[tp][t] = uint2{h0 | (h1 << 16), h2 | (h3 << 16)};
           }
@@ -1091,20 +995,20 @@ __global__ __launch_bounds__(256, V == 1 ? 3 : 2) void wgrad_lds_kernel(const Wg
 #pragma unroll
         for (int tp = 0; tp < TAPS; ++tp)
 #pragma unroll
-          for (int t = 0; t < AN; ++t)
+          for (int t = 0; t < NNT; ++t)
 #pragma unroll
-            for (int m = 0; m < AM; ++m) acc[tp][m][t] = mfma_bf16(av[m], bvv[tp][t], acc[tp][m][t]);
+            for (int m = 0; m < NMT; ++m) acc[tp][m][t] = mfma_bf16(av[m], bvv[tp][t], acc[tp][m][t]);
       }
     } else
     // ---- MFMA over this wave's K steps (4 consecutive tile pixels each); all LDS reads of a step are issued
     //      before its MFMAs so their latency overlaps
-    for (int ks = TS ? 0 : wv; ks * 4 < NP; ks += TS ? 1 : 4) {
+    for (int ks = wv; ks * 4 < NP; ks += 4) {
       const int pix = ks * 4 + q;
       const bool pin = pix < NP;
       const int pixs = pin ? pix : 0;
-      float av[AM], bvv[TAPS][AN];
+      float av[NMT], bvv[TAPS][NNT];
 #pragma unroll
-      for (int m = 0; m < AM; ++m) av[m] = YS[((TS ? m_w : m) * NP + pixs) * P.CSy + n];
+      for (int m = 0; m < NMT; ++m) av[m] = YS[(m * NP + pixs) * P.CSy + n];
       int xb;
       if constexpr (TAPS == 1) {
         xb = pixs * P.CSx + n;
@@ -1116,75 +1020,26 @@ __global__ __launch_bounds__(256, V == 1 ? 3 : 2) void wgrad_lds_kernel(const Wg
       for (int tp = 0; tp < TAPS; ++tp) {
         const int ty = (TAPS == 9) ? tp / 3 : 0, tx = (TAPS == 9) ? tp % 3 : 0;
 #pragma unroll
-        for (int t = 0; t < AN; ++t) bvv[tp][t] = XS[xb + ((TS ? t_w : t) * XP + ty * P.XW + tx) * P.CSx];
+        for (int t = 0; t < NNT; ++t) bvv[tp][t] = XS[xb + (t * XP + ty * P.XW + tx) * P.CSx];
       }
       if (!pin) {
 #pragma unroll
-        for (int m = 0; m < AM; ++m) av[m] = 0.f;
+        for (int m = 0; m < NMT; ++m) av[m] = 0.f;
       }
 #pragma unroll
-      for (int m = 0; m < AM; ++m) bsum[m] += av[m];
+      for (int m = 0; m < NMT; ++m) bsum[m] += av[m];
 #pragma unroll
       for (int tp = 0; tp < TAPS; ++tp)
 #pragma unroll
-        for (int t = 0; t < AN; ++t)
+        for (int t = 0; t < NNT; ++t)
 #pragma unroll
-          for (int m = 0; m < AM; ++m) acc[tp][m][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[m], bvv[tp][t], acc[tp][m][t], 0, 0, 0);
+          for (int m = 0; m < NMT; ++m) acc[tp][m][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[m], bvv[tp][t], acc[tp][m][t], 0, 0, 0);
     }
   }
 
-#ifdef LMN_WG_TIMING
-  {
-    const unsigned long long tk_e = LMN_TCLK();
-    const int bid = blockIdx.y * gridDim.x + blockIdx.x;
-    if (tid == 0 && bid < 4096) {
-      g_wg_timing[bid * 6 + 0] = tk_s1;
-      g_wg_timing[bid * 6 + 1] = tk_s2;
-      g_wg_timing[bid * 6 + 2] = tk_s3;
-      g_wg_timing[bid * 6 + 3] = tk_e - tk0 - tk_s1 - tk_s2 - tk_s3;
-      g_wg_timing[bid * 6 + 4] = tk0;
-      g_wg_timing[bid * 6 + 5] = tk_e;
-    }
-  }
-#endif
   // ---- block-level reduction in LDS (4 waves -> 1): plain stores / read-add-stores in four wave rounds.
   //      (LDS float atomics cost ~3 cycles per LANE on gfx950 -- measured 180 us for this tail with ds_add_f32.)
   constexpr int NT = TAPS * NMT * NNT;
-  if constexpr (TS) {
-    // every wave holds the finished sums of ITS tile: straight to the block partial (coalesced, the layout of the
-    // LDS-reduced form: [tap][m][t][r][lane], then the bias sums) or to dW
-    float* dst = P.partial ? P.partial + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * (NT * 256 + NMT * 16) : nullptr;
-    const int nt = nt0 + t_w;
-    int sidx = 0;
-    while (sidx + 1 < A.nsrc && nt >= P.ntile_off[sidx + 1]) ++sidx;
-    const int ch = (nt - P.ntile_off[sidx]) * 16 + n;
-#pragma unroll
-    for (int tp = 0; tp < TAPS; ++tp)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        if (dst) {
-          dst[(((tp * NMT + m_w) * NNT + t_w) * 4 + r) * 64 + lane] = acc[tp][0][0][r];
-        } else {
-          const int co = (mt0 + m_w) * 16 + q * 4 + r;
-          if ((mt0 + m_w) < P.NMTT && co < A.Cout && nt < P.NNTT && ch < A.src[sidx].C)
-            atomicAdd(wgrad_dst(P, co, sidx, ch, TAPS) + tp, acc[tp][0][0][r]);
-        }
-      }
-    if (t_w == 0) {
-      float v = bsum[0];
-      v += __shfl_xor(v, 16, 64);
-      v += __shfl_xor(v, 32, 64);
-      if (q == 0) {
-        const int co = (mt0 + m_w) * 16 + n;
-        if (dst) dst[NT * 256 + m_w * 16 + n] = v;
-        else if (A.db && nset == 0 && co < A.Cout && (mt0 + m_w) < P.NMTT) {
-          atomicAdd(A.db + co, v);
-          if (A.db2) atomicAdd(A.db2 + co, v);
-        }
-      }
-    }
-    return;
-  }
   __syncthreads();
   float* s_acc = smem;  // reuse the staging area (>= NT*256 + NMT*16 floats, checked on the host)
   for (int w = 0; w < 4; ++w) {
@@ -1238,6 +1093,361 @@ __global__ __launch_bounds__(256, V == 1 ? 3 : 2) void wgrad_lds_kernel(const Wg
         atomicAdd(A.db + co, s_acc[NT * 256 + i]);
         if (A.db2) atomicAdd(A.db2 + co, s_acc[NT * 256 + i]);
       }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------ weight gradient, 3x3 stride 1, maps >= 32 wide
+// The LDS-staged form above specialised for the layers that carry most of the weight-gradient time (tile 32 pixels wide,
+// window 34 wide, one-tile or 2 x 2-tile blocks).  Against the general kernel:
+//  * 2 x 2-tile blocks give each wave ONE output tile (wave w: cout tile w / 2, cin tile w % 2) with all 9 taps over ALL K steps
+//    of the tile, instead of all four tiles over every fourth step: 36 accumulator VGPRs instead of 144 (room for a third
+//    resident block per CU and the prefetch registers below) and no cross-wave reduction at the end;
+//  * the global loads of tile i+1 are issued BEFORE the K loop of tile i and committed to LDS after it, so a tile's memory
+//    latency hides behind this block's own MFMAs, not only behind those of the CU's other blocks;
+//  * index math is hoisted out of the per-tile / per-step paths (it ran at ~35 VALU per K step and ~25 per staged item, which
+//    on 3-wave SIMDs competes with the MFMA issue slots -- measured: MFMA busy 47 % with the K phase at 70 % of a block's
+//    life).  A K step lies in ONE tile row (32 | tile width): row / column are scalar shifts of the step index and the nine tap
+//    reads are immediate offsets from one lane address.  Staged items are addressed by per-thread offsets computed once per
+//    kernel plus a scalar tile base; raw buffer loads return 0 for the halo outside the image (offset forced out of range),
+//    so the commit is a plain register -> LDS copy when the source has no on-load transform (bf16 storage: the loaded words
+//    go to LDS untouched).
+// LDS planes are padded to whole 64-pixel item rounds ([tile][UX * 64 px][CS]): every plane / round offset is an immediate.
+template <int ESZ> struct RawOf { typedef f32x4 type; };
+template <> struct RawOf<2> { typedef u32x2 type; };
+__device__ __forceinline__ f32x4 raw_f32(f32x4 v) { return v; }
+__device__ __forceinline__ f32x4 raw_f32(u32x2 v) { return f32x4{lmn_bf16_lo(v.x), lmn_bf16_hi(v.x), lmn_bf16_lo(v.y), lmn_bf16_hi(v.y)}; }
+template <typename RawT> __device__ __forceinline__ RawT raw_load(BufRsrc r, uint32_t off) {
+  if constexpr (sizeof(RawT) == 16) return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, 0, 0));
+  else return __builtin_amdgcn_raw_buffer_load_b64(r, (int)off, 0, 0);
+}
+#ifdef LMN_WG_TIMING
+// phase clocks (debug builds only): per block {tile-top barrier, commit, second barrier + issue, rest, start, end}
+__device__ unsigned long long g_wg_timing[4096 * 6];
+#define LMN_TCLK() __builtin_amdgcn_s_memtime()
+#endif
+
+template <int NMT, int NNT, int PM>
+__global__ __launch_bounds__(256, 3) void wgrad3_kernel(const WgradParams P) {
+  static_assert(NMT * NNT == 4 || NMT * NNT == 1, "one-tile or 2 x 2-tile blocks");
+  constexpr bool TS = NMT * NNT == 4;  // one output tile per wave
+  constexpr bool BF = PM >= 1;
+  typedef typename ActT<PM>::type TA;
+  constexpr int ESZ = sizeof(TA);
+  typedef typename RawOf<ESZ>::type RawT;
+  constexpr int XWC = 34, CS = BF ? 12 : 16;  // window width; dwords per LDS pixel (bf16: 8 + 4 pad)
+  constexpr int QW = BF ? 2 : 4;              // dwords of one staged (pixel, channel quad) item in LDS
+  constexpr int UX = TS ? 4 : 6, UY = TS ? 2 : 4;  // staged items per thread: window, dy tile
+  constexpr int XPA = UX * 64, NPA = UY * 64;      // padded plane sizes in pixels
+  const lmn_wgrad_args_t& A = P.a;
+  const uint32_t soff = A.seed_ctr ? *A.seed_ctr : 0u;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* XS = smem;                     // [NNT][XPA][CS]
+  float* YS = smem + NNT * XPA * CS;    // [NMT][NPA][CS]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int q = lane >> 4, n = lane & 15;
+  const int m_w = TS ? wv / NNT : 0, t_w = TS ? wv % NNT : 0;
+  const int mset = blockIdx.y / P.nsets_n, nset = blockIdx.y - mset * P.nsets_n;
+  const int mt0 = mset * NMT, nt0 = nset * NNT;
+  const int NP = P.TH * 32;
+  const int j = tid & 3, pl = tid >> 2;  // this thread's channel quad and pixel-in-round of every staged item
+
+  // per cin tile of this block: source, channel base, buffer descriptor
+  const float* tscale[NNT];
+  int tC[NNT], tcs[NNT], tflags[NNT], tch0[NNT];
+  uint32_t tseed[NNT];
+  float tp_[NNT], tik[NNT];
+  BufRsrc rx[NNT];
+  bool cx[NNT];
+#pragma unroll
+  for (int t = 0; t < NNT; ++t) {
+    const int nt = nt0 + t;
+    int sidx = 0;
+    while (sidx + 1 < A.nsrc && nt >= P.ntile_off[sidx + 1]) ++sidx;
+    tscale[t] = A.src[sidx].scale;
+    tC[t] = nt < P.NNTT ? A.src[sidx].C : 0;
+    tcs[t] = A.src[sidx].cstride;
+    tflags[t] = A.src[sidx].flags;
+    tseed[t] = A.src[sidx].drop_seed + soff;
+    tp_[t] = A.src[sidx].drop_p;
+    tik[t] = P.inv_keep_src[sidx];
+    tch0[t] = (nt - P.ntile_off[sidx]) * 16;
+    rx[t] = make_rsrc(A.src[sidx].ptr, (unsigned)((int64_t)A.B * A.Hin * A.Win * tcs[t] * ESZ));
+    cx[t] = tch0[t] + j * 4 < tC[t];
+  }
+  const BufRsrc ry = make_rsrc(A.dy, (unsigned)((int64_t)A.B * A.Hout * A.Wout * A.dy_cstride * ESZ));
+
+  // tile-invariant item descriptors: window items (row, column) and byte offsets from the window's first pixel
+  uint32_t xrc[UX], xo[UX][NNT];
+#pragma unroll
+  for (int u = 0; u < UX; ++u) {
+    const int pix = u * 64 + pl, r = pix / XWC, c = pix - r * XWC;
+    xrc[u] = r < P.XH ? (uint32_t)(r << 16 | c) : 0x7fff0000u;  // rows past the window never pass the bounds test
+#pragma unroll
+    for (int t = 0; t < NNT; ++t) xo[u][t] = (uint32_t)(((r * A.Win + c) * tcs[t] + tch0[t] + j * 4) * ESZ);
+  }
+  // dy items: pixel u * 64 + pl of the 32-wide tile = row 2u + (pl >> 5), column pl & 31
+  const int yc = pl & 31, yr0 = pl >> 5;
+  uint32_t yo0[NMT];
+  bool cy[NMT];
+#pragma unroll
+  for (int m = 0; m < NMT; ++m) {
+    const int co = (mt0 + m) * 16 + j * 4;
+    cy[m] = (mt0 + m) < P.NMTT && co < A.Cout;
+    yo0[m] = (uint32_t)(((yr0 * A.Wout + yc) * A.dy_cstride + (cy[m] ? co : 0)) * ESZ);
+  }
+  const uint32_t ystep = (uint32_t)(2 * A.Wout * A.dy_cstride * ESZ);  // two tile rows
+
+  f32x4 acc[9];
+  float bsum = 0.f;  // bias gradient: this lane's dy values (pixel q of every K step, channel n)
+#pragma unroll
+  for (int tp = 0; tp < 9; ++tp) acc[tp] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  RawT vx[UX][NNT], vy[UY][NMT];
+  const int tpi = P.tiles_x * P.tiles_y;
+  auto issue = [&](int tile) __attribute__((always_inline)) {
+    const int b = tile / tpi, tt = tile - b * tpi;
+    const int ty_ = tt / P.tiles_x;
+    const int oy0 = ty_ * P.TH, ox0 = (tt - ty_ * P.tiles_x) * 32;
+    const int iy0 = oy0 - 1, ix0 = ox0 - 1;
+    const int wpix = (b * A.Hin + iy0) * A.Win + ix0;  // window's first pixel (may lie before the tensor: wraps back below)
+#pragma unroll
+    for (int u = 0; u < UX; ++u) {
+      const int r = (int)(xrc[u] >> 16), c = (int)(xrc[u] & 0xffffu);
+      const bool inb = (unsigned)(iy0 + r) < (unsigned)A.Hin && (unsigned)(ix0 + c) < (unsigned)A.Win;
+#pragma unroll
+      for (int t = 0; t < NNT; ++t) {
+        const uint32_t off = (uint32_t)(wpix * tcs[t] * ESZ) + xo[u][t];
+        vx[u][t] = raw_load<RawT>(rx[t], (inb && cx[t]) ? off : 0xffffffffu);
+      }
+    }
+    const uint32_t ybase = (uint32_t)(((b * A.Hout + oy0) * A.Wout + ox0) * A.dy_cstride * ESZ);
+    const bool cok = ox0 + yc < A.Wout;
+    const int rlim = (A.Hout - oy0 < P.TH ? A.Hout - oy0 : P.TH) - yr0;  // rows of this tile inside the image
+#pragma unroll
+    for (int u = 0; u < UY; ++u) {
+      const bool inb = cok && 2 * u < rlim;
+#pragma unroll
+      for (int m = 0; m < NMT; ++m)
+        vy[u][m] = raw_load<RawT>(ry, (inb && cy[m]) ? ybase + (uint32_t)u * ystep + yo0[m] : 0xffffffffu);
+    }
+  };
+  float* xl = XS + pl * CS + j * QW;
+  float* yl = YS + pl * CS + j * QW;
+  auto commit = [&](int tile) __attribute__((always_inline)) {
+    const int b = tile / tpi, tt = tile - b * tpi;
+    const int ty_ = tt / P.tiles_x;
+    const int oy0 = ty_ * P.TH, ox0 = (tt - ty_ * P.tiles_x) * 32;
+#pragma unroll
+    for (int t = 0; t < NNT; ++t) {
+      const bool tf = tflags[t] != 0 || tscale[t] != nullptr;  // block-uniform
+#pragma unroll
+      for (int u = 0; u < UX; ++u) {
+        float* dst = xl + (t * XPA + u * 64) * CS;
+        if (!tf) {
+          if constexpr (ESZ == 2) *reinterpret_cast<u32x2*>(dst) = vx[u][t];
+          else if constexpr (BF) *reinterpret_cast<uint2*>(dst) = pk4_bf16(raw_f32(vx[u][t]));
+          else *reinterpret_cast<f32x4*>(dst) = raw_f32(vx[u][t]);
+          continue;
+        }
+        f32x4 w = raw_f32(vx[u][t]);  // lanes outside the image / past the channels hold 0 and stay 0 under every transform
+        const int chs = cx[t] ? tch0[t] + j * 4 : 0;
+        if (tflags[t] & LMN_SRC_GELU) {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) w[k] = lmn_gelu(w[k]);
+        }
+        if (tflags[t] & LMN_SRC_DROP) {
+          const int r = (int)(xrc[u] >> 16), c = (int)(xrc[u] & 0xffffu);
+          const int gp = (b * A.Hin + oy0 - 1 + r) * A.Win + ox0 - 1 + c;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) w[k] *= lmn_drop_scale(tseed[t], (uint32_t)(gp * tC[t] + chs + k), tp_[t], tik[t]);
+        }
+        if (tscale[t]) w *= ld4(tscale[t] + b * tC[t] + chs);
+        if constexpr (BF) *reinterpret_cast<uint2*>(dst) = pk4_bf16(w);
+        else *reinterpret_cast<f32x4*>(dst) = w;
+      }
+    }
+#pragma unroll
+    for (int m = 0; m < NMT; ++m) {
+#pragma unroll
+      for (int u = 0; u < UY; ++u) {
+        float* dst = yl + (m * NPA + u * 64) * CS;
+        if (!(A.dy_flags & LMN_SRC_DROP)) {
+          if constexpr (ESZ == 2) *reinterpret_cast<u32x2*>(dst) = vy[u][m];
+          else if constexpr (BF) *reinterpret_cast<uint2*>(dst) = pk4_bf16(raw_f32(vy[u][m]));
+          else *reinterpret_cast<f32x4*>(dst) = raw_f32(vy[u][m]);
+          continue;
+        }
+        f32x4 w = raw_f32(vy[u][m]);
+        const int cos = cy[m] ? (mt0 + m) * 16 + j * 4 : 0;
+        const int gp = (b * A.Hout + oy0 + 2 * u + yr0) * A.Wout + ox0 + yc;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) w[k] *= lmn_drop_scale(A.dy_seed + soff, (uint32_t)(gp * A.Cout + cos + k), A.dy_p, P.inv_keep_dy);
+        if constexpr (BF) *reinterpret_cast<uint2*>(dst) = pk4_bf16(w);
+        else *reinterpret_cast<f32x4*>(dst) = w;
+      }
+    }
+  };
+
+  const int t_begin = (int)(((int64_t)blockIdx.x * P.total_tiles) / gridDim.x);
+  const int t_end = (int)(((int64_t)(blockIdx.x + 1) * P.total_tiles) / gridDim.x);
+#ifdef LMN_WG_TIMING
+  unsigned long long tk0 = LMN_TCLK(), tk_s1 = 0, tk_s2 = 0, tk_s3 = 0, tk_a, tk_b;
+#endif
+  if (t_begin < t_end) issue(t_begin);
+  const int K0 = TS ? 0 : wv, KSTEP = TS ? 1 : 4;
+  for (int tile = t_begin; tile < t_end; ++tile) {
+#ifdef LMN_WG_TIMING
+    tk_a = LMN_TCLK();
+#endif
+    __syncthreads();  // previous tile's reads are done
+#ifdef LMN_WG_TIMING
+    tk_b = LMN_TCLK(); tk_s1 += tk_b - tk_a; tk_a = tk_b;
+#endif
+    commit(tile);
+#ifdef LMN_WG_TIMING
+    __builtin_amdgcn_s_waitcnt(0);
+    tk_b = LMN_TCLK(); tk_s2 += tk_b - tk_a; tk_a = tk_b;
+#endif
+    __syncthreads();
+    if (tile + 1 < t_end) issue(tile + 1);
+#ifdef LMN_WG_TIMING
+    tk_b = LMN_TCLK(); tk_s3 += tk_b - tk_a;
+#endif
+    if constexpr (BF) {
+      // K steps of 16 consecutive tile pixels; lane (q, n) owns pixels 4q..4q+3 of the step, channel n
+      const uint16_t* xw = reinterpret_cast<const uint16_t*>(XS) + (t_w * XPA + q * 4) * (CS * 2) + n;
+      const uint16_t* yw = reinterpret_cast<const uint16_t*>(YS) + (m_w * NPA + q * 4) * (CS * 2) + n;
+      for (int ks = K0; ks * 16 < NP; ks += KSTEP) {
+        const int pix0 = ks * 16, pr = pix0 >> 5, pc0 = pix0 & 31;
+        const uint16_t* xp = xw + (pr * XWC + pc0) * (CS * 2);
+        const uint16_t* yp = yw + pix0 * (CS * 2);
+        uint32_t h[4];
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+          h[jj] = yp[jj * CS * 2];
+          bsum += __builtin_bit_cast(float, h[jj] << 16);
+        }
+        const uint2 av = uint2{h[0] | (h[1] << 16), h[2] | (h[3] << 16)};
+        uint2 bv[9];
+#pragma unroll
+        for (int tp = 0; tp < 9; ++tp) {
+          const uint16_t* xt = xp + ((tp / 3) * XWC + tp % 3) * (CS * 2);
+          const uint32_t h0 = xt[0], h1 = xt[CS * 2], h2 = xt[2 * CS * 2], h3 = xt[3 * CS * 2];
+          bv[tp] = uint2{h0 | (h1 << 16), h2 | (h3 << 16)};
+        }
+#pragma unroll
+        for (int tp = 0; tp < 9; ++tp) acc[tp] = mfma_bf16(av, bv[tp], acc[tp]);
+      }
+    } else {
+      const float* xw = XS + (t_w * XPA + q) * CS + n;
+      const float* yw = YS + (m_w * NPA + q) * CS + n;
+      for (int ks = K0; ks * 4 < NP; ks += KSTEP) {
+        const int pix0 = ks * 4, pr = pix0 >> 5, pc0 = pix0 & 31;
+        const float* xp = xw + (pr * XWC + pc0) * CS;
+        const float av = yw[pix0 * CS];
+        float bv[9];
+#pragma unroll
+        for (int tp = 0; tp < 9; ++tp) bv[tp] = xp[((tp / 3) * XWC + tp % 3) * CS];
+        bsum += av;
+#pragma unroll
+        for (int tp = 0; tp < 9; ++tp) acc[tp] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv[tp], acc[tp], 0, 0, 0);
+      }
+    }
+  }
+#ifdef LMN_WG_TIMING
+  {
+    const unsigned long long tk_e = LMN_TCLK();
+    const int bid = blockIdx.y * gridDim.x + blockIdx.x;
+    if (tid == 0 && bid < 4096) {
+      g_wg_timing[bid * 6 + 0] = tk_s1;
+      g_wg_timing[bid * 6 + 1] = tk_s2;
+      g_wg_timing[bid * 6 + 2] = tk_s3;
+      g_wg_timing[bid * 6 + 3] = tk_e - tk0 - tk_s1 - tk_s2 - tk_s3;
+      g_wg_timing[bid * 6 + 4] = tk0;
+      g_wg_timing[bid * 6 + 5] = tk_e;
+    }
+  }
+#endif
+
+  constexpr int NT = 9 * NMT * NNT;
+  float* pdst = P.partial ? P.partial + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * (NT * 256 + NMT * 16) : nullptr;
+  if constexpr (TS) {
+    // every wave holds the finished sums of ITS tile: straight to the block partial (the layout of the LDS-reduced form:
+    // [tap][m][t][r][lane], then the bias sums) or to dW
+    const int nt = nt0 + t_w;
+    int sidx = 0;
+    while (sidx + 1 < A.nsrc && nt >= P.ntile_off[sidx + 1]) ++sidx;
+    const int ch = (nt - P.ntile_off[sidx]) * 16 + n;
+#pragma unroll
+    for (int tp = 0; tp < 9; ++tp)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        if (pdst) {
+          pdst[(((tp * NMT + m_w) * NNT + t_w) * 4 + r) * 64 + lane] = acc[tp][r];
+        } else {
+          const int co = (mt0 + m_w) * 16 + q * 4 + r;
+          if ((mt0 + m_w) < P.NMTT && co < A.Cout && nt < P.NNTT && ch < A.src[sidx].C)
+            atomicAdd(wgrad_dst(P, co, sidx, ch, 9) + tp, acc[tp][r]);
+        }
+      }
+    if (t_w == 0) {
+      float v = bsum;
+      v += __shfl_xor(v, 16, 64);
+      v += __shfl_xor(v, 32, 64);
+      if (q == 0) {
+        const int co = (mt0 + m_w) * 16 + n;
+        if (pdst) pdst[NT * 256 + m_w * 16 + n] = v;
+        else if (A.db && nset == 0 && co < A.Cout && (mt0 + m_w) < P.NMTT) {
+          atomicAdd(A.db + co, v);
+          if (A.db2) atomicAdd(A.db2 + co, v);
+        }
+      }
+    }
+    return;
+  }
+  // one-tile blocks: the four waves hold K-split partial sums of the same tile -- reduce in LDS in four wave rounds
+  __syncthreads();
+  float* s_acc = smem;
+  for (int w = 0; w < 4; ++w) {
+    if (wv == w) {
+#pragma unroll
+      for (int tp = 0; tp < 9; ++tp)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float* d = &s_acc[(tp * 4 + r) * 64 + lane];
+          *d = (w == 0) ? acc[tp][r] : *d + acc[tp][r];
+        }
+      float v = bsum;
+      v += __shfl_xor(v, 16, 64);
+      v += __shfl_xor(v, 32, 64);
+      if (q == 0) {
+        float* d = &s_acc[NT * 256 + n];
+        *d = (w == 0) ? v : *d + v;
+      }
+    }
+    __syncthreads();
+  }
+  if (pdst) {
+    for (int i = tid; i < NT * 256 + 16; i += 256) pdst[i] = s_acc[i];
+    return;
+  }
+  for (int i = tid; i < NT * 256; i += 256) {
+    const int ln = i & 63, r = (i >> 6) & 3, tp = i >> 8;
+    const int co = mt0 * 16 + (ln >> 4) * 4 + r;
+    if (mt0 >= P.NMTT || co >= A.Cout || nt0 >= P.NNTT) continue;
+    int sidx = 0;
+    while (sidx + 1 < A.nsrc && nt0 >= P.ntile_off[sidx + 1]) ++sidx;
+    const int ch = (nt0 - P.ntile_off[sidx]) * 16 + (ln & 15);
+    if (ch >= A.src[sidx].C) continue;
+    atomicAdd(wgrad_dst(P, co, sidx, ch, 9) + tp, s_acc[i]);
+  }
+  if (A.db && nset == 0 && tid < 16) {
+    const int co = mt0 * 16 + tid;
+    if (co < A.Cout && mt0 < P.NMTT) {
+      atomicAdd(A.db + co, s_acc[NT * 256 + tid]);
+      if (A.db2) atomicAdd(A.db2 + co, s_acc[NT * 256 + tid]);
     }
   }
 }
@@ -1736,8 +1946,9 @@ static void wgrad_tile_shape(const lmn_wgrad_args_t& a, int nmtt, int nntt, int*
   *NMT = small ? 1 : 2; *NNT = small ? 1 : 2;  // LDS-staged kernel: (1,2)/(2,1) measured slower here
 }
 
-// 3x3 stride-1 layers run wgrad_lds_kernel<.., V = 1> (cross-tile prefetch, tile-split waves): ~140 VGPRs and <= 42 KB of
-// LDS per block, so THREE blocks are resident per CU and the K-split aims at 768 blocks instead of 512.
+// 3x3 stride-1 layers on maps >= 32 wide run wgrad3_kernel: <= 154 VGPRs and <= 48 KB of LDS per block, so THREE blocks are
+// resident per CU and the K-split aims at 768 blocks instead of 512.  LMN_WGRAD_V1=0 selects the
+// general kernel (A/B runs), LMN_WGRAD_CAP overrides the block count.
 static int wgrad_v1_env() {
   static int v = -1;
   if (v < 0) { const char* e = getenv("LMN_WGRAD_V1"); v = e ? atoi(e) : 1; }
@@ -1746,8 +1957,9 @@ static int wgrad_v1_env() {
 static bool wgrad_v1(const lmn_wgrad_args_t& a) { return a.ksize == 3 && a.stride == 1 && wgrad_v1_env() != 0; }
 static int wgrad_blocks_total(const lmn_wgrad_args_t& a) {
   static int c = -1;
-  if (c < 0) { const char* e = getenv("LMN_WGRAD_CAP"); c = e ? atoi(e) : 768; }
-  return wgrad_v1(a) ? c : 512;
+  if (c < 0) { const char* e = getenv("LMN_WGRAD_CAP"); c = e ? atoi(e) : 0; }
+  if (!wgrad_v1(a)) return 512;
+  return c > 0 ? c : 768;  // 3 resident blocks per CU (bf16 storage would fit 4: 1024 blocks measured 3 % slower, more partials)
 }
 
 int64_t lmn_conv_wgrad_workspace(const lmn_wgrad_args_t* a) {
@@ -2185,9 +2397,18 @@ int lmn_conv_wgrad(const lmn_wgrad_args_t* args, lmn_stream_t stream) {
   LMN_REQUIRE(lds_floats * 4 <= 160 * 1024, "conv_wgrad: LDS tile too large (%lld B)", (long long)lds_floats * 4);
   // K-split: enough blocks to fill the chip (~1024 in total), each walking a contiguous range of tiles
   int64_t blocks64 = P.total_tiles;
-  // V1: the whole tile's float4 items in the prefetch registers (6 + 4 per thread for one-tile, 4 + 2 for 2 x 2-tile blocks)
-  const bool v1 = v1c && P.TW == 32 && P.XW == 34 && P.CSx == P.CSy &&
-                  P.XH * P.XW * 4 <= (NMT * NNT == 1 ? 6 : 4) * 256 && P.TH * P.TW * 4 <= (NMT * NNT == 1 ? 4 : 2) * 256;
+  // wgrad3_kernel: the whole tile's items in the prefetch registers (6 + 4 per thread for one-tile, 4 + 2 for 2 x 2-tile
+  // blocks), byte offsets in 32 bits (raw buffer descriptors)
+  const int64_t esz = A.act_dtype == LMN_BF16 ? 2 : 4;
+  bool v1 = v1c && P.TW == 32 && P.XW == 34 &&
+            P.XH * P.XW * 4 <= (NMT * NNT == 1 ? 6 : 4) * 256 && P.TH * P.TW * 4 <= (NMT * NNT == 1 ? 4 : 2) * 256 &&
+            (int64_t)A.B * A.Hout * A.Wout * A.dy_cstride * esz < 0xfffffff0LL;
+  for (int s = 0; s < A.nsrc; ++s) v1 = v1 && (int64_t)A.B * A.Hin * A.Win * A.src[s].cstride * esz < 0xfffffff0LL;
+  if (v1) {  // padded planes: [tile][UX * 64 pixels][CS dwords]
+    const int ux = NMT * NNT == 1 ? 6 : 4, uy = NMT * NNT == 1 ? 4 : 2, cs = bf ? 12 : 16;
+    lds_floats = (int64_t)(NNT * ux + NMT * uy) * 64 * cs;
+    if (NMT * NNT == 1 && lds_floats < per) lds_floats = per;
+  }
   const int btot = v1 ? wgrad_blocks_total(A) : 512;
   const int64_t cap = btot / gy > 2 ? btot / gy : 2;
   if (blocks64 > cap) blocks64 = cap;
@@ -2212,14 +2433,9 @@ int lmn_conv_wgrad(const lmn_wgrad_args_t* args, lmn_stream_t stream) {
     }                                                                                                               \
     if constexpr (T == 9 && (M * N == 4 || M * N == 1)) {                                                           \
       if (v1) {                                                                                                     \
-        if (shmem > 64 * 1024) {                                                                                    \
-          (void)hipFuncSetAttribute((const void*)wgrad_lds_kernel<T, M, N, 0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem); \
-          (void)hipFuncSetAttribute((const void*)wgrad_lds_kernel<T, M, N, 1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem); \
-          (void)hipFuncSetAttribute((const void*)wgrad_lds_kernel<T, M, N, 2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem); \
-        }                                                                                                           \
-        if (pm == 2) LMN_LAUNCH((wgrad_lds_kernel<T, M, N, 2, 1>), grid, dim3(256), shmem, st, P);          \
-        else if (pm == 1) LMN_LAUNCH((wgrad_lds_kernel<T, M, N, 1, 1>), grid, dim3(256), shmem, st, P);     \
-        else LMN_LAUNCH((wgrad_lds_kernel<T, M, N, 0, 1>), grid, dim3(256), shmem, st, P);                  \
+        if (pm == 2) LMN_LAUNCH((wgrad3_kernel<M, N, 2>), grid, dim3(256), shmem, st, P);                   \
+        else if (pm == 1) LMN_LAUNCH((wgrad3_kernel<M, N, 1>), grid, dim3(256), shmem, st, P);              \
+        else LMN_LAUNCH((wgrad3_kernel<M, N, 0>), grid, dim3(256), shmem, st, P);                           \
         goto wg_reduce_##T##M##N;                                                                                   \
       }                                                                                                             \
     }                                                                                                               \

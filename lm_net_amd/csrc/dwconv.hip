@@ -20,30 +20,6 @@ namespace {
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-// Raw buffer access (bounds-checked by the descriptor: out-of-range loads return 0, stores are dropped).
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-typedef __amdgpu_buffer_rsrc_t BufRsrc;
-typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ BufRsrc make_rsrc(const void* base, unsigned bytes) {
-  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
-}
-// 4 consecutive channels of storage type TA (16 B of fp32 / 8 B of bf16) at a per-lane byte offset (range-checked)
-template <typename TA> __device__ __forceinline__ f32x4 buf_load4(BufRsrc r, unsigned byte_off) {
-  if constexpr (sizeof(TA) == 4) {
-    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_off, 0, 0));
-  } else {
-    const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(r, (int)byte_off, 0, 0);
-    return f32x4{lmn_bf16_lo(v.x), lmn_bf16_hi(v.x), lmn_bf16_lo(v.y), lmn_bf16_hi(v.y)};
-  }
-}
-template <typename TA> __device__ __forceinline__ void buf_store4(BufRsrc r, unsigned byte_off, f32x4 v) {
-  if constexpr (sizeof(TA) == 4) {
-    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, (int)byte_off, 0, 0);
-  } else {
-    __builtin_amdgcn_raw_buffer_store_b64(u32x2{lmn_pk_bf16(v[0], v[1]), lmn_pk_bf16(v[2], v[3])}, r, (int)byte_off, 0, 0);
-  }
-}
-
 // XCD-aware block order (guide T1, bijective form): consecutive LOGICAL tiles run on the same XCD, so the 2-pixel
 // halos shared by neighbouring tiles hit that XCD's L2 instead of being re-fetched from HBM by another XCD.
 __device__ __forceinline__ int xcd_swizzle(int bid, int nwg) {
