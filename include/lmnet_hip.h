@@ -413,7 +413,10 @@ int lmn_plan_run(lmn_plan_t plan, int64_t lo, int64_t hi); /* re-issue ops [lo, 
  * name contains one of the '|'-separated substrings of `filter` (NULL / "" = all kernels).  lmn_prof_end stops the timer,
  * synchronises the device and writes one line per kernel name: "name\tlaunches\ttotal_us\tflops\tbytes\n", where
  * flops / bytes are the ALGORITHMIC costs (layer shapes; SURVEY 8d convention) the conv / depthwise / attention entries
- * declare per launch.  Returns the number of bytes needed for the full report.                                        */
+ * declare per launch.  Returns the number of bytes needed for the full report.
+ * A filter that starts with '@' reports one line per (kernel, declared cost) -- i.e. per layer shape ("name#flops/bytes");
+ * one that starts with '!' reports one line per LAUNCH: "name\tstream\tstart_us\tend_us\t0\n" on the device clock of the
+ * first timed launch (events of different streams are comparable: the overlapped timeline of a step).               */
 int lmn_prof_begin(const char* filter);
 int64_t lmn_prof_end(char* out, int64_t cap);
 

@@ -56,6 +56,7 @@ int wait_with(hipEvent_t e, hipStream_t waiter, hipStream_t waited) {
 // ------------------------------------------------------------------------------------------------ kernel timer
 struct ProfRec {
   const char* name;  // string literal of the launch site
+  hipStream_t st;
   hipEvent_t e0, e1;
   double flops, bytes;
 };
@@ -65,6 +66,8 @@ struct Prof {
   std::vector<std::string> parts;
   std::vector<ProfRec> recs;
   std::vector<hipEvent_t> pool;
+  bool detail = false;  // filter began with '@': one line per (kernel, declared cost) = per layer shape
+  bool timeline = false;  // filter began with '!': one line per LAUNCH: name, stream, start and end (us after the first launch)
 } g_prof;
 thread_local double g_cost_flops = 0.0, g_cost_bytes = 0.0;
 thread_local hipEvent_t g_open_e1 = nullptr;
@@ -104,6 +107,7 @@ bool lmn_prof_start(const char* kernel, hipStream_t st) {
   }
   ProfRec r;
   r.name = kernel;
+  r.st = st;
   r.e0 = prof_event();
   r.e1 = prof_event();
   r.flops = fl;
@@ -221,6 +225,9 @@ int lmn_prof_begin(const char* filter) {
   g_prof.recs.clear();
   g_prof.parts.clear();
   g_prof.filter = filter ? filter : "";
+  g_prof.detail = !g_prof.filter.empty() && g_prof.filter[0] == '@';
+  g_prof.timeline = !g_prof.filter.empty() && g_prof.filter[0] == '!';
+  if (g_prof.detail || g_prof.timeline) g_prof.filter.erase(0, 1);
   size_t a = 0;
   while (a <= g_prof.filter.size() && !g_prof.filter.empty()) {
     size_t b = g_prof.filter.find('|', a);
@@ -239,6 +246,24 @@ int64_t lmn_prof_end(char* out, int64_t cap) {
   g_lmn_prof_on = 0;
   (void)hipDeviceSynchronize();
   std::lock_guard<std::mutex> lk(g_prof.mu);
+  std::string s;
+  char line[512];
+  if (g_prof.timeline && !g_prof.recs.empty()) {
+    // events of different streams share the device clock: everything relative to the first launch's start event
+    const hipEvent_t base = g_prof.recs.front().e0;
+    for (ProfRec& r : g_prof.recs) {
+      float a = 0.f, b = 0.f;
+      if (hipEventElapsedTime(&a, base, r.e0) != hipSuccess || hipEventElapsedTime(&b, base, r.e1) != hipSuccess) continue;
+      snprintf(line, sizeof(line), "%s\t%llx\t%.3f\t%.3f\t0\n", r.name, (unsigned long long)(uintptr_t)r.st, a * 1e3, b * 1e3);
+      s += line;
+    }
+    if (out && cap > 0) {
+      const size_t k = s.size() < (size_t)cap - 1 ? s.size() : (size_t)cap - 1;
+      memcpy(out, s.data(), k);
+      out[k] = 0;
+    }
+    return (int64_t)s.size() + 1;
+  }
   struct Agg { int64_t n = 0; double us = 0, fl = 0, by = 0; };
   std::map<std::string, Agg> agg;
   for (ProfRec& r : g_prof.recs) {
@@ -246,11 +271,14 @@ int64_t lmn_prof_end(char* out, int64_t cap) {
     if (hipEventElapsedTime(&ms, r.e0, r.e1) != hipSuccess) continue;
     std::string nm = r.name;
     if (!nm.empty() && nm.front() == '(' && nm.back() == ')') nm = nm.substr(1, nm.size() - 2);
+    if (g_prof.detail) {
+      char tag[96];
+      snprintf(tag, sizeof(tag), "#%.4e/%.4e", r.flops, r.bytes);
+      nm += tag;
+    }
     Agg& a = agg[nm];
     a.n += 1; a.us += ms * 1e3; a.fl += r.flops; a.by += r.bytes;
   }
-  std::string s;
-  char line[512];
   for (auto& kv : agg) {
     snprintf(line, sizeof(line), "%s\t%lld\t%.3f\t%.6e\t%.6e\n", kv.first.c_str(), (long long)kv.second.n, kv.second.us,
              kv.second.fl, kv.second.by);

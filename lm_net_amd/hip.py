@@ -721,3 +721,20 @@ def prof_end():
         name, n, us, fl, by = line.split("\t")
         out[name] = dict(launches=int(n), total_us=float(us), flops=float(fl), bytes=float(by))
     return out
+
+
+def prof_timeline():
+    """After prof_begin("!..."): -> [(kernel, stream, start_us, end_us)] per launch, on the device clock of the first launch."""
+    lib = load()
+    cap = 1 << 20
+    while True:
+        buf = C.create_string_buffer(cap)
+        need = int(lib.lmn_prof_end(buf, _i64(cap)))
+        if need <= cap:
+            break
+        cap = need + 16
+    out = []
+    for line in buf.value.decode().splitlines():
+        name, st, t0, t1, _ = line.split("\t")
+        out.append((name.strip("()"), int(st, 16), float(t0), float(t1)))
+    return out

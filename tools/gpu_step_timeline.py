@@ -1,0 +1,72 @@
+"""Overlapped timeline of training steps from the in-library timer (HIP events per launch on every stream; unlike rocprofv3's
+kernel trace this does not serialise the streams).
+
+    python tools/gpu_step_timeline.py [--batch 8] [--size 352] [--dtype f32|bf16] [--steps 2] [--no-plans]
+Prints: wall per step, time with 0 / 1 / 2+ kernels in flight, the largest idle gaps (kernels on either side) and the kernels
+that most often run alone."""
+import argparse, os, sys
+from collections import defaultdict
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+from bench import make_batch
+from lm_net_amd import LM_Net, hip
+from lm_net_amd.loss import SegLoss
+from lm_net_amd.optim import FusedAdamW
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--batch", type=int, default=8); ap.add_argument("--size", type=int, default=352)
+ap.add_argument("--dtype", default="f32"); ap.add_argument("--steps", type=int, default=2)
+ap.add_argument("--no-plans", action="store_true")
+a = ap.parse_args()
+dev = torch.device("cuda", 0)
+net = LM_Net(3, 2).to(dev).train()
+net.compute_dtype = "bf16" if a.dtype == "bf16" else "fp32"
+if not a.no_plans:
+    net.enable_plans()
+opt = FusedAdamW(net, lr=1e-3, weight_decay=1e-4)
+crit = SegLoss(label_smoothing=1e-3).to(dev)
+x, y = make_batch(a.batch, a.size, a.size, dev, 1234)
+def step():
+    loss = crit(net(x), y); opt.zero_grad(set_to_none=True); loss.backward(); opt.step()
+for _ in range(5): step()
+torch.cuda.synchronize()
+import time
+t0 = time.perf_counter()
+for _ in range(a.steps): step()
+torch.cuda.synchronize()
+wall = (time.perf_counter() - t0) / a.steps * 1e3
+hip.prof_begin("!")
+for _ in range(a.steps): step()
+tl = hip.prof_timeline()
+streams = sorted(set(r[1] for r in tl))
+sname = {s: "S%d" % i for i, s in enumerate(streams)}
+T0, T1 = min(r[2] for r in tl), max(r[3] for r in tl)
+print("untimed wall %.2f ms/step; timed %d launches over %.2f ms (%d steps: %.2f ms/step); %d streams (torch ops between the "
+      "library's launches are not timed: they show up as idle)" % (wall, len(tl), (T1 - T0) / 1e3, a.steps, (T1 - T0) / 1e3 / a.steps, len(streams)))
+ev = sorted([(r[2], 1, i) for i, r in enumerate(tl)] + [(r[3], -1, i) for i, r in enumerate(tl)])
+active, last, by_n, solo = set(), T0, defaultdict(float), defaultdict(float)
+gaps = []
+prev_end = None
+for t, d, i in ev:
+    if t > last:
+        by_n[min(len(active), 3)] += t - last
+        if len(active) == 1:
+            solo[tl[next(iter(active))][0]] += t - last
+        if len(active) == 0:
+            gaps.append((t - last, last, prev_end, i))
+    last = t
+    if d > 0: active.add(i)
+    else:
+        active.discard(i); prev_end = i
+print("kernels in flight (per step): " + ", ".join("%s: %.2f ms" % ("3+" if n == 3 else n, v / 1e3 / a.steps) for n, v in sorted(by_n.items())))
+for s in streams:
+    rs = [r for r in tl if r[1] == s]
+    print("  %s: %5d launches, busy %.2f ms/step" % (sname[s], len(rs) // a.steps, sum(r[3] - r[2] for r in rs) / 1e3 / a.steps))
+print("largest idle gaps:")
+for g, at, pe, nx in sorted(gaps, reverse=True)[:12]:
+    print("  %7.1f us at %8.2f ms: %s -> %s" % (g, (at - T0) / 1e3, tl[pe][0][:50] if pe is not None else "-", tl[nx][0][:50]))
+print("idle in gaps < 20 us: %.2f ms/step (%d gaps/step)" % (sum(g[0] for g in gaps if g[0] < 20) / 1e3 / a.steps, sum(1 for g in gaps if g[0] < 20) // a.steps))
+print("alone on the GPU (per step):")
+for k, v in sorted(solo.items(), key=lambda kv: -kv[1])[:25]:
+    print("  %-60s %8.1f us" % (k[:60], v / a.steps))

@@ -21,8 +21,8 @@ def main():
     ks = [t for t in tabs if t.startswith("rocpd_info_kernel_symbol")][0]
     cols = [r[1] for r in db.execute("pragma table_info(%s)" % kd)]
     qcol = "stream_id" if "stream_id" in cols else "queue_id"
-    rows = db.execute("select s.kernel_name, d.start, d.end, d.%s from %s d join %s s on d.kernel_id=s.id order by d.start"
-                      % (qcol, kd, ks)).fetchall()
+    rows = db.execute("select s.kernel_name, d.start, d.end, d.%s, (d.grid_size_x/d.workgroup_size_x)*(d.grid_size_y/d.workgroup_size_y)*(d.grid_size_z/d.workgroup_size_z) "
+                      "from %s d join %s s on d.kernel_id=s.id order by d.start" % (qcol, kd, ks)).fetchall()
     marks = [i for i, r in enumerate(rows) if "adamw_kernel" in r[0]]
     if len(marks) < 2:
         raise SystemExit("need >= 2 steps in the trace")
@@ -30,6 +30,22 @@ def main():
     step = rows[lo:hi]
     t0, t1 = step[0][1], max(r[2] for r in step)
     print("step: %d kernels, %.2f ms wall" % (len(step), (t1 - t0) / 1e6))
+    # occupancy of the GPU over the step: sweep over kernel start / end events
+    ev = sorted([(r[1], 1, i) for i, r in enumerate(step)] + [(r[2], -1, i) for i, r in enumerate(step)])
+    active, last, by_n, solo = set(), t0, defaultdict(int), defaultdict(int)
+    for t, d, i in ev:
+        if t > last:
+            by_n[len(active)] += t - last
+            if len(active) == 1:
+                k = step[next(iter(active))]
+                solo[(short(k[0]), k[4] < 256)] += t - last
+        last = t
+        active.add(i) if d > 0 else active.discard(i)
+    print("kernels in flight: " + ", ".join("%d: %.2f ms" % (n, v / 1e6) for n, v in sorted(by_n.items())))
+    small = sum(v for (k, sm), v in solo.items() if sm)
+    print("alone on the GPU with < 256 workgroups: %.2f ms; top:" % (small / 1e6))
+    for (k, sm), v in sorted(solo.items(), key=lambda kv: -kv[1])[:12]:
+        print("  %-60s %s %7.1f us alone" % (k, "small" if sm else "     ", v / 1e3))
     per = defaultdict(list)
     for r in step:
         per[r[3]].append(r)
