@@ -82,6 +82,7 @@ __device__ __forceinline__ f32x4 mfma_bf16(uint2 a, uint2 b, f32x4 c) {
 // stride-1 problem over dy with a 1x1 / 1x2 / 2x1 / 2x2 sub-kernel: in = out_c + ((parity + pad - t) >> 1) for the taps of
 // matching parity.  The tile walks CLASS coordinates, the window is TH+1 x TW+1 pixels of dy, outputs land at
 // (2*yc + py, 2*xc + px).
+#define LMN_SLOT c
 template <int TAPS, int NCT, int EPI, bool S2T = false, int PM = 0>
 __global__ __launch_bounds__(256) void conv_tile_kernel(const ConvParams P) {
   constexpr bool BF = PM >= 1;
@@ -130,6 +131,20 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(const ConvParams P) {
   for (int c = 0; c < NCT; ++c) wtile[c] = min(ct0 + c, P.NCTT - 1) * WT;
 
   for (int i = tid; i < 2 * NCT * 16; i += 256) s_stats[i] = 0.f;
+  // epilogue parameter vectors (bias, bias2, p0..p6) of this block's cout range, staged ONCE: in the tile loop every one of
+  // them was an L2 round trip inside a tile's serial chain (window load -> MFMA -> parameters -> math -> store), and the
+  // run-time branches around them serialised those round trips (LINEAR 49 us, AFFINE_ACT 59 us, BN_BWD2 123 us for the
+  // same 1x1 conv at level 0).  Absent vectors and channels past Cout read 0.
+  float* s_par = s_stats + 2 * NCT * 16;  // [9][NCT*16]
+  {
+    const float* const pv[9] = {A.bias, A.bias2, A.p0, A.p1, A.p2, A.p3, A.p4, A.p5, A.p6};
+#pragma unroll
+    for (int k = 0; k < 9; ++k)
+      for (int i = tid; i < NCT * 16; i += 256) {
+        const int co = ct0 * 16 + i;
+        s_par[k * NCT * 16 + i] = (pv[k] && co < A.Cout) ? pv[k][co] : 0.f;
+      }
+  }
   float st0[NCT][4], st1[NCT][4];
 #pragma unroll
   for (int c = 0; c < NCT; ++c)
@@ -187,6 +202,21 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(const ConvParams P) {
     for (int g = 0; g < 2; ++g)
 #pragma unroll
       for (int c = 0; c < NCT; ++c) acc[g][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // BN_BWD instances: the epilogue's second operand (aux: an output-shaped tensor) is requested HERE, ahead of the staging
+    // barrier -- its HBM latency runs beside that of the window instead of after the MFMAs (two exposed round trips per
+    // tile -> one; level 0, cold operands: BN_BWD1 102 -> 88 us, BN_BWD2 122 -> 105 us; SE_BWD measured slower with it)
+    constexpr bool AUXP = EPI == 3 || EPI == 4;
+    f32x4 axp[AUXP ? 2 : 1][AUXP ? NCT : 1];
+    if constexpr (AUXP) {
+#pragma unroll
+      for (int g = 0; g < 2; ++g)
+#pragma unroll
+        for (int c = 0; c < NCT; ++c) {
+          const int co = (ct0 + c) * 16 + q * 4;
+          const int cos = ((ct0 + c < P.NCTT) && co < A.Cout) ? co : 0;
+          axp[g][c] = A.aux ? ld4((const TA*)A.aux + (uint32_t)opix[g] * A.aux_cstride + cos) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    }
 
     for (int s = 0; s < A.nsrc; ++s) {
       const lmn_src_t& S = A.src[s];
@@ -284,31 +314,33 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(const ConvParams P) {
         const bool live = pvalid[g] && cok && (g == 0 || g1);
         const int cos = cok ? co : 0;
         f32x4 v = acc[g][c];
-        if (A.bias) v += ld4(A.bias + cos);
-        if (A.bias2) v += ld4(A.bias2 + cos);
+        const float* sp = s_par + LMN_SLOT * 16 + q * 4;
+#define LMN_PAR(k) (*reinterpret_cast<const f32x4*>(sp + (k) * NCT * 16))
+        v += LMN_PAR(0) + LMN_PAR(1);
         f32x4 o = v;
         if (EPI && st_mode == LMN_STATS_SUM_SQ && live) {
           // sums about p4[co] when given (the BatchNorm's running mean): E[x^2] - E[x]^2 then subtracts numbers of the
           // size of the variance, not of the squared mean
-          const f32x4 sh = A.p4 ? ld4(A.p4 + cos) : f32x4{0.f, 0.f, 0.f, 0.f};
+          const f32x4 sh = LMN_PAR(6);
 #pragma unroll
           for (int r = 0; r < 4; ++r) { const float d = v[r] - sh[r]; st0[c][r] += d; st1[c][r] += d * d; }
         }
         if (ep_kind == LMN_EP_AFFINE_ACT) {
-          const f32x4 s0 = ld4(A.p0 + cos), s1 = ld4(A.p1 + cos);
+          const f32x4 s0 = LMN_PAR(2), s1 = LMN_PAR(3);
 #pragma unroll
           for (int r = 0; r < 4; ++r) o[r] = lmn_act(v[r] * s0[r] + s1[r], A.act);
         }
         if (EPI) {
           f32x4 ax = f32x4{0.f, 0.f, 0.f, 0.f};
-          if (A.aux) ax = ld4((const TA*)A.aux + opx * A.aux_cstride + cos);
+          if constexpr (AUXP) ax = axp[g][c];
+          else if (A.aux) ax = ld4((const TA*)A.aux + opx * A.aux_cstride + cos);
           switch (ep_kind) {
             case LMN_EP_DGELU: {
 #pragma unroll
               for (int r = 0; r < 4; ++r) o[r] = v[r] * lmn_dgelu(ax[r]);
             } break;
             case LMN_EP_BN_BWD1: {
-              const f32x4 mu = ld4(A.p0 + cos), rs = ld4(A.p1 + cos), ga = ld4(A.p2 + cos), be = ld4(A.p3 + cos);
+              const f32x4 mu = LMN_PAR(2), rs = LMN_PAR(3), ga = LMN_PAR(4), be = LMN_PAR(5);
 #pragma unroll
               for (int r = 0; r < 4; ++r) {
                 const float zh = (v[r] - mu[r]) * rs[r];
@@ -317,10 +349,9 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(const ConvParams P) {
               }
             } break;
             case LMN_EP_BN_BWD2: {
-              const f32x4 mu = ld4(A.p0 + cos), rs = ld4(A.p1 + cos), c1 = ld4(A.p2 + cos), c2 = ld4(A.p3 + cos),
-                          c3 = ld4(A.p4 + cos);
+              const f32x4 mu = LMN_PAR(2), rs = LMN_PAR(3), c1 = LMN_PAR(4), c2 = LMN_PAR(5), c3 = LMN_PAR(6);
               if (A.p5) {  // aux is the gradient w.r.t. the ACTIVATED output: dh = aux * act'(gamma*zh + beta) formed here
-                const f32x4 ga = ld4(A.p5 + cos), be = ld4(A.p6 + cos);
+                const f32x4 ga = LMN_PAR(7), be = LMN_PAR(8);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                   const float zh = (v[r] - mu[r]) * rs[r];
@@ -388,6 +419,8 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(const ConvParams P) {
 // Each weight fragment is then fetched by exactly one wave of the block (the N-split form pulls every fragment
 // through L1 four times; at Cout = 372 that stream, not the MFMAs, set the pace) and feeds 8 x 4 MFMAs; the pixel
 // operand comes from LDS, where re-reading it per wave is cheap.
+#undef LMN_SLOT
+#define LMN_SLOT (wv + 4 * c)
 template <int TAPS, int NCW, int EPI, int PM = 0>
 __global__ __launch_bounds__(256) void conv_tileM_kernel(const ConvParams P) {
   constexpr bool BF = PM >= 1;
@@ -421,6 +454,20 @@ __global__ __launch_bounds__(256) void conv_tileM_kernel(const ConvParams P) {
   for (int c = 0; c < NCW; ++c) wtile[c] = min(ct0 + wv + 4 * c, P.NCTT - 1) * WT;
 
   for (int i = tid; i < 2 * NCT * 16; i += 256) s_stats[i] = 0.f;
+  // epilogue parameter vectors (bias, bias2, p0..p6) of this block's cout range, staged ONCE: in the tile loop every one of
+  // them was an L2 round trip inside a tile's serial chain (window load -> MFMA -> parameters -> math -> store), and the
+  // run-time branches around them serialised those round trips (LINEAR 49 us, AFFINE_ACT 59 us, BN_BWD2 123 us for the
+  // same 1x1 conv at level 0).  Absent vectors and channels past Cout read 0.
+  float* s_par = s_stats + 2 * NCT * 16;  // [9][NCT*16]
+  {
+    const float* const pv[9] = {A.bias, A.bias2, A.p0, A.p1, A.p2, A.p3, A.p4, A.p5, A.p6};
+#pragma unroll
+    for (int k = 0; k < 9; ++k)
+      for (int i = tid; i < NCT * 16; i += 256) {
+        const int co = ct0 * 16 + i;
+        s_par[k * NCT * 16 + i] = (pv[k] && co < A.Cout) ? pv[k][co] : 0.f;
+      }
+  }
   float st0[NCW][4], st1[NCW][4];
 #pragma unroll
   for (int c = 0; c < NCW; ++c)
@@ -568,18 +615,19 @@ __global__ __launch_bounds__(256) void conv_tileM_kernel(const ConvParams P) {
         const bool live = pvalid[g] && cok && g < P.NG;
         const int cos = cok ? co : 0;
         f32x4 v = acc[g][c];
-        if (A.bias) v += ld4(A.bias + cos);
-        if (A.bias2) v += ld4(A.bias2 + cos);
+        const float* sp = s_par + LMN_SLOT * 16 + q * 4;
+#define LMN_PAR(k) (*reinterpret_cast<const f32x4*>(sp + (k) * NCT * 16))
+        v += LMN_PAR(0) + LMN_PAR(1);
         f32x4 o = v;
         if (EPI && st_mode == LMN_STATS_SUM_SQ && live) {
           // sums about p4[co] when given (the BatchNorm's running mean): E[x^2] - E[x]^2 then subtracts numbers of the
           // size of the variance, not of the squared mean
-          const f32x4 sh = A.p4 ? ld4(A.p4 + cos) : f32x4{0.f, 0.f, 0.f, 0.f};
+          const f32x4 sh = LMN_PAR(6);
 #pragma unroll
           for (int r = 0; r < 4; ++r) { const float d = v[r] - sh[r]; st0[c][r] += d; st1[c][r] += d * d; }
         }
         if (ep_kind == LMN_EP_AFFINE_ACT) {
-          const f32x4 s0 = ld4(A.p0 + cos), s1 = ld4(A.p1 + cos);
+          const f32x4 s0 = LMN_PAR(2), s1 = LMN_PAR(3);
 #pragma unroll
           for (int r = 0; r < 4; ++r) o[r] = lmn_act(v[r] * s0[r] + s1[r], A.act);
         }
@@ -592,7 +640,7 @@ __global__ __launch_bounds__(256) void conv_tileM_kernel(const ConvParams P) {
               for (int r = 0; r < 4; ++r) o[r] = v[r] * lmn_dgelu(ax[r]);
             } break;
             case LMN_EP_BN_BWD1: {
-              const f32x4 mu = ld4(A.p0 + cos), rs = ld4(A.p1 + cos), ga = ld4(A.p2 + cos), be = ld4(A.p3 + cos);
+              const f32x4 mu = LMN_PAR(2), rs = LMN_PAR(3), ga = LMN_PAR(4), be = LMN_PAR(5);
 #pragma unroll
               for (int r = 0; r < 4; ++r) {
                 const float zh = (v[r] - mu[r]) * rs[r];
@@ -601,10 +649,9 @@ __global__ __launch_bounds__(256) void conv_tileM_kernel(const ConvParams P) {
               }
             } break;
             case LMN_EP_BN_BWD2: {
-              const f32x4 mu = ld4(A.p0 + cos), rs = ld4(A.p1 + cos), c1 = ld4(A.p2 + cos), c2 = ld4(A.p3 + cos),
-                          c3 = ld4(A.p4 + cos);
+              const f32x4 mu = LMN_PAR(2), rs = LMN_PAR(3), c1 = LMN_PAR(4), c2 = LMN_PAR(5), c3 = LMN_PAR(6);
               if (A.p5) {  // aux is the gradient w.r.t. the ACTIVATED output: dh = aux * act'(gamma*zh + beta) formed here
-                const f32x4 ga = ld4(A.p5 + cos), be = ld4(A.p6 + cos);
+                const f32x4 ga = LMN_PAR(7), be = LMN_PAR(8);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                   const float zh = (v[r] - mu[r]) * rs[r];
@@ -2205,7 +2252,7 @@ int lmn_conv_fwd(const lmn_conv_args_t* args, lmn_stream_t stream) {
     T.mTW = (uint32_t)((1ull << 32) / (uint32_t)T.TW + 1);
     T.mXW = (uint32_t)((1ull << 32) / (uint32_t)T.XW + 1);
     LMN_REQUIRE(T.XH * T.XW < 65536, "conv_fwd: window too large");
-    const size_t shmem = ((size_t)T.XH * T.XW * T.CS + 2 * tnct * 16) * sizeof(float);
+    const size_t shmem = ((size_t)T.XH * T.XW * T.CS + (2 + 9) * tnct * 16) * sizeof(float);  // window, statistics, epilogue parameters
     LMN_REQUIRE(shmem <= 64 * 1024, "conv_fwd: LDS window %zu B", shmem);
     int blocks = T.total_tiles;
     int maxb = 1280 / tchunks > 256 ? 1280 / tchunks : 256;  // ~5 resident blocks per CU: one round of persistent blocks
@@ -2225,7 +2272,7 @@ int lmn_conv_fwd(const lmn_conv_args_t* args, lmn_stream_t stream) {
       const int mmax = 2048 / mchunks > 256 ? 2048 / mchunks : 256;
       if (mblocks > mmax) mblocks = mmax;
       const dim3 mgrid(mblocks, mchunks);
-      const size_t msh = ((size_t)T.XH * T.XW * T.CS + 2 * 4 * ncw * 16) * sizeof(float);
+      const size_t msh = ((size_t)T.XH * T.XW * T.CS + (2 + 9) * 4 * ncw * 16) * sizeof(float);
 #define LMN_CM(TT, NN, BFV)                                                                              \
   do {                                                                                                   \
     switch ((TT) == 1 ? ek : (ek > 2 ? 1 : ek)) {                                                        \

@@ -10,7 +10,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "liblmnet_hip.so")
+LIB_PATH = os.environ.get("LMNET_HIP_LIB") or os.path.join(_HERE, "liblmnet_hip.so")   # (override: A/B runs against another build)
 
 # ---- constants mirrored from include/lmnet_hip.h
 SRC_GELU, SRC_DROP = 1, 2

@@ -24,14 +24,14 @@ pytestmark = pytest.mark.gpu
 TOL = 1e-4
 
 
-def _golden_step(name, tol_g=4e-3, tol_affine=1.2e-2):
+def _golden_step(name, tol_g=4e-3, tol_affine=2.5e-2):
     """One training step (batch-stat BatchNorm, dropout off) against tests/golden/<name>.npz: the REAL reference run in
     float64 on the same name-keyed weights / inputs (tools/make_golden_f64.py).  Tolerances: logits 1e-4 (north_star);
     gradients, on the sampled entries relative to the tensor's largest element: 4e-3 for weight tensors (measured worst
-    1.4e-3, tools/gpu_model_check.py ... f64) and 1.2e-2 for the 1-D parameters (BatchNorm / LayerNorm affine, biases:
-    dgamma = sum dh*zhat over 10^5..10^6 pixels cancels to ~1e-3 of its terms, so fp32 rounding of the TERMS already shows
-    at 5-6e-3, measured; the reference's own fp32 CPU autograd is at 1.3e-2 on the same entries); 2e-3 on every tensor's
-    L2 norm."""
+    1.4e-3, tools/gpu_model_check.py ... f64) and 2.5e-2 for the 1-D parameters (BatchNorm / LayerNorm affine, biases:
+    dgamma = sum dh*zhat over 10^5..10^6 pixels cancels to ~1e-3 of its terms, so fp32 rounding of the TERMS already shows:
+    5e-3 .. 1.3e-2 from run to run (the statistics are summed with float atomics in arrival order; 12 runs of the batch-2
+    case), and the reference's own fp32 CPU autograd is at 1.3e-2 on the same entries); 2e-3 on every tensor's L2 norm."""
     import numpy as np
     from lm_net_amd import LM_Net
     from helpers import load_golden
