@@ -138,12 +138,14 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(const ConvParams P) {
   float* s_par = s_stats + 2 * NCT * 16;  // [9][NCT*16]
   {
     const float* const pv[9] = {A.bias, A.bias2, A.p0, A.p1, A.p2, A.p3, A.p4, A.p5, A.p6};
+    for (int i = tid; i < NCT * 16; i += 256) {   // (NCT * 16 <= 256: one trip; the nine loads are in flight together)
+      const int co = ct0 * 16 + i;
+      float t[9];
 #pragma unroll
-    for (int k = 0; k < 9; ++k)
-      for (int i = tid; i < NCT * 16; i += 256) {
-        const int co = ct0 * 16 + i;
-        s_par[k * NCT * 16 + i] = (pv[k] && co < A.Cout) ? pv[k][co] : 0.f;
-      }
+      for (int k = 0; k < 9; ++k) t[k] = (pv[k] ? pv[k] : A.wpack)[(pv[k] && co < A.Cout) ? co : 0];  // absent vector: any valid address
+#pragma unroll
+      for (int k = 0; k < 9; ++k) s_par[k * NCT * 16 + i] = (pv[k] && co < A.Cout) ? t[k] : 0.f;
+    }
   }
   float st0[NCT][4], st1[NCT][4];
 #pragma unroll
@@ -231,31 +233,51 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(const ConvParams P) {
         }
         __syncthreads();  // previous chunk / tile fully consumed
         // ---- stage the window chunk: unconditional float4 loads from clamped addresses, transforms, zero padding
-        const int per_px = nkbc * 4;
-        for (int i = tid; i < P.XH * P.XW * per_px; i += 256) {
-          const int f = i % per_px, pix = i / per_px;
-          const int r = (int)__umulhi((uint32_t)pix, P.mXW), c = pix - r * P.XW;
-          const int iy = wy0 + r, ix = wx0 + c;
-          const int ch = kb0 * 16 + f * 4;
-          const bool ok = ch < S.C && (unsigned)iy < (unsigned)A.Hin && (unsigned)ix < (unsigned)A.Win;
-          const int gp = ok ? (b * A.Hin + iy) * A.Win + ix : 0;
-          const int chs = ok ? ch : 0;
-          f32x4 v = ld4((const TA*)S.ptr + (uint32_t)(gp * S.cstride + chs));
-          if (S.flags & LMN_SRC_GELU) {
+        //      Rounds of SU x 256 items: ALL loads of a round are issued before the first is consumed (the plain loop compiled
+        //      to load -> s_waitcnt vmcnt(0) -> write per item, i.e. 3-6 serial HBM round trips per 3x3 chunk).
+        const int psh = nkbc == 2 ? 3 : 2, per_px = 1 << psh;   // quads per pixel: 4 (one K16 block) or 8
+        const int nitems = P.XH * P.XW * per_px;
+        constexpr int SU = TAPS == 1 ? 1 : 4;  // items per thread and round (1x1: the extra registers cost more occupancy than the
+                                               // second round trip of a 128-pixel tile costs time -- measured on cold operands)
+        for (int i0 = 0; i0 < nitems; i0 += SU * 256) {
+          f32x4 sv[SU];
+          int sgp[SU];  // global pixel index, -1 = outside the image / past the channels / past the window
 #pragma unroll
-            for (int k = 0; k < 4; ++k) v[k] = lmn_gelu(v[k]);
+          for (int u = 0; u < SU; ++u) {
+            const int i = i0 + u * 256 + tid;
+            const int f = i & (per_px - 1), pix = i >> psh;
+            const int r = (int)__umulhi((uint32_t)pix, P.mXW), c = pix - r * P.XW;
+            const int iy = wy0 + r, ix = wx0 + c;
+            const int ch = kb0 * 16 + f * 4;
+            const bool ok = i < nitems && ch < S.C && (unsigned)iy < (unsigned)A.Hin && (unsigned)ix < (unsigned)A.Win;
+            const int gp = ok ? (b * A.Hin + iy) * A.Win + ix : 0;
+            sgp[u] = ok ? gp : -1;
+            sv[u] = ld4((const TA*)S.ptr + (uint32_t)(gp * S.cstride + (ok ? ch : 0)));
           }
-          if (S.flags & LMN_SRC_DROP) {
 #pragma unroll
-            for (int k = 0; k < 4; ++k) v[k] *= lmn_drop_scale(S.drop_seed + soff, (uint32_t)(gp * S.C + chs + k), S.drop_p, P.inv_keep_src[s]);
-          }
-          if (S.scale) v *= ld4(S.scale + b * S.C + chs);
-          if (!ok) v = f32x4{0.f, 0.f, 0.f, 0.f};
-          if constexpr (BF) {  // natural channel order, 4 bf16 = one 8-byte fragment slot
-            *reinterpret_cast<uint2*>(&XS[pix * P.CS + f * 2]) = pk4_bf16(v);
-          } else {  // blocked K layout: channel 4*fl + r of its K16 block sits at position 4*r + fl (MFMA j reads channel 4j + q)
-            float* d = &XS[pix * P.CS + (f >> 2) * 16 + (f & 3)];
-            d[0] = v[0]; d[4] = v[1]; d[8] = v[2]; d[12] = v[3];
+          for (int u = 0; u < SU; ++u) {
+            const int i = i0 + u * 256 + tid;
+            if (i >= nitems) continue;
+            const int f = i & (per_px - 1), pix = i >> psh;
+            const bool ok = sgp[u] >= 0;
+            const int gp = ok ? sgp[u] : 0, chs = ok ? kb0 * 16 + f * 4 : 0;
+            f32x4 v = sv[u];
+            if (S.flags & LMN_SRC_GELU) {
+#pragma unroll
+              for (int k = 0; k < 4; ++k) v[k] = lmn_gelu(v[k]);
+            }
+            if (S.flags & LMN_SRC_DROP) {
+#pragma unroll
+              for (int k = 0; k < 4; ++k) v[k] *= lmn_drop_scale(S.drop_seed + soff, (uint32_t)(gp * S.C + chs + k), S.drop_p, P.inv_keep_src[s]);
+            }
+            if (S.scale) v *= ld4(S.scale + b * S.C + chs);
+            if (!ok) v = f32x4{0.f, 0.f, 0.f, 0.f};
+            if constexpr (BF) {  // natural channel order, 4 bf16 = one 8-byte fragment slot
+              *reinterpret_cast<uint2*>(&XS[pix * P.CS + f * 2]) = pk4_bf16(v);
+            } else {  // blocked K layout: channel 4*fl + r of its K16 block sits at position 4*r + fl (MFMA j reads channel 4j + q)
+              float* d = &XS[pix * P.CS + (f >> 2) * 16 + (f & 3)];
+              d[0] = v[0]; d[4] = v[1]; d[8] = v[2]; d[12] = v[3];
+            }
           }
         }
         __syncthreads();
@@ -461,12 +483,14 @@ __global__ __launch_bounds__(256) void conv_tileM_kernel(const ConvParams P) {
   float* s_par = s_stats + 2 * NCT * 16;  // [9][NCT*16]
   {
     const float* const pv[9] = {A.bias, A.bias2, A.p0, A.p1, A.p2, A.p3, A.p4, A.p5, A.p6};
+    for (int i = tid; i < NCT * 16; i += 256) {   // (NCT * 16 <= 256: one trip; the nine loads are in flight together)
+      const int co = ct0 * 16 + i;
+      float t[9];
 #pragma unroll
-    for (int k = 0; k < 9; ++k)
-      for (int i = tid; i < NCT * 16; i += 256) {
-        const int co = ct0 * 16 + i;
-        s_par[k * NCT * 16 + i] = (pv[k] && co < A.Cout) ? pv[k][co] : 0.f;
-      }
+      for (int k = 0; k < 9; ++k) t[k] = (pv[k] ? pv[k] : A.wpack)[(pv[k] && co < A.Cout) ? co : 0];  // absent vector: any valid address
+#pragma unroll
+      for (int k = 0; k < 9; ++k) s_par[k * NCT * 16 + i] = (pv[k] && co < A.Cout) ? t[k] : 0.f;
+    }
   }
   float st0[NCW][4], st1[NCW][4];
 #pragma unroll
@@ -538,31 +562,51 @@ __global__ __launch_bounds__(256) void conv_tileM_kernel(const ConvParams P) {
         }
         __syncthreads();  // previous chunk / tile fully consumed
         // ---- stage the window chunk: unconditional float4 loads from clamped addresses, transforms, zero padding
-        const int per_px = nkbc * 4;
-        for (int i = tid; i < P.XH * P.XW * per_px; i += 256) {
-          const int f = i % per_px, pix = i / per_px;
-          const int r = (int)__umulhi((uint32_t)pix, P.mXW), c = pix - r * P.XW;
-          const int iy = wy0 + r, ix = wx0 + c;
-          const int ch = kb0 * 16 + f * 4;
-          const bool ok = ch < S.C && (unsigned)iy < (unsigned)A.Hin && (unsigned)ix < (unsigned)A.Win;
-          const int gp = ok ? (b * A.Hin + iy) * A.Win + ix : 0;
-          const int chs = ok ? ch : 0;
-          f32x4 v = ld4((const TA*)S.ptr + (uint32_t)(gp * S.cstride + chs));
-          if (S.flags & LMN_SRC_GELU) {
+        //      Rounds of SU x 256 items: ALL loads of a round are issued before the first is consumed (the plain loop compiled
+        //      to load -> s_waitcnt vmcnt(0) -> write per item, i.e. 3-6 serial HBM round trips per 3x3 chunk).
+        const int psh = nkbc == 2 ? 3 : 2, per_px = 1 << psh;   // quads per pixel: 4 (one K16 block) or 8
+        const int nitems = P.XH * P.XW * per_px;
+        constexpr int SU = TAPS == 1 ? 1 : 4;  // items per thread and round (1x1: the extra registers cost more occupancy than the
+                                               // second round trip of a 128-pixel tile costs time -- measured on cold operands)
+        for (int i0 = 0; i0 < nitems; i0 += SU * 256) {
+          f32x4 sv[SU];
+          int sgp[SU];  // global pixel index, -1 = outside the image / past the channels / past the window
 #pragma unroll
-            for (int k = 0; k < 4; ++k) v[k] = lmn_gelu(v[k]);
+          for (int u = 0; u < SU; ++u) {
+            const int i = i0 + u * 256 + tid;
+            const int f = i & (per_px - 1), pix = i >> psh;
+            const int r = (int)__umulhi((uint32_t)pix, P.mXW), c = pix - r * P.XW;
+            const int iy = wy0 + r, ix = wx0 + c;
+            const int ch = kb0 * 16 + f * 4;
+            const bool ok = i < nitems && ch < S.C && (unsigned)iy < (unsigned)A.Hin && (unsigned)ix < (unsigned)A.Win;
+            const int gp = ok ? (b * A.Hin + iy) * A.Win + ix : 0;
+            sgp[u] = ok ? gp : -1;
+            sv[u] = ld4((const TA*)S.ptr + (uint32_t)(gp * S.cstride + (ok ? ch : 0)));
           }
-          if (S.flags & LMN_SRC_DROP) {
 #pragma unroll
-            for (int k = 0; k < 4; ++k) v[k] *= lmn_drop_scale(S.drop_seed + soff, (uint32_t)(gp * S.C + chs + k), S.drop_p, P.inv_keep_src[s]);
-          }
-          if (S.scale) v *= ld4(S.scale + b * S.C + chs);
-          if (!ok) v = f32x4{0.f, 0.f, 0.f, 0.f};
-          if constexpr (BF) {  // natural channel order, 4 bf16 = one 8-byte fragment slot
-            *reinterpret_cast<uint2*>(&XS[pix * P.CS + f * 2]) = pk4_bf16(v);
-          } else {  // blocked K layout: channel 4*fl + r of its K16 block sits at position 4*r + fl (MFMA j reads channel 4j + q)
-            float* d = &XS[pix * P.CS + (f >> 2) * 16 + (f & 3)];
-            d[0] = v[0]; d[4] = v[1]; d[8] = v[2]; d[12] = v[3];
+          for (int u = 0; u < SU; ++u) {
+            const int i = i0 + u * 256 + tid;
+            if (i >= nitems) continue;
+            const int f = i & (per_px - 1), pix = i >> psh;
+            const bool ok = sgp[u] >= 0;
+            const int gp = ok ? sgp[u] : 0, chs = ok ? kb0 * 16 + f * 4 : 0;
+            f32x4 v = sv[u];
+            if (S.flags & LMN_SRC_GELU) {
+#pragma unroll
+              for (int k = 0; k < 4; ++k) v[k] = lmn_gelu(v[k]);
+            }
+            if (S.flags & LMN_SRC_DROP) {
+#pragma unroll
+              for (int k = 0; k < 4; ++k) v[k] *= lmn_drop_scale(S.drop_seed + soff, (uint32_t)(gp * S.C + chs + k), S.drop_p, P.inv_keep_src[s]);
+            }
+            if (S.scale) v *= ld4(S.scale + b * S.C + chs);
+            if (!ok) v = f32x4{0.f, 0.f, 0.f, 0.f};
+            if constexpr (BF) {  // natural channel order, 4 bf16 = one 8-byte fragment slot
+              *reinterpret_cast<uint2*>(&XS[pix * P.CS + f * 2]) = pk4_bf16(v);
+            } else {  // blocked K layout: channel 4*fl + r of its K16 block sits at position 4*r + fl (MFMA j reads channel 4j + q)
+              float* d = &XS[pix * P.CS + (f >> 2) * 16 + (f & 3)];
+              d[0] = v[0]; d[4] = v[1]; d[8] = v[2]; d[12] = v[3];
+            }
           }
         }
         __syncthreads();

@@ -1,5 +1,7 @@
-"""Conv family micro-benchmark at the LM-Net layer shapes (B=8, 352x352): forward and data-gradient launches.
-    python tools/gpu_conv_bench.py [bf16]          (LMN_CONV_PIPE=0|1 selects the tile-kernel form)"""
+"""Conv family micro-benchmark at the LM-Net layer shapes (B=8, 352x352): forward and data-gradient launches, on COLD
+operands (every call works on the next of NSET tensor sets, together larger than the 256 MB memory-side cache -- as the
+layers of a training step do; NSET=1 python tools/gpu_conv_bench.py gives the hot-cache numbers).
+    python tools/gpu_conv_bench.py [bf16]"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -16,6 +18,7 @@ def timeit(fn, iters=30, warm=5):
     return e0.elapsed_time(e1) / iters * 1e-3
 
 B = 8
+NSET = int(os.environ.get("NSET", "6"))
 if len(sys.argv) > 1 and sys.argv[1] == "bf16":
     hip._MMA[0] = hip.BF16
 L = [("L0 1x1 4->24", 352, [4], 24, 1, 1), ("L0 1x1 12->24", 352, [12], 24, 1, 1), ("L0 1x1 24+12->12", 352, [24, 12], 12, 1, 1),
@@ -30,21 +33,29 @@ L = [("L0 1x1 4->24", 352, [4], 24, 1, 1), ("L0 1x1 12->24", 352, [12], 24, 1, 1
 tot_f = tot_t = 0.0
 for name, H, cins, cout, k, s in L:
     cin = sum(cins)
-    xs = [torch.randn(B, H, H, c, device="cuda") for c in cins]
+    Ho = (H + 2 * (k // 2) - k) // s + 1
+    one = (B * H * H * cin + B * Ho * Ho * cout) * 4
+    nset = max(1, min(NSET, int(1.2e9 // one)))
+    xss = [[torch.randn(B, H, H, c, device="cuda") for c in cins] for _ in range(nset)]
     w = torch.randn(cout, cin, k, k, device="cuda")
     wp = hip.conv_pack(w, k, cins)
-    Ho = (H + 2 * (k // 2) - k) // s + 1
-    out = torch.empty(B, Ho, Ho, cout, device="cuda")
-    t = timeit(lambda: hip.conv_fwd(xs, wp, out, B=B, Hin=H, Win=H, Hout=Ho, Wout=Ho, Cout=cout, ksize=k, stride=s))
+    outs = [torch.empty(B, Ho, Ho, cout, device="cuda") for _ in range(nset)]
+    ctr = [0]
+    def fwd():
+        ctr[0] = (ctr[0] + 1) % nset
+        hip.conv_fwd(xss[ctr[0]], wp, outs[ctr[0]], B=B, Hin=H, Win=H, Hout=Ho, Wout=Ho, Cout=cout, ksize=k, stride=s)
+    xs, out = xss[0], outs[0]
+    t = timeit(fwd)
     fl = 2.0 * B * Ho * Ho * cout * cin * k * k
     by = (sum(x.numel() for x in xs) + out.numel()) * 4
     line = "%-22s fwd %7.1f us %6.1f TF %6.0f GB/s" % (name, t * 1e6, fl / t / 1e12, by / t / 1e9)
     tot_f += t
     if len(cins) == 1 and s == 1:
-        dy = torch.randn_like(out)
         wpt = hip.conv_pack_t(w, k)
-        dx = torch.empty_like(xs[0])
-        t2 = timeit(lambda: hip.conv_fwd([dy], wpt, dx, B=B, Hin=Ho, Win=Ho, Hout=H, Wout=H, Cout=cin, ksize=k, stride=s, transposed=1))
+        def bwd():  # dy = an output buffer, dx = an input buffer of the next set
+            ctr[0] = (ctr[0] + 1) % nset
+            hip.conv_fwd([outs[ctr[0]]], wpt, xss[ctr[0]][0], B=B, Hin=Ho, Win=Ho, Hout=H, Wout=H, Cout=cin, ksize=k, stride=s, transposed=1)
+        t2 = timeit(bwd)
         line += "   dgrad %7.1f us %6.1f TF" % (t2 * 1e6, fl / t2 / 1e12)
         tot_t += t2
     print(line)
