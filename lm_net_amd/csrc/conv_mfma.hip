@@ -83,8 +83,13 @@ __device__ __forceinline__ f32x4 mfma_bf16(uint2 a, uint2 b, f32x4 c) {
 // matching parity.  The tile walks CLASS coordinates, the window is TH+1 x TW+1 pixels of dy, outputs land at
 // (2*yc + py, 2*xc + px).
 #define LMN_SLOT c
-template <int TAPS, int NCT, int EPI, bool S2T = false, int PM = 0>
+// WL (3x3): the packed weight fragments of a chunk (9 taps x <= 2 K16 blocks x NCT cout tiles) are staged in LDS -- once per
+// block when the layer is a single chunk -- and the MFMA loop reads its A operands with ds_read_b128.  Fetched from L2 one
+// step ahead, a fragment had 6-16 MFMAs (200-500 cycles) to arrive in: every step of the small-channel layers stalled on it
+// (phase clocks: the MFMA loop was 52-61 % of a block's life at 35 % MFMA-pipe use).
+template <int TAPS, int NCT, int EPI, bool S2T = false, int PM = 0, bool WL = false>
 __global__ __launch_bounds__(256) void conv_tile_kernel(const ConvParams P) {
+  static_assert(!WL || (TAPS == 9 && !S2T), "LDS-staged weights: 3x3 stride-1 windows");
   constexpr bool BF = PM >= 1;
   typedef typename ActT<PM>::type TA;   // activation storage type
   // BF: operands rounded to bf16 when they are staged / packed, v_mfma_f32_16x16x16_bf16 (8x the fp32 MFMA rate), the LDS
@@ -147,6 +152,20 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(const ConvParams P) {
       for (int k = 0; k < 9; ++k) s_par[k * NCT * 16 + i] = (pv[k] && co < A.Cout) ? t[k] : 0.f;
     }
   }
+  float* s_w = s_par + 9 * NCT * 16;  // WL: [tap * nkbc + kk][NCT][WT]
+  auto stage_w = [&](int s, int kb0, int nkbc) __attribute__((always_inline)) {
+    constexpr int Q = WT / 4;  // float4 per fragment tile (64 lanes x 16 or 8 bytes)
+    const int ksh = nkbc - 1;
+    for (int i = tid; i < TAPS * nkbc * NCT * Q; i += 256) {
+      const int t = i / Q, l = i - t * Q;
+      const int tk = t / NCT, c = t - tk * NCT;
+      const int tap = tk >> ksh, kk = tk & ksh;
+      const float* src = A.wpack + (((int64_t)tap * P.NKB + P.kb_off[s] + kb0 + kk) * P.NCTT + min(ct0 + c, P.NCTT - 1)) * WT + l * 4;
+      *reinterpret_cast<f32x4*>(&s_w[t * WT + l * 4]) = *reinterpret_cast<const f32x4*>(src);
+    }
+  };
+  const bool wonce = WL && A.nsrc == 1 && P.nkb[0] <= P.CKB;  // single-chunk layer: the block's weights are staged once
+  if (wonce) stage_w(0, 0, P.nkb[0]);
   float st0[NCT][4], st1[NCT][4];
 #pragma unroll
   for (int c = 0; c < NCT; ++c)
@@ -226,12 +245,15 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(const ConvParams P) {
         const int nkbc = P.nkb[s] - kb0 < P.CKB ? P.nkb[s] - kb0 : P.CKB;
         const int ksh = nkbc - 1, niter = (S2T ? s2_n : TAPS) * nkbc;  // step it = (tap, kk): tap = it >> ksh, kk = it & ksh (nkbc is 1 or 2)
         wfrag wcur[NCT];
-        {
+        if constexpr (!WL) {
           const float* wp = wlane + (((int64_t)(S2T ? s2_wt[0] : 0) * P.NKB + P.kb_off[s] + kb0) * P.NCTT) * WT;
 #pragma unroll
           for (int c = 0; c < NCT; ++c) wcur[c] = ldfrag<BF>(wp + wtile[c]);
         }
         __syncthreads();  // previous chunk / tile fully consumed
+        if constexpr (WL) {
+          if (!wonce) stage_w(s, kb0, nkbc);
+        }
         // ---- stage the window chunk: unconditional float4 loads from clamped addresses, transforms, zero padding
         //      Rounds of SU x 256 items: ALL loads of a round are issued before the first is consumed (the plain loop compiled
         //      to load -> s_waitcnt vmcnt(0) -> write per item, i.e. 3-6 serial HBM round trips per 3x3 chunk).
@@ -286,7 +308,10 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(const ConvParams P) {
         for (int it = 0; it < niter; ++it) {
           const int itn = it + 1 < niter ? it + 1 : it;
           wfrag wnext[NCT];
-          {
+          if constexpr (WL) {
+#pragma unroll
+            for (int c = 0; c < NCT; ++c) wcur[c] = ldfrag<BF>(&s_w[(it * NCT + c) * WT + lane * (BF ? 2 : 4)]);
+          } else {
             const int tapi = itn >> ksh, kkn = itn & ksh;
             const int tapn = S2T ? s2_wt[tapi & 3] : tapi;
             const float* wp = wlane + (((int64_t)tapn * P.NKB + P.kb_off[s] + kb0 + kkn) * P.NCTT) * WT;
@@ -319,8 +344,10 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(const ConvParams P) {
             }
           }
           }
+          if constexpr (!WL) {
 #pragma unroll
-          for (int c = 0; c < NCT; ++c) wcur[c] = wnext[c];
+            for (int c = 0; c < NCT; ++c) wcur[c] = wnext[c];
+          }
         }
       }
     }
@@ -2296,7 +2323,14 @@ int lmn_conv_fwd(const lmn_conv_args_t* args, lmn_stream_t stream) {
     T.mTW = (uint32_t)((1ull << 32) / (uint32_t)T.TW + 1);
     T.mXW = (uint32_t)((1ull << 32) / (uint32_t)T.XW + 1);
     LMN_REQUIRE(T.XH * T.XW < 65536, "conv_fwd: window too large");
-    const size_t shmem = ((size_t)T.XH * T.XW * T.CS + (2 + 9) * tnct * 16) * sizeof(float);  // window, statistics, epilogue parameters
+    size_t shmem = ((size_t)T.XH * T.XW * T.CS + (2 + 9) * tnct * 16) * sizeof(float);  // window, statistics, epilogue parameters
+    // LDS-staged weights (3x3 tile kernel) while the block stays within LMN_CONV_WL_KB of LDS (default 32: 5 blocks per CU; level-0
+    // 12 -> 12: 62 -> 52 us on cold operands; at 48 KB the 24-channel layers lose more to occupancy than they gain)
+    static int wl_kb = -1;
+    if (wl_kb < 0) { const char* e = getenv("LMN_CONV_WL_KB"); wl_kb = e ? atoi(e) : 32; }
+    const size_t wl_bytes = (size_t)9 * T.CKB * tnct * (a.mma_dtype == LMN_BF16 ? 128 : 256) * sizeof(float);
+    const bool wlk = a.ksize == 3 && !s2t && shmem + wl_bytes <= (size_t)wl_kb * 1024;
+    if (wlk) shmem += wl_bytes;
     LMN_REQUIRE(shmem <= 64 * 1024, "conv_fwd: LDS window %zu B", shmem);
     int blocks = T.total_tiles;
     int maxb = 1280 / tchunks > 256 ? 1280 / tchunks : 256;  // ~5 resident blocks per CU: one round of persistent blocks
@@ -2356,12 +2390,15 @@ int lmn_conv_fwd(const lmn_conv_args_t* args, lmn_stream_t stream) {
 #define LMN_CT(TT, NN, BFV)                                                                              \
   do {                                                                                                   \
     switch ((TT) == 1 ? ek : (ek > 2 ? 1 : ek)) {                                                        \
-      case 0: LMN_LAUNCH((conv_tile_kernel<TT, NN, 0, false, BFV>), grid, dim3(256), shmem, st, T); break;   \
-      case 2: LMN_LAUNCH((conv_tile_kernel<TT, NN, 2, false, BFV>), grid, dim3(256), shmem, st, T); break;   \
+      case 0: if ((TT) == 9 && wlk) LMN_LAUNCH((conv_tile_kernel<9, NN, 0, false, BFV, true>), grid, dim3(256), shmem, st, T); \
+              else LMN_LAUNCH((conv_tile_kernel<TT, NN, 0, false, BFV>), grid, dim3(256), shmem, st, T); break;   \
+      case 2: if ((TT) == 9 && wlk) LMN_LAUNCH((conv_tile_kernel<9, NN, 2, false, BFV, true>), grid, dim3(256), shmem, st, T); \
+              else LMN_LAUNCH((conv_tile_kernel<TT, NN, 2, false, BFV>), grid, dim3(256), shmem, st, T); break;   \
       case 3: LMN_LAUNCH((conv_tile_kernel<1, NN, 3, false, BFV>), grid, dim3(256), shmem, st, T); break;    \
       case 4: LMN_LAUNCH((conv_tile_kernel<1, NN, 4, false, BFV>), grid, dim3(256), shmem, st, T); break;    \
       case 5: LMN_LAUNCH((conv_tile_kernel<1, NN, 5, false, BFV>), grid, dim3(256), shmem, st, T); break;    \
-      default: LMN_LAUNCH((conv_tile_kernel<TT, NN, 1, false, BFV>), grid, dim3(256), shmem, st, T); break;  \
+      default: if ((TT) == 9 && wlk) LMN_LAUNCH((conv_tile_kernel<9, NN, 1, false, BFV, true>), grid, dim3(256), shmem, st, T); \
+               else LMN_LAUNCH((conv_tile_kernel<TT, NN, 1, false, BFV>), grid, dim3(256), shmem, st, T); break;  \
     }                                                                                                    \
   } while (0)
 #define LMN_CTN(TT)                                                                                      \
