@@ -82,6 +82,10 @@ __device__ __forceinline__ f32x4 mfma_bf16(uint2 a, uint2 b, f32x4 c) {
 // stride-1 problem over dy with a 1x1 / 1x2 / 2x1 / 2x2 sub-kernel: in = out_c + ((parity + pad - t) >> 1) for the taps of
 // matching parity.  The tile walks CLASS coordinates, the window is TH+1 x TW+1 pixels of dy, outputs land at
 // (2*yc + py, 2*xc + px).
+#ifdef LMN_CT_TIMING
+// phase clocks of conv_tile_kernel (debug builds): per block {barrier 1, staging, barrier 2, MFMA, epilogue, life, start, end}
+__device__ unsigned long long g_ct_timing[4096 * 8];
+#endif
 #define LMN_SLOT c
 // WL (3x3): the packed weight fragments of a chunk (9 taps x <= 2 K16 blocks x NCT cout tiles) are staged in LDS -- once per
 // block when the layer is a single chunk -- and the MFMA loop reads its A operands with ds_read_b128.  Fetched from L2 one
@@ -178,7 +182,18 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(const ConvParams P) {
   const int t_begin = P.strided ? (int)blockIdx.x : (int)(((int64_t)blockIdx.x * P.total_tiles) / gridDim.x);
   const int t_end = P.strided ? P.total_tiles : (int)(((int64_t)(blockIdx.x + 1) * P.total_tiles) / gridDim.x);
   const int tstep = P.strided ? (int)gridDim.x : 1;
+#ifdef LMN_CT_TIMING
+  unsigned long long tk0 = __builtin_amdgcn_s_memtime(), tk_s[5] = {0, 0, 0, 0, 0}, tk_a = tk0, tk_b;
+#define LMN_TK(i) do { tk_b = __builtin_amdgcn_s_memtime(); tk_s[i] += tk_b - tk_a; tk_a = tk_b; } while (0)
+#define LMN_TK_DRAIN() __builtin_amdgcn_s_waitcnt(0)
+#else
+#define LMN_TK(i) do { } while (0)
+#define LMN_TK_DRAIN() do { } while (0)
+#endif
   for (int tile = t_begin; tile < t_end; tile += tstep) {
+#ifdef LMN_CT_TIMING
+    tk_a = __builtin_amdgcn_s_memtime();
+#endif
     const int b = tile / (P.tiles_x * P.tiles_y), tt = tile - b * P.tiles_x * P.tiles_y;
     const int oy0 = (tt / P.tiles_x) * P.TH, ox0 = (tt % P.tiles_x) * P.TW;
     // window origin in input coordinates (forward: out*s - pad; data gradient, stride 1: out - pad, taps flipped)
@@ -251,6 +266,7 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(const ConvParams P) {
           for (int c = 0; c < NCT; ++c) wcur[c] = ldfrag<BF>(wp + wtile[c]);
         }
         __syncthreads();  // previous chunk / tile fully consumed
+        LMN_TK(0);
         if constexpr (WL) {
           if (!wonce) stage_w(s, kb0, nkbc);
         }
@@ -302,7 +318,10 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(const ConvParams P) {
             }
           }
         }
+        LMN_TK_DRAIN();
+        LMN_TK(1);
         __syncthreads();
+        LMN_TK(2);
         // ---- MFMA: taps x K16 blocks of the chunk; the packed weights of step it+1 are fetched while step it runs
         //      (the first fetch was issued before the staging loop), so no L2 latency is exposed inside the loop
         for (int it = 0; it < niter; ++it) {
@@ -352,6 +371,8 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(const ConvParams P) {
       }
     }
 
+    LMN_TK_DRAIN();
+    LMN_TK(3);
     // ---- epilogue (lane holds channels co..co+3 of its pixel)
 #pragma unroll
     for (int g = 0; g < 2; ++g) {
@@ -430,7 +451,21 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(const ConvParams P) {
         __builtin_amdgcn_sched_barrier(0);
       }
     }
+    LMN_TK_DRAIN();
+    LMN_TK(4);
   }
+#ifdef LMN_CT_TIMING
+  {
+    const unsigned long long tk_e = __builtin_amdgcn_s_memtime();
+    const int bid = blockIdx.y * gridDim.x + blockIdx.x;
+    if (tid == 0 && bid < 4096) {
+      for (int k = 0; k < 5; ++k) g_ct_timing[bid * 8 + k] = tk_s[k];
+      g_ct_timing[bid * 8 + 5] = tk_e - tk0;
+      g_ct_timing[bid * 8 + 6] = tk0;
+      g_ct_timing[bid * 8 + 7] = tk_e;
+    }
+  }
+#endif
 
   // ---- statistics: wave shuffle over the 16 pixels -> LDS -> one global atomic per channel per block
   const bool se = EPI && ep_kind == LMN_EP_SE_BWD;
@@ -2095,6 +2130,11 @@ int64_t lmn_conv_wgrad_workspace(const lmn_wgrad_args_t* a) {
   return need <= (int64_t)(16 << 20) ? need : 0;  // at most 64 MB of partials; larger problems use atomics
 }
 const char* lmn_last_error(void) { return g_lmn_err; }
+#ifdef LMN_CT_TIMING
+int lmn_ct_timing(unsigned long long* out, int n) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ct_timing), sizeof(unsigned long long) * n);
+}
+#endif
 #ifdef LMN_WG_TIMING
 int lmn_wg_timing(unsigned long long* out, int n) {
   return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wg_timing), sizeof(unsigned long long) * n);
