@@ -39,7 +39,7 @@ extern "C" {
 
 typedef void* lmn_stream_t; /* hipStream_t */
 
-#define LMN_ABI_VERSION 5
+#define LMN_ABI_VERSION 6
 /* arithmetic type of the matrix-core operands of a dense contraction (accumulators, epilogues, statistics: fp32) */
 #define LMN_F32 0  /* v_mfma_f32_16x16x4_f32: exact fp32 (k-ordered fma chain)                                  */
 #define LMN_BF16 1 /* v_mfma_f32_16x16x16_bf16: operands rounded to bf16 (RNE) when staged / packed -- the mixed- */
@@ -96,6 +96,35 @@ typedef struct {
 #define LMN_STATS_SUM_SQ 1 /* [2][Cout]: sum d, sum d*d over all pixels, d = v - p4[co] (p4 NULL: d = v): BatchNorm batch statistics */
 #define LMN_STATS_EP 2     /* defined by the epilogue (BN_BWD1: [2][Cout]; SE_BWD: [B][Cout])        */
 
+/* In-kernel BatchNorm bookkeeping of lmn_conv_fwd: the conv that CONSUMES a batch statistic forms its per-channel
+ * coefficients itself -- every block for its own cout range, blocks with blockIdx.x == 0 also write the side outputs --
+ * which saves the lmn_bn_finalize / lmn_bn_bwd_coef launch between the statistics pass and the consuming pass (two
+ * dependent ~10 us launches per BatchNorm and step on the critical path).                                            */
+#define LMN_FIN_NONE 0
+#define LMN_FIN_BN 1     /* EP_AFFINE_ACT: p0 / p1 (A, shift) are formed from `sums` exactly as lmn_bn_finalize would  */
+#define LMN_FIN_BN_BWD 2 /* EP_BN_BWD2: p2 / p3 / p4 (c1, c2, c3) are formed from `sums` exactly as lmn_bn_bwd_coef would */
+typedef struct {
+  int32_t mode;          /* LMN_FIN_*                                                                              */
+  int32_t nrep;          /* slices of `sums` (1..16)                                                               */
+  float count, eps, momentum;
+  int32_t batch_stats;   /* LMN_FIN_BN_BWD: as lmn_bn_bwd_coef                                                     */
+  const float* sums;     /* [nrep][2][Cout]                                                                        */
+  const float* gamma;    /* LMN_FIN_BN                                                                             */
+  const float* beta;
+  const float* about;    /* LMN_FIN_BN: the per-channel shift the sums were taken about, or NULL.  It must NOT alias  */
+                         /* `rmean` (block 0 updates the running mean while other blocks still read `about`): pass    */
+                         /* the snapshot the statistics pass left behind its slices (lmn_conv_args_t.stats_snap)      */
+  float* mean;           /* LMN_FIN_BN outputs, each may be NULL                                                   */
+  float* rstd;
+  float* A;
+  float* shift;
+  float* rmean;          /* running statistics, updated in place (momentum, unbiased variance)                      */
+  float* rvar;
+  const float* Ain;      /* LMN_FIN_BN_BWD: A = gamma * rstd of the forward                                         */
+  float* dgamma;         /* LMN_FIN_BN_BWD: += sum dh*zhat, += sum dh (each may be NULL)                             */
+  float* dbeta;
+} lmn_bn_fin_t;
+
 typedef struct {
   int32_t B, Hout, Wout, Hin, Win;
   int32_t ksize;      /* 1 or 3; padding = ksize/2                                                */
@@ -133,6 +162,9 @@ typedef struct {
   int32_t _pad1;            /* LMN_BF16)                                                                             */
   const float* p5;          /* BN_BWD2 only: BatchNorm gamma / beta when `aux` is the gradient w.r.t. the ACTIVATED   */
   const float* p6;          /* output (the activation derivative is then applied here and dh is never written)        */
+  lmn_bn_fin_t fin;         /* optional in-kernel BatchNorm bookkeeping (fin.mode = LMN_FIN_NONE: off)                   */
+  int32_t stats_snap;       /* LMN_STATS_SUM_SQ: also copy the shift vector p4 (zeros if NULL) to stats[stats_rep*2*Cout..]: */
+  int32_t _pad2;            /* a snapshot that stays valid when p4 is a running mean updated by the consuming pass        */
 } lmn_conv_args_t;
 
 /* number of floats lmn_conv_pack writes for (ksize, Cout, src channel counts c[nsrc]) */

@@ -82,6 +82,79 @@ __device__ __forceinline__ f32x4 mfma_bf16(uint2 a, uint2 b, f32x4 c) {
 // stride-1 problem over dy with a 1x1 / 1x2 / 2x1 / 2x2 sub-kernel: in = out_c + ((parity + pad - t) >> 1) for the taps of
 // matching parity.  The tile walks CLASS coordinates, the window is TH+1 x TW+1 pixels of dy, outputs land at
 // (2*yc + py, 2*xc + px).
+// Epilogue parameter vectors (bias, bias2, p0..p6) of a block's cout range [ct0*16, +NCT*16) -> s_par[9][NCT*16], staged ONCE
+// per block: inside the tile loop every one of them was an L2 round trip in a tile's serial chain (window load -> MFMA ->
+// parameters -> math -> store), and the run-time branches around them serialised those round trips (LINEAR 49 us,
+// AFFINE_ACT 59 us, BN_BWD2 123 us for the same 1x1 conv at level 0).  Absent vectors and channels past Cout read 0.
+// fin (lmn_bn_fin_t): the BatchNorm coefficients this conv consumes are formed HERE from the batch sums instead of by a
+// separate lmn_bn_finalize / lmn_bn_bwd_coef launch (same arithmetic: slices summed in double / float); `first` blocks
+// (blockIdx.x == 0: one per cout range) also write the side outputs -- saved mean / rstd / A / shift and the running
+// statistics, or the gamma / beta gradients.  stats_snap: the shift vector p4 of a SUM_SQ statistics pass is copied behind
+// the slices, a copy that stays valid while the consuming pass updates the running mean it came from.
+template <int NCT>
+__device__ __forceinline__ void conv_stage_params(const lmn_conv_args_t& A, float* s_par, int ct0, int tid, bool first) {
+  const float* const pv[9] = {A.bias, A.bias2, A.p0, A.p1, A.p2, A.p3, A.p4, A.p5, A.p6};
+  const lmn_bn_fin_t& F = A.fin;
+  for (int i = tid; i < NCT * 16; i += 256) {   // (NCT * 16 <= 256: one trip; all loads of it are in flight together)
+    const int co = ct0 * 16 + i;
+    const bool cok = co < A.Cout;
+    const int cs = cok ? co : 0;
+    float t[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) t[k] = (pv[k] ? pv[k] : A.wpack)[pv[k] ? cs : 0];  // absent vector: any valid address
+#pragma unroll
+    for (int k = 0; k < 9; ++k) t[k] = (pv[k] && cok) ? t[k] : 0.f;
+    if (F.mode != LMN_FIN_NONE) {  // block-uniform
+      float u0[16], u1[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int rs = r < F.nrep ? r : 0;
+        u0[r] = F.sums[(int64_t)rs * 2 * A.Cout + cs];
+        u1[r] = F.sums[(int64_t)rs * 2 * A.Cout + A.Cout + cs];
+      }
+      if (F.mode == LMN_FIN_BN) {
+        const float ab = F.about ? F.about[cs] : 0.f, ga = F.gamma[cs], be = F.beta[cs];
+        double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          if (r < F.nrep) { s0 += (double)u0[r]; s1 += (double)u1[r]; }
+        const double md = s0 / (double)F.count;
+        float var = (float)(s1 / (double)F.count - md * md);  // biased
+        var = var > 0.f ? var : 0.f;
+        const float m = (float)md + ab;
+        const float rs = rsqrtf(var + F.eps);
+        const float a = ga * rs, sh = be - m * a;
+        t[2] = cok ? a : 0.f;
+        t[3] = cok ? sh : 0.f;
+        if (first && cok) {
+          if (F.mean) F.mean[co] = m;
+          if (F.rstd) F.rstd[co] = rs;
+          if (F.A) F.A[co] = a;
+          if (F.shift) F.shift[co] = sh;
+          if (F.rmean) F.rmean[co] = (1.f - F.momentum) * F.rmean[co] + F.momentum * m;
+          if (F.rvar) F.rvar[co] = (1.f - F.momentum) * F.rvar[co] + F.momentum * var * (F.count > 1.f ? F.count / (F.count - 1.f) : 1.f);
+        }
+      } else {  // LMN_FIN_BN_BWD
+        float S0 = 0.f, S1 = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          if (r < F.nrep) { S0 += u0[r]; S1 += u1[r]; }
+        const float a = F.Ain[cs];
+        t[4] = cok ? a : 0.f;
+        t[5] = (cok && F.batch_stats) ? a * S0 / F.count : 0.f;
+        t[6] = (cok && F.batch_stats) ? a * S1 / F.count : 0.f;
+        if (first && cok) {
+          if (F.dgamma) F.dgamma[co] += S1;
+          if (F.dbeta) F.dbeta[co] += S0;
+        }
+      }
+    }
+    if (A.stats_snap && first && cok && A.stats) A.stats[(int64_t)A.stats_rep * 2 * A.Cout + co] = t[6];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) s_par[k * NCT * 16 + i] = t[k];
+  }
+}
+
 #ifdef LMN_CT_TIMING
 // phase clocks of conv_tile_kernel (debug builds): per block {barrier 1, staging, barrier 2, MFMA, epilogue, life, start, end}
 __device__ unsigned long long g_ct_timing[4096 * 8];
@@ -140,22 +213,8 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(const ConvParams P) {
   for (int c = 0; c < NCT; ++c) wtile[c] = min(ct0 + c, P.NCTT - 1) * WT;
 
   for (int i = tid; i < 2 * NCT * 16; i += 256) s_stats[i] = 0.f;
-  // epilogue parameter vectors (bias, bias2, p0..p6) of this block's cout range, staged ONCE: in the tile loop every one of
-  // them was an L2 round trip inside a tile's serial chain (window load -> MFMA -> parameters -> math -> store), and the
-  // run-time branches around them serialised those round trips (LINEAR 49 us, AFFINE_ACT 59 us, BN_BWD2 123 us for the
-  // same 1x1 conv at level 0).  Absent vectors and channels past Cout read 0.
   float* s_par = s_stats + 2 * NCT * 16;  // [9][NCT*16]
-  {
-    const float* const pv[9] = {A.bias, A.bias2, A.p0, A.p1, A.p2, A.p3, A.p4, A.p5, A.p6};
-    for (int i = tid; i < NCT * 16; i += 256) {   // (NCT * 16 <= 256: one trip; the nine loads are in flight together)
-      const int co = ct0 * 16 + i;
-      float t[9];
-#pragma unroll
-      for (int k = 0; k < 9; ++k) t[k] = (pv[k] ? pv[k] : A.wpack)[(pv[k] && co < A.Cout) ? co : 0];  // absent vector: any valid address
-#pragma unroll
-      for (int k = 0; k < 9; ++k) s_par[k * NCT * 16 + i] = (pv[k] && co < A.Cout) ? t[k] : 0.f;
-    }
-  }
+  conv_stage_params<NCT>(A, s_par, ct0, tid, blockIdx.x == 0);
   float* s_w = s_par + 9 * NCT * 16;  // WL: [tap * nkbc + kk][NCT][WT]
   auto stage_w = [&](int s, int kb0, int nkbc) __attribute__((always_inline)) {
     constexpr int Q = WT / 4;  // float4 per fragment tile (64 lanes x 16 or 8 bytes)
@@ -538,22 +597,8 @@ __global__ __launch_bounds__(256) void conv_tileM_kernel(const ConvParams P) {
   for (int c = 0; c < NCW; ++c) wtile[c] = min(ct0 + wv + 4 * c, P.NCTT - 1) * WT;
 
   for (int i = tid; i < 2 * NCT * 16; i += 256) s_stats[i] = 0.f;
-  // epilogue parameter vectors (bias, bias2, p0..p6) of this block's cout range, staged ONCE: in the tile loop every one of
-  // them was an L2 round trip inside a tile's serial chain (window load -> MFMA -> parameters -> math -> store), and the
-  // run-time branches around them serialised those round trips (LINEAR 49 us, AFFINE_ACT 59 us, BN_BWD2 123 us for the
-  // same 1x1 conv at level 0).  Absent vectors and channels past Cout read 0.
   float* s_par = s_stats + 2 * NCT * 16;  // [9][NCT*16]
-  {
-    const float* const pv[9] = {A.bias, A.bias2, A.p0, A.p1, A.p2, A.p3, A.p4, A.p5, A.p6};
-    for (int i = tid; i < NCT * 16; i += 256) {   // (NCT * 16 <= 256: one trip; the nine loads are in flight together)
-      const int co = ct0 * 16 + i;
-      float t[9];
-#pragma unroll
-      for (int k = 0; k < 9; ++k) t[k] = (pv[k] ? pv[k] : A.wpack)[(pv[k] && co < A.Cout) ? co : 0];  // absent vector: any valid address
-#pragma unroll
-      for (int k = 0; k < 9; ++k) s_par[k * NCT * 16 + i] = (pv[k] && co < A.Cout) ? t[k] : 0.f;
-    }
-  }
+  conv_stage_params<NCT>(A, s_par, ct0, tid, blockIdx.x == 0);
   float st0[NCW][4], st1[NCW][4];
 #pragma unroll
   for (int c = 0; c < NCW; ++c)
@@ -2237,10 +2282,12 @@ int lmn_conv_fwd(const lmn_conv_args_t* args, lmn_stream_t stream) {
   if (A.aux) LMN_REQUIRE(A.aux_cstride >= A.Cout && A.aux_cstride % 4 == 0, "conv_fwd: aux_cstride %d", A.aux_cstride);
   switch (A.epilogue) {
     case LMN_EP_LINEAR: break;
-    case LMN_EP_AFFINE_ACT: LMN_REQUIRE(A.p0 && A.p1, "conv_fwd: AFFINE_ACT needs p0,p1"); break;
+    case LMN_EP_AFFINE_ACT: LMN_REQUIRE((A.p0 && A.p1) || A.fin.mode == LMN_FIN_BN, "conv_fwd: AFFINE_ACT needs p0,p1 (or fin)"); break;
     case LMN_EP_DGELU: LMN_REQUIRE(A.aux, "conv_fwd: DGELU needs aux"); break;
     case LMN_EP_BN_BWD1: LMN_REQUIRE(A.aux && A.p0 && A.p1 && A.p2 && A.p3 && A.stats, "conv_fwd: BN_BWD1 operands"); break;
-    case LMN_EP_BN_BWD2: LMN_REQUIRE(A.aux && A.p0 && A.p1 && A.p2 && A.p3 && A.p4 && (!A.p5 == !A.p6), "conv_fwd: BN_BWD2 operands"); break;
+    case LMN_EP_BN_BWD2:
+      LMN_REQUIRE(A.aux && A.p0 && A.p1 && ((A.p2 && A.p3 && A.p4) || A.fin.mode == LMN_FIN_BN_BWD) && (!A.p5 == !A.p6), "conv_fwd: BN_BWD2 operands");
+      break;
     case LMN_EP_SE_BWD: LMN_REQUIRE(A.aux && A.stats, "conv_fwd: SE_BWD operands"); break;
     default: LMN_REQUIRE(false, "conv_fwd: epilogue %d", A.epilogue);
   }
@@ -2252,6 +2299,16 @@ int lmn_conv_fwd(const lmn_conv_args_t* args, lmn_stream_t stream) {
     LMN_REQUIRE(A.Hin == (A.Hout + 2 * (A.ksize / 2) - A.ksize) / A.stride + 1 && A.Win == (A.Wout + 2 * (A.ksize / 2) - A.ksize) / A.stride + 1,
                 "conv_fwd(T): dy %dx%d inconsistent with dx %dx%d k%d s%d", A.Hin, A.Win, A.Hout, A.Wout, A.ksize, A.stride);
   }
+  LMN_REQUIRE(A.fin.mode == LMN_FIN_NONE || A.fin.mode == LMN_FIN_BN || A.fin.mode == LMN_FIN_BN_BWD, "conv_fwd: fin.mode %d", A.fin.mode);
+  if (A.fin.mode != LMN_FIN_NONE) {
+    LMN_REQUIRE(A.fin.sums && A.fin.nrep >= 1 && A.fin.nrep <= 16 && A.fin.count > 0.f, "conv_fwd: fin needs sums, 1..16 slices, count > 0");
+    if (A.fin.mode == LMN_FIN_BN)
+      LMN_REQUIRE(A.epilogue == LMN_EP_AFFINE_ACT && A.fin.gamma && A.fin.beta && (!A.fin.about || A.fin.about != A.fin.rmean),
+                  "conv_fwd: LMN_FIN_BN belongs to EP_AFFINE_ACT, needs gamma / beta, and `about` must not alias rmean");
+    else
+      LMN_REQUIRE(A.epilogue == LMN_EP_BN_BWD2 && A.fin.Ain, "conv_fwd: LMN_FIN_BN_BWD belongs to EP_BN_BWD2 and needs Ain");
+  }
+  LMN_REQUIRE(!A.stats_snap || (A.stats && A.stats_mode == LMN_STATS_SUM_SQ), "conv_fwd: stats_snap belongs to a SUM_SQ statistics pass");
   if (g_lmn_prof_on) {  // algorithmic cost of this launch (each HBM tensor once, MACs of the layer shape)
     int64_t cin = 0;
     for (int s = 0; s < A.nsrc; ++s) cin += A.src[s].C;

@@ -14,6 +14,7 @@ forward and backward are explicit kernel schedules over NHWC fp32 activations:
     all-reduced on a side stream as soon as their last kernel has been enqueued (``ddp.py``).
 """
 import contextlib
+import os
 
 import torch
 
@@ -141,6 +142,8 @@ class Engine:
         self.sides = {}           # issuing stream handle -> [weight-gradient stream, busy]
         self.branch = None        # second compute stream of the backward schedule (LM_Net._backward_body)
         self.branch_overlap = True
+        # BatchNorm bookkeeping inside the consuming conv (lmn_bn_fin_t) instead of separate launches (LMN_FUSE_BN=0: A/B runs)
+        self.fuse_bn = os.environ.get("LMN_FUSE_BN", "1") != "0"
         self.zpool_fwd, self.zpool_bwd = ZeroPool(), ZeroPool()
         self.packs_fwd, self.packs_bwd = hip.PackPlan(), hip.PackPlan()
         self.mma = hip.F32        # matrix-core operand type of the dense contractions of the pass (hip.F32 | hip.BF16)
@@ -316,15 +319,29 @@ class Engine:
         E, Cout, N = m.cexp, m.cout, B * H * W
         ec, ebn = m.expand_conv[0], m.expand_conv[1]
         wpe = hip.conv_pack(ec.weight, 1, [x.shape[-1]])   # (a 3-channel weight on the NHWC4 input: zero column packed)
-        sums1 = None
-        if self.training:
-            sums1 = _Z(x, STATS_REP, 2, E)
-            hip.conv_fwd([x], wpe, None, B=B, Hin=H, Win=W, Hout=H, Wout=W, Cout=E, bias=ec.bias, stats=sums1,
-                         stats_mode=hip.STATS_SUM_SQ, stats_rep=STATS_REP, p=(None, None, None, None, ebn.running_mean))
-        mean1, rstd1, A1, sh1 = self.bn_stats(ebn, sums1, N, x)
         x1 = _A(x, B, H, W, E)
-        hip.conv_fwd([x], wpe, x1, B=B, Hin=H, Win=W, Hout=H, Wout=W, Cout=E, bias=ec.bias, epilogue=hip.EP_AFFINE_ACT,
-                     act=hip.ACT_HSWISH, p=(A1, sh1))
+        if self.training and self.fuse_bn:
+            # statistics pass (sums about the running mean, whose snapshot lands behind the slices), then the applying pass
+            # forms mean / rstd / A / shift itself (lmn_bn_fin_t): no lmn_bn_finalize launch in between
+            sums1 = _Z(x, STATS_REP + 1, 2, E)
+            hip.conv_fwd([x], wpe, None, B=B, Hin=H, Win=W, Hout=H, Wout=W, Cout=E, bias=ec.bias, stats=sums1,
+                         stats_mode=hip.STATS_SUM_SQ, stats_rep=STATS_REP, stats_snap=True,
+                         p=(None, None, None, None, ebn.running_mean))
+            mean1, rstd1, A1, sh1 = (_E(x, E) for _ in range(4))
+            fin = dict(mode=hip.FIN_BN, sums=sums1, nrep=STATS_REP, count=N, gamma=ebn.weight, beta=ebn.bias, eps=ebn.eps,
+                       momentum=ebn.momentum if ebn.momentum is not None else 0.1, about=sums1[STATS_REP, 0],
+                       mean=mean1, rstd=rstd1, A=A1, shift=sh1, rmean=ebn.running_mean, rvar=ebn.running_var)
+            hip.conv_fwd([x], wpe, x1, B=B, Hin=H, Win=W, Hout=H, Wout=W, Cout=E, bias=ec.bias, epilogue=hip.EP_AFFINE_ACT,
+                         act=hip.ACT_HSWISH, p=(A1, sh1), fin=fin)
+        else:
+            sums1 = None
+            if self.training:
+                sums1 = _Z(x, STATS_REP, 2, E)
+                hip.conv_fwd([x], wpe, None, B=B, Hin=H, Win=W, Hout=H, Wout=W, Cout=E, bias=ec.bias, stats=sums1,
+                             stats_mode=hip.STATS_SUM_SQ, stats_rep=STATS_REP, p=(None, None, None, None, ebn.running_mean))
+            mean1, rstd1, A1, sh1 = self.bn_stats(ebn, sums1, N, x)
+            hip.conv_fwd([x], wpe, x1, B=B, Hin=H, Win=W, Hout=H, Wout=W, Cout=E, bias=ec.bias, epilogue=hip.EP_AFFINE_ACT,
+                         act=hip.ACT_HSWISH, p=(A1, sh1))
         # depthwise branches
         if m.deploy:
             keff, beff = m.fuse_conv.weight, m.fuse_conv.bias
@@ -429,11 +446,17 @@ class Engine:
         hip.conv_fwd([x], wpe, None, B=B, Hin=H, Win=W, Hout=H, Wout=W, Cout=E, bias=ec.bias, epilogue=hip.EP_BN_BWD1,
                      act=hip.ACT_HSWISH, p=(S["mean1"], S["rstd1"], ebn.weight, ebn.bias), aux=dx1, stats=st,
                      stats_mode=hip.STATS_EP, stats_rep=STATS_REP)
-        c1, c2, c3 = (_E(x, E) for _ in range(3))
-        hip.bn_bwd_coef(st, N, S["A1"], G[ebn.weight], G[ebn.bias], c1, c2, c3, self.training)
         dz = dpre  # reuse
-        hip.conv_fwd([x], wpe, dz, B=B, Hin=H, Win=W, Hout=H, Wout=W, Cout=E, bias=ec.bias, epilogue=hip.EP_BN_BWD2,
-                     act=hip.ACT_HSWISH, p=(S["mean1"], S["rstd1"], c1, c2, c3, ebn.weight, ebn.bias), aux=dx1)
+        if self.fuse_bn:   # c1, c2, c3 and the gamma / beta gradients are formed inside pass 2 (lmn_bn_fin_t)
+            fin = dict(mode=hip.FIN_BN_BWD, sums=st, nrep=STATS_REP, count=N, batch_stats=self.training, Ain=S["A1"],
+                       dgamma=G[ebn.weight], dbeta=G[ebn.bias])
+            hip.conv_fwd([x], wpe, dz, B=B, Hin=H, Win=W, Hout=H, Wout=W, Cout=E, bias=ec.bias, epilogue=hip.EP_BN_BWD2,
+                         act=hip.ACT_HSWISH, p=(S["mean1"], S["rstd1"], None, None, None, ebn.weight, ebn.bias), aux=dx1, fin=fin)
+        else:
+            c1, c2, c3 = (_E(x, E) for _ in range(3))
+            hip.bn_bwd_coef(st, N, S["A1"], G[ebn.weight], G[ebn.bias], c1, c2, c3, self.training)
+            hip.conv_fwd([x], wpe, dz, B=B, Hin=H, Win=W, Hout=H, Wout=W, Cout=E, bias=ec.bias, epilogue=hip.EP_BN_BWD2,
+                         act=hip.ACT_HSWISH, p=(S["mean1"], S["rstd1"], c1, c2, c3, ebn.weight, ebn.bias), aux=dx1)
         if cw == Cin:
             self.wgrad([x], dz, ec.weight, ec.bias, Hin=H, Win=W)
         else:

@@ -19,12 +19,22 @@ ACT_NONE, ACT_HSWISH, ACT_GELU = 0, 1, 2
 STATS_NONE, STATS_SUM_SQ, STATS_EP = 0, 1, 2
 F32, BF16 = 0, 1            # matrix-core operand type of the dense contractions (LMN_F32 / LMN_BF16)
 _MMA = [F32]                # ... of the pass in flight (engine.begin_pass)
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 
 class SrcT(C.Structure):
     _fields_ = [("ptr", C.c_void_p), ("scale", C.c_void_p), ("C", C.c_int32), ("cstride", C.c_int32),
                 ("flags", C.c_int32), ("drop_seed", C.c_uint32), ("drop_p", C.c_float), ("_pad", C.c_int32)]
+
+
+class BnFin(C.Structure):
+    _fields_ = [("mode", C.c_int32), ("nrep", C.c_int32), ("count", C.c_float), ("eps", C.c_float), ("momentum", C.c_float),
+                ("batch_stats", C.c_int32), ("sums", C.c_void_p), ("gamma", C.c_void_p), ("beta", C.c_void_p),
+                ("about", C.c_void_p), ("mean", C.c_void_p), ("rstd", C.c_void_p), ("A", C.c_void_p), ("shift", C.c_void_p),
+                ("rmean", C.c_void_p), ("rvar", C.c_void_p), ("Ain", C.c_void_p), ("dgamma", C.c_void_p), ("dbeta", C.c_void_p)]
+
+
+FIN_BN, FIN_BN_BWD = 1, 2
 
 
 class ConvArgs(C.Structure):
@@ -37,7 +47,7 @@ class ConvArgs(C.Structure):
                 ("epilogue", C.c_int32), ("act", C.c_int32), ("stats_mode", C.c_int32),
                 ("drop_p", C.c_float), ("drop_seed", C.c_uint32), ("seed_ctr", C.c_void_p), ("bias2", C.c_void_p),
                 ("stats_rep", C.c_int32), ("mma_dtype", C.c_int32), ("act_dtype", C.c_int32), ("_pad1", C.c_int32),
-                ("p5", C.c_void_p), ("p6", C.c_void_p)]
+                ("p5", C.c_void_p), ("p6", C.c_void_p), ("fin", BnFin), ("stats_snap", C.c_int32), ("_pad2", C.c_int32)]
 
 
 class WgradArgs(C.Structure):
@@ -327,7 +337,9 @@ def conv_pack_t(w, ksize, row_off=0, rows=None, out=None, cred=None):
 
 def conv_fwd(srcs, wpack, out, *, B, Hin, Win, Hout, Wout, Cout, ksize=1, stride=1, transposed=0, bias=None, bias2=None,
              epilogue=EP_LINEAR, act=ACT_NONE, p=(), aux=None, residual=None, stats=None, stats_mode=STATS_NONE,
-             drop_p=0.0, drop_seed=0, stats_rep=1):
+             drop_p=0.0, drop_seed=0, stats_rep=1, stats_snap=False, fin=None):
+    """fin: dict(mode=FIN_BN | FIN_BN_BWD, sums=[nrep(+1), 2, C] tensor, nrep, count, ...) -- in-kernel BatchNorm bookkeeping
+    (lmn_bn_fin_t): tensors for gamma / beta / about / mean / rstd / A / shift / rmean / rvar / Ain / dgamma / dbeta."""
     a = ConvArgs()
     a.B, a.Hout, a.Wout, a.Hin, a.Win = B, Hout, Wout, Hin, Win
     a.ksize, a.stride, a.transposed, a.nsrc, a.Cout = ksize, stride, transposed, len(srcs), Cout
@@ -349,6 +361,14 @@ def conv_fwd(srcs, wpack, out, *, B, Hin, Win, Hout, Wout, Cout, ksize=1, stride
         a.out, a.out_cstride = v.ptr, v.cstride
     a.stats = stats.data_ptr() if stats is not None else None
     a.stats_rep = stats_rep
+    a.stats_snap = int(bool(stats_snap))
+    if fin is not None:
+        f = a.fin
+        f.mode, f.nrep, f.count = fin["mode"], fin["nrep"], float(fin["count"])
+        f.eps, f.momentum, f.batch_stats = float(fin.get("eps", 0.0)), float(fin.get("momentum", 0.0)), int(fin.get("batch_stats", 1))
+        for k in ("sums", "gamma", "beta", "about", "mean", "rstd", "A", "shift", "rmean", "rvar", "Ain", "dgamma", "dbeta"):
+            t = fin.get(k)
+            setattr(f, k, t.data_ptr() if t is not None else None)
     a.epilogue, a.act, a.stats_mode = epilogue, act, stats_mode
     a.drop_p, a.drop_seed = drop_p, drop_seed
     a.mma_dtype = _MMA[0]

@@ -510,6 +510,38 @@ def check_conv_bn_epilogues(B=2, H=9, W=8, tag=""):
                  act=hip.ACT_HSWISH, p=(dev(mean), dev(rstd), c1, c2, c3, dev(g), dev(be)), aux=nhwc(dx1))
     rows.append(("conv BN_BWD2 with the activation derivative fused (dz from dx1)" + tag, rel(nchw(dz2), zr.grad), 2e-4))
 
+    # the same pass 2 with c1 / c2 / c3 and the gamma / beta gradients formed in-kernel (lmn_bn_fin_t, LMN_FIN_BN_BWD)
+    dz3 = torch.full((B, H, W, E), float("nan"), device=DEV)
+    dg3, db3 = torch.zeros(E, device=DEV), torch.zeros(E, device=DEV)
+    hip.conv_fwd([xd], wp, dz3, B=B, Hin=H, Win=W, Hout=H, Wout=W, Cout=E, bias=dev(b), epilogue=hip.EP_BN_BWD2,
+                 act=hip.ACT_HSWISH, p=(dev(mean), dev(rstd), None, None, None, dev(g), dev(be)), aux=nhwc(dx1),
+                 fin=dict(mode=hip.FIN_BN_BWD, sums=st2, nrep=1, count=N, batch_stats=True, Ain=A, dgamma=dg3, dbeta=db3))
+    rows.append(("conv BN_BWD2 with in-kernel coefficients: dz" + tag, rel(nchw(dz3), zr.grad), 2e-4))
+    rows.append(("conv BN_BWD2 with in-kernel coefficients: dgamma" + tag, rel(dg3, g.grad), 2e-4))
+    rows.append(("conv BN_BWD2 with in-kernel coefficients: dbeta" + tag, rel(db3, be.grad), 2e-4))
+    # forward: statistics pass about a running mean (snapshot behind the slices) + applying pass with in-kernel finalize
+    # (LMN_FIN_BN) against lmn_bn_finalize and against torch's batch norm; running statistics updated once
+    REP = 4
+    rm0, rv0 = R(E, seed=141, scale=0.3), R(E, seed=142).abs() + 0.5
+    rm_a, rv_a, rm_b, rv_b = dev(rm0).clone(), dev(rv0).clone(), dev(rm0).clone(), dev(rv0).clone()
+    sums = torch.zeros(REP + 1, 2, E, device=DEV)
+    hip.conv_fwd([xd], wp, None, B=B, Hin=H, Win=W, Hout=H, Wout=W, Cout=E, bias=dev(b), stats=sums, stats_mode=hip.STATS_SUM_SQ,
+                 stats_rep=REP, stats_snap=True, p=(None, None, None, None, rm_a))
+    rows.append(("conv SUM_SQ statistics: shift snapshot" + tag, rel(sums[REP, 0], dev(rm0)), 1e-7))
+    m_a, r_a, A_a, s_a = (torch.zeros(E, device=DEV) for _ in range(4))
+    x1k = torch.full((B, H, W, E), float("nan"), device=DEV)
+    hip.conv_fwd([xd], wp, x1k, B=B, Hin=H, Win=W, Hout=H, Wout=W, Cout=E, bias=dev(b), epilogue=hip.EP_AFFINE_ACT,
+                 act=hip.ACT_HSWISH, p=(A_a, s_a),
+                 fin=dict(mode=hip.FIN_BN, sums=sums, nrep=REP, count=N, gamma=dev(g), beta=dev(be), eps=1e-5, momentum=0.1,
+                          about=sums[REP, 0], mean=m_a, rstd=r_a, A=A_a, shift=s_a, rmean=rm_a, rvar=rv_a))
+    m_b, r_b, A_b, s_b = (torch.zeros(E, device=DEV) for _ in range(4))
+    hip.bn_finalize(sums[:REP], N, dev(g), dev(be), 1e-5, 0.1, m_b, r_b, A_b, s_b, rm_b, rv_b, about=sums[REP, 0])
+    rows.append(("conv AFFINE_ACT with in-kernel BN finalize: x1" + tag, rel(nchw(x1k), x1.detach()), 2e-4))
+    for nm, ta, tb in (("mean", m_a, m_b), ("rstd", r_a, r_b), ("A", A_a, A_b), ("shift", s_a, s_b), ("running mean", rm_a, rm_b),
+                       ("running var", rv_a, rv_b)):
+        rows.append(("in-kernel BN finalize == lmn_bn_finalize: %s" % nm + tag, rel(ta, tb), 1e-6))
+    rows.append(("in-kernel BN finalize: mean vs torch" + tag, rel(m_a, mean), 2e-5))
+
     # SE_BWD: o = v, stats[b][c] += v * gelu(aux)
     pre = R(B, E, H, W, seed=137)
     dy = R(B, Cin, H, W, seed=138)
