@@ -242,6 +242,13 @@ int lmn_dw_stats(const void* x1, int B, int H, int W, int E, const float* w5, co
  * input) and accumulates gsum[B][E] += sum_hw gelu(pre) for the SE squeeze (modules.py:1030). */
 int lmn_dw_fwd(const void* x1, void* pre, float* gsum, int B, int H, int W, int E, const float* keff,
                const float* beff, int act_dtype, lmn_stream_t stream);
+/* lmn_dw_finalize_merge + lmn_dw_fwd in ONE launch (training): every wave forms the merged stencil of its channel pair from
+ * the batch sums `stats` [4][2][E] and the four branch weights, the first block of a channel chunk writes mean / rstd / A
+ * [4][E] and updates the running statistics.  Arguments as lmn_dw_finalize_merge; no keff / beff tensors exist.        */
+int lmn_dw_fwd_bn(const void* x1, void* pre, float* gsum, int B, int H, int W, int E, const float* stats, float count,
+                  const float* const* gamma, const float* const* beta, float* const* running_mean, float* const* running_var,
+                  const float* eps, const float* momentum, const float* w5, const float* w3, const float* wv, const float* wh,
+                  float* mean, float* rstd, float* A, int act_dtype, lmn_stream_t stream);
 /* builds keff/beff on the device from the four branch weights and per-branch affine (A_b, shift_b) */
 /* Training forward between lmn_dw_stats and lmn_dw_fwd, one launch: finalise the four branch BatchNorms from the
  * batch sums `stats` [4][2][E] (mean/rstd/A [4][E] out, running statistics updated with `momentum`, unbiased variance
@@ -270,6 +277,13 @@ int lmn_dw_bwd_coef(const float* bstats, const float* mean, const float* rstd, c
 int lmn_dw_bwd(const void* x1, const void* dpre, void* dx1, int B, int H, int W, int E, const float* w5,
                const float* w3, const float* wv, const float* wh, const float* cA, const float* cC,
                const float* cD, float* dw5, float* dw3, float* dwv, float* dwh, int act_dtype, lmn_stream_t stream);
+
+/* lmn_dw_bwd_coef + lmn_dw_bwd in ONE launch: the coefficients of f_b are formed per wave from bstats / mean / rstd / A,
+ * the first block of a channel chunk adds the gamma / beta gradients (dgamma / dbeta: host arrays of 4 device pointers). */
+int lmn_dw_bwd_bn(const void* x1, const void* dpre, void* dx1, int B, int H, int W, int E, const float* w5, const float* w3,
+                  const float* wv, const float* wh, const float* bstats, const float* mean, const float* rstd, const float* A,
+                  float count, int batch_stats, float* const* dgamma, float* const* dbeta, float* dw5, float* dw3, float* dwv,
+                  float* dwh, int act_dtype, lmn_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * SE gate (core/modules.py:1020-1036): s = hardsigmoid(W2 relu(W1 m + b1) + b2), m = gsum/HW.

@@ -27,6 +27,31 @@ __device__ __forceinline__ int xcd_swizzle(int bid, int nwg) {
   return (xcd < r ? xcd * (qd + 1) : r * (qd + 1) + (xcd - r) * qd) + (bid >> 3);
 }
 
+// In-kernel BatchNorm bookkeeping of the depthwise block (by value in the kernel arguments; stats / bstats == NULL: off).
+// Forward: the merged 5x5 stencil of a wave's channel pair is formed from the batch sums and the four branch weights
+// (lmn_dw_finalize_merge arithmetic); backward: the coefficients cA / cC / cD of f_b (lmn_dw_bwd_coef arithmetic).  The
+// first block of every channel chunk also writes the side outputs (saved mean / rstd / A and the running statistics; the
+// gamma / beta gradients).
+struct DwFin {
+  const float* stats;  // [4][2][E] batch sums
+  float count;
+  const float* gamma[4];
+  const float* beta[4];
+  float* rmean[4];
+  float* rvar[4];
+  float eps[4], mom[4];
+  const float* w5; const float* w3; const float* wv; const float* wh;
+  float* mean; float* rstd; float* A;  // [4][E] out
+};
+struct DwCoef {
+  const float* bstats;  // [5][E]
+  const float* mean; const float* rstd; const float* A;  // [4][E] of the forward
+  float count;
+  int batch_stats;
+  float* dg[4];
+  float* db[4];
+};
+
 struct BranchW {  // this thread's channel pair of the four branch kernels
   f32x2 w5[25], w3[9], wv[3], wh[3];
 };
@@ -200,7 +225,7 @@ __global__ __launch_bounds__(256) void dw_bwd_strip_kernel(
     const TA* __restrict__ x1, const TA* __restrict__ dpre, TA* __restrict__ dx1, int B, int H, int W, int E,
     const float* __restrict__ w5, const float* __restrict__ w3, const float* __restrict__ wvv,
     const float* __restrict__ whh, const float* __restrict__ cA, const float* __restrict__ cC,
-    const float* __restrict__ cD, float* __restrict__ dw5, float* __restrict__ dw3, float* __restrict__ dwv,
+    const float* __restrict__ cD, const DwCoef CF, float* __restrict__ dw5, float* __restrict__ dw3, float* __restrict__ dwv,
     float* __restrict__ dwh, int strips, int segs, int seg_rows, int chunks) {
   __shared__ __attribute__((aligned(16))) float XS[SW_XR * SW_XC * SW_CS];
   __shared__ __attribute__((aligned(16))) float DPS[SW_R * SW_FC * SW_CS];
@@ -222,9 +247,28 @@ __global__ __launch_bounds__(256) void dw_bwd_strip_kernel(
   f32x2 ca[4], cc[4], cd[4];
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
+    if (CF.bstats) {  // block-uniform: coefficients formed here (lmn_dw_bwd_coef arithmetic)
+      float a2[2], c2[2], d2[2];
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int e = chs + h, i = k * E + e;
+        const float S0 = CF.bstats[e], S1 = CF.bstats[(1 + k) * E + e];
+        const float mu = CF.mean[i], rs = CF.rstd[i], a = CF.A[i];
+        const float T = (S1 - mu * S0) * rs;  // sum dpre * yhat_b
+        const float c = CF.batch_stats ? -a * T * rs / CF.count : 0.f;
+        a2[h] = a; c2[h] = c;
+        d2[h] = CF.batch_stats ? (-a * S0 / CF.count - c * mu) : 0.f;
+        if (cok && lane == 0 && strip == 0 && seg == 0 && b == 0) {  // one wave per channel pair
+          CF.dg[k][e] += T;
+          CF.db[k][e] += S0;
+        }
+      }
+      ca[k] = f32x2{a2[0], a2[1]}; cc[k] = f32x2{c2[0], c2[1]}; cd[k] = f32x2{d2[0], d2[1]};
+    } else {
     ca[k] = f32x2{cA[k * E + chs], cA[k * E + chs + 1]};
     cc[k] = f32x2{cC[k * E + chs], cC[k * E + chs + 1]};
     cd[k] = f32x2{cD[k * E + chs], cD[k * E + chs + 1]};
+    }
     // the 80 weight SGPRs already fill the scalar file: keep the 24 coefficient floats in VGPRs (otherwise the
     // allocator spills weights to VGPR lanes and every use costs v_readlane x2 + s_nop)
     asm volatile("" : "+v"(ca[k].x), "+v"(ca[k].y), "+v"(cc[k].x), "+v"(cc[k].y), "+v"(cd[k].x), "+v"(cd[k].y));
@@ -413,8 +457,8 @@ template <typename TA>
 __global__ __launch_bounds__(256) void dw_fwd_strip_kernel(const TA* __restrict__ x1, TA* __restrict__ pre,
                                                             float* __restrict__ gsum, int H, int W, int E,
                                                             const float* __restrict__ keff,
-                                                            const float* __restrict__ beff, int strips, int segs,
-                                                            int seg_rows, int chunks) {
+                                                            const float* __restrict__ beff, const DwFin FN, int strips,
+                                                            int segs, int seg_rows, int chunks) {
   __shared__ __attribute__((aligned(16))) float XS[FS_XR * SW_XC * SW_CS];
   __shared__ __attribute__((aligned(16))) float OUT[SW_R * SW_FC * SW_CS];
   __shared__ float gs_s[SW_CH];
@@ -429,9 +473,50 @@ __global__ __launch_bounds__(256) void dw_fwd_strip_kernel(const TA* __restrict_
   const bool cok = ch < E;
   const int chs = cok ? ch : 0;
   f32x2 w[25];
+  f32x2 bias;
+  if (FN.stats) {  // block-uniform: the four branch BatchNorms are finalised and merged here (lmn_dw_finalize_merge arithmetic)
+    float wm[2][25], bs[2];
 #pragma unroll
-  for (int t = 0; t < 25; ++t) w[t] = f32x2{keff[(int64_t)chs * 25 + t], keff[(int64_t)(chs + 1) * 25 + t]};
-  const f32x2 bias = f32x2{beff[chs], beff[chs + 1]};
+    for (int h = 0; h < 2; ++h) {
+      const int e = chs + h;
+      float a4[4];
+      float sh = 0.f;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const float m = FN.stats[(t * 2) * E + e] / FN.count;
+        float var = FN.stats[(t * 2 + 1) * E + e] / FN.count - m * m;  // biased
+        var = var > 0.f ? var : 0.f;
+        const float rs = rsqrtf(var + FN.eps[t]);
+        const float a = FN.gamma[t][e] * rs;
+        a4[t] = a;
+        sh += FN.beta[t][e] - m * a;
+        if (cok && lane == 0 && strip == 0 && seg == 0 && b == 0) {  // one wave per channel pair writes the side outputs
+          FN.mean[t * E + e] = m;
+          FN.rstd[t * E + e] = rs;
+          FN.A[t * E + e] = a;
+          FN.rmean[t][e] = (1.f - FN.mom[t]) * FN.rmean[t][e] + FN.mom[t] * m;
+          FN.rvar[t][e] = (1.f - FN.mom[t]) * FN.rvar[t][e] + FN.mom[t] * var * (FN.count > 1.f ? FN.count / (FN.count - 1.f) : 1.f);
+        }
+      }
+      bs[h] = sh;
+#pragma unroll
+      for (int t = 0; t < 25; ++t) {
+        const int ky = t / 5, kx = t - ky * 5;
+        float v = a4[0] * FN.w5[e * 25 + t];
+        if (ky >= 1 && ky <= 3 && kx >= 1 && kx <= 3) v += a4[1] * FN.w3[e * 9 + (ky - 1) * 3 + (kx - 1)];
+        if (kx == 2 && ky >= 1 && ky <= 3) v += a4[2] * FN.wv[e * 3 + (ky - 1)];
+        if (ky == 2 && kx >= 1 && kx <= 3) v += a4[3] * FN.wh[e * 3 + (kx - 1)];
+        wm[h][t] = v;
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < 25; ++t) w[t] = f32x2{wm[0][t], wm[1][t]};
+    bias = f32x2{bs[0], bs[1]};
+  } else {
+#pragma unroll
+    for (int t = 0; t < 25; ++t) w[t] = f32x2{keff[(int64_t)chs * 25 + t], keff[(int64_t)(chs + 1) * 25 + t]};
+    bias = f32x2{beff[chs], beff[chs + 1]};
+  }
   const int ys = seg * seg_rows, ye = min(ys + seg_rows, H);
   const int xs = strip * SW_FC;
   const bool cvalid = cok && xs + lane < W;
@@ -871,8 +956,40 @@ int lmn_dw_fwd(const void* x1, void* pre, float* gsum, int B, int H, int W, int 
   LMN_REQUIRE(nblk < (1LL << 31), "dw_fwd: grid too large");
   if (g_lmn_prof_on) lmn_prof_cost(2.0 * 25 * (double)B * H * W * E, (act_dtype == LMN_BF16 ? 2.0 : 4.0) * 2 * (double)B * H * W * E);
   LMN_ACT_DISPATCH(act_dtype, LMN_LAUNCH((dw_fwd_strip_kernel<T>), dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, (const T*)x1, (T*)pre, gsum, H, W, E, keff,
-                     beff, strips, segs, seg_rows, chunks));
+                     beff, DwFin{}, strips, segs, seg_rows, chunks));
   return lmn_launch_status("dw_fwd");
+}
+
+int lmn_dw_fwd_bn(const void* x1, void* pre, float* gsum, int B, int H, int W, int E, const float* stats, float count,
+                  const float* const* gamma, const float* const* beta, float* const* running_mean, float* const* running_var,
+                  const float* eps, const float* momentum, const float* w5, const float* w3, const float* wv, const float* wh,
+                  float* mean, float* rstd, float* A, int act_dtype, lmn_stream_t stream) {
+  LMN_REQUIRE_DT(act_dtype, "dw_fwd_bn");
+  LMN_REQUIRE(x1 && pre && gsum && stats && gamma && beta && running_mean && running_var && eps && momentum && w5 && w3 && wv && wh &&
+                  mean && rstd && A && count > 0.f, "dw_fwd_bn: bad argument");
+  LMN_REQUIRE(B > 0 && H > 0 && W > 0 && E > 0 && E % 4 == 0, "dw_fwd_bn: E=%d must be a multiple of 4", E);
+  LMN_REQUIRE((int64_t)(H + 8) * W * E * 4 < (1LL << 30), "dw_fwd_bn: one image (%d x %d x %d) must stay below 1 GiB", H, W, E);
+  DwFin fn;
+  fn.stats = stats; fn.count = count;
+  for (int b = 0; b < 4; ++b) {
+    LMN_REQUIRE(gamma[b] && beta[b] && running_mean[b] && running_var[b], "dw_fwd_bn: null BatchNorm tensor %d", b);
+    fn.gamma[b] = gamma[b]; fn.beta[b] = beta[b]; fn.rmean[b] = running_mean[b]; fn.rvar[b] = running_var[b];
+    fn.eps[b] = eps[b]; fn.mom[b] = momentum[b];
+  }
+  fn.w5 = w5; fn.w3 = w3; fn.wv = wv; fn.wh = wh; fn.mean = mean; fn.rstd = rstd; fn.A = A;
+  const int strips = lmn_cdiv(W, SW_FC), chunks = lmn_cdiv(E, SW_CH);
+  int seg_rows;
+  const int segs = strip_segments((int64_t)B * strips * chunks, H, 4, 4, &seg_rows);
+  const int64_t nblk = (int64_t)B * strips * chunks * segs;
+  LMN_REQUIRE(nblk < (1LL << 31), "dw_fwd_bn: grid too large");
+  auto launch = [=]() -> int {
+    if (g_lmn_prof_on) lmn_prof_cost(2.0 * 25 * (double)B * H * W * E, (act_dtype == LMN_BF16 ? 2.0 : 4.0) * 2 * (double)B * H * W * E);
+    LMN_ACT_DISPATCH(act_dtype, LMN_LAUNCH((dw_fwd_strip_kernel<T>), dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, (const T*)x1, (T*)pre, gsum, H, W, E,
+                       (const float*)nullptr, (const float*)nullptr, fn, strips, segs, seg_rows, chunks));
+    return lmn_launch_status("dw_fwd_bn");
+  };
+  if (g_lmn_rec) lmn_rec_push(launch);
+  return launch();
 }
 
 int lmn_dw_finalize_merge(const float* stats, float count, const float* const* gamma, const float* const* beta,
@@ -960,8 +1077,38 @@ int lmn_dw_bwd(const void* x1, const void* dpre, void* dx1, int B, int H, int W,
   LMN_REQUIRE(nblk < (1LL << 31), "dw_bwd: grid too large");
   if (g_lmn_prof_on) lmn_prof_cost(2.0 * 2 * 42 * (double)B * H * W * E, (act_dtype == LMN_BF16 ? 2.0 : 4.0) * 3 * (double)B * H * W * E);
   LMN_ACT_DISPATCH(act_dtype, LMN_LAUNCH((dw_bwd_strip_kernel<T>), dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, (const T*)x1, (const T*)dpre, (T*)dx1, B, H, W, E, w5,
-                     w3, wv, wh, cA, cC, cD, dw5, dw3, dwv, dwh, strips, segs, seg_rows, chunks));
+                     w3, wv, wh, cA, cC, cD, DwCoef{}, dw5, dw3, dwv, dwh, strips, segs, seg_rows, chunks));
   return lmn_launch_status("dw_bwd");
+}
+
+int lmn_dw_bwd_bn(const void* x1, const void* dpre, void* dx1, int B, int H, int W, int E, const float* w5, const float* w3,
+                  const float* wv, const float* wh, const float* bstats, const float* mean, const float* rstd, const float* A,
+                  float count, int batch_stats, float* const* dgamma, float* const* dbeta, float* dw5, float* dw3, float* dwv,
+                  float* dwh, int act_dtype, lmn_stream_t stream) {
+  LMN_REQUIRE_DT(act_dtype, "dw_bwd_bn");
+  LMN_REQUIRE(x1 && dpre && dx1 && w5 && w3 && wv && wh && bstats && mean && rstd && A && dgamma && dbeta && dw5 && dw3 && dwv && dwh &&
+                  count > 0.f, "dw_bwd_bn: bad argument");
+  LMN_REQUIRE(B > 0 && H > 0 && W > 0 && E > 0 && E % 4 == 0, "dw_bwd_bn: E=%d must be a multiple of 4", E);
+  LMN_REQUIRE((int64_t)(H + 16) * W * E * 4 < (1LL << 30), "dw_bwd_bn: one image (%d x %d x %d) must stay below 1 GiB", H, W, E);
+  DwCoef cf;
+  cf.bstats = bstats; cf.mean = mean; cf.rstd = rstd; cf.A = A; cf.count = count; cf.batch_stats = batch_stats;
+  for (int b = 0; b < 4; ++b) {
+    LMN_REQUIRE(dgamma[b] && dbeta[b], "dw_bwd_bn: null gradient tensor %d", b);
+    cf.dg[b] = dgamma[b]; cf.db[b] = dbeta[b];
+  }
+  const int strips = lmn_cdiv(W, SW_OC), chunks = lmn_cdiv(E, SW_CH);
+  int seg_rows;
+  const int segs = strip_segments((int64_t)B * strips * chunks, H, 10, 2, &seg_rows);
+  const int64_t nblk = (int64_t)B * strips * chunks * segs;
+  LMN_REQUIRE(nblk < (1LL << 31), "dw_bwd_bn: grid too large");
+  auto launch = [=]() -> int {
+    if (g_lmn_prof_on) lmn_prof_cost(2.0 * 2 * 42 * (double)B * H * W * E, (act_dtype == LMN_BF16 ? 2.0 : 4.0) * 3 * (double)B * H * W * E);
+    LMN_ACT_DISPATCH(act_dtype, LMN_LAUNCH((dw_bwd_strip_kernel<T>), dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, (const T*)x1, (const T*)dpre, (T*)dx1, B, H, W, E, w5,
+                       w3, wv, wh, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, cf, dw5, dw3, dwv, dwh, strips, segs, seg_rows, chunks));
+    return lmn_launch_status("dw_bwd_bn");
+  };
+  if (g_lmn_rec) lmn_rec_push(launch);
+  return launch();
 }
 
 }  // extern "C"

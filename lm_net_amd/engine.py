@@ -354,17 +354,24 @@ class Engine:
             if self.training:
                 st2 = _Z(x, 4, 2, E)
                 hip.dw_stats(x1, *ws, st2)
-            keff, beff = _E(x, E, 25), _E(x, E)
-            if self.training:   # the four finalizes and the merge in one launch
+            keff = beff = None
+            if self.training and self.fuse_bn:
+                pass            # finalize + merge happen inside the depthwise pass itself (hip.dw_fwd_bn below)
+            elif self.training:   # the four finalizes and the merge in one launch
+                keff, beff = _E(x, E, 25), _E(x, E)
                 hip.dw_finalize_merge(st2, N, [b.bn for b in brs], ws, bmean, brstd, bA, keff, beff)
             else:
+                keff, beff = _E(x, E, 25), _E(x, E)
                 for i, b in enumerate(brs):
                     bn = b.bn
                     hip.bn_fold(bn.running_mean, bn.running_var, bn.weight, bn.bias, bn.eps, bmean[i], brstd[i], bA[i], bshift[i])
                 hip.dw_merge(*ws, bA, bshift, keff, beff)
         pre = _A(x, B, H, W, E)
         gsum = _Z(x, B, E)
-        hip.dw_fwd(x1, pre, gsum, keff, beff)
+        if keff is None:
+            hip.dw_fwd_bn(x1, pre, gsum, st2, N, [b.bn for b in brs], ws, bmean, brstd, bA)
+        else:
+            hip.dw_fwd(x1, pre, gsum, keff, beff)
         se = m.se
         R = se.fc1.weight.shape[0]
         sgate, hid = _E(x, B, E), _E(x, B, R)
@@ -433,11 +440,15 @@ class Engine:
         dpre = _A(x, B, H, W, E)
         bst = _Z(x, 5, E)
         hip.dw_bwd_stats(x1, pre, u, sgate, dm, dpre, *ws, bst)
-        cA, cC, cD = (_E(x, 4, E) for _ in range(3))
-        hip.dw_bwd_coef(bst, S["bmean"], S["brstd"], S["bA"], N, self.training, cA, cC, cD,
-                        [G[b.bn.weight] for b in brs], [G[b.bn.bias] for b in brs])
         dx1 = u  # reuse
-        hip.dw_bwd(x1, dpre, dx1, *ws, cA, cC, cD, *[G[w] for w in ws])
+        if self.fuse_bn:   # the coefficients of f_b and the gamma / beta gradients are formed inside the pass
+            hip.dw_bwd_bn(x1, dpre, dx1, *ws, bst, S["bmean"], S["brstd"], S["bA"], N, self.training,
+                          [G[b.bn.weight] for b in brs], [G[b.bn.bias] for b in brs], *[G[w] for w in ws])
+        else:
+            cA, cC, cD = (_E(x, 4, E) for _ in range(3))
+            hip.dw_bwd_coef(bst, S["bmean"], S["brstd"], S["bA"], N, self.training, cA, cC, cD,
+                            [G[b.bn.weight] for b in brs], [G[b.bn.bias] for b in brs])
+            hip.dw_bwd(x1, dpre, dx1, *ws, cA, cC, cD, *[G[w] for w in ws])
         # ---- A1 backward: Hardswish' and BatchNorm backward fused into the recomputed 1x1 conv
         wpe = S["wpe"]
         # pass 1 is statistics only (dh = dx1 * hswish'(h) is not written); pass 2 forms dh again from dx1 and turns it into

@@ -63,7 +63,7 @@ class WgradArgs(C.Structure):
 SYMBOLS = [
     "lmn_abi_version", "lmn_sizeof_conv_args", "lmn_sizeof_src", "lmn_sizeof_wgrad_args", "lmn_last_error",
     "lmn_conv_pack_size", "lmn_conv_pack", "lmn_conv_pack_batch", "lmn_sizeof_pack_job", "lmn_conv_fwd", "lmn_conv_wgrad", "lmn_conv_wgrad_workspace",
-    "lmn_dw_stats", "lmn_dw_fwd", "lmn_dw_merge", "lmn_dw_finalize_merge", "lmn_dw_bwd_stats", "lmn_dw_bwd_coef", "lmn_dw_bwd",
+    "lmn_dw_stats", "lmn_dw_fwd", "lmn_dw_merge", "lmn_dw_finalize_merge", "lmn_dw_bwd_stats", "lmn_dw_bwd_coef", "lmn_dw_bwd", "lmn_dw_fwd_bn", "lmn_dw_bwd_bn",
     "lmn_se_fwd", "lmn_se_bwd", "lmn_na_fwd", "lmn_na_bwd", "lmn_gattn_fwd", "lmn_gattn_bwd",
     "lmn_ln_fwd", "lmn_ln_bwd", "lmn_bnact_fwd", "lmn_bnact_bwd_stats", "lmn_bnact_bwd",
     "lmn_bn_finalize", "lmn_bn_fold", "lmn_bn_bwd_coef", "lmn_up2_fwd", "lmn_up2_bwd", "lmn_avgpool_fwd", "lmn_avgpool_bwd",
@@ -446,6 +446,29 @@ def dw_finalize_merge(stats, count, bns, ws, mean, rstd, A, keff, beff):
         F4(*[b.eps for b in bns]), F4(*[(b.momentum if b.momentum is not None else 0.1) for b in bns]),
         _p(ws[0]), _p(ws[1]), _p(ws[2]), _p(ws[3]), _p(mean), _p(rstd), _p(A), _p(keff), _p(beff), E, _stream()),
         "dw_finalize_merge")
+
+
+def dw_fwd_bn(x1, pre, gsum, stats, count, bns, ws, mean, rstd, A):
+    """dw_finalize_merge + dw_fwd in one launch (training): bns / ws as in dw_finalize_merge."""
+    P4 = C.c_void_p * 4
+    F4 = C.c_float * 4
+    B, H, W, E = x1.shape
+    _check(load().lmn_dw_fwd_bn(
+        _pa(x1), _pa(pre), _p(gsum), B, H, W, E, _p(stats), _f(count), P4(*[b.weight.data_ptr() for b in bns]),
+        P4(*[b.bias.data_ptr() for b in bns]), P4(*[b.running_mean.data_ptr() for b in bns]),
+        P4(*[b.running_var.data_ptr() for b in bns]), F4(*[b.eps for b in bns]),
+        F4(*[(b.momentum if b.momentum is not None else 0.1) for b in bns]), _p(ws[0]), _p(ws[1]), _p(ws[2]), _p(ws[3]),
+        _p(mean), _p(rstd), _p(A), _dt(x1, pre), _stream()), "dw_fwd_bn")
+
+
+def dw_bwd_bn(x1, dpre, dx1, w5, w3, wv, wh, bstats, mean, rstd, A, count, batch_stats, dgs, dbs, dw5, dw3, dwv, dwh):
+    """dw_bwd_coef + dw_bwd in one launch."""
+    P4 = C.c_void_p * 4
+    B, H, W, E = x1.shape
+    _check(load().lmn_dw_bwd_bn(_pa(x1), _pa(dpre), _pa(dx1), B, H, W, E, _p(w5), _p(w3), _p(wv), _p(wh), _p(bstats), _p(mean),
+                                _p(rstd), _p(A), _f(count), int(batch_stats), P4(*[t.data_ptr() for t in dgs]),
+                                P4(*[t.data_ptr() for t in dbs]), _p(dw5), _p(dw3), _p(dwv), _p(dwh), _dt(x1, dpre, dx1),
+                                _stream()), "dw_bwd_bn")
 
 
 def dw_bwd_stats(x1, pre, u, s, dm, dpre, w5, w3, wv, wh, bstats):

@@ -321,6 +321,41 @@ def check_dw():
         rows.append(("dw_bwd dx1" + tag, rel(nchw(dx1), x1r.grad), TOL))
         for nm, got, ref in zip(("dW5", "dW3", "dWv", "dWh"), dws, wsr):
             rows.append(("dw_bwd " + nm + tag, rel(got, ref.grad), 2e-4))
+        # --- the one-launch forms (BatchNorm bookkeeping inside the depthwise passes): same results as the launch pairs
+        class _BN:   # the four attributes hip.dw_fwd_bn / dw_finalize_merge read of a BatchNorm2d
+            def __init__(self, i, rm, rv):
+                self.weight, self.bias, self.running_mean, self.running_var, self.eps, self.momentum = dev(gam[i]), dev(bet[i]), rm, rv, 1e-5, 0.1
+        rm0 = [dev(R(E, seed=90 + i) * 0.2) for i in range(4)]
+        rv0 = [dev(R(E, seed=94 + i).abs() + 0.5) for i in range(4)]
+        bn_a = [_BN(i, rm0[i].clone(), rv0[i].clone()) for i in range(4)]
+        bn_b = [_BN(i, rm0[i].clone(), rv0[i].clone()) for i in range(4)]
+        sref_d = dev(sref)
+        m_a, r_a, A_a = (torch.zeros(4, E, device=DEV) for _ in range(3))
+        m_b, r_b, A_b = (torch.zeros(4, E, device=DEV) for _ in range(3))
+        keff2, beff2 = torch.empty(E, 25, device=DEV), torch.empty(E, device=DEV)
+        hip.dw_finalize_merge(sref_d, N, bn_b, wd, m_b, r_b, A_b, keff2, beff2)
+        pre_b = torch.full((B, H, W, E), float("nan"), device=DEV); gs_b = torch.zeros(B, E, device=DEV)
+        hip.dw_fwd(x1d, pre_b, gs_b, keff2, beff2)
+        pre_a = torch.full((B, H, W, E), float("nan"), device=DEV); gs_a = torch.zeros(B, E, device=DEV)
+        hip.dw_fwd_bn(x1d, pre_a, gs_a, sref_d, N, bn_a, wd, m_a, r_a, A_a)
+        rows.append(("dw_fwd_bn pre vs finalize_merge + fwd" + tag, rel(pre_a, pre_b), 1e-6))
+        rows.append(("dw_fwd_bn pre vs reference" + tag, rel(nchw(pre_a), pre_ref), TOL))
+        rows.append(("dw_fwd_bn gsum" + tag, rel(gs_a, gs_b), 1e-5))
+        for nm, ta, tb in (("mean", m_a, m_b), ("rstd", r_a, r_b), ("A", A_a, A_b)):
+            rows.append(("dw_fwd_bn %s" % nm + tag, rel(ta, tb), 1e-6))
+        for i in range(4):
+            rows.append(("dw_fwd_bn running stats[%d]" % i + tag, max(rel(bn_a[i].running_mean, bn_b[i].running_mean),
+                                                                     rel(bn_a[i].running_var, bn_b[i].running_var)), 1e-6))
+        dx1b = torch.full((B, H, W, E), float("nan"), device=DEV)
+        dws2 = [torch.zeros_like(dev(w)) for w in ws]
+        dgs2 = [torch.zeros(E, device=DEV) for _ in range(4)]
+        dbs2 = [torch.zeros(E, device=DEV) for _ in range(4)]
+        hip.dw_bwd_bn(x1d, nhwc(dpre_ref), dx1b, *wd, dev(bref), dev(torch.stack(mean)), dev(torch.stack(rstd)), dev(A), N, True,
+                      dgs2, dbs2, *dws2)
+        rows.append(("dw_bwd_bn dx1 vs coef + bwd" + tag, rel(dx1b, dx1), 1e-6))
+        for i in range(4):
+            rows.append(("dw_bwd_bn dgamma/dbeta[%d]" % i + tag, max(rel(dgs2[i], dgs[i]), rel(dbs2[i], dbs[i])), 1e-6))
+            rows.append(("dw_bwd_bn dW[%d]" % i + tag, rel(dws2[i], dws[i]), 1e-5))
     return rows
 
 

@@ -380,7 +380,7 @@ def test_plan_mode_matches_host_launches():
     b.enable_plans()
     (la, _), (lb, ob) = run(a, 7), run(b, 7)
     ps = [p for p in b._plans.values() if p.fwd is not None]
-    assert len(ps) == 1 and ps[0].bwd is not None and ps[0].fwd.size() > 200 and ps[0].bwd.size() > 400
+    assert len(ps) == 1 and ps[0].bwd is not None and ps[0].fwd.size() > 150 and ps[0].bwd.size() > 300
     assert max(abs(u - v) / abs(u) for u, v in zip(la, lb)) < 2e-3, (la, lb)
     assert ob._flat_grad().data_ptr() == ps[0].flat.data_ptr()          # the optimizer reads the static buffer in place
     na_, nb = [[m for m in n.modules() if isinstance(m, torch.nn.BatchNorm2d)][0] for n in (a, b)]
