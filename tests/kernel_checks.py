@@ -361,7 +361,14 @@ def check_dw():
 
 def check_se():
     rows = []
-    B, E, Rr, HW = 3, 24, 6, 35
+    for cfg in ((3, 24, 6, 35), (8, 192, 48, 121), (30, 192, 48, 64)):   # the last one: the per-image kernel (batch too large for one block)
+        rows += _check_se(*cfg)
+    return rows
+
+
+def _check_se(B, E, Rr, HW):
+    rows = []
+    tag = " B=%d E=%d" % (B, E)
     gsum = R(B, E, seed=81) * HW * 0.3
     w1, b1 = R(Rr, E, seed=82, scale=0.4).requires_grad_(True), R(Rr, seed=83).requires_grad_(True)
     w2, b2 = R(E, Rr, seed=84, scale=0.8).requires_grad_(True), R(E, seed=85).requires_grad_(True)
@@ -376,14 +383,14 @@ def check_se():
     (s_ref * ds).sum().backward()
     s, hid = torch.empty(B, E, device=DEV), torch.empty(B, Rr, device=DEV)
     hip.se_fwd(dev(gsum), 1.0 / HW, dev(w1), dev(b1), dev(w2), dev(b2), s, hid)
-    rows.append(("se_fwd s", rel(s, s_ref), TOL))
+    rows.append(("se_fwd s" + tag, rel(s, s_ref), TOL))
     dm = torch.empty(B, E, device=DEV)
     dw1, db1 = torch.zeros(Rr, E, device=DEV), torch.zeros(Rr, device=DEV)
     dw2, db2 = torch.zeros(E, Rr, device=DEV), torch.zeros(E, device=DEV)
     hip.se_bwd(dev(ds), dev(gsum), 1.0 / HW, dev(w1), dev(b1), dev(w2), dev(b2), hid, dm, dw1, db1, dw2, db2)
-    rows.append(("se_bwd dm (=d gsum)", rel(dm, gs.grad), TOL))
+    rows.append(("se_bwd dm (=d gsum)" + tag, rel(dm, gs.grad), TOL))
     for nm, got, ref in (("dw1", dw1, w1.grad), ("db1", db1, b1.grad), ("dw2", dw2, w2.grad), ("db2", db2, b2.grad)):
-        rows.append(("se_bwd " + nm, rel(got, ref), 2e-4))
+        rows.append(("se_bwd " + nm + tag, rel(got, ref), 2e-4))
     return rows
 
 
