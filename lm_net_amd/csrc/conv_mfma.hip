@@ -253,8 +253,12 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(const ConvParams P) {
 #ifdef LMN_CT_TIMING
     tk_a = __builtin_amdgcn_s_memtime();
 #endif
-    const int b = tile / (P.tiles_x * P.tiles_y), tt = tile - b * P.tiles_x * P.tiles_y;
-    const int oy0 = (tt / P.tiles_x) * P.TH, ox0 = (tt % P.tiles_x) * P.TW;
+    // (1x1: the host flattens the image to ONE row of H*W pixels -- tiles_y == 1, TH == 1, no padding: the row / window terms of
+    //  the general index math are dropped at compile time; these kernels are instruction-issue bound, PMC: some instruction of the
+    //  SIMD's five waves active 69 % of the time, 190 VALU + 215 SALU per wave and 128-pixel tile before this)
+    const int b = TAPS == 1 ? tile / P.tiles_x : tile / (P.tiles_x * P.tiles_y);
+    const int tt = TAPS == 1 ? tile - b * P.tiles_x : tile - b * P.tiles_x * P.tiles_y;
+    const int oy0 = TAPS == 1 ? 0 : (tt / P.tiles_x) * P.TH, ox0 = TAPS == 1 ? tt * P.TW : (tt % P.tiles_x) * P.TW;
     // window origin in input coordinates (forward: out*s - pad; data gradient, stride 1: out - pad, taps flipped)
     const int wy0 = S2T ? oy0 : (A.transposed ? oy0 - pad : oy0 * A.stride - pad);
     const int wx0 = S2T ? ox0 : (A.transposed ? ox0 - pad : ox0 * A.stride - pad);
@@ -283,7 +287,7 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(const ConvParams P) {
       const int i = (wv + 4 * g) * 16 + n;
       const bool in_t = i < P.TP;
       const int is = in_t ? i : 0;
-      const int r = (int)__umulhi((uint32_t)is, P.mTW), c = is - r * P.TW;
+      const int r = TAPS == 1 ? 0 : (int)__umulhi((uint32_t)is, P.mTW), c = is - r * P.TW;
       const int oy = S2T ? 2 * (oy0 + r) + cpy : oy0 + r, ox = S2T ? 2 * (ox0 + c) + cpx : ox0 + c;
       pvalid[g] = in_t && oy < A.Hout && ox < A.Wout;
       opix[g] = pvalid[g] ? (b * A.Hout + oy) * A.Wout + ox : 0;
@@ -343,11 +347,11 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(const ConvParams P) {
           for (int u = 0; u < SU; ++u) {
             const int i = i0 + u * 256 + tid;
             const int f = i & (per_px - 1), pix = i >> psh;
-            const int r = (int)__umulhi((uint32_t)pix, P.mXW), c = pix - r * P.XW;
+            const int r = TAPS == 1 ? 0 : (int)__umulhi((uint32_t)pix, P.mXW), c = pix - r * P.XW;
             const int iy = wy0 + r, ix = wx0 + c;
             const int ch = kb0 * 16 + f * 4;
-            const bool ok = i < nitems && ch < S.C && (unsigned)iy < (unsigned)A.Hin && (unsigned)ix < (unsigned)A.Win;
-            const int gp = ok ? (b * A.Hin + iy) * A.Win + ix : 0;
+            const bool ok = i < nitems && ch < S.C && (TAPS == 1 || (unsigned)iy < (unsigned)A.Hin) && (unsigned)ix < (unsigned)A.Win;
+            const int gp = ok ? (TAPS == 1 ? b * A.Win + ix : (b * A.Hin + iy) * A.Win + ix) : 0;
             sgp[u] = ok ? gp : -1;
             sv[u] = ld4((const TA*)S.ptr + (uint32_t)(gp * S.cstride + (ok ? ch : 0)));
           }
