@@ -669,6 +669,34 @@ __device__ __forceinline__ void ss_step(f32x2 (&a5)[5], f32x2 (&a3)[5], f32x2 (&
   a5[D] = a3[D] = av[D] = ah[D] = z2;
 }
 
+// MODE 1 without the branch outputs: sum_p dpre[p] * y_b[p] = sum_t w_b[t] * G[t] with G[t] = sum_p dpre[p] * x1[p + t] (the 5x5
+// correlation of dpre with x1, of which the 3x3 / 3x1 / 1x3 taps are subsets), so the pass accumulates the 25 G products per
+// pixel (25 packed FMAs) instead of the four y_b (40) and their products with dpre (4), and contracts G with the four kernels
+// once per block.  dpre depends on pre / u only, so its row o is formed at step o -- when x1 row o+2 (ring row o) arrives -- and
+// pairs with x1 ring rows o .. o+4 over the next five steps: G[ky][kx] += dpre[j - ky] * x1ring[j][x + kx - 2] at step j.
+template <int P>
+__device__ __forceinline__ void ss_step_g(f32x2 (&G)[25], f32x2 (&hist)[5], f32x2& sum0, const float* XS, const float* PS,
+                                          const float* US, float* OUT, int j, int lane, int wv, bool row_ok, bool valid,
+                                          f32x2 sv, f32x2 dv) {
+  const float* xr = XS + ((j % FS_XR) * SW_XC + lane) * SW_CS + wv * 2;
+  f32x2 in[5];
+#pragma unroll
+  for (int d = 0; d < 5; ++d) in[d] = *reinterpret_cast<const f32x2*>(xr + d * SW_CS);
+  const int o = (P * SW_FC + lane) * SW_CS + wv * 2;
+  const f32x2 pv = *reinterpret_cast<const f32x2*>(PS + o), uv = *reinterpret_cast<const f32x2*>(US + o);
+  f32x2 d;
+  d[0] = (uv[0] * sv[0] + dv[0]) * lmn_dgelu(pv[0]);
+  d[1] = (uv[1] * sv[1] + dv[1]) * lmn_dgelu(pv[1]);
+  *reinterpret_cast<f32x2*>(OUT + o) = d;            // rows past the segment are dropped by the store descriptor
+  d *= (valid && row_ok) ? 1.f : 0.f;
+  sum0 += d;
+  hist[P] = d;
+#pragma unroll
+  for (int ky = 0; ky < 5; ++ky)
+#pragma unroll
+    for (int kx = 0; kx < 5; ++kx) G[ky * 5 + kx] += hist[(P - ky + 5) % 5] * in[kx];
+}
+
 template <int MODE, typename TA>
 __global__ __launch_bounds__(256) void dw_stats_strip_kernel(
     const TA* __restrict__ x1, const TA* __restrict__ pre, const TA* __restrict__ u,
@@ -691,11 +719,13 @@ __global__ __launch_bounds__(256) void dw_stats_strip_kernel(
   const bool cok = ch < E;
   const int chs = cok ? ch : 0;
   BranchW bw;
-  load_branch_w(bw, w5, w3, wvv, whh, chs, E);
+  if constexpr (MODE == 0) {   // (MODE 1 needs the kernels only for the final contraction: loaded there)
+    load_branch_w(bw, w5, w3, wvv, whh, chs, E);
 #pragma unroll
-  for (int k = 0; k < 9; ++k) asm volatile("" : "+v"(bw.w3[k].x), "+v"(bw.w3[k].y));
+    for (int k = 0; k < 9; ++k) asm volatile("" : "+v"(bw.w3[k].x), "+v"(bw.w3[k].y));
 #pragma unroll
-  for (int k = 0; k < 3; ++k) asm volatile("" : "+v"(bw.wv[k].x), "+v"(bw.wv[k].y), "+v"(bw.wh[k].x), "+v"(bw.wh[k].y));
+    for (int k = 0; k < 3; ++k) asm volatile("" : "+v"(bw.wv[k].x), "+v"(bw.wv[k].y), "+v"(bw.wh[k].x), "+v"(bw.wh[k].y));
+  }
   f32x2 sv = f32x2{0.f, 0.f}, dv = f32x2{0.f, 0.f};
   if (MODE == 1) {
     sv = f32x2{sgate[(int64_t)b * E + chs], sgate[(int64_t)b * E + chs + 1]};
@@ -737,7 +767,7 @@ __global__ __launch_bounds__(256) void dw_stats_strip_kernel(
       const int k4 = i & 1, pc = i >> 1;
       const int rr = pc / SW_FC, c = pc - rr * SW_FC;
       const bool ok = i < SW_R * SW_FC * 2 && xs + c < W && ch0 + k4 * 4 < E;
-      so[k] = ok ? (unsigned)(((rr - 4) * W + xs + c) * E + ch0 + k4 * 4) * ES : OOB;
+      so[k] = ok ? (unsigned)((rr * W + xs + c) * E + ch0 + k4 * 4) * ES : OOB;   // output row j0 + rr of the batch at step j0
       lo[k] = (rr * SW_FC + c) * SW_CS + k4 * 4;
     }
   }
@@ -746,7 +776,7 @@ __global__ __launch_bounds__(256) void dw_stats_strip_kernel(
     const unsigned base = (unsigned)((ys + j0) * rowb);
 #pragma unroll
     for (int k = 0; k < NX; ++k) px[k] = buf_load4<TA>(rin, fo[k] + base);
-    if (MODE == 1) {  // pre / u rows of the OUTPUT rows of batch j0: segment rows j0-4+rr
+    if (MODE == 1) {  // pre / u rows of the batch: segment rows j0+rr (past the segment: 0 by the descriptor)
       const unsigned sbase = (unsigned)(j0 * rowb);
 #pragma unroll
       for (int k = 0; k < ND; ++k) {
@@ -778,7 +808,7 @@ __global__ __launch_bounds__(256) void dw_stats_strip_kernel(
       }
     }
   };
-  auto drain = [&](int j0) {  // MODE 1: dpre rows finished by steps j0 .. j0+4 (segment rows j0-4+rr)
+  auto drain = [&](int j0) {  // MODE 1: dpre rows formed by steps j0 .. j0+4 (segment rows j0+rr)
     const unsigned sbase = (unsigned)(j0 * rowb);
 #pragma unroll
     for (int k = 0; k < (MODE == 1 ? ND : 0); ++k) {
@@ -792,8 +822,11 @@ __global__ __launch_bounds__(256) void dw_stats_strip_kernel(
 
   const f32x2 z2 = f32x2{0.f, 0.f};
   f32x2 a5[5], a3[5], av[5], ah[5], sum[NS];
+  f32x2 G[MODE == 1 ? 25 : 1], hist[5];
 #pragma unroll
-  for (int k = 0; k < 5; ++k) a5[k] = a3[k] = av[k] = ah[k] = z2;
+  for (int k = 0; k < 5; ++k) a5[k] = a3[k] = av[k] = ah[k] = hist[k] = z2;
+#pragma unroll
+  for (int k = 0; k < (MODE == 1 ? 25 : 1); ++k) G[k] = z2;
 #pragma unroll
   for (int k = 0; k < NS; ++k) sum[k] = z2;
   fetch(0);
@@ -804,7 +837,10 @@ __global__ __launch_bounds__(256) void dw_stats_strip_kernel(
 #define LMN_SS_STEP(PH)                                                                                          \
     {                                                                                                            \
       const int j = j0 + PH;                                                                                     \
-      if (j < nsteps) ss_step<PH, MODE>(a5, a3, av, ah, sum, bw, XS, PS, US, OUT, j, lane, wv, j >= 4, cvalid, sv, dv); \
+      if (j < nsteps) {                                                                                          \
+        if constexpr (MODE == 1) ss_step_g<PH>(G, hist, sum[0], XS, PS, US, OUT, j, lane, wv, j < ye - ys, cvalid, sv, dv); \
+        else ss_step<PH, MODE>(a5, a3, av, ah, sum, bw, XS, PS, US, OUT, j, lane, wv, j >= 4, cvalid, sv, dv);   \
+      }                                                                                                          \
     }
     LMN_SS_STEP(0) LMN_SS_STEP(1) LMN_SS_STEP(2) LMN_SS_STEP(3) LMN_SS_STEP(4)
 #undef LMN_SS_STEP
@@ -812,6 +848,18 @@ __global__ __launch_bounds__(256) void dw_stats_strip_kernel(
     if (MODE == 1) drain(j0);
     if (j0 + SW_R < nsteps) commit(j0 + SW_R);
     __syncthreads();
+  }
+  if constexpr (MODE == 1) {  // sum dpre * y_b = <w_b, G> (taps of the small kernels embedded in the 5x5 window as in dw_merge)
+    load_branch_w(bw, w5, w3, wvv, whh, chs, E);
+#pragma unroll
+    for (int t = 0; t < 25; ++t) sum[1] += bw.w5[t] * G[t];
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) sum[2] += bw.w3[ky * 3 + kx] * G[(ky + 1) * 5 + kx + 1];
+      sum[3] += bw.wv[ky] * G[(ky + 1) * 5 + 2];
+      sum[4] += bw.wh[ky] * G[2 * 5 + ky + 1];
+    }
   }
 #pragma unroll
   for (int k = 0; k < NS; ++k) {
