@@ -335,67 +335,6 @@ __global__ __launch_bounds__(256) void se_bwd_kernel(const float* __restrict__ d
   }
 }
 
-// All images in ONE block (B * (2E + 2R) floats of LDS): the per-image form above adds E*R weight-gradient products per image
-// with global atomics onto the same addresses from B blocks (B=8, E=192, R=48: 147 K same-address atomics, 14.6 us); here every
-// gradient element has one owner thread that sums over the images in registers and adds once (1024 threads, ~5 us).
-__global__ __launch_bounds__(1024) void se_bwd_all_kernel(const float* __restrict__ ds, const float* __restrict__ gsum,
-                                                          float inv_hw, const float* __restrict__ w1,
-                                                          const float* __restrict__ w2, const float* __restrict__ b2,
-                                                          const float* __restrict__ hidden, float* __restrict__ dm,
-                                                          float* dw1, float* db1, float* dw2, float* db2, int B, int E, int R) {
-  extern __shared__ float sm[];  // m[B][E], dt[B][E], h[B][R], da[B][R]
-  float* m = sm;
-  float* dt = sm + B * E;
-  float* h = sm + 2 * B * E;
-  float* da = h + B * R;
-  const int tid = threadIdx.x, NT = blockDim.x;
-  for (int i = tid; i < B * R; i += NT) h[i] = hidden[i];
-  for (int i = tid; i < B * E; i += NT) m[i] = gsum[i] * inv_hw;
-  __syncthreads();
-  for (int i = tid; i < B * E; i += NT) {  // dt[b][e] = ds * hsigmoid'(b2 + W2 h_b)
-    const int b = i / E, e = i - b * E;
-    float a = b2[e];
-    for (int r = 0; r < R; ++r) a += w2[(int64_t)e * R + r] * h[b * R + r];
-    dt[i] = ds[i] * lmn_dhsigmoid(a);
-  }
-  __syncthreads();
-  for (int i = tid; i < B * R; i += NT) {  // da[b][r] = relu'(h) * (W2^T dt_b)
-    const int b = i / R, r = i - b * R;
-    float a = 0.f;
-    for (int e = 0; e < E; ++e) a += w2[(int64_t)e * R + r] * dt[b * E + e];
-    da[i] = h[i] > 0.f ? a : 0.f;
-  }
-  for (int i = tid; i < E * R; i += NT) {  // dW2[e][r] += sum_b dt[b][e] h[b][r]
-    const int e = i / R, r = i - e * R;
-    float a = 0.f;
-    for (int b = 0; b < B; ++b) a += dt[b * E + e] * h[b * R + r];
-    dw2[i] += a;
-  }
-  for (int e = tid; e < E; e += NT) {
-    float a = 0.f;
-    for (int b = 0; b < B; ++b) a += dt[b * E + e];
-    db2[e] += a;
-  }
-  __syncthreads();
-  for (int i = tid; i < E * R; i += NT) {  // dW1[r][e] += sum_b da[b][r] m[b][e]
-    const int r = i / E, e = i - r * E;
-    float a = 0.f;
-    for (int b = 0; b < B; ++b) a += da[b * R + r] * m[b * E + e];
-    dw1[i] += a;
-  }
-  for (int r = tid; r < R; r += NT) {
-    float a = 0.f;
-    for (int b = 0; b < B; ++b) a += da[b * R + r];
-    db1[r] += a;
-  }
-  for (int i = tid; i < B * E; i += NT) {  // dm[b][e] = (W1^T da_b) / HW
-    const int b = i / E, e = i - b * E;
-    float a = 0.f;
-    for (int r = 0; r < R; ++r) a += w1[(int64_t)r * E + e] * da[b * R + r];
-    dm[i] = a * inv_hw;
-  }
-}
-
 // ------------------------------------------------------------------------------------ bilinear x2, align_corners=True
 // index arithmetic mirrors ATen's upsample_bilinear2d (fp32): src = dst * (in-1)/(out-1)
 __device__ __forceinline__ void up_coord(int dst, int in, float scale, int& i0, int& ip, float& l0, float& l1) {
@@ -973,11 +912,6 @@ int lmn_se_bwd(const float* ds, const float* gsum, float inv_hw, const float* w1
   (void)b1;
   LMN_REQUIRE(ds && gsum && w1 && w2 && b2 && hidden && dm && dw1 && db1 && dw2 && db2 && B > 0 && E > 0 && R > 0, "se_bwd: bad argument");
   LMN_REQUIRE((2 * E + 2 * R) * sizeof(float) <= 60000, "se_bwd: E=%d too large", E);
-  if ((size_t)B * (2 * E + 2 * R) * sizeof(float) <= 48 * 1024) {  // small batches: all images in one block, no atomics
-    LMN_LAUNCH(se_bwd_all_kernel, dim3(1), dim3(1024), (size_t)B * (2 * E + 2 * R) * sizeof(float), (hipStream_t)stream, ds, gsum,
-               inv_hw, w1, w2, b2, hidden, dm, dw1, db1, dw2, db2, B, E, R);
-    return lmn_launch_status("se_bwd");
-  }
   LMN_LAUNCH(se_bwd_kernel, dim3(B), dim3(256), (2 * E + 2 * R) * sizeof(float), (hipStream_t)stream, ds, gsum,
                      inv_hw, w1, w2, b2, hidden, dm, dw1, db1, dw2, db2, E, R);
   return lmn_launch_status("se_bwd");
