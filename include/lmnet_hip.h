@@ -283,7 +283,8 @@ int lmn_dw_bwd(const void* x1, const void* dpre, void* dx1, int B, int H, int W,
 int lmn_dw_bwd_bn(const void* x1, const void* dpre, void* dx1, int B, int H, int W, int E, const float* w5, const float* w3,
                   const float* wv, const float* wh, const float* bstats, const float* mean, const float* rstd, const float* A,
                   float count, int batch_stats, float* const* dgamma, float* const* dbeta, float* dw5, float* dw3, float* dwv,
-                  float* dwh, int act_dtype, lmn_stream_t stream);
+                  float* dwh, int part /* 0: everything; 1: dx1 (+ gamma / beta gradients) only; 2: the four weight gradients only */,
+                  int act_dtype, lmn_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * SE gate (core/modules.py:1020-1036): s = hardsigmoid(W2 relu(W1 m + b1) + b2), m = gsum/HW.

@@ -135,7 +135,9 @@ struct SwState {
 };
 
 // One row step.  P = step index mod 5 (compile time, so every slot below is a fixed register).
-template <int P>
+// PART: 0 = dx1 and the weight gradients in one pass, 1 = dx1 only, 2 = weight gradients only (the two halves can then run on
+// different streams: dx1 is on the critical path of the backward, the weight gradients are not)
+template <int P, int PART>
 __device__ __forceinline__ void sw_step(SwState& S, const BranchW& bw, const f32x2 (&ca)[4], const f32x2 (&cc)[4],
                                         const f32x2 (&cd)[4], const float* XS, const float* DPS, float* OUT, int j,
                                         int lane, int wv, bool frow_in, bool col_in, bool own, bool dx_row, bool dw_ok) {
@@ -172,7 +174,7 @@ __device__ __forceinline__ void sw_step(SwState& S, const BranchW& bw, const f32
   S.hv[Q] = own ? fv : z2;
   S.hh[Q] = own ? fh : z2;
   // ---- dx1: f row q feeds dx rows q-2..q+2; column neighbours by DPP.  sh[k][l] = f[l + 2 - k]
-  {
+  if constexpr (PART != 2) {
     f32x2 sh[5];
     sh[2] = f5;
     sh[1] = lane_from_right(f5);
@@ -197,10 +199,12 @@ __device__ __forceinline__ void sw_step(SwState& S, const BranchW& bw, const f32
   }
   // ---- dx row j-4 is complete
   constexpr int D = (P + 1) % 5;
-  if (dx_row) *reinterpret_cast<f32x2*>(OUT + (P * SW_FC + lane) * SW_CS + wv * 2) = S.dxa[D];
-  S.dxa[D] = z2;
+  if constexpr (PART != 2) {
+    if (dx_row) *reinterpret_cast<f32x2*>(OUT + (P * SW_FC + lane) * SW_CS + wv * 2) = S.dxa[D];
+    S.dxa[D] = z2;
+  }
   // ---- weight gradients: x1 row j-4 (re-read) against the own-pixel f history
-  if (dw_ok) {
+  if (PART != 1 && dw_ok) {
     const float* x2 = XS + (((j + SW_XR - 4) % SW_XR) * SW_XC + lane) * SW_CS + wv * 2;
     f32x2 i2[5];
 #pragma unroll
@@ -220,7 +224,7 @@ __device__ __forceinline__ void sw_step(SwState& S, const BranchW& bw, const f32
   }
 }
 
-template <typename TA>
+template <typename TA, int PART = 0>
 __global__ __launch_bounds__(256) void dw_bwd_strip_kernel(
     const TA* __restrict__ x1, const TA* __restrict__ dpre, TA* __restrict__ dx1, int B, int H, int W, int E,
     const float* __restrict__ w5, const float* __restrict__ w3, const float* __restrict__ wvv,
@@ -258,7 +262,7 @@ __global__ __launch_bounds__(256) void dw_bwd_strip_kernel(
         const float c = CF.batch_stats ? -a * T * rs / CF.count : 0.f;
         a2[h] = a; c2[h] = c;
         d2[h] = CF.batch_stats ? (-a * S0 / CF.count - c * mu) : 0.f;
-        if (cok && lane == 0 && strip == 0 && seg == 0 && b == 0) {  // one wave per channel pair
+        if (PART != 2 && cok && lane == 0 && strip == 0 && seg == 0 && b == 0) {  // one wave per channel pair
           CF.dg[k][e] += T;
           CF.db[k][e] += S0;
         }
@@ -357,7 +361,7 @@ __global__ __launch_bounds__(256) void dw_bwd_strip_kernel(
         vd[k] = buf_load4<TA>(rd, off);
         ld[k] = (rr * SW_FC + c) * SW_CS + k4 * 4;
       }
-      if (j0 >= 8 + SW_R - 4) drain(j0 - SW_R);  // dx rows of the previous batch leave while the loads are in flight
+      if (PART != 2 && j0 >= 8 + SW_R - 4) drain(j0 - SW_R);  // dx rows of the previous batch leave while the loads are in flight
 #pragma unroll
       for (int k = 0; k < NXB; ++k) {
         if (k * 256 + 255 < SW_R * SW_XC * 2 || tv + k * 256 < SW_R * SW_XC * 2) {
@@ -382,14 +386,15 @@ __global__ __launch_bounds__(256) void dw_bwd_strip_kernel(
         const int fy = ys - 6 + j;                                                                            \
         const bool frow_in = j >= 4 && fy >= 0 && fy < H;                                                     \
         const bool own = own_col && fy >= ys && fy < ye;                                                      \
-        sw_step<PH>(S, bw, ca, cc, cd, XS, DPS, OUT, j, lane, wv, frow_in, col_in, own, j >= 8 && j < ndx, j >= 4);      \
+        sw_step<PH, PART>(S, bw, ca, cc, cd, XS, DPS, OUT, j, lane, wv, frow_in, col_in, own, j >= 8 && j < ndx, j >= 4); \
       }                                                                                                       \
     }
     LMN_SW_STEP(0) LMN_SW_STEP(1) LMN_SW_STEP(2) LMN_SW_STEP(3) LMN_SW_STEP(4)
 #undef LMN_SW_STEP
   }
   __syncthreads();
-  drain(((nsteps + SW_R - 1) / SW_R) * SW_R - SW_R);  // dx rows of the last batch
+  if (PART != 2) drain(((nsteps + SW_R - 1) / SW_R) * SW_R - SW_R);  // dx rows of the last batch
+  if (PART == 1) return;
   // ---- weight gradients: butterfly over the 64 columns, one LDS row per wave, then one atomic per (tap, channel)
   __syncthreads();
   float* red = XS;  // [4 waves][40 taps][2]
@@ -1132,8 +1137,9 @@ int lmn_dw_bwd(const void* x1, const void* dpre, void* dx1, int B, int H, int W,
 int lmn_dw_bwd_bn(const void* x1, const void* dpre, void* dx1, int B, int H, int W, int E, const float* w5, const float* w3,
                   const float* wv, const float* wh, const float* bstats, const float* mean, const float* rstd, const float* A,
                   float count, int batch_stats, float* const* dgamma, float* const* dbeta, float* dw5, float* dw3, float* dwv,
-                  float* dwh, int act_dtype, lmn_stream_t stream) {
+                  float* dwh, int part, int act_dtype, lmn_stream_t stream) {
   LMN_REQUIRE_DT(act_dtype, "dw_bwd_bn");
+  LMN_REQUIRE(part >= 0 && part <= 2, "dw_bwd_bn: part %d", part);
   LMN_REQUIRE(x1 && dpre && dx1 && w5 && w3 && wv && wh && bstats && mean && rstd && A && dgamma && dbeta && dw5 && dw3 && dwv && dwh &&
                   count > 0.f, "dw_bwd_bn: bad argument");
   LMN_REQUIRE(B > 0 && H > 0 && W > 0 && E > 0 && E % 4 == 0, "dw_bwd_bn: E=%d must be a multiple of 4", E);
@@ -1146,13 +1152,15 @@ int lmn_dw_bwd_bn(const void* x1, const void* dpre, void* dx1, int B, int H, int
   }
   const int strips = lmn_cdiv(W, SW_OC), chunks = lmn_cdiv(E, SW_CH);
   int seg_rows;
-  const int segs = strip_segments((int64_t)B * strips * chunks, H, 10, 2, &seg_rows);
+  const int segs = strip_segments((int64_t)B * strips * chunks, H, 10, part == 1 ? 3 : 2, &seg_rows);  // dx1 only: 151 VGPRs, 3 blocks per CU
   const int64_t nblk = (int64_t)B * strips * chunks * segs;
   LMN_REQUIRE(nblk < (1LL << 31), "dw_bwd_bn: grid too large");
   auto launch = [=]() -> int {
     if (g_lmn_prof_on) lmn_prof_cost(2.0 * 2 * 42 * (double)B * H * W * E, (act_dtype == LMN_BF16 ? 2.0 : 4.0) * 3 * (double)B * H * W * E);
-    LMN_ACT_DISPATCH(act_dtype, LMN_LAUNCH((dw_bwd_strip_kernel<T>), dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, (const T*)x1, (const T*)dpre, (T*)dx1, B, H, W, E, w5,
-                       w3, wv, wh, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, cf, dw5, dw3, dwv, dwh, strips, segs, seg_rows, chunks));
+#define LMN_DWB(PT) LMN_ACT_DISPATCH(act_dtype, LMN_LAUNCH((dw_bwd_strip_kernel<T, PT>), dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, (const T*)x1, (const T*)dpre, (T*)dx1, B, H, W, E, w5, \
+                       w3, wv, wh, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, cf, dw5, dw3, dwv, dwh, strips, segs, seg_rows, chunks))
+    if (part == 1) { LMN_DWB(1); } else if (part == 2) { LMN_DWB(2); } else { LMN_DWB(0); }
+#undef LMN_DWB
     return lmn_launch_status("dw_bwd_bn");
   };
   if (g_lmn_rec) lmn_rec_push(launch);

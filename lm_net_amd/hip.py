@@ -461,13 +461,13 @@ def dw_fwd_bn(x1, pre, gsum, stats, count, bns, ws, mean, rstd, A):
         _p(mean), _p(rstd), _p(A), _dt(x1, pre), _stream()), "dw_fwd_bn")
 
 
-def dw_bwd_bn(x1, dpre, dx1, w5, w3, wv, wh, bstats, mean, rstd, A, count, batch_stats, dgs, dbs, dw5, dw3, dwv, dwh):
-    """dw_bwd_coef + dw_bwd in one launch."""
+def dw_bwd_bn(x1, dpre, dx1, w5, w3, wv, wh, bstats, mean, rstd, A, count, batch_stats, dgs, dbs, dw5, dw3, dwv, dwh, part=0):
+    """dw_bwd_coef + dw_bwd in one launch (part 1: dx1 + gamma / beta gradients only, part 2: the weight gradients only)."""
     P4 = C.c_void_p * 4
     B, H, W, E = x1.shape
     _check(load().lmn_dw_bwd_bn(_pa(x1), _pa(dpre), _pa(dx1), B, H, W, E, _p(w5), _p(w3), _p(wv), _p(wh), _p(bstats), _p(mean),
                                 _p(rstd), _p(A), _f(count), int(batch_stats), P4(*[t.data_ptr() for t in dgs]),
-                                P4(*[t.data_ptr() for t in dbs]), _p(dw5), _p(dw3), _p(dwv), _p(dwh), _dt(x1, dpre, dx1),
+                                P4(*[t.data_ptr() for t in dbs]), _p(dw5), _p(dw3), _p(dwv), _p(dwh), part, _dt(x1, dpre, dx1),
                                 _stream()), "dw_bwd_bn")
 
 
