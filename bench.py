@@ -129,6 +129,23 @@ def roofline_block(dominant, live, survey, tot_us, B, H, W, step_s, alone):
                 r["row_A7"][k] = {f: _entry(k, v)[f] for f in ("avg_us", "achieved", "frac")}
                 if k in alone:
                     r["row_A7"][k]["frac_alone"] = _entry(k, alone[k])["frac"]
+    # the conv families, from the survey steps (every launch timed, four streams live): algorithmic bytes / FLOPs of all launches
+    # of a family / the sum of their event durations, against the roofline that bounds the family as a whole
+    fam = {"conv 1x1 fwd + dgrad (rows A1, A3, A6/A8 linears)": ("conv_tile_kernel<1,", "conv_tileM_kernel<1,"),
+           "conv 3x3 fwd + dgrad (rows A4, A9-A11)": ("conv_tile_kernel<9,", "conv_tileM_kernel<9,"),
+           "weight gradients 1x1": ("wgrad_1x1w_kernel", "wgrad_1x1_kernel", "wgrad_reduce_kernel<1,"),
+           "weight gradients 3x3": ("wgrad3_kernel", "wgrad_lds_kernel", "wgrad_reduce_kernel<9,")}
+    r["families_survey"] = {}
+    for label, prefixes in fam.items():
+        tot = {"launches": 0, "total_us": 0.0, "flops": 0.0, "bytes": 0.0}
+        for k, v in survey.items():
+            if k.startswith(prefixes):
+                for f in tot:
+                    tot[f] += v[f]
+        if tot["total_us"] > 0:
+            e = _entry(label, tot)
+            r["families_survey"][label] = {k: e[k] for k in ("bound", "launches", "achieved", "peak", "unit", "frac")}
+            r["families_survey"][label]["share_of_gpu_time"] = round(tot["total_us"] / tot_us, 4)
     scale = (H * W) / (352.0 * 352.0)
     mb, gf = STEP_MB_352 * scale * B, STEP_GFLOP_352 * scale * B
     r["whole_step"] = {"algorithmic_MB": round(mb, 1), "algorithmic_GFLOP": round(gf, 1),
