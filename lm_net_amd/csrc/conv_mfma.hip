@@ -2067,40 +2067,44 @@ __global__ __launch_bounds__(256) void wgrad_1x1w_kernel(const WgradParams P) {
 }
 
 // second stage: dW[co][ci][tap] += sum over the K-split blocks of their partial tiles (fixed order => deterministic).
-// 1024 threads = 64 consecutive elements x 16 K-slices; each thread keeps 8 loads in flight.
+// 1024 threads = epq groups of 4 consecutive elements (one 16 B load each) x ksl K-slices, 4 loads in flight per thread: the
+// 768 partials of a 3x3 layer are 28 MB, and with 4 B loads the 145 blocks of that launch had 2.4 MB in flight (1 TB/s).
 template <int TAPS, int NMT, int NNT>
 __global__ __launch_bounds__(1024) void wgrad_reduce_kernel(const WgradParams P, int nblk, int ksl) {
-  // a block sums epb = 1024 / ksl elements over the nblk partials in ksl slices (ksl = 1 .. 16, a power of two sized to
-  // nblk on the host: with 2-3 partials, 16 slices left 13 of 16 waves idle and the grid 4x too large)
+  // ksl = 1 .. 64, a power of two sized to nblk on the host (with 2-3 partials, many slices leave most waves idle)
   const lmn_wgrad_args_t& A = P.a;
-  constexpr int NT = TAPS * NMT * NNT, PER = NT * 256 + NMT * 16;
-  __shared__ float red[1024];
+  constexpr int NT = TAPS * NMT * NNT, PER = NT * 256 + NMT * 16;  // PER % 4 == 0
+  __shared__ __attribute__((aligned(16))) float red[4096];
   const int mset = blockIdx.y / P.nsets_n, nset = blockIdx.y - mset * P.nsets_n;
   const int mt0 = mset * NMT, nt0 = nset * NNT;
   const float* src = P.partial + (int64_t)blockIdx.y * nblk * PER;
-  const int epb = 1024 / ksl;
-  const int e = threadIdx.x & (epb - 1), ks = threadIdx.x / epb;
-  const int i = blockIdx.x * epb + e;
-  float sum = 0.f;
-  if (i < PER) {
+  const int epq = 1024 / ksl, epb = epq * 4;
+  const int q = threadIdx.x & (epq - 1), ks = threadIdx.x / epq;
+  const int i4 = (blockIdx.x * epq + q) * 4;
+  f32x4 s4 = f32x4{0.f, 0.f, 0.f, 0.f};
+  if (i4 < PER) {
+    const float* sp = src + i4;
 #pragma unroll 4
-    for (int k = ks; k < nblk; k += ksl) sum += src[(int64_t)k * PER + i];
+    for (int k = ks; k < nblk; k += ksl) s4 += *reinterpret_cast<const f32x4*>(sp + (int64_t)k * PER);
   }
-  red[threadIdx.x] = sum;
+  *reinterpret_cast<f32x4*>(&red[threadIdx.x * 4]) = s4;
   __syncthreads();
-  if (ks != 0 || i >= PER) return;
-  for (int k = 1; k < ksl; ++k) sum += red[k * epb + e];
+  for (int e = threadIdx.x; e < epb; e += 1024) {  // (epb > 1024 for ksl < 4)
+  const int i = blockIdx.x * epb + e;
+  if (i >= PER) return;
+  float sum = 0.f;
+  for (int k = 0; k < ksl; ++k) sum += red[k * epb + e];
   if (i < NT * 256) {
     const int ln = i & 63, r = (i >> 6) & 3, tile = i >> 8;
     const int t = tile % NNT, m = (tile / NNT) % NMT, tp = tile / (NNT * NMT);
     const int qq = ln >> 4, nn = ln & 15;
     const int co = (mt0 + m) * 16 + qq * 4 + r;
     const int nt = nt0 + t;
-    if ((mt0 + m) >= P.NMTT || co >= A.Cout || nt >= P.NNTT) return;
+    if ((mt0 + m) >= P.NMTT || co >= A.Cout || nt >= P.NNTT) continue;
     int sidx = 0;
     while (sidx + 1 < A.nsrc && nt >= P.ntile_off[sidx + 1]) ++sidx;
     const int ch = (nt - P.ntile_off[sidx]) * 16 + nn;
-    if (ch >= A.src[sidx].C) return;
+    if (ch >= A.src[sidx].C) continue;
     wgrad_dst(P, co, sidx, ch, TAPS)[tp] += sum;
   } else if (A.db && nset == 0) {
     const int j = i - NT * 256, co = mt0 * 16 + j;
@@ -2108,6 +2112,7 @@ __global__ __launch_bounds__(1024) void wgrad_reduce_kernel(const WgradParams P,
       A.db[co] += sum;
       if (A.db2) A.db2[co] += sum;
     }
+  }
   }
 }
 
@@ -2523,9 +2528,9 @@ int lmn_conv_fwd(const lmn_conv_args_t* args, lmn_stream_t stream) {
   return -1;
 }
 
-static int reduce_slices(int nblk) {  // k-slices of the reduction kernel: ~4 partials per slice, at most 16
+static int reduce_slices(int nblk) {  // k-slices of the reduction kernel: ~4 partials per slice, at most 64
   int k = 1;
-  while (k < 16 && k * 4 < nblk) k <<= 1;
+  while (k < 64 && k * 4 < nblk) k <<= 1;
   return k;
 }
 
@@ -2674,7 +2679,7 @@ int lmn_conv_wgrad(const lmn_wgrad_args_t* args, lmn_stream_t stream) {
   wg_reduce_##T##M##N:                                                                                              \
     if (P.partial) {                                                                                                \
       const int ksl = reduce_slices(blocks);                                                                        \
-      const int rb = (int)((per + 1024 / ksl - 1) / (1024 / ksl));                                                  \
+      const int rb = (int)((per + 4096 / ksl - 1) / (4096 / ksl));                                                    \
       LMN_LAUNCH((wgrad_reduce_kernel<T, M, N>), dim3(rb, gy), dim3(1024), 0, st, P, blocks, ksl);          \
     }                                                                                                               \
   } while (0)
@@ -2708,7 +2713,7 @@ int lmn_conv_wgrad(const lmn_wgrad_args_t* args, lmn_stream_t stream) {
     else LMN_LAUNCH((wgrad_1x1_kernel<M, N, 0>), dgrid, dim3(256), 0, st, P);                               \
     if (P.partial) {                                                                                                \
       const int ksl = reduce_slices((int)nb);                                                                       \
-      const int rb = (int)((per + 1024 / ksl - 1) / (1024 / ksl));                                                  \
+      const int rb = (int)((per + 4096 / ksl - 1) / (4096 / ksl));                                                    \
       LMN_LAUNCH((wgrad_reduce_kernel<1, M, N>), dim3(rb, gy), dim3(1024), 0, st, P, (int)nb, ksl);         \
     }                                                                                                               \
   } while (0)
@@ -2721,7 +2726,7 @@ int lmn_conv_wgrad(const lmn_wgrad_args_t* args, lmn_stream_t stream) {
     else LMN_LAUNCH((wgrad_1x1w_kernel<M, N, 0>), dgrid, dim3(256), wsh, st, P);                            \
     if (P.partial) {                                                                                                \
       const int ksl = reduce_slices((int)nb);                                                                       \
-      const int rb = (int)((per + 1024 / ksl - 1) / (1024 / ksl));                                                  \
+      const int rb = (int)((per + 4096 / ksl - 1) / (4096 / ksl));                                                    \
       LMN_LAUNCH((wgrad_reduce_kernel<1, M, N>), dim3(rb, gy), dim3(1024), 0, st, P, (int)nb, ksl);         \
     }                                                                                                               \
   } while (0)

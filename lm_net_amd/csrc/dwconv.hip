@@ -137,42 +137,55 @@ struct SwState {
 // One row step.  P = step index mod 5 (compile time, so every slot below is a fixed register).
 // PART: 0 = dx1 and the weight gradients in one pass, 1 = dx1 only, 2 = weight gradients only (the two halves can then run on
 // different streams: dx1 is on the critical path of the backward, the weight gradients are not)
-template <int P, int PART>
+// FAST: a step in the interior of the segment (f row owned, dx row stored, weight-gradient products on): no row flags at all.
+// Column flags never appear here: columns outside the image carry zero coefficients (ca / cc / cd are per-lane registers), the
+// halo lanes of the strip are dropped from the weight-gradient sums at the end of the kernel.  Accumulator slots are not
+// zeroed: the first contribution to a row (kernel row 0 for y_b, kernel row 4 for dx1) is a plain product.
+template <int P, int PART, bool FAST>
 __device__ __forceinline__ void sw_step(SwState& S, const BranchW& bw, const f32x2 (&ca)[4], const f32x2 (&cc)[4],
                                         const f32x2 (&cd)[4], const float* XS, const float* DPS, float* OUT, int j,
-                                        int lane, int wv, bool frow_in, bool col_in, bool own, bool dx_row, bool dw_ok) {
+                                        int lane, int wv, bool frow_in, bool own, bool dx_row, bool dw_ok) {
   const f32x2 z2 = f32x2{0.f, 0.f};
   // ---- x1 row j: columns x-2 .. x+2
   const float* xr = XS + ((j % SW_XR) * SW_XC + lane) * SW_CS + wv * 2;
   f32x2 in[5];
 #pragma unroll
   for (int d = 0; d < 5; ++d) in[d] = *reinterpret_cast<const f32x2*>(xr + d * SW_CS);
+  S.a5[(P + 2) % 5] = bw.w5[0] * in[0];
 #pragma unroll
-  for (int ky = 0; ky < 5; ++ky)
+  for (int d = 1; d < 5; ++d) S.a5[(P + 2) % 5] += bw.w5[d] * in[d];
+#pragma unroll
+  for (int ky = 1; ky < 5; ++ky)
 #pragma unroll
     for (int d = 0; d < 5; ++d) S.a5[(P - ky + 7) % 5] += bw.w5[ky * 5 + d] * in[d];
+  S.a3[(P + 1) % 5] = bw.w3[0] * in[1];
+  S.a3[(P + 1) % 5] += bw.w3[1] * in[2];
+  S.a3[(P + 1) % 5] += bw.w3[2] * in[3];
+  S.av[(P + 1) % 5] = bw.wv[0] * in[2];
 #pragma unroll
-  for (int ky = 0; ky < 3; ++ky) {
+  for (int ky = 1; ky < 3; ++ky) {
 #pragma unroll
     for (int d = 0; d < 3; ++d) S.a3[(P - ky + 6) % 5] += bw.w3[ky * 3 + d] * in[1 + d];
     S.av[(P - ky + 6) % 5] += bw.wv[ky] * in[2];
   }
-#pragma unroll
-  for (int d = 0; d < 3; ++d) S.ah[P] += bw.wh[d] * in[1 + d];
+  S.ah[P] = bw.wh[0] * in[1];
+  S.ah[P] += bw.wh[1] * in[2];
+  S.ah[P] += bw.wh[2] * in[3];
   // ---- row q = j-2 is complete: f_b
   constexpr int Q = (P + 3) % 5;
   const f32x2 dp = *reinterpret_cast<const f32x2*>(DPS + (P * SW_FC + lane) * SW_CS + wv * 2);
-  const bool fin = frow_in && col_in;
   f32x2 f5 = cc[0] * S.a5[Q] + (ca[0] * dp + cd[0]);
   f32x2 f3 = cc[1] * S.a3[Q] + (ca[1] * dp + cd[1]);
   f32x2 fv = cc[2] * S.av[Q] + (ca[2] * dp + cd[2]);
   f32x2 fh = cc[3] * S.ah[Q] + (ca[3] * dp + cd[3]);
-  if (!fin) f5 = f3 = fv = fh = z2;
-  S.a5[Q] = S.a3[Q] = S.av[Q] = S.ah[Q] = z2;
-  S.h5[Q] = own ? f5 : z2;
-  S.h3[Q] = own ? f3 : z2;
-  S.hv[Q] = own ? fv : z2;
-  S.hh[Q] = own ? fh : z2;
+  if constexpr (!FAST) {
+    if (!frow_in) f5 = f3 = fv = fh = z2;
+  }
+  if (FAST || own) {
+    S.h5[Q] = f5; S.h3[Q] = f3; S.hv[Q] = fv; S.hh[Q] = fh;
+  } else {
+    S.h5[Q] = S.h3[Q] = S.hv[Q] = S.hh[Q] = z2;
+  }
   // ---- dx1: f row q feeds dx rows q-2..q+2; column neighbours by DPP.  sh[k][l] = f[l + 2 - k]
   if constexpr (PART != 2) {
     f32x2 sh[5];
@@ -181,8 +194,11 @@ __device__ __forceinline__ void sw_step(SwState& S, const BranchW& bw, const f32
     sh[0] = lane_from_right(sh[1]);
     sh[3] = lane_from_left(f5);
     sh[4] = lane_from_left(sh[3]);
+    S.dxa[P] = bw.w5[20] * sh[0];  // dx row j: first contribution
 #pragma unroll
-    for (int ky = 0; ky < 5; ++ky)
+    for (int kx = 1; kx < 5; ++kx) S.dxa[P] += bw.w5[20 + kx] * sh[kx];
+#pragma unroll
+    for (int ky = 0; ky < 4; ++ky)
 #pragma unroll
       for (int kx = 0; kx < 5; ++kx) S.dxa[(P + ky + 1) % 5] += bw.w5[ky * 5 + kx] * sh[kx];
     f32x2 s3[3];
@@ -200,11 +216,10 @@ __device__ __forceinline__ void sw_step(SwState& S, const BranchW& bw, const f32
   // ---- dx row j-4 is complete
   constexpr int D = (P + 1) % 5;
   if constexpr (PART != 2) {
-    if (dx_row) *reinterpret_cast<f32x2*>(OUT + (P * SW_FC + lane) * SW_CS + wv * 2) = S.dxa[D];
-    S.dxa[D] = z2;
+    if (FAST || dx_row) *reinterpret_cast<f32x2*>(OUT + (P * SW_FC + lane) * SW_CS + wv * 2) = S.dxa[D];
   }
   // ---- weight gradients: x1 row j-4 (re-read) against the own-pixel f history
-  if (PART != 1 && dw_ok) {
+  if (PART != 1 && (FAST || dw_ok)) {
     const float* x2 = XS + (((j + SW_XR - 4) % SW_XR) * SW_XC + lane) * SW_CS + wv * 2;
     f32x2 i2[5];
 #pragma unroll
@@ -225,7 +240,7 @@ __device__ __forceinline__ void sw_step(SwState& S, const BranchW& bw, const f32
 }
 
 template <typename TA, int PART = 0>
-__global__ __launch_bounds__(256) void dw_bwd_strip_kernel(
+__global__ __launch_bounds__(256, 2) void dw_bwd_strip_kernel(
     const TA* __restrict__ x1, const TA* __restrict__ dpre, TA* __restrict__ dx1, int B, int H, int W, int E,
     const float* __restrict__ w5, const float* __restrict__ w3, const float* __restrict__ wvv,
     const float* __restrict__ whh, const float* __restrict__ cA, const float* __restrict__ cC,
@@ -281,7 +296,11 @@ __global__ __launch_bounds__(256) void dw_bwd_strip_kernel(
   const int xs = strip * SW_OC;
   const int cx = xs - 2 + lane;
   const bool col_in = cx >= 0 && cx < W;
-  const bool own_col = lane >= 2 && lane < 2 + SW_OC && cx < W;
+  const bool own_col = lane >= 2 && lane < 2 + SW_OC;
+  if (!col_in) {  // f_b = 0 in columns outside the image
+#pragma unroll
+    for (int k = 0; k < 4; ++k) ca[k] = cc[k] = cd[k] = f32x2{0.f, 0.f};
+  }
   const TA* xb = x1 + (int64_t)b * H * W * E;
   const TA* db = dpre + (int64_t)b * H * W * E;
   TA* ob = dx1 + (int64_t)b * H * W * E;
@@ -329,7 +348,7 @@ __global__ __launch_bounds__(256) void dw_bwd_strip_kernel(
       }
     }
   };
-  for (int j0 = 0; j0 < nsteps; j0 += SW_R) {
+  auto stage = [&](int j0) {
     __syncthreads();  // previous batch computed: OUT holds its dx rows, XS/DPS slots are free
     // ---- stage x1 rows (image rows ys-4+j, columns xs-4 .. xs+63) and dpre rows (rows ys-6+j, columns xs-2 .. xs+61)
     {
@@ -378,20 +397,36 @@ __global__ __launch_bounds__(256) void dw_bwd_strip_kernel(
       }
     }
     __syncthreads();
-    // ---- five row steps (fixed register slots per phase)
+  };
+  // ---- five row steps per batch (fixed register slots per phase).  Interior batches (every step: f row owned by the segment, dx
+  // row stored, weight-gradient products on) take the flag-free form of the step; the three loops run one after the other (both
+  // forms inside ONE loop made the allocator spill 200 registers to scratch)
 #define LMN_SW_STEP(PH)                                                                                       \
     {                                                                                                         \
       const int j = j0 + PH;                                                                                  \
       if (j < nsteps) {                                                                                       \
         const int fy = ys - 6 + j;                                                                            \
         const bool frow_in = j >= 4 && fy >= 0 && fy < H;                                                     \
-        const bool own = own_col && fy >= ys && fy < ye;                                                      \
-        sw_step<PH, PART>(S, bw, ca, cc, cd, XS, DPS, OUT, j, lane, wv, frow_in, col_in, own, j >= 8 && j < ndx, j >= 4); \
+        const bool own = fy >= ys && fy < ye;                                                                 \
+        sw_step<PH, PART, false>(S, bw, ca, cc, cd, XS, DPS, OUT, j, lane, wv, frow_in, own, j >= 8 && j < ndx, j >= 4); \
       }                                                                                                       \
     }
+#define LMN_SW_FAST(PH) sw_step<PH, PART, true>(S, bw, ca, cc, cd, XS, DPS, OUT, j0 + PH, lane, wv, true, true, true, true);
+  int j0 = 0;
+  for (; j0 < nsteps && j0 < 8; j0 += SW_R) {
+    stage(j0);
     LMN_SW_STEP(0) LMN_SW_STEP(1) LMN_SW_STEP(2) LMN_SW_STEP(3) LMN_SW_STEP(4)
-#undef LMN_SW_STEP
   }
+  for (; j0 + 4 < (ye - ys) + 6; j0 += SW_R) {
+    stage(j0);
+    LMN_SW_FAST(0) LMN_SW_FAST(1) LMN_SW_FAST(2) LMN_SW_FAST(3) LMN_SW_FAST(4)
+  }
+  for (; j0 < nsteps; j0 += SW_R) {
+    stage(j0);
+    LMN_SW_STEP(0) LMN_SW_STEP(1) LMN_SW_STEP(2) LMN_SW_STEP(3) LMN_SW_STEP(4)
+  }
+#undef LMN_SW_STEP
+#undef LMN_SW_FAST
   __syncthreads();
   if (PART != 2) drain(((nsteps + SW_R - 1) / SW_R) * SW_R - SW_R);  // dx rows of the last batch
   if (PART == 1) return;
@@ -399,7 +434,7 @@ __global__ __launch_bounds__(256) void dw_bwd_strip_kernel(
   __syncthreads();
   float* red = XS;  // [4 waves][40 taps][2]
   auto wave_sum_store = [&](f32x2 v, int t) {  // DPP reduction: total lands in lane 63 (no LDS round trips)
-    float a = v.x, c = v.y;
+    float a = own_col ? v.x : 0.f, c = own_col ? v.y : 0.f;  // (the halo lanes of the strip belong to its neighbours)
 #define LMN_DPP_ADD(CTRL)                                                                               \
     a += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(a), CTRL, 0xF, 0xF, true));       \
     c += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(c), CTRL, 0xF, 0xF, true));
