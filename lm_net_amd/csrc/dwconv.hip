@@ -173,7 +173,7 @@ __device__ __forceinline__ void sw_step(SwState& S, const BranchW& bw, const f32
   S.ah[P] += bw.wh[2] * in[3];
   // ---- row q = j-2 is complete: f_b
   constexpr int Q = (P + 3) % 5;
-  const f32x2 dp = *reinterpret_cast<const f32x2*>(DPS + (P * SW_FC + lane) * SW_CS + wv * 2);
+  const f32x2 dp = *reinterpret_cast<const f32x2*>(DPS + (P * SW_XC + lane) * SW_CS + wv * 2);
   f32x2 f5 = cc[0] * S.a5[Q] + (ca[0] * dp + cd[0]);
   f32x2 f3 = cc[1] * S.a3[Q] + (ca[1] * dp + cd[1]);
   f32x2 fv = cc[2] * S.av[Q] + (ca[2] * dp + cd[2]);
@@ -216,7 +216,7 @@ __device__ __forceinline__ void sw_step(SwState& S, const BranchW& bw, const f32
   // ---- dx row j-4 is complete
   constexpr int D = (P + 1) % 5;
   if constexpr (PART != 2) {
-    if (FAST || dx_row) *reinterpret_cast<f32x2*>(OUT + (P * SW_FC + lane) * SW_CS + wv * 2) = S.dxa[D];
+    if (FAST || dx_row) *reinterpret_cast<f32x2*>(OUT + (P * SW_XC + lane) * SW_CS + wv * 2) = S.dxa[D];
   }
   // ---- weight gradients: x1 row j-4 (re-read) against the own-pixel f history
   if (PART != 1 && (FAST || dw_ok)) {
@@ -247,8 +247,8 @@ __global__ __launch_bounds__(256, 2) void dw_bwd_strip_kernel(
     const float* __restrict__ cD, const DwCoef CF, float* __restrict__ dw5, float* __restrict__ dw3, float* __restrict__ dwv,
     float* __restrict__ dwh, int strips, int segs, int seg_rows, int chunks) {
   __shared__ __attribute__((aligned(16))) float XS[SW_XR * SW_XC * SW_CS];
-  __shared__ __attribute__((aligned(16))) float DPS[SW_R * SW_FC * SW_CS];
-  __shared__ __attribute__((aligned(16))) float OUT[SW_R * SW_FC * SW_CS];
+  __shared__ __attribute__((aligned(16))) float DPS[SW_R * SW_XC * SW_CS];  // (rows of 68 like XS: one LDS index per staged item)
+  __shared__ __attribute__((aligned(16))) float OUT[SW_R * SW_XC * SW_CS];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   // logical block id: channel chunk fastest (siblings share the x1 / dpre cache lines -> same XCD, same L2)
@@ -324,27 +324,39 @@ __global__ __launch_bounds__(256, 2) void dw_bwd_strip_kernel(
   // num_records, rows above the image wrap negative, rows below it exceed num_records: loads return 0, stores are
   // dropped), offsets are 32-bit, and ALL loads of a batch are issued before the first LDS write (one exposed
   // memory latency per batch instead of six).
+  // Geometry is fixed per thread: item i = tid + k*256 is (row rr, column c, channel half k4) of a 5-row x 68-column batch, and
+  // x1 (columns xs-4+c), dpre (c in [2, 66)) and dx1 (c in [4, 64)) all use THE SAME item -> image column map, so one byte
+  // offset fo[k] and one LDS index li[k] per item serve the three tensors (a batch adds its wave-uniform row offset).
   constexpr unsigned OOB = 0x80000000u;
-  constexpr int NXB = (SW_R * SW_XC * 2 + 255) / 256, NDB = (SW_R * SW_FC * 2 + 255) / 256, NOB = (SW_R * SW_OC * 2 + 255) / 256;
+  constexpr int NXB = (SW_R * SW_XC * 2 + 255) / 256;
   constexpr unsigned ES = sizeof(TA);
   const int rowb = W * E * (int)ES;  // bytes per image row (host: (H+16)*W*E*4 < 2^30)
   const BufRsrc rx = make_rsrc(xb, (unsigned)H * rowb);
   const BufRsrc rd = make_rsrc(db, (unsigned)H * rowb);
   const BufRsrc ro = make_rsrc(ob + (int64_t)ys * W * E, (unsigned)(ye - ys) * rowb);
-  auto drain = [&](int jb) {  // dx rows of the batch that started at step jb: segment rows jb-8+rr
-    int tv = tid;
-    asm volatile("" : "+v"(tv));  // keep the index math inside the batch (hoisted, it costs accumulator registers)
+  unsigned fo[NXB];
+  int li[NXB];  // LDS float index of the item in a 5 x 68 x SW_CS batch | bit 16: dpre item | bit 17: dx1 item
 #pragma unroll
-    for (int k = 0; k < NOB; ++k) {
-      const int i = tv + k * 256;
-      if (k * 256 + 255 < SW_R * SW_OC * 2 || i < SW_R * SW_OC * 2) {
-        const int k4 = i & 1, pc = i >> 1;
-        const int rr = pc / SW_OC, c = pc - rr * SW_OC;
-        const bool ok = xs + c < W && ch0 + k4 * 4 < E;
-        const unsigned off = ok ? (unsigned)(((jb - 8 + rr) * W + xs + c) * E + ch0 + k4 * 4) * ES : OOB;
-        const float* o = &OUT[(rr * SW_FC + c + 2) * SW_CS + k4 * 4];
+  for (int k = 0; k < NXB; ++k) {
+    const int i = tid + k * 256;
+    const int k4 = i & 1, pc = i >> 1;
+    const int rr = pc / SW_XC, c = pc - rr * SW_XC;
+    const int gx = xs - 4 + c;
+    const bool ok = i < SW_R * SW_XC * 2 && gx >= 0 && gx < W && ch0 + k4 * 4 < E;
+    fo[k] = ok ? (unsigned)((rr * W + gx) * E + ch0 + k4 * 4) * ES : OOB;
+    const bool in = i < SW_R * SW_XC * 2;
+    li[k] = ((rr * SW_XC + c) * SW_CS + k4 * 4) | (in && c >= 2 && c < 2 + SW_FC ? 0x10000 : 0) | (in && c >= 4 && c < 4 + SW_OC ? 0x20000 : 0);
+  }
+  auto drain = [&](int jb) {  // dx rows of the batch that started at step jb: segment rows jb-8+rr
+    const unsigned base = (unsigned)((jb - 8) * rowb);
+#pragma unroll
+    for (int k = 0; k < NXB; ++k) {
+      int l = li[k];
+      asm volatile("" : "+v"(l));  // (derived indices / masks stay inside the batch: hoisted, they cost accumulator registers)
+      if (l & 0x20000) {
+        const float* o = &OUT[(l & 0xFFFF) - 2 * SW_CS];  // dx column c-4 sits at lane c-2
         const f32x2 a = *reinterpret_cast<const f32x2*>(o), d = *reinterpret_cast<const f32x2*>(o + 2);
-        buf_store4<TA>(ro, off, f32x4{a[0], a[1], d[0], d[1]});
+        buf_store4<TA>(ro, fo[k] + base, f32x4{a[0], a[1], d[0], d[1]});
       }
     }
   };
@@ -352,47 +364,34 @@ __global__ __launch_bounds__(256, 2) void dw_bwd_strip_kernel(
     __syncthreads();  // previous batch computed: OUT holds its dx rows, XS/DPS slots are free
     // ---- stage x1 rows (image rows ys-4+j, columns xs-4 .. xs+63) and dpre rows (rows ys-6+j, columns xs-2 .. xs+61)
     {
-      int tv = tid;
-      asm volatile("" : "+v"(tv));
-      f32x4 vx[NXB];
-      int lx[NXB];
+      const unsigned bx = (unsigned)((ys - 4 + j0) * rowb), bd = (unsigned)((ys - 6 + j0) * rowb);
+      f32x4 vx[NXB], vd[NXB];
+      int l[NXB];
 #pragma unroll
       for (int k = 0; k < NXB; ++k) {
-        const int i = tv + k * 256;
-        const int k4 = i & 1, pc = i >> 1;
-        const int rr = pc / SW_XC, c = pc - rr * SW_XC;
-        const int gx = xs - 4 + c;
-        const bool ok = i < SW_R * SW_XC * 2 && gx >= 0 && gx < W && ch0 + k4 * 4 < E;
-        const unsigned off = ok ? (unsigned)(((ys - 4 + j0 + rr) * W + gx) * E + ch0 + k4 * 4) * ES : OOB;
-        vx[k] = buf_load4<TA>(rx, off);
-        lx[k] = (((j0 + rr) % SW_XR) * SW_XC + c) * SW_CS + k4 * 4;
+        l[k] = li[k];
+        asm volatile("" : "+v"(l[k]));
       }
-      f32x4 vd[NDB];
-      int ld[NDB];
 #pragma unroll
-      for (int k = 0; k < NDB; ++k) {
-        const int i = tv + k * 256;
-        const int k4 = i & 1, pc = i >> 1;
-        const int rr = pc / SW_FC, c = pc - rr * SW_FC;
-        const int gx = xs - 2 + c;
-        const bool ok = i < SW_R * SW_FC * 2 && gx >= 0 && gx < W && ch0 + k4 * 4 < E;
-        const unsigned off = ok ? (unsigned)(((ys - 6 + j0 + rr) * W + gx) * E + ch0 + k4 * 4) * ES : OOB;
-        vd[k] = buf_load4<TA>(rd, off);
-        ld[k] = (rr * SW_FC + c) * SW_CS + k4 * 4;
-      }
+      for (int k = 0; k < NXB; ++k) vx[k] = buf_load4<TA>(rx, fo[k] + bx);  // (OOB + base stays out of range)
+#pragma unroll
+      for (int k = 0; k < NXB; ++k) vd[k] = buf_load4<TA>(rd, (l[k] & 0x10000) ? fo[k] + bd : OOB);
       if (PART != 2 && j0 >= 8 + SW_R - 4) drain(j0 - SW_R);  // dx rows of the previous batch leave while the loads are in flight
+      float* ring = XS + (j0 % SW_XR) * (SW_XC * SW_CS);
 #pragma unroll
       for (int k = 0; k < NXB; ++k) {
-        if (k * 256 + 255 < SW_R * SW_XC * 2 || tv + k * 256 < SW_R * SW_XC * 2) {
-          *reinterpret_cast<f32x2*>(&XS[lx[k]]) = f32x2{vx[k][0], vx[k][1]};
-          *reinterpret_cast<f32x2*>(&XS[lx[k] + 2]) = f32x2{vx[k][2], vx[k][3]};
+        if (k * 256 + 255 < SW_R * SW_XC * 2 || tid + k * 256 < SW_R * SW_XC * 2) {
+          float* d = ring + (l[k] & 0xFFFF);
+          *reinterpret_cast<f32x2*>(d) = f32x2{vx[k][0], vx[k][1]};
+          *reinterpret_cast<f32x2*>(d + 2) = f32x2{vx[k][2], vx[k][3]};
         }
       }
 #pragma unroll
-      for (int k = 0; k < NDB; ++k) {
-        if (k * 256 + 255 < SW_R * SW_FC * 2 || tv + k * 256 < SW_R * SW_FC * 2) {
-          *reinterpret_cast<f32x2*>(&DPS[ld[k]]) = f32x2{vd[k][0], vd[k][1]};
-          *reinterpret_cast<f32x2*>(&DPS[ld[k] + 2]) = f32x2{vd[k][2], vd[k][3]};
+      for (int k = 0; k < NXB; ++k) {
+        if (l[k] & 0x10000) {
+          float* d = &DPS[(l[k] & 0xFFFF) - 2 * SW_CS];  // dpre column c-2 sits at lane c-2
+          *reinterpret_cast<f32x2*>(d) = f32x2{vd[k][0], vd[k][1]};
+          *reinterpret_cast<f32x2*>(d + 2) = f32x2{vd[k][2], vd[k][3]};
         }
       }
     }
@@ -474,23 +473,24 @@ constexpr int FS_XR = 2 * SW_R;  // x1 ring: the batch being consumed + the batc
 
 template <int P>
 __device__ __forceinline__ void fs_step(f32x2 (&acc)[5], f32x2& gs, const f32x2 (&w)[25], f32x2 bias, const float* XS,
-                                        float* OUT, int j, int lane, int wv, bool row_out, bool cvalid) {
+                                        float* OUT, int j, int lane, int wv, bool row_out) {
   const float* xr = XS + ((j % FS_XR) * SW_XC + lane) * SW_CS + wv * 2;
   f32x2 in[5];
 #pragma unroll
   for (int d = 0; d < 5; ++d) in[d] = *reinterpret_cast<const f32x2*>(xr + d * SW_CS);
+  acc[P] = w[0] * in[0];  // output row j: first contribution (no zeroed accumulators)
 #pragma unroll
-  for (int ky = 0; ky < 5; ++ky)
+  for (int d = 1; d < 5; ++d) acc[P] += w[d] * in[d];
+#pragma unroll
+  for (int ky = 1; ky < 5; ++ky)
 #pragma unroll
     for (int d = 0; d < 5; ++d) acc[(P - ky + 5) % 5] += w[ky * 5 + d] * in[d];
   constexpr int D = (P + 1) % 5;  // output row j-4 is complete
   if (row_out) {
     const f32x2 pv = acc[D] + bias;
     *reinterpret_cast<f32x2*>(OUT + (P * SW_FC + lane) * SW_CS + wv * 2) = pv;
-    const float m = cvalid ? 1.f : 0.f;
-    gs += f32x2{lmn_gelu(pv[0]), lmn_gelu(pv[1])} * m;
+    gs += f32x2{lmn_gelu(pv[0]), lmn_gelu(pv[1])};  // (columns outside the image are dropped from the lane sums at the end)
   }
-  acc[D] = f32x2{0.f, 0.f};
 }
 
 template <typename TA>
@@ -636,7 +636,7 @@ __global__ __launch_bounds__(256) void dw_fwd_strip_kernel(const TA* __restrict_
 #define LMN_FS_STEP(PH)                                                                         \
     {                                                                                           \
       const int j = j0 + PH;                                                                    \
-      if (j < nsteps) fs_step<PH>(acc, gs, w, bias, XS, OUT, j, lane, wv, j >= 4, cvalid);      \
+      if (j < nsteps) fs_step<PH>(acc, gs, w, bias, XS, OUT, j, lane, wv, j >= 4);              \
     }
     LMN_FS_STEP(0) LMN_FS_STEP(1) LMN_FS_STEP(2) LMN_FS_STEP(3) LMN_FS_STEP(4)
 #undef LMN_FS_STEP
@@ -647,7 +647,7 @@ __global__ __launch_bounds__(256) void dw_fwd_strip_kernel(const TA* __restrict_
   }
   // SE squeeze: wave total by DPP (lands in lane 63), parked in LDS
   {
-    float a = gs.x, c = gs.y;
+    float a = cvalid ? gs.x : 0.f, c = cvalid ? gs.y : 0.f;
 #define LMN_DPP_ADD(CTRL)                                                                               \
     a += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(a), CTRL, 0xF, 0xF, true));       \
     c += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(c), CTRL, 0xF, 0xF, true));
@@ -671,31 +671,39 @@ __device__ __forceinline__ void ss_step(f32x2 (&a5)[5], f32x2 (&a3)[5], f32x2 (&
                                         f32x2 (&sum)[MODE == 0 ? 8 : 5], const BranchW& bw, const float* XS, const float* PS,
                                         const float* US, float* OUT, int j, int lane, int wv, bool row_out, bool valid,
                                         f32x2 sv, f32x2 dv) {
-  const f32x2 z2 = f32x2{0.f, 0.f};
   const float* xr = XS + ((j % FS_XR) * SW_XC + lane) * SW_CS + wv * 2;
   f32x2 in[5];
 #pragma unroll
   for (int d = 0; d < 5; ++d) in[d] = *reinterpret_cast<const f32x2*>(xr + d * SW_CS);
+  // the first contribution to an output row is a plain product (no zeroed accumulators, no register rotation)
+  a5[P] = bw.w5[0] * in[0];
 #pragma unroll
-  for (int ky = 0; ky < 5; ++ky)
+  for (int d = 1; d < 5; ++d) a5[P] += bw.w5[d] * in[d];
+#pragma unroll
+  for (int ky = 1; ky < 5; ++ky)
 #pragma unroll
     for (int d = 0; d < 5; ++d) a5[(P - ky + 5) % 5] += bw.w5[ky * 5 + d] * in[d];
+  a3[(P + 4) % 5] = bw.w3[0] * in[1];
+  a3[(P + 4) % 5] += bw.w3[1] * in[2];
+  a3[(P + 4) % 5] += bw.w3[2] * in[3];
+  av[(P + 4) % 5] = bw.wv[0] * in[2];
 #pragma unroll
-  for (int ky = 0; ky < 3; ++ky) {
+  for (int ky = 1; ky < 3; ++ky) {
 #pragma unroll
     for (int d = 0; d < 3; ++d) a3[(P + 4 - ky) % 5] += bw.w3[ky * 3 + d] * in[1 + d];
     av[(P + 4 - ky) % 5] += bw.wv[ky] * in[2];
   }
-#pragma unroll
-  for (int d = 0; d < 3; ++d) ah[(P + 3) % 5] += bw.wh[d] * in[1 + d];
+  ah[(P + 3) % 5] = bw.wh[0] * in[1];
+  ah[(P + 3) % 5] += bw.wh[1] * in[2];
+  ah[(P + 3) % 5] += bw.wh[2] * in[3];
   constexpr int D = (P + 1) % 5;  // output row j-4 is complete in every branch
   if (row_out) {
-    const float m = valid ? 1.f : 0.f;
-    const f32x2 y5 = a5[D] * m, y3 = a3[D] * m, yv = av[D] * m, yh = ah[D] * m;
-    if (MODE == 0) {
+    const f32x2 y5 = a5[D], y3 = a3[D], yv = av[D], yh = ah[D];
+    if (MODE == 0) {  // (columns outside the image are dropped from the lane sums at the end)
       sum[0] += y5; sum[1] += y3; sum[2] += yv; sum[3] += yh;
       sum[4] += y5 * y5; sum[5] += y3 * y3; sum[6] += yv * yv; sum[7] += yh * yh;
     } else {
+      const float m = valid ? 1.f : 0.f;
       const int o = (P * SW_FC + lane) * SW_CS + wv * 2;
       const f32x2 pv = *reinterpret_cast<const f32x2*>(PS + o), uv = *reinterpret_cast<const f32x2*>(US + o);
       f32x2 d;
@@ -706,7 +714,6 @@ __device__ __forceinline__ void ss_step(f32x2 (&a5)[5], f32x2 (&a3)[5], f32x2 (&
       sum[0] += d; sum[1] += d * y5; sum[2] += d * y3; sum[3] += d * yv; sum[4] += d * yh;
     }
   }
-  a5[D] = a3[D] = av[D] = ah[D] = z2;
 }
 
 // MODE 1 without the branch outputs: sum_p dpre[p] * y_b[p] = sum_t w_b[t] * G[t] with G[t] = sum_p dpre[p] * x1[p + t] (the 5x5
@@ -904,6 +911,7 @@ __global__ __launch_bounds__(256) void dw_stats_strip_kernel(
 #pragma unroll
   for (int k = 0; k < NS; ++k) {
     float a = sum[k].x, c = sum[k].y;
+    if (MODE == 0 && !cvalid) a = c = 0.f;
 #define LMN_DPP_ADD(CTRL)                                                                               \
     a += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(a), CTRL, 0xF, 0xF, true));       \
     c += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(c), CTRL, 0xF, 0xF, true));
