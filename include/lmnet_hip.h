@@ -295,6 +295,15 @@ int lmn_se_fwd(const float* gsum, float inv_hw, const float* w1, const float* b1
 int lmn_se_bwd(const float* ds, const float* gsum, float inv_hw, const float* w1, const float* b1, const float* w2,
                const float* b2, const float* hidden, float* dm, float* dw1, float* db1, float* dw2, float* db2,
                int B, int E, int R, lmn_stream_t stream);
+/* The same backward in two launches (core/modules.py:150-153, autograd of fc1 / ReLU / fc2 / Hardsigmoid):
+ * lmn_se_bwd_dm     ds[B][E], the saved gate s[B][E] (hardsigmoid' = 1/6 where 0 < s < 1), hidden[B][R] ->
+ *                   dm[B][E] (divided by HW) and dvec[B][E+R] = (d pre-gate | d pre-ReLU) per image; no atomics
+ * lmn_se_bwd_params dvec, gsum, hidden -> dw1[R][E], db1[R], dw2[E][R], db2[E] (+=), a batch reduction without atomics;
+ *                   independent of everything downstream of dm, i.e. it can run on a side stream. */
+int lmn_se_bwd_dm(const float* ds, const float* s, float inv_hw, const float* w1, const float* w2, const float* hidden,
+                  float* dm, float* dvec, int B, int E, int R, lmn_stream_t stream);
+int lmn_se_bwd_params(const float* dvec, const float* gsum, float inv_hw, const float* hidden, float* dw1, float* db1,
+                      float* dw2, float* db2, int B, int E, int R, lmn_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Neighborhood attention core (row A7; natten2dqkrpb + softmax + natten2dav fused).

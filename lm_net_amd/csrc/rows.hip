@@ -335,6 +335,76 @@ __global__ __launch_bounds__(256) void se_bwd_kernel(const float* __restrict__ d
   }
 }
 
+// SE backward in two launches: the per-image vectors (dm feeds the depthwise backward: critical path) and the parameter
+// gradients (a batch reduction without atomics; the engine puts it on the weight-gradient stream).  The one-launch form above
+// adds 2*E*R float atomics per image (590 k per call at E = 384) on the critical path.
+// hardsigmoid'(a) is recovered from the saved gate s = clamp(a/6 + 1/2, 0, 1): 1/6 where 0 < s < 1.
+__global__ __launch_bounds__(256) void se_bwd_dm_kernel(const float* __restrict__ ds, const float* __restrict__ sgate,
+                                                        float inv_hw, const float* __restrict__ w1,
+                                                        const float* __restrict__ w2, const float* __restrict__ hidden,
+                                                        float* __restrict__ dm, float* __restrict__ dvec, int E, int R) {
+  extern __shared__ float sm[];  // dt[E], da[R], part[256]
+  float* dt = sm;
+  float* da = sm + E;
+  float* part = sm + E + R;
+  const int b = blockIdx.x, t = threadIdx.x;
+  for (int e = t; e < E; e += 256) {
+    const float sv = sgate[(int64_t)b * E + e];
+    const float d = (sv > 0.f && sv < 1.f) ? ds[(int64_t)b * E + e] * (1.f / 6.f) : 0.f;
+    dt[e] = d;
+    dvec[(int64_t)b * (E + R) + e] = d;
+  }
+  __syncthreads();
+  // da[r] = relu'(h[r]) * sum_e w2[e][r] * dt[e]: groups of R threads (coalesced rows of w2) split the e range
+  const int groups = R <= 256 ? 256 / R : 1;
+  for (int r0 = 0; r0 < R; r0 += 256) {  // (one pass unless R > 256)
+    const int g = t / R, r = r0 + (R <= 256 ? t - g * R : t);
+    float a = 0.f;
+    if (g < groups && r < R)
+      for (int e = g; e < E; e += groups) a += w2[(int64_t)e * R + r] * dt[e];
+    part[t] = a;
+    __syncthreads();
+    if (t < R - r0 && t < 256) {
+      float v = 0.f;
+      if (R <= 256) { for (int k = 0; k < groups; ++k) v += part[k * R + t]; }
+      else v = part[t];
+      const int rr = r0 + t;
+      v = hidden[(int64_t)b * R + rr] > 0.f ? v : 0.f;
+      da[rr] = v;
+      dvec[(int64_t)b * (E + R) + E + rr] = v;
+    }
+    __syncthreads();
+  }
+  for (int e = t; e < E; e += 256) {
+    float a = 0.f;
+    for (int r = 0; r < R; ++r) a += w1[(int64_t)r * E + e] * da[r];
+    dm[(int64_t)b * E + e] = a * inv_hw;
+  }
+}
+
+__global__ __launch_bounds__(256) void se_bwd_params_kernel(const float* __restrict__ dvec, const float* __restrict__ gsum,
+                                                            float inv_hw, const float* __restrict__ hidden, float* dw1,
+                                                            float* db1, float* dw2, float* db2, int B, int E, int R) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  const int ER = E * R, S = E + R;
+  if (i < ER) {  // dw2[e][r] += sum_b dt[b][e] * h[b][r]
+    const int e = i / R, r = i - e * R;
+    float a = 0.f;
+    for (int b = 0; b < B; ++b) a += dvec[(int64_t)b * S + e] * hidden[(int64_t)b * R + r];
+    dw2[i] += a;
+  } else if (i < 2 * ER) {  // dw1[r][e] += sum_b da[b][r] * m[b][e]
+    const int k = i - ER, r = k / E, e = k - r * E;
+    float a = 0.f;
+    for (int b = 0; b < B; ++b) a += dvec[(int64_t)b * S + E + r] * (gsum[(int64_t)b * E + e] * inv_hw);
+    dw1[k] += a;
+  } else if (i < 2 * ER + S) {  // db2[e] | db1[r]
+    const int k = i - 2 * ER;
+    float a = 0.f;
+    for (int b = 0; b < B; ++b) a += dvec[(int64_t)b * S + k];
+    if (k < E) db2[k] += a; else db1[k - E] += a;
+  }
+}
+
 // ------------------------------------------------------------------------------------ bilinear x2, align_corners=True
 // index arithmetic mirrors ATen's upsample_bilinear2d (fp32): src = dst * (in-1)/(out-1)
 __device__ __forceinline__ void up_coord(int dst, int in, float scale, int& i0, int& ip, float& l0, float& l1) {
@@ -915,6 +985,26 @@ int lmn_se_bwd(const float* ds, const float* gsum, float inv_hw, const float* w1
   LMN_LAUNCH(se_bwd_kernel, dim3(B), dim3(256), (2 * E + 2 * R) * sizeof(float), (hipStream_t)stream, ds, gsum,
                      inv_hw, w1, w2, b2, hidden, dm, dw1, db1, dw2, db2, E, R);
   return lmn_launch_status("se_bwd");
+}
+
+int lmn_se_bwd_dm(const float* ds, const float* s, float inv_hw, const float* w1, const float* w2, const float* hidden,
+                  float* dm, float* dvec, int B, int E, int R, lmn_stream_t stream) {
+  LMN_REC(lmn_se_bwd_dm(ds, s, inv_hw, w1, w2, hidden, dm, dvec, B, E, R, stream));
+  LMN_REQUIRE(ds && s && w1 && w2 && hidden && dm && dvec && B > 0 && E > 0 && R > 0, "se_bwd_dm: bad argument");
+  LMN_REQUIRE((E + R + 256) * sizeof(float) <= 60000, "se_bwd_dm: E=%d too large", E);
+  LMN_LAUNCH(se_bwd_dm_kernel, dim3(B), dim3(256), (E + R + 256) * sizeof(float), (hipStream_t)stream, ds, s, inv_hw, w1, w2,
+             hidden, dm, dvec, E, R);
+  return lmn_launch_status("se_bwd_dm");
+}
+
+int lmn_se_bwd_params(const float* dvec, const float* gsum, float inv_hw, const float* hidden, float* dw1, float* db1,
+                      float* dw2, float* db2, int B, int E, int R, lmn_stream_t stream) {
+  LMN_REC(lmn_se_bwd_params(dvec, gsum, inv_hw, hidden, dw1, db1, dw2, db2, B, E, R, stream));
+  LMN_REQUIRE(dvec && gsum && hidden && dw1 && db1 && dw2 && db2 && B > 0 && E > 0 && R > 0, "se_bwd_params: bad argument");
+  const int64_t total = 2 * (int64_t)E * R + E + R;
+  LMN_LAUNCH(se_bwd_params_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, dvec, gsum, inv_hw,
+             hidden, dw1, db1, dw2, db2, B, E, R);
+  return lmn_launch_status("se_bwd_params");
 }
 
 int lmn_up2_fwd(const void* x, void* y, int B, int Hin, int Win, int C, int x_cstride, int y_cstride, int act_dtype,

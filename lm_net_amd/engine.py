@@ -146,6 +146,7 @@ class Engine:
         self.fuse_bn = os.environ.get("LMN_FUSE_BN", "1") != "0"
         # depthwise backward in two halves (dx1 here, weight gradients on the side stream; LMN_DW_SPLIT=1)
         self.split_dw = os.environ.get("LMN_DW_SPLIT", "0") == "1"
+        self.split_se = os.environ.get("LMN_SE_SPLIT", "1") != "0"   # SE backward in two launches (parameter gradients on the side stream)
         self.zpool_fwd, self.zpool_bwd = ZeroPool(), ZeroPool()
         self.packs_fwd, self.packs_bwd = hip.PackPlan(), hip.PackPlan()
         self.mma = hip.F32        # matrix-core operand type of the dense contractions of the pass (hip.F32 | hip.BF16)
@@ -453,8 +454,16 @@ class Engine:
             self.conv_T(dy, sc.weight, dx_sc, Hin=H, Win=W, rows=Cin)
         # ---- SE backward
         dm = _E(x, B, E)
-        hip.se_bwd(ds, S["gsum"], 1.0 / (H * W), se.fc1.weight, se.fc1.bias, se.fc2.weight, se.fc2.bias, S["hid"], dm,
-                   G[se.fc1.weight], G[se.fc1.bias], G[se.fc2.weight], G[se.fc2.bias])
+        if self.split_se:
+            # dm (critical path: it feeds the depthwise backward) here, the parameter gradients on the weight-gradient stream
+            dvec = _E(x, B, E + se.fc1.weight.shape[0])
+            hip.se_bwd_dm(ds, sgate, 1.0 / (H * W), se.fc1.weight, se.fc2.weight, S["hid"], dm, dvec)
+            gs_, hid_ = S["gsum"], S["hid"]
+            self.side_call(x, lambda: hip.se_bwd_params(dvec, gs_, 1.0 / (H * W), hid_, G[se.fc1.weight], G[se.fc1.bias],
+                                                        G[se.fc2.weight], G[se.fc2.bias]), keep=(dvec, gs_, hid_))
+        else:
+            hip.se_bwd(ds, S["gsum"], 1.0 / (H * W), se.fc1.weight, se.fc1.bias, se.fc2.weight, se.fc2.bias, S["hid"], dm,
+                       G[se.fc1.weight], G[se.fc1.bias], G[se.fc2.weight], G[se.fc2.bias])
         # ---- A2 backward
         brs = m.branches()
         ws = [b.conv.weight for b in brs]

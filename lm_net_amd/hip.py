@@ -64,7 +64,7 @@ SYMBOLS = [
     "lmn_abi_version", "lmn_sizeof_conv_args", "lmn_sizeof_src", "lmn_sizeof_wgrad_args", "lmn_last_error",
     "lmn_conv_pack_size", "lmn_conv_pack", "lmn_conv_pack_batch", "lmn_sizeof_pack_job", "lmn_conv_fwd", "lmn_conv_wgrad", "lmn_conv_wgrad_workspace",
     "lmn_dw_stats", "lmn_dw_fwd", "lmn_dw_merge", "lmn_dw_finalize_merge", "lmn_dw_bwd_stats", "lmn_dw_bwd_coef", "lmn_dw_bwd", "lmn_dw_fwd_bn", "lmn_dw_bwd_bn",
-    "lmn_se_fwd", "lmn_se_bwd", "lmn_na_fwd", "lmn_na_bwd", "lmn_gattn_fwd", "lmn_gattn_bwd",
+    "lmn_se_fwd", "lmn_se_bwd", "lmn_se_bwd_dm", "lmn_se_bwd_params", "lmn_na_fwd", "lmn_na_bwd", "lmn_gattn_fwd", "lmn_gattn_bwd",
     "lmn_ln_fwd", "lmn_ln_bwd", "lmn_bnact_fwd", "lmn_bnact_bwd_stats", "lmn_bnact_bwd",
     "lmn_bn_finalize", "lmn_bn_fold", "lmn_bn_bwd_coef", "lmn_up2_fwd", "lmn_up2_bwd", "lmn_avgpool_fwd", "lmn_avgpool_bwd",
     "lmn_nchw_to_nhwc", "lmn_nhwc_to_nchw", "lmn_adamw_step", "lmn_segloss_fwd", "lmn_segloss_bwd", "lmn_confusion", "lmn_preprocess_u8", "lmn_fill", "lmn_add", "lmn_colsum", "lmn_copy_slice", "lmn_copy2d",
@@ -499,6 +499,18 @@ def se_bwd(ds, gsum, inv_hw, w1, b1, w2, b2, hidden, dm, dw1, db1, dw2, db2):
     B, E = gsum.shape
     _check(load().lmn_se_bwd(_p(ds), _p(gsum), _f(inv_hw), _p(w1), _p(b1), _p(w2), _p(b2), _p(hidden), _p(dm), _p(dw1),
                              _p(db1), _p(dw2), _p(db2), B, E, w1.shape[0], _stream()), "se_bwd")
+
+
+def se_bwd_dm(ds, s, inv_hw, w1, w2, hidden, dm, dvec):
+    B, E = s.shape
+    _check(load().lmn_se_bwd_dm(_p(ds), _p(s), _f(inv_hw), _p(w1), _p(w2), _p(hidden), _p(dm), _p(dvec), B, E, w1.shape[0],
+                                _stream()), "se_bwd_dm")
+
+
+def se_bwd_params(dvec, gsum, inv_hw, hidden, dw1, db1, dw2, db2):
+    B, E = gsum.shape
+    _check(load().lmn_se_bwd_params(_p(dvec), _p(gsum), _f(inv_hw), _p(hidden), _p(dw1), _p(db1), _p(dw2), _p(db2), B, E,
+                                    dw1.shape[0], _stream()), "se_bwd_params")
 
 
 # ------------------------------------------------------------------------------------------ attention

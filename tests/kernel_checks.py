@@ -391,6 +391,14 @@ def _check_se(B, E, Rr, HW):
     rows.append(("se_bwd dm (=d gsum)" + tag, rel(dm, gs.grad), TOL))
     for nm, got, ref in (("dw1", dw1, w1.grad), ("db1", db1, b1.grad), ("dw2", dw2, w2.grad), ("db2", db2, b2.grad)):
         rows.append(("se_bwd " + nm + tag, rel(got, ref), 2e-4))
+    # the two-launch form (per-image vectors, then the parameter gradients as a batch reduction without atomics)
+    dm2, dvec = torch.empty(B, E, device=DEV), torch.empty(B, E + Rr, device=DEV)
+    g1 = [torch.full_like(t, 0.5) for t in (dw1, db1, dw2, db2)]   # (+= semantics)
+    hip.se_bwd_dm(dev(ds), s, 1.0 / HW, dev(w1), dev(w2), hid, dm2, dvec)
+    hip.se_bwd_params(dvec, dev(gsum), 1.0 / HW, hid, *g1)
+    rows.append(("se_bwd_dm dm" + tag, rel(dm2, gs.grad), TOL))
+    for nm, got, ref in (("dw1", g1[0], w1.grad), ("db1", g1[1], b1.grad), ("dw2", g1[2], w2.grad), ("db2", g1[3], b2.grad)):
+        rows.append(("se_bwd_params " + nm + tag, rel(got - 0.5, ref), 2e-4))
     return rows
 
 
