@@ -615,7 +615,13 @@ __global__ __launch_bounds__(256) void conv_tileM_kernel(const ConvParams P) {
   const int t_begin = P.strided ? (int)blockIdx.x : (int)(((int64_t)blockIdx.x * P.total_tiles) / gridDim.x);
   const int t_end = P.strided ? P.total_tiles : (int)(((int64_t)(blockIdx.x + 1) * P.total_tiles) / gridDim.x);
   const int tstep = P.strided ? (int)gridDim.x : 1;
+#ifdef LMN_CT_TIMING
+  unsigned long long tk0 = __builtin_amdgcn_s_memtime(), tk_s[5] = {0, 0, 0, 0, 0}, tk_a = tk0, tk_b;
+#endif
   for (int tile = t_begin; tile < t_end; tile += tstep) {
+#ifdef LMN_CT_TIMING
+    tk_a = __builtin_amdgcn_s_memtime();
+#endif
     const int b = tile / (P.tiles_x * P.tiles_y), tt = tile - b * P.tiles_x * P.tiles_y;
     const int oy0 = (tt / P.tiles_x) * P.TH, ox0 = (tt % P.tiles_x) * P.TW;
     // window origin in input coordinates (forward: out*s - pad; data gradient, stride 1: out - pad, taps flipped)
@@ -664,7 +670,10 @@ __global__ __launch_bounds__(256) void conv_tileM_kernel(const ConvParams P) {
       const lmn_src_t& S = A.src[s];
       for (int kb0 = 0; kb0 < P.nkb[s]; kb0 += P.CKB) {
         const int nkbc = P.nkb[s] - kb0 < P.CKB ? P.nkb[s] - kb0 : P.CKB;
-        const int ksh = nkbc - 1, niter = TAPS * nkbc;  // step it = (tap, kk): tap = it >> ksh, kk = it & ksh (nkbc is 1 or 2)
+        // step it = (tap, kk).  3x3: nkbc is 1 or 2, tap = it >> ksh, kk = it & ksh; 1x1: kk = it, chunks of up to 8 K16 blocks (the
+        // whole K of most wide layers: ONE staging round trip + barrier pair per tile instead of one per 32 channels -- on the small
+        // maps a block's life was that chain, phase clocks: staging + barriers 40-50 %, MFMA 36 %)
+        const int ksh = nkbc - 1, niter = TAPS * nkbc;
         wfrag wcur[NCW];
         {
           const float* wp = wlane + ((int64_t)(P.kb_off[s] + kb0) * P.NCTT) * WT;
@@ -672,13 +681,14 @@ __global__ __launch_bounds__(256) void conv_tileM_kernel(const ConvParams P) {
           for (int c = 0; c < NCW; ++c) wcur[c] = ldfrag<BF>(wp + wtile[c]);
         }
         __syncthreads();  // previous chunk / tile fully consumed
+        LMN_TK(0);
         // ---- stage the window chunk: unconditional float4 loads from clamped addresses, transforms, zero padding
         //      Rounds of SU x 256 items: ALL loads of a round are issued before the first is consumed (the plain loop compiled
         //      to load -> s_waitcnt vmcnt(0) -> write per item, i.e. 3-6 serial HBM round trips per 3x3 chunk).
-        const int psh = nkbc == 2 ? 3 : 2, per_px = 1 << psh;   // quads per pixel: 4 (one K16 block) or 8
+        const int psh = nkbc <= 1 ? 2 : nkbc == 2 ? 3 : nkbc <= 4 ? 4 : 5, per_px = 1 << psh;   // quad slots per pixel: 4 per K16 block, rounded up to a power of two
+        const int nq = nkbc * 4;                                                                // quads per pixel in this chunk
         const int nitems = P.XH * P.XW * per_px;
-        constexpr int SU = TAPS == 1 ? 1 : 4;  // items per thread and round (1x1: the extra registers cost more occupancy than the
-                                               // second round trip of a 128-pixel tile costs time -- measured on cold operands)
+        constexpr int SU = 4;  // items per thread and round
         for (int i0 = 0; i0 < nitems; i0 += SU * 256) {
           f32x4 sv[SU];
           int sgp[SU];  // global pixel index, -1 = outside the image / past the channels / past the window
@@ -689,7 +699,7 @@ __global__ __launch_bounds__(256) void conv_tileM_kernel(const ConvParams P) {
             const int r = (int)__umulhi((uint32_t)pix, P.mXW), c = pix - r * P.XW;
             const int iy = wy0 + r, ix = wx0 + c;
             const int ch = kb0 * 16 + f * 4;
-            const bool ok = i < nitems && ch < S.C && (unsigned)iy < (unsigned)A.Hin && (unsigned)ix < (unsigned)A.Win;
+            const bool ok = i < nitems && f < nq && ch < S.C && (unsigned)iy < (unsigned)A.Hin && (unsigned)ix < (unsigned)A.Win;
             const int gp = ok ? (b * A.Hin + iy) * A.Win + ix : 0;
             sgp[u] = ok ? gp : -1;
             sv[u] = ld4((const TA*)S.ptr + (uint32_t)(gp * S.cstride + (ok ? ch : 0)));
@@ -699,6 +709,7 @@ __global__ __launch_bounds__(256) void conv_tileM_kernel(const ConvParams P) {
             const int i = i0 + u * 256 + tid;
             if (i >= nitems) continue;
             const int f = i & (per_px - 1), pix = i >> psh;
+            if (f >= nq) continue;
             const bool ok = sgp[u] >= 0;
             const int gp = ok ? sgp[u] : 0, chs = ok ? kb0 * 16 + f * 4 : 0;
             f32x4 v = sv[u];
@@ -720,19 +731,22 @@ __global__ __launch_bounds__(256) void conv_tileM_kernel(const ConvParams P) {
             }
           }
         }
+        LMN_TK_DRAIN();
+        LMN_TK(1);
         __syncthreads();
+        LMN_TK(2);
         // ---- MFMA: taps x K16 blocks of the chunk; weights of step it+1 are fetched while step it runs (the first
         //      fetch was issued before the staging loop)
         for (int it = 0; it < niter; ++it) {
           const int itn = it + 1 < niter ? it + 1 : it;
           wfrag wnext[NCW];
           {
-            const int tapn = itn >> ksh, kkn = itn & ksh;
+            const int tapn = TAPS == 1 ? 0 : itn >> ksh, kkn = TAPS == 1 ? itn : itn & ksh;
             const float* wp = wlane + (((int64_t)tapn * P.NKB + P.kb_off[s] + kb0 + kkn) * P.NCTT) * WT;
 #pragma unroll
             for (int c = 0; c < NCW; ++c) wnext[c] = ldfrag<BF>(wp + wtile[c]);
           }
-          const int tap = it >> ksh, kk = it & ksh;
+          const int tap = TAPS == 1 ? 0 : it >> ksh, kk = TAPS == 1 ? it : it & ksh;
           const int ty = tap / KS, tx = tap - ty * KS;
           const int fy = A.transposed ? KS - 1 - ty : ty, fx = A.transposed ? KS - 1 - tx : tx;
           const int toff = (fy * P.XW + fx) * P.CS;
@@ -755,6 +769,7 @@ __global__ __launch_bounds__(256) void conv_tileM_kernel(const ConvParams P) {
 #pragma unroll
           for (int c = 0; c < NCW; ++c) wcur[c] = wnext[c];
         }
+        LMN_TK(3);
       }
     }
 
@@ -836,7 +851,21 @@ __global__ __launch_bounds__(256) void conv_tileM_kernel(const ConvParams P) {
         __builtin_amdgcn_sched_barrier(0);
       }
     }
+    LMN_TK_DRAIN();
+    LMN_TK(4);
   }
+#ifdef LMN_CT_TIMING
+  {
+    const unsigned long long tk_e = __builtin_amdgcn_s_memtime();
+    const int bid = blockIdx.y * gridDim.x + blockIdx.x;
+    if (tid == 0 && bid < 4096) {
+      for (int k = 0; k < 5; ++k) g_ct_timing[bid * 8 + k] = tk_s[k];
+      g_ct_timing[bid * 8 + 5] = tk_e - tk0;
+      g_ct_timing[bid * 8 + 6] = tk0;
+      g_ct_timing[bid * 8 + 7] = tk_e;
+    }
+  }
+#endif
 
   // ---- statistics: wave shuffle over the 16 pixels -> LDS -> one global atomic per channel per block
   const bool se = EPI && ep_kind == LMN_EP_SE_BWD;
@@ -2414,6 +2443,13 @@ int lmn_conv_fwd(const lmn_conv_args_t* args, lmn_stream_t stream) {
     int maxkb = 0;
     for (int s = 0; s < a.nsrc; ++s) maxkb = P.nkb[s] > maxkb ? P.nkb[s] : maxkb;
     T.CKB = maxkb < 2 ? maxkb : 2;
+    if (ncw && a.ksize == 1) {  // M-split 1x1: K chunks of up to 8 K16 blocks while the window stays within ~36 KB of LDS
+      static int ckb_cap = -1;
+      if (ckb_cap < 0) { const char* e = getenv("LMN_CONVM_CKB"); ckb_cap = e ? atoi(e) : 8; }
+      int c = maxkb < ckb_cap ? maxkb : ckb_cap;
+      while (c > 2 && (size_t)T.TP * (c * 16 + 8) * sizeof(float) > 37 * 1024) --c;
+      if (c > T.CKB) T.CKB = c;
+    }
     // LDS pixel stride: conflict-free ds_read_b128 for 16 pixels st_in apart (brute-forced over the b128 lane groups):
     // +8 floats at unit stride, +4 at stride 2 (PMC: 0.5 conflict cycles per LDS cycle with +4 at unit stride)
     T.CS = T.CKB * 16 + (st_in == 1 ? 8 : 4);

@@ -151,26 +151,26 @@ __device__ __forceinline__ void sw_step(SwState& S, const BranchW& bw, const f32
   f32x2 in[5];
 #pragma unroll
   for (int d = 0; d < 5; ++d) in[d] = *reinterpret_cast<const f32x2*>(xr + d * SW_CS);
-  S.a5[(P + 2) % 5] = bw.w5[0] * in[0];
+  // (column-major order: consecutive FMAs go to DIFFERENT row accumulators.  Row-major, each accumulator took its five products
+  //  back to back -- a dependent chain the two waves of a SIMD cannot hide: the pass ran at a third of its VALU issue bound)
 #pragma unroll
-  for (int d = 1; d < 5; ++d) S.a5[(P + 2) % 5] += bw.w5[d] * in[d];
+  for (int d = 0; d < 5; ++d) {
+    if (d == 0) S.a5[(P + 2) % 5] = bw.w5[0] * in[0];
+    else S.a5[(P + 2) % 5] += bw.w5[d] * in[d];
 #pragma unroll
-  for (int ky = 1; ky < 5; ++ky)
+    for (int ky = 1; ky < 5; ++ky) S.a5[(P - ky + 7) % 5] += bw.w5[ky * 5 + d] * in[d];
+    if (d >= 1 && d <= 3) {
+      if (d == 1) { S.a3[(P + 1) % 5] = bw.w3[0] * in[1]; S.ah[P] = bw.wh[0] * in[1]; }
+      else { S.a3[(P + 1) % 5] += bw.w3[d - 1] * in[d]; S.ah[P] += bw.wh[d - 1] * in[d]; }
 #pragma unroll
-    for (int d = 0; d < 5; ++d) S.a5[(P - ky + 7) % 5] += bw.w5[ky * 5 + d] * in[d];
-  S.a3[(P + 1) % 5] = bw.w3[0] * in[1];
-  S.a3[(P + 1) % 5] += bw.w3[1] * in[2];
-  S.a3[(P + 1) % 5] += bw.w3[2] * in[3];
-  S.av[(P + 1) % 5] = bw.wv[0] * in[2];
+      for (int ky = 1; ky < 3; ++ky) S.a3[(P - ky + 6) % 5] += bw.w3[ky * 3 + d - 1] * in[d];
+    }
+    if (d == 2) {
+      S.av[(P + 1) % 5] = bw.wv[0] * in[2];
 #pragma unroll
-  for (int ky = 1; ky < 3; ++ky) {
-#pragma unroll
-    for (int d = 0; d < 3; ++d) S.a3[(P - ky + 6) % 5] += bw.w3[ky * 3 + d] * in[1 + d];
-    S.av[(P - ky + 6) % 5] += bw.wv[ky] * in[2];
+      for (int ky = 1; ky < 3; ++ky) S.av[(P - ky + 6) % 5] += bw.wv[ky] * in[2];
+    }
   }
-  S.ah[P] = bw.wh[0] * in[1];
-  S.ah[P] += bw.wh[1] * in[2];
-  S.ah[P] += bw.wh[2] * in[3];
   // ---- row q = j-2 is complete: f_b
   constexpr int Q = (P + 3) % 5;
   const f32x2 dp = *reinterpret_cast<const f32x2*>(DPS + (P * SW_XC + lane) * SW_CS + wv * 2);
@@ -194,24 +194,29 @@ __device__ __forceinline__ void sw_step(SwState& S, const BranchW& bw, const f32
     sh[0] = lane_from_right(sh[1]);
     sh[3] = lane_from_left(f5);
     sh[4] = lane_from_left(sh[3]);
-    S.dxa[P] = bw.w5[20] * sh[0];  // dx row j: first contribution
-#pragma unroll
-    for (int kx = 1; kx < 5; ++kx) S.dxa[P] += bw.w5[20 + kx] * sh[kx];
-#pragma unroll
-    for (int ky = 0; ky < 4; ++ky)
-#pragma unroll
-      for (int kx = 0; kx < 5; ++kx) S.dxa[(P + ky + 1) % 5] += bw.w5[ky * 5 + kx] * sh[kx];
     f32x2 s3[3];
     s3[1] = f3;
     s3[0] = lane_from_right(f3);
     s3[2] = lane_from_left(f3);
+    const f32x2 hr = lane_from_right(fh), hl = lane_from_left(fh);
+    // column-major again: the five dx rows take their products in turn (dx row j gets its first contribution from kernel row 4)
 #pragma unroll
-    for (int ky = 0; ky < 3; ++ky) {
+    for (int kx = 0; kx < 5; ++kx) {
+      if (kx == 0) S.dxa[P] = bw.w5[20] * sh[0];
+      else S.dxa[P] += bw.w5[20 + kx] * sh[kx];
 #pragma unroll
-      for (int kx = 0; kx < 3; ++kx) S.dxa[(P + ky + 2) % 5] += bw.w3[ky * 3 + kx] * s3[kx];
-      S.dxa[(P + ky + 2) % 5] += bw.wv[ky] * fv;
+      for (int ky = 0; ky < 4; ++ky) S.dxa[(P + ky + 1) % 5] += bw.w5[ky * 5 + kx] * sh[kx];
     }
-    S.dxa[Q] += bw.wh[0] * lane_from_right(fh) + bw.wh[1] * fh + bw.wh[2] * lane_from_left(fh);
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky) S.dxa[(P + ky + 2) % 5] += bw.w3[ky * 3 + kx] * s3[kx];
+    }
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) S.dxa[(P + ky + 2) % 5] += bw.wv[ky] * fv;
+    S.dxa[Q] += bw.wh[0] * hr;
+    S.dxa[Q] += bw.wh[1] * fh;
+    S.dxa[Q] += bw.wh[2] * hl;
   }
   // ---- dx row j-4 is complete
   constexpr int D = (P + 1) % 5;
@@ -239,6 +244,13 @@ __device__ __forceinline__ void sw_step(SwState& S, const BranchW& bw, const f32
   }
 }
 
+#ifdef LMN_DW_TIMING
+// phase clocks of dw_bwd_strip_kernel (debug builds, tools/gpu_dw_phases.py): per block {staging incl. barriers, row steps, life}
+__device__ unsigned long long g_dw_timing[4096 * 4];
+#define LMN_DTK(i) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); dtk[i] += t_ - dta; dta = t_; } while (0)
+#else
+#define LMN_DTK(i) do { } while (0)
+#endif
 template <typename TA, int PART = 0>
 __global__ __launch_bounds__(256, 2) void dw_bwd_strip_kernel(
     const TA* __restrict__ x1, const TA* __restrict__ dpre, TA* __restrict__ dx1, int B, int H, int W, int E,
@@ -411,19 +423,35 @@ __global__ __launch_bounds__(256, 2) void dw_bwd_strip_kernel(
       }                                                                                                       \
     }
 #define LMN_SW_FAST(PH) sw_step<PH, PART, true>(S, bw, ca, cc, cd, XS, DPS, OUT, j0 + PH, lane, wv, true, true, true, true);
+#ifdef LMN_DW_TIMING
+  unsigned long long dtk[2] = {0, 0}, dta = __builtin_amdgcn_s_memtime();
+  const unsigned long long dt0 = dta;
+#endif
   int j0 = 0;
   for (; j0 < nsteps && j0 < 8; j0 += SW_R) {
     stage(j0);
+    LMN_DTK(0);
     LMN_SW_STEP(0) LMN_SW_STEP(1) LMN_SW_STEP(2) LMN_SW_STEP(3) LMN_SW_STEP(4)
+    LMN_DTK(1);
   }
   for (; j0 + 4 < (ye - ys) + 6; j0 += SW_R) {
     stage(j0);
+    LMN_DTK(0);
     LMN_SW_FAST(0) LMN_SW_FAST(1) LMN_SW_FAST(2) LMN_SW_FAST(3) LMN_SW_FAST(4)
+    LMN_DTK(1);
   }
   for (; j0 < nsteps; j0 += SW_R) {
     stage(j0);
+    LMN_DTK(0);
     LMN_SW_STEP(0) LMN_SW_STEP(1) LMN_SW_STEP(2) LMN_SW_STEP(3) LMN_SW_STEP(4)
+    LMN_DTK(1);
   }
+#ifdef LMN_DW_TIMING
+  if (tid == 0 && blockIdx.x < 4096) {
+    g_dw_timing[blockIdx.x * 4] = dtk[0]; g_dw_timing[blockIdx.x * 4 + 1] = dtk[1];
+    g_dw_timing[blockIdx.x * 4 + 2] = __builtin_amdgcn_s_memtime() - dt0; g_dw_timing[blockIdx.x * 4 + 3] = nsteps;
+  }
+#endif
 #undef LMN_SW_STEP
 #undef LMN_SW_FAST
   __syncthreads();
@@ -1036,6 +1064,12 @@ static int launch_dw_strip_stats(const void* x1, const void* pre, const void* u,
 
 
 extern "C" {
+
+#ifdef LMN_DW_TIMING
+int lmn_dw_timing(unsigned long long* out, int n) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_dw_timing), sizeof(unsigned long long) * n);
+}
+#endif
 
 int lmn_dw_fwd(const void* x1, void* pre, float* gsum, int B, int H, int W, int E, const float* keff,
                const float* beff, int act_dtype, lmn_stream_t stream) {
