@@ -145,7 +145,6 @@ template <int P, int PART, bool FAST>
 __device__ __forceinline__ void sw_step(SwState& S, const BranchW& bw, const f32x2 (&ca)[4], const f32x2 (&cc)[4],
                                         const f32x2 (&cd)[4], const float* XS, const float* DPS, float* OUT, int j,
                                         int lane, int wv, bool frow_in, bool own, bool dx_row, bool dw_ok) {
-  const f32x2 z2 = f32x2{0.f, 0.f};
   // ---- x1 row j: columns x-2 .. x+2
   const float* xr = XS + ((j % SW_XR) * SW_XC + lane) * SW_CS + wv * 2;
   f32x2 in[5];
@@ -178,13 +177,15 @@ __device__ __forceinline__ void sw_step(SwState& S, const BranchW& bw, const f32
   f32x2 f3 = cc[1] * S.a3[Q] + (ca[1] * dp + cd[1]);
   f32x2 fv = cc[2] * S.av[Q] + (ca[2] * dp + cd[2]);
   f32x2 fh = cc[3] * S.ah[Q] + (ca[3] * dp + cd[3]);
-  if constexpr (!FAST) {
-    if (!frow_in) f5 = f3 = fv = fh = z2;
-  }
-  if (FAST || own) {
+  if constexpr (FAST) {
     S.h5[Q] = f5; S.h3[Q] = f3; S.hv[Q] = fv; S.hh[Q] = fh;
   } else {
-    S.h5[Q] = S.h3[Q] = S.hv[Q] = S.hh[Q] = z2;
+    // row flags as wave-uniform 0 / 1 factors (one SGPR each) instead of lane masks (an SGPR pair each, next to the 80 weight
+    // SGPRs: the selects made this form reload 50 spilled scalars per step); the accumulators are zero-initialised, so the
+    // products of the warm-up steps are finite
+    const float mf = frow_in ? 1.f : 0.f, mo = own ? mf : 0.f;
+    f5 *= mf; f3 *= mf; fv *= mf; fh *= mf;
+    S.h5[Q] = f5 * mo; S.h3[Q] = f3 * mo; S.hv[Q] = fv * mo; S.hh[Q] = fh * mo;
   }
   // ---- dx1: f row q feeds dx rows q-2..q+2; column neighbours by DPP.  sh[k][l] = f[l + 2 - k]
   if constexpr (PART != 2) {
