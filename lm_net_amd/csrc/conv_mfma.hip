@@ -304,7 +304,7 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(const ConvParams P) {
     // BN_BWD instances: the epilogue's second operand (aux: an output-shaped tensor) is requested HERE, ahead of the staging
     // barrier -- its HBM latency runs beside that of the window instead of after the MFMAs (two exposed round trips per
     // tile -> one; level 0, cold operands: BN_BWD1 102 -> 88 us, BN_BWD2 122 -> 105 us; SE_BWD measured slower with it)
-    constexpr bool AUXP = EPI == 3 || EPI == 4;
+    constexpr bool AUXP = (EPI == 3 && NCT <= 2) || EPI == 4;  // (three cout tiles: the 12 prefetch registers cost BN_BWD1 a wave per SIMD -- 137 -> 122 VGPRs, 38.9 -> 32.4 us at level 1)
     f32x4 axp[AUXP ? 2 : 1][AUXP ? NCT : 1];
     if constexpr (AUXP) {
 #pragma unroll

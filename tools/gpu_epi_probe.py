@@ -11,7 +11,7 @@ mode = sys.argv[1] if len(sys.argv) > 1 else "f32"
 dt = torch.float32
 if mode == "bf16":
     hip._MMA[0] = hip.BF16; dt = torch.bfloat16
-dev = "cuda"; B, H, Cin, E = 8, 352, 12, 24
+dev = "cuda"; B, H, Cin, E = 8, int(os.environ.get("EPI_H", "352")), int(os.environ.get("EPI_CIN", "12")), int(os.environ.get("EPI_E", "24"))   # EPI_H=176 EPI_CIN=24 EPI_E=48: level 1
 NSET = 6
 xs = [torch.randn(B, H, H, Cin, device=dev).to(dt) for _ in range(NSET)]
 outs = [torch.empty(B, H, H, E, device=dev, dtype=dt) for _ in range(NSET)]
