@@ -338,8 +338,9 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(const ConvParams P) {
         //      to load -> s_waitcnt vmcnt(0) -> write per item, i.e. 3-6 serial HBM round trips per 3x3 chunk).
         const int psh = nkbc == 2 ? 3 : 2, per_px = 1 << psh;   // quads per pixel: 4 (one K16 block) or 8
         const int nitems = P.XH * P.XW * per_px;
-        constexpr int SU = TAPS == 1 ? 1 : 4;  // items per thread and round (1x1: the extra registers cost more occupancy than the
-                                               // second round trip of a 128-pixel tile costs time -- measured on cold operands)
+        constexpr int SU = TAPS == 1 ? 2 : 4;  // items per thread and round.  1x1: four in flight cost the epilogue-heavy instances a wave per
+                                               // SIMD; two (+6 VGPRs, same occupancy bracket for all but <1,3,0>) halve the 4-6 serial round
+                                               // trips of the 24-48 channel layers: +0.3 % fp32 batch 8, +1.6 % bf16 batch 64
         for (int i0 = 0; i0 < nitems; i0 += SU * 256) {
           f32x4 sv[SU];
           int sgp[SU];  // global pixel index, -1 = outside the image / past the channels / past the window
