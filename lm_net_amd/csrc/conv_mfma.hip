@@ -150,6 +150,7 @@ __device__ __forceinline__ void conv_stage_params(const lmn_conv_args_t& A, floa
       }
     }
     if (A.stats_snap && first && cok && A.stats) A.stats[(int64_t)A.stats_rep * 2 * A.Cout + co] = t[6];
+    t[0] += t[1];  // slot 0 = bias + bias2: the accumulators of a tile START from it (no zeroing, no bias add in the epilogue)
 #pragma unroll
     for (int k = 0; k < 9; ++k) s_par[k * NCT * 16 + i] = t[k];
   }
@@ -215,6 +216,7 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(const ConvParams P) {
   for (int i = tid; i < 2 * NCT * 16; i += 256) s_stats[i] = 0.f;
   float* s_par = s_stats + 2 * NCT * 16;  // [9][NCT*16]
   conv_stage_params<NCT>(A, s_par, ct0, tid, blockIdx.x == 0);
+  __syncthreads();  // the tiles read s_par from their first instruction on (accumulators start from the bias)
   float* s_w = s_par + 9 * NCT * 16;  // WL: [tap * nkbc + kk][NCT][WT]
   auto stage_w = [&](int s, int kb0, int nkbc) __attribute__((always_inline)) {
     constexpr int Q = WT / 4;  // float4 per fragment tile (64 lanes x 16 or 8 bytes)
@@ -296,11 +298,9 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(const ConvParams P) {
     }
     const bool g1 = (wv + 4) < P.NG;  // wave-uniform: second group exists
 
-    f32x4 acc[2][NCT];
+    f32x4 acc[2][NCT];  // start from bias (+ bias2): 4 channels q*4.. of cout tile c, the same for both pixel groups
 #pragma unroll
-    for (int g = 0; g < 2; ++g)
-#pragma unroll
-      for (int c = 0; c < NCT; ++c) acc[g][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int c = 0; c < NCT; ++c) acc[0][c] = acc[1][c] = *reinterpret_cast<const f32x4*>(s_par + c * 16 + q * 4);
     // BN_BWD instances: the epilogue's second operand (aux: an output-shaped tensor) is requested HERE, ahead of the staging
     // barrier -- its HBM latency runs beside that of the window instead of after the MFMAs (two exposed round trips per
     // tile -> one; level 0, cold operands: BN_BWD1 102 -> 88 us, BN_BWD2 122 -> 105 us; SE_BWD measured slower with it)
@@ -450,7 +450,6 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(const ConvParams P) {
         f32x4 v = acc[g][c];
         const float* sp = s_par + LMN_SLOT * 16 + q * 4;
 #define LMN_PAR(k) (*reinterpret_cast<const f32x4*>(sp + (k) * NCT * 16))
-        v += LMN_PAR(0) + LMN_PAR(1);
         f32x4 o = v;
         if (EPI && st_mode == LMN_STATS_SUM_SQ && live) {
           // sums about p4[co] when given (the BatchNorm's running mean): E[x^2] - E[x]^2 then subtracts numbers of the
@@ -604,6 +603,7 @@ __global__ __launch_bounds__(256) void conv_tileM_kernel(const ConvParams P) {
   for (int i = tid; i < 2 * NCT * 16; i += 256) s_stats[i] = 0.f;
   float* s_par = s_stats + 2 * NCT * 16;  // [9][NCT*16]
   conv_stage_params<NCT>(A, s_par, ct0, tid, blockIdx.x == 0);
+  __syncthreads();  // the tiles read s_par from their first instruction on (accumulators start from the bias)
   float st0[NCW][4], st1[NCW][4];
 #pragma unroll
   for (int c = 0; c < NCW; ++c)
@@ -661,11 +661,13 @@ __global__ __launch_bounds__(256) void conv_tileM_kernel(const ConvParams P) {
       const int sr = A.transposed ? r : r * A.stride, sc = A.transposed ? c : c * A.stride;
       pbase[g] = (sr * P.XW + sc) * P.CS + q * (BF ? 2 : 4);
     }
-    f32x4 acc[NGM][NCW];
+    f32x4 acc[NGM][NCW];  // start from bias (+ bias2)
 #pragma unroll
-    for (int g = 0; g < NGM; ++g)
+    for (int c = 0; c < NCW; ++c) {
+      const f32x4 b4 = *reinterpret_cast<const f32x4*>(s_par + (wv + 4 * c) * 16 + q * 4);
 #pragma unroll
-      for (int c = 0; c < NCW; ++c) acc[g][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int g = 0; g < NGM; ++g) acc[g][c] = b4;
+    }
 
     for (int s = 0; s < A.nsrc; ++s) {
       const lmn_src_t& S = A.src[s];
@@ -788,7 +790,6 @@ __global__ __launch_bounds__(256) void conv_tileM_kernel(const ConvParams P) {
         f32x4 v = acc[g][c];
         const float* sp = s_par + LMN_SLOT * 16 + q * 4;
 #define LMN_PAR(k) (*reinterpret_cast<const f32x4*>(sp + (k) * NCT * 16))
-        v += LMN_PAR(0) + LMN_PAR(1);
         f32x4 o = v;
         if (EPI && st_mode == LMN_STATS_SUM_SQ && live) {
           // sums about p4[co] when given (the BatchNorm's running mean): E[x^2] - E[x]^2 then subtracts numbers of the
