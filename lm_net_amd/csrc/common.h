@@ -131,6 +131,31 @@ __device__ __forceinline__ float lmn_act(float x, int act) {
 __device__ __forceinline__ float lmn_dact(float x, int act) {
   return act == LMN_ACT_HSWISH ? lmn_dhswish(x) : (act == LMN_ACT_GELU ? lmn_dgelu(x) : 1.0f);
 }
+// four-wide forms: ONE wave-uniform branch on the activation kind per vector (the scalar forms, called per element of an
+// unrolled loop, compiled to a compare-and-branch ladder per element: 16 ladders per conv tile and wave)
+typedef float lmn_f32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ lmn_f32x4 lmn_act4(lmn_f32x4 x, int act) {
+  lmn_f32x4 y = x;
+  if (act == LMN_ACT_HSWISH) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) y[r] = lmn_hswish(x[r]);
+  } else if (act == LMN_ACT_GELU) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) y[r] = lmn_gelu(x[r]);
+  }
+  return y;
+}
+__device__ __forceinline__ lmn_f32x4 lmn_dact4(lmn_f32x4 x, int act) {
+  lmn_f32x4 y = lmn_f32x4{1.f, 1.f, 1.f, 1.f};
+  if (act == LMN_ACT_HSWISH) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) y[r] = lmn_dhswish(x[r]);
+  } else if (act == LMN_ACT_GELU) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) y[r] = lmn_dgelu(x[r]);
+  }
+  return y;
+}
 
 // ---------------------------------------------------------------- counter-based dropout mask
 // keep(seed, idx) is a pure function of the dropout stream id and the element's linear index in its

@@ -460,8 +460,7 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(const ConvParams P) {
         }
         if (ep_kind == LMN_EP_AFFINE_ACT) {
           const f32x4 s0 = LMN_PAR(2), s1 = LMN_PAR(3);
-#pragma unroll
-          for (int r = 0; r < 4; ++r) o[r] = lmn_act(v[r] * s0[r] + s1[r], A.act);
+          o = lmn_act4(v * s0 + s1, A.act);
         }
         if (EPI) {
           f32x4 ax = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -474,22 +473,19 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(const ConvParams P) {
             } break;
             case LMN_EP_BN_BWD1: {
               const f32x4 mu = LMN_PAR(2), rs = LMN_PAR(3), ga = LMN_PAR(4), be = LMN_PAR(5);
+              const f32x4 zh = (v - mu) * rs;
+              o = ax * lmn_dact4(ga * zh + be, A.act);
+              if (live) {
 #pragma unroll
-              for (int r = 0; r < 4; ++r) {
-                const float zh = (v[r] - mu[r]) * rs[r];
-                o[r] = ax[r] * lmn_dact(ga[r] * zh + be[r], A.act);
-                if (live) { st0[c][r] += o[r]; st1[c][r] += o[r] * zh; }
+                for (int r = 0; r < 4; ++r) { st0[c][r] += o[r]; st1[c][r] += o[r] * zh[r]; }
               }
             } break;
             case LMN_EP_BN_BWD2: {
               const f32x4 mu = LMN_PAR(2), rs = LMN_PAR(3), c1 = LMN_PAR(4), c2 = LMN_PAR(5), c3 = LMN_PAR(6);
               if (A.p5) {  // aux is the gradient w.r.t. the ACTIVATED output: dh = aux * act'(gamma*zh + beta) formed here
                 const f32x4 ga = LMN_PAR(7), be = LMN_PAR(8);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                  const float zh = (v[r] - mu[r]) * rs[r];
-                  o[r] = c1[r] * (ax[r] * lmn_dact(ga[r] * zh + be[r], A.act)) - c2[r] - zh * c3[r];
-                }
+                const f32x4 zh = (v - mu) * rs;
+                o = c1 * (ax * lmn_dact4(ga * zh + be, A.act)) - c2 - zh * c3;
               } else {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) o[r] = c1[r] * ax[r] - c2[r] - (v[r] - mu[r]) * rs[r] * c3[r];
@@ -800,8 +796,7 @@ __global__ __launch_bounds__(256) void conv_tileM_kernel(const ConvParams P) {
         }
         if (ep_kind == LMN_EP_AFFINE_ACT) {
           const f32x4 s0 = LMN_PAR(2), s1 = LMN_PAR(3);
-#pragma unroll
-          for (int r = 0; r < 4; ++r) o[r] = lmn_act(v[r] * s0[r] + s1[r], A.act);
+          o = lmn_act4(v * s0 + s1, A.act);
         }
         if (EPI) {
           f32x4 ax = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -813,22 +808,19 @@ __global__ __launch_bounds__(256) void conv_tileM_kernel(const ConvParams P) {
             } break;
             case LMN_EP_BN_BWD1: {
               const f32x4 mu = LMN_PAR(2), rs = LMN_PAR(3), ga = LMN_PAR(4), be = LMN_PAR(5);
+              const f32x4 zh = (v - mu) * rs;
+              o = ax * lmn_dact4(ga * zh + be, A.act);
+              if (live) {
 #pragma unroll
-              for (int r = 0; r < 4; ++r) {
-                const float zh = (v[r] - mu[r]) * rs[r];
-                o[r] = ax[r] * lmn_dact(ga[r] * zh + be[r], A.act);
-                if (live) { st0[c][r] += o[r]; st1[c][r] += o[r] * zh; }
+                for (int r = 0; r < 4; ++r) { st0[c][r] += o[r]; st1[c][r] += o[r] * zh[r]; }
               }
             } break;
             case LMN_EP_BN_BWD2: {
               const f32x4 mu = LMN_PAR(2), rs = LMN_PAR(3), c1 = LMN_PAR(4), c2 = LMN_PAR(5), c3 = LMN_PAR(6);
               if (A.p5) {  // aux is the gradient w.r.t. the ACTIVATED output: dh = aux * act'(gamma*zh + beta) formed here
                 const f32x4 ga = LMN_PAR(7), be = LMN_PAR(8);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                  const float zh = (v[r] - mu[r]) * rs[r];
-                  o[r] = c1[r] * (ax[r] * lmn_dact(ga[r] * zh + be[r], A.act)) - c2[r] - zh * c3[r];
-                }
+                const f32x4 zh = (v - mu) * rs;
+                o = c1 * (ax * lmn_dact4(ga * zh + be, A.act)) - c2 - zh * c3;
               } else {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) o[r] = c1[r] * ax[r] - c2[r] - (v[r] - mu[r]) * rs[r] * c3[r];
