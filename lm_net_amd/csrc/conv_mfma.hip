@@ -388,6 +388,17 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(const ConvParams P) {
         LMN_TK(2);
         // ---- MFMA: taps x K16 blocks of the chunk; the packed weights of step it+1 are fetched while step it runs
         //      (the first fetch was issued before the staging loop), so no L2 latency is exposed inside the loop
+        // 3x3: the pixel operands of step it+1 are read from LDS while the MFMAs of step it run (cold operands, 24 -> 24 at level 1:
+        // 51 -> 46 us, (24,24,24) -> 24: 134 -> 120 us; the one-cout-tile layers with LDS-resident weights lose 6 % to the 8
+        // extra registers and keep the plain order)
+        constexpr bool XPF = TAPS == 9 && (!WL || NCT >= 2);
+        wfrag xq0, xq1;
+        if constexpr (XPF) {
+          const int fy0 = A.transposed ? KS - 1 : 0, fx0 = A.transposed ? KS - 1 : 0;
+          const int toff0 = S2T ? s2_off[0] * P.CS : (fy0 * P.XW + fx0) * P.CS;
+          xq0 = ldfrag<BF>(&XS[pbase[0] + toff0]);
+          xq1 = ldfrag<BF>(&XS[pbase[1] + toff0]);
+        }
         for (int it = 0; it < niter; ++it) {
           const int itn = it + 1 < niter ? it + 1 : it;
           wfrag wnext[NCT];
@@ -405,8 +416,19 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(const ConvParams P) {
           const int ty = tap / KS, tx = tap - ty * KS;
           const int fy = A.transposed ? KS - 1 - ty : ty, fx = A.transposed ? KS - 1 - tx : tx;
           const int toff = S2T ? s2_off[tap & 3] * P.CS : (fy * P.XW + fx) * P.CS;
-          const wfrag x0 = ldfrag<BF>(&XS[pbase[0] + toff + kk * KD]);
-          const wfrag x1 = ldfrag<BF>(&XS[pbase[1] + toff + kk * KD]);
+          wfrag x0, x1;
+          if constexpr (XPF) {
+            x0 = xq0; x1 = xq1;
+            const int tapq = itn >> ksh, kkq = itn & ksh;
+            const int tyq = tapq / KS, txq = tapq - tyq * KS;
+            const int fyq = A.transposed ? KS - 1 - tyq : tyq, fxq = A.transposed ? KS - 1 - txq : txq;
+            const int toffq = S2T ? s2_off[tapq & 3] * P.CS : (fyq * P.XW + fxq) * P.CS;
+            xq0 = ldfrag<BF>(&XS[pbase[0] + toffq + kkq * KD]);
+            xq1 = ldfrag<BF>(&XS[pbase[1] + toffq + kkq * KD]);
+          } else {
+            x0 = ldfrag<BF>(&XS[pbase[0] + toff + kk * KD]);
+            x1 = ldfrag<BF>(&XS[pbase[1] + toff + kk * KD]);
+          }
           if constexpr (BF) {
 #pragma unroll
             for (int c = 0; c < NCT; ++c) {
