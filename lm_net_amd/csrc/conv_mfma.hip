@@ -772,18 +772,27 @@ __global__ __launch_bounds__(256) void conv_tileM_kernel(const ConvParams P) {
           const int fy = A.transposed ? KS - 1 - ty : ty, fx = A.transposed ? KS - 1 - tx : tx;
           const int toff = (fy * P.XW + fx) * P.CS;
           // (no zero-slice skipping here: wide layers have few partial K16 blocks, and the branch cost this loop its schedule)
+          // the pixel operands of four groups are requested together, ahead of the (wave-uniform) tests for missing groups: with a
+          // read -> wait -> 4 MFMAs chain per group, a block that has a SIMD to itself (the small maps) kept the matrix core
+          // waiting on LDS half of the time
 #pragma unroll
-          for (int g = 0; g < NGM; ++g) {
-            if (g < P.NG) {
-              const wfrag xg = ldfrag<BF>(&XS[pbase[g] + toff + kk * KD]);
-              if constexpr (BF) {
+          for (int h = 0; h < NGM; h += 4) {
+            wfrag xg[4];
 #pragma unroll
-                for (int c = 0; c < NCW; ++c) acc[g][c] = mfma_bf16(wcur[c], xg, acc[g][c]);
-              } else {
+            for (int u = 0; u < 4; ++u) xg[u] = ldfrag<BF>(&XS[pbase[h + u] + toff + kk * KD]);   // (groups past NG read pixel 0)
 #pragma unroll
-              for (int c = 0; c < NCW; ++c)
+            for (int u = 0; u < 4; ++u) {
+              const int g = h + u;
+              if (g < P.NG) {
+                if constexpr (BF) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) acc[g][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(wcur[c][j], xg[j], acc[g][c], 0, 0, 0);
+                  for (int c = 0; c < NCW; ++c) acc[g][c] = mfma_bf16(wcur[c], xg[u], acc[g][c]);
+                } else {
+#pragma unroll
+                  for (int c = 0; c < NCW; ++c)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[g][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(wcur[c][j], xg[u][j], acc[g][c], 0, 0, 0);
+                }
               }
             }
           }
