@@ -758,6 +758,16 @@ __global__ __launch_bounds__(256) void conv_tileM_kernel(const ConvParams P) {
         LMN_TK(2);
         // ---- MFMA: taps x K16 blocks of the chunk; weights of step it+1 are fetched while step it runs (the first
         //      fetch was issued before the staging loop)
+        // 3x3: two half-sets of four groups in flight -- the second half of step it is requested before the MFMAs of its first half,
+        // the first half of step it+1 before the MFMAs of the second (the loop then never waits on LDS with one wave per SIMD)
+        constexpr bool XPF = TAPS == 9;
+        wfrag xa[4];
+        if constexpr (XPF) {
+          const int fy0 = A.transposed ? KS - 1 : 0, fx0 = A.transposed ? KS - 1 : 0;
+          const int toff0 = (fy0 * P.XW + fx0) * P.CS;
+#pragma unroll
+          for (int u = 0; u < 4; ++u) xa[u] = ldfrag<BF>(&XS[pbase[u] + toff0]);
+        }
         for (int it = 0; it < niter; ++it) {
           const int itn = it + 1 < niter ? it + 1 : it;
           wfrag wnext[NCW];
@@ -775,11 +785,27 @@ __global__ __launch_bounds__(256) void conv_tileM_kernel(const ConvParams P) {
           // the pixel operands of four groups are requested together, ahead of the (wave-uniform) tests for missing groups: with a
           // read -> wait -> 4 MFMAs chain per group, a block that has a SIMD to itself (the small maps) kept the matrix core
           // waiting on LDS half of the time
+          int toffq = 0, kkq = 0;
+          if constexpr (XPF) {
+            const int tapq = itn >> ksh, tyq = tapq / KS, txq = tapq - tyq * KS;
+            const int fyq = A.transposed ? KS - 1 - tyq : tyq, fxq = A.transposed ? KS - 1 - txq : txq;
+            toffq = (fyq * P.XW + fxq) * P.CS; kkq = itn & ksh;
+          }
 #pragma unroll
           for (int h = 0; h < NGM; h += 4) {
             wfrag xg[4];
+            if constexpr (XPF) {
+              if (h == 0) {
 #pragma unroll
-            for (int u = 0; u < 4; ++u) xg[u] = ldfrag<BF>(&XS[pbase[h + u] + toff + kk * KD]);   // (groups past NG read pixel 0)
+                for (int u = 0; u < 4; ++u) { xg[u] = xa[u]; xa[u] = ldfrag<BF>(&XS[pbase[4 + u] + toff + kk * KD]); }   // second half of this step
+              } else {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { xg[u] = xa[u]; xa[u] = ldfrag<BF>(&XS[pbase[u] + toffq + kkq * KD]); }     // first half of the next step
+              }
+            } else {
+#pragma unroll
+              for (int u = 0; u < 4; ++u) xg[u] = ldfrag<BF>(&XS[pbase[h + u] + toff + kk * KD]);   // (groups past NG read pixel 0)
+            }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
               const int g = h + u;
