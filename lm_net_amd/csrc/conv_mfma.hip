@@ -758,9 +758,10 @@ __global__ __launch_bounds__(256) void conv_tileM_kernel(const ConvParams P) {
         LMN_TK(2);
         // ---- MFMA: taps x K16 blocks of the chunk; weights of step it+1 are fetched while step it runs (the first
         //      fetch was issued before the staging loop)
-        // 3x3: two half-sets of four groups in flight -- the second half of step it is requested before the MFMAs of its first half,
-        // the first half of step it+1 before the MFMAs of the second (the loop then never waits on LDS with one wave per SIMD)
-        constexpr bool XPF = TAPS == 9;
+        // two half-sets of four groups in flight -- the second half of step it is requested before the MFMAs of its first half,
+        // the first half of step it+1 before the MFMAs of the second (the loop then never waits on LDS with one wave per SIMD;
+        // 1x1: +16 VGPRs put the two-tile instances at two waves per SIMD, and the step still gains 0.6 %)
+        constexpr bool XPF = true;
         wfrag xa[4];
         if constexpr (XPF) {
           const int fy0 = A.transposed ? KS - 1 : 0, fx0 = A.transposed ? KS - 1 : 0;
@@ -787,9 +788,9 @@ __global__ __launch_bounds__(256) void conv_tileM_kernel(const ConvParams P) {
           // waiting on LDS half of the time
           int toffq = 0, kkq = 0;
           if constexpr (XPF) {
-            const int tapq = itn >> ksh, tyq = tapq / KS, txq = tapq - tyq * KS;
+            const int tapq = TAPS == 1 ? 0 : itn >> ksh, tyq = tapq / KS, txq = tapq - tyq * KS;
             const int fyq = A.transposed ? KS - 1 - tyq : tyq, fxq = A.transposed ? KS - 1 - txq : txq;
-            toffq = (fyq * P.XW + fxq) * P.CS; kkq = itn & ksh;
+            toffq = (fyq * P.XW + fxq) * P.CS; kkq = TAPS == 1 ? itn : itn & ksh;
           }
 #pragma unroll
           for (int h = 0; h < NGM; h += 4) {
