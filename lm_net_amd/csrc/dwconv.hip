@@ -500,22 +500,24 @@ __global__ __launch_bounds__(256, 2) void dw_bwd_strip_kernel(
 // 16 B stores.  No halo recompute along x (68 staged columns for 64 outputs), 4 halo rows per row segment.
 constexpr int FS_XR = 2 * SW_R;  // x1 ring: the batch being consumed + the batch being committed
 
-template <int P>
+template <int P, bool FAST = false>
 __device__ __forceinline__ void fs_step(f32x2 (&acc)[5], f32x2& gs, const f32x2 (&w)[25], f32x2 bias, const float* XS,
                                         float* OUT, int j, int lane, int wv, bool row_out) {
   const float* xr = XS + ((j % FS_XR) * SW_XC + lane) * SW_CS + wv * 2;
   f32x2 in[5];
 #pragma unroll
   for (int d = 0; d < 5; ++d) in[d] = *reinterpret_cast<const f32x2*>(xr + d * SW_CS);
-  acc[P] = w[0] * in[0];  // output row j: first contribution (no zeroed accumulators)
+  // column-major: consecutive FMAs go to different row accumulators (back-to-back dependent v_pk_fma_f32 cost an s_nop each);
+  // output row j gets its first contribution as a plain product (no zeroed accumulators)
 #pragma unroll
-  for (int d = 1; d < 5; ++d) acc[P] += w[d] * in[d];
+  for (int d = 0; d < 5; ++d) {
+    if (d == 0) acc[P] = w[0] * in[0];
+    else acc[P] += w[d] * in[d];
 #pragma unroll
-  for (int ky = 1; ky < 5; ++ky)
-#pragma unroll
-    for (int d = 0; d < 5; ++d) acc[(P - ky + 5) % 5] += w[ky * 5 + d] * in[d];
+    for (int ky = 1; ky < 5; ++ky) acc[(P - ky + 5) % 5] += w[ky * 5 + d] * in[d];
+  }
   constexpr int D = (P + 1) % 5;  // output row j-4 is complete
-  if (row_out) {
+  if (FAST || row_out) {
     const f32x2 pv = acc[D] + bias;
     *reinterpret_cast<f32x2*>(OUT + (P * SW_FC + lane) * SW_CS + wv * 2) = pv;
     gs += f32x2{lmn_gelu(pv[0]), lmn_gelu(pv[1])};  // (columns outside the image are dropped from the lane sums at the end)
@@ -695,7 +697,7 @@ __global__ __launch_bounds__(256) void dw_fwd_strip_kernel(const TA* __restrict_
 //   MODE 1: backward pass 1            dpre = (u*s + dm)*gelu'(pre) -> store; stats[5][E] += (sum dpre, sum dpre*y_b)
 // Sums stay in registers for the whole segment; wave totals by DPP, parked in LDS, ONE atomic instruction per block
 // (a first version issued 16 single-lane atomics per wave: 73 k atomic instructions on 192 addresses = 170 us).
-template <int P, int MODE>
+template <int P, int MODE, bool FAST = false>
 __device__ __forceinline__ void ss_step(f32x2 (&a5)[5], f32x2 (&a3)[5], f32x2 (&av)[5], f32x2 (&ah)[5],
                                         f32x2 (&sum)[MODE == 0 ? 8 : 5], const BranchW& bw, const float* XS, const float* PS,
                                         const float* US, float* OUT, int j, int lane, int wv, bool row_out, bool valid,
@@ -704,29 +706,28 @@ __device__ __forceinline__ void ss_step(f32x2 (&a5)[5], f32x2 (&a3)[5], f32x2 (&
   f32x2 in[5];
 #pragma unroll
   for (int d = 0; d < 5; ++d) in[d] = *reinterpret_cast<const f32x2*>(xr + d * SW_CS);
-  // the first contribution to an output row is a plain product (no zeroed accumulators, no register rotation)
-  a5[P] = bw.w5[0] * in[0];
+  // the first contribution to an output row is a plain product (no zeroed accumulators, no register rotation); column-major:
+  // consecutive FMAs go to different accumulators (back-to-back dependent v_pk_fma_f32 cost an s_nop each)
 #pragma unroll
-  for (int d = 1; d < 5; ++d) a5[P] += bw.w5[d] * in[d];
+  for (int d = 0; d < 5; ++d) {
+    if (d == 0) a5[P] = bw.w5[0] * in[0];
+    else a5[P] += bw.w5[d] * in[d];
 #pragma unroll
-  for (int ky = 1; ky < 5; ++ky)
+    for (int ky = 1; ky < 5; ++ky) a5[(P - ky + 5) % 5] += bw.w5[ky * 5 + d] * in[d];
+    if (d >= 1 && d <= 3) {
+      if (d == 1) { a3[(P + 4) % 5] = bw.w3[0] * in[1]; ah[(P + 3) % 5] = bw.wh[0] * in[1]; }
+      else { a3[(P + 4) % 5] += bw.w3[d - 1] * in[d]; ah[(P + 3) % 5] += bw.wh[d - 1] * in[d]; }
 #pragma unroll
-    for (int d = 0; d < 5; ++d) a5[(P - ky + 5) % 5] += bw.w5[ky * 5 + d] * in[d];
-  a3[(P + 4) % 5] = bw.w3[0] * in[1];
-  a3[(P + 4) % 5] += bw.w3[1] * in[2];
-  a3[(P + 4) % 5] += bw.w3[2] * in[3];
-  av[(P + 4) % 5] = bw.wv[0] * in[2];
+      for (int ky = 1; ky < 3; ++ky) a3[(P + 4 - ky) % 5] += bw.w3[ky * 3 + d - 1] * in[d];
+    }
+    if (d == 2) {
+      av[(P + 4) % 5] = bw.wv[0] * in[2];
 #pragma unroll
-  for (int ky = 1; ky < 3; ++ky) {
-#pragma unroll
-    for (int d = 0; d < 3; ++d) a3[(P + 4 - ky) % 5] += bw.w3[ky * 3 + d] * in[1 + d];
-    av[(P + 4 - ky) % 5] += bw.wv[ky] * in[2];
+      for (int ky = 1; ky < 3; ++ky) av[(P + 4 - ky) % 5] += bw.wv[ky] * in[2];
+    }
   }
-  ah[(P + 3) % 5] = bw.wh[0] * in[1];
-  ah[(P + 3) % 5] += bw.wh[1] * in[2];
-  ah[(P + 3) % 5] += bw.wh[2] * in[3];
   constexpr int D = (P + 1) % 5;  // output row j-4 is complete in every branch
-  if (row_out) {
+  if (FAST || row_out) {
     const f32x2 y5 = a5[D], y3 = a3[D], yv = av[D], yh = ah[D];
     if (MODE == 0) {  // (columns outside the image are dropped from the lane sums at the end)
       sum[0] += y5; sum[1] += y3; sum[2] += yv; sum[3] += yh;
