@@ -39,17 +39,33 @@ def dice_loss(logits, target, weight=(1.0, 4.0), smooth=1e-5):
     return loss / n
 
 
+def _pmc():
+    """The committed PMC reduction of this very command (profiles/rNN_pmc.json, newest round first), or None."""
+    for name in ("r03_pmc.json", "r02_pmc.json"):
+        path = os.path.join(ROOT, "profiles", name)
+        if os.path.isfile(path):
+            try:
+                with open(path) as f:
+                    d = json.load(f)
+                d["_file"] = "profiles/" + name
+                return d
+            except (OSError, ValueError):
+                pass
+    return None
+
+
 def pmc_traffic(kernel):
     """HBM bytes per launch of `kernel`, measured by separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this
     very command and committed under profiles/ (a PMC pass cannot run inside the timed loop)."""
     try:
-        with open(os.path.join(ROOT, "profiles", "r02_pmc.json")) as f:
-            return round(json.load(f)["kernels"][kernel]["hbm_bytes_per_launch"])
-    except (OSError, KeyError, ValueError):
+        return round(_pmc()["kernels"][kernel]["hbm_bytes_per_launch"])
+    except (TypeError, KeyError, ValueError):
         return None
 
 
 MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: dense fp32 MFMA (v_mfma_f32_16x16x4_f32) = fp32 vector peak
+MFMA_BF16_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA (~2.5 PF; the 2:1-sparsity figure is never used)
+_PEAK = [MFMA_F32_PEAK_TFLOPS]  # matrix-core peak of the arithmetic of the run being reported (set by run_config)
 # SURVEY.md 8d, per image at 352x352 fp32 (scaled by pixels for other sizes): algorithmic bytes / FLOPs of one training step
 STEP_MB_352, STEP_GFLOP_352 = 2085.54, 59.7
 
@@ -59,12 +75,13 @@ def _entry(name, rec, extra_us=0.0):
     t = (rec["total_us"] + extra_us) * 1e-6
     n = max(rec["launches"], 1)
     gbs, tfs = rec["bytes"] / t / 1e9 if t > 0 else 0.0, rec["flops"] / t / 1e12 if t > 0 else 0.0
-    t_hbm, t_mfma = rec["bytes"] / (HBM_PEAK_GBS * 1e9), rec["flops"] / (MFMA_F32_PEAK_TFLOPS * 1e12)
+    pk = _PEAK[0]
+    t_hbm, t_mfma = rec["bytes"] / (HBM_PEAK_GBS * 1e9), rec["flops"] / (pk * 1e12)
     bound = "mfma" if t_mfma > t_hbm else "hbm"
     return {"kernel": name, "bound": bound, "launches": rec["launches"], "avg_us": round(rec["total_us"] / n, 2),
-            "achieved": round(tfs if bound == "mfma" else gbs, 2), "peak": MFMA_F32_PEAK_TFLOPS if bound == "mfma" else HBM_PEAK_GBS,
+            "achieved": round(tfs if bound == "mfma" else gbs, 2), "peak": pk if bound == "mfma" else HBM_PEAK_GBS,
             "unit": "TFLOP/s" if bound == "mfma" else "GB/s",
-            "frac": round((tfs / MFMA_F32_PEAK_TFLOPS) if bound == "mfma" else (gbs / HBM_PEAK_GBS), 4),
+            "frac": round((tfs / pk) if bound == "mfma" else (gbs / HBM_PEAK_GBS), 4),
             "algorithmic_flops_per_launch": round(rec["flops"] / n), "algorithmic_bytes_per_launch": round(rec["bytes"] / n)}
 
 
@@ -77,7 +94,7 @@ def _group(live, names):
     return tot
 
 
-def roofline_block(dominant, live, survey, tot_us, B, H, W, step_s, alone):
+def roofline_block(dominant, live, survey, tot_us, B, H, W, step_s, alone, esz=4):
     """`roofline` of the bench line: the kernel that takes the most GPU time (found by timing EVERY launch over two untimed
     steps), measured live with HIP events on its launch stream inside the timed region; algorithmic FLOPs / bytes from the
     layer shapes of each launch (SURVEY 8d convention).  Secondary entries: rows A2 / A7 (north_star's >= 70 % HBM targets)
@@ -98,8 +115,7 @@ def roofline_block(dominant, live, survey, tot_us, B, H, W, step_s, alone):
                          for k, v in sorted(survey.items(), key=lambda kv: -kv[1]["total_us"])[:5]]
     a2 = _group(live, ("dw_fwd_strip_kernel", "dw_bwd_strip_kernel", "dw_stats_strip_kernel"))
     a7 = _group(live, ("na_fwd_kernel", "na_bwd_q_kernel", "na_bwd_kv_kernel", "na_bwd_q_tile_kernel", "na_bwd_kv_tile_kernel"))
-    pm = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc.json"))).get("whole_step") if os.path.isfile(
-        os.path.join(ROOT, "profiles", "r02_pmc.json")) else None
+    pm = (_pmc() or {}).get("whole_step")
     # row totals under the 8d convention: A2 train = 5*E*HW*B*4 (the statistics passes are extra passes, not extra bytes)
     A2K = ("dw_fwd_strip_kernel", "dw_bwd_strip_kernel", "dw_stats_strip_kernel")
     A7K = ("na_fwd_kernel", "na_bwd_q_kernel", "na_bwd_kv_kernel", "na_bwd_q_tile_kernel", "na_bwd_kv_tile_kernel")
@@ -147,11 +163,13 @@ def roofline_block(dominant, live, survey, tot_us, B, H, W, step_s, alone):
             r["families_survey"][label] = {k: e[k] for k in ("bound", "launches", "achieved", "peak", "unit", "frac")}
             r["families_survey"][label]["share_of_gpu_time"] = round(tot["total_us"] / tot_us, 4)
     scale = (H * W) / (352.0 * 352.0)
-    mb, gf = STEP_MB_352 * scale * B, STEP_GFLOP_352 * scale * B
+    # activation elements x 4 B (fp32) or x 2 B (bf16 storage); the matrix-core peak is that of the operand type
+    mb, gf = STEP_MB_352 * scale * B * (esz / 4.0), STEP_GFLOP_352 * scale * B
     r["whole_step"] = {"algorithmic_MB": round(mb, 1), "algorithmic_GFLOP": round(gf, 1),
                        "hbm_GBps": round(mb / 1e3 / step_s, 1), "hbm_frac": round(mb / 1e3 / step_s / HBM_PEAK_GBS, 4),
-                       "TFLOPs": round(gf / 1e3 / step_s, 2), "mfma_frac": round(gf / 1e3 / step_s / MFMA_F32_PEAK_TFLOPS, 4)}
-    if pm and (B, H, W) == (8, 352, 352):
+                       "TFLOPs": round(gf / 1e3 / step_s, 2), "mfma_peak_TFLOPs": _PEAK[0],
+                       "mfma_frac": round(gf / 1e3 / step_s / _PEAK[0], 4)}
+    if pm and (B, H, W) == (8, 352, 352) and esz == 4:
         r["whole_step"]["hbm_traffic_MB_pmc"] = pm["hbm_total_MB"]            # FETCH_SIZE x2 + WRITE_SIZE over one step
         r["whole_step"]["mfma_busy_ms_per_simd_pmc"] = pm["mfma_busy_ms_per_simd_at_2p4GHz"]
     r["note"] = ("dominant kernel = largest share of GPU kernel time over two untimed steps with every launch timed; its "
@@ -164,9 +182,8 @@ def roofline_block(dominant, live, survey, tot_us, B, H, W, step_s, alone):
 
 def pmc_field(kernel, field):
     try:
-        with open(os.path.join(ROOT, "profiles", "r02_pmc.json")) as f:
-            return json.load(f)["kernels"][kernel][field]
-    except (OSError, KeyError, ValueError):
+        return _pmc()["kernels"][kernel][field]
+    except (TypeError, KeyError, ValueError):
         return None
 
 
@@ -212,6 +229,110 @@ def cpu_baseline(H, W, threads=16, budget_s=25.0):
         return {"value": None, "unit": "images/sec", "cores": threads, "kind": "port", "sample": "failed: %s" % str(e)[:200]}
 
 
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def spawn_ranks(n, argv):
+    """`python bench.py --gpus N` without a launcher: start N fresh rank processes (torch.distributed.run, one per GPU,
+    rendezvous on 127.0.0.1) BEFORE this process has touched the GPU, relay their output (rank 0 prints the JSON line) and
+    exit with the launcher's code.  Fewer than N visible GPUs is an error, never a silent 1-GPU run."""
+    import subprocess
+    have = torch.cuda.device_count()        # (counting devices does not initialise the GPU on this image)
+    if have < n:
+        print("bench.py: --gpus %d requested but only %d GPU(s) visible; refusing to report a smaller run as n_gpus=%d"
+              % (n, have, n), file=sys.stderr)
+        sys.exit(2)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", "8")
+    sys.exit(subprocess.call(cmd, env=env))
+
+
+class Run:
+    """One benchmark configuration: model, optimizer, fused loss and a resident synthetic batch on `dev`."""
+
+    def __init__(self, dev, world, rank, dtype, B, size, plans=True, graphs=False):
+        from lm_net_amd import LM_Net
+        from lm_net_amd.ddp import DistributedLMNet
+        from lm_net_amd.loss import SegLoss
+        from lm_net_amd.optim import FusedAdamW
+        torch.manual_seed(1234)
+        self.net = LM_Net(3, 2).to(dev)
+        self.net.compute_dtype = "bf16" if dtype == "bf16" else "fp32"
+        self.model = DistributedLMNet(self.net) if world > 1 else self.net
+        self.model.train()
+        if graphs:
+            self.net.enable_graphs()    # forward / backward as two hipGraph replays per step (captured during the warm-up)
+        elif plans:
+            self.net.enable_plans()     # forward / backward as one lmn_plan_run each (recorded on the 3rd step of the shape)
+        self.opt = FusedAdamW(self.net, lr=1e-3, weight_decay=1e-4)     # torch.optim.AdamW semantics, one launch per step
+        self.x, self.y = make_batch(B, size, size, dev, 1234 + rank)    # rank-offset data seed (train.py:42)
+        self.crit = SegLoss(ce_weight=(1.0, 4.0), dice_weight=(1.0, 4.0), label_smoothing=0.001).to(dev)   # fused CE + Dice
+        self.B, self.size, self.dtype = B, size, dtype
+
+    def step(self):
+        out = self.model(self.x)
+        loss = self.crit(out, self.y)
+        self.opt.zero_grad(set_to_none=True)
+        loss.backward()
+        self.opt.step()
+        return loss
+
+    def timed(self, steps, world, dev):
+        """EXACTLY `steps` steps between barrier + synchronize pairs; max over ranks."""
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            loss = self.step()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt, loss
+
+
+def other_config(dev, dtype, B, size, steps=10, warmup=5):
+    """A further BASELINE configuration timed in the same process (never the headline): warm-up (incl. plan recording), then
+    `steps` steps between synchronisations.  Returns the entry for `other_configs`."""
+    _PEAK[0] = MFMA_BF16_PEAK_TFLOPS if dtype == "bf16" else MFMA_F32_PEAK_TFLOPS
+    try:
+        r = Run(dev, 1, 0, dtype, B, size)
+        for _ in range(max(warmup, 4)):
+            r.step()
+        dt, loss = r.timed(steps, 1, dev)
+        step_s = dt / steps
+        esz = 2 if dtype == "bf16" else 4
+        scale = (size * size) / (352.0 * 352.0)
+        mb, gf = STEP_MB_352 * scale * B * (esz / 4.0), STEP_GFLOP_352 * scale * B
+        ent = {"value": round(B * steps / dt, 2), "unit": "images/sec", "ms_per_step": round(step_s * 1e3, 3), "steps": steps,
+               "warmup": max(warmup, 4), "dtype": dtype, "batch": B, "image": [3, size, size],
+               "final_loss": round(float(loss.detach()), 5),
+               "whole_step": {"algorithmic_MB": round(mb, 1), "hbm_frac": round(mb / 1e3 / step_s / HBM_PEAK_GBS, 4),
+                              "algorithmic_GFLOP": round(gf, 1), "mfma_peak_TFLOPs": _PEAK[0],
+                              "mfma_frac": round(gf / 1e3 / step_s / _PEAK[0], 4)}}
+    except Exception as e:       # never lose the headline because a side configuration misbehaved
+        ent = {"value": None, "error": str(e)[:300], "dtype": dtype, "batch": B, "image": [3, size, size]}
+    finally:
+        _PEAK[0] = MFMA_F32_PEAK_TFLOPS
+    r = None
+    torch.cuda.empty_cache()
+    return ent
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -220,6 +341,8 @@ def main():
     ap.add_argument("--batch", type=int, default=8, help="images per GPU")
     ap.add_argument("--size", type=int, default=352)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="skip the extra lines for BASELINE configs[2] (bf16, batch 64) and configs[4] at one GPU (512x512, batch 32)")
     ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"],
                     help="arithmetic of the dense contractions: f32 (BASELINE configs[1], the headline) or bf16 matrix-core operands "
                          "with fp32 accumulation / statistics / master weights (BASELINE configs[2]; run with --batch 64)")
@@ -232,46 +355,36 @@ def main():
                          "the step is GPU-bound and host launches measured 7 %% faster than the replay)")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        spawn_ranks(args.gpus, sys.argv[1:])            # never returns; nothing has touched the GPU yet
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    backend = os.environ.get("LMNET_BENCH_BACKEND", "nccl")   # "gloo" only to exercise this path with several ranks on ONE GPU
+    if args.gpus != world:
+        if rank == 0:
+            print("bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks; refusing to report a mislabelled run"
+                  % (args.gpus, world), file=sys.stderr)
+        sys.exit(2)
+    ngpu = torch.cuda.device_count()
+    if ngpu < 1 or (world > ngpu and backend == "nccl"):
+        if rank == 0:
+            print("bench.py: %d rank(s) but %d GPU(s) visible (one rank per GPU over RCCL)" % (world, ngpu), file=sys.stderr)
+        sys.exit(2)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        # RCCL ("nccl") over xGMI; LMNET_BENCH_BACKEND=gloo only to exercise this code path with several ranks on ONE GPU
-        dist.init_process_group(os.environ.get("LMNET_BENCH_BACKEND", "nccl"), rank=rank, world_size=world)
-    if args.gpus != world and rank == 0 and world > 1:
-        print("warning: --gpus %d but WORLD_SIZE %d" % (args.gpus, world), file=sys.stderr)
-    local = local % max(torch.cuda.device_count(), 1)
+        dist.init_process_group(backend, rank=rank, world_size=world)     # "nccl" = RCCL over xGMI
+    local = local % ngpu
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
-    from lm_net_amd import LM_Net
-    from lm_net_amd.ddp import DistributedLMNet
-    torch.manual_seed(1234)
-    net = LM_Net(3, 2).to(dev)
-    net.compute_dtype = "bf16" if args.dtype == "bf16" else "fp32"
-    model = DistributedLMNet(net) if world > 1 else net
-    model.train()
     if args.graphs:
         args.plans = False
-    if args.plans:
-        net.enable_plans()      # forward / backward as one lmn_plan_run each (recorded on the 3rd step of the shape)
-    if args.graphs:
-        net.enable_graphs()     # forward / backward as two hipGraph replays per step (captured during the warm-up)
-    from lm_net_amd.optim import FusedAdamW
-    opt = FusedAdamW(net, lr=1e-3, weight_decay=1e-4)     # torch.optim.AdamW semantics, one launch per step
+    esz = 2 if args.dtype == "bf16" else 4
+    _PEAK[0] = MFMA_BF16_PEAK_TFLOPS if args.dtype == "bf16" else MFMA_F32_PEAK_TFLOPS
+    run = Run(dev, world, rank, args.dtype, args.batch, args.size, plans=args.plans, graphs=args.graphs)
+    net, step = run.net, run.step
     B, H, W = args.batch, args.size, args.size
-    x, y = make_batch(B, H, W, dev, 1234 + rank)          # rank-offset data seed (train.py:42)
-    from lm_net_amd.loss import SegLoss
-    crit = SegLoss(ce_weight=(1.0, 4.0), dice_weight=(1.0, 4.0), label_smoothing=0.001).to(dev)   # fused CE + Dice
-
-    def step():
-        out = model(x)
-        loss = crit(out, y)
-        opt.zero_grad(set_to_none=True)
-        loss.backward()
-        opt.step()
-        return loss
 
     for _ in range(max(args.warmup, 4 if (args.graphs or args.plans) else 0)):   # graph capture happens on the 3rd step of a shape
         step()
@@ -287,28 +400,17 @@ def main():
         step()
     survey = hip.prof_end()
     net.use_graphs = saved_graphs
+    launches_per_step = sum(v["launches"] for v in survey.values()) // 2
     tot_us = sum(v["total_us"] for v in survey.values()) or 1.0
     ranked = sorted(survey.items(), key=lambda kv: -kv[1]["total_us"])
     dominant = ranked[0][0]
     watch = [dominant] + [k for k in survey if k.startswith(("dw_", "na_")) or "wgrad_reduce" in k]
     # ---- timed region: the dominant kernel and the A2 / A7 kernels (north_star targets) are timed live
     torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
     if not net.use_graphs:
         hip.prof_begin("|".join(sorted(set(w.split("<")[0] for w in watch))))
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss = step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    dt = time.perf_counter() - t0
+    dt, loss = run.timed(args.steps, world, dev)
     live = hip.prof_end() if not net.use_graphs else {}
-    if world > 1:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
     if net.use_graphs:      # replays run no host code: time the same kernels over 5 host-launched steps right after
         net.use_graphs = False
         hip.prof_begin("|".join(sorted(set(w.split("<")[0] for w in watch))))
@@ -316,9 +418,14 @@ def main():
             step()
         live = hip.prof_end()
         net.use_graphs = True
+    comm = None
+    if world > 1:
+        red = run.model.reducer
+        comm = {"backend": "RCCL (torch.distributed 'nccl')" if backend == "nccl" else backend, "ranks": dist.get_world_size(),
+                "buckets_per_step": len(red.launched), "launched_before_finish": red.launched_before_finish,
+                "gradient_MB": round(net._grad_flat.numel() * 4 / 1e6, 2) if net._grad_flat is not None else None}
     # the same kernels with nothing else on the GPU: 3 more steps launched from the host with the branch / weight-gradient
     # streams switched off (inside the timed region a kernel shares the CUs with the other streams of the step)
-    eng = net._engine
     saved = (eng.branch_overlap, eng.overlap_wgrad, net.use_graphs, net.use_plans)
     eng.branch_overlap, eng.overlap_wgrad, net.use_graphs, net.use_plans = False, False, False, False
     for _ in range(2):
@@ -330,6 +437,7 @@ def main():
     eng.branch_overlap, eng.overlap_wgrad, net.use_graphs, net.use_plans = saved
     if rank == 0:
         step_s = dt / args.steps
+        cfg_idx = 1 if args.dtype == "f32" else 2
         res = {
             "metric": "train images/sec at 352x352, 1/2/4/8 MI355X; Dice vs ref",
             "value": round(world * B * args.steps / dt, 2), "unit": "images/sec", "n_gpus": world,
@@ -338,13 +446,26 @@ def main():
             "config": {"workload": "LM-Net %s training step (fwd + CE/Dice loss + bwd + AdamW), batch %d/GPU, %dx%d "
                                    "synthetic disc masks (BASELINE configs[%d])" % (
                                        "fp32" if args.dtype == "f32" else "bf16 mixed-precision (bf16 MFMA operands, fp32 accumulate / "
-                                       "statistics / master weights)", B, H, W, 1 if args.dtype == "f32" else 2),
+                                       "statistics / master weights)", B, H, W, cfg_idx if world == 1 else 3),
                        "global_batch": world * B, "image": [3, H, W], "parallelism": "dp%d" % world,
                        "launch": "hipGraph replay (fwd + bwd graphs per step)" if args.graphs else
                                  ("lmn_plan_run (recorded C-side schedule, one crossing per pass)" if args.plans else "host"),
+                       "kernel_launches_per_step": launches_per_step,
                        "final_loss": round(float(loss.detach()), 5)},
-            "roofline": roofline_block(dominant, live, survey, tot_us, B, H, W, step_s, alone),
+            "roofline": roofline_block(dominant, live, survey, tot_us, B, H, W, step_s, alone, esz),
         }
+        if comm is not None:
+            res["allreduce"] = comm
+    run = net = step = None
+    if rank == 0:
+        default_headline = world == 1 and (args.dtype, B, H) == ("f32", 8, 352)
+        if default_headline and not args.no_other_configs:
+            torch.cuda.empty_cache()
+            # the two other single-GPU BASELINE configurations, timed in this process AFTER the headline (value / config / dtype of
+            # the line stay configs[1]): configs[2] = bf16 storage + bf16 MFMA operands at batch 64; configs[4] at one GPU =
+            # 512x512 inputs, batch 32
+            res["other_configs"] = {"configs[2] bf16 mixed precision, batch 64, 352x352": other_config(dev, "bf16", 64, 352),
+                                    "configs[4] on 1 GPU: fp32, 512x512, batch 32": other_config(dev, "f32", 32, 512)}
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(H, W)
         print(json.dumps(res))

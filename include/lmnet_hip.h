@@ -39,7 +39,7 @@ extern "C" {
 
 typedef void* lmn_stream_t; /* hipStream_t */
 
-#define LMN_ABI_VERSION 6
+#define LMN_ABI_VERSION 7
 /* arithmetic type of the matrix-core operands of a dense contraction (accumulators, epilogues, statistics: fp32) */
 #define LMN_F32 0  /* v_mfma_f32_16x16x4_f32: exact fp32 (k-ordered fma chain)                                  */
 #define LMN_BF16 1 /* v_mfma_f32_16x16x16_bf16: operands rounded to bf16 (RNE) when staged / packed -- the mixed- */
@@ -221,11 +221,36 @@ typedef struct {
   float* db2;       /* optional second bias gradient receiving the same sum as db                              */
   int32_t mma_dtype; /* LMN_F32 | LMN_BF16: operand type of the pixel-reduction MFMAs (accumulators fp32)                */
   int32_t act_dtype; /* storage of src[].ptr and dy                                                                      */
+  int32_t defer_reduce; /* 1: with a workspace, the call only writes its K-split block partials; the caller sums them    */
+  int32_t _pad;         /*    later with lmn_wgrad_reduce_batch (job description: lmn_conv_wgrad_job).  The workspace    */
+                        /*    must then be the call's own until that launch (not a scratch shared with other calls)      */
 } lmn_wgrad_args_t;
 int lmn_sizeof_wgrad_args(void);
 /* floats of workspace that make lmn_conv_wgrad use the two-stage reduction for this problem (0: not useful) */
 int64_t lmn_conv_wgrad_workspace(const lmn_wgrad_args_t* args);
 int lmn_conv_wgrad(const lmn_wgrad_args_t* args, lmn_stream_t stream);
+/* Deferred second stage of the K-split reduction.  Every weight gradient of a backward pass used to be followed by its own
+ * reduction launch (82 launches of 8-11 us per LM-Net training step); with defer_reduce the partials stay in per-call
+ * workspaces and ONE launch per gradient bucket sums all of them (same fixed order: deterministic).
+ * lmn_conv_wgrad_job: host arithmetic only -- describes the reduction the call with these arguments leaves behind
+ * (out->nblk == 0: the call reduces by itself, nothing to defer).  The caller fills first_block (running sum of
+ * gy * blocks_per_set over the jobs of a batch), copies the jobs to device memory and launches them together.          */
+typedef struct {
+  const float* partial;   /* [gy][nblk][per] block partials */
+  int64_t first_block;
+  int32_t nblk, per, gy, nsets_n;
+  int32_t taps, NMT, NNT, nsrc;
+  int32_t Cout, Cin, NMTT, NNTT;
+  int32_t srcC[3], ntile_off[3], cbase[3];
+  int32_t ksl, blocks_per_set, _pad;
+  float* dW;
+  float* dW_src[3];
+  float* db;
+  float* db2;
+} lmn_reduce_job_t;
+int lmn_sizeof_reduce_job(void);
+int lmn_conv_wgrad_job(const lmn_wgrad_args_t* args, lmn_reduce_job_t* out);
+int lmn_wgrad_reduce_batch(const lmn_reduce_job_t* jobs_dev, int njobs, int64_t total_blocks, lmn_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Multi-branch depthwise stencil of ReparamConv (row A2): four depthwise convs 5x5, 3x3, 3x1,

@@ -95,6 +95,8 @@ class _PlannedStep:
         self.shapes = None
         self.marks = []            # backward: (op index, block name, producer streams) at every finished gradient block
         self.pending = False       # a forward whose backward has not run yet
+        self.rec = None            # hip.Plan being recorded by the backward (its size marks the gradient-block boundaries)
+        self.key = None
 
 
 class _LMNetPlanFunction(torch.autograd.Function):
@@ -145,6 +147,8 @@ class LM_Net(nn.Module):
         self._grad_flat = None
         self._grad_layout = None
         self._recording = None
+        self._pend = None          # gradient blocks enqueued but not handed on yet: [lo, hi) of the flat buffer (see _done)
+        self._emitted = False
         self._save_tape = False
         self._keep_taps = False
         self._taps = None
@@ -239,101 +243,134 @@ class LM_Net(nn.Module):
         return self
 
     def _plan_for(self, x):
-        train = bool(self.training and self._save_tape)
-        key = (tuple(x.shape), x.device, self.training, self._save_tape, self._engine.pm())
+        taped = bool(self._save_tape)          # a backward may follow (training, or eval-mode BatchNorm with gradients enabled)
+        key = self._plan_key(x)
         ps = self._plans.get(key)
         if ps is None:
             ps = self._plans[key] = _PlannedStep()
+            ps.key = key
         if ps.fwd is not None:
-            if ps.pending and train:
+            if ps.pending and taped:
                 return None            # a second forward before the backward of the first: that one runs launch by launch
             return ps
         ps.warm += 1
         if ps.warm <= 2:
             return None
-        if train and ps.need_bwd == 0:
+        if taped and ps.need_bwd == 0:
             return None                # no backward has been seen for this shape yet: keep warming up
         eng = self._engine
         if eng.seed_ctr is None:
             eng.seed_ctr = torch.zeros(1, device=x.device, dtype=torch.int32)
         return ps
 
+    def _plan_key(self, x):
+        """(shape, device, mode, precision, launch stream): recorded launches carry the stream that was current while recording,
+        so a call under another current stream gets its own plan instead of racing with this one."""
+        return (tuple(x.shape), x.device, self.training, self._save_tape, self._engine.pm(),
+                torch.cuda.current_stream(x.device).cuda_stream)
+
+    def _drop_plan(self, ps):
+        """A recording failed: forget the (possibly truncated) plans of this shape; it runs launch by launch from now on."""
+        for k, v in list(self._plans.items()):
+            if v is ps:
+                del self._plans[k]
+        ps.fwd = ps.bwd = None
+
     def _plan_forward(self, ps, x):
         eng = self._engine
-        if ps.fwd is None:                          # record while running
-            train = bool(self.training and self._save_tape)
-            L = self._ensure_grad_layout()
-            need = ps.need_fwd + (ps.need_bwd + L["total"] if train else 0)
-            ps.arena = Arena(int(need * 1.02) + (1 << 16), x.device)
-            ps.x = ps.arena.alloc(tuple(x.shape))
-            ps.x.copy_(x)
-            ps.cx = Ctx() if self._save_tape else None
-            ps.fwd = hip.Plan()
-            eng.arena, eng.planning = ps.arena, True
-            try:
-                ps.fwd.record_begin()
-                ps.out = self._forward_impl(ps.x, ps.cx)
-            finally:
-                ps.fwd.record_end()
-                eng.arena, eng.planning = None, False
-            ps.keep = [eng.packs_fwd.table, eng.packs_bwd.table]     # device job tables the recorded pack launches read
-        else:
-            ps.x.copy_(x)
-            self._step_bookkeeping()
-            if ps.cx is not None:
-                ps.cx.training = self.training
-                ps.cx.mma, ps.cx.act_dtype = eng.mma, eng.act_dtype
-            ps.fwd.run()
-        ps.pending = ps.cx is not None
-        return ps.out.clone()
+        with torch.cuda.device(x.device):
+            if ps.fwd is None:                          # record while running
+                L = self._ensure_grad_layout()
+                # the arena holds the backward's tensors whenever a tape is kept (eval-mode BatchNorm with gradients too)
+                need = ps.need_fwd + (ps.need_bwd + L["total"] if self._save_tape else 0)
+                ps.arena = Arena(int(need * 1.02) + (1 << 16), x.device)
+                ps.x = ps.arena.alloc(tuple(x.shape))
+                ps.x.copy_(x)
+                ps.cx = Ctx() if self._save_tape else None
+                plan = hip.Plan()
+                eng.arena, eng.planning = ps.arena, True
+                ok = False
+                try:
+                    plan.record_begin()
+                    out = self._forward_impl(ps.x, ps.cx)
+                    ok = True
+                finally:
+                    plan.record_end()
+                    eng.arena, eng.planning = None, False
+                    if not ok:
+                        self._drop_plan(ps)
+                ps.out, ps.fwd = out, plan              # (assigned only once the recording is complete)
+                ps.keep = [eng.packs_fwd.table, eng.packs_bwd.table]     # device job tables the recorded pack launches read
+            else:
+                ps.x.copy_(x)
+                self._step_bookkeeping()
+                if ps.cx is not None:
+                    ps.cx.training = self.training
+                    ps.cx.mma, ps.cx.act_dtype = eng.mma, eng.act_dtype
+                ps.fwd.run()
+            ps.pending = ps.cx is not None
+            return ps.out.clone()
 
     def _plan_backward(self, ps, dlogits):
         eng = self._engine
         L = self._ensure_grad_layout()
         params = self._param_list()
-        p0 = params[0]
-        acc = ps.flat is not None and p0.grad is not None and \
-            ps.flat.data_ptr() <= p0.grad.data_ptr() < ps.flat.data_ptr() + 4 * ps.flat.numel()
-        old = ps.flat.clone() if acc else None      # a .grad still aliases the static buffer: keep its values
-        if ps.bwd is None:                          # record while running
-            ps.dlogits = ps.arena.alloc(tuple(dlogits.shape))
-            ps.dlogits.copy_(dlogits)
-            ps.flat = ps.arena.alloc((L["total"],))
-            ps.G = {}
-            for p in L["order"]:
-                a, b = L["offs"][id(p)]
-                ps.G[p] = ps.flat[a:b].view(p.shape)
-            ps.sizes = [(L["offs"][id(p)][0], p.numel(), tuple(p.shape)) for p in params]
-            ps.bwd = hip.Plan()
-            ps.marks = []
-            eng.arena, eng.planning = ps.arena, True
-            try:
-                ps.bwd.record_begin()
-                self._backward_impl(ps.cx, ps.dlogits, False, plan=ps)
-            finally:
-                ps.bwd.record_end()
-                eng.arena, eng.planning = None, False
-            ps.keep += [eng.packs_fwd.table, eng.packs_bwd.table]
-        else:
-            ps.dlogits.copy_(dlogits)
-            self._grad_flat = ps.flat
-            if self.grad_begin_hook is not None:
-                self.grad_begin_hook(ps.flat)
-            if self.grad_ready_hook is None:
-                ps.bwd.run()
+        with torch.cuda.device(dlogits.device):
+            lo_b = ps.flat.data_ptr() if ps.flat is not None else 0
+            hi_b = lo_b + 4 * ps.flat.numel() if ps.flat is not None else 0
+            alias = [p.grad is not None and lo_b <= p.grad.data_ptr() < hi_b for p in params] if ps.flat is not None else []
+            acc = any(alias)
+            old = ps.flat.clone() if acc else None      # some .grad still aliases the static buffer: keep its values
+            if ps.bwd is None:                          # record while running
+                ps.dlogits = ps.arena.alloc(tuple(dlogits.shape))
+                ps.dlogits.copy_(dlogits)
+                ps.flat = ps.arena.alloc((L["total"],))
+                ps.G = {}
+                for p in L["order"]:
+                    a, b = L["offs"][id(p)]
+                    ps.G[p] = ps.flat[a:b].view(p.shape)
+                ps.sizes = [(L["offs"][id(p)][0], p.numel(), tuple(p.shape)) for p in params]
+                plan = hip.Plan()
+                ps.rec = plan
+                ps.marks = []
+                eng.arena, eng.planning = ps.arena, True
+                ok = False
+                try:
+                    plan.record_begin()
+                    self._backward_impl(ps.cx, ps.dlogits, False, plan=ps)
+                    ok = True
+                finally:
+                    plan.record_end()
+                    eng.arena, eng.planning = None, False
+                    ps.rec = None
+                    if not ok:
+                        self._drop_plan(ps)
+                ps.bwd = plan
+                ps.keep += [eng.packs_fwd.table, eng.packs_bwd.table] + list(eng.reduce_tabs)
             else:
-                lo = 0
-                for idx, name, streams in ps.marks:
-                    ps.bwd.run(lo, idx)
-                    lo = idx
-                    self.grad_ready_hook(*L["blocks"][name], streams)
-                ps.bwd.run(lo, -1)
-            if self.grad_finish_hook is not None:
-                self.grad_finish_hook()
-        ps.pending = False
-        src = ps.flat if old is None else old
-        # fresh views every time: AccumulateGrad then takes them as .grad without a copy
-        return [src[a:a + n].view(shp) for a, n, shp in ps.sizes]
+                ps.dlogits.copy_(dlogits)
+                self._grad_flat = ps.flat
+                if self.grad_begin_hook is not None:
+                    self.grad_begin_hook(ps.flat)
+                if self.grad_ready_hook is None:
+                    ps.bwd.run()
+                else:
+                    lo = 0
+                    for idx, rng, streams in ps.marks:
+                        ps.bwd.run(lo, idx)
+                        lo = idx
+                        self.grad_ready_hook(rng[0], rng[1], streams)
+                    ps.bwd.run(lo, -1)
+                if self.grad_finish_hook is not None:
+                    self.grad_finish_hook()
+            ps.pending = False
+            # fresh views every time: AccumulateGrad then takes them as .grad without a copy.  A parameter whose .grad still
+            # aliases the static buffer gets its gradient from a copy (autograd then adds it to the kept values, see `old`)
+            if old is None:
+                return [ps.flat[a:a + n].view(shp) for a, n, shp in ps.sizes]
+            new = ps.flat.clone()
+            ps.flat.copy_(old)                          # the aliased .grad tensors keep their accumulated values
+            return [new[a:a + n].view(shp) for a, n, shp in ps.sizes]
 
     # ------------------------------------------------------------------ hipGraph capture of the training step
     def enable_graphs(self, on=True):
@@ -446,7 +483,7 @@ class LM_Net(nn.Module):
                 nf = eng.alloc_floats
                 eng.end_pass()
         if self.use_plans:
-            key = (tuple(x.shape), x.device, self.training, self._save_tape, eng.pm())
+            key = self._plan_key(x)
             ps = self._plans.get(key)
             if ps is not None:
                 ps.need_fwd = max(ps.need_fwd, nf)
@@ -605,18 +642,41 @@ class LM_Net(nn.Module):
             G[p] = flat[a:b].view(p.shape)
         return flat, G
 
-    def _done(self, name):
+    def _done(self, name, force=False):
+        """Block `name` of the flat gradient buffer has been enqueued.  Blocks are handed on in BUCKETS (>= 1 MB for the first,
+        >= 4 MB after it, and whenever the issuing stream changes): one batched launch sums the deferred K-split partials of the
+        bucket's weight gradients (engine.flush_reduce), then the data-parallel reducer / the plan recorder is told."""
         plan = self._recording
-        if self.grad_ready_hook is not None or plan is not None:
-            # the block's weight gradients run on the side stream of the current stream: the collective waits for
-            # that stream, the compute chain does not (it joins once, at the end of backward)
-            cur = torch.cuda.current_stream(self._grad_flat.device) if self._grad_flat.is_cuda else None
-            ent = self._engine.sides.get(cur.cuda_stream) if cur is not None else None
-            streams = ([cur] if cur is not None else []) + ([ent[0]] if ent is not None else [])
-            if plan is not None:                     # replays call the hook between plan segments
-                plan.marks.append((plan.bwd.size(), name, streams))
-            if self.grad_ready_hook is not None:
-                self.grad_ready_hook(*self._grad_layout["blocks"][name], streams)
+        if self.grad_ready_hook is None and plan is None:
+            return
+        lo, hi = self._grad_layout["blocks"][name]
+        if self._pend is None:
+            self._pend = [lo, hi]
+        else:
+            self._pend[1] = hi
+        cap = (1 << 18) if not self._emitted else (1 << 20)        # floats
+        if force or self._pend[1] - self._pend[0] >= cap:
+            self._emit_done()
+
+    def _emit_done(self):
+        if self._pend is None:
+            return
+        lo, hi = self._pend
+        self._pend = None
+        self._emitted = True
+        plan = self._recording
+        dev = self._grad_flat.device
+        if self._grad_flat.is_cuda:
+            self._engine.flush_reduce(dev)
+        # the block's weight gradients run on the side stream of the current stream: the collective waits for
+        # that stream, the compute chain does not (it joins once, at the end of backward)
+        cur = torch.cuda.current_stream(dev) if self._grad_flat.is_cuda else None
+        ent = self._engine.sides.get(cur.cuda_stream) if cur is not None else None
+        streams = ([cur] if cur is not None else []) + ([ent[0]] if ent is not None else [])
+        if plan is not None:                     # replays call the hook between plan segments
+            plan.marks.append((plan.rec.size(), (lo, hi), streams))
+        if self.grad_ready_hook is not None:
+            self.grad_ready_hook(lo, hi, streams)
 
     # ------------------------------------------------------------------ backward schedule
     def _backward_impl(self, cx, dlogits, need_dx, plan=None):
@@ -632,6 +692,7 @@ class LM_Net(nn.Module):
                 flat, G = plan.flat, plan.G
             self._grad_flat = flat
             self._recording = plan
+            self._pend, self._emitted = None, False
             if self.grad_begin_hook is not None:
                 self.grad_begin_hook(flat)
             eng.G = G
@@ -640,6 +701,7 @@ class LM_Net(nn.Module):
                 if plan is not None:
                     hip.fill(flat, 0.0)                          # recorded: every replay starts from zero gradients
                 dx = self._backward_body(cx, dlogits, need_dx, G)
+                self._emit_done()
                 eng.join_side(dlogits.device)
             finally:
                 nb = eng.alloc_floats
@@ -698,9 +760,10 @@ class LM_Net(nn.Module):
         def branch_blocks_done():
             if not fork or (self.grad_ready_hook is None and self._recording is None):
                 return False
+            self._emit_done()                            # blocks pending on the main stream leave from there
             with eng.on_stream(bst):
                 for name in ("natt4", "natt3", "natt2", "natt1", "skip4", "skip3", "skip2", "skip1"):
-                    self._done(name)
+                    self._done(name, force=name == "skip1")
             return True
 
         # decoder (the branch work of level k is forked as soon as dt_k exists)

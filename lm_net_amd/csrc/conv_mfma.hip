@@ -215,7 +215,7 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(const ConvParams P) {
 
   for (int i = tid; i < 2 * NCT * 16; i += 256) s_stats[i] = 0.f;
   float* s_par = s_stats + 2 * NCT * 16;  // [9][NCT*16]
-  conv_stage_params<NCT>(A, s_par, ct0, tid, blockIdx.x == 0);
+  conv_stage_params<NCT>(A, s_par, ct0, tid, blockIdx.x == 0 && blockIdx.z == 0);  // (one writer per cout range, also with parity classes in grid.z)
   __syncthreads();  // the tiles read s_par from their first instruction on (accumulators start from the bias)
   float* s_w = s_par + 9 * NCT * 16;  // WL: [tap * nkbc + kk][NCT][WT]
   auto stage_w = [&](int s, int kb0, int nkbc) __attribute__((always_inline)) {
@@ -2197,6 +2197,65 @@ __global__ __launch_bounds__(1024) void wgrad_reduce_kernel(const WgradParams P,
   }
 }
 
+// All deferred reductions of a pass (lmn_wgrad_args_t.defer_reduce) in ONE launch: block b finds its job by bisection over the
+// jobs' first-block table, then sums one slice of one tile set exactly as wgrad_reduce_kernel does (same fixed order =>
+// deterministic).  82 reduction launches of 8-11 us each per training step become one or a few.
+__global__ __launch_bounds__(1024) void wgrad_reduce_batch_kernel(const lmn_reduce_job_t* __restrict__ jobs, int njobs) {
+  __shared__ __attribute__((aligned(16))) float red[4096];
+  int lo = 0, hi = njobs - 1;
+  const int64_t b = blockIdx.x;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (jobs[mid].first_block <= b) lo = mid; else hi = mid - 1;
+  }
+  const lmn_reduce_job_t& J = jobs[lo];
+  const int rel = (int)(b - J.first_block);
+  const int set = rel / J.blocks_per_set, bx = rel - set * J.blocks_per_set;
+  const int NMT = J.NMT, NNT = J.NNT, TAPS = J.taps, PER = J.per, nblk = J.nblk, ksl = J.ksl;
+  const int NT = TAPS * NMT * NNT;
+  const int mset = set / J.nsets_n, nset = set - mset * J.nsets_n;
+  const int mt0 = mset * NMT, nt0 = nset * NNT;
+  const float* src = J.partial + (int64_t)set * nblk * PER;
+  const int epq = 1024 / ksl, epb = epq * 4;
+  const int q = threadIdx.x & (epq - 1), ks = threadIdx.x / epq;
+  const int i4 = (bx * epq + q) * 4;
+  f32x4 s4 = f32x4{0.f, 0.f, 0.f, 0.f};
+  if (i4 < PER) {
+    const float* sp = src + i4;
+#pragma unroll 4
+    for (int k = ks; k < nblk; k += ksl) s4 += *reinterpret_cast<const f32x4*>(sp + (int64_t)k * PER);
+  }
+  *reinterpret_cast<f32x4*>(&red[threadIdx.x * 4]) = s4;
+  __syncthreads();
+  for (int e = threadIdx.x; e < epb; e += 1024) {  // (epb > 1024 for ksl < 4)
+    const int i = bx * epb + e;
+    if (i >= PER) return;
+    float sum = 0.f;
+    for (int k = 0; k < ksl; ++k) sum += red[k * epb + e];
+    if (i < NT * 256) {
+      const int ln = i & 63, r = (i >> 6) & 3, tile = i >> 8;
+      const int t = tile % NNT, m = (tile / NNT) % NMT, tp = tile / (NNT * NMT);
+      const int qq = ln >> 4, nn = ln & 15;
+      const int co = (mt0 + m) * 16 + qq * 4 + r;
+      const int nt = nt0 + t;
+      if ((mt0 + m) >= J.NMTT || co >= J.Cout || nt >= J.NNTT) continue;
+      int sidx = 0;
+      while (sidx + 1 < J.nsrc && nt >= J.ntile_off[sidx + 1]) ++sidx;
+      const int ch = (nt - J.ntile_off[sidx]) * 16 + nn;
+      if (ch >= J.srcC[sidx]) continue;
+      float* own = J.dW_src[sidx];
+      float* d = own ? own + ((int64_t)co * J.srcC[sidx] + ch) * TAPS : J.dW + ((int64_t)co * J.Cin + J.cbase[sidx] + ch) * TAPS;
+      d[tp] += sum;
+    } else if (J.db && nset == 0) {
+      const int j = i - NT * 256, co = mt0 * 16 + j;
+      if (co < J.Cout && (mt0 + j / 16) < J.NMTT) {
+        J.db[co] += sum;
+        if (J.db2) J.db2[co] += sum;
+      }
+    }
+  }
+}
+
 }  // namespace
 
 thread_local char g_lmn_err[256] = {0};
@@ -2629,13 +2688,17 @@ static bool wgrad_two_stage(int64_t gy, int64_t blocks, int64_t per) {
   return blocks > 48 || gy * blocks * per > 256 * 1024;
 }
 
-int lmn_conv_wgrad(const lmn_wgrad_args_t* args, lmn_stream_t stream) {
-  if (args && g_lmn_rec) {
-    const lmn_wgrad_args_t copy = *args;
-    lmn_rec_push([copy, stream]() -> int { return lmn_conv_wgrad(&copy, stream); });
-  }
-  LMN_REQUIRE(args, "conv_wgrad: null args");
-  const lmn_wgrad_args_t& A = *args;
+// Geometry of one weight-gradient call: tile shape, K-split block count, reduction form.  ONE source of truth for the launch
+// (lmn_conv_wgrad) and for the description of its deferred reduction (lmn_conv_wgrad_job).
+struct WgGeom {
+  int NMT, NNT, gy, taps, blocks;   // cout x cin tiles per block, tile sets (grid.y), K-split blocks (grid.x)
+  int64_t per;                      // floats of one block partial
+  bool direct, v1, wave_staged;
+  size_t shmem;
+  int pm;
+};
+
+static int wgrad_setup(const lmn_wgrad_args_t& A, WgradParams& P, WgGeom& G) {
   LMN_REQUIRE(A.ksize == 1 || A.ksize == 3, "conv_wgrad: ksize %d", A.ksize);
   LMN_REQUIRE(A.stride == 1 || A.stride == 2, "conv_wgrad: stride %d", A.stride);
   LMN_REQUIRE(A.nsrc >= 1 && A.nsrc <= 3, "conv_wgrad: nsrc %d", A.nsrc);
@@ -2646,7 +2709,6 @@ int lmn_conv_wgrad(const lmn_wgrad_args_t* args, lmn_stream_t stream) {
   LMN_REQUIRE(A.mma_dtype == LMN_F32 || A.mma_dtype == LMN_BF16, "conv_wgrad: mma_dtype %d", A.mma_dtype);
   LMN_REQUIRE(A.act_dtype == LMN_F32 || (A.act_dtype == LMN_BF16 && A.mma_dtype == LMN_BF16),
               "conv_wgrad: act_dtype %d with mma_dtype %d", A.act_dtype, A.mma_dtype);
-  WgradParams P;
   P.a = A;
   P.NNTT = 0;
   P.Cin = 0;
@@ -2664,10 +2726,6 @@ int lmn_conv_wgrad(const lmn_wgrad_args_t* args, lmn_stream_t stream) {
     if (A.src[s].flags & LMN_SRC_DROP) P.inv_keep_src[s] = 1.f / (1.f - A.src[s].drop_p);
   }
   P.inv_keep_dy = (A.dy_flags & LMN_SRC_DROP) ? 1.f / (1.f - A.dy_p) : 1.f;
-  if (g_lmn_prof_on) {  // algorithmic cost: MACs of the layer shape; every source and dy read once
-    const double opix = (double)A.B * A.Hout * A.Wout, ipix = (double)A.B * A.Hin * A.Win;
-    lmn_prof_cost(2.0 * opix * (double)P.Cin * A.Cout * A.ksize * A.ksize, (A.act_dtype == LMN_BF16 ? 2.0 : 4.0) * (ipix * P.Cin + opix * A.Cout));
-  }
   P.NMTT = (A.Cout + 15) / 16;
   P.steps_per_img = (A.Hout * A.Wout + 3) / 4;
   LMN_REQUIRE((int64_t)A.B * P.steps_per_img < (1LL << 31), "conv_wgrad: too many pixels");
@@ -2687,18 +2745,18 @@ int lmn_conv_wgrad(const lmn_wgrad_args_t* args, lmn_stream_t stream) {
   const int taps = A.ksize * A.ksize;
   const int64_t per = (int64_t)taps * NMT * NNT * 256 + NMT * 16;
   // ---- tile geometry of the LDS-staged kernel
-  const lmn_wgrad_args_t& G = P.a;  // (flattened) geometry
+  const lmn_wgrad_args_t& Gm = P.a;  // (flattened) geometry
   // tile pixels: 256 for the 1x1 form, for one-tile blocks and on the small maps (fewer barriers and less halo per pixel:
   // -5..10 %), 128 where a 2x2-tile block would need 76 KB of LDS for it (+3 % there)
-  const bool v1c = wgrad_v1(A) && G.Wout >= 32 && (NMT * NNT == 4 || NMT * NNT == 1);  // V1 candidate (item counts checked below)
-  const int npmax = G.stride == 2 ? 64 : ((G.ksize == 1 || NMT * NNT == 1 || (G.Wout <= 32 && !v1c)) ? 256 : 128);
-  P.TW = G.Wout < (G.ksize == 1 ? npmax : 32) ? G.Wout : (G.ksize == 1 ? npmax : 32);
-  if (G.stride == 2 && P.TW > 16) P.TW = 16;
+  const bool v1c = wgrad_v1(A) && Gm.Wout >= 32 && (NMT * NNT == 4 || NMT * NNT == 1);  // V1 candidate (item counts checked below)
+  const int npmax = Gm.stride == 2 ? 64 : ((Gm.ksize == 1 || NMT * NNT == 1 || (Gm.Wout <= 32 && !v1c)) ? 256 : 128);
+  P.TW = Gm.Wout < (Gm.ksize == 1 ? npmax : 32) ? Gm.Wout : (Gm.ksize == 1 ? npmax : 32);
+  if (Gm.stride == 2 && P.TW > 16) P.TW = 16;
   P.TH = npmax / P.TW;
-  if (P.TH > G.Hout) P.TH = G.Hout;
+  if (P.TH > Gm.Hout) P.TH = Gm.Hout;
   if (P.TH < 1) P.TH = 1;
-  P.XH = (P.TH - 1) * G.stride + G.ksize;
-  P.XW = (P.TW - 1) * G.stride + G.ksize;
+  P.XH = (P.TH - 1) * Gm.stride + Gm.ksize;
+  P.XW = (P.TW - 1) * Gm.stride + Gm.ksize;
   // LDS planes [tile][pixel][CS]: the 4 pixels of a K step are CS*stride floats apart; 16 (stride 1) and 24
   // (stride 2: 48 = 16 mod 32 banks) keep the two 16-lane halves of a ds_read_b32 group on disjoint banks
   P.CSy = 16;
@@ -2707,8 +2765,8 @@ int lmn_conv_wgrad(const lmn_wgrad_args_t* args, lmn_stream_t stream) {
   const int pm = bf ? (A.act_dtype == LMN_BF16 ? 2 : 1) : 0;
   // bf16 planes: 16 bf16 = 8 dwords per pixel, +4: the lane groups q (pixels 4 apart) read disjoint bank ranges
   if (bf) P.CSy = P.CSx = 12;
-  P.tiles_x = (G.Wout + P.TW - 1) / P.TW;
-  P.tiles_y = (G.Hout + P.TH - 1) / P.TH;
+  P.tiles_x = (Gm.Wout + P.TW - 1) / P.TW;
+  P.tiles_y = (Gm.Hout + P.TH - 1) / P.TH;
   P.total_tiles = A.B * P.tiles_x * P.tiles_y;
   P.dbg = 0;
   LMN_REQUIRE(P.XH * P.XW < 65536 && P.TH * P.TW < 65536, "conv_wgrad: tile too large");
@@ -2735,6 +2793,13 @@ int lmn_conv_wgrad(const lmn_wgrad_args_t* args, lmn_stream_t stream) {
   const int64_t cap = btot / gy > 2 ? btot / gy : 2;
   if (blocks64 > cap) blocks64 = cap;
   if (blocks64 < 1) blocks64 = 1;
+  G.direct = A.ksize == 1 && A.stride == 1 && (int64_t)Gm.Hout * Gm.Wout >= 32;
+  if (G.direct) {  // direct (no LDS) kernels: K steps split over ~1024*4/gy waves, at least 16 steps per wave
+    const int64_t steps = ((int64_t)A.B * Gm.Hout * Gm.Wout + 3) / 4;
+    blocks64 = (steps + 63) / 64;
+    if (blocks64 > cap) blocks64 = cap;
+    if (blocks64 < 1) blocks64 = 1;
+  }
   // two-stage reduction when the caller's workspace holds every block partial; else LDS-reduced atomics with fewer blocks
   P.partial = nullptr;
   if (A.workspace && wgrad_two_stage(gy, blocks64, per) && (int64_t)gy * blocks64 * per <= A.workspace_floats) {
@@ -2742,10 +2807,78 @@ int lmn_conv_wgrad(const lmn_wgrad_args_t* args, lmn_stream_t stream) {
   } else if (blocks64 > 512 / gy && 512 / gy >= 2) {
     blocks64 = 512 / gy;  // atomics: fewer blocks
   }
-  const int blocks = (int)blocks64;
+  G.NMT = NMT; G.NNT = NNT; G.gy = gy; G.taps = taps; G.per = per; G.blocks = (int)blocks64;
+  G.v1 = v1; G.pm = pm; G.shmem = (size_t)lds_floats * 4;
+  // 1x1 data path: wave-staged chunks (wgrad_1x1w_kernel) except for bf16-stored operands without on-load transforms in
+  // one of the direct kernel's shapes, where one 2-byte load per lane and MFMA operand is faster (measured, level 0:
+  // 28 vs 40 us; with transforms 70 vs 63 us; fp32 storage: wave-staged -19 % over the 13 probe layers)
+  bool any_tf = (A.dy_flags & LMN_SRC_DROP) != 0;
+  for (int s = 0; s < A.nsrc; ++s) any_tf = any_tf || A.src[s].flags != 0 || A.src[s].scale != nullptr;
+  const bool old_shape = (NMT == 1 && NNT <= 4) || (NNT == 1 && NMT <= 4) || (NMT == 2 && NNT == 2);
+  G.wave_staged = !(pm == 2 && !any_tf && old_shape);
+  return 0;
+}
+
+int lmn_sizeof_reduce_job(void) { return (int)sizeof(lmn_reduce_job_t); }
+
+// Description of the reduction a deferred weight-gradient call (args->defer_reduce) leaves behind: `out->nblk == 0` when the call
+// reduces on its own (atomics: small totals, or no workspace).  Pure host arithmetic, nothing is launched.
+int lmn_conv_wgrad_job(const lmn_wgrad_args_t* args, lmn_reduce_job_t* out) {
+  LMN_REQUIRE(args && out, "conv_wgrad_job: null pointer");
+  WgradParams P;
+  WgGeom G;
+  const int rc = wgrad_setup(*args, P, G);
+  if (rc) return rc;
+  memset(out, 0, sizeof(*out));
+  if (!P.partial) return 0;
+  const lmn_wgrad_args_t& A = *args;
+  out->partial = P.partial;
+  out->nblk = G.blocks; out->per = (int32_t)G.per; out->gy = G.gy; out->nsets_n = P.nsets_n;
+  out->taps = G.taps; out->NMT = G.NMT; out->NNT = G.NNT; out->nsrc = A.nsrc;
+  out->Cout = A.Cout; out->Cin = P.Cin; out->NMTT = P.NMTT; out->NNTT = P.NNTT;
+  for (int s = 0; s < 3; ++s) {
+    out->srcC[s] = s < A.nsrc ? A.src[s].C : 0;
+    out->ntile_off[s] = P.ntile_off[s];
+    out->cbase[s] = P.cbase[s];
+    out->dW_src[s] = A.dW_src[s];
+  }
+  out->dW = A.dW; out->db = A.db; out->db2 = A.db2;
+  out->ksl = reduce_slices(G.blocks);
+  out->blocks_per_set = (int32_t)((G.per + 4096 / out->ksl - 1) / (4096 / out->ksl));
+  return 0;
+}
+
+int lmn_wgrad_reduce_batch(const lmn_reduce_job_t* jobs_dev, int njobs, int64_t total_blocks, lmn_stream_t stream) {
+  LMN_REC(lmn_wgrad_reduce_batch(jobs_dev, njobs, total_blocks, stream));
+  LMN_REQUIRE(jobs_dev && njobs > 0 && total_blocks > 0 && total_blocks < (1LL << 31), "wgrad_reduce_batch: bad job table");
+  LMN_LAUNCH(wgrad_reduce_batch_kernel, dim3((unsigned)total_blocks), dim3(1024), 0, (hipStream_t)stream, jobs_dev, njobs);
+  return lmn_launch_status("wgrad_reduce_batch");
+}
+
+int lmn_conv_wgrad(const lmn_wgrad_args_t* args, lmn_stream_t stream) {
+  if (args && g_lmn_rec) {
+    const lmn_wgrad_args_t copy = *args;
+    lmn_rec_push([copy, stream]() -> int { return lmn_conv_wgrad(&copy, stream); });
+  }
+  LMN_REQUIRE(args, "conv_wgrad: null args");
+  const lmn_wgrad_args_t& A = *args;
+  WgradParams P;
+  WgGeom G;
+  {
+    const int rc = wgrad_setup(A, P, G);
+    if (rc) return rc;
+  }
+  if (g_lmn_prof_on) {  // algorithmic cost: MACs of the layer shape; every source and dy read once
+    const double opix = (double)A.B * A.Hout * A.Wout, ipix = (double)A.B * A.Hin * A.Win;
+    lmn_prof_cost(2.0 * opix * (double)P.Cin * A.Cout * A.ksize * A.ksize, (A.act_dtype == LMN_BF16 ? 2.0 : 4.0) * (ipix * P.Cin + opix * A.Cout));
+  }
+  const int NMT = G.NMT, NNT = G.NNT, gy = G.gy, pm = G.pm, blocks = G.blocks;
+  const int64_t per = G.per;
+  const bool v1 = G.v1;
+  const bool reduce_now = P.partial && !A.defer_reduce;   // deferred: the caller batches the reductions (lmn_wgrad_reduce_batch)
+  const size_t shmem = G.shmem;
   hipStream_t st = (hipStream_t)stream;
   const dim3 grid(blocks, gy);
-  const size_t shmem = (size_t)lds_floats * 4;
 #define LMN_WG(T, M, N)                                                                                             \
   do {                                                                                                              \
     if (shmem > 64 * 1024) {                                                                                        \
@@ -2765,29 +2898,16 @@ int lmn_conv_wgrad(const lmn_wgrad_args_t* args, lmn_stream_t stream) {
     else if (pm == 1) LMN_LAUNCH((wgrad_lds_kernel<T, M, N, 1>), grid, dim3(256), shmem, st, P);            \
     else LMN_LAUNCH((wgrad_lds_kernel<T, M, N, 0>), grid, dim3(256), shmem, st, P);                         \
   wg_reduce_##T##M##N:                                                                                              \
-    if (P.partial) {                                                                                                \
+    if (reduce_now) {                                                                                               \
       const int ksl = reduce_slices(blocks);                                                                        \
       const int rb = (int)((per + 4096 / ksl - 1) / (4096 / ksl));                                                    \
       LMN_LAUNCH((wgrad_reduce_kernel<T, M, N>), dim3(rb, gy), dim3(1024), 0, st, P, blocks, ksl);          \
     }                                                                                                               \
   } while (0)
-  if (A.ksize == 1 && A.stride == 1 && (int64_t)G.Hout * G.Wout >= 32) {
-    // direct (no LDS) kernel: K steps split over ~1024*4/gy waves, at least 16 steps per wave
-    const int64_t steps = ((int64_t)A.B * G.Hout * G.Wout + 3) / 4;
-    int64_t nb = (steps + 63) / 64;  // >= 16 steps per wave
-    if (nb > cap) nb = cap;
-    if (nb < 1) nb = 1;
-    P.partial = nullptr;
-    if (A.workspace && wgrad_two_stage(gy, nb, per) && (int64_t)gy * nb * per <= A.workspace_floats) P.partial = A.workspace;
-    else if (nb > 512 / gy && 512 / gy >= 2) nb = 512 / gy;
+  if (G.direct) {
+    const int64_t nb = blocks;
     const dim3 dgrid((unsigned)nb, gy);
-    // data path: wave-staged chunks (wgrad_1x1w_kernel) except for bf16-stored operands without on-load transforms in
-    // one of the direct kernel's shapes, where one 2-byte load per lane and MFMA operand is faster (measured, level 0:
-    // 28 vs 40 us; with transforms 70 vs 63 us; fp32 storage: wave-staged -19 % over the 13 probe layers)
-    bool any_tf = (A.dy_flags & LMN_SRC_DROP) != 0;
-    for (int s = 0; s < A.nsrc; ++s) any_tf = any_tf || A.src[s].flags != 0 || A.src[s].scale != nullptr;
-    const bool old_shape = (NMT == 1 && NNT <= 4) || (NNT == 1 && NMT <= 4) || (NMT == 2 && NNT == 2);
-    const bool wave_staged = !(pm == 2 && !any_tf && old_shape);
+    const bool wave_staged = G.wave_staged;
 #define LMN_WD(M, N)                                                                                               \
   do {                                                                                                              \
     if (wave_staged) {                                                                                              \
@@ -2799,7 +2919,7 @@ int lmn_conv_wgrad(const lmn_wgrad_args_t* args, lmn_stream_t stream) {
     } else if (pm == 2) LMN_LAUNCH((wgrad_1x1_kernel<M, N, 2>), dgrid, dim3(256), 0, st, P);                \
     else if (pm == 1) LMN_LAUNCH((wgrad_1x1_kernel<M, N, 1>), dgrid, dim3(256), 0, st, P);                  \
     else LMN_LAUNCH((wgrad_1x1_kernel<M, N, 0>), dgrid, dim3(256), 0, st, P);                               \
-    if (P.partial) {                                                                                                \
+    if (reduce_now) {                                                                                               \
       const int ksl = reduce_slices((int)nb);                                                                       \
       const int rb = (int)((per + 4096 / ksl - 1) / (4096 / ksl));                                                    \
       LMN_LAUNCH((wgrad_reduce_kernel<1, M, N>), dim3(rb, gy), dim3(1024), 0, st, P, (int)nb, ksl);         \
@@ -2812,7 +2932,7 @@ int lmn_conv_wgrad(const lmn_wgrad_args_t* args, lmn_stream_t stream) {
     if (pm == 2) LMN_LAUNCH((wgrad_1x1w_kernel<M, N, 2>), dgrid, dim3(256), wsh, st, P);                    \
     else if (pm == 1) LMN_LAUNCH((wgrad_1x1w_kernel<M, N, 1>), dgrid, dim3(256), wsh, st, P);               \
     else LMN_LAUNCH((wgrad_1x1w_kernel<M, N, 0>), dgrid, dim3(256), wsh, st, P);                            \
-    if (P.partial) {                                                                                                \
+    if (reduce_now) {                                                                                               \
       const int ksl = reduce_slices((int)nb);                                                                       \
       const int rb = (int)((per + 4096 / ksl - 1) / (4096 / ksl));                                                    \
       LMN_LAUNCH((wgrad_reduce_kernel<1, M, N>), dim3(rb, gy), dim3(1024), 0, st, P, (int)nb, ksl);         \

@@ -154,6 +154,9 @@ class Engine:
         self.arena = None         # plan mode (LM_Net.enable_plans): bump arena all tensors of the pass come from
         self.planning = False     # a plan is being recorded: buffers come from the arena, no allocator stream bookkeeping
         self.alloc_floats = 0     # floats requested since begin_pass (sizes the arena during the eager warm-up steps)
+        # second stage of the weight gradients' K-split reductions batched per gradient bucket (LMN_DEFER_REDUCE=0: A/B runs)
+        self.defer_reduce = os.environ.get("LMN_DEFER_REDUCE", "1") != "0"
+        self.reduce_tabs = []     # device job tables of the batched reductions of the pass in flight (kept by recorded plans)
 
     def pm(self):
         """precision mode of the pass: 0 fp32, 1 bf16 MFMA operands on fp32 storage, 2 bf16 storage + bf16 operands."""
@@ -172,6 +175,8 @@ class Engine:
     def begin_pass(self, backward, device):
         _ENG[0] = self
         self.alloc_floats = 0
+        self.reduce_tabs = []
+        hip.wgrad_reduce_drop()
         hip._ALLOC[0] = self.alloc
         hip._STREAM[0] = None
         hip._STREAM[0] = hip._stream()          # one stream lookup per pass instead of one per launch
@@ -243,8 +248,11 @@ class Engine:
             dW = self.G[w_param]
         db = (self.G[b_param] if b_param is not None else None) if db is None else db
         cout = dW.shape[0] if dW is not None else kw["dW_src"][0].shape[0]
+        # second stage of the K-split reduction: deferred and batched per gradient bucket (flush_reduce) unless the caller
+        # reads the result right away
+        defer = self.defer_reduce and not explicit and not self.capturing   # (a capture cannot upload the job table)
         if not self.overlap_wgrad or self.capturing:
-            hip.conv_wgrad(srcs, dy, dW, db, B=B, Hin=Hin, Win=Win, Hout=Ho, Wout=Wo, Cout=cout, ksize=k, stride=s, **kw)
+            hip.conv_wgrad(srcs, dy, dW, db, B=B, Hin=Hin, Win=Win, Hout=Ho, Wout=Wo, Cout=cout, ksize=k, stride=s, defer=defer, **kw)
             return
         # Weight gradients feed nothing downstream in the backward chain: they run on a side stream and overlap the
         # data-gradient chain on the main stream (at batch 8 most kernels of levels 2-4 cannot fill 256 CUs alone).
@@ -257,11 +265,13 @@ class Engine:
         saved = hip._STREAM[0]
         hip._STREAM[0] = hip.C.c_void_p(side.cuda_stream)
         try:
-            hip.conv_wgrad(srcs, dy, dW, db, B=B, Hin=Hin, Win=Win, Hout=Ho, Wout=Wo, Cout=cout, ksize=k, stride=s, **kw)
+            ws = hip.conv_wgrad(srcs, dy, dW, db, B=B, Hin=Hin, Win=Win, Hout=Ho, Wout=Wo, Cout=cout, ksize=k, stride=s, defer=defer, **kw)
         finally:
             hip._STREAM[0] = saved
         if self.arena is None:          # caching-allocator tensors: keep them alive for the side stream
             d.record_stream(side)
+            if ws is not None:
+                ws.record_stream(side)
             for src in srcs:
                 self._t(src).record_stream(side)
                 if isinstance(src, dict) and src.get("scale") is not None:
@@ -298,8 +308,29 @@ class Engine:
         ent[1] = True
         return ent[0]
 
+    def flush_reduce(self, device):
+        """ONE launch per stream for the deferred K-split reductions (hip.conv_wgrad(defer=True)) of the weight gradients issued
+        from the current stream: on its weight-gradient stream, and on the stream itself where they ran there."""
+        cur = torch.cuda.current_stream(device)
+        tab = hip.wgrad_reduce_flush()
+        if tab is not None:
+            self.reduce_tabs.append(tab)
+        ent = self.sides.get(cur.cuda_stream)
+        if ent is not None and hip.wgrad_reduce_pending(ent[0].cuda_stream):
+            saved = hip._STREAM[0]
+            hip._STREAM[0] = hip.C.c_void_p(ent[0].cuda_stream)
+            try:
+                tab = hip.wgrad_reduce_flush()
+            finally:
+                hip._STREAM[0] = saved
+            if tab is not None:
+                self.reduce_tabs.append(tab)
+                if self.arena is None:
+                    tab.record_stream(ent[0])
+
     def join_side(self, device):
-        """Make the current stream wait for its weight-gradient stream."""
+        """Make the current stream wait for its weight-gradient stream (whose deferred reductions are launched first)."""
+        self.flush_reduce(device)
         cur = torch.cuda.current_stream(device)
         ent = self.sides.get(cur.cuda_stream)
         if ent is not None and ent[1]:
@@ -425,6 +456,23 @@ class Engine:
         hip.conv_pack(w1, 1, [c1], out=wp[n0 // h:(n0 + n1) // h], persistent=own)
         return wp
 
+    @staticmethod
+    def _pack2_t(w0, w1, cred0, cred1, rows, ref):
+        """Data-gradient operators of two 1x1 convs that share their input (rows = its channels), as ONE two-source conv:
+        dx = W0^T . dy0 + W1^T . dy1.  Each transposed operator is packed into its K-block range."""
+        n0 = hip.conv_pack_size(1, rows, [cred0])
+        n1 = hip.conv_pack_size(1, rows, [cred1])
+        plan = hip._PLAN[0]
+        own = plan is not None and isinstance(w0, torch.nn.Parameter) and isinstance(w1, torch.nn.Parameter)
+        if own:
+            wp = plan.buffer(("pack2t", w0.data_ptr(), w1.data_ptr(), rows, hip._MMA[0]), n0 + n1, ref.device)
+        else:
+            wp = _E(ref, n0 + n1)
+        h = 2 if hip._MMA[0] == hip.BF16 else 1
+        hip.conv_pack_t(w0, 1, 0, rows, out=wp[:n0 // h], cred=cred0, persistent=own)
+        hip.conv_pack_t(w1, 1, 0, rows, out=wp[n0 // h:(n0 + n1) // h], cred=cred1, persistent=own)
+        return wp
+
     def reparam_bwd(self, m, dy, cx, need_dx=True):
         if m.deploy:
             raise NotImplementedError("backward through a deployed (re-parameterised) ReparamConv is not supported; "
@@ -448,10 +496,7 @@ class Engine:
         u = _A(x, B, H, W, E)
         ds = _Z(x, B, E)
         self.conv_T(dy, pw.weight, u, Hin=H, Win=W, epilogue=hip.EP_SE_BWD, aux=pre, stats=ds, stats_mode=hip.STATS_EP)
-        dx_sc = None
-        if need_dx:
-            dx_sc = _A(x, B, H, W, Cin)
-            self.conv_T(dy, sc.weight, dx_sc, Hin=H, Win=W, rows=Cin)
+        # (the shortcut's data gradient W_sc^T . dy is the second source of the LAST conv of this function: no dx_sc tensor)
         # ---- SE backward
         dm = _E(x, B, E)
         if self.split_se:
@@ -515,8 +560,10 @@ class Engine:
             hip.copy2d(dWp, G[ec.weight], E, cw, Cin, cw)         # un-pad (layout copy)
         if not need_dx:
             return None
+        # dx = W_e^T . dz + W_sc^T . dy: one conv over two sources (the forward's expand + shortcut share x)
         dx = _A(x, B, H, W, Cin)
-        self.conv_T(dz, ec.weight, dx, Hin=H, Win=W, rows=Cin, residual=dx_sc)
+        wpt = self._pack2_t(ec.weight, sc.weight, E, self._c(dy), Cin, x)
+        hip.conv_fwd([dz, dy], wpt, dx, B=B, Hin=H, Win=W, Hout=H, Wout=W, Cout=Cin)
         return dx
 
     def stage_fwd(self, seq, x, cx):

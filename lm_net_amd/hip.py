@@ -19,7 +19,7 @@ ACT_NONE, ACT_HSWISH, ACT_GELU = 0, 1, 2
 STATS_NONE, STATS_SUM_SQ, STATS_EP = 0, 1, 2
 F32, BF16 = 0, 1            # matrix-core operand type of the dense contractions (LMN_F32 / LMN_BF16)
 _MMA = [F32]                # ... of the pass in flight (engine.begin_pass)
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 
 class SrcT(C.Structure):
@@ -56,13 +56,26 @@ class WgradArgs(C.Structure):
                 ("src", SrcT * 3), ("dy", C.c_void_p), ("dy_cstride", C.c_int32), ("dy_flags", C.c_int32),
                 ("dy_seed", C.c_uint32), ("dy_p", C.c_float), ("dW", C.c_void_p), ("db", C.c_void_p),
                 ("workspace", C.c_void_p), ("workspace_floats", C.c_int64), ("seed_ctr", C.c_void_p),
-                ("dW_src", C.c_void_p * 3), ("db2", C.c_void_p), ("mma_dtype", C.c_int32), ("act_dtype", C.c_int32)]
+                ("dW_src", C.c_void_p * 3), ("db2", C.c_void_p), ("mma_dtype", C.c_int32), ("act_dtype", C.c_int32),
+                ("defer_reduce", C.c_int32), ("_pad", C.c_int32)]
+
+
+class ReduceJob(C.Structure):
+    """Mirror of lmn_reduce_job_t (the deferred second stage of a weight gradient's K-split reduction)."""
+    _fields_ = [("partial", C.c_void_p), ("first_block", C.c_int64),
+                ("nblk", C.c_int32), ("per", C.c_int32), ("gy", C.c_int32), ("nsets_n", C.c_int32),
+                ("taps", C.c_int32), ("NMT", C.c_int32), ("NNT", C.c_int32), ("nsrc", C.c_int32),
+                ("Cout", C.c_int32), ("Cin", C.c_int32), ("NMTT", C.c_int32), ("NNTT", C.c_int32),
+                ("srcC", C.c_int32 * 3), ("ntile_off", C.c_int32 * 3), ("cbase", C.c_int32 * 3),
+                ("ksl", C.c_int32), ("blocks_per_set", C.c_int32), ("_pad", C.c_int32),
+                ("dW", C.c_void_p), ("dW_src", C.c_void_p * 3), ("db", C.c_void_p), ("db2", C.c_void_p)]
 
 
 # every symbol include/lmnet_hip.h declares (the CPU test suite checks the library exports all of them)
 SYMBOLS = [
     "lmn_abi_version", "lmn_sizeof_conv_args", "lmn_sizeof_src", "lmn_sizeof_wgrad_args", "lmn_last_error",
     "lmn_conv_pack_size", "lmn_conv_pack", "lmn_conv_pack_batch", "lmn_sizeof_pack_job", "lmn_conv_fwd", "lmn_conv_wgrad", "lmn_conv_wgrad_workspace",
+    "lmn_conv_wgrad_job", "lmn_wgrad_reduce_batch", "lmn_sizeof_reduce_job",
     "lmn_dw_stats", "lmn_dw_fwd", "lmn_dw_merge", "lmn_dw_finalize_merge", "lmn_dw_bwd_stats", "lmn_dw_bwd_coef", "lmn_dw_bwd", "lmn_dw_fwd_bn", "lmn_dw_bwd_bn",
     "lmn_se_fwd", "lmn_se_bwd", "lmn_se_bwd_dm", "lmn_se_bwd_params", "lmn_na_fwd", "lmn_na_bwd", "lmn_gattn_fwd", "lmn_gattn_bwd",
     "lmn_ln_fwd", "lmn_ln_bwd", "lmn_bnact_fwd", "lmn_bnact_bwd_stats", "lmn_bnact_bwd",
@@ -98,7 +111,7 @@ def load():
     if lib.lmn_abi_version() != ABI_VERSION:
         raise RuntimeError("lm_net_amd: ABI version mismatch")
     if (lib.lmn_sizeof_conv_args() != C.sizeof(ConvArgs) or lib.lmn_sizeof_src() != C.sizeof(SrcT)
-            or lib.lmn_sizeof_wgrad_args() != C.sizeof(WgradArgs)):
+            or lib.lmn_sizeof_wgrad_args() != C.sizeof(WgradArgs) or lib.lmn_sizeof_reduce_job() != C.sizeof(ReduceJob)):
         raise RuntimeError("lm_net_amd: argument struct layout differs between hip.py and lmnet_hip.h")
     _lib = lib
     return lib
@@ -310,17 +323,17 @@ def conv_pack(w, ksize, src_channels, out=None, persistent=False):
     return out
 
 
-def conv_pack_t(w, ksize, row_off=0, rows=None, out=None, cred=None):
+def conv_pack_t(w, ksize, row_off=0, rows=None, out=None, cred=None, persistent=False):
     """Pack the data-gradient operator of a forward weight [Cout, Cin(,k,k)]: rows = input channels
     [row_off, row_off+rows), reduction over Cout.  `rows` may exceed the weight's Cin and `cred` (channels of the dy
     operand) its Cout by the zero padding to a multiple of 4 (RGB input as NHWC4, 2-class head on 4 rows)."""
     cout, cin = w.shape[0], w.shape[1]
     rows = cin - row_off if rows is None else rows
     cred = cout if cred is None else cred
-    planned = _planned(w, out, False)
+    planned = _planned(w, out, persistent)
     dt = _MMA[0]
     if planned:
-        key = (w.data_ptr(), ksize, (cred,), 1, row_off, rows, dt)
+        key = (w.data_ptr(), ksize, (cred,), 1, row_off, rows, out.data_ptr() if out is not None else 0, dt)
         hit = _PLAN[0].lookup(key)
         if hit is not None:
             return hit
@@ -378,8 +391,10 @@ def conv_fwd(srcs, wpack, out, *, B, Hin, Win, Hout, Wout, Cout, ksize=1, stride
 
 
 def conv_wgrad(srcs, dy, dW, db, *, B, Hin, Win, Hout, Wout, Cout, ksize=1, stride=1, dy_flags=0, dy_seed=0, dy_p=0.0,
-               dW_src=None, db2=None):
-    """dW_src: optional list (one entry per source, None = use the columns of dW) of per-source gradient tensors."""
+               dW_src=None, db2=None, defer=False):
+    """dW_src: optional list (one entry per source, None = use the columns of dW) of per-source gradient tensors.
+    defer: leave the second stage of the K-split reduction to `wgrad_reduce_flush()` (one launch for all deferred calls of the
+    launch stream); the call then writes its block partials to a workspace of its own.  Returns that workspace (or None)."""
     a = WgradArgs()
     a.B, a.Hout, a.Wout, a.Hin, a.Win = B, Hout, Wout, Hin, Win
     a.ksize, a.stride, a.nsrc, a.Cout = ksize, stride, len(srcs), Cout
@@ -396,12 +411,69 @@ def conv_wgrad(srcs, dy, dW, db, *, B, Hin, Win, Hout, Wout, Cout, ksize=1, stri
     if dW_src is not None:
         for i, t in enumerate(dW_src):
             a.dW_src[i] = t.data_ptr() if t is not None else None
-    need = int(load().lmn_conv_wgrad_workspace(C.byref(a)))
-    if need > 0:
-        ws = _workspace(v.t.device, need)
-        a.workspace, a.workspace_floats = ws.data_ptr(), ws.numel()
+    lib = load()
+    need = int(lib.lmn_conv_wgrad_workspace(C.byref(a)))
+    ws = None
+    if need > 0 and defer:
+        # the call's own workspace, sized to the partials it will really write (lmn_conv_wgrad_workspace is the upper bound)
+        a.workspace, a.workspace_floats = 0x1000, need      # (any non-null pointer: the geometry query does not touch it)
+        job = ReduceJob()
+        _check(lib.lmn_conv_wgrad_job(C.byref(a), C.byref(job)), "conv_wgrad_job")
+        if job.nblk > 0:
+            nfl = job.gy * job.nblk * job.per
+            ws = (_ALLOC[0] or _default_alloc)(v.t.device, (nfl,))
+            a.workspace, a.workspace_floats = ws.data_ptr(), nfl
+            a.defer_reduce = 1
+            job.partial = ws.data_ptr()
+            key = _STREAM[0].value if _STREAM[0] is not None else 0
+            _RJOBS.setdefault(key, []).append((job, ws))
+        else:
+            a.workspace, a.workspace_floats = None, 0
+            need = 0
+    elif need > 0:
+        wsh = _workspace(v.t.device, need)
+        a.workspace, a.workspace_floats = wsh.data_ptr(), wsh.numel()
     a.seed_ctr = _SEED_CTR[0].data_ptr() if _SEED_CTR[0] is not None else None
-    _check(load().lmn_conv_wgrad(C.byref(a), _stream()), "conv_wgrad")
+    _check(lib.lmn_conv_wgrad(C.byref(a), _stream()), "conv_wgrad")
+    return ws
+
+
+_RJOBS = {}          # launch stream handle -> [(ReduceJob, workspace tensor)] deferred since the last flush on that stream
+_RTABLES = {}        # bytes of a job table -> its device copy (pointers repeat from step to step: no H2D copy per flush)
+
+
+def wgrad_reduce_pending(stream_key=None):
+    key = stream_key if stream_key is not None else (_STREAM[0].value if _STREAM[0] is not None else 0)
+    return len(_RJOBS.get(key, ()))
+
+
+def wgrad_reduce_flush():
+    """Sum the block partials of every deferred weight gradient of the CURRENT launch stream in one launch.  Returns the
+    device job table (the caller keeps it alive while a recorded plan references it) or None."""
+    key = _STREAM[0].value if _STREAM[0] is not None else 0
+    jobs = _RJOBS.pop(key, None)
+    if not jobs:
+        return None
+    arr = (ReduceJob * len(jobs))()
+    blk = 0
+    for i, (j, _) in enumerate(jobs):
+        j.first_block = blk
+        C.memmove(C.byref(arr[i]), C.byref(j), C.sizeof(ReduceJob))
+        blk += j.gy * j.blocks_per_set
+    raw = bytes(arr)
+    dev = jobs[0][1].device
+    tab = _RTABLES.get((dev, raw))
+    if tab is None:
+        if len(_RTABLES) > 4096:
+            _RTABLES.clear()
+        tab = _RTABLES[(dev, raw)] = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(dev)
+    _check(load().lmn_wgrad_reduce_batch(C.c_void_p(tab.data_ptr()), len(jobs), _i64(blk), _stream()), "wgrad_reduce_batch")
+    return tab
+
+
+def wgrad_reduce_drop():
+    """Forget deferred jobs (a pass that raised)."""
+    _RJOBS.clear()
 
 
 _ws_cache = {}

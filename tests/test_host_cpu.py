@@ -117,3 +117,32 @@ def test_pack_plan_records_once_and_drops_on_storage_change():
     w.data = torch.ones(4, 4)                     # storage replaced (model.to(), load via .data=)
     plan.refresh()
     assert not plan.jobs and not plan.fresh
+
+
+def test_wgrad_reduce_job_geometry_is_host_arithmetic():
+    """lmn_conv_wgrad_job (no GPU call): the deferred reduction it describes fits the workspace lmn_conv_wgrad_workspace asks
+    for, covers every cout x cin tile set, and small problems keep reducing by themselves (nblk == 0)."""
+    from lm_net_amd import hip
+    lib = hip.load()
+    assert lib.lmn_sizeof_reduce_job() == ctypes.sizeof(hip.ReduceJob)
+
+    def job(B, H, W, cin, cout, k):
+        a = hip.WgradArgs()
+        a.B, a.Hout, a.Wout, a.Hin, a.Win, a.ksize, a.stride, a.nsrc, a.Cout = B, H, W, H, W, k, 1, 1, cout
+        a.src[0].ptr, a.src[0].C, a.src[0].cstride = 0x10000, cin, cin
+        a.dy, a.dy_cstride, a.dW = 0x20000, cout, 0x30000
+        need = int(lib.lmn_conv_wgrad_workspace(ctypes.byref(a)))
+        a.workspace, a.workspace_floats, a.defer_reduce = 0x40000 if need else None, need, 1
+        j = hip.ReduceJob()
+        assert lib.lmn_conv_wgrad_job(ctypes.byref(a), ctypes.byref(j)) == 0
+        return need, j
+
+    for (B, H, W, cin, cout, k) in [(8, 352, 352, 12, 24, 1), (8, 176, 176, 72, 24, 3), (8, 44, 44, 192, 96, 1), (8, 22, 22, 372, 372, 3)]:
+        need, j = job(B, H, W, cin, cout, k)
+        assert need > 0 and j.nblk > 0
+        assert j.gy * j.nblk * j.per <= need
+        assert j.per == j.taps * j.NMT * j.NNT * 256 + j.NMT * 16 and j.taps == k * k
+        assert j.gy == -(-j.NMTT // j.NMT) * j.nsets_n and j.NMTT == -(-cout // 16) and j.NNTT == -(-cin // 16)
+        assert j.ksl in (1, 2, 4, 8, 16, 32, 64) and j.blocks_per_set * (4096 // j.ksl) >= j.per
+    need, j = job(1, 4, 4, 12, 12, 1)        # 16 pixels: one block, atomics
+    assert j.nblk == 0
