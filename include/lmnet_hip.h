@@ -265,15 +265,34 @@ int lmn_dw_stats(const void* x1, int B, int H, int W, int E, const float* w5, co
  * (training: A_b = gamma_b*rstd_b from lmn_dw_stats; eval/deploy: running stats, i.e. exactly
  * ReparamConv.get_equivalent_kernel_bias, core/modules.py:622-642).  Writes `pre` (the GELU
  * input) and accumulates gsum[B][E] += sum_hw gelu(pre) for the SE squeeze (modules.py:1030). */
+/* Squeeze-excite gate inside the depthwise forward (core/modules.py:1030-1036: s = Hardsigmoid(fc2(ReLU(fc1(mean_HW g))))):
+ * the block that completes an image's GELU sums (an arrival counter per image, `ticket` [B] zeroed by the caller) computes
+ * s[B][E] and hidden[B][R] there -- no lmn_se_fwd launch between the depthwise pass and the pointwise conv.  NULL: off.  */
+typedef struct {
+  uint32_t* ticket;
+  const float* w1; const float* b1; const float* w2; const float* b2;   /* fc1 [R][E], [R]; fc2 [E][R], [E] */
+  float* s; float* hidden;
+  float inv_hw;
+  int32_t R;
+} lmn_se_fuse_t;
+/* Squeeze-excite backward inside lmn_dw_bwd_stats: every block forms dm[b][its channels] = d(loss)/d(mean_HW g) from
+ * ds[B][E] (lmn_conv_fwd, LMN_EP_SE_BWD), the saved gate and hidden vectors (lmn_se_bwd_dm arithmetic; E*R MACs per block),
+ * the first block of an image writes dvec[B][E+R] for lmn_se_bwd_params.  NULL: dm comes from the caller.                */
+typedef struct {
+  const float* ds; const float* w1; const float* w2; const float* hidden;
+  float* dvec;
+  float inv_hw;
+  int32_t R;
+} lmn_se_bwd_t;
 int lmn_dw_fwd(const void* x1, void* pre, float* gsum, int B, int H, int W, int E, const float* keff,
-               const float* beff, int act_dtype, lmn_stream_t stream);
+               const float* beff, const lmn_se_fuse_t* se, int act_dtype, lmn_stream_t stream);
 /* lmn_dw_finalize_merge + lmn_dw_fwd in ONE launch (training): every wave forms the merged stencil of its channel pair from
  * the batch sums `stats` [4][2][E] and the four branch weights, the first block of a channel chunk writes mean / rstd / A
  * [4][E] and updates the running statistics.  Arguments as lmn_dw_finalize_merge; no keff / beff tensors exist.        */
 int lmn_dw_fwd_bn(const void* x1, void* pre, float* gsum, int B, int H, int W, int E, const float* stats, float count,
                   const float* const* gamma, const float* const* beta, float* const* running_mean, float* const* running_var,
                   const float* eps, const float* momentum, const float* w5, const float* w3, const float* wv, const float* wh,
-                  float* mean, float* rstd, float* A, int act_dtype, lmn_stream_t stream);
+                  float* mean, float* rstd, float* A, const lmn_se_fuse_t* se, int act_dtype, lmn_stream_t stream);
 /* builds keff/beff on the device from the four branch weights and per-branch affine (A_b, shift_b) */
 /* Training forward between lmn_dw_stats and lmn_dw_fwd, one launch: finalise the four branch BatchNorms from the
  * batch sums `stats` [4][2][E] (mean/rstd/A [4][E] out, running statistics updated with `momentum`, unbiased variance
@@ -290,7 +309,7 @@ int lmn_dw_merge(const float* w5, const float* w3, const float* wv, const float*
  * bstats[5][E] += (sum dpre, sum dpre*y_b for the 4 branches).                               */
 int lmn_dw_bwd_stats(const void* x1, const void* pre, const void* u, const float* s, const float* dm,
                      void* dpre, int B, int H, int W, int E, const float* w5, const float* w3, const float* wv,
-                     const float* wh, float* bstats, int act_dtype, lmn_stream_t stream);
+                     const float* wh, float* bstats, const lmn_se_bwd_t* seb, int act_dtype, lmn_stream_t stream);
 /* per-branch BatchNorm-backward coefficients from bstats (pass 1) and the forward statistics
  * mean/rstd/A ([4][E] each): dgamma_b += T_b, dbeta_b += S0, and f_b = cA*dpre + cC*y_b + cD
  * (batch_stats=0, i.e. eval-mode BN: cC = cD = 0).                                            */

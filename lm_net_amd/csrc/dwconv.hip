@@ -528,11 +528,13 @@ template <typename TA>
 __global__ __launch_bounds__(256) void dw_fwd_strip_kernel(const TA* __restrict__ x1, TA* __restrict__ pre,
                                                             float* __restrict__ gsum, int H, int W, int E,
                                                             const float* __restrict__ keff,
-                                                            const float* __restrict__ beff, const DwFin FN, int strips,
+                                                            const float* __restrict__ beff, const DwFin FN,
+                                                            const lmn_se_fuse_t SE, int strips,
                                                             int segs, int seg_rows, int chunks) {
   __shared__ __attribute__((aligned(16))) float XS[FS_XR * SW_XC * SW_CS];
   __shared__ __attribute__((aligned(16))) float OUT[SW_R * SW_FC * SW_CS];
   __shared__ float gs_s[SW_CH];
+  __shared__ int s_last;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   int lid = xcd_swizzle(blockIdx.x, gridDim.x);  // channel chunk fastest: siblings share cache lines and an L2
@@ -687,7 +689,44 @@ __global__ __launch_bounds__(256) void dw_fwd_strip_kernel(const TA* __restrict_
     if (lane == 63) { gs_s[wv * 2] = a; gs_s[wv * 2 + 1] = c; }
   }
   __syncthreads();  // the block's 8 channel sums leave as ONE atomic instruction (single-lane atomics per wave queue up in L2)
-  if (tid < SW_CH && ch0 + tid < E) atomicAdd(gsum + (int64_t)b * E + ch0 + tid, gs_s[tid]);
+  if (SE.ticket == nullptr) {
+    if (tid < SW_CH && ch0 + tid < E) atomicAdd(gsum + (int64_t)b * E + ch0 + tid, gs_s[tid]);
+    return;
+  }
+  // ---- squeeze-excite gate of image b by the block that completes its sums (lmn_se_fuse_t).  Hand-off: wave 0 adds this
+  // block's sums with RETURNING atomics -- a no-return add is acknowledged (vmcnt) before it is performed at the memory side,
+  // and under load a later reader saw the sum without it (one image's gate off by 5e-4, once in ~50 steps); the returned value
+  // arrives only after the add has been performed.  Then its lane 0 draws a ticket; the block that draws the last one reads
+  // the sums back with returning atomics too (performed where the adds were: no cache can hold an older value).
+  if (tid < 64) {
+    if (tid < SW_CH && ch0 + tid < E) {
+      const float old = __hip_atomic_fetch_add(gsum + (int64_t)b * E + ch0 + tid, gs_s[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      asm volatile("" :: "v"(old) : "memory");   // the add has returned: it is in the sum every later reader sees
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (tid == 0) s_last = atomicAdd(SE.ticket + b, 1u) == (unsigned)(strips * segs * chunks - 1) ? 1 : 0;
+  }
+  __syncthreads();
+  if (!s_last) return;
+  float* m = OUT;        // [E]
+  float* h = OUT + E;    // [R]   (E + R <= SW_R * SW_FC * SW_CS: checked on the host)
+  const int R = SE.R;
+  for (int e = tid; e < E; e += 256)
+    m[e] = __hip_atomic_fetch_add(gsum + (int64_t)b * E + e, 0.0f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) * SE.inv_hw;
+  __syncthreads();
+  for (int r = tid; r < R; r += 256) {
+    float a = SE.b1[r];
+    for (int e = 0; e < E; ++e) a += SE.w1[(int64_t)r * E + e] * m[e];
+    a = a > 0.f ? a : 0.f;
+    h[r] = a;
+    SE.hidden[(int64_t)b * R + r] = a;
+  }
+  __syncthreads();
+  for (int e = tid; e < E; e += 256) {
+    float a = SE.b2[e];
+    for (int r = 0; r < R; ++r) a += SE.w2[(int64_t)e * R + r] * h[r];
+    SE.s[(int64_t)b * E + e] = lmn_hsigmoid(a);
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -779,7 +818,8 @@ __global__ __launch_bounds__(256) void dw_stats_strip_kernel(
     const TA* __restrict__ x1, const TA* __restrict__ pre, const TA* __restrict__ u,
     const float* __restrict__ sgate, const float* __restrict__ dm, TA* __restrict__ dpre, int H, int W, int E,
     const float* __restrict__ w5, const float* __restrict__ w3, const float* __restrict__ wvv,
-    const float* __restrict__ whh, float* __restrict__ stats, int strips, int segs, int seg_rows, int chunks) {
+    const float* __restrict__ whh, float* __restrict__ stats, const lmn_se_bwd_t SB, int strips, int segs, int seg_rows,
+    int chunks) {
   constexpr int NS = MODE == 0 ? 8 : 5;
   constexpr int NAUX = MODE == 1 ? SW_R * SW_FC * SW_CS : 4;
   __shared__ __attribute__((aligned(16))) float XS[FS_XR * SW_XC * SW_CS];
@@ -806,7 +846,53 @@ __global__ __launch_bounds__(256) void dw_stats_strip_kernel(
   f32x2 sv = f32x2{0.f, 0.f}, dv = f32x2{0.f, 0.f};
   if (MODE == 1) {
     sv = f32x2{sgate[(int64_t)b * E + chs], sgate[(int64_t)b * E + chs + 1]};
-    dv = f32x2{dm[(int64_t)b * E + chs], dm[(int64_t)b * E + chs + 1]};
+    if (SB.ds) {
+      // squeeze-excite backward of image b (lmn_se_bwd_t, lmn_se_bwd_dm arithmetic), formed by every block for its own channels:
+      //   dt[e] = ds[b][e] * hardsigmoid'(.) (1/6 where 0 < s < 1);  da[r] = relu'(h[r]) * sum_e w2[e][r] * dt[e];
+      //   dm[e] = inv_hw * sum_r w1[r][e] * da[r]
+      const int R = SB.R;
+      float* dt = XS;            // [E]      (the staging ring is not in use yet)
+      float* da = XS + E;        // [R]
+      float* part = XS + E + R;  // [256]
+      const bool writer = chunk == 0 && strip == 0 && seg == 0;   // one block per image keeps dt / da for lmn_se_bwd_params
+      for (int e = tid; e < E; e += 256) {
+        const float g = sgate[(int64_t)b * E + e];
+        const float d = (g > 0.f && g < 1.f) ? SB.ds[(int64_t)b * E + e] * (1.f / 6.f) : 0.f;
+        dt[e] = d;
+        if (writer) SB.dvec[(int64_t)b * (E + R) + e] = d;
+      }
+      __syncthreads();
+      const int groups = R <= 256 ? 256 / R : 1;
+      for (int r0 = 0; r0 < R; r0 += 256) {
+        const int g = tid / R, r = r0 + (R <= 256 ? tid - g * R : tid);
+        float a = 0.f;
+        if (g < groups && r < R)
+          for (int e = g; e < E; e += groups) a += SB.w2[(int64_t)e * R + r] * dt[e];
+        part[tid] = a;
+        __syncthreads();
+        if (tid < R - r0 && tid < 256) {
+          float v = 0.f;
+          if (R <= 256) { for (int k = 0; k < groups; ++k) v += part[k * R + tid]; }
+          else v = part[tid];
+          const int rr = r0 + tid;
+          v = SB.hidden[(int64_t)b * R + rr] > 0.f ? v : 0.f;
+          da[rr] = v;
+          if (writer) SB.dvec[(int64_t)b * (E + R) + E + rr] = v;
+        }
+        __syncthreads();
+      }
+      float d2[2] = {0.f, 0.f};
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        float a = 0.f;
+        for (int r = 0; r < R; ++r) a += SB.w1[(int64_t)r * E + chs + k] * da[r];
+        d2[k] = a * SB.inv_hw;
+      }
+      dv = f32x2{d2[0], d2[1]};
+      __syncthreads();           // dt / da are consumed: the ring may be staged
+    } else {
+      dv = f32x2{dm[(int64_t)b * E + chs], dm[(int64_t)b * E + chs + 1]};
+    }
   }
   const int ys = seg * seg_rows, ye = min(ys + seg_rows, H);
   const int xs = strip * SW_FC;
@@ -1051,7 +1137,8 @@ static int strip_segments(int64_t blocks_per_seg, int H, int halo, int occ, int*
 template <int MODE>
 static int launch_dw_strip_stats(const void* x1, const void* pre, const void* u, const float* s, const float* dm,
                                  void* dpre, int B, int H, int W, int E, const float* w5, const float* w3,
-                                 const float* wv, const float* wh, float* stats, int act_dtype, hipStream_t st) {
+                                 const float* wv, const float* wh, float* stats, const lmn_se_bwd_t& sb, int act_dtype,
+                                 hipStream_t st) {
   LMN_REQUIRE((int64_t)(H + 8) * W * E * 4 < (1LL << 30), "dw statistics: one image (%d x %d x %d) must stay below 1 GiB", H, W, E);
   const int strips = lmn_cdiv(W, SW_FC), chunks = lmn_cdiv(E, SW_CH);
   int seg_rows;
@@ -1060,7 +1147,7 @@ static int launch_dw_strip_stats(const void* x1, const void* pre, const void* u,
   if (nblk >= (1LL << 31)) return -1;
   if (g_lmn_prof_on) lmn_prof_cost(2.0 * 42 * (double)B * H * W * E, (act_dtype == LMN_BF16 ? 2.0 : 4.0) * (MODE == 0 ? 1 : 4) * (double)B * H * W * E);
   LMN_ACT_DISPATCH(act_dtype, LMN_LAUNCH((dw_stats_strip_kernel<MODE, T>), dim3((unsigned)nblk), dim3(256), 0, st, (const T*)x1, (const T*)pre, (const T*)u, s, dm, (T*)dpre, H, W, E,
-                     w5, w3, wv, wh, stats, strips, segs, seg_rows, chunks));
+                     w5, w3, wv, wh, stats, sb, strips, segs, seg_rows, chunks));
   return 0;
 }
 
@@ -1073,9 +1160,20 @@ int lmn_dw_timing(unsigned long long* out, int n) {
 }
 #endif
 
+static int se_fuse_check(const lmn_se_fuse_t* se, lmn_se_fuse_t* out, int E, const char* what) {
+  memset(out, 0, sizeof(*out));
+  if (!se || !se->ticket) return 0;
+  LMN_REQUIRE(se->w1 && se->b1 && se->w2 && se->b2 && se->s && se->hidden && se->R > 0 && se->inv_hw > 0.f, "%s: squeeze-excite operands", what);
+  LMN_REQUIRE(E + se->R <= SW_R * SW_FC * SW_CS, "%s: E + R = %d exceeds the block's scratch", what, E + se->R);
+  *out = *se;
+  return 0;
+}
+
 int lmn_dw_fwd(const void* x1, void* pre, float* gsum, int B, int H, int W, int E, const float* keff,
-               const float* beff, int act_dtype, lmn_stream_t stream) {
-  LMN_REC(lmn_dw_fwd(x1, pre, gsum, B, H, W, E, keff, beff, act_dtype, stream));
+               const float* beff, const lmn_se_fuse_t* se, int act_dtype, lmn_stream_t stream) {
+  lmn_se_fuse_t sf;
+  { const int rc = se_fuse_check(se, &sf, E, "dw_fwd"); if (rc) return rc; }
+  if (g_lmn_rec) lmn_rec_push([=]() -> int { return lmn_dw_fwd(x1, pre, gsum, B, H, W, E, keff, beff, &sf, act_dtype, stream); });
   LMN_REQUIRE_DT(act_dtype, "dw_fwd");
   LMN_REQUIRE(x1 && pre && gsum && keff && beff, "dw_fwd: null pointer");
   LMN_REQUIRE(B > 0 && H > 0 && W > 0 && E > 0 && E % 4 == 0, "dw_fwd: E=%d must be a multiple of 4", E);
@@ -1088,15 +1186,17 @@ int lmn_dw_fwd(const void* x1, void* pre, float* gsum, int B, int H, int W, int 
   LMN_REQUIRE(nblk < (1LL << 31), "dw_fwd: grid too large");
   if (g_lmn_prof_on) lmn_prof_cost(2.0 * 25 * (double)B * H * W * E, (act_dtype == LMN_BF16 ? 2.0 : 4.0) * 2 * (double)B * H * W * E);
   LMN_ACT_DISPATCH(act_dtype, LMN_LAUNCH((dw_fwd_strip_kernel<T>), dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, (const T*)x1, (T*)pre, gsum, H, W, E, keff,
-                     beff, DwFin{}, strips, segs, seg_rows, chunks));
+                     beff, DwFin{}, sf, strips, segs, seg_rows, chunks));
   return lmn_launch_status("dw_fwd");
 }
 
 int lmn_dw_fwd_bn(const void* x1, void* pre, float* gsum, int B, int H, int W, int E, const float* stats, float count,
                   const float* const* gamma, const float* const* beta, float* const* running_mean, float* const* running_var,
                   const float* eps, const float* momentum, const float* w5, const float* w3, const float* wv, const float* wh,
-                  float* mean, float* rstd, float* A, int act_dtype, lmn_stream_t stream) {
+                  float* mean, float* rstd, float* A, const lmn_se_fuse_t* se, int act_dtype, lmn_stream_t stream) {
   LMN_REQUIRE_DT(act_dtype, "dw_fwd_bn");
+  lmn_se_fuse_t sf;
+  { const int rc = se_fuse_check(se, &sf, E, "dw_fwd_bn"); if (rc) return rc; }
   LMN_REQUIRE(x1 && pre && gsum && stats && gamma && beta && running_mean && running_var && eps && momentum && w5 && w3 && wv && wh &&
                   mean && rstd && A && count > 0.f, "dw_fwd_bn: bad argument");
   LMN_REQUIRE(B > 0 && H > 0 && W > 0 && E > 0 && E % 4 == 0, "dw_fwd_bn: E=%d must be a multiple of 4", E);
@@ -1117,7 +1217,7 @@ int lmn_dw_fwd_bn(const void* x1, void* pre, float* gsum, int B, int H, int W, i
   auto launch = [=]() -> int {
     if (g_lmn_prof_on) lmn_prof_cost(2.0 * 25 * (double)B * H * W * E, (act_dtype == LMN_BF16 ? 2.0 : 4.0) * 2 * (double)B * H * W * E);
     LMN_ACT_DISPATCH(act_dtype, LMN_LAUNCH((dw_fwd_strip_kernel<T>), dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, (const T*)x1, (T*)pre, gsum, H, W, E,
-                       (const float*)nullptr, (const float*)nullptr, fn, strips, segs, seg_rows, chunks));
+                       (const float*)nullptr, (const float*)nullptr, fn, sf, strips, segs, seg_rows, chunks));
     return lmn_launch_status("dw_fwd_bn");
   };
   if (g_lmn_rec) lmn_rec_push(launch);
@@ -1167,18 +1267,25 @@ int lmn_dw_stats(const void* x1, int B, int H, int W, int E, const float* w5, co
   LMN_REQUIRE_DT(act_dtype, "dw_stats");
   LMN_REQUIRE(x1 && w5 && w3 && wv && wh && stats, "dw_stats: null pointer");
   LMN_REQUIRE(B > 0 && H > 0 && W > 0 && E > 0 && E % 4 == 0, "dw_stats: E=%d must be a multiple of 4", E);
-  launch_dw_strip_stats<0>(x1, nullptr, nullptr, nullptr, nullptr, nullptr, B, H, W, E, w5, w3, wv, wh, stats, act_dtype, (hipStream_t)stream);
+  launch_dw_strip_stats<0>(x1, nullptr, nullptr, nullptr, nullptr, nullptr, B, H, W, E, w5, w3, wv, wh, stats, lmn_se_bwd_t{}, act_dtype, (hipStream_t)stream);
   return lmn_launch_status("dw_stats");
 }
 
 int lmn_dw_bwd_stats(const void* x1, const void* pre, const void* u, const float* s, const float* dm, void* dpre,
                      int B, int H, int W, int E, const float* w5, const float* w3, const float* wv, const float* wh,
-                     float* bstats, int act_dtype, lmn_stream_t stream) {
-  LMN_REC(lmn_dw_bwd_stats(x1, pre, u, s, dm, dpre, B, H, W, E, w5, w3, wv, wh, bstats, act_dtype, stream));
+                     float* bstats, const lmn_se_bwd_t* seb, int act_dtype, lmn_stream_t stream) {
+  lmn_se_bwd_t sb;
+  memset(&sb, 0, sizeof(sb));
+  if (seb && seb->ds) {
+    LMN_REQUIRE(seb->w1 && seb->w2 && seb->hidden && seb->dvec && seb->R > 0 && seb->inv_hw > 0.f, "dw_bwd_stats: squeeze-excite operands");
+    LMN_REQUIRE(E + seb->R + 256 <= FS_XR * SW_XC * SW_CS, "dw_bwd_stats: E + R = %d exceeds the block's scratch", E + seb->R);
+    sb = *seb;
+  }
+  if (g_lmn_rec) lmn_rec_push([=]() -> int { return lmn_dw_bwd_stats(x1, pre, u, s, dm, dpre, B, H, W, E, w5, w3, wv, wh, bstats, &sb, act_dtype, stream); });
   LMN_REQUIRE_DT(act_dtype, "dw_bwd_stats");
-  LMN_REQUIRE(x1 && pre && u && s && dm && dpre && w5 && w3 && wv && wh && bstats, "dw_bwd_stats: null pointer");
+  LMN_REQUIRE(x1 && pre && u && s && (dm || sb.ds) && dpre && w5 && w3 && wv && wh && bstats, "dw_bwd_stats: null pointer");
   LMN_REQUIRE(B > 0 && H > 0 && W > 0 && E > 0 && E % 4 == 0, "dw_bwd_stats: E=%d must be a multiple of 4", E);
-  launch_dw_strip_stats<1>(x1, pre, u, s, dm, dpre, B, H, W, E, w5, w3, wv, wh, bstats, act_dtype, (hipStream_t)stream);
+  launch_dw_strip_stats<1>(x1, pre, u, s, dm, dpre, B, H, W, E, w5, w3, wv, wh, bstats, sb, act_dtype, (hipStream_t)stream);
   return lmn_launch_status("dw_bwd_stats");
 }
 

@@ -147,6 +147,8 @@ class Engine:
         # depthwise backward in two halves (dx1 here, weight gradients on the side stream; LMN_DW_SPLIT=1)
         self.split_dw = os.environ.get("LMN_DW_SPLIT", "0") == "1"
         self.split_se = os.environ.get("LMN_SE_SPLIT", "1") != "0"   # SE backward in two launches (parameter gradients on the side stream)
+        # squeeze-excite gate / its backward formed inside the depthwise passes (no se_fwd / se_bwd_dm launches; LMN_FUSE_SE=0: A/B)
+        self.fuse_se = int(os.environ.get("LMN_FUSE_SE", "3"))      # bit 0: forward gate, bit 1: backward
         self.zpool_fwd, self.zpool_bwd = ZeroPool(), ZeroPool()
         self.packs_fwd, self.packs_bwd = hip.PackPlan(), hip.PackPlan()
         self.mma = hip.F32        # matrix-core operand type of the dense contractions of the pass (hip.F32 | hip.BF16)
@@ -156,6 +158,7 @@ class Engine:
         self.alloc_floats = 0     # floats requested since begin_pass (sizes the arena during the eager warm-up steps)
         # second stage of the weight gradients' K-split reductions batched per gradient bucket (LMN_DEFER_REDUCE=0: A/B runs)
         self.defer_reduce = os.environ.get("LMN_DEFER_REDUCE", "1") != "0"
+        self.debug_keep = None    # dict: reparam_bwd keeps clones of its intermediates per module (debug tools only)
         self.reduce_tabs = []     # device job tables of the batched reductions of the pass in flight (kept by recorded plans)
 
     def pm(self):
@@ -421,14 +424,18 @@ class Engine:
                 hip.dw_merge(*ws, bA, bshift, keff, beff)
         pre = _A(x, B, H, W, E)
         gsum = _Z(x, B, E)
-        if keff is None:
-            hip.dw_fwd_bn(x1, pre, gsum, st2, N, [b.bn for b in brs], ws, bmean, brstd, bA)
-        else:
-            hip.dw_fwd(x1, pre, gsum, keff, beff)
         se = m.se
         R = se.fc1.weight.shape[0]
         sgate, hid = _E(x, B, E), _E(x, B, R)
-        hip.se_fwd(gsum, 1.0 / (H * W), se.fc1.weight, se.fc1.bias, se.fc2.weight, se.fc2.bias, sgate, hid)
+        # the squeeze-excite gate is formed by the block of the depthwise pass that completes an image's sums (no launch)
+        sef = dict(ticket=_Z(x, B), fc1w=se.fc1.weight, fc1b=se.fc1.bias, fc2w=se.fc2.weight, fc2b=se.fc2.bias, s=sgate,
+                   hidden=hid, inv_hw=1.0 / (H * W)) if (self.fuse_se & 1) else None
+        if keff is None:
+            hip.dw_fwd_bn(x1, pre, gsum, st2, N, [b.bn for b in brs], ws, bmean, brstd, bA, se=sef)
+        else:
+            hip.dw_fwd(x1, pre, gsum, keff, beff, se=sef)
+        if sef is None:
+            hip.se_fwd(gsum, 1.0 / (H * W), se.fc1.weight, se.fc1.bias, se.fc2.weight, se.fc2.bias, sgate, hid)
         # pointwise(g*s) + shortcut(x): one conv over two sources
         wpw, wsc = m.pointwise_conv[0].weight, m.shortcut[0].weight
         wp3 = self._pack2(wpw, wsc, E, x.shape[-1], Cout, x)
@@ -498,8 +505,15 @@ class Engine:
         self.conv_T(dy, pw.weight, u, Hin=H, Win=W, epilogue=hip.EP_SE_BWD, aux=pre, stats=ds, stats_mode=hip.STATS_EP)
         # (the shortcut's data gradient W_sc^T . dy is the second source of the LAST conv of this function: no dx_sc tensor)
         # ---- SE backward
-        dm = _E(x, B, E)
-        if self.split_se:
+        dm = None
+        seb = None
+        if self.fuse_se & 2:
+            # dm is formed inside the depthwise statistics pass (every block for its own channels); parameter gradients on the
+            # weight-gradient stream once that pass has written dvec
+            dvec = _E(x, B, E + se.fc1.weight.shape[0])
+            seb = dict(ds=ds, fc1w=se.fc1.weight, fc2w=se.fc2.weight, hidden=S["hid"], dvec=dvec, inv_hw=1.0 / (H * W))
+        elif self.split_se:
+            dm = _E(x, B, E)
             # dm (critical path: it feeds the depthwise backward) here, the parameter gradients on the weight-gradient stream
             dvec = _E(x, B, E + se.fc1.weight.shape[0])
             hip.se_bwd_dm(ds, sgate, 1.0 / (H * W), se.fc1.weight, se.fc2.weight, S["hid"], dm, dvec)
@@ -507,6 +521,7 @@ class Engine:
             self.side_call(x, lambda: hip.se_bwd_params(dvec, gs_, 1.0 / (H * W), hid_, G[se.fc1.weight], G[se.fc1.bias],
                                                         G[se.fc2.weight], G[se.fc2.bias]), keep=(dvec, gs_, hid_))
         else:
+            dm = _E(x, B, E)
             hip.se_bwd(ds, S["gsum"], 1.0 / (H * W), se.fc1.weight, se.fc1.bias, se.fc2.weight, se.fc2.bias, S["hid"], dm,
                        G[se.fc1.weight], G[se.fc1.bias], G[se.fc2.weight], G[se.fc2.bias])
         # ---- A2 backward
@@ -514,7 +529,11 @@ class Engine:
         ws = [b.conv.weight for b in brs]
         dpre = _A(x, B, H, W, E)
         bst = _Z(x, 5, E)
-        hip.dw_bwd_stats(x1, pre, u, sgate, dm, dpre, *ws, bst)
+        hip.dw_bwd_stats(x1, pre, u, sgate, dm, dpre, *ws, bst, seb=seb)
+        if seb is not None:
+            gs_, hid_ = S["gsum"], S["hid"]
+            self.side_call(x, lambda: hip.se_bwd_params(dvec, gs_, 1.0 / (H * W), hid_, G[se.fc1.weight], G[se.fc1.bias],
+                                                        G[se.fc2.weight], G[se.fc2.bias]), keep=(dvec, gs_, hid_))
         dx1 = u  # reuse
         split = self.fuse_bn and self.split_dw and self.overlap_wgrad and not self.capturing
         if split:
@@ -538,6 +557,7 @@ class Engine:
         # pass 1 is statistics only (dh = dx1 * hswish'(h) is not written); pass 2 forms dh again from dx1 and turns it into
         # dz in the same epilogue: one E-wide write and one E-wide read fewer than writing dh in between
         st = _Z(x, STATS_REP, 2, E)
+        st_before = st.clone() if self.debug_keep is not None else None
         hip.conv_fwd([x], wpe, None, B=B, Hin=H, Win=W, Hout=H, Wout=W, Cout=E, bias=ec.bias, epilogue=hip.EP_BN_BWD1,
                      act=hip.ACT_HSWISH, p=(S["mean1"], S["rstd1"], ebn.weight, ebn.bias), aux=dx1, stats=st,
                      stats_mode=hip.STATS_EP, stats_rep=STATS_REP)
@@ -552,6 +572,9 @@ class Engine:
             hip.bn_bwd_coef(st, N, S["A1"], G[ebn.weight], G[ebn.bias], c1, c2, c3, self.training)
             hip.conv_fwd([x], wpe, dz, B=B, Hin=H, Win=W, Hout=H, Wout=W, Cout=E, bias=ec.bias, epilogue=hip.EP_BN_BWD2,
                          act=hip.ACT_HSWISH, p=(S["mean1"], S["rstd1"], c1, c2, c3, ebn.weight, ebn.bias), aux=dx1)
+        if self.debug_keep is not None:      # (tools/gpu_glitch_locate.py: intermediates of one block, cloned in stream order)
+            self.debug_keep[m] = dict(st0=st_before, wpe=wpe.clone(), dy=dy.clone(), u_dx1=dx1.clone(), st=st.clone(), dz=dz.clone(), bst=bst.clone(), ds=ds.clone(),
+                                      x=x.clone(), mean1=S["mean1"].clone(), rstd1=S["rstd1"].clone(), A1=S["A1"].clone())
         if cw == Cin:
             self.wgrad([x], dz, ec.weight, ec.bias, Hin=H, Win=W)
         else:

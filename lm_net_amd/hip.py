@@ -60,6 +60,30 @@ class WgradArgs(C.Structure):
                 ("defer_reduce", C.c_int32), ("_pad", C.c_int32)]
 
 
+class SeFuse(C.Structure):
+    """Mirror of lmn_se_fuse_t."""
+    _fields_ = [("ticket", C.c_void_p), ("w1", C.c_void_p), ("b1", C.c_void_p), ("w2", C.c_void_p), ("b2", C.c_void_p),
+                ("s", C.c_void_p), ("hidden", C.c_void_p), ("inv_hw", C.c_float), ("R", C.c_int32)]
+
+
+class SeBwd(C.Structure):
+    """Mirror of lmn_se_bwd_t."""
+    _fields_ = [("ds", C.c_void_p), ("w1", C.c_void_p), ("w2", C.c_void_p), ("hidden", C.c_void_p), ("dvec", C.c_void_p),
+                ("inv_hw", C.c_float), ("R", C.c_int32)]
+
+
+def _se_fuse(se):
+    """se: None | dict(ticket=[B] zeroed fp32/int32 tensor, fc1w, fc1b, fc2w, fc2b, s, hidden, inv_hw)"""
+    if se is None:
+        return None
+    f = SeFuse()
+    f.ticket = se["ticket"].data_ptr()
+    f.w1, f.b1, f.w2, f.b2 = (_p(se[k]).value for k in ("fc1w", "fc1b", "fc2w", "fc2b"))
+    f.s, f.hidden = _p(se["s"]).value, _p(se["hidden"]).value
+    f.inv_hw, f.R = float(se["inv_hw"]), se["fc1w"].shape[0]
+    return C.byref(f)
+
+
 class ReduceJob(C.Structure):
     """Mirror of lmn_reduce_job_t (the deferred second stage of a weight gradient's K-split reduction)."""
     _fields_ = [("partial", C.c_void_p), ("first_block", C.c_int64),
@@ -502,9 +526,10 @@ def dw_merge(w5, w3, wv, wh, A, shift, keff, beff):
                                _stream()), "dw_merge")
 
 
-def dw_fwd(x1, pre, gsum, keff, beff):
+def dw_fwd(x1, pre, gsum, keff, beff, se=None):
+    """se: squeeze-excite gate formed inside the pass (see _se_fuse), or None."""
     B, H, W, E = x1.shape
-    _check(load().lmn_dw_fwd(_pa(x1), _pa(pre), _p(gsum), B, H, W, E, _p(keff), _p(beff), _dt(x1, pre), _stream()), "dw_fwd")
+    _check(load().lmn_dw_fwd(_pa(x1), _pa(pre), _p(gsum), B, H, W, E, _p(keff), _p(beff), _se_fuse(se), _dt(x1, pre), _stream()), "dw_fwd")
 
 
 def dw_finalize_merge(stats, count, bns, ws, mean, rstd, A, keff, beff):
@@ -520,7 +545,7 @@ def dw_finalize_merge(stats, count, bns, ws, mean, rstd, A, keff, beff):
         "dw_finalize_merge")
 
 
-def dw_fwd_bn(x1, pre, gsum, stats, count, bns, ws, mean, rstd, A):
+def dw_fwd_bn(x1, pre, gsum, stats, count, bns, ws, mean, rstd, A, se=None):
     """dw_finalize_merge + dw_fwd in one launch (training): bns / ws as in dw_finalize_merge."""
     P4 = C.c_void_p * 4
     F4 = C.c_float * 4
@@ -530,7 +555,7 @@ def dw_fwd_bn(x1, pre, gsum, stats, count, bns, ws, mean, rstd, A):
         P4(*[b.bias.data_ptr() for b in bns]), P4(*[b.running_mean.data_ptr() for b in bns]),
         P4(*[b.running_var.data_ptr() for b in bns]), F4(*[b.eps for b in bns]),
         F4(*[(b.momentum if b.momentum is not None else 0.1) for b in bns]), _p(ws[0]), _p(ws[1]), _p(ws[2]), _p(ws[3]),
-        _p(mean), _p(rstd), _p(A), _dt(x1, pre), _stream()), "dw_fwd_bn")
+        _p(mean), _p(rstd), _p(A), _se_fuse(se), _dt(x1, pre), _stream()), "dw_fwd_bn")
 
 
 def dw_bwd_bn(x1, dpre, dx1, w5, w3, wv, wh, bstats, mean, rstd, A, count, batch_stats, dgs, dbs, dw5, dw3, dwv, dwh, part=0):
@@ -543,10 +568,17 @@ def dw_bwd_bn(x1, dpre, dx1, w5, w3, wv, wh, bstats, mean, rstd, A, count, batch
                                 _stream()), "dw_bwd_bn")
 
 
-def dw_bwd_stats(x1, pre, u, s, dm, dpre, w5, w3, wv, wh, bstats):
+def dw_bwd_stats(x1, pre, u, s, dm, dpre, w5, w3, wv, wh, bstats, seb=None):
+    """seb: dict(ds, fc1w, fc2w, hidden, dvec, inv_hw) -- the squeeze-excite backward formed inside the pass (dm may be None)."""
     B, H, W, E = x1.shape
+    sb = None
+    if seb is not None:
+        f = SeBwd()
+        f.ds, f.w1, f.w2, f.hidden, f.dvec = (_p(seb[k]).value for k in ("ds", "fc1w", "fc2w", "hidden", "dvec"))
+        f.inv_hw, f.R = float(seb["inv_hw"]), seb["fc1w"].shape[0]
+        sb = C.byref(f)
     _check(load().lmn_dw_bwd_stats(_pa(x1), _pa(pre), _pa(u), _p(s), _p(dm), _pa(dpre), B, H, W, E, _p(w5), _p(w3), _p(wv),
-                                   _p(wh), _p(bstats), _dt(x1, pre, u, dpre), _stream()), "dw_bwd_stats")
+                                   _p(wh), _p(bstats), sb, _dt(x1, pre, u, dpre), _stream()), "dw_bwd_stats")
 
 
 def dw_bwd_coef(bstats, mean, rstd, A, count, batch_stats, cA, cC, cD, dgs, dbs):

@@ -292,6 +292,18 @@ def check_dw():
         hip.dw_fwd(x1d, pre, gsum, keff, beff)
         rows.append(("dw_fwd pre" + tag, rel(nchw(pre), pre_ref), TOL))
         rows.append(("dw_fwd gsum" + tag, rel(gsum, gelu(pre_ref).sum((2, 3)).detach()), 2e-4))
+        # --- squeeze-excite gate formed inside the pass (arrival counter per image) == lmn_se_fwd on the finished sums
+        Rr = max(E // 4, 1)
+        fw1, fb1 = dev(R(Rr, E, seed=101, scale=0.4)), dev(R(Rr, seed=102))
+        fw2, fb2 = dev(R(E, Rr, seed=103, scale=0.8)), dev(R(E, seed=104))
+        s_sep, h_sep = torch.empty(B, E, device=DEV), torch.empty(B, Rr, device=DEV)
+        hip.se_fwd(gsum, 1.0 / (H * W), fw1, fb1, fw2, fb2, s_sep, h_sep)
+        for rep in range(3):      # (repeated: the hand-off must hold whichever block arrives last)
+            pre_f = torch.full((B, H, W, E), float("nan"), device=DEV); gs_f = torch.zeros(B, E, device=DEV)
+            s_f, h_f = torch.full((B, E), float("nan"), device=DEV), torch.full((B, Rr), float("nan"), device=DEV)
+            hip.dw_fwd(x1d, pre_f, gs_f, keff, beff, se=dict(ticket=torch.zeros(B, device=DEV), fc1w=fw1, fc1b=fb1, fc2w=fw2,
+                                                             fc2b=fb2, s=s_f, hidden=h_f, inv_hw=1.0 / (H * W)))
+            rows.append(("dw_fwd + fused SE gate (run %d)" % rep + tag, max(rel(s_f, s_sep), rel(h_f, h_sep), rel(pre_f, pre)), 2e-5))
         # --- backward: dpre = (u*s + dm) * gelu'(pre)
         u = R(B, E, H, W, seed=70)
         s = R(B, E, seed=71).abs()
@@ -307,6 +319,16 @@ def check_dw():
         rows.append(("dw_bwd_stats dpre" + tag, rel(nchw(dpre), dpre_ref), TOL))
         bref = torch.stack([dpre_ref.sum((0, 2, 3))] + [(dpre_ref * y.detach()).sum((0, 2, 3)) for y in ys])
         rows.append(("dw_bwd_stats sums" + tag, rel(bstats, bref), 2e-4))
+        # --- squeeze-excite backward formed inside the pass == lmn_se_bwd_dm feeding the plain pass
+        ds_t = dev(R(B, E, seed=105))
+        dm_sep, dvec_sep = torch.empty(B, E, device=DEV), torch.empty(B, E + Rr, device=DEV)
+        hip.se_bwd_dm(ds_t, s_sep, 1.0 / (H * W), fw1, fw2, h_sep, dm_sep, dvec_sep)
+        dpre_s, bst_s = torch.full((B, H, W, E), float("nan"), device=DEV), torch.zeros(5, E, device=DEV)
+        hip.dw_bwd_stats(x1d, nhwc(pre_ref.detach()), nhwc(u), s_sep, dm_sep, dpre_s, *wd, bst_s)
+        dpre_f, bst_f, dvec_f = torch.full((B, H, W, E), float("nan"), device=DEV), torch.zeros(5, E, device=DEV), torch.full((B, E + Rr), float("nan"), device=DEV)
+        hip.dw_bwd_stats(x1d, nhwc(pre_ref.detach()), nhwc(u), s_sep, None, dpre_f, *wd, bst_f,
+                         seb=dict(ds=ds_t, fc1w=fw1, fc2w=fw2, hidden=h_sep, dvec=dvec_f, inv_hw=1.0 / (H * W)))
+        rows.append(("dw_bwd_stats + fused SE backward" + tag, max(rel(dpre_f, dpre_s), rel(bst_f, bst_s), rel(dvec_f, dvec_sep)), 2e-5))
         # coefficients from the exact fp64 sums: f_b = A_b dpre + C_b y_b + D_b ; dgamma_b, dbeta_b
         cA, cC, cD = (torch.empty(4, E, device=DEV) for _ in range(3))
         dgs = [torch.zeros(E, device=DEV) for _ in range(4)]

@@ -397,8 +397,13 @@ def test_plan_mode_matches_host_launches():
             (m(x) * G).sum().backward()
     gmax = max(float(p.grad.abs().max()) for p in c.parameters())
 
-    def same(u, v):     # float-atomic noise only (pre-BatchNorm biases have an exact gradient of 0: absolute scale)
-        return rel_err(u, v) < 2e-4 or float((u - v).abs().max()) < 1e-5 * gmax
+    def same(u, v):
+        # float-atomic noise (pre-BatchNorm biases have an exact gradient of 0: absolute scale) -- and one legitimate two-valued
+        # outcome: Hardswish' jumps by 1/2 at |h| = 3 (ATen's hardswish_backward likewise), and for these weights / this input
+        # one pre-activation of dconv4.0 (pixel 5012, channel 5) lies within 3e-6 of the kink, so the last bits of the batch
+        # statistics (summed in arrival order) decide its branch: every gradient downstream then moves by 4e-4 .. 1e-3
+        # (tools/gpu_glitch_locate.py).  A wrong coefficient or a stale buffer in a replay shows at the 1e-1 level.
+        return rel_err(u, v) < 2e-3 or float((u - v).abs().max()) < 1e-5 * gmax
 
     for (k, pc), (_, pd) in zip(c.named_parameters(), d.named_parameters()):
         assert same(pd.grad, pc.grad), k

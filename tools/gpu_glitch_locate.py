@@ -1,0 +1,79 @@
+"""Two identical eager models stepped back to back without synchronisation; on a gradient mismatch report the first forward
+stage (taps) at which the two passes differ."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import torch
+from helpers import rel_err, no_dropout
+from tools.detweights import det_input, fill_module
+from lm_net_amd import LM_Net
+
+def net(seed):
+    m = LM_Net(3, 2); fill_module(m, seed); no_dropout(m)
+    m = m.cuda().train(); m._keep_taps = True
+    return m
+
+x = det_input((2, 3, 64, 96), "plan/x").cuda()
+G = det_input((2, 2, 64, 96), "plan/G").cuda()
+c, d = net(17), net(17)
+c._engine.debug_keep, d._engine.debug_keep = {}, {}
+ORDER = ["x1", "x2", "x3", "x4", "x5", "xs1", "xs2", "xs3", "xs4", "x46", "x37", "x28", "x19", "x6", "x7", "x8", "x9"]
+for it in range(40):
+    outs, taps = [], []
+    for m in (c, d):
+        for p in m.parameters(): p.grad = None
+        o = m(x)
+        taps.append({k: v.detach().clone() for k, v in m._taps.items()})
+        outs.append(o.detach().clone())
+        (o * G).sum().backward()
+    gmax = max(float(p.grad.abs().max()) for p in c.parameters())
+    nb = sum(1 for (k, pc), (_, pd) in zip(c.named_parameters(), d.named_parameters())
+             if rel_err(pd.grad, pc.grad) >= 2e-4 and float((pd.grad - pc.grad).abs().max()) >= 1e-5 * gmax)
+    fw = rel_err(outs[1], outs[0])
+    if it == 0:
+        ref = {k: p.grad.detach().clone() for k, p in c.named_parameters()}
+    if nb or fw > 1e-5:
+        for name, m in (("c", c), ("d", d)):
+            w = max((rel_err(p.grad, ref[k]), k) for k, p in m.named_parameters() if k.startswith("up4."))
+            print("   model %s vs iteration-0 reference: up4 worst %.2e" % (name, w[0]))
+        kc, kd = c._engine.debug_keep[c.dconv4[0]], d._engine.debug_keep[d.dconv4[0]]
+        print("   st before the statistics pass: |c| %.3e |d| %.3e ; nonzero entries c %d d %d" % (float(kc["st0"].abs().max()), float(kd["st0"].abs().max()),
+              int((kc["st0"] != 0).sum()), int((kd["st0"] != 0).sum())))
+        dd = (kd["st"] - kc["st"]).flatten(); print("   st diff nonzero at", [int(i) for i in (dd.abs() > 1e-3 * float(kc["st"].abs().max())).nonzero().flatten()[:20]], "of", dd.numel())
+        sc_, sd_ = kc["st"].view(16, 2, -1), kd["st"].view(16, 2, -1)
+        print("   S0[:, 5] good:", [round(float(v), 3) for v in sc_[:, 0, 5]])
+        print("   S0[:, 5] bad :", [round(float(v), 3) for v in sd_[:, 0, 5]])
+        print("   S1[:, 5] good:", [round(float(v), 3) for v in sc_[:, 1, 5]])
+        print("   S1[:, 5] bad :", [round(float(v), 3) for v in sd_[:, 1, 5]])
+        mod = d.dconv4[0]
+        W_, b_ = mod.expand_conv[0].weight.detach().double().view(24, 12), mod.expand_conv[0].bias.detach().double()
+        for nm, kk in (("good", kc), ("bad", kd)):
+            z = kk["x"].double() @ W_.t() + b_
+            h = mod.expand_conv[1].weight.detach().double() * ((z - kk["mean1"].double()) * kk["rstd1"].double()) + mod.expand_conv[1].bias.detach().double()
+            dist = (h.abs() - 3.0).abs()
+            i = int(dist[..., 5].argmin())
+            print("   %s: closest pre-activation of channel 5 to the hardswish kinks: |h| - 3 = %.3e at pixel %d (tile %d); over all channels min %.3e" % (
+                nm, float((h.abs() - 3.0)[..., 5].flatten()[i]), i, i // 128, float(dist.min())))
+        dxd = (kd["u_dx1"] - kc["u_dx1"]).abs(); print("   dx1 max abs diff %.3e at flat index %d of %d" % (float(dxd.max()), int(dxd.argmax()), dxd.numel()))
+        for k in kc:
+            print("   dconv4.0 intermediate %-6s rel %.2e" % (k, rel_err(kd[k], kc[k])))
+        kc, kd = c._engine.debug_keep[c.dconv4[1]], d._engine.debug_keep[d.dconv4[1]]
+        for k in kc:
+            print("   dconv4.1 intermediate %-6s rel %.2e" % (k, rel_err(kd[k], kc[k])))
+        bad = d if max(rel_err(p.grad, ref[k]) for k, p in d.named_parameters() if k.startswith("up4.")) > 1e-4 else c
+        for k, p in bad.named_parameters():
+            if k.startswith("dconv4."):
+                print("      %-44s %.2e   |g| %.3e" % (k, rel_err(p.grad, ref[k]), float(ref[k].abs().max())))
+        print("it %d: %d gradient offenders, logits rel %.2e" % (it, nb, fw))
+        from lm_net_amd.LM_Net import BACKWARD_ORDER
+        for blk in BACKWARD_ORDER:
+            ps = [(k, rel_err(pd.grad, pc.grad)) for (k, pc), (_, pd) in zip(c.named_parameters(), d.named_parameters()) if k.startswith(blk + ".")]
+            print("   %-13s worst %.2e  median %.2e  n=%d   %s" % (blk, max(e for _, e in ps), sorted(e for _, e in ps)[len(ps) // 2], len(ps),
+                                                                  max(ps, key=lambda t: t[1])[0]))
+        # running statistics of the two models
+        for (k, bc), (_, bd) in zip(c.named_buffers(), d.named_buffers()):
+            if "running" in k and rel_err(bd, bc) > 1e-5:
+                print("   buffer", k, "%.2e" % rel_err(bd, bc)); break
+        break
+else:
+    print("no glitch in 40 iterations")
