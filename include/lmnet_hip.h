@@ -249,6 +249,18 @@ typedef struct {
   float* db2;
 } lmn_reduce_job_t;
 int lmn_sizeof_reduce_job(void);
+/* ReparamConv backward on the z-path (lmn_dw_pre_t): the BatchNorm backward of the expand conv (core/modules.py:537-539, 587)
+ * folded into weights.  From hstats [2][E] = (sum dh, sum dh * z) (lmn_dw_bwd_bn) and the forward's mean / rstd / A it forms
+ *   dz = a * dh + b * z + c   (a = A, b = -A T rstd / N, c = -A S0 / N - b mean, T = (S1 - mean S0) rstd; eval-mode BN: b = c = 0)
+ * writes coef [3][E] = (a, b, c) for the weight-gradient side (lmn_affine2), adds dgamma += T, dbeta += S0, and -- since
+ * z = W_e x + b_e -- packs the block's whole data gradient as ONE three-source 1x1 conv for lmn_conv_fwd:
+ *   dx = [W_e^T diag(a)] dh + [W_e^T diag(b) W_e] x + W_sc^T dy + kbias,   kbias = W_e^T (b * b_e + c)
+ * wpack: lmn_conv_pack_size(1, rows, {E, rows, cred}) floats; rows / cred = channels of x / dy (>= the weights' cin_w / cout_w,
+ * zero-padded operators).  w_expand [E][cin_w], w_shortcut [cout_w][cin_w] in torch layout.                                    */
+int lmn_reparam_fold(const float* hstats, const float* mean, const float* rstd, const float* A, float count, int batch_stats,
+                     const float* w_expand, const float* b_expand, const float* w_shortcut, int E, int rows, int cin_w, int cred,
+                     int cout_w, float* wpack, float* kbias, float* coef, float* dgamma, float* dbeta, int dtype,
+                     lmn_stream_t stream);
 int lmn_conv_wgrad_job(const lmn_wgrad_args_t* args, lmn_reduce_job_t* out);
 int lmn_wgrad_reduce_batch(const lmn_reduce_job_t* jobs_dev, int njobs, int64_t total_blocks, lmn_stream_t stream);
 
@@ -257,10 +269,22 @@ int lmn_wgrad_reduce_batch(const lmn_reduce_job_t* jobs_dev, int njobs, int64_t 
  * 1x3 (zero pad k/2, no bias), each followed by its own BatchNorm, summed, then GELU
  * (core/modules.py:548-574, 592-597).  Weight pointers use torch layouts [E][1][kh][kw].
  * ------------------------------------------------------------------------------------------ */
+/* z-path of ReparamConv (core/modules.py:587, 592-597): the tensor handed to the depthwise kernels is z, the output of the
+ * expand conv BEFORE its BatchNorm and Hardswish; x1 = Hardswish(A * z + shift) is formed when the kernels stage their rows
+ * (once per staged element, zero padding applied after it).  The training forward then needs no statistics-only conv over the
+ * expand conv's input -- its batch sums come out of the one pass that writes z (lmn_conv_fwd: LMN_STATS_SUM_SQ with `out`) and
+ * lmn_dw_stats finalises them (fin.mode = LMN_FIN_BN: A / shift formed per block, the first block of a channel chunk writes
+ * mean / rstd / A / shift and blends the running statistics) -- and the backward forms dh = dx1 * Hardswish'(A z + shift) and
+ * its BatchNorm-backward sums where dx1 leaves lmn_dw_bwd_bn.  NULL / A == NULL and fin.mode == NONE: the tensor holds x1.   */
+typedef struct {
+  const float* A;
+  const float* shift;
+  lmn_bn_fin_t fin;   /* lmn_dw_stats only */
+} lmn_dw_pre_t;
 /* batch statistics of the four branch outputs: stats[4][2][E] += (sum y_b, sum y_b^2), b=0..3
  * in the order large(5x5), square(3x3), ver(3x1), hor(1x3); each [2][E] row pair feeds lmn_bn_finalize. */
 int lmn_dw_stats(const void* x1, int B, int H, int W, int E, const float* w5, const float* w3, const float* wv,
-                 const float* wh, float* stats, int act_dtype, lmn_stream_t stream);
+                 const float* wh, float* stats, const lmn_dw_pre_t* zpre, int act_dtype, lmn_stream_t stream);
 /* pre = sum_b A_b * conv_b(x1) + bias  expressed as ONE merged 5x5 stencil keff[E][25] + beff[E]
  * (training: A_b = gamma_b*rstd_b from lmn_dw_stats; eval/deploy: running stats, i.e. exactly
  * ReparamConv.get_equivalent_kernel_bias, core/modules.py:622-642).  Writes `pre` (the GELU
@@ -285,14 +309,15 @@ typedef struct {
   int32_t R;
 } lmn_se_bwd_t;
 int lmn_dw_fwd(const void* x1, void* pre, float* gsum, int B, int H, int W, int E, const float* keff,
-               const float* beff, const lmn_se_fuse_t* se, int act_dtype, lmn_stream_t stream);
+               const float* beff, const lmn_se_fuse_t* se, const lmn_dw_pre_t* zpre, int act_dtype, lmn_stream_t stream);
 /* lmn_dw_finalize_merge + lmn_dw_fwd in ONE launch (training): every wave forms the merged stencil of its channel pair from
  * the batch sums `stats` [4][2][E] and the four branch weights, the first block of a channel chunk writes mean / rstd / A
  * [4][E] and updates the running statistics.  Arguments as lmn_dw_finalize_merge; no keff / beff tensors exist.        */
 int lmn_dw_fwd_bn(const void* x1, void* pre, float* gsum, int B, int H, int W, int E, const float* stats, float count,
                   const float* const* gamma, const float* const* beta, float* const* running_mean, float* const* running_var,
                   const float* eps, const float* momentum, const float* w5, const float* w3, const float* wv, const float* wh,
-                  float* mean, float* rstd, float* A, const lmn_se_fuse_t* se, int act_dtype, lmn_stream_t stream);
+                  float* mean, float* rstd, float* A, const lmn_se_fuse_t* se, const lmn_dw_pre_t* zpre, int act_dtype,
+                  lmn_stream_t stream);
 /* builds keff/beff on the device from the four branch weights and per-branch affine (A_b, shift_b) */
 /* Training forward between lmn_dw_stats and lmn_dw_fwd, one launch: finalise the four branch BatchNorms from the
  * batch sums `stats` [4][2][E] (mean/rstd/A [4][E] out, running statistics updated with `momentum`, unbiased variance
@@ -309,7 +334,8 @@ int lmn_dw_merge(const float* w5, const float* w3, const float* wv, const float*
  * bstats[5][E] += (sum dpre, sum dpre*y_b for the 4 branches).                               */
 int lmn_dw_bwd_stats(const void* x1, const void* pre, const void* u, const float* s, const float* dm,
                      void* dpre, int B, int H, int W, int E, const float* w5, const float* w3, const float* wv,
-                     const float* wh, float* bstats, const lmn_se_bwd_t* seb, int act_dtype, lmn_stream_t stream);
+                     const float* wh, float* bstats, const lmn_se_bwd_t* seb, const lmn_dw_pre_t* zpre, int act_dtype,
+                     lmn_stream_t stream);
 /* per-branch BatchNorm-backward coefficients from bstats (pass 1) and the forward statistics
  * mean/rstd/A ([4][E] each): dgamma_b += T_b, dbeta_b += S0, and f_b = cA*dpre + cC*y_b + cD
  * (batch_stats=0, i.e. eval-mode BN: cC = cD = 0).                                            */
@@ -328,6 +354,8 @@ int lmn_dw_bwd_bn(const void* x1, const void* dpre, void* dx1, int B, int H, int
                   const float* wv, const float* wh, const float* bstats, const float* mean, const float* rstd, const float* A,
                   float count, int batch_stats, float* const* dgamma, float* const* dbeta, float* dw5, float* dw3, float* dwv,
                   float* dwh, int part /* 0: everything; 1: dx1 (+ gamma / beta gradients) only; 2: the four weight gradients only */,
+                  const lmn_dw_pre_t* zpre /* z-path: x1 is z, `dx1` receives dh = dx1 * Hardswish'(A z + shift) and           */,
+                  float* hstats /* [2][E] += (sum dh, sum dh * z) over all pixels: the expand conv's BatchNorm-backward sums */,
                   int act_dtype, lmn_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
@@ -471,6 +499,9 @@ int lmn_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, floa
                    float eps, float weight_decay, float bias_corr1, float bias_corr2, lmn_stream_t stream);
 int lmn_fill(float* p, float v, int64_t n, lmn_stream_t stream);
 /* y = a + b (+ c) (+ d); any of c,d may be NULL; y may alias a */
+/* y[p][c] = coef[0][c] * u[p][c] + coef[1][c] * v[p][c] + coef[2][c]  over `rows` pixels of C channels (activation tensors):
+ * dz = a * dh + b * z + c of the z-path (lmn_reparam_fold), materialised beside the critical path for the weight gradient */
+int lmn_affine2(const void* u, const void* v, const float* coef, void* y, int64_t rows, int C, int act_dtype, lmn_stream_t stream);
 int lmn_add(const void* a, const void* b, const void* c, const void* d, void* y, int64_t n, int act_dtype,
             lmn_stream_t stream);
 /* out[C] += column sums of x[rows][cstride] (bias gradients) */

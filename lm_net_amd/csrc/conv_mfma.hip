@@ -1028,6 +1028,90 @@ __global__ __launch_bounds__(256) void conv_pack_batch_kernel(const lmn_pack_job
   }
 }
 
+// ------------------------------------------------------------------------------------ ReparamConv backward, folded
+// z-path (lmn_dw_pre_t): BatchNorm backward of the expand conv folded into WEIGHTS.  With dh = dL/d(BN output) and the sums
+// S0 = sum dh, S1 = sum dh * z (lmn_dw_bwd_bn), the gradient w.r.t. the conv output is affine in two stored tensors,
+//     dz = a * dh + b * z + c,   a = A,  b = -A * T * rstd / N,  c = -A * S0 / N - b * mean,  T = (S1 - mean * S0) * rstd
+// (eval-mode BatchNorm: b = c = 0), and z = W_e x + bias_e, so the gradient w.r.t. the block input is ONE conv over three sources
+//     dx = [W_e^T diag(a)] dh + [W_e^T diag(b) W_e] x + W_sc^T dy + W_e^T (b * bias_e + c)
+// -- no statistics conv, no second conv that writes dz, no separate shortcut gradient on the critical path.  This kernel forms
+// a / b / c (every block, in LDS; block 0 stores them for the weight-gradient side and adds the gamma / beta gradients) and
+// writes the three operators straight into the packed fragment order of lmn_conv_fwd (sources dh [E], x [Cin], dy [Cout]).
+struct FoldParams {
+  const float* hstats; const float* mean; const float* rstd; const float* A;   // [2][E], [E] x 3
+  const float* we; const float* be; const float* wsc;                          // [E][cinw], [E], [coutw][cinw]  (torch layouts, k = 1)
+  float* wpack; float* kbias; float* coef; float* dgamma; float* dbeta;        // packed operators, [rows], [3][E], [E] +=, [E] +=
+  float count; int batch_stats;
+  int E, rows, cinw, cred, coutw, bf16;   // rows: channels of x / dx (a multiple of 4 >= cinw); cred: channels of dy (>= coutw)
+};
+__global__ __launch_bounds__(256) void reparam_fold_kernel(const FoldParams P) {
+  // one block per packed fragment tile (K16 block kb, row tile ct): 64 lanes x 4 elements.  The Q tiles need E-long dot
+  // products of two 16-column panels of W_e: both panels are staged in LDS with coalesced 64-byte rows (read straight from
+  // global memory, the loop was a chain of 2 * E dependent L2 round trips per thread: 24 us for a 2 MFLOP problem).
+  extern __shared__ float sm[];   // a[E], b[E], c[E], panel R [E][16], panel K [E][16]
+  float* sa = sm; float* sb = sm + P.E; float* sc = sm + 2 * P.E;
+  float* pr = sm + 3 * P.E; float* pk = pr + P.E * 16;
+  const int tid = threadIdx.x;
+  for (int e = tid; e < P.E; e += 256) {
+    const float S0 = P.hstats[e], S1 = P.hstats[P.E + e];
+    const float mu = P.mean[e], rs = P.rstd[e], A = P.A[e];
+    const float T = (S1 - mu * S0) * rs;   // sum dh * zhat
+    const float b = P.batch_stats ? -A * T * rs / P.count : 0.f;
+    const float c = P.batch_stats ? (-A * S0 / P.count - b * mu) : 0.f;
+    sa[e] = A; sb[e] = b; sc[e] = c;
+    if (blockIdx.x == 0) {
+      P.coef[e] = A; P.coef[P.E + e] = b; P.coef[2 * P.E + e] = c;
+      if (P.dgamma) P.dgamma[e] += T;
+      if (P.dbeta) P.dbeta[e] += S0;
+    }
+  }
+  const int nkb0 = (P.E + 15) / 16, nkb1 = (P.rows + 15) / 16, nkb2 = (P.cred + 15) / 16;
+  const int NCTT = (P.rows + 15) / 16;
+  const int ntiles = (nkb0 + nkb1 + nkb2) * NCTT;
+  if ((int)blockIdx.x < ntiles) {
+    const int ct = blockIdx.x % NCTT, kb = blockIdx.x / NCTT;
+    const int s = kb < nkb0 ? 0 : (kb < nkb0 + nkb1 ? 1 : 2);
+    const int kbl = kb - (s == 0 ? 0 : (s == 1 ? nkb0 : nkb0 + nkb1));
+    if (s == 1) {   // panels W_e[:, ct*16 .. +16) and W_e[:, kbl*16 .. +16)
+      for (int i = tid; i < P.E * 16; i += 256) {
+        const int e = i >> 4, c = i & 15;
+        const int r0 = ct * 16 + c, k0 = kbl * 16 + c;
+        pr[i] = r0 < P.cinw ? P.we[(int64_t)e * P.cinw + r0] : 0.f;
+        pk[i] = k0 < P.cinw ? P.we[(int64_t)e * P.cinw + k0] : 0.f;
+      }
+    }
+    __syncthreads();
+    const int lane = tid >> 2, j = tid & 3;
+    const int kq = P.bf16 ? (lane >> 4) * 4 + j : j * 4 + (lane >> 4);   // reduction index inside the K16 block
+    const int kk = kbl * 16 + kq, rl = lane & 15, row = ct * 16 + rl;
+    float v = 0.f;
+    if (row < P.cinw) {
+      if (s == 0) {
+        if (kk < P.E) v = P.we[(int64_t)kk * P.cinw + row] * sa[kk];
+      } else if (s == 1) {
+        if (kk < P.cinw) {
+          float q = 0.f;
+          for (int e = 0; e < P.E; ++e) q += pr[e * 16 + rl] * sb[e] * pk[e * 16 + kq];
+          v = q;
+        }
+      } else {
+        if (kk < P.coutw) v = P.wsc[(int64_t)kk * P.cinw + row];
+      }
+    }
+    pack_store(P.wpack, (int64_t)blockIdx.x * 256 + tid, v, P.bf16);
+  } else {   // the last block: kbias[row] = sum_e W_e[e][row] * (b[e] * bias_e[e] + c[e])  (16 lanes per row over e)
+    __syncthreads();
+    const int sub = tid & 15;
+    for (int row = tid >> 4; row < P.rows; row += 16) {
+      float k = 0.f;
+      if (row < P.cinw)
+        for (int e = sub; e < P.E; e += 16) k += P.we[(int64_t)e * P.cinw + row] * (sb[e] * P.be[e] + sc[e]);
+      k += __shfl_xor(k, 1, 64); k += __shfl_xor(k, 2, 64); k += __shfl_xor(k, 4, 64); k += __shfl_xor(k, 8, 64);
+      if (sub == 0) P.kbias[row] = k;
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------ weight gradient
 struct WgradParams {
   lmn_wgrad_args_t a;
@@ -2846,6 +2930,27 @@ int lmn_conv_wgrad_job(const lmn_wgrad_args_t* args, lmn_reduce_job_t* out) {
   out->ksl = reduce_slices(G.blocks);
   out->blocks_per_set = (int32_t)((G.per + 4096 / out->ksl - 1) / (4096 / out->ksl));
   return 0;
+}
+
+int lmn_reparam_fold(const float* hstats, const float* mean, const float* rstd, const float* A, float count, int batch_stats,
+                     const float* w_expand, const float* b_expand, const float* w_shortcut, int E, int rows, int cin_w, int cred,
+                     int cout_w, float* wpack, float* kbias, float* coef, float* dgamma, float* dbeta, int dtype,
+                     lmn_stream_t stream) {
+  LMN_REC(lmn_reparam_fold(hstats, mean, rstd, A, count, batch_stats, w_expand, b_expand, w_shortcut, E, rows, cin_w, cred, cout_w,
+                           wpack, kbias, coef, dgamma, dbeta, dtype, stream));
+  LMN_REQUIRE(hstats && mean && rstd && A && w_expand && b_expand && w_shortcut && wpack && kbias && coef && count > 0.f,
+              "reparam_fold: null pointer");
+  LMN_REQUIRE(E > 0 && rows > 0 && rows % 4 == 0 && cin_w > 0 && cin_w <= rows && cout_w > 0 && cout_w <= cred && cred % 4 == 0,
+              "reparam_fold: E=%d rows=%d cin=%d cred=%d cout=%d", E, rows, cin_w, cred, cout_w);
+  LMN_REQUIRE(dtype == LMN_F32 || dtype == LMN_BF16, "reparam_fold: dtype %d", dtype);
+  FoldParams P;
+  P.hstats = hstats; P.mean = mean; P.rstd = rstd; P.A = A; P.we = w_expand; P.be = b_expand; P.wsc = w_shortcut;
+  P.wpack = wpack; P.kbias = kbias; P.coef = coef; P.dgamma = dgamma; P.dbeta = dbeta; P.count = count; P.batch_stats = batch_stats;
+  P.E = E; P.rows = rows; P.cinw = cin_w; P.cred = cred; P.coutw = cout_w; P.bf16 = dtype == LMN_BF16;
+  const int ntiles = ((E + 15) / 16 + (rows + 15) / 16 + (cred + 15) / 16) * ((rows + 15) / 16);
+  LMN_REQUIRE((size_t)35 * E * sizeof(float) <= 64 * 1024, "reparam_fold: E = %d too wide for the block's scratch", E);
+  LMN_LAUNCH(reparam_fold_kernel, dim3(ntiles + 1), dim3(256), (size_t)35 * E * sizeof(float), (hipStream_t)stream, P);
+  return lmn_launch_status("reparam_fold");
 }
 
 int lmn_wgrad_reduce_batch(const lmn_reduce_job_t* jobs_dev, int njobs, int64_t total_blocks, lmn_stream_t stream) {

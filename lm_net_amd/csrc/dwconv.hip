@@ -27,6 +27,70 @@ __device__ __forceinline__ int xcd_swizzle(int bid, int nwg) {
   return (xcd < r ? xcd * (qd + 1) : r * (qd + 1) + (xcd - r) * qd) + (bid >> 3);
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// z-path (lmn_dw_pre_t): the tensor handed to the depthwise kernels is z, the expand conv's output BEFORE its BatchNorm and
+// Hardswish; x1 = Hardswish(A * z + shift) is formed when a row batch is committed to LDS (once per staged element).  The
+// training forward then needs no statistics-only conv and no second read of the expand conv's input, and the backward can
+// form dh = dx1 * Hardswish'(A * z + shift) and its BatchNorm-backward sums where dx1 leaves the depthwise backward.
+// Zero padding: rows / columns / channels outside the tensor must stay 0 AFTER the transform -> an explicit 0 / 1 factor.
+typedef lmn_dw_pre_t DwPreK;   // A / shift [E] (NULL: the tensor holds x1, no transform); fin.mode LMN_FIN_BN: formed in the kernel
+struct DwPreS { const float* A; const float* shift; };   // the same without the finalisation (kernel arguments of the other passes)
+__device__ __forceinline__ f32x4 dw_pre4(f32x4 z, f32x4 a, f32x4 sh, float ok) {
+  f32x4 x = z * a + sh;
+  f32x4 t = x * (1.f / 6.f) + 0.5f;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) t[r] = __builtin_amdgcn_fmed3f(t[r], 0.f, 1.f);
+  return x * t * ok;
+}
+// A / shift of the block's SW_CH = 8 channels -> pre_s[0..7] = A, pre_s[8..15] = shift (threads 0..7), formed from the batch sums
+// of the expand conv when fin.mode says so (lmn_bn_fin_t arithmetic: slices summed in double about `about`); `writer` blocks
+// also store mean / rstd / A / shift and blend the running statistics.
+__device__ __forceinline__ void dw_pre_setup(const DwPreS& P, float* pre_s, int ch0, int E, int tid) {
+  if (tid < 8) {
+    const int e = ch0 + tid;
+    const bool cok = e < E;
+    pre_s[tid] = cok ? P.A[e] : 0.f;
+    pre_s[8 + tid] = cok ? P.shift[e] : 0.f;
+  }
+}
+__device__ __forceinline__ void dw_pre_setup(const DwPreK& P, float* pre_s, int ch0, int E, int tid, bool writer) {
+  if (tid < 8) {
+    const int e = ch0 + tid;
+    const bool cok = e < E;
+    const int es = cok ? e : 0;
+    float a = 0.f, sh = 0.f;
+    if (P.fin.mode == LMN_FIN_BN) {
+      const lmn_bn_fin_t& F = P.fin;
+      double s0 = 0.0, s1 = 0.0;
+      for (int r = 0; r < F.nrep; ++r) {
+        s0 += (double)F.sums[(int64_t)r * 2 * E + es];
+        s1 += (double)F.sums[(int64_t)r * 2 * E + E + es];
+      }
+      const double md = s0 / (double)F.count;
+      float var = (float)(s1 / (double)F.count - md * md);  // biased
+      var = var > 0.f ? var : 0.f;
+      const float m = (float)md + (F.about ? F.about[es] : 0.f);
+      const float rs = rsqrtf(var + F.eps);
+      a = F.gamma[es] * rs;
+      sh = F.beta[es] - m * a;
+      if (writer && cok) {
+        if (F.mean) F.mean[e] = m;
+        if (F.rstd) F.rstd[e] = rs;
+        if (F.A) F.A[e] = a;
+        if (F.shift) F.shift[e] = sh;
+        if (F.rmean) F.rmean[e] = (1.f - F.momentum) * F.rmean[e] + F.momentum * m;
+        if (F.rvar) F.rvar[e] = (1.f - F.momentum) * F.rvar[e] + F.momentum * var * (F.count > 1.f ? F.count / (F.count - 1.f) : 1.f);
+      }
+    } else if (P.A) {
+      a = P.A[es];
+      sh = P.shift[es];
+    }
+    pre_s[tid] = cok ? a : 0.f;
+    pre_s[8 + tid] = cok ? sh : 0.f;
+  }
+}
+
 // In-kernel BatchNorm bookkeeping of the depthwise block (by value in the kernel arguments; stats / bstats == NULL: off).
 // Forward: the merged 5x5 stencil of a wave's channel pair is formed from the batch sums and the four branch weights
 // (lmn_dw_finalize_merge arithmetic); backward: the coefficients cA / cC / cD of f_b (lmn_dw_bwd_coef arithmetic).  The
@@ -252,16 +316,21 @@ __device__ unsigned long long g_dw_timing[4096 * 4];
 #else
 #define LMN_DTK(i) do { } while (0)
 #endif
-template <typename TA, int PART = 0>
+template <typename TA, int PART = 0, bool ZT = false>
 __global__ __launch_bounds__(256, 2) void dw_bwd_strip_kernel(
     const TA* __restrict__ x1, const TA* __restrict__ dpre, TA* __restrict__ dx1, int B, int H, int W, int E,
     const float* __restrict__ w5, const float* __restrict__ w3, const float* __restrict__ wvv,
     const float* __restrict__ whh, const float* __restrict__ cA, const float* __restrict__ cC,
     const float* __restrict__ cD, const DwCoef CF, float* __restrict__ dw5, float* __restrict__ dw3, float* __restrict__ dwv,
-    float* __restrict__ dwh, int strips, int segs, int seg_rows, int chunks) {
+    float* __restrict__ dwh, const DwPreS PRE, float* __restrict__ hstats, int strips, int segs, int seg_rows, int chunks) {
   __shared__ __attribute__((aligned(16))) float XS[SW_XR * SW_XC * SW_CS];
   __shared__ __attribute__((aligned(16))) float DPS[SW_R * SW_XC * SW_CS];  // (rows of 68 like XS: one LDS index per staged item)
   __shared__ __attribute__((aligned(16))) float OUT[SW_R * SW_XC * SW_CS];
+  // z-path (DwPreK): x1 is formed from z when a batch is staged; the drain turns dx1 into dh = dx1 * Hardswish'(A z + shift) and
+  // sums dh, dh * z per channel (hstats [2][E]: the BatchNorm-backward statistics of the expand conv).  The per-thread sums
+  // live in LDS (hacc[j][tid]: conflict-free, no accumulator registers in a kernel that has none to spare)
+  __shared__ __attribute__((aligned(16))) float pre_s[16];
+  __shared__ float hacc[(PART == 2 || !ZT) ? 1 : 8 * 256];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   // logical block id: channel chunk fastest (siblings share the x1 / dpre cache lines -> same XCD, same L2)
@@ -274,6 +343,14 @@ __global__ __launch_bounds__(256, 2) void dw_bwd_strip_kernel(
   const int ch = ch0 + wv * 2;
   const bool cok = ch < E;                      // wave-uniform: pairs past E (partial last chunk) compute on zeros
   const int chs = cok ? ch : 0;
+  constexpr bool zt = ZT;                       // the input tensor is z (see DwPreK)
+  if constexpr (ZT) {
+    dw_pre_setup(PRE, pre_s, ch0, E, tid);
+    if (PART != 2) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) hacc[j * 256 + tid] = 0.f;
+    }
+  }
   BranchW bw;
   load_branch_w(bw, w5, w3, wvv, whh, chs, E);
   f32x2 ca[4], cc[4], cd[4];
@@ -349,6 +426,7 @@ __global__ __launch_bounds__(256, 2) void dw_bwd_strip_kernel(
   const BufRsrc ro = make_rsrc(ob + (int64_t)ys * W * E, (unsigned)(ye - ys) * rowb);
   unsigned fo[NXB];
   int li[NXB];  // LDS float index of the item in a 5 x 68 x SW_CS batch | bit 16: dpre item | bit 17: dx1 item
+                // | bit 18: inside the tensor (column, channel) | bits 20..22: its row in the batch   (the last two: z-path)
 #pragma unroll
   for (int k = 0; k < NXB; ++k) {
     const int i = tid + k * 256;
@@ -358,10 +436,58 @@ __global__ __launch_bounds__(256, 2) void dw_bwd_strip_kernel(
     const bool ok = i < SW_R * SW_XC * 2 && gx >= 0 && gx < W && ch0 + k4 * 4 < E;
     fo[k] = ok ? (unsigned)((rr * W + gx) * E + ch0 + k4 * 4) * ES : OOB;
     const bool in = i < SW_R * SW_XC * 2;
-    li[k] = ((rr * SW_XC + c) * SW_CS + k4 * 4) | (in && c >= 2 && c < 2 + SW_FC ? 0x10000 : 0) | (in && c >= 4 && c < 4 + SW_OC ? 0x20000 : 0);
+    li[k] = ((rr * SW_XC + c) * SW_CS + k4 * 4) | (in && c >= 2 && c < 2 + SW_FC ? 0x10000 : 0) | (in && c >= 4 && c < 4 + SW_OC ? 0x20000 : 0) |
+            (ok ? 0x40000 : 0) | (rr & 7) << 20;
   }
+  if (zt) __syncthreads();   // pre_s, hacc
+  // z-path: the z rows a drain needs (the rows of the dx batch; this block staged the same lines one or two batches ago, so they
+  // come back from L2) are requested at the END of the batch's row steps -- the step temporaries are dead there -- and are in
+  // registers when the next staging phase drains: no load latency inside the drain, no overlap with the x1 / dpre loads' registers
+  f32x4 vz[ZT ? NXB : 1];
+  auto zfetch = [&](int jb) {
+    if constexpr (ZT) {
+      const unsigned zb = (unsigned)((ys + jb - 8) * rowb);
+#pragma unroll
+      for (int k = 0; k < NXB; ++k) {
+        int l = li[k];
+        asm volatile("" : "+v"(l));
+        vz[k] = buf_load4<TA>(rx, (l & 0x20000) ? fo[k] + zb : OOB);
+      }
+    }
+  };
   auto drain = [&](int jb) {  // dx rows of the batch that started at step jb: segment rows jb-8+rr
     const unsigned base = (unsigned)((jb - 8) * rowb);
+    if constexpr (ZT) {
+      // dh = dx1 * Hardswish'(A z + shift); sum dh, sum dh * z over the rows of this segment inside the image (vz: zfetch)
+      const f32x4 tA = *reinterpret_cast<const f32x4*>(&pre_s[(tid & 1) * 4]), tS = *reinterpret_cast<const f32x4*>(&pre_s[8 + (tid & 1) * 4]);
+      int l[NXB];
+#pragma unroll
+      for (int k = 0; k < NXB; ++k) {
+        l[k] = li[k];
+        asm volatile("" : "+v"(l[k]));
+      }
+      f32x4 h0 = f32x4{0.f, 0.f, 0.f, 0.f}, h1 = h0;
+#pragma unroll
+      for (int k = 0; k < NXB; ++k) {
+        if (l[k] & 0x20000) {
+          const float* o = &OUT[(l[k] & 0xFFFF) - 2 * SW_CS];
+          const f32x2 a = *reinterpret_cast<const f32x2*>(o), d = *reinterpret_cast<const f32x2*>(o + 2);
+          const f32x4 hh = vz[k] * tA + tS;
+          f32x4 dh = f32x4{a[0] * lmn_dhswish(hh[0]), a[1] * lmn_dhswish(hh[1]), d[0] * lmn_dhswish(hh[2]), d[1] * lmn_dhswish(hh[3])};
+          buf_store4<TA>(ro, fo[k] + base, dh);
+          const bool in = (l[k] & 0x40000) && (unsigned)(jb - 8 + ((l[k] >> 20) & 7)) < (unsigned)(ye - ys);
+          if (!in) dh = f32x4{0.f, 0.f, 0.f, 0.f};   // (a select: rows past the segment hold whatever the LDS held)
+          h0 += dh;
+          h1 += dh * vz[k];
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        hacc[j * 256 + tid] += h0[j];
+        hacc[(4 + j) * 256 + tid] += h1[j];
+      }
+      return;
+    }
 #pragma unroll
     for (int k = 0; k < NXB; ++k) {
       int l = li[k];
@@ -375,6 +501,9 @@ __global__ __launch_bounds__(256, 2) void dw_bwd_strip_kernel(
   };
   auto stage = [&](int j0) {
     __syncthreads();  // previous batch computed: OUT holds its dx rows, XS/DPS slots are free
+    if constexpr (ZT) {
+      if (PART != 2 && j0 >= 8 + SW_R - 4) drain(j0 - SW_R);  // (before the loads below are requested: their 24 registers and the drain's do not add up)
+    }
     // ---- stage x1 rows (image rows ys-4+j, columns xs-4 .. xs+63) and dpre rows (rows ys-6+j, columns xs-2 .. xs+61)
     {
       const unsigned bx = (unsigned)((ys - 4 + j0) * rowb), bd = (unsigned)((ys - 6 + j0) * rowb);
@@ -389,8 +518,21 @@ __global__ __launch_bounds__(256, 2) void dw_bwd_strip_kernel(
       for (int k = 0; k < NXB; ++k) vx[k] = buf_load4<TA>(rx, fo[k] + bx);  // (OOB + base stays out of range)
 #pragma unroll
       for (int k = 0; k < NXB; ++k) vd[k] = buf_load4<TA>(rd, (l[k] & 0x10000) ? fo[k] + bd : OOB);
-      if (PART != 2 && j0 >= 8 + SW_R - 4) drain(j0 - SW_R);  // dx rows of the previous batch leave while the loads are in flight
+      if constexpr (!ZT) {
+        if (PART != 2 && j0 >= 8 + SW_R - 4) drain(j0 - SW_R);  // dx rows of the previous batch leave while the loads are in flight
+      }
       float* ring = XS + (j0 % SW_XR) * (SW_XC * SW_CS);
+      if constexpr (ZT) {   // x1 = Hardswish(A z + shift) where the batch is committed; rows / columns outside the image stay 0
+        const f32x4 tA = *reinterpret_cast<const f32x4*>(&pre_s[(tid & 1) * 4]), tS = *reinterpret_cast<const f32x4*>(&pre_s[8 + (tid & 1) * 4]);
+        const int yb = ys - 4 + j0;
+        const bool inner = yb >= 0 && yb + SW_R <= H;
+#pragma unroll
+        for (int k = 0; k < NXB; ++k) {
+          bool ok = (l[k] & 0x40000) != 0;
+          if (!inner) ok = ok && (unsigned)(yb + ((l[k] >> 20) & 7)) < (unsigned)H;
+          vx[k] = dw_pre4(vx[k], tA, tS, ok ? 1.f : 0.f);
+        }
+      }
 #pragma unroll
       for (int k = 0; k < NXB; ++k) {
         if (k * 256 + 255 < SW_R * SW_XC * 2 || tid + k * 256 < SW_R * SW_XC * 2) {
@@ -433,18 +575,21 @@ __global__ __launch_bounds__(256, 2) void dw_bwd_strip_kernel(
     stage(j0);
     LMN_DTK(0);
     LMN_SW_STEP(0) LMN_SW_STEP(1) LMN_SW_STEP(2) LMN_SW_STEP(3) LMN_SW_STEP(4)
+    if (PART != 2) zfetch(j0);
     LMN_DTK(1);
   }
   for (; j0 + 4 < (ye - ys) + 6; j0 += SW_R) {
     stage(j0);
     LMN_DTK(0);
     LMN_SW_FAST(0) LMN_SW_FAST(1) LMN_SW_FAST(2) LMN_SW_FAST(3) LMN_SW_FAST(4)
+    if (PART != 2) zfetch(j0);
     LMN_DTK(1);
   }
   for (; j0 < nsteps; j0 += SW_R) {
     stage(j0);
     LMN_DTK(0);
     LMN_SW_STEP(0) LMN_SW_STEP(1) LMN_SW_STEP(2) LMN_SW_STEP(3) LMN_SW_STEP(4)
+    if (PART != 2) zfetch(j0);
     LMN_DTK(1);
   }
 #ifdef LMN_DW_TIMING
@@ -457,6 +602,16 @@ __global__ __launch_bounds__(256, 2) void dw_bwd_strip_kernel(
 #undef LMN_SW_FAST
   __syncthreads();
   if (PART != 2) drain(((nsteps + SW_R - 1) / SW_R) * SW_R - SW_R);  // dx rows of the last batch
+  if (PART != 2 && zt) {   // hstats: 128 threads per channel quad -> 16 sums per block -> one atomic instruction
+    __syncthreads();
+    if (tid < 16) {
+      const int k4 = (tid >> 2) & 1, r = tid & 3, which = tid >> 3;   // tid = which * 8 + k4 * 4 + r
+      float a = 0.f;
+      for (int t = k4; t < 256; t += 2) a += hacc[(which * 4 + r) * 256 + t];
+      const int e = ch0 + k4 * 4 + r;
+      if (e < E) atomicAdd(hstats + (int64_t)which * E + e, a);
+    }
+  }
   if (PART == 1) return;
   // ---- weight gradients: butterfly over the 64 columns, one LDS row per wave, then one atomic per (tap, channel)
   __syncthreads();
@@ -529,12 +684,13 @@ __global__ __launch_bounds__(256) void dw_fwd_strip_kernel(const TA* __restrict_
                                                             float* __restrict__ gsum, int H, int W, int E,
                                                             const float* __restrict__ keff,
                                                             const float* __restrict__ beff, const DwFin FN,
-                                                            const lmn_se_fuse_t SE, int strips,
+                                                            const lmn_se_fuse_t SE, const DwPreS PRE, int strips,
                                                             int segs, int seg_rows, int chunks) {
   __shared__ __attribute__((aligned(16))) float XS[FS_XR * SW_XC * SW_CS];
   __shared__ __attribute__((aligned(16))) float OUT[SW_R * SW_FC * SW_CS];
   __shared__ float gs_s[SW_CH];
   __shared__ int s_last;
+  __shared__ __attribute__((aligned(16))) float pre_s[16];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   int lid = xcd_swizzle(blockIdx.x, gridDim.x);  // channel chunk fastest: siblings share cache lines and an L2
@@ -545,6 +701,8 @@ __global__ __launch_bounds__(256) void dw_fwd_strip_kernel(const TA* __restrict_
   const int ch0 = chunk * SW_CH, ch = ch0 + wv * 2;
   const bool cok = ch < E;
   const int chs = cok ? ch : 0;
+  const bool zt = PRE.A != nullptr;   // block-uniform: the input tensor is z (see DwPreK)
+  if (zt) dw_pre_setup(PRE, pre_s, ch0, E, tid);
   f32x2 w[25];
   f32x2 bias;
   if (FN.stats) {  // block-uniform: the four branch BatchNorms are finalised and merged here (lmn_dw_finalize_merge arithmetic)
@@ -609,6 +767,7 @@ __global__ __launch_bounds__(256) void dw_fwd_strip_kernel(const TA* __restrict_
   const BufRsrc rout = make_rsrc(ob + (int64_t)ys * W * E, (unsigned)(ye - ys) * rowb);
   unsigned fo[NX], so[ND];
   int li[NX], lo[ND];
+  int okrr = 0;  // z-path: per staged item k, bit k = inside the tensor (column, channel), bits 8+4k.. = its row in the batch
 #pragma unroll
   for (int k = 0; k < NX; ++k) {
     const int i = tid + k * 256;
@@ -618,6 +777,7 @@ __global__ __launch_bounds__(256) void dw_fwd_strip_kernel(const TA* __restrict_
     const bool ok = i < SW_R * SW_XC * 2 && gx >= 0 && gx < W && ch0 + k4 * 4 < E;
     fo[k] = ok ? (unsigned)(((rr - 2) * W + gx) * E + ch0 + k4 * 4) * ES : OOB;
     li[k] = (rr * SW_XC + c) * SW_CS + k4 * 4;
+    okrr |= (ok ? 1 : 0) << k | (rr & 15) << (8 + 4 * k);
   }
 #pragma unroll
   for (int k = 0; k < ND; ++k) {
@@ -628,6 +788,7 @@ __global__ __launch_bounds__(256) void dw_fwd_strip_kernel(const TA* __restrict_
     so[k] = ok ? (unsigned)(((rr - 4) * W + xs + c) * E + ch0 + k4 * 4) * ES : OOB;
     lo[k] = (rr * SW_FC + c) * SW_CS + k4 * 4;
   }
+  if (zt) __syncthreads();   // pre_s
   f32x4 px[NX];
   auto fetch = [&](int j0) {  // x1 rows ys-2+j0 .. +4
     const unsigned base = (unsigned)((ys + j0) * rowb);
@@ -636,12 +797,21 @@ __global__ __launch_bounds__(256) void dw_fwd_strip_kernel(const TA* __restrict_
   };
   auto commit = [&](int j0) {
     float* ring = XS + (j0 % FS_XR) * (SW_XC * SW_CS);
+    const int yb = ys - 2 + j0;                       // image row of the batch's first row
+    const bool inner = yb >= 0 && yb + SW_R <= H;     // block-uniform: every row of the batch lies inside the image
 #pragma unroll
     for (int k = 0; k < NX; ++k) {
       if (k * 256 + 255 < SW_R * SW_XC * 2 || tid + k * 256 < SW_R * SW_XC * 2) {
         float* d = ring + li[k];
-        *reinterpret_cast<f32x2*>(d) = f32x2{px[k][0], px[k][1]};
-        *reinterpret_cast<f32x2*>(d + 2) = f32x2{px[k][2], px[k][3]};
+        f32x4 v = px[k];
+        if (zt) {
+          const f32x4 tA = *reinterpret_cast<const f32x4*>(&pre_s[(tid & 1) * 4]), tS = *reinterpret_cast<const f32x4*>(&pre_s[8 + (tid & 1) * 4]);
+          bool ok = (okrr >> k) & 1;
+          if (!inner) ok = ok && (unsigned)(yb + ((okrr >> (8 + 4 * k)) & 15)) < (unsigned)H;
+          v = dw_pre4(v, tA, tS, ok ? 1.f : 0.f);
+        }
+        *reinterpret_cast<f32x2*>(d) = f32x2{v[0], v[1]};
+        *reinterpret_cast<f32x2*>(d + 2) = f32x2{v[2], v[3]};
       }
     }
   };
@@ -818,9 +988,10 @@ __global__ __launch_bounds__(256) void dw_stats_strip_kernel(
     const TA* __restrict__ x1, const TA* __restrict__ pre, const TA* __restrict__ u,
     const float* __restrict__ sgate, const float* __restrict__ dm, TA* __restrict__ dpre, int H, int W, int E,
     const float* __restrict__ w5, const float* __restrict__ w3, const float* __restrict__ wvv,
-    const float* __restrict__ whh, float* __restrict__ stats, const lmn_se_bwd_t SB, int strips, int segs, int seg_rows,
-    int chunks) {
+    const float* __restrict__ whh, float* __restrict__ stats, const lmn_se_bwd_t SB, const DwPreK PRE, int strips, int segs,
+    int seg_rows, int chunks) {
   constexpr int NS = MODE == 0 ? 8 : 5;
+  __shared__ __attribute__((aligned(16))) float pre_s[16];
   constexpr int NAUX = MODE == 1 ? SW_R * SW_FC * SW_CS : 4;
   __shared__ __attribute__((aligned(16))) float XS[FS_XR * SW_XC * SW_CS];
   __shared__ __attribute__((aligned(16))) float PS[NAUX], US[NAUX], OUT[NAUX];
@@ -835,6 +1006,8 @@ __global__ __launch_bounds__(256) void dw_stats_strip_kernel(
   const int ch0 = chunk * SW_CH, ch = ch0 + wv * 2;
   const bool cok = ch < E;
   const int chs = cok ? ch : 0;
+  const bool zt = PRE.A != nullptr || PRE.fin.mode == LMN_FIN_BN;   // block-uniform: the input tensor is z (see DwPreK)
+  if (zt) dw_pre_setup(PRE, pre_s, ch0, E, tid, strip == 0 && seg == 0 && b == 0);
   BranchW bw;
   if constexpr (MODE == 0) {   // (MODE 1 needs the kernels only for the final contraction: loaded there)
     load_branch_w(bw, w5, w3, wvv, whh, chs, E);
@@ -913,6 +1086,7 @@ __global__ __launch_bounds__(256) void dw_stats_strip_kernel(
   const BufRsrc rout = make_rsrc(MODE == 1 ? dpre + sb : xb, MODE == 1 ? (unsigned)(ye - ys) * rowb : 0u);
   unsigned fo[NX], so[MODE == 1 ? ND : 1];
   int li[NX], lo[MODE == 1 ? ND : 1];
+  int okrr = 0;  // z-path: per staged item k, bit k = inside the tensor (column, channel), bits 8+4k.. = its row in the batch
 #pragma unroll
   for (int k = 0; k < NX; ++k) {
     const int i = tid + k * 256;
@@ -922,7 +1096,9 @@ __global__ __launch_bounds__(256) void dw_stats_strip_kernel(
     const bool ok = i < SW_R * SW_XC * 2 && gx >= 0 && gx < W && ch0 + k4 * 4 < E;
     fo[k] = ok ? (unsigned)(((rr - 2) * W + gx) * E + ch0 + k4 * 4) * ES : OOB;
     li[k] = (rr * SW_XC + c) * SW_CS + k4 * 4;
+    okrr |= (ok ? 1 : 0) << k | (rr & 15) << (8 + 4 * k);
   }
+  if (zt) __syncthreads();   // pre_s
   if (MODE == 1) {
 #pragma unroll
     for (int k = 0; k < ND; ++k) {
@@ -950,12 +1126,21 @@ __global__ __launch_bounds__(256) void dw_stats_strip_kernel(
   };
   auto commit = [&](int j0) {
     float* ring = XS + (j0 % FS_XR) * (SW_XC * SW_CS);
+    const int yb = ys - 2 + j0;                       // image row of the batch's first row
+    const bool inner = yb >= 0 && yb + SW_R <= H;     // block-uniform: every row of the batch lies inside the image
 #pragma unroll
     for (int k = 0; k < NX; ++k) {
       if (k * 256 + 255 < SW_R * SW_XC * 2 || tid + k * 256 < SW_R * SW_XC * 2) {
         float* d = ring + li[k];
-        *reinterpret_cast<f32x2*>(d) = f32x2{px[k][0], px[k][1]};
-        *reinterpret_cast<f32x2*>(d + 2) = f32x2{px[k][2], px[k][3]};
+        f32x4 v = px[k];
+        if (zt) {
+          const f32x4 tA = *reinterpret_cast<const f32x4*>(&pre_s[(tid & 1) * 4]), tS = *reinterpret_cast<const f32x4*>(&pre_s[8 + (tid & 1) * 4]);
+          bool ok = (okrr >> k) & 1;
+          if (!inner) ok = ok && (unsigned)(yb + ((okrr >> (8 + 4 * k)) & 15)) < (unsigned)H;
+          v = dw_pre4(v, tA, tS, ok ? 1.f : 0.f);
+        }
+        *reinterpret_cast<f32x2*>(d) = f32x2{v[0], v[1]};
+        *reinterpret_cast<f32x2*>(d + 2) = f32x2{v[2], v[3]};
       }
     }
     if (MODE == 1) {
@@ -1137,8 +1322,8 @@ static int strip_segments(int64_t blocks_per_seg, int H, int halo, int occ, int*
 template <int MODE>
 static int launch_dw_strip_stats(const void* x1, const void* pre, const void* u, const float* s, const float* dm,
                                  void* dpre, int B, int H, int W, int E, const float* w5, const float* w3,
-                                 const float* wv, const float* wh, float* stats, const lmn_se_bwd_t& sb, int act_dtype,
-                                 hipStream_t st) {
+                                 const float* wv, const float* wh, float* stats, const lmn_se_bwd_t& sb, const lmn_dw_pre_t& zp,
+                                 int act_dtype, hipStream_t st) {
   LMN_REQUIRE((int64_t)(H + 8) * W * E * 4 < (1LL << 30), "dw statistics: one image (%d x %d x %d) must stay below 1 GiB", H, W, E);
   const int strips = lmn_cdiv(W, SW_FC), chunks = lmn_cdiv(E, SW_CH);
   int seg_rows;
@@ -1147,7 +1332,7 @@ static int launch_dw_strip_stats(const void* x1, const void* pre, const void* u,
   if (nblk >= (1LL << 31)) return -1;
   if (g_lmn_prof_on) lmn_prof_cost(2.0 * 42 * (double)B * H * W * E, (act_dtype == LMN_BF16 ? 2.0 : 4.0) * (MODE == 0 ? 1 : 4) * (double)B * H * W * E);
   LMN_ACT_DISPATCH(act_dtype, LMN_LAUNCH((dw_stats_strip_kernel<MODE, T>), dim3((unsigned)nblk), dim3(256), 0, st, (const T*)x1, (const T*)pre, (const T*)u, s, dm, (T*)dpre, H, W, E,
-                     w5, w3, wv, wh, stats, sb, strips, segs, seg_rows, chunks));
+                     w5, w3, wv, wh, stats, sb, zp, strips, segs, seg_rows, chunks));
   return 0;
 }
 
@@ -1160,6 +1345,21 @@ int lmn_dw_timing(unsigned long long* out, int n) {
 }
 #endif
 
+static int dw_pre_check(const lmn_dw_pre_t* pre, lmn_dw_pre_t* out, bool allow_fin, const char* what) {
+  memset(out, 0, sizeof(*out));
+  if (!pre || (!pre->A && pre->fin.mode == LMN_FIN_NONE)) return 0;
+  if (pre->fin.mode != LMN_FIN_NONE) {
+    const lmn_bn_fin_t& F = pre->fin;
+    LMN_REQUIRE(allow_fin && F.mode == LMN_FIN_BN, "%s: the expand conv's BatchNorm can only be finalised by lmn_dw_stats", what);
+    LMN_REQUIRE(F.sums && F.nrep >= 1 && F.nrep <= 64 && F.count > 0.f && F.gamma && F.beta && (!F.about || F.about != F.rmean),
+                "%s: fin needs sums, slices, count, gamma / beta (and `about` must not alias rmean)", what);
+  } else {
+    LMN_REQUIRE(pre->A && pre->shift, "%s: z-path needs A and shift", what);
+  }
+  *out = *pre;
+  return 0;
+}
+
 static int se_fuse_check(const lmn_se_fuse_t* se, lmn_se_fuse_t* out, int E, const char* what) {
   memset(out, 0, sizeof(*out));
   if (!se || !se->ticket) return 0;
@@ -1170,10 +1370,12 @@ static int se_fuse_check(const lmn_se_fuse_t* se, lmn_se_fuse_t* out, int E, con
 }
 
 int lmn_dw_fwd(const void* x1, void* pre, float* gsum, int B, int H, int W, int E, const float* keff,
-               const float* beff, const lmn_se_fuse_t* se, int act_dtype, lmn_stream_t stream) {
+               const float* beff, const lmn_se_fuse_t* se, const lmn_dw_pre_t* zpre, int act_dtype, lmn_stream_t stream) {
   lmn_se_fuse_t sf;
   { const int rc = se_fuse_check(se, &sf, E, "dw_fwd"); if (rc) return rc; }
-  if (g_lmn_rec) lmn_rec_push([=]() -> int { return lmn_dw_fwd(x1, pre, gsum, B, H, W, E, keff, beff, &sf, act_dtype, stream); });
+  lmn_dw_pre_t zp;
+  { const int rc = dw_pre_check(zpre, &zp, false, "dw_fwd"); if (rc) return rc; }
+  if (g_lmn_rec) lmn_rec_push([=]() -> int { return lmn_dw_fwd(x1, pre, gsum, B, H, W, E, keff, beff, &sf, &zp, act_dtype, stream); });
   LMN_REQUIRE_DT(act_dtype, "dw_fwd");
   LMN_REQUIRE(x1 && pre && gsum && keff && beff, "dw_fwd: null pointer");
   LMN_REQUIRE(B > 0 && H > 0 && W > 0 && E > 0 && E % 4 == 0, "dw_fwd: E=%d must be a multiple of 4", E);
@@ -1186,17 +1388,20 @@ int lmn_dw_fwd(const void* x1, void* pre, float* gsum, int B, int H, int W, int 
   LMN_REQUIRE(nblk < (1LL << 31), "dw_fwd: grid too large");
   if (g_lmn_prof_on) lmn_prof_cost(2.0 * 25 * (double)B * H * W * E, (act_dtype == LMN_BF16 ? 2.0 : 4.0) * 2 * (double)B * H * W * E);
   LMN_ACT_DISPATCH(act_dtype, LMN_LAUNCH((dw_fwd_strip_kernel<T>), dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, (const T*)x1, (T*)pre, gsum, H, W, E, keff,
-                     beff, DwFin{}, sf, strips, segs, seg_rows, chunks));
+                     beff, DwFin{}, sf, DwPreS{zp.A, zp.shift}, strips, segs, seg_rows, chunks));
   return lmn_launch_status("dw_fwd");
 }
 
 int lmn_dw_fwd_bn(const void* x1, void* pre, float* gsum, int B, int H, int W, int E, const float* stats, float count,
                   const float* const* gamma, const float* const* beta, float* const* running_mean, float* const* running_var,
                   const float* eps, const float* momentum, const float* w5, const float* w3, const float* wv, const float* wh,
-                  float* mean, float* rstd, float* A, const lmn_se_fuse_t* se, int act_dtype, lmn_stream_t stream) {
+                  float* mean, float* rstd, float* A, const lmn_se_fuse_t* se, const lmn_dw_pre_t* zpre, int act_dtype,
+                  lmn_stream_t stream) {
   LMN_REQUIRE_DT(act_dtype, "dw_fwd_bn");
   lmn_se_fuse_t sf;
   { const int rc = se_fuse_check(se, &sf, E, "dw_fwd_bn"); if (rc) return rc; }
+  lmn_dw_pre_t zp;
+  { const int rc = dw_pre_check(zpre, &zp, false, "dw_fwd_bn"); if (rc) return rc; }
   LMN_REQUIRE(x1 && pre && gsum && stats && gamma && beta && running_mean && running_var && eps && momentum && w5 && w3 && wv && wh &&
                   mean && rstd && A && count > 0.f, "dw_fwd_bn: bad argument");
   LMN_REQUIRE(B > 0 && H > 0 && W > 0 && E > 0 && E % 4 == 0, "dw_fwd_bn: E=%d must be a multiple of 4", E);
@@ -1217,7 +1422,7 @@ int lmn_dw_fwd_bn(const void* x1, void* pre, float* gsum, int B, int H, int W, i
   auto launch = [=]() -> int {
     if (g_lmn_prof_on) lmn_prof_cost(2.0 * 25 * (double)B * H * W * E, (act_dtype == LMN_BF16 ? 2.0 : 4.0) * 2 * (double)B * H * W * E);
     LMN_ACT_DISPATCH(act_dtype, LMN_LAUNCH((dw_fwd_strip_kernel<T>), dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, (const T*)x1, (T*)pre, gsum, H, W, E,
-                       (const float*)nullptr, (const float*)nullptr, fn, sf, strips, segs, seg_rows, chunks));
+                       (const float*)nullptr, (const float*)nullptr, fn, sf, DwPreS{zp.A, zp.shift}, strips, segs, seg_rows, chunks));
     return lmn_launch_status("dw_fwd_bn");
   };
   if (g_lmn_rec) lmn_rec_push(launch);
@@ -1262,18 +1467,22 @@ int lmn_dw_merge(const float* w5, const float* w3, const float* wv, const float*
 }
 
 int lmn_dw_stats(const void* x1, int B, int H, int W, int E, const float* w5, const float* w3, const float* wv,
-                 const float* wh, float* stats, int act_dtype, lmn_stream_t stream) {
-  LMN_REC(lmn_dw_stats(x1, B, H, W, E, w5, w3, wv, wh, stats, act_dtype, stream));
+                 const float* wh, float* stats, const lmn_dw_pre_t* zpre, int act_dtype, lmn_stream_t stream) {
+  lmn_dw_pre_t zp;
+  { const int rc = dw_pre_check(zpre, &zp, true, "dw_stats"); if (rc) return rc; }
+  if (g_lmn_rec) lmn_rec_push([=]() -> int { return lmn_dw_stats(x1, B, H, W, E, w5, w3, wv, wh, stats, &zp, act_dtype, stream); });
   LMN_REQUIRE_DT(act_dtype, "dw_stats");
   LMN_REQUIRE(x1 && w5 && w3 && wv && wh && stats, "dw_stats: null pointer");
   LMN_REQUIRE(B > 0 && H > 0 && W > 0 && E > 0 && E % 4 == 0, "dw_stats: E=%d must be a multiple of 4", E);
-  launch_dw_strip_stats<0>(x1, nullptr, nullptr, nullptr, nullptr, nullptr, B, H, W, E, w5, w3, wv, wh, stats, lmn_se_bwd_t{}, act_dtype, (hipStream_t)stream);
+  launch_dw_strip_stats<0>(x1, nullptr, nullptr, nullptr, nullptr, nullptr, B, H, W, E, w5, w3, wv, wh, stats, lmn_se_bwd_t{}, zp, act_dtype, (hipStream_t)stream);
   return lmn_launch_status("dw_stats");
 }
 
 int lmn_dw_bwd_stats(const void* x1, const void* pre, const void* u, const float* s, const float* dm, void* dpre,
                      int B, int H, int W, int E, const float* w5, const float* w3, const float* wv, const float* wh,
-                     float* bstats, const lmn_se_bwd_t* seb, int act_dtype, lmn_stream_t stream) {
+                     float* bstats, const lmn_se_bwd_t* seb, const lmn_dw_pre_t* zpre, int act_dtype, lmn_stream_t stream) {
+  lmn_dw_pre_t zp;
+  { const int rc = dw_pre_check(zpre, &zp, false, "dw_bwd_stats"); if (rc) return rc; }
   lmn_se_bwd_t sb;
   memset(&sb, 0, sizeof(sb));
   if (seb && seb->ds) {
@@ -1281,11 +1490,11 @@ int lmn_dw_bwd_stats(const void* x1, const void* pre, const void* u, const float
     LMN_REQUIRE(E + seb->R + 256 <= FS_XR * SW_XC * SW_CS, "dw_bwd_stats: E + R = %d exceeds the block's scratch", E + seb->R);
     sb = *seb;
   }
-  if (g_lmn_rec) lmn_rec_push([=]() -> int { return lmn_dw_bwd_stats(x1, pre, u, s, dm, dpre, B, H, W, E, w5, w3, wv, wh, bstats, &sb, act_dtype, stream); });
+  if (g_lmn_rec) lmn_rec_push([=]() -> int { return lmn_dw_bwd_stats(x1, pre, u, s, dm, dpre, B, H, W, E, w5, w3, wv, wh, bstats, &sb, &zp, act_dtype, stream); });
   LMN_REQUIRE_DT(act_dtype, "dw_bwd_stats");
   LMN_REQUIRE(x1 && pre && u && s && (dm || sb.ds) && dpre && w5 && w3 && wv && wh && bstats, "dw_bwd_stats: null pointer");
   LMN_REQUIRE(B > 0 && H > 0 && W > 0 && E > 0 && E % 4 == 0, "dw_bwd_stats: E=%d must be a multiple of 4", E);
-  launch_dw_strip_stats<1>(x1, pre, u, s, dm, dpre, B, H, W, E, w5, w3, wv, wh, bstats, sb, act_dtype, (hipStream_t)stream);
+  launch_dw_strip_stats<1>(x1, pre, u, s, dm, dpre, B, H, W, E, w5, w3, wv, wh, bstats, sb, zp, act_dtype, (hipStream_t)stream);
   return lmn_launch_status("dw_bwd_stats");
 }
 
@@ -1316,15 +1525,18 @@ int lmn_dw_bwd(const void* x1, const void* dpre, void* dx1, int B, int H, int W,
   LMN_REQUIRE(nblk < (1LL << 31), "dw_bwd: grid too large");
   if (g_lmn_prof_on) lmn_prof_cost(2.0 * 2 * 42 * (double)B * H * W * E, (act_dtype == LMN_BF16 ? 2.0 : 4.0) * 3 * (double)B * H * W * E);
   LMN_ACT_DISPATCH(act_dtype, LMN_LAUNCH((dw_bwd_strip_kernel<T>), dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, (const T*)x1, (const T*)dpre, (T*)dx1, B, H, W, E, w5,
-                     w3, wv, wh, cA, cC, cD, DwCoef{}, dw5, dw3, dwv, dwh, strips, segs, seg_rows, chunks));
+                     w3, wv, wh, cA, cC, cD, DwCoef{}, dw5, dw3, dwv, dwh, DwPreS{nullptr, nullptr}, (float*)nullptr, strips, segs, seg_rows, chunks));
   return lmn_launch_status("dw_bwd");
 }
 
 int lmn_dw_bwd_bn(const void* x1, const void* dpre, void* dx1, int B, int H, int W, int E, const float* w5, const float* w3,
                   const float* wv, const float* wh, const float* bstats, const float* mean, const float* rstd, const float* A,
                   float count, int batch_stats, float* const* dgamma, float* const* dbeta, float* dw5, float* dw3, float* dwv,
-                  float* dwh, int part, int act_dtype, lmn_stream_t stream) {
+                  float* dwh, int part, const lmn_dw_pre_t* zpre, float* hstats, int act_dtype, lmn_stream_t stream) {
   LMN_REQUIRE_DT(act_dtype, "dw_bwd_bn");
+  lmn_dw_pre_t zp;
+  { const int rc = dw_pre_check(zpre, &zp, false, "dw_bwd_bn"); if (rc) return rc; }
+  LMN_REQUIRE(!zp.A || (hstats && part != 2), "dw_bwd_bn: the z-path writes dh and needs hstats [2][E] (part 0 or 1)");
   LMN_REQUIRE(part >= 0 && part <= 2, "dw_bwd_bn: part %d", part);
   LMN_REQUIRE(x1 && dpre && dx1 && w5 && w3 && wv && wh && bstats && mean && rstd && A && dgamma && dbeta && dw5 && dw3 && dwv && dwh &&
                   count > 0.f, "dw_bwd_bn: bad argument");
@@ -1343,9 +1555,11 @@ int lmn_dw_bwd_bn(const void* x1, const void* dpre, void* dx1, int B, int H, int
   LMN_REQUIRE(nblk < (1LL << 31), "dw_bwd_bn: grid too large");
   auto launch = [=]() -> int {
     if (g_lmn_prof_on) lmn_prof_cost(2.0 * 2 * 42 * (double)B * H * W * E, (act_dtype == LMN_BF16 ? 2.0 : 4.0) * 3 * (double)B * H * W * E);
-#define LMN_DWB(PT) LMN_ACT_DISPATCH(act_dtype, LMN_LAUNCH((dw_bwd_strip_kernel<T, PT>), dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, (const T*)x1, (const T*)dpre, (T*)dx1, B, H, W, E, w5, \
-                       w3, wv, wh, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, cf, dw5, dw3, dwv, dwh, strips, segs, seg_rows, chunks))
+#define LMN_DWB2(PT, Z) LMN_ACT_DISPATCH(act_dtype, LMN_LAUNCH((dw_bwd_strip_kernel<T, PT, Z>), dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, (const T*)x1, (const T*)dpre, (T*)dx1, B, H, W, E, w5, \
+                       w3, wv, wh, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, cf, dw5, dw3, dwv, dwh, DwPreS{zp.A, zp.shift}, hstats, strips, segs, seg_rows, chunks))
+#define LMN_DWB(PT) do { if (zp.A) LMN_DWB2(PT, true); else LMN_DWB2(PT, false); } while (0)
     if (part == 1) { LMN_DWB(1); } else if (part == 2) { LMN_DWB(2); } else { LMN_DWB(0); }
+#undef LMN_DWB2
 #undef LMN_DWB
     return lmn_launch_status("dw_bwd_bn");
   };

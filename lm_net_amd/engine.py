@@ -149,6 +149,9 @@ class Engine:
         self.split_se = os.environ.get("LMN_SE_SPLIT", "1") != "0"   # SE backward in two launches (parameter gradients on the side stream)
         # squeeze-excite gate / its backward formed inside the depthwise passes (no se_fwd / se_bwd_dm launches; LMN_FUSE_SE=0: A/B)
         self.fuse_se = int(os.environ.get("LMN_FUSE_SE", "3"))      # bit 0: forward gate, bit 1: backward
+        # z-path of ReparamConv (include/lmnet_hip.h, lmn_dw_pre_t / lmn_reparam_fold): the expand conv's BatchNorm + Hardswish
+        # applied inside the depthwise kernels, its backward folded into the weights of one three-source conv (LMN_ZPATH=0: A/B)
+        self.zpath = os.environ.get("LMN_ZPATH", "1") != "0"
         self.zpool_fwd, self.zpool_bwd = ZeroPool(), ZeroPool()
         self.packs_fwd, self.packs_bwd = hip.PackPlan(), hip.PackPlan()
         self.mma = hip.F32        # matrix-core operand type of the dense contractions of the pass (hip.F32 | hip.BF16)
@@ -376,7 +379,22 @@ class Engine:
         ec, ebn = m.expand_conv[0], m.expand_conv[1]
         wpe = hip.conv_pack(ec.weight, 1, [x.shape[-1]])   # (a 3-channel weight on the NHWC4 input: zero column packed)
         x1 = _A(x, B, H, W, E)
-        if self.training and self.fuse_bn:
+        zpath = self.training and self.fuse_bn and self.zpath and not m.deploy
+        zp = None
+        if zpath:
+            # z-path: ONE pass writes z = conv(x) + bias and its batch sums; the depthwise kernels form x1 = Hardswish(A1 z + sh1)
+            # themselves when they stage their rows (lmn_dw_pre_t), the first of them (lmn_dw_stats) finalises the BatchNorm --
+            # no statistics-only conv, no second read of x (x1 below HOLDS z)
+            sums1 = _Z(x, STATS_REP + 1, 2, E)
+            hip.conv_fwd([x], wpe, x1, B=B, Hin=H, Win=W, Hout=H, Wout=W, Cout=E, bias=ec.bias, stats=sums1,
+                         stats_mode=hip.STATS_SUM_SQ, stats_rep=STATS_REP, stats_snap=True,
+                         p=(None, None, None, None, ebn.running_mean))
+            mean1, rstd1, A1, sh1 = (_E(x, E) for _ in range(4))
+            zfin = dict(mode=hip.FIN_BN, sums=sums1, nrep=STATS_REP, count=N, gamma=ebn.weight, beta=ebn.bias, eps=ebn.eps,
+                        momentum=ebn.momentum if ebn.momentum is not None else 0.1, about=sums1[STATS_REP, 0],
+                        mean=mean1, rstd=rstd1, A=A1, shift=sh1, rmean=ebn.running_mean, rvar=ebn.running_var)
+            zp = dict(A=A1, shift=sh1)
+        elif self.training and self.fuse_bn:
             # statistics pass (sums about the running mean, whose snapshot lands behind the slices), then the applying pass
             # forms mean / rstd / A / shift itself (lmn_bn_fin_t): no lmn_bn_finalize launch in between
             sums1 = _Z(x, STATS_REP + 1, 2, E)
@@ -409,7 +427,7 @@ class Engine:
             st2 = None
             if self.training:
                 st2 = _Z(x, 4, 2, E)
-                hip.dw_stats(x1, *ws, st2)
+                hip.dw_stats(x1, *ws, st2, zpre=dict(fin=zfin) if zpath else None)
             keff = beff = None
             if self.training and self.fuse_bn:
                 pass            # finalize + merge happen inside the depthwise pass itself (hip.dw_fwd_bn below)
@@ -431,7 +449,7 @@ class Engine:
         sef = dict(ticket=_Z(x, B), fc1w=se.fc1.weight, fc1b=se.fc1.bias, fc2w=se.fc2.weight, fc2b=se.fc2.bias, s=sgate,
                    hidden=hid, inv_hw=1.0 / (H * W)) if (self.fuse_se & 1) else None
         if keff is None:
-            hip.dw_fwd_bn(x1, pre, gsum, st2, N, [b.bn for b in brs], ws, bmean, brstd, bA, se=sef)
+            hip.dw_fwd_bn(x1, pre, gsum, st2, N, [b.bn for b in brs], ws, bmean, brstd, bA, se=sef, zpre=zp)
         else:
             hip.dw_fwd(x1, pre, gsum, keff, beff, se=sef)
         if sef is None:
@@ -444,7 +462,7 @@ class Engine:
                      Cout=Cout, bias=m.pointwise_conv[0].bias, bias2=m.shortcut[0].bias)
         if cx is not None:
             cx.t[m] = dict(x=x, x1=x1, pre=pre, gsum=gsum, s=sgate, hid=hid, wpe=wpe, mean1=mean1, rstd1=rstd1, A1=A1,
-                           bmean=bmean, brstd=brstd, bA=bA)
+                           bmean=bmean, brstd=brstd, bA=bA, zp=zp)        # (zp: x1 holds z, the z-path)
         return y
 
     @staticmethod
@@ -529,12 +547,40 @@ class Engine:
         ws = [b.conv.weight for b in brs]
         dpre = _A(x, B, H, W, E)
         bst = _Z(x, 5, E)
-        hip.dw_bwd_stats(x1, pre, u, sgate, dm, dpre, *ws, bst, seb=seb)
+        zp = S.get("zp")
+        hip.dw_bwd_stats(x1, pre, u, sgate, dm, dpre, *ws, bst, seb=seb, zpre=zp)
         if seb is not None:
             gs_, hid_ = S["gsum"], S["hid"]
             self.side_call(x, lambda: hip.se_bwd_params(dvec, gs_, 1.0 / (H * W), hid_, G[se.fc1.weight], G[se.fc1.bias],
                                                         G[se.fc2.weight], G[se.fc2.bias]), keep=(dvec, gs_, hid_))
         dx1 = u  # reuse
+        if zp is not None:
+            # ---- z-path: the depthwise backward writes dh = dx1 * Hardswish'(A1 z + sh1) and its BatchNorm-backward sums; ONE tiny
+            # launch folds the BatchNorm backward into the operators of ONE conv over (dh, x, dy) -> dx.  The weight gradient's
+            # dz = a dh + b z + c is materialised beside the critical path.
+            hst = _Z(x, 2, E)
+            hip.dw_bwd_bn(x1, dpre, dx1, *ws, bst, S["bmean"], S["brstd"], S["bA"], N, self.training,
+                          [G[b.bn.weight] for b in brs], [G[b.bn.bias] for b in brs], *[G[w] for w in ws], zpre=zp, hstats=hst)
+            dh = dx1
+            cdy = self._c(dy)
+            wp3 = _E(x, hip.conv_pack_size(1, Cin, [E, Cin, cdy]))
+            kb, coef = _E(x, Cin), _E(x, 3, E)
+            hip.reparam_fold(hst, S["mean1"], S["rstd1"], S["A1"], N, self.training, ec.weight, ec.bias, sc.weight, Cin, cdy,
+                             wp3, kb, coef, G[ebn.weight], G[ebn.bias])
+            dz = dpre  # (reuse: its last reader on this stream was the depthwise backward)
+            z_ = x1
+            self.side_call(x, lambda: hip.affine2(dh, z_, coef, dz), keep=(dh, z_, coef, dz))
+            if cw == Cin:
+                self.wgrad([x], dz, ec.weight, ec.bias, Hin=H, Win=W)
+            else:
+                dWp = _Z(x, E, Cin)
+                self.wgrad([x], dz, None, None, Hin=H, Win=W, dW=dWp, db=G[ec.bias])
+                hip.copy2d(dWp, G[ec.weight], E, cw, Cin, cw)         # un-pad (layout copy)
+            if not need_dx:
+                return None
+            dx = _A(x, B, H, W, Cin)
+            hip.conv_fwd([dh, x, dy], wp3, dx, B=B, Hin=H, Win=W, Hout=H, Wout=W, Cout=Cin, bias=kb)
+            return dx
         split = self.fuse_bn and self.split_dw and self.overlap_wgrad and not self.capturing
         if split:
             # dx1 (critical path) on this stream, the four weight gradients of the same pass on the side stream: the halves share

@@ -60,6 +60,31 @@ class WgradArgs(C.Structure):
                 ("defer_reduce", C.c_int32), ("_pad", C.c_int32)]
 
 
+class DwPre(C.Structure):
+    """Mirror of lmn_dw_pre_t (z-path of ReparamConv: the depthwise kernels form x1 = Hardswish(A z + shift) themselves)."""
+    _fields_ = [("A", C.c_void_p), ("shift", C.c_void_p), ("fin", BnFin)]
+
+
+def _fill_fin(f, fin):
+    f.mode, f.nrep, f.count = fin["mode"], fin["nrep"], float(fin["count"])
+    f.eps, f.momentum, f.batch_stats = float(fin.get("eps", 0.0)), float(fin.get("momentum", 0.0)), int(fin.get("batch_stats", 1))
+    for k in ("sums", "gamma", "beta", "about", "mean", "rstd", "A", "shift", "rmean", "rvar", "Ain", "dgamma", "dbeta"):
+        t = fin.get(k)
+        setattr(f, k, t.data_ptr() if t is not None else None)
+
+
+def _dw_pre(zpre):
+    """zpre: None | dict(A=, shift=) | dict(fin=dict(...)) (lmn_dw_stats only: A / shift are formed from the batch sums)"""
+    if zpre is None:
+        return None
+    p = DwPre()
+    if zpre.get("fin") is not None:
+        _fill_fin(p.fin, zpre["fin"])
+    else:
+        p.A, p.shift = _p(zpre["A"]).value, _p(zpre["shift"]).value
+    return C.byref(p)
+
+
 class SeFuse(C.Structure):
     """Mirror of lmn_se_fuse_t."""
     _fields_ = [("ticket", C.c_void_p), ("w1", C.c_void_p), ("b1", C.c_void_p), ("w2", C.c_void_p), ("b2", C.c_void_p),
@@ -99,7 +124,7 @@ class ReduceJob(C.Structure):
 SYMBOLS = [
     "lmn_abi_version", "lmn_sizeof_conv_args", "lmn_sizeof_src", "lmn_sizeof_wgrad_args", "lmn_last_error",
     "lmn_conv_pack_size", "lmn_conv_pack", "lmn_conv_pack_batch", "lmn_sizeof_pack_job", "lmn_conv_fwd", "lmn_conv_wgrad", "lmn_conv_wgrad_workspace",
-    "lmn_conv_wgrad_job", "lmn_wgrad_reduce_batch", "lmn_sizeof_reduce_job",
+    "lmn_conv_wgrad_job", "lmn_wgrad_reduce_batch", "lmn_sizeof_reduce_job", "lmn_reparam_fold", "lmn_affine2",
     "lmn_dw_stats", "lmn_dw_fwd", "lmn_dw_merge", "lmn_dw_finalize_merge", "lmn_dw_bwd_stats", "lmn_dw_bwd_coef", "lmn_dw_bwd", "lmn_dw_fwd_bn", "lmn_dw_bwd_bn",
     "lmn_se_fwd", "lmn_se_bwd", "lmn_se_bwd_dm", "lmn_se_bwd_params", "lmn_na_fwd", "lmn_na_bwd", "lmn_gattn_fwd", "lmn_gattn_bwd",
     "lmn_ln_fwd", "lmn_ln_bwd", "lmn_bnact_fwd", "lmn_bnact_bwd_stats", "lmn_bnact_bwd",
@@ -400,12 +425,7 @@ def conv_fwd(srcs, wpack, out, *, B, Hin, Win, Hout, Wout, Cout, ksize=1, stride
     a.stats_rep = stats_rep
     a.stats_snap = int(bool(stats_snap))
     if fin is not None:
-        f = a.fin
-        f.mode, f.nrep, f.count = fin["mode"], fin["nrep"], float(fin["count"])
-        f.eps, f.momentum, f.batch_stats = float(fin.get("eps", 0.0)), float(fin.get("momentum", 0.0)), int(fin.get("batch_stats", 1))
-        for k in ("sums", "gamma", "beta", "about", "mean", "rstd", "A", "shift", "rmean", "rvar", "Ain", "dgamma", "dbeta"):
-            t = fin.get(k)
-            setattr(f, k, t.data_ptr() if t is not None else None)
+        _fill_fin(a.fin, fin)
     a.epilogue, a.act, a.stats_mode = epilogue, act, stats_mode
     a.drop_p, a.drop_seed = drop_p, drop_seed
     a.mma_dtype = _MMA[0]
@@ -516,9 +536,10 @@ def _workspace(device, nfloats):
 
 
 # ------------------------------------------------------------------------------------------ depthwise block
-def dw_stats(x1, w5, w3, wv, wh, stats):
+def dw_stats(x1, w5, w3, wv, wh, stats, zpre=None):
+    """zpre: the tensor is z (z-path, see _dw_pre); with zpre['fin'] the expand conv's BatchNorm is finalised here."""
     B, H, W, E = x1.shape
-    _check(load().lmn_dw_stats(_pa(x1), B, H, W, E, _p(w5), _p(w3), _p(wv), _p(wh), _p(stats), _dt(x1), _stream()), "dw_stats")
+    _check(load().lmn_dw_stats(_pa(x1), B, H, W, E, _p(w5), _p(w3), _p(wv), _p(wh), _p(stats), _dw_pre(zpre), _dt(x1), _stream()), "dw_stats")
 
 
 def dw_merge(w5, w3, wv, wh, A, shift, keff, beff):
@@ -526,10 +547,10 @@ def dw_merge(w5, w3, wv, wh, A, shift, keff, beff):
                                _stream()), "dw_merge")
 
 
-def dw_fwd(x1, pre, gsum, keff, beff, se=None):
-    """se: squeeze-excite gate formed inside the pass (see _se_fuse), or None."""
+def dw_fwd(x1, pre, gsum, keff, beff, se=None, zpre=None):
+    """se: squeeze-excite gate formed inside the pass (see _se_fuse), or None; zpre: the tensor is z (see _dw_pre)."""
     B, H, W, E = x1.shape
-    _check(load().lmn_dw_fwd(_pa(x1), _pa(pre), _p(gsum), B, H, W, E, _p(keff), _p(beff), _se_fuse(se), _dt(x1, pre), _stream()), "dw_fwd")
+    _check(load().lmn_dw_fwd(_pa(x1), _pa(pre), _p(gsum), B, H, W, E, _p(keff), _p(beff), _se_fuse(se), _dw_pre(zpre), _dt(x1, pre), _stream()), "dw_fwd")
 
 
 def dw_finalize_merge(stats, count, bns, ws, mean, rstd, A, keff, beff):
@@ -545,7 +566,7 @@ def dw_finalize_merge(stats, count, bns, ws, mean, rstd, A, keff, beff):
         "dw_finalize_merge")
 
 
-def dw_fwd_bn(x1, pre, gsum, stats, count, bns, ws, mean, rstd, A, se=None):
+def dw_fwd_bn(x1, pre, gsum, stats, count, bns, ws, mean, rstd, A, se=None, zpre=None):
     """dw_finalize_merge + dw_fwd in one launch (training): bns / ws as in dw_finalize_merge."""
     P4 = C.c_void_p * 4
     F4 = C.c_float * 4
@@ -555,20 +576,22 @@ def dw_fwd_bn(x1, pre, gsum, stats, count, bns, ws, mean, rstd, A, se=None):
         P4(*[b.bias.data_ptr() for b in bns]), P4(*[b.running_mean.data_ptr() for b in bns]),
         P4(*[b.running_var.data_ptr() for b in bns]), F4(*[b.eps for b in bns]),
         F4(*[(b.momentum if b.momentum is not None else 0.1) for b in bns]), _p(ws[0]), _p(ws[1]), _p(ws[2]), _p(ws[3]),
-        _p(mean), _p(rstd), _p(A), _se_fuse(se), _dt(x1, pre), _stream()), "dw_fwd_bn")
+        _p(mean), _p(rstd), _p(A), _se_fuse(se), _dw_pre(zpre), _dt(x1, pre), _stream()), "dw_fwd_bn")
 
 
-def dw_bwd_bn(x1, dpre, dx1, w5, w3, wv, wh, bstats, mean, rstd, A, count, batch_stats, dgs, dbs, dw5, dw3, dwv, dwh, part=0):
-    """dw_bwd_coef + dw_bwd in one launch (part 1: dx1 + gamma / beta gradients only, part 2: the weight gradients only)."""
+def dw_bwd_bn(x1, dpre, dx1, w5, w3, wv, wh, bstats, mean, rstd, A, count, batch_stats, dgs, dbs, dw5, dw3, dwv, dwh, part=0,
+              zpre=None, hstats=None):
+    """dw_bwd_coef + dw_bwd in one launch (part 1: dx1 + gamma / beta gradients only, part 2: the weight gradients only).
+    zpre / hstats: z-path -- x1 is z, `dx1` receives dh = dx1 * Hardswish'(A z + shift), hstats [2][E] += (sum dh, sum dh z)."""
     P4 = C.c_void_p * 4
     B, H, W, E = x1.shape
     _check(load().lmn_dw_bwd_bn(_pa(x1), _pa(dpre), _pa(dx1), B, H, W, E, _p(w5), _p(w3), _p(wv), _p(wh), _p(bstats), _p(mean),
                                 _p(rstd), _p(A), _f(count), int(batch_stats), P4(*[t.data_ptr() for t in dgs]),
-                                P4(*[t.data_ptr() for t in dbs]), _p(dw5), _p(dw3), _p(dwv), _p(dwh), part, _dt(x1, dpre, dx1),
-                                _stream()), "dw_bwd_bn")
+                                P4(*[t.data_ptr() for t in dbs]), _p(dw5), _p(dw3), _p(dwv), _p(dwh), part, _dw_pre(zpre),
+                                _p(hstats), _dt(x1, dpre, dx1), _stream()), "dw_bwd_bn")
 
 
-def dw_bwd_stats(x1, pre, u, s, dm, dpre, w5, w3, wv, wh, bstats, seb=None):
+def dw_bwd_stats(x1, pre, u, s, dm, dpre, w5, w3, wv, wh, bstats, seb=None, zpre=None):
     """seb: dict(ds, fc1w, fc2w, hidden, dvec, inv_hw) -- the squeeze-excite backward formed inside the pass (dm may be None)."""
     B, H, W, E = x1.shape
     sb = None
@@ -578,7 +601,7 @@ def dw_bwd_stats(x1, pre, u, s, dm, dpre, w5, w3, wv, wh, bstats, seb=None):
         f.inv_hw, f.R = float(seb["inv_hw"]), seb["fc1w"].shape[0]
         sb = C.byref(f)
     _check(load().lmn_dw_bwd_stats(_pa(x1), _pa(pre), _pa(u), _p(s), _p(dm), _pa(dpre), B, H, W, E, _p(w5), _p(w3), _p(wv),
-                                   _p(wh), _p(bstats), sb, _dt(x1, pre, u, dpre), _stream()), "dw_bwd_stats")
+                                   _p(wh), _p(bstats), sb, _dw_pre(zpre), _dt(x1, pre, u, dpre), _stream()), "dw_bwd_stats")
 
 
 def dw_bwd_coef(bstats, mean, rstd, A, count, batch_stats, cA, cC, cD, dgs, dbs):
@@ -781,6 +804,21 @@ def preprocess_u8(images, masks, flips, out, labels, mean, std):
 def adamw_step(p, g, m, v, lr, beta1, beta2, eps, weight_decay, bias_corr1, bias_corr2):
     _check(load().lmn_adamw_step(_p(p), _p(g), _p(m), _p(v), _i64(p.numel()), _f(lr), _f(beta1), _f(beta2), _f(eps),
                                  _f(weight_decay), _f(bias_corr1), _f(bias_corr2), _stream()), "adamw_step")
+
+
+def reparam_fold(hstats, mean, rstd, A, count, batch_stats, w_expand, b_expand, w_shortcut, rows, cred, wpack, kbias, coef, dgamma,
+                 dbeta):
+    """lmn_reparam_fold: BatchNorm backward of the expand conv folded into the packed operators of ONE three-source conv."""
+    E, cinw = w_expand.shape[0], w_expand.shape[1]
+    _check(load().lmn_reparam_fold(_p(hstats), _p(mean), _p(rstd), _p(A), _f(count), int(batch_stats), _p(w_expand), _p(b_expand),
+                                   _p(w_shortcut), E, rows, cinw, cred, w_shortcut.shape[0], _p(wpack), _p(kbias), _p(coef),
+                                   _p(dgamma), _p(dbeta), _MMA[0], _stream()), "reparam_fold")
+
+
+def affine2(u, v, coef, y):
+    """y = coef[0] * u + coef[1] * v + coef[2] per channel (activation tensors of shape [..., C])."""
+    Cn = u.shape[-1]
+    _check(load().lmn_affine2(_pa(u), _pa(v), _p(coef), _pa(y), _i64(u.numel() // Cn), Cn, _dt(u, v, y), _stream()), "affine2")
 
 
 def fill(t, v):

@@ -381,6 +381,114 @@ def check_dw():
     return rows
 
 
+def check_zpath():
+    """z-path of ReparamConv (lmn_dw_pre_t, lmn_reparam_fold, lmn_affine2): the depthwise kernels fed z + (A, shift) must reproduce
+    what they compute from x1 = Hardswish(A z + shift); the depthwise backward's drain must deliver dh and its sums; the folded
+    three-source conv must equal the BatchNorm backward + both data gradients of the reference graph (fp64)."""
+    rows = []
+    for (B, H, W, Cin, E, Cout) in [(2, 20, 19, 12, 24, 12), (1, 33, 17, 24, 48, 24), (2, 9, 61, 4, 8, 12), (1, 70, 130, 12, 24, 12)]:
+        tag = " Cin=%d E=%d %dx%d" % (Cin, E, H, W)
+        N = B * H * W
+        x = R(B, Cin, H, W, seed=201)
+        we, be = R(E, Cin, seed=202, scale=0.5), R(E, seed=203, scale=0.2)
+        ga, bt = R(E, seed=204).abs() + 0.5, R(E, seed=205) * 0.3
+        wsc = R(Cout, Cin, seed=206, scale=0.5)
+        ws = [R(E, 1, 5, 5, seed=52, scale=0.2), R(E, 1, 3, 3, seed=53, scale=0.3), R(E, 1, 3, 1, seed=54, scale=0.5), R(E, 1, 1, 3, seed=55, scale=0.5)]
+        # ---- fp64 reference graph: z -> BN (batch stats) -> hswish -> x1 ; loss through x1 with a given dx1 ; shortcut through dy
+        xr = x.clone().requires_grad_(True)
+        wer, ber, gar, btr = (t.clone().requires_grad_(True) for t in (we, be, ga, bt))
+        z = F.conv2d(xr, wer.view(E, Cin, 1, 1), ber)
+        mu, var = z.mean((0, 2, 3)), z.var((0, 2, 3), unbiased=False)
+        rstd = 1.0 / torch.sqrt(var + 1e-5)
+        A1, sh1 = (gar * rstd), (btr - mu * gar * rstd)
+        h = z * A1.view(1, E, 1, 1) + sh1.view(1, E, 1, 1)
+        x1 = F.hardswish(h)
+        dx1 = R(B, E, H, W, seed=207)
+        dy = R(B, Cout, H, W, seed=208)
+        ((x1 * dx1).sum() + (F.conv2d(xr, wsc.view(Cout, Cin, 1, 1)) * dy).sum()).backward()
+        zd, x1d = nhwc(z.detach()), nhwc(x1.detach())
+        A1d, sh1d = dev(A1.detach()), dev(sh1.detach())
+        wd = [dev(w) for w in ws]
+        zp = dict(A=A1d, shift=sh1d)
+        # ---- forward-side kernels: z + transform == x1
+        st_a, st_b = torch.zeros(4, 2, E, device=DEV), torch.zeros(4, 2, E, device=DEV)
+        hip.dw_stats(x1d, *wd, st_a)
+        hip.dw_stats(zd, *wd, st_b, zpre=zp)
+        rows.append(("dw_stats z-path" + tag, rel(st_b, st_a), 2e-5))
+        # ... with the BatchNorm finalised inside (fin): sums of z about a shift, 3 slices
+        about = dev(R(E, seed=209) * 0.1)
+        zc = z.detach() - about.double().cpu().view(1, E, 1, 1)
+        sl = torch.zeros(3, 2, E, dtype=torch.float64)
+        sl[0, 0], sl[0, 1] = zc.sum((0, 2, 3)) * 0.25, (zc * zc).sum((0, 2, 3)) * 0.5
+        sl[1, 0], sl[1, 1] = zc.sum((0, 2, 3)) * 0.75, (zc * zc).sum((0, 2, 3)) * 0.25
+        sl[2, 1] = (zc * zc).sum((0, 2, 3)) * 0.25
+        rm, rv = dev(R(E, seed=210) * 0.2), dev(R(E, seed=211).abs() + 0.5)
+        rm0, rv0 = rm.clone(), rv.clone()
+        mo, ro, Ao, so = (torch.full((E,), float("nan"), device=DEV) for _ in range(4))
+        st_c = torch.zeros(4, 2, E, device=DEV)
+        fin = dict(mode=hip.FIN_BN, sums=dev(sl), nrep=3, count=N, gamma=dev(ga), beta=dev(bt), eps=1e-5, momentum=0.1, about=about,
+                   mean=mo, rstd=ro, A=Ao, shift=so, rmean=rm, rvar=rv)
+        hip.dw_stats(zd, *wd, st_c, zpre=dict(fin=fin))
+        rows.append(("dw_stats z-path + BN finalise: sums" + tag, rel(st_c, st_a), 1e-4))
+        rows.append(("dw_stats z-path + BN finalise: A / shift / mean / rstd" + tag,
+                     max(rel(Ao, A1), rel(so, sh1), rel(mo, mu), rel(ro, rstd)), 1e-5))
+        rows.append(("dw_stats z-path + BN finalise: running stats" + tag,
+                     max(rel(rm, 0.9 * rm0.double().cpu() + 0.1 * mu.detach()), rel(rv, 0.9 * rv0.double().cpu() + 0.1 * var.detach() * N / (N - 1))), 1e-5))
+        keff, beff = dev(R(E, 25, seed=212, scale=0.2)), dev(R(E, seed=213) * 0.1)
+        pa, pb = torch.full((B, H, W, E), float("nan"), device=DEV), torch.full((B, H, W, E), float("nan"), device=DEV)
+        ga_, gb_ = torch.zeros(B, E, device=DEV), torch.zeros(B, E, device=DEV)
+        hip.dw_fwd(x1d, pa, ga_, keff, beff)
+        hip.dw_fwd(zd, pb, gb_, keff, beff, zpre=zp)
+        rows.append(("dw_fwd z-path" + tag, max(rel(pb, pa), rel(gb_, ga_)), 2e-5))
+        u, sg, dm = nhwc(R(B, E, H, W, seed=214)), dev(R(B, E, seed=215).abs()), dev(R(B, E, seed=216) * 0.01)
+        da_, db_ = torch.full((B, H, W, E), float("nan"), device=DEV), torch.full((B, H, W, E), float("nan"), device=DEV)
+        ba_, bb_ = torch.zeros(5, E, device=DEV), torch.zeros(5, E, device=DEV)
+        hip.dw_bwd_stats(x1d, pa, u, sg, dm, da_, *wd, ba_)
+        hip.dw_bwd_stats(zd, pa, u, sg, dm, db_, *wd, bb_, zpre=zp)
+        rows.append(("dw_bwd_stats z-path" + tag, max(rel(db_, da_), rel(bb_, ba_)), 2e-5))
+        # ---- depthwise backward: dx1 from x1 (old) vs dh + sums from z (new)
+        bm, br_, bA = dev(R(4, E, seed=217) * 0.1), dev(R(4, E, seed=218).abs() + 0.5), dev(R(4, E, seed=219).abs() + 0.3)
+        bst = dev(R(5, E, seed=220))
+        dgs, dbs = [torch.zeros(E, device=DEV) for _ in range(4)], [torch.zeros(E, device=DEV) for _ in range(4)]
+        dws = [torch.zeros_like(w) for w in wd]
+        dxo = torch.full((B, H, W, E), float("nan"), device=DEV)
+        hip.dw_bwd_bn(x1d, da_, dxo, *wd, bst, bm, br_, bA, N, True, dgs, dbs, *dws)
+        dgs2, dbs2 = [torch.zeros(E, device=DEV) for _ in range(4)], [torch.zeros(E, device=DEV) for _ in range(4)]
+        dws2 = [torch.zeros_like(w) for w in wd]
+        dhz, hst = torch.full((B, H, W, E), float("nan"), device=DEV), torch.zeros(2, E, device=DEV)
+        hip.dw_bwd_bn(zd, da_, dhz, *wd, bst, bm, br_, bA, N, True, dgs2, dbs2, *dws2, zpre=zp, hstats=hst)
+        hd = nhwc(h.detach()).double().cpu()
+        dhs = torch.where(hd < -3, torch.zeros_like(hd), torch.where(hd <= 3, hd / 3 + 0.5, torch.ones_like(hd)))
+        dh_ref = dxo.double().cpu() * dhs
+        rows.append(("dw_bwd_bn z-path dh" + tag, rel(dhz, dh_ref), 2e-5))
+        rows.append(("dw_bwd_bn z-path sums (dh, dh z)" + tag,
+                     rel(hst, torch.stack([dh_ref.sum((0, 1, 2)), (dh_ref * zd.double().cpu()).sum((0, 1, 2))])), 2e-4))
+        rows.append(("dw_bwd_bn z-path weight gradients" + tag, max(rel(a_, b_) for a_, b_ in zip(dws2 + dgs2, dws + dgs)), 2e-5))
+        # ---- fold: dh := the reference's gradient w.r.t. the BatchNorm output, sums from fp64
+        dh64 = (dx1 * torch.where(h.detach() < -3, torch.zeros_like(h), torch.where(h.detach() <= 3, h.detach() / 3 + 0.5, torch.ones_like(h))).detach())
+        hst64 = torch.stack([dh64.sum((0, 2, 3)), (dh64 * z.detach()).sum((0, 2, 3))])
+        rows_c = (Cin + 3) // 4 * 4
+        n3 = hip.conv_pack_size(1, rows_c, [E, rows_c, Cout])
+        wp3, kb, coef = torch.full((n3,), float("nan"), device=DEV), torch.full((rows_c,), float("nan"), device=DEV), torch.full((3, E), float("nan"), device=DEV)
+        dg, dbt = torch.zeros(E, device=DEV), torch.zeros(E, device=DEV)
+        hip.reparam_fold(dev(hst64), dev(mu.detach()), dev(rstd.detach()), A1d, N, True, dev(we), dev(be), dev(wsc), rows_c, Cout, wp3, kb, coef, dg, dbt)
+        rows.append(("reparam_fold dgamma / dbeta" + tag, max(rel(dg, gar.grad), rel(dbt, btr.grad)), 2e-4))
+        xin = x if rows_c == Cin else torch.cat([x, torch.zeros(B, rows_c - Cin, H, W, dtype=x.dtype)], 1)
+        dxo3 = torch.full((B, H, W, rows_c), float("nan"), device=DEV)
+        hip.conv_fwd([nhwc(dh64), nhwc(xin), nhwc(dy)], wp3, dxo3, B=B, Hin=H, Win=W, Hout=H, Wout=W, Cout=rows_c, bias=kb)
+        rows.append(("reparam_fold + three-source conv: dx" + tag, rel(nchw(dxo3)[:, :Cin], xr.grad), TOL))
+        dzo = torch.full((B, H, W, E), float("nan"), device=DEV)
+        hip.affine2(nhwc(dh64), zd, coef, dzo)
+        # dz of the reference: BatchNorm backward in closed form (fp64)
+        T = ((dh64 * ((z.detach() - mu.detach().view(1, E, 1, 1)) * rstd.detach().view(1, E, 1, 1))).sum((0, 2, 3)))
+        dz64 = A1.detach().view(1, E, 1, 1) * (dh64 - hst64[0].view(1, E, 1, 1) / N
+                                              - (z.detach() - mu.detach().view(1, E, 1, 1)) * rstd.detach().view(1, E, 1, 1) * T.view(1, E, 1, 1) / N)
+        rows.append(("affine2 dz" + tag, rel(nchw(dzo), dz64), TOL))
+        rows.append(("dz -> expand weight gradient (reference)" + tag,
+                     rel(torch.einsum("behw,bchw->ec", dz64, x), wer.grad), 1e-9))
+    return rows
+
+
 def check_se():
     rows = []
     for cfg in ((3, 24, 6, 35), (8, 192, 48, 121), (30, 192, 48, 64)):   # the last one: the per-image kernel (batch too large for one block)
