@@ -499,6 +499,12 @@ int lmn_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, floa
                    float eps, float weight_decay, float bias_corr1, float bias_corr2, lmn_stream_t stream);
 int lmn_fill(float* p, float v, int64_t n, lmn_stream_t stream);
 /* y = a + b (+ c) (+ d); any of c,d may be NULL; y may alias a */
+/* Weight / bias gradient of the expand conv on the z-path WITHOUT materialising dz (no lmn_affine2 pass, no second read of z):
+ *   dW_e += diag(a) R + diag(b) (W_e M + b_e m^T) + c m^T ;  db_e += a S0 + b (W_e m + N b_e) + c N
+ * R [E][rows] = sum dh x^T (lmn_conv_wgrad over (x, dh)); M [rows][rows] = sum x x^T, m [rows] = sum x (lmn_conv_wgrad over (x, x),
+ * issued once in the forward); coef [3][E] and hstats from lmn_reparam_fold / lmn_dw_bwd_bn.  dW [E][cin_w], db [E] (or NULL). */
+int lmn_reparam_wfin(const float* R, const float* M, const float* m, const float* coef, const float* hstats, const float* w_expand,
+                     const float* b_expand, float count, int E, int rows, int cin_w, float* dW, float* db, lmn_stream_t stream);
 /* y[p][c] = coef[0][c] * u[p][c] + coef[1][c] * v[p][c] + coef[2][c]  over `rows` pixels of C channels (activation tensors):
  * dz = a * dh + b * z + c of the z-path (lmn_reparam_fold), materialised beside the critical path for the weight gradient */
 int lmn_affine2(const void* u, const void* v, const float* coef, void* y, int64_t rows, int C, int act_dtype, lmn_stream_t stream);

@@ -300,7 +300,7 @@ class LM_Net(nn.Module):
                     if not ok:
                         self._drop_plan(ps)
                 ps.out, ps.fwd = out, plan              # (assigned only once the recording is complete)
-                ps.keep = [eng.packs_fwd.table, eng.packs_bwd.table]     # device job tables the recorded pack launches read
+                ps.keep = [eng.packs_fwd.table, eng.packs_bwd.table] + list(eng.reduce_tabs)    # device job tables the recorded launches read
             else:
                 ps.x.copy_(x)
                 self._step_bookkeeping()
@@ -479,6 +479,7 @@ class LM_Net(nn.Module):
             eng.begin_pass(False, x.device)
             try:
                 out = self._forward_body(x, cx)
+                eng.flush_reduce(x.device)        # (weight-gradient-style launches of the forward: the moments of the z-path)
             finally:
                 nf = eng.alloc_floats
                 eng.end_pass()

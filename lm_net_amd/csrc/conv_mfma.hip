@@ -1112,6 +1112,30 @@ __global__ __launch_bounds__(256) void reparam_fold_kernel(const FoldParams P) {
   }
 }
 
+// Weight / bias gradient of the expand conv on the z-path without materialising dz = a dh + b z + c:
+//   dW_e = sum_p dz x^T = diag(a) R + diag(b) (W_e M + b_e m^T) + c m^T,   R = sum dh x^T (the raw weight gradient),
+//   M = sum x x^T, m = sum x (one weight-gradient launch over x alone, in the forward), since z = W_e x + b_e;
+//   db_e = a S0 + b (W_e m + N b_e) + c N   (zero up to rounding under batch statistics, as in the reference's autograd).
+__global__ __launch_bounds__(256) void reparam_wfin_kernel(const float* __restrict__ R, const float* __restrict__ M,
+                                                           const float* __restrict__ m, const float* __restrict__ coef,
+                                                           const float* __restrict__ hstats, const float* __restrict__ we,
+                                                           const float* __restrict__ be, float count, int E, int rows, int cinw,
+                                                           float* __restrict__ dW, float* __restrict__ db) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= E * (cinw + 1)) return;
+  const int e = i / (cinw + 1), c = i - e * (cinw + 1);
+  const float a = coef[e], b = coef[E + e], k = coef[2 * E + e];
+  if (c < cinw) {
+    float zx = be[e] * m[c];
+    for (int j = 0; j < cinw; ++j) zx += we[(int64_t)e * cinw + j] * M[(int64_t)j * rows + c];
+    dW[(int64_t)e * cinw + c] += a * R[(int64_t)e * rows + c] + b * zx + k * m[c];
+  } else if (db) {
+    float zs = count * be[e];
+    for (int j = 0; j < cinw; ++j) zs += we[(int64_t)e * cinw + j] * m[j];
+    db[e] += a * hstats[e] + b * zs + k * count;
+  }
+}
+
 // ------------------------------------------------------------------------------------ weight gradient
 struct WgradParams {
   lmn_wgrad_args_t a;
@@ -2951,6 +2975,16 @@ int lmn_reparam_fold(const float* hstats, const float* mean, const float* rstd, 
   LMN_REQUIRE((size_t)35 * E * sizeof(float) <= 64 * 1024, "reparam_fold: E = %d too wide for the block's scratch", E);
   LMN_LAUNCH(reparam_fold_kernel, dim3(ntiles + 1), dim3(256), (size_t)35 * E * sizeof(float), (hipStream_t)stream, P);
   return lmn_launch_status("reparam_fold");
+}
+
+int lmn_reparam_wfin(const float* R, const float* M, const float* m, const float* coef, const float* hstats, const float* w_expand,
+                     const float* b_expand, float count, int E, int rows, int cin_w, float* dW, float* db, lmn_stream_t stream) {
+  LMN_REC(lmn_reparam_wfin(R, M, m, coef, hstats, w_expand, b_expand, count, E, rows, cin_w, dW, db, stream));
+  LMN_REQUIRE(R && M && m && coef && hstats && w_expand && b_expand && dW && E > 0 && rows >= cin_w && cin_w > 0 && count > 0.f,
+              "reparam_wfin: bad argument");
+  LMN_LAUNCH(reparam_wfin_kernel, dim3(lmn_cdiv((int64_t)E * (cin_w + 1), 256)), dim3(256), 0, (hipStream_t)stream, R, M, m, coef,
+             hstats, w_expand, b_expand, count, E, rows, cin_w, dW, db);
+  return lmn_launch_status("reparam_wfin");
 }
 
 int lmn_wgrad_reduce_batch(const lmn_reduce_job_t* jobs_dev, int njobs, int64_t total_blocks, lmn_stream_t stream) {

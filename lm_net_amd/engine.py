@@ -163,6 +163,10 @@ class Engine:
         self.defer_reduce = os.environ.get("LMN_DEFER_REDUCE", "1") != "0"
         self.debug_keep = None    # dict: reparam_bwd keeps clones of its intermediates per module (debug tools only)
         self.reduce_tabs = []     # device job tables of the batched reductions of the pass in flight (kept by recorded plans)
+        self.post_reduce = {}     # launch stream handle -> follow-ups of deferred weight gradients (run after the batched reduction)
+        # z-path: expand-conv weight gradient from the raw gradient and the moments of x (lmn_reparam_wfin) instead of a pass that
+        # materialises dz (LMN_ZPATH_M=0: lmn_affine2 + plain weight gradient, A/B runs)
+        self.zpath_m = os.environ.get("LMN_ZPATH_M", "1") != "0"
 
     def pm(self):
         """precision mode of the pass: 0 fp32, 1 bf16 MFMA operands on fp32 storage, 2 bf16 storage + bf16 operands."""
@@ -182,6 +186,7 @@ class Engine:
         _ENG[0] = self
         self.alloc_floats = 0
         self.reduce_tabs = []
+        self.post_reduce = {}
         hip.wgrad_reduce_drop()
         hip._ALLOC[0] = self.alloc
         hip._STREAM[0] = None
@@ -244,21 +249,28 @@ class Engine:
         hip.conv_fwd([dy], wpt, out, B=B, Hin=Ho, Win=Wo, Hout=Hin, Wout=Win, Cout=rows, ksize=k, stride=s,
                      transposed=1, **kw)
 
-    def wgrad(self, srcs, dy, w_param, b_param, *, Hin, Win, k=1, s=1, dW=None, db=None, **kw):
+    def wgrad(self, srcs, dy, w_param, b_param, *, Hin, Win, k=1, s=1, dW=None, db=None, join=True, after=None, deferred=False, **kw):
+        """join=False: an explicit dW is NOT read on the issuing stream right away (no join; the K-split reduction stays deferred
+        when after is given).  after: callable run on the gradient's stream right after the batched reduction that completes it."""
         d = dy.t if isinstance(dy, V) else dy
         B = d.shape[0]
         Ho = (Hin + 2 * (k // 2) - k) // s + 1
         Wo = (Win + 2 * (k // 2) - k) // s + 1
-        explicit = dW is not None                      # caller reads the result on the main stream right away
+        explicit = dW is not None and join             # caller reads the result on the main stream right away
         if dW is None and w_param is not None:
             dW = self.G[w_param]
         db = (self.G[b_param] if b_param is not None else None) if db is None else db
         cout = dW.shape[0] if dW is not None else kw["dW_src"][0].shape[0]
         # second stage of the K-split reduction: deferred and batched per gradient bucket (flush_reduce) unless the caller
         # reads the result right away
-        defer = self.defer_reduce and not explicit and not self.capturing   # (a capture cannot upload the job table)
+        defer = self.defer_reduce and not explicit and not self.capturing and (join or deferred or after is not None)   # (a capture cannot upload the job table)
         if not self.overlap_wgrad or self.capturing:
             hip.conv_wgrad(srcs, dy, dW, db, B=B, Hin=Hin, Win=Win, Hout=Ho, Wout=Wo, Cout=cout, ksize=k, stride=s, defer=defer, **kw)
+            if after is not None:
+                if defer:
+                    self.post_reduce.setdefault(hip._STREAM[0].value if hip._STREAM[0] is not None else 0, []).append(after)
+                else:
+                    after()
             return
         # Weight gradients feed nothing downstream in the backward chain: they run on a side stream and overlap the
         # data-gradient chain on the main stream (at batch 8 most kernels of levels 2-4 cannot fill 256 CUs alone).
@@ -274,6 +286,15 @@ class Engine:
             ws = hip.conv_wgrad(srcs, dy, dW, db, B=B, Hin=Hin, Win=Win, Hout=Ho, Wout=Wo, Cout=cout, ksize=k, stride=s, defer=defer, **kw)
         finally:
             hip._STREAM[0] = saved
+        if after is not None:
+            if defer:
+                self.post_reduce.setdefault(side.cuda_stream, []).append(after)
+            else:
+                hip._STREAM[0] = hip.C.c_void_p(side.cuda_stream)
+                try:
+                    after()
+                finally:
+                    hip._STREAM[0] = saved
         if self.arena is None:          # caching-allocator tensors: keep them alive for the side stream
             d.record_stream(side)
             if ws is not None:
@@ -316,23 +337,29 @@ class Engine:
 
     def flush_reduce(self, device):
         """ONE launch per stream for the deferred K-split reductions (hip.conv_wgrad(defer=True)) of the weight gradients issued
-        from the current stream: on its weight-gradient stream, and on the stream itself where they ran there."""
+        from the current stream: on its weight-gradient stream, and on the stream itself where they ran there.  Then the
+        follow-ups registered for those gradients (wgrad(after=...)) on the same stream."""
         cur = torch.cuda.current_stream(device)
-        tab = hip.wgrad_reduce_flush()
-        if tab is not None:
-            self.reduce_tabs.append(tab)
+        keys = [(cur.cuda_stream, None)]
         ent = self.sides.get(cur.cuda_stream)
-        if ent is not None and hip.wgrad_reduce_pending(ent[0].cuda_stream):
+        if ent is not None:
+            keys.append((ent[0].cuda_stream, ent[0]))
+        for key, stream in keys:
+            fns = self.post_reduce.pop(key, None)
+            if not hip.wgrad_reduce_pending(key) and not fns:
+                continue
             saved = hip._STREAM[0]
-            hip._STREAM[0] = hip.C.c_void_p(ent[0].cuda_stream)
+            hip._STREAM[0] = hip.C.c_void_p(key)
             try:
                 tab = hip.wgrad_reduce_flush()
+                for fn in fns or ():
+                    fn()
             finally:
                 hip._STREAM[0] = saved
             if tab is not None:
                 self.reduce_tabs.append(tab)
-                if self.arena is None:
-                    tab.record_stream(ent[0])
+                if self.arena is None and stream is not None:
+                    tab.record_stream(stream)
 
     def join_side(self, device):
         """Make the current stream wait for its weight-gradient stream (whose deferred reductions are launched first)."""
@@ -394,6 +421,11 @@ class Engine:
                         momentum=ebn.momentum if ebn.momentum is not None else 0.1, about=sums1[STATS_REP, 0],
                         mean=mean1, rstd=rstd1, A=A1, shift=sh1, rmean=ebn.running_mean, rvar=ebn.running_var)
             zp = dict(A=A1, shift=sh1)
+            if self.zpath_m and cx is not None:
+                # moments of x for the backward's weight gradient: M = sum x x^T, m = sum x -- one weight-gradient launch over
+                # (x, x) on the weight-gradient stream, which idles in the forward
+                zp["M"], zp["m"] = _Z(x, x.shape[-1], x.shape[-1]), _Z(x, x.shape[-1])
+                self.wgrad([x], x, None, None, Hin=H, Win=W, dW=zp["M"], db=zp["m"], join=False, deferred=True)   # (reduced at the end of the pass)
         elif self.training and self.fuse_bn:
             # statistics pass (sums about the running mean, whose snapshot lands behind the slices), then the applying pass
             # forms mean / rstd / A / shift itself (lmn_bn_fin_t): no lmn_bn_finalize launch in between
@@ -567,15 +599,23 @@ class Engine:
             kb, coef = _E(x, Cin), _E(x, 3, E)
             hip.reparam_fold(hst, S["mean1"], S["rstd1"], S["A1"], N, self.training, ec.weight, ec.bias, sc.weight, Cin, cdy,
                              wp3, kb, coef, G[ebn.weight], G[ebn.bias])
-            dz = dpre  # (reuse: its last reader on this stream was the depthwise backward)
-            z_ = x1
-            self.side_call(x, lambda: hip.affine2(dh, z_, coef, dz), keep=(dh, z_, coef, dz))
-            if cw == Cin:
-                self.wgrad([x], dz, ec.weight, ec.bias, Hin=H, Win=W)
+            if zp.get("M") is not None:
+                # dW_e = diag(a) R + diag(b) (W_e M + b_e m^T) + c m^T with R = sum dh x^T: the raw gradient into a scratch, the
+                # closed form right after the batched reduction that completes it (same stream)
+                Rw = _Z(x, E, Cin)
+                Mx, mx, gw, gb = zp["M"], zp["m"], G[ec.weight], G[ec.bias]
+                self.wgrad([x], dh, None, None, Hin=H, Win=W, dW=Rw, db=None, join=False,
+                           after=lambda: hip.reparam_wfin(Rw, Mx, mx, coef, hst, ec.weight, ec.bias, N, gw, gb))
             else:
-                dWp = _Z(x, E, Cin)
-                self.wgrad([x], dz, None, None, Hin=H, Win=W, dW=dWp, db=G[ec.bias])
-                hip.copy2d(dWp, G[ec.weight], E, cw, Cin, cw)         # un-pad (layout copy)
+                dz = dpre  # (reuse: its last reader on this stream was the depthwise backward)
+                z_ = x1
+                self.side_call(x, lambda: hip.affine2(dh, z_, coef, dz), keep=(dh, z_, coef, dz))
+                if cw == Cin:
+                    self.wgrad([x], dz, ec.weight, ec.bias, Hin=H, Win=W)
+                else:
+                    dWp = _Z(x, E, Cin)
+                    self.wgrad([x], dz, None, None, Hin=H, Win=W, dW=dWp, db=G[ec.bias])
+                    hip.copy2d(dWp, G[ec.weight], E, cw, Cin, cw)         # un-pad (layout copy)
             if not need_dx:
                 return None
             dx = _A(x, B, H, W, Cin)

@@ -124,7 +124,7 @@ class ReduceJob(C.Structure):
 SYMBOLS = [
     "lmn_abi_version", "lmn_sizeof_conv_args", "lmn_sizeof_src", "lmn_sizeof_wgrad_args", "lmn_last_error",
     "lmn_conv_pack_size", "lmn_conv_pack", "lmn_conv_pack_batch", "lmn_sizeof_pack_job", "lmn_conv_fwd", "lmn_conv_wgrad", "lmn_conv_wgrad_workspace",
-    "lmn_conv_wgrad_job", "lmn_wgrad_reduce_batch", "lmn_sizeof_reduce_job", "lmn_reparam_fold", "lmn_affine2",
+    "lmn_conv_wgrad_job", "lmn_wgrad_reduce_batch", "lmn_sizeof_reduce_job", "lmn_reparam_fold", "lmn_affine2", "lmn_reparam_wfin",
     "lmn_dw_stats", "lmn_dw_fwd", "lmn_dw_merge", "lmn_dw_finalize_merge", "lmn_dw_bwd_stats", "lmn_dw_bwd_coef", "lmn_dw_bwd", "lmn_dw_fwd_bn", "lmn_dw_bwd_bn",
     "lmn_se_fwd", "lmn_se_bwd", "lmn_se_bwd_dm", "lmn_se_bwd_params", "lmn_na_fwd", "lmn_na_bwd", "lmn_gattn_fwd", "lmn_gattn_bwd",
     "lmn_ln_fwd", "lmn_ln_bwd", "lmn_bnact_fwd", "lmn_bnact_bwd_stats", "lmn_bnact_bwd",
@@ -813,6 +813,13 @@ def reparam_fold(hstats, mean, rstd, A, count, batch_stats, w_expand, b_expand, 
     _check(load().lmn_reparam_fold(_p(hstats), _p(mean), _p(rstd), _p(A), _f(count), int(batch_stats), _p(w_expand), _p(b_expand),
                                    _p(w_shortcut), E, rows, cinw, cred, w_shortcut.shape[0], _p(wpack), _p(kbias), _p(coef),
                                    _p(dgamma), _p(dbeta), _MMA[0], _stream()), "reparam_fold")
+
+
+def reparam_wfin(R, M, m, coef, hstats, w_expand, b_expand, count, dW, db):
+    """lmn_reparam_wfin: expand-conv weight / bias gradient from the raw gradient R = sum dh x^T and the moments of x."""
+    E, cinw = w_expand.shape[0], w_expand.shape[1]
+    _check(load().lmn_reparam_wfin(_p(R), _p(M), _p(m), _p(coef), _p(hstats), _p(w_expand), _p(b_expand), _f(count), E, R.shape[1],
+                                   cinw, _p(dW), _p(db), _stream()), "reparam_wfin")
 
 
 def affine2(u, v, coef, y):

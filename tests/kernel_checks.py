@@ -484,6 +484,14 @@ def check_zpath():
         dz64 = A1.detach().view(1, E, 1, 1) * (dh64 - hst64[0].view(1, E, 1, 1) / N
                                               - (z.detach() - mu.detach().view(1, E, 1, 1)) * rstd.detach().view(1, E, 1, 1) * T.view(1, E, 1, 1) / N)
         rows.append(("affine2 dz" + tag, rel(nchw(dzo), dz64), TOL))
+        # weight / bias gradient without dz: raw gradient R = sum dh x^T and the moments of x (lmn_reparam_wfin)
+        xin64 = xin.double()
+        Rr = torch.einsum("behw,bchw->ec", dh64, xin64)
+        Mr, mr = torch.einsum("bjhw,bchw->jc", xin64, xin64), xin64.sum((0, 2, 3))
+        dWf, dbf = torch.zeros(E, Cin, device=DEV), torch.zeros(E, device=DEV)
+        hip.reparam_wfin(dev(Rr), dev(Mr), dev(mr), coef, dev(hst64), dev(we), dev(be), N, dWf, dbf)
+        rows.append(("reparam_wfin dW_e" + tag, rel(dWf, wer.grad), 2e-4))
+        rows.append(("reparam_wfin db_e (exact 0 under batch statistics)" + tag, float(dbf.abs().max()) / float(Rr.abs().max()), 1e-5))
         rows.append(("dz -> expand weight gradient (reference)" + tag,
                      rel(torch.einsum("behw,bchw->ec", dz64, x), wer.grad), 1e-9))
     return rows

@@ -14,19 +14,20 @@ import csv, glob, json, os, shutil, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(ROOT, "gpurun_out", sys.argv[1])
 dst = os.path.join(ROOT, "profiles")
+PFX = (sys.argv[2] if len(sys.argv) > 2 else "r03") + "_"      # round prefix of the files written
 
 
 def last_json(path):
     return [l for l in open(path) if l.startswith("{")][-1]
 
 
-open(os.path.join(dst, "r02_bench_n1.json"), "w").write(last_json(os.path.join(src, "bench_n1.json")))
+open(os.path.join(dst, PFX + "bench_n1.json"), "w").write(last_json(os.path.join(src, "bench_n1.json")))
 for f in glob.glob(os.path.join(src, "bench_*.json")):
     name = os.path.basename(f)
     if name != "bench_n1.json":
-        open(os.path.join(dst, "r02_" + name), "w").write(last_json(f))
+        open(os.path.join(dst, PFX + name), "w").write(last_json(f))
 rows = list(csv.DictReader(open(os.path.join(src, "stats", "r_kernel_stats.csv"))))
-with open(os.path.join(dst, "r02_bench_kernel_stats.csv"), "w") as f:
+with open(os.path.join(dst, PFX + "bench_kernel_stats.csv"), "w") as f:
     w = csv.writer(f)
     w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs"])
     for r in rows:
@@ -72,7 +73,7 @@ json.dump(dict(note="rocprofv3 --pmc passes over `python3 bench.py --steps 2 --w
                                hbm_total_MB=round((tot_f + tot_w) / STEPS / 1e6, 1), algorithmic_MB=round(2085.54 * 8, 1),
                                mfma_busy_ms_per_simd_at_2p4GHz=round(tot_busy / STEPS / 1024 / 2.4e6, 3),
                                serialized_gpu_ms_at_2p4GHz=round(tot_cyc / STEPS / 2.4e6, 2)),
-               kernels=out), open(os.path.join(dst, "r02_pmc.json"), "w"), indent=1)
-print(json.dumps(json.load(open(os.path.join(dst, "r02_pmc.json")))["whole_step"]))
+               kernels=out), open(os.path.join(dst, PFX + "pmc.json"), "w"), indent=1)
+print(json.dumps(json.load(open(os.path.join(dst, PFX + "pmc.json")))["whole_step"]))
 for k in ("wgrad_lds_kernel<9, 2, 2, 0>", "dw_fwd_strip_kernel<float>", "dw_bwd_strip_kernel<float, 0>", "na_fwd_kernel<1, float>"):
     print(k, {a: (round(b) if b > 10 else b) for a, b in out.get(k, {}).items()})
