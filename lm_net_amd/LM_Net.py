@@ -656,7 +656,10 @@ class LM_Net(nn.Module):
         else:
             self._pend[1] = hi
         cap = (1 << 18) if not self._emitted else (1 << 20)        # floats
-        if force or self._pend[1] - self._pend[0] >= cap:
+        # the encoder blocks come last: their weight-gradient reductions / follow-ups are handed on block by block, so that only the
+        # last block's are left when the compute chain ends (the step's tail is the weight-gradient stream finishing)
+        tail = name in ("down4", "conv4", "down3", "conv3", "down2", "conv2", "down1", "conv1")
+        if force or tail or self._pend[1] - self._pend[0] >= cap:
             self._emit_done()
 
     def _emit_done(self):

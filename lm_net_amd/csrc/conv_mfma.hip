@@ -68,6 +68,16 @@ template <bool BF> __device__ __forceinline__ typename Frag<BF>::type ldfrag(con
 __device__ __forceinline__ f32x4 mfma_bf16(uint2 a, uint2 b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s16x4, a), __builtin_bit_cast(s16x4, b), c, 0, 0, 0);
 }
+// gfx950's own shape, v_mfma_f32_16x16x32_bf16 (twice the K per instruction at the cycles of the 16x16x16 form): TWO 4-bf16
+// fragments per operand.  The instruction's k index of lane group q, element j is 8q + j; the fragments carry (block 0: channels
+// 4q..4q+3 | block 1: channels 16+4q..16+4q+3) -- a different bijection k <-> channel, which is fine as long as A and B use the
+// SAME one: the sum over k is the sum over the 32 channels.  So two K16 blocks (or two 16-pixel K steps of a weight gradient)
+// are fused with the LDS / packed layouts unchanged.
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ f32x4 mfma_bf16x2(uint2 a0, uint2 a1, uint2 b0, uint2 b1, f32x4 c) {
+  const uint4 a = uint4{a0.x, a0.y, a1.x, a1.y}, b = uint4{b0.x, b0.y, b1.x, b1.y};
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+}
 
 // ------------------------------------------------------------------------------------ LDS-tiled forward / data-gradient
 // Implicit-GEMM convolution on v_mfma_f32_16x16x4_f32 (M = cout tile: a lane holds 4 consecutive output channels of one
@@ -398,6 +408,48 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(const ConvParams P) {
           const int toff0 = S2T ? s2_off[0] * P.CS : (fy0 * P.XW + fx0) * P.CS;
           xq0 = ldfrag<BF>(&XS[pbase[0] + toff0]);
           xq1 = ldfrag<BF>(&XS[pbase[1] + toff0]);
+        }
+        if constexpr (BF) {
+          if (nkbc == 2) {   // wave-uniform: both K16 blocks of a tap in ONE v_mfma_f32_16x16x32_bf16 (see mfma_bf16x2)
+            const int ntap = S2T ? s2_n : TAPS;
+            uint2 wa[NCT], wb[NCT];
+            if constexpr (!WL) {
+              const float* wp1 = wlane + (((int64_t)(S2T ? s2_wt[0] : 0) * P.NKB + P.kb_off[s] + kb0 + 1) * P.NCTT) * WT;
+#pragma unroll
+              for (int c = 0; c < NCT; ++c) { wa[c] = wcur[c]; wb[c] = ldfrag<true>(wp1 + wtile[c]); }
+            }
+            for (int t = 0; t < ntap; ++t) {
+              const int tn = t + 1 < ntap ? t + 1 : t;
+              uint2 wna[NCT], wnb[NCT];
+              if constexpr (WL) {
+#pragma unroll
+                for (int c = 0; c < NCT; ++c) {
+                  wa[c] = ldfrag<true>(&s_w[((2 * t) * NCT + c) * WT + lane * 2]);
+                  wb[c] = ldfrag<true>(&s_w[((2 * t + 1) * NCT + c) * WT + lane * 2]);
+                }
+              } else {
+                const int tapn = S2T ? s2_wt[tn & 3] : tn;
+                const float* wp = wlane + (((int64_t)tapn * P.NKB + P.kb_off[s] + kb0) * P.NCTT) * WT;
+#pragma unroll
+                for (int c = 0; c < NCT; ++c) { wna[c] = ldfrag<true>(wp + wtile[c]); wnb[c] = ldfrag<true>(wp + P.NCTT * WT + wtile[c]); }
+              }
+              const int ty = t / KS, tx = t - ty * KS;
+              const int fy = A.transposed ? KS - 1 - ty : ty, fx = A.transposed ? KS - 1 - tx : tx;
+              const int toff = S2T ? s2_off[t & 3] * P.CS : (fy * P.XW + fx) * P.CS;
+              const uint2 xa0 = ldfrag<true>(&XS[pbase[0] + toff]), xb0 = ldfrag<true>(&XS[pbase[0] + toff + KD]);
+              const uint2 xa1 = ldfrag<true>(&XS[pbase[1] + toff]), xb1 = ldfrag<true>(&XS[pbase[1] + toff + KD]);
+#pragma unroll
+              for (int c = 0; c < NCT; ++c) {
+                acc[0][c] = mfma_bf16x2(wa[c], wb[c], xa0, xb0, acc[0][c]);
+                acc[1][c] = mfma_bf16x2(wa[c], wb[c], xa1, xb1, acc[1][c]);
+              }
+              if constexpr (!WL) {
+#pragma unroll
+                for (int c = 0; c < NCT; ++c) { wa[c] = wna[c]; wb[c] = wnb[c]; }
+              }
+            }
+            continue;
+          }
         }
         for (int it = 0; it < niter; ++it) {
           const int itn = it + 1 < niter ? it + 1 : it;
@@ -761,6 +813,69 @@ __global__ __launch_bounds__(256) void conv_tileM_kernel(const ConvParams P) {
         // two half-sets of four groups in flight -- the second half of step it is requested before the MFMAs of its first half,
         // the first half of step it+1 before the MFMAs of the second (the loop then never waits on LDS with one wave per SIMD;
         // 1x1: +16 VGPRs put the two-tile instances at two waves per SIMD, and the step still gains 0.6 %)
+        if constexpr (BF) {
+          if (nkbc >= 2) {   // wave-uniform: pairs of K16 blocks in ONE v_mfma_f32_16x16x32_bf16 (mfma_bf16x2); an odd last block alone
+            const int npair = nkbc >> 1;
+            const int nstep = TAPS * npair;
+            uint2 wa[NCW], wb[NCW];
+            {
+              const float* wp1 = wlane + ((int64_t)(P.kb_off[s] + kb0 + 1) * P.NCTT) * WT;
+#pragma unroll
+              for (int c = 0; c < NCW; ++c) { wa[c] = wcur[c]; wb[c] = ldfrag<true>(wp1 + wtile[c]); }
+            }
+            for (int st = 0; st < nstep; ++st) {
+              const int sn = st + 1 < nstep ? st + 1 : st;
+              const int tap = st / npair, pp = st - tap * npair;
+              const int tapn = sn / npair, ppn = sn - tapn * npair;
+              uint2 wna[NCW], wnb[NCW];
+              {
+                const float* wp = wlane + (((int64_t)tapn * P.NKB + P.kb_off[s] + kb0 + 2 * ppn) * P.NCTT) * WT;
+#pragma unroll
+                for (int c = 0; c < NCW; ++c) { wna[c] = ldfrag<true>(wp + wtile[c]); wnb[c] = ldfrag<true>(wp + P.NCTT * WT + wtile[c]); }
+              }
+              const int ty = tap / KS, tx = tap - ty * KS;
+              const int fy = A.transposed ? KS - 1 - ty : ty, fx = A.transposed ? KS - 1 - tx : tx;
+              const int toff = (fy * P.XW + fx) * P.CS + 2 * pp * KD;
+#pragma unroll
+              for (int h = 0; h < NGM; h += 4) {
+                uint2 x0[4], x1[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { x0[u] = ldfrag<true>(&XS[pbase[h + u] + toff]); x1[u] = ldfrag<true>(&XS[pbase[h + u] + toff + KD]); }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                  if (h + u < P.NG) {
+#pragma unroll
+                    for (int c = 0; c < NCW; ++c) acc[h + u][c] = mfma_bf16x2(wa[c], wb[c], x0[u], x1[u], acc[h + u][c]);
+                  }
+                }
+              }
+#pragma unroll
+              for (int c = 0; c < NCW; ++c) { wa[c] = wna[c]; wb[c] = wnb[c]; }
+            }
+            if (nkbc & 1) {   // the odd last K16 block of the chunk: the 16x16x16 form, per tap
+              const int kk = nkbc - 1;
+              for (int tap = 0; tap < TAPS; ++tap) {
+                const float* wp = wlane + (((int64_t)tap * P.NKB + P.kb_off[s] + kb0 + kk) * P.NCTT) * WT;
+                uint2 w1[NCW];
+#pragma unroll
+                for (int c = 0; c < NCW; ++c) w1[c] = ldfrag<true>(wp + wtile[c]);
+                const int ty = tap / KS, tx = tap - ty * KS;
+                const int fy = A.transposed ? KS - 1 - ty : ty, fx = A.transposed ? KS - 1 - tx : tx;
+                const int toff = (fy * P.XW + fx) * P.CS + kk * KD;
+#pragma unroll
+                for (int g = 0; g < NGM; ++g) {
+                  if (g < P.NG) {
+                    const uint2 xg = ldfrag<true>(&XS[pbase[g] + toff]);
+#pragma unroll
+                    for (int c = 0; c < NCW; ++c) acc[g][c] = mfma_bf16(w1[c], xg, acc[g][c]);
+                  }
+                }
+              }
+            }
+            LMN_TK(3);
+            continue;
+          }
+        }
         constexpr bool XPF = true;
         wfrag xa[4];
         if constexpr (XPF) {
@@ -1710,7 +1825,7 @@ __global__ __launch_bounds__(256, 3) void wgrad3_kernel(const WgradParams P) {
       // K steps of 16 consecutive tile pixels; lane (q, n) owns pixels 4q..4q+3 of the step, channel n
       const uint16_t* xw = reinterpret_cast<const uint16_t*>(XS) + (t_w * XPA + q * 4) * (CS * 2) + n;
       const uint16_t* yw = reinterpret_cast<const uint16_t*>(YS) + (m_w * NPA + q * 4) * (CS * 2) + n;
-      for (int ks = K0; ks * 16 < NP; ks += KSTEP) {
+      auto kfrag = [&](int ks, uint2& av, uint2 (&bv)[9]) __attribute__((always_inline)) {   // operands of the 16-pixel K step ks
         const int pix0 = ks * 16, pr = pix0 >> 5, pc0 = pix0 & 31;
         const uint16_t* xp = xw + (pr * XWC + pc0) * (CS * 2);
         const uint16_t* yp = yw + pix0 * (CS * 2);
@@ -1720,14 +1835,26 @@ __global__ __launch_bounds__(256, 3) void wgrad3_kernel(const WgradParams P) {
           h[jj] = yp[jj * CS * 2];
           bsum += __builtin_bit_cast(float, h[jj] << 16);
         }
-        const uint2 av = uint2{h[0] | (h[1] << 16), h[2] | (h[3] << 16)};
-        uint2 bv[9];
+        av = uint2{h[0] | (h[1] << 16), h[2] | (h[3] << 16)};
 #pragma unroll
         for (int tp = 0; tp < 9; ++tp) {
           const uint16_t* xt = xp + ((tp / 3) * XWC + tp % 3) * (CS * 2);
           const uint32_t h0 = xt[0], h1 = xt[CS * 2], h2 = xt[2 * CS * 2], h3 = xt[3 * CS * 2];
           bv[tp] = uint2{h0 | (h1 << 16), h2 | (h3 << 16)};
         }
+      };
+      // two 16-pixel K steps per v_mfma_f32_16x16x32_bf16 (mfma_bf16x2: K = 32 pixels); an odd last step in the 16x16x16 form
+      int ks = K0;
+      for (; (ks + KSTEP) * 16 < NP; ks += 2 * KSTEP) {
+        uint2 av0, av1, bv0[9], bv1[9];
+        kfrag(ks, av0, bv0);
+        kfrag(ks + KSTEP, av1, bv1);
+#pragma unroll
+        for (int tp = 0; tp < 9; ++tp) acc[tp] = mfma_bf16x2(av0, av1, bv0[tp], bv1[tp], acc[tp]);
+      }
+      if (ks * 16 < NP) {
+        uint2 av, bv[9];
+        kfrag(ks, av, bv);
 #pragma unroll
         for (int tp = 0; tp < 9; ++tp) acc[tp] = mfma_bf16(av, bv[tp], acc[tp]);
       }
@@ -2614,7 +2741,9 @@ int lmn_conv_fwd(const lmn_conv_args_t* args, lmn_stream_t stream) {
     const int gW = s2t ? (a.Wout + 1) / 2 : a.Wout, gH = s2t ? (a.Hout + 1) / 2 : a.Hout;  // tiled grid (S2T: class coordinates)
     int ncw = 0;  // > 0: M-split kernel with ncw cout tiles per wave
     // M-split from 6 cout tiles: 5 tiles split 2+1+1+1 over the four waves (24->72 3x3 at 176x176: 242 us, N-split 185 us)
-    constexpr int msplit_min = 6;
+    static int msplit_env = -1;   // LMN_MSPLIT_MIN: A/B runs
+    if (msplit_env < 0) { const char* e = getenv("LMN_MSPLIT_MIN"); msplit_env = e ? atoi(e) : 6; }
+    const int msplit_min = msplit_env;
     int tnct = nct, tchunks = chunks;  // N-split form: cout tiles per block (<= 3), cout chunks (grid.y)
     if (P.NCTT > 3) { tnct = 3; tchunks = (P.NCTT + 2) / 3; }
     if (a.ksize == 1) { T.TW = a.Wout < tpmax ? a.Wout : tpmax; T.TH = 1; }
@@ -2633,7 +2762,10 @@ int lmn_conv_fwd(const lmn_conv_args_t* args, lmn_stream_t stream) {
       for (int cand = 0; cand < 16; ++cand) {
         int tw, th;
         if (a.ksize == 1) {
+          static int tp_env = -1;   // LMN_CONVM_TP: force the 1x1 tile (pixels), A/B runs
+          if (tp_env < 0) { const char* e = getenv("LMN_CONVM_TP"); tp_env = e ? atoi(e) : 0; }
           if (cand > 2) break;
+          if (tp_env > 0 && (tpmax >> cand) != tp_env && tp_env <= a.Wout) continue;
           tw = tpmax >> cand; th = 1;
           if (tw > a.Wout) { if (cand) continue; tw = a.Wout; }
           if (cand && tw < 16) continue;

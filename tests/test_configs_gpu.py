@@ -142,6 +142,53 @@ def _ref_loss(logits, target, eps=1e-3):
     return ce + dl / 2
 
 
+# ------------------------------------------------------------------------------------------------ configs[2]: bf16, batch 64
+def test_config2_bf16_batch64_352_full_size_properties():
+    """BASELINE configs[2] at its real size (bf16 storage + bf16 MFMA operands, batch 64, 352x352): one training step.  The
+    loss equals the fp32 path's (itself pinned to the reference's float64 goldens) to bf16 tolerance, every parameter gets a
+    finite gradient, the gradients agree with the fp32 path's in L2 (median / worst over the 514 tensors), BatchNorm statistics
+    advance once.  (A float64 run of the reference at batch 64 takes minutes of CPU time and 40 GB: the fp32 path stands in.)"""
+    from lm_net_amd import LM_Net
+    from lm_net_amd.loss import SegLoss
+    B = 64
+    x = det_input((B, 3, 352, 352), "c2b64/x").cuda()
+    y = disc_labels(B, 352, 352).cuda()
+    crit = SegLoss(label_smoothing=1e-3).cuda()
+    res = {}
+    for mode in ("fp32", "bf16"):
+        m = LM_Net(3, 2)
+        fill_module(m, 31)
+        no_dropout(m)
+        m = m.cuda().train()
+        m.compute_dtype = mode
+        rm0 = m.conv1[0].expand_conv[1].running_mean.clone()
+        out = m(x)
+        loss = crit(out, y)
+        loss.backward()
+        torch.cuda.synchronize()
+        assert torch.isfinite(out).all() and bool(torch.isfinite(loss)), mode
+        bn = m.conv1[0].expand_conv[1]
+        assert int(bn.num_batches_tracked) == 1 and float((bn.running_mean - rm0).abs().max()) > 0, mode
+        res[mode] = (float(loss), {k: p.grad.detach().clone() for k, p in m.named_parameters()}, bn.running_mean.clone())
+        del m, out, loss
+        torch.cuda.empty_cache()
+    l32, g32, rm32 = res["fp32"]
+    l16, g16, rm16 = res["bf16"]
+    assert abs(l16 - l32) < 2e-2 * abs(l32), (l16, l32)
+    assert rel_err(rm16, rm32) < 1e-2
+    errs = []
+    gmax = max(float(g.abs().max()) for g in g32.values())
+    for k, g in g16.items():
+        assert bool(torch.isfinite(g).all()), k
+        ref = g32[k]
+        if float(ref.abs().max()) < 2e-5 * gmax:          # pre-BatchNorm biases: exact gradient 0
+            continue
+        errs.append(float((g - ref).norm() / (ref.norm() + 1e-30)))
+    assert sum(float(g.abs().sum()) > 0 for g in g16.values()) >= 510
+    errs.sort()
+    assert errs[len(errs) // 2] < 0.1 and errs[-1] < 0.5, (errs[len(errs) // 2], errs[-1])
+
+
 # ------------------------------------------------------------------------------------------------ configs[3]: RCCL
 def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
