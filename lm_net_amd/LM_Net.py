@@ -741,6 +741,10 @@ class LM_Net(nn.Module):
         fork = eng.branch_overlap and not eng.capturing
         bst = eng.branch_stream(dev) if fork else None
 
+        # weight gradients of the branch chains: issued late (engine.wgrad, lazy_on) unless a data-parallel reducer wants the
+        # natt* / skip* buckets early
+        lazy = bool(fork and eng.lazy_wgrad and self.grad_ready_hook is None)
+
         def branch(nat, skip, dt):
             """Backward of one neighborhood-attention block and its skip fuser.  Their only input is dt (the decoder
             stage gradient) and nothing on the decoder chain waits for them, so they run on the branch stream while
@@ -751,9 +755,13 @@ class LM_Net(nn.Module):
             if eng.arena is None:
                 dt.record_stream(bst)
             with eng.on_stream(bst):
-                dxs = eng.nat_bwd(nat, dt, cx)
-                eng.skip_bwd(skip, dxs, cx, gacc)
-                eng.join_side(dev)                       # this chain's weight gradients
+                eng.lazy_on = lazy
+                try:
+                    dxs = eng.nat_bwd(nat, dt, cx)
+                    eng.skip_bwd(skip, dxs, cx, gacc)
+                finally:
+                    eng.lazy_on = False
+                eng.join_side(dev)                       # this chain's weight gradients (none when they are issued late)
             return None
 
         # The flat gradient buffer lists natt4..1 before skip4..1 (BACKWARD_ORDER) and a data-parallel bucket is a
@@ -784,9 +792,19 @@ class LM_Net(nn.Module):
         p1 = branch(self.natt1, self.skip1, dt1)
         dx5 = eng.up_bwd(self.up1, dt1, cx, A["x5"].shape); self._done("up1")
         if fork:
-            reported = branch_blocks_done()              # natt* / skip*: complete on the branch stream from here on
+            reported = False
+            if not lazy:
+                reported = branch_blocks_done()          # natt* / skip*: complete on the branch stream from here on
             dcat = eng.gft_bwd(self.gft, dx5, cx)        # independent of the branch chains: before the join
             hip.stream_wait(main, bst)                   # join: the encoder gradients in gacc are complete
+            if lazy:
+                # the chains' weight gradients now: their stream starts once the chains are through (it waits for the branch stream)
+                # and runs beside the encoder's backward below
+                lq, eng.lazy_q = eng.lazy_q, []
+                with eng.on_stream(bst):
+                    for fn in lq:
+                        fn()
+                reported = branch_blocks_done()
             if eng.arena is None:
                 for slot in gacc.values():
                     if slot.g is not None:
@@ -821,6 +839,10 @@ class LM_Net(nn.Module):
         dxd1 = eng.stage_bwd(self.conv2, g2, cx); self._done("conv2")
         eng.conv3_bwd(self.down1[0], A["x1"], dxd1, s=2, dx=g1, accumulate=True); self._done("down1")
         dxin = eng.stage_bwd(self.conv1, g1, cx, need_dx=need_dx); self._done("conv1")
+        if lazy:                                         # the late weight gradients of the branch chains
+            with eng.on_stream(bst):
+                eng.join_side(dev)
+            hip.stream_wait(main, bst)
         dx = None
         if need_dx:
             dx = _E(dev, B, self.channel, H, W)

@@ -152,6 +152,12 @@ class Engine:
         # z-path of ReparamConv (include/lmnet_hip.h, lmn_dw_pre_t / lmn_reparam_fold): the expand conv's BatchNorm + Hardswish
         # applied inside the depthwise kernels, its backward folded into the weights of one three-source conv (LMN_ZPATH=0: A/B)
         self.zpath = os.environ.get("LMN_ZPATH", "1") != "0"
+        # weight gradients of the branch chains issued late, beside the encoder's backward (LMN_LAZY_WGRAD=0: A/B runs)
+        self.lazy_wgrad = os.environ.get("LMN_LAZY_WGRAD", "1") != "0"
+        self.lazy_on = False
+        self.lazy_q = []
+        self.side_prio = int(os.environ.get("LMN_SIDE_PRIO", "0"))   # HIP priority of the weight-gradient streams (-1: high; A/B runs)
+        self.branch_prio = int(os.environ.get("LMN_BRANCH_PRIO", "0"))
         self.zpool_fwd, self.zpool_bwd = ZeroPool(), ZeroPool()
         self.packs_fwd, self.packs_bwd = hip.PackPlan(), hip.PackPlan()
         self.mma = hip.F32        # matrix-core operand type of the dense contractions of the pass (hip.F32 | hip.BF16)
@@ -187,6 +193,7 @@ class Engine:
         self.alloc_floats = 0
         self.reduce_tabs = []
         self.post_reduce = {}
+        self.lazy_q, self.lazy_on = [], False
         hip.wgrad_reduce_drop()
         hip._ALLOC[0] = self.alloc
         hip._STREAM[0] = None
@@ -253,6 +260,18 @@ class Engine:
         """join=False: an explicit dW is NOT read on the issuing stream right away (no join; the K-split reduction stays deferred
         when after is given).  after: callable run on the gradient's stream right after the batched reduction that completes it."""
         d = dy.t if isinstance(dy, V) else dy
+        if self.lazy_on and not (dW is not None and join):
+            # late scheduling (LM_Net._backward_body): the weight gradients of the skip / neighborhood-attention chains have no
+            # consumer before the optimizer; they are issued once the compute chain has reached the encoder's small feature maps,
+            # which cannot fill the GPU, instead of next to the level-0 chains that already saturate it
+            G_ = self.G
+            if dW is None and w_param is not None:
+                dW = G_[w_param]
+            if db is None and b_param is not None:
+                db = G_[b_param]
+            self.lazy_q.append(lambda: self.wgrad(srcs, dy, None, None, Hin=Hin, Win=Win, k=k, s=s, dW=dW, db=db, join=False,
+                                                  after=after, deferred=True, **kw))
+            return
         B = d.shape[0]
         Ho = (Hin + 2 * (k // 2) - k) // s + 1
         Wo = (Win + 2 * (k // 2) - k) // s + 1
@@ -331,7 +350,7 @@ class Engine:
         key = issuing.cuda_stream
         ent = self.sides.get(key)
         if ent is None:
-            ent = self.sides[key] = [torch.cuda.Stream(device=issuing.device), False]
+            ent = self.sides[key] = [torch.cuda.Stream(device=issuing.device, priority=self.side_prio), False]
         ent[1] = True
         return ent[0]
 
@@ -383,7 +402,7 @@ class Engine:
 
     def branch_stream(self, device):
         if self.branch is None or self.branch.device != device:
-            self.branch = torch.cuda.Stream(device=device)
+            self.branch = torch.cuda.Stream(device=device, priority=self.branch_prio)
         return self.branch
 
     def bn_stats(self, bn, sums, count, ref):

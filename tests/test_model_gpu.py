@@ -397,21 +397,27 @@ def test_plan_mode_matches_host_launches():
             (m(x) * G).sum().backward()
     gmax = max(float(p.grad.abs().max()) for p in c.parameters())
 
-    def same(u, v):
-        # float-atomic noise (pre-BatchNorm biases have an exact gradient of 0: absolute scale) -- and one legitimate two-valued
-        # outcome: Hardswish' jumps by 1/2 at |h| = 3 (ATen's hardswish_backward likewise), and for these weights / this input
-        # one pre-activation of dconv4.0 (pixel 5012, channel 5) lies within 3e-6 of the kink, so the last bits of the batch
-        # statistics (summed in arrival order) decide its branch: every gradient downstream then moves by 4e-4 .. 1e-3
-        # (tools/gpu_glitch_locate.py).  A wrong coefficient or a stale buffer in a replay shows at the 1e-1 level.
-        return rel_err(u, v) < 2e-3 or float((u - v).abs().max()) < 1e-5 * gmax
+    def same(u, v, tol=2e-3):
+        return rel_err(u, v) < tol or float((u - v).abs().max()) < 1e-5 * gmax
 
-    for (k, pc), (_, pd) in zip(c.named_parameters(), d.named_parameters()):
-        assert same(pd.grad, pc.grad), k
+    def agree(pairs):
+        # Two runs of the SAME schedule already differ by more than float-atomic noise now and then: Hardswish' jumps by 1/2 at
+        # |h| = 3 (ATen's hardswish_backward likewise) and among the ~10^7 pre-activations of a pass one or two lie within 1e-6
+        # of the kink (for these weights: pixel 5012, channel 5 of dconv4.0, tools/gpu_glitch_locate.py), where the last bits of
+        # the batch statistics (summed in arrival order) decide the branch; every gradient upstream of that element then moves
+        # by 4e-4 .. 3e-3.  So: each parameter within 2e-2, the gradient as a whole within 3e-3 (pre-BatchNorm biases have an
+        # exact gradient of 0: absolute scale).  A wrong coefficient or a stale buffer in a replay shows at the 1e-1 level.
+        pairs = list(pairs)
+        for k, u, v in pairs:
+            assert same(u, v, 2e-2), (k, rel_err(u, v))
+        fu, fv = (torch.cat([t[i].reshape(-1) for t in pairs]) for i in (1, 2))
+        assert rel_err(fu, fv) < 3e-3, rel_err(fu, fv)
+
+    agree((k, pd.grad, pc.grad) for (k, pc), (_, pd) in zip(c.named_parameters(), d.named_parameters()))
     # gradient accumulation into a .grad that aliases the static buffer: second backward adds
     g1 = [p.grad.clone() for p in d.parameters()]
     (d(x) * G).sum().backward()
-    for g, p in zip(g1, d.parameters()):
-        assert same(p.grad, 2 * g)
+    agree((i, p.grad, 2 * g) for i, (g, p) in enumerate(zip(g1, d.parameters())))
     # an eval forward between a training forward and its backward neither disturbs the tape nor the BatchNorm mode
     for p in d.parameters():
         p.grad = None
@@ -421,8 +427,7 @@ def test_plan_mode_matches_host_launches():
         ye = [d(x) for _ in range(4)]                # eval plans: 2 eager, record, replay
     d.train()
     (out * G).sum().backward()
-    for (k, pc), (_, pd) in zip(c.named_parameters(), d.named_parameters()):
-        assert same(pd.grad, pc.grad), k
+    agree((k, pd.grad, pc.grad) for (k, pc), (_, pd) in zip(c.named_parameters(), d.named_parameters()))
     assert rel_err(ye[3], ye[0]) < 1e-5
     # dropout on: replays must not repeat the mask
     from lm_net_amd import LM_Net

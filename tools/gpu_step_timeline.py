@@ -70,3 +70,14 @@ print("idle in gaps < 20 us: %.2f ms/step (%d gaps/step)" % (sum(g[0] for g in g
 print("alone on the GPU (per step):")
 for k, v in sorted(solo.items(), key=lambda kv: -kv[1])[:25]:
     print("  %-60s %8.1f us" % (k[:60], v / a.steps))
+# per stream: kernel time by name, and the stream's own idle time between its first and last launch of a step
+for s in streams:
+    rs = sorted([r for r in tl if r[1] == s], key=lambda r: r[2])
+    by = defaultdict(lambda: [0, 0.0])
+    for r in rs:
+        by[r[0]][0] += 1; by[r[0]][1] += r[3] - r[2]
+    gap = sum(max(0.0, b[2] - a_[3]) for a_, b in zip(rs, rs[1:]) if b[2] - a_[3] < 200.0)
+    print("stream %s: %d launches/step, busy %.2f ms/step, gaps < 200 us between its launches %.2f ms/step" % (
+        sname[s], len(rs) // a.steps, sum(r[3] - r[2] for r in rs) / 1e3 / a.steps, gap / 1e3 / a.steps))
+    for k, (n, t) in sorted(by.items(), key=lambda kv: -kv[1][1])[:28]:
+        print("    %-52s %4d x %7.1f us = %8.1f us/step" % (k[:52], n // a.steps, t / n, t / a.steps))
