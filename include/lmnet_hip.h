@@ -39,7 +39,7 @@ extern "C" {
 
 typedef void* lmn_stream_t; /* hipStream_t */
 
-#define LMN_ABI_VERSION 7
+#define LMN_ABI_VERSION 8
 /* arithmetic type of the matrix-core operands of a dense contraction (accumulators, epilogues, statistics: fp32) */
 #define LMN_F32 0  /* v_mfma_f32_16x16x4_f32: exact fp32 (k-ordered fma chain)                                  */
 #define LMN_BF16 1 /* v_mfma_f32_16x16x16_bf16: operands rounded to bf16 (RNE) when staged / packed -- the mixed- */
@@ -381,14 +381,17 @@ int lmn_se_bwd_params(const float* dvec, const float* gsum, float inv_hw, const 
  * Neighborhood attention core (row A7; natten2dqkrpb + softmax + natten2dav fused).
  * qkv: [B,H,W,3C] with channel = which*C + head*hd + d (the layout natten's module gives:
  * reshape(B,H,W,3,heads,hd)); out: [B,H,W,C] channel = head*hd + d; rpb: [heads][2K-1][2K-1].
- * K = 3 (the reference hard-codes kernel_size=3, core/modules.py:509).  scale = hd^-0.5.
+ * K: natten's kernel_size, odd, 3..13 (window start = clamp(i - K/2, 0, L - K), bias index = neighbour - query + K - 1).
+ * The reference constructs K = 3 (core/modules.py:509; the LDS-tiled kernels), its LM_Net signature also carries [3, 5]
+ * (core/LM_Net.py:81-84): any other K runs the direct form, and so does K given NEGATIVE (-3: the direct form at K = 3,
+ * which the tests compare with the tiled kernels).  scale = hd^-0.5.
  * ------------------------------------------------------------------------------------------ */
-int lmn_na_fwd(const void* qkv, const float* rpb, void* out, int B, int H, int W, int heads, int hd, float scale,
+int lmn_na_fwd(const void* qkv, const float* rpb, void* out, int B, int H, int W, int heads, int hd, int K, float scale,
                int act_dtype, lmn_stream_t stream);
 /* dqkv is fully overwritten (two gather passes, no atomics, deterministic); drpb +=;
  * stat: caller workspace of 2*heads floats per pixel ([B*H*W][2][heads]: log-sum-exp and sum_n p_n dp_n) */
 int lmn_na_bwd(const void* qkv, const float* rpb, const void* dout, void* dqkv, float* drpb, float* stat, int B,
-               int H, int W, int heads, int hd, float scale, int act_dtype, lmn_stream_t stream);
+               int H, int W, int heads, int hd, int K, float scale, int act_dtype, lmn_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Dense global attention of GFT (core/modules.py:267-279): qkv [B,N,3C] (channel = which*C +

@@ -114,7 +114,9 @@ class _LMNetPlanFunction(torch.autograd.Function):
 
 
 class LM_Net(nn.Module):
-    def __init__(self, channel, n_classes=2, filters=[12, 24, 48, 96, 192], deep_supervision=False):
+    def __init__(self, channel, n_classes=2, filters=[12, 24, 48, 96, 192], deep_supervision=False, na_kernel_size=3):
+        # (na_kernel_size is not in the reference signature, core/LM_Net.py:6: its four NAT blocks are built with kernel_size 3,
+        #  core/modules.py:509 -- other odd sizes run the run-time-K neighborhood-attention kernels, csrc/na.hip)
         super().__init__()
         f = list(filters)
         assert all(c % NUM_HEADS == 0 for c in f[:4]) and sum(f) % NUM_HEADS == 0, \
@@ -138,10 +140,10 @@ class LM_Net(nn.Module):
         self.skip2 = M3Skip([f[1], f[2], f[3]])
         self.skip3 = M3Skip([f[0], f[1], f[2]])
         self.skip4 = M2Skip([f[0], f[1]], "top")
-        self.natt1 = NeighborhoodTransformer(f[3], NUM_HEADS)
-        self.natt2 = NeighborhoodTransformer(f[2], NUM_HEADS)
-        self.natt3 = NeighborhoodTransformer(f[1], NUM_HEADS)
-        self.natt4 = NeighborhoodTransformer(f[0], NUM_HEADS)
+        self.natt1 = NeighborhoodTransformer(f[3], NUM_HEADS, na_kernel_size)
+        self.natt2 = NeighborhoodTransformer(f[2], NUM_HEADS, na_kernel_size)
+        self.natt3 = NeighborhoodTransformer(f[1], NUM_HEADS, na_kernel_size)
+        self.natt4 = NeighborhoodTransformer(f[0], NUM_HEADS, na_kernel_size)
         self.output_layer = nn.Conv2d(f[0], n_classes, 1)
         self._engine = Engine(self)
         self._grad_flat = None

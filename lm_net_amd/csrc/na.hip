@@ -628,20 +628,238 @@ __global__ __launch_bounds__(256) void na_bwd_kv_tile_kernel(const TA* __restric
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Window sizes other than 3 (natten's kernel_size 5, 7, ...: core/LM_Net.py:81-84 passes [3, 5], BASELINE configs[4] names a
+// larger window): the same three passes in the direct form -- a thread owns a channel quad of one pixel, lanes walk the
+// channel axis first, the K x K re-use of k / v is served by L1 / L2 -- with K a run-time argument (one instantiation per
+// head_dim).  Scores are formed twice (max, then exp / sums) instead of being kept in K*K registers.  K = 3 keeps the
+// LDS-tiled kernels above; tests/kernel_checks.py also runs these on K = 3 as a cross-check of the two forms.
+__device__ __forceinline__ int wstart_k(int i, int L, int K) {
+  int s = i - (K >> 1);
+  s = s < 0 ? 0 : s;
+  return s > L - K ? L - K : s;
+}
+
+template <int HD, typename TA>
+__global__ __launch_bounds__(256) void na_fwd_gen_kernel(const TA* __restrict__ qkv, const float* __restrict__ rpb,
+                                                         TA* __restrict__ out, const NaGeom g, int K) {
+  const int RB = 2 * K - 1;
+  const int64_t total = (int64_t)g.B * g.H * g.W * g.C4;
+  const int64_t nit = (total + (int64_t)gridDim.x * 256 - 1) / ((int64_t)gridDim.x * 256);
+  for (int64_t it = 0; it < nit; ++it) {
+    int64_t idx = (it * gridDim.x + blockIdx.x) * 256 + threadIdx.x;
+    const bool ok = idx < total;
+    if (!ok) idx = total - 1;   // keep every lane in the shuffles
+    const int c = (int)(idx % g.C4) * 4;
+    const int64_t pix = idx / g.C4;
+    const int x = (int)(pix % g.W), y = (int)((pix / g.W) % g.H), b = (int)(pix / ((int64_t)g.W * g.H));
+    const TA* base = qkv + (int64_t)b * g.H * g.W * 3 * g.C;
+    const int sy = wstart_k(y, g.H, K), sx = wstart_k(x, g.W, K);
+    const f32x4 q = ld4(base + ((int64_t)y * g.W + x) * 3 * g.C + c) * g.scale;
+    int hidx[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) hidx[k] = ((c + k) / HD) * RB * RB;
+    auto score = [&](int ki, int kj) {
+      const f32x4 kk = ld4(base + ((int64_t)(sy + ki) * g.W + sx + kj) * 3 * g.C + g.C + c);
+      f32x4 sc = head_sum<HD>(q * kk);
+      const int bo = (sy + ki - y + K - 1) * RB + (sx + kj - x + K - 1);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) sc[k] += rpb[hidx[k] + bo];
+      return sc;
+    };
+    f32x4 mx = f32x4{-3.0e38f, -3.0e38f, -3.0e38f, -3.0e38f};
+    for (int ki = 0; ki < K; ++ki)
+      for (int kj = 0; kj < K; ++kj) {
+        const f32x4 sc = score(ki, kj);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) mx[k] = fmaxf(mx[k], sc[k]);
+      }
+    f32x4 den = f32x4{0.f, 0.f, 0.f, 0.f}, o = den;
+    for (int ki = 0; ki < K; ++ki)
+      for (int kj = 0; kj < K; ++kj) {
+        f32x4 e = score(ki, kj);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) e[k] = __expf(e[k] - mx[k]);
+        den += e;
+        o += e * ld4(base + ((int64_t)(sy + ki) * g.W + sx + kj) * 3 * g.C + 2 * g.C + c);
+      }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) o[k] = o[k] / den[k];
+    if (ok) st4(out + pix * g.C + c, o);
+  }
+}
+
+template <int HD, typename TA>
+__global__ __launch_bounds__(256) void na_bwd_q_gen_kernel(const TA* __restrict__ qkv, const float* __restrict__ rpb,
+                                                           const TA* __restrict__ dout, TA* __restrict__ dqkv,
+                                                           float* __restrict__ drpb, float* __restrict__ stat,
+                                                           const NaGeom g, int K) {
+  extern __shared__ float s_tab[];  // [heads][(2K-1)^2] bias-gradient bins of the block
+  const int RB = 2 * K - 1, NB = g.heads * RB * RB;
+  for (int i = threadIdx.x; i < NB; i += 256) s_tab[i] = 0.f;
+  __syncthreads();
+  const int64_t total = (int64_t)g.B * g.H * g.W * g.C4;
+  const int64_t nit = (total + (int64_t)gridDim.x * 256 - 1) / ((int64_t)gridDim.x * 256);
+  for (int64_t it = 0; it < nit; ++it) {
+    int64_t idx = (it * gridDim.x + blockIdx.x) * 256 + threadIdx.x;
+    const bool ok = idx < total;
+    if (!ok) idx = total - 1;
+    const int c = (int)(idx % g.C4) * 4;
+    const int64_t pix = idx / g.C4;
+    const int x = (int)(pix % g.W), y = (int)((pix / g.W) % g.H), b = (int)(pix / ((int64_t)g.W * g.H));
+    const int64_t ib = (int64_t)b * g.H * g.W * 3 * g.C;
+    const TA* base = qkv + ib;
+    const int sy = wstart_k(y, g.H, K), sx = wstart_k(x, g.W, K);
+    const f32x4 q = ld4(base + ((int64_t)y * g.W + x) * 3 * g.C + c) * g.scale;
+    const f32x4 dO = ld4(dout + pix * g.C + c);
+    int hidx[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) hidx[k] = ((c + k) / HD) * RB * RB;
+    auto score = [&](int ki, int kj, f32x4& kk) {
+      kk = ld4(base + ((int64_t)(sy + ki) * g.W + sx + kj) * 3 * g.C + g.C + c);
+      f32x4 sc = head_sum<HD>(q * kk);
+      const int bo = (sy + ki - y + K - 1) * RB + (sx + kj - x + K - 1);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) sc[k] += rpb[hidx[k] + bo];
+      return sc;
+    };
+    f32x4 kk;
+    f32x4 mx = f32x4{-3.0e38f, -3.0e38f, -3.0e38f, -3.0e38f};
+    for (int ki = 0; ki < K; ++ki)
+      for (int kj = 0; kj < K; ++kj) {
+        const f32x4 sc = score(ki, kj, kk);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) mx[k] = fmaxf(mx[k], sc[k]);
+      }
+    f32x4 den = f32x4{0.f, 0.f, 0.f, 0.f}, edp = den;
+    for (int ki = 0; ki < K; ++ki)
+      for (int kj = 0; kj < K; ++kj) {
+        f32x4 e = score(ki, kj, kk);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) e[k] = __expf(e[k] - mx[k]);
+        den += e;
+        edp += e * head_sum<HD>(dO * ld4(base + ((int64_t)(sy + ki) * g.W + sx + kj) * 3 * g.C + 2 * g.C + c));
+      }
+    f32x4 dsum, rden;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { rden[k] = 1.f / den[k]; dsum[k] = edp[k] * rden[k]; }
+    bool rep[4];  // the lane owning a head's FIRST channel reports for that head
+#pragma unroll
+    for (int k = 0; k < 4; ++k) rep[k] = ok && ((c + k) % HD == 0);
+    f32x4 dq = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int ki = 0; ki < K; ++ki)
+      for (int kj = 0; kj < K; ++kj) {
+        f32x4 e = score(ki, kj, kk);
+        const f32x4 dp = head_sum<HD>(dO * ld4(base + ((int64_t)(sy + ki) * g.W + sx + kj) * 3 * g.C + 2 * g.C + c));
+        f32x4 ds;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) ds[k] = __expf(e[k] - mx[k]) * rden[k] * (dp[k] - dsum[k]);
+        dq += ds * kk;
+        const int bo = (sy + ki - y + K - 1) * RB + (sx + kj - x + K - 1);
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          if (rep[k]) atomicAdd(&s_tab[hidx[k] + bo], ds[k]);
+      }
+    if (ok) st4(dqkv + ib + ((int64_t)y * g.W + x) * 3 * g.C + c, dq * g.scale);
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      if (rep[k]) {
+        const int h = (c + k) / HD;
+        stat[pix * 2 * g.heads + h] = mx[k] + __logf(den[k]);
+        stat[pix * 2 * g.heads + g.heads + h] = dsum[k];
+      }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < NB; i += 256)
+    if (s_tab[i] != 0.f) atomicAdd(drpb + i, s_tab[i]);
+}
+
+template <int HD, typename TA>
+__global__ __launch_bounds__(256) void na_bwd_kv_gen_kernel(const TA* __restrict__ qkv, const float* __restrict__ rpb,
+                                                            const TA* __restrict__ dout, TA* __restrict__ dqkv,
+                                                            const float* __restrict__ stat, const NaGeom g, int K) {
+  const int RB = 2 * K - 1;
+  const int64_t total = (int64_t)g.B * g.H * g.W * g.C4;
+  const int64_t nit = (total + (int64_t)gridDim.x * 256 - 1) / ((int64_t)gridDim.x * 256);
+  for (int64_t it = 0; it < nit; ++it) {
+    int64_t idx = (it * gridDim.x + blockIdx.x) * 256 + threadIdx.x;
+    const bool ok = idx < total;
+    if (!ok) idx = total - 1;
+    const int c = (int)(idx % g.C4) * 4;
+    const int64_t pix = idx / g.C4;
+    const int jx = (int)(pix % g.W), jy = (int)((pix / g.W) % g.H), b = (int)(pix / ((int64_t)g.W * g.H));
+    const int64_t ib = (int64_t)b * g.H * g.W * 3 * g.C;
+    const TA* base = qkv + ib;
+    const int64_t kpo = ((int64_t)jy * g.W + jx) * 3 * g.C;
+    const f32x4 kj = ld4(base + kpo + g.C + c), vj = ld4(base + kpo + 2 * g.C + c);
+    int hd_[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) hd_[k] = (c + k) / HD;
+    f32x4 dk = f32x4{0.f, 0.f, 0.f, 0.f}, dv = dk;
+    // key j is seen by query i iff 0 <= j - wstart(i) < K on both axes (pixel-uniform tests: lane pairs stay converged)
+    for (int iy = jy - K + 1; iy <= jy + K - 1; ++iy) {
+      if (iy < 0 || iy >= g.H) continue;
+      const int ki = jy - wstart_k(iy, g.H, K);
+      if (ki < 0 || ki >= K) continue;
+      for (int ix = jx - K + 1; ix <= jx + K - 1; ++ix) {
+        if (ix < 0 || ix >= g.W) continue;
+        const int kx = jx - wstart_k(ix, g.W, K);
+        if (kx < 0 || kx >= K) continue;
+        const int64_t ipix = ((int64_t)b * g.H + iy) * g.W + ix;
+        const f32x4 qi = ld4(base + ((int64_t)iy * g.W + ix) * 3 * g.C + c) * g.scale;
+        const f32x4 dOi = ld4(dout + ipix * g.C + c);
+        const float* sp = stat + ipix * 2 * g.heads;
+        const f32x4 s = head_sum<HD>(qi * kj), dp = head_sum<HD>(dOi * vj);
+        const int bo = (jy - iy + K - 1) * RB + (jx - ix + K - 1);
+        f32x4 pij, ds;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          pij[k] = __expf(s[k] + rpb[hd_[k] * RB * RB + bo] - sp[hd_[k]]);
+          ds[k] = pij[k] * (dp[k] - sp[g.heads + hd_[k]]);
+        }
+        dk += ds * qi;   // qi carries the scale
+        dv += pij * dOi;
+      }
+    }
+    if (ok) {
+      st4(dqkv + ib + kpo + g.C + c, dk);
+      st4(dqkv + ib + kpo + 2 * g.C + c, dv);
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" {
 
-int lmn_na_fwd(const void* qkv, const float* rpb, void* out, int B, int H, int W, int heads, int hd, float scale,
+int lmn_na_fwd(const void* qkv, const float* rpb, void* out, int B, int H, int W, int heads, int hd, int K, float scale,
                int act_dtype, lmn_stream_t stream) {
-  LMN_REC(lmn_na_fwd(qkv, rpb, out, B, H, W, heads, hd, scale, act_dtype, stream));
+  LMN_REC(lmn_na_fwd(qkv, rpb, out, B, H, W, heads, hd, K, scale, act_dtype, stream));
   LMN_REQUIRE_DT(act_dtype, "na_fwd");
   LMN_REQUIRE(qkv && rpb && out, "na_fwd: null pointer");
-  LMN_REQUIRE(B > 0 && H >= 3 && W >= 3, "na_fwd: feature map %dx%d smaller than the 3x3 window", H, W);
+  const bool gen = K < 0;   // -K: the direct (run-time K) form, also for K = 3 (tests)
+  if (gen) K = -K;
+  LMN_REQUIRE(K >= 3 && K <= 13 && (K & 1), "na_fwd: window %d (odd, 3..13)", K);
+  LMN_REQUIRE(B > 0 && H >= K && W >= K, "na_fwd: feature map %dx%d smaller than the %dx%d window", H, W, K, K);
   LMN_REQUIRE(hd == 1 || hd == 2 || hd == 4 || hd == 8 || hd == 16, "na_fwd: head_dim %d not in {1,2,4,8,16}", hd);
   LMN_REQUIRE((heads * hd) % 4 == 0, "na_fwd: C=%d must be a multiple of 4", heads * hd);
   LMN_REQUIRE(heads <= 16, "na_fwd: %d heads (the LDS bias table holds 16)", heads);
   NaGeom g{B, H, W, heads * hd, heads * hd / 4, heads, scale};
+  if (gen || K != 3) {
+    hipStream_t st = (hipStream_t)stream;
+    const int grid = na_grid((int64_t)B * H * W * g.C4);
+    if (g_lmn_prof_on) lmn_prof_cost(2.0 * 2 * K * K * (double)B * H * W * g.C, (act_dtype == LMN_BF16 ? 2.0 : 4.0) * 4 * (double)B * H * W * g.C);
+#define LMN_NAG(HDV) LMN_LAUNCH((na_fwd_gen_kernel<HDV, T>), dim3(grid), dim3(256), 0, st, (const T*)qkv, rpb, (T*)out, g, K)
+    LMN_ACT_DISPATCH(act_dtype, switch (hd) {
+      case 1: LMN_NAG(1); break;
+      case 2: LMN_NAG(2); break;
+      case 4: LMN_NAG(4); break;
+      case 8: LMN_NAG(8); break;
+      default: LMN_NAG(16); break;
+    });
+#undef LMN_NAG
+    return lmn_launch_status("na_fwd");
+  }
   // channel chunk: whole heads and whole lane pairs; tile 16x16 while the k/v window fits 64 KB of LDS, else 8x8
   int cch = g.C <= 48 ? g.C : 48;
   while (g.C % cch || cch % (hd > 4 ? hd : 4)) cch -= 4;
@@ -665,13 +883,16 @@ int lmn_na_fwd(const void* qkv, const float* rpb, void* out, int B, int H, int W
 }
 
 int lmn_na_bwd(const void* qkv_, const float* rpb, const void* dout_, void* dqkv_, float* drpb, float* stat, int B,
-               int H, int W, int heads, int hd, float scale, int act_dtype, lmn_stream_t stream) {
-  LMN_REC(lmn_na_bwd(qkv_, rpb, dout_, dqkv_, drpb, stat, B, H, W, heads, hd, scale, act_dtype, stream));
+               int H, int W, int heads, int hd, int K, float scale, int act_dtype, lmn_stream_t stream) {
+  LMN_REC(lmn_na_bwd(qkv_, rpb, dout_, dqkv_, drpb, stat, B, H, W, heads, hd, K, scale, act_dtype, stream));
   LMN_REQUIRE_DT(act_dtype, "na_bwd");
   const void *qkv = qkv_, *dout = dout_;
   void* dqkv = dqkv_;
   LMN_REQUIRE(qkv && rpb && dout && dqkv && drpb && stat, "na_bwd: null pointer");
-  LMN_REQUIRE(B > 0 && H >= 3 && W >= 3, "na_bwd: feature map %dx%d smaller than the 3x3 window", H, W);
+  const bool gen = K < 0;
+  if (gen) K = -K;
+  LMN_REQUIRE(K >= 3 && K <= 13 && (K & 1), "na_bwd: window %d (odd, 3..13)", K);
+  LMN_REQUIRE(B > 0 && H >= K && W >= K, "na_bwd: feature map %dx%d smaller than the %dx%d window", H, W, K, K);
   LMN_REQUIRE(hd == 1 || hd == 2 || hd == 4 || hd == 8 || hd == 16, "na_bwd: head_dim %d not in {1,2,4,8,16}", hd);
   LMN_REQUIRE((heads * hd) % 4 == 0 && heads <= 16, "na_bwd: heads=%d hd=%d (C %% 4 == 0, at most 16 heads)", heads, hd);
   NaGeom g{B, H, W, heads * hd, heads * hd / 4, heads, scale};
@@ -679,6 +900,25 @@ int lmn_na_bwd(const void* qkv_, const float* rpb, const void* dout_, void* dqkv
   const int gq = grid > 2048 ? 2048 : grid;
   hipStream_t st = (hipStream_t)stream;
   const size_t sh = (2 * heads * 25 + 256 * 36) * sizeof(float);
+  if (gen || K != 3) {
+    const size_t gsh = (size_t)heads * (2 * K - 1) * (2 * K - 1) * sizeof(float);
+#define LMN_NAG(HDV)                                                                                                 \
+  do {                                                                                                               \
+    if (g_lmn_prof_on) lmn_prof_cost(2.0 * 3 * K * K * (double)B * H * W * g.C, (act_dtype == LMN_BF16 ? 2.0 : 4.0) * 5 * (double)B * H * W * g.C); \
+    LMN_LAUNCH((na_bwd_q_gen_kernel<HDV, T>), dim3(gq), dim3(256), gsh, st, (const T*)qkv, rpb, (const T*)dout, (T*)dqkv, drpb, stat, g, K);      \
+    if (g_lmn_prof_on) lmn_prof_cost(2.0 * 3 * K * K * (double)B * H * W * g.C, (act_dtype == LMN_BF16 ? 2.0 : 4.0) * 2 * (double)B * H * W * g.C); \
+    LMN_LAUNCH((na_bwd_kv_gen_kernel<HDV, T>), dim3(grid), dim3(256), 0, st, (const T*)qkv, rpb, (const T*)dout, (T*)dqkv, stat, g, K);          \
+  } while (0)
+    LMN_ACT_DISPATCH(act_dtype, switch (hd) {
+      case 1: LMN_NAG(1); break;
+      case 2: LMN_NAG(2); break;
+      case 4: LMN_NAG(4); break;
+      case 8: LMN_NAG(8); break;
+      default: LMN_NAG(16); break;
+    });
+#undef LMN_NAG
+    return lmn_launch_status("na_bwd");
+  }
   // algorithmic cost (7*C per pixel for the pair): query pass reads q,k,v,dout and writes dq; key pass writes dk,dv
 #define NA_COST_Q if (g_lmn_prof_on) lmn_prof_cost(2.0 * 3 * 9 * (double)B * H * W * g.C, (act_dtype == LMN_BF16 ? 2.0 : 4.0) * 5 * (double)B * H * W * g.C)
 #define NA_COST_KV if (g_lmn_prof_on) lmn_prof_cost(2.0 * 3 * 9 * (double)B * H * W * g.C, (act_dtype == LMN_BF16 ? 2.0 : 4.0) * 2 * (double)B * H * W * g.C)

@@ -19,7 +19,7 @@ ACT_NONE, ACT_HSWISH, ACT_GELU = 0, 1, 2
 STATS_NONE, STATS_SUM_SQ, STATS_EP = 0, 1, 2
 F32, BF16 = 0, 1            # matrix-core operand type of the dense contractions (LMN_F32 / LMN_BF16)
 _MMA = [F32]                # ... of the pass in flight (engine.begin_pass)
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 
 class SrcT(C.Structure):
@@ -641,19 +641,26 @@ def se_bwd_params(dvec, gsum, inv_hw, hidden, dw1, db1, dw2, db2):
 
 
 # ------------------------------------------------------------------------------------------ attention
-def na_fwd(qkv, rpb, out, heads):
+def _na_k(rpb, heads, direct):
+    K = (rpb.shape[-1] + 1) // 2          # rpb: [heads][2K-1][2K-1]
+    assert tuple(rpb.shape) == (heads, 2 * K - 1, 2 * K - 1), tuple(rpb.shape)
+    return -K if direct else K            # negative: the direct (run-time K) kernels also at K = 3
+
+
+def na_fwd(qkv, rpb, out, heads, direct=False):
     B, H, W, C3 = qkv.shape
     hd = C3 // 3 // heads
-    _check(load().lmn_na_fwd(_pa(qkv), _p(rpb), _pa(out), B, H, W, heads, hd, _f(hd ** -0.5), _dt(qkv, out), _stream()), "na_fwd")
+    _check(load().lmn_na_fwd(_pa(qkv), _p(rpb), _pa(out), B, H, W, heads, hd, _na_k(rpb, heads, direct), _f(hd ** -0.5),
+                             _dt(qkv, out), _stream()), "na_fwd")
 
 
-def na_bwd(qkv, rpb, dout, dqkv, drpb, heads, stat=None):
+def na_bwd(qkv, rpb, dout, dqkv, drpb, heads, stat=None, direct=False):
     B, H, W, C3 = qkv.shape
     hd = C3 // 3 // heads
     if stat is None:
         stat = (_ALLOC[0] or _default_alloc)(qkv.device, (B * H * W * 2 * heads,))
     _check(load().lmn_na_bwd(_pa(qkv), _p(rpb), _pa(dout), _pa(dqkv), _p(drpb), _p(stat), B, H, W, heads, hd,
-                             _f(hd ** -0.5), _dt(qkv, dout, dqkv), _stream()), "na_bwd")
+                             _na_k(rpb, heads, direct), _f(hd ** -0.5), _dt(qkv, dout, dqkv), _stream()), "na_bwd")
 
 
 def gattn_fwd(qkv, out, lse, heads):

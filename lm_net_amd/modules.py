@@ -148,7 +148,7 @@ class NeighborhoodAttention2D(_Container):
 
     def __init__(self, dim, num_heads, kernel_size=3):
         super().__init__()
-        assert kernel_size == 3, "the reference hard-codes kernel_size=3"
+        assert kernel_size % 2 == 1 and 3 <= kernel_size <= 13, kernel_size   # (the reference constructs 3: the LDS-tiled kernels)
         assert dim % num_heads == 0
         self.num_heads, self.head_dim, self.kernel_size = num_heads, dim // num_heads, kernel_size
         self.qkv = nn.Linear(dim, 3 * dim)
@@ -158,11 +158,11 @@ class NeighborhoodAttention2D(_Container):
 
 
 class NeighborhoodTransformer(_Container):  # core/modules.py:504-521
-    def __init__(self, ch, num_heads):
+    def __init__(self, ch, num_heads, kernel_size=3):
         super().__init__()
         self.patchembedding = OverlapPatchEmbed(ch, ch)
         self.norm1 = nn.LayerNorm(ch)
-        self.att1 = NeighborhoodAttention2D(ch, num_heads, 3)
+        self.att1 = NeighborhoodAttention2D(ch, num_heads, kernel_size)   # (the reference: always 3, core/modules.py:509)
         self.norm2 = nn.LayerNorm(ch)
         self.mlp = Mlp(ch, 2 * ch, ch)
 

@@ -236,11 +236,11 @@ class NeighborhoodTransformer(nn.Module):
     """3x3 patch-embed -> pre-LN block with neighborhood attention (K=3) + Mlp(C,2C,C).
     core/modules.py:504-521."""
 
-    def __init__(self, ch, num_heads):
+    def __init__(self, ch, num_heads, kernel_size=3):
         super().__init__()
         self.patchembedding = OverlapPatchEmbed(ch, ch)
         self.norm1 = nn.LayerNorm(ch)
-        self.att1 = NeighborhoodAttention2D(dim=ch, num_heads=num_heads, kernel_size=3)
+        self.att1 = NeighborhoodAttention2D(dim=ch, num_heads=num_heads, kernel_size=kernel_size)   # (the reference: 3)
         self.norm2 = nn.LayerNorm(ch)
         self.mlp = Mlp(ch, 2 * ch, ch)
 
@@ -258,7 +258,7 @@ def _stage(cin, cexp, cout):
 class LM_Net(nn.Module):
     """core/LM_Net.py:5-123 (ctor 6-87, structural_reparam 90-93, forward 95-123)."""
 
-    def __init__(self, channel, n_classes=2, filters=(12, 24, 48, 96, 192), deep_supervision=False):
+    def __init__(self, channel, n_classes=2, filters=(12, 24, 48, 96, 192), deep_supervision=False, na_kernel_size=3):
         super().__init__()
         f = list(filters)
         self.filters, self.deep_supervision = f, deep_supervision
@@ -280,10 +280,10 @@ class LM_Net(nn.Module):
         self.skip2 = M3Skip([f[1], f[2], f[3]])
         self.skip3 = M3Skip([f[0], f[1], f[2]])
         self.skip4 = M2Skip([f[0], f[1]], "top")
-        self.natt1 = NeighborhoodTransformer(f[3], NUM_HEADS)
-        self.natt2 = NeighborhoodTransformer(f[2], NUM_HEADS)
-        self.natt3 = NeighborhoodTransformer(f[1], NUM_HEADS)
-        self.natt4 = NeighborhoodTransformer(f[0], NUM_HEADS)
+        self.natt1 = NeighborhoodTransformer(f[3], NUM_HEADS, na_kernel_size)
+        self.natt2 = NeighborhoodTransformer(f[2], NUM_HEADS, na_kernel_size)
+        self.natt3 = NeighborhoodTransformer(f[1], NUM_HEADS, na_kernel_size)
+        self.natt4 = NeighborhoodTransformer(f[0], NUM_HEADS, na_kernel_size)
         self.output_layer = _conv(f[0], n_classes, 1)
 
     def structural_reparam(self):

@@ -542,29 +542,36 @@ def _check_se(B, E, Rr, HW):
 
 # ------------------------------------------------------------------------------------------------ attention
 def check_na():
+    """K = 3: the LDS-tiled kernels and (direct=True) the run-time-K direct kernels; K = 5, 7: the direct kernels (natten kernel_size;
+    core/LM_Net.py:81-84 carries [3, 5]).  Oracle: oracle/natten_ref.py for every K (test_oracle_na.py pins its K = 5 form)."""
     rows = []
-    for (B, H, W, hd) in [(2, 7, 9, 1), (1, 6, 5, 2), (2, 5, 8, 4), (1, 9, 6, 8), (1, 3, 3, 2), (1, 3, 17, 1),
-                          (2, 37, 41, 1), (1, 16, 52, 2), (2, 31, 18, 2), (1, 48, 33, 1)]:  # LDS-tiled query pass (C <= 24, maps >= 16)
+    cases = [(3, s) for s in [(2, 7, 9, 1), (1, 6, 5, 2), (2, 5, 8, 4), (1, 9, 6, 8), (1, 3, 3, 2), (1, 3, 17, 1),
+                              (2, 37, 41, 1), (1, 16, 52, 2), (2, 31, 18, 2), (1, 48, 33, 1)]]  # LDS-tiled query pass (C <= 24, maps >= 16)
+    cases += [(5, s) for s in [(2, 7, 9, 1), (1, 5, 5, 2), (1, 9, 6, 4), (2, 23, 18, 2), (1, 11, 12, 8), (1, 5, 21, 16)]]
+    cases += [(7, s) for s in [(1, 7, 7, 1), (2, 9, 12, 2), (1, 22, 15, 4), (1, 8, 13, 8)]]
+    for K, (B, H, W, hd) in cases:
         heads, Cn = 12, 12 * hd
         qkv = R(B, H, W, 3 * Cn, seed=91).requires_grad_(True)
-        rpb = (R(heads, 5, 5, seed=92) * 0.5).requires_grad_(True)
+        rpb = (R(heads, 2 * K - 1, 2 * K - 1, seed=92) * 0.5).requires_grad_(True)
         q, k, v = qkv.reshape(B, H, W, 3, heads, hd).permute(3, 0, 4, 1, 2, 5).unbind(0)
-        attn = torch.softmax(natten_ref.na2d_qkrpb(q * hd ** -0.5, k, rpb, 3), -1)
-        o_ref = natten_ref.na2d_av(attn, v, 3).permute(0, 2, 3, 1, 4).reshape(B, H, W, Cn)
+        attn = torch.softmax(natten_ref.na2d_qkrpb(q * hd ** -0.5, k, rpb, K), -1)
+        o_ref = natten_ref.na2d_av(attn, v, K).permute(0, 2, 3, 1, 4).reshape(B, H, W, Cn)
         do = R(B, H, W, Cn, seed=93)
         o_ref.backward(do)
-        tag = " hd=%d %dx%d" % (hd, H, W)
+        tag = " K=%d hd=%d %dx%d" % (K, hd, H, W)
         if H * W <= 64:
-            bf = natten_ref.na2d_bruteforce(q.detach() * hd ** -0.5, k.detach(), v.detach(), rpb.detach(), 3)
+            bf = natten_ref.na2d_bruteforce(q.detach() * hd ** -0.5, k.detach(), v.detach(), rpb.detach(), K)
             rows.append(("na oracle vec==bruteforce" + tag, rel(o_ref, bf.permute(0, 2, 3, 1, 4).reshape(B, H, W, Cn)), 1e-9))
-        out = torch.full((B, H, W, Cn), float("nan"), device=DEV)
-        hip.na_fwd(dev(qkv), dev(rpb), out, heads)
-        rows.append(("na_fwd" + tag, rel(out, o_ref), TOL))
-        dqkv = torch.full((B, H, W, 3 * Cn), float("nan"), device=DEV)
-        drpb = torch.zeros(heads, 5, 5, device=DEV)
-        hip.na_bwd(dev(qkv), dev(rpb), dev(do), dqkv, drpb, heads)
-        rows.append(("na_bwd dqkv" + tag, rel(dqkv, qkv.grad), 2e-4))
-        rows.append(("na_bwd drpb" + tag, rel(drpb, rpb.grad), 2e-4))
+        for direct in ((False, True) if K == 3 else (False,)):
+            t2 = tag + (" direct" if direct else "")
+            out = torch.full((B, H, W, Cn), float("nan"), device=DEV)
+            hip.na_fwd(dev(qkv), dev(rpb), out, heads, direct=direct)
+            rows.append(("na_fwd" + t2, rel(out, o_ref), TOL))
+            dqkv = torch.full((B, H, W, 3 * Cn), float("nan"), device=DEV)
+            drpb = torch.zeros(heads, 2 * K - 1, 2 * K - 1, device=DEV)
+            hip.na_bwd(dev(qkv), dev(rpb), dev(do), dqkv, drpb, heads, direct=direct)
+            rows.append(("na_bwd dqkv" + t2, rel(dqkv, qkv.grad), 2e-4))
+            rows.append(("na_bwd drpb" + t2, rel(drpb, rpb.grad), 2e-4))
     return rows
 
 

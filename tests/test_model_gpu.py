@@ -193,6 +193,34 @@ def test_non_square_and_odd_tile_sizes_vs_oracle():
         assert err < 2e-3 * float(po.grad.abs().max()) or err < 5e-5 * gmax, (k, err)
 
 
+@pytest.mark.parametrize("K", [5, 7])
+def test_larger_neighborhood_window_vs_oracle(K):
+    """natten kernel_size 5 / 7 in the four NAT blocks (the reference's LM_Net signature carries [3, 5], core/LM_Net.py:81-84; it
+    constructs 3, core/modules.py:509): whole model, training mode, logits and every gradient against the CPU oracle.  112x128:
+    the coarsest NAT map is 14x16 >= K."""
+    from oracle.lmnet_ref import LM_Net as Oracle
+    from lm_net_amd import LM_Net
+    ora = Oracle(3, 2, na_kernel_size=K)
+    fill_module(ora, 21)
+    no_dropout(ora)
+    m = LM_Net(3, 2, na_kernel_size=K)
+    fill_module(m, 21)
+    no_dropout(m)
+    m = m.cuda()
+    assert m.natt4.att1.rpb.shape == (12, 2 * K - 1, 2 * K - 1)
+    x = det_input((2, 3, 112, 128), "nak/x")
+    ora.train(); m.train()
+    yo, yg = ora(x), m(x.cuda())
+    assert rel_err(yg, yo) < TOL
+    G = det_input(tuple(yo.shape), "nak/G")
+    (yo * G).sum().backward()
+    (yg * G.cuda()).sum().backward()
+    gmax = max(float(p.grad.abs().max()) for p in ora.parameters())
+    for (k, po), (_, pg) in zip(ora.named_parameters(), m.named_parameters()):
+        err = float((pg.grad.cpu() - po.grad).abs().max())
+        assert err < 2e-3 * float(po.grad.abs().max()) or err < 5e-5 * gmax, (k, err)
+
+
 def test_fused_adamw_matches_torch_adamw_and_exchanges_state():
     """lm_net_amd.optim.FusedAdamW (one kernel over the flat buffers) against torch.optim.AdamW -- the reference's
     optimizer (train.py:156) -- on the same model, data and loss: parameters after 3 steps, then a state_dict

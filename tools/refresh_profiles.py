@@ -75,5 +75,5 @@ json.dump(dict(note="rocprofv3 --pmc passes over `python3 bench.py --steps 2 --w
                                serialized_gpu_ms_at_2p4GHz=round(tot_cyc / STEPS / 2.4e6, 2)),
                kernels=out), open(os.path.join(dst, PFX + "pmc.json"), "w"), indent=1)
 print(json.dumps(json.load(open(os.path.join(dst, PFX + "pmc.json")))["whole_step"]))
-for k in ("wgrad_lds_kernel<9, 2, 2, 0>", "dw_fwd_strip_kernel<float>", "dw_bwd_strip_kernel<float, 0>", "na_fwd_kernel<1, float>"):
+for k in ("wgrad_lds_kernel<9, 2, 2, 0>", "dw_fwd_strip_kernel<float>", "dw_bwd_strip_kernel<float, 0, true>", "na_fwd_kernel<1, float>"):
     print(k, {a: (round(b) if b > 10 else b) for a, b in out.get(k, {}).items()})
