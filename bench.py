@@ -272,7 +272,8 @@ class Run:
         if graphs:
             self.net.enable_graphs()    # forward / backward as two hipGraph replays per step (captured during the warm-up)
         elif plans:
-            self.net.enable_plans()     # forward / backward as one lmn_plan_run each (recorded on the 3rd step of the shape)
+            # forward / backward as one lmn_plan_run each (recorded on the 3rd step of the shape); the backward node assigns .grad itself
+            self.net.enable_plans(direct_grads=True)
         self.opt = FusedAdamW(self.net, lr=1e-3, weight_decay=1e-4)     # torch.optim.AdamW semantics, one launch per step
         self.x, self.y = make_batch(B, size, size, dev, 1234 + rank)    # rank-offset data seed (train.py:42)
         self.crit = SegLoss(ce_weight=(1.0, 4.0), dice_weight=(1.0, 4.0), label_smoothing=0.001).to(dev)   # fused CE + Dice

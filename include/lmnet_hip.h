@@ -547,6 +547,9 @@ int lmn_plan_record_begin(lmn_plan_t plan);              /* start / resume recor
 int64_t lmn_plan_record_end(lmn_plan_t plan, int seal);  /* pause (seal=0) or finish (seal=1); returns #ops recorded  */
 int64_t lmn_plan_size(lmn_plan_t plan);
 int lmn_plan_run(lmn_plan_t plan, int64_t lo, int64_t hi); /* re-issue ops [lo, hi); hi < 0 = to the end              */
+/* diagnostics: run the plan once timing every entry on the HOST clock; text lines "entry \t ops \t total_us" (returns the bytes
+ * needed incl. the terminator; -1 on error) */
+int64_t lmn_plan_host_profile(lmn_plan_t plan, char* out, int64_t cap);
 
 /* ------------------------------------------------------------------------------------------
  * In-library kernel timer (measurement): HIP events on the launch stream around every kernel launch whose

@@ -90,6 +90,7 @@ class _PlannedStep:
         self.x = self.out = self.dlogits = None
         self.cx = None
         self.flat = None           # static flat gradient buffer
+        self.views = None          # per-parameter views of it (direct_grads)
         self.G = None
         self.sizes = None
         self.shapes = None
@@ -111,6 +112,31 @@ class _LMNetPlanFunction(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dlogits):
         return (None, None, None) + tuple(ctx.model._plan_backward(ctx.ps, dlogits))
+
+
+class _LMNetPlanDirectFunction(torch.autograd.Function):
+    """enable_plans(direct_grads=True): the node has TWO tensor inputs (the batch and a one-element anchor) instead of the
+    batch and ~510 parameters, and its backward assigns the gradient views to `.grad` itself.  The autograd engine then runs
+    no AccumulateGrad node per parameter (2.5 ms of host time per step: at batch 1 the step is host-bound)."""
+
+    @staticmethod
+    def forward(ctx, x, anchor, model, ps):
+        ctx.model, ctx.ps = model, ps
+        return model._plan_forward(ps, x)
+
+    @staticmethod
+    def backward(ctx, dlogits):
+        model = ctx.model
+        grads = model._plan_backward(ctx.ps, dlogits, direct=True)
+        if grads is not None:                      # (None: accumulated in place into the .grad tensors that alias the buffer)
+            for p, g in zip(model._param_list(), grads):
+                if not p.requires_grad:
+                    continue
+                if p.grad is None:
+                    p.grad = g
+                else:
+                    p.grad += g
+        return None, None, None, None
 
 
 class LM_Net(nn.Module):
@@ -165,6 +191,7 @@ class LM_Net(nn.Module):
         #  AMP branch, utils/train_eval_utils.py:130-138, keeps working)
         self.compute_dtype = None
         self.use_plans = False    # replay recorded C-side schedules (see enable_plans)
+        self._direct_grads = False
         self._plans = {}
         self._head_bias4 = None
         # data-parallel hooks (ddp.py): begin(flat) at the start of backward, ready(lo, hi) when the
@@ -203,6 +230,8 @@ class LM_Net(nn.Module):
             ps = self._plan_for(x)
             if ps is not None:
                 if self._save_tape:
+                    if self._direct_grads:
+                        return _LMNetPlanDirectFunction.apply(x, self._grad_anchor(x.device), self, ps)
                     return _LMNetPlanFunction.apply(x, self, ps, *params)
                 return self._plan_forward(ps, x)
         if self.use_graphs and self.training and self._save_tape and not x.requires_grad and not self._keep_taps:
@@ -230,19 +259,31 @@ class LM_Net(nn.Module):
         raise ValueError("LM_Net.compute_dtype must be None, 'fp32', 'bf16' or 'bf16-mma' (got %r)" % (cd,))
 
     # ------------------------------------------------------------------ recorded C-side schedules (lmn_plan_*)
-    def enable_plans(self, on=True):
+    def enable_plans(self, on=True, direct_grads=False):
         """Run every pass of a repeated input shape as ONE call into the library (include/lmnet_hip.h, lmn_plan_*): the
         first two passes of a (shape, mode) run launch by launch and size the arena, the third is recorded while it runs,
         later ones are `lmn_plan_run` replays -- same kernels, same four HIP streams and cross-stream events as the
         host-launched schedule (unlike a hipGraph capture, which cannot carry the stream forks), ~2 ms of host time per
         step instead of 16-20.  Contract while enabled: fixed parameter storage; the returned gradients are views of one
         static buffer (as `zero_grad(set_to_none=True)` expects; a `.grad` that still aliases it is accumulated into
-        correctly); data-parallel buckets are reported between plan segments; dropout draws from a device-side counter."""
+        correctly); data-parallel buckets are reported between plan segments; dropout draws from a device-side counter.
+        direct_grads=True: the backward node writes `.grad` itself instead of returning ~510 gradients to the autograd engine
+        (one AccumulateGrad node each, 2.5 ms of host time per step).  `loss.backward()` then behaves as before (including
+        accumulation into existing `.grad`); `torch.autograd.grad(loss, parameters)` and tensor hooks on parameters do not see
+        these gradients -- hence opt-in."""
         self.use_plans = bool(on)
+        self._direct_grads = bool(on and direct_grads)
         if not on:
             self._plans = {}
             self._engine.seed_ctr = None if not self.use_graphs else self._engine.seed_ctr
         return self
+
+    def _grad_anchor(self, dev):
+        a = self.__dict__.get("_anchor")
+        if a is None or a.device != dev:
+            a = torch.zeros(1, device=dev, requires_grad=True)      # what makes the direct node part of the autograd graph
+            self.__dict__["_anchor"] = a
+        return a
 
     def _plan_for(self, x):
         taped = bool(self._save_tape)          # a backward may follow (training, or eval-mode BatchNorm with gradients enabled)
@@ -313,7 +354,7 @@ class LM_Net(nn.Module):
             ps.pending = ps.cx is not None
             return ps.out.clone()
 
-    def _plan_backward(self, ps, dlogits):
+    def _plan_backward(self, ps, dlogits, direct=False):
         eng = self._engine
         L = self._ensure_grad_layout()
         params = self._param_list()
@@ -369,7 +410,14 @@ class LM_Net(nn.Module):
             # fresh views every time: AccumulateGrad then takes them as .grad without a copy.  A parameter whose .grad still
             # aliases the static buffer gets its gradient from a copy (autograd then adds it to the kept values, see `old`)
             if old is None:
+                if direct:                              # the same view objects every step: assigned to .grad by the node
+                    if ps.views is None:
+                        ps.views = [ps.flat[a:a + n].view(shp) for a, n, shp in ps.sizes]
+                    return ps.views
                 return [ps.flat[a:a + n].view(shp) for a, n, shp in ps.sizes]
+            if direct and all(al or not p.requires_grad for al, p in zip(alias, params)):
+                ps.flat.add_(old)                       # every .grad aliases the buffer: accumulate in place, one launch
+                return None
             new = ps.flat.clone()
             ps.flat.copy_(old)                          # the aliased .grad tensors keep their accumulated values
             return [new[a:a + n].view(shp) for a, n, shp in ps.sizes]

@@ -51,11 +51,11 @@ void lmn_prof_cost(double flops, double bytes);  // algorithmic cost of the NEXT
 #ifdef __cplusplus
 #include <functional>
 extern thread_local void* g_lmn_rec;  // plan being recorded by this thread, or NULL
-void lmn_rec_push(std::function<int()>&& f);
+void lmn_rec_push(std::function<int()>&& f, const char* what);
 // LMN_REC(call-expression using only by-value locals): record the entry, then fall through and execute it
 #define LMN_REC(...)                                                    \
   do {                                                                  \
-    if (g_lmn_rec) lmn_rec_push([=]() -> int { return __VA_ARGS__; });  \
+    if (g_lmn_rec) lmn_rec_push([=]() -> int { return __VA_ARGS__; }, #__VA_ARGS__);  \
   } while (0)
 #endif
 

@@ -2583,7 +2583,7 @@ int lmn_conv_pack(const float* w, float* wpack, int ksize, int Cout, int Cin, in
   if (g_lmn_rec && nsrc >= 1 && nsrc <= 3) {
     int32_t cc[3] = {c[0], nsrc > 1 ? c[1] : 0, nsrc > 2 ? c[2] : 0};
     const int32_t c0 = cc[0], c1 = cc[1], c2 = cc[2];
-    lmn_rec_push([=]() -> int { const int32_t ca[3] = {c0, c1, c2}; return lmn_conv_pack(w, wpack, ksize, Cout, Cin, nsrc, ca, transposed, row_off, rows, dtype, stream); });
+    lmn_rec_push([=]() -> int { const int32_t ca[3] = {c0, c1, c2}; return lmn_conv_pack(w, wpack, ksize, Cout, Cin, nsrc, ca, transposed, row_off, rows, dtype, stream); }, "lmn_conv_pack(");
   }
   LMN_REQUIRE(ksize == 1 || ksize == 3, "conv_pack: ksize %d", ksize);
   LMN_REQUIRE(nsrc >= 1 && nsrc <= 3, "conv_pack: nsrc %d", nsrc);
@@ -2619,7 +2619,7 @@ int lmn_conv_fwd(const lmn_conv_args_t* args, lmn_stream_t stream) {
   LMN_REQUIRE(args, "conv_fwd: null args");
   if (g_lmn_rec) {
     const lmn_conv_args_t copy = *args;
-    lmn_rec_push([copy, stream]() -> int { return lmn_conv_fwd(&copy, stream); });
+    lmn_rec_push([copy, stream]() -> int { return lmn_conv_fwd(&copy, stream); }, "lmn_conv_fwd(");
   }
   const lmn_conv_args_t& A = *args;
   LMN_REQUIRE(A.ksize == 1 || A.ksize == 3, "conv_fwd: ksize %d", A.ksize);
@@ -3129,7 +3129,7 @@ int lmn_wgrad_reduce_batch(const lmn_reduce_job_t* jobs_dev, int njobs, int64_t 
 int lmn_conv_wgrad(const lmn_wgrad_args_t* args, lmn_stream_t stream) {
   if (args && g_lmn_rec) {
     const lmn_wgrad_args_t copy = *args;
-    lmn_rec_push([copy, stream]() -> int { return lmn_conv_wgrad(&copy, stream); });
+    lmn_rec_push([copy, stream]() -> int { return lmn_conv_wgrad(&copy, stream); }, "lmn_conv_wgrad(");
   }
   LMN_REQUIRE(args, "conv_wgrad: null args");
   const lmn_wgrad_args_t& A = *args;

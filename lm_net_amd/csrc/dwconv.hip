@@ -1375,7 +1375,7 @@ int lmn_dw_fwd(const void* x1, void* pre, float* gsum, int B, int H, int W, int 
   { const int rc = se_fuse_check(se, &sf, E, "dw_fwd"); if (rc) return rc; }
   lmn_dw_pre_t zp;
   { const int rc = dw_pre_check(zpre, &zp, false, "dw_fwd"); if (rc) return rc; }
-  if (g_lmn_rec) lmn_rec_push([=]() -> int { return lmn_dw_fwd(x1, pre, gsum, B, H, W, E, keff, beff, &sf, &zp, act_dtype, stream); });
+  if (g_lmn_rec) lmn_rec_push([=]() -> int { return lmn_dw_fwd(x1, pre, gsum, B, H, W, E, keff, beff, &sf, &zp, act_dtype, stream); }, "lmn_dw_fwd(");
   LMN_REQUIRE_DT(act_dtype, "dw_fwd");
   LMN_REQUIRE(x1 && pre && gsum && keff && beff, "dw_fwd: null pointer");
   LMN_REQUIRE(B > 0 && H > 0 && W > 0 && E > 0 && E % 4 == 0, "dw_fwd: E=%d must be a multiple of 4", E);
@@ -1425,7 +1425,7 @@ int lmn_dw_fwd_bn(const void* x1, void* pre, float* gsum, int B, int H, int W, i
                        (const float*)nullptr, (const float*)nullptr, fn, sf, DwPreS{zp.A, zp.shift}, strips, segs, seg_rows, chunks));
     return lmn_launch_status("dw_fwd_bn");
   };
-  if (g_lmn_rec) lmn_rec_push(launch);
+  if (g_lmn_rec) lmn_rec_push(launch, "lmn_dw_fwd_bn(");
   return launch();
 }
 
@@ -1444,7 +1444,7 @@ int lmn_dw_finalize_merge(const float* stats, float count, const float* const* g
     }
     lmn_rec_push([=]() -> int {
       return lmn_dw_finalize_merge(stats, count, a.g, a.b, a.rm, a.rv, a.eps, a.mom, w5, w3, wv, wh, mean, rstd, A, keff, beff, E, stream);
-    });
+    }, "lmn_dw_finalize_merge(");
   }
   DwBnPtrs bn;
   for (int b = 0; b < 4; ++b) {
@@ -1470,7 +1470,7 @@ int lmn_dw_stats(const void* x1, int B, int H, int W, int E, const float* w5, co
                  const float* wh, float* stats, const lmn_dw_pre_t* zpre, int act_dtype, lmn_stream_t stream) {
   lmn_dw_pre_t zp;
   { const int rc = dw_pre_check(zpre, &zp, true, "dw_stats"); if (rc) return rc; }
-  if (g_lmn_rec) lmn_rec_push([=]() -> int { return lmn_dw_stats(x1, B, H, W, E, w5, w3, wv, wh, stats, &zp, act_dtype, stream); });
+  if (g_lmn_rec) lmn_rec_push([=]() -> int { return lmn_dw_stats(x1, B, H, W, E, w5, w3, wv, wh, stats, &zp, act_dtype, stream); }, "lmn_dw_stats(");
   LMN_REQUIRE_DT(act_dtype, "dw_stats");
   LMN_REQUIRE(x1 && w5 && w3 && wv && wh && stats, "dw_stats: null pointer");
   LMN_REQUIRE(B > 0 && H > 0 && W > 0 && E > 0 && E % 4 == 0, "dw_stats: E=%d must be a multiple of 4", E);
@@ -1490,7 +1490,7 @@ int lmn_dw_bwd_stats(const void* x1, const void* pre, const void* u, const float
     LMN_REQUIRE(E + seb->R + 256 <= FS_XR * SW_XC * SW_CS, "dw_bwd_stats: E + R = %d exceeds the block's scratch", E + seb->R);
     sb = *seb;
   }
-  if (g_lmn_rec) lmn_rec_push([=]() -> int { return lmn_dw_bwd_stats(x1, pre, u, s, dm, dpre, B, H, W, E, w5, w3, wv, wh, bstats, &sb, &zp, act_dtype, stream); });
+  if (g_lmn_rec) lmn_rec_push([=]() -> int { return lmn_dw_bwd_stats(x1, pre, u, s, dm, dpre, B, H, W, E, w5, w3, wv, wh, bstats, &sb, &zp, act_dtype, stream); }, "lmn_dw_bwd_stats(");
   LMN_REQUIRE_DT(act_dtype, "dw_bwd_stats");
   LMN_REQUIRE(x1 && pre && u && s && (dm || sb.ds) && dpre && w5 && w3 && wv && wh && bstats, "dw_bwd_stats: null pointer");
   LMN_REQUIRE(B > 0 && H > 0 && W > 0 && E > 0 && E % 4 == 0, "dw_bwd_stats: E=%d must be a multiple of 4", E);
@@ -1563,7 +1563,7 @@ int lmn_dw_bwd_bn(const void* x1, const void* dpre, void* dx1, int B, int H, int
 #undef LMN_DWB
     return lmn_launch_status("dw_bwd_bn");
   };
-  if (g_lmn_rec) lmn_rec_push(launch);
+  if (g_lmn_rec) lmn_rec_push(launch, "lmn_dw_bwd_bn(");
   return launch();
 }
 

@@ -7,6 +7,7 @@
 // the cross-stream dependencies re-created by events -- without any host code per kernel.
 #include "common.h"
 
+#include <chrono>
 #include <map>
 #include <mutex>
 #include <string>
@@ -20,6 +21,7 @@ namespace {
 // ------------------------------------------------------------------------------------------------ plan
 struct Plan {
   std::vector<std::function<int()>> ops;
+  std::vector<const char*> names;  // the recorded call expressions (string literals of the entry points)
   std::vector<hipEvent_t> events;  // owned by the plan: one per recorded cross-stream wait
   bool sealed = false;
 };
@@ -85,9 +87,12 @@ hipEvent_t prof_event() {
 
 }  // namespace
 
-void lmn_rec_push(std::function<int()>&& f) {
+void lmn_rec_push(std::function<int()>&& f, const char* what) {
   Plan* p = (Plan*)g_lmn_rec;
-  if (p && !p->sealed) p->ops.push_back(std::move(f));
+  if (p && !p->sealed) {
+    p->ops.push_back(std::move(f));
+    p->names.push_back(what);
+  }
 }
 
 void lmn_prof_cost(double flops, double bytes) {
@@ -216,6 +221,37 @@ int lmn_plan_run(lmn_plan_t plan, int64_t lo, int64_t hi) {
     if (rc != 0) return rc;
   }
   return 0;
+}
+
+// Host-side cost of a replay: runs the plan once, timing every entry on the host clock, and writes one line per entry point
+//   name \t ops \t total_us \n     (returns the bytes needed including the terminator, like lmn_prof_end)
+int64_t lmn_plan_host_profile(lmn_plan_t plan, char* out, int64_t cap) {
+  Plan* p = (Plan*)plan;
+  if (!p || g_lmn_rec) return -1;
+  struct Agg { int64_t n = 0; double us = 0; };
+  std::map<std::string, Agg> agg;
+  for (size_t i = 0; i < p->ops.size(); ++i) {
+    const auto t0 = std::chrono::steady_clock::now();
+    if (p->ops[i]() != 0) return -1;
+    const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+    std::string nm = i < p->names.size() && p->names[i] ? p->names[i] : "?";
+    nm = nm.substr(0, nm.find('('));
+    Agg& a = agg[nm];
+    a.n += 1;
+    a.us += us;
+  }
+  std::string s;
+  char line[256];
+  for (auto& kv : agg) {
+    snprintf(line, sizeof(line), "%s\t%lld\t%.1f\n", kv.first.c_str(), (long long)kv.second.n, kv.second.us);
+    s += line;
+  }
+  if (out && cap > 0) {
+    const size_t k = s.size() < (size_t)cap - 1 ? s.size() : (size_t)cap - 1;
+    memcpy(out, s.data(), k);
+    out[k] = 0;
+  }
+  return (int64_t)s.size() + 1;
 }
 
 // ---- kernel timer

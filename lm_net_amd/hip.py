@@ -126,7 +126,7 @@ SYMBOLS = [
     "lmn_conv_pack_size", "lmn_conv_pack", "lmn_conv_pack_batch", "lmn_sizeof_pack_job", "lmn_conv_fwd", "lmn_conv_wgrad", "lmn_conv_wgrad_workspace",
     "lmn_conv_wgrad_job", "lmn_wgrad_reduce_batch", "lmn_sizeof_reduce_job", "lmn_reparam_fold", "lmn_affine2", "lmn_reparam_wfin",
     "lmn_dw_stats", "lmn_dw_fwd", "lmn_dw_merge", "lmn_dw_finalize_merge", "lmn_dw_bwd_stats", "lmn_dw_bwd_coef", "lmn_dw_bwd", "lmn_dw_fwd_bn", "lmn_dw_bwd_bn",
-    "lmn_se_fwd", "lmn_se_bwd", "lmn_se_bwd_dm", "lmn_se_bwd_params", "lmn_na_fwd", "lmn_na_bwd", "lmn_gattn_fwd", "lmn_gattn_bwd",
+    "lmn_se_fwd", "lmn_se_bwd", "lmn_se_bwd_dm", "lmn_se_bwd_params", "lmn_na_fwd", "lmn_na_bwd", "lmn_plan_host_profile", "lmn_gattn_fwd", "lmn_gattn_bwd",
     "lmn_ln_fwd", "lmn_ln_bwd", "lmn_bnact_fwd", "lmn_bnact_bwd_stats", "lmn_bnact_bwd",
     "lmn_bn_finalize", "lmn_bn_fold", "lmn_bn_bwd_coef", "lmn_up2_fwd", "lmn_up2_bwd", "lmn_avgpool_fwd", "lmn_avgpool_bwd",
     "lmn_nchw_to_nhwc", "lmn_nhwc_to_nchw", "lmn_adamw_step", "lmn_segloss_fwd", "lmn_segloss_bwd", "lmn_confusion", "lmn_preprocess_u8", "lmn_fill", "lmn_add", "lmn_colsum", "lmn_copy_slice", "lmn_copy2d",
@@ -901,6 +901,16 @@ class Plan:
 
     def run(self, lo=0, hi=-1):
         _check(load().lmn_plan_run(self.h, _i64(lo), _i64(hi)), "plan_run")
+
+    def host_profile(self):
+        """Runs the plan once; -> {entry point: (ops, host microseconds)}"""
+        lib = load()
+        lib.lmn_plan_host_profile.restype = C.c_int64
+        buf = C.create_string_buffer(1 << 16)
+        n = int(lib.lmn_plan_host_profile(self.h, buf, _i64(1 << 16)))
+        if n < 0:
+            raise RuntimeError("plan_host_profile failed: " + last_error())
+        return {a: (int(b), float(c)) for a, b, c in (ln.split("\t") for ln in buf.value.decode().splitlines())}
 
     def __del__(self):
         try:

@@ -446,6 +446,20 @@ def test_plan_mode_matches_host_launches():
     g1 = [p.grad.clone() for p in d.parameters()]
     (d(x) * G).sum().backward()
     agree((i, p.grad, 2 * g) for i, (g, p) in enumerate(zip(g1, d.parameters())))
+    # direct_grads: the node assigns .grad itself (no AccumulateGrad per parameter) -- same gradients, same accumulation
+    dd = _net(seed=17).train()
+    dd.enable_plans(direct_grads=True)
+    for it in range(5):
+        for p in dd.parameters():
+            p.grad = None
+        (dd(x) * G).sum().backward()
+    assert all(p.grad is not None for p in dd.parameters())
+    pl = [q for q in dd._plans.values() if q.fwd is not None][0]
+    lo = pl.flat.data_ptr()
+    assert all(lo <= p.grad.data_ptr() < lo + 4 * pl.flat.numel() for p in dd.parameters())     # views of the static buffer
+    agree((k, pd.grad, pc.grad) for (k, pc), (_, pd) in zip(c.named_parameters(), dd.named_parameters()))
+    (dd(x) * G).sum().backward()                                            # second backward: accumulated in place
+    agree((k, pd.grad, 2 * pc.grad) for (k, pc), (_, pd) in zip(c.named_parameters(), dd.named_parameters()))
     # an eval forward between a training forward and its backward neither disturbs the tape nor the BatchNorm mode
     for p in d.parameters():
         p.grad = None
