@@ -791,9 +791,10 @@ class LM_Net(nn.Module):
         fork = eng.branch_overlap and not eng.capturing
         bst = eng.branch_stream(dev) if fork else None
 
-        # weight gradients of the branch chains: issued late (engine.wgrad, lazy_on) unless a data-parallel reducer wants the
-        # natt* / skip* buckets early
-        lazy = bool(fork and eng.lazy_wgrad and self.grad_ready_hook is None)
+        # weight gradients of the branch chains: issued late (engine.wgrad, lazy_on).  With a data-parallel reducer attached the
+        # natt* / skip* buckets are then handed on from the branch stream after that late issue (their all-reduce, a few MB, runs
+        # beside the encoder's backward like the weight gradients themselves)
+        lazy = bool(fork and eng.lazy_wgrad)
 
         def branch(nat, skip, dt):
             """Backward of one neighborhood-attention block and its skip fuser.  Their only input is dt (the decoder
