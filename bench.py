@@ -54,13 +54,55 @@ def _pmc():
     return None
 
 
+def _targs(name):
+    """('base', [template arguments]) of a kernel name; nested <> kept inside an argument."""
+    base, _, rest = name.partition("<")
+    args, cur, depth = [], "", 0
+    for ch in rest.rsplit(">", 1)[0] if rest else "":
+        if ch == "," and depth == 0:
+            args.append(cur.strip()); cur = ""
+        else:
+            depth += (ch == "<") - (ch == ">")
+            cur += ch
+    if cur.strip():
+        args.append(cur.strip())
+    return base.strip(), args
+
+
+def _pmc_match(kernel):
+    """PMC records of the kernels the in-library timer files under `kernel`.  The timer keys a launch by the text of its launch
+    site (`dw_stats_strip_kernel<MODE, T>`), rocprofv3 by the instantiated name (`dw_stats_strip_kernel<1, float>`): same base
+    name, and every LITERAL template argument of the launch site (numbers, true / false) equal; symbolic ones match anything."""
+    d = _pmc()
+    if not d:
+        return []
+    ks = d["kernels"]
+    if kernel in ks:
+        return [ks[kernel]]
+    base, args = _targs(kernel)
+    out = []
+    for name, rec in ks.items():
+        b2, a2 = _targs(name)
+        if b2 != base or len(a2) != len(args) or not rec:
+            continue
+        lit = lambda a: a in ("true", "false") or a.lstrip("-").isdigit()
+        if all((not lit(a)) or a == b for a, b in zip(args, a2)):
+            out.append(rec)
+    return out
+
+
+def pmc_field(kernel, field):
+    """Launch-weighted mean of a per-launch PMC figure over the instantiations behind `kernel` (profiles/rNN_pmc.json), or None."""
+    recs = [r for r in _pmc_match(kernel) if r.get(field) is not None and r.get("launches_sampled")]
+    n = sum(r["launches_sampled"] for r in recs)
+    return sum(r[field] * r["launches_sampled"] for r in recs) / n if n else None
+
+
 def pmc_traffic(kernel):
     """HBM bytes per launch of `kernel`, measured by separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this
     very command and committed under profiles/ (a PMC pass cannot run inside the timed loop)."""
-    try:
-        return round(_pmc()["kernels"][kernel]["hbm_bytes_per_launch"])
-    except (TypeError, KeyError, ValueError):
-        return None
+    v = pmc_field(kernel, "hbm_bytes_per_launch")
+    return None if v is None else round(v)
 
 
 MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: dense fp32 MFMA (v_mfma_f32_16x16x4_f32) = fp32 vector peak
@@ -178,13 +220,6 @@ def roofline_block(dominant, live, survey, tot_us, B, H, W, step_s, alone, esz=4
                  "(*_alone: the same events over 3 further steps of this process with the extra streams switched off); "
                  "traffic / mfma_util_pmc from the committed rocprofv3 PMC passes (profiles/)")
     return r
-
-
-def pmc_field(kernel, field):
-    try:
-        return _pmc()["kernels"][kernel][field]
-    except (TypeError, KeyError, ValueError):
-        return None
 
 
 def make_batch(B, H, W, device, seed):
