@@ -553,7 +553,8 @@ class LM_Net(nn.Module):
         main = torch.cuda.current_stream(dev)
         fork = eng.branch_overlap and not eng.capturing
         bst = eng.branch_stream(dev) if fork else None
-        slots = {2: 0, 4: 1, 6: 2, 8: 3}     # lmn event slot of each chain (by dropout tag)
+        sb = eng.slot_base                   # (four lmn event slots per engine: two models of one process do not share them)
+        slots = {2: sb, 4: sb + 1, 6: sb + 2, 8: sb + 3}     # lmn event slot of each chain (by dropout tag)
 
         def chain(skip, nat, xs_in, tag):
             """Skip fuser + neighborhood-attention block of one level: needs only encoder outputs and is needed

@@ -897,7 +897,10 @@ int lmn_na_bwd(const void* qkv_, const float* rpb, const void* dout_, void* dqkv
   LMN_REQUIRE((heads * hd) % 4 == 0 && heads <= 16, "na_bwd: heads=%d hd=%d (C %% 4 == 0, at most 16 heads)", heads, hd);
   NaGeom g{B, H, W, heads * hd, heads * hd / 4, heads, scale};
   const int grid = na_grid((int64_t)B * H * W * g.C4);
-  const int gq = grid > 2048 ? 2048 : grid;
+  // query pass: persistent blocks -- every block ends with one global atomic per (head, bias entry), and 1452 blocks x 300 entries
+  // serialised on 300 addresses were most of the pass on the small maps (level 3: 72 -> 51 us for the backward pair at 512 blocks)
+  static const int qcap = getenv("LMN_NA_QGRID") ? atoi(getenv("LMN_NA_QGRID")) : 512;
+  const int gq = grid > qcap ? qcap : grid;
   hipStream_t st = (hipStream_t)stream;
   const size_t sh = (2 * heads * 25 + 256 * 36) * sizeof(float);
   if (gen || K != 3) {

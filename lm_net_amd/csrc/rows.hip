@@ -157,6 +157,39 @@ __global__ __launch_bounds__(256) void bnact_fwd_kernel(const T* __restrict__ z,
   }
 }
 
+// Block-level sum of per-thread partials whose owner pattern is "thread t holds channel quad t % C4 of pixel slot t / C4"
+// (C4 need not be a power of two, so no DPP tree): the NV float4 partials of every thread are parked in LDS ([NV*4][256]) and
+// summed in two short chains (G groups of slots, then the G group sums) -- LDS atomics on the 4*C4 addresses serialised the
+// whole block at its tail (2040 atomics on 24 addresses at C = 12: ~20 us of a 42 us kernel over its four block rounds).
+// Result: red[v * C + c] for v < NV, c < C.  `park` holds NV*4*256 + NV*C*G floats.
+template <int NV>
+__device__ __forceinline__ void chan_block_reduce(const f32x4 (&s)[NV], float* park, float* red, int C, int C4, int NTH, int rpb, int tid) {
+#pragma unroll
+  for (int v = 0; v < NV; ++v)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) park[(v * 4 + k) * 256 + tid] = tid < NTH ? s[v][k] : 0.f;
+  __syncthreads();
+  const int nred = NV * C;
+  int G = 256 / nred;
+  if (G < 1) G = 1;
+  if (G > rpb) G = rpb;
+  float* p2 = park + NV * 4 * 256;
+  for (int i = tid; i < nred * G; i += 256) {
+    const int o = i / G, g = i - o * G;
+    const int v = o / C, ch = o - v * C, q = ch >> 2, k = ch & 3;
+    float a = 0.f;
+    for (int r = g; r < rpb; r += G) a += park[(v * 4 + k) * 256 + r * C4 + q];
+    p2[i] = a;
+  }
+  __syncthreads();
+  for (int o = tid; o < nred; o += 256) {
+    float a = 0.f;
+    for (int g = 0; g < G; ++g) a += p2[o * G + g];
+    red[o] = a;
+  }
+  __syncthreads();
+}
+
 // MODE 0: stats[2][C] += (sum dh, sum dh*zhat);  MODE 1: dz = c1*dh - c2 - zhat*c3
 // MODE 2: out[C] += column sums of x (bias gradients); x has pixel stride cstride
 template <int MODE, typename T>
@@ -173,10 +206,6 @@ __global__ __launch_bounds__(256) void chan_kernel(const T* __restrict__ z, cons
   const int NTH = (256 / C4) * C4;  // active threads: each keeps a fixed channel quad
   const int rpb = NTH / C4;
   const int tid = threadIdx.x;
-  if (MODE != 1) {
-    for (int i = tid; i < 2 * C; i += 256) red[i] = 0.f;
-    __syncthreads();
-  }
   f32x4 s0 = f32x4{0, 0, 0, 0}, s1 = s0;
   if (tid < NTH) {
     const int c = (tid % C4) * 4;
@@ -199,16 +228,16 @@ __global__ __launch_bounds__(256) void chan_kernel(const T* __restrict__ z, cons
         if (MODE == 1) st4(out_act + row * C + c, o);
       }
     }
-    if (MODE != 1) {
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        atomicAdd(&red[c + k], s0[k]);
-        if (MODE == 0) atomicAdd(&red[C + c + k], s1[k]);
-      }
-    }
   }
   if (MODE != 1) {
-    __syncthreads();
+    float* park = red + 2 * C;
+    if (MODE == 0) {
+      const f32x4 sv[2] = {s0, s1};
+      chan_block_reduce<2>(sv, park, red, C, C4, NTH, rpb, tid);
+    } else {
+      const f32x4 sv[1] = {s0};
+      chan_block_reduce<1>(sv, park, red, C, C4, NTH, rpb, tid);
+    }
     const int nred = MODE == 0 ? 2 * C : C;
     for (int i = tid; i < nred; i += 256) atomicAdd(out + i, red[i]);
   }
@@ -862,6 +891,9 @@ __global__ void copy2d_kernel(const float* __restrict__ x, float* __restrict__ y
 
 }  // namespace
 
+// dynamic LDS of chan_kernel: red[2C] | parked partials [8][256] | group sums (<= max(256, 2C))
+static size_t chan_shmem(int C) { return (size_t)(2 * C + 8 * 256 + (2 * C > 256 ? 2 * C : 256)) * sizeof(float); }
+
 extern "C" {
 
 int lmn_copy2d(const float* x, float* y, int64_t rows, int cols, int x_stride, int y_stride, lmn_stream_t stream) {
@@ -921,7 +953,7 @@ int lmn_bnact_bwd_stats(const void* z, const void* dy, const float* mean, const 
   LMN_REQUIRE(z && dy && mean && rstd && gamma && beta && stats && rows > 0, "bnact_bwd_stats: bad argument");
   LMN_REQUIRE(C % 4 == 0 && C >= 4 && C <= 1024, "bnact_bwd_stats: C=%d", C);
   const int rpb = 256 / (C / 4);
-  LMN_ACT_DISPATCH(act_dtype, LMN_LAUNCH((chan_kernel<0, T>), dim3(grid_for(rows, rpb * 8, 1024)), dim3(256), 2 * C * sizeof(float),
+  LMN_ACT_DISPATCH(act_dtype, LMN_LAUNCH((chan_kernel<0, T>), dim3(grid_for(rows, rpb * 8, 1024)), dim3(256), chan_shmem(C),
                      (hipStream_t)stream, (const T*)z, (const T*)dy, mean, rstd, gamma, beta, nullptr, nullptr, nullptr, (void*)stats, rows, C, C, act));
   return lmn_launch_status("bnact_bwd_stats");
 }
@@ -934,7 +966,7 @@ int lmn_bnact_bwd(const void* z, const void* dy, const float* mean, const float*
   LMN_REQUIRE(z && dy && mean && rstd && gamma && beta && c1 && c2 && c3 && dz && rows > 0, "bnact_bwd: bad argument");
   LMN_REQUIRE(C % 4 == 0 && C >= 4 && C <= 1024, "bnact_bwd: C=%d", C);
   const int rpb = 256 / (C / 4);
-  LMN_ACT_DISPATCH(act_dtype, LMN_LAUNCH((chan_kernel<1, T>), dim3(grid_for(rows, rpb * 4, 4096)), dim3(256), 2 * C * sizeof(float),
+  LMN_ACT_DISPATCH(act_dtype, LMN_LAUNCH((chan_kernel<1, T>), dim3(grid_for(rows, rpb * 4, 4096)), dim3(256), chan_shmem(C),
                      (hipStream_t)stream, (const T*)z, (const T*)dy, mean, rstd, gamma, beta, c1, c2, c3, dz, rows, C, C, act));
   return lmn_launch_status("bnact_bwd");
 }
@@ -944,7 +976,7 @@ int lmn_colsum(const void* x, float* out, int64_t rows, int C, int cstride, int 
   LMN_REQUIRE_DT(act_dtype, "colsum");
   LMN_REQUIRE(x && out && rows > 0 && C % 4 == 0 && C >= 4 && C <= 1024 && cstride >= C && cstride % 4 == 0, "colsum: bad argument");
   const int rpb = 256 / (C / 4);
-  LMN_ACT_DISPATCH(act_dtype, LMN_LAUNCH((chan_kernel<2, T>), dim3(grid_for(rows, rpb * 8, 1024)), dim3(256), 2 * C * sizeof(float),
+  LMN_ACT_DISPATCH(act_dtype, LMN_LAUNCH((chan_kernel<2, T>), dim3(grid_for(rows, rpb * 8, 1024)), dim3(256), chan_shmem(C),
                      (hipStream_t)stream, (const T*)x, (const T*)nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, (void*)out,
                      rows, C, cstride, 0));
   return lmn_launch_status("colsum");

@@ -130,6 +130,8 @@ STATS_REP = 16
 
 
 class Engine:
+    _instances = 0
+
     def __init__(self, model):
         self.m = model
         self.G = None            # param -> gradient view (set per backward)
@@ -158,6 +160,8 @@ class Engine:
         self.lazy_q = []
         self.side_prio = int(os.environ.get("LMN_SIDE_PRIO", "0"))   # HIP priority of the weight-gradient streams (-1: high; A/B runs)
         self.branch_prio = int(os.environ.get("LMN_BRANCH_PRIO", "0"))
+        self.slot_base = 4 * (Engine._instances % 16)     # this engine's four numbered events (lmn_event_record / wait: 64 per process)
+        Engine._instances += 1
         self.zpool_fwd, self.zpool_bwd = ZeroPool(), ZeroPool()
         self.packs_fwd, self.packs_bwd = hip.PackPlan(), hip.PackPlan()
         self.mma = hip.F32        # matrix-core operand type of the dense contractions of the pass (hip.F32 | hip.BF16)
