@@ -79,6 +79,24 @@ class _LMNetGraphFunction(torch.autograd.Function):
         return (None, None, None) + tuple(grads)
 
 
+class _gc_paused:
+    """No cyclic garbage collection inside a hipGraph capture: the capture runs a whole pass of Python (thousands of allocations),
+    and a collection in the middle of it may finalise objects of EARLIER models -- graphs, plans, streams, device tensors -- whose
+    destructors call into HIP, which aborts the process while a stream is capturing."""
+
+    def __enter__(self):
+        import gc
+        gc.collect()
+        self.was = gc.isenabled()
+        gc.disable()
+
+    def __exit__(self, *exc):
+        import gc
+        if self.was:
+            gc.enable()
+        return False
+
+
 class _PlannedStep:
     """One recorded pass pair (forward, backward) for a fixed input shape and mode: two lmn plans over one arena."""
 
@@ -457,7 +475,7 @@ class LM_Net(nn.Module):
             eng.capturing = True
             try:
                 gs.fwd = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(gs.fwd):
+                with _gc_paused(), torch.cuda.graph(gs.fwd):
                     gs.out = self._forward_impl(gs.x, Ctx())
             finally:
                 eng.capturing = False
@@ -488,12 +506,12 @@ class LM_Net(nn.Module):
         eng.capturing = True
         try:
             gs.fwd = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(gs.fwd):
+            with _gc_paused(), torch.cuda.graph(gs.fwd):
                 gs.cx = Ctx()
                 gs.out = self._forward_impl(gs.x, gs.cx)
             gs.dlogits = torch.zeros_like(gs.out)
             gs.bwd = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(gs.bwd, pool=gs.fwd.pool()):
+            with _gc_paused(), torch.cuda.graph(gs.bwd, pool=gs.fwd.pool()):
                 _, grads = self._backward_impl(gs.cx, gs.dlogits, False)
             gs.flat, gs.grads = self._grad_flat, grads
         finally:

@@ -205,9 +205,12 @@ struct SwState {
 // Column flags never appear here: columns outside the image carry zero coefficients (ca / cc / cd are per-lane registers), the
 // halo lanes of the strip are dropped from the weight-gradient sums at the end of the kernel.  Accumulator slots are not
 // zeroed: the first contribution to a row (kernel row 0 for y_b, kernel row 4 for dx1) is a plain product.
-template <int P, int PART, bool FAST>
+// CL: the coefficients of f_b come from LDS (CFS; z-path instances, whose drain needs the registers: 26 spilled VGPRs -> 1,
+// -3..4 % there; the plain instances keep them in registers: +12 % with the LDS form)
+template <int P, int PART, bool FAST, bool CL>
 __device__ __forceinline__ void sw_step(SwState& S, const BranchW& bw, const f32x2 (&ca)[4], const f32x2 (&cc)[4],
-                                        const f32x2 (&cd)[4], const float* XS, const float* DPS, float* OUT, int j,
+                                        const f32x2 (&cd)[4], const float* CFS, f32x2 cm, const float* XS,
+                                        const float* DPS, float* OUT, int j,
                                         int lane, int wv, bool frow_in, bool own, bool dx_row, bool dw_ok) {
   // ---- x1 row j: columns x-2 .. x+2
   const float* xr = XS + ((j % SW_XR) * SW_XC + lane) * SW_CS + wv * 2;
@@ -237,10 +240,23 @@ __device__ __forceinline__ void sw_step(SwState& S, const BranchW& bw, const f32
   // ---- row q = j-2 is complete: f_b
   constexpr int Q = (P + 3) % 5;
   const f32x2 dp = *reinterpret_cast<const f32x2*>(DPS + (P * SW_XC + lane) * SW_CS + wv * 2);
-  f32x2 f5 = cc[0] * S.a5[Q] + (ca[0] * dp + cd[0]);
-  f32x2 f3 = cc[1] * S.a3[Q] + (ca[1] * dp + cd[1]);
-  f32x2 fv = cc[2] * S.av[Q] + (ca[2] * dp + cd[2]);
-  f32x2 fh = cc[3] * S.ah[Q] + (ca[3] * dp + cd[3]);
+  f32x2 f5, f3, fv, fh;
+  if constexpr (CL) {
+    // coefficients of the wave's channel pair from LDS (broadcast reads: CFS[(k * 3 + {a, c, d}) * 2]); cm = 0 in columns outside
+    // the image (f_b = 0 there), 1 elsewhere
+    const float* cfp = CFS;
+    asm volatile("" : "+v"(cfp));   // (re-read per step: hoisted out of the loop the 24 values are 24 registers again)
+    const f32x2* cf = reinterpret_cast<const f32x2*>(cfp);
+    f5 = (cf[1] * S.a5[Q] + (cf[0] * dp + cf[2])) * cm;
+    f3 = (cf[4] * S.a3[Q] + (cf[3] * dp + cf[5])) * cm;
+    fv = (cf[7] * S.av[Q] + (cf[6] * dp + cf[8])) * cm;
+    fh = (cf[10] * S.ah[Q] + (cf[9] * dp + cf[11])) * cm;
+  } else {   // per-lane registers (zero in columns outside the image)
+    f5 = cc[0] * S.a5[Q] + (ca[0] * dp + cd[0]);
+    f3 = cc[1] * S.a3[Q] + (ca[1] * dp + cd[1]);
+    fv = cc[2] * S.av[Q] + (ca[2] * dp + cd[2]);
+    fh = cc[3] * S.ah[Q] + (ca[3] * dp + cd[3]);
+  }
   if constexpr (FAST) {
     S.h5[Q] = f5; S.h3[Q] = f3; S.hv[Q] = fv; S.hh[Q] = fh;
   } else {
@@ -330,6 +346,7 @@ __global__ __launch_bounds__(256, 2) void dw_bwd_strip_kernel(
   // sums dh, dh * z per channel (hstats [2][E]: the BatchNorm-backward statistics of the expand conv).  The per-thread sums
   // live in LDS (hacc[j][tid]: conflict-free, no accumulator registers in a kernel that has none to spare)
   __shared__ __attribute__((aligned(16))) float pre_s[16];
+  __shared__ __attribute__((aligned(16))) float coef_s[ZT ? SW_NW * 24 : 4];   // z-path, per wave: (cA, cC, cD) x 4 branches x channel pair
   __shared__ float hacc[(PART == 2 || !ZT) ? 1 : 8 * 256];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -378,16 +395,27 @@ __global__ __launch_bounds__(256, 2) void dw_bwd_strip_kernel(
     cc[k] = f32x2{cC[k * E + chs], cC[k * E + chs + 1]};
     cd[k] = f32x2{cD[k * E + chs], cD[k * E + chs + 1]};
     }
-    // the 80 weight SGPRs already fill the scalar file: keep the 24 coefficient floats in VGPRs (otherwise the
-    // allocator spills weights to VGPR lanes and every use costs v_readlane x2 + s_nop)
-    asm volatile("" : "+v"(ca[k].x), "+v"(ca[k].y), "+v"(cc[k].x), "+v"(cc[k].y), "+v"(cd[k].x), "+v"(cd[k].y));
+    if constexpr (ZT) {
+      // the 80 weight SGPRs already fill the scalar file and, with the z-path drain, the vector file is full as well: the 24
+      // coefficient floats of the wave live in LDS (12 broadcast ds_read_b64 per row step)
+      if (lane == 0) {
+        float* c = coef_s + wv * 24 + k * 6;
+        c[0] = ca[k].x; c[1] = ca[k].y; c[2] = cc[k].x; c[3] = cc[k].y; c[4] = cd[k].x; c[5] = cd[k].y;
+      }
+    } else {
+      // the 80 weight SGPRs already fill the scalar file: keep the 24 coefficient floats in VGPRs (otherwise the
+      // allocator spills weights to VGPR lanes and every use costs v_readlane x2 + s_nop)
+      asm volatile("" : "+v"(ca[k].x), "+v"(ca[k].y), "+v"(cc[k].x), "+v"(cc[k].y), "+v"(cd[k].x), "+v"(cd[k].y));
+    }
   }
+  const float* CFS = coef_s + wv * 24;
   const int ys = seg * seg_rows, ye = min(ys + seg_rows, H);
   const int xs = strip * SW_OC;
   const int cx = xs - 2 + lane;
   const bool col_in = cx >= 0 && cx < W;
   const bool own_col = lane >= 2 && lane < 2 + SW_OC;
-  if (!col_in) {  // f_b = 0 in columns outside the image
+  const f32x2 cm = col_in ? f32x2{1.f, 1.f} : f32x2{0.f, 0.f};   // f_b = 0 in columns outside the image
+  if (!ZT && !col_in) {
 #pragma unroll
     for (int k = 0; k < 4; ++k) ca[k] = cc[k] = cd[k] = f32x2{0.f, 0.f};
   }
@@ -439,7 +467,7 @@ __global__ __launch_bounds__(256, 2) void dw_bwd_strip_kernel(
     li[k] = ((rr * SW_XC + c) * SW_CS + k4 * 4) | (in && c >= 2 && c < 2 + SW_FC ? 0x10000 : 0) | (in && c >= 4 && c < 4 + SW_OC ? 0x20000 : 0) |
             (ok ? 0x40000 : 0) | (rr & 7) << 20;
   }
-  if (zt) __syncthreads();   // pre_s, hacc
+  if (zt) __syncthreads();   // coef_s, pre_s, hacc
   // z-path: the z rows a drain needs (the rows of the dx batch; this block staged the same lines one or two batches ago, so they
   // come back from L2) are requested at the END of the batch's row steps -- the step temporaries are dead there -- and are in
   // registers when the next staging phase drains: no load latency inside the drain, no overlap with the x1 / dpre loads' registers
@@ -562,10 +590,10 @@ __global__ __launch_bounds__(256, 2) void dw_bwd_strip_kernel(
         const int fy = ys - 6 + j;                                                                            \
         const bool frow_in = j >= 4 && fy >= 0 && fy < H;                                                     \
         const bool own = fy >= ys && fy < ye;                                                                 \
-        sw_step<PH, PART, false>(S, bw, ca, cc, cd, XS, DPS, OUT, j, lane, wv, frow_in, own, j >= 8 && j < ndx, j >= 4); \
+        sw_step<PH, PART, false, ZT>(S, bw, ca, cc, cd, CFS, cm, XS, DPS, OUT, j, lane, wv, frow_in, own, j >= 8 && j < ndx, j >= 4); \
       }                                                                                                       \
     }
-#define LMN_SW_FAST(PH) sw_step<PH, PART, true>(S, bw, ca, cc, cd, XS, DPS, OUT, j0 + PH, lane, wv, true, true, true, true);
+#define LMN_SW_FAST(PH) sw_step<PH, PART, true, ZT>(S, bw, ca, cc, cd, CFS, cm, XS, DPS, OUT, j0 + PH, lane, wv, true, true, true, true);
 #ifdef LMN_DW_TIMING
   unsigned long long dtk[2] = {0, 0}, dta = __builtin_amdgcn_s_memtime();
   const unsigned long long dt0 = dta;
