@@ -541,6 +541,13 @@ int lmn_stream_wait(lmn_stream_t waiter, lmn_stream_t waited);
  * that is joined later, after more work has been queued behind the point); recorded by plans like any entry        */
 int lmn_event_record(int slot, lmn_stream_t stream);
 int lmn_event_wait(int slot, lmn_stream_t stream);
+/* Deterministic mode (process-wide; default off): every cross-block float reduction (BatchNorm / SE / LayerNorm statistics, bias /
+ * gamma / beta / bias-table gradients, depthwise weight gradients, K-split weight-gradient partials) is summed in a FIXED order --
+ * per-block partials in private slots of a per-stream scratch, folded by a sum kernel right after the producer -- instead of by
+ * float atomics in arrival order: two runs of a step on the same inputs give bit-identical results.  Slower (one or more extra
+ * launches per reducing kernel); the scratch is the one buffer the library allocates itself (hipMalloc, per stream, grown on demand). */
+int lmn_set_deterministic(int on);
+int lmn_get_deterministic(void);
 lmn_plan_t lmn_plan_create(void);
 int lmn_plan_destroy(lmn_plan_t plan);
 int lmn_plan_record_begin(lmn_plan_t plan);              /* start / resume recording on this thread                  */

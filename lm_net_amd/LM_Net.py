@@ -238,6 +238,8 @@ class LM_Net(nn.Module):
         if x.shape[2] % 16 or x.shape[3] % 16 or x.shape[2] < 32 or x.shape[3] < 32:
             raise ValueError("H and W must be multiples of 16 and >= 32 (got %dx%d)" % (x.shape[2], x.shape[3]))
         hip.load()
+        if hip.get_deterministic() != self._engine.deterministic:     # the switch is process-wide: every model follows it
+            self._engine.set_deterministic(hip.get_deterministic())
         params = self._param_list()
         if params and not params[0].is_cuda:
             raise RuntimeError("lm_net_amd.LM_Net: parameters are on %s; call model.to('cuda')" % params[0].device)
@@ -261,6 +263,17 @@ class LM_Net(nn.Module):
             if out is not None:
                 return out
         return _LMNetFunction.apply(x, self, *params)
+
+    @property
+    def deterministic(self):
+        """Bit-reproducible passes: every cross-block float reduction of the library is summed in a fixed order
+        (include/lmnet_hip.h, lmn_set_deterministic -- a PROCESS-WIDE switch) and the squeeze-excite gate is computed by its own
+        launch instead of by the last block of the depthwise forward.  Slower (extra launches); default off, or LMN_DETERMINISTIC=1."""
+        return self._engine.deterministic
+
+    @deterministic.setter
+    def deterministic(self, on):
+        self._engine.set_deterministic(bool(on))
 
     def _precision(self):
         """(matrix-core operand type, activation storage type) of the next pass."""
@@ -328,7 +341,7 @@ class LM_Net(nn.Module):
         """(shape, device, mode, precision, launch stream): recorded launches carry the stream that was current while recording,
         so a call under another current stream gets its own plan instead of racing with this one."""
         return (tuple(x.shape), x.device, self.training, self._save_tape, self._engine.pm(),
-                torch.cuda.current_stream(x.device).cuda_stream)
+                torch.cuda.current_stream(x.device).cuda_stream, self._engine.deterministic)
 
     def _drop_plan(self, ps):
         """A recording failed: forget the (possibly truncated) plans of this shape; it runs launch by launch from now on."""

@@ -38,6 +38,16 @@ static inline int lmn_cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b)
 //     (arguments by value) to the plan; lmn_plan_run re-issues the recorded entries in order -- one FFI crossing per
 //     pass instead of one per kernel.
 extern int g_lmn_prof_on;
+// (3) deterministic mode (lmn_set_deterministic): every cross-block float reduction writes per-block partials into SLOTS -- private
+//     copies of its destination arrays in a per-stream scratch -- with plain stores instead of float atomics, and a fixed-order
+//     sum kernel folds the slots into the real destination right after the producer (same stream, same entry).
+extern int g_lmn_det;
+// a zeroed scratch region of `floats` floats on stream st (hipMemsetAsync; the scratch itself is hipMalloc'ed once per stream and
+// grown on demand: the one place where the library owns device memory).  lmn_det_begin resets the stream's scratch (once per entry).
+void lmn_det_begin(hipStream_t st);
+float* lmn_det_slots(hipStream_t st, size_t floats);
+// dst[i] += sum_{s < nslots} slots[s * size + i]  (s ascending in fixed groups: bit-reproducible)
+void lmn_det_sum(hipStream_t st, const float* slots, int nslots, int64_t size, float* dst);
 bool lmn_prof_start(const char* kernel, hipStream_t st);
 void lmn_prof_stop(hipStream_t st);
 void lmn_prof_cost(double flops, double bytes);  // algorithmic cost of the NEXT launch of this thread (consumed by it)
@@ -60,6 +70,14 @@ void lmn_rec_push(std::function<int()>&& f, const char* what);
 #endif
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+#ifdef __HIPCC__
+// one block's contribution to a reduced value: float atomic (arrival order) or, in deterministic mode, a plain store into the
+// block's slot (the pointer then addresses the slot copy of the destination)
+__device__ __forceinline__ void lmn_red_add(float* p, float v, bool det) {
+  if (det) *p = v;
+  else atomicAdd(p, v);
+}
+#endif
 
 // ---------------------------------------------------------------- activation storage: fp32 or bf16
 // Every activation tensor of a call has ONE storage type (lmn act_dtype: LMN_F32 | LMN_BF16); kernels are templated on it

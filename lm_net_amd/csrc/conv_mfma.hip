@@ -41,6 +41,7 @@ struct ConvParams {
   int TH, TW, TP, NG, XH, XW, CS, CKB, tiles_x, tiles_y, total_tiles;
   uint32_t mTW, mXW;
   int strided;
+  float* det_stats;       // deterministic mode: slot copies of the statistics destination (one slot per block / per wave), else NULL
 };
 
 // precision mode of a conv-family kernel instance: 0 = fp32 storage + fp32 MFMA, 1 = fp32 storage + bf16 MFMA operands,
@@ -284,7 +285,8 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(const ConvParams P) {
             float t = st0[c][r];
             t += __shfl_xor(t, 1, 64); t += __shfl_xor(t, 2, 64); t += __shfl_xor(t, 4, 64); t += __shfl_xor(t, 8, 64);
             const int co = (ct0 + c) * 16 + q * 4 + r;
-            if (n == 0 && (ct0 + c < P.NCTT) && co < A.Cout) atomicAdd(A.stats + cur_b * A.Cout + co, t);
+            if (n == 0 && (ct0 + c < P.NCTT) && co < A.Cout)   // (deterministic mode: slot of this wave, [B][Cout] per slot)
+              lmn_red_add((P.det_stats ? P.det_stats + (int64_t)((blockIdx.x + gridDim.x * blockIdx.z) * 4 + wv) * A.B * A.Cout : A.stats) + cur_b * A.Cout + co, t, P.det_stats != nullptr);
             st0[c][r] = 0.f;
           }
       }
@@ -604,6 +606,7 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(const ConvParams P) {
   const bool se = EPI && ep_kind == LMN_EP_SE_BWD;
   const bool chan_stats = EPI && ((st_mode == LMN_STATS_SUM_SQ) || (ep_kind == LMN_EP_BN_BWD1) || se);
   if (chan_stats) {
+    __syncthreads();   // (block-uniform) every wave is through with the window of the last tile: it now parks the wave sums
 #pragma unroll
     for (int c = 0; c < NCT; ++c)
 #pragma unroll
@@ -614,18 +617,25 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(const ConvParams P) {
           a += __shfl_xor(a, m, 64);
           bb += __shfl_xor(bb, m, 64);
         }
-        if (n == 0) {
-          atomicAdd(&s_stats[c * 16 + q * 4 + r], a);
-          atomicAdd(&s_stats[NCT * 16 + c * 16 + q * 4 + r], bb);
+        if (n == 0) {   // the four waves' sums side by side in the (now free) window, added in wave order below: no LDS atomics
+          XS[wv * 2 * NCT * 16 + c * 16 + q * 4 + r] = a;
+          XS[wv * 2 * NCT * 16 + NCT * 16 + c * 16 + q * 4 + r] = bb;
         }
       }
     __syncthreads();
+    const bool det = P.det_stats != nullptr;
     for (int i = tid; i < (se ? 1 : 2) * NCT * 16; i += 256) {
       const int which = i / (NCT * 16), cc = i - which * NCT * 16;
       const int co = ct0 * 16 + cc;
+      const float v = ((XS[i] + XS[2 * NCT * 16 + i]) + XS[4 * NCT * 16 + i]) + XS[6 * NCT * 16 + i];
       if (co < A.Cout) {
-        if (se) { if (cur_b >= 0) atomicAdd(A.stats + cur_b * A.Cout + co, s_stats[i]); }
-        else atomicAdd(A.stats + (A.stats_rep > 1 ? (int64_t)(blockIdx.x % A.stats_rep) * 2 * A.Cout : 0) + (int64_t)which * A.Cout + co, s_stats[i]);
+        if (se) {
+          if (cur_b >= 0) lmn_red_add((det ? P.det_stats + (int64_t)((blockIdx.x + gridDim.x * blockIdx.z) * 4) * A.B * A.Cout : A.stats) + cur_b * A.Cout + co, v, det);
+        } else if (det) {
+          P.det_stats[(int64_t)(blockIdx.x + gridDim.x * blockIdx.z) * 2 * A.Cout + (int64_t)which * A.Cout + co] = v;   // slot of this block: [2][Cout]
+        } else {
+          atomicAdd(A.stats + (A.stats_rep > 1 ? (int64_t)(blockIdx.x % A.stats_rep) * 2 * A.Cout : 0) + (int64_t)which * A.Cout + co, v);
+        }
       }
     }
   }
@@ -709,7 +719,8 @@ __global__ __launch_bounds__(256) void conv_tileM_kernel(const ConvParams P) {
             t += __shfl_xor(t, 1, 64); t += __shfl_xor(t, 2, 64); t += __shfl_xor(t, 4, 64); t += __shfl_xor(t, 8, 64);
             const int ctc = ct0 + wv + 4 * c;
             const int co = ctc * 16 + q * 4 + r;
-            if (n == 0 && ctc < P.NCTT && co < A.Cout) atomicAdd(A.stats + cur_b * A.Cout + co, t);
+            if (n == 0 && ctc < P.NCTT && co < A.Cout)   // (the waves own different channels: one slot per block)
+              lmn_red_add((P.det_stats ? P.det_stats + (int64_t)(blockIdx.x * 4) * A.B * A.Cout : A.stats) + cur_b * A.Cout + co, t, P.det_stats != nullptr);
             st0[c][r] = 0.f;
           }
       }
@@ -1057,9 +1068,15 @@ __global__ __launch_bounds__(256) void conv_tileM_kernel(const ConvParams P) {
     for (int i = tid; i < (se ? 1 : 2) * NCT * 16; i += 256) {
       const int which = i / (NCT * 16), cc = i - which * NCT * 16;
       const int co = ct0 * 16 + cc;
+      const bool det = P.det_stats != nullptr;
       if (co < A.Cout) {
-        if (se) { if (cur_b >= 0) atomicAdd(A.stats + cur_b * A.Cout + co, s_stats[i]); }
-        else atomicAdd(A.stats + (A.stats_rep > 1 ? (int64_t)(blockIdx.x % A.stats_rep) * 2 * A.Cout : 0) + (int64_t)which * A.Cout + co, s_stats[i]);
+        if (se) {
+          if (cur_b >= 0) lmn_red_add((det ? P.det_stats + (int64_t)(blockIdx.x * 4) * A.B * A.Cout : A.stats) + cur_b * A.Cout + co, s_stats[i], det);
+        } else if (det) {
+          P.det_stats[(int64_t)blockIdx.x * 2 * A.Cout + (int64_t)which * A.Cout + co] = s_stats[i];
+        } else {
+          atomicAdd(A.stats + (A.stats_rep > 1 ? (int64_t)(blockIdx.x % A.stats_rep) * 2 * A.Cout : 0) + (int64_t)which * A.Cout + co, s_stats[i]);
+        }
       }
     }
   }
@@ -2634,6 +2651,7 @@ int lmn_conv_fwd(const lmn_conv_args_t* args, lmn_stream_t stream) {
   LMN_REQUIRE(A.out || A.stats, "conv_fwd: neither out nor stats requested");
   LMN_REQUIRE(!(A.transposed && A.nsrc != 1), "conv_fwd: transposed form takes one source");
   ConvParams P;
+  P.det_stats = nullptr;
   P.a = A;
   P.NKB = 0;
   for (int s = 0; s < 3; ++s) {
@@ -2837,12 +2855,28 @@ int lmn_conv_fwd(const lmn_conv_args_t* args, lmn_stream_t stream) {
     else if (a.epilogue == LMN_EP_BN_BWD1 && a.stats_mode == LMN_STATS_EP) ek = 3;
     else if (a.epilogue == LMN_EP_BN_BWD2 && a.stats_mode == LMN_STATS_NONE) ek = 4;
     else if (a.epilogue == LMN_EP_SE_BWD && a.stats_mode == LMN_STATS_EP) ek = 5;
+    // deterministic mode: the statistics go to one slot per block (SE_BWD: per wave) of the stream's scratch, summed in fixed order
+    // by lmn_det_sum right after the launch into slice 0 of the caller's buffer
+    int det_ns = 0;
+    int64_t det_sz = 0;
+    auto det_prep = [&](int nbx) -> int {
+      if (!g_lmn_det || !a.stats || a.stats_mode == LMN_STATS_NONE) return 0;
+      const bool sebwd = a.epilogue == LMN_EP_SE_BWD;
+      det_ns = sebwd ? nbx * 4 : nbx;
+      det_sz = sebwd ? (int64_t)a.B * a.Cout : 2 * (int64_t)a.Cout;
+      lmn_det_begin(st);
+      T.det_stats = lmn_det_slots(st, (size_t)det_ns * det_sz);
+      LMN_REQUIRE(T.det_stats, "conv_fwd: deterministic mode: no scratch for %d x %lld statistics slots", det_ns, (long long)det_sz);
+      return 0;
+    };
+    auto det_finish = [&]() { if (T.det_stats) lmn_det_sum(st, T.det_stats, det_ns, det_sz, a.stats); };
     if (ncw) {
       const int mchunks = (P.NCTT + 4 * ncw - 1) / (4 * ncw);
       int mblocks = T.total_tiles;
       const int mmax = 2048 / mchunks > 256 ? 2048 / mchunks : 256;
       if (mblocks > mmax) mblocks = mmax;
       const dim3 mgrid(mblocks, mchunks);
+      if (int rc = det_prep(mblocks)) return rc;
       const size_t msh = ((size_t)T.XH * T.XW * T.CS + (2 + 9) * 4 * ncw * 16) * sizeof(float);
 #define LMN_CM(TT, NN, BFV)                                                                              \
   do {                                                                                                   \
@@ -2860,10 +2894,12 @@ int lmn_conv_fwd(const lmn_conv_args_t* args, lmn_stream_t stream) {
       else { if (ncw == 2) LMN_CMB(9, 2); else LMN_CMB(9, 1); }
 #undef LMN_CMB
 #undef LMN_CM
+      det_finish();
       return lmn_launch_status("conv_fwd(tileM)");
     }
     if (s2t) {
       const dim3 zgrid(blocks, tchunks, 4);
+      if (int rc = det_prep(blocks * 4)) return rc;
 #define LMN_CZ(NN, BFV)                                                                                       \
   do {                                                                                                        \
     if (ek == 0) LMN_LAUNCH((conv_tile_kernel<9, NN, 0, true, BFV>), zgrid, dim3(256), shmem, st, T); \
@@ -2877,9 +2913,11 @@ int lmn_conv_fwd(const lmn_conv_args_t* args, lmn_stream_t stream) {
       }
 #undef LMN_CZB
 #undef LMN_CZ
+      det_finish();
       return lmn_launch_status("conv_fwd(tile, stride-2 data gradient)");
     }
     const dim3 grid(blocks, tchunks);
+    if (int rc = det_prep(blocks)) return rc;
 #define LMN_CT(TT, NN, BFV)                                                                              \
   do {                                                                                                   \
     switch ((TT) == 1 ? ek : (ek > 2 ? 1 : ek)) {                                                        \
@@ -2909,6 +2947,7 @@ int lmn_conv_fwd(const lmn_conv_args_t* args, lmn_stream_t stream) {
     if (a.ksize == 1) { LMN_CTN(1) } else { LMN_CTN(9) }
 #undef LMN_CTN
 #undef LMN_CT
+    det_finish();
     return lmn_launch_status("conv_fwd(tile)");
   }
   LMN_REQUIRE(false, "conv_fwd: the data gradient of a stride-2 conv is implemented for 3x3 kernels (got ksize %d, epilogue %d)", A.ksize, A.epilogue);
@@ -3042,8 +3081,10 @@ static int wgrad_setup(const lmn_wgrad_args_t& A, WgradParams& P, WgGeom& G) {
   }
   // two-stage reduction when the caller's workspace holds every block partial; else LDS-reduced atomics with fewer blocks
   P.partial = nullptr;
-  if (A.workspace && wgrad_two_stage(gy, blocks64, per) && (int64_t)gy * blocks64 * per <= A.workspace_floats) {
+  if (A.workspace && (wgrad_two_stage(gy, blocks64, per) || (g_lmn_det && blocks64 > 1)) && (int64_t)gy * blocks64 * per <= A.workspace_floats) {
     P.partial = A.workspace;
+  } else if (g_lmn_det) {
+    blocks64 = 1;         // deterministic mode without room for the partials: no K split (one block per tile set adds its sums alone)
   } else if (blocks64 > 512 / gy && 512 / gy >= 2) {
     blocks64 = 512 / gy;  // atomics: fewer blocks
   }

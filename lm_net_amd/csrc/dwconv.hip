@@ -338,7 +338,7 @@ __global__ __launch_bounds__(256, 2) void dw_bwd_strip_kernel(
     const float* __restrict__ w5, const float* __restrict__ w3, const float* __restrict__ wvv,
     const float* __restrict__ whh, const float* __restrict__ cA, const float* __restrict__ cC,
     const float* __restrict__ cD, const DwCoef CF, float* __restrict__ dw5, float* __restrict__ dw3, float* __restrict__ dwv,
-    float* __restrict__ dwh, const DwPreS PRE, float* __restrict__ hstats, int strips, int segs, int seg_rows, int chunks) {
+    float* __restrict__ dwh, const DwPreS PRE, float* __restrict__ hstats, int strips, int segs, int seg_rows, int chunks, int det) {
   __shared__ __attribute__((aligned(16))) float XS[SW_XR * SW_XC * SW_CS];
   __shared__ __attribute__((aligned(16))) float DPS[SW_R * SW_XC * SW_CS];  // (rows of 68 like XS: one LDS index per staged item)
   __shared__ __attribute__((aligned(16))) float OUT[SW_R * SW_XC * SW_CS];
@@ -637,7 +637,8 @@ __global__ __launch_bounds__(256, 2) void dw_bwd_strip_kernel(
       float a = 0.f;
       for (int t = k4; t < 256; t += 2) a += hacc[(which * 4 + r) * 256 + t];
       const int e = ch0 + k4 * 4 + r;
-      if (e < E) atomicAdd(hstats + (int64_t)which * E + e, a);
+      // (deterministic mode: hstats / dw5 .. dwh address slot copies of the destinations, one slot per (image, segment, strip))
+      if (e < E) lmn_red_add(hstats + (det ? (int64_t)((b * segs + seg) * strips + strip) * 2 * E : 0) + (int64_t)which * E + e, a, det);
     }
   }
   if (PART == 1) return;
@@ -669,10 +670,11 @@ __global__ __launch_bounds__(256, 2) void dw_bwd_strip_kernel(
     const int e = ch0 + w * 2 + k;
     if (e >= E) continue;
     const float v = red[i];
-    if (t < 25) atomicAdd(dw5 + (int64_t)e * 25 + t, v);
-    else if (t < 34) atomicAdd(dw3 + (int64_t)e * 9 + t - 25, v);
-    else if (t < 37) atomicAdd(dwv + (int64_t)e * 3 + t - 34, v);
-    else atomicAdd(dwh + (int64_t)e * 3 + t - 37, v);
+    const int64_t ds = det ? (int64_t)((b * segs + seg) * strips + strip) * E : 0;   // slot offset in channels
+    if (t < 25) lmn_red_add(dw5 + (ds + e) * 25 + t, v, det);
+    else if (t < 34) lmn_red_add(dw3 + (ds + e) * 9 + t - 25, v, det);
+    else if (t < 37) lmn_red_add(dwv + (ds + e) * 3 + t - 34, v, det);
+    else lmn_red_add(dwh + (ds + e) * 3 + t - 37, v, det);
   }
 }
 
@@ -713,7 +715,7 @@ __global__ __launch_bounds__(256) void dw_fwd_strip_kernel(const TA* __restrict_
                                                             const float* __restrict__ keff,
                                                             const float* __restrict__ beff, const DwFin FN,
                                                             const lmn_se_fuse_t SE, const DwPreS PRE, int strips,
-                                                            int segs, int seg_rows, int chunks) {
+                                                            int segs, int seg_rows, int chunks, int det) {
   __shared__ __attribute__((aligned(16))) float XS[FS_XR * SW_XC * SW_CS];
   __shared__ __attribute__((aligned(16))) float OUT[SW_R * SW_FC * SW_CS];
   __shared__ float gs_s[SW_CH];
@@ -888,7 +890,8 @@ __global__ __launch_bounds__(256) void dw_fwd_strip_kernel(const TA* __restrict_
   }
   __syncthreads();  // the block's 8 channel sums leave as ONE atomic instruction (single-lane atomics per wave queue up in L2)
   if (SE.ticket == nullptr) {
-    if (tid < SW_CH && ch0 + tid < E) atomicAdd(gsum + (int64_t)b * E + ch0 + tid, gs_s[tid]);
+    // (deterministic mode: gsum addresses slot copies of [B][E], one slot per (segment, strip))
+    if (tid < SW_CH && ch0 + tid < E) lmn_red_add(gsum + (det ? (int64_t)(seg * strips + strip) * (int)(gridDim.x / (unsigned)(strips * segs * chunks)) * E : 0) + (int64_t)b * E + ch0 + tid, gs_s[tid], det);
     return;
   }
   // ---- squeeze-excite gate of image b by the block that completes its sums (lmn_se_fuse_t).  Hand-off: wave 0 adds this
@@ -1017,7 +1020,7 @@ __global__ __launch_bounds__(256) void dw_stats_strip_kernel(
     const float* __restrict__ sgate, const float* __restrict__ dm, TA* __restrict__ dpre, int H, int W, int E,
     const float* __restrict__ w5, const float* __restrict__ w3, const float* __restrict__ wvv,
     const float* __restrict__ whh, float* __restrict__ stats, const lmn_se_bwd_t SB, const DwPreK PRE, int strips, int segs,
-    int seg_rows, int chunks) {
+    int seg_rows, int chunks, int det) {
   constexpr int NS = MODE == 0 ? 8 : 5;
   __shared__ __attribute__((aligned(16))) float pre_s[16];
   constexpr int NAUX = MODE == 1 ? SW_R * SW_FC * SW_CS : 4;
@@ -1252,7 +1255,8 @@ __global__ __launch_bounds__(256) void dw_stats_strip_kernel(
   if (tid < NS * SW_CH) {
     const int k = tid / SW_CH, cc = tid - k * SW_CH;
     const int row = MODE == 0 ? ((k & 3) * 2 + (k >> 2)) : k;  // MODE 0: [branch][sum|sumsq][E]
-    if (ch0 + cc < E) atomicAdd(stats + (int64_t)row * E + ch0 + cc, red[tid]);
+    // (deterministic mode: stats addresses slot copies of [NS][E], one slot per (image, segment, strip))
+    if (ch0 + cc < E) lmn_red_add(stats + (det ? (int64_t)((b * segs + seg) * strips + strip) * NS * E : 0) + (int64_t)row * E + ch0 + cc, red[tid], det);
   }
 }
 
@@ -1359,8 +1363,16 @@ static int launch_dw_strip_stats(const void* x1, const void* pre, const void* u,
   const int64_t nblk = (int64_t)B * strips * chunks * segs;
   if (nblk >= (1LL << 31)) return -1;
   if (g_lmn_prof_on) lmn_prof_cost(2.0 * 42 * (double)B * H * W * E, (act_dtype == LMN_BF16 ? 2.0 : 4.0) * (MODE == 0 ? 1 : 4) * (double)B * H * W * E);
+  float* sdst = stats;
+  const int nslots = B * segs * strips, NS = MODE == 0 ? 8 : 5;
+  if (g_lmn_det) {   // per-block sums into slot copies of [NS][E], folded in fixed order below
+    lmn_det_begin(st);
+    sdst = lmn_det_slots(st, (size_t)nslots * NS * E);
+    LMN_REQUIRE(sdst, "dw statistics: deterministic mode: no scratch");
+  }
   LMN_ACT_DISPATCH(act_dtype, LMN_LAUNCH((dw_stats_strip_kernel<MODE, T>), dim3((unsigned)nblk), dim3(256), 0, st, (const T*)x1, (const T*)pre, (const T*)u, s, dm, (T*)dpre, H, W, E,
-                     w5, w3, wv, wh, stats, sb, zp, strips, segs, seg_rows, chunks));
+                     w5, w3, wv, wh, sdst, sb, zp, strips, segs, seg_rows, chunks, g_lmn_det));
+  if (g_lmn_det) lmn_det_sum(st, sdst, nslots, (int64_t)NS * E, stats);
   return 0;
 }
 
@@ -1415,8 +1427,16 @@ int lmn_dw_fwd(const void* x1, void* pre, float* gsum, int B, int H, int W, int 
   const int64_t nblk = (int64_t)B * strips * chunks * segs;
   LMN_REQUIRE(nblk < (1LL << 31), "dw_fwd: grid too large");
   if (g_lmn_prof_on) lmn_prof_cost(2.0 * 25 * (double)B * H * W * E, (act_dtype == LMN_BF16 ? 2.0 : 4.0) * 2 * (double)B * H * W * E);
-  LMN_ACT_DISPATCH(act_dtype, LMN_LAUNCH((dw_fwd_strip_kernel<T>), dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, (const T*)x1, (T*)pre, gsum, H, W, E, keff,
-                     beff, DwFin{}, sf, DwPreS{zp.A, zp.shift}, strips, segs, seg_rows, chunks));
+  LMN_REQUIRE(!g_lmn_det || !sf.ticket, "dw_fwd: deterministic mode takes the squeeze-excite sums without the fused gate (lmn_se_fuse_t NULL)");
+  float* gdst = gsum;
+  if (g_lmn_det) {   // per-block sums into slot copies of [B][E]
+    lmn_det_begin((hipStream_t)stream);
+    gdst = lmn_det_slots((hipStream_t)stream, (size_t)segs * strips * B * E);
+    LMN_REQUIRE(gdst, "dw_fwd: deterministic mode: no scratch");
+  }
+  LMN_ACT_DISPATCH(act_dtype, LMN_LAUNCH((dw_fwd_strip_kernel<T>), dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, (const T*)x1, (T*)pre, gdst, H, W, E, keff,
+                     beff, DwFin{}, sf, DwPreS{zp.A, zp.shift}, strips, segs, seg_rows, chunks, g_lmn_det));
+  if (g_lmn_det) lmn_det_sum((hipStream_t)stream, gdst, segs * strips, (int64_t)B * E, gsum);
   return lmn_launch_status("dw_fwd");
 }
 
@@ -1449,8 +1469,16 @@ int lmn_dw_fwd_bn(const void* x1, void* pre, float* gsum, int B, int H, int W, i
   LMN_REQUIRE(nblk < (1LL << 31), "dw_fwd_bn: grid too large");
   auto launch = [=]() -> int {
     if (g_lmn_prof_on) lmn_prof_cost(2.0 * 25 * (double)B * H * W * E, (act_dtype == LMN_BF16 ? 2.0 : 4.0) * 2 * (double)B * H * W * E);
-    LMN_ACT_DISPATCH(act_dtype, LMN_LAUNCH((dw_fwd_strip_kernel<T>), dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, (const T*)x1, (T*)pre, gsum, H, W, E,
-                       (const float*)nullptr, (const float*)nullptr, fn, sf, DwPreS{zp.A, zp.shift}, strips, segs, seg_rows, chunks));
+    LMN_REQUIRE(!g_lmn_det || !sf.ticket, "dw_fwd_bn: deterministic mode takes the squeeze-excite sums without the fused gate (lmn_se_fuse_t NULL)");
+    float* gdst = gsum;
+    if (g_lmn_det) {   // per-block sums into slot copies of [B][E]
+      lmn_det_begin((hipStream_t)stream);
+      gdst = lmn_det_slots((hipStream_t)stream, (size_t)segs * strips * B * E);
+      LMN_REQUIRE(gdst, "dw_fwd_bn: deterministic mode: no scratch");
+    }
+    LMN_ACT_DISPATCH(act_dtype, LMN_LAUNCH((dw_fwd_strip_kernel<T>), dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, (const T*)x1, (T*)pre, gdst, H, W, E,
+                       (const float*)nullptr, (const float*)nullptr, fn, sf, DwPreS{zp.A, zp.shift}, strips, segs, seg_rows, chunks, g_lmn_det));
+    if (g_lmn_det) lmn_det_sum((hipStream_t)stream, gdst, segs * strips, (int64_t)B * E, gsum);
     return lmn_launch_status("dw_fwd_bn");
   };
   if (g_lmn_rec) lmn_rec_push(launch, "lmn_dw_fwd_bn(");
@@ -1552,8 +1580,22 @@ int lmn_dw_bwd(const void* x1, const void* dpre, void* dx1, int B, int H, int W,
   const int64_t nblk = (int64_t)B * strips * chunks * segs;
   LMN_REQUIRE(nblk < (1LL << 31), "dw_bwd: grid too large");
   if (g_lmn_prof_on) lmn_prof_cost(2.0 * 2 * 42 * (double)B * H * W * E, (act_dtype == LMN_BF16 ? 2.0 : 4.0) * 3 * (double)B * H * W * E);
+  float *g5 = dw5, *g3 = dw3, *gv = dwv, *gh = dwh;
+  const int nslots = B * segs * strips;
+  if (g_lmn_det) {   // per-block weight-gradient sums into slot copies of the four tensors
+    hipStream_t st = (hipStream_t)stream;
+    lmn_det_begin(st);
+    float* base = lmn_det_slots(st, (size_t)nslots * 40 * E);
+    LMN_REQUIRE(base, "dw_bwd: deterministic mode: no scratch");
+    g5 = base; g3 = g5 + (size_t)nslots * 25 * E; gv = g3 + (size_t)nslots * 9 * E; gh = gv + (size_t)nslots * 3 * E;
+  }
   LMN_ACT_DISPATCH(act_dtype, LMN_LAUNCH((dw_bwd_strip_kernel<T>), dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, (const T*)x1, (const T*)dpre, (T*)dx1, B, H, W, E, w5,
-                     w3, wv, wh, cA, cC, cD, DwCoef{}, dw5, dw3, dwv, dwh, DwPreS{nullptr, nullptr}, (float*)nullptr, strips, segs, seg_rows, chunks));
+                     w3, wv, wh, cA, cC, cD, DwCoef{}, g5, g3, gv, gh, DwPreS{nullptr, nullptr}, (float*)nullptr, strips, segs, seg_rows, chunks, g_lmn_det));
+  if (g_lmn_det) {
+    hipStream_t st = (hipStream_t)stream;
+    lmn_det_sum(st, g5, nslots, (int64_t)25 * E, dw5); lmn_det_sum(st, g3, nslots, (int64_t)9 * E, dw3);
+    lmn_det_sum(st, gv, nslots, (int64_t)3 * E, dwv); lmn_det_sum(st, gh, nslots, (int64_t)3 * E, dwh);
+  }
   return lmn_launch_status("dw_bwd");
 }
 
@@ -1583,12 +1625,29 @@ int lmn_dw_bwd_bn(const void* x1, const void* dpre, void* dx1, int B, int H, int
   LMN_REQUIRE(nblk < (1LL << 31), "dw_bwd_bn: grid too large");
   auto launch = [=]() -> int {
     if (g_lmn_prof_on) lmn_prof_cost(2.0 * 2 * 42 * (double)B * H * W * E, (act_dtype == LMN_BF16 ? 2.0 : 4.0) * 3 * (double)B * H * W * E);
+    float *g5 = dw5, *g3 = dw3, *gv = dwv, *gh = dwh, *hs = hstats;
+    const int nslots = B * segs * strips;
+    hipStream_t st = (hipStream_t)stream;
+    if (g_lmn_det) {   // per-block sums into slot copies of the four weight-gradient tensors and of hstats [2][E]
+      lmn_det_begin(st);
+      float* base = lmn_det_slots(st, (size_t)nslots * 42 * E);
+      LMN_REQUIRE(base, "dw_bwd_bn: deterministic mode: no scratch");
+      g5 = base; g3 = g5 + (size_t)nslots * 25 * E; gv = g3 + (size_t)nslots * 9 * E; gh = gv + (size_t)nslots * 3 * E;
+      if (hstats) hs = gh + (size_t)nslots * 3 * E;
+    }
 #define LMN_DWB2(PT, Z) LMN_ACT_DISPATCH(act_dtype, LMN_LAUNCH((dw_bwd_strip_kernel<T, PT, Z>), dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, (const T*)x1, (const T*)dpre, (T*)dx1, B, H, W, E, w5, \
-                       w3, wv, wh, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, cf, dw5, dw3, dwv, dwh, DwPreS{zp.A, zp.shift}, hstats, strips, segs, seg_rows, chunks))
+                       w3, wv, wh, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, cf, g5, g3, gv, gh, DwPreS{zp.A, zp.shift}, hs, strips, segs, seg_rows, chunks, g_lmn_det))
 #define LMN_DWB(PT) do { if (zp.A) LMN_DWB2(PT, true); else LMN_DWB2(PT, false); } while (0)
     if (part == 1) { LMN_DWB(1); } else if (part == 2) { LMN_DWB(2); } else { LMN_DWB(0); }
 #undef LMN_DWB2
 #undef LMN_DWB
+    if (g_lmn_det) {
+      if (part != 1) {
+        lmn_det_sum(st, g5, nslots, (int64_t)25 * E, dw5); lmn_det_sum(st, g3, nslots, (int64_t)9 * E, dw3);
+        lmn_det_sum(st, gv, nslots, (int64_t)3 * E, dwv); lmn_det_sum(st, gh, nslots, (int64_t)3 * E, dwh);
+      }
+      if (hstats && part != 2) lmn_det_sum(st, hs, nslots, (int64_t)2 * E, hstats);
+    }
     return lmn_launch_status("dw_bwd_bn");
   };
   if (g_lmn_rec) lmn_rec_push(launch, "lmn_dw_bwd_bn(");

@@ -141,11 +141,15 @@ template <int HD, typename TA>
 __global__ __launch_bounds__(256) void na_bwd_q_kernel(const TA* __restrict__ qkv, const float* __restrict__ rpb,
                                                        const TA* __restrict__ dout, TA* __restrict__ dqkv,
                                                        float* __restrict__ drpb, float* __restrict__ stat,
-                                                       const NaGeom g) {
-  extern __shared__ float s_drpb[];  // [heads][25] | per-thread interior bins [256][36]
+                                                       const NaGeom g, int det) {
+  extern __shared__ float s_drpb[];  // [heads][25] | per-thread interior bins [256][36] | rpb copy | border bins per wave [4][heads][25]
   float* s_bins = s_drpb + g.heads * 25;
   float* s_rpb = s_bins + 256 * 36;  // [heads][25] copy of the bias table
+  // border pixels add with LDS atomics into the table of THEIR wave (program order within a wave; the four tables and the interior
+  // sums are added in a fixed order at the end: the block's result does not depend on how its waves interleave)
+  float* s_wave = s_rpb + g.heads * 25 + (threadIdx.x >> 6) * g.heads * 25;
   for (int i = threadIdx.x; i < g.heads * 25; i += 256) { s_drpb[i] = 0.f; s_rpb[i] = rpb[i]; }
+  for (int i = threadIdx.x; i < 4 * g.heads * 25; i += 256) s_rpb[g.heads * 25 + i] = 0.f;
   __syncthreads();
   // A thread keeps ONE channel quad for the whole kernel (quad = tid % C4, pixel slot = tid / C4), so the rpb
   // gradient of interior pixels -- whose 9 neighbours always hit the same 9 bins -- accumulates in 36 registers.
@@ -230,7 +234,7 @@ __global__ __launch_bounds__(256) void na_bwd_q_kernel(const TA* __restrict__ qk
           const int bo = (ny - y + 2) * 5 + (nx - x + 2);
 #pragma unroll
           for (int k = 0; k < 4; ++k)
-            if (rep[k]) atomicAdd(&s_drpb[hidx[k] + bo], ds[k]);
+            if (rep[k]) atomicAdd(&s_wave[hidx[k] + bo], ds[k]);
         }
       }
     if (ok) st4(dqkv + ib + ((int64_t)y * g.W + x) * 3 * g.C + c, dq * g.scale);
@@ -255,11 +259,14 @@ __global__ __launch_bounds__(256) void na_bwd_q_kernel(const TA* __restrict__ qk
     if (ch % HD != 0) continue;
     float v = 0.f;
     for (int sl = 0; sl < PB; ++sl) v += s_bins[(sl * g.C4 + qd) * 36 + nk];
-    atomicAdd(&s_drpb[(ch / HD) * 25 + (n / 3 + 1) * 5 + (n % 3 + 1)], v);
+    s_drpb[(ch / HD) * 25 + (n / 3 + 1) * 5 + (n % 3 + 1)] = v;   // (one writer per (head, bin))
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < g.heads * 25; i += 256)
-    if (s_drpb[i] != 0.f) atomicAdd(drpb + i, s_drpb[i]);
+  for (int i = threadIdx.x; i < g.heads * 25; i += 256) {
+    const float* wt = s_rpb + g.heads * 25;
+    const float v = (((s_drpb[i] + wt[i]) + wt[g.heads * 25 + i]) + wt[2 * g.heads * 25 + i]) + wt[3 * g.heads * 25 + i];
+    if (v != 0.f) lmn_red_add(drpb + (det ? (int64_t)blockIdx.x * g.heads * 25 : 0) + i, v, det);   // (deterministic mode: slot copies [blocks][heads][25])
+  }
 }
 
 template <int HD, typename TA>
@@ -267,7 +274,7 @@ __global__ __launch_bounds__(256) void na_bwd_q_tile_kernel(const TA* __restrict
                                                             const TA* __restrict__ dout, TA* __restrict__ dqkv,
                                                             float* __restrict__ drpb, float* __restrict__ stat,
                                                             const NaGeom g, int TH, int TW, int tiles_x, int tiles_img,
-                                                            int total_tiles) {
+                                                            int total_tiles, int det) {
   // Query pass for C <= 24 (levels 0-1) with the k/v window of a TH x TW query tile staged in LDS, as the forward
   // does: the direct form is bound by the L1 address path (PMC: TA busy 78 % of the kernel, 49 cache accesses per wave
   // load -- 21 pixels x 48 B at a 144 B stride).  Persistent blocks walk tiles; a thread keeps its channel quad, so
@@ -275,10 +282,13 @@ __global__ __launch_bounds__(256) void na_bwd_q_tile_kernel(const TA* __restrict
   extern __shared__ __attribute__((aligned(16))) float s_drpb[];  // [heads][25] | rpb copy [heads][25] (padded to 16 B) | KV window / bins
   const int ntab = (g.heads * 25 + 3) & ~3;
   float* s_rpb = s_drpb + ntab;
-  float* KV = s_rpb + ntab;   // [(TH+2)*(TW+2)][2][C]
+  float* s_wt = s_rpb + ntab;                            // border bins per wave [4][ntab] (see na_bwd_q_kernel)
+  float* s_wave = s_wt + (threadIdx.x >> 6) * ntab;
+  float* KV = s_wt + 4 * ntab;   // [(TH+2)*(TW+2)][2][C]
   float* s_bins = KV;         // [256][36] after the last tile
   const int RW = TW + 2, RH = TH + 2;
   for (int i = threadIdx.x; i < g.heads * 25; i += 256) { s_drpb[i] = 0.f; s_rpb[i] = rpb[i]; }
+  for (int i = threadIdx.x; i < 4 * ntab; i += 256) s_wt[i] = 0.f;
   __syncthreads();
   // A thread keeps ONE channel quad for the whole kernel (quad = tid % C4, pixel slot = tid / C4), so the rpb
   // gradient of interior pixels -- whose 9 neighbours always hit the same 9 bins -- accumulates in 36 registers.
@@ -388,7 +398,7 @@ __global__ __launch_bounds__(256) void na_bwd_q_tile_kernel(const TA* __restrict
           const int bo = (ny - y + 2) * 5 + (nx - x + 2);
 #pragma unroll
           for (int k = 0; k < 4; ++k)
-            if (rep[k]) atomicAdd(&s_drpb[hidx[k] + bo], ds[k]);
+            if (rep[k]) atomicAdd(&s_wave[hidx[k] + bo], ds[k]);
         }
       }
     if (ok) st4(dqkv + ib + ((int64_t)y * g.W + x) * 3 * g.C + c, dq * g.scale);
@@ -415,11 +425,13 @@ __global__ __launch_bounds__(256) void na_bwd_q_tile_kernel(const TA* __restrict
     if (ch % HD != 0) continue;
     float v = 0.f;
     for (int sl = 0; sl < PB; ++sl) v += s_bins[(sl * g.C4 + qd) * 36 + nk];
-    atomicAdd(&s_drpb[(ch / HD) * 25 + (n / 3 + 1) * 5 + (n % 3 + 1)], v);
+    s_drpb[(ch / HD) * 25 + (n / 3 + 1) * 5 + (n % 3 + 1)] = v;   // (one writer per (head, bin))
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < g.heads * 25; i += 256)
-    if (s_drpb[i] != 0.f) atomicAdd(drpb + i, s_drpb[i]);
+  for (int i = threadIdx.x; i < g.heads * 25; i += 256) {
+    const float v = (((s_drpb[i] + s_wt[i]) + s_wt[ntab + i]) + s_wt[2 * ntab + i]) + s_wt[3 * ntab + i];
+    if (v != 0.f) lmn_red_add(drpb + (det ? (int64_t)blockIdx.x * g.heads * 25 : 0) + i, v, det);
+  }
 }
 
 template <int HD, typename TA>
@@ -693,10 +705,11 @@ template <int HD, typename TA>
 __global__ __launch_bounds__(256) void na_bwd_q_gen_kernel(const TA* __restrict__ qkv, const float* __restrict__ rpb,
                                                            const TA* __restrict__ dout, TA* __restrict__ dqkv,
                                                            float* __restrict__ drpb, float* __restrict__ stat,
-                                                           const NaGeom g, int K) {
-  extern __shared__ float s_tab[];  // [heads][(2K-1)^2] bias-gradient bins of the block
+                                                           const NaGeom g, int K, int det) {
+  extern __shared__ float s_all[];  // bias-gradient bins per wave [4][heads][(2K-1)^2] (program order within a wave, fixed-order sum at the end)
   const int RB = 2 * K - 1, NB = g.heads * RB * RB;
-  for (int i = threadIdx.x; i < NB; i += 256) s_tab[i] = 0.f;
+  float* s_tab = s_all + (threadIdx.x >> 6) * NB;
+  for (int i = threadIdx.x; i < 4 * NB; i += 256) s_all[i] = 0.f;
   __syncthreads();
   const int64_t total = (int64_t)g.B * g.H * g.W * g.C4;
   const int64_t nit = (total + (int64_t)gridDim.x * 256 - 1) / ((int64_t)gridDim.x * 256);
@@ -770,8 +783,10 @@ __global__ __launch_bounds__(256) void na_bwd_q_gen_kernel(const TA* __restrict_
       }
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < NB; i += 256)
-    if (s_tab[i] != 0.f) atomicAdd(drpb + i, s_tab[i]);
+  for (int i = threadIdx.x; i < NB; i += 256) {
+    const float v = ((s_all[i] + s_all[NB + i]) + s_all[2 * NB + i]) + s_all[3 * NB + i];
+    if (v != 0.f) lmn_red_add(drpb + (det ? (int64_t)blockIdx.x * NB : 0) + i, v, det);
+  }
 }
 
 template <int HD, typename TA>
@@ -902,13 +917,27 @@ int lmn_na_bwd(const void* qkv_, const float* rpb, const void* dout_, void* dqkv
   static const int qcap = getenv("LMN_NA_QGRID") ? atoi(getenv("LMN_NA_QGRID")) : 512;
   const int gq = grid > qcap ? qcap : grid;
   hipStream_t st = (hipStream_t)stream;
-  const size_t sh = (2 * heads * 25 + 256 * 36) * sizeof(float);
+  const size_t sh = (6 * heads * 25 + 256 * 36) * sizeof(float);   // bins | parked interior bins | bias table | border bins per wave [4]
+  // deterministic mode: the bias-table gradient of every block into its own slot, folded in fixed order after the query pass
+  const int ntabK = heads * (2 * K - 1) * (2 * K - 1);
+  float* dslot = drpb;
+  int dn = 0;
+  auto det_prep = [&](int nblk) -> int {
+    if (!g_lmn_det) return 0;
+    lmn_det_begin(st);
+    dslot = lmn_det_slots(st, (size_t)nblk * ntabK);
+    LMN_REQUIRE(dslot, "na_bwd: deterministic mode: no scratch");
+    dn = nblk;
+    return 0;
+  };
   if (gen || K != 3) {
-    const size_t gsh = (size_t)heads * (2 * K - 1) * (2 * K - 1) * sizeof(float);
+    const size_t gsh = (size_t)4 * heads * (2 * K - 1) * (2 * K - 1) * sizeof(float);
+    if (int rc = det_prep(gq)) return rc;
 #define LMN_NAG(HDV)                                                                                                 \
   do {                                                                                                               \
     if (g_lmn_prof_on) lmn_prof_cost(2.0 * 3 * K * K * (double)B * H * W * g.C, (act_dtype == LMN_BF16 ? 2.0 : 4.0) * 5 * (double)B * H * W * g.C); \
-    LMN_LAUNCH((na_bwd_q_gen_kernel<HDV, T>), dim3(gq), dim3(256), gsh, st, (const T*)qkv, rpb, (const T*)dout, (T*)dqkv, drpb, stat, g, K);      \
+    LMN_LAUNCH((na_bwd_q_gen_kernel<HDV, T>), dim3(gq), dim3(256), gsh, st, (const T*)qkv, rpb, (const T*)dout, (T*)dqkv, dslot, stat, g, K, g_lmn_det); \
+    if (g_lmn_det) lmn_det_sum(st, dslot, dn, ntabK, drpb);                                                          \
     if (g_lmn_prof_on) lmn_prof_cost(2.0 * 3 * K * K * (double)B * H * W * g.C, (act_dtype == LMN_BF16 ? 2.0 : 4.0) * 2 * (double)B * H * W * g.C); \
     LMN_LAUNCH((na_bwd_kv_gen_kernel<HDV, T>), dim3(grid), dim3(256), 0, st, (const T*)qkv, rpb, (const T*)dout, (T*)dqkv, stat, g, K);          \
   } while (0)
@@ -927,7 +956,9 @@ int lmn_na_bwd(const void* qkv_, const float* rpb, const void* dout_, void* dqkv
 #define NA_COST_KV if (g_lmn_prof_on) lmn_prof_cost(2.0 * 3 * 9 * (double)B * H * W * g.C, (act_dtype == LMN_BF16 ? 2.0 : 4.0) * 2 * (double)B * H * W * g.C)
 #define LMN_NA(HDV)                                                                                                  \
   do {                                                                                                               \
-    NA_COST_Q; LMN_LAUNCH((na_bwd_q_kernel<HDV, T>), dim3(gq), dim3(256), sh, st, (const T*)qkv, rpb, (const T*)dout, (T*)dqkv, drpb, stat, g);    \
+    if (int rc = det_prep(gq)) return rc;                                                                            \
+    NA_COST_Q; LMN_LAUNCH((na_bwd_q_kernel<HDV, T>), dim3(gq), dim3(256), sh, st, (const T*)qkv, rpb, (const T*)dout, (T*)dqkv, dslot, stat, g, g_lmn_det); \
+    if (g_lmn_det) lmn_det_sum(st, dslot, dn, ntabK, drpb);                                                          \
     NA_COST_KV; LMN_LAUNCH((na_bwd_kv_kernel<HDV, T>), dim3(grid), dim3(256), 0, st, (const T*)qkv, rpb, (const T*)dout, (T*)dqkv, stat, g);        \
   } while (0)
   // C <= 24 (levels 0-1): query pass with the k/v window in LDS; tile sizes are whole multiples of the 256/C4 pixels a
@@ -938,10 +969,12 @@ int lmn_na_bwd(const void* qkv_, const float* rpb, const void* dout_, void* dqkv
     const int tx = lmn_cdiv(W, TW), ty = lmn_cdiv(H, TH), total = tx * ty * B;                                       \
     const int ntab = (heads * 25 + 3) & ~3;                                                                          \
     const int win = (TH + 2) * (TW + 2) * 2 * g.C;                                                                   \
-    const size_t tsh = (size_t)(2 * ntab + (win > 256 * 36 ? win : 256 * 36)) * sizeof(float);                       \
+    const size_t tsh = (size_t)(6 * ntab + (win > 256 * 36 ? win : 256 * 36)) * sizeof(float);                       \
     const int gt = total > 1024 ? 1024 : total;                                                                      \
-    NA_COST_Q; LMN_LAUNCH((na_bwd_q_tile_kernel<HDV, T>), dim3(gt), dim3(256), tsh, st, (const T*)qkv, rpb, (const T*)dout, (T*)dqkv, drpb, stat, g, TH, TW, \
-                       tx, tx * ty, total);                                                                          \
+    if (int rc = det_prep(gt)) return rc;                                                                            \
+    NA_COST_Q; LMN_LAUNCH((na_bwd_q_tile_kernel<HDV, T>), dim3(gt), dim3(256), tsh, st, (const T*)qkv, rpb, (const T*)dout, (T*)dqkv, dslot, stat, g, TH, TW, \
+                       tx, tx * ty, total, g_lmn_det);                                                               \
+    if (g_lmn_det) lmn_det_sum(st, dslot, dn, ntabK, drpb);                                                          \
     if (g.C4 == 3) {  /* key pass in LDS form only at C = 12 (measured: 208 -> 181 us; at C = 24 it is slower, 71 -> 97 us) */ \
       const int KT = 16;  /* key tile: window (KT+2)^2 x (C + 2*heads) floats of LDS */                              \
       const int kx = lmn_cdiv(W, KT), ky = lmn_cdiv(H, KT);                                                          \

@@ -53,7 +53,7 @@ template <int G, typename T>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ x, const float* __restrict__ gamma,
                                                      const T* __restrict__ dy, const T* __restrict__ dres,
                                                      T* __restrict__ dx, float* __restrict__ dgamma,
-                                                     float* __restrict__ dbeta, int64_t rows, int C) {
+                                                     float* __restrict__ dbeta, int64_t rows, int C, int det) {
   extern __shared__ float red[];  // [4 waves][2][C]
   const int C4 = C >> 2;
   const int j = threadIdx.x % G;
@@ -138,7 +138,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ x, co
   __syncthreads();
   for (int i = threadIdx.x; i < 2 * C; i += 256) {
     const float v = red[i] + red[2 * C + i] + red[4 * C + i] + red[6 * C + i];
-    atomicAdd((i < C ? dgamma : dbeta - C) + i, v);
+    // (deterministic mode: dgamma / dbeta address slot copies [blocks][C] of the two vectors)
+    lmn_red_add((i < C ? dgamma : dbeta - C) + (det ? (int64_t)blockIdx.x * C : 0) + i, v, det);
   }
 }
 
@@ -198,7 +199,7 @@ __global__ __launch_bounds__(256) void chan_kernel(const T* __restrict__ z, cons
                                                    const float* __restrict__ gamma, const float* __restrict__ beta,
                                                    const float* __restrict__ c1, const float* __restrict__ c2,
                                                    const float* __restrict__ c3, void* __restrict__ out_,
-                                                   int64_t rows, int C, int cstride, int act) {
+                                                   int64_t rows, int C, int cstride, int act, int det) {
   float* out = reinterpret_cast<float*>(out_);   // MODE 0 / 2: fp32 statistics; MODE 1: the activation tensor dz
   T* out_act = reinterpret_cast<T*>(out_);
   extern __shared__ float red[];  // [2][C] (MODE 0), [C] (MODE 2)
@@ -239,7 +240,8 @@ __global__ __launch_bounds__(256) void chan_kernel(const T* __restrict__ z, cons
       chan_block_reduce<1>(sv, park, red, C, C4, NTH, rpb, tid);
     }
     const int nred = MODE == 0 ? 2 * C : C;
-    for (int i = tid; i < nred; i += 256) atomicAdd(out + i, red[i]);
+    // (deterministic mode: out addresses slot copies [blocks][nred])
+    for (int i = tid; i < nred; i += 256) lmn_red_add(out + (det ? (int64_t)blockIdx.x * nred : 0) + i, red[i], det);
   }
 }
 
@@ -521,13 +523,12 @@ __global__ __launch_bounds__(256) void up2_bwd_kernel(const T* __restrict__ dy, 
 template <typename T>
 __global__ __launch_bounds__(256) void avgpool_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, int Hout,
                                                           int Wout, int f, int C, int xcs, int ycs) {
-  extern __shared__ float red[];  // [C]
+  extern __shared__ float red[];  // [C] | parked partials [4][256] | group sums (chan_block_reduce)
   const int C4 = C >> 2;
   const int NTH = (256 / C4) * C4, per = NTH / C4;
   const int tid = threadIdx.x;
   const int ox = blockIdx.x % Wout, oy = (blockIdx.x / Wout) % Hout, b = blockIdx.x / (Wout * Hout);
-  for (int i = tid; i < C; i += 256) red[i] = 0.f;
-  __syncthreads();
+  f32x4 sv[1] = {f32x4{0, 0, 0, 0}};
   if (tid < NTH) {
     const int c = (tid % C4) * 4;
     f32x4 s = f32x4{0, 0, 0, 0};
@@ -536,10 +537,9 @@ __global__ __launch_bounds__(256) void avgpool_fwd_kernel(const T* __restrict__ 
       const int wy = w / f, wx = w - wy * f;
       s += ld4(x + (((int64_t)b * Hin + oy * f + wy) * Win + ox * f + wx) * xcs + c);
     }
-#pragma unroll
-    for (int k = 0; k < 4; ++k) atomicAdd(&red[c + k], s[k]);
+    sv[0] = s;
   }
-  __syncthreads();
+  chan_block_reduce<1>(sv, red + C, red, C, C4, NTH, per, tid);   // (fixed order, no LDS atomics)
   const float inv = 1.0f / (float)(f * f);
   for (int i = tid; i < C; i += 256) st1(y + (((int64_t)b * Hout + oy) * Wout + ox) * ycs + i, red[i] * inv);
 }
@@ -682,7 +682,7 @@ __device__ __forceinline__ void loss_softmax(const float* __restrict__ lg, int64
 template <int C>
 __global__ __launch_bounds__(256) void segloss_sums_kernel(const float* __restrict__ logits, const int64_t* __restrict__ target,
                                                            const float* __restrict__ wce, int B, int64_t hw,
-                                                           float* __restrict__ sums) {
+                                                           float* __restrict__ sums, int det) {
   constexpr int NS = 3 + 3 * C;
   float acc[NS];
 #pragma unroll
@@ -721,7 +721,8 @@ __global__ __launch_bounds__(256) void segloss_sums_kernel(const float* __restri
     if (lane == 0) red[wv][k] = v;
   }
   __syncthreads();
-  if (threadIdx.x < NS) atomicAdd(sums + threadIdx.x, red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
+  if (threadIdx.x < NS)   // (deterministic mode: sums addresses slot copies [blocks][NS])
+    lmn_red_add(sums + (det ? (int64_t)blockIdx.x * NS : 0) + threadIdx.x, red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x], det);
 }
 
 // coef: [0] (1-eps)/S_w  [1] (eps/C)/S_w  [2] sum_c w_c   [3+c] a_c  [3+C+c] b_c   with dL_dice/dp_c = a_c*t_c + b_c*p_c
@@ -930,9 +931,17 @@ int lmn_ln_bwd(const void* x, const float* gamma, const void* dy, const void* dr
   const int grid = grid_for(rows, 256 / G, C <= 12 ? 1024 : 512);
   hipStream_t st = (hipStream_t)stream;
   const size_t sh = 8 * C * sizeof(float);
-#define LN_CASE(g) case g: LMN_LAUNCH((ln_bwd_kernel<g, T>), dim3(grid), dim3(256), sh, st, (const T*)x, gamma, (const T*)dy, (const T*)dres, (T*)dx, dgamma, dbeta, rows, C); break;
+  float *dgs = dgamma, *dbs = dbeta;
+  if (g_lmn_det) {   // per-block sums into slot copies of dgamma / dbeta, folded in fixed order below
+    lmn_det_begin(st);
+    dgs = lmn_det_slots(st, (size_t)2 * grid * C);
+    LMN_REQUIRE(dgs, "ln_bwd: deterministic mode: no scratch");
+    dbs = dgs + (size_t)grid * C;
+  }
+#define LN_CASE(g) case g: LMN_LAUNCH((ln_bwd_kernel<g, T>), dim3(grid), dim3(256), sh, st, (const T*)x, gamma, (const T*)dy, (const T*)dres, (T*)dx, dgs, dbs, rows, C, g_lmn_det); break;
   LMN_ACT_DISPATCH(act_dtype, switch (G) { LN_CASE(1) LN_CASE(2) LN_CASE(4) LN_CASE(8) LN_CASE(16) LN_CASE(32) LN_CASE(64) });
 #undef LN_CASE
+  if (g_lmn_det) { lmn_det_sum(st, dgs, grid, C, dgamma); lmn_det_sum(st, dbs, grid, C, dbeta); }
   return lmn_launch_status("ln_bwd");
 }
 
@@ -953,8 +962,17 @@ int lmn_bnact_bwd_stats(const void* z, const void* dy, const float* mean, const 
   LMN_REQUIRE(z && dy && mean && rstd && gamma && beta && stats && rows > 0, "bnact_bwd_stats: bad argument");
   LMN_REQUIRE(C % 4 == 0 && C >= 4 && C <= 1024, "bnact_bwd_stats: C=%d", C);
   const int rpb = 256 / (C / 4);
-  LMN_ACT_DISPATCH(act_dtype, LMN_LAUNCH((chan_kernel<0, T>), dim3(grid_for(rows, rpb * 8, 1024)), dim3(256), chan_shmem(C),
-                     (hipStream_t)stream, (const T*)z, (const T*)dy, mean, rstd, gamma, beta, nullptr, nullptr, nullptr, (void*)stats, rows, C, C, act));
+  const int grid = grid_for(rows, rpb * 8, 1024);
+  hipStream_t st = (hipStream_t)stream;
+  float* sd = stats;
+  if (g_lmn_det) {
+    lmn_det_begin(st);
+    sd = lmn_det_slots(st, (size_t)grid * 2 * C);
+    LMN_REQUIRE(sd, "bnact_bwd_stats: deterministic mode: no scratch");
+  }
+  LMN_ACT_DISPATCH(act_dtype, LMN_LAUNCH((chan_kernel<0, T>), dim3(grid), dim3(256), chan_shmem(C),
+                     st, (const T*)z, (const T*)dy, mean, rstd, gamma, beta, nullptr, nullptr, nullptr, (void*)sd, rows, C, C, act, g_lmn_det));
+  if (g_lmn_det) lmn_det_sum(st, sd, grid, (int64_t)2 * C, stats);
   return lmn_launch_status("bnact_bwd_stats");
 }
 
@@ -967,7 +985,7 @@ int lmn_bnact_bwd(const void* z, const void* dy, const float* mean, const float*
   LMN_REQUIRE(C % 4 == 0 && C >= 4 && C <= 1024, "bnact_bwd: C=%d", C);
   const int rpb = 256 / (C / 4);
   LMN_ACT_DISPATCH(act_dtype, LMN_LAUNCH((chan_kernel<1, T>), dim3(grid_for(rows, rpb * 4, 4096)), dim3(256), chan_shmem(C),
-                     (hipStream_t)stream, (const T*)z, (const T*)dy, mean, rstd, gamma, beta, c1, c2, c3, dz, rows, C, C, act));
+                     (hipStream_t)stream, (const T*)z, (const T*)dy, mean, rstd, gamma, beta, c1, c2, c3, dz, rows, C, C, act, 0));
   return lmn_launch_status("bnact_bwd");
 }
 
@@ -976,9 +994,18 @@ int lmn_colsum(const void* x, float* out, int64_t rows, int C, int cstride, int 
   LMN_REQUIRE_DT(act_dtype, "colsum");
   LMN_REQUIRE(x && out && rows > 0 && C % 4 == 0 && C >= 4 && C <= 1024 && cstride >= C && cstride % 4 == 0, "colsum: bad argument");
   const int rpb = 256 / (C / 4);
-  LMN_ACT_DISPATCH(act_dtype, LMN_LAUNCH((chan_kernel<2, T>), dim3(grid_for(rows, rpb * 8, 1024)), dim3(256), chan_shmem(C),
-                     (hipStream_t)stream, (const T*)x, (const T*)nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, (void*)out,
-                     rows, C, cstride, 0));
+  const int grid = grid_for(rows, rpb * 8, 1024);
+  hipStream_t st = (hipStream_t)stream;
+  float* sd = out;
+  if (g_lmn_det) {
+    lmn_det_begin(st);
+    sd = lmn_det_slots(st, (size_t)grid * C);
+    LMN_REQUIRE(sd, "colsum: deterministic mode: no scratch");
+  }
+  LMN_ACT_DISPATCH(act_dtype, LMN_LAUNCH((chan_kernel<2, T>), dim3(grid), dim3(256), chan_shmem(C),
+                     st, (const T*)x, (const T*)nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, (void*)sd,
+                     rows, C, cstride, 0, g_lmn_det));
+  if (g_lmn_det) lmn_det_sum(st, sd, grid, C, out);
   return lmn_launch_status("colsum");
 }
 
@@ -1024,6 +1051,7 @@ int lmn_se_bwd(const float* ds, const float* gsum, float inv_hw, const float* w1
                const float* b2, const float* hidden, float* dm, float* dw1, float* db1, float* dw2, float* db2, int B,
                int E, int R, lmn_stream_t stream) {
   LMN_REC(lmn_se_bwd(ds, gsum, inv_hw, w1, b1, w2, b2, hidden, dm, dw1, db1, dw2, db2, B, E, R, stream));
+  LMN_REQUIRE(!g_lmn_det, "se_bwd: the one-launch form sums with float atomics; deterministic mode takes lmn_se_bwd_dm + lmn_se_bwd_params");
   (void)b1;
   LMN_REQUIRE(ds && gsum && w1 && w2 && b2 && hidden && dm && dw1 && db1 && dw2 && db2 && B > 0 && E > 0 && R > 0, "se_bwd: bad argument");
   LMN_REQUIRE((2 * E + 2 * R) * sizeof(float) <= 60000, "se_bwd: E=%d too large", E);
@@ -1079,7 +1107,7 @@ int lmn_avgpool_fwd(const void* x, void* y, int B, int Hout, int Wout, int f, in
   LMN_REC(lmn_avgpool_fwd(x, y, B, Hout, Wout, f, C, x_cstride, y_cstride, act_dtype, stream));
   LMN_REQUIRE_DT(act_dtype, "avgpool_fwd");
   LMN_REQUIRE(x && y && B > 0 && Hout > 0 && Wout > 0 && f >= 1 && C % 4 == 0 && C >= 4 && C <= 1024 && x_cstride >= C && y_cstride >= C && x_cstride % 4 == 0, "avgpool_fwd: bad argument");
-  LMN_ACT_DISPATCH(act_dtype, LMN_LAUNCH((avgpool_fwd_kernel<T>), dim3(B * Hout * Wout), dim3(256), C * sizeof(float), (hipStream_t)stream, (const T*)x, (T*)y,
+  LMN_ACT_DISPATCH(act_dtype, LMN_LAUNCH((avgpool_fwd_kernel<T>), dim3(B * Hout * Wout), dim3(256), (size_t)(C + 4 * 256 + (C > 256 ? C : 256)) * sizeof(float), (hipStream_t)stream, (const T*)x, (T*)y,
                      Hout, Wout, f, C, x_cstride, y_cstride));
   return lmn_launch_status("avgpool_fwd");
 }
@@ -1121,12 +1149,19 @@ int lmn_segloss_fwd(const float* logits, const int64_t* target, const float* w_c
   hipStream_t st = (hipStream_t)stream;
   const int grid = grid_for((int64_t)B * HW) > 1024 ? 1024 : grid_for((int64_t)B * HW);
   LMN_LAUNCH(fill_kernel, dim3(1), dim3(64), 0, st, sums, 0.f, (int64_t)(3 + 3 * C));
-  switch (C) {
-    case 2: LMN_LAUNCH((segloss_sums_kernel<2>), dim3(grid), dim3(256), 0, st, logits, target, w_ce, B, HW, sums); break;
-    case 3: LMN_LAUNCH((segloss_sums_kernel<3>), dim3(grid), dim3(256), 0, st, logits, target, w_ce, B, HW, sums); break;
-    case 4: LMN_LAUNCH((segloss_sums_kernel<4>), dim3(grid), dim3(256), 0, st, logits, target, w_ce, B, HW, sums); break;
-    default: LMN_LAUNCH((segloss_sums_kernel<8>), dim3(grid), dim3(256), 0, st, logits, target, w_ce, B, HW, sums); break;
+  float* sd = sums;
+  if (g_lmn_det) {
+    lmn_det_begin(st);
+    sd = lmn_det_slots(st, (size_t)grid * (3 + 3 * C));
+    LMN_REQUIRE(sd, "segloss_fwd: deterministic mode: no scratch");
   }
+  switch (C) {
+    case 2: LMN_LAUNCH((segloss_sums_kernel<2>), dim3(grid), dim3(256), 0, st, logits, target, w_ce, B, HW, sd, g_lmn_det); break;
+    case 3: LMN_LAUNCH((segloss_sums_kernel<3>), dim3(grid), dim3(256), 0, st, logits, target, w_ce, B, HW, sd, g_lmn_det); break;
+    case 4: LMN_LAUNCH((segloss_sums_kernel<4>), dim3(grid), dim3(256), 0, st, logits, target, w_ce, B, HW, sd, g_lmn_det); break;
+    default: LMN_LAUNCH((segloss_sums_kernel<8>), dim3(grid), dim3(256), 0, st, logits, target, w_ce, B, HW, sd, g_lmn_det); break;
+  }
+  if (g_lmn_det) lmn_det_sum(st, sd, grid, 3 + 3 * C, sums);
   LMN_LAUNCH(segloss_finish_kernel, dim3(1), dim3(64), 0, st, sums, w_ce, w_dice, C, label_smoothing, smooth, loss, coef);
   return lmn_launch_status("segloss_fwd");
 }

@@ -14,6 +14,7 @@
 #include <vector>
 
 int g_lmn_prof_on = 0;
+int g_lmn_det = 0;
 thread_local void* g_lmn_rec = nullptr;
 
 namespace {
@@ -129,6 +130,62 @@ void lmn_prof_stop(hipStream_t st) {
   g_open_e1 = nullptr;
 }
 
+// ---- deterministic mode: per-stream slot scratch + fixed-order slot sum
+namespace {
+struct DetWs { char* base = nullptr; size_t bytes = 0, used = 0; };
+std::map<hipStream_t, DetWs> g_det_ws;
+std::mutex g_det_mu;
+
+// block = 8 values x 32 slot groups: thread (v, g) sums slots g, g + 32, ... in ascending order, then the 32 group sums are added
+// in ascending order by one thread per value
+__global__ __launch_bounds__(256) void det_sum_kernel(const float* __restrict__ slots, int nslots, int64_t size, float* __restrict__ dst) {
+  __shared__ float part[8][33];
+  const int v = threadIdx.x >> 5, g = threadIdx.x & 31;
+  const int64_t i = (int64_t)blockIdx.x * 8 + v;
+  float a = 0.f;
+  if (i < size)
+    for (int s = g; s < nslots; s += 32) a += slots[(int64_t)s * size + i];
+  part[v][g] = a;
+  __syncthreads();
+  if (g == 0 && i < size) {
+    float t = 0.f;
+    for (int k = 0; k < 32; ++k) t += part[v][k];
+    dst[i] += t;
+  }
+}
+}  // namespace
+
+void lmn_det_begin(hipStream_t st) {
+  std::lock_guard<std::mutex> lk(g_det_mu);
+  g_det_ws[st].used = 0;
+}
+
+float* lmn_det_slots(hipStream_t st, size_t floats) {
+  std::lock_guard<std::mutex> lk(g_det_mu);
+  DetWs& w = g_det_ws[st];
+  const size_t need = ((floats * sizeof(float) + 255) / 256) * 256;
+  if (w.used + need > w.bytes) {
+    // grow: the old scratch may still be read by work queued on the stream -> wait for the stream, then replace it
+    (void)hipStreamSynchronize(st);
+    if (w.base) (void)hipFree(w.base);
+    size_t nb = w.bytes ? w.bytes : (size_t)32 << 20;
+    while (nb < w.used + need) nb *= 2;
+    w.base = nullptr;
+    if (hipMalloc((void**)&w.base, nb) != hipSuccess) { w.bytes = w.used = 0; return nullptr; }
+    w.bytes = nb;
+    w.used = 0;   // (regions handed out earlier in this entry are gone: callers take all their regions before launching)
+  }
+  float* p = (float*)(w.base + w.used);
+  w.used += need;
+  (void)hipMemsetAsync(p, 0, need, st);
+  return p;
+}
+
+void lmn_det_sum(hipStream_t st, const float* slots, int nslots, int64_t size, float* dst) {
+  if (size <= 0 || nslots <= 0) return;
+  hipLaunchKernelGGL(det_sum_kernel, dim3((unsigned)((size + 7) / 8)), dim3(256), 0, st, slots, nslots, size, dst);
+}
+
 extern "C" {
 
 // ---- stream ordering without torch: `waiter` waits for everything enqueued on `waited` so far
@@ -175,6 +232,13 @@ int lmn_event_wait(int slot, lmn_stream_t stream) {
   LMN_REQUIRE(r == hipSuccess, "event_wait: %s", hipGetErrorString(r));
   return 0;
 }
+
+// ---- deterministic mode switch (see common.h (3))
+int lmn_set_deterministic(int on) {
+  g_lmn_det = on ? 1 : 0;
+  return 0;
+}
+int lmn_get_deterministic(void) { return g_lmn_det; }
 
 // ---- plans
 lmn_plan_t lmn_plan_create(void) { return (lmn_plan_t) new Plan(); }

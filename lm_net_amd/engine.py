@@ -151,6 +151,10 @@ class Engine:
         self.split_se = os.environ.get("LMN_SE_SPLIT", "1") != "0"   # SE backward in two launches (parameter gradients on the side stream)
         # squeeze-excite gate / its backward formed inside the depthwise passes (no se_fwd / se_bwd_dm launches; LMN_FUSE_SE=0: A/B)
         self.fuse_se = int(os.environ.get("LMN_FUSE_SE", "3"))      # bit 0: forward gate, bit 1: backward
+        self._fuse_se0 = self.fuse_se
+        self.deterministic = False
+        if os.environ.get("LMN_DETERMINISTIC", "0") == "1":
+            self.set_deterministic(True)
         # z-path of ReparamConv (include/lmnet_hip.h, lmn_dw_pre_t / lmn_reparam_fold): the expand conv's BatchNorm + Hardswish
         # applied inside the depthwise kernels, its backward folded into the weights of one three-source conv (LMN_ZPATH=0: A/B)
         self.zpath = os.environ.get("LMN_ZPATH", "1") != "0"
@@ -328,6 +332,17 @@ class Engine:
                     src["scale"].record_stream(side)
         if explicit:
             self.join_side(d.device)
+
+    def set_deterministic(self, on):
+        """Fixed-order reductions in every kernel (hip.set_deterministic: process-wide) and no ticket-based squeeze-excite gate in the
+        depthwise forward (its sums arrive by float atomics in that form)."""
+        self.deterministic = bool(on)
+        self.fuse_se = (self._fuse_se0 & ~1) if on else self._fuse_se0
+        try:
+            hip.set_deterministic(on)
+        except Exception:
+            if on:
+                raise
 
     def side_call(self, ref, fn, keep=()):
         """Run fn() (library launches) on the weight-gradient side stream of the current stream, ordered after everything

@@ -126,7 +126,7 @@ SYMBOLS = [
     "lmn_conv_pack_size", "lmn_conv_pack", "lmn_conv_pack_batch", "lmn_sizeof_pack_job", "lmn_conv_fwd", "lmn_conv_wgrad", "lmn_conv_wgrad_workspace",
     "lmn_conv_wgrad_job", "lmn_wgrad_reduce_batch", "lmn_sizeof_reduce_job", "lmn_reparam_fold", "lmn_affine2", "lmn_reparam_wfin",
     "lmn_dw_stats", "lmn_dw_fwd", "lmn_dw_merge", "lmn_dw_finalize_merge", "lmn_dw_bwd_stats", "lmn_dw_bwd_coef", "lmn_dw_bwd", "lmn_dw_fwd_bn", "lmn_dw_bwd_bn",
-    "lmn_se_fwd", "lmn_se_bwd", "lmn_se_bwd_dm", "lmn_se_bwd_params", "lmn_na_fwd", "lmn_na_bwd", "lmn_plan_host_profile", "lmn_gattn_fwd", "lmn_gattn_bwd",
+    "lmn_se_fwd", "lmn_se_bwd", "lmn_se_bwd_dm", "lmn_se_bwd_params", "lmn_na_fwd", "lmn_na_bwd", "lmn_plan_host_profile", "lmn_set_deterministic", "lmn_get_deterministic", "lmn_gattn_fwd", "lmn_gattn_bwd",
     "lmn_ln_fwd", "lmn_ln_bwd", "lmn_bnact_fwd", "lmn_bnact_bwd_stats", "lmn_bnact_bwd",
     "lmn_bn_finalize", "lmn_bn_fold", "lmn_bn_bwd_coef", "lmn_up2_fwd", "lmn_up2_bwd", "lmn_avgpool_fwd", "lmn_avgpool_bwd",
     "lmn_nchw_to_nhwc", "lmn_nhwc_to_nchw", "lmn_adamw_step", "lmn_segloss_fwd", "lmn_segloss_bwd", "lmn_confusion", "lmn_preprocess_u8", "lmn_fill", "lmn_add", "lmn_colsum", "lmn_copy_slice", "lmn_copy2d",
@@ -919,6 +919,15 @@ class Plan:
         except Exception:
             pass
         self.h = None
+
+
+def set_deterministic(on):
+    """Fixed-order reductions in every kernel (include/lmnet_hip.h, lmn_set_deterministic): bit-reproducible steps, slower."""
+    _check(load().lmn_set_deterministic(1 if on else 0), "set_deterministic")
+
+
+def get_deterministic():
+    return bool(load().lmn_get_deterministic())
 
 
 def prof_begin(filter_=None):

@@ -80,6 +80,33 @@ def test_config1_train_step_352_batch8_vs_reference_f64():
     _golden_step("train_f64_352_b8")
 
 
+def test_config1_batch8_deterministic_mode_bit_identical_gradients():
+    """BASELINE configs[1] shape in deterministic mode (LM_Net.deterministic / lmn_set_deterministic: fixed-order reductions instead
+    of arrival-order float atomics): two fresh runs of the batch-8 training step give bit-identical logits and gradients -- all 514
+    tensors (the default mode differs in ~510 of them, tools/gpu_determinism_check.py) -- and the step still matches the float64
+    reference within the usual tolerances."""
+    from lm_net_amd import LM_Net, hip
+
+    def run():
+        m = LM_Net(3, 2)
+        fill_module(m, 8)
+        m = m.cuda().train()             # dropout on, batch-statistics BatchNorm
+        m.deterministic = True
+        x = det_input((8, 3, 352, 352), "det8/x").cuda()
+        y = m(x)
+        (y * det_input(tuple(y.shape), "det8/G").cuda()).sum().backward()
+        torch.cuda.synchronize()
+        return y.detach().clone(), [p.grad.detach().clone() for p in m.parameters()]
+
+    try:
+        (ya, ga), (yb, gb) = run(), run()
+        assert torch.equal(ya, yb)
+        assert all(torch.equal(u, v) for u, v in zip(ga, gb)), [i for i, (u, v) in enumerate(zip(ga, gb)) if not torch.equal(u, v)][:8]
+        _golden_step("train_f64_352_b8")     # (the process-wide switch is still on: the golden step runs in deterministic mode)
+    finally:
+        hip.set_deterministic(False)
+
+
 def test_train_step_352_batch2_vs_reference_f64():
     _golden_step("train_f64_352_b2")
 

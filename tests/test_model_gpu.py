@@ -221,6 +221,56 @@ def test_larger_neighborhood_window_vs_oracle(K):
         assert err < 2e-3 * float(po.grad.abs().max()) or err < 5e-5 * gmax, (k, err)
 
 
+def test_deterministic_mode_is_bit_reproducible():
+    """model.deterministic = True (lmn_set_deterministic): fixed-order reductions everywhere -- two fresh runs of three training steps
+    (batch-statistics BatchNorm, dropout on, fused loss, AdamW; launch by launch and as recorded plans) give BIT-IDENTICAL losses,
+    gradients, parameters and running statistics; the default mode agrees with it to the float-atomic noise level."""
+    from lm_net_amd import LM_Net, hip
+    from lm_net_amd.loss import SegLoss
+    from lm_net_amd.optim import FusedAdamW
+    x = det_input((2, 3, 96, 128), "det/x").cuda()
+    y = disc_labels(2, 96, 128).cuda()
+
+    def run(det, plans, steps):
+        m = LM_Net(3, 2)
+        fill_module(m, 31)
+        m = m.cuda().train()
+        m.deterministic = det
+        if plans:
+            m.enable_plans()
+        crit = SegLoss(label_smoothing=1e-3).cuda()
+        opt = FusedAdamW(m, lr=1e-3, weight_decay=1e-4)
+        losses = []
+        for _ in range(steps):
+            loss = crit(m(x), y)
+            opt.zero_grad(set_to_none=True)
+            loss.backward()
+            grads = [p.grad.detach().clone() for p in m.parameters()]
+            opt.step()
+            losses.append(loss.detach().clone())
+        torch.cuda.synchronize()
+        return losses, grads, [p.detach().clone() for p in m.parameters()], [b.detach().clone() for b in m.buffers()]
+
+    try:
+        for plans, steps in ((False, 3), (True, 5)):
+            a, b = run(True, plans, steps), run(True, plans, steps)
+            for u, v in zip(a[0], b[0]):
+                assert torch.equal(u, v), (plans, float(u), float(v))
+            for part in (1, 2, 3):
+                for i, (u, v) in enumerate(zip(a[part], b[part])):
+                    assert torch.equal(u, v), (plans, part, i, float((u - v).abs().max()))
+        assert hip.get_deterministic()
+        ref = run(False, False, 1)
+        one = run(True, False, 1)
+        assert abs(float(ref[0][0]) - float(one[0][0])) < 1e-4 * abs(float(ref[0][0]))
+        gmax = max(float(g.abs().max()) for g in ref[1])
+        for i, (u, v) in enumerate(zip(ref[1], one[1])):
+            assert rel_err(u, v) < 2e-2 or float((u - v).abs().max()) < 1e-5 * gmax, (i, rel_err(u, v))
+    finally:
+        hip.set_deterministic(False)
+    assert not hip.get_deterministic()
+
+
 def test_fused_adamw_matches_torch_adamw_and_exchanges_state():
     """lm_net_amd.optim.FusedAdamW (one kernel over the flat buffers) against torch.optim.AdamW -- the reference's
     optimizer (train.py:156) -- on the same model, data and loss: parameters after 3 steps, then a state_dict
