@@ -231,9 +231,11 @@ def test_deterministic_mode_is_bit_reproducible():
     x = det_input((2, 3, 96, 128), "det/x").cuda()
     y = disc_labels(2, 96, 128).cuda()
 
-    def run(det, plans, steps):
+    def run(det, plans, steps, drop=True):
         m = LM_Net(3, 2)
         fill_module(m, 31)
+        if not drop:
+            no_dropout(m)
         m = m.cuda().train()
         m.deterministic = det
         if plans:
@@ -260,6 +262,15 @@ def test_deterministic_mode_is_bit_reproducible():
                 for i, (u, v) in enumerate(zip(a[part], b[part])):
                     assert torch.equal(u, v), (plans, part, i, float((u - v).abs().max()))
         assert hip.get_deterministic()
+        # recorded plans replay the SAME launches: in deterministic mode their results equal the host-launched ones bit for bit (the
+        # strict form of test_plan_mode_matches_host_launches, whose tolerance has to cover the arrival-order noise of the default mode)
+        # (dropout off here: plans draw their masks from a device-side counter, host launches from host seeds)
+        e5, p5 = run(True, False, 5, drop=False), run(True, True, 5, drop=False)
+        for u, v in zip(e5[0], p5[0]):
+            assert torch.equal(u, v), ("eager vs plans", float(u), float(v))
+        for part in (1, 2, 3):
+            for i, (u, v) in enumerate(zip(e5[part], p5[part])):
+                assert torch.equal(u, v), ("eager vs plans", part, i, float((u - v).abs().max()))
         ref = run(False, False, 1)
         one = run(True, False, 1)
         assert abs(float(ref[0][0]) - float(one[0][0])) < 1e-4 * abs(float(ref[0][0]))
