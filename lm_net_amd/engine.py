@@ -295,7 +295,7 @@ class Engine:
             hip.conv_wgrad(srcs, dy, dW, db, B=B, Hin=Hin, Win=Win, Hout=Ho, Wout=Wo, Cout=cout, ksize=k, stride=s, defer=defer, **kw)
             if after is not None:
                 if defer:
-                    self.post_reduce.setdefault(hip._STREAM[0].value if hip._STREAM[0] is not None else 0, []).append(after)
+                    self.post_reduce.setdefault(hip.stream_key(), []).append(after)
                 else:
                     after()
             return

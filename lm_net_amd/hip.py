@@ -222,6 +222,13 @@ def _stream():
     return _STREAM[0] if _STREAM[0] is not None else C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+def stream_key():
+    """The launch stream as a dictionary key: its handle as an int (0 = the legacy default stream; `c_void_p(0).value` is None,
+    which once made the deferred reductions of a serial run on the default stream unreachable)."""
+    v = _STREAM[0].value if _STREAM[0] is not None else torch.cuda.current_stream().cuda_stream
+    return int(v or 0)
+
+
 def _i64(v):
     return C.c_int64(int(v))
 
@@ -469,8 +476,7 @@ def conv_wgrad(srcs, dy, dW, db, *, B, Hin, Win, Hout, Wout, Cout, ksize=1, stri
             a.workspace, a.workspace_floats = ws.data_ptr(), nfl
             a.defer_reduce = 1
             job.partial = ws.data_ptr()
-            key = _STREAM[0].value if _STREAM[0] is not None else 0
-            _RJOBS.setdefault(key, []).append((job, ws))
+            _RJOBS.setdefault(stream_key(), []).append((job, ws))
         else:
             a.workspace, a.workspace_floats = None, 0
             need = 0
@@ -486,15 +492,15 @@ _RJOBS = {}          # launch stream handle -> [(ReduceJob, workspace tensor)] d
 _RTABLES = {}        # bytes of a job table -> its device copy (pointers repeat from step to step: no H2D copy per flush)
 
 
-def wgrad_reduce_pending(stream_key=None):
-    key = stream_key if stream_key is not None else (_STREAM[0].value if _STREAM[0] is not None else 0)
+def wgrad_reduce_pending(key=None):
+    key = int(key or 0) if key is not None else stream_key()
     return len(_RJOBS.get(key, ()))
 
 
 def wgrad_reduce_flush():
     """Sum the block partials of every deferred weight gradient of the CURRENT launch stream in one launch.  Returns the
     device job table (the caller keeps it alive while a recorded plan references it) or None."""
-    key = _STREAM[0].value if _STREAM[0] is not None else 0
+    key = stream_key()
     jobs = _RJOBS.pop(key, None)
     if not jobs:
         return None
@@ -527,7 +533,7 @@ def _workspace(device, nfloats):
     """Scratch buffer of the weight-gradient K-split reduction, one per (device, launch stream): users of one
     stream reuse it in stream order.  Allocated once at the library's cap (lmn_conv_wgrad_workspace never asks for
     more than 16 M floats), so it is never re-allocated under kernels still in flight on another stream."""
-    key = (device, _STREAM[0].value if _STREAM[0] is not None else 0)
+    key = (device, stream_key())
     ws = _ws_cache.get(key)
     if ws is None or ws.numel() < nfloats:
         ws = torch.empty(max(nfloats, 16 << 20), device=device, dtype=torch.float32)

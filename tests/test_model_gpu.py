@@ -282,6 +282,49 @@ def test_deterministic_mode_is_bit_reproducible():
     assert not hip.get_deterministic()
 
 
+def test_multi_stream_schedule_equals_serial_schedule_bit_for_bit():
+    """Deterministic mode as a race detector: the training step on the four-stream schedule (branch chains, weight-gradient streams,
+    late weight-gradient issue) and the same step launched serially on one stream run the same kernels on the same grids -- only the
+    streams and the interleaving differ -- so their losses and all gradients must be bit-identical; a missing dependency between
+    streams, or a reduction that is never flushed on one of the paths (the serial path once lost its deferred weight-gradient
+    reductions on the default stream), shows as a difference."""
+    from lm_net_amd import LM_Net, hip
+    x = det_input((2, 3, 96, 128), "race/x").cuda()
+    G = det_input((2, 2, 96, 128), "race/G").cuda()
+
+    def run(**cfg):
+        m = LM_Net(3, 2)
+        fill_module(m, 37)
+        no_dropout(m)
+        m = m.cuda().train()
+        m.deterministic = True
+        for k, v in cfg.items():
+            setattr(m._engine, k, v)
+        out = []
+        for _ in range(2):
+            for p in m.parameters():
+                p.grad = None
+            y = m(x)
+            (y * G).sum().backward()
+            torch.cuda.synchronize()
+            out.append((y.detach().clone(), [p.grad.detach().clone() for p in m.parameters()]))
+        return out
+
+    try:
+        ref = run(branch_overlap=False, overlap_wgrad=False)
+        nz = sum(1 for g in ref[1][1] if float(g.abs().max()) > 0)
+        assert nz >= len(ref[1][1]) - 40, nz          # (only the pre-BatchNorm biases have an exactly zero gradient)
+        names = [n for n, _ in LM_Net(3, 2).named_parameters()]
+        for cfg in ({}, dict(lazy_wgrad=False), dict(overlap_wgrad=False), dict(branch_overlap=False)):
+            got = run(**cfg)
+            for (yr, gr), (yg, gg) in zip(ref, got):
+                assert torch.equal(yr, yg), cfg
+                bad = [names[i] for i, (u, v) in enumerate(zip(gr, gg)) if not torch.equal(u, v)]
+                assert not bad, (cfg, len(bad), bad[:6])
+    finally:
+        hip.set_deterministic(False)
+
+
 def test_fused_adamw_matches_torch_adamw_and_exchanges_state():
     """lm_net_amd.optim.FusedAdamW (one kernel over the flat buffers) against torch.optim.AdamW -- the reference's
     optimizer (train.py:156) -- on the same model, data and loss: parameters after 3 steps, then a state_dict
