@@ -264,7 +264,7 @@ class Engine:
         hip.conv_fwd([dy], wpt, out, B=B, Hin=Ho, Win=Wo, Hout=Hin, Wout=Win, Cout=rows, ksize=k, stride=s,
                      transposed=1, **kw)
 
-    def wgrad(self, srcs, dy, w_param, b_param, *, Hin, Win, k=1, s=1, dW=None, db=None, join=True, after=None, deferred=False, **kw):
+    def wgrad(self, srcs, dy, w_param, b_param, *, Hin, Win, k=1, s=1, dW=None, db=None, join=True, after=None, deferred=False, keep=(), **kw):
         """join=False: an explicit dW is NOT read on the issuing stream right away (no join; the K-split reduction stays deferred
         when after is given).  after: callable run on the gradient's stream right after the batched reduction that completes it."""
         d = dy.t if isinstance(dy, V) else dy
@@ -278,7 +278,7 @@ class Engine:
             if db is None and b_param is not None:
                 db = G_[b_param]
             self.lazy_q.append(lambda: self.wgrad(srcs, dy, None, None, Hin=Hin, Win=Win, k=k, s=s, dW=dW, db=db, join=False,
-                                                  after=after, deferred=True, **kw))
+                                                  after=after, deferred=True, keep=keep, **kw))
             return
         B = d.shape[0]
         Ho = (Hin + 2 * (k // 2) - k) // s + 1
@@ -326,6 +326,12 @@ class Engine:
             d.record_stream(side)
             if ws is not None:
                 ws.record_stream(side)
+            for t in keep:              # (tensors only the follow-up `after` touches: without this mark the allocator hands their memory
+                t.record_stream(side)   #  to the next main-stream allocation while the side stream has not run the follow-up yet)
+            if dW is not None:
+                dW.record_stream(side)
+            if db is not None:
+                db.record_stream(side)
             for src in srcs:
                 self._t(src).record_stream(side)
                 if isinstance(src, dict) and src.get("scale") is not None:
@@ -642,7 +648,7 @@ class Engine:
                 # closed form right after the batched reduction that completes it (same stream)
                 Rw = _Z(x, E, Cin)
                 Mx, mx, gw, gb = zp["M"], zp["m"], G[ec.weight], G[ec.bias]
-                self.wgrad([x], dh, None, None, Hin=H, Win=W, dW=Rw, db=None, join=False,
+                self.wgrad([x], dh, None, None, Hin=H, Win=W, dW=Rw, db=None, join=False, keep=(Rw, Mx, mx, coef, hst),
                            after=lambda: hip.reparam_wfin(Rw, Mx, mx, coef, hst, ec.weight, ec.bias, N, gw, gb))
             else:
                 dz = dpre  # (reuse: its last reader on this stream was the depthwise backward)
