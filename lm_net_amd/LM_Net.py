@@ -463,6 +463,9 @@ class LM_Net(nn.Module):
         are cloned if a `.grad` still aliases it), data-parallel gradients are all-reduced after the backward
         replay instead of bucket by bucket inside it.  Dropout draws a new mask per replay from a device-side
         counter."""
+        if on and self._engine.deterministic:
+            raise RuntimeError("enable_graphs(): hipGraph capture is not available in deterministic mode (its slot scratch cannot be "
+                               "allocated inside a capture); use enable_plans()")
         self.use_graphs = bool(on)
         if not on:
             self._graphs = {}

@@ -165,6 +165,10 @@ float* lmn_det_slots(hipStream_t st, size_t floats) {
   DetWs& w = g_det_ws[st];
   const size_t need = ((floats * sizeof(float) + 255) / 256) * 256;
   if (w.used + need > w.bytes) {
+    // (a stream that is being captured into a hipGraph can neither be waited for nor allocate: deterministic mode then needs a
+    //  scratch that already exists for that stream -- enable_graphs() captures on a stream of its own, so it is refused)
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) return nullptr;
     // grow: the old scratch may still be read by work queued on the stream -> wait for the stream, then replace it
     (void)hipStreamSynchronize(st);
     if (w.base) (void)hipFree(w.base);
