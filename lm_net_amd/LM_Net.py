@@ -254,11 +254,12 @@ class LM_Net(nn.Module):
                         return _LMNetPlanDirectFunction.apply(x, self._grad_anchor(x.device), self, ps)
                     return _LMNetPlanFunction.apply(x, self, ps, *params)
                 return self._plan_forward(ps, x)
-        if self.use_graphs and self.training and self._save_tape and not x.requires_grad and not self._keep_taps:
+        graphs = self.use_graphs and not self._engine.deterministic       # (no capture in deterministic mode: see enable_graphs)
+        if graphs and self.training and self._save_tape and not x.requires_grad and not self._keep_taps:
             gs = self._graph_for(x)
             if gs is not None:
                 return _LMNetGraphFunction.apply(x, self, gs, *params)
-        if self.use_graphs and not self.training and not self._save_tape and not self._keep_taps:
+        if graphs and not self.training and not self._save_tape and not self._keep_taps:
             out = self._infer_replay(x)
             if out is not None:
                 return out
