@@ -11,7 +11,7 @@ from tools.detweights import det_input, disc_labels, fill_module
 from tests.helpers import no_dropout
 
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 3
-B, S = 8, 352
+B, S = int(os.environ.get('BATCH', '8')), int(os.environ.get('SIZE', '352'))
 x = det_input((B, 3, S, S), "race/x").cuda()
 y = disc_labels(B, S, S).cuda()
 
@@ -22,6 +22,7 @@ def run(cfg, steps=int(os.environ.get('STEPS', '2'))):
     no_dropout(m)
     m = m.cuda().train()
     m.deterministic = True
+    m.compute_dtype = os.environ.get('DTYPE', 'fp32')
     e = m._engine
     for k, v in cfg.items():
         setattr(e, k, v)
