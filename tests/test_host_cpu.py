@@ -146,3 +146,19 @@ def test_wgrad_reduce_job_geometry_is_host_arithmetic():
         assert j.ksl in (1, 2, 4, 8, 16, 32, 64) and j.blocks_per_set * (4096 // j.ksl) >= j.per
     need, j = job(1, 4, 4, 12, 12, 1)        # 16 pixels: one block, atomics
     assert j.nblk == 0
+
+
+def test_stream_key_of_the_default_stream_is_zero_not_none():
+    """hip.stream_key(): the launch stream as a dictionary key.  `ctypes.c_void_p(0).value` is None -- the deferred weight-gradient
+    reductions of a serial run on the default stream were once filed under 0 and looked up under None (never flushed)."""
+    import ctypes
+    from lm_net_amd import hip
+    saved = hip._STREAM[0]
+    try:
+        hip._STREAM[0] = ctypes.c_void_p(0)
+        assert hip.stream_key() == 0 and isinstance(hip.stream_key(), int)
+        hip._STREAM[0] = ctypes.c_void_p(0x7f00deadbeef)
+        assert hip.stream_key() == 0x7f00deadbeef
+        assert hip.wgrad_reduce_pending(0) == 0 and hip.wgrad_reduce_pending() == 0
+    finally:
+        hip._STREAM[0] = saved
