@@ -343,6 +343,45 @@ class Run:
         return dt, loss
 
 
+def deterministic_check(dev, B, size, steps=5):
+    """Deterministic mode (LM_Net.deterministic / lmn_set_deterministic) on the headline shape: two fresh runs of two training steps,
+    all gradient tensors compared bit for bit, then the step time of the mode over `steps` replayed steps."""
+    from lm_net_amd import hip
+    out = {"mode": "fixed-order reductions (lmn_set_deterministic)"}
+    try:
+        grads = []
+        for _ in range(2):
+            r = Run(dev, 1, 0, "f32", B, size, plans=False)
+            r.net.deterministic = True
+            for _ in range(2):
+                loss = r.crit(r.model(r.x), r.y)
+                r.opt.zero_grad(set_to_none=True)
+                loss.backward()
+                g = [p.grad.detach().clone() for p in r.net.parameters()]
+                r.opt.step()
+            torch.cuda.synchronize()
+            grads.append((float(loss.detach()), g))
+            del r
+        (la, ga), (lb, gb) = grads
+        out["gradient_tensors"] = len(ga)
+        out["differing_tensors"] = sum(0 if torch.equal(u, v) else 1 for u, v in zip(ga, gb))
+        out["bit_identical"] = bool(out["differing_tensors"] == 0 and la == lb)
+        del grads, ga, gb
+        r = Run(dev, 1, 0, "f32", B, size)
+        r.net.deterministic = True
+        for _ in range(5):
+            r.step()
+        dt, _ = r.timed(steps, 1, dev)
+        out["ms_per_step"] = round(dt / steps * 1e3, 3)
+        del r
+    except Exception as e:                      # (reported, never fatal for the headline)
+        out["error"] = str(e)[:300]
+    finally:
+        hip.set_deterministic(False)
+        torch.cuda.empty_cache()
+    return out
+
+
 def other_config(dev, dtype, B, size, steps=10, warmup=5):
     """A further BASELINE configuration timed in the same process (never the headline): warm-up (incl. plan recording), then
     `steps` steps between synchronisations.  Returns the entry for `other_configs`."""
@@ -517,6 +556,7 @@ def main():
             # 512x512 inputs, batch 32
             res["other_configs"] = {"configs[2] bf16 mixed precision, batch 64, 352x352": other_config(dev, "bf16", 64, 352),
                                     "configs[4] on 1 GPU: fp32, 512x512, batch 32": other_config(dev, "f32", 32, 512)}
+            res["deterministic_mode"] = deterministic_check(dev, 8, 352)
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(H, W)
         print(json.dumps(res))
