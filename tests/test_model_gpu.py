@@ -325,6 +325,36 @@ def test_multi_stream_schedule_equals_serial_schedule_bit_for_bit():
         hip.set_deterministic(False)
 
 
+@pytest.mark.parametrize("shape", [(1, 32, 32), (2, 32, 48), (5, 48, 48)])
+def test_minimum_and_ragged_sizes_vs_oracle(shape):
+    """Edge of the domain: the smallest input the five-level pyramid admits (32x32: a 2x2 bottleneck map, BatchNorm batch
+    statistics over 4 .. 1024 pixels, 4x4 neighborhood-attention maps with every window clamped), batch 1, an odd batch, strips and
+    tiles that are mostly padding -- eval and training mode, logits and every gradient against the CPU oracle."""
+    from oracle.lmnet_ref import LM_Net as Oracle
+    B, H, W = shape
+    ora = Oracle(3, 2)
+    fill_module(ora, 9)
+    no_dropout(ora)
+    m = _net(seed=9)
+    x = det_input((B, 3, H, W), "edge/x")
+    G = det_input((B, 2, H, W), "edge/G")
+    for train in (False, True):
+        ora.train(train); m.train(train)
+        for p in list(ora.parameters()) + list(m.parameters()):
+            p.grad = None
+        xo = x.clone().requires_grad_(True)
+        xg = x.cuda().requires_grad_(True)
+        yo, yg = ora(xo), m(xg)
+        assert rel_err(yg, yo) < TOL, (shape, train)
+        (yo * G).sum().backward()
+        (yg * G.cuda()).sum().backward()
+        assert rel_err(xg.grad, xo.grad) < 2e-3, (shape, train)
+        gmax = max(float(p.grad.abs().max()) for p in ora.parameters())
+        for (k, po), (_, pg) in zip(ora.named_parameters(), m.named_parameters()):
+            err = float((pg.grad.cpu() - po.grad).abs().max())
+            assert err < 4e-3 * float(po.grad.abs().max()) or err < 5e-5 * gmax, (shape, train, k, err)
+
+
 def test_fused_adamw_matches_torch_adamw_and_exchanges_state():
     """lm_net_amd.optim.FusedAdamW (one kernel over the flat buffers) against torch.optim.AdamW -- the reference's
     optimizer (train.py:156) -- on the same model, data and loss: parameters after 3 steps, then a state_dict
