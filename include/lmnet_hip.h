@@ -395,7 +395,7 @@ int lmn_na_bwd(const void* qkv, const float* rpb, const void* dout, void* dqkv, 
 
 /* ------------------------------------------------------------------------------------------
  * Dense global attention of GFT (core/modules.py:267-279): qkv [B,N,3C] (channel = which*C +
- * head*hd + d), out [B,N,C].  N <= 1024 tokens, hd <= 32.
+ * head*hd + d), out [B,N,C].  Any N (streamed over key tiles; exercised up to 16384 tokens = 2048x2048 inputs), hd <= 32.
  * ------------------------------------------------------------------------------------------ */
 int lmn_gattn_fwd(const void* qkv, void* out, float* lse, int B, int N, int heads, int hd, float scale, int act_dtype,
                   lmn_stream_t stream);
