@@ -577,7 +577,7 @@ def check_na():
 
 def check_gattn():
     rows = []
-    for (B, N, heads, hd) in [(2, 70, 12, 31), (1, 484, 12, 31), (1, 130, 3, 8)]:
+    for (B, N, heads, hd) in [(2, 70, 12, 31), (1, 484, 12, 31), (1, 130, 3, 8), (1, 1024, 12, 31), (1, 2500, 2, 8)]:   # (512x512 / 800x800 inputs)
         Cn = heads * hd
         qkv = (R(B, N, 3 * Cn, seed=101) * 0.7).requires_grad_(True)
         q, k, v = qkv.view(B, N, 3, heads, hd).permute(2, 0, 3, 1, 4).unbind(0)
