@@ -71,7 +71,7 @@ def _targs(name):
 
 def _pmc_match(kernel):
     """PMC records of the kernels the in-library timer files under `kernel`.  The timer keys a launch by the text of its launch
-    site (`dw_stats_strip_kernel<MODE, T>`), rocprofv3 by the instantiated name (`dw_stats_strip_kernel<1, float>`): same base
+    site (`dw_bwd_kernel<T, PT, HL, Z, WP>`), rocprofv3 by the instantiated name (`dw_bwd_kernel<float, 0, true, true, 2>`): same base
     name, and every LITERAL template argument of the launch site (numbers, true / false) equal; symbolic ones match anything."""
     d = _pmc()
     if not d:
@@ -155,11 +155,11 @@ def roofline_block(dominant, live, survey, tot_us, B, H, W, step_s, alone, esz=4
     r["mfma_util_pmc"] = pmc_field(dominant, "mfma_busy_frac") if (B, H, W) == (8, 352, 352) else None
     r["top5_by_time"] = [{"kernel": k, "share": round(v["total_us"] / tot_us, 4), "avg_us": round(v["total_us"] / max(v["launches"], 1), 1)}
                          for k, v in sorted(survey.items(), key=lambda kv: -kv[1]["total_us"])[:5]]
-    a2 = _group(live, ("dw_fwd_strip_kernel", "dw_bwd_strip_kernel", "dw_stats_strip_kernel"))
+    a2 = _group(live, ("dw_fwd_kernel", "dw_bwd_kernel", "dw_stats0_kernel", "dw_stats1_kernel"))
     a7 = _group(live, ("na_fwd_kernel", "na_bwd_q_kernel", "na_bwd_kv_kernel", "na_bwd_q_tile_kernel", "na_bwd_kv_tile_kernel"))
     pm = (_pmc() or {}).get("whole_step")
     # row totals under the 8d convention: A2 train = 5*E*HW*B*4 (the statistics passes are extra passes, not extra bytes)
-    A2K = ("dw_fwd_strip_kernel", "dw_bwd_strip_kernel", "dw_stats_strip_kernel")
+    A2K = ("dw_fwd_kernel", "dw_bwd_kernel", "dw_stats0_kernel", "dw_stats1_kernel")
     A7K = ("na_fwd_kernel", "na_bwd_q_kernel", "na_bwd_kv_kernel", "na_bwd_q_tile_kernel", "na_bwd_kv_tile_kernel")
 
     def a2_bytes(d):   # 8d convention: A2 train = 5*E*HW*B*4 = the bytes of fwd + bwd (the statistics passes add time, not bytes)
@@ -172,7 +172,7 @@ def roofline_block(dominant, live, survey, tot_us, B, H, W, step_s, alone, esz=4
         if al["total_us"] > 0:
             r["row_A2"]["frac_alone"] = _entry("", dict(al, bytes=a2_bytes(alone)))["frac"]
         for k, v in live.items():
-            if k.startswith(("dw_fwd_strip_kernel", "dw_bwd_strip_kernel")):
+            if k.startswith(("dw_fwd_kernel", "dw_bwd_kernel")):
                 r["row_A2"][k] = {f: _entry(k, v)[f] for f in ("avg_us", "achieved", "frac")}
                 if k in alone:
                     r["row_A2"][k]["frac_alone"] = _entry(k, alone[k])["frac"]

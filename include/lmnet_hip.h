@@ -21,6 +21,15 @@
  *     (b,y,x,c) of a tensor with pixel stride `cstride` lives at ((b*H+y)*W+x)*cstride + c.
  *     A pointer may address a channel slice of a wider buffer (cstride > C) -- this is how
  *     torch.cat along channels (core/modules.py:104,139,497) is expressed without a copy.
+ *   - ROW-PLANAR tensors ("RP4", round 4): the E-wide tensors INSIDE a ReparamConv block (core/modules.py:587-599: the expand
+ *     conv's output z / x1, the GELU input `pre`, and in the backward u, dpre, dh / dx1, dz) are stored as
+ *         element (b,y,x,c)  at  ((b*H + y) * (C/4) + (c >> 2)) * 4*W + 4*x + (c & 3)
+ *     i.e. one contiguous plane of W pixels x 4 channels per image row and channel quad (the reference's own NCHW
+ *     with the channel quad folded next to x).  The depthwise stencils (lmn_dw_*) take ONLY this layout: their lanes run
+ *     along x with a wave-uniform channel, so a wave's row is one coalesced load and needs no transpose.  The 1x1 convs
+ *     and weight gradients either side of them read / write it when told so: lmn_src_t.rp_w, lmn_conv_args_t.out_rp_w /
+ *     aux_rp_w, lmn_wgrad_args_t.dy_rp_w = W (0: NHWC); every row-planar operand of one call has the same W, is a whole
+ *     tensor (cstride == C) and belongs to a 1x1 stride-1 call.
  *   - the caller owns every buffer (incl. workspace); kernels never allocate, free or synchronise;
  *     everything is enqueued on `stream` (hipStream_t) and is stream-ordered and re-entrant.
  *   - return value: 0 on success, <0 = LMN_E_* argument error, >0 = hipError_t from the launch.
@@ -39,7 +48,7 @@ extern "C" {
 
 typedef void* lmn_stream_t; /* hipStream_t */
 
-#define LMN_ABI_VERSION 8
+#define LMN_ABI_VERSION 9
 /* arithmetic type of the matrix-core operands of a dense contraction (accumulators, epilogues, statistics: fp32) */
 #define LMN_F32 0  /* v_mfma_f32_16x16x4_f32: exact fp32 (k-ordered fma chain)                                  */
 #define LMN_BF16 1 /* v_mfma_f32_16x16x16_bf16: operands rounded to bf16 (RNE) when staged / packed -- the mixed- */
@@ -76,7 +85,7 @@ typedef struct {
   int32_t flags;      /* LMN_SRC_*                                                                */
   uint32_t drop_seed; /* dropout stream id for LMN_SRC_DROP                                       */
   float drop_p;       /* dropout probability for LMN_SRC_DROP                                     */
-  int32_t _pad;
+  int32_t rp_w;       /* 0: NHWC; W > 0: the tensor is row-planar (RP4, see Conventions) with image width W */
 } lmn_src_t;
 
 /* epilogues; v = accumulator + bias[co] */
@@ -159,12 +168,12 @@ typedef struct {
                             /* (lmn_bn_finalize / lmn_bn_bwd_coef, argument nrep) sum the slices                */
                             /* mma_dtype: LMN_F32 | LMN_BF16 -- `wpack` must have been packed with the same dtype */
   int32_t act_dtype;        /* storage of src[].ptr / aux / residual / out: LMN_F32, or LMN_BF16 (needs mma_dtype   */
-  int32_t _pad1;            /* LMN_BF16)                                                                             */
+  int32_t out_rp_w;         /* LMN_BF16).  out_rp_w / aux_rp_w: 0 = NHWC, W > 0 = `out` / `aux` is row-planar (RP4)      */
   const float* p5;          /* BN_BWD2 only: BatchNorm gamma / beta when `aux` is the gradient w.r.t. the ACTIVATED   */
   const float* p6;          /* output (the activation derivative is then applied here and dh is never written)        */
   lmn_bn_fin_t fin;         /* optional in-kernel BatchNorm bookkeeping (fin.mode = LMN_FIN_NONE: off)                   */
   int32_t stats_snap;       /* LMN_STATS_SUM_SQ: also copy the shift vector p4 (zeros if NULL) to stats[stats_rep*2*Cout..]: */
-  int32_t _pad2;            /* a snapshot that stays valid when p4 is a running mean updated by the consuming pass        */
+  int32_t aux_rp_w;         /* a snapshot that stays valid when p4 is a running mean updated by the consuming pass        */
 } lmn_conv_args_t;
 
 /* number of floats lmn_conv_pack writes for (ksize, Cout, src channel counts c[nsrc]) */
@@ -222,8 +231,9 @@ typedef struct {
   int32_t mma_dtype; /* LMN_F32 | LMN_BF16: operand type of the pixel-reduction MFMAs (accumulators fp32)                */
   int32_t act_dtype; /* storage of src[].ptr and dy                                                                      */
   int32_t defer_reduce; /* 1: with a workspace, the call only writes its K-split block partials; the caller sums them    */
-  int32_t _pad;         /*    later with lmn_wgrad_reduce_batch (job description: lmn_conv_wgrad_job).  The workspace    */
+  int32_t dy_rp_w;      /*    later with lmn_wgrad_reduce_batch (job description: lmn_conv_wgrad_job).  The workspace    */
                         /*    must then be the call's own until that launch (not a scratch shared with other calls)      */
+                        /* dy_rp_w: 0 = NHWC, W > 0 = `dy` is row-planar (RP4)                                           */
 } lmn_wgrad_args_t;
 int lmn_sizeof_wgrad_args(void);
 /* floats of workspace that make lmn_conv_wgrad use the two-stage reduction for this problem (0: not useful) */
@@ -268,6 +278,8 @@ int lmn_wgrad_reduce_batch(const lmn_reduce_job_t* jobs_dev, int njobs, int64_t 
  * Multi-branch depthwise stencil of ReparamConv (row A2): four depthwise convs 5x5, 3x3, 3x1,
  * 1x3 (zero pad k/2, no bias), each followed by its own BatchNorm, summed, then GELU
  * (core/modules.py:548-574, 592-597).  Weight pointers use torch layouts [E][1][kh][kw].
+ * Every ACTIVATION tensor of this family (x1 / z, pre, u, dpre, dx1 / dh) is ROW-PLANAR (RP4, see Conventions) with
+ * C = E and the W of the call.
  * ------------------------------------------------------------------------------------------ */
 /* z-path of ReparamConv (core/modules.py:587, 592-597): the tensor handed to the depthwise kernels is z, the output of the
  * expand conv BEFORE its BatchNorm and Hardswish; x1 = Hardswish(A * z + shift) is formed when the kernels stage their rows
@@ -509,8 +521,9 @@ int lmn_fill(float* p, float v, int64_t n, lmn_stream_t stream);
 int lmn_reparam_wfin(const float* R, const float* M, const float* m, const float* coef, const float* hstats, const float* w_expand,
                      const float* b_expand, float count, int E, int rows, int cin_w, float* dW, float* db, lmn_stream_t stream);
 /* y[p][c] = coef[0][c] * u[p][c] + coef[1][c] * v[p][c] + coef[2][c]  over `rows` pixels of C channels (activation tensors):
- * dz = a * dh + b * z + c of the z-path (lmn_reparam_fold), materialised beside the critical path for the weight gradient */
-int lmn_affine2(const void* u, const void* v, const float* coef, void* y, int64_t rows, int C, int act_dtype, lmn_stream_t stream);
+ * dz = a * dh + b * z + c of the z-path (lmn_reparam_fold), materialised beside the critical path for the weight gradient.
+ * rp_w: 0 = NHWC tensors, W > 0 = all three are row-planar (RP4) with image width W. */
+int lmn_affine2(const void* u, const void* v, const float* coef, void* y, int64_t rows, int C, int rp_w, int act_dtype, lmn_stream_t stream);
 int lmn_add(const void* a, const void* b, const void* c, const void* d, void* y, int64_t n, int act_dtype,
             lmn_stream_t stream);
 /* out[C] += column sums of x[rows][cstride] (bias gradients) */

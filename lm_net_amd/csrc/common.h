@@ -113,6 +113,27 @@ __device__ __forceinline__ void st1(lmn_bf16* p, float v) { *p = (lmn_bf16)v; }
   } while (0)
 #define LMN_REQUIRE_DT(dt, what) LMN_REQUIRE((dt) == LMN_F32 || (dt) == LMN_BF16, what ": act_dtype %d", (int)(dt))
 
+
+// ---------------------------------------------------------------- RP4: row-planar layout of the E-wide ReparamConv tensors
+// element (global pixel gp = (b*H + y)*W + x, channel c) of a tensor with C channels lives at
+//   (gp / W) * (C * W) + (c >> 2) * 4 * W + 4 * (gp % W) + (c & 3)
+// (one plane of W pixels x 4 channels per image row and channel quad: include/lmnet_hip.h).  w == 0: plain NHWC.
+struct LmnRp { int32_t w; uint32_t magic; int32_t cw; int32_t _pad; };
+static inline LmnRp lmn_rp_make(int w, int C) {
+  LmnRp r;
+  r.w = w; r.cw = C * w; r._pad = 0;
+  r.magic = w > 1 ? (uint32_t)(0x100000000ULL / (uint64_t)w) : (w == 1 ? 0xFFFFFFFFu : 0u);   // floor(2^32 / W): quotient estimate short by at most 1
+  return r;
+}
+#ifdef __HIPCC__
+__device__ __forceinline__ uint32_t lmn_rp_off(uint32_t gp, int ch, const LmnRp& R) {
+  uint32_t row = __umulhi(gp, R.magic);
+  uint32_t x = gp - row * (uint32_t)R.w;
+  if (x >= (uint32_t)R.w) { ++row; x -= (uint32_t)R.w; }
+  return row * (uint32_t)R.cw + (uint32_t)(ch >> 2) * (uint32_t)(4 * R.w) + 4u * x + (uint32_t)(ch & 3);
+}
+#endif
+
 // ---------------------------------------------------------------- activations
 // erf: Abramowitz & Stegun 7.1.26 (|abs error| <= 1.5e-7 over the whole line), branch-free: the libm erff has two
 // branches that a wave almost always takes both of (~45 instructions per element against ~13 here).  The

@@ -42,6 +42,7 @@ struct ConvParams {
   uint32_t mTW, mXW;
   int strided;
   float* det_stats;       // deterministic mode: slot copies of the statistics destination (one slot per block / per wave), else NULL
+  LmnRp rp_src[3], rp_out, rp_aux;   // row-planar operands (1x1 convs only; w == 0: NHWC)
 };
 
 // precision mode of a conv-family kernel instance: 0 = fp32 storage + fp32 MFMA, 1 = fp32 storage + bf16 MFMA operands,
@@ -325,7 +326,7 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(const ConvParams P) {
         for (int c = 0; c < NCT; ++c) {
           const int co = (ct0 + c) * 16 + q * 4;
           const int cos = ((ct0 + c < P.NCTT) && co < A.Cout) ? co : 0;
-          axp[g][c] = A.aux ? ld4((const TA*)A.aux + (uint32_t)opix[g] * A.aux_cstride + cos) : f32x4{0.f, 0.f, 0.f, 0.f};
+          axp[g][c] = A.aux ? ld4((const TA*)A.aux + ((TAPS == 1 && P.rp_aux.w) ? lmn_rp_off((uint32_t)opix[g], cos, P.rp_aux) : (uint32_t)opix[g] * A.aux_cstride + cos)) : f32x4{0.f, 0.f, 0.f, 0.f};
         }
     }
 
@@ -366,7 +367,7 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(const ConvParams P) {
             const bool ok = i < nitems && ch < S.C && (TAPS == 1 || (unsigned)iy < (unsigned)A.Hin) && (unsigned)ix < (unsigned)A.Win;
             const int gp = ok ? (TAPS == 1 ? b * A.Win + ix : (b * A.Hin + iy) * A.Win + ix) : 0;
             sgp[u] = ok ? gp : -1;
-            sv[u] = ld4((const TA*)S.ptr + (uint32_t)(gp * S.cstride + (ok ? ch : 0)));
+            sv[u] = ld4((const TA*)S.ptr + ((TAPS == 1 && P.rp_src[s].w) ? lmn_rp_off((uint32_t)gp, ok ? ch : 0, P.rp_src[s]) : (uint32_t)(gp * S.cstride + (ok ? ch : 0))));
           }
 #pragma unroll
           for (int u = 0; u < SU; ++u) {
@@ -541,7 +542,7 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(const ConvParams P) {
         if (EPI) {
           f32x4 ax = f32x4{0.f, 0.f, 0.f, 0.f};
           if constexpr (AUXP) ax = axp[g][c];
-          else if (A.aux) ax = ld4((const TA*)A.aux + opx * A.aux_cstride + cos);
+          else if (A.aux) ax = ld4((const TA*)A.aux + ((TAPS == 1 && P.rp_aux.w) ? lmn_rp_off(opx, cos, P.rp_aux) : opx * A.aux_cstride + cos));
           switch (ep_kind) {
             case LMN_EP_DGELU: {
 #pragma unroll
@@ -582,7 +583,7 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(const ConvParams P) {
           for (int r = 0; r < 4; ++r) o[r] *= lmn_drop_scale(A.drop_seed + soff, idx + r, A.drop_p, P.inv_keep_ep);
         }
         if (A.residual) o += ld4((const TA*)A.residual + opx * A.res_cstride + cos);
-        if (A.out && live) st4((TA*)A.out + opx * A.out_cstride + cos, o);
+        if (A.out && live) st4((TA*)A.out + ((TAPS == 1 && P.rp_out.w) ? lmn_rp_off(opx, cos, P.rp_out) : opx * A.out_cstride + cos), o);
         __builtin_amdgcn_sched_barrier(0);
       }
     }
@@ -786,7 +787,7 @@ __global__ __launch_bounds__(256) void conv_tileM_kernel(const ConvParams P) {
             const bool ok = i < nitems && f < nq && ch < S.C && (unsigned)iy < (unsigned)A.Hin && (unsigned)ix < (unsigned)A.Win;
             const int gp = ok ? (b * A.Hin + iy) * A.Win + ix : 0;
             sgp[u] = ok ? gp : -1;
-            sv[u] = ld4((const TA*)S.ptr + (uint32_t)(gp * S.cstride + (ok ? ch : 0)));
+            sv[u] = ld4((const TA*)S.ptr + ((TAPS == 1 && P.rp_src[s].w) ? lmn_rp_off((uint32_t)gp, ok ? ch : 0, P.rp_src[s]) : (uint32_t)(gp * S.cstride + (ok ? ch : 0))));
           }
 #pragma unroll
           for (int u = 0; u < SU; ++u) {
@@ -984,7 +985,7 @@ __global__ __launch_bounds__(256) void conv_tileM_kernel(const ConvParams P) {
         }
         if (EPI) {
           f32x4 ax = f32x4{0.f, 0.f, 0.f, 0.f};
-          if (A.aux) ax = ld4((const TA*)A.aux + opx * A.aux_cstride + cos);
+          if (A.aux) ax = ld4((const TA*)A.aux + ((TAPS == 1 && P.rp_aux.w) ? lmn_rp_off(opx, cos, P.rp_aux) : opx * A.aux_cstride + cos));
           switch (ep_kind) {
             case LMN_EP_DGELU: {
 #pragma unroll
@@ -1025,7 +1026,7 @@ __global__ __launch_bounds__(256) void conv_tileM_kernel(const ConvParams P) {
           for (int r = 0; r < 4; ++r) o[r] *= lmn_drop_scale(A.drop_seed + soff, idx + r, A.drop_p, P.inv_keep_ep);
         }
         if (A.residual) o += ld4((const TA*)A.residual + opx * A.res_cstride + cos);
-        if (A.out && live) st4((TA*)A.out + opx * A.out_cstride + cos, o);
+        if (A.out && live) st4((TA*)A.out + ((TAPS == 1 && P.rp_out.w) ? lmn_rp_off(opx, cos, P.rp_out) : opx * A.out_cstride + cos), o);
         __builtin_amdgcn_sched_barrier(0);
       }
     }
@@ -1270,6 +1271,7 @@ __global__ __launch_bounds__(256) void reparam_wfin_kernel(const float* __restri
 
 // ------------------------------------------------------------------------------------ weight gradient
 struct WgradParams {
+  LmnRp rp_src[3], rp_dy;   // row-planar operands (1x1 kernels only; w == 0: NHWC)
   lmn_wgrad_args_t a;
   int ntile_src[3];  // 16-channel tiles per source
   int ntile_off[3];
@@ -2013,6 +2015,7 @@ __global__ __launch_bounds__(256) void wgrad_1x1_kernel(const WgradParams P) {
   const TA* sptr[NNT];
   const float* sscale[NNT];
   int sC[NNT], scs[NNT], sflags[NNT], sch[NNT];
+  LmnRp srp[NNT];
   uint32_t sseed[NNT];
   float sp[NNT], sik[NNT];
   bool any_tf = (A.dy_flags & LMN_SRC_DROP) != 0;
@@ -2026,6 +2029,7 @@ __global__ __launch_bounds__(256) void wgrad_1x1_kernel(const WgradParams P) {
     sscale[t] = A.src[s].scale;
     sC[t] = A.src[s].C;
     scs[t] = A.src[s].cstride;
+    srp[t] = P.rp_src[s];
     sflags[t] = A.src[s].flags;
     sseed[t] = A.src[s].drop_seed + soff;
     sp[t] = A.src[s].drop_p;
@@ -2065,9 +2069,9 @@ __global__ __launch_bounds__(256) void wgrad_1x1_kernel(const WgradParams P) {
       const bool ok = (BF ? px < se * 4 : step0 + u < se) && px < NPX;
       const int ps = ok ? px : 0;
 #pragma unroll
-      for (int m = 0; m < NMT; ++m) av[u][m] = ld1((const TA*)A.dy + (uint32_t)(ps * A.dy_cstride + (mco[m] >= 0 ? mco[m] : 0)));
+      for (int m = 0; m < NMT; ++m) av[u][m] = ld1((const TA*)A.dy + (P.rp_dy.w ? lmn_rp_off((uint32_t)ps, mco[m] >= 0 ? mco[m] : 0, P.rp_dy) : (uint32_t)(ps * A.dy_cstride + (mco[m] >= 0 ? mco[m] : 0))));
 #pragma unroll
-      for (int t = 0; t < NNT; ++t) bv[u][t] = ld1(sptr[t] + (uint32_t)(ps * scs[t] + (sch[t] >= 0 ? sch[t] : 0)));
+      for (int t = 0; t < NNT; ++t) bv[u][t] = ld1(sptr[t] + (srp[t].w ? lmn_rp_off((uint32_t)ps, sch[t] >= 0 ? sch[t] : 0, srp[t]) : (uint32_t)(ps * scs[t] + (sch[t] >= 0 ? sch[t] : 0))));
     }
     // ---- on-load transforms (wave-uniform flags) and masking
     int b0 = 0;
@@ -2227,6 +2231,7 @@ __global__ __launch_bounds__(256) void wgrad_1x1w_kernel(const WgradParams P) {
   const TA* sptr[NNT];
   const float* sscale[NNT];
   int sC[NNT], scs[NNT], sflags[NNT], sch4[NNT];
+  LmnRp srp[NNT];
   uint32_t sseed[NNT];
   float sp[NNT], sik[NNT];
 #pragma unroll
@@ -2239,6 +2244,7 @@ __global__ __launch_bounds__(256) void wgrad_1x1w_kernel(const WgradParams P) {
     sscale[t] = A.src[s].scale;
     sC[t] = A.src[s].C;
     scs[t] = A.src[s].cstride;
+    srp[t] = P.rp_src[s];
     sflags[t] = A.src[s].flags;
     sseed[t] = A.src[s].drop_seed + soff;
     sp[t] = A.src[s].drop_p;
@@ -2266,9 +2272,9 @@ __global__ __launch_bounds__(256) void wgrad_1x1w_kernel(const WgradParams P) {
     const int px = c * 16 + lp;
     const int ps = px < NPX ? px : 0;
 #pragma unroll
-    for (int m = 0; m < NMT; ++m) stg[m] = ld4((const TA*)A.dy + (uint32_t)(ps * A.dy_cstride + (mco4[m] >= 0 ? mco4[m] : 0)));
+    for (int m = 0; m < NMT; ++m) stg[m] = ld4((const TA*)A.dy + (P.rp_dy.w ? lmn_rp_off((uint32_t)ps, mco4[m] >= 0 ? mco4[m] : 0, P.rp_dy) : (uint32_t)(ps * A.dy_cstride + (mco4[m] >= 0 ? mco4[m] : 0))));
 #pragma unroll
-    for (int t = 0; t < NNT; ++t) stg[NMT + t] = ld4(sptr[t] + (uint32_t)(ps * scs[t] + (sch4[t] >= 0 ? sch4[t] : 0)));
+    for (int t = 0; t < NNT; ++t) stg[NMT + t] = ld4(sptr[t] + (srp[t].w ? lmn_rp_off((uint32_t)ps, sch4[t] >= 0 ? sch4[t] : 0, srp[t]) : (uint32_t)(ps * scs[t] + (sch4[t] >= 0 ? sch4[t] : 0))));
   };
   auto chunk_put = [&](int c) {   // transforms, masking, LDS
     const int px = c * 16 + lp;
@@ -2523,7 +2529,9 @@ int lmn_sizeof_pack_job(void) { return (int)sizeof(lmn_pack_job_t); }
 // cout x cin 16-channel tiles per block.  The direct 1x1 kernel holds up to 4 accumulator tiles in any shape (a
 // one-tile-wide side is read exactly once); the LDS-staged kernel is instantiated for 1 or 2 tiles per side.
 static void wgrad_tile_shape(const lmn_wgrad_args_t& a, int nmtt, int nntt, int* NMT, int* NNT) {
-  const bool direct = a.ksize == 1 && a.stride == 1 && (int64_t)a.Hout * a.Wout >= 32;
+  bool rp_any = a.dy_rp_w != 0;
+  for (int s = 0; s < a.nsrc && s < 3; ++s) rp_any = rp_any || a.src[s].rp_w != 0;
+  const bool direct = a.ksize == 1 && a.stride == 1 && ((int64_t)a.Hout * a.Wout >= 32 || rp_any);   // (row-planar operands: direct kernels only)
   if (direct) {
     // 1x1: a block of (M x N) tiles reads its M dy tiles and N source tiles once per pixel; the grid's tile sets re-read
     // dy ceil(nntt/N) times and the sources ceil(nmtt/M) times: take the instantiated shape with the fewest bytes per
@@ -2667,6 +2675,25 @@ int lmn_conv_fwd(const lmn_conv_args_t* args, lmn_stream_t stream) {
     if (A.src[s].flags & LMN_SRC_DROP) {
       LMN_REQUIRE(A.src[s].drop_p >= 0.f && A.src[s].drop_p < 1.f, "conv_fwd: source dropout p");
       P.inv_keep_src[s] = 1.f / (1.f - A.src[s].drop_p);
+    }
+  }
+  {  // row-planar operands (RP4): whole tensors of a 1x1 stride-1 call, one image width for all of them
+    int rw = 0;
+    for (int s = 0; s < 3; ++s) {
+      const int w = s < A.nsrc ? A.src[s].rp_w : 0;
+      P.rp_src[s] = lmn_rp_make(w, s < A.nsrc ? A.src[s].C : 0);
+      if (w) {
+        LMN_REQUIRE(A.src[s].cstride == A.src[s].C && (rw == 0 || rw == w), "conv_fwd: row-planar source %d must be a whole tensor (cstride == C) of the call's width", s);
+        rw = w;
+      }
+    }
+    P.rp_out = lmn_rp_make(A.out ? A.out_rp_w : 0, A.Cout);
+    P.rp_aux = lmn_rp_make(A.aux ? A.aux_rp_w : 0, A.Cout);
+    if (P.rp_out.w) { LMN_REQUIRE(A.out_cstride == A.Cout && (rw == 0 || rw == P.rp_out.w), "conv_fwd: row-planar out must be a whole tensor of the call's width"); rw = P.rp_out.w; }
+    if (P.rp_aux.w) { LMN_REQUIRE(A.aux_cstride == A.Cout && (rw == 0 || rw == P.rp_aux.w), "conv_fwd: row-planar aux must be a whole tensor of the call's width"); rw = P.rp_aux.w; }
+    if (rw) {
+      LMN_REQUIRE(A.ksize == 1 && A.stride == 1 && rw > 0 && ((int64_t)A.Hin * A.Win) % rw == 0 && ((int64_t)A.Hout * A.Wout) % rw == 0,
+                  "conv_fwd: row-planar operands belong to 1x1 stride-1 calls whose image is a whole number of rows of width %d", rw);
     }
   }
   {  // kernels index with 32-bit element offsets
@@ -3005,6 +3032,20 @@ static int wgrad_setup(const lmn_wgrad_args_t& A, WgradParams& P, WgGeom& G) {
     if (A.src[s].flags & LMN_SRC_DROP) P.inv_keep_src[s] = 1.f / (1.f - A.src[s].drop_p);
   }
   P.inv_keep_dy = (A.dy_flags & LMN_SRC_DROP) ? 1.f / (1.f - A.dy_p) : 1.f;
+  {  // row-planar operands (RP4): whole tensors of a 1x1 stride-1 call, one image width for all of them
+    int rw = 0;
+    for (int s = 0; s < 3; ++s) {
+      const int w = s < A.nsrc ? A.src[s].rp_w : 0;
+      P.rp_src[s] = lmn_rp_make(w, s < A.nsrc ? A.src[s].C : 0);
+      if (w) {
+        LMN_REQUIRE(A.src[s].cstride == A.src[s].C && (rw == 0 || rw == w), "conv_wgrad: row-planar source %d must be a whole tensor (cstride == C) of the call's width", s);
+        rw = w;
+      }
+    }
+    P.rp_dy = lmn_rp_make(A.dy_rp_w, A.Cout);
+    if (P.rp_dy.w) { LMN_REQUIRE(A.dy_cstride == A.Cout && (rw == 0 || rw == P.rp_dy.w), "conv_wgrad: row-planar dy must be a whole tensor of the call's width"); rw = P.rp_dy.w; }
+    if (rw) LMN_REQUIRE(A.ksize == 1 && A.stride == 1 && ((int64_t)A.Hout * A.Wout) % rw == 0, "conv_wgrad: row-planar operands belong to 1x1 stride-1 calls");
+  }
   P.NMTT = (A.Cout + 15) / 16;
   P.steps_per_img = (A.Hout * A.Wout + 3) / 4;
   LMN_REQUIRE((int64_t)A.B * P.steps_per_img < (1LL << 31), "conv_wgrad: too many pixels");
@@ -3072,7 +3113,9 @@ static int wgrad_setup(const lmn_wgrad_args_t& A, WgradParams& P, WgGeom& G) {
   const int64_t cap = btot / gy > 2 ? btot / gy : 2;
   if (blocks64 > cap) blocks64 = cap;
   if (blocks64 < 1) blocks64 = 1;
-  G.direct = A.ksize == 1 && A.stride == 1 && (int64_t)Gm.Hout * Gm.Wout >= 32;
+  bool rp_any = A.dy_rp_w != 0;
+  for (int s = 0; s < A.nsrc; ++s) rp_any = rp_any || A.src[s].rp_w != 0;
+  G.direct = A.ksize == 1 && A.stride == 1 && ((int64_t)Gm.Hout * Gm.Wout >= 32 || rp_any);
   if (G.direct) {  // direct (no LDS) kernels: K steps split over ~1024*4/gy waves, at least 16 steps per wave
     const int64_t steps = ((int64_t)A.B * Gm.Hout * Gm.Wout + 3) / 4;
     blocks64 = (steps + 63) / 64;
@@ -3096,7 +3139,7 @@ static int wgrad_setup(const lmn_wgrad_args_t& A, WgradParams& P, WgGeom& G) {
   bool any_tf = (A.dy_flags & LMN_SRC_DROP) != 0;
   for (int s = 0; s < A.nsrc; ++s) any_tf = any_tf || A.src[s].flags != 0 || A.src[s].scale != nullptr;
   const bool old_shape = (NMT == 1 && NNT <= 4) || (NNT == 1 && NMT <= 4) || (NMT == 2 && NNT == 2);
-  G.wave_staged = !(pm == 2 && !any_tf && old_shape);
+  G.wave_staged = !(pm == 2 && !any_tf && old_shape) || (rp_any && (int64_t)Gm.Hout * Gm.Wout < 32);   // (tiny maps: the staged kernel divides per pixel)
   return 0;
 }
 

@@ -602,11 +602,11 @@ __global__ __launch_bounds__(256) void add_kernel(const T* __restrict__ a, const
 // z-path (dz = a * dh + b * z + c, lmn_reparam_fold), run beside the critical path for the weight gradient
 template <typename T>
 __global__ __launch_bounds__(256) void affine2_kernel(const T* __restrict__ u, const T* __restrict__ v, const float* __restrict__ coef,
-                                                      T* __restrict__ y, int64_t rows, int C4) {
+                                                      T* __restrict__ y, int64_t rows, int C4, int rp_w) {
   const int64_t total = rows * C4;
   const int C = C4 * 4;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-    const int c = (int)(i % C4) * 4;
+    const int c = (int)((rp_w ? i / rp_w : i) % C4) * 4;   // (row-planar: quad i is (image row, channel quad, x))
     const f32x4 a = ld4(coef + c), b = ld4(coef + C + c), k = ld4(coef + 2 * C + c);
     st4(y + i * 4, a * ld4(u + i * 4) + b * ld4(v + i * 4) + k);
   }
@@ -1241,13 +1241,13 @@ int lmn_add(const void* a, const void* b, const void* c, const void* d, void* y,
   return lmn_launch_status("add");
 }
 
-int lmn_affine2(const void* u, const void* v, const float* coef, void* y, int64_t rows, int C, int act_dtype, lmn_stream_t stream) {
-  LMN_REC(lmn_affine2(u, v, coef, y, rows, C, act_dtype, stream));
+int lmn_affine2(const void* u, const void* v, const float* coef, void* y, int64_t rows, int C, int rp_w, int act_dtype, lmn_stream_t stream) {
+  LMN_REC(lmn_affine2(u, v, coef, y, rows, C, rp_w, act_dtype, stream));
   LMN_REQUIRE_DT(act_dtype, "affine2");
   LMN_REQUIRE(u && v && coef && y && rows > 0 && C > 0 && C % 4 == 0, "affine2: bad argument (C must be a multiple of 4)");
   if (g_lmn_prof_on) lmn_prof_cost(4.0 * rows * C, (act_dtype == LMN_BF16 ? 2.0 : 4.0) * 3 * rows * C);
   LMN_ACT_DISPATCH(act_dtype, LMN_LAUNCH((affine2_kernel<T>), dim3(grid_for(rows * (C / 4))), dim3(256), 0, (hipStream_t)stream, (const T*)u, (const T*)v, coef,
-                     (T*)y, rows, C / 4));
+                     (T*)y, rows, C / 4, rp_w));
   return lmn_launch_status("affine2");
 }
 

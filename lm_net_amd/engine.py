@@ -76,6 +76,12 @@ def _A(ref, *shape):
     return eng.alloc(dev, shape, eng.act_dtype)
 
 
+def _R(ref, *shape):
+    """ROW-PLANAR activation tensor [B, H, W, E] (hip.rp4): the E-wide tensors inside a ReparamConv block (z / x1, pre, u, dpre,
+    dh / dx1, dz), written and read by the depthwise kernels and by the 1x1 convs either side of them."""
+    return hip.rp4(_A(ref, *shape))
+
+
 class ZeroPool:
     """All small zero-initialised accumulators (BN sums, SE sums, ...) of one forward or backward pass come
     out of ONE buffer zeroed by ONE memset (their total size is learnt on the first pass)."""
@@ -449,8 +455,9 @@ class Engine:
         E, Cout, N = m.cexp, m.cout, B * H * W
         ec, ebn = m.expand_conv[0], m.expand_conv[1]
         wpe = hip.conv_pack(ec.weight, 1, [x.shape[-1]])   # (a 3-channel weight on the NHWC4 input: zero column packed)
-        x1 = _A(x, B, H, W, E)
-        zpath = self.training and self.fuse_bn and self.zpath and not m.deploy
+        x1 = _R(x, B, H, W, E)
+        # (lmn_reparam_fold keeps two [E]-wide operator panels of the expand conv in LDS: wider blocks take the two-pass BatchNorm form)
+        zpath = self.training and self.fuse_bn and self.zpath and not m.deploy and 35 * E * 4 <= 65536
         zp = None
         if zpath:
             # z-path: ONE pass writes z = conv(x) + bias and its batch sums; the depthwise kernels form x1 = Hardswish(A1 z + sh1)
@@ -516,7 +523,7 @@ class Engine:
                     bn = b.bn
                     hip.bn_fold(bn.running_mean, bn.running_var, bn.weight, bn.bias, bn.eps, bmean[i], brstd[i], bA[i], bshift[i])
                 hip.dw_merge(*ws, bA, bshift, keff, beff)
-        pre = _A(x, B, H, W, E)
+        pre = _R(x, B, H, W, E)
         gsum = _Z(x, B, E)
         se = m.se
         R = se.fc1.weight.shape[0]
@@ -594,7 +601,7 @@ class Engine:
             dWp = _Z(x, Cout, Cin)
             self.wgrad([x], dy, None, None, Hin=H, Win=W, dW=dWp, db=G[sc.bias])
             hip.copy2d(dWp, G[sc.weight], Cout, cw, Cin, cw)      # un-pad (layout copy)
-        u = _A(x, B, H, W, E)
+        u = _R(x, B, H, W, E)
         ds = _Z(x, B, E)
         self.conv_T(dy, pw.weight, u, Hin=H, Win=W, epilogue=hip.EP_SE_BWD, aux=pre, stats=ds, stats_mode=hip.STATS_EP)
         # (the shortcut's data gradient W_sc^T . dy is the second source of the LAST conv of this function: no dx_sc tensor)
@@ -621,7 +628,7 @@ class Engine:
         # ---- A2 backward
         brs = m.branches()
         ws = [b.conv.weight for b in brs]
-        dpre = _A(x, B, H, W, E)
+        dpre = _R(x, B, H, W, E)
         bst = _Z(x, 5, E)
         zp = S.get("zp")
         hip.dw_bwd_stats(x1, pre, u, sgate, dm, dpre, *ws, bst, seb=seb, zpre=zp)
@@ -691,7 +698,7 @@ class Engine:
         hip.conv_fwd([x], wpe, None, B=B, Hin=H, Win=W, Hout=H, Wout=W, Cout=E, bias=ec.bias, epilogue=hip.EP_BN_BWD1,
                      act=hip.ACT_HSWISH, p=(S["mean1"], S["rstd1"], ebn.weight, ebn.bias), aux=dx1, stats=st,
                      stats_mode=hip.STATS_EP, stats_rep=STATS_REP)
-        dz = _A(x, B, H, W, E) if split else dpre  # (reuse, unless the side stream still reads dpre)
+        dz = _R(x, B, H, W, E) if split else dpre  # (reuse, unless the side stream still reads dpre)
         if self.fuse_bn:   # c1, c2, c3 and the gamma / beta gradients are formed inside pass 2 (lmn_bn_fin_t)
             fin = dict(mode=hip.FIN_BN_BWD, sums=st, nrep=STATS_REP, count=N, batch_stats=self.training, Ain=S["A1"],
                        dgamma=G[ebn.weight], dbeta=G[ebn.bias])

@@ -19,12 +19,12 @@ ACT_NONE, ACT_HSWISH, ACT_GELU = 0, 1, 2
 STATS_NONE, STATS_SUM_SQ, STATS_EP = 0, 1, 2
 F32, BF16 = 0, 1            # matrix-core operand type of the dense contractions (LMN_F32 / LMN_BF16)
 _MMA = [F32]                # ... of the pass in flight (engine.begin_pass)
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 
 class SrcT(C.Structure):
     _fields_ = [("ptr", C.c_void_p), ("scale", C.c_void_p), ("C", C.c_int32), ("cstride", C.c_int32),
-                ("flags", C.c_int32), ("drop_seed", C.c_uint32), ("drop_p", C.c_float), ("_pad", C.c_int32)]
+                ("flags", C.c_int32), ("drop_seed", C.c_uint32), ("drop_p", C.c_float), ("rp_w", C.c_int32)]
 
 
 class BnFin(C.Structure):
@@ -46,8 +46,8 @@ class ConvArgs(C.Structure):
                 ("aux_cstride", C.c_int32), ("res_cstride", C.c_int32), ("out_cstride", C.c_int32),
                 ("epilogue", C.c_int32), ("act", C.c_int32), ("stats_mode", C.c_int32),
                 ("drop_p", C.c_float), ("drop_seed", C.c_uint32), ("seed_ctr", C.c_void_p), ("bias2", C.c_void_p),
-                ("stats_rep", C.c_int32), ("mma_dtype", C.c_int32), ("act_dtype", C.c_int32), ("_pad1", C.c_int32),
-                ("p5", C.c_void_p), ("p6", C.c_void_p), ("fin", BnFin), ("stats_snap", C.c_int32), ("_pad2", C.c_int32)]
+                ("stats_rep", C.c_int32), ("mma_dtype", C.c_int32), ("act_dtype", C.c_int32), ("out_rp_w", C.c_int32),
+                ("p5", C.c_void_p), ("p6", C.c_void_p), ("fin", BnFin), ("stats_snap", C.c_int32), ("aux_rp_w", C.c_int32)]
 
 
 class WgradArgs(C.Structure):
@@ -57,7 +57,7 @@ class WgradArgs(C.Structure):
                 ("dy_seed", C.c_uint32), ("dy_p", C.c_float), ("dW", C.c_void_p), ("db", C.c_void_p),
                 ("workspace", C.c_void_p), ("workspace_floats", C.c_int64), ("seed_ctr", C.c_void_p),
                 ("dW_src", C.c_void_p * 3), ("db2", C.c_void_p), ("mma_dtype", C.c_int32), ("act_dtype", C.c_int32),
-                ("defer_reduce", C.c_int32), ("_pad", C.c_int32)]
+                ("defer_reduce", C.c_int32), ("dy_rp_w", C.c_int32)]
 
 
 class DwPre(C.Structure):
@@ -237,14 +237,44 @@ def _f(v):
     return C.c_float(float(v))
 
 
+def rp4(t):
+    """Mark ``t`` (shape [B, H, W, C], contiguous) as ROW-PLANAR: its memory holds element (b, y, x, c) at
+    ((b*H + y) * (C/4) + (c >> 2)) * 4*W + 4*x + (c & 3) (include/lmnet_hip.h, Conventions) -- the layout of the E-wide tensors
+    inside a ReparamConv block.  The shape stays [B, H, W, C] (it names the sizes); the conv family picks the layout up from the
+    mark (lmn_src_t.rp_w / out_rp_w / aux_rp_w / dy_rp_w), the depthwise family takes nothing else."""
+    t._lmn_rp = True
+    return t
+
+
+def is_rp4(t):
+    return getattr(t, "_lmn_rp", False)
+
+
+def nhwc_to_rp4(t):
+    """torch-side layout conversion (tests, debugging): NHWC values -> a row-planar tensor of the same shape."""
+    B, H, W, Cn = t.shape
+    return rp4(t.reshape(B, H, W, Cn // 4, 4).permute(0, 1, 3, 2, 4).contiguous().reshape(B, H, W, Cn))
+
+
+def rp4_to_nhwc(t):
+    """torch-side layout conversion (tests, debugging): the NHWC values of a row-planar tensor."""
+    B, H, W, Cn = t.shape
+    return t.reshape(B, H, Cn // 4, W, 4).permute(0, 1, 3, 2, 4).contiguous().reshape(B, H, W, Cn)
+
+
 class V:
-    """A channel slice [off, off+C) of an NHWC tensor ``t`` of shape [..., Ctot] (contiguous)."""
-    __slots__ = ("t", "off", "C")
+    """A channel slice [off, off+C) of an NHWC tensor ``t`` of shape [..., Ctot] (contiguous); rp: image width W when the
+    tensor is row-planar (whole tensors only), else 0."""
+    __slots__ = ("t", "off", "C", "rp")
 
     def __init__(self, t, off=0, Cn=None):
         assert t.is_contiguous()
         self.t, self.off = t, off
         self.C = t.shape[-1] - off if Cn is None else Cn
+        self.rp = 0
+        if getattr(t, "_lmn_rp", False):
+            assert off == 0 and self.C == t.shape[-1] and t.dim() == 4, "row-planar tensors are used whole"
+            self.rp = t.shape[2]
 
     @property
     def ptr(self):
@@ -266,14 +296,14 @@ def _fill_src(dst, s):
     if isinstance(s, dict):
         v = _as_view(s["view"])
         scale = s.get("scale")
-        dst.ptr, dst.C, dst.cstride = v.ptr, v.C, v.cstride
+        dst.ptr, dst.C, dst.cstride, dst.rp_w = v.ptr, v.C, v.cstride, v.rp
         dst.scale = scale.data_ptr() if scale is not None else None
         dst.flags = s.get("flags", 0)
         dst.drop_seed = s.get("drop_seed", 0)
         dst.drop_p = s.get("drop_p", 0.0)
     else:
         v = _as_view(s)
-        dst.ptr, dst.C, dst.cstride = v.ptr, v.C, v.cstride
+        dst.ptr, dst.C, dst.cstride, dst.rp_w = v.ptr, v.C, v.cstride, v.rp
         dst.scale, dst.flags, dst.drop_seed, dst.drop_p = None, 0, 0, 0.0
     return v.C
 
@@ -421,13 +451,14 @@ def conv_fwd(srcs, wpack, out, *, B, Hin, Win, Hout, Wout, Cout, ksize=1, stride
     a.p0, a.p1, a.p2, a.p3, a.p4, a.p5, a.p6 = ps
     if aux is not None:
         v = _as_view(aux)
-        a.aux, a.aux_cstride = v.ptr, v.cstride
+        a.aux, a.aux_cstride, a.aux_rp_w = v.ptr, v.cstride, v.rp
     if residual is not None:
         v = _as_view(residual)
+        assert not v.rp, "conv_fwd: a row-planar residual is not supported"
         a.residual, a.res_cstride = v.ptr, v.cstride
     if out is not None:
         v = _as_view(out)
-        a.out, a.out_cstride = v.ptr, v.cstride
+        a.out, a.out_cstride, a.out_rp_w = v.ptr, v.cstride, v.rp
     a.stats = stats.data_ptr() if stats is not None else None
     a.stats_rep = stats_rep
     a.stats_snap = int(bool(stats_snap))
@@ -452,7 +483,7 @@ def conv_wgrad(srcs, dy, dW, db, *, B, Hin, Win, Hout, Wout, Cout, ksize=1, stri
     for i, s in enumerate(srcs):
         _fill_src(a.src[i], s)
     v = _as_view(dy)
-    a.dy, a.dy_cstride = v.ptr, v.cstride
+    a.dy, a.dy_cstride, a.dy_rp_w = v.ptr, v.cstride, v.rp
     a.dy_flags, a.dy_seed, a.dy_p = dy_flags, dy_seed, dy_p
     a.dW = dW.data_ptr() if dW is not None else None
     a.db = db.data_ptr() if db is not None else None
@@ -838,7 +869,9 @@ def reparam_wfin(R, M, m, coef, hstats, w_expand, b_expand, count, dW, db):
 def affine2(u, v, coef, y):
     """y = coef[0] * u + coef[1] * v + coef[2] per channel (activation tensors of shape [..., C])."""
     Cn = u.shape[-1]
-    _check(load().lmn_affine2(_pa(u), _pa(v), _p(coef), _pa(y), _i64(u.numel() // Cn), Cn, _dt(u, v, y), _stream()), "affine2")
+    rp = is_rp4(u)
+    assert rp == is_rp4(v) == is_rp4(y), "affine2: operands of one layout"
+    _check(load().lmn_affine2(_pa(u), _pa(v), _p(coef), _pa(y), _i64(u.numel() // Cn), Cn, u.shape[2] if rp else 0, _dt(u, v, y), _stream()), "affine2")
 
 
 def fill(t, v):

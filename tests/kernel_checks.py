@@ -47,6 +47,14 @@ def nchw(t):  # NHWC device -> NCHW fp64 cpu
     return t.detach().double().cpu().permute(0, 3, 1, 2)
 
 
+def nhwcE(t):  # NCHW fp64 cpu -> ROW-PLANAR fp32 device (the E-wide tensors of a ReparamConv block, hip.rp4)
+    return hip.nhwc_to_rp4(nhwc(t))
+
+
+def nchwE(t):  # row-planar device -> NCHW fp64 cpu
+    return nchw(hip.rp4_to_nhwc(t))
+
+
 def gelu(x):
     return 0.5 * x * (1 + torch.erf(x / math.sqrt(2)))
 
@@ -273,7 +281,7 @@ def check_dw():
         pre_ref, ys = _dw_ref(x1r, wsr, gr, br, True)
         tag = " E=%d %dx%d" % (E, H, W)
         # --- stats
-        x1d = nhwc(x1)
+        x1d = nhwcE(x1)
         wd = [dev(w) for w in ws]
         stats = torch.zeros(4, 2, E, device=DEV)
         hip.dw_stats(x1d, *wd, stats)
@@ -290,7 +298,7 @@ def check_dw():
         pre = torch.full((B, H, W, E), float("nan"), device=DEV)
         gsum = torch.zeros(B, E, device=DEV)
         hip.dw_fwd(x1d, pre, gsum, keff, beff)
-        rows.append(("dw_fwd pre" + tag, rel(nchw(pre), pre_ref), TOL))
+        rows.append(("dw_fwd pre" + tag, rel(nchwE(pre), pre_ref), TOL))
         rows.append(("dw_fwd gsum" + tag, rel(gsum, gelu(pre_ref).sum((2, 3)).detach()), 2e-4))
         # --- squeeze-excite gate formed inside the pass (arrival counter per image) == lmn_se_fwd on the finished sums
         Rr = max(E // 4, 1)
@@ -315,8 +323,8 @@ def check_dw():
         pre_ref.backward(dpre_ref)
         dpre = torch.full((B, H, W, E), float("nan"), device=DEV)
         bstats = torch.zeros(5, E, device=DEV)
-        hip.dw_bwd_stats(x1d, nhwc(pre_ref.detach()), nhwc(u), dev(s), dev(dm), dpre, *wd, bstats)
-        rows.append(("dw_bwd_stats dpre" + tag, rel(nchw(dpre), dpre_ref), TOL))
+        hip.dw_bwd_stats(x1d, nhwcE(pre_ref.detach()), nhwcE(u), dev(s), dev(dm), dpre, *wd, bstats)
+        rows.append(("dw_bwd_stats dpre" + tag, rel(nchwE(dpre), dpre_ref), TOL))
         bref = torch.stack([dpre_ref.sum((0, 2, 3))] + [(dpre_ref * y.detach()).sum((0, 2, 3)) for y in ys])
         rows.append(("dw_bwd_stats sums" + tag, rel(bstats, bref), 2e-4))
         # --- squeeze-excite backward formed inside the pass == lmn_se_bwd_dm feeding the plain pass
@@ -324,9 +332,9 @@ def check_dw():
         dm_sep, dvec_sep = torch.empty(B, E, device=DEV), torch.empty(B, E + Rr, device=DEV)
         hip.se_bwd_dm(ds_t, s_sep, 1.0 / (H * W), fw1, fw2, h_sep, dm_sep, dvec_sep)
         dpre_s, bst_s = torch.full((B, H, W, E), float("nan"), device=DEV), torch.zeros(5, E, device=DEV)
-        hip.dw_bwd_stats(x1d, nhwc(pre_ref.detach()), nhwc(u), s_sep, dm_sep, dpre_s, *wd, bst_s)
+        hip.dw_bwd_stats(x1d, nhwcE(pre_ref.detach()), nhwcE(u), s_sep, dm_sep, dpre_s, *wd, bst_s)
         dpre_f, bst_f, dvec_f = torch.full((B, H, W, E), float("nan"), device=DEV), torch.zeros(5, E, device=DEV), torch.full((B, E + Rr), float("nan"), device=DEV)
-        hip.dw_bwd_stats(x1d, nhwc(pre_ref.detach()), nhwc(u), s_sep, None, dpre_f, *wd, bst_f,
+        hip.dw_bwd_stats(x1d, nhwcE(pre_ref.detach()), nhwcE(u), s_sep, None, dpre_f, *wd, bst_f,
                          seb=dict(ds=ds_t, fc1w=fw1, fc2w=fw2, hidden=h_sep, dvec=dvec_f, inv_hw=1.0 / (H * W)))
         rows.append(("dw_bwd_stats + fused SE backward" + tag, max(rel(dpre_f, dpre_s), rel(bst_f, bst_s), rel(dvec_f, dvec_sep)), 2e-5))
         # coefficients from the exact fp64 sums: f_b = A_b dpre + C_b y_b + D_b ; dgamma_b, dbeta_b
@@ -339,8 +347,8 @@ def check_dw():
             rows.append(("dw_bwd_coef dbeta[%d]" % i + tag, rel(dbs[i], br[i].grad), 2e-4))
         dx1 = torch.full((B, H, W, E), float("nan"), device=DEV)
         dws = [torch.zeros_like(dev(w)) for w in ws]
-        hip.dw_bwd(x1d, nhwc(dpre_ref), dx1, *wd, cA, cC, cD, *dws)
-        rows.append(("dw_bwd dx1" + tag, rel(nchw(dx1), x1r.grad), TOL))
+        hip.dw_bwd(x1d, nhwcE(dpre_ref), dx1, *wd, cA, cC, cD, *dws)
+        rows.append(("dw_bwd dx1" + tag, rel(nchwE(dx1), x1r.grad), TOL))
         for nm, got, ref in zip(("dW5", "dW3", "dWv", "dWh"), dws, wsr):
             rows.append(("dw_bwd " + nm + tag, rel(got, ref.grad), 2e-4))
         # --- the one-launch forms (BatchNorm bookkeeping inside the depthwise passes): same results as the launch pairs
@@ -361,7 +369,7 @@ def check_dw():
         pre_a = torch.full((B, H, W, E), float("nan"), device=DEV); gs_a = torch.zeros(B, E, device=DEV)
         hip.dw_fwd_bn(x1d, pre_a, gs_a, sref_d, N, bn_a, wd, m_a, r_a, A_a)
         rows.append(("dw_fwd_bn pre vs finalize_merge + fwd" + tag, rel(pre_a, pre_b), 1e-6))
-        rows.append(("dw_fwd_bn pre vs reference" + tag, rel(nchw(pre_a), pre_ref), TOL))
+        rows.append(("dw_fwd_bn pre vs reference" + tag, rel(nchwE(pre_a), pre_ref), TOL))
         rows.append(("dw_fwd_bn gsum" + tag, rel(gs_a, gs_b), 1e-5))
         for nm, ta, tb in (("mean", m_a, m_b), ("rstd", r_a, r_b), ("A", A_a, A_b)):
             rows.append(("dw_fwd_bn %s" % nm + tag, rel(ta, tb), 1e-6))
@@ -372,7 +380,7 @@ def check_dw():
         dws2 = [torch.zeros_like(dev(w)) for w in ws]
         dgs2 = [torch.zeros(E, device=DEV) for _ in range(4)]
         dbs2 = [torch.zeros(E, device=DEV) for _ in range(4)]
-        hip.dw_bwd_bn(x1d, nhwc(dpre_ref), dx1b, *wd, dev(bref), dev(torch.stack(mean)), dev(torch.stack(rstd)), dev(A), N, True,
+        hip.dw_bwd_bn(x1d, nhwcE(dpre_ref), dx1b, *wd, dev(bref), dev(torch.stack(mean)), dev(torch.stack(rstd)), dev(A), N, True,
                       dgs2, dbs2, *dws2)
         rows.append(("dw_bwd_bn dx1 vs coef + bwd" + tag, rel(dx1b, dx1), 1e-6))
         for i in range(4):
@@ -406,7 +414,7 @@ def check_zpath():
         dx1 = R(B, E, H, W, seed=207)
         dy = R(B, Cout, H, W, seed=208)
         ((x1 * dx1).sum() + (F.conv2d(xr, wsc.view(Cout, Cin, 1, 1)) * dy).sum()).backward()
-        zd, x1d = nhwc(z.detach()), nhwc(x1.detach())
+        zd, x1d = nhwcE(z.detach()), nhwcE(x1.detach())
         A1d, sh1d = dev(A1.detach()), dev(sh1.detach())
         wd = [dev(w) for w in ws]
         zp = dict(A=A1d, shift=sh1d)
@@ -440,7 +448,7 @@ def check_zpath():
         hip.dw_fwd(x1d, pa, ga_, keff, beff)
         hip.dw_fwd(zd, pb, gb_, keff, beff, zpre=zp)
         rows.append(("dw_fwd z-path" + tag, max(rel(pb, pa), rel(gb_, ga_)), 2e-5))
-        u, sg, dm = nhwc(R(B, E, H, W, seed=214)), dev(R(B, E, seed=215).abs()), dev(R(B, E, seed=216) * 0.01)
+        u, sg, dm = nhwcE(R(B, E, H, W, seed=214)), dev(R(B, E, seed=215).abs()), dev(R(B, E, seed=216) * 0.01)
         da_, db_ = torch.full((B, H, W, E), float("nan"), device=DEV), torch.full((B, H, W, E), float("nan"), device=DEV)
         ba_, bb_ = torch.zeros(5, E, device=DEV), torch.zeros(5, E, device=DEV)
         hip.dw_bwd_stats(x1d, pa, u, sg, dm, da_, *wd, ba_)
@@ -459,10 +467,10 @@ def check_zpath():
         hip.dw_bwd_bn(zd, da_, dhz, *wd, bst, bm, br_, bA, N, True, dgs2, dbs2, *dws2, zpre=zp, hstats=hst)
         hd = nhwc(h.detach()).double().cpu()
         dhs = torch.where(hd < -3, torch.zeros_like(hd), torch.where(hd <= 3, hd / 3 + 0.5, torch.ones_like(hd)))
-        dh_ref = dxo.double().cpu() * dhs
-        rows.append(("dw_bwd_bn z-path dh" + tag, rel(dhz, dh_ref), 2e-5))
+        dh_ref = hip.rp4_to_nhwc(dxo).double().cpu() * dhs
+        rows.append(("dw_bwd_bn z-path dh" + tag, rel(hip.rp4_to_nhwc(dhz), dh_ref), 2e-5))
         rows.append(("dw_bwd_bn z-path sums (dh, dh z)" + tag,
-                     rel(hst, torch.stack([dh_ref.sum((0, 1, 2)), (dh_ref * zd.double().cpu()).sum((0, 1, 2))])), 2e-4))
+                     rel(hst, torch.stack([dh_ref.sum((0, 1, 2)), (dh_ref * nhwc(z.detach()).double().cpu()).sum((0, 1, 2))])), 2e-4))
         rows.append(("dw_bwd_bn z-path weight gradients" + tag, max(rel(a_, b_) for a_, b_ in zip(dws2 + dgs2, dws + dgs)), 2e-5))
         # ---- fold: dh := the reference's gradient w.r.t. the BatchNorm output, sums from fp64
         dh64 = (dx1 * torch.where(h.detach() < -3, torch.zeros_like(h), torch.where(h.detach() <= 3, h.detach() / 3 + 0.5, torch.ones_like(h))).detach())
@@ -475,15 +483,15 @@ def check_zpath():
         rows.append(("reparam_fold dgamma / dbeta" + tag, max(rel(dg, gar.grad), rel(dbt, btr.grad)), 2e-4))
         xin = x if rows_c == Cin else torch.cat([x, torch.zeros(B, rows_c - Cin, H, W, dtype=x.dtype)], 1)
         dxo3 = torch.full((B, H, W, rows_c), float("nan"), device=DEV)
-        hip.conv_fwd([nhwc(dh64), nhwc(xin), nhwc(dy)], wp3, dxo3, B=B, Hin=H, Win=W, Hout=H, Wout=W, Cout=rows_c, bias=kb)
+        hip.conv_fwd([nhwcE(dh64), nhwc(xin), nhwc(dy)], wp3, dxo3, B=B, Hin=H, Win=W, Hout=H, Wout=W, Cout=rows_c, bias=kb)
         rows.append(("reparam_fold + three-source conv: dx" + tag, rel(nchw(dxo3)[:, :Cin], xr.grad), TOL))
-        dzo = torch.full((B, H, W, E), float("nan"), device=DEV)
-        hip.affine2(nhwc(dh64), zd, coef, dzo)
+        dzo = hip.rp4(torch.full((B, H, W, E), float("nan"), device=DEV))
+        hip.affine2(nhwcE(dh64), zd, coef, dzo)
         # dz of the reference: BatchNorm backward in closed form (fp64)
         T = ((dh64 * ((z.detach() - mu.detach().view(1, E, 1, 1)) * rstd.detach().view(1, E, 1, 1))).sum((0, 2, 3)))
         dz64 = A1.detach().view(1, E, 1, 1) * (dh64 - hst64[0].view(1, E, 1, 1) / N
                                               - (z.detach() - mu.detach().view(1, E, 1, 1)) * rstd.detach().view(1, E, 1, 1) * T.view(1, E, 1, 1) / N)
-        rows.append(("affine2 dz" + tag, rel(nchw(dzo), dz64), TOL))
+        rows.append(("affine2 dz" + tag, rel(nchwE(dzo), dz64), TOL))
         # weight / bias gradient without dz: raw gradient R = sum dh x^T and the moments of x (lmn_reparam_wfin)
         xin64 = xin.double()
         Rr = torch.einsum("behw,bchw->ec", dh64, xin64)
@@ -494,6 +502,67 @@ def check_zpath():
         rows.append(("reparam_wfin db_e (exact 0 under batch statistics)" + tag, float(dbf.abs().max()) / float(Rr.abs().max()), 1e-5))
         rows.append(("dz -> expand weight gradient (reference)" + tag,
                      rel(torch.einsum("behw,bchw->ec", dz64, x), wer.grad), 1e-9))
+    return rows
+
+
+def check_conv_rp():
+    """Row-planar (RP4) operands of the 1x1 conv family: every role a ReparamConv block uses -- out (expand conv), source with
+    on-load GELU x gate (pointwise conv), out + aux (SE-gradient epilogue), source / dy of the weight gradients, first source of the
+    three-source data gradient -- against the SAME call on NHWC tensors holding the same values (equal up to the order of the
+    atomics), at map sizes from 4x4 to 20x52, both conv kernels (Cout <= 80 / > 80) and both storage types."""
+    rows = []
+    to_rp, to_nhwc = hip.nhwc_to_rp4, hip.rp4_to_nhwc
+    for (B, H, W, Cin, E, Cout, dt) in [(2, 20, 52, 12, 24, 12, torch.float32), (2, 4, 4, 96, 192, 96, torch.float32), (3, 9, 13, 24, 48, 24, torch.float32),
+                                        (1, 12, 16, 48, 96, 48, torch.float32), (2, 8, 12, 12, 24, 12, torch.bfloat16)]:
+        tag = " Cin=%d E=%d %dx%d %s" % (Cin, E, H, W, "bf16" if dt == torch.bfloat16 else "fp32")
+        tol = 1e-6 if dt == torch.float32 else 2e-2
+        prev = hip._MMA[0]
+        hip._MMA[0] = hip.BF16 if dt == torch.bfloat16 else hip.F32
+        try:
+            cast = lambda t: t.to(dt).contiguous()
+            x, pre, dy = cast(nhwc(R(B, Cin, H, W, seed=301))), cast(nhwc(R(B, E, H, W, seed=302))), cast(nhwc(R(B, Cout, H, W, seed=303)))
+            dh = cast(nhwc(R(B, E, H, W, seed=304)))
+            we, be = dev(R(E, Cin, seed=305, scale=0.3)), dev(R(E, seed=306))
+            wpw, wsc = dev(R(Cout, E, seed=307, scale=0.2)), dev(R(Cout, Cin, seed=308, scale=0.3))
+            gate = dev(R(B, E, seed=309).abs())
+            pre_r, dh_r = to_rp(pre), to_rp(dh)
+            mk = lambda *sh: torch.full(sh, float("nan"), device=DEV, dtype=dt)
+            # expand conv: out row-planar (+ batch sums)
+            wpe = hip.conv_pack(we, 1, [Cin])
+            za, zb = mk(B, H, W, E), hip.rp4(mk(B, H, W, E))
+            sa, sb = torch.zeros(2, E, device=DEV), torch.zeros(2, E, device=DEV)
+            kw = dict(B=B, Hin=H, Win=W, Hout=H, Wout=W)
+            hip.conv_fwd([x], wpe, za, Cout=E, bias=be, stats=sa, stats_mode=hip.STATS_SUM_SQ, **kw)
+            hip.conv_fwd([x], wpe, zb, Cout=E, bias=be, stats=sb, stats_mode=hip.STATS_SUM_SQ, **kw)
+            rows.append(("conv out row-planar" + tag, max(rel(to_nhwc(zb), za), rel(sb, sa) * 1e-2), tol))
+            # pointwise + shortcut: first source row-planar with GELU x gate
+            n0, n1 = hip.conv_pack_size(1, Cout, [E]), hip.conv_pack_size(1, Cout, [Cin])
+            h2 = 2 if dt == torch.bfloat16 else 1
+            wp2 = torch.empty(n0 + n1, device=DEV)
+            hip.conv_pack(wpw, 1, [E], out=wp2[:n0 // h2])
+            hip.conv_pack(wsc, 1, [Cin], out=wp2[n0 // h2:(n0 + n1) // h2])
+            ya, yb = mk(B, H, W, Cout), mk(B, H, W, Cout)
+            hip.conv_fwd([dict(view=pre, scale=gate, flags=hip.SRC_GELU), x], wp2, ya, Cout=Cout, **kw)
+            hip.conv_fwd([dict(view=pre_r, scale=gate, flags=hip.SRC_GELU), x], wp2, yb, Cout=Cout, **kw)
+            rows.append(("conv source row-planar (GELU x gate)" + tag, rel(yb, ya), tol))
+            # data gradient of the pointwise conv with the SE-gradient epilogue: out and aux row-planar
+            wpt = hip.conv_pack_t(wpw, 1, 0, E, cred=Cout)
+            ua, ub = mk(B, H, W, E), hip.rp4(mk(B, H, W, E))
+            da, db_ = torch.zeros(B, E, device=DEV), torch.zeros(B, E, device=DEV)
+            hip.conv_fwd([dy], wpt, ua, Cout=E, transposed=1, epilogue=hip.EP_SE_BWD, aux=pre, stats=da, stats_mode=hip.STATS_EP, **kw)
+            hip.conv_fwd([dy], wpt, ub, Cout=E, transposed=1, epilogue=hip.EP_SE_BWD, aux=pre_r, stats=db_, stats_mode=hip.STATS_EP, **kw)
+            rows.append(("conv out + aux row-planar (SE gradient)" + tag, max(rel(to_nhwc(ub), ua), rel(db_, da) * (1e-2 if dt == torch.float32 else 1.0)), tol))
+            # weight gradients: row-planar source (GELU x gate) / row-planar dy
+            for nm, srcs_a, srcs_b, dya, dyb, co, ci in [
+                    ("wgrad source row-planar", [dict(view=pre, scale=gate, flags=hip.SRC_GELU), x], [dict(view=pre_r, scale=gate, flags=hip.SRC_GELU), x], dy, dy, Cout, E + Cin),
+                    ("wgrad dy row-planar", [x], [x], dh, dh_r, E, Cin)]:
+                ga_, gb_ = torch.zeros(co, ci, device=DEV), torch.zeros(co, ci, device=DEV)
+                ba_, bb_ = torch.zeros(co, device=DEV), torch.zeros(co, device=DEV)
+                hip.conv_wgrad(srcs_a, dya, ga_, ba_, Cout=co, **kw)
+                hip.conv_wgrad(srcs_b, dyb, gb_, bb_, Cout=co, **kw)
+                rows.append((nm + tag, max(rel(gb_, ga_), rel(bb_, ba_)), 2e-5 if dt == torch.float32 else tol))
+        finally:
+            hip._MMA[0] = prev
     return rows
 
 
