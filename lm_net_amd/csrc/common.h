@@ -115,22 +115,26 @@ __device__ __forceinline__ void st1(lmn_bf16* p, float v) { *p = (lmn_bf16)v; }
 
 
 // ---------------------------------------------------------------- RP4: row-planar layout of the E-wide ReparamConv tensors
-// element (global pixel gp = (b*H + y)*W + x, channel c) of a tensor with C channels lives at
-//   (gp / W) * (C * W) + (c >> 2) * 4 * W + 4 * (gp % W) + (c & 3)
-// (one plane of W pixels x 4 channels per image row and channel quad: include/lmnet_hip.h).  w == 0: plain NHWC.
-struct LmnRp { int32_t w; uint32_t magic; int32_t cw; int32_t _pad; };
-static inline LmnRp lmn_rp_make(int w, int C) {
-  LmnRp r;
-  r.w = w; r.cw = C * w; r._pad = 0;
-  r.magic = w > 1 ? (uint32_t)(0x100000000ULL / (uint64_t)w) : (w == 1 ? 0xFFFFFFFFu : 0u);   // floor(2^32 / W): quotient estimate short by at most 1
-  return r;
+// element (global pixel gp = (b*H + y)*W + x, channel c) of a row-planar tensor with C channels lives at
+//   (gp / W) * (C * W) + (c >> 2) * 4 * W + 4 * (gp % W) + (c & 3)  =  gp * 4 + (c >> 2) * 4W + (c & 3) + (gp / W) * (C - 4) * W
+// (one plane of W pixels x 4 channels per image row and channel quad: include/lmnet_hip.h), an NHWC one at gp * cstride + c.
+// Both are ONE linear form, so the kernels carry no second code path and no layout struct per operand:
+//   offset = gp * cs + (c >> 2) * qs + (c & 3) + row * rf      NHWC: cs = cstride, qs = 4, rf = 0;  RP4: cs = 4, qs = 4W, rf = (C - 4) W
+// with row = gp / W needed only where rf != 0 (a wave-uniform test).
+struct LmnLay { int32_t cs, qs, rf; };
+static inline LmnLay lmn_lay_make(int rp_w, int C, int cstride) {
+  LmnLay l;
+  if (rp_w > 0) { l.cs = 4; l.qs = 4 * rp_w; l.rf = (C - 4) * rp_w; }
+  else { l.cs = cstride; l.qs = 4; l.rf = 0; }
+  return l;
 }
+static inline uint32_t lmn_div_magic(int w) { return w > 1 ? (uint32_t)(0x100000000ULL / (uint64_t)w) : (w == 1 ? 0xFFFFFFFFu : 0u); }
 #ifdef __HIPCC__
-__device__ __forceinline__ uint32_t lmn_rp_off(uint32_t gp, int ch, const LmnRp& R) {
-  uint32_t row = __umulhi(gp, R.magic);
-  uint32_t x = gp - row * (uint32_t)R.w;
-  if (x >= (uint32_t)R.w) { ++row; x -= (uint32_t)R.w; }
-  return row * (uint32_t)R.cw + (uint32_t)(ch >> 2) * (uint32_t)(4 * R.w) + 4u * x + (uint32_t)(ch & 3);
+// gp / w for any gp < 2^32: floor(2^32 / w) as the multiplier gives a quotient short by at most one
+__device__ __forceinline__ uint32_t lmn_div_row(uint32_t gp, uint32_t w, uint32_t magic) {
+  uint32_t row = __umulhi(gp, magic);
+  if (gp - row * w >= w) ++row;
+  return row;
 }
 #endif
 

@@ -42,7 +42,9 @@ struct ConvParams {
   uint32_t mTW, mXW;
   int strided;
   float* det_stats;       // deterministic mode: slot copies of the statistics destination (one slot per block / per wave), else NULL
-  LmnRp rp_src[3], rp_out, rp_aux;   // row-planar operands (1x1 convs only; w == 0: NHWC)
+  LmnLay lay_src[3], lay_out, lay_aux;   // address forms of the operands (common.h: NHWC or row-planar)
+  int32_t rpw;                           // image width of the row-planar operands of the call (0: none)
+  uint32_t rp_magic;                     // floor(2^32 / rpw)
 };
 
 // precision mode of a conv-family kernel instance: 0 = fp32 storage + fp32 MFMA, 1 = fp32 storage + bf16 MFMA operands,
@@ -180,8 +182,13 @@ __device__ unsigned long long g_ct_timing[4096 * 8];
 template <int TAPS, int NCT, int EPI, bool S2T = false, int PM = 0, bool WL = false>
 __global__ __launch_bounds__(256) void conv_tile_kernel(const ConvParams P) {
   static_assert(!WL || (TAPS == 9 && !S2T), "LDS-staged weights: 3x3 stride-1 windows");
-  constexpr bool BF = PM >= 1;
-  typedef typename ActT<PM>::type TA;   // activation storage type
+  // PM bit 2 (RP): some operand of this 1x1 call is ROW-PLANAR (common.h LmnLay) -- a separate instantiation, so that the NHWC
+  // instances keep their registers (the layout arithmetic in every instance cost the SE-gradient conv its fifth wave per SIMD)
+  constexpr int PMB = PM & 3;
+  constexpr bool RP = (PM & 4) != 0;
+  static_assert(!RP || TAPS == 1, "row-planar operands: 1x1 convs");
+  constexpr bool BF = PMB >= 1;
+  typedef typename ActT<PMB>::type TA;   // activation storage type
   // BF: operands rounded to bf16 when they are staged / packed, v_mfma_f32_16x16x16_bf16 (8x the fp32 MFMA rate), the LDS
   // window holds 4-bf16 fragments (pixel stride P.CS dwords = 8 per K16 block + 4: conflict-free ds_read_b64)
   typedef typename Frag<BF>::type wfrag;
@@ -321,17 +328,26 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(const ConvParams P) {
     f32x4 axp[AUXP ? 2 : 1][AUXP ? NCT : 1];
     if constexpr (AUXP) {
 #pragma unroll
-      for (int g = 0; g < 2; ++g)
+      for (int g = 0; g < 2; ++g) {
+        uint32_t oa = 0;
+        if constexpr (RP) {   // pixel part of the aux offset (common.h LmnLay)
+          oa = (uint32_t)opix[g] * (uint32_t)P.lay_aux.cs;
+          if (P.lay_aux.rf) oa += lmn_div_row((uint32_t)opix[g], (uint32_t)P.rpw, P.rp_magic) * (uint32_t)P.lay_aux.rf;
+        }
 #pragma unroll
         for (int c = 0; c < NCT; ++c) {
           const int co = (ct0 + c) * 16 + q * 4;
           const int cos = ((ct0 + c < P.NCTT) && co < A.Cout) ? co : 0;
-          axp[g][c] = A.aux ? ld4((const TA*)A.aux + ((TAPS == 1 && P.rp_aux.w) ? lmn_rp_off((uint32_t)opix[g], cos, P.rp_aux) : (uint32_t)opix[g] * A.aux_cstride + cos)) : f32x4{0.f, 0.f, 0.f, 0.f};
+          if constexpr (RP) axp[g][c] = A.aux ? ld4((const TA*)A.aux + (oa + (uint32_t)(cos >> 2) * (uint32_t)P.lay_aux.qs)) : f32x4{0.f, 0.f, 0.f, 0.f};
+          else axp[g][c] = A.aux ? ld4((const TA*)A.aux + (uint32_t)opix[g] * A.aux_cstride + cos) : f32x4{0.f, 0.f, 0.f, 0.f};
         }
+      }
     }
 
     for (int s = 0; s < A.nsrc; ++s) {
       const lmn_src_t& S = A.src[s];
+      const LmnLay LS = P.lay_src[s];   // (used by the row-planar instances only)
+      (void)LS;
       for (int kb0 = 0; kb0 < P.nkb[s]; kb0 += P.CKB) {
         const int nkbc = P.nkb[s] - kb0 < P.CKB ? P.nkb[s] - kb0 : P.CKB;
         const int ksh = nkbc - 1, niter = (S2T ? s2_n : TAPS) * nkbc;  // step it = (tap, kk): tap = it >> ksh, kk = it & ksh (nkbc is 1 or 2)
@@ -367,7 +383,13 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(const ConvParams P) {
             const bool ok = i < nitems && ch < S.C && (TAPS == 1 || (unsigned)iy < (unsigned)A.Hin) && (unsigned)ix < (unsigned)A.Win;
             const int gp = ok ? (TAPS == 1 ? b * A.Win + ix : (b * A.Hin + iy) * A.Win + ix) : 0;
             sgp[u] = ok ? gp : -1;
-            sv[u] = ld4((const TA*)S.ptr + ((TAPS == 1 && P.rp_src[s].w) ? lmn_rp_off((uint32_t)gp, ok ? ch : 0, P.rp_src[s]) : (uint32_t)(gp * S.cstride + (ok ? ch : 0))));
+            if constexpr (RP) {
+              uint32_t so_ = (uint32_t)(gp * LS.cs) + (uint32_t)((ok ? ch : 0) >> 2) * (uint32_t)LS.qs;
+              if (LS.rf) so_ += lmn_div_row((uint32_t)gp, (uint32_t)P.rpw, P.rp_magic) * (uint32_t)LS.rf;   // (wave-uniform: row-planar source)
+              sv[u] = ld4((const TA*)S.ptr + so_);
+            } else {
+              sv[u] = ld4((const TA*)S.ptr + (uint32_t)(gp * S.cstride + (ok ? ch : 0)));
+            }
           }
 #pragma unroll
           for (int u = 0; u < SU; ++u) {
@@ -518,6 +540,13 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(const ConvParams P) {
 #pragma unroll
     for (int g = 0; g < 2; ++g) {
       const uint32_t opx = (uint32_t)opix[g];
+      uint32_t oout_g = 0, oaux_g = 0;   // row-planar instances: pixel part of the out / aux offsets (LmnLay)
+      if constexpr (RP) {
+        const uint32_t rowp = lmn_div_row(opx, (uint32_t)P.rpw, P.rp_magic);
+        oout_g = opx * (uint32_t)P.lay_out.cs + rowp * (uint32_t)P.lay_out.rf;
+        oaux_g = opx * (uint32_t)P.lay_aux.cs + rowp * (uint32_t)P.lay_aux.rf;
+      }
+      (void)oout_g; (void)oaux_g;
 #pragma unroll
       for (int c = 0; c < NCT; ++c) {
         const int co = (ct0 + c) * 16 + q * 4;
@@ -542,7 +571,7 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(const ConvParams P) {
         if (EPI) {
           f32x4 ax = f32x4{0.f, 0.f, 0.f, 0.f};
           if constexpr (AUXP) ax = axp[g][c];
-          else if (A.aux) ax = ld4((const TA*)A.aux + ((TAPS == 1 && P.rp_aux.w) ? lmn_rp_off(opx, cos, P.rp_aux) : opx * A.aux_cstride + cos));
+          else if (A.aux) { if constexpr (RP) ax = ld4((const TA*)A.aux + (oaux_g + (uint32_t)(cos >> 2) * (uint32_t)P.lay_aux.qs)); else ax = ld4((const TA*)A.aux + opx * A.aux_cstride + cos); }
           switch (ep_kind) {
             case LMN_EP_DGELU: {
 #pragma unroll
@@ -583,7 +612,7 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(const ConvParams P) {
           for (int r = 0; r < 4; ++r) o[r] *= lmn_drop_scale(A.drop_seed + soff, idx + r, A.drop_p, P.inv_keep_ep);
         }
         if (A.residual) o += ld4((const TA*)A.residual + opx * A.res_cstride + cos);
-        if (A.out && live) st4((TA*)A.out + ((TAPS == 1 && P.rp_out.w) ? lmn_rp_off(opx, cos, P.rp_out) : opx * A.out_cstride + cos), o);
+        if (A.out && live) { if constexpr (RP) st4((TA*)A.out + (oout_g + (uint32_t)(cos >> 2) * (uint32_t)P.lay_out.qs), o); else st4((TA*)A.out + opx * A.out_cstride + cos, o); }
         __builtin_amdgcn_sched_barrier(0);
       }
     }
@@ -651,8 +680,11 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(const ConvParams P) {
 #define LMN_SLOT (wv + 4 * c)
 template <int TAPS, int NCW, int EPI, int PM = 0>
 __global__ __launch_bounds__(256) void conv_tileM_kernel(const ConvParams P) {
-  constexpr bool BF = PM >= 1;
-  typedef typename ActT<PM>::type TA;
+  constexpr int PMB = PM & 3;
+  constexpr bool RP = (PM & 4) != 0;      // (row-planar operands: see conv_tile_kernel)
+  static_assert(!RP || TAPS == 1, "row-planar operands: 1x1 convs");
+  constexpr bool BF = PMB >= 1;
+  typedef typename ActT<PMB>::type TA;
   typedef typename Frag<BF>::type wfrag;  // (bf16 operand form: see conv_tile_kernel)
   constexpr int WT = BF ? 128 : 256;
   constexpr int KD = BF ? 8 : 16;
@@ -753,6 +785,8 @@ __global__ __launch_bounds__(256) void conv_tileM_kernel(const ConvParams P) {
 
     for (int s = 0; s < A.nsrc; ++s) {
       const lmn_src_t& S = A.src[s];
+      const LmnLay LS = P.lay_src[s];   // (used by the row-planar instances only)
+      (void)LS;
       for (int kb0 = 0; kb0 < P.nkb[s]; kb0 += P.CKB) {
         const int nkbc = P.nkb[s] - kb0 < P.CKB ? P.nkb[s] - kb0 : P.CKB;
         // step it = (tap, kk).  3x3: nkbc is 1 or 2, tap = it >> ksh, kk = it & ksh; 1x1: kk = it, chunks of up to 8 K16 blocks (the
@@ -787,7 +821,13 @@ __global__ __launch_bounds__(256) void conv_tileM_kernel(const ConvParams P) {
             const bool ok = i < nitems && f < nq && ch < S.C && (unsigned)iy < (unsigned)A.Hin && (unsigned)ix < (unsigned)A.Win;
             const int gp = ok ? (b * A.Hin + iy) * A.Win + ix : 0;
             sgp[u] = ok ? gp : -1;
-            sv[u] = ld4((const TA*)S.ptr + ((TAPS == 1 && P.rp_src[s].w) ? lmn_rp_off((uint32_t)gp, ok ? ch : 0, P.rp_src[s]) : (uint32_t)(gp * S.cstride + (ok ? ch : 0))));
+            if constexpr (RP) {
+              uint32_t so_ = (uint32_t)(gp * LS.cs) + (uint32_t)((ok ? ch : 0) >> 2) * (uint32_t)LS.qs;
+              if (LS.rf) so_ += lmn_div_row((uint32_t)gp, (uint32_t)P.rpw, P.rp_magic) * (uint32_t)LS.rf;   // (wave-uniform: row-planar source)
+              sv[u] = ld4((const TA*)S.ptr + so_);
+            } else {
+              sv[u] = ld4((const TA*)S.ptr + (uint32_t)(gp * S.cstride + (ok ? ch : 0)));
+            }
           }
 #pragma unroll
           for (int u = 0; u < SU; ++u) {
@@ -961,6 +1001,13 @@ __global__ __launch_bounds__(256) void conv_tileM_kernel(const ConvParams P) {
 #pragma unroll
     for (int g = 0; g < NGM; ++g) {
       const uint32_t opx = (uint32_t)opix[g];
+      uint32_t oout_g = 0, oaux_g = 0;   // row-planar instances: pixel part of the out / aux offsets (LmnLay)
+      if constexpr (RP) {
+        const uint32_t rowp = lmn_div_row(opx, (uint32_t)P.rpw, P.rp_magic);
+        oout_g = opx * (uint32_t)P.lay_out.cs + rowp * (uint32_t)P.lay_out.rf;
+        oaux_g = opx * (uint32_t)P.lay_aux.cs + rowp * (uint32_t)P.lay_aux.rf;
+      }
+      (void)oout_g; (void)oaux_g;
 #pragma unroll
       for (int c = 0; c < NCW; ++c) {
         const int ctc = ct0 + wv + 4 * c;
@@ -985,7 +1032,7 @@ __global__ __launch_bounds__(256) void conv_tileM_kernel(const ConvParams P) {
         }
         if (EPI) {
           f32x4 ax = f32x4{0.f, 0.f, 0.f, 0.f};
-          if (A.aux) ax = ld4((const TA*)A.aux + ((TAPS == 1 && P.rp_aux.w) ? lmn_rp_off(opx, cos, P.rp_aux) : opx * A.aux_cstride + cos));
+          if (A.aux) { if constexpr (RP) ax = ld4((const TA*)A.aux + (oaux_g + (uint32_t)(cos >> 2) * (uint32_t)P.lay_aux.qs)); else ax = ld4((const TA*)A.aux + opx * A.aux_cstride + cos); }
           switch (ep_kind) {
             case LMN_EP_DGELU: {
 #pragma unroll
@@ -1026,7 +1073,7 @@ __global__ __launch_bounds__(256) void conv_tileM_kernel(const ConvParams P) {
           for (int r = 0; r < 4; ++r) o[r] *= lmn_drop_scale(A.drop_seed + soff, idx + r, A.drop_p, P.inv_keep_ep);
         }
         if (A.residual) o += ld4((const TA*)A.residual + opx * A.res_cstride + cos);
-        if (A.out && live) st4((TA*)A.out + ((TAPS == 1 && P.rp_out.w) ? lmn_rp_off(opx, cos, P.rp_out) : opx * A.out_cstride + cos), o);
+        if (A.out && live) { if constexpr (RP) st4((TA*)A.out + (oout_g + (uint32_t)(cos >> 2) * (uint32_t)P.lay_out.qs), o); else st4((TA*)A.out + opx * A.out_cstride + cos, o); }
         __builtin_amdgcn_sched_barrier(0);
       }
     }
@@ -1271,7 +1318,9 @@ __global__ __launch_bounds__(256) void reparam_wfin_kernel(const float* __restri
 
 // ------------------------------------------------------------------------------------ weight gradient
 struct WgradParams {
-  LmnRp rp_src[3], rp_dy;   // row-planar operands (1x1 kernels only; w == 0: NHWC)
+  LmnLay lay_src[3], lay_dy;   // address forms of the operands (common.h: NHWC or row-planar; 1x1 kernels only)
+  int32_t rpw;                 // image width of the row-planar operands (0: none)
+  uint32_t rp_magic;
   lmn_wgrad_args_t a;
   int ntile_src[3];  // 16-channel tiles per source
   int ntile_off[3];
@@ -1998,8 +2047,10 @@ __global__ __launch_bounds__(256, 3) void wgrad3_kernel(const WgradParams P) {
 // 4q..4q+3 of one K16 step, i.e. step 4h + q, pixel j) into one bf16 fragment: 2 instead of 8 MFMAs per tile and batch.
 template <int NMT, int NNT, int PM = 0>
 __global__ __launch_bounds__(256) void wgrad_1x1_kernel(const WgradParams P) {
-  constexpr bool BF = PM >= 1;
-  typedef typename ActT<PM>::type TA;
+  constexpr int PMB = PM & 3;
+  constexpr bool RP = (PM & 4) != 0;   // some operand is row-planar (LmnLay): its own instantiation, as in conv_tile_kernel
+  constexpr bool BF = PMB >= 1;
+  typedef typename ActT<PMB>::type TA;
   constexpr int U = 8;
   const lmn_wgrad_args_t& A = P.a;
   const uint32_t soff = A.seed_ctr ? *A.seed_ctr : 0u;  // device-side dropout stream offset (graph replays: one bump per step)
@@ -2015,7 +2066,7 @@ __global__ __launch_bounds__(256) void wgrad_1x1_kernel(const WgradParams P) {
   const TA* sptr[NNT];
   const float* sscale[NNT];
   int sC[NNT], scs[NNT], sflags[NNT], sch[NNT];
-  LmnRp srp[NNT];
+  uint32_t scho[NNT], srf[NNT];   // channel part of the offset, row term (LmnLay)
   uint32_t sseed[NNT];
   float sp[NNT], sik[NNT];
   bool any_tf = (A.dy_flags & LMN_SRC_DROP) != 0;
@@ -2028,18 +2079,22 @@ __global__ __launch_bounds__(256) void wgrad_1x1_kernel(const WgradParams P) {
     sptr[t] = (const TA*)A.src[s].ptr;
     sscale[t] = A.src[s].scale;
     sC[t] = A.src[s].C;
-    scs[t] = A.src[s].cstride;
-    srp[t] = P.rp_src[s];
+    scs[t] = RP ? P.lay_src[s].cs : A.src[s].cstride;
+    srf[t] = RP ? (uint32_t)P.lay_src[s].rf : 0u;
     sflags[t] = A.src[s].flags;
     sseed[t] = A.src[s].drop_seed + soff;
     sp[t] = A.src[s].drop_p;
     sik[t] = P.inv_keep_src[s];
     sch[t] = (nt < P.NNTT && ch < A.src[s].C) ? ch : -1;
+    { const int chc = sch[t] >= 0 ? sch[t] : 0; scho[t] = (uint32_t)(chc >> 2) * (uint32_t)P.lay_src[s].qs + (uint32_t)(chc & 3); }
     any_tf = any_tf || sflags[t] != 0 || sscale[t] != nullptr;
   }
   int mco[NMT];  // this lane's cout per tile, or -1
 #pragma unroll
   for (int m = 0; m < NMT; ++m) mco[m] = ((mt0 + m) < P.NMTT && (mt0 + m) * 16 + n < A.Cout) ? (mt0 + m) * 16 + n : -1;
+  uint32_t mcho[NMT];
+#pragma unroll
+  for (int m = 0; m < NMT; ++m) { const int cc = mco[m] >= 0 ? mco[m] : 0; mcho[m] = (uint32_t)(cc >> 2) * (uint32_t)P.lay_dy.qs + (uint32_t)(cc & 3); }
 
   f32x4 acc[NMT][NNT];
   float bsum[NMT];
@@ -2068,10 +2123,18 @@ __global__ __launch_bounds__(256) void wgrad_1x1_kernel(const WgradParams P) {
       const int px = BF ? step0 * 4 + (u >> 2) * 16 + q * 4 + (u & 3) : (step0 + u) * 4 + q;
       const bool ok = (BF ? px < se * 4 : step0 + u < se) && px < NPX;
       const int ps = ok ? px : 0;
+      if constexpr (RP) {
+        const uint32_t rowp = lmn_div_row((uint32_t)ps, (uint32_t)P.rpw, P.rp_magic);   // (row term of the row-planar operands)
 #pragma unroll
-      for (int m = 0; m < NMT; ++m) av[u][m] = ld1((const TA*)A.dy + (P.rp_dy.w ? lmn_rp_off((uint32_t)ps, mco[m] >= 0 ? mco[m] : 0, P.rp_dy) : (uint32_t)(ps * A.dy_cstride + (mco[m] >= 0 ? mco[m] : 0))));
+        for (int m = 0; m < NMT; ++m) av[u][m] = ld1((const TA*)A.dy + ((uint32_t)(ps * P.lay_dy.cs) + mcho[m] + rowp * (uint32_t)P.lay_dy.rf));
 #pragma unroll
-      for (int t = 0; t < NNT; ++t) bv[u][t] = ld1(sptr[t] + (srp[t].w ? lmn_rp_off((uint32_t)ps, sch[t] >= 0 ? sch[t] : 0, srp[t]) : (uint32_t)(ps * scs[t] + (sch[t] >= 0 ? sch[t] : 0))));
+        for (int t = 0; t < NNT; ++t) bv[u][t] = ld1(sptr[t] + ((uint32_t)(ps * scs[t]) + scho[t] + rowp * srf[t]));
+      } else {
+#pragma unroll
+        for (int m = 0; m < NMT; ++m) av[u][m] = ld1((const TA*)A.dy + (uint32_t)(ps * A.dy_cstride + (mco[m] >= 0 ? mco[m] : 0)));
+#pragma unroll
+        for (int t = 0; t < NNT; ++t) bv[u][t] = ld1(sptr[t] + (uint32_t)(ps * scs[t] + (sch[t] >= 0 ? sch[t] : 0)));
+      }
     }
     // ---- on-load transforms (wave-uniform flags) and masking
     int b0 = 0;
@@ -2210,8 +2273,10 @@ __global__ __launch_bounds__(256) void wgrad_1x1_kernel(const WgradParams P) {
 // chunk c is multiplied.
 template <int NMT, int NNT, int PM>
 __global__ __launch_bounds__(256) void wgrad_1x1w_kernel(const WgradParams P) {
-  constexpr bool BF = PM >= 1;
-  typedef typename ActT<PM>::type TA;
+  constexpr int PMB = PM & 3;
+  constexpr bool RP = (PM & 4) != 0;   // some operand is row-planar (LmnLay): its own instantiation, as in conv_tile_kernel
+  constexpr bool BF = PMB >= 1;
+  typedef typename ActT<PMB>::type TA;
   constexpr int NTT = NMT + NNT;              // staged tiles per chunk: dy tiles first, then source tiles
   const lmn_wgrad_args_t& A = P.a;
   const uint32_t soff = A.seed_ctr ? *A.seed_ctr : 0u;
@@ -2231,7 +2296,7 @@ __global__ __launch_bounds__(256) void wgrad_1x1w_kernel(const WgradParams P) {
   const TA* sptr[NNT];
   const float* sscale[NNT];
   int sC[NNT], scs[NNT], sflags[NNT], sch4[NNT];
-  LmnRp srp[NNT];
+  uint32_t scho[NNT], srf[NNT];   // channel part of the offset, row term (LmnLay)
   uint32_t sseed[NNT];
   float sp[NNT], sik[NNT];
 #pragma unroll
@@ -2243,17 +2308,21 @@ __global__ __launch_bounds__(256) void wgrad_1x1w_kernel(const WgradParams P) {
     sptr[t] = (const TA*)A.src[s].ptr;
     sscale[t] = A.src[s].scale;
     sC[t] = A.src[s].C;
-    scs[t] = A.src[s].cstride;
-    srp[t] = P.rp_src[s];
+    scs[t] = RP ? P.lay_src[s].cs : A.src[s].cstride;
+    srf[t] = RP ? (uint32_t)P.lay_src[s].rf : 0u;
     sflags[t] = A.src[s].flags;
     sseed[t] = A.src[s].drop_seed + soff;
     sp[t] = A.src[s].drop_p;
     sik[t] = P.inv_keep_src[s];
     sch4[t] = (nt < P.NNTT && ch < A.src[s].C) ? ch : -1;   // first channel of this lane's quad, or -1
+    scho[t] = (uint32_t)((sch4[t] >= 0 ? sch4[t] : 0) >> 2) * (uint32_t)P.lay_src[s].qs;
   }
   int mco4[NMT];
 #pragma unroll
   for (int m = 0; m < NMT; ++m) mco4[m] = ((mt0 + m) < P.NMTT && (mt0 + m) * 16 + lq * 4 < A.Cout) ? (mt0 + m) * 16 + lq * 4 : -1;
+  uint32_t mcho[NMT];
+#pragma unroll
+  for (int m = 0; m < NMT; ++m) mcho[m] = (uint32_t)((mco4[m] >= 0 ? mco4[m] : 0) >> 2) * (uint32_t)P.lay_dy.qs;
 
   f32x4 acc[NMT][NNT];
   float bsum[NMT];
@@ -2271,10 +2340,18 @@ __global__ __launch_bounds__(256) void wgrad_1x1w_kernel(const WgradParams P) {
   auto chunk_load = [&](int c) {
     const int px = c * 16 + lp;
     const int ps = px < NPX ? px : 0;
+    if constexpr (RP) {
+      const uint32_t rowp = lmn_div_row((uint32_t)ps, (uint32_t)P.rpw, P.rp_magic);   // (row term of the row-planar operands)
 #pragma unroll
-    for (int m = 0; m < NMT; ++m) stg[m] = ld4((const TA*)A.dy + (P.rp_dy.w ? lmn_rp_off((uint32_t)ps, mco4[m] >= 0 ? mco4[m] : 0, P.rp_dy) : (uint32_t)(ps * A.dy_cstride + (mco4[m] >= 0 ? mco4[m] : 0))));
+      for (int m = 0; m < NMT; ++m) stg[m] = ld4((const TA*)A.dy + ((uint32_t)(ps * P.lay_dy.cs) + mcho[m] + rowp * (uint32_t)P.lay_dy.rf));
 #pragma unroll
-    for (int t = 0; t < NNT; ++t) stg[NMT + t] = ld4(sptr[t] + (srp[t].w ? lmn_rp_off((uint32_t)ps, sch4[t] >= 0 ? sch4[t] : 0, srp[t]) : (uint32_t)(ps * scs[t] + (sch4[t] >= 0 ? sch4[t] : 0))));
+      for (int t = 0; t < NNT; ++t) stg[NMT + t] = ld4(sptr[t] + ((uint32_t)(ps * scs[t]) + scho[t] + rowp * srf[t]));
+    } else {
+#pragma unroll
+      for (int m = 0; m < NMT; ++m) stg[m] = ld4((const TA*)A.dy + (uint32_t)(ps * A.dy_cstride + (mco4[m] >= 0 ? mco4[m] : 0)));
+#pragma unroll
+      for (int t = 0; t < NNT; ++t) stg[NMT + t] = ld4(sptr[t] + (uint32_t)(ps * scs[t] + (sch4[t] >= 0 ? sch4[t] : 0)));
+    }
   };
   auto chunk_put = [&](int c) {   // transforms, masking, LDS
     const int px = c * 16 + lp;
@@ -2681,20 +2758,23 @@ int lmn_conv_fwd(const lmn_conv_args_t* args, lmn_stream_t stream) {
     int rw = 0;
     for (int s = 0; s < 3; ++s) {
       const int w = s < A.nsrc ? A.src[s].rp_w : 0;
-      P.rp_src[s] = lmn_rp_make(w, s < A.nsrc ? A.src[s].C : 0);
+      P.lay_src[s] = lmn_lay_make(w, s < A.nsrc ? A.src[s].C : 4, s < A.nsrc ? A.src[s].cstride : 4);
       if (w) {
-        LMN_REQUIRE(A.src[s].cstride == A.src[s].C && (rw == 0 || rw == w), "conv_fwd: row-planar source %d must be a whole tensor (cstride == C) of the call's width", s);
+        LMN_REQUIRE(w > 0 && A.src[s].cstride == A.src[s].C && (rw == 0 || rw == w), "conv_fwd: row-planar source %d must be a whole tensor (cstride == C) of the call's width", s);
         rw = w;
       }
     }
-    P.rp_out = lmn_rp_make(A.out ? A.out_rp_w : 0, A.Cout);
-    P.rp_aux = lmn_rp_make(A.aux ? A.aux_rp_w : 0, A.Cout);
-    if (P.rp_out.w) { LMN_REQUIRE(A.out_cstride == A.Cout && (rw == 0 || rw == P.rp_out.w), "conv_fwd: row-planar out must be a whole tensor of the call's width"); rw = P.rp_out.w; }
-    if (P.rp_aux.w) { LMN_REQUIRE(A.aux_cstride == A.Cout && (rw == 0 || rw == P.rp_aux.w), "conv_fwd: row-planar aux must be a whole tensor of the call's width"); rw = P.rp_aux.w; }
+    const int ow = A.out ? A.out_rp_w : 0, aw = A.aux ? A.aux_rp_w : 0;
+    P.lay_out = lmn_lay_make(ow, A.Cout, A.out_cstride);
+    P.lay_aux = lmn_lay_make(aw, A.Cout, A.aux_cstride);
+    if (ow) { LMN_REQUIRE(ow > 0 && A.out_cstride == A.Cout && (rw == 0 || rw == ow), "conv_fwd: row-planar out must be a whole tensor of the call's width"); rw = ow; }
+    if (aw) { LMN_REQUIRE(aw > 0 && A.aux_cstride == A.Cout && (rw == 0 || rw == aw), "conv_fwd: row-planar aux must be a whole tensor of the call's width"); rw = aw; }
     if (rw) {
-      LMN_REQUIRE(A.ksize == 1 && A.stride == 1 && rw > 0 && ((int64_t)A.Hin * A.Win) % rw == 0 && ((int64_t)A.Hout * A.Wout) % rw == 0,
+      LMN_REQUIRE(A.ksize == 1 && A.stride == 1 && ((int64_t)A.Hin * A.Win) % rw == 0 && ((int64_t)A.Hout * A.Wout) % rw == 0,
                   "conv_fwd: row-planar operands belong to 1x1 stride-1 calls whose image is a whole number of rows of width %d", rw);
     }
+    P.rpw = rw;
+    P.rp_magic = lmn_div_magic(rw);
   }
   {  // kernels index with 32-bit element offsets
     const int64_t lim = (1LL << 31) - 1;
@@ -2917,8 +2997,11 @@ int lmn_conv_fwd(const lmn_conv_args_t* args, lmn_stream_t stream) {
     }                                                                                                    \
   } while (0)
 #define LMN_CMB(TT, NN) do { if (pm == 2) LMN_CM(TT, NN, 2); else if (pm == 1) LMN_CM(TT, NN, 1); else LMN_CM(TT, NN, 0); } while (0)
-      if (a.ksize == 1) { if (ncw == 2) LMN_CMB(1, 2); else LMN_CMB(1, 1); }
+#define LMN_CMR(NN) do { if (pm == 2) LMN_CM(1, NN, 6); else if (pm == 1) LMN_CM(1, NN, 5); else LMN_CM(1, NN, 4); } while (0)
+      if (a.ksize == 1 && T.rpw) { if (ncw == 2) LMN_CMR(2); else LMN_CMR(1); }   // (row-planar operands: their own instances)
+      else if (a.ksize == 1) { if (ncw == 2) LMN_CMB(1, 2); else LMN_CMB(1, 1); }
       else { if (ncw == 2) LMN_CMB(9, 2); else LMN_CMB(9, 1); }
+#undef LMN_CMR
 #undef LMN_CMB
 #undef LMN_CM
       det_finish();
@@ -2948,14 +3031,14 @@ int lmn_conv_fwd(const lmn_conv_args_t* args, lmn_stream_t stream) {
 #define LMN_CT(TT, NN, BFV)                                                                              \
   do {                                                                                                   \
     switch ((TT) == 1 ? ek : (ek > 2 ? 1 : ek)) {                                                        \
-      case 0: if ((TT) == 9 && wlk) LMN_LAUNCH((conv_tile_kernel<9, NN, 0, false, BFV, true>), grid, dim3(256), shmem, st, T); \
+      case 0: if ((TT) == 9 && wlk) LMN_LAUNCH((conv_tile_kernel<9, NN, 0, false, (BFV) & 3, true>), grid, dim3(256), shmem, st, T); \
               else LMN_LAUNCH((conv_tile_kernel<TT, NN, 0, false, BFV>), grid, dim3(256), shmem, st, T); break;   \
-      case 2: if ((TT) == 9 && wlk) LMN_LAUNCH((conv_tile_kernel<9, NN, 2, false, BFV, true>), grid, dim3(256), shmem, st, T); \
+      case 2: if ((TT) == 9 && wlk) LMN_LAUNCH((conv_tile_kernel<9, NN, 2, false, (BFV) & 3, true>), grid, dim3(256), shmem, st, T); \
               else LMN_LAUNCH((conv_tile_kernel<TT, NN, 2, false, BFV>), grid, dim3(256), shmem, st, T); break;   \
       case 3: LMN_LAUNCH((conv_tile_kernel<1, NN, 3, false, BFV>), grid, dim3(256), shmem, st, T); break;    \
       case 4: LMN_LAUNCH((conv_tile_kernel<1, NN, 4, false, BFV>), grid, dim3(256), shmem, st, T); break;    \
       case 5: LMN_LAUNCH((conv_tile_kernel<1, NN, 5, false, BFV>), grid, dim3(256), shmem, st, T); break;    \
-      default: if ((TT) == 9 && wlk) LMN_LAUNCH((conv_tile_kernel<9, NN, 1, false, BFV, true>), grid, dim3(256), shmem, st, T); \
+      default: if ((TT) == 9 && wlk) LMN_LAUNCH((conv_tile_kernel<9, NN, 1, false, (BFV) & 3, true>), grid, dim3(256), shmem, st, T); \
                else LMN_LAUNCH((conv_tile_kernel<TT, NN, 1, false, BFV>), grid, dim3(256), shmem, st, T); break;  \
     }                                                                                                    \
   } while (0)
@@ -2971,7 +3054,19 @@ int lmn_conv_fwd(const lmn_conv_args_t* args, lmn_stream_t stream) {
     case 14: LMN_CT(TT, 3, 2); break;                                                                    \
     default: LMN_CT(TT, 3, 0); break;                                                                    \
   }
-    if (a.ksize == 1) { LMN_CTN(1) } else { LMN_CTN(9) }
+    if (a.ksize == 1 && T.rpw) {   // (row-planar operands: their own instances, precision mode | 4)
+      switch ((tnct > 3 ? 3 : tnct) * 4 + pm) {
+        case 4: LMN_CT(1, 1, 4); break;
+        case 5: LMN_CT(1, 1, 5); break;
+        case 6: LMN_CT(1, 1, 6); break;
+        case 8: LMN_CT(1, 2, 4); break;
+        case 9: LMN_CT(1, 2, 5); break;
+        case 10: LMN_CT(1, 2, 6); break;
+        case 13: LMN_CT(1, 3, 5); break;
+        case 14: LMN_CT(1, 3, 6); break;
+        default: LMN_CT(1, 3, 4); break;
+      }
+    } else if (a.ksize == 1) { LMN_CTN(1) } else { LMN_CTN(9) }
 #undef LMN_CTN
 #undef LMN_CT
     det_finish();
@@ -3036,15 +3131,17 @@ static int wgrad_setup(const lmn_wgrad_args_t& A, WgradParams& P, WgGeom& G) {
     int rw = 0;
     for (int s = 0; s < 3; ++s) {
       const int w = s < A.nsrc ? A.src[s].rp_w : 0;
-      P.rp_src[s] = lmn_rp_make(w, s < A.nsrc ? A.src[s].C : 0);
+      P.lay_src[s] = lmn_lay_make(w, s < A.nsrc ? A.src[s].C : 4, s < A.nsrc ? A.src[s].cstride : 4);
       if (w) {
-        LMN_REQUIRE(A.src[s].cstride == A.src[s].C && (rw == 0 || rw == w), "conv_wgrad: row-planar source %d must be a whole tensor (cstride == C) of the call's width", s);
+        LMN_REQUIRE(w > 0 && A.src[s].cstride == A.src[s].C && (rw == 0 || rw == w), "conv_wgrad: row-planar source %d must be a whole tensor (cstride == C) of the call's width", s);
         rw = w;
       }
     }
-    P.rp_dy = lmn_rp_make(A.dy_rp_w, A.Cout);
-    if (P.rp_dy.w) { LMN_REQUIRE(A.dy_cstride == A.Cout && (rw == 0 || rw == P.rp_dy.w), "conv_wgrad: row-planar dy must be a whole tensor of the call's width"); rw = P.rp_dy.w; }
+    P.lay_dy = lmn_lay_make(A.dy_rp_w, A.Cout, A.dy_cstride);
+    if (A.dy_rp_w) { LMN_REQUIRE(A.dy_rp_w > 0 && A.dy_cstride == A.Cout && (rw == 0 || rw == A.dy_rp_w), "conv_wgrad: row-planar dy must be a whole tensor of the call's width"); rw = A.dy_rp_w; }
     if (rw) LMN_REQUIRE(A.ksize == 1 && A.stride == 1 && ((int64_t)A.Hout * A.Wout) % rw == 0, "conv_wgrad: row-planar operands belong to 1x1 stride-1 calls");
+    P.rpw = rw;
+    P.rp_magic = lmn_div_magic(rw);
   }
   P.NMTT = (A.Cout + 15) / 16;
   P.steps_per_img = (A.Hout * A.Wout + 3) / 4;
@@ -3263,17 +3360,23 @@ int lmn_conv_wgrad(const lmn_wgrad_args_t* args, lmn_stream_t stream) {
     const int64_t nb = blocks;
     const dim3 dgrid((unsigned)nb, gy);
     const bool wave_staged = G.wave_staged;
+#define LMN_WDK(KERN, M, N, SH)                                                                                    \
+  do {                                                                                                              \
+    if (P.rpw) {   /* row-planar operands: their own instances (precision mode | 4) */                              \
+      if (pm == 2) LMN_LAUNCH((KERN<M, N, 6>), dgrid, dim3(256), SH, st, P);                                        \
+      else if (pm == 1) LMN_LAUNCH((KERN<M, N, 5>), dgrid, dim3(256), SH, st, P);                                   \
+      else LMN_LAUNCH((KERN<M, N, 4>), dgrid, dim3(256), SH, st, P);                                                \
+    } else if (pm == 2) LMN_LAUNCH((KERN<M, N, 2>), dgrid, dim3(256), SH, st, P);                                   \
+    else if (pm == 1) LMN_LAUNCH((KERN<M, N, 1>), dgrid, dim3(256), SH, st, P);                                     \
+    else LMN_LAUNCH((KERN<M, N, 0>), dgrid, dim3(256), SH, st, P);                                                  \
+  } while (0)
 #define LMN_WD(M, N)                                                                                               \
   do {                                                                                                              \
     if (wave_staged) {                                                                                              \
       const int64_t stf = 4 * (M + N) * 256, rdf = (int64_t)M * N * 256 + M * 16;                                   \
       const size_t wsh = (size_t)(stf > rdf ? stf : rdf) * 4;                                                       \
-      if (pm == 2) LMN_LAUNCH((wgrad_1x1w_kernel<M, N, 2>), dgrid, dim3(256), wsh, st, P);                  \
-      else if (pm == 1) LMN_LAUNCH((wgrad_1x1w_kernel<M, N, 1>), dgrid, dim3(256), wsh, st, P);             \
-      else LMN_LAUNCH((wgrad_1x1w_kernel<M, N, 0>), dgrid, dim3(256), wsh, st, P);                          \
-    } else if (pm == 2) LMN_LAUNCH((wgrad_1x1_kernel<M, N, 2>), dgrid, dim3(256), 0, st, P);                \
-    else if (pm == 1) LMN_LAUNCH((wgrad_1x1_kernel<M, N, 1>), dgrid, dim3(256), 0, st, P);                  \
-    else LMN_LAUNCH((wgrad_1x1_kernel<M, N, 0>), dgrid, dim3(256), 0, st, P);                               \
+      LMN_WDK(wgrad_1x1w_kernel, M, N, wsh);                                                                        \
+    } else LMN_WDK(wgrad_1x1_kernel, M, N, 0);                                                                      \
     if (reduce_now) {                                                                                               \
       const int ksl = reduce_slices((int)nb);                                                                       \
       const int rb = (int)((per + 4096 / ksl - 1) / (4096 / ksl));                                                    \
@@ -3284,9 +3387,7 @@ int lmn_conv_wgrad(const lmn_wgrad_args_t* args, lmn_stream_t stream) {
   do {                                                                                                              \
     const int64_t stf = 4 * (M + N) * 256, rdf = (int64_t)M * N * 256 + M * 16;                                     \
     const size_t wsh = (size_t)(stf > rdf ? stf : rdf) * 4;                                                         \
-    if (pm == 2) LMN_LAUNCH((wgrad_1x1w_kernel<M, N, 2>), dgrid, dim3(256), wsh, st, P);                    \
-    else if (pm == 1) LMN_LAUNCH((wgrad_1x1w_kernel<M, N, 1>), dgrid, dim3(256), wsh, st, P);               \
-    else LMN_LAUNCH((wgrad_1x1w_kernel<M, N, 0>), dgrid, dim3(256), wsh, st, P);                            \
+    LMN_WDK(wgrad_1x1w_kernel, M, N, wsh);                                                                          \
     if (reduce_now) {                                                                                               \
       const int ksl = reduce_slices((int)nb);                                                                       \
       const int rb = (int)((per + 4096 / ksl - 1) / (4096 / ksl));                                                    \
@@ -3309,6 +3410,7 @@ int lmn_conv_wgrad(const lmn_wgrad_args_t* args, lmn_stream_t stream) {
     }
 #undef LMN_WW
 #undef LMN_WD
+#undef LMN_WDK
     return lmn_launch_status("conv_wgrad(1x1)");
   }
 #define LMN_WGS(T)                                                   \

@@ -702,7 +702,6 @@ __device__ __forceinline__ void sw_step(SwState& S, const W2& bw, const f32x2 (&
   if (PART != 1) {
 #pragma unroll
     for (int d = 0; d < 5; ++d) i2[d] = x2[d];
-    LMN_NOP0();
 #pragma unroll
     for (int ky = 1; ky < 5; ++ky)
 #pragma unroll
@@ -716,7 +715,6 @@ __device__ __forceinline__ void sw_step(SwState& S, const W2& bw, const f32x2 (&
 #pragma unroll
     for (int kx = 0; kx < 3; ++kx) pkfma_vv(S.gh[kx], S.hh[(P + 1) % 5], i2[1 + kx]);
   }
-  LMN_NOP0();
   // ---- x1 row j: the four branch outputs y_b (column-major: consecutive FMAs go to DIFFERENT row accumulators; the first
   //      contribution to a row is a plain product: no zeroed accumulators)
 #pragma unroll
@@ -737,7 +735,6 @@ __device__ __forceinline__ void sw_step(SwState& S, const W2& bw, const f32x2 (&
       for (int ky = 1; ky < 3; ++ky) pkfma(S.av[(P - ky + 6) % 5], in[2], LMN_WV(ky));
     }
   }
-  LMN_NOP0();
   // ---- row q = j-2 is complete: f_b = (cC a + cA dp + cD) m;  co[k] = {cA_k, cC_k} (k < 4), co[4] = {cD_0, cD_1}, co[5] = {cD_2, cD_3}
   constexpr int Q = (P + 3) % 5;
   const V m = mf * cm;     // f_b = 0 in columns outside the image and in rows outside it (per half)
@@ -747,7 +744,6 @@ __device__ __forceinline__ void sw_step(SwState& S, const W2& bw, const f32x2 (&
   {
     V d0, d1, d2, d3;   // (m * cD_k)
     pkmul(d0, m, co[4], 0); pkmul(d1, m, co[4], 1); pkmul(d2, m, co[5], 0); pkmul(d3, m, co[5], 1);
-    LMN_NOP0();
     f5 = f5 * m + d0; f3 = f3 * m + d1; fv = fv * m + d2; fh = fh * m + d3;
   }
   S.h5[Q] = f5 * mo; S.h3[Q] = f3 * mo; S.hv[Q] = fv * mo; S.hh[Q] = fh * mo;
@@ -764,7 +760,6 @@ __device__ __forceinline__ void sw_step(SwState& S, const W2& bw, const f32x2 (&
     s3[0] = lane_from_right(f3);
     s3[2] = lane_from_left(f3);
     const V hr = lane_from_right(fh), hl = lane_from_left(fh);
-    LMN_NOP0();
 #pragma unroll
     for (int kx = 0; kx < 5; ++kx) {
       if (kx == 0) pkmul(S.dxa[P], sh[0], LMN_W5(20));
@@ -783,14 +778,13 @@ __device__ __forceinline__ void sw_step(SwState& S, const W2& bw, const f32x2 (&
     pkfma(S.dxa[Q], hr, LMN_WH(0));
     pkfma(S.dxa[(P + 4) % 5], fv, LMN_WV(2));
     pkfma(S.dxa[Q], fh, LMN_WH(1));
-    LMN_NOP0();
+    LMN_NOP0();   // (the one chain of the step: two consecutive statements into the same accumulator)
     pkfma(S.dxa[Q], hl, LMN_WH(2));
-    LMN_NOP0();
   }
   if (PART != 1) {   // f row j-2 (this step's) against x1 row j-4: kernel row 0 of the 5x5 gradient
+    if (PART == 2) LMN_NOP0();   // (h5[Q] is a packed result of the lines above; with the dx1 block in between it is long done)
 #pragma unroll
     for (int kx = 0; kx < 5; ++kx) pkfma_vv(S.g5[kx], S.h5[Q], i2[kx]);
-    LMN_NOP0();
   }
 }
 
@@ -823,7 +817,12 @@ __global__ __launch_bounds__(256, WPS) void dw_bwd_kernel(
   const int xs = strip * QS;
   const unsigned rowb = (unsigned)(E * W) * (unsigned)ES, qoff = (unsigned)(quad * 4 * W) * (unsigned)ES;
   const int r0 = b * H;
-  auto so = [&](int iy) -> unsigned { const int y = min(max(iy, 0), H - 1); return (unsigned)(r0 + y) * rowb + qoff; };
+  // row offsets (soffset of the buffer accesses): rows outside the image read a SAFE row of the half instead (one scalar select:
+  // no clamps; their values are masked by rm / mf below), stores of rows outside the segment are skipped by a scalar branch
+  const int HB = rowsB > 0 ? H : 0;
+  const unsigned safeA = (unsigned)(r0 + ysA) * rowb + qoff, safeB = rowsB > 0 ? (unsigned)(r0 + ysB) * rowb + qoff : safeA;
+  auto soA = [&](int iy) -> unsigned { return (unsigned)iy < (unsigned)H ? (unsigned)(r0 + iy) * rowb + qoff : safeA; };
+  auto soB = [&](int iy) -> unsigned { return (unsigned)iy < (unsigned)HB ? (unsigned)(r0 + iy) * rowb + qoff : safeB; };
   V* XS = XSa[wv];
   V* ZS = ZSa[wv];
   for (int i = lane; i < 5 * 68; i += 64) XS[i] = V{0.f, 0.f};
@@ -883,11 +882,13 @@ __global__ __launch_bounds__(256, WPS) void dw_bwd_kernel(
   const int nsteps = rowsA + 10;   // rowsA >= rowsB
   V pfz[5], pfh[5], pfd[5];
   auto ldz = [&](int j, V& zz, V& zh_) {
-    const unsigned a = so(ysA - 4 + j), bb = so(ysB - 4 + j);
+    const unsigned a = soA(ysA - 4 + j), bb = soB(ysB - 4 + j);
     zz = V{ld_one<TA>(rz, voff, a), ld_one<TA>(rz, voff, bb)};
     if (HALO) zh_ = V{ld_one<TA>(rz, vhalo, a), ld_one<TA>(rz, vhalo, bb)};
   };
-  auto ldd = [&](int j, V& dd) { dd = V{ld_one<TA>(rd, voff, so(ysA - 6 + j)), ld_one<TA>(rd, voff, so(ysB - 6 + j))}; };
+  auto ldd = [&](int j, V& dd) { dd = V{ld_one<TA>(rd, voff, soA(ysA - 6 + j)), ld_one<TA>(rd, voff, soB(ysB - 6 + j))}; };
+  // f rows of half h live at image rows [fl_h, H): inside the image and not above the first row the segment needs (ys - 2)
+  const int flA = max(ysA - 2, 0), flB = max(ysB - 2, 0);
 #pragma unroll
   for (int d = 0; d < D; ++d) ldz(d, pfz[d], pfh[d]);
 #pragma unroll
@@ -908,8 +909,7 @@ __global__ __launch_bounds__(256, WPS) void dw_bwd_kernel(
   {                                                                                                                \
     const int j = j0 + P;                                                                                          \
     const V zv = pfz[P];                                                                                           \
-    const int iyA = ysA - 4 + j, iyB = ysB - 4 + j;                                                                \
-    const V rm = msk(iyA >= 0 && iyA < H, iyB >= 0 && iyB < H && rowsB > 0);                                       \
+    const V rm = msk((unsigned)(ysA - 4 + j) < (unsigned)H, (unsigned)(ysB - 4 + j) < (unsigned)HB);               \
     V x1v = (ZT ? hswish2(zv, V{pa, pa}, V{ps, ps}) : zv) * (rm * cm);                                             \
     V x1h = z2;                                                                                                    \
     if (HALO) x1h = (ZT ? hswish2(pfh[P], V{pa, pa}, V{ps, ps}) : pfh[P]) * (rm * hm);                             \
@@ -922,12 +922,12 @@ __global__ __launch_bounds__(256, WPS) void dw_bwd_kernel(
     if (ZT && PART != 2) ZS[P * 64 + lane] = zv;                                                                   \
     LMN_WAVE_SYNC();                                                                                               \
     const int fyA = ysA - 6 + j, fyB = ysB - 6 + j;                                                                \
-    const V mf = msk(j >= 4 && fyA >= 0 && fyA < H, j >= 4 && fyB >= 0 && fyB < H && rowsB > 0);                   \
-    const V mo = msk(fyA >= ysA && fyA < yeA, fyB >= ysB && fyB < yeB);                                            \
+    const V mf = msk((unsigned)(fyA - flA) < (unsigned)(H - flA), (unsigned)(fyB - flB) < (unsigned)(HB - flB) && rowsB > 0); \
+    const V mo = msk((unsigned)(fyA - ysA) < (unsigned)rowsA, (unsigned)(fyB - ysB) < (unsigned)rowsB);            \
     sw_step<P, PART>(S, bw, co, cm, XS, lane, x1v, dp, mf, mo);                                                    \
     if (PART != 2) {   /* dx row j-4 is complete */                                                                \
       constexpr int DD = (P + 1) % 5;                                                                              \
-      const bool okA = j >= 8 && j < rowsA + 8, okB = j >= 8 && j < rowsB + 8;                                     \
+      const bool okA = (unsigned)(j - 8) < (unsigned)rowsA, okB = (unsigned)(j - 8) < (unsigned)rowsB;             \
       V dv = S.dxa[DD];                                                                                            \
       if (ZT) {   /* dh = dx1 * Hardswish'(A z + shift); sum dh, sum dh * z over the rows of the two segments */   \
         const V zr = ZS[DD * 64 + lane];                                                                           \
@@ -936,8 +936,8 @@ __global__ __launch_bounds__(256, WPS) void dw_bwd_kernel(
         hs0 += dv;                                                                                                 \
         hs1 += dv * zr;                                                                                            \
       }                                                                                                            \
-      st_one<TA>(ro, okA ? vst : OOB, so(ysA - 8 + j), dv.x);                                                      \
-      st_one<TA>(ro, okB ? vst : OOB, so(ysB - 8 + j), dv.y);                                                      \
+      if (okA) st_one<TA>(ro, vst, (unsigned)(r0 + ysA - 8 + j) * rowb + qoff, dv.x);                              \
+      if (okB) st_one<TA>(ro, vst, (unsigned)(r0 + ysB - 8 + j) * rowb + qoff, dv.y);                              \
     }                                                                                                              \
     LMN_SB();                                                                                                      \
   }
@@ -1047,22 +1047,25 @@ __global__ void dw_bwd_coef_kernel(const float* __restrict__ bst, const float* _
 
 }  // namespace
 
-// Row segments of a pass.  A wave walks (rows + halo) row steps (padded to batches of 5); `per_seg` waves exist per segment; a SIMD
-// holds `wps` waves and the machine 1024 SIMDs.  While all waves are resident the pass takes (waves per SIMD, rounded up) x steps;
-// past that, waves / 1024 x steps plus a tail -- pick the count that minimises it (level 0 of the backward, 1152 waves per segment
-// pair: 2 pairs = 2304 waves on 2048 slots ran as two rounds, 185 us; 3 pairs: ~130 us).
-static int dw_segments(int64_t per_seg, int H, int halo, int wps, int mult, int* seg_rows) {
+// Row segments of a pass.  A wave walks (rows + halo) row steps (padded to batches of 5); `per_seg` waves exist per segment (pair); a
+// SIMD holds `wps` waves and the machine 1024 SIMDs.  A row step of ONE wave is a dependent chain (load -> transform -> LDS
+// exchange -> FMAs) that takes about `lat` times its issue time, so up to `lat` waves per SIMD run for free; beyond that the pass
+// is issue-bound: time ~ steps x max(waves per SIMD, lat) while all waves are resident, waves / 1024 x steps plus a tail past
+// that.  (Level 3, 44 x 44 x 192 channels: one segment = 768 waves of 50 steps took 31 us, four segments of 15 steps 12 us; level 0
+// of the backward: 2 segment pairs = 2304 waves on 2048 slots ran as two rounds.)
+static int dw_segments(int64_t per_seg, int H, int halo, int wps, int mult, double lat, int* seg_rows) {
   int best = mult;
   double best_cost = -1.0;
   for (int sg = mult; sg <= H; sg += mult) {
     const int rows = lmn_cdiv(H, sg);
-    if (sg > mult && rows < 8) break;
+    if (sg > mult && rows < 6) break;
     const int nseg = lmn_cdiv(H, rows);
     if (lmn_cdiv(nseg, mult) * mult != sg) continue;  // same partition as a smaller count
     const int steps = lmn_cdiv(rows + halo, 5) * 5;
     const double waves = (double)per_seg * (sg / mult);
     const double per_simd = waves / 1024.0;
-    const double occ = waves <= 1024.0 * wps ? (double)lmn_cdiv((int64_t)waves, 1024) : per_simd + 0.5 * wps;
+    double occ = waves <= 1024.0 * wps ? (double)lmn_cdiv((int64_t)waves, 1024) : per_simd + 0.5 * wps;
+    if (occ < lat) occ = lat;
     const double cost = occ * steps;
     if (best_cost < 0.0 || cost < best_cost) { best_cost = cost; best = sg; }
   }
@@ -1078,7 +1081,7 @@ static int launch_dw_stats(const void* x1, const void* pre, const void* u, const
   LMN_REQUIRE((int64_t)B * H * W * E * 4 < (1LL << 32), "dw statistics: the tensor (%d x %d x %d x %d) must stay below 4 GiB", B, H, W, E);
   const int strips = lmn_cdiv(W, QW), chunks = lmn_cdiv(E, 8);
   int seg_rows;
-  const int segs = dw_segments((int64_t)B * strips * chunks * 4, H, 4, MODE == 0 ? 4 : 3, 1, &seg_rows);
+  const int segs = dw_segments((int64_t)B * strips * chunks * 4, H, 4, MODE == 0 ? 4 : 3, 1, 3.0, &seg_rows);
   const int nseg = lmn_cdiv(H, seg_rows);
   const int64_t nblk = (int64_t)B * strips * chunks * nseg;
   (void)segs;
@@ -1135,7 +1138,7 @@ static int dw_fwd_launch(const void* x1, void* pre, float* gsum, int B, int H, i
   // blocks = B x row segments x strips (60 output columns) x 8-channel chunks
   const int strips = lmn_cdiv(W, QW), chunks = lmn_cdiv(E, 8);
   int seg_rows;
-  dw_segments((int64_t)B * strips * chunks * 4, H, 4, 4, 1, &seg_rows);
+  dw_segments((int64_t)B * strips * chunks * 4, H, 4, 4, 1, 3.0, &seg_rows);
   const int segs = lmn_cdiv(H, seg_rows);
   const int64_t nblk = (int64_t)B * strips * chunks * segs;
   LMN_REQUIRE(nblk < (1LL << 31), "%s: grid too large", what);
@@ -1287,7 +1290,7 @@ static int dw_bwd_launch(const void* x1, const void* dpre, void* dx1, int B, int
   const int strips = halo ? lmn_cdiv(W, 60) : lmn_cdiv(W, 56), chunks = E / 4;
   const int wps = part == 1 ? 4 : 2;
   int seg_rows;
-  const int segs = dw_segments((int64_t)B * strips * chunks * 4, H, 10, wps, 2, &seg_rows);   // even: a wave walks the pair (sa, sa + segs/2)
+  const int segs = dw_segments((int64_t)B * strips * chunks * 4, H, 10, wps, 2, part == 1 ? 3.0 : 2.0, &seg_rows);   // even: a wave walks the pair (sa, sa + segs/2)
   const int hs = segs / 2;
   const int64_t nblk = (int64_t)B * strips * chunks * hs;
   LMN_REQUIRE(nblk < (1LL << 31), "%s: grid too large", what);
