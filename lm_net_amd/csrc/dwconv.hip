@@ -211,15 +211,15 @@ __device__ __forceinline__ GeoP decode_pair(int E, int H, int W, int strips, int
   g.r0 = g.b * H;
   return g;
 }
-__device__ __forceinline__ unsigned row_off(const GeoP& g, int iy, int H) {   // row clamped into the image (callers mask the value)
-  const int y = min(max(iy, 0), H - 1);
+__device__ __forceinline__ unsigned row_off(const GeoP& g, int iy, int H) {   // rows outside the image read the segment's first row (callers mask the value)
+  const int y = (unsigned)iy < (unsigned)H ? iy : g.ys;
   return (unsigned)(g.r0 + y) * g.rowb + g.qoff;
 }
 
 // ---------------------------------------------------------------------------------------------------------------
 // Forward batch statistics: stats[4][2][E] += (sum y_b, sum y_b^2).  z row (ys-2+j) is exchanged during step j-1, its FMAs run at
 // step j (the exchange of the next row is software-pipelined under them); output row (ys+j-4) completes at step j.
-template <typename TA>
+template <typename TA, bool ZT>
 __global__ __launch_bounds__(256, 4) void dw_stats0_kernel(const TA* __restrict__ x1, int H, int W, int E, const float* __restrict__ w5,
                                                             const float* __restrict__ w3, const float* __restrict__ wvv,
                                                             const float* __restrict__ whh, float* __restrict__ stats, const DwPreK PRE,
@@ -231,7 +231,7 @@ __global__ __launch_bounds__(256, 4) void dw_stats0_kernel(const TA* __restrict_
   const int tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const GeoP g = decode_pair<ES>(E, H, W, strips, segs, seg_rows, chunks, wv);
-  const bool zt = PRE.A != nullptr || PRE.fin.mode == LMN_FIN_BN;   // block-uniform: the input tensor is z (see DwPreK)
+  constexpr bool zt = ZT;   // the input tensor is z (see DwPreK): a template argument, so that the row steps carry no branch on it
   if (zt) dw_pre_setup(PRE, pre_s, g.ch0, E, tid, g.strip == 0 && g.seg == 0 && g.b == 0);
   f32x2* XS0 = XSa[wv][0];
   if (lane < 8) XS0[(lane >> 2) * 68 + ((lane & 3) < 2 ? (lane & 3) : 64 + (lane & 3))] = f32x2{0.f, 0.f};
@@ -324,7 +324,7 @@ __global__ __launch_bounds__(256, 4) void dw_stats0_kernel(const TA* __restrict_
 // ---------------------------------------------------------------------------------------------------------------
 // Forward (flagship HBM-bound kernel of row A2): pre = merged 5x5 (+ bias) -> store; gsum[b][e] += sum GELU(pre) (SE squeeze), and
 // optionally the squeeze-excite gate of an image by the block that completes its sums (lmn_se_fuse_t).
-template <typename TA>
+template <typename TA, bool ZT>
 __global__ __launch_bounds__(256, 4) void dw_fwd_kernel(const TA* __restrict__ x1, TA* __restrict__ pre, float* __restrict__ gsum, int H, int W,
                                                          int E, const float* __restrict__ keff, const float* __restrict__ beff, const DwFin FN,
                                                          const lmn_se_fuse_t SE, const DwPreS PRE, int strips, int segs, int seg_rows, int chunks,
@@ -338,7 +338,7 @@ __global__ __launch_bounds__(256, 4) void dw_fwd_kernel(const TA* __restrict__ x
   const int tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const GeoP g = decode_pair<ES>(E, H, W, strips, segs, seg_rows, chunks, wv);
-  const bool zt = PRE.A != nullptr;   // block-uniform: the input tensor is z (see DwPreK)
+  constexpr bool zt = ZT;   // the input tensor is z (see DwPreK)
   if (zt) dw_pre_setup(PRE, pre_s, g.ch0, E, tid);
   f32x2* XS0 = XSa[wv][0];
   if (lane < 8) XS0[(lane >> 2) * 68 + ((lane & 3) < 2 ? (lane & 3) : 64 + (lane & 3))] = f32x2{0.f, 0.f};
@@ -494,7 +494,7 @@ __global__ __launch_bounds__(256, 4) void dw_fwd_kernel(const TA* __restrict__ x
 // of which the 3x3 / 3x1 / 1x3 taps are subsets): 25 packed FMAs per pixel pair, contracted with the four kernels once per wave.
 // dpre row o (segment row) is formed at step o -- when x1 row o+2 (ring row o) is in `in` -- and pairs with x1 ring rows o .. o+4
 // over the next five steps: G[ky][kx] += dpre[j - ky] * x1ring[j][x + kx - 2] at step j.
-template <typename TA>
+template <typename TA, bool ZT>
 __global__ __launch_bounds__(256, 3) void dw_stats1_kernel(const TA* __restrict__ x1, const TA* __restrict__ pre, const TA* __restrict__ u,
                                                             const float* __restrict__ sgate, const float* __restrict__ dm, TA* __restrict__ dpre,
                                                             int H, int W, int E, const float* __restrict__ w5, const float* __restrict__ w3,
@@ -509,7 +509,7 @@ __global__ __launch_bounds__(256, 3) void dw_stats1_kernel(const TA* __restrict_
   const int tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const GeoP g = decode_pair<ES>(E, H, W, strips, segs, seg_rows, chunks, wv);
-  const bool zt = PRE.A != nullptr || PRE.fin.mode == LMN_FIN_BN;
+  constexpr bool zt = ZT;
   if (zt) dw_pre_setup(PRE, pre_s, g.ch0, E, tid, false);
   f32x2* XS0 = XSa[wv][0];
   if (lane < 8) XS0[(lane >> 2) * 68 + ((lane & 3) < 2 ? (lane & 3) : 64 + (lane & 3))] = f32x2{0.f, 0.f};
@@ -796,7 +796,7 @@ __global__ __launch_bounds__(256, WPS) void dw_bwd_kernel(
     float* __restrict__ dw3, float* __restrict__ dwv, float* __restrict__ dwh, const DwPreS PRE, float* __restrict__ hstats, int strips,
     int segs /* even */, int seg_rows, int chunks /* quads */, int det) {
   typedef f32x2 V;
-  constexpr int ES = sizeof(TA), D = 3, D2 = 2;
+  constexpr int ES = sizeof(TA), D = 3, D2 = 2;   // rows in flight (z / dpre); 5 / 4 measured the same: the pass does not wait for memory
   constexpr int QS = HALO ? 60 : 56;
   __shared__ V XSa[4][5 * 68];
   __shared__ V ZSa[4][ZT && PART != 2 ? 5 * 64 : 1];
@@ -1095,11 +1095,17 @@ static int launch_dw_stats(const void* x1, const void* pre, const void* u, const
     LMN_REQUIRE(sdst, "dw statistics: deterministic mode: no scratch");
   }
   if (MODE == 0) {
-    LMN_ACT_DISPATCH(act_dtype, LMN_LAUNCH((dw_stats0_kernel<T>), dim3((unsigned)nblk), dim3(256), 0, st, (const T*)x1, H, W, E, w5, w3, wv, wh, sdst, zp, strips, nseg,
-                                          seg_rows, chunks, g_lmn_det));
+    const bool zt = zp.A != nullptr || zp.fin.mode == LMN_FIN_BN;
+#define LMN_DS0(Z) LMN_ACT_DISPATCH(act_dtype, LMN_LAUNCH((dw_stats0_kernel<T, Z>), dim3((unsigned)nblk), dim3(256), 0, st, (const T*)x1, H, W, E, w5, w3, wv, wh, sdst, zp, strips, nseg, \
+                                          seg_rows, chunks, g_lmn_det))
+    if (zt) LMN_DS0(true); else LMN_DS0(false);
+#undef LMN_DS0
   } else {
-    LMN_ACT_DISPATCH(act_dtype, LMN_LAUNCH((dw_stats1_kernel<T>), dim3((unsigned)nblk), dim3(256), 0, st, (const T*)x1, (const T*)pre, (const T*)u, s, dm, (T*)dpre, H, W, E,
-                                          w5, w3, wv, wh, sdst, sb, zp, strips, nseg, seg_rows, chunks, g_lmn_det));
+    const bool zt = zp.A != nullptr;
+#define LMN_DS1(Z) LMN_ACT_DISPATCH(act_dtype, LMN_LAUNCH((dw_stats1_kernel<T, Z>), dim3((unsigned)nblk), dim3(256), 0, st, (const T*)x1, (const T*)pre, (const T*)u, s, dm, (T*)dpre, H, W, E, \
+                                          w5, w3, wv, wh, sdst, sb, zp, strips, nseg, seg_rows, chunks, g_lmn_det))
+    if (zt) LMN_DS1(true); else LMN_DS1(false);
+#undef LMN_DS1
   }
   if (g_lmn_det) lmn_det_sum(st, sdst, nslots, (int64_t)NS * E, stats);
   return 0;
@@ -1150,8 +1156,10 @@ static int dw_fwd_launch(const void* x1, void* pre, float* gsum, int B, int H, i
     gdst = lmn_det_slots(st, (size_t)segs * strips * B * E);
     LMN_REQUIRE(gdst, "%s: deterministic mode: no scratch", what);
   }
-  LMN_ACT_DISPATCH(act_dtype, LMN_LAUNCH((dw_fwd_kernel<T>), dim3((unsigned)nblk), dim3(256), 0, st, (const T*)x1, (T*)pre, gdst, H, W, E, keff, beff, fn, sf,
-                                        DwPreS{zp.A, zp.shift}, strips, segs, seg_rows, chunks, g_lmn_det, B));
+#define LMN_DF(Z) LMN_ACT_DISPATCH(act_dtype, LMN_LAUNCH((dw_fwd_kernel<T, Z>), dim3((unsigned)nblk), dim3(256), 0, st, (const T*)x1, (T*)pre, gdst, H, W, E, keff, beff, fn, sf, \
+                                        DwPreS{zp.A, zp.shift}, strips, segs, seg_rows, chunks, g_lmn_det, B))
+  if (zp.A) LMN_DF(true); else LMN_DF(false);
+#undef LMN_DF
   if (g_lmn_det) lmn_det_sum(st, gdst, segs * strips, (int64_t)B * E, gsum);
   return lmn_launch_status(what);
 }
