@@ -41,7 +41,7 @@ def dice_loss(logits, target, weight=(1.0, 4.0), smooth=1e-5):
 
 def _pmc():
     """The committed PMC reduction of this very command (profiles/rNN_pmc.json, newest round first), or None."""
-    for name in ("r03_pmc.json", "r02_pmc.json"):
+    for name in ("r04_pmc.json", "r03_pmc.json", "r02_pmc.json"):
         path = os.path.join(ROOT, "profiles", name)
         if os.path.isfile(path):
             try:
@@ -70,9 +70,9 @@ def _targs(name):
 
 
 def _pmc_match(kernel):
-    """PMC records of the kernels the in-library timer files under `kernel`.  The timer keys a launch by the text of its launch
-    site (`dw_bwd_kernel<T, PT, HL, Z, WP>`), rocprofv3 by the instantiated name (`dw_bwd_kernel<float, 0, true, true, 2>`): same base
-    name, and every LITERAL template argument of the launch site (numbers, true / false) equal; symbolic ones match anything."""
+    """PMC records of `kernel`.  The in-library timer and rocprofv3 file a launch under the same key -- the instantiated kernel name,
+    template arguments resolved (`dw_bwd_kernel<float, 0, true, true, 2>`; lmn_kname in csrc/runtime.hip) -- so this is a lookup.
+    (A key without resolved arguments, as the round-3 library produced, still matches by base name + literal arguments.)"""
     d = _pmc()
     if not d:
         return []
@@ -86,7 +86,7 @@ def _pmc_match(kernel):
         if b2 != base or len(a2) != len(args) or not rec:
             continue
         lit = lambda a: a in ("true", "false") or a.lstrip("-").isdigit()
-        if all((not lit(a)) or a == b for a, b in zip(args, a2)):
+        if any(not lit(a) and a not in ("float", "__bf16") for a in args) and all((not lit(a)) or a == b for a, b in zip(args, a2)):
             out.append(rec)
     return out
 
@@ -112,6 +112,10 @@ _PEAK = [MFMA_F32_PEAK_TFLOPS]  # matrix-core peak of the arithmetic of the run 
 STEP_MB_352, STEP_GFLOP_352 = 2085.54, 59.7
 
 
+COPY_CEILING_GBS = 6290.0       # measured device copy ceiling (the spec figure HBM_PEAK_GBS is the `peak` of the contract)
+HBM_ROWS = ("row", "dw_", "na_", "ln_", "affine", "pool", "up2_", "adamw", "loss")   # kernels of the byte-bound rows (8d "which roofline")
+
+
 def _entry(name, rec, extra_us=0.0):
     """One kernel's achieved rates from the in-library timer record {launches, total_us, flops, bytes}."""
     t = (rec["total_us"] + extra_us) * 1e-6
@@ -119,12 +123,27 @@ def _entry(name, rec, extra_us=0.0):
     gbs, tfs = rec["bytes"] / t / 1e9 if t > 0 else 0.0, rec["flops"] / t / 1e12 if t > 0 else 0.0
     pk = _PEAK[0]
     t_hbm, t_mfma = rec["bytes"] / (HBM_PEAK_GBS * 1e9), rec["flops"] / (pk * 1e12)
-    bound = "mfma" if t_mfma > t_hbm else "hbm"
-    return {"kernel": name, "bound": bound, "launches": rec["launches"], "avg_us": round(rec["total_us"] / n, 2),
-            "achieved": round(tfs if bound == "mfma" else gbs, 2), "peak": pk if bound == "mfma" else HBM_PEAK_GBS,
-            "unit": "TFLOP/s" if bound == "mfma" else "GB/s",
-            "frac": round((tfs / pk) if bound == "mfma" else (gbs / HBM_PEAK_GBS), 4),
-            "algorithmic_flops_per_launch": round(rec["flops"] / n), "algorithmic_bytes_per_launch": round(rec["bytes"] / n)}
+    bound = "mfma" if t_mfma > t_hbm and not name.startswith(HBM_ROWS) else "hbm"
+    e = {"kernel": name, "bound": bound, "launches": rec["launches"], "avg_us": round(rec["total_us"] / n, 2),
+         "achieved": round(tfs if bound == "mfma" else gbs, 2), "peak": pk if bound == "mfma" else HBM_PEAK_GBS,
+         "unit": "TFLOP/s" if bound == "mfma" else "GB/s",
+         "frac": round((tfs / pk) if bound == "mfma" else (gbs / HBM_PEAK_GBS), 4),
+         "algorithmic_flops_per_launch": round(rec["flops"] / n), "algorithmic_bytes_per_launch": round(rec["bytes"] / n)}
+    e["frac_vs_copy_ceiling"] = round(gbs / COPY_CEILING_GBS, 4) if bound == "hbm" else None
+    return e
+
+
+def _traffic_ratio(recs, _unused=None):
+    """PMC HBM bytes / algorithmic bytes of a set of timer records {name: rec}: per-launch PMC bytes of each instantiation
+    (profiles/rNN_pmc.json) x its launches, over the algorithmic bytes the same launches declared.  None without PMC data."""
+    phys, alg = 0.0, 0.0
+    for k, v in recs.items():
+        t = pmc_field(k, "hbm_bytes_per_launch")
+        if t is None:
+            return None
+        phys += t * v["launches"]
+        alg += v["bytes"]
+    return round(phys / alg, 3) if alg > 0 else None
 
 
 def _group(live, names):
@@ -142,51 +161,49 @@ def roofline_block(dominant, live, survey, tot_us, B, H, W, step_s, alone, esz=4
     layer shapes of each launch (SURVEY 8d convention).  Secondary entries: rows A2 / A7 (north_star's >= 70 % HBM targets)
     and the whole step against both rooflines."""
     rec = live.get(dominant) or survey[dominant]
-    red = dominant.replace("wgrad_lds_kernel", "wgrad_reduce_kernel").replace("wgrad_1x1_kernel<", "wgrad_reduce_kernel<1, ")
-    red = red.rsplit(",", 1)[0] + ">" if red != dominant else red        # (the reduce kernel has no precision-mode argument)
+    at_headline = (B, H, W) == (8, 352, 352) and esz == 4         # the committed PMC passes are of the default command
     r = _entry(dominant, rec)
     r["share_of_gpu_time"] = round(survey[dominant]["total_us"] / tot_us, 4)
     if dominant in alone:
         ea = _entry(dominant, alone[dominant])
         r["achieved_alone"], r["frac_alone"], r["avg_us_alone"] = ea["achieved"], ea["frac"], ea["avg_us"]
-    if red != dominant and red in live:
-        r["frac_with_reduce_launches"] = _entry(dominant, rec, live[red]["total_us"])["frac"]
-    r["traffic"] = pmc_traffic(dominant) if (B, H, W) == (8, 352, 352) else None
-    r["mfma_util_pmc"] = pmc_field(dominant, "mfma_busy_frac") if (B, H, W) == (8, 352, 352) else None
+    # split-K weight gradients: the fixed-order reduction launches that finish the dominant kernel's partial sums
+    red = [k for k in live if k.startswith("wgrad_reduce_kernel<%s," % ("1" if "1x1" in dominant else "9"))] if dominant.startswith("wgrad") else []
+    if red:
+        r["frac_with_reduce_launches"] = _entry(dominant, rec, sum(live[k]["total_us"] for k in red))["frac"]
+    r["traffic"] = pmc_traffic(dominant) if at_headline else None
+    r["traffic_ratio"] = (round(r["traffic"] / r["algorithmic_bytes_per_launch"], 3)
+                          if r["traffic"] and r["algorithmic_bytes_per_launch"] else None)
+    r["mfma_util_pmc"] = pmc_field(dominant, "mfma_busy_frac") if at_headline else None
     r["top5_by_time"] = [{"kernel": k, "share": round(v["total_us"] / tot_us, 4), "avg_us": round(v["total_us"] / max(v["launches"], 1), 1)}
                          for k, v in sorted(survey.items(), key=lambda kv: -kv[1]["total_us"])[:5]]
-    a2 = _group(live, ("dw_fwd_kernel", "dw_bwd_kernel", "dw_stats0_kernel", "dw_stats1_kernel"))
-    a7 = _group(live, ("na_fwd_kernel", "na_bwd_q_kernel", "na_bwd_kv_kernel", "na_bwd_q_tile_kernel", "na_bwd_kv_tile_kernel"))
     pm = (_pmc() or {}).get("whole_step")
-    # row totals under the 8d convention: A2 train = 5*E*HW*B*4 (the statistics passes are extra passes, not extra bytes)
-    A2K = ("dw_fwd_kernel", "dw_bwd_kernel", "dw_stats0_kernel", "dw_stats1_kernel")
-    A7K = ("na_fwd_kernel", "na_bwd_q_kernel", "na_bwd_kv_kernel", "na_bwd_q_tile_kernel", "na_bwd_kv_tile_kernel")
-
-    def a2_bytes(d):   # 8d convention: A2 train = 5*E*HW*B*4 = the bytes of fwd + bwd (the statistics passes add time, not bytes)
-        return sum(v["bytes"] for k, v in d.items() if k.startswith(("dw_fwd", "dw_bwd")))
-
-    if a2["total_us"] > 0:
-        e = _entry("row A2 (depthwise branches: fwd + 2 statistics passes + bwd)", dict(a2, bytes=a2_bytes(live)))
-        r["row_A2"] = {k: e[k] for k in ("kernel", "launches", "achieved", "peak", "unit", "frac")}
-        al = _group(alone, A2K)
+    # rows A2 / A7 under the 8d convention.  A2 train = 5*E*HW*B*esz: the forward (2 tensor passes) and the backward (3) declare
+    # them; the two BatchNorm statistics passes declare ZERO bytes (extra passes of this implementation: they add time, and PMC
+    # traffic, not algorithmic bytes).  A7 train = 11*C*HW*B*esz over the forward and the backward kernels.
+    ROWS = (("row_A2", "row A2 (depthwise branches: fwd + 2 statistics passes + bwd)",
+             ("dw_fwd_kernel", "dw_bwd_kernel", "dw_stats0_kernel", "dw_stats1_kernel")),
+            ("row_A7", "row A7 (fused neighborhood attention: fwd + bwd)",
+             ("na_fwd_kernel", "na_bwd_kernel", "na_bwd_q_kernel", "na_bwd_kv_kernel", "na_bwd_q_tile_kernel", "na_bwd_kv_tile_kernel")))
+    for key, label, names in ROWS:
+        grp = _group(live, names)
+        if grp["total_us"] <= 0:
+            continue
+        e = _entry(label, grp)
+        row = {k: e[k] for k in ("kernel", "launches", "achieved", "peak", "unit", "frac", "frac_vs_copy_ceiling")}
+        al = _group(alone, names)
         if al["total_us"] > 0:
-            r["row_A2"]["frac_alone"] = _entry("", dict(al, bytes=a2_bytes(alone)))["frac"]
-        for k, v in live.items():
-            if k.startswith(("dw_fwd_kernel", "dw_bwd_kernel")):
-                r["row_A2"][k] = {f: _entry(k, v)[f] for f in ("avg_us", "achieved", "frac")}
-                if k in alone:
-                    r["row_A2"][k]["frac_alone"] = _entry(k, alone[k])["frac"]
-    if a7["total_us"] > 0:
-        e = _entry("row A7 (fused neighborhood attention: fwd + query pass + key pass)", a7)
-        r["row_A7"] = {k: e[k] for k in ("kernel", "launches", "achieved", "peak", "unit", "frac")}
-        al = _group(alone, A7K)
-        if al["total_us"] > 0:
-            r["row_A7"]["frac_alone"] = _entry("", al)["frac"]
-        for k, v in live.items():
-            if k.startswith("na_fwd_kernel"):
-                r["row_A7"][k] = {f: _entry(k, v)[f] for f in ("avg_us", "achieved", "frac")}
-                if k in alone:
-                    r["row_A7"][k]["frac_alone"] = _entry(k, alone[k])["frac"]
+            row["frac_alone"] = _entry(label, al)["frac"]
+        members = {k: v for k, v in live.items() if k.split("<")[0] in names}
+        row["traffic_ratio"] = _traffic_ratio(members, None) if at_headline else None
+        for k, v in sorted(members.items()):
+            ek = _entry(k, v)
+            row[k] = {f: ek[f] for f in ("launches", "avg_us", "achieved", "frac")}
+            if k in alone:
+                row[k]["frac_alone"] = _entry(k, alone[k])["frac"]
+            if at_headline:
+                row[k]["traffic"] = pmc_traffic(k)
+        r[key] = row
     # the conv families, from the survey steps (every launch timed, four streams live): algorithmic bytes / FLOPs of all launches
     # of a family / the sum of their event durations, against the roofline that bounds the family as a whole
     fam = {"conv 1x1 fwd + dgrad (rows A1, A3, A6/A8 linears)": ("conv_tile_kernel<1,", "conv_tileM_kernel<1,"),
@@ -220,7 +237,10 @@ def roofline_block(dominant, live, survey, tot_us, B, H, W, step_s, alone, esz=4
                  "(*_alone: the same events over 3 further steps of this process with the extra streams switched off); "
                  "row_A2 / row_A7: their other kernels are timed over the same number of steps right after the timed region (the "
                  "events of ~90 more launches cost the headline 0.45 ms per step); "
-                 "traffic / mfma_util_pmc from the committed rocprofv3 PMC passes (profiles/)")
+                 "kernel names are instantiated names = the Name column of profiles/*_kernel_stats.csv minus `void ` and the "
+                 "parameter list; frac_vs_copy_ceiling = achieved / 6.29 TB/s (measured copy ceiling, SURVEY 8d); "
+                 "traffic / traffic_ratio / mfma_util_pmc from the committed rocprofv3 PMC passes (profiles/): HBM bytes per "
+                 "launch (FETCH_SIZE x2 + WRITE_SIZE) and their ratio to the algorithmic bytes")
     return r
 
 
@@ -401,6 +421,21 @@ def other_config(dev, dtype, B, size, steps=10, warmup=5):
                "whole_step": {"algorithmic_MB": round(mb, 1), "hbm_frac": round(mb / 1e3 / step_s / HBM_PEAK_GBS, 4),
                               "algorithmic_GFLOP": round(gf, 1), "mfma_peak_TFLOPs": _PEAK[0],
                               "mfma_frac": round(gf / 1e3 / step_s / _PEAK[0], 4)}}
+        # rows A2 / A7 of this configuration (8d bytes at this storage width), timed over 3 more steps outside the timed region
+        from lm_net_amd import hip
+        torch.cuda.synchronize()
+        hip.prof_begin("dw_|na_")
+        for _ in range(3):
+            r.step()
+        rows = hip.prof_end()
+        for key, names in (("row_A2", ("dw_fwd_kernel", "dw_bwd_kernel", "dw_stats0_kernel", "dw_stats1_kernel")),
+                           ("row_A7", ("na_fwd_kernel", "na_bwd_kernel", "na_bwd_q_kernel", "na_bwd_kv_kernel", "na_bwd_q_tile_kernel",
+                                       "na_bwd_kv_tile_kernel"))):
+            g = _group(rows, names)
+            if g["total_us"] > 0:
+                e = _entry(key, g)
+                ent[key] = {"ms_per_step": round(g["total_us"] / 3e3, 3), "achieved": e["achieved"], "unit": "GB/s", "frac": e["frac"],
+                            "frac_vs_copy_ceiling": round(e["achieved"] / COPY_CEILING_GBS, 4)}
     except Exception as e:       # never lose the headline because a side configuration misbehaved
         ent = {"value": None, "error": str(e)[:300], "dtype": dtype, "batch": B, "image": [3, size, size]}
     finally:

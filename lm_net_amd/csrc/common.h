@@ -51,9 +51,18 @@ void lmn_det_sum(hipStream_t st, const float* slots, int nslots, int64_t size, f
 bool lmn_prof_start(const char* kernel, hipStream_t st);
 void lmn_prof_stop(hipStream_t st);
 void lmn_prof_cost(double flops, double bytes);  // algorithmic cost of the NEXT launch of this thread (consumed by it)
+// The timer files a launch under the INSTANTIATED kernel name (`dw_fwd_kernel<float, true>`: template arguments resolved), the name
+// rocprofv3 prints for the same launch minus `void ` and the parameter list -- so a line of profiles/*_kernel_stats.csv and a record
+// of the timer are the same key.  lmn_kname demangles the type name of LmnKTag<&kernel> once per instantiation (runtime.hip).
+#ifdef __cplusplus
+#include <typeinfo>
+template <auto K> struct LmnKTag {};
+const char* lmn_kname(const char* tag_type_name);
+#define LMN_KNAME(kern) lmn_kname(typeid(LmnKTag<kern>).name())
+#endif
 #define LMN_LAUNCH(kern, grid, block, shmem, stream, ...)                        \
   do {                                                                           \
-    const bool _lmn_pf = g_lmn_prof_on && lmn_prof_start(#kern, (stream));       \
+    const bool _lmn_pf = g_lmn_prof_on && lmn_prof_start(LMN_KNAME(kern), (stream)); \
     hipLaunchKernelGGL(kern, grid, block, shmem, stream, __VA_ARGS__);           \
     if (_lmn_pf) lmn_prof_stop((stream));                                        \
   } while (0)

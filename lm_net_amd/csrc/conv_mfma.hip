@@ -2595,6 +2595,13 @@ __global__ __launch_bounds__(1024) void wgrad_reduce_batch_kernel(const lmn_redu
 
 thread_local char g_lmn_err[256] = {0};
 
+// (a function template of its own: only there is the `if constexpr` branch of the tile shapes wgrad3_kernel does not have discarded
+// without being instantiated)
+template <int M, int N, int PM>
+static void wgrad3_launch(dim3 grid, size_t shmem, hipStream_t st, const WgradParams& P) {
+  if constexpr (M * N == 4 || M * N == 1) LMN_LAUNCH((wgrad3_kernel<M, N, PM>), grid, dim3(256), shmem, st, P);
+}
+
 extern "C" {
 
 int lmn_abi_version(void) { return LMN_ABI_VERSION; }
@@ -3340,9 +3347,9 @@ int lmn_conv_wgrad(const lmn_wgrad_args_t* args, lmn_stream_t stream) {
     }                                                                                                               \
     if constexpr (T == 9 && (M * N == 4 || M * N == 1)) {                                                           \
       if (v1) {                                                                                                     \
-        if (pm == 2) LMN_LAUNCH((wgrad3_kernel<M, N, 2>), grid, dim3(256), shmem, st, P);                   \
-        else if (pm == 1) LMN_LAUNCH((wgrad3_kernel<M, N, 1>), grid, dim3(256), shmem, st, P);              \
-        else LMN_LAUNCH((wgrad3_kernel<M, N, 0>), grid, dim3(256), shmem, st, P);                           \
+        if (pm == 2) wgrad3_launch<M, N, 2>(grid, shmem, st, P);                                                    \
+        else if (pm == 1) wgrad3_launch<M, N, 1>(grid, shmem, st, P);                                               \
+        else wgrad3_launch<M, N, 0>(grid, shmem, st, P);                                                            \
         goto wg_reduce_##T##M##N;                                                                                   \
       }                                                                                                             \
     }                                                                                                               \

@@ -1086,7 +1086,10 @@ static int launch_dw_stats(const void* x1, const void* pre, const void* u, const
   const int64_t nblk = (int64_t)B * strips * chunks * nseg;
   (void)segs;
   if (nblk >= (1LL << 31)) return -1;
-  if (g_lmn_prof_on) lmn_prof_cost(2.0 * 42 * (double)B * H * W * E, (act_dtype == LMN_BF16 ? 2.0 : 4.0) * (MODE == 0 ? 1 : 4) * (double)B * H * W * E);
+  // row A2 is priced at 2 tensor passes forward + 3 backward (lmn_dw_fwd / lmn_dw_bwd declare them).  The two BatchNorm
+  // statistics passes are extra passes of this implementation: they declare ZERO algorithmic bytes (their time lowers row A2's
+  // achieved fraction; what they physically move -- 1 resp. 4 tensor passes -- is the PMC `traffic` of the bench line)
+  if (g_lmn_prof_on) lmn_prof_cost(2.0 * 42 * (double)B * H * W * E, 0.0);
   float* sdst = stats;
   const int nslots = B * nseg * strips, NS = MODE == 0 ? 8 : 5;
   if (g_lmn_det) {   // per-block sums into slot copies of [NS][E], folded in fixed order below

@@ -7,7 +7,10 @@
 // the cross-stream dependencies re-created by events -- without any host code per kernel.
 #include "common.h"
 
+#include <cxxabi.h>
+
 #include <chrono>
+#include <cstdlib>
 #include <map>
 #include <mutex>
 #include <string>
@@ -94,6 +97,37 @@ void lmn_rec_push(std::function<int()>&& f, const char* what) {
     p->ops.push_back(std::move(f));
     p->names.push_back(what);
   }
+}
+
+// "N2..7LmnKTagIXadL_Z...EEE" -> "dw_fwd_kernel<float, true>".  The host demangler of this image predates the bf16 type code
+// (DF16b): it is swapped for `t` (unsigned short, a builtin like it, so substitution indices are unchanged; no kernel takes a u16) and
+// swapped back in the text.
+const char* lmn_kname(const char* tag) {
+  static std::mutex mu;
+  static std::map<const char*, std::string> names;
+  std::lock_guard<std::mutex> lk(mu);
+  auto it = names.find(tag);
+  if (it != names.end()) return it->second.c_str();
+  std::string m(tag);
+  for (size_t p; (p = m.find("DF16b")) != std::string::npos;) m.replace(p, 5, "t");
+  int status = 0;
+  char* d = abi::__cxa_demangle(m.c_str(), nullptr, nullptr, &status);
+  std::string s = (status == 0 && d) ? d : tag;
+  free(d);
+  for (size_t p; (p = s.find("(anonymous namespace)::")) != std::string::npos;) s.erase(p, 23);
+  for (size_t p; (p = s.find("unsigned short")) != std::string::npos;) s.replace(p, 14, "__bf16");
+  size_t b = s.find("&(void ");           // LmnKTag<&(void NAME<ARGS>(PARAMS))>
+  if (b != std::string::npos) {
+    b += 7;
+    size_t e = b;
+    for (int depth = 0; e < s.size(); ++e) {
+      if (s[e] == '<') ++depth;
+      else if (s[e] == '>') --depth;
+      else if (s[e] == '(' && depth == 0) break;
+    }
+    s = s.substr(b, e - b);
+  }
+  return names.emplace(tag, std::move(s)).first->second.c_str();
 }
 
 void lmn_prof_cost(double flops, double bytes) {

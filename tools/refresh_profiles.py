@@ -14,7 +14,7 @@ import csv, glob, json, os, shutil, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(ROOT, "gpurun_out", sys.argv[1])
 dst = os.path.join(ROOT, "profiles")
-PFX = (sys.argv[2] if len(sys.argv) > 2 else "r03") + "_"      # round prefix of the files written
+PFX = (sys.argv[2] if len(sys.argv) > 2 else "r04") + "_"      # round prefix of the files written
 
 
 def last_json(path):
@@ -75,5 +75,6 @@ json.dump(dict(note="rocprofv3 --pmc passes over `python3 bench.py --steps 2 --w
                                serialized_gpu_ms_at_2p4GHz=round(tot_cyc / STEPS / 2.4e6, 2)),
                kernels=out), open(os.path.join(dst, PFX + "pmc.json"), "w"), indent=1)
 print(json.dumps(json.load(open(os.path.join(dst, PFX + "pmc.json")))["whole_step"]))
-for k in ("wgrad_lds_kernel<9, 2, 2, 0>", "dw_fwd_strip_kernel<float>", "dw_bwd_strip_kernel<float, 0, true>", "na_fwd_kernel<1, float>"):
+for k in ("wgrad3_kernel<2, 2, 0>", "dw_fwd_kernel<float, true>", "dw_bwd_kernel<float, 0, true, true, 2>", "dw_stats1_kernel<float, true>",
+          "na_fwd_kernel<1, float>"):
     print(k, {a: (round(b) if b > 10 else b) for a, b in out.get(k, {}).items()})
