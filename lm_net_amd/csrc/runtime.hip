@@ -116,9 +116,10 @@ const char* lmn_kname(const char* tag) {
   free(d);
   for (size_t p; (p = s.find("(anonymous namespace)::")) != std::string::npos;) s.erase(p, 23);
   for (size_t p; (p = s.find("unsigned short")) != std::string::npos;) s.replace(p, 14, "__bf16");
-  size_t b = s.find("&(void ");           // LmnKTag<&(void NAME<ARGS>(PARAMS))>
+  size_t b = s.find("&(void ");           // LmnKTag<&(void NAME<ARGS>(PARAMS))>, or LmnKTag<&NAME> / LmnKTag<&NAME(PARAMS)> of a plain function
+  if (b != std::string::npos) b += 7;
+  else if ((b = s.find("<&")) != std::string::npos) { b += 2; if (s.back() == '>') s.pop_back(); }
   if (b != std::string::npos) {
-    b += 7;
     size_t e = b;
     for (int depth = 0; e < s.size(); ++e) {
       if (s[e] == '<') ++depth;
