@@ -473,16 +473,31 @@ __global__ __launch_bounds__(256, 4) void dw_fwd_kernel(const TA* __restrict__ x
   for (int e = tid; e < E; e += 256)
     m[e] = __hip_atomic_fetch_add(gsum + (int64_t)g.b * E + e, 0.0f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) * SE.inv_hw;
   __syncthreads();
-  for (int r = tid; r < R; r += 256) {
-    float a = SE.b1[r];
-    for (int e = 0; e < E; ++e) a += SE.w1[(int64_t)r * E + e] * m[e];
-    a = a > 0.f ? a : 0.f;
-    h[r] = a;
-    SE.hidden[(int64_t)g.b * R + r] = a;
+  // (this tail is serial latency at the end of the kernel: one thread per hidden unit walking E loads cost 13 us at E = 192.
+  // G = 256 / R threads per hidden unit, each a strided part of the row with 8 loads in flight, partials through LDS.)
+  float* part = scr + E + R;   // [256]  (E + R + 256 <= 2048: checked on the host)
+  for (int r0 = 0; r0 < R; r0 += 256) {
+    const int G = R - r0 >= 256 ? 1 : 256 / (R - r0);
+    const int r = r0 + tid / G, q = tid - (tid / G) * G;
+    float a = 0.f;
+    if (r < R) {
+#pragma unroll 8
+      for (int e = q; e < E; e += G) a += SE.w1[(int64_t)r * E + e] * m[e];
+    }
+    part[tid] = a;
+    __syncthreads();
+    if (q == 0 && r < R) {
+      float v = SE.b1[r];
+      for (int k = 0; k < G; ++k) v += part[tid + k];
+      v = v > 0.f ? v : 0.f;
+      h[r] = v;
+      SE.hidden[(int64_t)g.b * R + r] = v;
+    }
+    __syncthreads();
   }
-  __syncthreads();
   for (int e = tid; e < E; e += 256) {
     float a = SE.b2[e];
+#pragma unroll 8
     for (int r = 0; r < R; ++r) a += SE.w2[(int64_t)e * R + r] * h[r];
     SE.s[(int64_t)g.b * E + e] = lmn_hsigmoid(a);
   }
@@ -514,6 +529,27 @@ __global__ __launch_bounds__(256, 3) void dw_stats1_kernel(const TA* __restrict_
   f32x2* XS0 = XSa[wv][0];
   if (lane < 8) XS0[(lane >> 2) * 68 + ((lane & 3) < 2 ? (lane & 3) : 64 + (lane & 3))] = f32x2{0.f, 0.f};
   f32x2 sv = g.cok ? f32x2{sgate[(int64_t)g.b * E + g.ch], sgate[(int64_t)g.b * E + g.ch + 1]} : f32x2{0.f, 0.f};
+  if (zt) __syncthreads();
+  const f32x2 pa = zt ? f32x2{pre_s[wv * 2], pre_s[wv * 2 + 1]} : f32x2{0.f, 0.f};
+  const f32x2 ps = zt ? f32x2{pre_s[8 + wv * 2], pre_s[8 + wv * 2 + 1]} : f32x2{0.f, 0.f};
+  const int cx = g.xs - 2 + lane;
+  const bool col_in = cx >= 0 && cx < W && g.cok;
+  const float cm = col_in ? 1.f : 0.f;
+  const bool ovalid = lane >= 2 && lane < 62 && cx < W && g.cok;
+  const float om = ovalid ? 1.f : 0.f;
+  const unsigned voff = col_in ? (unsigned)(cx * 4 + (g.ch & 3)) * (unsigned)ES : OOB;
+  const unsigned vst = ovalid ? voff : OOB;
+  const BufRsrc rz = make_rsrc(x1, NREC), rp = make_rsrc(pre, NREC), ru = make_rsrc(u, NREC), ro = make_rsrc(dpre, NREC);
+  const int rows = g.ye - g.ys, nsteps = rows + 4;
+  f32x2 pf[5], pp[5], pu[5];
+#pragma unroll
+  for (int d = 0; d < D; ++d) {
+    pf[d] = ld_pair<TA>(rz, voff, row_off(g, g.ys - 2 + d, H));
+    const unsigned so = row_off(g, g.ys + d, H);
+    pp[d] = ld_pair<TA>(rp, vst, so);
+    pu[d] = ld_pair<TA>(ru, vst, so);
+  }
+  // (the first rows are in flight while the squeeze-excite vector below is formed)
   f32x2 dv = f32x2{0.f, 0.f};
   if (SB.ds) {
     // squeeze-excite backward of image b (lmn_se_bwd_t, lmn_se_bwd_dm arithmetic), formed by every block for its own channels:
@@ -535,8 +571,10 @@ __global__ __launch_bounds__(256, 3) void dw_stats1_kernel(const TA* __restrict_
     for (int r0 = 0; r0 < R; r0 += 256) {
       const int gq = tid / R, r = r0 + (R <= 256 ? tid - gq * R : tid);
       float a = 0.f;
-      if (gq < groups && r < R)
+      if (gq < groups && r < R) {
+#pragma unroll 8
         for (int e = gq; e < E; e += groups) a += SB.w2[(int64_t)e * R + r] * dt[e];
+      }
       part[tid] = a;
       __syncthreads();
       if (tid < R - r0 && tid < 256) {
@@ -550,36 +588,20 @@ __global__ __launch_bounds__(256, 3) void dw_stats1_kernel(const TA* __restrict_
       }
       __syncthreads();
     }
+    // dm of the wave's channel pair: lanes over r (a chain of 2 R dependent loads before: this prologue delays every block's first row)
     float d2[2] = {0.f, 0.f};
-#pragma unroll
-    for (int k = 0; k < 2; ++k) {
-      float a = 0.f;
-      for (int r = 0; r < R; ++r) a += SB.w1[(int64_t)r * E + g.ch + k] * da[r];
-      d2[k] = a * SB.inv_hw;
+    if (g.cok) {
+      for (int r = lane; r < R; r += 64) {
+        const float d = da[r];
+        d2[0] += SB.w1[(int64_t)r * E + g.ch] * d;
+        d2[1] += SB.w1[(int64_t)r * E + g.ch + 1] * d;
+      }
     }
-    dv = g.cok ? f32x2{d2[0], d2[1]} : f32x2{0.f, 0.f};
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { d2[0] += __shfl_xor(d2[0], o, 64); d2[1] += __shfl_xor(d2[1], o, 64); }
+    dv = g.cok ? f32x2{d2[0] * SB.inv_hw, d2[1] * SB.inv_hw} : f32x2{0.f, 0.f};
   } else {
     dv = g.cok ? f32x2{dm[(int64_t)g.b * E + g.ch], dm[(int64_t)g.b * E + g.ch + 1]} : f32x2{0.f, 0.f};
-  }
-  if (zt) __syncthreads();
-  const f32x2 pa = zt ? f32x2{pre_s[wv * 2], pre_s[wv * 2 + 1]} : f32x2{0.f, 0.f};
-  const f32x2 ps = zt ? f32x2{pre_s[8 + wv * 2], pre_s[8 + wv * 2 + 1]} : f32x2{0.f, 0.f};
-  const int cx = g.xs - 2 + lane;
-  const bool col_in = cx >= 0 && cx < W && g.cok;
-  const float cm = col_in ? 1.f : 0.f;
-  const bool ovalid = lane >= 2 && lane < 62 && cx < W && g.cok;
-  const float om = ovalid ? 1.f : 0.f;
-  const unsigned voff = col_in ? (unsigned)(cx * 4 + (g.ch & 3)) * (unsigned)ES : OOB;
-  const unsigned vst = ovalid ? voff : OOB;
-  const BufRsrc rz = make_rsrc(x1, NREC), rp = make_rsrc(pre, NREC), ru = make_rsrc(u, NREC), ro = make_rsrc(dpre, NREC);
-  const int rows = g.ye - g.ys, nsteps = rows + 4;
-  f32x2 pf[5], pp[5], pu[5];
-#pragma unroll
-  for (int d = 0; d < D; ++d) {
-    pf[d] = ld_pair<TA>(rz, voff, row_off(g, g.ys - 2 + d, H));
-    const unsigned so = row_off(g, g.ys + d, H);
-    pp[d] = ld_pair<TA>(rp, vst, so);
-    pu[d] = ld_pair<TA>(ru, vst, so);
   }
   const f32x2 z2 = f32x2{0.f, 0.f};
   f32x2 G[25], hist[5], sum0 = z2;
@@ -1136,7 +1158,7 @@ static int se_fuse_check(const lmn_se_fuse_t* se, lmn_se_fuse_t* out, int E, con
   memset(out, 0, sizeof(*out));
   if (!se || !se->ticket) return 0;
   LMN_REQUIRE(se->w1 && se->b1 && se->w2 && se->b2 && se->s && se->hidden && se->R > 0 && se->inv_hw > 0.f, "%s: squeeze-excite operands", what);
-  LMN_REQUIRE(E + se->R <= 2048, "%s: E + R = %d exceeds the block's scratch", what, E + se->R);
+  LMN_REQUIRE(E + se->R + 256 <= 2048, "%s: E + R = %d exceeds the block's scratch", what, E + se->R);
   *out = *se;
   return 0;
 }
