@@ -1151,11 +1151,11 @@ __device__ __forceinline__ float pack_element(const float* __restrict__ w, const
   const int NCTT = (nrows + 15) / 16;
   const int j = (int)(i & 3);
   const int lane = (int)((i >> 2) & 63);
-  int64_t t = i >> 8;
-  const int ct = (int)(t % NCTT);
-  t /= NCTT;
-  const int kb = (int)(t % NKB);
-  const int tap = (int)(t / NKB);
+  uint32_t t = (uint32_t)(i >> 8);   // (a packed weight has < 2^31 elements: 32-bit divisions -- the 64-bit ones were most of this kernel's time)
+  const int ct = (int)(t % (uint32_t)NCTT);
+  t /= (uint32_t)NCTT;
+  const int kb = (int)(t % (uint32_t)NKB);
+  const int tap = (int)(t / (uint32_t)NKB);
   int s = 0;
   while (s + 1 < g.nsrc && kb >= kboff[s + 1]) ++s;
   // MFMA j of a K16 block covers channels 4j .. 4j+3 (k slot = lane >> 4): a source whose last block holds fewer than
@@ -2717,6 +2717,7 @@ int lmn_conv_pack(const float* w, float* wpack, int ksize, int Cout, int Cin, in
   }
   const int nrows = transposed ? rows : (Cout + 3) / 4 * 4;
   const int64_t total = lmn_conv_pack_size(ksize, nrows, nsrc, c);
+  LMN_REQUIRE(total < (1LL << 31), "conv_pack: %lld packed elements (32-bit index arithmetic)", (long long)total);
   const int blocks = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
   PackGeom g;
   g.taps = ksize * ksize; g.Cout = Cout; g.Cin = Cin; g.nsrc = nsrc;

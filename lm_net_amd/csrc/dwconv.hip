@@ -45,6 +45,9 @@ __device__ __forceinline__ f32x2 wave_total(f32x2 v) { return f32x2{wave_total(v
 
 // the lanes of ONE wave exchange data through LDS: hipcc sees no per-thread alias between a lane's store and its reads of the
 // neighbours' slots (it hoisted the reads above the store), so both directions get a code-free wave-level fence
+#ifndef LMN_DWF_OCC
+#define LMN_DWF_OCC 3
+#endif
 #define LMN_WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
 #define LMN_SB() __builtin_amdgcn_sched_barrier(0)
 
@@ -74,6 +77,60 @@ template <typename TA> __device__ __forceinline__ void st_one(BufRsrc r, unsigne
 // Zero padding: rows / columns / channels outside the tensor must stay 0 AFTER the transform -> explicit 0 / 1 factors.
 typedef lmn_dw_pre_t DwPreK;   // A / shift [E] (NULL: the tensor holds x1, no transform); fin.mode LMN_FIN_BN: formed in the kernel
 struct DwPreS { const float* A; const float* shift; };   // the same without the finalisation (kernel arguments of the other passes)
+// ---- nn.GELU() (erf form) and its derivative on a channel pair, in packed arithmetic.
+// erf(u) = u A P(t) / Q(t), t = u^2, |u| <= 4 (erf(4) = 1 - 1.5e-8): an [11/10] rational form fitted here (weighted least squares
+// on Chebyshev nodes, fit error 2.3e-8), P and Q monic so that each Horner chain starts with an add.  Evaluated in fp32:
+// |gelu error| <= 2.6e-7 max(|x|, 1), |gelu' error| <= 3.2e-7 (checked against scipy over [-12, 12] in steps of 1e-5).
+// The scalar lmn_erf (7.1.26: exp + rcp + a 5-term polynomial per element: 17 VALU instructions, two of them quarter-rate, plus
+// their wait states) was as much issue time in the forward as the 25-tap stencil; here a pair costs 17 packed instructions + 2 rcp.
+// The constants travel as halves of SGPR pairs selected by op_sel (hipcc builds {c, c} VGPR pairs with two v_mov per use otherwise).
+#define LMN_PK_K(NAME, OP, ARGS, LO, HI)                                                                        \
+  __device__ __forceinline__ f32x2 NAME(f32x2 a, f32x2 b, f32x2 kp, int hi) {                                   \
+    f32x2 r;                                                                                                    \
+    if (hi) asm(OP " %0, " ARGS " " HI : "=v"(r) : "v"(a), "v"(b), "s"(kp));                                   \
+    else asm(OP " %0, " ARGS " " LO : "=v"(r) : "v"(a), "v"(b), "s"(kp));                                      \
+    return r;                                                                                                   \
+  }
+LMN_PK_K(pk_fma_k, "v_pk_fma_f32", "%1, %2, %3", "op_sel_hi:[1,1,0]", "op_sel:[0,0,1] op_sel_hi:[1,1,1]")   // a * b + k
+LMN_PK_K(pk_add_k, "v_pk_add_f32", "%1, %3", "op_sel_hi:[1,0]", "op_sel:[0,1] op_sel_hi:[1,1]")              // a + k   (b unused)
+LMN_PK_K(pk_mul_k, "v_pk_mul_f32", "%1, %3", "op_sel_hi:[1,0]", "op_sel:[0,1] op_sel_hi:[1,1]")              // a * k   (b unused)
+LMN_PK_K(pk_mad_k, "v_pk_fma_f32", "%1, %3, %2", "op_sel_hi:[1,0,1]", "op_sel:[0,1,0] op_sel_hi:[1,1,1]")   // a * k + b
+#undef LMN_PK_K
+struct ErfQ { f32x2 u, pr; };   // clamped argument, P(t) / Q(t)
+__device__ __forceinline__ ErfQ erf_parts(f32x2 x) {
+  const f32x2 K0 = {0.70710678118654752440f, 1.443648930e+02f}, K1 = {1.985670226e+03f, 2.685849656e+04f},
+              K2 = {9.820033276e+04f, 5.689660988e+05f}, K3 = {3.201790747e+01f, 4.086303418e+02f},
+              K4 = {3.091390772e+03f, 1.349988240e+04f}, K5 = {2.668350604e+04f, 0.f};
+  f32x2 u = pk_mul_k(x, x, K0, 0);
+  u.x = __builtin_amdgcn_fmed3f(u.x, -4.f, 4.f);
+  u.y = __builtin_amdgcn_fmed3f(u.y, -4.f, 4.f);
+  const f32x2 t = u * u;
+  f32x2 p = pk_add_k(t, t, K0, 1);
+  p = pk_fma_k(p, t, K1, 0);
+  p = pk_fma_k(p, t, K1, 1);
+  p = pk_fma_k(p, t, K2, 0);
+  p = pk_fma_k(p, t, K2, 1);
+  f32x2 q = pk_add_k(t, t, K3, 0);
+  q = pk_fma_k(q, t, K3, 1);
+  q = pk_fma_k(q, t, K4, 0);
+  q = pk_fma_k(q, t, K4, 1);
+  q = pk_fma_k(q, t, K5, 0);
+  return ErfQ{u, p * f32x2{__builtin_amdgcn_rcpf(q.x), __builtin_amdgcn_rcpf(q.y)}};
+}
+__device__ __forceinline__ f32x2 gelu2(f32x2 x) {   // x / 2 + (x A / 2) u P / Q
+  const f32x2 KA = {2.645949311e-02f, 0.39894228040143267794f};
+  const ErfQ e = erf_parts(x);
+  const f32x2 m = (pk_mul_k(x, x, KA, 0) * e.u) * e.pr;
+  return x * 0.5f + m;
+}
+__device__ __forceinline__ f32x2 dgelu2(f32x2 x) {   // 1/2 + (A / 2) u P / Q + x exp(-x^2 / 2) / sqrt(2 pi)
+  const f32x2 KA = {2.645949311e-02f, 0.39894228040143267794f}, KE = {-0.72134752044448170368f, 0.f};
+  const ErfQ e = erf_parts(x);
+  const f32x2 m = pk_mul_k(e.u, e.u, KA, 0) * e.pr + 0.5f;
+  const f32x2 a = pk_mul_k(x * x, x, KE, 0);   // -x^2 / 2 in base 2
+  const f32x2 xe = x * f32x2{__builtin_amdgcn_exp2f(a.x), __builtin_amdgcn_exp2f(a.y)};
+  return pk_mad_k(xe, m, KA, 1);
+}
 __device__ __forceinline__ f32x2 hswish2(f32x2 z, f32x2 a, f32x2 s) {
   const f32x2 x = z * a + s;
   f32x2 t = x * (1.f / 6.f) + 0.5f;
@@ -325,7 +382,7 @@ __global__ __launch_bounds__(256, 4) void dw_stats0_kernel(const TA* __restrict_
 // Forward (flagship HBM-bound kernel of row A2): pre = merged 5x5 (+ bias) -> store; gsum[b][e] += sum GELU(pre) (SE squeeze), and
 // optionally the squeeze-excite gate of an image by the block that completes its sums (lmn_se_fuse_t).
 template <typename TA, bool ZT>
-__global__ __launch_bounds__(256, 4) void dw_fwd_kernel(const TA* __restrict__ x1, TA* __restrict__ pre, float* __restrict__ gsum, int H, int W,
+__global__ __launch_bounds__(256, LMN_DWF_OCC) void dw_fwd_kernel(const TA* __restrict__ x1, TA* __restrict__ pre, float* __restrict__ gsum, int H, int W,
                                                          int E, const float* __restrict__ keff, const float* __restrict__ beff, const DwFin FN,
                                                          const lmn_se_fuse_t SE, const DwPreS PRE, int strips, int segs, int seg_rows, int chunks,
                                                          int det, int nimg) {
@@ -435,7 +492,7 @@ __global__ __launch_bounds__(256, 4) void dw_fwd_kernel(const TA* __restrict__ x
     if (j >= 4 && j < nsteps) {                                                                                    \
       const f32x2 pv = acc[DD] + bias;                                                                             \
       st_pair<TA>(ro, vst, row_off(g, g.ys + j - 4, H), pv);                                                       \
-      gs += f32x2{lmn_gelu(pv.x), lmn_gelu(pv.y)};                                                                 \
+      gs += gelu2(pv);                                                                                                \
     }                                                                                                              \
     _Pragma("unroll") for (int d = 0; d < 5; ++d) in[d] = inn[d];                                                  \
     LMN_SB();                                                                                                      \
@@ -633,7 +690,7 @@ __global__ __launch_bounds__(256, 3) void dw_stats1_kernel(const TA* __restrict_
     LMN_WAVE_SYNC();                                                                                               \
     inn[0] = XS[lane]; inn[1] = XS[lane + 1]; inn[2] = x1n; inn[3] = XS[lane + 3]; inn[4] = XS[lane + 4];          \
     const bool rok = j < rows;                                                                                     \
-    f32x2 d = (uv * sv + dv) * f32x2{lmn_dgelu(pv.x), lmn_dgelu(pv.y)} * (rok ? om : 0.f);                          \
+    f32x2 d = (uv * sv + dv) * dgelu2(pv) * (rok ? om : 0.f);                                                   \
     st_pair<TA>(ro, rok ? vst : OOB, row_off(g, g.ys + j, H), d);                                                  \
     sum0 += d;                                                                                                     \
     hist[P] = d;                                                                                                   \
