@@ -564,7 +564,10 @@ class LM_Net(nn.Module):
             eng.begin_pass(False, x.device)
             try:
                 out = self._forward_body(x, cx)
-                eng.flush_reduce(x.device)        # (weight-gradient-style launches of the forward: the moments of the z-path)
+                # weight-gradient-style launches of the forward (the moments of the z-path, on the weight-gradient stream): reduced and
+                # JOINED here, so that the backward's lmn_reparam_wfin depends on them whatever stream / overlap setting it runs
+                # with (the side stream is idle at the end of the forward: the join costs nothing)
+                eng.join_side(x.device)
             finally:
                 nf = eng.alloc_floats
                 eng.end_pass()

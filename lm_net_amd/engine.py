@@ -164,6 +164,7 @@ class Engine:
         # z-path of ReparamConv (include/lmnet_hip.h, lmn_dw_pre_t / lmn_reparam_fold): the expand conv's BatchNorm + Hardswish
         # applied inside the depthwise kernels, its backward folded into the weights of one three-source conv (LMN_ZPATH=0: A/B)
         self.zpath = os.environ.get("LMN_ZPATH", "1") != "0"
+        self.zpath_lds = 65536    # bytes of LDS lmn_reparam_fold may use (35 E floats): wider blocks keep the two-pass BatchNorm form (E > 468)
         # weight gradients of the branch chains issued late, beside the encoder's backward (LMN_LAZY_WGRAD=0: A/B runs)
         self.lazy_wgrad = os.environ.get("LMN_LAZY_WGRAD", "1") != "0"
         self.lazy_on = False
@@ -401,12 +402,12 @@ class Engine:
             saved = hip._STREAM[0]
             hip._STREAM[0] = hip.C.c_void_p(key)
             try:
-                tab = hip.wgrad_reduce_flush()
+                tabs = hip.wgrad_reduce_flush()
                 for fn in fns or ():
                     fn()
             finally:
                 hip._STREAM[0] = saved
-            if tab is not None:
+            for tab in tabs:
                 self.reduce_tabs.append(tab)
                 if self.arena is None and stream is not None:
                     tab.record_stream(stream)
@@ -457,7 +458,7 @@ class Engine:
         wpe = hip.conv_pack(ec.weight, 1, [x.shape[-1]])   # (a 3-channel weight on the NHWC4 input: zero column packed)
         x1 = _R(x, B, H, W, E)
         # (lmn_reparam_fold keeps two [E]-wide operator panels of the expand conv in LDS: wider blocks take the two-pass BatchNorm form)
-        zpath = self.training and self.fuse_bn and self.zpath and not m.deploy and 35 * E * 4 <= 65536
+        zpath = self.training and self.fuse_bn and self.zpath and not m.deploy and 35 * E * 4 <= self.zpath_lds
         zp = None
         if zpath:
             # z-path: ONE pass writes z = conv(x) + bias and its batch sums; the depthwise kernels form x1 = Hardswish(A1 z + sh1)

@@ -528,28 +528,46 @@ def wgrad_reduce_pending(key=None):
     return len(_RJOBS.get(key, ()))
 
 
+def _reduce_targets(j):
+    return {int(v) for v in (j.dW, j.dW_src[0], j.dW_src[1], j.dW_src[2], j.db, j.db2) if v}
+
+
 def wgrad_reduce_flush():
     """Sum the block partials of every deferred weight gradient of the CURRENT launch stream in one launch.  Returns the
-    device job table (the caller keeps it alive while a recorded plan references it) or None."""
+    device job tables (the caller keeps them alive while a recorded plan references them); [] when nothing was pending.
+    The batched kernel adds into its destinations with plain read-modify-writes, so two jobs of one launch must not share a
+    destination (a weight used twice, a module called twice, accumulation into one explicit dW): such jobs are split into
+    consecutive launches, which the stream serialises as the per-layer reduce launches used to."""
     key = stream_key()
     jobs = _RJOBS.pop(key, None)
     if not jobs:
-        return None
-    arr = (ReduceJob * len(jobs))()
-    blk = 0
-    for i, (j, _) in enumerate(jobs):
-        j.first_block = blk
-        C.memmove(C.byref(arr[i]), C.byref(j), C.sizeof(ReduceJob))
-        blk += j.gy * j.blocks_per_set
-    raw = bytes(arr)
-    dev = jobs[0][1].device
-    tab = _RTABLES.get((dev, raw))
-    if tab is None:
-        if len(_RTABLES) > 4096:
-            _RTABLES.clear()
-        tab = _RTABLES[(dev, raw)] = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(dev)
-    _check(load().lmn_wgrad_reduce_batch(C.c_void_p(tab.data_ptr()), len(jobs), _i64(blk), _stream()), "wgrad_reduce_batch")
-    return tab
+        return []
+    groups, seen = [[]], set()
+    for job in jobs:
+        t = _reduce_targets(job[0])
+        if groups[-1] and (t & seen):
+            groups.append([])
+            seen = set()
+        groups[-1].append(job)
+        seen |= t
+    tabs = []
+    for grp in groups:
+        arr = (ReduceJob * len(grp))()
+        blk = 0
+        for i, (j, _) in enumerate(grp):
+            j.first_block = blk
+            C.memmove(C.byref(arr[i]), C.byref(j), C.sizeof(ReduceJob))
+            blk += j.gy * j.blocks_per_set
+        raw = bytes(arr)
+        dev = grp[0][1].device
+        tab = _RTABLES.get((dev, raw))
+        if tab is None:
+            if len(_RTABLES) > 4096:
+                _RTABLES.clear()
+            tab = _RTABLES[(dev, raw)] = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(dev)
+        _check(load().lmn_wgrad_reduce_batch(C.c_void_p(tab.data_ptr()), len(grp), _i64(blk), _stream()), "wgrad_reduce_batch")
+        tabs.append(tab)
+    return tabs
 
 
 def wgrad_reduce_drop():

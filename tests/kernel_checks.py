@@ -226,6 +226,25 @@ def check_conv_wgrad():
     rows.append(("conv_wgrad per-source large dW[0]", rel(parts[0], w.grad[:, :24]), 2e-4))
     rows.append(("conv_wgrad per-source large dW[1]", rel(parts[1], w.grad[:, 24:]), 2e-4))
     rows.append(("conv_wgrad per-source large db/db2", rel(db1 + db2, 2 * dy.sum((0, 2, 3))), 2e-4))
+    # deferred K-split reductions that share a destination (a weight used by two calls): the batched reduce adds with plain
+    # read-modify-writes, so hip.wgrad_reduce_flush must put such jobs into consecutive launches -- dW = sum of both calls
+    B, H, W, cin, cout = 2, 64, 64, 24, 24
+    x1, x2 = R(B, cin, H, W, seed=51), R(B, cin, H, W, seed=52)
+    w = R(cout, cin, 3, 3, seed=53, scale=0.1).requires_grad_(True)
+    b = R(cout, seed=54).requires_grad_(True)
+    y1, y2 = F.conv2d(x1, w, b, padding=1), F.conv2d(x2, w, b, padding=1)
+    d1, d2 = R(*y1.shape, seed=55), R(*y2.shape, seed=56)
+    (y1 * d1).sum().backward()
+    (y2 * d2).sum().backward()
+    dW, db = torch.zeros(cout, cin, 3, 3, device=DEV), torch.zeros(cout, device=DEV)
+    keep = [hip.conv_wgrad([nhwc(xx)], nhwc(dd), dW, db, B=B, Hin=H, Win=W, Hout=H, Wout=W, Cout=cout, ksize=3, defer=True)
+            for xx, dd in ((x1, d1), (x2, d2))]
+    ntab = len(hip.wgrad_reduce_flush())
+    torch.cuda.synchronize()
+    if keep[0] is not None:   # (both calls really deferred a K-split reduction)
+        rows.append(("conv_wgrad deferred, shared destination: launches", abs(ntab - 2), 0))
+    rows.append(("conv_wgrad deferred, shared destination dW", rel(dW, w.grad), 2e-4))
+    rows.append(("conv_wgrad deferred, shared destination db", rel(db, b.grad), 2e-4))
     return rows
 
 

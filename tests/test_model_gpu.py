@@ -193,6 +193,38 @@ def test_non_square_and_odd_tile_sizes_vs_oracle():
         assert err < 2e-3 * float(po.grad.abs().max()) or err < 5e-5 * gmax, (k, err)
 
 
+def test_zpath_gate_per_block_vs_oracle():
+    """`lmn_reparam_fold` stages two W_e panels of 35 E floats in 64 KB of LDS, so engine.reparam_fwd takes the z-path per block only
+    while 35 * E * 4 <= engine.zpath_lds and the two-pass BatchNorm form beyond (E > 468; the model's other kernels stop at 512
+    channels, so no LM_Net reaches it: here the limit is lowered to E = 48, which puts levels 0-1 on the z-path and levels 2-3 on
+    the other form IN ONE STEP).  Logits and every gradient of a training step against the CPU oracle."""
+    from oracle.lmnet_ref import LM_Net as Oracle
+    from lm_net_amd import hip
+    ora = Oracle(3, 2)
+    fill_module(ora, 13)
+    no_dropout(ora)
+    m = _net(seed=13)
+    m._engine.zpath_lds = 35 * 48 * 4
+    x = det_input((2, 3, 32, 48), "gate/x")
+    ora.train(); m.train()
+    xo = x.clone().requires_grad_(True)
+    xg = x.cuda().requires_grad_(True)
+    hip.prof_begin("reparam_fold|dw_stats0")
+    yo, yg = ora(xo), m(xg)
+    assert rel_err(yg, yo) < TOL
+    G = det_input(tuple(yo.shape), "gate/G")
+    (yo * G).sum().backward()
+    (yg * G.cuda()).sum().backward()
+    prof = hip.prof_end()
+    folds = sum(v["launches"] for k, v in prof.items() if k.startswith("reparam_fold"))
+    assert folds == 8, prof          # the 2 x 2 encoder + 2 x 2 decoder blocks of levels 0-1; the other 8 blocks took the other path
+    assert rel_err(xg.grad, xo.grad) < 2e-3
+    gmax = max(float(p.grad.abs().max()) for p in ora.parameters())
+    for (k, po), (_, pg) in zip(ora.named_parameters(), m.named_parameters()):
+        err = float((pg.grad.cpu() - po.grad).abs().max())
+        assert err < 4e-3 * float(po.grad.abs().max()) or err < 5e-5 * gmax, (k, err)
+
+
 @pytest.mark.parametrize("K", [5, 7])
 def test_larger_neighborhood_window_vs_oracle(K):
     """natten kernel_size 5 / 7 in the four NAT blocks (the reference's LM_Net signature carries [3, 5], core/LM_Net.py:81-84; it
