@@ -43,7 +43,8 @@ extern int g_lmn_prof_on;
 //     sum kernel folds the slots into the real destination right after the producer (same stream, same entry).
 extern int g_lmn_det;
 // a zeroed scratch region of `floats` floats on stream st (hipMemsetAsync; the scratch itself is hipMalloc'ed once per stream and
-// grown on demand: the one place where the library owns device memory).  lmn_det_begin resets the stream's scratch (once per entry).
+// grown on demand: the one place where the library owns device memory; a region stays valid when a later request of the same entry
+// outgrows the block -- the old block is retired, not freed).  lmn_det_begin resets the stream's scratch (once per entry).
 void lmn_det_begin(hipStream_t st);
 float* lmn_det_slots(hipStream_t st, size_t floats);
 // dst[i] += sum_{s < nslots} slots[s * size + i]  (s ascending in fixed groups: bit-reproducible)

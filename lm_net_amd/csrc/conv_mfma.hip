@@ -2913,8 +2913,11 @@ int lmn_conv_fwd(const lmn_conv_args_t* args, lmn_stream_t stream) {
           if (tw > a.Wout) { if (cand) continue; tw = a.Wout; }
           if (cand && tw < 16) continue;
         } else {
+          static int th_env = -1;   // LMN_CONVM_TH: force the 3x3 tile height (A/B runs)
+          if (th_env < 0) { const char* e = getenv("LMN_CONVM_TH"); th_env = e ? atoi(e) : 0; }
           tw = T.TW; th = T.TH - cand;
           if (th < 1) break;
+          if (th_env > 0 && th_env <= T.TH && th != th_env) continue;
         }
         const int ng = (tw * th + 15) / 16;
         const long tiles = (long)a.B * ((a.Wout + tw - 1) / tw) * ((a.Hout + th - 1) / th);

@@ -167,7 +167,7 @@ void lmn_prof_stop(hipStream_t st) {
 
 // ---- deterministic mode: per-stream slot scratch + fixed-order slot sum
 namespace {
-struct DetWs { char* base = nullptr; size_t bytes = 0, used = 0; };
+struct DetWs { char* base = nullptr; size_t bytes = 0, used = 0; std::vector<char*> retired; };   // retired: outgrown blocks (see lmn_det_slots)
 std::map<hipStream_t, DetWs> g_det_ws;
 std::mutex g_det_mu;
 
@@ -204,19 +204,24 @@ float* lmn_det_slots(hipStream_t st, size_t floats) {
     //  scratch that already exists for that stream -- enable_graphs() captures on a stream of its own, so it is refused)
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(st, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) return nullptr;
-    // grow: the old scratch may still be read by work queued on the stream -> wait for the stream, then replace it
+    // grow: a larger block replaces the scratch.  The outgrown block is RETIRED, not freed: regions handed out earlier in this
+    // entry live in it and stay valid, and work already queued on the stream may still read it.  Retired blocks are freed at the
+    // next growth, after a wait for the stream (growth happens a handful of times in a process: sizes repeat from step to step).
     (void)hipStreamSynchronize(st);
-    if (w.base) (void)hipFree(w.base);
+    for (char* r : w.retired) (void)hipFree(r);
+    w.retired.clear();
+    if (w.base) w.retired.push_back(w.base);
     size_t nb = w.bytes ? w.bytes : (size_t)32 << 20;
-    while (nb < w.used + need) nb *= 2;
+    while (nb < need) nb *= 2;
+    if (nb < 2 * w.bytes) nb = 2 * w.bytes;
     w.base = nullptr;
     if (hipMalloc((void**)&w.base, nb) != hipSuccess) { w.bytes = w.used = 0; return nullptr; }
     w.bytes = nb;
-    w.used = 0;   // (regions handed out earlier in this entry are gone: callers take all their regions before launching)
+    w.used = 0;
   }
   float* p = (float*)(w.base + w.used);
   w.used += need;
-  (void)hipMemsetAsync(p, 0, need, st);
+  if (hipMemsetAsync(p, 0, need, st) != hipSuccess) return nullptr;
   return p;
 }
 
