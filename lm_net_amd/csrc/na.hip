@@ -30,6 +30,30 @@ __device__ __forceinline__ f32x4 head_sum(f32x4 p) {
   return f32x4{s, s, s, s};
 }
 
+// Bias entries of a channel quad's heads for window offset `bo` from the TRANSPOSED table tab[25][heads] (LDS): the heads of a quad are
+// adjacent, so the quad reads ONE 16- / 8- / 4-byte word instead of four gathers at a 25-word head stride (hd = 1: 36 -> 9 LDS reads
+// per query; all pixels of a wave share `bo` in the interior, so the reads are broadcasts).  heads * hd % 4 == 0 keeps them aligned.
+template <int HD>
+__device__ __forceinline__ f32x4 rpb4(const float* tab, int heads, int bo, int c) {
+  const float* p = tab + bo * heads + c / HD;
+  if constexpr (HD == 1) return *reinterpret_cast<const f32x4*>(p);
+  else if constexpr (HD == 2) {
+    const float2 a = *reinterpret_cast<const float2*>(p);
+    return f32x4{a.x, a.x, a.y, a.y};
+  } else {
+    const float a = *p;
+    return f32x4{a, a, a, a};
+  }
+}
+// per-(pixel, head) scalars of a channel quad (lse / dsum): one vector store per quad at hd <= 2, the head's first lane otherwise
+template <int HD>
+__device__ __forceinline__ void stat_store(float* dst, int c, f32x4 v, bool ok) {
+  if (!ok) return;
+  if constexpr (HD == 1) *reinterpret_cast<f32x4*>(dst + c) = v;
+  else if constexpr (HD == 2) *reinterpret_cast<float2*>(dst + c / 2) = float2{v[0], v[2]};
+  else if (c % HD == 0) dst[c / HD] = v[0];
+}
+
 struct NaGeom {
   int B, H, W, C, C4, heads;
   float scale;
@@ -57,8 +81,8 @@ __global__ __launch_bounds__(256) void na_fwd_kernel(const TA* __restrict__ qkv,
                                                      TA* __restrict__ out, const NaGeom g, int T, int cch,
                                                      int tiles_x, int tiles, int chunks) {
   extern __shared__ __attribute__((aligned(16))) float KV[];  // [(T+2)^2][2][cch]
-  __shared__ float s_rpb[16 * 25];  // the bias table: per-lane gathers from LDS, not 36 global gathers per pixel
-  for (int i = threadIdx.x; i < g.heads * 25; i += 256) s_rpb[i] = rpb[i];
+  __shared__ __attribute__((aligned(16))) float s_rpb[16 * 25];  // the bias table, transposed to [25][heads] (rpb4)
+  for (int i = threadIdx.x; i < g.heads * 25; i += 256) s_rpb[(i % 25) * g.heads + i / 25] = rpb[i];
   const int R = T + 2;
   const int lid = xcd_swizzle(blockIdx.x, gridDim.x);
   const int t = lid % tiles, cb = lid / tiles;
@@ -92,9 +116,6 @@ __global__ __launch_bounds__(256) void na_fwd_kernel(const TA* __restrict__ qkv,
     const int cc = c < g.C ? c : g.C - 4, ccl = cc - ch0;
     const int sy = wstart(y, g.H), sx = wstart(x, g.W);
     const f32x4 q = ld4(base + ((int64_t)y * g.W + x) * 3 * g.C + cc) * g.scale;
-    int hidx[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) hidx[k] = ((cc + k) / HD) * 25;
     const float* kv0 = KV + (((sy - rlo) * R + (sx - clo)) * 2) * cch + ccl;
     f32x4 l[9];
     f32x4 mx = f32x4{-3.0e38f, -3.0e38f, -3.0e38f, -3.0e38f};
@@ -105,8 +126,7 @@ __global__ __launch_bounds__(256) void na_fwd_kernel(const TA* __restrict__ qkv,
         const f32x4 kk = *reinterpret_cast<const f32x4*>(kv0 + ((ki * R + kj) * 2) * cch);
         f32x4 sc = head_sum<HD>(q * kk);
         const int bo = (sy + ki - y + 2) * 5 + (sx + kj - x + 2);
-#pragma unroll
-        for (int k = 0; k < 4; ++k) sc[k] += s_rpb[hidx[k] + bo];
+        sc += rpb4<HD>(s_rpb, g.heads, bo, cc);
         l[ki * 3 + kj] = sc;
 #pragma unroll
         for (int k = 0; k < 4; ++k) mx[k] = fmaxf(mx[k], sc[k]);
@@ -142,13 +162,13 @@ __global__ __launch_bounds__(256) void na_bwd_q_kernel(const TA* __restrict__ qk
                                                        const TA* __restrict__ dout, TA* __restrict__ dqkv,
                                                        float* __restrict__ drpb, float* __restrict__ stat,
                                                        const NaGeom g, int det) {
-  extern __shared__ float s_drpb[];  // [heads][25] | per-thread interior bins [256][36] | rpb copy | border bins per wave [4][heads][25]
+  extern __shared__ __attribute__((aligned(16))) float s_drpb[];  // [heads][25] | per-thread interior bins [256][36] | rpb copy | border bins per wave [4][heads][25]
   float* s_bins = s_drpb + g.heads * 25;
   float* s_rpb = s_bins + 256 * 36;  // [heads][25] copy of the bias table
   // border pixels add with LDS atomics into the table of THEIR wave (program order within a wave; the four tables and the interior
   // sums are added in a fixed order at the end: the block's result does not depend on how its waves interleave)
   float* s_wave = s_rpb + g.heads * 25 + (threadIdx.x >> 6) * g.heads * 25;
-  for (int i = threadIdx.x; i < g.heads * 25; i += 256) { s_drpb[i] = 0.f; s_rpb[i] = rpb[i]; }
+  for (int i = threadIdx.x; i < g.heads * 25; i += 256) { s_drpb[i] = 0.f; s_rpb[(i % 25) * g.heads + i / 25] = rpb[i]; }   // (s_rpb transposed: rpb4)
   for (int i = threadIdx.x; i < 4 * g.heads * 25; i += 256) s_rpb[g.heads * 25 + i] = 0.f;
   __syncthreads();
   // A thread keeps ONE channel quad for the whole kernel (quad = tid % C4, pixel slot = tid / C4), so the rpb
@@ -188,8 +208,7 @@ __global__ __launch_bounds__(256) void na_bwd_q_kernel(const TA* __restrict__ qk
         const f32x4 kk = ld4(base + po + g.C + c), vv = ld4(base + po + 2 * g.C + c);
         f32x4 s = head_sum<HD>(q * kk);
         const int bo = (ny - y + 2) * 5 + (nx - x + 2);
-#pragma unroll
-        for (int k = 0; k < 4; ++k) s[k] += s_rpb[hidx[k] + bo];
+        s += rpb4<HD>(s_rpb, g.heads, bo, c);
         p[ki * 3 + kj] = s;
         dp[ki * 3 + kj] = head_sum<HD>(dO * vv);
 #pragma unroll
@@ -238,13 +257,13 @@ __global__ __launch_bounds__(256) void na_bwd_q_kernel(const TA* __restrict__ qk
         }
       }
     if (ok) st4(dqkv + ib + ((int64_t)y * g.W + x) * 3 * g.C + c, dq * g.scale);
+    {
+      f32x4 lse;
 #pragma unroll
-    for (int k = 0; k < 4; ++k)
-      if (rep[k]) {
-        const int h = (c + k) / HD;
-        stat[pix * 2 * g.heads + h] = mx[k] + __logf(den[k]);
-        stat[pix * 2 * g.heads + g.heads + h] = dsum[k];
-      }
+      for (int k = 0; k < 4; ++k) lse[k] = mx[k] + __logf(den[k]);
+      stat_store<HD>(stat + pix * 2 * g.heads, c, lse, ok);
+      stat_store<HD>(stat + pix * 2 * g.heads + g.heads, c, dsum, ok);
+    }
   }
   // interior bins: park per thread, then one thread per (quad, neighbour, component) sums its PB pixel slots
 #pragma unroll
@@ -287,7 +306,7 @@ __global__ __launch_bounds__(256) void na_bwd_q_tile_kernel(const TA* __restrict
   float* KV = s_wt + 4 * ntab;   // [(TH+2)*(TW+2)][2][C]
   float* s_bins = KV;         // [256][36] after the last tile
   const int RW = TW + 2, RH = TH + 2;
-  for (int i = threadIdx.x; i < g.heads * 25; i += 256) { s_drpb[i] = 0.f; s_rpb[i] = rpb[i]; }
+  for (int i = threadIdx.x; i < g.heads * 25; i += 256) { s_drpb[i] = 0.f; s_rpb[(i % 25) * g.heads + i / 25] = rpb[i]; }   // (s_rpb transposed: rpb4)
   for (int i = threadIdx.x; i < 4 * ntab; i += 256) s_wt[i] = 0.f;
   __syncthreads();
   // A thread keeps ONE channel quad for the whole kernel (quad = tid % C4, pixel slot = tid / C4), so the rpb
@@ -352,8 +371,7 @@ __global__ __launch_bounds__(256) void na_bwd_q_tile_kernel(const TA* __restrict
         const f32x4 kk = *reinterpret_cast<const f32x4*>(kvn), vv = *reinterpret_cast<const f32x4*>(kvn + g.C);
         f32x4 s = head_sum<HD>(q * kk);
         const int bo = (ny - y + 2) * 5 + (nx - x + 2);
-#pragma unroll
-        for (int k = 0; k < 4; ++k) s[k] += s_rpb[hidx[k] + bo];
+        s += rpb4<HD>(s_rpb, g.heads, bo, c);
         p[ki * 3 + kj] = s;
         dp[ki * 3 + kj] = head_sum<HD>(dO * vv);
 #pragma unroll
@@ -402,13 +420,13 @@ __global__ __launch_bounds__(256) void na_bwd_q_tile_kernel(const TA* __restrict
         }
       }
     if (ok) st4(dqkv + ib + ((int64_t)y * g.W + x) * 3 * g.C + c, dq * g.scale);
+    {
+      f32x4 lse;
 #pragma unroll
-    for (int k = 0; k < 4; ++k)
-      if (rep[k]) {
-        const int h = (c + k) / HD;
-        stat[pix * 2 * g.heads + h] = mx[k] + __logf(den[k]);
-        stat[pix * 2 * g.heads + g.heads + h] = dsum[k];
-      }
+      for (int k = 0; k < 4; ++k) lse[k] = mx[k] + __logf(den[k]);
+      stat_store<HD>(stat + pix * 2 * g.heads, c, lse, ok);
+      stat_store<HD>(stat + pix * 2 * g.heads + g.heads, c, dsum, ok);
+    }
    }
   }
   __syncthreads();  // every window read is done: the parking area reuses that memory
@@ -438,8 +456,11 @@ template <int HD, typename TA>
 __global__ __launch_bounds__(256) void na_bwd_kv_kernel(const TA* __restrict__ qkv, const float* __restrict__ rpb,
                                                         const TA* __restrict__ dout, TA* __restrict__ dqkv,
                                                         const float* __restrict__ stat, const NaGeom g) {
-  // (the bias table stays in global memory here: with 12 heads x 25 entries gathered per lane the LDS copy was
-  //  slower than the L1-resident table -- 25-word head stride = bank conflicts)
+  // (the bias table in LDS, transposed to [25][heads]: the quad's heads are one vector read (rpb4); in the [heads][25] order the LDS
+  //  copy was slower than the L1-resident table -- a 25-word head stride = bank conflicts)
+  __shared__ __attribute__((aligned(16))) float s_rpb[16 * 25];
+  for (int i = threadIdx.x; i < g.heads * 25; i += 256) s_rpb[(i % 25) * g.heads + i / 25] = rpb[i];
+  __syncthreads();
   const int64_t total = (int64_t)g.B * g.H * g.W * g.C4;
   const int64_t nit = (total + (int64_t)gridDim.x * 256 - 1) / ((int64_t)gridDim.x * 256);
   for (int64_t it = 0; it < nit; ++it) {
@@ -480,10 +501,11 @@ __global__ __launch_bounds__(256) void na_bwd_kv_kernel(const TA* __restrict__ q
       const f32x4 s = head_sum<HD>(qi * kj);
       const f32x4 dp = head_sum<HD>(dOi * vj);
       const int bo = (jy - iy + 2) * 5 + (jx - ix + 2);
+      const f32x4 rb = rpb4<HD>(s_rpb, g.heads, bo, c);
       f32x4 pij, ds;
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
-        pij[k] = __expf(s[k] + rpb[hidx[k] + bo] - lse4[k]);
+        pij[k] = __expf(s[k] + rb[k] - lse4[k]);
         ds[k] = pij[k] * (dp[k] - dsm4[k]);
       }
       dk += ds * qi;   // qi carries the scale
@@ -535,6 +557,8 @@ __global__ __launch_bounds__(256) void na_bwd_kv_tile_kernel(const TA* __restric
   // dO is contiguous per pixel and stays a global load.  Keys within 3 pixels of the border (clamped windows: up to 25
   // candidate queries) keep the direct path.
   extern __shared__ __attribute__((aligned(16))) float QS[];
+  __shared__ __attribute__((aligned(16))) float s_rpb[16 * 25];   // bias table, transposed to [25][heads] (rpb4)
+  for (int i = threadIdx.x; i < g.heads * 25; i += 256) s_rpb[(i % 25) * g.heads + i / 25] = rpb[i];
   const int PS = g.C + 2 * g.heads, RW = T + 2;
   const int tile = blockIdx.x;
   const int b = tile / tiles_img, tt = tile - b * tiles_img;
@@ -601,10 +625,11 @@ __global__ __launch_bounds__(256) void na_bwd_kv_tile_kernel(const TA* __restric
       const f32x4 s = head_sum<HD>(qi * kj);
       const f32x4 dp = head_sum<HD>(dOi * vj);
       const int bo = (jy - iy + 2) * 5 + (jx - ix + 2);
+      const f32x4 rb = rpb4<HD>(s_rpb, g.heads, bo, c);
       f32x4 pij, ds;
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
-        pij[k] = __expf(s[k] + rpb[hidx[k] + bo] - lse4[k]);
+        pij[k] = __expf(s[k] + rb[k] - lse4[k]);
         ds[k] = pij[k] * (dp[k] - dsm4[k]);
       }
       dk += ds * qi;   // qi carries the scale
