@@ -567,7 +567,7 @@ class LM_Net(nn.Module):
                 # weight-gradient-style launches of the forward (the moments of the z-path, on the weight-gradient stream): reduced and
                 # JOINED here, so that the backward's lmn_reparam_wfin depends on them whatever stream / overlap setting it runs
                 # with (the side stream is idle at the end of the forward: the join costs nothing)
-                eng.join_side(x.device)
+                (eng.join_side if eng.fwd_join else eng.flush_reduce)(x.device)
             finally:
                 nf = eng.alloc_floats
                 eng.end_pass()

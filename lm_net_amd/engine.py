@@ -164,6 +164,7 @@ class Engine:
         # z-path of ReparamConv (include/lmnet_hip.h, lmn_dw_pre_t / lmn_reparam_fold): the expand conv's BatchNorm + Hardswish
         # applied inside the depthwise kernels, its backward folded into the weights of one three-source conv (LMN_ZPATH=0: A/B)
         self.zpath = os.environ.get("LMN_ZPATH", "1") != "0"
+        self.fwd_join = os.environ.get("LMN_FWD_JOIN", "1") != "0"   # the forward ends with a join of its weight-gradient stream (A/B)
         self.zpath_lds = 65536    # bytes of LDS lmn_reparam_fold may use (35 E floats): wider blocks keep the two-pass BatchNorm form (E > 468)
         # weight gradients of the branch chains issued late, beside the encoder's backward (LMN_LAZY_WGRAD=0: A/B runs)
         self.lazy_wgrad = os.environ.get("LMN_LAZY_WGRAD", "1") != "0"
