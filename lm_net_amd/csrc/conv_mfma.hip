@@ -2660,7 +2660,11 @@ static int wgrad_blocks_total(const lmn_wgrad_args_t& a) {
   static int c = -1;
   if (c < 0) { const char* e = getenv("LMN_WGRAD_CAP"); c = e ? atoi(e) : 0; }
   if (!wgrad_v1(a)) return 512;
-  return c > 0 ? c : 768;  // 3 resident blocks per CU (bf16 storage would fit 4: 1024 blocks measured 3 % slower, more partials)
+  // 512 = two resident blocks per CU.  Alone the kernel is fastest at 768 (three per CU), but it runs on the weight-gradient stream
+  // beside the backward chain: inside the step 512 blocks measured 14.59 ms against 14.68 (768), 14.63 (384), 14.65 (640), 14.71 (256)
+  // -- fewer partials to write and re-read (28 -> 19 MB per 24-channel layer) and more CU time left to the chain (round 4, three
+  // runs each on one box).  (bf16 storage would fit 4 per CU: 1024 blocks measured 3 % slower.)
+  return c > 0 ? c : 512;
 }
 
 int64_t lmn_conv_wgrad_workspace(const lmn_wgrad_args_t* a) {
