@@ -1133,6 +1133,9 @@ __global__ void dw_bwd_coef_kernel(const float* __restrict__ bst, const float* _
 // that.  (Level 3, 44 x 44 x 192 channels: one segment = 768 waves of 50 steps took 31 us, four segments of 15 steps 12 us; level 0
 // of the backward: 2 segment pairs = 2304 waves on 2048 slots ran as two rounds.)
 static int dw_segments(int64_t per_seg, int H, int halo, int wps, int mult, double lat, int* seg_rows) {
+  static double lat_scale = -1.0;   // LMN_DW_LAT: scales `lat` (A/B runs of the segment counts inside the step)
+  if (lat_scale < 0.0) { const char* e = getenv("LMN_DW_LAT"); lat_scale = e ? atof(e) : 1.0; }
+  lat *= lat_scale;
   int best = mult;
   double best_cost = -1.0;
   for (int sg = mult; sg <= H; sg += mult) {
@@ -1226,7 +1229,7 @@ static int dw_fwd_launch(const void* x1, void* pre, float* gsum, int B, int H, i
   // blocks = B x row segments x strips (60 output columns) x 8-channel chunks
   const int strips = lmn_cdiv(W, QW), chunks = lmn_cdiv(E, 8);
   int seg_rows;
-  dw_segments((int64_t)B * strips * chunks * 4, H, 4, 4, 1, 3.0, &seg_rows);
+  dw_segments((int64_t)B * strips * chunks * 4, H, 4, LMN_DWF_OCC, 1, 3.0, &seg_rows);
   const int segs = lmn_cdiv(H, seg_rows);
   const int64_t nblk = (int64_t)B * strips * chunks * segs;
   LMN_REQUIRE(nblk < (1LL << 31), "%s: grid too large", what);
