@@ -3231,7 +3231,9 @@ static int wgrad_setup(const lmn_wgrad_args_t& A, WgradParams& P, WgGeom& G) {
     lds_floats = (int64_t)(NNT * ux + NMT * uy) * 64 * cs;
     if (NMT * NNT == 1 && lds_floats < per) lds_floats = per;
   }
-  const int btot = v1 ? wgrad_blocks_total(A) : 512;
+  static int cap_other = -1;   // LMN_WGRAD_CAP_OTHER: K-split blocks of the other weight-gradient kernels (1x1, LDS-staged 3x3), A/B runs
+  if (cap_other < 0) { const char* e = getenv("LMN_WGRAD_CAP_OTHER"); cap_other = e && atoi(e) > 0 ? atoi(e) : 512; }
+  const int btot = v1 ? wgrad_blocks_total(A) : cap_other;
   const int64_t cap = btot / gy > 2 ? btot / gy : 2;
   if (blocks64 > cap) blocks64 = cap;
   if (blocks64 < 1) blocks64 = 1;
