@@ -184,7 +184,7 @@ def roofline_block(dominant, live, survey, tot_us, B, H, W, step_s, alone, esz=4
     ROWS = (("row_A2", "row A2 (depthwise branches: fwd + 2 statistics passes + bwd)",
              ("dw_fwd_kernel", "dw_bwd_kernel", "dw_stats0_kernel", "dw_stats1_kernel")),
             ("row_A7", "row A7 (fused neighborhood attention: fwd + bwd)",
-             ("na_fwd_kernel", "na_bwd_kernel", "na_bwd_q_kernel", "na_bwd_kv_kernel", "na_bwd_q_tile_kernel", "na_bwd_kv_tile_kernel")))
+             ("na_fwd_kernel", "na_bwd_fused_kernel", "na_bwd_q_kernel", "na_bwd_kv_kernel", "na_bwd_q_tile_kernel", "na_bwd_kv_tile_kernel")))
     for key, label, names in ROWS:
         grp = _group(live, names)
         if grp["total_us"] <= 0:
@@ -429,7 +429,7 @@ def other_config(dev, dtype, B, size, steps=10, warmup=5):
             r.step()
         rows = hip.prof_end()
         for key, names in (("row_A2", ("dw_fwd_kernel", "dw_bwd_kernel", "dw_stats0_kernel", "dw_stats1_kernel")),
-                           ("row_A7", ("na_fwd_kernel", "na_bwd_kernel", "na_bwd_q_kernel", "na_bwd_kv_kernel", "na_bwd_q_tile_kernel",
+                           ("row_A7", ("na_fwd_kernel", "na_bwd_fused_kernel", "na_bwd_q_kernel", "na_bwd_kv_kernel", "na_bwd_q_tile_kernel",
                                        "na_bwd_kv_tile_kernel"))):
             g = _group(rows, names)
             if g["total_us"] > 0:

@@ -666,6 +666,259 @@ __global__ __launch_bounds__(256) void na_bwd_kv_tile_kernel(const TA* __restric
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// Backward in ONE pass for head_dim <= 2 (levels 0-1: C = 12 / 24).  At head_dim 1 the per-(pixel, head) scalars the two-pass form
+// exchanges through HBM (lse, dsum) are as large as q or k themselves; here they live in LDS for one tile:
+//   stage k, v of the tile +- 2 (the windows of the queries below)                                   -> LDS window W
+//   phase A, queries of the tile +- 1 (every query that sees a key of the tile): softmax statistics   -> LDS table ST;
+//            queries INSIDE the tile also: dq -> HBM, bias-table gradient (register bins as in na_bwd_q_tile_kernel)
+//   restage q, dO of the tile +- 1 over W (second read of the same bytes: L2)
+//   phase B, keys of the tile: dk, dv from the 3x3 (border: up to 5x5) candidate queries, everything from LDS -> HBM
+// Queries 2 pixels from a key see it only through a window clamped at the image border (query row 0 sees key row 2, row H-1 sees
+// H-3): the statistics region is the tile +- 1 clipped to the image, extended by one row / column where that reaches H-2 / W-2.
+// A thread keeps one channel quad; blockDim = 85 pixel slots x C/4 quads (255 of 256 threads at C = 12, 510 of 512 at C = 24), and
+// the 15 x 17 tile is 3 such rounds, its 17 x 19 statistics region 4.  HBM traffic: the algorithmic 7 C per pixel plus halo
+// re-reads that neighbouring blocks find in L2; no lse / dsum workspace.
+template <int HD, typename TA>
+__global__ __launch_bounds__(512) void na_bwd_fused_kernel(const TA* __restrict__ qkv, const float* __restrict__ rpb,
+                                                           const TA* __restrict__ dout, TA* __restrict__ dqkv,
+                                                           float* __restrict__ drpb, const NaGeom g, int TH, int TW, int tiles_x,
+                                                           int tiles_img, int total_tiles, int st_floats, int det) {
+  extern __shared__ __attribute__((aligned(16))) float s_drpb[];  // [ntab] | bias table, transposed [ntab] | border bins per wave | ST | W
+  const int NT = blockDim.x, nwave = NT >> 6;
+  const int ntab = (g.heads * 25 + 3) & ~3;
+  float* s_rpb = s_drpb + ntab;
+  float* s_wt = s_rpb + ntab;                                  // [nwave][ntab]
+  float* s_wave = s_wt + (threadIdx.x >> 6) * ntab;
+  float* ST = s_wt + nwave * ntab;                             // [statistics region][2*heads]: lse | dsum  (st_floats: the largest region of this map)
+  float* Wn = ST + st_floats;                                  // k, v window, then q, dO window, then the parked bins
+  const int tid = threadIdx.x;
+  for (int i = tid; i < g.heads * 25; i += NT) { s_drpb[i] = 0.f; s_rpb[(i % 25) * g.heads + i / 25] = rpb[i]; }
+  for (int i = tid; i < nwave * ntab; i += NT) s_wt[i] = 0.f;
+  const int PB = NT / g.C4;
+  const int c = (tid % g.C4) * 4;
+  const int slot = tid / g.C4;
+  const int SH2 = 2 * g.heads;
+  f32x4 bins[9];
+#pragma unroll
+  for (int n = 0; n < 9; ++n) bins[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+  int hidx[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) hidx[k] = ((c + k) / HD) * 25;
+  for (int tile = blockIdx.x; tile < total_tiles; tile += gridDim.x) {
+    const int b = tile / tiles_img, tt = tile - b * tiles_img;
+    const int ty0 = (tt / tiles_x) * TH, tx0 = (tt % tiles_x) * TW;
+    const int ty1 = min(ty0 + TH, g.H), tx1 = min(tx0 + TW, g.W);
+    // statistics region (queries) and k / v region (their windows)
+    int sy0 = max(ty0 - 1, 0), sy1 = min(ty1 + 1, g.H), sx0 = max(tx0 - 1, 0), sx1 = min(tx1 + 1, g.W);
+    if (sy0 == 1) sy0 = 0;
+    if (sx0 == 1) sx0 = 0;
+    if (sy1 == g.H - 1) sy1 = g.H;
+    if (sx1 == g.W - 1) sx1 = g.W;
+    const int SHt = sy1 - sy0, SWd = sx1 - sx0, nsp = SHt * SWd;
+    const int ky0 = wstart(sy0, g.H), kx0 = wstart(sx0, g.W);
+    const int KH = wstart(sy1 - 1, g.H) + 3 - ky0, KW = wstart(sx1 - 1, g.W) + 3 - kx0;
+    const int64_t ib = (int64_t)b * g.H * g.W * 3 * g.C;
+    const TA* base = qkv + ib;
+    __syncthreads();  // the previous tile's windows are consumed (first tile: the tables are written)
+    {  // ---- k, v of the K region -> Wn [(pixel)*2 + which][C]
+      const int nit = KH * KW * 2 * g.C4;
+      for (int i0 = 0; i0 < nit; i0 += 4 * NT) {
+        f32x4 sv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int i = i0 + u * NT + tid;
+          const bool in = i < nit;
+          const int ii = in ? i : 0;
+          const int c4 = ii % g.C4, w = (ii / g.C4) & 1, wp = ii / (2 * g.C4);
+          const int gy = ky0 + wp / KW, gx = kx0 + wp % KW;
+          sv[u] = ld4(base + ((int64_t)gy * g.W + gx) * 3 * g.C + (1 + w) * g.C + c4 * 4);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int i = i0 + u * NT + tid;
+          if (i < nit) *reinterpret_cast<f32x4*>(&Wn[(i / g.C4) * g.C + (i % g.C4) * 4]) = sv[u];
+        }
+      }
+    }
+    __syncthreads();
+    // ---- phase A
+    for (int p0 = 0; p0 < nsp; p0 += PB) {
+      const int pl = p0 + slot;
+      const bool ok = slot < PB && pl < nsp;
+      const int pls = ok ? pl : 0;
+      const int y = sy0 + pls / SWd, x = sx0 + pls % SWd;
+      const bool own = ok && y >= ty0 && y < ty1 && x >= tx0 && x < tx1;   // a query of the tile: dq and the bias gradient are this block's
+      const int64_t pix = ((int64_t)b * g.H + y) * g.W + x;
+      const int sy = wstart(y, g.H), sx = wstart(x, g.W);
+      const float* kv0 = Wn + (((sy - ky0) * KW + (sx - kx0)) * 2) * g.C + c;
+      const f32x4 q = ld4(base + ((int64_t)y * g.W + x) * 3 * g.C + c) * g.scale;
+      const f32x4 dO = ld4(dout + pix * g.C + c);
+      f32x4 p[9], dp[9];
+      f32x4 mx = f32x4{-3.0e38f, -3.0e38f, -3.0e38f, -3.0e38f};
+#pragma unroll
+      for (int ki = 0; ki < 3; ++ki)
+#pragma unroll
+        for (int kj = 0; kj < 3; ++kj) {
+          const float* kvn = kv0 + ((ki * KW + kj) * 2) * g.C;
+          const f32x4 kk = *reinterpret_cast<const f32x4*>(kvn), vv = *reinterpret_cast<const f32x4*>(kvn + g.C);
+          f32x4 sc = head_sum<HD>(q * kk);
+          const int bo = (sy + ki - y + 2) * 5 + (sx + kj - x + 2);
+          sc += rpb4<HD>(s_rpb, g.heads, bo, c);
+          p[ki * 3 + kj] = sc;
+          dp[ki * 3 + kj] = head_sum<HD>(dO * vv);
+#pragma unroll
+          for (int k = 0; k < 4; ++k) mx[k] = fmaxf(mx[k], sc[k]);
+        }
+      f32x4 den = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int n = 0; n < 9; ++n) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) p[n][k] = __expf(p[n][k] - mx[k]);
+        den += p[n];
+      }
+      f32x4 dsum = f32x4{0.f, 0.f, 0.f, 0.f}, rden, lse;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { rden[k] = __builtin_amdgcn_rcpf(den[k]); lse[k] = mx[k] + __logf(den[k]); }
+#pragma unroll
+      for (int n = 0; n < 9; ++n) {
+        p[n] = p[n] * rden;
+        dsum += p[n] * dp[n];
+      }
+      stat_store<HD>(ST + pls * SH2, c, lse, ok);
+      stat_store<HD>(ST + pls * SH2 + g.heads, c, dsum, ok);
+      if (own) {   // (block-divergent only at tile edges; head_sum has no shuffles at hd <= 2)
+        f32x4 dq = f32x4{0.f, 0.f, 0.f, 0.f};
+        const bool inter = sy == y - 1 && sx == x - 1;  // unclamped window: neighbour n always lands in bin (ki+1, kj+1)
+        f32x4 rm;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) rm[k] = (inter && (c + k) % HD == 0) ? 1.f : 0.f;
+#pragma unroll
+        for (int ki = 0; ki < 3; ++ki)
+#pragma unroll
+          for (int kj = 0; kj < 3; ++kj) {
+            const int n = ki * 3 + kj;
+            const f32x4 ds = p[n] * (dp[n] - dsum);
+            dq += ds * *reinterpret_cast<const f32x4*>(kv0 + ((ki * KW + kj) * 2) * g.C);
+            bins[n] += ds * rm;
+            if (!inter) {  // border pixels (the clamped window shifts the bins): rare, through LDS atomics
+              const int bo = (sy + ki - y + 2) * 5 + (sx + kj - x + 2);
+#pragma unroll
+              for (int k = 0; k < 4; ++k)
+                if ((c + k) % HD == 0) atomicAdd(&s_wave[hidx[k] + bo], ds[k]);
+            }
+          }
+        st4(dqkv + ib + ((int64_t)y * g.W + x) * 3 * g.C + c, dq * g.scale);
+      }
+    }
+    __syncthreads();  // ST complete; the k / v window is consumed
+    {  // ---- q, dO of the statistics region -> Wn [(pixel)*2 + which][C]
+      const int nit = nsp * 2 * g.C4;
+      for (int i0 = 0; i0 < nit; i0 += 4 * NT) {
+        f32x4 sv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int i = i0 + u * NT + tid;
+          const bool in = i < nit;
+          const int ii = in ? i : 0;
+          const int c4 = ii % g.C4, w = (ii / g.C4) & 1, wp = ii / (2 * g.C4);
+          const int gy = sy0 + wp / SWd, gx = sx0 + wp % SWd;
+          sv[u] = w ? ld4(dout + (((int64_t)b * g.H + gy) * g.W + gx) * g.C + c4 * 4)
+                    : ld4(base + ((int64_t)gy * g.W + gx) * 3 * g.C + c4 * 4);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int i = i0 + u * NT + tid;
+          if (i < nit) *reinterpret_cast<f32x4*>(&Wn[(i / g.C4) * g.C + (i % g.C4) * 4]) = sv[u];
+        }
+      }
+    }
+    __syncthreads();
+    // ---- phase B
+    const int tw = tx1 - tx0, ntp = (ty1 - ty0) * tw;
+    for (int p0 = 0; p0 < ntp; p0 += PB) {
+      const int pl = p0 + slot;
+      const bool ok = slot < PB && pl < ntp;
+      const int pls = ok ? pl : 0;
+      const int jy = ty0 + pls / tw, jx = tx0 + pls % tw;
+      const int64_t kpo = ((int64_t)jy * g.W + jx) * 3 * g.C;
+      const f32x4 kj = ld4(base + kpo + g.C + c), vj = ld4(base + kpo + 2 * g.C + c);
+      f32x4 dk = f32x4{0.f, 0.f, 0.f, 0.f}, dv = dk;
+      auto candidate = [&](int iy, int ix) {
+        const int sl = (iy - sy0) * SWd + (ix - sx0);
+        const f32x4 qi = *reinterpret_cast<const f32x4*>(Wn + (sl * 2) * g.C + c) * g.scale;
+        const f32x4 dOi = *reinterpret_cast<const f32x4*>(Wn + (sl * 2 + 1) * g.C + c);
+        const float* sp = ST + sl * SH2;
+        f32x4 lse4, dsm4;
+        if constexpr (HD == 1) {
+          lse4 = *reinterpret_cast<const f32x4*>(sp + c);
+          dsm4 = *reinterpret_cast<const f32x4*>(sp + g.heads + c);
+        } else {
+          const float2 a = *reinterpret_cast<const float2*>(sp + c / 2), bq = *reinterpret_cast<const float2*>(sp + g.heads + c / 2);
+          lse4 = f32x4{a.x, a.x, a.y, a.y};
+          dsm4 = f32x4{bq.x, bq.x, bq.y, bq.y};
+        }
+        const f32x4 sc = head_sum<HD>(qi * kj);
+        const f32x4 dpv = head_sum<HD>(dOi * vj);
+        const int bo = (jy - iy + 2) * 5 + (jx - ix + 2);
+        const f32x4 rb = rpb4<HD>(s_rpb, g.heads, bo, c);
+        f32x4 pij, ds;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          pij[k] = __expf(sc[k] + rb[k] - lse4[k]);
+          ds[k] = pij[k] * (dpv[k] - dsm4[k]);
+        }
+        dk += ds * qi;   // qi carries the scale
+        dv += pij * dOi;
+      };
+      if (jy >= 3 && jy <= g.H - 4 && jx >= 3 && jx <= g.W - 4) {   // interior key: exactly its 3x3 neighbourhood, all unclamped
+#pragma unroll
+        for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+          for (int dx = -1; dx <= 1; ++dx) candidate(jy + dy, jx + dx);
+      } else {
+        for (int iy = jy - 2; iy <= jy + 2; ++iy) {
+          if (iy < 0 || iy >= g.H) continue;
+          const int ki = jy - wstart(iy, g.H);
+          if (ki < 0 || ki > 2) continue;
+          for (int ix = jx - 2; ix <= jx + 2; ++ix) {
+            if (ix < 0 || ix >= g.W) continue;
+            const int kx = jx - wstart(ix, g.W);
+            if (kx < 0 || kx > 2) continue;
+            candidate(iy, ix);
+          }
+        }
+      }
+      if (ok) {
+        st4(dqkv + ib + kpo + g.C + c, dk);
+        st4(dqkv + ib + kpo + 2 * g.C + c, dv);
+      }
+    }
+  }
+  __syncthreads();  // every window read is done: the parking area reuses that memory
+  float* s_bins = Wn;   // [NT][36]
+#pragma unroll
+  for (int n = 0; n < 9; ++n)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) s_bins[tid * 36 + n * 4 + k] = bins[n][k];
+  __syncthreads();
+  for (int o = tid; o < g.C4 * 36; o += NT) {
+    const int qd = o / 36, nk = o - qd * 36;
+    const int n = nk >> 2, k = nk & 3;
+    const int ch = qd * 4 + k;
+    if (ch % HD != 0) continue;
+    float v = 0.f;
+    for (int sl = 0; sl < PB; ++sl) v += s_bins[(sl * g.C4 + qd) * 36 + nk];
+    s_drpb[(ch / HD) * 25 + (n / 3 + 1) * 5 + (n % 3 + 1)] = v;   // (one writer per (head, bin))
+  }
+  __syncthreads();
+  for (int i = tid; i < g.heads * 25; i += NT) {
+    float v = s_drpb[i];
+    for (int w = 0; w < nwave; ++w) v += s_wt[w * ntab + i];
+    if (v != 0.f) lmn_red_add(drpb + (det ? (int64_t)blockIdx.x * g.heads * 25 : 0) + i, v, det);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // Window sizes other than 3 (natten's kernel_size 5, 7, ...: core/LM_Net.py:81-84 passes [3, 5], BASELINE configs[4] names a
 // larger window): the same three passes in the direct form -- a thread owns a channel quad of one pixel, lanes walk the
 // channel axis first, the K x K re-use of k / v is served by L1 / L2 -- with K a run-time argument (one instantiation per
@@ -1011,6 +1264,38 @@ int lmn_na_bwd(const void* qkv_, const float* rpb, const void* dout_, void* dqkv
     }                                                                                                                \
   } while (0)
   const bool tiled = (g.C4 == 3 || g.C4 == 6) && hd <= 2 && heads % 2 == 0 && H >= 16 && W >= 16;
+  // ---- one-pass form (na_bwd_fused_kernel): 15 x 17 tiles = 3 rounds of 85 pixel slots, statistics region 17 x 19 (+1 where a tile
+  // ends two short of the border), k / v window +2.  LMN_NA_FUSED=0: the two-pass tile kernels (A/B runs)
+  static const int fused_env = getenv("LMN_NA_FUSED") ? atoi(getenv("LMN_NA_FUSED")) : 1;
+  if (tiled && fused_env && (hd == 1 ? heads % 4 == 0 : true)) {
+    const int TH = 15, TW = 17, NT = g.C4 == 3 ? 256 : 512, nwave = NT / 64;
+    const int tx = lmn_cdiv(W, TW), ty = lmn_cdiv(H, TH), total = tx * ty * B;
+    const int ey = (H - 2 >= TH && (H - 2) % TH == 0) ? 1 : 0, ex = (W - 2 >= TW && (W - 2) % TW == 0) ? 1 : 0;
+    const int SHm = (TH + 2 + ey < H ? TH + 2 + ey : H), SWm = (TW + 2 + ex < W ? TW + 2 + ex : W);
+    const int KHm = (SHm + 2 < H ? SHm + 2 : H), KWm = (SWm + 2 < W ? SWm + 2 : W);
+    const int ntab = (heads * 25 + 3) & ~3;
+    const int st_floats = SHm * SWm * 2 * heads;
+    int wfl = KHm * KWm * 2 * g.C;
+    if (wfl < SHm * SWm * 2 * g.C) wfl = SHm * SWm * 2 * g.C;
+    if (wfl < NT * 36) wfl = NT * 36;
+    const size_t fsh = (size_t)(ntab * (2 + nwave) + st_floats + wfl) * sizeof(float);
+    const int cap = g.C4 == 3 ? 512 : 256;   // resident blocks: two per CU at C = 12 (76 KB each), one of 512 threads at C = 24 (120 KB)
+    const int gf = total > cap ? cap : total;
+    if (fsh <= 160 * 1024) {
+      if (int rc = det_prep(gf)) return rc;
+      if (g_lmn_prof_on) lmn_prof_cost(2.0 * 6 * 9 * (double)B * H * W * g.C, (act_dtype == LMN_BF16 ? 2.0 : 4.0) * 7 * (double)B * H * W * g.C);
+#define LMN_NAF(HDV)                                                                                                                \
+  do {                                                                                                                              \
+    if (fsh > 64 * 1024) (void)hipFuncSetAttribute((const void*)na_bwd_fused_kernel<HDV, T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fsh); \
+    LMN_LAUNCH((na_bwd_fused_kernel<HDV, T>), dim3(gf), dim3(NT), fsh, st, (const T*)qkv, rpb, (const T*)dout, (T*)dqkv, dslot, g, TH, TW, tx, \
+               tx * ty, total, st_floats, g_lmn_det);                                                                               \
+  } while (0)
+      LMN_ACT_DISPATCH(act_dtype, if (hd == 1) LMN_NAF(1); else LMN_NAF(2););
+#undef LMN_NAF
+      if (g_lmn_det) lmn_det_sum(st, dslot, dn, ntabK, drpb);
+      return lmn_launch_status("na_bwd");
+    }
+  }
   LMN_ACT_DISPATCH(act_dtype, switch (hd) {
     case 1: if (tiled) LMN_NAT(1); else LMN_NA(1); break;
     case 2: if (tiled) LMN_NAT(2); else LMN_NA(2); break;

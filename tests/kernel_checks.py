@@ -634,7 +634,8 @@ def check_na():
     core/LM_Net.py:81-84 carries [3, 5]).  Oracle: oracle/natten_ref.py for every K (test_oracle_na.py pins its K = 5 form)."""
     rows = []
     cases = [(3, s) for s in [(2, 7, 9, 1), (1, 6, 5, 2), (2, 5, 8, 4), (1, 9, 6, 8), (1, 3, 3, 2), (1, 3, 17, 1),
-                              (2, 37, 41, 1), (1, 16, 52, 2), (2, 31, 18, 2), (1, 48, 33, 1)]]  # LDS-tiled query pass (C <= 24, maps >= 16)
+                              (2, 37, 41, 1), (1, 16, 52, 2), (2, 31, 18, 2), (1, 48, 33, 1),   # LDS-tiled / one-pass backward (C <= 24, maps >= 16)
+                              (1, 17, 19, 1), (2, 47, 19, 2), (1, 32, 36, 2), (1, 62, 70, 1)]]  # tiles ending two short of the border (H - 2, W - 2 multiples of 15 / 17), several tiles per block
     cases += [(5, s) for s in [(2, 7, 9, 1), (1, 5, 5, 2), (1, 9, 6, 4), (2, 23, 18, 2), (1, 11, 12, 8), (1, 5, 21, 16)]]
     cases += [(7, s) for s in [(1, 7, 7, 1), (2, 9, 12, 2), (1, 22, 15, 4), (1, 8, 13, 8)]]
     for K, (B, H, W, hd) in cases:
