@@ -401,7 +401,8 @@ int lmn_se_bwd_params(const float* dvec, const float* gsum, float inv_hw, const 
 int lmn_na_fwd(const void* qkv, const float* rpb, void* out, int B, int H, int W, int heads, int hd, int K, float scale,
                int act_dtype, lmn_stream_t stream);
 /* dqkv is fully overwritten (two gather passes, no atomics, deterministic); drpb +=;
- * stat: caller workspace of 2*heads floats per pixel ([B*H*W][2][heads]: log-sum-exp and sum_n p_n dp_n) */
+ * stat: caller workspace of 2*heads floats per pixel ([B*H*W][2][heads]: log-sum-exp and sum_n p_n dp_n) of the two-pass forms;
+ *       the one-pass kernel of head_dim <= 2 (K = 3, C = 12 / 24, maps >= 16 x 16) keeps these in LDS and does not touch it */
 int lmn_na_bwd(const void* qkv, const float* rpb, const void* dout, void* dqkv, float* drpb, float* stat, int B,
                int H, int W, int heads, int hd, int K, float scale, int act_dtype, lmn_stream_t stream);
 
