@@ -704,7 +704,8 @@ __global__ __launch_bounds__(512) void na_bwd_fused_kernel(const TA* __restrict_
   int hidx[4];
 #pragma unroll
   for (int k = 0; k < 4; ++k) hidx[k] = ((c + k) / HD) * 25;
-  for (int tile = blockIdx.x; tile < total_tiles; tile += gridDim.x) {
+  // (XCD-aware order: the blocks of one XCD walk CONSECUTIVE tiles, whose halos overlap, at the same time -- the re-reads hit that XCD's L2)
+  for (int tile = xcd_swizzle(blockIdx.x, gridDim.x); tile < total_tiles; tile += gridDim.x) {
     const int b = tile / tiles_img, tt = tile - b * tiles_img;
     const int ty0 = (tt / tiles_x) * TH, tx0 = (tt % tiles_x) * TW;
     const int ty1 = min(ty0 + TH, g.H), tx1 = min(tx0 + TW, g.W);
