@@ -287,7 +287,8 @@ def _dw_ref(x1, ws, gam, bet, train, rm=None, rv=None):
 
 def check_dw():
     rows = []
-    for (B, H, W, E) in [(2, 20, 19, 24), (1, 33, 17, 48), (2, 18, 21, 12), (1, 70, 130, 24), (1, 9, 61, 8)]:
+    for (B, H, W, E) in [(2, 20, 19, 24), (1, 33, 17, 48), (2, 18, 21, 12), (1, 70, 130, 24), (1, 9, 61, 8),
+                         (3, 5, 120, 16), (1, 64, 57, 24), (1, 4, 4, 4), (2, 130, 60, 8)]:   # two whole strips / the halo instance (57 = 56 + 1) / the smallest map / many row segments of one strip
         x1 = R(B, E, H, W, seed=51)
         ws = [R(E, 1, 5, 5, seed=52, scale=0.2), R(E, 1, 3, 3, seed=53, scale=0.3), R(E, 1, 3, 1, seed=54, scale=0.5),
               R(E, 1, 1, 3, seed=55, scale=0.5)]
