@@ -162,3 +162,26 @@ def test_stream_key_of_the_default_stream_is_zero_not_none():
         assert hip.wgrad_reduce_pending(0) == 0 and hip.wgrad_reduce_pending() == 0
     finally:
         hip._STREAM[0] = saved
+
+
+def test_row_planar_layout_helpers_follow_the_documented_index():
+    """include/lmnet_hip.h, Conventions: element (b, y, x, c) of a row-planar (RP4) tensor sits at
+    ((b*H + y)*(C/4) + (c >> 2))*4W + 4x + (c & 3).  hip.nhwc_to_rp4 / rp4_to_nhwc are what tests and callers holding NHWC data use
+    to talk to the depthwise entries: check them against the formula element by element, that they invert each other, that the
+    marker attribute travels with rp4() and that V() picks the image width up."""
+    from lm_net_amd import hip
+    B, H, W, Cn = 2, 3, 5, 12
+    t = torch.arange(B * H * W * Cn, dtype=torch.float32).reshape(B, H, W, Cn)
+    r = hip.nhwc_to_rp4(t)
+    assert r.shape == t.shape and hip.is_rp4(r) and not hip.is_rp4(t)
+    flat = r.reshape(-1)
+    for b in range(B):
+        for y in range(H):
+            for x in range(W):
+                for c in range(Cn):
+                    off = ((b * H + y) * (Cn // 4) + (c >> 2)) * 4 * W + 4 * x + (c & 3)
+                    assert float(flat[off]) == float(t[b, y, x, c]), (b, y, x, c)
+    assert torch.equal(hip.rp4_to_nhwc(r), t)
+    assert hip.V(r).rp == W and hip.V(t).rp == 0
+    with pytest.raises(AssertionError):
+        hip.V(r, 4, 4)          # a channel slice of a row-planar tensor is not a strided view: refused
