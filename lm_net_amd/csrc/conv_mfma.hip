@@ -72,15 +72,26 @@ template <bool BF> __device__ __forceinline__ typename Frag<BF>::type ldfrag(con
 __device__ __forceinline__ f32x4 mfma_bf16(uint2 a, uint2 b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s16x4, a), __builtin_bit_cast(s16x4, b), c, 0, 0, 0);
 }
-// gfx950's own shape, v_mfma_f32_16x16x32_bf16 (twice the K per instruction at the cycles of the 16x16x16 form): TWO 4-bf16
-// fragments per operand.  The instruction's k index of lane group q, element j is 8q + j; the fragments carry (block 0: channels
-// 4q..4q+3 | block 1: channels 16+4q..16+4q+3) -- a different bijection k <-> channel, which is fine as long as A and B use the
-// SAME one: the sum over k is the sum over the 32 channels.  So two K16 blocks (or two 16-pixel K steps of a weight gradient)
-// are fused with the LDS / packed layouts unchanged.
+// Two K16 blocks (or two 16-pixel K steps of a weight gradient) per call: TWO v_mfma_f32_16x16x16_bf16.
+// gfx950 has a shape of its own for this, v_mfma_f32_16x16x32_bf16 (twice the K per instruction at the cycles of the 16x16x16 form;
+// its k index of lane group q, element j is 8q + j, the fragments carry block 0: channels 4q..4q+3 | block 1: channels 16+4q..16+4q+3
+// -- a different bijection k <-> channel, which is fine as long as A and B use the same one), and rounds 2-3 used it (+1.6 % at
+// bf16 batch 64).  NOT USED ANY MORE (round 4): kernels issuing it corrupt the results of OTHER kernels running beside them on
+// another stream.  Found with the deterministic-mode schedule check in bf16: the neighborhood-attention backward of level 1 came
+// out with wrong sum_n p_n dp_n terms for ~0.4 % of the queries (errors of 0.2 on values of order 1: wrong dq / dk, correct dv)
+// whenever a bf16 3x3 conv or weight gradient ran on a second stream; reproduced stand-alone (tools/gpu_na_stress2.py: 27 of 30
+// runs wrong against a quiet re-run and against the fp32 oracle; the fp32 attention kernel beside a bf16 conv likewise; inputs,
+// canaries around the buffers and the kernels' register allocations all intact); 0 of 80 with this function as two 16x16x16
+// MFMAs, 0 with fp32 conv kernels, 0 with the bf16 instances that never reach the 32-wide form (one K16 block; the M-split and
+// 1x1 instances were not seen to do it either).  -DLMN_MFMA_X2 restores the instruction for experiments.
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 __device__ __forceinline__ f32x4 mfma_bf16x2(uint2 a0, uint2 a1, uint2 b0, uint2 b1, f32x4 c) {
+#ifdef LMN_MFMA_X2
   const uint4 a = uint4{a0.x, a0.y, a1.x, a1.y}, b = uint4{b0.x, b0.y, b1.x, b1.y};
   return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+#else
+  return mfma_bf16(a1, b1, mfma_bf16(a0, b0, c));
+#endif
 }
 
 // ------------------------------------------------------------------------------------ LDS-tiled forward / data-gradient

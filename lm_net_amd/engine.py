@@ -912,13 +912,26 @@ class Engine:
         do = _A(x, B, H, W, C)
         self._lin_bwd(m.att1.proj, o, da, do)
         dqkv = _A(x, B, H, W, 3 * C)
+        dbg = {} if self.debug_keep is not None else None
+        if dbg is not None:
+            dbg["do"] = do.clone()
         hip.na_bwd(qkv, m.att1.rpb, do, dqkv, G[m.att1.rpb], m.att1.num_heads)
+        if dbg is not None:
+            dbg["dqkv_now"] = dqkv.clone()
+            dbg["do_after"] = do.clone()
+            # the same call again into a second buffer (bias gradient into a dummy): equal inputs, equal kernel -> equal output?
+            dq2 = torch.empty_like(dqkv)
+            hip.na_bwd(qkv, m.att1.rpb, do, dq2, torch.zeros_like(G[m.att1.rpb]), m.att1.num_heads)
+            dbg["dqkv_second"] = dq2
         dn1 = do
         self._lin_bwd(m.att1.qkv, n1, dqkv, dn1)
         de = _A(x, B, H, W, C)
         hip.ln_bwd(e, m.norm1.weight, dn1, da, de, G[m.norm1.weight], G[m.norm1.bias])
         dx = _A(x, B, H, W, C)
         self.conv3_bwd(m.patchembedding.patch_embeddings, x, de, dx=dx)
+        if self.debug_keep is not None:      # (tools/gpu_race_locate.py: intermediates of the block, cloned in stream order)
+            self.debug_keep[m] = dict(dy=dy.clone(), dn2=dn2.clone(), da=da.clone(), dqkv=dqkv.clone(), dn1=dn1.clone(), de=de.clone(), dx=dx.clone(),
+                                      qkv=qkv.clone(), o=o.clone(), n1=n1.clone(), **dbg)
         return dx
 
     def gft_fwd(self, m, catp, cx, tag):
