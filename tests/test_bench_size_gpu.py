@@ -113,16 +113,17 @@ def test_multi_stream_equals_serial_in_bf16(names):
         hip.set_deterministic(False)
 
 
-def test_hooks_plans_and_host_launches_agree_at_bench_size(names):
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_hooks_plans_and_host_launches_agree_at_bench_size(names, dtype):
     """Gradient-bucket hooks on / off x host launches / recorded plans: identical bits after five steps (the plan is recorded on the
     third and replayed after), and the reported buckets tile the flat gradient buffer contiguously from 0
-    (tools/gpu_bucket_hook_check.py as a test)."""
+    (tools/gpu_bucket_hook_check.py as a test); in the fp32 and in the bf16 mode."""
     from lm_net_amd import hip
     try:
-        ref = _train(steps=5)
+        ref = _train(steps=5, dtype=dtype)
         for hooks, plans in ((True, False), (False, True), (True, True)):
             calls = [] if hooks else None
-            got = _train(steps=5, plans=plans, hooks=calls)
+            got = _train(steps=5, plans=plans, hooks=calls, dtype=dtype)
             _same_bits(ref, got, names, (hooks, plans))
             if hooks:
                 cov = [c for c in calls if isinstance(c[0], int)]
