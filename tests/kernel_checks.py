@@ -1030,6 +1030,74 @@ def check_conv_bf16():
     return rows
 
 
+def check_bf16_storage_rows():
+    """bf16 activation STORAGE in the kernels that are not dense contractions (the conv family has check_conv_bf16): the depthwise
+    passes and the neighborhood-attention kernels templated on the storage type.  On bf16-representable inputs the bf16-storage
+    launch must equal the fp32-storage launch of the same kernel up to the rounding of its outputs to bf16 (2^-8 relative per
+    element; statistics, weight and bias-table gradients stay fp32: 2e-4 / float-atomic noise) -- a wrong element size in an address
+    computation or a mis-paired half cannot hide behind the model-level bf16 tolerances."""
+    rows = []
+    bf = lambda t: t.to(torch.bfloat16)
+    # ---- depthwise passes (row-planar tensors)
+    for (B, H, W, E) in [(2, 20, 19, 24), (1, 33, 61, 8), (1, 9, 130, 16)]:
+        x1 = R(B, E, H, W, seed=301).to(torch.bfloat16).double()
+        wd = [dev(R(E, 1, 5, 5, seed=302, scale=0.2)), dev(R(E, 1, 3, 3, seed=303, scale=0.3)), dev(R(E, 1, 3, 1, seed=304, scale=0.5)),
+              dev(R(E, 1, 1, 3, seed=305, scale=0.5))]
+        tag = " E=%d %dx%d" % (E, H, W)
+        x32 = nhwcE(x1)
+        x16 = hip.rp4(bf(x32))
+        st32, st16 = torch.zeros(4, 2, E, device=DEV), torch.zeros(4, 2, E, device=DEV)
+        hip.dw_stats(x32, *wd, st32)
+        hip.dw_stats(x16, *wd, st16)
+        rows.append(("bf16 storage dw_stats" + tag, rel(st16, st32), 2e-4))
+        keff, beff = dev(R(E, 25, seed=306, scale=0.2)), dev(R(E, seed=307))
+        p32, p16 = torch.full((B, H, W, E), float("nan"), device=DEV), hip.rp4(torch.full((B, H, W, E), float("nan"), device=DEV, dtype=torch.bfloat16))
+        g32, g16 = torch.zeros(B, E, device=DEV), torch.zeros(B, E, device=DEV)
+        hip.dw_fwd(x32, hip.rp4(p32), g32, keff, beff)
+        hip.dw_fwd(x16, p16, g16, keff, beff)
+        rows.append(("bf16 storage dw_fwd pre" + tag, rel(p16.float(), p32), 8e-3))
+        rows.append(("bf16 storage dw_fwd gsum" + tag, rel(g16, g32), 2e-4))
+        # backward pair on the bf16-rounded pre (so that both launches see the same inputs)
+        pre_in = p16.float()
+        u = nhwcE(R(B, E, H, W, seed=308).to(torch.bfloat16).double())
+        sg, dm = dev(torch.rand(B, E, dtype=torch.float64) * 0.8 + 0.1), dev(R(B, E, seed=309) * 0.01)
+        d32, d16 = hip.rp4(torch.full((B, H, W, E), float("nan"), device=DEV)), hip.rp4(torch.full((B, H, W, E), float("nan"), device=DEV, dtype=torch.bfloat16))
+        b32, b16 = torch.zeros(5, E, device=DEV), torch.zeros(5, E, device=DEV)
+        hip.dw_bwd_stats(x32, hip.rp4(pre_in.clone()), u, sg, dm, d32, *wd, b32)
+        hip.dw_bwd_stats(x16, p16, hip.rp4(bf(u)), sg, dm, d16, *wd, b16)
+        rows.append(("bf16 storage dw_bwd_stats dpre" + tag, rel(d16.float(), d32), 8e-3))
+        rows.append(("bf16 storage dw_bwd_stats sums" + tag, rel(b16, b32), 5e-3))       # (sums of the ROUNDED dpre on one side)
+        cA, cC, cD = dev(R(4, E, seed=310)), dev(R(4, E, seed=311) * 0.1), dev(R(4, E, seed=312) * 0.01)
+        dq = hip.rp4(d16.float().contiguous())          # the same (bf16-representable) dpre for both
+        outs = []
+        for xin, din, dt_ in ((x32, dq, torch.float32), (x16, d16, torch.bfloat16)):
+            dx = hip.rp4(torch.full((B, H, W, E), float("nan"), device=DEV, dtype=dt_))
+            gw = [torch.zeros_like(w) for w in wd]
+            hip.dw_bwd(xin, din, dx, *wd, cA, cC, cD, *gw)
+            outs.append((dx.float(), gw))
+        rows.append(("bf16 storage dw_bwd dx1" + tag, rel(outs[1][0], outs[0][0]), 8e-3))
+        for i, nm in enumerate(("w5", "w3", "wv", "wh")):
+            rows.append(("bf16 storage dw_bwd d%s%s" % (nm, tag), rel(outs[1][1][i], outs[0][1][i]), 2e-4))
+    # ---- neighborhood attention (all head dims of the model; the one-pass backward at hd <= 2, the two-pass kernels above)
+    for (B, H, W, hd) in [(2, 37, 41, 1), (1, 32, 36, 2), (2, 47, 19, 2), (1, 20, 23, 4), (1, 12, 9, 8)]:
+        heads, Cn = 12, 12 * hd
+        qkv = dev(R(B, H, W, 3 * Cn, seed=321).to(torch.bfloat16).double())
+        rpb = dev(R(heads, 5, 5, seed=322) * 0.5)
+        do = dev(R(B, H, W, Cn, seed=323).to(torch.bfloat16).double())
+        tag = " hd=%d %dx%d" % (hd, H, W)
+        o32, o16 = torch.full((B, H, W, Cn), float("nan"), device=DEV), torch.full((B, H, W, Cn), float("nan"), device=DEV, dtype=torch.bfloat16)
+        hip.na_fwd(qkv, rpb, o32, heads)
+        hip.na_fwd(bf(qkv), rpb, o16, heads)
+        rows.append(("bf16 storage na_fwd" + tag, rel(o16.float(), o32), 8e-3))
+        g32, g16 = torch.full_like(qkv, float("nan")), torch.full((B, H, W, 3 * Cn), float("nan"), device=DEV, dtype=torch.bfloat16)
+        r32, r16 = torch.zeros_like(rpb), torch.zeros_like(rpb)
+        hip.na_bwd(qkv, rpb, do, g32, r32, heads)
+        hip.na_bwd(bf(qkv), rpb, bf(do), g16, r16, heads)
+        rows.append(("bf16 storage na_bwd dqkv" + tag, rel(g16.float(), g32), 8e-3))
+        rows.append(("bf16 storage na_bwd drpb" + tag, rel(r16, r32), 2e-4))
+    return rows
+
+
 def check_bn_shifted_stats():
     """Batch variance when |mean| >> std (a large conv bias: |mean| / std ~ 1e3).  The conv epilogue sums about the
     BatchNorm's running mean (lmn_conv_fwd p4 / lmn_bn_finalize `about`), so E[d^2] - E[d]^2 does not cancel the squared
