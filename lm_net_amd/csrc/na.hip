@@ -678,7 +678,12 @@ __global__ __launch_bounds__(256) void na_bwd_kv_tile_kernel(const TA* __restric
 // A thread keeps one channel quad; blockDim = 85 pixel slots x C/4 quads (255 of 256 threads at C = 12, 510 of 512 at C = 24), and
 // the 15 x 17 tile is 3 such rounds, its 17 x 19 statistics region 4.  HBM traffic: the algorithmic 7 C per pixel plus halo
 // re-reads that neighbouring blocks find in L2; no lse / dsum workspace.
-template <int HD, typename TA>
+// q = (n * m) >> 16 with m = ceil(65536 / d): exact for n < 1024, d <= 64 (pixel indices inside a tile's windows); the generic
+// 32-bit signed divisions the index arithmetic compiled to were a quarter of the kernel's instructions
+__device__ __forceinline__ uint32_t na_magic16(uint32_t d) { return (65535u + d) / d; }
+__device__ __forceinline__ int na_div16(int n, uint32_t m) { return (int)(((uint32_t)n * m) >> 16); }
+
+template <int HD, int C4, typename TA>
 __global__ __launch_bounds__(512) void na_bwd_fused_kernel(const TA* __restrict__ qkv, const float* __restrict__ rpb,
                                                            const TA* __restrict__ dout, TA* __restrict__ dqkv,
                                                            float* __restrict__ drpb, const NaGeom g, int TH, int TW, int tiles_x,
@@ -692,11 +697,15 @@ __global__ __launch_bounds__(512) void na_bwd_fused_kernel(const TA* __restrict_
   float* ST = s_wt + nwave * ntab;                             // [statistics region][2*heads]: lse | dsum  (st_floats: the largest region of this map)
   float* Wn = ST + st_floats;                                  // k, v window, then q, dO window, then the parked bins
   const int tid = threadIdx.x;
-  for (int i = tid; i < g.heads * 25; i += NT) { s_drpb[i] = 0.f; s_rpb[(i % 25) * g.heads + i / 25] = rpb[i]; }
+  // scores are kept in base 2 (q and the bias table carry log2(e)): softmax weights are v_exp_f32 of a difference, no multiply
+  constexpr float LOG2E = 1.4426950408889634f;
+  const float scale2 = g.scale * LOG2E;
+  for (int i = tid; i < g.heads * 25; i += NT) { s_drpb[i] = 0.f; s_rpb[(i % 25) * g.heads + i / 25] = rpb[i] * LOG2E; }
   for (int i = tid; i < nwave * ntab; i += NT) s_wt[i] = 0.f;
-  const int PB = NT / g.C4;
-  const int c = (tid % g.C4) * 4;
-  const int slot = tid / g.C4;
+  constexpr int C = 4 * C4;   // (= g.C: a template argument so that the channel-quad arithmetic is constant division)
+  const int PB = NT / C4;
+  const int c = (tid % C4) * 4;
+  const int slot = tid / C4;
   const int SH2 = 2 * g.heads;
   f32x4 bins[9];
 #pragma unroll
@@ -718,11 +727,12 @@ __global__ __launch_bounds__(512) void na_bwd_fused_kernel(const TA* __restrict_
     const int SHt = sy1 - sy0, SWd = sx1 - sx0, nsp = SHt * SWd;
     const int ky0 = wstart(sy0, g.H), kx0 = wstart(sx0, g.W);
     const int KH = wstart(sy1 - 1, g.H) + 3 - ky0, KW = wstart(sx1 - 1, g.W) + 3 - kx0;
-    const int64_t ib = (int64_t)b * g.H * g.W * 3 * g.C;
+    const uint32_t mKW = na_magic16((uint32_t)KW), mSW = na_magic16((uint32_t)SWd);
+    const int64_t ib = (int64_t)b * g.H * g.W * 3 * C;
     const TA* base = qkv + ib;
     __syncthreads();  // the previous tile's windows are consumed (first tile: the tables are written)
     {  // ---- k, v of the K region -> Wn [(pixel)*2 + which][C]
-      const int nit = KH * KW * 2 * g.C4;
+      const int nit = KH * KW * 2 * C4;
       for (int i0 = 0; i0 < nit; i0 += 4 * NT) {
         f32x4 sv[4];
 #pragma unroll
@@ -730,14 +740,15 @@ __global__ __launch_bounds__(512) void na_bwd_fused_kernel(const TA* __restrict_
           const int i = i0 + u * NT + tid;
           const bool in = i < nit;
           const int ii = in ? i : 0;
-          const int c4 = ii % g.C4, w = (ii / g.C4) & 1, wp = ii / (2 * g.C4);
-          const int gy = ky0 + wp / KW, gx = kx0 + wp % KW;
-          sv[u] = ld4(base + ((int64_t)gy * g.W + gx) * 3 * g.C + (1 + w) * g.C + c4 * 4);
+          const int c4 = ii % C4, w = (ii / C4) & 1, wp = ii / (2 * C4);
+          const int wr = na_div16(wp, mKW);
+          const int gy = ky0 + wr, gx = kx0 + wp - wr * KW;
+          sv[u] = ld4(base + (gy * g.W + gx) * 3 * C + (1 + w) * C + c4 * 4);
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
           const int i = i0 + u * NT + tid;
-          if (i < nit) *reinterpret_cast<f32x4*>(&Wn[(i / g.C4) * g.C + (i % g.C4) * 4]) = sv[u];
+          if (i < nit) *reinterpret_cast<f32x4*>(&Wn[i * 4]) = sv[u];      // [(pixel * 2 + which) * C + quad * 4] = 4 i
         }
       }
     }
@@ -747,21 +758,22 @@ __global__ __launch_bounds__(512) void na_bwd_fused_kernel(const TA* __restrict_
       const int pl = p0 + slot;
       const bool ok = slot < PB && pl < nsp;
       const int pls = ok ? pl : 0;
-      const int y = sy0 + pls / SWd, x = sx0 + pls % SWd;
+      const int pr = na_div16(pls, mSW);
+      const int y = sy0 + pr, x = sx0 + pls - pr * SWd;
       const bool own = ok && y >= ty0 && y < ty1 && x >= tx0 && x < tx1;   // a query of the tile: dq and the bias gradient are this block's
       const int64_t pix = ((int64_t)b * g.H + y) * g.W + x;
       const int sy = wstart(y, g.H), sx = wstart(x, g.W);
-      const float* kv0 = Wn + (((sy - ky0) * KW + (sx - kx0)) * 2) * g.C + c;
-      const f32x4 q = ld4(base + ((int64_t)y * g.W + x) * 3 * g.C + c) * g.scale;
-      const f32x4 dO = ld4(dout + pix * g.C + c);
+      const float* kv0 = Wn + (((sy - ky0) * KW + (sx - kx0)) * 2) * C + c;
+      const f32x4 q = ld4(base + (y * g.W + x) * 3 * C + c) * scale2;
+      const f32x4 dO = ld4(dout + pix * C + c);
       f32x4 p[9], dp[9];
       f32x4 mx = f32x4{-3.0e38f, -3.0e38f, -3.0e38f, -3.0e38f};
 #pragma unroll
       for (int ki = 0; ki < 3; ++ki)
 #pragma unroll
         for (int kj = 0; kj < 3; ++kj) {
-          const float* kvn = kv0 + ((ki * KW + kj) * 2) * g.C;
-          const f32x4 kk = *reinterpret_cast<const f32x4*>(kvn), vv = *reinterpret_cast<const f32x4*>(kvn + g.C);
+          const float* kvn = kv0 + ((ki * KW + kj) * 2) * C;
+          const f32x4 kk = *reinterpret_cast<const f32x4*>(kvn), vv = *reinterpret_cast<const f32x4*>(kvn + C);
           f32x4 sc = head_sum<HD>(q * kk);
           const int bo = (sy + ki - y + 2) * 5 + (sx + kj - x + 2);
           sc += rpb4<HD>(s_rpb, g.heads, bo, c);
@@ -774,12 +786,12 @@ __global__ __launch_bounds__(512) void na_bwd_fused_kernel(const TA* __restrict_
 #pragma unroll
       for (int n = 0; n < 9; ++n) {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) p[n][k] = __expf(p[n][k] - mx[k]);
+        for (int k = 0; k < 4; ++k) p[n][k] = __builtin_amdgcn_exp2f(p[n][k] - mx[k]);
         den += p[n];
       }
-      f32x4 dsum = f32x4{0.f, 0.f, 0.f, 0.f}, rden, lse;
+      f32x4 dsum = f32x4{0.f, 0.f, 0.f, 0.f}, rden, lse;   // lse in base 2 as well
 #pragma unroll
-      for (int k = 0; k < 4; ++k) { rden[k] = __builtin_amdgcn_rcpf(den[k]); lse[k] = mx[k] + __logf(den[k]); }
+      for (int k = 0; k < 4; ++k) { rden[k] = __builtin_amdgcn_rcpf(den[k]); lse[k] = mx[k] + __builtin_amdgcn_logf(den[k]); }
 #pragma unroll
       for (int n = 0; n < 9; ++n) {
         p[n] = p[n] * rden;
@@ -799,7 +811,7 @@ __global__ __launch_bounds__(512) void na_bwd_fused_kernel(const TA* __restrict_
           for (int kj = 0; kj < 3; ++kj) {
             const int n = ki * 3 + kj;
             const f32x4 ds = p[n] * (dp[n] - dsum);
-            dq += ds * *reinterpret_cast<const f32x4*>(kv0 + ((ki * KW + kj) * 2) * g.C);
+            dq += ds * *reinterpret_cast<const f32x4*>(kv0 + ((ki * KW + kj) * 2) * C);
             bins[n] += ds * rm;
             if (!inter) {  // border pixels (the clamped window shifts the bins): rare, through LDS atomics
               const int bo = (sy + ki - y + 2) * 5 + (sx + kj - x + 2);
@@ -808,12 +820,13 @@ __global__ __launch_bounds__(512) void na_bwd_fused_kernel(const TA* __restrict_
                 if ((c + k) % HD == 0) atomicAdd(&s_wave[hidx[k] + bo], ds[k]);
             }
           }
-        st4(dqkv + ib + ((int64_t)y * g.W + x) * 3 * g.C + c, dq * g.scale);
+        st4(dqkv + ib + (y * g.W + x) * 3 * C + c, dq * g.scale);
       }
     }
     __syncthreads();  // ST complete; the k / v window is consumed
     {  // ---- q, dO of the statistics region -> Wn [(pixel)*2 + which][C]
-      const int nit = nsp * 2 * g.C4;
+      const int nit = nsp * 2 * C4;
+      const TA* dob = dout + (int64_t)b * g.H * g.W * C;
       for (int i0 = 0; i0 < nit; i0 += 4 * NT) {
         f32x4 sv[4];
 #pragma unroll
@@ -821,33 +834,35 @@ __global__ __launch_bounds__(512) void na_bwd_fused_kernel(const TA* __restrict_
           const int i = i0 + u * NT + tid;
           const bool in = i < nit;
           const int ii = in ? i : 0;
-          const int c4 = ii % g.C4, w = (ii / g.C4) & 1, wp = ii / (2 * g.C4);
-          const int gy = sy0 + wp / SWd, gx = sx0 + wp % SWd;
-          sv[u] = w ? ld4(dout + (((int64_t)b * g.H + gy) * g.W + gx) * g.C + c4 * 4)
-                    : ld4(base + ((int64_t)gy * g.W + gx) * 3 * g.C + c4 * 4);
+          const int c4 = ii % C4, w = (ii / C4) & 1, wp = ii / (2 * C4);
+          const int wr = na_div16(wp, mSW);
+          const int gp = (sy0 + wr) * g.W + sx0 + wp - wr * SWd;
+          sv[u] = w ? ld4(dob + gp * C + c4 * 4) : ld4(base + gp * 3 * C + c4 * 4) * scale2;   // (q staged with the score scale: once per element, not per candidate)
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
           const int i = i0 + u * NT + tid;
-          if (i < nit) *reinterpret_cast<f32x4*>(&Wn[(i / g.C4) * g.C + (i % g.C4) * 4]) = sv[u];
+          if (i < nit) *reinterpret_cast<f32x4*>(&Wn[i * 4]) = sv[u];
         }
       }
     }
     __syncthreads();
     // ---- phase B
     const int tw = tx1 - tx0, ntp = (ty1 - ty0) * tw;
+    const uint32_t mtw = na_magic16((uint32_t)tw);
     for (int p0 = 0; p0 < ntp; p0 += PB) {
       const int pl = p0 + slot;
       const bool ok = slot < PB && pl < ntp;
       const int pls = ok ? pl : 0;
-      const int jy = ty0 + pls / tw, jx = tx0 + pls % tw;
-      const int64_t kpo = ((int64_t)jy * g.W + jx) * 3 * g.C;
-      const f32x4 kj = ld4(base + kpo + g.C + c), vj = ld4(base + kpo + 2 * g.C + c);
+      const int jr = na_div16(pls, mtw);
+      const int jy = ty0 + jr, jx = tx0 + pls - jr * tw;
+      const int kpo = (jy * g.W + jx) * 3 * C;
+      const f32x4 kj = ld4(base + kpo + C + c), vj = ld4(base + kpo + 2 * C + c);
       f32x4 dk = f32x4{0.f, 0.f, 0.f, 0.f}, dv = dk;
       auto candidate = [&](int iy, int ix) {
         const int sl = (iy - sy0) * SWd + (ix - sx0);
-        const f32x4 qi = *reinterpret_cast<const f32x4*>(Wn + (sl * 2) * g.C + c) * g.scale;
-        const f32x4 dOi = *reinterpret_cast<const f32x4*>(Wn + (sl * 2 + 1) * g.C + c);
+        const f32x4 qi = *reinterpret_cast<const f32x4*>(Wn + (sl * 2) * C + c);
+        const f32x4 dOi = *reinterpret_cast<const f32x4*>(Wn + (sl * 2 + 1) * C + c);
         const float* sp = ST + sl * SH2;
         f32x4 lse4, dsm4;
         if constexpr (HD == 1) {
@@ -865,10 +880,10 @@ __global__ __launch_bounds__(512) void na_bwd_fused_kernel(const TA* __restrict_
         f32x4 pij, ds;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-          pij[k] = __expf(sc[k] + rb[k] - lse4[k]);
+          pij[k] = __builtin_amdgcn_exp2f(sc[k] + rb[k] - lse4[k]);
           ds[k] = pij[k] * (dpv[k] - dsm4[k]);
         }
-        dk += ds * qi;   // qi carries the scale
+        dk += ds * qi;   // qi carries scale * log2(e): taken out once below
         dv += pij * dOi;
       };
       if (jy >= 3 && jy <= g.H - 4 && jx >= 3 && jx <= g.W - 4) {   // interior key: exactly its 3x3 neighbourhood, all unclamped
@@ -890,8 +905,8 @@ __global__ __launch_bounds__(512) void na_bwd_fused_kernel(const TA* __restrict_
         }
       }
       if (ok) {
-        st4(dqkv + ib + kpo + g.C + c, dk);
-        st4(dqkv + ib + kpo + 2 * g.C + c, dv);
+        st4(dqkv + ib + kpo + C + c, dk * (1.0f / LOG2E));
+        st4(dqkv + ib + kpo + 2 * C + c, dv);
       }
     }
   }
@@ -902,13 +917,13 @@ __global__ __launch_bounds__(512) void na_bwd_fused_kernel(const TA* __restrict_
 #pragma unroll
     for (int k = 0; k < 4; ++k) s_bins[tid * 36 + n * 4 + k] = bins[n][k];
   __syncthreads();
-  for (int o = tid; o < g.C4 * 36; o += NT) {
+  for (int o = tid; o < C4 * 36; o += NT) {
     const int qd = o / 36, nk = o - qd * 36;
     const int n = nk >> 2, k = nk & 3;
     const int ch = qd * 4 + k;
     if (ch % HD != 0) continue;
     float v = 0.f;
-    for (int sl = 0; sl < PB; ++sl) v += s_bins[(sl * g.C4 + qd) * 36 + nk];
+    for (int sl = 0; sl < PB; ++sl) v += s_bins[(sl * C4 + qd) * 36 + nk];
     s_drpb[(ch / HD) * 25 + (n / 3 + 1) * 5 + (n % 3 + 1)] = v;   // (one writer per (head, bin))
   }
   __syncthreads();
@@ -1268,7 +1283,7 @@ int lmn_na_bwd(const void* qkv_, const float* rpb, const void* dout_, void* dqkv
   // ---- one-pass form (na_bwd_fused_kernel): 15 x 17 tiles = 3 rounds of 85 pixel slots, statistics region 17 x 19 (+1 where a tile
   // ends two short of the border), k / v window +2.  LMN_NA_FUSED=0: the two-pass tile kernels (A/B runs)
   static const int fused_env = getenv("LMN_NA_FUSED") ? atoi(getenv("LMN_NA_FUSED")) : 1;
-  if (tiled && fused_env && (hd == 1 ? heads % 4 == 0 : true)) {
+  if (tiled && fused_env && heads == 12) {   // (the kernel's channel-quad count is a template argument: 12 heads x head_dim / 4)
     const int TH = 15, TW = 17, NT = g.C4 == 3 ? 256 : 512, nwave = NT / 64;
     const int tx = lmn_cdiv(W, TW), ty = lmn_cdiv(H, TH), total = tx * ty * B;
     const int ey = (H - 2 >= TH && (H - 2) % TH == 0) ? 1 : 0, ex = (W - 2 >= TW && (W - 2) % TW == 0) ? 1 : 0;
@@ -1287,8 +1302,8 @@ int lmn_na_bwd(const void* qkv_, const float* rpb, const void* dout_, void* dqkv
       if (g_lmn_prof_on) lmn_prof_cost(2.0 * 6 * 9 * (double)B * H * W * g.C, (act_dtype == LMN_BF16 ? 2.0 : 4.0) * 7 * (double)B * H * W * g.C);
 #define LMN_NAF(HDV)                                                                                                                \
   do {                                                                                                                              \
-    if (fsh > 64 * 1024) (void)hipFuncSetAttribute((const void*)na_bwd_fused_kernel<HDV, T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fsh); \
-    LMN_LAUNCH((na_bwd_fused_kernel<HDV, T>), dim3(gf), dim3(NT), fsh, st, (const T*)qkv, rpb, (const T*)dout, (T*)dqkv, dslot, g, TH, TW, tx, \
+    if (fsh > 64 * 1024) (void)hipFuncSetAttribute((const void*)na_bwd_fused_kernel<HDV, 3 * HDV, T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fsh); \
+    LMN_LAUNCH((na_bwd_fused_kernel<HDV, 3 * HDV, T>), dim3(gf), dim3(NT), fsh, st, (const T*)qkv, rpb, (const T*)dout, (T*)dqkv, dslot, g, TH, TW, tx, \
                tx * ty, total, st_floats, g_lmn_det);                                                                               \
   } while (0)
       LMN_ACT_DISPATCH(act_dtype, if (hd == 1) LMN_NAF(1); else LMN_NAF(2););
