@@ -57,7 +57,22 @@ __device__ __forceinline__ void stat_store(float* dst, int c, f32x4 v, bool ok) 
 struct NaGeom {
   int B, H, W, C, C4, heads;
   float scale;
-};
+  uint32_t mW, mHW, mC4;   // floor(2^32 / d) for d = W, H*W, C4 (lmn_div_row): the index decodes below were 64-bit software divisions,
+};                         // three to five per item -- several hundred instructions next to ~200 of arithmetic
+
+// flat item index -> channel quad, image, row, column (all < 2^31: checked on the host)
+struct NaPix { int c, b, y, x; };
+__device__ __forceinline__ NaPix na_decode_pix(const NaGeom& g, uint32_t pix) {
+  const uint32_t b = lmn_div_row(pix, (uint32_t)(g.H * g.W), g.mHW), r = pix - b * (uint32_t)(g.H * g.W);
+  const uint32_t y = lmn_div_row(r, (uint32_t)g.W, g.mW);
+  return NaPix{0, (int)b, (int)y, (int)(r - y * (uint32_t)g.W)};
+}
+__device__ __forceinline__ NaPix na_decode_item(const NaGeom& g, uint32_t idx) {
+  const uint32_t pix = lmn_div_row(idx, (uint32_t)g.C4, g.mC4);
+  NaPix p = na_decode_pix(g, pix);
+  p.c = (int)(idx - pix * (uint32_t)g.C4) * 4;
+  return p;
+}
 
 // window start (clamped, never padded) -- oracle/natten_ref.py: window_start
 __device__ __forceinline__ int wstart(int i, int L) {
@@ -177,18 +192,17 @@ __global__ __launch_bounds__(256) void na_bwd_q_kernel(const TA* __restrict__ qk
   const int PB = 256 / g.C4;                       // pixels per block iteration
   const int c = (threadIdx.x % g.C4) * 4;
   const int slot = threadIdx.x / g.C4;
-  const int64_t npix = (int64_t)g.B * g.H * g.W;
-  const int64_t nit = (npix + (int64_t)gridDim.x * PB - 1) / ((int64_t)gridDim.x * PB);
+  const int npix = g.B * g.H * g.W;
+  const int nit = (npix + (int)gridDim.x * PB - 1) / ((int)gridDim.x * PB);
   f32x4 bins[9];
 #pragma unroll
   for (int n = 0; n < 9; ++n) bins[n] = f32x4{0.f, 0.f, 0.f, 0.f};
-  for (int64_t it = 0; it < nit; ++it) {
-    int64_t pix = (it * gridDim.x + blockIdx.x) * PB + slot;
+  for (int it = 0; it < nit; ++it) {
+    int pix = (it * (int)gridDim.x + (int)blockIdx.x) * PB + slot;
     const bool ok = slot < PB && pix < npix;
     if (!ok) pix = npix - 1;  // keep every lane in the shuffles
-    const int x = (int)(pix % g.W);
-    const int y = (int)((pix / g.W) % g.H);
-    const int b = (int)(pix / ((int64_t)g.W * g.H));
+    const NaPix pd = na_decode_pix(g, (uint32_t)pix);
+    const int x = pd.x, y = pd.y, b = pd.b;
     const int sy = wstart(y, g.H), sx = wstart(x, g.W);
     const int64_t ib = (int64_t)b * g.H * g.W * 3 * g.C;
     const TA* base = qkv + ib;
@@ -461,17 +475,15 @@ __global__ __launch_bounds__(256) void na_bwd_kv_kernel(const TA* __restrict__ q
   __shared__ __attribute__((aligned(16))) float s_rpb[16 * 25];
   for (int i = threadIdx.x; i < g.heads * 25; i += 256) s_rpb[(i % 25) * g.heads + i / 25] = rpb[i];
   __syncthreads();
-  const int64_t total = (int64_t)g.B * g.H * g.W * g.C4;
-  const int64_t nit = (total + (int64_t)gridDim.x * 256 - 1) / ((int64_t)gridDim.x * 256);
-  for (int64_t it = 0; it < nit; ++it) {
-    int64_t idx = (it * gridDim.x + blockIdx.x) * 256 + threadIdx.x;
+  const int total = g.B * g.H * g.W * g.C4;
+  const int nit = (total + (int)gridDim.x * 256 - 1) / ((int)gridDim.x * 256);
+  for (int it = 0; it < nit; ++it) {
+    int idx = (it * (int)gridDim.x + (int)blockIdx.x) * 256 + (int)threadIdx.x;
     const bool ok = idx < total;
     if (!ok) idx = total - 1;
-    const int c = (int)(idx % g.C4) * 4;
-    const int64_t pix = idx / g.C4;
-    const int jx = (int)(pix % g.W);
-    const int jy = (int)((pix / g.W) % g.H);
-    const int b = (int)(pix / ((int64_t)g.W * g.H));
+    const NaPix pd = na_decode_item(g, (uint32_t)idx);
+    const int c = pd.c;
+    const int jx = pd.x, jy = pd.y, b = pd.b;
     const int64_t ib = (int64_t)b * g.H * g.W * 3 * g.C;
     const TA* base = qkv + ib;
     const int64_t kpo = ((int64_t)jy * g.W + jx) * 3 * g.C;
@@ -950,15 +962,16 @@ template <int HD, typename TA>
 __global__ __launch_bounds__(256) void na_fwd_gen_kernel(const TA* __restrict__ qkv, const float* __restrict__ rpb,
                                                          TA* __restrict__ out, const NaGeom g, int K) {
   const int RB = 2 * K - 1;
-  const int64_t total = (int64_t)g.B * g.H * g.W * g.C4;
-  const int64_t nit = (total + (int64_t)gridDim.x * 256 - 1) / ((int64_t)gridDim.x * 256);
-  for (int64_t it = 0; it < nit; ++it) {
-    int64_t idx = (it * gridDim.x + blockIdx.x) * 256 + threadIdx.x;
+  const int total = g.B * g.H * g.W * g.C4;
+  const int nit = (total + (int)gridDim.x * 256 - 1) / ((int)gridDim.x * 256);
+  for (int it = 0; it < nit; ++it) {
+    int idx = (it * (int)gridDim.x + (int)blockIdx.x) * 256 + (int)threadIdx.x;
     const bool ok = idx < total;
     if (!ok) idx = total - 1;   // keep every lane in the shuffles
-    const int c = (int)(idx % g.C4) * 4;
-    const int64_t pix = idx / g.C4;
-    const int x = (int)(pix % g.W), y = (int)((pix / g.W) % g.H), b = (int)(pix / ((int64_t)g.W * g.H));
+    const NaPix pd = na_decode_item(g, (uint32_t)idx);
+    const int c = pd.c;
+    const int64_t pix = (int64_t)(pd.b * g.H + pd.y) * g.W + pd.x;
+    const int x = pd.x, y = pd.y, b = pd.b;
     const TA* base = qkv + (int64_t)b * g.H * g.W * 3 * g.C;
     const int sy = wstart_k(y, g.H, K), sx = wstart_k(x, g.W, K);
     const f32x4 q = ld4(base + ((int64_t)y * g.W + x) * 3 * g.C + c) * g.scale;
@@ -1005,15 +1018,16 @@ __global__ __launch_bounds__(256) void na_bwd_q_gen_kernel(const TA* __restrict_
   float* s_tab = s_all + (threadIdx.x >> 6) * NB;
   for (int i = threadIdx.x; i < 4 * NB; i += 256) s_all[i] = 0.f;
   __syncthreads();
-  const int64_t total = (int64_t)g.B * g.H * g.W * g.C4;
-  const int64_t nit = (total + (int64_t)gridDim.x * 256 - 1) / ((int64_t)gridDim.x * 256);
-  for (int64_t it = 0; it < nit; ++it) {
-    int64_t idx = (it * gridDim.x + blockIdx.x) * 256 + threadIdx.x;
+  const int total = g.B * g.H * g.W * g.C4;
+  const int nit = (total + (int)gridDim.x * 256 - 1) / ((int)gridDim.x * 256);
+  for (int it = 0; it < nit; ++it) {
+    int idx = (it * (int)gridDim.x + (int)blockIdx.x) * 256 + (int)threadIdx.x;
     const bool ok = idx < total;
     if (!ok) idx = total - 1;
-    const int c = (int)(idx % g.C4) * 4;
-    const int64_t pix = idx / g.C4;
-    const int x = (int)(pix % g.W), y = (int)((pix / g.W) % g.H), b = (int)(pix / ((int64_t)g.W * g.H));
+    const NaPix pd = na_decode_item(g, (uint32_t)idx);
+    const int c = pd.c;
+    const int64_t pix = (int64_t)(pd.b * g.H + pd.y) * g.W + pd.x;
+    const int x = pd.x, y = pd.y, b = pd.b;
     const int64_t ib = (int64_t)b * g.H * g.W * 3 * g.C;
     const TA* base = qkv + ib;
     const int sy = wstart_k(y, g.H, K), sx = wstart_k(x, g.W, K);
@@ -1088,15 +1102,15 @@ __global__ __launch_bounds__(256) void na_bwd_kv_gen_kernel(const TA* __restrict
                                                             const TA* __restrict__ dout, TA* __restrict__ dqkv,
                                                             const float* __restrict__ stat, const NaGeom g, int K) {
   const int RB = 2 * K - 1;
-  const int64_t total = (int64_t)g.B * g.H * g.W * g.C4;
-  const int64_t nit = (total + (int64_t)gridDim.x * 256 - 1) / ((int64_t)gridDim.x * 256);
-  for (int64_t it = 0; it < nit; ++it) {
-    int64_t idx = (it * gridDim.x + blockIdx.x) * 256 + threadIdx.x;
+  const int total = g.B * g.H * g.W * g.C4;
+  const int nit = (total + (int)gridDim.x * 256 - 1) / ((int)gridDim.x * 256);
+  for (int it = 0; it < nit; ++it) {
+    int idx = (it * (int)gridDim.x + (int)blockIdx.x) * 256 + (int)threadIdx.x;
     const bool ok = idx < total;
     if (!ok) idx = total - 1;
-    const int c = (int)(idx % g.C4) * 4;
-    const int64_t pix = idx / g.C4;
-    const int jx = (int)(pix % g.W), jy = (int)((pix / g.W) % g.H), b = (int)(pix / ((int64_t)g.W * g.H));
+    const NaPix pd = na_decode_item(g, (uint32_t)idx);
+    const int c = pd.c;
+    const int jx = pd.x, jy = pd.y, b = pd.b;
     const int64_t ib = (int64_t)b * g.H * g.W * 3 * g.C;
     const TA* base = qkv + ib;
     const int64_t kpo = ((int64_t)jy * g.W + jx) * 3 * g.C;
@@ -1153,7 +1167,8 @@ int lmn_na_fwd(const void* qkv, const float* rpb, void* out, int B, int H, int W
   LMN_REQUIRE(hd == 1 || hd == 2 || hd == 4 || hd == 8 || hd == 16, "na_fwd: head_dim %d not in {1,2,4,8,16}", hd);
   LMN_REQUIRE((heads * hd) % 4 == 0, "na_fwd: C=%d must be a multiple of 4", heads * hd);
   LMN_REQUIRE(heads <= 16, "na_fwd: %d heads (the LDS bias table holds 16)", heads);
-  NaGeom g{B, H, W, heads * hd, heads * hd / 4, heads, scale};
+  LMN_REQUIRE((int64_t)B * H * W * (heads * hd / 4) < (1LL << 31), "neighborhood attention: %d x %d x %d x %d channels exceeds the 32-bit item index", B, H, W, heads * hd);
+  NaGeom g{B, H, W, heads * hd, heads * hd / 4, heads, scale, lmn_div_magic(W), lmn_div_magic(H * W), lmn_div_magic(heads * hd / 4)};
   if (gen || K != 3) {
     hipStream_t st = (hipStream_t)stream;
     const int grid = na_grid((int64_t)B * H * W * g.C4);
@@ -1204,7 +1219,8 @@ int lmn_na_bwd(const void* qkv_, const float* rpb, const void* dout_, void* dqkv
   LMN_REQUIRE(B > 0 && H >= K && W >= K, "na_bwd: feature map %dx%d smaller than the %dx%d window", H, W, K, K);
   LMN_REQUIRE(hd == 1 || hd == 2 || hd == 4 || hd == 8 || hd == 16, "na_bwd: head_dim %d not in {1,2,4,8,16}", hd);
   LMN_REQUIRE((heads * hd) % 4 == 0 && heads <= 16, "na_bwd: heads=%d hd=%d (C %% 4 == 0, at most 16 heads)", heads, hd);
-  NaGeom g{B, H, W, heads * hd, heads * hd / 4, heads, scale};
+  LMN_REQUIRE((int64_t)B * H * W * (heads * hd / 4) < (1LL << 31), "neighborhood attention: %d x %d x %d x %d channels exceeds the 32-bit item index", B, H, W, heads * hd);
+  NaGeom g{B, H, W, heads * hd, heads * hd / 4, heads, scale, lmn_div_magic(W), lmn_div_magic(H * W), lmn_div_magic(heads * hd / 4)};
   const int grid = na_grid((int64_t)B * H * W * g.C4);
   // query pass: persistent blocks -- every block ends with one global atomic per (head, bias entry), and 1452 blocks x 300 entries
   // serialised on 300 addresses were most of the pass on the small maps (level 3: 72 -> 51 us for the backward pair at 512 blocks)
