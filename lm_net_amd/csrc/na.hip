@@ -94,7 +94,8 @@ __device__ __forceinline__ int xcd_swizzle(int bid, int nwg) {
 template <int HD, typename TA>
 __global__ __launch_bounds__(256) void na_fwd_kernel(const TA* __restrict__ qkv, const float* __restrict__ rpb,
                                                      TA* __restrict__ out, const NaGeom g, int T, int cch,
-                                                     int tiles_x, int tiles, int chunks) {
+                                                     int tiles_x, int tiles, int chunks, uint32_t mC4c, uint32_t mR, uint32_t mT) {
+  // (mC4c, mR, mT: floor(2^32 / d) for the per-item divisions by cch / 4, T + 2 and T -- lmn_div_row)
   extern __shared__ __attribute__((aligned(16))) float KV[];  // [(T+2)^2][2][cch]
   __shared__ __attribute__((aligned(16))) float s_rpb[16 * 25];  // the bias table, transposed to [25][heads] (rpb4)
   for (int i = threadIdx.x; i < g.heads * 25; i += 256) s_rpb[(i % 25) * g.heads + i / 25] = rpb[i];
@@ -107,8 +108,10 @@ __global__ __launch_bounds__(256) void na_fwd_kernel(const TA* __restrict__ qkv,
   const int cch4 = cch >> 2;
   const TA* base = qkv + (int64_t)b * g.H * g.W * 3 * g.C;
   for (int i = threadIdx.x; i < R * R * 2 * cch4; i += 256) {
-    const int c4 = i % cch4, w = (i / cch4) & 1, pix = i / (2 * cch4);
-    const int gy = rlo + pix / R, gx = clo + pix % R;
+    const int iw = (int)lmn_div_row((uint32_t)i, (uint32_t)cch4, mC4c);
+    const int c4 = i - iw * cch4, w = iw & 1, pix = iw >> 1;
+    const int pr = (int)lmn_div_row((uint32_t)pix, (uint32_t)R, mR);
+    const int gy = rlo + pr, gx = clo + pix - pr * R;
     const bool in = gy < g.H && gx < g.W && ch0 + c4 * 4 < g.C;
     const int sy = in ? gy : 0, sx = in ? gx : 0, sc = in ? ch0 + c4 * 4 : 0;
     f32x4 v = ld4(base + ((int64_t)sy * g.W + sx) * 3 * g.C + (1 + w) * g.C + sc);
@@ -122,8 +125,9 @@ __global__ __launch_bounds__(256) void na_fwd_kernel(const TA* __restrict__ qkv,
     int idx = it * 256 + threadIdx.x;
     bool ok = idx < items;
     if (!ok) idx = items - 1;  // keep every lane in the shuffles
-    const int cl = (idx % cch4) * 4, pl = idx / cch4;
-    int y = ty0 + pl / T, x = tx0 + pl % T;
+    const int pl = (int)lmn_div_row((uint32_t)idx, (uint32_t)cch4, mC4c), cl = (idx - pl * cch4) * 4;
+    const int plr = (int)lmn_div_row((uint32_t)pl, (uint32_t)T, mT);
+    int y = ty0 + plr, x = tx0 + pl - plr * T;
     const int c = ch0 + cl;
     if (y >= g.H || x >= g.W || c >= g.C) ok = false;
     y = y < g.H ? y : g.H - 1;
@@ -1194,7 +1198,8 @@ int lmn_na_fwd(const void* qkv, const float* rpb, void* out, int B, int H, int W
   const size_t sh = (size_t)(TS + 2) * (TS + 2) * 2 * cch * sizeof(float);
   hipStream_t st = (hipStream_t)stream;
   if (g_lmn_prof_on) lmn_prof_cost(2.0 * 2 * 9 * (double)B * H * W * g.C, (act_dtype == LMN_BF16 ? 2.0 : 4.0) * 4 * (double)B * H * W * g.C);
-#define LMN_NAF(HDV) LMN_LAUNCH((na_fwd_kernel<HDV, T>), dim3(grid), dim3(256), sh, st, (const T*)qkv, rpb, (T*)out, g, TS, cch, tx, tx * ty, chunks)
+#define LMN_NAF(HDV) LMN_LAUNCH((na_fwd_kernel<HDV, T>), dim3(grid), dim3(256), sh, st, (const T*)qkv, rpb, (T*)out, g, TS, cch, tx, tx * ty, chunks, \
+                                 lmn_div_magic(cch / 4), lmn_div_magic(TS + 2), lmn_div_magic(TS))
   LMN_ACT_DISPATCH(act_dtype, switch (hd) {
     case 1: LMN_NAF(1); break;
     case 2: LMN_NAF(2); break;
