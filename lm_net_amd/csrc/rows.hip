@@ -521,6 +521,45 @@ __global__ __launch_bounds__(256) void up2_bwd_kernel(const T* __restrict__ dy, 
 }
 
 // ------------------------------------------------------------------------------------ f x f mean pool
+// Wave-per-output form (C <= 256): a wave owns one output pixel -- lane = (window slot, channel quad), a lane sums its slots of the
+// f x f window, the slots meet in a wave-private LDS tile (wave-level fence, no block barrier) and lane ch writes channel ch.  The
+// block-per-output form below (three block barriers and a divided reduction per output pixel) took 59 us per launch inside the
+// step against 12 alone: every one of its 3872 blocks is a chain of barriers that waits for CU slots next to the other streams.
+template <typename T>
+__global__ __launch_bounds__(256) void avgpool_fwd_wave_kernel(const T* __restrict__ x, T* __restrict__ y, int Hout, int Wout, int f,
+                                                               int C, int xcs, int ycs, int total, uint32_t mW, uint32_t mHW, uint32_t mC4) {
+  __shared__ __attribute__((aligned(16))) float park[4][64 * 4];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int op = blockIdx.x * 4 + wv;
+  if (op >= total) return;                      // (wave-uniform; no block barrier below)
+  const int C4 = C >> 2, nsl = 64 / C4;         // window slots per pass
+  const uint32_t b = lmn_div_row((uint32_t)op, (uint32_t)(Hout * Wout), mHW), r = (uint32_t)op - b * (uint32_t)(Hout * Wout);
+  const int oy = (int)lmn_div_row(r, (uint32_t)Wout, mW), ox = (int)r - oy * Wout;
+  const int slot = (int)lmn_div_row((uint32_t)lane, (uint32_t)C4, mC4), q = lane - slot * C4;
+  const int Win = Wout * f;
+  const T* base = x + (((int64_t)((int)b * Hout + oy) * f) * Win + (int64_t)ox * f) * xcs + q * 4;
+  const bool pow2 = (f & (f - 1)) == 0;
+  const int lf = 31 - __clz(f);
+  f32x4 s = f32x4{0, 0, 0, 0};
+  if (slot < nsl) {
+    for (int w = slot; w < f * f; w += nsl) {
+      const int wy = pow2 ? (w >> lf) : w / f, wx = w - wy * f;
+      s += ld4(base + ((int64_t)wy * Win + wx) * xcs);
+    }
+  }
+  *reinterpret_cast<f32x4*>(&park[wv][lane * 4]) = s;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  const float inv = 1.0f / (float)(f * f);
+  for (int ch = lane; ch < C; ch += 64) {
+    const int qq = ch >> 2, k = ch & 3;
+    float a = 0.f;
+    for (int sl = 0; sl < nsl; ++sl) a += park[wv][(sl * C4 + qq) * 4 + k];    // fixed order: deterministic
+    st1(y + (int64_t)op * ycs + ch, a * inv);
+  }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void avgpool_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, int Hout,
                                                           int Wout, int f, int C, int xcs, int ycs) {
@@ -548,19 +587,19 @@ __global__ __launch_bounds__(256) void avgpool_fwd_kernel(const T* __restrict__ 
 template <typename T>
 __global__ __launch_bounds__(256) void avgpool_bwd_kernel(const T* __restrict__ dy, T* __restrict__ dx, int B,
                                                           int Hout, int Wout, int f, int C4, int dycs, int dxcs,
-                                                          int accumulate) {
+                                                          int accumulate, uint32_t mC4, uint32_t mf) {
+  // one block row (grid-strided) = one input row of one image: the vertical index arithmetic is block-uniform; columns by magic
+  // multipliers (the flat-index form: five 64- / 32-bit divisions per element around one load and one store)
   const int Hin = Hout * f, Win = Wout * f;
   const float inv = 1.0f / (float)(f * f);
-  const int64_t total = (int64_t)B * Hin * Win * C4;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-    const int c = (int)(i % C4) * 4;
-    int64_t p = i / C4;
-    const int ix = (int)(p % Win);
-    p /= Win;
-    const int iy = (int)(p % Hin);
-    const int b = (int)(p / Hin);
-    f32x4 g = inv * ld4(dy + (((int64_t)b * Hout + iy / f) * Wout + ix / f) * dycs + c);
-    T* o = dx + (((int64_t)b * Hin + iy) * Win + ix) * dxcs + c;
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= Win * C4) return;
+  const int ix = (int)lmn_div_row((uint32_t)j, (uint32_t)C4, mC4), c = (j - ix * C4) * 4;
+  const int oxc = (int)lmn_div_row((uint32_t)ix, (uint32_t)f, mf);
+  for (int row = blockIdx.y; row < B * Hin; row += gridDim.y) {
+    const int b = row / Hin, iy = row - b * Hin;
+    f32x4 g = inv * ld4(dy + (((int64_t)b * Hout + iy / f) * Wout + oxc) * dycs + c);
+    T* o = dx + ((int64_t)row * Win + ix) * dxcs + c;
     if (accumulate) g += ld4(o);
     st4(o, g);
   }
@@ -1110,6 +1149,12 @@ int lmn_avgpool_fwd(const void* x, void* y, int B, int Hout, int Wout, int f, in
   LMN_REC(lmn_avgpool_fwd(x, y, B, Hout, Wout, f, C, x_cstride, y_cstride, act_dtype, stream));
   LMN_REQUIRE_DT(act_dtype, "avgpool_fwd");
   LMN_REQUIRE(x && y && B > 0 && Hout > 0 && Wout > 0 && f >= 1 && C % 4 == 0 && C >= 4 && C <= 1024 && x_cstride >= C && y_cstride >= C && x_cstride % 4 == 0, "avgpool_fwd: bad argument");
+  if (C <= 256 && (int64_t)B * Hout * Wout < (1LL << 30)) {   // wave per output pixel
+    const int total = B * Hout * Wout;
+    LMN_ACT_DISPATCH(act_dtype, LMN_LAUNCH((avgpool_fwd_wave_kernel<T>), dim3(lmn_cdiv(total, 4)), dim3(256), 0, (hipStream_t)stream, (const T*)x, (T*)y,
+                       Hout, Wout, f, C, x_cstride, y_cstride, total, lmn_div_magic(Wout), lmn_div_magic(Hout * Wout), lmn_div_magic(C / 4)));
+    return lmn_launch_status("avgpool_fwd");
+  }
   LMN_ACT_DISPATCH(act_dtype, LMN_LAUNCH((avgpool_fwd_kernel<T>), dim3(B * Hout * Wout), dim3(256), (size_t)(C + 4 * 256 + (C > 256 ? C : 256)) * sizeof(float), (hipStream_t)stream, (const T*)x, (T*)y,
                      Hout, Wout, f, C, x_cstride, y_cstride));
   return lmn_launch_status("avgpool_fwd");
@@ -1120,9 +1165,10 @@ int lmn_avgpool_bwd(const void* dy, void* dx, int B, int Hout, int Wout, int f, 
   LMN_REC(lmn_avgpool_bwd(dy, dx, B, Hout, Wout, f, C, dy_cstride, dx_cstride, accumulate, act_dtype, stream));
   LMN_REQUIRE_DT(act_dtype, "avgpool_bwd");
   LMN_REQUIRE(dy && dx && B > 0 && Hout > 0 && Wout > 0 && f >= 1 && C % 4 == 0 && C >= 4 && dy_cstride >= C && dx_cstride >= C && dy_cstride % 4 == 0 && dx_cstride % 4 == 0, "avgpool_bwd: bad argument");
-  const int64_t total = (int64_t)B * Hout * f * Wout * f * (C / 4);
-  LMN_ACT_DISPATCH(act_dtype, LMN_LAUNCH((avgpool_bwd_kernel<T>), dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, (const T*)dy, (T*)dx, B, Hout, Wout,
-                     f, C / 4, dy_cstride, dx_cstride, accumulate));
+  LMN_REQUIRE((int64_t)B * Hout * f < (1LL << 31) && (int64_t)Wout * f * (C / 4) < (1LL << 31), "avgpool_bwd: image too large for 32-bit row / column indices");
+  const dim3 grid((unsigned)lmn_cdiv((int64_t)Wout * f * (C / 4), 256), (unsigned)((int64_t)B * Hout * f < 65535 ? B * Hout * f : 65535));
+  LMN_ACT_DISPATCH(act_dtype, LMN_LAUNCH((avgpool_bwd_kernel<T>), grid, dim3(256), 0, (hipStream_t)stream, (const T*)dy, (T*)dx, B, Hout, Wout,
+                     f, C / 4, dy_cstride, dx_cstride, accumulate, lmn_div_magic(C / 4), lmn_div_magic(f)));
   return lmn_launch_status("avgpool_bwd");
 }
 
