@@ -1,0 +1,25 @@
+// conv_tileM_kernel instances (M-split form for wide layers: 1x1 incl. row-planar operands, 3x3).
+#include "conv_tileM.h"
+
+int lmn_launch_conv_tileM(const ConvParams& T, dim3 mgrid, size_t msh, hipStream_t st, int taps, int ncw, int pm, int ek, bool rp) {
+#define LMN_CM(TT, NN, BFV)                                                                              \
+  do {                                                                                                   \
+    switch ((TT) == 1 ? ek : (ek > 2 ? 1 : ek)) {                                                        \
+      case 0: LMN_LAUNCH((conv_tileM_kernel<TT, NN, 0, BFV>), mgrid, dim3(256), msh, st, T); break;   \
+      case 2: LMN_LAUNCH((conv_tileM_kernel<TT, NN, 2, BFV>), mgrid, dim3(256), msh, st, T); break;   \
+      case 3: LMN_LAUNCH((conv_tileM_kernel<1, NN, 3, BFV>), mgrid, dim3(256), msh, st, T); break;    \
+      case 4: LMN_LAUNCH((conv_tileM_kernel<1, NN, 4, BFV>), mgrid, dim3(256), msh, st, T); break;    \
+      case 5: LMN_LAUNCH((conv_tileM_kernel<1, NN, 5, BFV>), mgrid, dim3(256), msh, st, T); break;    \
+      default: LMN_LAUNCH((conv_tileM_kernel<TT, NN, 1, BFV>), mgrid, dim3(256), msh, st, T); break;  \
+    }                                                                                                    \
+  } while (0)
+#define LMN_CMB(TT, NN) do { if (pm == 2) LMN_CM(TT, NN, 2); else if (pm == 1) LMN_CM(TT, NN, 1); else LMN_CM(TT, NN, 0); } while (0)
+#define LMN_CMR(NN) do { if (pm == 2) LMN_CM(1, NN, 6); else if (pm == 1) LMN_CM(1, NN, 5); else LMN_CM(1, NN, 4); } while (0)
+  if (taps == 1 && rp) { if (ncw == 2) LMN_CMR(2); else LMN_CMR(1); }   // (row-planar operands: their own instances)
+  else if (taps == 1) { if (ncw == 2) LMN_CMB(1, 2); else LMN_CMB(1, 1); }
+  else { if (ncw == 2) LMN_CMB(9, 2); else LMN_CMB(9, 1); }
+#undef LMN_CMR
+#undef LMN_CMB
+#undef LMN_CM
+  return 0;
+}

@@ -1160,7 +1160,7 @@ static int launch_dw_stats(const void* x1, const void* pre, const void* u, const
                            void* dpre, int B, int H, int W, int E, const float* w5, const float* w3,
                            const float* wv, const float* wh, float* stats, const lmn_se_bwd_t& sb, const lmn_dw_pre_t& zp,
                            int act_dtype, hipStream_t st) {
-  LMN_REQUIRE((int64_t)B * H * W * E * 4 < (1LL << 32), "dw statistics: the tensor (%d x %d x %d x %d) must stay below 4 GiB", B, H, W, E);
+  LMN_REQUIRE((int64_t)B * H * W * E * (act_dtype == LMN_BF16 ? 2 : 4) < (1LL << 32), "dw statistics: the tensor (%d x %d x %d x %d) must stay below 4 GiB (row offsets travel in the 32-bit soffset)", B, H, W, E);
   const int strips = lmn_cdiv(W, QW), chunks = lmn_cdiv(E, 8);
   int seg_rows;
   const int segs = dw_segments((int64_t)B * strips * chunks * 4, H, 4, MODE == 0 ? 4 : 3, 1, 3.0, &seg_rows);
@@ -1225,7 +1225,7 @@ static int se_fuse_check(const lmn_se_fuse_t* se, lmn_se_fuse_t* out, int E, con
 
 static int dw_fwd_launch(const void* x1, void* pre, float* gsum, int B, int H, int W, int E, const float* keff, const float* beff,
                          const DwFin& fn, const lmn_se_fuse_t& sf, const lmn_dw_pre_t& zp, int act_dtype, hipStream_t st, const char* what) {
-  LMN_REQUIRE((int64_t)B * H * W * E * 4 < (1LL << 32), "%s: the tensor (%d x %d x %d x %d) must stay below 4 GiB", what, B, H, W, E);
+  LMN_REQUIRE((int64_t)B * H * W * E * (act_dtype == LMN_BF16 ? 2 : 4) < (1LL << 32), "%s: the tensor (%d x %d x %d x %d) must stay below 4 GiB (row offsets travel in the 32-bit soffset)", what, B, H, W, E);
   // blocks = B x row segments x strips (60 output columns) x 8-channel chunks
   const int strips = lmn_cdiv(W, QW), chunks = lmn_cdiv(E, 8);
   int seg_rows;
@@ -1378,7 +1378,7 @@ int lmn_dw_bwd_coef(const float* bstats, const float* mean, const float* rstd, c
 static int dw_bwd_launch(const void* x1, const void* dpre, void* dx1, int B, int H, int W, int E, const float* w5, const float* w3, const float* wv,
                          const float* wh, const float* cA, const float* cC, const float* cD, const DwCoef& cf, float* dw5, float* dw3, float* dwv,
                          float* dwh, int part, const lmn_dw_pre_t& zp, float* hstats, int act_dtype, hipStream_t st, const char* what) {
-  LMN_REQUIRE((int64_t)B * H * W * E * 4 < (1LL << 32), "%s: the tensor (%d x %d x %d x %d) must stay below 4 GiB", what, B, H, W, E);
+  LMN_REQUIRE((int64_t)B * H * W * E * (act_dtype == LMN_BF16 ? 2 : 4) < (1LL << 32), "%s: the tensor (%d x %d x %d x %d) must stay below 4 GiB (row offsets travel in the 32-bit soffset)", what, B, H, W, E);
   const bool halo = lmn_cdiv(W, 60) < lmn_cdiv(W, 56);   // the four extra x1 columns only where they save a strip
   const int strips = halo ? lmn_cdiv(W, 60) : lmn_cdiv(W, 56), chunks = E / 4;
   const int wps = part == 1 ? 4 : 2;

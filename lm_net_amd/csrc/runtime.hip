@@ -192,7 +192,18 @@ __global__ __launch_bounds__(256) void det_sum_kernel(const float* __restrict__ 
 
 void lmn_det_begin(hipStream_t st) {
   std::lock_guard<std::mutex> lk(g_det_mu);
-  g_det_ws[st].used = 0;
+  DetWs& w = g_det_ws[st];
+  w.used = 0;
+  // blocks outgrown by an EARLIER entry are freed here, at the start of the next one and after a wait for the stream: no region of
+  // the new entry lives in them, and whatever the earlier entry queued against them has run (never inside lmn_det_slots, where a
+  // second growth of one entry would free the block that holds the entry's first region while its kernels are still to be launched)
+  if (!w.retired.empty()) {
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) return;   // (cannot wait inside a capture: keep them)
+    (void)hipStreamSynchronize(st);
+    for (char* r : w.retired) (void)hipFree(r);
+    w.retired.clear();
+  }
 }
 
 float* lmn_det_slots(hipStream_t st, size_t floats) {
@@ -205,11 +216,8 @@ float* lmn_det_slots(hipStream_t st, size_t floats) {
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(st, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) return nullptr;
     // grow: a larger block replaces the scratch.  The outgrown block is RETIRED, not freed: regions handed out earlier in this
-    // entry live in it and stay valid, and work already queued on the stream may still read it.  Retired blocks are freed at the
-    // next growth, after a wait for the stream (growth happens a handful of times in a process: sizes repeat from step to step).
-    (void)hipStreamSynchronize(st);
-    for (char* r : w.retired) (void)hipFree(r);
-    w.retired.clear();
+    // entry live in it and stay valid, and work already queued on the stream may still read it.  Retired blocks are freed by the
+    // next lmn_det_begin on this stream (growth happens a handful of times in a process: sizes repeat from step to step).
     if (w.base) w.retired.push_back(w.base);
     size_t nb = w.bytes ? w.bytes : (size_t)32 << 20;
     while (nb < need) nb *= 2;
@@ -220,8 +228,8 @@ float* lmn_det_slots(hipStream_t st, size_t floats) {
     w.used = 0;
   }
   float* p = (float*)(w.base + w.used);
+  if (hipMemsetAsync(p, 0, need, st) != hipSuccess) return nullptr;   // (the region is not handed out: `used` stays)
   w.used += need;
-  if (hipMemsetAsync(p, 0, need, st) != hipSuccess) return nullptr;
   return p;
 }
 

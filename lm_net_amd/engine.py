@@ -183,7 +183,8 @@ class Engine:
         self.alloc_floats = 0     # floats requested since begin_pass (sizes the arena during the eager warm-up steps)
         # second stage of the weight gradients' K-split reductions batched per gradient bucket (LMN_DEFER_REDUCE=0: A/B runs)
         self.defer_reduce = os.environ.get("LMN_DEFER_REDUCE", "1") != "0"
-        self.debug_keep = None    # dict: reparam_bwd keeps clones of its intermediates per module (debug tools only)
+        self.probe = None         # debug hook fn(tag, module, tensors: dict) called in stream order at a few points of the backward
+                                  # (tools/gpu_race_locate.py, tools/gpu_glitch_locate.py clone what they need there); None in production
         self.reduce_tabs = []     # device job tables of the batched reductions of the pass in flight (kept by recorded plans)
         self.post_reduce = {}     # launch stream handle -> follow-ups of deferred weight gradients (run after the batched reduction)
         # z-path: expand-conv weight gradient from the raw gradient and the moments of x (lmn_reparam_wfin) instead of a pass that
@@ -696,7 +697,8 @@ class Engine:
         # pass 1 is statistics only (dh = dx1 * hswish'(h) is not written); pass 2 forms dh again from dx1 and turns it into
         # dz in the same epilogue: one E-wide write and one E-wide read fewer than writing dh in between
         st = _Z(x, STATS_REP, 2, E)
-        st_before = st.clone() if self.debug_keep is not None else None
+        if self.probe is not None:
+            self.probe("reparam_bwd:stats0", m, dict(st=st))
         hip.conv_fwd([x], wpe, None, B=B, Hin=H, Win=W, Hout=H, Wout=W, Cout=E, bias=ec.bias, epilogue=hip.EP_BN_BWD1,
                      act=hip.ACT_HSWISH, p=(S["mean1"], S["rstd1"], ebn.weight, ebn.bias), aux=dx1, stats=st,
                      stats_mode=hip.STATS_EP, stats_rep=STATS_REP)
@@ -711,9 +713,8 @@ class Engine:
             hip.bn_bwd_coef(st, N, S["A1"], G[ebn.weight], G[ebn.bias], c1, c2, c3, self.training)
             hip.conv_fwd([x], wpe, dz, B=B, Hin=H, Win=W, Hout=H, Wout=W, Cout=E, bias=ec.bias, epilogue=hip.EP_BN_BWD2,
                          act=hip.ACT_HSWISH, p=(S["mean1"], S["rstd1"], c1, c2, c3, ebn.weight, ebn.bias), aux=dx1)
-        if self.debug_keep is not None:      # (tools/gpu_glitch_locate.py: intermediates of one block, cloned in stream order)
-            self.debug_keep[m] = dict(st0=st_before, wpe=wpe.clone(), dy=dy.clone(), u_dx1=dx1.clone(), st=st.clone(), dz=dz.clone(), bst=bst.clone(), ds=ds.clone(),
-                                      x=x.clone(), mean1=S["mean1"].clone(), rstd1=S["rstd1"].clone(), A1=S["A1"].clone())
+        if self.probe is not None:
+            self.probe("reparam_bwd", m, dict(wpe=wpe, dy=dy, u_dx1=dx1, st=st, dz=dz, bst=bst, ds=ds, x=x, mean1=S["mean1"], rstd1=S["rstd1"], A1=S["A1"]))
         if cw == Cin:
             self.wgrad([x], dz, ec.weight, ec.bias, Hin=H, Win=W)
         else:
@@ -912,26 +913,17 @@ class Engine:
         do = _A(x, B, H, W, C)
         self._lin_bwd(m.att1.proj, o, da, do)
         dqkv = _A(x, B, H, W, 3 * C)
-        dbg = {} if self.debug_keep is not None else None
-        if dbg is not None:
-            dbg["do"] = do.clone()
         hip.na_bwd(qkv, m.att1.rpb, do, dqkv, G[m.att1.rpb], m.att1.num_heads)
-        if dbg is not None:
-            dbg["dqkv_now"] = dqkv.clone()
-            dbg["do_after"] = do.clone()
-            # the same call again into a second buffer (bias gradient into a dummy): equal inputs, equal kernel -> equal output?
-            dq2 = torch.empty_like(dqkv)
-            hip.na_bwd(qkv, m.att1.rpb, do, dq2, torch.zeros_like(G[m.att1.rpb]), m.att1.num_heads)
-            dbg["dqkv_second"] = dq2
+        if self.probe is not None:
+            self.probe("nat_bwd:na", m, dict(qkv=qkv, do=do, dqkv=dqkv, rpb=m.att1.rpb, heads=m.att1.num_heads))
         dn1 = do
         self._lin_bwd(m.att1.qkv, n1, dqkv, dn1)
         de = _A(x, B, H, W, C)
         hip.ln_bwd(e, m.norm1.weight, dn1, da, de, G[m.norm1.weight], G[m.norm1.bias])
         dx = _A(x, B, H, W, C)
         self.conv3_bwd(m.patchembedding.patch_embeddings, x, de, dx=dx)
-        if self.debug_keep is not None:      # (tools/gpu_race_locate.py: intermediates of the block, cloned in stream order)
-            self.debug_keep[m] = dict(dy=dy.clone(), dn2=dn2.clone(), da=da.clone(), dqkv=dqkv.clone(), dn1=dn1.clone(), de=de.clone(), dx=dx.clone(),
-                                      qkv=qkv.clone(), o=o.clone(), n1=n1.clone(), **dbg)
+        if self.probe is not None:
+            self.probe("nat_bwd", m, dict(dy=dy, dn2=dn2, da=da, dqkv=dqkv, dn1=dn1, de=de, dx=dx, qkv=qkv, o=o, n1=n1))
         return dx
 
     def gft_fwd(self, m, catp, cx, tag):

@@ -241,13 +241,26 @@ def rp4(t):
     """Mark ``t`` (shape [B, H, W, C], contiguous) as ROW-PLANAR: its memory holds element (b, y, x, c) at
     ((b*H + y) * (C/4) + (c >> 2)) * 4*W + 4*x + (c & 3) (include/lmnet_hip.h, Conventions) -- the layout of the E-wide tensors
     inside a ReparamConv block.  The shape stays [B, H, W, C] (it names the sizes); the conv family picks the layout up from the
-    mark (lmn_src_t.rp_w / out_rp_w / aux_rp_w / dy_rp_w), the depthwise family takes nothing else."""
+    mark (lmn_src_t.rp_w / out_rp_w / aux_rp_w / dy_rp_w), the depthwise family takes nothing else.
+    The mark is a Python attribute: clone() / view() / detach() / slicing return UNMARKED tensors -- the depthwise wrappers
+    refuse those (_rp_req) instead of reading NHWC memory as row-planar."""
+    if t.dim() != 4 or not t.is_contiguous() or t.shape[-1] % 4 != 0:
+        raise RuntimeError("lm_net_amd: rp4() takes a contiguous [B, H, W, C] tensor with C %% 4 == 0 (got shape %s, contiguous=%s)"
+                           % (tuple(t.shape), t.is_contiguous()))
     t._lmn_rp = True
     return t
 
 
 def is_rp4(t):
     return getattr(t, "_lmn_rp", False)
+
+
+def _rp_req(name, **ts):
+    """The depthwise family reads and writes row-planar tensors only: every activation operand must carry the rp4 mark."""
+    for k, t in ts.items():
+        if t is not None and not getattr(t, "_lmn_rp", False):
+            raise RuntimeError("lm_net_amd: %s: operand `%s` is not marked row-planar (hip.rp4 / hip.nhwc_to_rp4); "
+                               "an NHWC tensor here would be read with permuted channels" % (name, k))
 
 
 def nhwc_to_rp4(t):
@@ -594,6 +607,7 @@ def _workspace(device, nfloats):
 def dw_stats(x1, w5, w3, wv, wh, stats, zpre=None):
     """zpre: the tensor is z (z-path, see _dw_pre); with zpre['fin'] the expand conv's BatchNorm is finalised here."""
     B, H, W, E = x1.shape
+    _rp_req("dw_stats", x1=x1)
     _check(load().lmn_dw_stats(_pa(x1), B, H, W, E, _p(w5), _p(w3), _p(wv), _p(wh), _p(stats), _dw_pre(zpre), _dt(x1), _stream()), "dw_stats")
 
 
@@ -605,6 +619,7 @@ def dw_merge(w5, w3, wv, wh, A, shift, keff, beff):
 def dw_fwd(x1, pre, gsum, keff, beff, se=None, zpre=None):
     """se: squeeze-excite gate formed inside the pass (see _se_fuse), or None; zpre: the tensor is z (see _dw_pre)."""
     B, H, W, E = x1.shape
+    _rp_req("dw_fwd", x1=x1, pre=pre)
     _check(load().lmn_dw_fwd(_pa(x1), _pa(pre), _p(gsum), B, H, W, E, _p(keff), _p(beff), _se_fuse(se), _dw_pre(zpre), _dt(x1, pre), _stream()), "dw_fwd")
 
 
@@ -626,6 +641,7 @@ def dw_fwd_bn(x1, pre, gsum, stats, count, bns, ws, mean, rstd, A, se=None, zpre
     P4 = C.c_void_p * 4
     F4 = C.c_float * 4
     B, H, W, E = x1.shape
+    _rp_req("dw_fwd_bn", x1=x1, pre=pre)
     _check(load().lmn_dw_fwd_bn(
         _pa(x1), _pa(pre), _p(gsum), B, H, W, E, _p(stats), _f(count), P4(*[b.weight.data_ptr() for b in bns]),
         P4(*[b.bias.data_ptr() for b in bns]), P4(*[b.running_mean.data_ptr() for b in bns]),
@@ -640,6 +656,7 @@ def dw_bwd_bn(x1, dpre, dx1, w5, w3, wv, wh, bstats, mean, rstd, A, count, batch
     zpre / hstats: z-path -- x1 is z, `dx1` receives dh = dx1 * Hardswish'(A z + shift), hstats [2][E] += (sum dh, sum dh z)."""
     P4 = C.c_void_p * 4
     B, H, W, E = x1.shape
+    _rp_req("dw_bwd_bn", x1=x1, dpre=dpre, dx1=dx1)
     _check(load().lmn_dw_bwd_bn(_pa(x1), _pa(dpre), _pa(dx1), B, H, W, E, _p(w5), _p(w3), _p(wv), _p(wh), _p(bstats), _p(mean),
                                 _p(rstd), _p(A), _f(count), int(batch_stats), P4(*[t.data_ptr() for t in dgs]),
                                 P4(*[t.data_ptr() for t in dbs]), _p(dw5), _p(dw3), _p(dwv), _p(dwh), part, _dw_pre(zpre),
@@ -655,6 +672,7 @@ def dw_bwd_stats(x1, pre, u, s, dm, dpre, w5, w3, wv, wh, bstats, seb=None, zpre
         f.ds, f.w1, f.w2, f.hidden, f.dvec = (_p(seb[k]).value for k in ("ds", "fc1w", "fc2w", "hidden", "dvec"))
         f.inv_hw, f.R = float(seb["inv_hw"]), seb["fc1w"].shape[0]
         sb = C.byref(f)
+    _rp_req("dw_bwd_stats", x1=x1, pre=pre, u=u, dpre=dpre)
     _check(load().lmn_dw_bwd_stats(_pa(x1), _pa(pre), _pa(u), _p(s), _p(dm), _pa(dpre), B, H, W, E, _p(w5), _p(w3), _p(wv),
                                    _p(wh), _p(bstats), sb, _dw_pre(zpre), _dt(x1, pre, u, dpre), _stream()), "dw_bwd_stats")
 
@@ -667,6 +685,7 @@ def dw_bwd_coef(bstats, mean, rstd, A, count, batch_stats, cA, cC, cD, dgs, dbs)
 
 def dw_bwd(x1, dpre, dx1, w5, w3, wv, wh, cA, cC, cD, dw5, dw3, dwv, dwh):
     B, H, W, E = x1.shape
+    _rp_req("dw_bwd", x1=x1, dpre=dpre, dx1=dx1)
     _check(load().lmn_dw_bwd(_pa(x1), _pa(dpre), _pa(dx1), B, H, W, E, _p(w5), _p(w3), _p(wv), _p(wh), _p(cA), _p(cC),
                              _p(cD), _p(dw5), _p(dw3), _p(dwv), _p(dwh), _dt(x1, dpre, dx1), _stream()), "dw_bwd")
 

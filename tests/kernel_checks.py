@@ -55,6 +55,10 @@ def nchwE(t):  # row-planar device -> NCHW fp64 cpu
     return nchw(hip.rp4_to_nhwc(t))
 
 
+def nanE(B, H, W, E, dtype=torch.float32):  # NaN-filled ROW-PLANAR output buffer of a depthwise pass (the wrappers refuse unmarked tensors)
+    return hip.rp4(torch.full((B, H, W, E), float("nan"), device=DEV, dtype=dtype))
+
+
 def gelu(x):
     return 0.5 * x * (1 + torch.erf(x / math.sqrt(2)))
 
@@ -315,7 +319,7 @@ def check_dw():
         shift = torch.stack([bet[i] - mean[i] * A[i] for i in range(4)])
         keff, beff = torch.empty(E, 25, device=DEV), torch.empty(E, device=DEV)
         hip.dw_merge(*wd, dev(A), dev(shift), keff, beff)
-        pre = torch.full((B, H, W, E), float("nan"), device=DEV)
+        pre = nanE(B, H, W, E)
         gsum = torch.zeros(B, E, device=DEV)
         hip.dw_fwd(x1d, pre, gsum, keff, beff)
         rows.append(("dw_fwd pre" + tag, rel(nchwE(pre), pre_ref), TOL))
@@ -327,7 +331,7 @@ def check_dw():
         s_sep, h_sep = torch.empty(B, E, device=DEV), torch.empty(B, Rr, device=DEV)
         hip.se_fwd(gsum, 1.0 / (H * W), fw1, fb1, fw2, fb2, s_sep, h_sep)
         for rep in range(3):      # (repeated: the hand-off must hold whichever block arrives last)
-            pre_f = torch.full((B, H, W, E), float("nan"), device=DEV); gs_f = torch.zeros(B, E, device=DEV)
+            pre_f = nanE(B, H, W, E); gs_f = torch.zeros(B, E, device=DEV)
             s_f, h_f = torch.full((B, E), float("nan"), device=DEV), torch.full((B, Rr), float("nan"), device=DEV)
             hip.dw_fwd(x1d, pre_f, gs_f, keff, beff, se=dict(ticket=torch.zeros(B, device=DEV), fc1w=fw1, fc1b=fb1, fc2w=fw2,
                                                              fc2b=fb2, s=s_f, hidden=h_f, inv_hw=1.0 / (H * W)))
@@ -341,7 +345,7 @@ def check_dw():
         (g * (u * s.view(B, E, 1, 1) + dm.view(B, E, 1, 1))).sum().backward()
         dpre_ref = pre_l.grad
         pre_ref.backward(dpre_ref)
-        dpre = torch.full((B, H, W, E), float("nan"), device=DEV)
+        dpre = nanE(B, H, W, E)
         bstats = torch.zeros(5, E, device=DEV)
         hip.dw_bwd_stats(x1d, nhwcE(pre_ref.detach()), nhwcE(u), dev(s), dev(dm), dpre, *wd, bstats)
         rows.append(("dw_bwd_stats dpre" + tag, rel(nchwE(dpre), dpre_ref), TOL))
@@ -351,9 +355,9 @@ def check_dw():
         ds_t = dev(R(B, E, seed=105))
         dm_sep, dvec_sep = torch.empty(B, E, device=DEV), torch.empty(B, E + Rr, device=DEV)
         hip.se_bwd_dm(ds_t, s_sep, 1.0 / (H * W), fw1, fw2, h_sep, dm_sep, dvec_sep)
-        dpre_s, bst_s = torch.full((B, H, W, E), float("nan"), device=DEV), torch.zeros(5, E, device=DEV)
+        dpre_s, bst_s = nanE(B, H, W, E), torch.zeros(5, E, device=DEV)
         hip.dw_bwd_stats(x1d, nhwcE(pre_ref.detach()), nhwcE(u), s_sep, dm_sep, dpre_s, *wd, bst_s)
-        dpre_f, bst_f, dvec_f = torch.full((B, H, W, E), float("nan"), device=DEV), torch.zeros(5, E, device=DEV), torch.full((B, E + Rr), float("nan"), device=DEV)
+        dpre_f, bst_f, dvec_f = nanE(B, H, W, E), torch.zeros(5, E, device=DEV), torch.full((B, E + Rr), float("nan"), device=DEV)
         hip.dw_bwd_stats(x1d, nhwcE(pre_ref.detach()), nhwcE(u), s_sep, None, dpre_f, *wd, bst_f,
                          seb=dict(ds=ds_t, fc1w=fw1, fc2w=fw2, hidden=h_sep, dvec=dvec_f, inv_hw=1.0 / (H * W)))
         rows.append(("dw_bwd_stats + fused SE backward" + tag, max(rel(dpre_f, dpre_s), rel(bst_f, bst_s), rel(dvec_f, dvec_sep)), 2e-5))
@@ -365,7 +369,7 @@ def check_dw():
         for i in range(4):
             rows.append(("dw_bwd_coef dgamma[%d]" % i + tag, rel(dgs[i], gr[i].grad), 2e-4))
             rows.append(("dw_bwd_coef dbeta[%d]" % i + tag, rel(dbs[i], br[i].grad), 2e-4))
-        dx1 = torch.full((B, H, W, E), float("nan"), device=DEV)
+        dx1 = nanE(B, H, W, E)
         dws = [torch.zeros_like(dev(w)) for w in ws]
         hip.dw_bwd(x1d, nhwcE(dpre_ref), dx1, *wd, cA, cC, cD, *dws)
         rows.append(("dw_bwd dx1" + tag, rel(nchwE(dx1), x1r.grad), TOL))
@@ -384,9 +388,9 @@ def check_dw():
         m_b, r_b, A_b = (torch.zeros(4, E, device=DEV) for _ in range(3))
         keff2, beff2 = torch.empty(E, 25, device=DEV), torch.empty(E, device=DEV)
         hip.dw_finalize_merge(sref_d, N, bn_b, wd, m_b, r_b, A_b, keff2, beff2)
-        pre_b = torch.full((B, H, W, E), float("nan"), device=DEV); gs_b = torch.zeros(B, E, device=DEV)
+        pre_b = nanE(B, H, W, E); gs_b = torch.zeros(B, E, device=DEV)
         hip.dw_fwd(x1d, pre_b, gs_b, keff2, beff2)
-        pre_a = torch.full((B, H, W, E), float("nan"), device=DEV); gs_a = torch.zeros(B, E, device=DEV)
+        pre_a = nanE(B, H, W, E); gs_a = torch.zeros(B, E, device=DEV)
         hip.dw_fwd_bn(x1d, pre_a, gs_a, sref_d, N, bn_a, wd, m_a, r_a, A_a)
         rows.append(("dw_fwd_bn pre vs finalize_merge + fwd" + tag, rel(pre_a, pre_b), 1e-6))
         rows.append(("dw_fwd_bn pre vs reference" + tag, rel(nchwE(pre_a), pre_ref), TOL))
@@ -396,7 +400,7 @@ def check_dw():
         for i in range(4):
             rows.append(("dw_fwd_bn running stats[%d]" % i + tag, max(rel(bn_a[i].running_mean, bn_b[i].running_mean),
                                                                      rel(bn_a[i].running_var, bn_b[i].running_var)), 1e-6))
-        dx1b = torch.full((B, H, W, E), float("nan"), device=DEV)
+        dx1b = nanE(B, H, W, E)
         dws2 = [torch.zeros_like(dev(w)) for w in ws]
         dgs2 = [torch.zeros(E, device=DEV) for _ in range(4)]
         dbs2 = [torch.zeros(E, device=DEV) for _ in range(4)]
@@ -463,13 +467,13 @@ def check_zpath():
         rows.append(("dw_stats z-path + BN finalise: running stats" + tag,
                      max(rel(rm, 0.9 * rm0.double().cpu() + 0.1 * mu.detach()), rel(rv, 0.9 * rv0.double().cpu() + 0.1 * var.detach() * N / (N - 1))), 1e-5))
         keff, beff = dev(R(E, 25, seed=212, scale=0.2)), dev(R(E, seed=213) * 0.1)
-        pa, pb = torch.full((B, H, W, E), float("nan"), device=DEV), torch.full((B, H, W, E), float("nan"), device=DEV)
+        pa, pb = nanE(B, H, W, E), nanE(B, H, W, E)
         ga_, gb_ = torch.zeros(B, E, device=DEV), torch.zeros(B, E, device=DEV)
         hip.dw_fwd(x1d, pa, ga_, keff, beff)
         hip.dw_fwd(zd, pb, gb_, keff, beff, zpre=zp)
         rows.append(("dw_fwd z-path" + tag, max(rel(pb, pa), rel(gb_, ga_)), 2e-5))
         u, sg, dm = nhwcE(R(B, E, H, W, seed=214)), dev(R(B, E, seed=215).abs()), dev(R(B, E, seed=216) * 0.01)
-        da_, db_ = torch.full((B, H, W, E), float("nan"), device=DEV), torch.full((B, H, W, E), float("nan"), device=DEV)
+        da_, db_ = nanE(B, H, W, E), nanE(B, H, W, E)
         ba_, bb_ = torch.zeros(5, E, device=DEV), torch.zeros(5, E, device=DEV)
         hip.dw_bwd_stats(x1d, pa, u, sg, dm, da_, *wd, ba_)
         hip.dw_bwd_stats(zd, pa, u, sg, dm, db_, *wd, bb_, zpre=zp)
@@ -479,11 +483,11 @@ def check_zpath():
         bst = dev(R(5, E, seed=220))
         dgs, dbs = [torch.zeros(E, device=DEV) for _ in range(4)], [torch.zeros(E, device=DEV) for _ in range(4)]
         dws = [torch.zeros_like(w) for w in wd]
-        dxo = torch.full((B, H, W, E), float("nan"), device=DEV)
+        dxo = nanE(B, H, W, E)
         hip.dw_bwd_bn(x1d, da_, dxo, *wd, bst, bm, br_, bA, N, True, dgs, dbs, *dws)
         dgs2, dbs2 = [torch.zeros(E, device=DEV) for _ in range(4)], [torch.zeros(E, device=DEV) for _ in range(4)]
         dws2 = [torch.zeros_like(w) for w in wd]
-        dhz, hst = torch.full((B, H, W, E), float("nan"), device=DEV), torch.zeros(2, E, device=DEV)
+        dhz, hst = nanE(B, H, W, E), torch.zeros(2, E, device=DEV)
         hip.dw_bwd_bn(zd, da_, dhz, *wd, bst, bm, br_, bA, N, True, dgs2, dbs2, *dws2, zpre=zp, hstats=hst)
         hd = nhwc(h.detach()).double().cpu()
         dhs = torch.where(hd < -3, torch.zeros_like(hd), torch.where(hd <= 3, hd / 3 + 0.5, torch.ones_like(hd)))

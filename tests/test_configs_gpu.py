@@ -102,7 +102,11 @@ def test_config1_batch8_deterministic_mode_bit_identical_gradients():
         (ya, ga), (yb, gb) = run(), run()
         assert torch.equal(ya, yb)
         assert all(torch.equal(u, v) for u, v in zip(ga, gb)), [i for i, (u, v) in enumerate(zip(ga, gb)) if not torch.equal(u, v)][:8]
-        _golden_step("train_f64_352_b8")     # (the process-wide switch is still on: the golden step runs in deterministic mode)
+        # (the process-wide switch is still on: the golden step runs in deterministic mode, where the statistics are summed in a fixed
+        #  order -- no arrival-order spread on the 1-D parameters, so the affine tolerance is the 1.2e-2 DESIGN section 2 derives from
+        #  the measured 5-6e-3, not the 2.5e-2 the default mode needs for its 1.3e-2 run-to-run worst case)
+        worst = _golden_step("train_f64_352_b8", tol_affine=1.2e-2)
+        print("deterministic golden step: worst sampled gradient error %.3e of the tensor's largest element" % worst)
     finally:
         hip.set_deterministic(False)
 

@@ -26,8 +26,8 @@ def main():
     B = 8
     print("device:", torch.cuda.get_device_name(0))
     for (H, E) in [(352, 24), (176, 48), (88, 96), (44, 192)]:
-        x1 = torch.randn(B, H, H, E, device=dev)
-        pre = torch.empty_like(x1)
+        x1 = hip.rp4(torch.randn(B, H, H, E, device=dev))
+        pre = hip.rp4(torch.empty_like(x1))
         gsum = torch.zeros(B, E, device=dev)
         keff, beff = torch.randn(E, 25, device=dev), torch.randn(E, device=dev)
         t = timeit(lambda: hip.dw_fwd(x1, pre, gsum, keff, beff))
@@ -37,12 +37,12 @@ def main():
         st = torch.zeros(4, 2, E, device=dev)
         t = timeit(lambda: hip.dw_stats(x1, w5, w3, wv, wh, st))
         print("dw_stats    H=%3d E=%3d  %8.1f us  %7.1f GB/s" % (H, E, t * 1e6, x1.numel() * 4 / t / 1e9))
-        u, s, dm, dpre, bst = torch.randn_like(x1), torch.rand(B, E, device=dev), torch.zeros(B, E, device=dev), torch.empty_like(x1), torch.zeros(5, E, device=dev)
+        u, s, dm, dpre, bst = hip.rp4(torch.randn_like(x1)), torch.rand(B, E, device=dev), torch.zeros(B, E, device=dev), hip.rp4(torch.empty_like(x1)), torch.zeros(5, E, device=dev)
         t = timeit(lambda: hip.dw_bwd_stats(x1, pre, u, s, dm, dpre, w5, w3, wv, wh, bst))
         print("dw_bwd_stat H=%3d E=%3d  %8.1f us  %7.1f GB/s" % (H, E, t * 1e6, 4 * x1.numel() * 4 / t / 1e9))
         cA = torch.rand(4, E, device=dev)
         dws = [torch.zeros_like(w) for w in (w5, w3, wv, wh)]
-        dx1 = torch.empty_like(x1)
+        dx1 = hip.rp4(torch.empty_like(x1))
         t = timeit(lambda: hip.dw_bwd(x1, dpre, dx1, w5, w3, wv, wh, cA, cA, cA, *dws))
         print("dw_bwd      H=%3d E=%3d  %8.1f us  %7.1f GB/s" % (H, E, t * 1e6, 3 * x1.numel() * 4 / t / 1e9))
     for (H, C) in [(352, 12), (176, 24), (88, 48), (44, 96)]:

@@ -46,10 +46,10 @@ if what == "conv72":
     conv_case(88, [24], 80, 1, 1, True, False)
 if what == "dw":
     H, E = 352, 24
-    x1 = torch.randn(B, H, H, E, device=dev); pre = torch.empty_like(x1); gsum = torch.zeros(B, E, device=dev)
+    x1 = hip.rp4(torch.randn(B, H, H, E, device=dev)); pre = hip.rp4(torch.empty_like(x1)); gsum = torch.zeros(B, E, device=dev)
     keff, beff = torch.randn(E, 25, device=dev), torch.randn(E, device=dev)
     w5, w3, wv, wh = (torch.randn(E, 1, a, b, device=dev) for a, b in ((5, 5), (3, 3), (3, 1), (1, 3)))
-    cA = torch.rand(4, E, device=dev); dws = [torch.zeros_like(w) for w in (w5, w3, wv, wh)]; dx1 = torch.empty_like(x1)
+    cA = torch.rand(4, E, device=dev); dws = [torch.zeros_like(w) for w in (w5, w3, wv, wh)]; dx1 = hip.rp4(torch.empty_like(x1))
     for _ in range(2):
         hip.dw_fwd(x1, pre, gsum, keff, beff)
         hip.dw_bwd(x1, pre, dx1, w5, w3, wv, wh, cA, cA, cA, *dws)

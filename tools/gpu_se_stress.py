@@ -13,12 +13,12 @@ side = torch.cuda.Stream()
 junk = torch.randn(64 << 20, device=dev)
 for (B, H, W, E) in [(8, 352, 352, 24), (8, 176, 176, 48), (8, 88, 88, 96), (8, 44, 44, 192), (2, 64, 96, 24), (3, 40, 130, 8)]:
     R = max(E // 4, 1)
-    x1 = torch.randn(B, H, W, E, device=dev)
+    x1 = hip.rp4(torch.randn(B, H, W, E, device=dev))
     keff, beff = torch.randn(E, 25, device=dev) * 0.2, torch.randn(E, device=dev) * 0.1
     w1, b1 = torch.randn(R, E, device=dev) * 0.4, torch.randn(R, device=dev)
     w2, b2 = torch.randn(E, R, device=dev) * 0.8, torch.randn(E, device=dev)
     for it in range(60):
-        pre = torch.empty(B, H, W, E, device=dev)
+        pre = hip.rp4(torch.empty(B, H, W, E, device=dev))
         gs, gs2 = torch.zeros(B, E, device=dev), torch.zeros(B, E, device=dev)
         s, h = torch.full((B, E), float("nan"), device=dev), torch.full((B, R), float("nan"), device=dev)
         with torch.cuda.stream(side):
