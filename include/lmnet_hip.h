@@ -48,7 +48,7 @@ extern "C" {
 
 typedef void* lmn_stream_t; /* hipStream_t */
 
-#define LMN_ABI_VERSION 9
+#define LMN_ABI_VERSION 10
 /* arithmetic type of the matrix-core operands of a dense contraction (accumulators, epilogues, statistics: fp32) */
 #define LMN_F32 0  /* v_mfma_f32_16x16x4_f32: exact fp32 (k-ordered fma chain)                                  */
 #define LMN_BF16 1 /* v_mfma_f32_16x16x16_bf16: operands rounded to bf16 (RNE) when staged / packed -- the mixed- */
@@ -76,6 +76,18 @@ const char* lmn_last_error(void);
 /* source (input operand) transforms applied on load, in this order */
 #define LMN_SRC_GELU 1 /* x <- gelu(x)                (exact erf form, nn.GELU default)          */
 #define LMN_SRC_DROP 2 /* x <- x * keep(seed,idx)/(1-p) (same mask as the forward epilogue)      */
+/* (round 5) fused producers: the tensor that the reference materialises between two modules is formed where the conv stages it.
+ * LMN_SRC_LN  x <- LayerNorm_C(x) * ln_gamma + ln_beta over the source's C channels of each pixel (biased variance, ln_eps):
+ *             `norm1` -> `qkv` and `norm2` -> `fc1` of the transformer blocks as ONE row each (core/modules.py:516-518, 343-344,
+ *             50-56; SURVEY 8a "LN1+qkv") -- n1 / n2 never cross HBM.  1x1 stride-1 single-source calls only, applied before
+ *             the other transforms.  lmn_conv_fwd computes (mean, rstd) per pixel in its staging and, when ln_stats != NULL,
+ *             stores them as [pixels][2]; lmn_conv_wgrad READS them there (ln_stats required) and applies the same transform.
+ * LMN_SRC_UP2 the source tensor is [B][Hin/2][Win/2][C] and x is its bilinear x2 upsampling with align_corners=True
+ *             (F.interpolate / nn.Upsample, core/LM_Net.py:59-72, core/modules.py:94,129; ATen index arithmetic:
+ *             src = dst * (in - 1) / (out - 1) in fp32) sampled where the 3x3 window is staged -- `up` never crosses HBM
+ *             (SURVEY row A10 "fuse upsample into the conv's tile load").  3x3 stride-1 calls (forward and weight gradient). */
+#define LMN_SRC_LN 4
+#define LMN_SRC_UP2 8
 
 typedef struct {
   const void* ptr;    /* NHWC base (act_dtype of the call), already offset to the slice's first channel */
@@ -86,6 +98,11 @@ typedef struct {
   uint32_t drop_seed; /* dropout stream id for LMN_SRC_DROP                                       */
   float drop_p;       /* dropout probability for LMN_SRC_DROP                                     */
   int32_t rp_w;       /* 0: NHWC; W > 0: the tensor is row-planar (RP4, see Conventions) with image width W */
+  const float* ln_gamma; /* LMN_SRC_LN: [C] affine of the LayerNorm                                  */
+  const float* ln_beta;
+  float* ln_stats;       /* LMN_SRC_LN: [pixels][2] = (mean, rstd); conv_fwd writes (or NULL), conv_wgrad reads */
+  float ln_eps;          /* LMN_SRC_LN: nn.LayerNorm eps (1e-5)                                      */
+  int32_t _pad0;
 } lmn_src_t;
 
 /* epilogues; v = accumulator + bias[co] */

@@ -81,6 +81,17 @@ void lmn_rec_push(std::function<int()>&& f, const char* what);
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 #ifdef __HIPCC__
+// bilinear x2, align_corners=True: source coordinate of output index `dst` along an axis of `in` source samples, scale =
+// (in - 1) / (out - 1) in fp32 -- ATen's upsample_bilinear2d arithmetic: i0 = (int)(scale * dst), second tap i0 + ip, weights l0 / l1.
+// Used by lmn_up2_fwd / lmn_up2_bwd (rows.hip) and by the LMN_SRC_UP2 staging of the 3x3 convs, so that the fused and the
+// materialised forms sample identical values.
+__device__ __forceinline__ void lmn_up_coord(int dst, int in, float scale, int& i0, int& ip, float& l0, float& l1) {
+  const float r = scale * (float)dst;
+  i0 = (int)r;
+  ip = (i0 < in - 1) ? 1 : 0;
+  l1 = r - (float)i0;
+  l0 = 1.f - l1;
+}
 // one block's contribution to a reduced value: float atomic (arrival order) or, in deterministic mode, a plain store into the
 // block's slot (the pointer then addresses the slot copy of the destination)
 __device__ __forceinline__ void lmn_red_add(float* p, float v, bool det) {

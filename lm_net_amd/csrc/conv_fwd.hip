@@ -322,6 +322,26 @@ int lmn_conv_fwd(const lmn_conv_args_t* args, lmn_stream_t stream) {
       P.inv_keep_src[s] = 1.f / (1.f - A.src[s].drop_p);
     }
   }
+  bool ln = false;   // LMN_SRC_LN: LayerNorm of the source where it is staged
+  for (int s = 0; s < A.nsrc; ++s) ln = ln || (A.src[s].flags & LMN_SRC_LN) != 0;
+  if (ln) {
+    LMN_REQUIRE(A.nsrc == 1 && A.ksize == 1 && A.stride == 1 && !A.transposed && A.src[0].rp_w == 0 && !A.out_rp_w,
+                "conv_fwd: LMN_SRC_LN belongs to single-source NHWC 1x1 stride-1 forward calls");
+    LMN_REQUIRE(A.src[0].ln_gamma && A.src[0].ln_beta && A.src[0].ln_eps > 0.f, "conv_fwd: LMN_SRC_LN needs ln_gamma / ln_beta / ln_eps");
+    LMN_REQUIRE(A.epilogue == LMN_EP_LINEAR && A.stats_mode == LMN_STATS_NONE && A.drop_p == 0.f && A.fin.mode == LMN_FIN_NONE,
+                "conv_fwd: LMN_SRC_LN comes with the plain epilogue (bias / residual only)");
+    LMN_REQUIRE(!(A.src[0].flags & ~LMN_SRC_LN) && !A.src[0].scale, "conv_fwd: LMN_SRC_LN does not combine with other source transforms");
+  }
+  bool up2 = false;  // LMN_SRC_UP2: the source is the half-resolution map, sampled through bilinear x2 where the window is staged
+  for (int s = 0; s < A.nsrc; ++s) up2 = up2 || (A.src[s].flags & LMN_SRC_UP2) != 0;
+  if (up2) {
+    LMN_REQUIRE(A.nsrc == 1 && A.ksize == 3 && A.stride == 1 && !A.transposed && A.src[0].rp_w == 0 && !A.out_rp_w,
+                "conv_fwd: LMN_SRC_UP2 belongs to single-source NHWC 3x3 stride-1 forward calls");
+    LMN_REQUIRE(A.Hin % 2 == 0 && A.Win % 2 == 0 && A.Hin >= 4 && A.Win >= 4, "conv_fwd: LMN_SRC_UP2: Hin x Win (%d x %d) is the UPSAMPLED size, twice the source map", A.Hin, A.Win);
+    LMN_REQUIRE(A.epilogue == LMN_EP_LINEAR && A.stats_mode == LMN_STATS_NONE && A.drop_p == 0.f && A.fin.mode == LMN_FIN_NONE,
+                "conv_fwd: LMN_SRC_UP2 comes with the plain epilogue (bias / residual only)");
+    LMN_REQUIRE(!(A.src[0].flags & ~LMN_SRC_UP2) && !A.src[0].scale, "conv_fwd: LMN_SRC_UP2 does not combine with other source transforms");
+  }
   {  // row-planar operands (RP4): whole tensors of a 1x1 stride-1 call, one image width for all of them
     int rw = 0;
     for (int s = 0; s < 3; ++s) {
@@ -448,7 +468,10 @@ int lmn_conv_fwd(const lmn_conv_args_t* args, lmn_stream_t stream) {
       if (T.TH > gH) T.TH = gH;
       if (T.TH < 1) T.TH = 1;
     }
-    if (P.NCTT >= msplit_min && !s2t) {
+    // (LayerNorm on load: the N-split kernel reduces a pixel's statistics inside one staging round of <= 32 channels; wider sources
+    //  take the M-split kernel, whose pre-pass handles any width)
+    const bool ln_wide = ln && P.nkb[0] > 2;
+    if ((P.NCTT >= msplit_min || ln_wide) && !s2t) {
       // Wide layer -> M-split kernel.  Wide layers sit on the small feature maps, where a 128-pixel tile times a
       // few cout chunks can leave most of the 256 CUs idle: pick (tile pixels, cout tiles per wave) by a cost model
       // -- rounds of 256 blocks x per-block MFMA work (+ staging, inflated by the halo for short 3x3 tiles).
@@ -557,8 +580,8 @@ int lmn_conv_fwd(const lmn_conv_args_t* args, lmn_stream_t stream) {
       if (mblocks > mmax) mblocks = mmax;
       const dim3 mgrid(mblocks, mchunks);
       if (int rc = det_prep(mblocks)) return rc;
-      const size_t msh = ((size_t)T.XH * T.XW * T.CS + (2 + 9) * 4 * ncw * 16) * sizeof(float);
-      lmn_launch_conv_tileM(T, mgrid, msh, st, a.ksize == 1 ? 1 : 9, ncw, pm, ek, a.ksize == 1 && T.rpw != 0);
+      const size_t msh = ((size_t)T.XH * T.XW * T.CS + (2 + 9) * 4 * ncw * 16 + (ln ? 2 * T.XH * T.XW : 0)) * sizeof(float);
+      lmn_launch_conv_tileM(T, mgrid, msh, st, a.ksize == 1 ? 1 : 9, ncw, pm, ek, a.ksize == 1 && T.rpw != 0, ln, up2);
       det_finish();
       return lmn_launch_status("conv_fwd(tileM)");
     }
@@ -571,8 +594,8 @@ int lmn_conv_fwd(const lmn_conv_args_t* args, lmn_stream_t stream) {
     }
     const dim3 grid(blocks, tchunks);
     if (int rc = det_prep(blocks)) return rc;
-    if (a.ksize == 1) lmn_launch_conv_tile_1x1(T, grid, shmem, st, tnct, pm, ek, T.rpw != 0);
-    else lmn_launch_conv_tile_3x3(T, grid, shmem, st, tnct, pm, ek, wlk);
+    if (a.ksize == 1) lmn_launch_conv_tile_1x1(T, grid, shmem, st, tnct, pm, ek, T.rpw != 0, ln);
+    else lmn_launch_conv_tile_3x3(T, grid, shmem, st, tnct, pm, ek, wlk, up2);
     det_finish();
     return lmn_launch_status("conv_fwd(tile)");
   }

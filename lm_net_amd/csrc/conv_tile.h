@@ -96,9 +96,21 @@ __device__ __forceinline__ void conv_stage_params(const lmn_conv_args_t& A, floa
 // block when the layer is a single chunk -- and the MFMA loop reads its A operands with ds_read_b128.  Fetched from L2 one
 // step ahead, a fragment had 6-16 MFMAs (200-500 cycles) to arrive in: every step of the small-channel layers stalled on it
 // (phase clocks: the MFMA loop was 52-61 % of a block's life at 35 % MFMA-pipe use).
-template <int TAPS, int NCT, int EPI, bool S2T = false, int PM = 0, bool WL = false>
+// LN (1x1, one source, plain epilogue): LMN_SRC_LN -- the source is layer-normalised over its channels where it is staged.  The quads
+// of a pixel sit in ADJACENT lanes of the staging loop (item = pixel * per_px + quad, per_px = 4 or 8, the source is a single chunk
+// of <= 32 channels: the host sends wider sources to the M-split kernel), so mean and variance are two DPP reductions over 4 / 8
+// lanes on the loaded registers (two-pass form: deviations from the mean) -- no extra memory access, no barrier.  The blocks of
+// cout chunk 0 store (mean, rstd) per pixel for the weight gradient.
+// UP (3x3 stride-1 forward, one source): LMN_SRC_UP2 -- the source tensor is the HALF-resolution map and the window is sampled from its
+// bilinear x2 upsampling (align_corners=True, lmn_up_coord: the arithmetic of lmn_up2_fwd) where it is staged: four float4 loads per
+// (window pixel, channel quad) from the quarter-size tensor (neighbouring window pixels share their taps: L1 / L2 hits) instead of
+// one from a materialised `up` tensor that a separate kernel wrote.  Window pixels outside the UPSAMPLED image are the conv's zero
+// padding.  Two items per thread and round (8 loads in flight).
+template <int TAPS, int NCT, int EPI, bool S2T = false, int PM = 0, bool WL = false, bool LN = false, bool UP = false>
 __global__ __launch_bounds__(256) void conv_tile_kernel(const ConvParams P) {
+  static_assert(!UP || (TAPS == 9 && !S2T && (PM & 4) == 0), "bilinear x2 on load: NHWC 3x3 stride-1 forward calls");
   static_assert(!WL || (TAPS == 9 && !S2T), "LDS-staged weights: 3x3 stride-1 windows");
+  static_assert(!LN || (TAPS == 1 && EPI == 0 && (PM & 4) == 0), "LayerNorm on load: NHWC 1x1 calls with the plain epilogue");
   // PM bit 2 (RP): some operand of this 1x1 call is ROW-PLANAR (common.h LmnLay) -- a separate instantiation, so that the NHWC
   // instances keep their registers (the layout arithmetic in every instance cost the SE-gradient conv its fifth wave per SIMD)
   constexpr int PMB = PM & 3;
@@ -173,6 +185,16 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(const ConvParams P) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) st0[c][r] = st1[c][r] = 0.f;
   int cur_b = -1;  // image whose SE_BWD sums are in st0
+  // LN: a thread stages the same channel quad of every item (item index = tid mod per_px): its gamma / beta once per kernel
+  f32x4 ln_g = f32x4{0.f, 0.f, 0.f, 0.f}, ln_b = ln_g;
+  float ln_invC = 0.f;
+  if constexpr (LN) {
+    const lmn_src_t& S0 = A.src[0];
+    const int ppx = P.nkb[0] >= 2 ? 8 : 4;
+    const int ch = (tid & (ppx - 1)) * 4;
+    if (ch < S0.C) { ln_g = ld4(S0.ln_gamma + ch); ln_b = ld4(S0.ln_beta + ch); }
+    ln_invC = 1.f / (float)S0.C;
+  }
 
   // tiles of a block: contiguous range [t_begin, t_end) (tstep 1), or every gridDim.x-th tile (P.strided: all blocks
   // get floor or ceil of the average and the surplus lands on the first-dispatched blocks, one per CU)
@@ -279,6 +301,52 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(const ConvParams P) {
         //      to load -> s_waitcnt vmcnt(0) -> write per item, i.e. 3-6 serial HBM round trips per 3x3 chunk).
         const int psh = nkbc == 2 ? 3 : 2, per_px = 1 << psh;   // quads per pixel: 4 (one K16 block) or 8
         const int nitems = P.XH * P.XW * per_px;
+        if constexpr (UP) {
+          const int hs = A.Hin >> 1, ws = A.Win >> 1;   // the source map (A.Hin x A.Win is the upsampled image the conv sees)
+          const float sh = (float)(hs - 1) / (float)(A.Hin - 1), sw = (float)(ws - 1) / (float)(A.Win - 1);
+          constexpr int SUU = 2;
+          for (int i0 = 0; i0 < nitems; i0 += SUU * 256) {
+            f32x4 t4[SUU][4];
+            bool tok[SUU];
+#pragma unroll
+            for (int u = 0; u < SUU; ++u) {
+              const int i = i0 + u * 256 + tid;
+              const int f = i & (per_px - 1), pix = i >> psh;
+              const int r = (int)__umulhi((uint32_t)pix, P.mXW), c = pix - r * P.XW;
+              const int iy = wy0 + r, ix = wx0 + c;
+              const int ch = kb0 * 16 + f * 4;
+              const bool ok = i < nitems && ch < S.C && (unsigned)iy < (unsigned)A.Hin && (unsigned)ix < (unsigned)A.Win;
+              tok[u] = ok;
+              int y0, yp, x0, xp;
+              float l0, l1;
+              lmn_up_coord(ok ? iy : 0, hs, sh, y0, yp, l0, l1);
+              lmn_up_coord(ok ? ix : 0, ws, sw, x0, xp, l0, l1);
+              const TA* p00 = (const TA*)S.ptr + (uint32_t)(((b * hs + y0) * ws + x0) * S.cstride + (ok ? ch : 0));
+              const TA* p10 = p00 + yp * ws * S.cstride;
+              t4[u][0] = ld4(p00); t4[u][1] = ld4(p00 + xp * S.cstride);
+              t4[u][2] = ld4(p10); t4[u][3] = ld4(p10 + xp * S.cstride);
+            }
+#pragma unroll
+            for (int u = 0; u < SUU; ++u) {
+              const int i = i0 + u * 256 + tid;
+              if (i >= nitems) continue;
+              const int f = i & (per_px - 1), pix = i >> psh;
+              const int r = (int)__umulhi((uint32_t)pix, P.mXW), c = pix - r * P.XW;
+              int y0, yp, x0, xp;
+              float ly0, ly1, lx0, lx1;
+              lmn_up_coord(tok[u] ? wy0 + r : 0, hs, sh, y0, yp, ly0, ly1);
+              lmn_up_coord(tok[u] ? wx0 + c : 0, ws, sw, x0, xp, lx0, lx1);
+              f32x4 v = ly0 * (lx0 * t4[u][0] + lx1 * t4[u][1]) + ly1 * (lx0 * t4[u][2] + lx1 * t4[u][3]);   // (the expression of up2_fwd_kernel)
+              if (!tok[u]) v = f32x4{0.f, 0.f, 0.f, 0.f};
+              if constexpr (BF) {
+                *reinterpret_cast<uint2*>(&XS[pix * P.CS + f * 2]) = pk4_bf16(v);
+              } else {
+                float* d = &XS[pix * P.CS + (f >> 2) * 16 + (f & 3)];
+                d[0] = v[0]; d[4] = v[1]; d[8] = v[2]; d[12] = v[3];
+              }
+            }
+          }
+        } else {
         constexpr int SU = TAPS == 1 ? 2 : 4;  // items per thread and round.  1x1: four in flight cost the epilogue-heavy instances a wave per
                                                // SIMD; two (+6 VGPRs, same occupancy bracket for all but <1,3,0>) halve the 4-6 serial round
                                                // trips of the 24-48 channel layers: +0.3 % fp32 batch 8, +1.6 % bf16 batch 64
@@ -311,6 +379,22 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(const ConvParams P) {
             const bool ok = sgp[u] >= 0;
             const int gp = ok ? sgp[u] : 0, chs = ok ? kb0 * 16 + f * 4 : 0;
             f32x4 v = sv[u];
+            if constexpr (LN) {
+              // (items past the window end in whole pixels: the lanes of a pixel are all active here or all skipped above)
+              auto px_sum = [&](float t) -> float {
+                t += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(t), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
+                t += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(t), 0x4E, 0xF, 0xF, true));   // quad_perm [2,3,0,1]
+                if (per_px == 8) t += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(t), 0x141, 0xF, 0xF, true));   // row_half_mirror: the other quad of the 8
+                return t;
+              };
+              const bool cok = chs + 0 < S.C && ok;   // (a quad past the channels loaded channel 0..3: it must not enter the sums)
+              const float mean = px_sum(cok ? (v[0] + v[1]) + (v[2] + v[3]) : 0.f) * ln_invC;
+              const f32x4 dv = v - mean;
+              const float var = px_sum(cok ? (dv[0] * dv[0] + dv[1] * dv[1]) + (dv[2] * dv[2] + dv[3] * dv[3]) : 0.f) * ln_invC;
+              const float rstd = rsqrtf(var + S.ln_eps);
+              v = dv * rstd * ln_g + ln_b;
+              if (f == 0 && ok && blockIdx.y == 0 && S.ln_stats) *reinterpret_cast<float2*>(S.ln_stats + 2 * (int64_t)gp) = float2{mean, rstd};
+            }
             if (S.flags & LMN_SRC_GELU) {
 #pragma unroll
               for (int k = 0; k < 4; ++k) v[k] = lmn_gelu(v[k]);
@@ -329,6 +413,7 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(const ConvParams P) {
             }
           }
         }
+        }   // (!UP)
         LMN_TK_DRAIN();
         LMN_TK(1);
         __syncthreads();

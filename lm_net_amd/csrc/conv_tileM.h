@@ -10,8 +10,16 @@ namespace {
 // through L1 four times; at Cout = 372 that stream, not the MFMAs, set the pace) and feeds 8 x 4 MFMAs; the pixel
 // operand comes from LDS, where re-reading it per wave is cheap.
 #define LMN_SLOT (wv + 4 * c)
-template <int TAPS, int NCW, int EPI, int PM = 0>
+// LN (1x1, one source, plain epilogue): LMN_SRC_LN on a source of ANY width (K chunks of <= 128 channels: the statistics of a pixel
+// are not in one staging round).  A pre-pass per tile -- two threads per pixel walk the pixel's channels in global memory (the lines
+// the staging reads right after: L2 / L1 hits) with sums about the pixel's first channel value (no cancellation against a large mean)
+// -- leaves (mean, rstd) of the tile's pixels in LDS; the staging applies (x - mean) * rstd * gamma + beta.  Wide sources sit on the
+// small feature maps (C = 48 / 96 / 372 at 88^2 / 44^2 / 22^2): the pre-pass is a few microseconds per launch.
+// UP (3x3 forward, one source): LMN_SRC_UP2, as in conv_tile_kernel.
+template <int TAPS, int NCW, int EPI, int PM = 0, bool LN = false, bool UP = false>
 __global__ __launch_bounds__(256) void conv_tileM_kernel(const ConvParams P) {
+  static_assert(!UP || (TAPS == 9 && (PM & 4) == 0), "bilinear x2 on load: NHWC 3x3 stride-1 forward calls");
+  static_assert(!LN || (TAPS == 1 && EPI == 0 && (PM & 4) == 0), "LayerNorm on load: NHWC 1x1 calls with the plain epilogue");
   constexpr int PMB = PM & 3;
   constexpr bool RP = (PM & 4) != 0;      // (row-planar operands: see conv_tile_kernel)
   static_assert(!RP || TAPS == 1, "row-planar operands: 1x1 convs");
@@ -47,6 +55,8 @@ __global__ __launch_bounds__(256) void conv_tileM_kernel(const ConvParams P) {
 
   for (int i = tid; i < 2 * NCT * 16; i += 256) s_stats[i] = 0.f;
   float* s_par = s_stats + 2 * NCT * 16;  // [9][NCT*16]
+  float* s_ln = s_par + 9 * NCT * 16;     // LN: [XH*XW][2] = (mean, rstd) of the tile's pixels
+  (void)s_ln;
   conv_stage_params<NCT>(A, s_par, ct0, tid, blockIdx.x == 0);
   __syncthreads();  // the tiles read s_par from their first instruction on (accumulators start from the bias)
   float st0[NCW][4], st1[NCW][4];
@@ -115,6 +125,39 @@ __global__ __launch_bounds__(256) void conv_tileM_kernel(const ConvParams P) {
       for (int g = 0; g < NGM; ++g) acc[g][c] = b4;
     }
 
+    if constexpr (LN) {
+      // statistics of the tile's pixels (the previous tile's staging -- the last reader of s_ln -- finished before its MFMA
+      // barrier; the chunk loop's leading barrier below orders these writes before the staging reads)
+      const lmn_src_t& S0 = A.src[0];
+      const int C4 = S0.C >> 2;
+      const float invC = 1.f / (float)S0.C;
+      for (int p = tid >> 1; p < P.XH * P.XW; p += 128) {
+        const int h = tid & 1;
+        const int r = (int)__umulhi((uint32_t)p, P.mXW), c = p - r * P.XW;
+        const int iy = wy0 + r, ix = wx0 + c;
+        const bool okp = (unsigned)iy < (unsigned)A.Hin && (unsigned)ix < (unsigned)A.Win;
+        const int gp = okp ? (b * A.Hin + iy) * A.Win + ix : 0;
+        const TA* px = (const TA*)S0.ptr + (uint32_t)(gp * S0.cstride);
+        const float x0 = ld4(px)[0];
+        float sm = 0.f, sq = 0.f;
+        for (int f = h; f < C4; f += 2) {
+          const f32x4 d = ld4(px + f * 4) - x0;
+          sm += (d[0] + d[1]) + (d[2] + d[3]);
+          sq += (d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3]);
+        }
+        sm += __shfl_xor(sm, 1, 64);
+        sq += __shfl_xor(sq, 1, 64);
+        const float md = sm * invC;
+        float var = sq * invC - md * md;
+        var = var > 0.f ? var : 0.f;
+        const float mean = x0 + md, rstd = rsqrtf(var + S0.ln_eps);
+        if (h == 0) {
+          s_ln[2 * p] = mean;
+          s_ln[2 * p + 1] = rstd;
+          if (okp && blockIdx.y == 0 && S0.ln_stats) *reinterpret_cast<float2*>(S0.ln_stats + 2 * (int64_t)gp) = float2{mean, rstd};
+        }
+      }
+    }
     for (int s = 0; s < A.nsrc; ++s) {
       const lmn_src_t& S = A.src[s];
       const LmnLay LS = P.lay_src[s];   // (used by the row-planar instances only)
@@ -139,6 +182,53 @@ __global__ __launch_bounds__(256) void conv_tileM_kernel(const ConvParams P) {
         const int psh = nkbc <= 1 ? 2 : nkbc == 2 ? 3 : nkbc <= 4 ? 4 : 5, per_px = 1 << psh;   // quad slots per pixel: 4 per K16 block, rounded up to a power of two
         const int nq = nkbc * 4;                                                                // quads per pixel in this chunk
         const int nitems = P.XH * P.XW * per_px;
+        if constexpr (UP) {
+          const int hs = A.Hin >> 1, ws = A.Win >> 1;   // the source map (A.Hin x A.Win is the upsampled image the conv sees)
+          const float sh = (float)(hs - 1) / (float)(A.Hin - 1), sw = (float)(ws - 1) / (float)(A.Win - 1);
+          constexpr int SUU = 2;
+          for (int i0 = 0; i0 < nitems; i0 += SUU * 256) {
+            f32x4 t4[SUU][4];
+            bool tok[SUU];
+#pragma unroll
+            for (int u = 0; u < SUU; ++u) {
+              const int i = i0 + u * 256 + tid;
+              const int f = i & (per_px - 1), pix = i >> psh;
+              const int r = (int)__umulhi((uint32_t)pix, P.mXW), c = pix - r * P.XW;
+              const int iy = wy0 + r, ix = wx0 + c;
+              const int ch = kb0 * 16 + f * 4;
+              const bool ok = i < nitems && f < nq && ch < S.C && (unsigned)iy < (unsigned)A.Hin && (unsigned)ix < (unsigned)A.Win;
+              tok[u] = ok;
+              int y0, yp, x0, xp;
+              float l0, l1;
+              lmn_up_coord(ok ? iy : 0, hs, sh, y0, yp, l0, l1);
+              lmn_up_coord(ok ? ix : 0, ws, sw, x0, xp, l0, l1);
+              const TA* p00 = (const TA*)S.ptr + (uint32_t)(((b * hs + y0) * ws + x0) * S.cstride + (ok ? ch : 0));
+              const TA* p10 = p00 + yp * ws * S.cstride;
+              t4[u][0] = ld4(p00); t4[u][1] = ld4(p00 + xp * S.cstride);
+              t4[u][2] = ld4(p10); t4[u][3] = ld4(p10 + xp * S.cstride);
+            }
+#pragma unroll
+            for (int u = 0; u < SUU; ++u) {
+              const int i = i0 + u * 256 + tid;
+              if (i >= nitems) continue;
+              const int f = i & (per_px - 1), pix = i >> psh;
+              if (f >= nq) continue;
+              const int r = (int)__umulhi((uint32_t)pix, P.mXW), c = pix - r * P.XW;
+              int y0, yp, x0, xp;
+              float ly0, ly1, lx0, lx1;
+              lmn_up_coord(tok[u] ? wy0 + r : 0, hs, sh, y0, yp, ly0, ly1);
+              lmn_up_coord(tok[u] ? wx0 + c : 0, ws, sw, x0, xp, lx0, lx1);
+              f32x4 v = ly0 * (lx0 * t4[u][0] + lx1 * t4[u][1]) + ly1 * (lx0 * t4[u][2] + lx1 * t4[u][3]);   // (the expression of up2_fwd_kernel)
+              if (!tok[u]) v = f32x4{0.f, 0.f, 0.f, 0.f};
+              if constexpr (BF) {
+                *reinterpret_cast<uint2*>(&XS[pix * P.CS + f * 2]) = pk4_bf16(v);
+              } else {
+                float* d = &XS[pix * P.CS + (f >> 2) * 16 + (f & 3)];
+                d[0] = v[0]; d[4] = v[1]; d[8] = v[2]; d[12] = v[3];
+              }
+            }
+          }
+        } else {
         constexpr int SU = 4;  // items per thread and round
         for (int i0 = 0; i0 < nitems; i0 += SU * 256) {
           f32x4 sv[SU];
@@ -170,6 +260,10 @@ __global__ __launch_bounds__(256) void conv_tileM_kernel(const ConvParams P) {
             const bool ok = sgp[u] >= 0;
             const int gp = ok ? sgp[u] : 0, chs = ok ? kb0 * 16 + f * 4 : 0;
             f32x4 v = sv[u];
+            if constexpr (LN) {
+              const float2 mr = *reinterpret_cast<const float2*>(&s_ln[2 * pix]);
+              v = (v - mr.x) * mr.y * ld4(S.ln_gamma + chs) + ld4(S.ln_beta + chs);
+            }
             if (S.flags & LMN_SRC_GELU) {
 #pragma unroll
               for (int k = 0; k < 4; ++k) v[k] = lmn_gelu(v[k]);
@@ -188,6 +282,7 @@ __global__ __launch_bounds__(256) void conv_tileM_kernel(const ConvParams P) {
             }
           }
         }
+        }   // (!UP)
         LMN_TK_DRAIN();
         LMN_TK(1);
         __syncthreads();

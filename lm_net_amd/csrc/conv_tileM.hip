@@ -1,7 +1,23 @@
 // conv_tileM_kernel instances (M-split form for wide layers: 1x1 incl. row-planar operands, 3x3).
 #include "conv_tileM.h"
 
-int lmn_launch_conv_tileM(const ConvParams& T, dim3 mgrid, size_t msh, hipStream_t st, int taps, int ncw, int pm, int ek, bool rp) {
+int lmn_launch_conv_tileM(const ConvParams& T, dim3 mgrid, size_t msh, hipStream_t st, int taps, int ncw, int pm, int ek, bool rp, bool ln, bool up) {
+  if (up) {   // bilinear x2 on load (LMN_SRC_UP2): plain-epilogue 3x3 instances of their own
+#define LMN_CU(NN) do { if (pm == 2) LMN_LAUNCH((conv_tileM_kernel<9, NN, 0, 2, false, true>), mgrid, dim3(256), msh, st, T); \
+                        else if (pm == 1) LMN_LAUNCH((conv_tileM_kernel<9, NN, 0, 1, false, true>), mgrid, dim3(256), msh, st, T); \
+                        else LMN_LAUNCH((conv_tileM_kernel<9, NN, 0, 0, false, true>), mgrid, dim3(256), msh, st, T); } while (0)
+    if (ncw == 2) LMN_CU(2); else LMN_CU(1);
+#undef LMN_CU
+    return 0;
+  }
+  if (ln) {   // LayerNorm on load (LMN_SRC_LN): plain-epilogue NHWC 1x1 instances of their own
+#define LMN_CL(NN) do { if (pm == 2) LMN_LAUNCH((conv_tileM_kernel<1, NN, 0, 2, true>), mgrid, dim3(256), msh, st, T); \
+                        else if (pm == 1) LMN_LAUNCH((conv_tileM_kernel<1, NN, 0, 1, true>), mgrid, dim3(256), msh, st, T); \
+                        else LMN_LAUNCH((conv_tileM_kernel<1, NN, 0, 0, true>), mgrid, dim3(256), msh, st, T); } while (0)
+    if (ncw == 2) LMN_CL(2); else LMN_CL(1);
+#undef LMN_CL
+    return 0;
+  }
 #define LMN_CM(TT, NN, BFV)                                                                              \
   do {                                                                                                   \
     switch ((TT) == 1 ? ek : (ek > 2 ? 1 : ek)) {                                                        \

@@ -2,7 +2,27 @@
 // and the parity-class data gradient of the stride-2 convs (S2T).
 #include "conv_tile.h"
 
-int lmn_launch_conv_tile_3x3(const ConvParams& T, dim3 grid, size_t shmem, hipStream_t st, int tnct, int pm, int ek, bool wlk) {
+int lmn_launch_conv_tile_3x3(const ConvParams& T, dim3 grid, size_t shmem, hipStream_t st, int tnct, int pm, int ek, bool wlk, bool up) {
+  if (up) {   // bilinear x2 on load (LMN_SRC_UP2): plain-epilogue instances of their own
+#define LMN_CU(NN, BFV)                                                                                               \
+  do {                                                                                                                \
+    if (wlk) LMN_LAUNCH((conv_tile_kernel<9, NN, 0, false, BFV, true, false, true>), grid, dim3(256), shmem, st, T);   \
+    else LMN_LAUNCH((conv_tile_kernel<9, NN, 0, false, BFV, false, false, true>), grid, dim3(256), shmem, st, T);      \
+  } while (0)
+    switch ((tnct > 3 ? 3 : tnct) * 4 + pm) {
+      case 4: LMN_CU(1, 0); break;
+      case 5: LMN_CU(1, 1); break;
+      case 6: LMN_CU(1, 2); break;
+      case 8: LMN_CU(2, 0); break;
+      case 9: LMN_CU(2, 1); break;
+      case 10: LMN_CU(2, 2); break;
+      case 13: LMN_CU(3, 1); break;
+      case 14: LMN_CU(3, 2); break;
+      default: LMN_CU(3, 0); break;
+    }
+#undef LMN_CU
+    return 0;
+  }
   const int ekk = ek > 2 ? 1 : ek;   // (the BatchNorm-backward / SE-gradient epilogue instances exist for 1x1 convs only)
 #define LMN_CT(NN, BFV)                                                                                  \
   do {                                                                                                   \

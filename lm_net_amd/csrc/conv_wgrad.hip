@@ -981,6 +981,22 @@ __global__ __launch_bounds__(256) void wgrad_1x1w_kernel(const WgradParams P) {
   const int NPX = A.B * HW;
   // staging role of this lane: pixel lp of the chunk, channel quad lq of every tile
   const int lp = lane >> 2, lq = lane & 3;
+  // LMN_SRC_LN (single source): the source is layer-normalised where a chunk is parked -- (mean, rstd) of a pixel from the table the
+  // forward conv left (ln_stats, one 8-byte load per lane and chunk, in flight with the chunk), gamma / beta of the block's channel
+  // tiles from LDS (behind the staging / reduction area: [NNT][gamma 16 | beta 16])
+  constexpr int LNOFF = (4 * NTT * 256 > NMT * NNT * 256 + NMT * 16) ? 4 * NTT * 256 : NMT * NNT * 256 + NMT * 16;
+  float* s_gb = smem + LNOFF;
+  const bool ln = (A.src[0].flags & LMN_SRC_LN) != 0;   // block-uniform
+  if (ln) {
+    for (int i = threadIdx.x; i < NNT * 16; i += 256) {
+      const int t = i >> 4, c = i & 15, ch = (nt0 + t) * 16 + c;
+      const bool cok = (nt0 + t) < P.NNTT && ch < A.src[0].C;
+      s_gb[t * 32 + c] = cok ? A.src[0].ln_gamma[ch] : 0.f;
+      s_gb[t * 32 + 16 + c] = cok ? A.src[0].ln_beta[ch] : 0.f;
+    }
+    __syncthreads();
+  }
+  float2 lnmr = float2{0.f, 1.f};
 
   const TA* sptr[NNT];
   const float* sscale[NNT];
@@ -1029,6 +1045,7 @@ __global__ __launch_bounds__(256) void wgrad_1x1w_kernel(const WgradParams P) {
   auto chunk_load = [&](int c) {
     const int px = c * 16 + lp;
     const int ps = px < NPX ? px : 0;
+    if (ln) lnmr = *reinterpret_cast<const float2*>(A.src[0].ln_stats + 2 * (int64_t)ps);
     if constexpr (RP) {
       const uint32_t rowp = lmn_div_row((uint32_t)ps, (uint32_t)P.rpw, P.rp_magic);   // (row term of the row-planar operands)
 #pragma unroll
@@ -1060,6 +1077,7 @@ __global__ __launch_bounds__(256) void wgrad_1x1w_kernel(const WgradParams P) {
     for (int t = 0; t < NNT; ++t) {
       f32x4 v = stg[NMT + t];
       const int chs = sch4[t] >= 0 ? sch4[t] : 0;
+      if (ln) v = (v - lnmr.x) * lnmr.y * (*reinterpret_cast<const f32x4*>(&s_gb[t * 32 + lq * 4])) + (*reinterpret_cast<const f32x4*>(&s_gb[t * 32 + 16 + lq * 4]));
       if (sflags[t] & LMN_SRC_GELU) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) v[k] = lmn_gelu(v[k]);
@@ -1523,6 +1541,14 @@ static int wgrad_setup(const lmn_wgrad_args_t& A, WgradParams& P, WgGeom& G) {
   for (int s = 0; s < A.nsrc; ++s) any_tf = any_tf || A.src[s].flags != 0 || A.src[s].scale != nullptr;
   const bool old_shape = (NMT == 1 && NNT <= 4) || (NNT == 1 && NMT <= 4) || (NMT == 2 && NNT == 2);
   G.wave_staged = !(pm == 2 && !any_tf && old_shape) || (rp_any && (int64_t)Gm.Hout * Gm.Wout < 32);   // (tiny maps: the staged kernel divides per pixel)
+  for (int s = 0; s < A.nsrc; ++s) {
+    if (A.src[s].flags & LMN_SRC_LN) {   // LayerNorm on load: the wave-staged 1x1 kernel, statistics from the forward conv's table
+      LMN_REQUIRE(A.nsrc == 1 && G.direct && G.wave_staged && !rp_any, "conv_wgrad: LMN_SRC_LN belongs to single-source NHWC 1x1 stride-1 calls over >= 32 pixels");
+      LMN_REQUIRE(A.src[s].ln_gamma && A.src[s].ln_beta && A.src[s].ln_stats, "conv_wgrad: LMN_SRC_LN needs ln_gamma / ln_beta and the ln_stats table of the forward conv");
+      LMN_REQUIRE(!(A.src[s].flags & ~LMN_SRC_LN) && !A.src[s].scale, "conv_wgrad: LMN_SRC_LN does not combine with other source transforms");
+    }
+    LMN_REQUIRE(!(A.src[s].flags & LMN_SRC_UP2), "conv_wgrad: LMN_SRC_UP2 is not built into this kernel family yet");
+  }
   return 0;
 }
 
@@ -1628,7 +1654,7 @@ int lmn_conv_wgrad(const lmn_wgrad_args_t* args, lmn_stream_t stream) {
   do {                                                                                                              \
     if (wave_staged) {                                                                                              \
       const int64_t stf = 4 * (M + N) * 256, rdf = (int64_t)M * N * 256 + M * 16;                                   \
-      const size_t wsh = (size_t)(stf > rdf ? stf : rdf) * 4;                                                       \
+      const size_t wsh = (size_t)((stf > rdf ? stf : rdf) + 32 * N) * 4;   /* (+ the LayerNorm gamma / beta tiles) */ \
       LMN_WDK(wgrad_1x1w_kernel, M, N, wsh);                                                                        \
     } else LMN_WDK(wgrad_1x1_kernel, M, N, 0);                                                                      \
     if (reduce_now) {                                                                                               \
@@ -1640,7 +1666,7 @@ int lmn_conv_wgrad(const lmn_wgrad_args_t* args, lmn_stream_t stream) {
 #define LMN_WW(M, N)                                                                                               \
   do {                                                                                                              \
     const int64_t stf = 4 * (M + N) * 256, rdf = (int64_t)M * N * 256 + M * 16;                                     \
-    const size_t wsh = (size_t)(stf > rdf ? stf : rdf) * 4;                                                         \
+    const size_t wsh = (size_t)((stf > rdf ? stf : rdf) + 32 * N) * 4;                                              \
     LMN_WDK(wgrad_1x1w_kernel, M, N, wsh);                                                                          \
     if (reduce_now) {                                                                                               \
       const int ksl = reduce_slices((int)nb);                                                                       \

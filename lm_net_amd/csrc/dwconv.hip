@@ -767,35 +767,119 @@ struct SwState {
 };
 
 // PART: 0 = dx1 and the weight gradients in one pass, 1 = dx1 only, 2 = weight gradients only
+// Round 5: the step in a form that issues fewer non-FMA instructions (ISA of the round-4 loop: 645 v_pk_fma of 1045 VALU per five
+// steps -- 130 v_pk_mul, 80 v_mov_dpp, 76 v_readlane / v_writelane of spilled scalars, 54 v_cndmask, 61 s_nop):
+//   * f row q = j - 3 (one step later than before) is formed FIRST, from branch accumulators that were completed by the previous
+//     step, as two packed FMAs per branch -- dp * cA' + cD', then + a_b * cC' -- with the BatchNorm-backward coefficients as per-lane
+//     VGPR pairs that carry the column mask (cA' = cA * [column inside the image], ...): no mask multiplies, 12 SGPRs fewer;
+//   * its column neighbours (f5 +-1, +-2; f3 +-1; fh +-1) travel through ds_bpermute_b32 -- the LDS crossbar, no VALU issue slot
+//     (v_pk_fma_f32 takes no DPP operand: the 16 v_mov_dpp per step were pure issue overhead) -- requested right after f is formed
+//     and consumed by the dx1 FMAs at the END of the step, behind the 40 branch-output and 40 weight-gradient FMAs;
+//   * the row masks (rows outside the image / outside the wave's own segment) are wave-uniform: interior steps skip them by ONE
+//     scalar branch (msk_on), only the own-row mask of the weight-gradient history (h = f * mo) stays a multiply.
+// Rows by step j (P = j mod 5; slots are row mod 5): x1 row j enters (ring slot P, whose previous content -- row j - 5 -- was read
+// as i2 before); branch outputs accumulate into rows j - 2 .. j + 2; f row j - 3; weight-gradient products of x1 row j - 5 against
+// f rows j - 3 .. j - 7; dx rows j - 5 .. j - 1, of which row j - 5 is complete after this step.
+// f = dp * sA[hi] + vD[hi]: the scalar coefficient cA_b from an SGPR pair (two branches per pair), cD_b' = cD_b * column mask from a
+// per-lane VGPR pair (two branches per pair)
+__device__ __forceinline__ void pkfma_cA(f32x2& f, f32x2 dp, f32x2 sA, f32x2 vD, int hi) {
+  if (hi) asm volatile("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,1] op_sel_hi:[1,1,1]" : "=v"(f) : "v"(dp), "s"(sA), "v"(vD));
+  else asm volatile("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=v"(f) : "v"(dp), "s"(sA), "v"(vD));
+}
+__device__ __forceinline__ void pkfma_cC(f32x2& f, f32x2 a, f32x2 vC, int hi) {   // f += a * vC[hi]  (cC_b' = cC_b * column mask, per lane)
+  if (hi) asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "+v"(f) : "v"(a), "v"(vC));
+  else asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]" : "+v"(f) : "v"(a), "v"(vC));
+}
+__device__ __forceinline__ f32x2 pk_hsw_affine(f32x2 z, f32x2 as) {   // z * as.lo + as.hi  (A' / shift' of the lane in ONE VGPR pair)
+  f32x2 x;
+  asm("v_pk_fma_f32 %0, %1, %2, %2 op_sel:[0,0,1] op_sel_hi:[1,0,1]" : "=v"(x) : "v"(z), "v"(as));
+  return x;
+}
+__device__ __forceinline__ f32x2 hswish2_as(f32x2 z, f32x2 as) {
+  const f32x2 x = pk_hsw_affine(z, as);
+  f32x2 t = x * (1.f / 6.f) + 0.5f;
+  t.x = __builtin_amdgcn_fmed3f(t.x, 0.f, 1.f);
+  t.y = __builtin_amdgcn_fmed3f(t.y, 0.f, 1.f);
+  return x * t;
+}
+__device__ __forceinline__ f32x2 bperm2(int addr, f32x2 v) {   // lane l <- lane (addr / 4) mod 64 (both halves)
+  f32x2 r;
+  r.x = __int_as_float(__builtin_amdgcn_ds_bpermute(addr, __float_as_int(v.x)));
+  r.y = __int_as_float(__builtin_amdgcn_ds_bpermute(addr, __float_as_int(v.y)));
+  return r;
+}
+struct SwCoef { f32x2 sA[2], vC[2], vD[2]; };   // {cA_0, cA_1}, {cA_2, cA_3} (scalars); cC / cD likewise, times the lane's column mask
+struct SwF { f32x2 sh[5], s3[3], hr, hl, fv, fh; };   // f row q and its column neighbours: sh[k][l] = f5[l + 2 - k], s3[k][l] = f3[l + 1 - k]
+
+// first half of a step: f row q = j - 3, its neighbours (requested), the weight-gradient products of x1 row j - 5 (i2)
+__device__ __forceinline__ void pkmul_s2(f32x2& d, f32x2 x, f32x2 sp) {   // d = x * {sp.lo, sp.hi}: a per-half scalar mask from an SGPR pair
+  asm volatile("v_pk_mul_f32 %0, %1, %2" : "=v"(d) : "v"(x), "s"(sp));
+}
+// msk_on (wave-uniform): a step that touches rows outside the image (mf: the f row of each half); mo: the f row lies in the wave's own
+// segment (weight-gradient history; always applied: it is the one mask whose off / on forms would need two registers per value)
 template <int P, int PART>
-__device__ __forceinline__ void sw_step(SwState& S, const W2& bw, const f32x2 (&co)[6], float cm, const f32x2* XSw, int lane, f32x2 x1, f32x2 dp,
-                                        f32x2 mf, f32x2 mo) {
+__device__ __forceinline__ void sw_step_f(SwState& S, const SwCoef& CF, SwF& F, const f32x2 (&i2)[5], f32x2 dp, f32x2 mf, f32x2 mo, bool msk_on,
+                                          int bp0) {
   typedef f32x2 V;
-  // ---- shifted copies of this step's x1 row, then the weight-gradient products that only need OLD f rows (x1 row j-4 against f
-  //      rows j-3 .. j-6): they cover the latency of the reads
-  V in[5];
-  const V* xr = XSw + P * 68 + lane;
-  in[0] = xr[0]; in[1] = xr[1]; in[2] = x1; in[3] = xr[3]; in[4] = xr[4];
-  const V* x2 = XSw + ((P + 1) % 5) * 68 + lane;
-  V i2[5];
+  constexpr int Q = (P + 2) % 5;   // slot of row j - 3: all four branch outputs of that row were completed by the previous step
+  V f5, f3, fv, fh;
+  pkfma_cA(f5, dp, CF.sA[0], CF.vD[0], 0); pkfma_cA(f3, dp, CF.sA[0], CF.vD[0], 1);
+  pkfma_cA(fv, dp, CF.sA[1], CF.vD[1], 0); pkfma_cA(fh, dp, CF.sA[1], CF.vD[1], 1);
+  pkfma_cC(f5, S.a5[Q], CF.vC[0], 0); pkfma_cC(f3, S.a3[Q], CF.vC[0], 1); pkfma_cC(fv, S.av[Q], CF.vC[1], 0); pkfma_cC(fh, S.ah[Q], CF.vC[1], 1);
+  LMN_NOP0();
+  if (msk_on) { pkmul_s2(f5, f5, mf); pkmul_s2(f3, f3, mf); pkmul_s2(fv, fv, mf); pkmul_s2(fh, fh, mf); LMN_NOP0(); }   // (rows outside the image)
+  if constexpr (PART != 2) {   // column neighbours through the LDS crossbar; bp0 = 4 * ((lane - 2) & 63): lanes -2, -1, +1, +2 at +0, +4, +12, +16
+    F.sh[4] = bperm2(bp0, f5); F.sh[3] = bperm2(bp0 + 4, f5); F.sh[1] = bperm2(bp0 + 12, f5); F.sh[0] = bperm2(bp0 + 16, f5);
+    F.s3[2] = bperm2(bp0 + 4, f3); F.s3[0] = bperm2(bp0 + 12, f3);
+    F.hl = bperm2(bp0 + 4, fh); F.hr = bperm2(bp0 + 12, fh);
+    F.sh[2] = f5; F.s3[1] = f3; F.fv = fv; F.fh = fh;
+  }
+  pkmul_s2(S.h5[Q], f5, mo); pkmul_s2(S.h3[Q], f3, mo); pkmul_s2(S.hv[Q], fv, mo); pkmul_s2(S.hh[Q], fh, mo);   // own rows only: the weight-gradient history
+  // ---- weight gradients: x1 row j - 5 (i2) against f rows j - 3 - ky (5x5), j - 4 - ky (3x3, 3x1), j - 5 (1x3)
   if (PART != 1) {
 #pragma unroll
-    for (int d = 0; d < 5; ++d) i2[d] = x2[d];
+    for (int ky = 4; ky >= 0; --ky)   // (the row of this step's h last: its multiply above is a packed result)
 #pragma unroll
-    for (int ky = 1; ky < 5; ++ky)
-#pragma unroll
-      for (int kx = 0; kx < 5; ++kx) pkfma_vv(S.g5[ky * 5 + kx], S.h5[(P + 8 - ky) % 5], i2[kx]);
+      for (int kx = 0; kx < 5; ++kx) pkfma_vv(S.g5[ky * 5 + kx], S.h5[(P + 7 - ky) % 5], i2[kx]);
 #pragma unroll
     for (int ky = 0; ky < 3; ++ky) {
 #pragma unroll
-      for (int kx = 0; kx < 3; ++kx) pkfma_vv(S.g3[ky * 3 + kx], S.h3[(P + 7 - ky) % 5], i2[1 + kx]);
-      pkfma_vv(S.gv[ky], S.hv[(P + 7 - ky) % 5], i2[2]);
+      for (int kx = 0; kx < 3; ++kx) pkfma_vv(S.g3[ky * 3 + kx], S.h3[(P + 6 - ky) % 5], i2[1 + kx]);
+      pkfma_vv(S.gv[ky], S.hv[(P + 6 - ky) % 5], i2[2]);
     }
 #pragma unroll
-    for (int kx = 0; kx < 3; ++kx) pkfma_vv(S.gh[kx], S.hh[(P + 1) % 5], i2[1 + kx]);
+    for (int kx = 0; kx < 3; ++kx) pkfma_vv(S.gh[kx], S.hh[P], i2[1 + kx]);
   }
-  // ---- x1 row j: the four branch outputs y_b (column-major: consecutive FMAs go to DIFFERENT row accumulators; the first
-  //      contribution to a row is a plain product: no zeroed accumulators)
+}
+// dx1: f row q = j - 3 feeds dx rows q - 2 .. q + 2 = j - 5 .. j - 1 (slots P .. P + 4; row j - 1 starts here, row j - 5 completes)
+template <int P>
+__device__ __forceinline__ void sw_step_dx(SwState& S, const W2& bw, const SwF& F) {
+  constexpr int Q = (P + 2) % 5;
+#pragma unroll
+  for (int kx = 0; kx < 5; ++kx) {
+    if (kx == 0) pkmul(S.dxa[(P + 4) % 5], F.sh[0], LMN_W5(20));
+    else pkfma(S.dxa[(P + 4) % 5], F.sh[kx], LMN_W5(20 + kx));
+#pragma unroll
+    for (int ky = 0; ky < 4; ++ky) pkfma(S.dxa[(P + ky) % 5], F.sh[kx], LMN_W5(ky * 5 + kx));
+  }
+#pragma unroll
+  for (int kx = 0; kx < 3; ++kx) {
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) pkfma(S.dxa[(P + ky + 1) % 5], F.s3[kx], LMN_W3(ky * 3 + kx));
+  }
+  // 3x1 and 1x3: interleaved so that no statement reads the accumulator its predecessor wrote
+  pkfma(S.dxa[(P + 2) % 5], F.fv, LMN_WV(1));
+  pkfma(S.dxa[(P + 1) % 5], F.fv, LMN_WV(0));
+  pkfma(S.dxa[Q], F.hr, LMN_WH(0));
+  pkfma(S.dxa[(P + 3) % 5], F.fv, LMN_WV(2));
+  pkfma(S.dxa[Q], F.fh, LMN_WH(1));
+  LMN_NOP0();   // (the one chain of the step: two consecutive statements into the same accumulator)
+  pkfma(S.dxa[Q], F.hl, LMN_WH(2));
+}
+// x1 row j: the four branch outputs y_b (column-major: consecutive FMAs go to DIFFERENT row accumulators; the first contribution to
+// a row is a plain product: no zeroed accumulators)
+template <int P>
+__device__ __forceinline__ void sw_step_y(SwState& S, const W2& bw, const f32x2 (&in)[5]) {
 #pragma unroll
   for (int d = 0; d < 5; ++d) {
     if (d == 0) pkmul(S.a5[(P + 2) % 5], in[0], LMN_W5(0));
@@ -813,57 +897,6 @@ __device__ __forceinline__ void sw_step(SwState& S, const W2& bw, const f32x2 (&
 #pragma unroll
       for (int ky = 1; ky < 3; ++ky) pkfma(S.av[(P - ky + 6) % 5], in[2], LMN_WV(ky));
     }
-  }
-  // ---- row q = j-2 is complete: f_b = (cC a + cA dp + cD) m;  co[k] = {cA_k, cC_k} (k < 4), co[4] = {cD_0, cD_1}, co[5] = {cD_2, cD_3}
-  constexpr int Q = (P + 3) % 5;
-  const V m = mf * cm;     // f_b = 0 in columns outside the image and in rows outside it (per half)
-  V f5, f3, fv, fh;
-  pkmul(f5, dp, co[0], 0); pkmul(f3, dp, co[1], 0); pkmul(fv, dp, co[2], 0); pkmul(fh, dp, co[3], 0);
-  pkfma(f5, S.a5[Q], co[0], 1); pkfma(f3, S.a3[Q], co[1], 1); pkfma(fv, S.av[Q], co[2], 1); pkfma(fh, S.ah[Q], co[3], 1);
-  {
-    V d0, d1, d2, d3;   // (m * cD_k)
-    pkmul(d0, m, co[4], 0); pkmul(d1, m, co[4], 1); pkmul(d2, m, co[5], 0); pkmul(d3, m, co[5], 1);
-    f5 = f5 * m + d0; f3 = f3 * m + d1; fv = fv * m + d2; fh = fh * m + d3;
-  }
-  S.h5[Q] = f5 * mo; S.h3[Q] = f3 * mo; S.hv[Q] = fv * mo; S.hh[Q] = fh * mo;
-  // ---- dx1: f row q feeds dx rows q-2..q+2; column neighbours by DPP.  sh[k][l] = f[l + 2 - k]
-  if constexpr (PART != 2) {
-    V sh[5];
-    sh[2] = f5;
-    sh[1] = lane_from_right(f5);
-    sh[0] = lane_from_right(sh[1]);
-    sh[3] = lane_from_left(f5);
-    sh[4] = lane_from_left(sh[3]);
-    V s3[3];
-    s3[1] = f3;
-    s3[0] = lane_from_right(f3);
-    s3[2] = lane_from_left(f3);
-    const V hr = lane_from_right(fh), hl = lane_from_left(fh);
-#pragma unroll
-    for (int kx = 0; kx < 5; ++kx) {
-      if (kx == 0) pkmul(S.dxa[P], sh[0], LMN_W5(20));
-      else pkfma(S.dxa[P], sh[kx], LMN_W5(20 + kx));
-#pragma unroll
-      for (int ky = 0; ky < 4; ++ky) pkfma(S.dxa[(P + ky + 1) % 5], sh[kx], LMN_W5(ky * 5 + kx));
-    }
-#pragma unroll
-    for (int kx = 0; kx < 3; ++kx) {
-#pragma unroll
-      for (int ky = 0; ky < 3; ++ky) pkfma(S.dxa[(P + ky + 2) % 5], s3[kx], LMN_W3(ky * 3 + kx));
-    }
-    // 3x1 and 1x3: interleaved so that no statement reads the accumulator its predecessor wrote
-    pkfma(S.dxa[(P + 3) % 5], fv, LMN_WV(1));
-    pkfma(S.dxa[(P + 2) % 5], fv, LMN_WV(0));
-    pkfma(S.dxa[Q], hr, LMN_WH(0));
-    pkfma(S.dxa[(P + 4) % 5], fv, LMN_WV(2));
-    pkfma(S.dxa[Q], fh, LMN_WH(1));
-    LMN_NOP0();   // (the one chain of the step: two consecutive statements into the same accumulator)
-    pkfma(S.dxa[Q], hl, LMN_WH(2));
-  }
-  if (PART != 1) {   // f row j-2 (this step's) against x1 row j-4: kernel row 0 of the 5x5 gradient
-    if (PART == 2) LMN_NOP0();   // (h5[Q] is a packed result of the lines above; with the dx1 block in between it is long done)
-#pragma unroll
-    for (int kx = 0; kx < 5; ++kx) pkfma_vv(S.g5[kx], S.h5[Q], i2[kx]);
   }
 }
 
@@ -916,9 +949,8 @@ __global__ __launch_bounds__(256, WPS) void dw_bwd_kernel(
   for (int k = 0; k < 5; ++k) bw.w3[k] = V{wl(w3, 9, 2 * k), wl(w3, 9, 2 * k + 1)};
 #pragma unroll
   for (int k = 0; k < 2; ++k) { bw.wv[k] = V{wl(wvv, 3, 2 * k), wl(wvv, 3, 2 * k + 1)}; bw.wh[k] = V{wl(whh, 3, 2 * k), wl(whh, 3, 2 * k + 1)}; }
-  V co[6];
+  float a4[4], c4[4], d4[4];   // BatchNorm-backward coefficients of f_b = cA dpre + cC y_b + cD (per channel: wave-uniform)
   {
-    float a4[4], c4[4], d4[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       if (CF.bstats) {  // block-uniform: coefficients formed here (lmn_dw_bwd_coef arithmetic)
@@ -937,12 +969,6 @@ __global__ __launch_bounds__(256, WPS) void dw_bwd_kernel(
         a4[k] = cA[k * E + ch]; c4[k] = cC[k * E + ch]; d4[k] = cD[k * E + ch];
       }
     }
-    // (provably wave-uniform for the "s" operands of the asm statements)
-    auto uni = [](float v) -> float { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); };
-#pragma unroll
-    for (int k = 0; k < 4; ++k) co[k] = V{uni(a4[k]), uni(c4[k])};
-    co[4] = V{uni(d4[0]), uni(d4[1])};
-    co[5] = V{uni(d4[2]), uni(d4[3])};
   }
   const float pa = ZT ? PRE.A[ch] : 0.f, ps = ZT ? PRE.shift[ch] : 0.f;
   const int cx = xs - (HALO ? 2 : 4) + lane;
@@ -958,14 +984,33 @@ __global__ __launch_bounds__(256, WPS) void dw_bwd_kernel(
   const unsigned vhalo = hcol_in ? (unsigned)(hx * 4 + (ch & 3)) * (unsigned)ES : OOB;
   const unsigned vst = ovalid ? voff : OOB;
   const BufRsrc rz = make_rsrc(x1, NREC), rd = make_rsrc(dpre, NREC), ro = make_rsrc(dx1, NREC);
-  const int nsteps = rowsA + 10;   // rowsA >= rowsB
+  // per-lane coefficient pairs with the column mask folded in (f_b = 0 in columns outside the image): VGPR operands of the two
+  // packed FMAs that form f_b (sw_step), instead of 12 SGPRs + mask multiplies
+  SwCoef CFv;
+  {
+    // (provably wave-uniform for the "s" operands of the asm statements)
+    auto uni = [](float v) -> float { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); };
+    CFv.sA[0] = V{uni(a4[0]), uni(a4[1])}; CFv.sA[1] = V{uni(a4[2]), uni(a4[3])};
+    CFv.vC[0] = V{c4[0] * cm, c4[1] * cm}; CFv.vC[1] = V{c4[2] * cm, c4[3] * cm};
+    CFv.vD[0] = V{d4[0] * cm, d4[1] * cm}; CFv.vD[1] = V{d4[2] * cm, d4[3] * cm};
+    asm volatile("" : "+v"(CFv.vC[0]), "+v"(CFv.vC[1]), "+v"(CFv.vD[0]), "+v"(CFv.vD[1]));
+  }
+  // Hardswish(A z + shift) with the column mask folded into A / shift ({A', shift'} of the lane in one VGPR pair): x1 = 0 in columns
+  // outside the image without a multiply
+  V pas = V{pa * cm, ps * cm}, pash = V{pa * hm, ps * hm};
+  asm volatile("" : "+v"(pas), "+v"(pash));
+  // (without the transform the loaded tensor IS x1, and lanes outside the image load 0 through the out-of-range voffset)
+  // column neighbours of f through ds_bpermute_b32 (byte address = 4 * source lane + instruction offset, modulo the wave; the
+  // wrap-around lanes are halo lanes whose dx is never stored)
+  const int bp0 = ((lane - 2) & 63) * 4;
+  const int nsteps = rowsA + 9;   // rowsA >= rowsB; the last dx row (ys + rows - 1) completes at step rows + 8
   V pfz[5], pfh[5], pfd[5];
   auto ldz = [&](int j, V& zz, V& zh_) {
     const unsigned a = soA(ysA - 4 + j), bb = soB(ysB - 4 + j);
     zz = V{ld_one<TA>(rz, voff, a), ld_one<TA>(rz, voff, bb)};
     if (HALO) zh_ = V{ld_one<TA>(rz, vhalo, a), ld_one<TA>(rz, vhalo, bb)};
   };
-  auto ldd = [&](int j, V& dd) { dd = V{ld_one<TA>(rd, voff, soA(ysA - 6 + j)), ld_one<TA>(rd, voff, soB(ysB - 6 + j))}; };
+  auto ldd = [&](int j, V& dd) { dd = V{ld_one<TA>(rd, voff, soA(ysA - 7 + j)), ld_one<TA>(rd, voff, soB(ysB - 7 + j))}; };
   // f rows of half h live at image rows [fl_h, H): inside the image and not above the first row the segment needs (ys - 2)
   const int flA = max(ysA - 2, 0), flB = max(ysB - 2, 0);
 #pragma unroll
@@ -983,41 +1028,71 @@ __global__ __launch_bounds__(256, WPS) void dw_bwd_kernel(
 #pragma unroll
   for (int k = 0; k < 3; ++k) S.gv[k] = S.gh[k] = z2;
   V hs0 = z2, hs1 = z2;
-  auto msk = [&](bool a, bool bq) -> V { return V{a ? 1.f : 0.f, bq ? 1.f : 0.f}; };
+  // interior steps: every row the step touches lies inside the image AND inside the wave's own segments, for both halves -- x1 row
+  // ys-4+j, f row ys-7+j, dx row ys-9+j: j in [9, jhi).  They skip the row-mask blocks by ONE scalar compare (msk_on); the conditions
+  // of the boundary steps are evaluated inside those blocks only (their scalars stay out of the interior path).
+  int jhi = rowsB + 7;
+  if (H + 4 - ysA < jhi) jhi = H + 4 - ysA;
+  if (H + 4 - ysB < jhi) jhi = H + 4 - ysB;
+  if (rowsB <= 0) jhi = 0;
+  const unsigned jn = jhi > 9 ? (unsigned)(jhi - 9) : 0u;
+  auto mskf = [](bool a) -> float { return a ? 1.f : 0.f; };
 #define LMN_STEP(P)                                                                                                \
   {                                                                                                                \
     const int j = j0 + P;                                                                                          \
     const V zv = pfz[P];                                                                                           \
-    const V rm = msk((unsigned)(ysA - 4 + j) < (unsigned)H, (unsigned)(ysB - 4 + j) < (unsigned)HB);               \
-    V x1v = (ZT ? hswish2(zv, V{pa, pa}, V{ps, ps}) : zv) * (rm * cm);                                             \
-    V x1h = z2;                                                                                                    \
-    if (HALO) x1h = (ZT ? hswish2(pfh[P], V{pa, pa}, V{ps, ps}) : pfh[P]) * (rm * hm);                             \
+    const V zh = pfh[P];                                                                                           \
+    const bool msk_on = !((unsigned)(j - 9) < jn);                                                                 \
+    /* f row ys-7+j inside the wave's own segment; dx row ys-9+j inside it (per half; wave-uniform) */             \
+    const bool oA = (unsigned)(j - 7) < (unsigned)rowsA, oB = (unsigned)(j - 7) < (unsigned)rowsB;                 \
+    const bool okA = (unsigned)(j - 9) < (unsigned)rowsA, okB = (unsigned)(j - 9) < (unsigned)rowsB;               \
+    V mf = z2;                                                                                                     \
+    if (msk_on) {   /* f row inside the image and not above the first row the segment needs */                     \
+      const int fyA = ysA - 7 + j, fyB = ysB - 7 + j;                                                              \
+      mf = V{mskf((unsigned)(fyA - flA) < (unsigned)(H - flA)), mskf((unsigned)(fyB - flB) < (unsigned)(HB - flB) && rowsB > 0)}; \
+    }                                                                                                              \
     const V dp = pfd[P];                                                                                           \
     ldz(j + D, pfz[(P + D) % 5], pfh[(P + D) % 5]);                                                                \
     ldd(j + D2, pfd[(P + D2) % 5]);                                                                                \
+    /* ring slot P still holds x1 row j-5 (and z row j-5): they are read here, the new row is written further down (the LDS      */ \
+    /* operations of a wave execute in order; the fences only keep the compiler from reordering them)                            */ \
+    V i2[5];                                                                                                       \
+    V zr = z2;                                                                                                     \
+    LMN_WAVE_SYNC();                                                                                               \
+    if (PART != 1) { _Pragma("unroll") for (int d = 0; d < 5; ++d) i2[d] = XS[P * 68 + lane + d]; }                \
+    if (ZT && PART != 2) zr = ZS[P * 64 + lane];                                                                   \
+    SwF F;                                                                                                         \
+    sw_step_f<P, PART>(S, CFv, F, i2, dp, mf, V{mskf(oA), mskf(oB)}, msk_on, bp0);                                 \
+    if (PART != 2) sw_step_dx<P>(S, bw, F);                                                                        \
+    V x1v = ZT ? hswish2_as(zv, pas) : zv;                                                                         \
+    V x1h = z2;                                                                                                    \
+    if (HALO) x1h = ZT ? hswish2_as(zh, pash) : zh;                                                                \
+    if (msk_on) {   /* x1 row ys-4+j inside the image */                                                           \
+      const V rm = V{mskf((unsigned)(ysA - 4 + j) < (unsigned)H), mskf((unsigned)(ysB - 4 + j) < (unsigned)HB)};   \
+      pkmul_s2(x1v, x1v, rm);                                                                                      \
+      if (HALO) pkmul_s2(x1h, x1h, rm);                                                                            \
+      LMN_NOP0();                                                                                                  \
+    }                                                                                                              \
     LMN_WAVE_SYNC();                                                                                               \
     XS[P * 68 + lane + 2] = x1v;                                                                                   \
     if (HALO) { if (lane < 4) XS[P * 68 + hidx] = x1h; }                                                           \
     if (ZT && PART != 2) ZS[P * 64 + lane] = zv;                                                                   \
     LMN_WAVE_SYNC();                                                                                               \
-    const int fyA = ysA - 6 + j, fyB = ysB - 6 + j;                                                                \
-    const V mf = msk((unsigned)(fyA - flA) < (unsigned)(H - flA), (unsigned)(fyB - flB) < (unsigned)(HB - flB) && rowsB > 0); \
-    const V mo = msk((unsigned)(fyA - ysA) < (unsigned)rowsA, (unsigned)(fyB - ysB) < (unsigned)rowsB);            \
-    sw_step<P, PART>(S, bw, co, cm, XS, lane, x1v, dp, mf, mo);                                                    \
-    if (PART != 2) {   /* dx row j-4 is complete */                                                                \
-      constexpr int DD = (P + 1) % 5;                                                                              \
-      const bool okA = (unsigned)(j - 8) < (unsigned)rowsA, okB = (unsigned)(j - 8) < (unsigned)rowsB;             \
-      V dv = S.dxa[DD];                                                                                            \
+    V in[5];                                                                                                       \
+    { const V* xr = XS + P * 68 + lane; in[0] = xr[0]; in[1] = xr[1]; in[2] = x1v; in[3] = xr[3]; in[4] = xr[4]; } \
+    if (PART != 2) {   /* dx row j-5 (image row ys-9+j) is complete; its drain covers the exchange of the x1 row */ \
+      V dv = S.dxa[P];                                                                                             \
       if (ZT) {   /* dh = dx1 * Hardswish'(A z + shift); sum dh, sum dh * z over the rows of the two segments */   \
-        const V zr = ZS[DD * 64 + lane];                                                                           \
         const V hh = zr * pa + ps;                                                                                 \
-        dv = dv * V{lmn_dhswish(hh.x), lmn_dhswish(hh.y)} * msk(okA, okB);                                         \
+        dv = dv * V{lmn_dhswish(hh.x), lmn_dhswish(hh.y)};                                                         \
+        if (msk_on) { pkmul_s2(dv, dv, V{mskf(okA), mskf(okB)}); LMN_NOP0(); }                                     \
         hs0 += dv;                                                                                                 \
         hs1 += dv * zr;                                                                                            \
       }                                                                                                            \
-      if (okA) st_one<TA>(ro, vst, (unsigned)(r0 + ysA - 8 + j) * rowb + qoff, dv.x);                              \
-      if (okB) st_one<TA>(ro, vst, (unsigned)(r0 + ysB - 8 + j) * rowb + qoff, dv.y);                              \
+      if (okA) st_one<TA>(ro, vst, (unsigned)(r0 + ysA - 9 + j) * rowb + qoff, dv.x);                              \
+      if (okB) st_one<TA>(ro, vst, (unsigned)(r0 + ysB - 9 + j) * rowb + qoff, dv.y);                              \
     }                                                                                                              \
+    sw_step_y<P>(S, bw, in);                                                                                       \
     LMN_SB();                                                                                                      \
   }
   for (int j0 = 0; j0 < nsteps; j0 += 5) { LMN_STEP(0) LMN_STEP(1) LMN_STEP(2) LMN_STEP(3) LMN_STEP(4) }
@@ -1383,7 +1458,7 @@ static int dw_bwd_launch(const void* x1, const void* dpre, void* dx1, int B, int
   const int strips = halo ? lmn_cdiv(W, 60) : lmn_cdiv(W, 56), chunks = E / 4;
   const int wps = part == 1 ? 4 : 2;
   int seg_rows;
-  const int segs = dw_segments((int64_t)B * strips * chunks * 4, H, 10, wps, 2, part == 1 ? 3.0 : 2.0, &seg_rows);   // even: a wave walks the pair (sa, sa + segs/2)
+  const int segs = dw_segments((int64_t)B * strips * chunks * 4, H, 9, wps, 2, part == 1 ? 3.0 : 2.0, &seg_rows);   // even: a wave walks the pair (sa, sa + segs/2)
   const int hs = segs / 2;
   const int64_t nblk = (int64_t)B * strips * chunks * hs;
   LMN_REQUIRE(nblk < (1LL << 31), "%s: grid too large", what);

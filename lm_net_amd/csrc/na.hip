@@ -699,6 +699,9 @@ __global__ __launch_bounds__(256) void na_bwd_kv_tile_kernel(const TA* __restric
 __device__ __forceinline__ uint32_t na_magic16(uint32_t d) { return (65535u + d) / d; }
 __device__ __forceinline__ int na_div16(int n, uint32_t m) { return (int)(((uint32_t)n * m) >> 16); }
 
+#ifdef LMN_NA_DBG
+__device__ unsigned g_na_dbg[8];   // debug build: {dO re-read differs, v window != memory, dp re-evaluation differs, dsum rebuild differs, k window != memory, -, -, items}
+#endif
 template <int HD, int C4, typename TA>
 __global__ __launch_bounds__(512) void na_bwd_fused_kernel(const TA* __restrict__ qkv, const float* __restrict__ rpb,
                                                            const TA* __restrict__ dout, TA* __restrict__ dqkv,
@@ -813,6 +816,42 @@ __global__ __launch_bounds__(512) void na_bwd_fused_kernel(const TA* __restrict_
         p[n] = p[n] * rden;
         dsum += p[n] * dp[n];
       }
+#ifdef LMN_NA_DBG
+      {   // debug build (tools/gpu_x2_canary.py): read dO and the v window AGAIN and rebuild dsum -- which operand moved?
+        asm volatile("" ::: "memory");
+        const f32x4 dO2 = ld4(dout + pix * C + c);
+        f32x4 dsum2 = f32x4{0.f, 0.f, 0.f, 0.f};
+        unsigned bad_v = 0, bad_k = 0;
+#pragma unroll
+        for (int ki = 0; ki < 3; ++ki)
+#pragma unroll
+          for (int kj = 0; kj < 3; ++kj) {
+            const float* kvn = kv0 + ((ki * KW + kj) * 2) * C;
+            const f32x4 vv2 = *reinterpret_cast<const f32x4*>(kvn + C);
+            const f32x4 dp2 = head_sum<HD>(dO * vv2);
+            const int gy = sy + ki, gx = sx + kj;
+            const f32x4 vg = ld4(base + (gy * g.W + gx) * 3 * C + 2 * C + c), kg = ld4(base + (gy * g.W + gx) * 3 * C + C + c);
+            const f32x4 kk2 = *reinterpret_cast<const f32x4*>(kvn);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+              bad_v += __float_as_uint(vv2[k]) != __float_as_uint(vg[k]);   // LDS window vs global memory
+              bad_k += __float_as_uint(kk2[k]) != __float_as_uint(kg[k]);
+              if (__float_as_uint(dp2[k]) != __float_as_uint(dp[ki * 3 + kj][k]) && ok) atomicAdd(&g_na_dbg[2], 1u);   // same inputs, second evaluation differs
+            }
+            dsum2 += p[ki * 3 + kj] * dp2;
+          }
+        if (ok) {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            if (__float_as_uint(dO2[k]) != __float_as_uint(dO[k])) atomicAdd(&g_na_dbg[0], 1u);     // dO changed between two reads
+            if (__float_as_uint(dsum2[k]) != __float_as_uint(dsum[k])) atomicAdd(&g_na_dbg[3], 1u); // rebuilt dsum differs
+          }
+          if (bad_v) atomicAdd(&g_na_dbg[1], bad_v);
+          if (bad_k) atomicAdd(&g_na_dbg[4], bad_k);
+          atomicAdd(&g_na_dbg[7], 1u);
+        }
+      }
+#endif
       stat_store<HD>(ST + pls * SH2, c, lse, ok);
       stat_store<HD>(ST + pls * SH2 + g.heads, c, dsum, ok);
       if (own) {   // (block-divergent only at tile edges; head_sum has no shuffles at hd <= 2)
@@ -1157,6 +1196,12 @@ __global__ __launch_bounds__(256) void na_bwd_kv_gen_kernel(const TA* __restrict
 
 }  // namespace
 
+#ifdef LMN_NA_DBG
+extern "C" int lmn_na_dbg(unsigned* out, int reset) {
+  if (reset) { unsigned z[8] = {0, 0, 0, 0, 0, 0, 0, 0}; return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_na_dbg), z, sizeof(z)); }
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_na_dbg), sizeof(unsigned) * 8);
+}
+#endif
 extern "C" {
 
 int lmn_na_fwd(const void* qkv, const float* rpb, void* out, int B, int H, int W, int heads, int hd, int K, float scale,

@@ -437,14 +437,9 @@ __global__ __launch_bounds__(256) void se_bwd_params_kernel(const float* __restr
 }
 
 // ------------------------------------------------------------------------------------ bilinear x2, align_corners=True
-// index arithmetic mirrors ATen's upsample_bilinear2d (fp32): src = dst * (in-1)/(out-1)
-__device__ __forceinline__ void up_coord(int dst, int in, float scale, int& i0, int& ip, float& l0, float& l1) {
-  const float r = scale * (float)dst;
-  i0 = (int)r;
-  ip = (i0 < in - 1) ? 1 : 0;
-  l1 = r - (float)i0;
-  l0 = 1.f - l1;
-}
+// index arithmetic mirrors ATen's upsample_bilinear2d (fp32): src = dst * (in-1)/(out-1)  (lmn_up_coord, common.h: shared with the conv
+// family's LMN_SRC_UP2 staging)
+#define up_coord lmn_up_coord
 
 // One block row (blockIdx.y, grid-strided) = one OUTPUT row of one image, so the vertical coordinate arithmetic is block-uniform;
 // blockIdx.x covers the (column, channel quad) items of that row, decoded with a magic multiplier.  (The flat-index form spent three

@@ -190,6 +190,12 @@ class Engine:
         # z-path: expand-conv weight gradient from the raw gradient and the moments of x (lmn_reparam_wfin) instead of a pass that
         # materialises dz (LMN_ZPATH_M=0: lmn_affine2 + plain weight gradient, A/B runs)
         self.zpath_m = os.environ.get("LMN_ZPATH_M", "1") != "0"
+        # LayerNorm fused into the consuming Linear (hip.SRC_LN: norm1 -> qkv, norm2 -> fc1 of the transformer blocks; LMN_FUSE_LN=0: the
+        # lmn_ln_fwd launches and the n1 / n2 tensors of rounds 1-4, A/B runs)
+        self.fuse_ln = os.environ.get("LMN_FUSE_LN", "1") != "0"
+        # bilinear x2 sampled where the 3x3 conv stages its window (hip.SRC_UP2: up1..4 and the `convs` branch of the skip fusers; the
+        # backward recomputes `up` for the weight gradient on the weight-gradient stream; LMN_FUSE_UP=0: lmn_up2_fwd in the forward)
+        self.fuse_up = os.environ.get("LMN_FUSE_UP", "1") != "0"
 
     def pm(self):
         """precision mode of the pass: 0 fp32, 1 bf16 MFMA operands on fp32 storage, 2 bf16 storage + bf16 operands."""
@@ -273,9 +279,11 @@ class Engine:
         hip.conv_fwd([dy], wpt, out, B=B, Hin=Ho, Win=Wo, Hout=Hin, Wout=Win, Cout=rows, ksize=k, stride=s,
                      transposed=1, **kw)
 
-    def wgrad(self, srcs, dy, w_param, b_param, *, Hin, Win, k=1, s=1, dW=None, db=None, join=True, after=None, deferred=False, keep=(), **kw):
+    def wgrad(self, srcs, dy, w_param, b_param, *, Hin, Win, k=1, s=1, dW=None, db=None, join=True, after=None, deferred=False, keep=(), pre=None, **kw):
         """join=False: an explicit dW is NOT read on the issuing stream right away (no join; the K-split reduction stays deferred
-        when after is given).  after: callable run on the gradient's stream right after the batched reduction that completes it."""
+        when after is given).  after: callable run on the gradient's stream right after the batched reduction that completes it.
+        pre: callable run on the gradient's stream right before the launch (recomputes an operand the forward did not keep: the
+        bilinear x2 `up` tensor of a LMN_SRC_UP2 conv); the tensors it touches go into `keep`."""
         d = dy.t if isinstance(dy, V) else dy
         if self.lazy_on and not (dW is not None and join):
             # late scheduling (LM_Net._backward_body): the weight gradients of the skip / neighborhood-attention chains have no
@@ -287,7 +295,7 @@ class Engine:
             if db is None and b_param is not None:
                 db = G_[b_param]
             self.lazy_q.append(lambda: self.wgrad(srcs, dy, None, None, Hin=Hin, Win=Win, k=k, s=s, dW=dW, db=db, join=False,
-                                                  after=after, deferred=True, keep=keep, **kw))
+                                                  after=after, deferred=True, keep=keep, pre=pre, **kw))
             return
         B = d.shape[0]
         Ho = (Hin + 2 * (k // 2) - k) // s + 1
@@ -301,6 +309,8 @@ class Engine:
         # reads the result right away
         defer = self.defer_reduce and not explicit and not self.capturing and (join or deferred or after is not None)   # (a capture cannot upload the job table)
         if not self.overlap_wgrad or self.capturing:
+            if pre is not None:
+                pre()
             hip.conv_wgrad(srcs, dy, dW, db, B=B, Hin=Hin, Win=Win, Hout=Ho, Wout=Wo, Cout=cout, ksize=k, stride=s, defer=defer, **kw)
             if after is not None:
                 if defer:
@@ -319,6 +329,8 @@ class Engine:
         saved = hip._STREAM[0]
         hip._STREAM[0] = hip.C.c_void_p(side.cuda_stream)
         try:
+            if pre is not None:
+                pre()
             ws = hip.conv_wgrad(srcs, dy, dW, db, B=B, Hin=Hin, Win=Win, Hout=Ho, Wout=Wo, Cout=cout, ksize=k, stride=s, defer=defer, **kw)
         finally:
             hip._STREAM[0] = saved
@@ -345,6 +357,8 @@ class Engine:
                 self._t(src).record_stream(side)
                 if isinstance(src, dict) and src.get("scale") is not None:
                     src["scale"].record_stream(side)
+                if isinstance(src, dict) and src.get("ln") is not None and src["ln"][3] is not None:
+                    src["ln"][3].record_stream(side)      # the (mean, rstd) table of a LayerNorm-on-load source
         if explicit:
             self.join_side(d.device)
 
@@ -741,6 +755,23 @@ class Engine:
         H, W = x_t.shape[1:3]
         self.conv([x], conv.weight, conv.bias, out, Hin=H, Win=W, k=3, s=s, **kw)
 
+    def conv3_up_fwd(self, conv, x, out, **kw):
+        """out = conv3x3(bilinear_x2(x)) with the upsampling sampled where the conv stages its window (hip.SRC_UP2): `up` is never
+        written (/root/reference/core/LM_Net.py:58-74, core/modules.py:94,129)."""
+        h, w = x.shape[1:3]
+        self.conv([dict(view=x, flags=hip.SRC_UP2)], conv.weight, conv.bias, out, Hin=2 * h, Win=2 * w, k=3, **kw)
+
+    def conv3_up_bwd(self, conv, x, dy, dx_small, tmp_ok=True):
+        """Backward of conv3_up_fwd.  Weight gradient: `up` is recomputed on the weight-gradient stream right before the launch
+        (off the compute chain; the forward kept nothing), then the plain 3x3 weight gradient.  Data gradient: dup = conv^T(dy),
+        dx = bilinear_x2^T(dup) into dx_small (written, not accumulated)."""
+        B, h, w, C = x.shape
+        up = _A(x, B, 2 * h, 2 * w, C)
+        self.wgrad([up], dy, conv.weight, conv.bias, Hin=2 * h, Win=2 * w, k=3, pre=lambda: hip.up2_fwd(x, up), keep=(x, up))
+        dup = _A(x, B, 2 * h, 2 * w, C)
+        self.conv_T(dy, conv.weight, dup, Hin=2 * h, Win=2 * w, k=3)
+        hip.up2_bwd(dup, dx_small)
+
     def conv3_bwd(self, conv, x, dy, s=1, dx=None, accumulate=False):
         """weight/bias grads; if dx is given: dx (+)= data gradient."""
         x_t = x.t if isinstance(x, V) else x
@@ -773,6 +804,8 @@ class Engine:
             self.conv3_fwd(m.convm[0], xm, V(cat, C, C))
         if bottom:
             self.conv3_fwd(m.convs[0], xsm, V(cat, C, C))
+        elif self.fuse_up:
+            self.conv3_up_fwd(m.convs[1], xsm, V(cat, (nb - 1) * C, C))
         else:
             up = _A(xl, B, H, W, xsm.shape[-1])
             hip.up2_fwd(xsm, up)
@@ -817,6 +850,15 @@ class Engine:
         xsm = xs_in[-1]
         if bottom:
             self._acc_conv(m.convs[0], xsm, V(dcat, C, C), 1, gacc)
+        elif up is None:      # (fuse_up: the forward sampled the upsampling on load and kept no `up`)
+            slot = gacc[id(xsm)]
+            first = slot.g is None
+            tgt = _A(z, *xsm.shape)
+            self.conv3_up_bwd(m.convs[1], xsm, V(dcat, (nb - 1) * C, C), tgt)
+            if first:
+                slot.g = tgt
+            else:
+                hip.add(slot.g, tgt)
         else:
             dup = _A(z, *up.shape)
             self.conv3_bwd(m.convs[1], up, V(dcat, (nb - 1) * C, C), dx=dup)
@@ -837,47 +879,57 @@ class Engine:
         self.conv3_bwd(conv, x, dy, s=s, dx=slot.g, accumulate=not first)
 
     # ------------------------------------------------------------------ transformer pieces (A6, A7, A8)
+    @staticmethod
+    def _ln_src(x, norm, stats):
+        """Source descriptor `LayerNorm(x)` (hip.SRC_LN): the conv / weight gradient normalises x where it stages it -- the
+        normalised tensor never exists in HBM.  stats: [pixels, 2] table of (mean, rstd), written by the forward conv, read by the
+        weight gradient."""
+        Cn = x.shape[-1]
+        return dict(view=x.view(1, 1, -1, Cn), ln=(norm.weight, norm.bias, norm.eps, stats))
+
     def _mlp_fwd(self, mlp, n2, a_res, y, tagbase):
-        """y = drop(fc2(drop(gelu(fc1(n2))))) + a_res ; returns a1 (pre-GELU), seeds."""
-        rows_shape = n2.shape[:-1]
+        """y = drop(fc2(drop(gelu(fc1(n2))))) + a_res ; returns a1 (pre-GELU), seeds.  n2: tensor, or an _ln_src descriptor (norm2 fused
+        into fc1)."""
         Cn, Ch = mlp.fc1.weight.shape[1], mlp.fc1.weight.shape[0]
-        n2f, yf, af = n2.view(1, 1, -1, Cn), y.view(1, 1, -1, Cn), a_res.view(1, 1, -1, Cn)
-        npx = n2f.shape[2]
-        a1 = _A(n2, 1, 1, npx, Ch)
+        n2f = n2 if isinstance(n2, dict) else n2.view(1, 1, -1, Cn)
+        yf, af = y.view(1, 1, -1, Cn), a_res.view(1, 1, -1, Cn)
+        npx = yf.shape[2]
+        a1 = _A(y, 1, 1, npx, Ch)
         p = mlp.dropout.p if self.training else 0.0
         s1, s2 = self._seed(tagbase), self._seed(tagbase + 1)
         self.conv([n2f], mlp.fc1.weight, mlp.fc1.bias, a1, Hin=1, Win=npx)
         src = dict(view=a1, flags=hip.SRC_GELU | (hip.SRC_DROP if p > 0 else 0), drop_seed=s1, drop_p=p)
         self.conv([src], mlp.fc2.weight, mlp.fc2.bias, yf, Hin=1, Win=npx, residual=af, drop_p=p, drop_seed=s2)
-        del rows_shape
         return a1, (p, s1, s2)
 
     def _mlp_bwd(self, mlp, n2, a1, dy, drop):
         """returns dn2; accumulates fc1/fc2 grads.  dy is the gradient of the block output."""
         p, s1, s2 = drop
         Cn, Ch = mlp.fc1.weight.shape[1], mlp.fc1.weight.shape[0]
-        n2f, dyf = n2.view(1, 1, -1, Cn), dy.view(1, 1, -1, Cn)
-        npx = n2f.shape[2]
+        n2f, dyf = (n2 if isinstance(n2, dict) else n2.view(1, 1, -1, Cn)), dy.view(1, 1, -1, Cn)     # (n2: tensor or _ln_src descriptor)
+        npx = dyf.shape[2]
         dflag = hip.SRC_DROP if p > 0 else 0
         hsrc = dict(view=a1, flags=hip.SRC_GELU | dflag, drop_seed=s1, drop_p=p)
         self.wgrad([hsrc], dyf, mlp.fc2.weight, mlp.fc2.bias, Hin=1, Win=npx, dy_flags=dflag, dy_seed=s2, dy_p=p)
-        da1 = _A(n2, 1, 1, npx, Ch)
+        da1 = _A(dy, 1, 1, npx, Ch)
         self.conv_T(dict(view=dyf, flags=dflag, drop_seed=s2, drop_p=p), mlp.fc2.weight, da1, Hin=1, Win=npx,
                     epilogue=hip.EP_DGELU, aux=a1, drop_p=p, drop_seed=s1)
         self.wgrad([n2f], da1, mlp.fc1.weight, mlp.fc1.bias, Hin=1, Win=npx)
-        dn2 = _A(n2, 1, 1, npx, Cn)
+        dn2 = _A(dy, 1, 1, npx, Cn)
         self.conv_T(da1, mlp.fc1.weight, dn2, Hin=1, Win=npx)
-        return dn2.view(n2.shape)
+        return dn2.view(dy.shape)
 
     def _lin(self, lin, x, out, **kw):
-        Cn = x.shape[-1]
-        xf = x.view(1, 1, -1, Cn)
-        self.conv([xf], lin.weight, lin.bias, out.view(1, 1, xf.shape[2], -1), Hin=1, Win=xf.shape[2], **kw)
+        """x: tensor, or an _ln_src descriptor (the LayerNorm in front of the Linear is applied where the conv stages its input)."""
+        Cn = lin.weight.shape[1]
+        xf = x if isinstance(x, dict) else x.view(1, 1, -1, Cn)
+        npx = out.numel() // lin.weight.shape[0]
+        self.conv([xf], lin.weight, lin.bias, out.view(1, 1, npx, -1), Hin=1, Win=npx, **kw)
 
     def _lin_bwd(self, lin, x, dy, dx):
-        Cn, Co = x.shape[-1], dy.shape[-1]
-        xf, dyf = x.view(1, 1, -1, Cn), dy.view(1, 1, -1, Co)
-        npx = xf.shape[2]
+        Cn, Co = lin.weight.shape[1], dy.shape[-1]
+        xf, dyf = (x if isinstance(x, dict) else x.view(1, 1, -1, Cn)), dy.view(1, 1, -1, Co)
+        npx = dyf.shape[2]
         self.wgrad([xf], dyf, lin.weight, lin.bias, Hin=1, Win=npx)
         self.conv_T(dyf, lin.weight, dx.view(1, 1, npx, Cn), Hin=1, Win=npx)
 
@@ -886,16 +938,25 @@ class Engine:
         heads = m.att1.num_heads
         e = _A(x, B, H, W, C)
         self.conv3_fwd(m.patchembedding.patch_embeddings, x, e)
-        n1 = _A(x, B, H, W, C)
-        hip.ln_fwd(e, m.norm1.weight, m.norm1.bias, n1)
+        # norm1 -> qkv and norm2 -> fc1 are ONE row each (SURVEY 8a "LN1+qkv"; core/modules.py:516-518): the LayerNorm is applied
+        # where the Linear stages its input (hip.SRC_LN), n1 / n2 never cross HBM; the (mean, rstd) tables serve the weight gradients
+        if self.fuse_ln:
+            st1, st2 = _E(x, B * H * W, 2), _E(x, B * H * W, 2)
+            n1 = self._ln_src(e, m.norm1, st1)
+        else:
+            n1 = _A(x, B, H, W, C)
+            hip.ln_fwd(e, m.norm1.weight, m.norm1.bias, n1)
         qkv = _A(x, B, H, W, 3 * C)
         self._lin(m.att1.qkv, n1, qkv)
         o = _A(x, B, H, W, C)
         hip.na_fwd(qkv, m.att1.rpb, o, heads)
         a = _A(x, B, H, W, C)
         self._lin(m.att1.proj, o, a, residual=e.view(1, 1, -1, C))
-        n2 = _A(x, B, H, W, C)
-        hip.ln_fwd(a, m.norm2.weight, m.norm2.bias, n2)
+        if self.fuse_ln:
+            n2 = self._ln_src(a, m.norm2, st2)
+        else:
+            n2 = _A(x, B, H, W, C)
+            hip.ln_fwd(a, m.norm2.weight, m.norm2.bias, n2)
         y = _A(x, B, H, W, C)
         a1, drop = self._mlp_fwd(m.mlp, n2, a, y, tag)
         if cx is not None:
@@ -923,7 +984,7 @@ class Engine:
         dx = _A(x, B, H, W, C)
         self.conv3_bwd(m.patchembedding.patch_embeddings, x, de, dx=dx)
         if self.probe is not None:
-            self.probe("nat_bwd", m, dict(dy=dy, dn2=dn2, da=da, dqkv=dqkv, dn1=dn1, de=de, dx=dx, qkv=qkv, o=o, n1=n1))
+            self.probe("nat_bwd", m, dict(dy=dy, dn2=dn2, da=da, dqkv=dqkv, dn1=dn1, de=de, dx=dx, qkv=qkv, o=o, e=e))
         return dx
 
     def gft_fwd(self, m, catp, cx, tag):
@@ -932,8 +993,12 @@ class Engine:
         heads = m.attention.num_heads
         e = _A(catp, B, h, w, C)
         self.conv3_fwd(m.patchembedding.patch_embeddings, catp, e)
-        n1 = _A(catp, B, N, C)
-        hip.ln_fwd(e, m.norm1.weight, m.norm1.bias, n1)
+        if self.fuse_ln:      # (as in nat_fwd: norm1 -> qkv, norm2 -> fc1 fused; core/modules.py:343-344)
+            st1, st2 = _E(catp, B * N, 2), _E(catp, B * N, 2)
+            n1 = self._ln_src(e, m.norm1, st1)
+        else:
+            n1 = _A(catp, B, N, C)
+            hip.ln_fwd(e, m.norm1.weight, m.norm1.bias, n1)
         qkv = _A(catp, B, N, 3 * C)
         self._lin(m.attention.qkv, n1, qkv)
         o = _A(catp, B, N, C)
@@ -941,8 +1006,11 @@ class Engine:
         hip.gattn_fwd(qkv, o, lse, heads)
         a = _A(catp, B, N, C)
         self._lin(m.attention.proj, o, a, residual=e.view(1, 1, -1, C))
-        n2 = _A(catp, B, N, C)
-        hip.ln_fwd(a, m.norm2.weight, m.norm2.bias, n2)
+        if self.fuse_ln:
+            n2 = self._ln_src(a, m.norm2, st2)
+        else:
+            n2 = _A(catp, B, N, C)
+            hip.ln_fwd(a, m.norm2.weight, m.norm2.bias, n2)
         y = _A(catp, B, N, C)
         a1, drop = self._mlp_fwd(m.mlp, n2, a, y, tag)
         cv = m.conv[0]
@@ -982,9 +1050,14 @@ class Engine:
         """conv3x3(bilinear_x2(x)) + skip"""
         B, h, w, C = x.shape
         conv = seq[1]
+        out = _A(x, B, 2 * h, 2 * w, conv.weight.shape[0])
+        if self.fuse_up:
+            self.conv3_up_fwd(conv, x, out, residual=skip)
+            if cx is not None:
+                cx.t[seq] = dict(up=None, x=x)
+            return out
         up = _A(x, B, 2 * h, 2 * w, C)
         hip.up2_fwd(x, up)
-        out = _A(x, B, 2 * h, 2 * w, conv.weight.shape[0])
         self.conv3_fwd(conv, up, out, residual=skip)
         if cx is not None:
             cx.t[seq] = dict(up=up)
@@ -992,6 +1065,10 @@ class Engine:
 
     def up_bwd(self, seq, dt, cx, xshape):
         up = cx.t[seq]["up"]
+        if up is None:
+            dx = _A(dt, *xshape)
+            self.conv3_up_bwd(seq[1], cx.t[seq]["x"], dt, dx)
+            return dx
         dup = _A(dt, *up.shape)
         self.conv3_bwd(seq[1], up, dt, dx=dup)
         dx = _A(dt, *xshape)

@@ -13,18 +13,19 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("LMNET_HIP_LIB") or os.path.join(_HERE, "liblmnet_hip.so")   # (override: A/B runs against another build)
 
 # ---- constants mirrored from include/lmnet_hip.h
-SRC_GELU, SRC_DROP = 1, 2
+SRC_GELU, SRC_DROP, SRC_LN, SRC_UP2 = 1, 2, 4, 8
 EP_LINEAR, EP_AFFINE_ACT, EP_DGELU, EP_BN_BWD1, EP_BN_BWD2, EP_SE_BWD = 0, 1, 2, 3, 4, 5
 ACT_NONE, ACT_HSWISH, ACT_GELU = 0, 1, 2
 STATS_NONE, STATS_SUM_SQ, STATS_EP = 0, 1, 2
 F32, BF16 = 0, 1            # matrix-core operand type of the dense contractions (LMN_F32 / LMN_BF16)
 _MMA = [F32]                # ... of the pass in flight (engine.begin_pass)
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 
 class SrcT(C.Structure):
     _fields_ = [("ptr", C.c_void_p), ("scale", C.c_void_p), ("C", C.c_int32), ("cstride", C.c_int32),
-                ("flags", C.c_int32), ("drop_seed", C.c_uint32), ("drop_p", C.c_float), ("rp_w", C.c_int32)]
+                ("flags", C.c_int32), ("drop_seed", C.c_uint32), ("drop_p", C.c_float), ("rp_w", C.c_int32),
+                ("ln_gamma", C.c_void_p), ("ln_beta", C.c_void_p), ("ln_stats", C.c_void_p), ("ln_eps", C.c_float), ("_pad0", C.c_int32)]
 
 
 class BnFin(C.Structure):
@@ -314,10 +315,21 @@ def _fill_src(dst, s):
         dst.flags = s.get("flags", 0)
         dst.drop_seed = s.get("drop_seed", 0)
         dst.drop_p = s.get("drop_p", 0.0)
+        ln = s.get("ln")          # (gamma, beta, eps, stats [pixels, 2] or None): LayerNorm on load (SRC_LN is set here)
+        if ln is not None:
+            g_, b_, eps_, st_ = ln
+            dst.flags |= SRC_LN
+            dst.ln_gamma, dst.ln_beta, dst.ln_eps = _p(g_).value, _p(b_).value, float(eps_)
+            dst.ln_stats = _p(st_).value if st_ is not None else None
+        else:
+            dst.ln_gamma = dst.ln_beta = dst.ln_stats = None
+            dst.ln_eps = 0.0
     else:
         v = _as_view(s)
         dst.ptr, dst.C, dst.cstride, dst.rp_w = v.ptr, v.C, v.cstride, v.rp
         dst.scale, dst.flags, dst.drop_seed, dst.drop_p = None, 0, 0, 0.0
+        dst.ln_gamma = dst.ln_beta = dst.ln_stats = None
+        dst.ln_eps = 0.0
     return v.C
 
 

@@ -713,6 +713,79 @@ def check_ln():
     return rows
 
 
+def check_ln_linear():
+    """LMN_SRC_LN: LayerNorm fused into the consuming Linear (norm1 -> qkv, norm2 -> fc1; /root/reference/core/modules.py:516-518,
+    343-344, 50-56): y = W . LN(x) + b (+ residual) in ONE conv launch vs fp64 F.layer_norm + F.linear, the (mean, rstd) table the
+    conv leaves for the backward, and the weight / bias gradient with the same transform on load.  Channel counts of the model
+    (12 / 24: in-register statistics of the N-split kernel; 48 / 96 / 372: the M-split kernel's pre-pass) plus 36 / 72 -> narrow
+    outputs, which reach the pre-pass through the `wide LayerNorm source` rule; pixel counts that leave partial tiles / chunks."""
+    rows = []
+    for Cn, Co, n in ((12, 36, 1043), (12, 24, 300), (24, 72, 777), (24, 48, 130), (48, 144, 333), (48, 96, 257), (96, 288, 203),
+                      (96, 192, 64), (372, 1116, 99), (372, 744, 50), (36, 24, 145), (72, 12, 77), (20, 8, 35)):
+        x = (R(n, Cn, seed=131) * 1.7 + 0.6).requires_grad_(True)
+        g, b = (R(Cn, seed=132).abs() + 0.5).requires_grad_(True), (R(Cn, seed=133) * 0.3).requires_grad_(True)
+        w, bias = R(Co, Cn, seed=134, scale=0.2).requires_grad_(True), R(Co, seed=135).requires_grad_(True)
+        res = R(n, Co, seed=136)
+        nrm = F.layer_norm(x, (Cn,), g, b, 1e-5)
+        nrm.retain_grad()
+        y_ref = F.linear(nrm, w, bias) + res
+        dy = R(n, Co, seed=137)
+        y_ref.backward(dy)
+        tag = " C=%d->%d n=%d" % (Cn, Co, n)
+        xd, dyd = dev(x).view(1, 1, n, Cn), dev(dy).view(1, 1, n, Co)
+        stats = torch.full((n, 2), float("nan"), device=DEV)
+        src = dict(view=xd, ln=(dev(g), dev(b), 1e-5, stats))
+        wp = hip.conv_pack(dev(w).view(Co, Cn, 1, 1), 1, [Cn])
+        y = torch.full((1, 1, n, Co), float("nan"), device=DEV)
+        hip.conv_fwd([src], wp, y, B=1, Hin=1, Win=n, Hout=1, Wout=n, Cout=Co, bias=dev(bias), residual=dev(res).view(1, 1, n, Co))
+        rows.append(("LN+linear fwd" + tag, rel(y.view(n, Co), y_ref), TOL))
+        mu = x.detach().mean(1)
+        rs = 1.0 / torch.sqrt(x.detach().var(1, unbiased=False) + 1e-5)
+        rows.append(("LN+linear stats table" + tag, max(rel(stats[:, 0], mu), rel(stats[:, 1], rs)), 2e-5))
+        dW, db = torch.zeros(Co, Cn, 1, 1, device=DEV), torch.zeros(Co, device=DEV)
+        hip.conv_wgrad([src], dyd, dW, db, B=1, Hin=1, Win=n, Hout=1, Wout=n, Cout=Co)
+        rows.append(("LN+linear wgrad dW" + tag, rel(dW.view(Co, Cn), w.grad), 2e-4))
+        rows.append(("LN+linear wgrad db" + tag, rel(db, bias.grad), 2e-4))
+        # the data gradient of the pair = Linear^T then lmn_ln_bwd on the un-normalised input (unchanged kernels): dx of the reference
+        dn = torch.full((1, 1, n, Cn), float("nan"), device=DEV)
+        wpt = hip.conv_pack_t(dev(w).view(Co, Cn, 1, 1), 1, 0, Cn, cred=Co)
+        hip.conv_fwd([dyd], wpt, dn, B=1, Hin=1, Win=n, Hout=1, Wout=n, Cout=Cn, transposed=1)
+        dx, dg, dbt = torch.full((n, Cn), float("nan"), device=DEV), torch.zeros(Cn, device=DEV), torch.zeros(Cn, device=DEV)
+        hip.ln_bwd(dev(x), dev(g), dn.view(n, Cn), None, dx, dg, dbt)
+        rows.append(("LN+linear dx (linear^T, ln_bwd)" + tag, rel(dx, x.grad), 2e-4))
+        rows.append(("LN+linear dgamma / dbeta" + tag, max(rel(dg, g.grad), rel(dbt, b.grad)), 2e-4))
+    return rows
+
+
+def check_conv_up2():
+    """LMN_SRC_UP2: bilinear x2 (align_corners=True) sampled where the 3x3 conv stages its window (up1..4, the `convs` branch of
+    the skip fusers; /root/reference/core/LM_Net.py:58-74,117-120, core/modules.py:94,129) vs fp64 F.interpolate + F.conv2d, and
+    against the materialised form (lmn_up2_fwd + plain conv) of rounds 1-4.  Shapes: the four decoder levels' channel pairs at small
+    sizes (N-split with one / two / three cout tiles, LDS-staged weights or not, the M-split kernel at Cout 96), odd tile remainders,
+    a source map as small as 2x2."""
+    rows = []
+    for (B, h, w, Cin, Cout) in ((2, 9, 11, 24, 12), (1, 22, 13, 48, 24), (1, 12, 12, 96, 48), (1, 8, 7, 192, 96), (2, 2, 2, 12, 12),
+                                 (1, 40, 37, 24, 12), (1, 5, 33, 36, 20)):
+        x = R(B, Cin, h, w, seed=141)
+        wt, bias = R(Cout, Cin, 3, 3, seed=142, scale=0.15), R(Cout, seed=143)
+        res = R(B, Cout, 2 * h, 2 * w, seed=144)
+        up_ref = F.interpolate(x, scale_factor=2, mode="bilinear", align_corners=True)
+        y_ref = F.conv2d(up_ref, wt, bias, padding=1) + res
+        tag = " %dx%d %d->%d" % (h, w, Cin, Cout)
+        xd = nhwc(x)
+        wp = hip.conv_pack(dev(wt), 3, [Cin])
+        y = torch.full((B, 2 * h, 2 * w, Cout), float("nan"), device=DEV)
+        hip.conv_fwd([dict(view=xd, flags=hip.SRC_UP2)], wp, y, B=B, Hin=2 * h, Win=2 * w, Hout=2 * h, Wout=2 * w, Cout=Cout, ksize=3,
+                     bias=dev(bias), residual=nhwc(res))
+        rows.append(("conv3x3(up2 on load)" + tag, rel(nchw(y), y_ref), TOL))
+        upd = torch.full((B, 2 * h, 2 * w, Cin), float("nan"), device=DEV)
+        hip.up2_fwd(xd, upd)
+        y2 = torch.full((B, 2 * h, 2 * w, Cout), float("nan"), device=DEV)
+        hip.conv_fwd([upd], wp, y2, B=B, Hin=2 * h, Win=2 * w, Hout=2 * h, Wout=2 * w, Cout=Cout, ksize=3, bias=dev(bias), residual=nhwc(res))
+        rows.append(("conv3x3(up2 on load) vs up2_fwd + conv" + tag, rel(y, y2), 2e-6))
+    return rows
+
+
 def check_bn_tail():
     """BatchNorm(batch stats)+GELU tail: bn_finalize, bnact_fwd, bnact_bwd_stats, bn_bwd_coef, bnact_bwd, colsum."""
     rows = []
@@ -1133,4 +1206,6 @@ def check_bn_shifted_stats():
 
 
 ALL_CHECKS.append(check_conv_bf16)
+ALL_CHECKS.append(check_ln_linear)
+ALL_CHECKS.append(check_conv_up2)
 ALL_CHECKS.append(check_bn_shifted_stats)
