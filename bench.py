@@ -41,7 +41,7 @@ def dice_loss(logits, target, weight=(1.0, 4.0), smooth=1e-5):
 
 def _pmc():
     """The committed PMC reduction of this very command (profiles/rNN_pmc.json, newest round first), or None."""
-    for name in ("r04_pmc.json", "r03_pmc.json", "r02_pmc.json"):
+    for name in ("r05_pmc.json", "r04_pmc.json", "r03_pmc.json", "r02_pmc.json"):
         path = os.path.join(ROOT, "profiles", name)
         if os.path.isfile(path):
             try:
@@ -89,6 +89,28 @@ def _pmc_match(kernel):
         if any(not lit(a) and a not in ("float", "__bf16") for a in args) and all((not lit(a)) or a == b for a, b in zip(args, a2)):
             out.append(rec)
     return out
+
+
+def rocprof_avg_us(kernel):
+    """AverageNs of `kernel` in the committed rocprofv3 --kernel-trace --stats summary of this command
+    (profiles/rNN_bench_kernel_stats.csv, newest round first; its Name column = `void ` + the instantiated name + the parameter
+    list), in microseconds, with the file it came from -- or (None, None).  The profiled run mixes four-stream and serial steps,
+    so this sits between avg_us (inside the step) and avg_us_alone."""
+    import csv
+    for name in ("r05_bench_kernel_stats.csv", "r04_bench_kernel_stats.csv"):
+        path = os.path.join(ROOT, "profiles", name)
+        if not os.path.isfile(path):
+            continue
+        try:
+            with open(path, newline="") as f:
+                for row in csv.DictReader(f):
+                    nm = row.get("Name", "")
+                    nm = nm[5:] if nm.startswith("void ") else nm
+                    if nm.split("(")[0].strip() == kernel:
+                        return float(row["AverageNs"]) / 1e3, "profiles/" + name
+        except (OSError, ValueError, KeyError):
+            pass
+    return None, None
 
 
 def pmc_field(kernel, field):
@@ -171,6 +193,15 @@ def roofline_block(dominant, live, survey, tot_us, B, H, W, step_s, alone, esz=4
     red = [k for k in live if k.startswith("wgrad_reduce_kernel<%s," % ("1" if "1x1" in dominant else "9"))] if dominant.startswith("wgrad") else []
     if red:
         r["frac_with_reduce_launches"] = _entry(dominant, rec, sum(live[k]["total_us"] for k in red))["frac"]
+    #  the same fraction from the committed rocprofv3 summary: algorithmic FLOPs (or bytes) per launch / the CSV's
+    # AverageNs of the same kernel name -- the line and profiles/ agree without a footnote
+    if at_headline:
+        us, src = rocprof_avg_us(dominant)
+        if us:
+            per = r["algorithmic_flops_per_launch"] if r["bound"] == "mfma" else r["algorithmic_bytes_per_launch"]
+            r["avg_us_rocprof"] = round(us, 2)
+            r["frac_rocprof"] = round(per / (us * 1e-6) / ((r["peak"] * 1e12) if r["bound"] == "mfma" else (r["peak"] * 1e9)), 4)
+            r["rocprof_file"] = src
     r["traffic"] = pmc_traffic(dominant) if at_headline else None
     r["traffic_ratio"] = (round(r["traffic"] / r["algorithmic_bytes_per_launch"], 3)
                           if r["traffic"] and r["algorithmic_bytes_per_launch"] else None)
@@ -548,6 +579,7 @@ def main():
         red = run.model.reducer
         comm = {"backend": "RCCL (torch.distributed 'nccl')" if backend == "nccl" else backend, "ranks": dist.get_world_size(),
                 "buckets_per_step": len(red.launched), "launched_before_finish": red.launched_before_finish,
+                "bucket_bounds_floats": [list(b) for b in red.launched],
                 "gradient_MB": round(net._grad_flat.numel() * 4 / 1e6, 2) if net._grad_flat is not None else None}
     # the same kernels with nothing else on the GPU: 3 more steps launched from the host with the branch / weight-gradient
     # streams switched off (inside the timed region a kernel shares the CUs with the other streams of the step)

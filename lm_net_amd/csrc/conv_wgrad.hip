@@ -1315,7 +1315,7 @@ int lmn_sizeof_wgrad_args(void) { return (int)sizeof(lmn_wgrad_args_t); }
 // one-tile-wide side is read exactly once); the LDS-staged kernel is instantiated for 1 or 2 tiles per side.
 static void wgrad_tile_shape(const lmn_wgrad_args_t& a, int nmtt, int nntt, int* NMT, int* NNT) {
   bool rp_any = a.dy_rp_w != 0;
-  for (int s = 0; s < a.nsrc && s < 3; ++s) rp_any = rp_any || a.src[s].rp_w != 0;
+  for (int s = 0; s < a.nsrc && s < 3; ++s) rp_any = rp_any || a.src[s].rp_w != 0 || (a.src[s].flags & LMN_SRC_LN) != 0;   // (LayerNorm on load: the wave-staged kernel only)
   const bool direct = a.ksize == 1 && a.stride == 1 && ((int64_t)a.Hout * a.Wout >= 32 || rp_any);   // (row-planar operands: direct kernels only)
   if (direct) {
     // 1x1: a block of (M x N) tiles reads its M dy tiles and N source tiles once per pixel; the grid's tile sets re-read
@@ -1514,9 +1514,9 @@ static int wgrad_setup(const lmn_wgrad_args_t& A, WgradParams& P, WgGeom& G) {
   const int64_t cap = btot / gy > 2 ? btot / gy : 2;
   if (blocks64 > cap) blocks64 = cap;
   if (blocks64 < 1) blocks64 = 1;
-  bool rp_any = A.dy_rp_w != 0;
-  for (int s = 0; s < A.nsrc; ++s) rp_any = rp_any || A.src[s].rp_w != 0;
-  G.direct = A.ksize == 1 && A.stride == 1 && ((int64_t)Gm.Hout * Gm.Wout >= 32 || rp_any);
+  bool rp_any = A.dy_rp_w != 0, ln_any = false;
+  for (int s = 0; s < A.nsrc; ++s) { rp_any = rp_any || A.src[s].rp_w != 0; ln_any = ln_any || (A.src[s].flags & LMN_SRC_LN) != 0; }
+  G.direct = A.ksize == 1 && A.stride == 1 && ((int64_t)Gm.Hout * Gm.Wout >= 32 || rp_any || ln_any);
   if (G.direct) {  // direct (no LDS) kernels: K steps split over ~1024*4/gy waves, at least 16 steps per wave
     const int64_t steps = ((int64_t)A.B * Gm.Hout * Gm.Wout + 3) / 4;
     blocks64 = (steps + 63) / 64;
@@ -1543,7 +1543,7 @@ static int wgrad_setup(const lmn_wgrad_args_t& A, WgradParams& P, WgGeom& G) {
   G.wave_staged = !(pm == 2 && !any_tf && old_shape) || (rp_any && (int64_t)Gm.Hout * Gm.Wout < 32);   // (tiny maps: the staged kernel divides per pixel)
   for (int s = 0; s < A.nsrc; ++s) {
     if (A.src[s].flags & LMN_SRC_LN) {   // LayerNorm on load: the wave-staged 1x1 kernel, statistics from the forward conv's table
-      LMN_REQUIRE(A.nsrc == 1 && G.direct && G.wave_staged && !rp_any, "conv_wgrad: LMN_SRC_LN belongs to single-source NHWC 1x1 stride-1 calls over >= 32 pixels");
+      LMN_REQUIRE(A.nsrc == 1 && G.direct && G.wave_staged && !rp_any, "conv_wgrad: LMN_SRC_LN belongs to single-source NHWC 1x1 stride-1 calls");
       LMN_REQUIRE(A.src[s].ln_gamma && A.src[s].ln_beta && A.src[s].ln_stats, "conv_wgrad: LMN_SRC_LN needs ln_gamma / ln_beta and the ln_stats table of the forward conv");
       LMN_REQUIRE(!(A.src[s].flags & ~LMN_SRC_LN) && !A.src[s].scale, "conv_wgrad: LMN_SRC_LN does not combine with other source transforms");
     }

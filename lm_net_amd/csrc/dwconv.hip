@@ -752,6 +752,24 @@ __device__ __forceinline__ void pkmul(f32x2& acc, f32x2 x, f32x2 wp, int hi) {  
   if (hi) asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1]" : "=v"(acc) : "v"(x), "s"(wp));
   else asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(acc) : "v"(x), "s"(wp));
 }
+// the same with the weight pair in a VGPR pair (the 3x3 / 3x1 / 1x3 kernels: 18 SGPRs fewer -- the scalar file was over-subscribed
+// by ~70 values, every spilled one a v_readlane in the loop)
+#ifndef LMN_DW_WSGPR
+#define LMN_DW_WSGPR 0
+#endif
+#if LMN_DW_WSGPR
+#define LMN_WC "s"
+#else
+#define LMN_WC "v"
+#endif
+__device__ __forceinline__ void pkfmaV(f32x2& acc, f32x2 x, f32x2 wp, int hi) {
+  if (hi) asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "+v"(acc) : "v"(x), LMN_WC(wp));
+  else asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]" : "+v"(acc) : "v"(x), LMN_WC(wp));
+}
+__device__ __forceinline__ void pkmulV(f32x2& acc, f32x2 x, f32x2 wp, int hi) {
+  if (hi) asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1]" : "=v"(acc) : "v"(x), LMN_WC(wp));
+  else asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(acc) : "v"(x), LMN_WC(wp));
+}
 __device__ __forceinline__ void pkfma_vv(f32x2& acc, f32x2 x, f32x2 y) { asm volatile("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(acc) : "v"(x), "v"(y)); }
 #define LMN_NOP0() asm volatile("s_nop 0")
 struct W2 { f32x2 w5[13], w3[5], wv[2], wh[2]; };   // tap t of a kernel: pair t >> 1, half t & 1
@@ -761,7 +779,6 @@ struct W2 { f32x2 w5[13], w3[5], wv[2], wh[2]; };   // tap t of a kernel: pair t
 #define LMN_WH(t) bw.wh[(t) >> 1], (t) & 1
 struct SwState {
   f32x2 a5[5], a3[5], av[5], ah[5];          // y_b accumulators, slot = row index mod 5
-  f32x2 h5[5], h3[5], hv[5], hh[5];          // own-pixel f_b history (masked), slot = row index mod 5
   f32x2 dxa[5];                              // dx1 row accumulators, slot = row index mod 5
   f32x2 g5[25], g3[9], gv[3], gh[3];         // weight-gradient accumulators
 };
@@ -817,38 +834,58 @@ __device__ __forceinline__ void pkmul_s2(f32x2& d, f32x2 x, f32x2 sp) {   // d =
 }
 // msk_on (wave-uniform): a step that touches rows outside the image (mf: the f row of each half); mo: the f row lies in the wave's own
 // segment (weight-gradient history; always applied: it is the one mask whose off / on forms would need two registers per value)
-template <int P, int PART>
-__device__ __forceinline__ void sw_step_f(SwState& S, const SwCoef& CF, SwF& F, const f32x2 (&i2)[5], f32x2 dp, f32x2 mf, f32x2 mo, bool msk_on,
-                                          int bp0) {
+// f row q (slot QS = q mod 5 of the branch accumulators, all four complete) and its column neighbours, requested through the LDS
+// crossbar: formed at the END of a step for the NEXT one, so that the round trip hides behind the loop edge and the next step's 40
+// branch-output FMAs.  mf (wave-uniform, boundary steps only): the f row of each half lies inside the image.
+template <int QS>
+__device__ __forceinline__ void sw_form_f(const SwState& S, const SwCoef& CF, SwF& F, f32x2 dp, f32x2 mf, bool msk_on, int bp0) {
   typedef f32x2 V;
-  constexpr int Q = (P + 2) % 5;   // slot of row j - 3: all four branch outputs of that row were completed by the previous step
   V f5, f3, fv, fh;
   pkfma_cA(f5, dp, CF.sA[0], CF.vD[0], 0); pkfma_cA(f3, dp, CF.sA[0], CF.vD[0], 1);
   pkfma_cA(fv, dp, CF.sA[1], CF.vD[1], 0); pkfma_cA(fh, dp, CF.sA[1], CF.vD[1], 1);
-  pkfma_cC(f5, S.a5[Q], CF.vC[0], 0); pkfma_cC(f3, S.a3[Q], CF.vC[0], 1); pkfma_cC(fv, S.av[Q], CF.vC[1], 0); pkfma_cC(fh, S.ah[Q], CF.vC[1], 1);
+  pkfma_cC(f5, S.a5[QS], CF.vC[0], 0); pkfma_cC(f3, S.a3[QS], CF.vC[0], 1); pkfma_cC(fv, S.av[QS], CF.vC[1], 0); pkfma_cC(fh, S.ah[QS], CF.vC[1], 1);
   LMN_NOP0();
   if (msk_on) { pkmul_s2(f5, f5, mf); pkmul_s2(f3, f3, mf); pkmul_s2(fv, fv, mf); pkmul_s2(fh, fh, mf); LMN_NOP0(); }   // (rows outside the image)
-  if constexpr (PART != 2) {   // column neighbours through the LDS crossbar; bp0 = 4 * ((lane - 2) & 63): lanes -2, -1, +1, +2 at +0, +4, +12, +16
-    F.sh[4] = bperm2(bp0, f5); F.sh[3] = bperm2(bp0 + 4, f5); F.sh[1] = bperm2(bp0 + 12, f5); F.sh[0] = bperm2(bp0 + 16, f5);
-    F.s3[2] = bperm2(bp0 + 4, f3); F.s3[0] = bperm2(bp0 + 12, f3);
-    F.hl = bperm2(bp0 + 4, fh); F.hr = bperm2(bp0 + 12, fh);
-    F.sh[2] = f5; F.s3[1] = f3; F.fv = fv; F.fh = fh;
-  }
-  pkmul_s2(S.h5[Q], f5, mo); pkmul_s2(S.h3[Q], f3, mo); pkmul_s2(S.hv[Q], fv, mo); pkmul_s2(S.hh[Q], fh, mo);   // own rows only: the weight-gradient history
-  // ---- weight gradients: x1 row j - 5 (i2) against f rows j - 3 - ky (5x5), j - 4 - ky (3x3, 3x1), j - 5 (1x3)
-  if (PART != 1) {
+#ifndef LMN_DW_ALWAYS_MSK
+#define LMN_DW_ALWAYS_MSK 0   // A/B builds: 1 = every step applies the row masks (no wave-uniform branches in the loop)
+#endif
+#ifndef LMN_DW_NB
+#define LMN_DW_NB 1   // how the column neighbours of f travel: 1 = DPP wave shifts (16 VALU slots per step; level 0 alone 203 us), 0 = ds_bpermute_b32 (LDS crossbar, no VALU slot: 209-218 us -- the kernel is not issue-bound at two waves per SIMD)
+#endif
+#if LMN_DW_NB == 1
+  F.sh[1] = lane_from_right(f5); F.sh[0] = lane_from_right(F.sh[1]); F.sh[3] = lane_from_left(f5); F.sh[4] = lane_from_left(F.sh[3]);
+  F.s3[0] = lane_from_right(f3); F.s3[2] = lane_from_left(f3);
+  F.hr = lane_from_right(fh); F.hl = lane_from_left(fh);
+  (void)bp0;
+#else
+  // bp0 = 4 * ((lane - 2) & 63): lanes -2, -1, +1, +2 at +0, +4, +12, +16 (byte address + instruction offset, modulo the wave)
+  F.sh[4] = bperm2(bp0, f5); F.sh[3] = bperm2(bp0 + 4, f5); F.sh[1] = bperm2(bp0 + 12, f5); F.sh[0] = bperm2(bp0 + 16, f5);
+  F.s3[2] = bperm2(bp0 + 4, f3); F.s3[0] = bperm2(bp0 + 12, f3);
+  F.hl = bperm2(bp0 + 4, fh); F.hr = bperm2(bp0 + 12, fh);
+#endif
+  F.sh[2] = f5; F.s3[1] = f3; F.fv = fv; F.fh = fh;
+}
+// weight gradients of f row q = j - 3 against ALL its x1 rows q - 2 .. q + 2 = j - 5 .. j - 1:
+//   dW_b[ky][kx] = sum_x f_b[q][x] x1[q + ky - 2][x + kx - 2] = sum_x' f_b[q][x' + 2 - kx] x1[q + ky - 2][x']
+// -- the SHIFTED copies of f that the dx1 FMAs need anyway (F.sh / F.s3 / F.hr / F.hl) against the wave's OWN column of the last five
+// x1 rows (xo[ky] = row j - 5 + ky: four plain LDS reads of the ring, requested at the top of the step, and the row the ring has just
+// lost, kept in a register).  No f history (40 VGPRs in the round-4 form), no shifted LDS read; lane l then holds the products of f
+// column l + 2 - kx, and the lanes whose f column is not one of the strip's own are dropped per kx in the final reduction.  mo (boundary steps): the f row lies inside the wave's own segment.
+template <int P>
+__device__ __forceinline__ void sw_step_dw(SwState& S, const SwF& F, const f32x2 (&xo)[5], f32x2 mo, bool msk_on) {
+  typedef f32x2 V;
 #pragma unroll
-    for (int ky = 4; ky >= 0; --ky)   // (the row of this step's h last: its multiply above is a packed result)
+  for (int ky = 0; ky < 5; ++ky) {
+    V X = xo[ky];
+    if (msk_on) { pkmul_s2(X, X, mo); LMN_NOP0(); }
 #pragma unroll
-      for (int kx = 0; kx < 5; ++kx) pkfma_vv(S.g5[ky * 5 + kx], S.h5[(P + 7 - ky) % 5], i2[kx]);
+    for (int kx = 0; kx < 5; ++kx) pkfma_vv(S.g5[ky * 5 + kx], F.sh[kx], X);
+    if (ky >= 1 && ky <= 3) {
 #pragma unroll
-    for (int ky = 0; ky < 3; ++ky) {
-#pragma unroll
-      for (int kx = 0; kx < 3; ++kx) pkfma_vv(S.g3[ky * 3 + kx], S.h3[(P + 6 - ky) % 5], i2[1 + kx]);
-      pkfma_vv(S.gv[ky], S.hv[(P + 6 - ky) % 5], i2[2]);
+      for (int kx = 0; kx < 3; ++kx) pkfma_vv(S.g3[(ky - 1) * 3 + kx], F.s3[kx], X);
+      pkfma_vv(S.gv[ky - 1], F.fv, X);
     }
-#pragma unroll
-    for (int kx = 0; kx < 3; ++kx) pkfma_vv(S.gh[kx], S.hh[P], i2[1 + kx]);
+    if (ky == 2) { pkfma_vv(S.gh[0], F.hr, X); pkfma_vv(S.gh[1], F.fh, X); pkfma_vv(S.gh[2], F.hl, X); }
   }
 }
 // dx1: f row q = j - 3 feeds dx rows q - 2 .. q + 2 = j - 5 .. j - 1 (slots P .. P + 4; row j - 1 starts here, row j - 5 completes)
@@ -865,16 +902,16 @@ __device__ __forceinline__ void sw_step_dx(SwState& S, const W2& bw, const SwF& 
 #pragma unroll
   for (int kx = 0; kx < 3; ++kx) {
 #pragma unroll
-    for (int ky = 0; ky < 3; ++ky) pkfma(S.dxa[(P + ky + 1) % 5], F.s3[kx], LMN_W3(ky * 3 + kx));
+    for (int ky = 0; ky < 3; ++ky) pkfmaV(S.dxa[(P + ky + 1) % 5], F.s3[kx], LMN_W3(ky * 3 + kx));
   }
   // 3x1 and 1x3: interleaved so that no statement reads the accumulator its predecessor wrote
-  pkfma(S.dxa[(P + 2) % 5], F.fv, LMN_WV(1));
-  pkfma(S.dxa[(P + 1) % 5], F.fv, LMN_WV(0));
-  pkfma(S.dxa[Q], F.hr, LMN_WH(0));
-  pkfma(S.dxa[(P + 3) % 5], F.fv, LMN_WV(2));
-  pkfma(S.dxa[Q], F.fh, LMN_WH(1));
+  pkfmaV(S.dxa[(P + 2) % 5], F.fv, LMN_WV(1));
+  pkfmaV(S.dxa[(P + 1) % 5], F.fv, LMN_WV(0));
+  pkfmaV(S.dxa[Q], F.hr, LMN_WH(0));
+  pkfmaV(S.dxa[(P + 3) % 5], F.fv, LMN_WV(2));
+  pkfmaV(S.dxa[Q], F.fh, LMN_WH(1));
   LMN_NOP0();   // (the one chain of the step: two consecutive statements into the same accumulator)
-  pkfma(S.dxa[Q], F.hl, LMN_WH(2));
+  pkfmaV(S.dxa[Q], F.hl, LMN_WH(2));
 }
 // x1 row j: the four branch outputs y_b (column-major: consecutive FMAs go to DIFFERENT row accumulators; the first contribution to
 // a row is a plain product: no zeroed accumulators)
@@ -887,15 +924,15 @@ __device__ __forceinline__ void sw_step_y(SwState& S, const W2& bw, const f32x2 
 #pragma unroll
     for (int ky = 1; ky < 5; ++ky) pkfma(S.a5[(P - ky + 7) % 5], in[d], LMN_W5(ky * 5 + d));
     if (d >= 1 && d <= 3) {
-      if (d == 1) { pkmul(S.a3[(P + 1) % 5], in[1], LMN_W3(0)); pkmul(S.ah[P], in[1], LMN_WH(0)); }
-      else { pkfma(S.a3[(P + 1) % 5], in[d], LMN_W3(d - 1)); pkfma(S.ah[P], in[d], LMN_WH(d - 1)); }
+      if (d == 1) { pkmulV(S.a3[(P + 1) % 5], in[1], LMN_W3(0)); pkmulV(S.ah[P], in[1], LMN_WH(0)); }
+      else { pkfmaV(S.a3[(P + 1) % 5], in[d], LMN_W3(d - 1)); pkfmaV(S.ah[P], in[d], LMN_WH(d - 1)); }
 #pragma unroll
-      for (int ky = 1; ky < 3; ++ky) pkfma(S.a3[(P - ky + 6) % 5], in[d], LMN_W3(ky * 3 + d - 1));
+      for (int ky = 1; ky < 3; ++ky) pkfmaV(S.a3[(P - ky + 6) % 5], in[d], LMN_W3(ky * 3 + d - 1));
     }
     if (d == 2) {
-      pkmul(S.av[(P + 1) % 5], in[2], LMN_WV(0));
+      pkmulV(S.av[(P + 1) % 5], in[2], LMN_WV(0));
 #pragma unroll
-      for (int ky = 1; ky < 3; ++ky) pkfma(S.av[(P - ky + 6) % 5], in[2], LMN_WV(ky));
+      for (int ky = 1; ky < 3; ++ky) pkfmaV(S.av[(P - ky + 6) % 5], in[2], LMN_WV(ky));
     }
   }
 }
@@ -908,7 +945,7 @@ __global__ __launch_bounds__(256, WPS) void dw_bwd_kernel(
     float* __restrict__ dw3, float* __restrict__ dwv, float* __restrict__ dwh, const DwPreS PRE, float* __restrict__ hstats, int strips,
     int segs /* even */, int seg_rows, int chunks /* quads */, int det) {
   typedef f32x2 V;
-  constexpr int ES = sizeof(TA), D = 3, D2 = 2;   // rows in flight (z / dpre); 5 / 4 measured the same: the pass does not wait for memory
+  constexpr int ES = sizeof(TA), D = 3, D2 = 2;   // rows in flight (z / dpre) beyond the next step's; 3 costs four more VGPRs (the prefetch rings), and the kernel sits at the 256 of two waves per SIMD
   constexpr int QS = HALO ? 60 : 56;
   __shared__ V XSa[4][5 * 68];
   __shared__ V ZSa[4][ZT && PART != 2 ? 5 * 64 : 1];
@@ -949,6 +986,13 @@ __global__ __launch_bounds__(256, WPS) void dw_bwd_kernel(
   for (int k = 0; k < 5; ++k) bw.w3[k] = V{wl(w3, 9, 2 * k), wl(w3, 9, 2 * k + 1)};
 #pragma unroll
   for (int k = 0; k < 2; ++k) { bw.wv[k] = V{wl(wvv, 3, 2 * k), wl(wvv, 3, 2 * k + 1)}; bw.wh[k] = V{wl(whh, 3, 2 * k), wl(whh, 3, 2 * k + 1)}; }
+  // (the 5x5 kernel in SGPR pairs, the three small kernels in VGPR pairs)
+#if !LMN_DW_WSGPR
+#pragma unroll
+  for (int k = 0; k < 5; ++k) asm volatile("" : "+v"(bw.w3[k]));
+#pragma unroll
+  for (int k = 0; k < 2; ++k) asm volatile("" : "+v"(bw.wv[k]), "+v"(bw.wh[k]));
+#endif
   float a4[4], c4[4], d4[4];   // BatchNorm-backward coefficients of f_b = cA dpre + cC y_b + cD (per channel: wave-uniform)
   {
 #pragma unroll
@@ -1014,13 +1058,13 @@ __global__ __launch_bounds__(256, WPS) void dw_bwd_kernel(
   // f rows of half h live at image rows [fl_h, H): inside the image and not above the first row the segment needs (ys - 2)
   const int flA = max(ysA - 2, 0), flB = max(ysB - 2, 0);
 #pragma unroll
-  for (int d = 0; d < D; ++d) ldz(d, pfz[d], pfh[d]);
+  for (int d = 0; d <= D; ++d) ldz(d, pfz[d], pfh[d]);       // z rows 0 .. D (row 0 is exchanged before the loop)
 #pragma unroll
-  for (int d = 0; d < D2; ++d) ldd(d, pfd[d]);
+  for (int d = 1; d <= D2; ++d) ldd(d, pfd[d]);              // dpre rows of f rows formed at the end of steps 0 .. D2 - 1
   SwState S;
   const V z2 = V{0.f, 0.f};
 #pragma unroll
-  for (int k = 0; k < 5; ++k) S.a5[k] = S.a3[k] = S.av[k] = S.ah[k] = S.h5[k] = S.h3[k] = S.hv[k] = S.hh[k] = S.dxa[k] = z2;
+  for (int k = 0; k < 5; ++k) S.a5[k] = S.a3[k] = S.av[k] = S.ah[k] = S.dxa[k] = z2;
 #pragma unroll
   for (int k = 0; k < 25; ++k) S.g5[k] = z2;
 #pragma unroll
@@ -1029,60 +1073,74 @@ __global__ __launch_bounds__(256, WPS) void dw_bwd_kernel(
   for (int k = 0; k < 3; ++k) S.gv[k] = S.gh[k] = z2;
   V hs0 = z2, hs1 = z2;
   // interior steps: every row the step touches lies inside the image AND inside the wave's own segments, for both halves -- x1 row
-  // ys-4+j, f row ys-7+j, dx row ys-9+j: j in [9, jhi).  They skip the row-mask blocks by ONE scalar compare (msk_on); the conditions
-  // of the boundary steps are evaluated inside those blocks only (their scalars stay out of the interior path).
+  // ys-4+j, f row ys-7+j, dx row ys-9+j: j in [9, jhi).  They skip the row-mask blocks by ONE scalar compare; the conditions of the
+  // boundary steps are evaluated inside those blocks only (their scalars stay out of the interior path).
   int jhi = rowsB + 7;
   if (H + 4 - ysA < jhi) jhi = H + 4 - ysA;
   if (H + 4 - ysB < jhi) jhi = H + 4 - ysB;
   if (rowsB <= 0) jhi = 0;
   const unsigned jn = jhi > 9 ? (unsigned)(jhi - 9) : 0u;
   auto mskf = [](bool a) -> float { return a ? 1.f : 0.f; };
-#define LMN_STEP(P)                                                                                                \
+  // ---- the step is software-pipelined over the loop edge: what a step needs through the LDS crossbar -- the shifted copies of f row
+  //      j - 3 (F) and of x1 row j (inn) -- is requested at the END of the previous step (LMN_NEXT), so that both round trips hide
+  //      behind the loop edge and the 40 branch-output FMAs that open a step.
+  SwF F;
+  F.sh[0] = F.sh[1] = F.sh[2] = F.sh[3] = F.sh[4] = F.s3[0] = F.s3[1] = F.s3[2] = F.hr = F.hl = F.fv = F.fh = z2;
+  V inn[5];
+  V xold = z2, xold2 = z2;   // own column of the x1 rows that left the ring last (at step j: rows j - 5 and, after X, j - 4)
+  // x1 row JN (ring slot PN) from its prefetched z row: transform, row mask on boundary steps, exchange of the +-1 / +-2 columns.  The
+  // row that leaves the ring (JN - 5) is read first (LDS operations of a wave execute in order).
+#define LMN_X1ROW(JN, PN, MSKN)                                                                                    \
   {                                                                                                                \
-    const int j = j0 + P;                                                                                          \
-    const V zv = pfz[P];                                                                                           \
-    const V zh = pfh[P];                                                                                           \
-    const bool msk_on = !((unsigned)(j - 9) < jn);                                                                 \
-    /* f row ys-7+j inside the wave's own segment; dx row ys-9+j inside it (per half; wave-uniform) */             \
-    const bool oA = (unsigned)(j - 7) < (unsigned)rowsA, oB = (unsigned)(j - 7) < (unsigned)rowsB;                 \
-    const bool okA = (unsigned)(j - 9) < (unsigned)rowsA, okB = (unsigned)(j - 9) < (unsigned)rowsB;               \
-    V mf = z2;                                                                                                     \
-    if (msk_on) {   /* f row inside the image and not above the first row the segment needs */                     \
-      const int fyA = ysA - 7 + j, fyB = ysB - 7 + j;                                                              \
-      mf = V{mskf((unsigned)(fyA - flA) < (unsigned)(H - flA)), mskf((unsigned)(fyB - flB) < (unsigned)(HB - flB) && rowsB > 0)}; \
-    }                                                                                                              \
-    const V dp = pfd[P];                                                                                           \
-    ldz(j + D, pfz[(P + D) % 5], pfh[(P + D) % 5]);                                                                \
-    ldd(j + D2, pfd[(P + D2) % 5]);                                                                                \
-    /* ring slot P still holds x1 row j-5 (and z row j-5): they are read here, the new row is written further down (the LDS      */ \
-    /* operations of a wave execute in order; the fences only keep the compiler from reordering them)                            */ \
-    V i2[5];                                                                                                       \
-    V zr = z2;                                                                                                     \
-    LMN_WAVE_SYNC();                                                                                               \
-    if (PART != 1) { _Pragma("unroll") for (int d = 0; d < 5; ++d) i2[d] = XS[P * 68 + lane + d]; }                \
-    if (ZT && PART != 2) zr = ZS[P * 64 + lane];                                                                   \
-    SwF F;                                                                                                         \
-    sw_step_f<P, PART>(S, CFv, F, i2, dp, mf, V{mskf(oA), mskf(oB)}, msk_on, bp0);                                 \
-    if (PART != 2) sw_step_dx<P>(S, bw, F);                                                                        \
+    const V zv = pfz[PN];                                                                                          \
     V x1v = ZT ? hswish2_as(zv, pas) : zv;                                                                         \
     V x1h = z2;                                                                                                    \
-    if (HALO) x1h = ZT ? hswish2_as(zh, pash) : zh;                                                                \
-    if (msk_on) {   /* x1 row ys-4+j inside the image */                                                           \
-      const V rm = V{mskf((unsigned)(ysA - 4 + j) < (unsigned)H), mskf((unsigned)(ysB - 4 + j) < (unsigned)HB)};   \
+    if (HALO) x1h = ZT ? hswish2_as(pfh[PN], pash) : pfh[PN];                                                      \
+    if (MSKN) {   /* x1 row ys-4+JN inside the image */                                                            \
+      const V rm = V{mskf((unsigned)(ysA - 4 + (JN)) < (unsigned)H), mskf((unsigned)(ysB - 4 + (JN)) < (unsigned)HB)}; \
       pkmul_s2(x1v, x1v, rm);                                                                                      \
       if (HALO) pkmul_s2(x1h, x1h, rm);                                                                            \
       LMN_NOP0();                                                                                                  \
     }                                                                                                              \
+    xold2 = XS[(PN) * 68 + lane + 2];   /* (same address as the write below: program order holds without a fence) */ \
+    XS[(PN) * 68 + lane + 2] = x1v;                                                                                \
+    if (HALO) { if (lane < 4) XS[(PN) * 68 + hidx] = x1h; }                                                        \
     LMN_WAVE_SYNC();                                                                                               \
-    XS[P * 68 + lane + 2] = x1v;                                                                                   \
-    if (HALO) { if (lane < 4) XS[P * 68 + hidx] = x1h; }                                                           \
-    if (ZT && PART != 2) ZS[P * 64 + lane] = zv;                                                                   \
-    LMN_WAVE_SYNC();                                                                                               \
-    V in[5];                                                                                                       \
-    { const V* xr = XS + P * 68 + lane; in[0] = xr[0]; in[1] = xr[1]; in[2] = x1v; in[3] = xr[3]; in[4] = xr[4]; } \
-    if (PART != 2) {   /* dx row j-5 (image row ys-9+j) is complete; its drain covers the exchange of the x1 row */ \
+    { const V* xr = XS + (PN) * 68 + lane; inn[0] = xr[0]; inn[1] = xr[1]; inn[2] = x1v; inn[3] = xr[3]; inn[4] = xr[4]; } \
+  }
+  { const bool m0 = !((unsigned)(0 - 9) < jn); LMN_X1ROW(0, 0, m0) }   // (row 0: step 0 is a boundary step)
+  // Order inside a step (A -> X -> B -> C -> D): the branch outputs of x1 row j (inn: requested a whole step ago); THEN the exchange of
+  // row j+1 is requested (its round trip hides behind B .. D); the weight gradients and dx1 of f row j-3 (F: requested at the end of the
+  // previous step, behind A); the drain of the completed dx row; f row j-2 for the next step.
+#define LMN_STEP(P)                                                                                                \
+  {                                                                                                                \
+    const int j = j0 + P;                                                                                          \
+    const bool msk_on = LMN_DW_ALWAYS_MSK || !((unsigned)(j - 9) < jn), msk_nx = LMN_DW_ALWAYS_MSK || !((unsigned)(j - 8) < jn);   /* this step's / the next step's rows */ \
+    /* f row ys-7+j inside the wave's own segment; dx row ys-9+j inside it (per half; wave-uniform) */             \
+    const bool oA = (unsigned)(j - 7) < (unsigned)rowsA, oB = (unsigned)(j - 7) < (unsigned)rowsB;                 \
+    const bool okA = (unsigned)(j - 9) < (unsigned)rowsA, okB = (unsigned)(j - 9) < (unsigned)rowsB;               \
+    ldz(j + 1 + D, pfz[(P + 1 + D) % 5], pfh[(P + 1 + D) % 5]);                                                    \
+    ldd(j + 1 + D2, pfd[(P + 1 + D2) % 5]);                                                                        \
+    /* own column of x1 rows j-5 .. j-1 for the weight gradients: rows j-5 / j-4 from registers (they left / leave the ring), */ \
+    /* rows j-3 .. j-1 from the ring                                                                                        */ \
+    V xo[5];                                                                                                       \
+    xo[0] = xold;                                                                                                  \
+    if (PART != 1) { _Pragma("unroll") for (int ky = 2; ky < 5; ++ky) xo[ky] = XS[((P + ky) % 5) * 68 + lane + 2]; } \
+    /* A: x1 row j (inn) -> the branch outputs; row j-2 of every branch is complete after it */                    \
+    sw_step_y<P>(S, bw, inn);                                                                                      \
+    /* X: x1 row j+1 into ring slot P+1 (whose row j-4 is kept: xold2); its shifted copies are requested for the next step */ \
+    LMN_X1ROW(j + 1, (P + 1) % 5, msk_nx)                                                                          \
+    xo[1] = xold2;                                                                                                 \
+    xold = xold2;                                                                                                  \
+    /* B: f row j-3 (F): weight gradients against x1 rows j-5 .. j-1 (xo), dx rows j-5 .. j-1 */                   \
+    if (PART != 1) sw_step_dw<P>(S, F, xo, V{mskf(oA), mskf(oB)}, msk_on);                                         \
+    if (PART != 2) sw_step_dx<P>(S, bw, F);                                                                        \
+    /* C: dx row j-5 (image row ys-9+j) is complete */                                                             \
+    if (PART != 2) {                                                                                               \
       V dv = S.dxa[P];                                                                                             \
       if (ZT) {   /* dh = dx1 * Hardswish'(A z + shift); sum dh, sum dh * z over the rows of the two segments */   \
+        const V zr = ZS[P * 64 + lane];   /* z row j-5; then z row j takes the slot (same address: program order holds) */ \
+        ZS[P * 64 + lane] = pfz[P];                                                                                \
         const V hh = zr * pa + ps;                                                                                 \
         dv = dv * V{lmn_dhswish(hh.x), lmn_dhswish(hh.y)};                                                         \
         if (msk_on) { pkmul_s2(dv, dv, V{mskf(okA), mskf(okB)}); LMN_NOP0(); }                                     \
@@ -1092,11 +1150,20 @@ __global__ __launch_bounds__(256, WPS) void dw_bwd_kernel(
       if (okA) st_one<TA>(ro, vst, (unsigned)(r0 + ysA - 9 + j) * rowb + qoff, dv.x);                              \
       if (okB) st_one<TA>(ro, vst, (unsigned)(r0 + ysB - 9 + j) * rowb + qoff, dv.y);                              \
     }                                                                                                              \
-    sw_step_y<P>(S, bw, in);                                                                                       \
+    /* D: f row j-2 for step j+1 (its branch outputs were completed by A); the neighbours are requested behind the loop edge */ \
+    {                                                                                                              \
+      V mf = z2;                                                                                                   \
+      if (msk_nx) {   /* f row ys-6+j inside the image and not above the first row the segment needs */            \
+        const int fyA = ysA - 6 + j, fyB = ysB - 6 + j;                                                            \
+        mf = V{mskf((unsigned)(fyA - flA) < (unsigned)(H - flA)), mskf((unsigned)(fyB - flB) < (unsigned)(HB - flB) && rowsB > 0)}; \
+      }                                                                                                            \
+      sw_form_f<(P + 3) % 5>(S, CFv, F, pfd[(P + 1) % 5], mf, msk_nx, bp0);                                        \
+    }                                                                                                              \
     LMN_SB();                                                                                                      \
   }
   for (int j0 = 0; j0 < nsteps; j0 += 5) { LMN_STEP(0) LMN_STEP(1) LMN_STEP(2) LMN_STEP(3) LMN_STEP(4) }
 #undef LMN_STEP
+#undef LMN_X1ROW
   // ---- reductions: both halves add up; wave totals by DPP (the total lands in lane 63), then one atomic per (tap, channel)
   float* rw = red + wv * 44;
   auto put = [&](V v, int t, bool ok) {
@@ -1105,12 +1172,16 @@ __global__ __launch_bounds__(256, WPS) void dw_bwd_kernel(
   };
   if (ZT && PART != 2) { put(hs0, 40, ovalid); put(hs1, 41, ovalid); }
   if (PART != 1) {
+    // lane l of g[..][kx] holds the products of f column l + 2 - kx (5x5) / l + 1 - kx (3x3, 1x3) / l (3x1): kept where that column is
+    // one of the strip's own
+    const int lo = HALO ? 2 : 4, hi = HALO ? 61 : 59;
+    auto ownf = [&](int l) -> bool { return l >= lo && l <= hi; };
 #pragma unroll
-    for (int t = 0; t < 25; ++t) put(S.g5[t], t, own_col);
+    for (int t = 0; t < 25; ++t) put(S.g5[t], t, ownf(lane + 2 - t % 5));
 #pragma unroll
-    for (int t = 0; t < 9; ++t) put(S.g3[t], 25 + t, own_col);
+    for (int t = 0; t < 9; ++t) put(S.g3[t], 25 + t, ownf(lane + 1 - t % 3));
 #pragma unroll
-    for (int t = 0; t < 3; ++t) { put(S.gv[t], 34 + t, own_col); put(S.gh[t], 37 + t, own_col); }
+    for (int t = 0; t < 3; ++t) { put(S.gv[t], 34 + t, ownf(lane)); put(S.gh[t], 37 + t, ownf(lane + 1 - t)); }
   }
   __syncthreads();
   // (deterministic mode: hstats / dw5 .. dwh address slot copies of the destinations, one slot per (image, segment pair, strip))
@@ -1456,9 +1527,9 @@ static int dw_bwd_launch(const void* x1, const void* dpre, void* dx1, int B, int
   LMN_REQUIRE((int64_t)B * H * W * E * (act_dtype == LMN_BF16 ? 2 : 4) < (1LL << 32), "%s: the tensor (%d x %d x %d x %d) must stay below 4 GiB (row offsets travel in the 32-bit soffset)", what, B, H, W, E);
   const bool halo = lmn_cdiv(W, 60) < lmn_cdiv(W, 56);   // the four extra x1 columns only where they save a strip
   const int strips = halo ? lmn_cdiv(W, 60) : lmn_cdiv(W, 56), chunks = E / 4;
-  const int wps = part == 1 ? 4 : 2;
+  const int wps = part == 1 ? 3 : 2;   // (dx1 alone: three waves per SIMD -- round 5: at the 128 VGPRs of four it spills)
   int seg_rows;
-  const int segs = dw_segments((int64_t)B * strips * chunks * 4, H, 9, wps, 2, part == 1 ? 3.0 : 2.0, &seg_rows);   // even: a wave walks the pair (sa, sa + segs/2)
+  const int segs = dw_segments((int64_t)B * strips * chunks * 4, H, 10, wps, 2, part == 1 ? 3.0 : 2.0, &seg_rows);   // even: a wave walks the pair (sa, sa + segs/2)
   const int hs = segs / 2;
   const int64_t nblk = (int64_t)B * strips * chunks * hs;
   LMN_REQUIRE(nblk < (1LL << 31), "%s: grid too large", what);
@@ -1476,7 +1547,7 @@ static int dw_bwd_launch(const void* x1, const void* dpre, void* dx1, int B, int
                        (T*)dx1, B, H, W, E, w5, w3, wv, wh, cA, cC, cD, cf, g5, g3, gv, gh, DwPreS{zp.A, zp.shift}, hs_, strips, segs, seg_rows, chunks, g_lmn_det))
 #define LMN_DWB3(PT, HL, WP) do { if (zp.A) LMN_DWB4(PT, HL, true, WP); else LMN_DWB4(PT, HL, false, WP); } while (0)
 #define LMN_DWB2(PT, WP) do { if (halo) LMN_DWB3(PT, true, WP); else LMN_DWB3(PT, false, WP); } while (0)
-  if (part == 1) { LMN_DWB2(1, 4); } else if (part == 2) { LMN_DWB2(2, 2); } else { LMN_DWB2(0, 2); }
+  if (part == 1) { LMN_DWB2(1, 3); } else if (part == 2) { LMN_DWB2(2, 2); } else { LMN_DWB2(0, 2); }
 #undef LMN_DWB4
 #undef LMN_DWB3
 #undef LMN_DWB2

@@ -721,7 +721,7 @@ def check_ln_linear():
     outputs, which reach the pre-pass through the `wide LayerNorm source` rule; pixel counts that leave partial tiles / chunks."""
     rows = []
     for Cn, Co, n in ((12, 36, 1043), (12, 24, 300), (24, 72, 777), (24, 48, 130), (48, 144, 333), (48, 96, 257), (96, 288, 203),
-                      (96, 192, 64), (372, 1116, 99), (372, 744, 50), (36, 24, 145), (72, 12, 77), (20, 8, 35)):
+                      (96, 192, 64), (372, 1116, 99), (372, 744, 50), (36, 24, 145), (72, 12, 77), (20, 8, 35), (12, 36, 24), (24, 48, 7)):
         x = (R(n, Cn, seed=131) * 1.7 + 0.6).requires_grad_(True)
         g, b = (R(Cn, seed=132).abs() + 0.5).requires_grad_(True), (R(Cn, seed=133) * 0.3).requires_grad_(True)
         w, bias = R(Co, Cn, seed=134, scale=0.2).requires_grad_(True), R(Co, seed=135).requires_grad_(True)

@@ -175,6 +175,12 @@ def test_bench_two_ranks_through_its_own_launcher():
     assert r["config"]["global_batch"] == 16 and r["config"]["parallelism"] == "dp2", r["config"]
     assert r["allreduce"]["ranks"] == 2 and r["allreduce"]["backend"] == "gloo", r["allreduce"]
     assert r["allreduce"]["launched_before_finish"] >= 2, r["allreduce"]
+    #  at least three buckets per step, and their boundaries tile the 15.87 MB flat gradient buffer from 0 without
+    # gaps or overlap -- what the first real 8-GPU run relies on (reference gesture: /root/reference/utils/distributed_utils.py:60-70)
+    bounds = r["allreduce"]["bucket_bounds_floats"]
+    assert r["allreduce"]["buckets_per_step"] >= 3 and len(bounds) == r["allreduce"]["buckets_per_step"], r["allreduce"]
+    assert bounds[0][0] == 0 and all(b0[1] == b1[0] for b0, b1 in zip(bounds, bounds[1:])) and all(hi > lo for lo, hi in bounds), bounds
+    assert abs(bounds[-1][1] * 4 / 1e6 - r["allreduce"]["gradient_MB"]) < 0.01 and 15.8 < r["allreduce"]["gradient_MB"] < 15.95, r["allreduce"]
     assert r["value"] > 0 and abs(r["value"] - 16 * 2 / (r["ms_per_step"] * 2e-3)) < 1e-2 * r["value"]
     assert "cpu_baseline" not in r and r["roofline"]["kernel"]
 

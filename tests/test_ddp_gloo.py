@@ -63,3 +63,35 @@ def test_grad_layout_is_backward_ordered_and_aligned():
     assert L["blocks"]["output_layer"][0] == 0                        # head gradients complete first
     # 15.87 MB of fp32 gradients (3,966,566 parameters) + alignment padding
     assert 3966566 <= L["total"] <= 3966566 + 4 * len(L["order"])
+
+
+def test_default_bucket_plan_tiles_the_15_87_MB_gradient_buffer():
+    """The bucket plan of the DEFAULT model under the default reducer sizes (first bucket >= 1 MB, then >= 4 MB), without a
+    process group: blocks reported in backward-completion order must leave at least three buckets whose boundaries tile the
+    15.87 MB flat buffer from 0 without gaps -- the plan the first 8-GPU run will execute (reference
+    gesture /root/reference/utils/distributed_utils.py:60-70)."""
+    from lm_net_amd import LM_Net
+    from lm_net_amd.ddp import GradReducer
+
+    class Plan(GradReducer):
+        def _launch(self):                      # record the bucket instead of calling the backend
+            lo, hi = self.pending_lo, self.pending_hi
+            if hi > lo:
+                self.launched.append((lo, hi))
+                self.pending_lo = hi
+
+    m = LM_Net(3, 2)
+    L = m._ensure_grad_layout()
+    red = Plan()
+    red.world = 2
+    flat = torch.zeros(L["total"])
+    red.begin(flat)
+    for name, (lo, hi) in L["blocks"].items():
+        red.ready(lo, hi)
+    red.launched_before_finish = len(red.launched)
+    red._launch()
+    b = red.launched
+    assert len(b) >= 3 and red.launched_before_finish >= 2, b
+    assert b[0][0] == 0 and b[-1][1] == L["total"] and all(x[1] == y[0] for x, y in zip(b, b[1:])), b
+    assert 15.8e6 < L["total"] * 4 < 15.95e6, L["total"]
+    assert (b[0][1] - b[0][0]) * 4 >= 1 << 20 and all((hi - lo) * 4 >= 4 << 20 for lo, hi in b[1:-1]), b
