@@ -305,14 +305,22 @@ def cpu_baseline(H, W, threads=16, budget_s=25.0):
         "n, t0 = 0, time.time()\n"
         "while n < 1 or (time.time() - t0 + warm < %f and n < 8):\n"
         "    step(); n += 1\n"
-        "print(json.dumps({'n': n, 'dt': time.time() - t0, 'B': B}))\n"
-    ) % (ROOT, threads, H, W, budget_s * 0.6)
+        "r = {'n': n, 'dt': time.time() - t0, 'B': B}\n"
+        "# SURVEY 8d's batch (8) once, beside the bounded batch-2 sample (VERDICT r4 item 7): one untimed + one timed step\n"
+        "B8 = 8; x, y = make_batch(B8, %d, %d, 'cpu', 98)\n"
+        "if time.time() - t0 + warm < %f:\n"
+        "    step(); t1 = time.time(); step(); r['b8_dt'] = time.time() - t1\n"
+        "print(json.dumps(r))\n"
+    ) % (ROOT, threads, H, W, budget_s * 0.6, H, W, budget_s * 1.2)
     try:
         out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=budget_s * 4, cwd=ROOT)
         r = json.loads(out.stdout.strip().splitlines()[-1])
-        return {"value": round(r["B"] * r["n"] / r["dt"], 3), "unit": "images/sec", "cores": threads, "kind": "port",
-                "sample": "%d train steps (fwd + CE/Dice + bwd + AdamW), batch %d, %dx%d, fp32, PyTorch-CPU oracle "
-                          "(oracle/lmnet_ref.py), %d threads of %d host cores" % (r["n"], r["B"], H, W, threads, os.cpu_count() or 0)}
+        res = {"value": round(r["B"] * r["n"] / r["dt"], 3), "unit": "images/sec", "cores": threads, "kind": "port",
+               "sample": "%d train steps (fwd + CE/Dice + bwd + AdamW), batch %d, %dx%d, fp32, PyTorch-CPU oracle "
+                         "(oracle/lmnet_ref.py), %d threads of %d host cores" % (r["n"], r["B"], H, W, threads, os.cpu_count() or 0)}
+        if r.get("b8_dt"):
+            res["value_batch8"] = round(8 / r["b8_dt"], 3)      # one train step at SURVEY 8d's batch 8, same threads
+        return res
     except Exception as e:  # never lose the GPU measurement because the CPU leg misbehaved
         return {"value": None, "unit": "images/sec", "cores": threads, "kind": "port", "sample": "failed: %s" % str(e)[:200]}
 

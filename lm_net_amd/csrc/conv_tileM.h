@@ -131,27 +131,38 @@ __global__ __launch_bounds__(256) void conv_tileM_kernel(const ConvParams P) {
       const lmn_src_t& S0 = A.src[0];
       const int C4 = S0.C >> 2;
       const float invC = 1.f / (float)S0.C;
-      for (int p = tid >> 1; p < P.XH * P.XW; p += 128) {
-        const int h = tid & 1;
-        const int r = (int)__umulhi((uint32_t)p, P.mXW), c = p - r * P.XW;
+      // tpp threads per pixel (a power of two: 256 / the tile's pixel count rounded up to one, at most 64): a thread walks every
+      // tpp-th channel quad -- at C = 372 on 32-pixel tiles 8 threads x 12 loads (two threads per pixel were 47 dependent-issue
+      // loads each: the fused GFT linears ran 24-42 us over the unfused pair)
+      const int npix = P.XH * P.XW;
+      int np2 = 4;
+      while (np2 < npix) np2 <<= 1;
+      const int tpp = 256 / np2;                       // npix <= 128: 2 .. 64
+      const int p = tid / tpp, h = tid - p * tpp;
+      {
+        const bool inp = p < npix;
+        const int ps = inp ? p : 0;
+        const int r = (int)__umulhi((uint32_t)ps, P.mXW), c = ps - r * P.XW;
         const int iy = wy0 + r, ix = wx0 + c;
-        const bool okp = (unsigned)iy < (unsigned)A.Hin && (unsigned)ix < (unsigned)A.Win;
+        const bool okp = inp && (unsigned)iy < (unsigned)A.Hin && (unsigned)ix < (unsigned)A.Win;
         const int gp = okp ? (b * A.Hin + iy) * A.Win + ix : 0;
         const TA* px = (const TA*)S0.ptr + (uint32_t)(gp * S0.cstride);
         const float x0 = ld4(px)[0];
         float sm = 0.f, sq = 0.f;
-        for (int f = h; f < C4; f += 2) {
+        for (int f = h; f < C4; f += tpp) {
           const f32x4 d = ld4(px + f * 4) - x0;
           sm += (d[0] + d[1]) + (d[2] + d[3]);
           sq += (d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3]);
         }
-        sm += __shfl_xor(sm, 1, 64);
-        sq += __shfl_xor(sq, 1, 64);
+        for (int m = tpp >> 1; m >= 1; m >>= 1) {
+          sm += __shfl_xor(sm, m, 64);
+          sq += __shfl_xor(sq, m, 64);
+        }
         const float md = sm * invC;
         float var = sq * invC - md * md;
         var = var > 0.f ? var : 0.f;
         const float mean = x0 + md, rstd = rsqrtf(var + S0.ln_eps);
-        if (h == 0) {
+        if (h == 0 && inp) {
           s_ln[2 * p] = mean;
           s_ln[2 * p + 1] = rstd;
           if (okp && blockIdx.y == 0 && S0.ln_stats) *reinterpret_cast<float2*>(S0.ln_stats + 2 * (int64_t)gp) = float2{mean, rstd};
