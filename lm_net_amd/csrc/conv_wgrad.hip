@@ -390,7 +390,12 @@ __device__ unsigned long long g_wg_timing[4096 * 6];
 #define LMN_TCLK() __builtin_amdgcn_s_memtime()
 #endif
 
-template <int NMT, int NNT, int PM>
+// UP (LMN_SRC_UP2, one source): the source tensor is the HALF-resolution map and the window is its bilinear x2 upsampling
+// (align_corners=True, lmn_up_coord: the arithmetic of lmn_up2_fwd and of the forward conv's LMN_SRC_UP2 staging).  The prefetch holds the
+// QUARTER-SIZE source window of the next tile (<= 5 x 19 / 7 x 19 pixels: 2 / 3 items per thread instead of 4 / 6); commit parks it in a
+// small LDS plane, one more block barrier, and every thread interpolates its window items LDS -> LDS (four float4 reads per item).  `up`
+// never exists in HBM: no lmn_up2_fwd launch in the backward, no second tensor of 4x the pixels.
+template <int NMT, int NNT, int PM, bool UP = false>
 __global__ __launch_bounds__(256, 3) void wgrad3_kernel(const WgradParams P) {
   static_assert(NMT * NNT == 4 || NMT * NNT == 1, "one-tile or 2 x 2-tile blocks");
   constexpr bool TS = NMT * NNT == 4;  // one output tile per wave
@@ -407,6 +412,10 @@ __global__ __launch_bounds__(256, 3) void wgrad3_kernel(const WgradParams P) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* XS = smem;                     // [NNT][XPA][CS]
   float* YS = smem + NNT * XPA * CS;    // [NMT][NPA][CS]
+  constexpr int USX = TS ? 2 : 3;       // UP: source-window items per thread (19 columns x <= 5 / 7 rows x 4 quads)
+  constexpr int SCW = 19, SPA = USX * 64;   // source window width; padded plane size in pixels
+  float* S2 = YS + NMT * NPA * CS;      // UP: [NNT][SPA][16] fp32 source window
+  (void)S2;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int q = lane >> 4, n = lane & 15;
@@ -436,7 +445,7 @@ __global__ __launch_bounds__(256, 3) void wgrad3_kernel(const WgradParams P) {
     tp_[t] = A.src[sidx].drop_p;
     tik[t] = P.inv_keep_src[sidx];
     tch0[t] = (nt - P.ntile_off[sidx]) * 16;
-    rx[t] = make_rsrc(A.src[sidx].ptr, (unsigned)((int64_t)A.B * A.Hin * A.Win * tcs[t] * ESZ));
+    rx[t] = make_rsrc(A.src[sidx].ptr, (unsigned)((int64_t)A.B * (UP ? (A.Hin >> 1) * (A.Win >> 1) : A.Hin * A.Win) * tcs[t] * ESZ));
     cx[t] = tch0[t] + j * 4 < tC[t];
   }
   const BufRsrc ry = make_rsrc(A.dy, (unsigned)((int64_t)A.B * A.Hout * A.Wout * A.dy_cstride * ESZ));
@@ -467,14 +476,37 @@ __global__ __launch_bounds__(256, 3) void wgrad3_kernel(const WgradParams P) {
 #pragma unroll
   for (int tp = 0; tp < 9; ++tp) acc[tp] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  RawT vx[UX][NNT], vy[UY][NMT];
+  RawT vx[UP ? 1 : UX][NNT], vy[UY][NMT];
+  RawT vs[UP ? USX : 1][NNT];           // UP: the source window of the next tile
   const int tpi = P.tiles_x * P.tiles_y;
+  // UP: source geometry.  hs x ws = the source map; the window rows iy0 .. iy0 + XH - 1 / columns ix0 .. ix0 + 33 of the upsampled image
+  // (clipped to it) read source rows ys0 .. and columns xs0 .. (first taps of the first clipped row / column)
+  const int hs = A.Hin >> 1, ws = A.Win >> 1;
+  const float up_sh = UP ? (float)(hs - 1) / (float)(A.Hin - 1) : 0.f, up_sw = UP ? (float)(ws - 1) / (float)(A.Win - 1) : 0.f;
+  auto src_org = [&](int iy0, int ix0, int& ys0, int& xs0) __attribute__((always_inline)) {
+    ys0 = (int)(up_sh * (float)(iy0 > 0 ? iy0 : 0));
+    xs0 = (int)(up_sw * (float)(ix0 > 0 ? ix0 : 0));
+  };
   auto issue = [&](int tile) __attribute__((always_inline)) {
     const int b = tile / tpi, tt = tile - b * tpi;
     const int ty_ = tt / P.tiles_x;
     const int oy0 = ty_ * P.TH, ox0 = (tt - ty_ * P.tiles_x) * 32;
     const int iy0 = oy0 - 1, ix0 = ox0 - 1;
     const int wpix = (b * A.Hin + iy0) * A.Win + ix0;  // window's first pixel (may lie before the tensor: wraps back below)
+    if constexpr (UP) {
+      int ys0, xs0;
+      src_org(iy0, ix0, ys0, xs0);
+#pragma unroll
+      for (int u = 0; u < USX; ++u) {
+        const int sp = u * 64 + pl, sr = sp / SCW, sc = sp - sr * SCW;
+        const bool inb = ys0 + sr < hs && xs0 + sc < ws;
+#pragma unroll
+        for (int t = 0; t < NNT; ++t) {
+          const uint32_t off = (uint32_t)((((b * hs + ys0 + sr) * ws + xs0 + sc) * tcs[t] + tch0[t] + j * 4) * ESZ);
+          vs[u][t] = raw_load<RawT>(rx[t], (inb && cx[t]) ? off : 0xffffffffu);
+        }
+      }
+    } else {
 #pragma unroll
     for (int u = 0; u < UX; ++u) {
       const int r = (int)(xrc[u] >> 16), c = (int)(xrc[u] & 0xffffu);
@@ -485,6 +517,7 @@ __global__ __launch_bounds__(256, 3) void wgrad3_kernel(const WgradParams P) {
         vx[u][t] = raw_load<RawT>(rx[t], (inb && cx[t]) ? off : 0xffffffffu);
       }
     }
+    }   // (!UP)
     const uint32_t ybase = (uint32_t)(((b * A.Hout + oy0) * A.Wout + ox0) * A.dy_cstride * ESZ);
     const bool cok = ox0 + yc < A.Wout;
     const int rlim = (A.Hout - oy0 < P.TH ? A.Hout - oy0 : P.TH) - yr0;  // rows of this tile inside the image
@@ -502,6 +535,39 @@ __global__ __launch_bounds__(256, 3) void wgrad3_kernel(const WgradParams P) {
     const int b = tile / tpi, tt = tile - b * tpi;
     const int ty_ = tt / P.tiles_x;
     const int oy0 = ty_ * P.TH, ox0 = (tt - ty_ * P.tiles_x) * 32;
+    if constexpr (UP) {
+      // the quarter-size source window -> S2 (fp32), barrier, then the window items by interpolation
+#pragma unroll
+      for (int t = 0; t < NNT; ++t)
+#pragma unroll
+        for (int u = 0; u < USX; ++u) *reinterpret_cast<f32x4*>(&S2[((t * SPA) + u * 64 + pl) * 16 + j * 4]) = raw_f32(vs[u][t]);
+      __syncthreads();
+      const int iy0 = oy0 - 1, ix0 = ox0 - 1;
+      int ys0, xs0;
+      src_org(iy0, ix0, ys0, xs0);
+#pragma unroll
+      for (int u = 0; u < UX; ++u) {
+        const int r = (int)(xrc[u] >> 16), c = (int)(xrc[u] & 0xffffu);
+        const int iy = iy0 + r, ix = ix0 + c;
+        const bool inb = (unsigned)iy < (unsigned)A.Hin && (unsigned)ix < (unsigned)A.Win;
+        int y0, yp, x0, xp;
+        float ly0, ly1, lx0, lx1;
+        lmn_up_coord(inb ? iy : 0, hs, up_sh, y0, yp, ly0, ly1);
+        lmn_up_coord(inb ? ix : 0, ws, up_sw, x0, xp, lx0, lx1);
+        const int l00 = inb ? (y0 - ys0) * SCW + (x0 - xs0) : 0;
+#pragma unroll
+        for (int t = 0; t < NNT; ++t) {
+          const float* sp = &S2[(t * SPA + l00) * 16 + j * 4];
+          const f32x4 v00 = *reinterpret_cast<const f32x4*>(sp), v01 = *reinterpret_cast<const f32x4*>(sp + xp * 16);
+          const f32x4 v10 = *reinterpret_cast<const f32x4*>(sp + yp * SCW * 16), v11 = *reinterpret_cast<const f32x4*>(sp + (yp * SCW + xp) * 16);
+          f32x4 w = ly0 * (lx0 * v00 + lx1 * v01) + ly1 * (lx0 * v10 + lx1 * v11);   // (the expression of up2_fwd_kernel)
+          if (!inb) w = f32x4{0.f, 0.f, 0.f, 0.f};
+          float* dst = xl + (t * XPA + u * 64) * CS;
+          if constexpr (BF) *reinterpret_cast<uint2*>(dst) = pk4_bf16(w);
+          else *reinterpret_cast<f32x4*>(dst) = w;
+        }
+      }
+    } else {
 #pragma unroll
     for (int t = 0; t < NNT; ++t) {
       const bool tf = tflags[t] != 0 || tscale[t] != nullptr;  // block-uniform
@@ -531,6 +597,7 @@ __global__ __launch_bounds__(256, 3) void wgrad3_kernel(const WgradParams P) {
         else *reinterpret_cast<f32x4*>(dst) = w;
       }
     }
+    }   // (!UP)
 #pragma unroll
     for (int m = 0; m < NMT; ++m) {
 #pragma unroll
@@ -1304,7 +1371,10 @@ __global__ __launch_bounds__(1024) void wgrad_reduce_batch_kernel(const lmn_redu
 // without being instantiated)
 template <int M, int N, int PM>
 static void wgrad3_launch(dim3 grid, size_t shmem, hipStream_t st, const WgradParams& P) {
-  if constexpr (M * N == 4 || M * N == 1) LMN_LAUNCH((wgrad3_kernel<M, N, PM>), grid, dim3(256), shmem, st, P);
+  if constexpr (M * N == 4 || M * N == 1) {
+    if (P.a.src[0].flags & LMN_SRC_UP2) LMN_LAUNCH((wgrad3_kernel<M, N, PM, true>), grid, dim3(256), shmem, st, P);
+    else LMN_LAUNCH((wgrad3_kernel<M, N, PM>), grid, dim3(256), shmem, st, P);
+  }
 }
 
 extern "C" {
@@ -1503,10 +1573,19 @@ static int wgrad_setup(const lmn_wgrad_args_t& A, WgradParams& P, WgGeom& G) {
             P.XH * P.XW * 4 <= (NMT * NNT == 1 ? 6 : 4) * 256 && P.TH * P.TW * 4 <= (NMT * NNT == 1 ? 4 : 2) * 256 &&
             (int64_t)A.B * A.Hout * A.Wout * A.dy_cstride * esz < 0xfffffff0LL;
   for (int s = 0; s < A.nsrc; ++s) v1 = v1 && (int64_t)A.B * A.Hin * A.Win * A.src[s].cstride * esz < 0xfffffff0LL;
+  bool up2 = false;
+  for (int s = 0; s < A.nsrc; ++s) up2 = up2 || (A.src[s].flags & LMN_SRC_UP2) != 0;
   if (v1) {  // padded planes: [tile][UX * 64 pixels][CS dwords]
     const int ux = NMT * NNT == 1 ? 6 : 4, uy = NMT * NNT == 1 ? 4 : 2, cs = bf ? 12 : 16;
     lds_floats = (int64_t)(NNT * ux + NMT * uy) * 64 * cs;
+    if (up2) lds_floats += (int64_t)NNT * (NMT * NNT == 1 ? 3 : 2) * 64 * 16;   // the fp32 source window (LMN_SRC_UP2)
     if (NMT * NNT == 1 && lds_floats < per) lds_floats = per;
+  }
+  if (up2) {
+    LMN_REQUIRE(A.nsrc == 1 && A.ksize == 3 && A.stride == 1 && A.Hin % 2 == 0 && A.Win % 2 == 0 && !(A.src[0].flags & ~LMN_SRC_UP2) && !A.src[0].scale,
+                "conv_wgrad: LMN_SRC_UP2 belongs to single-source 3x3 stride-1 calls (Hin x Win = the upsampled size) without other source transforms");
+    LMN_REQUIRE(v1 && (P.XH + 1) / 2 + 2 <= (NMT * NNT == 1 ? 3 : 2) * 64 / 19,
+                "conv_wgrad: LMN_SRC_UP2 needs the wgrad3 form (upsampled map >= 32 wide; lmn_conv_wgrad_up2_ok says so beforehand)");
   }
   static int cap_other = -1;   // LMN_WGRAD_CAP_OTHER: K-split blocks of the other weight-gradient kernels (1x1, LDS-staged 3x3), A/B runs
   if (cap_other < 0) { const char* e = getenv("LMN_WGRAD_CAP_OTHER"); cap_other = e && atoi(e) > 0 ? atoi(e) : 512; }
@@ -1547,7 +1626,6 @@ static int wgrad_setup(const lmn_wgrad_args_t& A, WgradParams& P, WgGeom& G) {
       LMN_REQUIRE(A.src[s].ln_gamma && A.src[s].ln_beta && A.src[s].ln_stats, "conv_wgrad: LMN_SRC_LN needs ln_gamma / ln_beta and the ln_stats table of the forward conv");
       LMN_REQUIRE(!(A.src[s].flags & ~LMN_SRC_LN) && !A.src[s].scale, "conv_wgrad: LMN_SRC_LN does not combine with other source transforms");
     }
-    LMN_REQUIRE(!(A.src[s].flags & LMN_SRC_UP2), "conv_wgrad: LMN_SRC_UP2 is not built into this kernel family yet");
   }
   return 0;
 }

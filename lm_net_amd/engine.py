@@ -196,6 +196,8 @@ class Engine:
         # bilinear x2 sampled where the 3x3 conv stages its window (hip.SRC_UP2: up1..4 and the `convs` branch of the skip fusers; the
         # backward recomputes `up` for the weight gradient on the weight-gradient stream; LMN_FUSE_UP=0: lmn_up2_fwd in the forward)
         self.fuse_up = os.environ.get("LMN_FUSE_UP", "1") != "0"
+        # ... and in the weight gradient's staging (LMN_FUSE_UP_WGRAD=0: `up` recomputed on the weight-gradient stream, A/B runs)
+        self.fuse_up_wgrad = os.environ.get("LMN_FUSE_UP_WGRAD", "1") != "0"
 
     def pm(self):
         """precision mode of the pass: 0 fp32, 1 bf16 MFMA operands on fp32 storage, 2 bf16 storage + bf16 operands."""
@@ -762,12 +764,16 @@ class Engine:
         self.conv([dict(view=x, flags=hip.SRC_UP2)], conv.weight, conv.bias, out, Hin=2 * h, Win=2 * w, k=3, **kw)
 
     def conv3_up_bwd(self, conv, x, dy, dx_small, tmp_ok=True):
-        """Backward of conv3_up_fwd.  Weight gradient: `up` is recomputed on the weight-gradient stream right before the launch
-        (off the compute chain; the forward kept nothing), then the plain 3x3 weight gradient.  Data gradient: dup = conv^T(dy),
-        dx = bilinear_x2^T(dup) into dx_small (written, not accumulated)."""
+        """Backward of conv3_up_fwd.  Weight gradient: the 3x3 weight gradient with the same on-load sampling (maps >= 32 wide);
+        smaller maps recompute `up` on the weight-gradient stream right before the launch (off the compute chain; the forward kept
+        nothing).  Data gradient: dup = conv^T(dy), dx = bilinear_x2^T(dup) into dx_small (written, not accumulated)."""
         B, h, w, C = x.shape
-        up = _A(x, B, 2 * h, 2 * w, C)
-        self.wgrad([up], dy, conv.weight, conv.bias, Hin=2 * h, Win=2 * w, k=3, pre=lambda: hip.up2_fwd(x, up), keep=(x, up))
+        if self.fuse_up_wgrad and 2 * w >= 32:
+            # the weight gradient samples the upsampling where it stages its window too (wgrad3_kernel<..., UP>: maps >= 32 wide)
+            self.wgrad([dict(view=x, flags=hip.SRC_UP2)], dy, conv.weight, conv.bias, Hin=2 * h, Win=2 * w, k=3)
+        else:
+            up = _A(x, B, 2 * h, 2 * w, C)
+            self.wgrad([up], dy, conv.weight, conv.bias, Hin=2 * h, Win=2 * w, k=3, pre=lambda: hip.up2_fwd(x, up), keep=(x, up))
         dup = _A(x, B, 2 * h, 2 * w, C)
         self.conv_T(dy, conv.weight, dup, Hin=2 * h, Win=2 * w, k=3)
         hip.up2_bwd(dup, dx_small)

@@ -783,6 +783,20 @@ def check_conv_up2():
         y2 = torch.full((B, 2 * h, 2 * w, Cout), float("nan"), device=DEV)
         hip.conv_fwd([upd], wp, y2, B=B, Hin=2 * h, Win=2 * w, Hout=2 * h, Wout=2 * w, Cout=Cout, ksize=3, bias=dev(bias), residual=nhwc(res))
         rows.append(("conv3x3(up2 on load) vs up2_fwd + conv" + tag, rel(y, y2), 2e-6))
+    # the weight gradient with the same sampling on load (wgrad3_kernel<..., UP>: upsampled maps >= 32 wide; 2x2-tile and one-tile
+    # blocks, partial tiles, K-split with and without the deferred reduction) vs fp64 autograd through F.interpolate + F.conv2d
+    for (B, h, w, Cin, Cout) in ((2, 16, 16, 24, 12), (1, 22, 37, 48, 24), (1, 17, 16, 12, 12), (2, 44, 44, 24, 12), (1, 20, 24, 192, 96), (1, 33, 18, 36, 20)):
+        x = R(B, Cin, h, w, seed=151)
+        wt = R(Cout, Cin, 3, 3, seed=152, scale=0.15).requires_grad_(True)
+        bias = R(Cout, seed=153).requires_grad_(True)
+        yr = F.conv2d(F.interpolate(x, scale_factor=2, mode="bilinear", align_corners=True), wt, bias, padding=1)
+        dy = R(*yr.shape, seed=154)
+        yr.backward(dy)
+        dW, db = torch.zeros(Cout, Cin, 3, 3, device=DEV), torch.zeros(Cout, device=DEV)
+        hip.conv_wgrad([dict(view=nhwc(x), flags=hip.SRC_UP2)], nhwc(dy), dW, db, B=B, Hin=2 * h, Win=2 * w, Hout=2 * h, Wout=2 * w, Cout=Cout, ksize=3)
+        tag = " %dx%d %d->%d" % (h, w, Cin, Cout)
+        rows.append(("wgrad3x3(up2 on load) dW" + tag, rel(dW, wt.grad), 2e-4))
+        rows.append(("wgrad3x3(up2 on load) db" + tag, rel(db, bias.grad), 2e-4))
     return rows
 
 
