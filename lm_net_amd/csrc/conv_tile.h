@@ -347,10 +347,7 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(const ConvParams P) {
             }
           }
         } else {
-#ifndef LMN_CT_SU9
-#define LMN_CT_SU9 4
-#endif
-        constexpr int SU = TAPS == 1 ? 2 : LMN_CT_SU9;  // items per thread and round.  1x1: four in flight cost the epilogue-heavy instances a wave per
+        constexpr int SU = TAPS == 1 ? 2 : 4;  // items per thread and round.  1x1: four in flight cost the epilogue-heavy instances a wave per
                                                // SIMD; two (+6 VGPRs, same occupancy bracket for all but <1,3,0>) halve the 4-6 serial round
                                                // trips of the 24-48 channel layers: +0.3 % fp32 batch 8, +1.6 % bf16 batch 64
         for (int i0 = 0; i0 < nitems; i0 += SU * 256) {

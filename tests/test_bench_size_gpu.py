@@ -101,7 +101,7 @@ def test_multi_stream_equals_serial_at_bench_size(cfg, serial, names):
 def test_multi_stream_equals_serial_in_bf16(names):
     """The same check in the bf16 mode (BASELINE configs[2] arithmetic: bf16 storage + bf16 MFMA operands), four repetitions of the
     four-stream schedule against one serial run.  This is the check that found the cross-kernel corruption by
-    v_mfma_f32_16x16x32_bf16 (csrc/conv_mfma.hip, mfma_bf16x2): with that instruction in the 3x3 conv / weight-gradient kernels about
+    v_mfma_f32_16x16x32_bf16 (csrc/conv_common.h, mfma_bf16x2): with that instruction in the 3x3 conv / weight-gradient kernels about
     every second repetition came out with ~1 % errors in the gradients of one attention block and of the encoder behind it -- inside
     the bf16 tolerances of the oracle comparisons, visible only bit for bit."""
     from lm_net_amd import hip

@@ -1,7 +1,7 @@
 #!/bin/bash
 R=$GRAFT_REPO_ROOT; cd $R
-bash tools/collect_profiles.sh r05n > $R/gpurun_out/r05n_collect.log 2>&1
-O=$R/gpurun_out/r05n
+bash tools/collect_profiles.sh r05p > $R/gpurun_out/r05p_collect.log 2>&1
+O=$R/gpurun_out/r05p
 timeout 200 python tools/gpu_step_timeline.py --steps 3 > $O/step_timeline.txt 2>&1
 timeout 200 python tools/gpu_prof_step.py --serial --top 200 > $O/serial_kernels.txt 2>&1
 timeout 200 python tools/gpu_prof_step.py --serial --layers --top 80 > $O/serial_layers.txt 2>&1
