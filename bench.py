@@ -558,7 +558,7 @@ def main():
     # statistics passes of row A2 declare zero bytes (extra passes add time, not algorithmic bytes), so a roofline
     # fraction of theirs would be 0 by construction; when one of them has the largest share it is named in
     # roofline.largest_share_without_algorithmic_cost, and its time counts fully against row_A2.
-    costed = [kv for kv in ranked if kv[1]["flops"] > 0 or kv[1]["bytes"] > 0]
+    costed = [kv for kv in ranked if (kv[1]["bytes"] > 0 if kv[0].startswith(HBM_ROWS) else (kv[1]["flops"] > 0 or kv[1]["bytes"] > 0))]   # (byte-bound rows: declared BYTES)
     dominant = (costed or ranked)[0][0]
     zero_cost_top = ranked[0][0] if ranked[0][0] != dominant else None
     watch = [dominant] + [k for k in survey if k.startswith(("dw_", "na_")) or "wgrad_reduce" in k]
