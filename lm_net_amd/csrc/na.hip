@@ -806,16 +806,32 @@ __global__ __launch_bounds__(512) void na_bwd_fused_kernel(const TA* __restrict_
       for (int n = 0; n < 9; ++n) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) p[n][k] = __builtin_amdgcn_exp2f(p[n][k] - mx[k]);
+#ifdef LMN_NA_EXPNOP     // experiment build: the same for the v_exp_f32 results
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_nop 7\n\ts_nop 7" : "+v"(p[n][0]), "+v"(p[n][1]), "+v"(p[n][2]), "+v"(p[n][3]));
+        __builtin_amdgcn_sched_barrier(0);
+#endif
         den += p[n];
       }
       f32x4 dsum = f32x4{0.f, 0.f, 0.f, 0.f}, rden, lse;   // lse in base 2 as well
 #pragma unroll
       for (int k = 0; k < 4; ++k) { rden[k] = __builtin_amdgcn_rcpf(den[k]); lse[k] = mx[k] + __builtin_amdgcn_logf(den[k]); }
+#ifdef LMN_NA_TRANSNOP   // experiment build (make x2na): the v_rcp_f32 / v_log_f32 results have 16 idle cycles to land before their first reader
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("s_nop 7\n\ts_nop 7" : "+v"(rden[0]), "+v"(rden[1]), "+v"(rden[2]), "+v"(rden[3]));
+      __builtin_amdgcn_sched_barrier(0);
+#endif
 #pragma unroll
       for (int n = 0; n < 9; ++n) {
         p[n] = p[n] * rden;
         dsum += p[n] * dp[n];
       }
+#ifdef LMN_NA_MEMBAR   // experiment build (make x2na): ONLY the compiler barrier of the debug block below -- does the changed schedule alone hide the failure?
+      asm volatile("" ::: "memory");
+#endif
+#ifdef LMN_NA_WAIT0    // experiment build: every outstanding memory operation of the item has landed before the statistics leave
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#endif
 #ifdef LMN_NA_DBG
       {   // debug build (tools/gpu_x2_canary.py): read dO and the v window AGAIN and rebuild dsum -- which operand moved?
         asm volatile("" ::: "memory");
