@@ -48,7 +48,7 @@ extern "C" {
 
 typedef void* lmn_stream_t; /* hipStream_t */
 
-#define LMN_ABI_VERSION 10
+#define LMN_ABI_VERSION 11
 /* arithmetic type of the matrix-core operands of a dense contraction (accumulators, epilogues, statistics: fp32) */
 #define LMN_F32 0  /* v_mfma_f32_16x16x4_f32: exact fp32 (k-ordered fma chain)                                  */
 #define LMN_BF16 1 /* v_mfma_f32_16x16x16_bf16: operands rounded to bf16 (RNE) when staged / packed -- the mixed- */
@@ -454,6 +454,15 @@ int lmn_bnact_bwd_stats(const void* z, const void* dy, const float* mean, const 
 int lmn_bnact_bwd(const void* z, const void* dy, const float* mean, const float* rstd, const float* gamma,
                   const float* beta, const float* c1, const float* c2, const float* c3, void* dz, int64_t rows,
                   int C, int act, int act_dtype, lmn_stream_t stream);
+/* The two tails with the tiny launch between statistics and application folded in (lmn_bn_fin_t):
+ * lmn_bnact_fwd_fin  fin.mode = LMN_FIN_BN: A / shift are formed from fin.sums by every block exactly as lmn_bn_finalize would (block 0
+ *                    stores mean / rstd / A / shift and blends the running statistics; fin.about must not alias fin.rmean);
+ * lmn_bnact_bwd_fin  fin.mode = LMN_FIN_BN_BWD: c1 / c2 / c3 are formed from fin.sums (the output of lmn_bnact_bwd_stats) and fin.Ain as
+ *                    lmn_bn_bwd_coef would, block 0 adds the gamma / beta gradients.  core/modules.py:83-143 (fuse_conv tails). */
+int lmn_bnact_fwd_fin(const void* z, const lmn_bn_fin_t* fin, void* y, int64_t rows, int C, int act, int act_dtype, lmn_stream_t stream);
+int lmn_bnact_bwd_fin(const void* z, const void* dy, const float* mean, const float* rstd, const float* gamma,
+                      const float* beta, const lmn_bn_fin_t* fin, void* dz, int64_t rows, int C, int act, int act_dtype,
+                      lmn_stream_t stream);
 
 /* BatchNorm bookkeeping on [C]-vectors (momentum 0.1, unbiased running var; torch semantics).
  * sums = [2][C] (sum, sumsq) over `count` elements.  Writes mean, rstd (biased var + eps),
@@ -536,8 +545,17 @@ int lmn_fill(float* p, float v, int64_t n, lmn_stream_t stream);
  *   dW_e += diag(a) R + diag(b) (W_e M + b_e m^T) + c m^T ;  db_e += a S0 + b (W_e m + N b_e) + c N
  * R [E][rows] = sum dh x^T (lmn_conv_wgrad over (x, dh)); M [rows][rows] = sum x x^T, m [rows] = sum x (lmn_conv_wgrad over (x, x),
  * issued once in the forward); coef [3][E] and hstats from lmn_reparam_fold / lmn_dw_bwd_bn.  dW [E][cin_w], db [E] (or NULL). */
+/* `se` (or NULL): the arguments of lmn_se_bwd_params of the same block -- extra thread blocks of this launch then form the squeeze-excite
+ * parameter gradients (both are small batch reductions beside the critical path: one launch instead of two per ReparamConv block). */
+typedef struct {
+  const float* dvec; const float* gsum; const float* hidden;
+  float* dw1; float* db1; float* dw2; float* db2;
+  float inv_hw;
+  int32_t B, E, R;
+} lmn_se_params_t;
 int lmn_reparam_wfin(const float* R, const float* M, const float* m, const float* coef, const float* hstats, const float* w_expand,
-                     const float* b_expand, float count, int E, int rows, int cin_w, float* dW, float* db, lmn_stream_t stream);
+                     const float* b_expand, float count, int E, int rows, int cin_w, float* dW, float* db, const lmn_se_params_t* se,
+                     lmn_stream_t stream);
 /* y[p][c] = coef[0][c] * u[p][c] + coef[1][c] * v[p][c] + coef[2][c]  over `rows` pixels of C channels (activation tensors):
  * dz = a * dh + b * z + c of the z-path (lmn_reparam_fold), materialised beside the critical path for the weight gradient.
  * rp_w: 0 = NHWC tensors, W > 0 = all three are row-planar (RP4) with image width W. */

@@ -80,6 +80,30 @@ void lmn_rec_push(std::function<int()>&& f, const char* what);
 #endif
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// Item i of the squeeze-excite parameter gradients (lmn_se_bwd_params; also run by extra blocks of lmn_reparam_wfin's launch):
+// dw2[e][r] += sum_b dt[b][e] h[b][r] | dw1[r][e] += sum_b da[b][r] m[b][e] | db2[e], db1[r] += sum_b dvec[b][.]
+__device__ __forceinline__ void lmn_se_bwd_params_item(int i, const float* __restrict__ dvec, const float* __restrict__ gsum, float inv_hw,
+                                                       const float* __restrict__ hidden, float* dw1, float* db1, float* dw2, float* db2,
+                                                       int B, int E, int R) {
+  const int ER = E * R, S = E + R;
+  if (i < ER) {
+    const int e = i / R, r = i - e * R;
+    float a = 0.f;
+    for (int b = 0; b < B; ++b) a += dvec[(int64_t)b * S + e] * hidden[(int64_t)b * R + r];
+    dw2[i] += a;
+  } else if (i < 2 * ER) {
+    const int k = i - ER, r = k / E, e = k - r * E;
+    float a = 0.f;
+    for (int b = 0; b < B; ++b) a += dvec[(int64_t)b * S + E + r] * (gsum[(int64_t)b * E + e] * inv_hw);
+    dw1[k] += a;
+  } else if (i < 2 * ER + S) {
+    const int k = i - 2 * ER;
+    float a = 0.f;
+    for (int b = 0; b < B; ++b) a += dvec[(int64_t)b * S + k];
+    if (k < E) db2[k] += a; else db1[k - E] += a;
+  }
+}
 #ifdef __HIPCC__
 // bilinear x2, align_corners=True: source coordinate of output index `dst` along an axis of `in` source samples, scale =
 // (in - 1) / (out - 1) in fp32 -- ATen's upsample_bilinear2d arithmetic: i0 = (int)(scale * dst), second tap i0 + ip, weights l0 / l1.

@@ -196,7 +196,13 @@ __global__ __launch_bounds__(256) void reparam_wfin_kernel(const float* __restri
                                                            const float* __restrict__ m, const float* __restrict__ coef,
                                                            const float* __restrict__ hstats, const float* __restrict__ we,
                                                            const float* __restrict__ be, float count, int E, int rows, int cinw,
-                                                           float* __restrict__ dW, float* __restrict__ db) {
+                                                           float* __restrict__ dW, float* __restrict__ db, const lmn_se_params_t se,
+                                                           int nw) {
+  if ((int)blockIdx.x >= nw) {   // (block-uniform) the squeeze-excite parameter gradients of the same block ride along
+    lmn_se_bwd_params_item(((int)blockIdx.x - nw) * 256 + (int)threadIdx.x, se.dvec, se.gsum, se.inv_hw, se.hidden, se.dw1, se.db1, se.dw2,
+                           se.db2, se.B, se.E, se.R);
+    return;
+  }
   // 16 lanes per output element split the cinw-long dot product (one thread per element was a chain of up to 192 dependent
   // L2 round trips: 24 us per launch, 16 launches per step)
   const int i = (blockIdx.x * 256 + threadIdx.x) >> 4, sub = threadIdx.x & 15;
@@ -625,12 +631,23 @@ int lmn_reparam_fold(const float* hstats, const float* mean, const float* rstd, 
 }
 
 int lmn_reparam_wfin(const float* R, const float* M, const float* m, const float* coef, const float* hstats, const float* w_expand,
-                     const float* b_expand, float count, int E, int rows, int cin_w, float* dW, float* db, lmn_stream_t stream) {
-  LMN_REC(lmn_reparam_wfin(R, M, m, coef, hstats, w_expand, b_expand, count, E, rows, cin_w, dW, db, stream));
+                     const float* b_expand, float count, int E, int rows, int cin_w, float* dW, float* db, const lmn_se_params_t* se,
+                     lmn_stream_t stream) {
+  lmn_se_params_t sp;
+  memset(&sp, 0, sizeof(sp));
+  if (se) sp = *se;
+  const bool has_se = se != nullptr;
+  if (g_lmn_rec) lmn_rec_push([=]() -> int { return lmn_reparam_wfin(R, M, m, coef, hstats, w_expand, b_expand, count, E, rows, cin_w, dW, db, has_se ? &sp : nullptr, stream); }, "lmn_reparam_wfin(");
   LMN_REQUIRE(R && M && m && coef && hstats && w_expand && b_expand && dW && E > 0 && rows >= cin_w && cin_w > 0 && count > 0.f,
               "reparam_wfin: bad argument");
-  LMN_LAUNCH(reparam_wfin_kernel, dim3(lmn_cdiv((int64_t)E * (cin_w + 1), 16)), dim3(256), 0, (hipStream_t)stream, R, M, m, coef,
-             hstats, w_expand, b_expand, count, E, rows, cin_w, dW, db);
+  int nse = 0;
+  if (has_se) {
+    LMN_REQUIRE(sp.dvec && sp.gsum && sp.hidden && sp.dw1 && sp.db1 && sp.dw2 && sp.db2 && sp.B > 0 && sp.E > 0 && sp.R > 0, "reparam_wfin: bad squeeze-excite argument");
+    nse = (int)lmn_cdiv(2 * (int64_t)sp.E * sp.R + sp.E + sp.R, 256);
+  }
+  const int nw = (int)lmn_cdiv((int64_t)E * (cin_w + 1), 16);
+  LMN_LAUNCH(reparam_wfin_kernel, dim3(nw + nse), dim3(256), 0, (hipStream_t)stream, R, M, m, coef,
+             hstats, w_expand, b_expand, count, E, rows, cin_w, dW, db, sp, nw);
   return lmn_launch_status("reparam_wfin");
 }
 

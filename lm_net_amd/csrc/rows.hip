@@ -158,6 +158,44 @@ __global__ __launch_bounds__(256) void bnact_fwd_kernel(const T* __restrict__ z,
   }
 }
 
+// The same with the BatchNorm finalize inside (lmn_bn_fin_t, LMN_FIN_BN: lmn_bn_finalize arithmetic): every block forms A / shift of
+// all C channels in LDS before its loop; block 0 also stores mean / rstd / A / shift and blends the running statistics (F.about must
+// not alias F.rmean: other blocks still read it).  One launch instead of two behind the statistics-writing conv of the skip fusers.
+template <typename T>
+__global__ __launch_bounds__(256) void bnact_fwd_fin_kernel(const T* __restrict__ z, const lmn_bn_fin_t F, T* __restrict__ y, int64_t n4,
+                                                            int C4, int act) {
+  extern __shared__ __attribute__((aligned(16))) float ab[];   // [2][C]
+  const int C = C4 * 4;
+  for (int c = threadIdx.x; c < C; c += 256) {
+    double s0 = 0.0, s1 = 0.0;
+    for (int r = 0; r < F.nrep; ++r) { s0 += (double)F.sums[r * 2 * C + c]; s1 += (double)F.sums[r * 2 * C + C + c]; }
+    const double md = s0 / (double)F.count;
+    float var = (float)(s1 / (double)F.count - md * md);  // biased
+    var = var > 0.f ? var : 0.f;
+    const float m = (float)md + (F.about ? F.about[c] : 0.f);
+    const float rs = rsqrtf(var + F.eps);
+    const float a = F.gamma[c] * rs, sh = F.beta[c] - m * a;
+    ab[c] = a; ab[C + c] = sh;
+    if (blockIdx.x == 0) {
+      if (F.mean) F.mean[c] = m;
+      if (F.rstd) F.rstd[c] = rs;
+      if (F.A) F.A[c] = a;
+      if (F.shift) F.shift[c] = sh;
+      if (F.rmean) F.rmean[c] = (1.f - F.momentum) * F.rmean[c] + F.momentum * m;
+      if (F.rvar) F.rvar[c] = (1.f - F.momentum) * F.rvar[c] + F.momentum * var * (F.count > 1.f ? F.count / (F.count - 1.f) : 1.f);
+    }
+  }
+  __syncthreads();
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+    const int c = (int)(i % C4) * 4;
+    const f32x4 v = ld4(z + i * 4), aa = *reinterpret_cast<const f32x4*>(&ab[c]), bb = *reinterpret_cast<const f32x4*>(&ab[C + c]);
+    f32x4 o;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) o[k] = lmn_act(v[k] * aa[k] + bb[k], act);
+    st4(y + i * 4, o);
+  }
+}
+
 // Block-level sum of per-thread partials whose owner pattern is "thread t holds channel quad t % C4 of pixel slot t / C4"
 // (C4 need not be a power of two, so no DPP tree): the NV float4 partials of every thread are parked in LDS ([NV*4][256]) and
 // summed in two short chains (G groups of slots, then the G group sums) -- LDS atomics on the 4*C4 addresses serialised the
@@ -199,7 +237,7 @@ __global__ __launch_bounds__(256) void chan_kernel(const T* __restrict__ z, cons
                                                    const float* __restrict__ gamma, const float* __restrict__ beta,
                                                    const float* __restrict__ c1, const float* __restrict__ c2,
                                                    const float* __restrict__ c3, void* __restrict__ out_,
-                                                   int64_t rows, int C, int cstride, int act, int det) {
+                                                   int64_t rows, int C, int cstride, int act, int det, const lmn_bn_fin_t F) {
   float* out = reinterpret_cast<float*>(out_);   // MODE 0 / 2: fp32 statistics; MODE 1: the activation tensor dz
   T* out_act = reinterpret_cast<T*>(out_);
   extern __shared__ float red[];  // [2][C] (MODE 0), [C] (MODE 2)
@@ -212,7 +250,22 @@ __global__ __launch_bounds__(256) void chan_kernel(const T* __restrict__ z, cons
     const int c = (tid % C4) * 4;
     f32x4 mu = s0, rs = s0, ga = s0, be = s0, k1 = s0, k2 = s0, k3 = s0;
     if (MODE != 2) { mu = ld4(mean + c); rs = ld4(rstd + c); ga = ld4(gamma + c); be = ld4(beta + c); }
-    if (MODE == 1) { k1 = ld4(c1 + c); k2 = ld4(c2 + c); k3 = ld4(c3 + c); }
+    if (MODE == 1) {
+      if (F.mode == LMN_FIN_BN_BWD) {   // (uniform) c1 / c2 / c3 formed here from the statistics pass's sums (lmn_bn_bwd_coef arithmetic)
+        f32x4 S0 = s0, S1 = s0;
+        for (int r = 0; r < F.nrep; ++r) { S0 += ld4(F.sums + r * 2 * C + c); S1 += ld4(F.sums + r * 2 * C + C + c); }
+        k1 = ld4(F.Ain + c);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          k2[k] = F.batch_stats ? k1[k] * S0[k] / F.count : 0.f;
+          k3[k] = F.batch_stats ? k1[k] * S1[k] / F.count : 0.f;
+        }
+        if (blockIdx.x == 0 && tid < C4) {   // one writer per channel quad
+          if (F.dgamma) { f32x4 g = ld4(F.dgamma + c); g += S1; *reinterpret_cast<f32x4*>(F.dgamma + c) = g; }
+          if (F.dbeta) { f32x4 g = ld4(F.dbeta + c); g += S0; *reinterpret_cast<f32x4*>(F.dbeta + c) = g; }
+        }
+      } else { k1 = ld4(c1 + c); k2 = ld4(c2 + c); k3 = ld4(c3 + c); }
+    }
     for (int64_t row = (int64_t)blockIdx.x * rpb + tid / C4; row < rows; row += (int64_t)gridDim.x * rpb) {
       if (MODE == 2) {
         s0 += ld4(z + row * cstride + c);
@@ -416,24 +469,7 @@ __global__ __launch_bounds__(256) void se_bwd_dm_kernel(const float* __restrict_
 __global__ __launch_bounds__(256) void se_bwd_params_kernel(const float* __restrict__ dvec, const float* __restrict__ gsum,
                                                             float inv_hw, const float* __restrict__ hidden, float* dw1,
                                                             float* db1, float* dw2, float* db2, int B, int E, int R) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  const int ER = E * R, S = E + R;
-  if (i < ER) {  // dw2[e][r] += sum_b dt[b][e] * h[b][r]
-    const int e = i / R, r = i - e * R;
-    float a = 0.f;
-    for (int b = 0; b < B; ++b) a += dvec[(int64_t)b * S + e] * hidden[(int64_t)b * R + r];
-    dw2[i] += a;
-  } else if (i < 2 * ER) {  // dw1[r][e] += sum_b da[b][r] * m[b][e]
-    const int k = i - ER, r = k / E, e = k - r * E;
-    float a = 0.f;
-    for (int b = 0; b < B; ++b) a += dvec[(int64_t)b * S + E + r] * (gsum[(int64_t)b * E + e] * inv_hw);
-    dw1[k] += a;
-  } else if (i < 2 * ER + S) {  // db2[e] | db1[r]
-    const int k = i - 2 * ER;
-    float a = 0.f;
-    for (int b = 0; b < B; ++b) a += dvec[(int64_t)b * S + k];
-    if (k < E) db2[k] += a; else db1[k - E] += a;
-  }
+  lmn_se_bwd_params_item(blockIdx.x * 256 + threadIdx.x, dvec, gsum, inv_hw, hidden, dw1, db1, dw2, db2, B, E, R);
 }
 
 // ------------------------------------------------------------------------------------ bilinear x2, align_corners=True
@@ -990,6 +1026,19 @@ int lmn_bnact_fwd(const void* z, const float* a, const float* b, void* y, int64_
   return lmn_launch_status("bnact_fwd");
 }
 
+int lmn_bnact_fwd_fin(const void* z, const lmn_bn_fin_t* fin, void* y, int64_t rows, int C, int act, int act_dtype, lmn_stream_t stream) {
+  LMN_REQUIRE(fin && fin->mode == LMN_FIN_BN, "bnact_fwd_fin: fin.mode must be LMN_FIN_BN");
+  const lmn_bn_fin_t F = *fin;
+  if (g_lmn_rec) lmn_rec_push([=]() -> int { return lmn_bnact_fwd_fin(z, &F, y, rows, C, act, act_dtype, stream); }, "lmn_bnact_fwd_fin(");
+  LMN_REQUIRE_DT(act_dtype, "bnact_fwd_fin");
+  LMN_REQUIRE(z && y && rows > 0 && C > 0 && C % 4 == 0 && C <= 4096, "bnact_fwd_fin: bad argument");
+  LMN_REQUIRE(F.sums && F.gamma && F.beta && F.nrep >= 1 && F.count > 0.f, "bnact_fwd_fin: fin needs sums / gamma / beta / nrep / count");
+  LMN_REQUIRE(!F.about || !F.rmean || F.about != F.rmean, "bnact_fwd_fin: fin.about must not alias fin.rmean (pass the statistics pass's snapshot)");
+  const int64_t n4 = rows * (C / 4);
+  LMN_ACT_DISPATCH(act_dtype, LMN_LAUNCH((bnact_fwd_fin_kernel<T>), dim3(grid_for(n4)), dim3(256), (size_t)2 * C * sizeof(float), (hipStream_t)stream, (const T*)z, F, (T*)y, n4, C / 4, act));
+  return lmn_launch_status("bnact_fwd_fin");
+}
+
 int lmn_bnact_bwd_stats(const void* z, const void* dy, const float* mean, const float* rstd, const float* gamma,
                         const float* beta, float* stats, int64_t rows, int C, int act, int act_dtype, lmn_stream_t stream) {
   LMN_REC(lmn_bnact_bwd_stats(z, dy, mean, rstd, gamma, beta, stats, rows, C, act, act_dtype, stream));
@@ -1006,7 +1055,7 @@ int lmn_bnact_bwd_stats(const void* z, const void* dy, const float* mean, const 
     LMN_REQUIRE(sd, "bnact_bwd_stats: deterministic mode: no scratch");
   }
   LMN_ACT_DISPATCH(act_dtype, LMN_LAUNCH((chan_kernel<0, T>), dim3(grid), dim3(256), chan_shmem(C),
-                     st, (const T*)z, (const T*)dy, mean, rstd, gamma, beta, nullptr, nullptr, nullptr, (void*)sd, rows, C, C, act, g_lmn_det));
+                     st, (const T*)z, (const T*)dy, mean, rstd, gamma, beta, nullptr, nullptr, nullptr, (void*)sd, rows, C, C, act, g_lmn_det, lmn_bn_fin_t{}));
   if (g_lmn_det) lmn_det_sum(st, sd, grid, (int64_t)2 * C, stats);
   return lmn_launch_status("bnact_bwd_stats");
 }
@@ -1020,8 +1069,23 @@ int lmn_bnact_bwd(const void* z, const void* dy, const float* mean, const float*
   LMN_REQUIRE(C % 4 == 0 && C >= 4 && C <= 1024, "bnact_bwd: C=%d", C);
   const int rpb = 256 / (C / 4);
   LMN_ACT_DISPATCH(act_dtype, LMN_LAUNCH((chan_kernel<1, T>), dim3(grid_for(rows, rpb * 4, 4096)), dim3(256), chan_shmem(C),
-                     (hipStream_t)stream, (const T*)z, (const T*)dy, mean, rstd, gamma, beta, c1, c2, c3, dz, rows, C, C, act, 0));
+                     (hipStream_t)stream, (const T*)z, (const T*)dy, mean, rstd, gamma, beta, c1, c2, c3, dz, rows, C, C, act, 0, lmn_bn_fin_t{}));
   return lmn_launch_status("bnact_bwd");
+}
+
+int lmn_bnact_bwd_fin(const void* z, const void* dy, const float* mean, const float* rstd, const float* gamma,
+                      const float* beta, const lmn_bn_fin_t* fin, void* dz, int64_t rows, int C, int act, int act_dtype,
+                      lmn_stream_t stream) {
+  LMN_REQUIRE(fin && fin->mode == LMN_FIN_BN_BWD, "bnact_bwd_fin: fin.mode must be LMN_FIN_BN_BWD");
+  const lmn_bn_fin_t F = *fin;
+  if (g_lmn_rec) lmn_rec_push([=]() -> int { return lmn_bnact_bwd_fin(z, dy, mean, rstd, gamma, beta, &F, dz, rows, C, act, act_dtype, stream); }, "lmn_bnact_bwd_fin(");
+  LMN_REQUIRE_DT(act_dtype, "bnact_bwd_fin");
+  LMN_REQUIRE(z && dy && mean && rstd && gamma && beta && dz && rows > 0 && F.sums && F.Ain && F.nrep >= 1 && F.count > 0.f, "bnact_bwd_fin: bad argument");
+  LMN_REQUIRE(C % 4 == 0 && C >= 4 && C <= 1024, "bnact_bwd_fin: C=%d", C);
+  const int rpb = 256 / (C / 4);
+  LMN_ACT_DISPATCH(act_dtype, LMN_LAUNCH((chan_kernel<1, T>), dim3(grid_for(rows, rpb * 4, 4096)), dim3(256), chan_shmem(C),
+                     (hipStream_t)stream, (const T*)z, (const T*)dy, mean, rstd, gamma, beta, nullptr, nullptr, nullptr, dz, rows, C, C, act, 0, F));
+  return lmn_launch_status("bnact_bwd_fin");
 }
 
 int lmn_colsum(const void* x, float* out, int64_t rows, int C, int cstride, int act_dtype, lmn_stream_t stream) {
@@ -1039,7 +1103,7 @@ int lmn_colsum(const void* x, float* out, int64_t rows, int C, int cstride, int 
   }
   LMN_ACT_DISPATCH(act_dtype, LMN_LAUNCH((chan_kernel<2, T>), dim3(grid), dim3(256), chan_shmem(C),
                      st, (const T*)x, (const T*)nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, (void*)sd,
-                     rows, C, cstride, 0, g_lmn_det));
+                     rows, C, cstride, 0, g_lmn_det, lmn_bn_fin_t{}));
   if (g_lmn_det) lmn_det_sum(st, sd, grid, C, out);
   return lmn_launch_status("colsum");
 }

@@ -198,6 +198,11 @@ class Engine:
         self.fuse_up = os.environ.get("LMN_FUSE_UP", "1") != "0"
         # ... and in the weight gradient's staging (LMN_FUSE_UP_WGRAD=0: `up` recomputed on the weight-gradient stream, A/B runs)
         self.fuse_up_wgrad = os.environ.get("LMN_FUSE_UP_WGRAD", "1") != "0"
+        # squeeze-excite parameter gradients in the launch of lmn_reparam_wfin (one launch instead of two per block; LMN_FUSE_SE_WFIN=0: A/B)
+        self.fuse_se_wfin = os.environ.get("LMN_FUSE_SE_WFIN", "1") != "0"
+        # skip fusers: BatchNorm finalize / backward coefficients inside the BN + GELU tails (lmn_bnact_fwd_fin / lmn_bnact_bwd_fin;
+        # LMN_FUSE_BN_TAIL=0: the lmn_bn_finalize / lmn_bn_bwd_coef launches, A/B runs)
+        self.fuse_bn_tail = os.environ.get("LMN_FUSE_BN_TAIL", "1") != "0"
 
     def pm(self):
         """precision mode of the pass: 0 fp32, 1 bf16 MFMA operands on fp32 storage, 2 bf16 storage + bf16 operands."""
@@ -651,10 +656,15 @@ class Engine:
         bst = _Z(x, 5, E)
         zp = S.get("zp")
         hip.dw_bwd_stats(x1, pre, u, sgate, dm, dpre, *ws, bst, seb=seb, zpre=zp)
+        sep = None   # squeeze-excite parameter gradients inside lmn_reparam_wfin's launch (same stream, later in this block's backward)
         if seb is not None:
             gs_, hid_ = S["gsum"], S["hid"]
-            self.side_call(x, lambda: hip.se_bwd_params(dvec, gs_, 1.0 / (H * W), hid_, G[se.fc1.weight], G[se.fc1.bias],
-                                                        G[se.fc2.weight], G[se.fc2.bias]), keep=(dvec, gs_, hid_))
+            if self.fuse_se_wfin and zp is not None and zp.get("M") is not None:
+                sep = dict(dvec=dvec, gsum=gs_, inv_hw=1.0 / (H * W), hidden=hid_, dw1=G[se.fc1.weight], db1=G[se.fc1.bias],
+                           dw2=G[se.fc2.weight], db2=G[se.fc2.bias])
+            else:
+                self.side_call(x, lambda: hip.se_bwd_params(dvec, gs_, 1.0 / (H * W), hid_, G[se.fc1.weight], G[se.fc1.bias],
+                                                            G[se.fc2.weight], G[se.fc2.bias]), keep=(dvec, gs_, hid_))
         dx1 = u  # reuse
         if zp is not None:
             # ---- z-path: the depthwise backward writes dh = dx1 * Hardswish'(A1 z + sh1) and its BatchNorm-backward sums; ONE tiny
@@ -674,8 +684,9 @@ class Engine:
                 # closed form right after the batched reduction that completes it (same stream)
                 Rw = _Z(x, E, Cin)
                 Mx, mx, gw, gb = zp["M"], zp["m"], G[ec.weight], G[ec.bias]
-                self.wgrad([x], dh, None, None, Hin=H, Win=W, dW=Rw, db=None, join=False, keep=(Rw, Mx, mx, coef, hst),
-                           after=lambda: hip.reparam_wfin(Rw, Mx, mx, coef, hst, ec.weight, ec.bias, N, gw, gb))
+                self.wgrad([x], dh, None, None, Hin=H, Win=W, dW=Rw, db=None, join=False,
+                           keep=(Rw, Mx, mx, coef, hst) + ((sep["dvec"], sep["gsum"], sep["hidden"]) if sep else ()),
+                           after=lambda: hip.reparam_wfin(Rw, Mx, mx, coef, hst, ec.weight, ec.bias, N, gw, gb, se=sep))
             else:
                 dz = dpre  # (reuse: its last reader on this stream was the depthwise backward)
                 z_ = x1
@@ -817,13 +828,25 @@ class Engine:
             hip.up2_fwd(xsm, up)
             self.conv3_fwd(m.convs[1], up, V(cat, (nb - 1) * C, C))
         z = _A(xl, B, H, W, C)
-        sums = _Z(xl, 2, C) if self.training else None
-        self.conv([cat], fconv.weight, fconv.bias, z, Hin=H, Win=W, k=3, stats=sums,
-                  stats_mode=hip.STATS_SUM_SQ if self.training else hip.STATS_NONE,
-                  p=(None, None, None, None, fbn.running_mean) if self.training else ())
-        mean, rstd, A, shift = self.bn_stats(fbn, sums, B * H * W, xl)
         y = _A(xl, B, H, W, C)
-        hip.bnact_fwd(z, A, shift, y, hip.ACT_GELU)
+        if self.training and self.fuse_bn_tail:
+            # the conv leaves its batch sums (about the running mean, whose snapshot lands behind the slice) and the BN + GELU tail
+            # finalises the BatchNorm itself (lmn_bnact_fwd_fin): no lmn_bn_finalize launch in between
+            sums = _Z(xl, 2, 2, C)
+            self.conv([cat], fconv.weight, fconv.bias, z, Hin=H, Win=W, k=3, stats=sums, stats_mode=hip.STATS_SUM_SQ, stats_rep=1,
+                      stats_snap=True, p=(None, None, None, None, fbn.running_mean))
+            mean, rstd, A, shift = (_E(xl, C) for _ in range(4))
+            fin = dict(mode=hip.FIN_BN, sums=sums, nrep=1, count=B * H * W, gamma=fbn.weight, beta=fbn.bias, eps=fbn.eps,
+                       momentum=fbn.momentum if fbn.momentum is not None else 0.1, about=sums[1, 0], mean=mean, rstd=rstd, A=A,
+                       shift=shift, rmean=fbn.running_mean, rvar=fbn.running_var)
+            hip.bnact_fwd_fin(z, fin, y, hip.ACT_GELU)
+        else:
+            sums = _Z(xl, 2, C) if self.training else None
+            self.conv([cat], fconv.weight, fconv.bias, z, Hin=H, Win=W, k=3, stats=sums,
+                      stats_mode=hip.STATS_SUM_SQ if self.training else hip.STATS_NONE,
+                      p=(None, None, None, None, fbn.running_mean) if self.training else ())
+            mean, rstd, A, shift = self.bn_stats(fbn, sums, B * H * W, xl)
+            hip.bnact_fwd(z, A, shift, y, hip.ACT_GELU)
         if cx is not None:
             cx.t[m] = dict(xs=xs_in, cat=cat, up=up, z=z, mean=mean, rstd=rstd, A=A)
         return y
@@ -840,10 +863,15 @@ class Engine:
         G = self.G
         st = _Z(z, 2, C)
         hip.bnact_bwd_stats(z, dy, S["mean"], S["rstd"], fbn.weight, fbn.bias, st, hip.ACT_GELU)
-        c1, c2, c3 = (_E(z, C) for _ in range(3))
-        hip.bn_bwd_coef(st, B * H * W, S["A"], G[fbn.weight], G[fbn.bias], c1, c2, c3, self.training)
         dz = _A(z, B, H, W, C)
-        hip.bnact_bwd(z, dy, S["mean"], S["rstd"], fbn.weight, fbn.bias, c1, c2, c3, dz, hip.ACT_GELU)
+        if self.fuse_bn_tail:   # c1 / c2 / c3 and the gamma / beta gradients inside the applying pass (lmn_bnact_bwd_fin)
+            fin = dict(mode=hip.FIN_BN_BWD, sums=st, nrep=1, count=B * H * W, batch_stats=int(self.training), Ain=S["A"],
+                       dgamma=G[fbn.weight], dbeta=G[fbn.bias])
+            hip.bnact_bwd_fin(z, dy, S["mean"], S["rstd"], fbn.weight, fbn.bias, fin, dz, hip.ACT_GELU)
+        else:
+            c1, c2, c3 = (_E(z, C) for _ in range(3))
+            hip.bn_bwd_coef(st, B * H * W, S["A"], G[fbn.weight], G[fbn.bias], c1, c2, c3, self.training)
+            hip.bnact_bwd(z, dy, S["mean"], S["rstd"], fbn.weight, fbn.bias, c1, c2, c3, dz, hip.ACT_GELU)
         self.wgrad([cat], dz, fconv.weight, fconv.bias, Hin=H, Win=W, k=3)
         nb = 3 if three else 2
         dcat = _A(z, B, H, W, nb * C)

@@ -19,7 +19,7 @@ ACT_NONE, ACT_HSWISH, ACT_GELU = 0, 1, 2
 STATS_NONE, STATS_SUM_SQ, STATS_EP = 0, 1, 2
 F32, BF16 = 0, 1            # matrix-core operand type of the dense contractions (LMN_F32 / LMN_BF16)
 _MMA = [F32]                # ... of the pass in flight (engine.begin_pass)
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 
 class SrcT(C.Structure):
@@ -125,7 +125,7 @@ class ReduceJob(C.Structure):
 SYMBOLS = [
     "lmn_abi_version", "lmn_sizeof_conv_args", "lmn_sizeof_src", "lmn_sizeof_wgrad_args", "lmn_last_error",
     "lmn_conv_pack_size", "lmn_conv_pack", "lmn_conv_pack_batch", "lmn_sizeof_pack_job", "lmn_conv_fwd", "lmn_conv_wgrad", "lmn_conv_wgrad_workspace",
-    "lmn_conv_wgrad_job", "lmn_wgrad_reduce_batch", "lmn_sizeof_reduce_job", "lmn_reparam_fold", "lmn_affine2", "lmn_reparam_wfin",
+    "lmn_conv_wgrad_job", "lmn_wgrad_reduce_batch", "lmn_sizeof_reduce_job", "lmn_reparam_fold", "lmn_affine2", "lmn_reparam_wfin", "lmn_bnact_fwd_fin", "lmn_bnact_bwd_fin",
     "lmn_dw_stats", "lmn_dw_fwd", "lmn_dw_merge", "lmn_dw_finalize_merge", "lmn_dw_bwd_stats", "lmn_dw_bwd_coef", "lmn_dw_bwd", "lmn_dw_fwd_bn", "lmn_dw_bwd_bn",
     "lmn_se_fwd", "lmn_se_bwd", "lmn_se_bwd_dm", "lmn_se_bwd_params", "lmn_na_fwd", "lmn_na_bwd", "lmn_plan_host_profile", "lmn_set_deterministic", "lmn_get_deterministic", "lmn_gattn_fwd", "lmn_gattn_bwd",
     "lmn_ln_fwd", "lmn_ln_bwd", "lmn_bnact_fwd", "lmn_bnact_bwd_stats", "lmn_bnact_bwd",
@@ -779,6 +779,23 @@ def bnact_fwd(z, a, b, y, act):
     _check(load().lmn_bnact_fwd(_pa(z), _p(a), _p(b), _pa(y), _i64(z.numel() // Cn), Cn, act, _dt(z, y), _stream()), "bnact_fwd")
 
 
+def bnact_fwd_fin(z, fin, y, act):
+    """lmn_bnact_fwd_fin: y = act(A z + shift) with A / shift formed in the kernel from the batch sums (fin: dict as for conv_fwd)."""
+    Cn = z.shape[-1]
+    f = BnFin()
+    _fill_fin(f, fin)
+    _check(load().lmn_bnact_fwd_fin(_pa(z), C.byref(f), _pa(y), _i64(z.numel() // Cn), Cn, act, _dt(z, y), _stream()), "bnact_fwd_fin")
+
+
+def bnact_bwd_fin(z, dy, mean, rstd, gamma, beta, fin, dz, act):
+    """lmn_bnact_bwd_fin: dz with c1 / c2 / c3 formed in the kernel from the sums of bnact_bwd_stats (fin: mode FIN_BN_BWD)."""
+    Cn = z.shape[-1]
+    f = BnFin()
+    _fill_fin(f, fin)
+    _check(load().lmn_bnact_bwd_fin(_pa(z), _pa(dy), _p(mean), _p(rstd), _p(gamma), _p(beta), C.byref(f), _pa(dz),
+                                    _i64(z.numel() // Cn), Cn, act, _dt(z, dy, dz), _stream()), "bnact_bwd_fin")
+
+
 def bnact_bwd_stats(z, dy, mean, rstd, gamma, beta, stats, act):
     Cn = z.shape[-1]
     _check(load().lmn_bnact_bwd_stats(_pa(z), _pa(dy), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(stats),
@@ -908,11 +925,22 @@ def reparam_fold(hstats, mean, rstd, A, count, batch_stats, w_expand, b_expand, 
                                    _p(dgamma), _p(dbeta), _MMA[0], _stream()), "reparam_fold")
 
 
-def reparam_wfin(R, M, m, coef, hstats, w_expand, b_expand, count, dW, db):
-    """lmn_reparam_wfin: expand-conv weight / bias gradient from the raw gradient R = sum dh x^T and the moments of x."""
+class SeParamsT(C.Structure):
+    _fields_ = [("dvec", C.c_void_p), ("gsum", C.c_void_p), ("hidden", C.c_void_p), ("dw1", C.c_void_p), ("db1", C.c_void_p),
+                ("dw2", C.c_void_p), ("db2", C.c_void_p), ("inv_hw", C.c_float), ("B", C.c_int32), ("E", C.c_int32), ("R", C.c_int32)]
+
+
+def reparam_wfin(R, M, m, coef, hstats, w_expand, b_expand, count, dW, db, se=None):
+    """lmn_reparam_wfin: expand-conv weight / bias gradient from the raw gradient R = sum dh x^T and the moments of x.
+    se = dict(dvec, gsum, inv_hw, hidden, dw1, db1, dw2, db2): the squeeze-excite parameter gradients of the same block in the same launch."""
     E, cinw = w_expand.shape[0], w_expand.shape[1]
+    sp = None
+    if se is not None:
+        Bn, En = se["gsum"].shape
+        sp = SeParamsT(*[_p(se[k]).value for k in ("dvec", "gsum", "hidden", "dw1", "db1", "dw2", "db2")],
+                       float(se["inv_hw"]), Bn, En, se["dw1"].shape[0])
     _check(load().lmn_reparam_wfin(_p(R), _p(M), _p(m), _p(coef), _p(hstats), _p(w_expand), _p(b_expand), _f(count), E, R.shape[1],
-                                   cinw, _p(dW), _p(db), _stream()), "reparam_wfin")
+                                   cinw, _p(dW), _p(db), C.byref(sp) if sp is not None else None, _stream()), "reparam_wfin")
 
 
 def affine2(u, v, coef, y):

@@ -630,6 +630,15 @@ def _check_se(B, E, Rr, HW):
     rows.append(("se_bwd_dm dm" + tag, rel(dm2, gs.grad), TOL))
     for nm, got, ref in (("dw1", g1[0], w1.grad), ("db1", g1[1], b1.grad), ("dw2", g1[2], w2.grad), ("db2", g1[3], b2.grad)):
         rows.append(("se_bwd_params " + nm + tag, rel(got - 0.5, ref), 2e-4))
+    # ... and riding along in lmn_reparam_wfin's launch (extra blocks; a dummy 8 x 4 expand conv in front)
+    g2 = [torch.full_like(t, 0.5) for t in (dw1, db1, dw2, db2)]
+    E0, C0 = 8, 4
+    z_ = lambda *sh: torch.zeros(*sh, device=DEV)
+    dW0, db0 = z_(E0, C0), z_(E0)
+    hip.reparam_wfin(z_(E0, C0), z_(C0, C0), z_(C0), z_(3, E0), z_(2, E0), z_(E0, C0), z_(E0), 7.0, dW0, db0,
+                     se=dict(dvec=dvec, gsum=dev(gsum), inv_hw=1.0 / HW, hidden=hid, dw1=g2[0], db1=g2[1], dw2=g2[2], db2=g2[3]))
+    same = all(torch.equal(a, b) for a, b in zip(g1, g2)) and float(dW0.abs().max()) == 0.0
+    rows.append(("se_bwd_params inside reparam_wfin == the separate launch (bitwise)" + tag, 0.0 if same else 1.0, 0.5))
     return rows
 
 
@@ -836,6 +845,29 @@ def check_bn_tail():
         dz = torch.full((n, Cn), float("nan"), device=DEV)
         hip.bnact_bwd(zd, dev(dy), mean, rstd, dev(g), dev(b), c1, c2, c3, dz, hip.ACT_GELU)
         rows.append(("bnact_bwd dz C=%d" % Cn, rel(dz, z.grad), 2e-4))
+        # the same tails with the finalize / coefficient launches inside (lmn_bnact_fwd_fin / lmn_bnact_bwd_fin): sums taken about a
+        # snapshot of the running mean, as the skip fusers' conv leaves them
+        about = dev(rm)
+        sums2 = torch.zeros(2, 2, Cn, device=DEV)
+        hip.colsum((zd - about).contiguous(), sums2[0, 0])
+        hip.colsum(((zd - about) * (zd - about)).contiguous(), sums2[0, 1])
+        sums2[1, 0] = about
+        mean2, rstd2, A2, shift2 = (torch.full((Cn,), float("nan"), device=DEV) for _ in range(4))
+        rmd2, rvd2 = dev(rm), dev(rv)
+        y2 = torch.full((n, Cn), float("nan"), device=DEV)
+        hip.bnact_fwd_fin(zd, dict(mode=hip.FIN_BN, sums=sums2, nrep=1, count=n, gamma=dev(g), beta=dev(b), eps=1e-5, momentum=0.1,
+                                   about=sums2[1, 0], mean=mean2, rstd=rstd2, A=A2, shift=shift2, rmean=rmd2, rvar=rvd2), y2, hip.ACT_GELU)
+        rows.append(("bnact_fwd_fin y C=%d" % Cn, rel(y2, y_ref), TOL))
+        rows.append(("bnact_fwd_fin running_mean C=%d" % Cn, rel(rmd2, rm_ref), TOL))
+        rows.append(("bnact_fwd_fin running_var C=%d" % Cn, rel(rvd2, rv_ref), TOL))
+        rows.append(("bnact_fwd_fin mean / rstd / A / shift vs bn_finalize C=%d" % Cn,
+                     max(rel(mean2, mean), rel(rstd2, rstd), rel(A2, A), rel(shift2, shift)), 2e-5))
+        dg2, db2 = torch.zeros(Cn, device=DEV), torch.zeros(Cn, device=DEV)
+        dz2 = torch.full((n, Cn), float("nan"), device=DEV)
+        hip.bnact_bwd_fin(zd, dev(dy), mean, rstd, dev(g), dev(b), dict(mode=hip.FIN_BN_BWD, sums=bst, nrep=1, count=n, batch_stats=1,
+                                                                         Ain=A, dgamma=dg2, dbeta=db2), dz2, hip.ACT_GELU)
+        rows.append(("bnact_bwd_fin dz == bn_bwd_coef + bnact_bwd (bitwise) C=%d" % Cn, 0.0 if torch.equal(dz2, dz) else 1.0, 0.5))
+        rows.append(("bnact_bwd_fin dgamma / dbeta C=%d" % Cn, max(rel(dg2, g.grad), rel(db2, b.grad)), 2e-4))
     return rows
 
 
