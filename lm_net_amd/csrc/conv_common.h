@@ -3,6 +3,7 @@
 // the host entry (conv_fwd.hip) calls.  The family is split over several translation units so that they compile in parallel
 // (one file took 3 min 45 s); `make timing` builds them as ONE unit (conv_unity.hip) so that the phase-clock arrays exist once.
 #pragma once
+#include <type_traits>
 #include "common.h"
 #include <stdlib.h>
 
@@ -28,7 +29,31 @@ struct ConvParams {
   LmnLay lay_src[3], lay_out, lay_aux;   // address forms of the operands (common.h: NHWC or row-planar)
   int32_t rpw;                           // image width of the row-planar operands of the call (0: none)
   uint32_t rp_magic;                     // floor(2^32 / rpw)
+  int32_t prio;                          // LMN_CONV_PRIO (experiment): > 0 = the co-resident waves of a SIMD get DISTINCT issue priorities
 };
+
+// Distinct issue priorities for the waves that share a SIMD (one wave of each co-resident block): equal-priority waves share the matrix
+// pipe round-robin, so co-resident blocks that entered their MFMA loops together also leave them together and then all stage at once
+// (phase clocks, DESIGN 5h: the pipe idles 45 % of a block's life although it is saturated inside the loops).  With a strict order the
+// highest-priority wave runs its loop at full rate and stages while the next one multiplies.
+__device__ __forceinline__ void lmn_wave_prio(int mode) {
+  uint32_t slot;
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID, 0, 4)" : "=s"(slot));   // wave slot of this wave on its SIMD
+  const uint32_t p = mode == 2 ? 3u - (slot & 3u) : (mode == 3 ? (slot & 1u) * 3u : (slot & 3u));
+  switch (p) {
+    case 0: __builtin_amdgcn_s_setprio(0); break;
+    case 1: __builtin_amdgcn_s_setprio(1); break;
+    case 2: __builtin_amdgcn_s_setprio(2); break;
+    default: __builtin_amdgcn_s_setprio(3); break;
+  }
+}
+
+#ifndef LMN_CONV_PF
+#define LMN_CONV_PF 0   // conv_tile_kernel: window of the next staging unit prefetched across the MFMA loop (experiment, DESIGN 5h: zero-sum -- the loop slows by what the staging gains, at a wave per SIMD less; -DLMN_CONV_PF=1 builds it)
+#endif
+#ifndef LMN_CONV_FAST
+#define LMN_CONV_FAST 0 // conv_tile_kernel: a copy of the staging loop without the per-item flag tests for plain sources (experiment, DESIGN 5h: no gain; -DLMN_CONV_FAST=1 builds it)
+#endif
 
 namespace {
 

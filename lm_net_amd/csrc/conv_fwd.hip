@@ -311,6 +311,7 @@ int lmn_conv_fwd(const lmn_conv_args_t* args, lmn_stream_t stream) {
   LMN_REQUIRE(!(A.transposed && A.nsrc != 1), "conv_fwd: transposed form takes one source");
   ConvParams P;
   P.det_stats = nullptr;
+  P.prio = 0;
   P.a = A;
   P.NKB = 0;
   for (int s = 0; s < 3; ++s) {
@@ -455,6 +456,11 @@ int lmn_conv_fwd(const lmn_conv_args_t* args, lmn_stream_t stream) {
     // ---- LDS-tiled kernel.  1x1: the image is a flat row of H*W pixels.
     ConvParams T = P;
     lmn_conv_args_t& a = T.a;
+    {
+      static int prio_env = -1;   // LMN_CONV_PRIO: 0 off | 1, 2, 3 = distinct issue priorities per wave slot (lmn_wave_prio); 3x3 calls only unless +10
+      if (prio_env < 0) { const char* e = getenv("LMN_CONV_PRIO"); prio_env = e ? atoi(e) : 0; }
+      T.prio = (a.ksize == 3 || prio_env >= 10) ? prio_env % 10 : 0;
+    }
     if (a.ksize == 1) {
       a.Wout *= a.Hout; a.Win *= a.Hin; a.Hout = a.Hin = 1;
     }
@@ -555,6 +561,11 @@ int lmn_conv_fwd(const lmn_conv_args_t* args, lmn_stream_t stream) {
     int blocks = T.total_tiles;
     int maxb = 1280 / tchunks > 256 ? 1280 / tchunks : 256;  // ~5 resident blocks per CU: one round of persistent blocks
     if (s2t) maxb = 320 / tchunks > 64 ? 320 / tchunks : 64;          // x 4 classes in grid.z
+    {
+      static int maxb_env = -1;   // LMN_CONV_MAXB: cap on the persistent blocks of a 3x3 call (occupancy experiments: 256 = one block per CU)
+      if (maxb_env < 0) { const char* e = getenv("LMN_CONV_MAXB"); maxb_env = e ? atoi(e) : 0; }
+      if (maxb_env > 0 && a.ksize == 3 && !s2t) maxb = maxb_env / tchunks > 1 ? maxb_env / tchunks : 1;
+    }
     if (blocks > maxb) blocks = maxb;
     // epilogue instance (see the kernel): 0 plain, 2 LINEAR+SUM_SQ, 3 BN_BWD1, 4 BN_BWD2, 5 SE_BWD, 1 everything else
     int ek = 1;

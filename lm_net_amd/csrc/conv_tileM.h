@@ -30,6 +30,7 @@ __global__ __launch_bounds__(256) void conv_tileM_kernel(const ConvParams P) {
   constexpr int KD = BF ? 8 : 16;
   constexpr int NCT = 4 * NCW;  // cout tiles per block
   const lmn_conv_args_t& A = P.a;
+  if (P.prio) lmn_wave_prio(P.prio);   // (uniform)
   const uint32_t soff = A.seed_ctr ? *A.seed_ctr : 0u;  // device-side dropout stream offset (graph replays: one bump per step)
   // EPI: 0 plain (LINEAR / AFFINE_ACT, no statistics), 1 generic, 2 LINEAR + SUM_SQ statistics, 3 BN_BWD1, 4 BN_BWD2,
   // 5 SE_BWD.  For EPI >= 2 the epilogue kind is a compile-time constant: each instance carries only its own code

@@ -9,7 +9,8 @@ import numpy as np, torch
 from lm_net_amd import hip
 B = 8
 NSET = 6
-for name, H, cin, cout, k in [("1x1 12->24", 352, 12, 24, 1), ("L1 1x1 24->48", 176, 24, 48, 1), ("L1 1x1 48->24", 176, 48, 24, 1), ("1x1 24->12", 352, 24, 12, 1), ("3x3 12->12", 352, 12, 12, 3), ("3x3 24->12", 352, 24, 12, 3),
+SHAPES3 = [("3x3 12->12", 352, 12, 12, 3), ("3x3 24->12", 352, 24, 12, 3), ("3x3 24->24", 176, 24, 24, 3), ("3x3 48->24", 176, 48, 24, 3), ("3x3 48->48", 88, 48, 48, 3)]
+for name, H, cin, cout, k in SHAPES3 if os.environ.get("PHASES_3X3") else [("1x1 12->24", 352, 12, 24, 1), ("L1 1x1 24->48", 176, 24, 48, 1), ("L1 1x1 48->24", 176, 48, 24, 1), ("1x1 24->12", 352, 24, 12, 1), ("3x3 12->12", 352, 12, 12, 3), ("3x3 24->12", 352, 24, 12, 3),
                               ("3x3 24->24", 176, 24, 24, 3), ("3x3 48->48", 88, 48, 48, 3)]:
     xs = [torch.randn(B, H, H, cin, device="cuda") for _ in range(NSET)]
     outs = [torch.empty(B, H, H, cout, device="cuda") for _ in range(NSET)]
