@@ -210,8 +210,8 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(const ConvParams P) {
   // and parked in registers across it; the top of the next unit only waits for what is still in flight, applies the zero padding and
   // writes LDS.  Phase clocks: the co-resident blocks of a CU stage and multiply in lockstep, so the 7 K cycles of window
   // round trips per 128-pixel tile ran with the matrix pipe idle (pipe busy 55 % of a block's life) and HBM idle during the loops.
-  constexpr bool PF = LMN_CONV_PF && TAPS == 9 && !S2T && !UP && !LN;
-  constexpr int PFN = 6;                 // float4 per thread parked across the loop (a 10 x 18 window of two K16 blocks = 5.6 rounds)
+  constexpr bool PF = LMN_CONV_PF && (TAPS == 9 || (LMN_CONV_PF >= 2 && !RP)) && !S2T && !UP && !LN;   // (-DLMN_CONV_PF=2: also the NHWC 1x1 instances)
+  constexpr int PFN = TAPS == 9 ? 6 : 4; // float4 per thread parked across the loop (3x3: a 10 x 18 window of two K16 blocks = 5.6 rounds; 1x1: 128 pixels of two K16 blocks = 4)
   f32x4 pfr[PF ? PFN : 1];
   bool pf_have = false;                  // (uniform) pfr holds the first PFN rounds of the unit about to be staged
   auto pf_plain = [&](int s_) -> bool { return A.src[s_].flags == 0 && A.src[s_].scale == nullptr; };
