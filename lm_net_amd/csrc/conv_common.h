@@ -121,5 +121,6 @@ __device__ unsigned long long g_ct_timing[4096 * 8];
 // rp: row-planar operands (1x1), ln: LayerNorm on load (LMN_SRC_LN; 1x1, ek 0), up: bilinear x2 on load (LMN_SRC_UP2; 3x3, ek 0), ncw: cout tiles per wave of the M-split kernel.
 int lmn_launch_conv_tile_1x1(const ConvParams& T, dim3 grid, size_t shmem, hipStream_t st, int tnct, int pm, int ek, bool rp, bool ln);
 int lmn_launch_conv_tile_3x3(const ConvParams& T, dim3 grid, size_t shmem, hipStream_t st, int tnct, int pm, int ek, bool wlk, bool up);
+int lmn_launch_conv_tile_3x3g(const ConvParams& T, dim3 grid, size_t shmem, hipStream_t st, int tnct, int pm, int ek, bool wlk);   // NPG = 4 (tnct <= 2)
 int lmn_launch_conv_tile_s2t(const ConvParams& T, dim3 grid, size_t shmem, hipStream_t st, int tnct, int pm, int ek);
 int lmn_launch_conv_tileM(const ConvParams& T, dim3 grid, size_t shmem, hipStream_t st, int taps, int ncw, int pm, int ek, bool rp, bool ln, bool up);

@@ -467,6 +467,7 @@ int lmn_conv_fwd(const lmn_conv_args_t* args, lmn_stream_t stream) {
     const int tpmax = (a.stride == 2 && !s2t) ? 64 : 128;
     const int gW = s2t ? (a.Wout + 1) / 2 : a.Wout, gH = s2t ? (a.Hout + 1) / 2 : a.Hout;  // tiled grid (S2T: class coordinates)
     int ncw = 0;  // > 0: M-split kernel with ncw cout tiles per wave
+    int npg = 2;  // pixel groups per wave of the N-split kernel (4: 3x3 tiles of up to 256 pixels)
     // M-split from 6 cout tiles: 5 tiles split 2+1+1+1 over the four waves (24->72 3x3 at 176x176: 242 us, N-split 185 us)
     static int msplit_env = -1;   // LMN_MSPLIT_MIN: A/B runs
     if (msplit_env < 0) { const char* e = getenv("LMN_MSPLIT_MIN"); msplit_env = e ? atoi(e) : 6; }
@@ -479,6 +480,25 @@ int lmn_conv_fwd(const lmn_conv_args_t* args, lmn_stream_t stream) {
       T.TH = tpmax / T.TW;
       if (T.TH > gH) T.TH = gH;
       if (T.TH < 1) T.TH = 1;
+      static int nth_env = -1;   // LMN_CONV_TH: force the tile height of the N-split 3x3 kernel (A/B runs)
+      if (nth_env < 0) { const char* e = getenv("LMN_CONV_TH"); nth_env = e ? atoi(e) : 0; }
+      if (nth_env > 0 && nth_env < T.TH) T.TH = nth_env;
+      // four pixel groups per wave (tiles of up to 256 pixels, conv_tile_kernel NPG = 4): stride-1 3x3 calls of the N-split form with at
+      // most two cout tiles per block on maps that hold such tiles (LMN_CONV_NPG=2: off, A/B runs).  Measured: -5 ... -13 % on the layers
+      // with 24+ channel sources alone, nothing inside the step (14.50 / 14.52 / 14.51 against 14.49 / 14.51 / 14.49 ms): not in the product
+#ifdef LMN_CONV_NPG4   // experiment build (make npg4): the instances live in conv_tile_3x3g.hip, which the product library does not carry
+      static int npg_env = -1;
+      if (npg_env < 0) { const char* e = getenv("LMN_CONV_NPG"); npg_env = e ? atoi(e) : 4; }
+      int maxkb0 = 0;
+      for (int s_ = 0; s_ < a.nsrc; ++s_) maxkb0 = P.nkb[s_] > maxkb0 ? P.nkb[s_] : maxkb0;
+      // (sources of <= 16 channels keep the 128-pixel tile: their window fits five blocks per CU WITH the weights in LDS, the larger one
+      //  does not -- 12 -> 12 at 352^2: 54 -> 65 us; sources of 24+ channels: 24 -> 12 107 -> 100 us, 72 -> 24 125 -> 113, data gradients -5 ... -13 %)
+      if (npg_env == 4 && !s2t && a.stride == 1 && !up2 && nth_env == 0 && P.NCTT < msplit_min && !ln && tnct <= 2 && gH >= 12 && gW >= 16 && maxkb0 >= 2) {
+        npg = 4;
+        T.TH = 256 / T.TW;
+        if (T.TH > gH) T.TH = gH;
+      }
+#endif
     }
     // (LayerNorm on load: the N-split kernel reduces a pixel's statistics inside one staging round of <= 32 channels; wider sources
     //  take the M-split kernel, whose pre-pass handles any width)
@@ -520,7 +540,7 @@ int lmn_conv_fwd(const lmn_conv_args_t* args, lmn_stream_t stream) {
     }
     T.TP = T.TH * T.TW;
     T.NG = (T.TP + 15) / 16;
-    LMN_REQUIRE(T.NG <= 8, "conv_fwd: tile of %d pixels", T.TP);
+    LMN_REQUIRE(T.NG <= 4 * npg, "conv_fwd: tile of %d pixels", T.TP);
     const int st_in = a.transposed ? 1 : a.stride;
     T.XH = s2t ? T.TH + 1 : (T.TH - 1) * st_in + a.ksize;
     T.XW = s2t ? T.TW + 1 : (T.TW - 1) * st_in + a.ksize;
@@ -560,6 +580,11 @@ int lmn_conv_fwd(const lmn_conv_args_t* args, lmn_stream_t stream) {
     LMN_REQUIRE(shmem <= 64 * 1024, "conv_fwd: LDS window %zu B", shmem);
     int blocks = T.total_tiles;
     int maxb = 1280 / tchunks > 256 ? 1280 / tchunks : 256;  // ~5 resident blocks per CU: one round of persistent blocks
+    if (npg == 4) {   // the larger window: as many blocks as the LDS of a CU holds (at most five)
+      int per_cu = (int)((160 * 1024) / (shmem + 512));
+      per_cu = per_cu > 5 ? 5 : (per_cu < 1 ? 1 : per_cu);
+      maxb = 256 * per_cu / tchunks > 256 ? 256 * per_cu / tchunks : 256;
+    }
     if (s2t) maxb = 320 / tchunks > 64 ? 320 / tchunks : 64;          // x 4 classes in grid.z
     {
       static int maxb_env = -1;   // LMN_CONV_MAXB: cap on the persistent blocks of a 3x3 call (occupancy experiments: 256 = one block per CU)
@@ -612,6 +637,9 @@ int lmn_conv_fwd(const lmn_conv_args_t* args, lmn_stream_t stream) {
     const dim3 grid(blocks, tchunks);
     if (int rc = det_prep(blocks)) return rc;
     if (a.ksize == 1) lmn_launch_conv_tile_1x1(T, grid, shmem, st, tnct, pm, ek, T.rpw != 0, ln);
+#ifdef LMN_CONV_NPG4
+    else if (npg == 4) lmn_launch_conv_tile_3x3g(T, grid, shmem, st, tnct, pm, ek, wlk);
+#endif
     else lmn_launch_conv_tile_3x3(T, grid, shmem, st, tnct, pm, ek, wlk, up2);
     det_finish();
     return lmn_launch_status("conv_fwd(tile)");

@@ -106,8 +106,12 @@ __device__ __forceinline__ void conv_stage_params(const lmn_conv_args_t& A, floa
 // (window pixel, channel quad) from the quarter-size tensor (neighbouring window pixels share their taps: L1 / L2 hits) instead of
 // one from a materialised `up` tensor that a separate kernel wrote.  Window pixels outside the UPSAMPLED image are the conv's zero
 // padding.  Two items per thread and round (8 loads in flight).
-template <int TAPS, int NCT, int EPI, bool S2T = false, int PM = 0, bool WL = false, bool LN = false, bool UP = false>
+// NPG: pixel groups (16 pixels) per wave.  2 = tiles of up to 128 pixels; 4 = up to 256 (3x3 only).  A tile costs a block the same
+// ~11 K cycles of window round trips, barriers and LDS latencies whatever its size (tile-height sweep, DESIGN 5h: 8 x 16 pixels 53 us,
+// 4 x 16 pixels 95 us for the same layer), so the larger tile halves that cost per pixel and doubles the MFMAs per LDS round trip.
+template <int TAPS, int NCT, int EPI, bool S2T = false, int PM = 0, bool WL = false, bool LN = false, bool UP = false, int NPG = 2>
 __global__ __launch_bounds__(256) void conv_tile_kernel(const ConvParams P) {
+  static_assert(NPG == 2 || (NPG == 4 && TAPS == 9 && !S2T), "four pixel groups per wave: 3x3 stride-1 windows");
   static_assert(!UP || (TAPS == 9 && !S2T && (PM & 4) == 0), "bilinear x2 on load: NHWC 3x3 stride-1 forward calls");
   static_assert(!WL || (TAPS == 9 && !S2T), "LDS-staged weights: 3x3 stride-1 windows");
   static_assert(!LN || (TAPS == 1 && EPI == 0 && (PM & 4) == 0), "LayerNorm on load: NHWC 1x1 calls with the plain epilogue");
@@ -265,11 +269,11 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(const ConvParams P) {
       cur_b = b;
     }
 
-    // this wave's two pixel groups: tile pixel -> (row, col), LDS base address, validity
-    int pbase[2], opix[2];
-    bool pvalid[2];
+    // this wave's NPG pixel groups (wv, wv + 4, ...): tile pixel -> (row, col), LDS base address, validity
+    int pbase[NPG], opix[NPG];
+    bool pvalid[NPG];
 #pragma unroll
-    for (int g = 0; g < 2; ++g) {
+    for (int g = 0; g < NPG; ++g) {
       const int i = (wv + 4 * g) * 16 + n;
       const bool in_t = i < P.TP;
       const int is = in_t ? i : 0;
@@ -280,19 +284,23 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(const ConvParams P) {
       const int sr = (S2T || A.transposed) ? r : r * A.stride, sc = (S2T || A.transposed) ? c : c * A.stride;
       pbase[g] = (sr * P.XW + sc) * P.CS + q * (BF ? 2 : 4);
     }
-    const bool g1 = (wv + 4) < P.NG;  // wave-uniform: second group exists
-
-    f32x4 acc[2][NCT];  // start from bias (+ bias2): 4 channels q*4.. of cout tile c, the same for both pixel groups
+    bool gl[NPG];  // wave-uniform: group g of this wave exists in the tile
 #pragma unroll
-    for (int c = 0; c < NCT; ++c) acc[0][c] = acc[1][c] = *reinterpret_cast<const f32x4*>(s_par + c * 16 + q * 4);
+    for (int g = 0; g < NPG; ++g) gl[g] = (wv + 4 * g) < P.NG;
+
+    f32x4 acc[NPG][NCT];  // start from bias (+ bias2): 4 channels q*4.. of cout tile c, the same for every pixel group
+#pragma unroll
+    for (int c = 0; c < NCT; ++c)
+#pragma unroll
+      for (int g = 0; g < NPG; ++g) acc[g][c] = *reinterpret_cast<const f32x4*>(s_par + c * 16 + q * 4);
     // BN_BWD instances: the epilogue's second operand (aux: an output-shaped tensor) is requested HERE, ahead of the staging
     // barrier -- its HBM latency runs beside that of the window instead of after the MFMAs (two exposed round trips per
     // tile -> one; level 0, cold operands: BN_BWD1 102 -> 88 us, BN_BWD2 122 -> 105 us; SE_BWD measured slower with it)
     constexpr bool AUXP = (EPI == 3 && NCT <= 2) || EPI == 4;  // (three cout tiles: the 12 prefetch registers cost BN_BWD1 a wave per SIMD -- 137 -> 122 VGPRs, 38.9 -> 32.4 us at level 1)
-    f32x4 axp[AUXP ? 2 : 1][AUXP ? NCT : 1];
+    f32x4 axp[AUXP ? NPG : 1][AUXP ? NCT : 1];
     if constexpr (AUXP) {
 #pragma unroll
-      for (int g = 0; g < 2; ++g) {
+      for (int g = 0; g < NPG; ++g) {
         uint32_t oa = 0;
         if constexpr (RP) {   // pixel part of the aux offset (common.h LmnLay)
           oa = (uint32_t)opix[g] * (uint32_t)P.lay_aux.cs;
@@ -500,12 +508,12 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(const ConvParams P) {
         // 51 -> 46 us, (24,24,24) -> 24: 134 -> 120 us; the one-cout-tile layers with LDS-resident weights lose 6 % to the 8
         // extra registers and keep the plain order)
         constexpr bool XPF = TAPS == 9 && (!WL || NCT >= 2);
-        wfrag xq0, xq1;
+        wfrag xq[NPG];
         if constexpr (XPF) {
           const int fy0 = A.transposed ? KS - 1 : 0, fx0 = A.transposed ? KS - 1 : 0;
           const int toff0 = S2T ? s2_off[0] * P.CS : (fy0 * P.XW + fx0) * P.CS;
-          xq0 = ldfrag<BF>(&XS[pbase[0] + toff0]);
-          xq1 = ldfrag<BF>(&XS[pbase[1] + toff0]);
+#pragma unroll
+          for (int g = 0; g < NPG; ++g) xq[g] = ldfrag<BF>(&XS[pbase[g] + toff0]);
         }
         if constexpr (BF) {
           if (nkbc == 2) {   // wave-uniform: both K16 blocks of a tap in ONE v_mfma_f32_16x16x32_bf16 (see mfma_bf16x2)
@@ -534,13 +542,13 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(const ConvParams P) {
               const int ty = t / KS, tx = t - ty * KS;
               const int fy = A.transposed ? KS - 1 - ty : ty, fx = A.transposed ? KS - 1 - tx : tx;
               const int toff = S2T ? s2_off[t & 3] * P.CS : (fy * P.XW + fx) * P.CS;
-              const uint2 xa0 = ldfrag<true>(&XS[pbase[0] + toff]), xb0 = ldfrag<true>(&XS[pbase[0] + toff + KD]);
-              const uint2 xa1 = ldfrag<true>(&XS[pbase[1] + toff]), xb1 = ldfrag<true>(&XS[pbase[1] + toff + KD]);
+              uint2 xa[NPG], xb[NPG];
 #pragma unroll
-              for (int c = 0; c < NCT; ++c) {
-                acc[0][c] = mfma_bf16x2(wa[c], wb[c], xa0, xb0, acc[0][c]);
-                acc[1][c] = mfma_bf16x2(wa[c], wb[c], xa1, xb1, acc[1][c]);
-              }
+              for (int g = 0; g < NPG; ++g) { xa[g] = ldfrag<true>(&XS[pbase[g] + toff]); xb[g] = ldfrag<true>(&XS[pbase[g] + toff + KD]); }
+#pragma unroll
+              for (int c = 0; c < NCT; ++c)
+#pragma unroll
+                for (int g = 0; g < NPG; ++g) acc[g][c] = mfma_bf16x2(wa[c], wb[c], xa[g], xb[g], acc[g][c]);
               if constexpr (!WL) {
 #pragma unroll
                 for (int c = 0; c < NCT; ++c) { wa[c] = wna[c]; wb[c] = wnb[c]; }
@@ -566,36 +574,35 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(const ConvParams P) {
           const int ty = tap / KS, tx = tap - ty * KS;
           const int fy = A.transposed ? KS - 1 - ty : ty, fx = A.transposed ? KS - 1 - tx : tx;
           const int toff = S2T ? s2_off[tap & 3] * P.CS : (fy * P.XW + fx) * P.CS;
-          wfrag x0, x1;
+          wfrag xg[NPG];
           if constexpr (XPF) {
-            x0 = xq0; x1 = xq1;
+#pragma unroll
+            for (int g = 0; g < NPG; ++g) xg[g] = xq[g];
             const int tapq = itn >> ksh, kkq = itn & ksh;
             const int tyq = tapq / KS, txq = tapq - tyq * KS;
             const int fyq = A.transposed ? KS - 1 - tyq : tyq, fxq = A.transposed ? KS - 1 - txq : txq;
             const int toffq = S2T ? s2_off[tapq & 3] * P.CS : (fyq * P.XW + fxq) * P.CS;
-            xq0 = ldfrag<BF>(&XS[pbase[0] + toffq + kkq * KD]);
-            xq1 = ldfrag<BF>(&XS[pbase[1] + toffq + kkq * KD]);
+#pragma unroll
+            for (int g = 0; g < NPG; ++g) xq[g] = ldfrag<BF>(&XS[pbase[g] + toffq + kkq * KD]);
           } else {
-            x0 = ldfrag<BF>(&XS[pbase[0] + toff + kk * KD]);
-            x1 = ldfrag<BF>(&XS[pbase[1] + toff + kk * KD]);
+#pragma unroll
+            for (int g = 0; g < NPG; ++g) xg[g] = ldfrag<BF>(&XS[pbase[g] + toff + kk * KD]);
           }
           if constexpr (BF) {
 #pragma unroll
-            for (int c = 0; c < NCT; ++c) {
-              acc[0][c] = mfma_bf16(wcur[c], x0, acc[0][c]);
-              acc[1][c] = mfma_bf16(wcur[c], x1, acc[1][c]);
-            }
+            for (int c = 0; c < NCT; ++c)
+#pragma unroll
+              for (int g = 0; g < NPG; ++g) acc[g][c] = mfma_bf16(wcur[c], xg[g], acc[g][c]);
           } else {
           const int nj = (S.C - (kb0 + kk) * 16 + 3) >> 2;  // K slices of this block that hold channels (wave-uniform)
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
             if (j == 0 || j < nj) {
 #pragma unroll
-              for (int c = 0; c < NCT; ++c) {
-                // both groups unconditionally (a missing second group reads pixel 0 and is dropped in the epilogue)
-                acc[0][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(wcur[c][j], x0[j], acc[0][c], 0, 0, 0);
-                acc[1][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(wcur[c][j], x1[j], acc[1][c], 0, 0, 0);
-              }
+              for (int c = 0; c < NCT; ++c)
+                // every group unconditionally (a missing group reads pixel 0 and is dropped in the epilogue)
+#pragma unroll
+                for (int g = 0; g < NPG; ++g) acc[g][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(wcur[c][j], xg[g][j], acc[g][c], 0, 0, 0);
             }
           }
           }
@@ -611,7 +618,7 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(const ConvParams P) {
     LMN_TK(3);
     // ---- epilogue (lane holds channels co..co+3 of its pixel)
 #pragma unroll
-    for (int g = 0; g < 2; ++g) {
+    for (int g = 0; g < NPG; ++g) {
       const uint32_t opx = (uint32_t)opix[g];
       uint32_t oout_g = 0, oaux_g = 0;   // row-planar instances: pixel part of the out / aux offsets (LmnLay)
       if constexpr (RP) {
@@ -624,7 +631,7 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(const ConvParams P) {
       for (int c = 0; c < NCT; ++c) {
         const int co = (ct0 + c) * 16 + q * 4;
         const bool cok = (ct0 + c < P.NCTT) && co < A.Cout;
-        const bool live = pvalid[g] && cok && (g == 0 || g1);
+        const bool live = pvalid[g] && cok && gl[g];
         const int cos = cok ? co : 0;
         f32x4 v = acc[g][c];
         const float* sp = s_par + LMN_SLOT * 16 + q * 4;
