@@ -138,6 +138,15 @@ __device__ __forceinline__ f32x2 hswish2(f32x2 z, f32x2 a, f32x2 s) {
   t.y = __builtin_amdgcn_fmed3f(t.y, 0.f, 1.f);
   return x * t;
 }
+// (experiment, LMN_DWF_ASM) Stencil FMAs of the forward-type passes as asm statements: they keep the source's order (round-robin over the five row accumulators),
+// so no packed result is read by the NEXT instruction.  Left to the scheduler, hipcc grouped the FMAs by accumulator and the hazard
+// recogniser then put an `s_nop 0` between every dependent pair (a packed fp32 result needs one wait state before a VALU read): ~20 of
+// ~85 issue slots per row step in kernels that the counters show issue-bound.
+__device__ __forceinline__ void fpk_fma(f32x2& acc, f32x2 x, f32x2 y) { asm volatile("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(acc) : "v"(x), "v"(y)); }
+__device__ __forceinline__ void fpk_mul(f32x2& acc, f32x2 x, f32x2 y) { asm volatile("v_pk_mul_f32 %0, %1, %2" : "=v"(acc) : "v"(x), "v"(y)); }
+__device__ __forceinline__ void fpk_fma_s(f32x2& acc, f32x2 x, f32x2 ws) { asm volatile("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(acc) : "v"(x), "s"(ws)); }   // weight pair in SGPRs
+__device__ __forceinline__ void fpk_mul_s(f32x2& acc, f32x2 x, f32x2 ws) { asm volatile("v_pk_mul_f32 %0, %1, %2" : "=v"(acc) : "v"(x), "s"(ws)); }
+
 // A / shift of the block's 8 channels -> pre_s[0..7] = A, pre_s[8..15] = shift (threads 0..7), formed from the batch sums of the
 // expand conv when fin.mode says so (lmn_bn_fin_t arithmetic: slices summed in double about `about`); `writer` blocks also
 // store mean / rstd / A / shift and blend the running statistics.
@@ -381,6 +390,9 @@ __global__ __launch_bounds__(256, 4) void dw_stats0_kernel(const TA* __restrict_
 // ---------------------------------------------------------------------------------------------------------------
 // Forward (flagship HBM-bound kernel of row A2): pre = merged 5x5 (+ bias) -> store; gsum[b][e] += sum GELU(pre) (SE squeeze), and
 // optionally the squeeze-excite gate of an image by the block that completes its sums (lmn_se_fuse_t).
+#ifndef LMN_DWF_ASM
+#define LMN_DWF_ASM 0   // experiment (-DLMN_DWF_ASM=1): stencil FMAs of dw_fwd as ordered asm statements -- 135 -> 51 s_nop, 135 -> 111 VGPRs, same time (59.2 -> 61.2 us at level 0): the pass is not issue-bound after all, DESIGN 5h
+#endif
 template <typename TA, bool ZT>
 __global__ __launch_bounds__(256, LMN_DWF_OCC) void dw_fwd_kernel(const TA* __restrict__ x1, TA* __restrict__ pre, float* __restrict__ gsum, int H, int W,
                                                          int E, const float* __restrict__ keff, const float* __restrict__ beff, const DwFin FN,
@@ -484,9 +496,15 @@ __global__ __launch_bounds__(256, LMN_DWF_OCC) void dw_fwd_kernel(const TA* __re
     LMN_WAVE_SYNC();                                                                                               \
     inn[0] = XS[lane]; inn[1] = XS[lane + 1]; inn[2] = x1n; inn[3] = XS[lane + 3]; inn[4] = XS[lane + 4];          \
     _Pragma("unroll") for (int d = 0; d < 5; ++d) {                                                                \
-      if (d == 0) acc[P] = w[0] * in[0];                                                                           \
-      else acc[P] += w[d] * in[d];                                                                                 \
-      _Pragma("unroll") for (int ky = 1; ky < 5; ++ky) acc[(P - ky + 5) % 5] += w[ky * 5 + d] * in[d];             \
+      if (LMN_DWF_ASM) {                                                                                           \
+        if (d == 0) fpk_mul(acc[P], in[0], w[0]);                                                                  \
+        else fpk_fma(acc[P], in[d], w[d]);                                                                         \
+        _Pragma("unroll") for (int ky = 1; ky < 5; ++ky) fpk_fma(acc[(P - ky + 5) % 5], in[d], w[ky * 5 + d]);      \
+      } else {                                                                                                     \
+        if (d == 0) acc[P] = w[0] * in[0];                                                                         \
+        else acc[P] += w[d] * in[d];                                                                               \
+        _Pragma("unroll") for (int ky = 1; ky < 5; ++ky) acc[(P - ky + 5) % 5] += w[ky * 5 + d] * in[d];           \
+      }                                                                                                            \
     }                                                                                                              \
     constexpr int DD = (P + 1) % 5;                                                                                \
     if (j >= 4 && j < nsteps) {                                                                                    \
