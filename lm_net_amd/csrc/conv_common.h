@@ -3,7 +3,6 @@
 // the host entry (conv_fwd.hip) calls.  The family is split over several translation units so that they compile in parallel
 // (one file took 3 min 45 s); `make timing` builds them as ONE unit (conv_unity.hip) so that the phase-clock arrays exist once.
 #pragma once
-#include <type_traits>
 #include "common.h"
 #include <stdlib.h>
 
@@ -47,13 +46,6 @@ __device__ __forceinline__ void lmn_wave_prio(int mode) {
     default: __builtin_amdgcn_s_setprio(3); break;
   }
 }
-
-#ifndef LMN_CONV_PF
-#define LMN_CONV_PF 0   // conv_tile_kernel: window of the next staging unit prefetched across the MFMA loop (experiment, DESIGN 5h: zero-sum -- the loop slows by what the staging gains, at a wave per SIMD less; -DLMN_CONV_PF=1 builds it)
-#endif
-#ifndef LMN_CONV_FAST
-#define LMN_CONV_FAST 0 // conv_tile_kernel: a copy of the staging loop without the per-item flag tests for plain sources (experiment, DESIGN 5h: no gain; -DLMN_CONV_FAST=1 builds it)
-#endif
 
 namespace {
 

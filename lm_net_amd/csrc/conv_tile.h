@@ -209,35 +209,6 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(const ConvParams P) {
 #ifdef LMN_CT_TIMING
   unsigned long long tk0 = __builtin_amdgcn_s_memtime(), tk_s[5] = {0, 0, 0, 0, 0}, tk_a = tk0, tk_b;
 #endif
-  // PF (3x3 stride-any forward / stride-1 data gradient, plain sources): the window of the NEXT staging unit -- the next K chunk or
-  // source of this tile, else the first chunk of the block's next tile -- is requested right before the MFMA loop of the current one
-  // and parked in registers across it; the top of the next unit only waits for what is still in flight, applies the zero padding and
-  // writes LDS.  Phase clocks: the co-resident blocks of a CU stage and multiply in lockstep, so the 7 K cycles of window
-  // round trips per 128-pixel tile ran with the matrix pipe idle (pipe busy 55 % of a block's life) and HBM idle during the loops.
-  constexpr bool PF = LMN_CONV_PF && (TAPS == 9 || (LMN_CONV_PF >= 2 && !RP)) && !S2T && !UP && !LN;   // (-DLMN_CONV_PF=2: also the NHWC 1x1 instances)
-  constexpr int PFN = TAPS == 9 ? 6 : 4; // float4 per thread parked across the loop (3x3: a 10 x 18 window of two K16 blocks = 5.6 rounds; 1x1: 128 pixels of two K16 blocks = 4)
-  f32x4 pfr[PF ? PFN : 1];
-  bool pf_have = false;                  // (uniform) pfr holds the first PFN rounds of the unit about to be staged
-  auto pf_plain = [&](int s_) -> bool { return A.src[s_].flags == 0 && A.src[s_].scale == nullptr; };
-  auto pf_issue = [&](int tile_, int s_, int kb0_) __attribute__((always_inline)) {
-    const lmn_src_t& S_ = A.src[s_];
-    const int b_ = tile_ / (P.tiles_x * P.tiles_y), tt_ = tile_ - b_ * P.tiles_x * P.tiles_y;
-    const int oy_ = (tt_ / P.tiles_x) * P.TH, ox_ = (tt_ % P.tiles_x) * P.TW;
-    const int wy_ = A.transposed ? oy_ - pad : oy_ * A.stride - pad, wx_ = A.transposed ? ox_ - pad : ox_ * A.stride - pad;
-    const int nkbc_ = P.nkb[s_] - kb0_ < P.CKB ? P.nkb[s_] - kb0_ : P.CKB;
-    const int psh_ = nkbc_ == 2 ? 3 : 2, nitems_ = P.XH * P.XW * (1 << psh_);
-#pragma unroll
-    for (int u = 0; u < PFN; ++u) {
-      const int i = u * 256 + tid;
-      const int f = i & ((1 << psh_) - 1), pix = i >> psh_;
-      const int r = (int)__umulhi((uint32_t)pix, P.mXW), c = pix - r * P.XW;
-      const int iy = wy_ + r, ix = wx_ + c;
-      const int ch = kb0_ * 16 + f * 4;
-      const bool ok = i < nitems_ && ch < S_.C && (unsigned)iy < (unsigned)A.Hin && (unsigned)ix < (unsigned)A.Win;
-      const int gp = ok ? (b_ * A.Hin + iy) * A.Win + ix : 0;
-      pfr[u] = ld4((const TA*)S_.ptr + (uint32_t)(gp * S_.cstride + (ok ? ch : 0)));
-    }
-  };
   for (int tile = t_begin; tile < t_end; tile += tstep) {
 #ifdef LMN_CT_TIMING
     tk_a = __builtin_amdgcn_s_memtime();
@@ -339,29 +310,6 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(const ConvParams P) {
         //      to load -> s_waitcnt vmcnt(0) -> write per item, i.e. 3-6 serial HBM round trips per 3x3 chunk).
         const int psh = nkbc == 2 ? 3 : 2, per_px = 1 << psh;   // quads per pixel: 4 (one K16 block) or 8
         const int nitems = P.XH * P.XW * per_px;
-        int i0_first = 0;
-        if constexpr (PF) {
-          if (pf_have) {   // (uniform) the first PFN rounds of this unit are in registers: zero padding, layout, LDS
-#pragma unroll
-            for (int u = 0; u < PFN; ++u) {
-              const int i = u * 256 + tid;
-              if (i < nitems) {
-                const int f = i & (per_px - 1), pix = i >> psh;
-                const int r = (int)__umulhi((uint32_t)pix, P.mXW), c = pix - r * P.XW;
-                const int iy = wy0 + r, ix = wx0 + c;
-                const bool ok = kb0 * 16 + f * 4 < S.C && (unsigned)iy < (unsigned)A.Hin && (unsigned)ix < (unsigned)A.Win;
-                const f32x4 v = ok ? pfr[u] : f32x4{0.f, 0.f, 0.f, 0.f};
-                if constexpr (BF) {
-                  *reinterpret_cast<uint2*>(&XS[pix * P.CS + f * 2]) = pk4_bf16(v);
-                } else {
-                  float* d = &XS[pix * P.CS + (f >> 2) * 16 + (f & 3)];
-                  d[0] = v[0]; d[4] = v[1]; d[8] = v[2]; d[12] = v[3];
-                }
-              }
-            }
-            i0_first = PFN * 256;   // (windows of more than PFN rounds: the rest the plain way)
-          }
-        }
         if constexpr (UP) {
           const int hs = A.Hin >> 1, ws = A.Win >> 1;   // the source map (A.Hin x A.Win is the upsampled image the conv sees)
           const float sh = (float)(hs - 1) / (float)(A.Hin - 1), sw = (float)(ws - 1) / (float)(A.Win - 1);
@@ -408,16 +356,10 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(const ConvParams P) {
             }
           }
         } else {
-        // PLAIN (experiment, -DLMN_CONV_FAST=1; a source without on-load transforms): a copy of the loop without the per-item tests of
-        // the descriptor's flag / scale words, which are re-read through the scalar cache for every item (s_load + s_waitcnt + branch).
-        // Measured: the second copy costs 12 VGPRs -- a wave per SIMD in the two- and three-tile instances -- and the
-        // one-tile layers do not move (56.0 -> 57.5 us): the staging phase is not issue-bound.
-        auto stage_rounds = [&](auto plain_tag) __attribute__((always_inline)) {
-        constexpr bool PLAIN = decltype(plain_tag)::value;
         constexpr int SU = TAPS == 1 ? 2 : 4;  // items per thread and round.  1x1: four in flight cost the epilogue-heavy instances a wave per
                                                // SIMD; two (+6 VGPRs, same occupancy bracket for all but <1,3,0>) halve the 4-6 serial round
                                                // trips of the 24-48 channel layers: +0.3 % fp32 batch 8, +1.6 % bf16 batch 64
-        for (int i0 = i0_first; i0 < nitems; i0 += SU * 256) {
+        for (int i0 = 0; i0 < nitems; i0 += SU * 256) {
           f32x4 sv[SU];
           int sgp[SU];  // global pixel index, -1 = outside the image / past the channels / past the window
 #pragma unroll
@@ -438,13 +380,6 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(const ConvParams P) {
               sv[u] = ld4((const TA*)S.ptr + (uint32_t)(gp * S.cstride + (ok ? ch : 0)));
             }
           }
-          // (PF builds: every load of the round is USED, also by the threads past the window: a load whose only use is skipped stays "pending" for
-          //  the compiler's wait-count bookkeeping, and the first LDS read of the MFMA loop into one of its registers then carries an
-          //  s_waitcnt vmcnt(0) -- which would also wait for the window prefetch that is in flight across that loop)
-          if constexpr (PF) {
-#pragma unroll
-            for (int u = 0; u < SU; ++u) asm volatile("" : "+v"(sv[u]));
-          }
 #pragma unroll
           for (int u = 0; u < SU; ++u) {
             const int i = i0 + u * 256 + tid;
@@ -453,7 +388,7 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(const ConvParams P) {
             const bool ok = sgp[u] >= 0;
             const int gp = ok ? sgp[u] : 0, chs = ok ? kb0 * 16 + f * 4 : 0;
             f32x4 v = sv[u];
-            if constexpr (LN && !PLAIN) {
+            if constexpr (LN) {
               // (items past the window end in whole pixels: the lanes of a pixel are all active here or all skipped above)
               auto px_sum = [&](float t) -> float {
                 t += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(t), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
@@ -469,15 +404,15 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(const ConvParams P) {
               v = dv * rstd * ln_g + ln_b;
               if (f == 0 && ok && blockIdx.y == 0 && S.ln_stats) *reinterpret_cast<float2*>(S.ln_stats + 2 * (int64_t)gp) = float2{mean, rstd};
             }
-            if (!PLAIN && (S.flags & LMN_SRC_GELU)) {
+            if (S.flags & LMN_SRC_GELU) {
 #pragma unroll
               for (int k = 0; k < 4; ++k) v[k] = lmn_gelu(v[k]);
             }
-            if (!PLAIN && (S.flags & LMN_SRC_DROP)) {
+            if (S.flags & LMN_SRC_DROP) {
 #pragma unroll
               for (int k = 0; k < 4; ++k) v[k] *= lmn_drop_scale(S.drop_seed + soff, (uint32_t)(gp * S.C + chs + k), S.drop_p, P.inv_keep_src[s]);
             }
-            if (!PLAIN && S.scale) v *= ld4(S.scale + b * S.C + chs);
+            if (S.scale) v *= ld4(S.scale + b * S.C + chs);
             if (!ok) v = f32x4{0.f, 0.f, 0.f, 0.f};
             if constexpr (BF) {  // natural channel order, 4 bf16 = one 8-byte fragment slot
               *reinterpret_cast<uint2*>(&XS[pix * P.CS + f * 2]) = pk4_bf16(v);
@@ -487,21 +422,11 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(const ConvParams P) {
             }
           }
         }
-        };
-        if (LMN_CONV_FAST && !LN && S.flags == 0 && S.scale == nullptr) stage_rounds(std::true_type{});   // (uniform)
-        else stage_rounds(std::false_type{});
         }   // (!UP)
         LMN_TK_DRAIN();
         LMN_TK(1);
         __syncthreads();
         LMN_TK(2);
-        if constexpr (PF) {   // the next staging unit (uniform arithmetic)
-          int ns = s, nkb0 = kb0 + P.CKB, ntile = tile;
-          if (nkb0 >= P.nkb[s]) { nkb0 = 0; ns = s + 1; }
-          if (ns >= A.nsrc) { ns = 0; ntile = tile + tstep; }
-          pf_have = ntile < t_end && pf_plain(ns);
-          if (pf_have) pf_issue(ntile, ns, nkb0);
-        }
         // ---- MFMA: taps x K16 blocks of the chunk; the packed weights of step it+1 are fetched while step it runs
         //      (the first fetch was issued before the staging loop), so no L2 latency is exposed inside the loop
         // 3x3: the pixel operands of step it+1 are read from LDS while the MFMAs of step it run (cold operands, 24 -> 24 at level 1:
