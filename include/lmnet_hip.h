@@ -48,7 +48,7 @@ extern "C" {
 
 typedef void* lmn_stream_t; /* hipStream_t */
 
-#define LMN_ABI_VERSION 11
+#define LMN_ABI_VERSION 12
 /* arithmetic type of the matrix-core operands of a dense contraction (accumulators, epilogues, statistics: fp32) */
 #define LMN_F32 0  /* v_mfma_f32_16x16x4_f32: exact fp32 (k-ordered fma chain)                                  */
 #define LMN_BF16 1 /* v_mfma_f32_16x16x16_bf16: operands rounded to bf16 (RNE) when staged / packed -- the mixed- */
@@ -112,6 +112,10 @@ typedef struct {
 #define LMN_EP_BN_BWD1 3    /* zh=(v-p0)*p1; h=p2*zh+p3; o=aux*act'(h); stats+=(o, o*zh); out may be NULL (statistics only) */
 #define LMN_EP_BN_BWD2 4    /* zh=(v-p0)*p1; dh = p5 ? aux*act'(p5*zh+p6) : aux; o=p2*dh - p3 - zh*p4 */
 #define LMN_EP_SE_BWD 5     /* o = v; stats[b][co] += v*gelu(aux)    (d gate of the SE block)     */
+#define LMN_EP_LN_BWD 6     /* LayerNorm backward behind the data gradient of the Linear it feeds (1x1, every cout in one block: Cout <= 48):   */
+                            /* g = v*p0 (gamma); zh = (aux - mean)*rstd with (mean, rstd) = p6[pixel][2], the table the LMN_SRC_LN forward left;    */
+                            /* o = rstd*(g - mean_c(g) - zh*mean_c(g*zh)) (+ residual); stats[2][Cout] += (sum_px v, sum_px v*zh) = (d beta, d gamma), */
+                            /* rows swapped when act != 0.  aux = the LayerNorm INPUT.  core/modules.py:516-518 backward, one launch instead of two  */
 
 #define LMN_ACT_NONE 0
 #define LMN_ACT_HSWISH 1 /* nn.Hardswish  core/modules.py:539 */

@@ -395,6 +395,10 @@ int lmn_conv_fwd(const lmn_conv_args_t* args, lmn_stream_t stream) {
       LMN_REQUIRE(A.aux && A.p0 && A.p1 && ((A.p2 && A.p3 && A.p4) || A.fin.mode == LMN_FIN_BN_BWD) && (!A.p5 == !A.p6), "conv_fwd: BN_BWD2 operands");
       break;
     case LMN_EP_SE_BWD: LMN_REQUIRE(A.aux && A.stats, "conv_fwd: SE_BWD operands"); break;
+    case LMN_EP_LN_BWD:
+      LMN_REQUIRE(A.aux && A.p0 && A.p6 && A.stats && A.out && A.ksize == 1 && A.Cout <= 48 && A.stats_mode == LMN_STATS_EP && A.out_rp_w == 0 && A.aux_rp_w == 0,
+                  "conv_fwd: LN_BWD: 1x1 NHWC call with aux (LayerNorm input), p0 (gamma), p6 ((mean, rstd) table), stats [2][Cout], Cout <= 48 (got %d)", A.Cout);
+      break;
     default: LMN_REQUIRE(false, "conv_fwd: epilogue %d", A.epilogue);
   }
   if (A.stats_mode == LMN_STATS_SUM_SQ) LMN_REQUIRE(A.stats, "conv_fwd: SUM_SQ needs stats");
@@ -600,6 +604,7 @@ int lmn_conv_fwd(const lmn_conv_args_t* args, lmn_stream_t stream) {
     else if (a.epilogue == LMN_EP_BN_BWD1 && a.stats_mode == LMN_STATS_EP) ek = 3;
     else if (a.epilogue == LMN_EP_BN_BWD2 && a.stats_mode == LMN_STATS_NONE) ek = 4;
     else if (a.epilogue == LMN_EP_SE_BWD && a.stats_mode == LMN_STATS_EP) ek = 5;
+    else if (a.epilogue == LMN_EP_LN_BWD) ek = 6;
     // deterministic mode: the statistics go to one slot per block (SE_BWD: per wave) of the stream's scratch, summed in fixed order
     // by lmn_det_sum right after the launch into slice 0 of the caller's buffer
     int det_ns = 0;
@@ -616,6 +621,7 @@ int lmn_conv_fwd(const lmn_conv_args_t* args, lmn_stream_t stream) {
     };
     auto det_finish = [&]() { if (T.det_stats) lmn_det_sum(st, T.det_stats, det_ns, det_sz, a.stats); };
     if (ncw) {
+      LMN_REQUIRE(a.epilogue != LMN_EP_LN_BWD, "conv_fwd: LN_BWD is an N-split epilogue (Cout <= 48)");
       const int mchunks = (P.NCTT + 4 * ncw - 1) / (4 * ncw);
       int mblocks = T.total_tiles;
       const int mmax = 2048 / mchunks > 256 ? 2048 / mchunks : 256;
@@ -635,6 +641,7 @@ int lmn_conv_fwd(const lmn_conv_args_t* args, lmn_stream_t stream) {
       return lmn_launch_status("conv_fwd(tile, stride-2 data gradient)");
     }
     const dim3 grid(blocks, tchunks);
+    LMN_REQUIRE(a.epilogue != LMN_EP_LN_BWD || (tchunks == 1 && a.ksize == 1 && T.rpw == 0 && !ln), "conv_fwd: LN_BWD needs every cout in one block (N-split 1x1 NHWC call)");
     if (int rc = det_prep(blocks)) return rc;
     if (a.ksize == 1) lmn_launch_conv_tile_1x1(T, grid, shmem, st, tnct, pm, ek, T.rpw != 0, ln);
 #ifdef LMN_CONV_NPG4

@@ -131,11 +131,11 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(const ConvParams P) {
   if (P.prio) lmn_wave_prio(P.prio);   // (uniform)
   const uint32_t soff = A.seed_ctr ? *A.seed_ctr : 0u;  // device-side dropout stream offset (graph replays: one bump per step)
   // EPI: 0 plain (LINEAR / AFFINE_ACT, no statistics), 1 generic, 2 LINEAR + SUM_SQ statistics, 3 BN_BWD1, 4 BN_BWD2,
-  // 5 SE_BWD.  For EPI >= 2 the epilogue kind is a compile-time constant: each instance carries only its own code
+  // 5 SE_BWD, 6 LN_BWD (1x1 NHWC only).  For EPI >= 2 the epilogue kind is a compile-time constant: each instance carries only its own code
   // (the generic instance keeps every variant resident: 125-160 VGPRs + spills, and measured 20-40 us over its
   // memory time at level 0).
-  const int ep_kind = EPI == 2 ? LMN_EP_LINEAR : EPI == 3 ? LMN_EP_BN_BWD1 : EPI == 4 ? LMN_EP_BN_BWD2 : EPI == 5 ? LMN_EP_SE_BWD : A.epilogue;
-  const int st_mode = EPI == 2 ? LMN_STATS_SUM_SQ : (EPI == 3 || EPI == 5) ? LMN_STATS_EP : EPI == 4 ? LMN_STATS_NONE : A.stats_mode;
+  const int ep_kind = EPI == 2 ? LMN_EP_LINEAR : EPI == 3 ? LMN_EP_BN_BWD1 : EPI == 4 ? LMN_EP_BN_BWD2 : EPI == 5 ? LMN_EP_SE_BWD : EPI == 6 ? LMN_EP_LN_BWD : A.epilogue;
+  const int st_mode = EPI == 2 ? LMN_STATS_SUM_SQ : (EPI == 3 || EPI == 5 || EPI == 6) ? LMN_STATS_EP : EPI == 4 ? LMN_STATS_NONE : A.stats_mode;
   const bool has_drop = EPI <= 1 && A.drop_p > 0.f;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* XS = smem;                       // [XH*XW][CS]
@@ -542,6 +542,52 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(const ConvParams P) {
     LMN_TK_DRAIN();
     LMN_TK(3);
     // ---- epilogue (lane holds channels co..co+3 of its pixel)
+    if constexpr (EPI == 6) {
+      // LayerNorm backward (LMN_EP_LN_BWD): the block holds every channel of its pixels (grid.y == 1) -- the channel means are sums over a
+      // lane's quads of the NCT cout tiles and over the four lane groups q of the pixel (two shuffles)
+      const float invC = 1.f / (float)A.Cout;
+#pragma unroll
+      for (int g = 0; g < NPG; ++g) {
+        const uint32_t opx = (uint32_t)opix[g];
+        const float2 mr = *reinterpret_cast<const float2*>(A.p6 + 2 * (size_t)opx);
+        f32x4 gx[NCT], zh[NCT];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int c = 0; c < NCT; ++c) {
+          const int co = (ct0 + c) * 16 + q * 4;
+          const bool cok = (ct0 + c < P.NCTT) && co < A.Cout;
+          const int cos = cok ? co : 0;
+          const f32x4 ga = *reinterpret_cast<const f32x4*>(s_par + c * 16 + q * 4 + 2 * NCT * 16);   // p0 = gamma (0 past Cout)
+          const f32x4 ax = ld4((const TA*)A.aux + opx * A.aux_cstride + cos);
+          const f32x4 v = acc[g][c];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            zh[c][r] = cok ? (ax[r] - mr.x) * mr.y : 0.f;
+            gx[c][r] = v[r] * ga[r];
+            s1 += gx[c][r];
+            s2 += gx[c][r] * zh[c][r];
+          }
+          if (pvalid[g] && cok && gl[g]) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { st0[c][r] += v[r]; st1[c][r] += v[r] * zh[c][r]; }
+          }
+        }
+        s1 += __shfl_xor(s1, 16, 64); s1 += __shfl_xor(s1, 32, 64);
+        s2 += __shfl_xor(s2, 16, 64); s2 += __shfl_xor(s2, 32, 64);
+        const float m1 = s1 * invC, m2 = s2 * invC;
+#pragma unroll
+        for (int c = 0; c < NCT; ++c) {
+          const int co = (ct0 + c) * 16 + q * 4;
+          const bool cok = (ct0 + c < P.NCTT) && co < A.Cout;
+          const int cos = cok ? co : 0;
+          f32x4 o;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) o[r] = mr.y * (gx[c][r] - m1 - zh[c][r] * m2);
+          if (A.residual) o += ld4((const TA*)A.residual + opx * A.res_cstride + cos);
+          if (A.out && pvalid[g] && cok && gl[g]) st4((TA*)A.out + opx * A.out_cstride + cos, o);
+        }
+      }
+    } else
 #pragma unroll
     for (int g = 0; g < NPG; ++g) {
       const uint32_t opx = (uint32_t)opix[g];
@@ -639,7 +685,7 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(const ConvParams P) {
 
   // ---- statistics: wave shuffle over the 16 pixels -> LDS -> one global atomic per channel per block
   const bool se = EPI && ep_kind == LMN_EP_SE_BWD;
-  const bool chan_stats = EPI && ((st_mode == LMN_STATS_SUM_SQ) || (ep_kind == LMN_EP_BN_BWD1) || se);
+  const bool chan_stats = EPI && ((st_mode == LMN_STATS_SUM_SQ) || (ep_kind == LMN_EP_BN_BWD1) || se || EPI == 6);
   if (chan_stats) {
     __syncthreads();   // (block-uniform) every wave is through with the window of the last tile: it now parks the wave sums
 #pragma unroll
@@ -659,6 +705,7 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(const ConvParams P) {
       }
     __syncthreads();
     const bool det = P.det_stats != nullptr;
+    const int wsw = (EPI == 6 && A.act != 0) ? 1 : 0;   // LN_BWD: rows (d beta, d gamma) or, swapped, (d gamma, d beta)
     for (int i = tid; i < (se ? 1 : 2) * NCT * 16; i += 256) {
       const int which = i / (NCT * 16), cc = i - which * NCT * 16;
       const int co = ct0 * 16 + cc;
@@ -667,9 +714,9 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(const ConvParams P) {
         if (se) {
           if (cur_b >= 0) lmn_red_add((det ? P.det_stats + (int64_t)((blockIdx.x + gridDim.x * blockIdx.z) * 4) * A.B * A.Cout : A.stats) + cur_b * A.Cout + co, v, det);
         } else if (det) {
-          P.det_stats[(int64_t)(blockIdx.x + gridDim.x * blockIdx.z) * 2 * A.Cout + (int64_t)which * A.Cout + co] = v;   // slot of this block: [2][Cout]
+          P.det_stats[(int64_t)(blockIdx.x + gridDim.x * blockIdx.z) * 2 * A.Cout + (int64_t)(which ^ wsw) * A.Cout + co] = v;   // slot of this block: [2][Cout]
         } else {
-          atomicAdd(A.stats + (A.stats_rep > 1 ? (int64_t)(blockIdx.x % A.stats_rep) * 2 * A.Cout : 0) + (int64_t)which * A.Cout + co, v);
+          atomicAdd(A.stats + (A.stats_rep > 1 ? (int64_t)(blockIdx.x % A.stats_rep) * 2 * A.Cout : 0) + (int64_t)(which ^ wsw) * A.Cout + co, v);
         }
       }
     }

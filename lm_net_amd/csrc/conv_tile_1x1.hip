@@ -26,11 +26,13 @@ int lmn_launch_conv_tile_1x1(const ConvParams& T, dim3 grid, size_t shmem, hipSt
       case 3: LMN_LAUNCH((conv_tile_kernel<1, NN, 3, false, BFV>), grid, dim3(256), shmem, st, T); break; \
       case 4: LMN_LAUNCH((conv_tile_kernel<1, NN, 4, false, BFV>), grid, dim3(256), shmem, st, T); break; \
       case 5: LMN_LAUNCH((conv_tile_kernel<1, NN, 5, false, BFV>), grid, dim3(256), shmem, st, T); break; \
+      LMN_CASE6(NN, BFV) \
       default: LMN_LAUNCH((conv_tile_kernel<1, NN, 1, false, BFV>), grid, dim3(256), shmem, st, T); break; \
     }                                                                                                    \
   } while (0)
   const int key = (tnct > 3 ? 3 : tnct) * 4 + pm;
-  if (rp) {   // row-planar operands: their own instances (precision mode | 4)
+  if (rp) {   // row-planar operands: their own instances (precision mode | 4); no LayerNorm-backward epilogue (NHWC calls only)
+#define LMN_CASE6(NN, BFV)
     switch (key) {
       case 4: LMN_CT(1, 4); break;
       case 5: LMN_CT(1, 5); break;
@@ -42,7 +44,9 @@ int lmn_launch_conv_tile_1x1(const ConvParams& T, dim3 grid, size_t shmem, hipSt
       case 14: LMN_CT(3, 6); break;
       default: LMN_CT(3, 4); break;
     }
+#undef LMN_CASE6
   } else {
+#define LMN_CASE6(NN, BFV) case 6: LMN_LAUNCH((conv_tile_kernel<1, NN, 6, false, BFV>), grid, dim3(256), shmem, st, T); break;
     switch (key) {
       case 4: LMN_CT(1, 0); break;
       case 5: LMN_CT(1, 1); break;
@@ -54,6 +58,7 @@ int lmn_launch_conv_tile_1x1(const ConvParams& T, dim3 grid, size_t shmem, hipSt
       case 14: LMN_CT(3, 2); break;
       default: LMN_CT(3, 0); break;
     }
+#undef LMN_CASE6
   }
 #undef LMN_CT
   return 0;

@@ -203,6 +203,9 @@ class Engine:
         # skip fusers: BatchNorm finalize / backward coefficients inside the BN + GELU tails (lmn_bnact_fwd_fin / lmn_bnact_bwd_fin;
         # LMN_FUSE_BN_TAIL=0: the lmn_bn_finalize / lmn_bn_bwd_coef launches, A/B runs)
         self.fuse_bn_tail = os.environ.get("LMN_FUSE_BN_TAIL", "1") != "0"
+        # LayerNorm backward in the epilogue of the data-gradient conv of the Linear it feeds (hip.EP_LN_BWD, C <= 48: the neighborhood-
+        # attention blocks of levels 0-2; LMN_FUSE_LN_BWD=0: lmn_ln_bwd launches, A/B runs)
+        self.fuse_ln_bwd = os.environ.get("LMN_FUSE_LN_BWD", "1") != "0"
 
     def pm(self):
         """precision mode of the pass: 0 fp32, 1 bf16 MFMA operands on fp32 storage, 2 bf16 storage + bf16 operands."""
@@ -936,8 +939,30 @@ class Engine:
         self.conv([src], mlp.fc2.weight, mlp.fc2.bias, yf, Hin=1, Win=npx, residual=af, drop_p=p, drop_seed=s2)
         return a1, (p, s1, s2)
 
-    def _mlp_bwd(self, mlp, n2, a1, dy, drop):
-        """returns dn2; accumulates fc1/fc2 grads.  dy is the gradient of the block output."""
+    def _ln_bwd_ep(self, nsrc, norm, residual, out):
+        """Keyword arguments that make a `conv_T` call finish the LayerNorm backward itself (hip.EP_LN_BWD: the data gradient of the Linear
+        behind `norm`, then dx = rstd (g - mean g - zh mean(g zh)) + residual in the epilogue, d gamma / d beta as its channel statistics),
+        or None when the call cannot take it: no (mean, rstd) table (LMN_FUSE_LN=0), more than 48 channels, or the two gradient slices of
+        the LayerNorm not adjacent in the flat buffer (the epilogue's [2][C] statistics land in them directly)."""
+        if not (self.fuse_ln_bwd and isinstance(nsrc, dict) and nsrc.get("ln") is not None):
+            return None
+        x = nsrc["view"]
+        Cn = x.shape[-1]
+        gw, gb = self.G[norm.weight], self.G[norm.bias]
+        if Cn > 48 or gw.dtype != torch.float32:
+            return None
+        if gw.data_ptr() + 4 * Cn == gb.data_ptr():
+            first, swap = gw, 1          # memory order (d gamma, d beta)
+        elif gb.data_ptr() + 4 * Cn == gw.data_ptr():
+            first, swap = gb, 0
+        else:
+            return None
+        return dict(epilogue=hip.EP_LN_BWD, act=swap, aux=x, p=(norm.weight, None, None, None, None, None, nsrc["ln"][3]),
+                    residual=residual.view(1, 1, -1, Cn), stats=first, stats_mode=hip.STATS_EP), out.view(1, 1, -1, Cn)
+
+    def _mlp_bwd(self, mlp, n2, a1, dy, drop, ln_bwd=None):
+        """returns dn2; accumulates fc1/fc2 grads.  dy is the gradient of the block output.  ln_bwd = (norm, residual, out): the LayerNorm
+        in front of fc1 is differentiated in the last conv's epilogue when _ln_bwd_ep allows (returns None then: `out` holds the result)."""
         p, s1, s2 = drop
         Cn, Ch = mlp.fc1.weight.shape[1], mlp.fc1.weight.shape[0]
         n2f, dyf = (n2 if isinstance(n2, dict) else n2.view(1, 1, -1, Cn)), dy.view(1, 1, -1, Cn)     # (n2: tensor or _ln_src descriptor)
@@ -949,6 +974,10 @@ class Engine:
         self.conv_T(dict(view=dyf, flags=dflag, drop_seed=s2, drop_p=p), mlp.fc2.weight, da1, Hin=1, Win=npx,
                     epilogue=hip.EP_DGELU, aux=a1, drop_p=p, drop_seed=s1)
         self.wgrad([n2f], da1, mlp.fc1.weight, mlp.fc1.bias, Hin=1, Win=npx)
+        ep = self._ln_bwd_ep(n2, *ln_bwd) if ln_bwd is not None else None
+        if ep is not None:
+            self.conv_T(da1, mlp.fc1.weight, ep[1], Hin=1, Win=npx, **ep[0])
+            return None
         dn2 = _A(dy, 1, 1, npx, Cn)
         self.conv_T(da1, mlp.fc1.weight, dn2, Hin=1, Win=npx)
         return dn2.view(dy.shape)
@@ -960,12 +989,19 @@ class Engine:
         npx = out.numel() // lin.weight.shape[0]
         self.conv([xf], lin.weight, lin.bias, out.view(1, 1, npx, -1), Hin=1, Win=npx, **kw)
 
-    def _lin_bwd(self, lin, x, dy, dx):
+    def _lin_bwd(self, lin, x, dy, dx, ln_bwd=None):
+        """ln_bwd = (norm, residual, out) as in _mlp_bwd: returns True when the data-gradient conv finished the LayerNorm backward (`dx`
+        is then untouched, `out` holds d(input of the LayerNorm))."""
         Cn, Co = lin.weight.shape[1], dy.shape[-1]
         xf, dyf = (x if isinstance(x, dict) else x.view(1, 1, -1, Cn)), dy.view(1, 1, -1, Co)
         npx = dyf.shape[2]
         self.wgrad([xf], dyf, lin.weight, lin.bias, Hin=1, Win=npx)
+        ep = self._ln_bwd_ep(x, *ln_bwd) if ln_bwd is not None else None
+        if ep is not None:
+            self.conv_T(dyf, lin.weight, ep[1], Hin=1, Win=npx, **ep[0])
+            return True
         self.conv_T(dyf, lin.weight, dx.view(1, 1, npx, Cn), Hin=1, Win=npx)
+        return False
 
     def nat_fwd(self, m, x, cx, tag):
         B, H, W, C = x.shape
@@ -1002,9 +1038,10 @@ class Engine:
         x, e, n1, qkv, o, a, n2 = S["x"], S["e"], S["n1"], S["qkv"], S["o"], S["a"], S["n2"]
         B, H, W, C = x.shape
         G = self.G
-        dn2 = self._mlp_bwd(m.mlp, n2, S["a1"], dy, S["drop"])
         da = _A(x, B, H, W, C)
-        hip.ln_bwd(a, m.norm2.weight, dn2, dy, da, G[m.norm2.weight], G[m.norm2.bias])
+        dn2 = self._mlp_bwd(m.mlp, n2, S["a1"], dy, S["drop"], ln_bwd=(m.norm2, dy, da))
+        if dn2 is not None:     # (else: the last conv of the Mlp backward wrote da -- LayerNorm backward in its epilogue)
+            hip.ln_bwd(a, m.norm2.weight, dn2, dy, da, G[m.norm2.weight], G[m.norm2.bias])
         do = _A(x, B, H, W, C)
         self._lin_bwd(m.att1.proj, o, da, do)
         dqkv = _A(x, B, H, W, 3 * C)
@@ -1012,9 +1049,9 @@ class Engine:
         if self.probe is not None:
             self.probe("nat_bwd:na", m, dict(qkv=qkv, do=do, dqkv=dqkv, rpb=m.att1.rpb, heads=m.att1.num_heads))
         dn1 = do
-        self._lin_bwd(m.att1.qkv, n1, dqkv, dn1)
         de = _A(x, B, H, W, C)
-        hip.ln_bwd(e, m.norm1.weight, dn1, da, de, G[m.norm1.weight], G[m.norm1.bias])
+        if not self._lin_bwd(m.att1.qkv, n1, dqkv, dn1, ln_bwd=(m.norm1, da, de)):
+            hip.ln_bwd(e, m.norm1.weight, dn1, da, de, G[m.norm1.weight], G[m.norm1.bias])
         dx = _A(x, B, H, W, C)
         self.conv3_bwd(m.patchembedding.patch_embeddings, x, de, dx=dx)
         if self.probe is not None:

@@ -14,12 +14,12 @@ LIB_PATH = os.environ.get("LMNET_HIP_LIB") or os.path.join(_HERE, "liblmnet_hip.
 
 # ---- constants mirrored from include/lmnet_hip.h
 SRC_GELU, SRC_DROP, SRC_LN, SRC_UP2 = 1, 2, 4, 8
-EP_LINEAR, EP_AFFINE_ACT, EP_DGELU, EP_BN_BWD1, EP_BN_BWD2, EP_SE_BWD = 0, 1, 2, 3, 4, 5
+EP_LINEAR, EP_AFFINE_ACT, EP_DGELU, EP_BN_BWD1, EP_BN_BWD2, EP_SE_BWD, EP_LN_BWD = 0, 1, 2, 3, 4, 5, 6
 ACT_NONE, ACT_HSWISH, ACT_GELU = 0, 1, 2
 STATS_NONE, STATS_SUM_SQ, STATS_EP = 0, 1, 2
 F32, BF16 = 0, 1            # matrix-core operand type of the dense contractions (LMN_F32 / LMN_BF16)
 _MMA = [F32]                # ... of the pass in flight (engine.begin_pass)
-ABI_VERSION = 11
+ABI_VERSION = 12
 
 
 class SrcT(C.Structure):

@@ -763,6 +763,20 @@ def check_ln_linear():
         hip.ln_bwd(dev(x), dev(g), dn.view(n, Cn), None, dx, dg, dbt)
         rows.append(("LN+linear dx (linear^T, ln_bwd)" + tag, rel(dx, x.grad), 2e-4))
         rows.append(("LN+linear dgamma / dbeta" + tag, max(rel(dg, g.grad), rel(dbt, b.grad)), 2e-4))
+        # ... and the LayerNorm backward inside the data-gradient conv (LMN_EP_LN_BWD, C <= 48): dx (+ a residual gradient), d gamma /
+        # d beta accumulated (+=) into a [2][C] pair in either row order
+        if Cn <= 48:
+            dres = R(n, Cn, seed=138)
+            for swap in (0, 1):
+                gpair = torch.full((2, Cn), 0.25, device=DEV)
+                dx2 = torch.full((1, 1, n, Cn), float("nan"), device=DEV)
+                hip.conv_fwd([dyd], wpt, dx2, B=1, Hin=1, Win=n, Hout=1, Wout=n, Cout=Cn, transposed=1, epilogue=hip.EP_LN_BWD, act=swap,
+                             aux=xd, p=(dev(g), None, None, None, None, None, stats), residual=dev(dres).view(1, 1, n, Cn), stats=gpair,
+                             stats_mode=hip.STATS_EP)
+                rows.append(("LN backward in the conv epilogue: dx" + tag + " swap=%d" % swap, rel(dx2.view(n, Cn), x.grad + dres), 2e-4))
+                dgf, dbf = (gpair[0], gpair[1]) if swap else (gpair[1], gpair[0])
+                rows.append(("LN backward in the conv epilogue: dgamma / dbeta (+=)" + tag + " swap=%d" % swap,
+                             max(rel(dgf - 0.25, g.grad), rel(dbf - 0.25, b.grad)), 2e-4))
     return rows
 
 
