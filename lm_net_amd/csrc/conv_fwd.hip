@@ -558,6 +558,21 @@ int lmn_conv_fwd(const lmn_conv_args_t* args, lmn_stream_t stream) {
       while (c > 2 && (size_t)T.TP * (c * 16 + 8) * sizeof(float) > 37 * 1024) --c;
       if (c > T.CKB) T.CKB = c;
     }
+    if (ncw && a.ksize == 3 && !up2) {
+      // M-split 3x3 on the small maps: a block is alone (or one of two) on its CU there, so nothing hides its staging round trips and
+      // barriers -- one per 32-channel chunk, twelve per tile at 372 channels (phase: MFMA duty 54 % of a 149 us kernel whose 240 blocks
+      // are one per CU).  K chunks of 4 / 8 K16 blocks while the grid leaves the LDS to at most two (one) blocks per CU.
+      static int ckb3_env = -1;   // LMN_CONVM_CKB3: cap (2 = the 32-channel chunks of rounds 2-4, A/B runs)
+      if (ckb3_env < 0) { const char* e = getenv("LMN_CONVM_CKB3"); ckb3_env = e ? atoi(e) : 8; }
+      const long mblk = (long)a.B * ((gW + T.TW - 1) / T.TW) * ((gH + T.TH - 1) / T.TH) * ((P.NCTT + 4 * ncw - 1) / (4 * ncw));
+      const size_t lds_cap = mblk <= 288 ? 144 * 1024 : (mblk <= 576 ? 72 * 1024 : 0);
+      for (int c = 8; c > 2; c >>= 1) {
+        if (c > ckb3_env || c > maxkb) continue;      // (a chunk size the layer's sources never fill)
+        const bool bf0 = a.mma_dtype == LMN_BF16;
+        const size_t need = ((size_t)T.XH * T.XW * (c * (bf0 ? 8 : 16) + (bf0 ? 4 : 8)) + (2 + 9) * 4 * ncw * 16) * sizeof(float);
+        if (need <= lds_cap) { T.CKB = c; break; }
+      }
+    }
     // LDS pixel stride: conflict-free ds_read_b128 for 16 pixels st_in apart (brute-forced over the b128 lane groups):
     // +8 floats at unit stride, +4 at stride 2 (PMC: 0.5 conflict cycles per LDS cycle with +4 at unit stride)
     T.CS = T.CKB * 16 + (st_in == 1 ? 8 : 4);
@@ -581,7 +596,7 @@ int lmn_conv_fwd(const lmn_conv_args_t* args, lmn_stream_t stream) {
     const size_t wl_bytes = (size_t)9 * T.CKB * tnct * (a.mma_dtype == LMN_BF16 ? 128 : 256) * sizeof(float);
     const bool wlk = a.ksize == 3 && !s2t && shmem + wl_bytes <= (size_t)wl_kb * 1024;
     if (wlk) shmem += wl_bytes;
-    LMN_REQUIRE(shmem <= 64 * 1024, "conv_fwd: LDS window %zu B", shmem);
+    LMN_REQUIRE(ncw || shmem <= 64 * 1024, "conv_fwd: LDS window %zu B", shmem);
     int blocks = T.total_tiles;
     int maxb = 1280 / tchunks > 256 ? 1280 / tchunks : 256;  // ~5 resident blocks per CU: one round of persistent blocks
     if (npg == 4) {   // the larger window: as many blocks as the LDS of a CU holds (at most five)

@@ -174,12 +174,13 @@ __global__ __launch_bounds__(256) void conv_tileM_kernel(const ConvParams P) {
       const lmn_src_t& S = A.src[s];
       const LmnLay LS = P.lay_src[s];   // (used by the row-planar instances only)
       (void)LS;
-      for (int kb0 = 0; kb0 < P.nkb[s]; kb0 += P.CKB) {
-        const int nkbc = P.nkb[s] - kb0 < P.CKB ? P.nkb[s] - kb0 : P.CKB;
-        // step it = (tap, kk).  3x3: nkbc is 1 or 2, tap = it >> ksh, kk = it & ksh; 1x1: kk = it, chunks of up to 8 K16 blocks (the
+      for (int kb0 = 0, nkbc = 0; kb0 < P.nkb[s]; kb0 += nkbc) {
+        nkbc = P.nkb[s] - kb0 < P.CKB ? P.nkb[s] - kb0 : P.CKB;
+        if (TAPS == 9) nkbc = nkbc >= 8 ? 8 : nkbc >= 4 ? 4 : nkbc >= 2 ? 2 : 1;   // 3x3: chunks of 1 / 2 / 4 / 8 K16 blocks (the step index splits by shift / mask)
+        // step it = (tap, kk).  3x3: nkbc is 1 or 2, tap = it >> ksh, kk = it & kmsk; 1x1: kk = it, chunks of up to 8 K16 blocks (the
         // whole K of most wide layers: ONE staging round trip + barrier pair per tile instead of one per 32 channels -- on the small
         // maps a block's life was that chain, phase clocks: staging + barriers 40-50 %, MFMA 36 %)
-        const int ksh = nkbc - 1, niter = TAPS * nkbc;
+        const int ksh = nkbc >= 8 ? 3 : nkbc >= 4 ? 2 : nkbc - 1, kmsk = nkbc - 1, niter = TAPS * nkbc;   // (3x3) tap = it >> ksh, kk = it & kmsk
         wfrag wcur[NCW];
         {
           const float* wp = wlane + ((int64_t)(P.kb_off[s] + kb0) * P.NCTT) * WT;
@@ -379,12 +380,12 @@ __global__ __launch_bounds__(256) void conv_tileM_kernel(const ConvParams P) {
           const int itn = it + 1 < niter ? it + 1 : it;
           wfrag wnext[NCW];
           {
-            const int tapn = TAPS == 1 ? 0 : itn >> ksh, kkn = TAPS == 1 ? itn : itn & ksh;
+            const int tapn = TAPS == 1 ? 0 : itn >> ksh, kkn = TAPS == 1 ? itn : itn & kmsk;
             const float* wp = wlane + (((int64_t)tapn * P.NKB + P.kb_off[s] + kb0 + kkn) * P.NCTT) * WT;
 #pragma unroll
             for (int c = 0; c < NCW; ++c) wnext[c] = ldfrag<BF>(wp + wtile[c]);
           }
-          const int tap = TAPS == 1 ? 0 : it >> ksh, kk = TAPS == 1 ? it : it & ksh;
+          const int tap = TAPS == 1 ? 0 : it >> ksh, kk = TAPS == 1 ? it : it & kmsk;
           const int ty = tap / KS, tx = tap - ty * KS;
           const int fy = A.transposed ? KS - 1 - ty : ty, fx = A.transposed ? KS - 1 - tx : tx;
           const int toff = (fy * P.XW + fx) * P.CS;
@@ -396,7 +397,7 @@ __global__ __launch_bounds__(256) void conv_tileM_kernel(const ConvParams P) {
           if constexpr (XPF) {
             const int tapq = TAPS == 1 ? 0 : itn >> ksh, tyq = tapq / KS, txq = tapq - tyq * KS;
             const int fyq = A.transposed ? KS - 1 - tyq : tyq, fxq = A.transposed ? KS - 1 - txq : txq;
-            toffq = (fyq * P.XW + fxq) * P.CS; kkq = TAPS == 1 ? itn : itn & ksh;
+            toffq = (fyq * P.XW + fxq) * P.CS; kkq = TAPS == 1 ? itn : itn & kmsk;
           }
 #pragma unroll
           for (int h = 0; h < NGM; h += 4) {

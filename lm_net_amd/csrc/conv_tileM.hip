@@ -18,15 +18,17 @@ int lmn_launch_conv_tileM(const ConvParams& T, dim3 mgrid, size_t msh, hipStream
 #undef LMN_CL
     return 0;
   }
+// (3x3 calls on the small maps stage K chunks of up to 128 channels: more than the default 64 KB of dynamic LDS)
+#define LMN_BIGLDS(kern) do { if (msh > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)msh); } while (0)
 #define LMN_CM(TT, NN, BFV)                                                                              \
   do {                                                                                                   \
     switch ((TT) == 1 ? ek : (ek > 2 ? 1 : ek)) {                                                        \
-      case 0: LMN_LAUNCH((conv_tileM_kernel<TT, NN, 0, BFV>), mgrid, dim3(256), msh, st, T); break;   \
-      case 2: LMN_LAUNCH((conv_tileM_kernel<TT, NN, 2, BFV>), mgrid, dim3(256), msh, st, T); break;   \
+      case 0: LMN_BIGLDS((conv_tileM_kernel<TT, NN, 0, BFV>)); LMN_LAUNCH((conv_tileM_kernel<TT, NN, 0, BFV>), mgrid, dim3(256), msh, st, T); break;   \
+      case 2: LMN_BIGLDS((conv_tileM_kernel<TT, NN, 2, BFV>)); LMN_LAUNCH((conv_tileM_kernel<TT, NN, 2, BFV>), mgrid, dim3(256), msh, st, T); break;   \
       case 3: LMN_LAUNCH((conv_tileM_kernel<1, NN, 3, BFV>), mgrid, dim3(256), msh, st, T); break;    \
       case 4: LMN_LAUNCH((conv_tileM_kernel<1, NN, 4, BFV>), mgrid, dim3(256), msh, st, T); break;    \
       case 5: LMN_LAUNCH((conv_tileM_kernel<1, NN, 5, BFV>), mgrid, dim3(256), msh, st, T); break;    \
-      default: LMN_LAUNCH((conv_tileM_kernel<TT, NN, 1, BFV>), mgrid, dim3(256), msh, st, T); break;  \
+      default: LMN_BIGLDS((conv_tileM_kernel<TT, NN, 1, BFV>)); LMN_LAUNCH((conv_tileM_kernel<TT, NN, 1, BFV>), mgrid, dim3(256), msh, st, T); break;  \
     }                                                                                                    \
   } while (0)
 #define LMN_CMB(TT, NN) do { if (pm == 2) LMN_CM(TT, NN, 2); else if (pm == 1) LMN_CM(TT, NN, 1); else LMN_CM(TT, NN, 0); } while (0)
@@ -37,5 +39,6 @@ int lmn_launch_conv_tileM(const ConvParams& T, dim3 mgrid, size_t msh, hipStream
 #undef LMN_CMR
 #undef LMN_CMB
 #undef LMN_CM
+#undef LMN_BIGLDS
   return 0;
 }
