@@ -48,7 +48,7 @@ extern "C" {
 
 typedef void* lmn_stream_t; /* hipStream_t */
 
-#define LMN_ABI_VERSION 12
+#define LMN_ABI_VERSION 13
 /* arithmetic type of the matrix-core operands of a dense contraction (accumulators, epilogues, statistics: fp32) */
 #define LMN_F32 0  /* v_mfma_f32_16x16x4_f32: exact fp32 (k-ordered fma chain)                                  */
 #define LMN_BF16 1 /* v_mfma_f32_16x16x16_bf16: operands rounded to bf16 (RNE) when staged / packed -- the mixed- */
@@ -260,6 +260,11 @@ int lmn_sizeof_wgrad_args(void);
 /* floats of workspace that make lmn_conv_wgrad use the two-stage reduction for this problem (0: not useful) */
 int64_t lmn_conv_wgrad_workspace(const lmn_wgrad_args_t* args);
 int lmn_conv_wgrad(const lmn_wgrad_args_t* args, lmn_stream_t stream);
+/* (ABI 13) 1 when lmn_conv_wgrad takes these arguments with LMN_SRC_UP2 on its source -- the 3x3 weight gradient of
+ * `Upsample(x2, bilinear, align_corners) -> Conv2d` (core/LM_Net.py:58-74, core/modules.py:94,129) sampling the upsampling
+ * where it stages its window; 0: the caller materialises the upsampled tensor (lmn_up2_fwd) and passes it as a plain source.
+ * Host arithmetic only (the launch's own geometry predicate), nothing is launched, lmn_last_error is left untouched.       */
+int lmn_conv_wgrad_up2_ok(const lmn_wgrad_args_t* args);
 /* Deferred second stage of the K-split reduction.  Every weight gradient of a backward pass used to be followed by its own
  * reduction launch (82 launches of 8-11 us per LM-Net training step); with defer_reduce the partials stay in per-call
  * workspaces and ONE launch per gradient bucket sums all of them (same fixed order: deterministic).

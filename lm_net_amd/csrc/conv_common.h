@@ -28,7 +28,8 @@ struct ConvParams {
   LmnLay lay_src[3], lay_out, lay_aux;   // address forms of the operands (common.h: NHWC or row-planar)
   int32_t rpw;                           // image width of the row-planar operands of the call (0: none)
   uint32_t rp_magic;                     // floor(2^32 / rpw)
-  int32_t prio;                          // LMN_CONV_PRIO (experiment): > 0 = the co-resident waves of a SIMD get DISTINCT issue priorities
+  int32_t prio;                          // LMN_CONV_PRIO (experiment): 1..3 = the co-resident waves of a SIMD get DISTINCT issue priorities;
+                                         // >= 100: start stagger of (prio - 100) x 256 cycles per wave slot (lmn_wave_stagger)
 };
 
 // Distinct issue priorities for the waves that share a SIMD (one wave of each co-resident block): equal-priority waves share the matrix
@@ -45,6 +46,17 @@ __device__ __forceinline__ void lmn_wave_prio(int mode) {
     case 2: __builtin_amdgcn_s_setprio(2); break;
     default: __builtin_amdgcn_s_setprio(3); break;
   }
+}
+
+// Start stagger: the persistent blocks of a launch are dispatched together, run the same program on tiles of the same size and share
+// the matrix pipe fairly, so the co-resident blocks of a CU stay in lock-step for the whole kernel -- all stage, then all multiply
+// (tile time = staging + N x loop) -- and nothing ever desynchronises them.  A one-off delay of slot x units x 256 cycles
+// before the first tile spreads their phases; equal tile times then keep the spacing.
+__device__ __forceinline__ void lmn_wave_stagger(int units) {
+  uint32_t slot;
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID, 0, 4)" : "=s"(slot));   // wave slot of this wave on its SIMD
+  const int n = (int)(slot & 7u) * units;
+  for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(4);   // 4 x 64 cycles
 }
 
 namespace {

@@ -464,6 +464,11 @@ int lmn_conv_fwd(const lmn_conv_args_t* args, lmn_stream_t stream) {
       static int prio_env = -1;   // LMN_CONV_PRIO: 0 off | 1, 2, 3 = distinct issue priorities per wave slot (lmn_wave_prio); 3x3 calls only unless +10
       if (prio_env < 0) { const char* e = getenv("LMN_CONV_PRIO"); prio_env = e ? atoi(e) : 0; }
       T.prio = (a.ksize == 3 || prio_env >= 10) ? prio_env % 10 : 0;
+      static int stag3 = -1, stag1 = -1;   // LMN_CONV_STAGGER / LMN_CONV_STAGGER1: start stagger of the 3x3 / 1x1 tile kernels, units of 256 cycles per wave slot
+      if (stag3 < 0) { const char* e = getenv("LMN_CONV_STAGGER"); stag3 = e ? atoi(e) : 0; }
+      if (stag1 < 0) { const char* e = getenv("LMN_CONV_STAGGER1"); stag1 = e ? atoi(e) : 0; }
+      const int stg = a.ksize == 3 ? stag3 : stag1;
+      if (stg > 0) T.prio = 100 + stg;
     }
     if (a.ksize == 1) {
       a.Wout *= a.Hout; a.Win *= a.Hin; a.Hout = a.Hin = 1;

@@ -128,7 +128,7 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(const ConvParams P) {
   constexpr int WT = BF ? 128 : 256;   // floats per packed weight fragment tile (64 lanes x 8 or 16 bytes)
   constexpr int KD = BF ? 8 : 16;      // LDS dwords per K16 block of a pixel
   const lmn_conv_args_t& A = P.a;
-  if (P.prio) lmn_wave_prio(P.prio);   // (uniform)
+  if (P.prio > 0 && P.prio < 100) lmn_wave_prio(P.prio);   // (uniform)
   const uint32_t soff = A.seed_ctr ? *A.seed_ctr : 0u;  // device-side dropout stream offset (graph replays: one bump per step)
   // EPI: 0 plain (LINEAR / AFFINE_ACT, no statistics), 1 generic, 2 LINEAR + SUM_SQ statistics, 3 BN_BWD1, 4 BN_BWD2,
   // 5 SE_BWD, 6 LN_BWD (1x1 NHWC only).  For EPI >= 2 the epilogue kind is a compile-time constant: each instance carries only its own code
@@ -170,6 +170,7 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(const ConvParams P) {
   float* s_par = s_stats + 2 * NCT * 16;  // [9][NCT*16]
   conv_stage_params<NCT>(A, s_par, ct0, tid, blockIdx.x == 0 && blockIdx.z == 0);  // (one writer per cout range, also with parity classes in grid.z)
   __syncthreads();  // the tiles read s_par from their first instruction on (accumulators start from the bias)
+  if (P.prio >= 100) lmn_wave_stagger(P.prio - 100);   // (uniform)
   float* s_w = s_par + 9 * NCT * 16;  // WL: [tap * nkbc + kk][NCT][WT]
   auto stage_w = [&](int s, int kb0, int nkbc) __attribute__((always_inline)) {
     constexpr int Q = WT / 4;  // float4 per fragment tile (64 lanes x 16 or 8 bytes)

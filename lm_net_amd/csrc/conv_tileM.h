@@ -30,7 +30,8 @@ __global__ __launch_bounds__(256) void conv_tileM_kernel(const ConvParams P) {
   constexpr int KD = BF ? 8 : 16;
   constexpr int NCT = 4 * NCW;  // cout tiles per block
   const lmn_conv_args_t& A = P.a;
-  if (P.prio) lmn_wave_prio(P.prio);   // (uniform)
+  if (P.prio > 0 && P.prio < 100) lmn_wave_prio(P.prio);   // (uniform)
+  if (P.prio >= 100) lmn_wave_stagger(P.prio - 100);
   const uint32_t soff = A.seed_ctr ? *A.seed_ctr : 0u;  // device-side dropout stream offset (graph replays: one bump per step)
   // EPI: 0 plain (LINEAR / AFFINE_ACT, no statistics), 1 generic, 2 LINEAR + SUM_SQ statistics, 3 BN_BWD1, 4 BN_BWD2,
   // 5 SE_BWD.  For EPI >= 2 the epilogue kind is a compile-time constant: each instance carries only its own code
@@ -162,7 +163,20 @@ __global__ __launch_bounds__(256) void conv_tileM_kernel(const ConvParams P) {
         const float md = sm * invC;
         float var = sq * invC - md * md;
         var = var > 0.f ? var : 0.f;
-        const float mean = x0 + md, rstd = rsqrtf(var + S0.ln_eps);
+        const float mean = x0 + md;
+        // The sums are about channel 0.  When that channel sits far from the row mean (md^2 >> var) the subtraction above cancels
+        // digits the variance needs: such rows (uniform over a pixel's tpp threads -- the values are the reduced ones) take a second
+        // pass about the mean itself, as the N-split kernel's in-register two-pass form does.  Its loads hit L1 / L2.
+        if (md * md > 4.f * var) {
+          float s2 = 0.f;
+          for (int f = h; f < C4; f += tpp) {
+            const f32x4 d = ld4(px + f * 4) - mean;
+            s2 += (d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3]);
+          }
+          for (int m = tpp >> 1; m >= 1; m >>= 1) s2 += __shfl_xor(s2, m, 64);
+          var = s2 * invC;
+        }
+        const float rstd = rsqrtf(var + S0.ln_eps);
         if (h == 0 && inp) {
           s_ln[2 * p] = mean;
           s_ln[2 * p + 1] = rstd;

@@ -1632,6 +1632,25 @@ static int wgrad_setup(const lmn_wgrad_args_t& A, WgradParams& P, WgGeom& G) {
 
 int lmn_sizeof_reduce_job(void) { return (int)sizeof(lmn_reduce_job_t); }
 
+// 1 when lmn_conv_wgrad accepts these arguments WITH LMN_SRC_UP2 on the source (the wgrad3 form samples the bilinear x2 where it
+// stages its window), 0 when the caller has to materialise the upsampled tensor first.  Host arithmetic only: the geometry of the
+// call without the flag (wgrad_setup: ONE predicate for the launch and for this query), then the two conditions of the fused form.
+int lmn_conv_wgrad_up2_ok(const lmn_wgrad_args_t* args) {
+  if (!args || args->nsrc != 1 || args->ksize != 3 || args->stride != 1 || (args->Hin & 1) || (args->Win & 1)) return 0;
+  if ((args->src[0].flags & ~LMN_SRC_UP2) || args->src[0].scale) return 0;
+  lmn_wgrad_args_t a = *args;
+  a.src[0].flags = 0;
+  // (the plain call describes the UPSAMPLED tensor: the 32-bit offset checks of wgrad_setup then bound the quarter-size source too)
+  WgradParams P;
+  WgGeom G;
+  char keep[sizeof(g_lmn_err)];
+  memcpy(keep, g_lmn_err, sizeof(keep));
+  const int rc = wgrad_setup(a, P, G);
+  memcpy(g_lmn_err, keep, sizeof(keep));   // a query leaves no error text behind
+  if (rc != 0 || !G.v1) return 0;
+  return (P.XH + 1) / 2 + 2 <= (G.NMT * G.NNT == 1 ? 3 : 2) * 64 / 19 ? 1 : 0;
+}
+
 // Description of the reduction a deferred weight-gradient call (args->defer_reduce) leaves behind: `out->nblk == 0` when the call
 // reduces on its own (atomics: small totals, or no workspace).  Pure host arithmetic, nothing is launched.
 int lmn_conv_wgrad_job(const lmn_wgrad_args_t* args, lmn_reduce_job_t* out) {

@@ -777,13 +777,13 @@ class Engine:
         h, w = x.shape[1:3]
         self.conv([dict(view=x, flags=hip.SRC_UP2)], conv.weight, conv.bias, out, Hin=2 * h, Win=2 * w, k=3, **kw)
 
-    def conv3_up_bwd(self, conv, x, dy, dx_small, tmp_ok=True):
-        """Backward of conv3_up_fwd.  Weight gradient: the 3x3 weight gradient with the same on-load sampling (maps >= 32 wide);
-        smaller maps recompute `up` on the weight-gradient stream right before the launch (off the compute chain; the forward kept
-        nothing).  Data gradient: dup = conv^T(dy), dx = bilinear_x2^T(dup) into dx_small (written, not accumulated)."""
+    def conv3_up_bwd(self, conv, x, dy, dx_small):
+        """Backward of conv3_up_fwd.  Weight gradient: the 3x3 weight gradient with the same on-load sampling where the library's own
+        predicate (hip.conv_wgrad_up2_ok: the wgrad3 form, maps >= 32 wide, 32-bit offsets) accepts it; otherwise `up` is recomputed
+        on the weight-gradient stream right before the launch (off the compute chain; the forward kept nothing).  Data gradient:
+        dup = conv^T(dy), dx = bilinear_x2^T(dup) into dx_small (written, not accumulated)."""
         B, h, w, C = x.shape
-        if self.fuse_up_wgrad and 2 * w >= 32:
-            # the weight gradient samples the upsampling where it stages its window too (wgrad3_kernel<..., UP>: maps >= 32 wide)
+        if self.fuse_up_wgrad and hip.conv_wgrad_up2_ok(x, dy, B=B, Hin=2 * h, Win=2 * w, Cout=conv.weight.shape[0]):
             self.wgrad([dict(view=x, flags=hip.SRC_UP2)], dy, conv.weight, conv.bias, Hin=2 * h, Win=2 * w, k=3)
         else:
             up = _A(x, B, 2 * h, 2 * w, C)

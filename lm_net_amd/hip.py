@@ -19,7 +19,7 @@ ACT_NONE, ACT_HSWISH, ACT_GELU = 0, 1, 2
 STATS_NONE, STATS_SUM_SQ, STATS_EP = 0, 1, 2
 F32, BF16 = 0, 1            # matrix-core operand type of the dense contractions (LMN_F32 / LMN_BF16)
 _MMA = [F32]                # ... of the pass in flight (engine.begin_pass)
-ABI_VERSION = 12
+ABI_VERSION = 13
 
 
 class SrcT(C.Structure):
@@ -125,7 +125,7 @@ class ReduceJob(C.Structure):
 SYMBOLS = [
     "lmn_abi_version", "lmn_sizeof_conv_args", "lmn_sizeof_src", "lmn_sizeof_wgrad_args", "lmn_last_error",
     "lmn_conv_pack_size", "lmn_conv_pack", "lmn_conv_pack_batch", "lmn_sizeof_pack_job", "lmn_conv_fwd", "lmn_conv_wgrad", "lmn_conv_wgrad_workspace",
-    "lmn_conv_wgrad_job", "lmn_wgrad_reduce_batch", "lmn_sizeof_reduce_job", "lmn_reparam_fold", "lmn_affine2", "lmn_reparam_wfin", "lmn_bnact_fwd_fin", "lmn_bnact_bwd_fin",
+    "lmn_conv_wgrad_job", "lmn_conv_wgrad_up2_ok", "lmn_wgrad_reduce_batch", "lmn_sizeof_reduce_job", "lmn_reparam_fold", "lmn_affine2", "lmn_reparam_wfin", "lmn_bnact_fwd_fin", "lmn_bnact_bwd_fin",
     "lmn_dw_stats", "lmn_dw_fwd", "lmn_dw_merge", "lmn_dw_finalize_merge", "lmn_dw_bwd_stats", "lmn_dw_bwd_coef", "lmn_dw_bwd", "lmn_dw_fwd_bn", "lmn_dw_bwd_bn",
     "lmn_se_fwd", "lmn_se_bwd", "lmn_se_bwd_dm", "lmn_se_bwd_params", "lmn_na_fwd", "lmn_na_bwd", "lmn_plan_host_profile", "lmn_set_deterministic", "lmn_get_deterministic", "lmn_gattn_fwd", "lmn_gattn_bwd",
     "lmn_ln_fwd", "lmn_ln_bwd", "lmn_bnact_fwd", "lmn_bnact_bwd_stats", "lmn_bnact_bwd",
@@ -495,6 +495,21 @@ def conv_fwd(srcs, wpack, out, *, B, Hin, Win, Hout, Wout, Cout, ksize=1, stride
     a.act_dtype = _dt(*[(s["view"] if isinstance(s, dict) else s) for s in srcs], aux, residual, out)
     a.seed_ctr = _SEED_CTR[0].data_ptr() if _SEED_CTR[0] is not None else None
     _check(load().lmn_conv_fwd(C.byref(a), _stream()), "conv_fwd")
+
+
+def conv_wgrad_up2_ok(src, dy, *, B, Hin, Win, Cout):
+    """True when conv_wgrad takes `src` (the half-resolution map) with SRC_UP2 for a 3x3 stride-1 weight gradient over the Hin x Win
+    upsampled image (lmn_conv_wgrad_up2_ok: the library's own launch predicate, host arithmetic only)."""
+    a = WgradArgs()
+    a.B, a.Hout, a.Wout, a.Hin, a.Win = B, Hin, Win, Hin, Win
+    a.ksize, a.stride, a.nsrc, a.Cout = 3, 1, 1, Cout
+    _fill_src(a.src[0], dict(view=src, flags=SRC_UP2))
+    v = _as_view(dy)
+    a.dy, a.dy_cstride, a.dy_rp_w = v.ptr, v.cstride, v.rp
+    a.dW = 0x1000   # (any non-null pointer: the query touches no memory)
+    a.mma_dtype = _MMA[0]
+    a.act_dtype = _dt(src, dy)
+    return bool(load().lmn_conv_wgrad_up2_ok(C.byref(a)))
 
 
 def conv_wgrad(srcs, dy, dW, db, *, B, Hin, Win, Hout, Wout, Cout, ksize=1, stride=1, dy_flags=0, dy_seed=0, dy_p=0.0,

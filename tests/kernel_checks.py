@@ -823,6 +823,120 @@ def check_conv_up2():
     return rows
 
 
+def check_fused_sources_modes():
+    """the on-load / epilogue fusions of round 5 (LMN_SRC_LN, LMN_SRC_UP2, LMN_EP_LN_BWD) in the modes that only the
+    end-to-end tests reached -- bf16 STORAGE (PM = 2 instances) and deterministic mode (slot path of the epilogue statistics) --
+    against the UNFUSED kernels of the same mode at tight tolerances (the model-level bf16 tolerances cannot see a 1 % single-block
+    error), plus LayerNorm rows whose channel 0 is far from the row mean (the M-split pre-pass sums about channel 0)."""
+    rows = []
+    bf = lambda t: t.to(torch.bfloat16)
+    # ---- LayerNorm rows with an outlier in channel 0 (fp32): N-split (12, 24), M-split pre-pass (48, 96, 372)
+    for Cn, Co, n in ((12, 36, 77), (24, 48, 130), (48, 96, 257), (96, 192, 64), (372, 744, 50)):
+        x = R(n, Cn, seed=161) * 0.7 + 0.2
+        x[:, 0] = 250.0 + R(n, seed=162) * 3.0
+        x[::3, 0] = -400.0
+        g, b = R(Cn, seed=163).abs() + 0.5, R(Cn, seed=164) * 0.3
+        w, bias = R(Co, Cn, seed=165, scale=0.2), R(Co, seed=166)
+        y_ref = F.linear(F.layer_norm(x, (Cn,), g, b, 1e-5), w, bias)
+        stats = torch.full((n, 2), float("nan"), device=DEV)
+        src = dict(view=dev(x).view(1, 1, n, Cn), ln=(dev(g), dev(b), 1e-5, stats))
+        wp = hip.conv_pack(dev(w).view(Co, Cn, 1, 1), 1, [Cn])
+        y = torch.full((1, 1, n, Co), float("nan"), device=DEV)
+        hip.conv_fwd([src], wp, y, B=1, Hin=1, Win=n, Hout=1, Wout=n, Cout=Co, bias=dev(bias))
+        xf = dev(x).double().cpu()   # (statistics of the fp32-rounded input: 250 +- 3 loses 2e-5 absolute to the rounding itself)
+        mu, rs = xf.mean(1), 1.0 / torch.sqrt(xf.var(1, unbiased=False) + 1e-5)
+        tag = " C=%d->%d n=%d" % (Cn, Co, n)
+        rows.append(("LN+linear, channel-0 outlier: stats table" + tag, max(rel(stats[:, 0], mu), rel(stats[:, 1], rs)), 2e-5))
+        rows.append(("LN+linear, channel-0 outlier: fwd" + tag, rel(y.view(n, Co), y_ref), 2e-4))
+    # ---- bf16 storage: fused LN -> linear against ln_fwd + plain conv, its weight gradient against the one over the stored LN output
+    mma0 = hip._MMA[0]
+    hip._MMA[0] = hip.BF16
+    try:
+        for Cn, Co, n in ((12, 36, 1043), (24, 72, 300), (48, 96, 257), (96, 192, 64), (372, 744, 50)):
+            x = bf(dev(R(n, Cn, seed=171) * 1.7 + 0.6))
+            g, b = dev(R(Cn, seed=172).abs() + 0.5), dev(R(Cn, seed=173) * 0.3)
+            w, bias = dev(R(Co, Cn, seed=174, scale=0.2)), dev(R(Co, seed=175))
+            dy = bf(dev(R(n, Co, seed=176)))
+            tag = " C=%d->%d n=%d" % (Cn, Co, n)
+            wp = hip.conv_pack(w.view(Co, Cn, 1, 1), 1, [Cn])
+            stats = torch.full((n, 2), float("nan"), device=DEV)
+            src = dict(view=x.view(1, 1, n, Cn), ln=(g, b, 1e-5, stats))
+            yf = torch.full((1, 1, n, Co), float("nan"), device=DEV, dtype=torch.bfloat16)
+            hip.conv_fwd([src], wp, yf, B=1, Hin=1, Win=n, Hout=1, Wout=n, Cout=Co, bias=bias)
+            nrm = torch.full((n, Cn), float("nan"), device=DEV, dtype=torch.bfloat16)
+            hip.ln_fwd(x, g, b, nrm)
+            yu = torch.full((1, 1, n, Co), float("nan"), device=DEV, dtype=torch.bfloat16)
+            hip.conv_fwd([nrm.view(1, 1, n, Cn)], wp, yu, B=1, Hin=1, Win=n, Hout=1, Wout=n, Cout=Co, bias=bias)
+            # (both round LN(x) to bf16 once; their fp32 values differ in the last bit, so single operands flip by one bf16 ulp)
+            rows.append(("bf16 storage LN+linear fwd vs ln_fwd + conv" + tag, rel(yf.float(), yu.float()), 1.2e-2))
+            dWf, dbf = torch.zeros(Co, Cn, 1, 1, device=DEV), torch.zeros(Co, device=DEV)
+            hip.conv_wgrad([src], dy.view(1, 1, n, Co), dWf, dbf, B=1, Hin=1, Win=n, Hout=1, Wout=n, Cout=Co)
+            dWu, dbu = torch.zeros(Co, Cn, 1, 1, device=DEV), torch.zeros(Co, device=DEV)
+            hip.conv_wgrad([nrm.view(1, 1, n, Cn)], dy.view(1, 1, n, Co), dWu, dbu, B=1, Hin=1, Win=n, Hout=1, Wout=n, Cout=Co)
+            rows.append(("bf16 storage LN+linear wgrad vs wgrad over ln_fwd" + tag, max(rel(dWf, dWu), rel(dbf, dbu)), 5e-3))
+        for (B, h, w_, Cin, Cout) in ((2, 9, 11, 24, 12), (1, 22, 13, 48, 24), (1, 8, 7, 192, 96), (2, 16, 16, 24, 12), (1, 22, 37, 48, 24)):
+            x = bf(nhwc(R(B, Cin, h, w_, seed=181)))
+            wt, bias = dev(R(Cout, Cin, 3, 3, seed=182, scale=0.15)), dev(R(Cout, seed=183))
+            tag = " %dx%d %d->%d" % (h, w_, Cin, Cout)
+            wp = hip.conv_pack(wt, 3, [Cin])
+            kw = dict(B=B, Hin=2 * h, Win=2 * w_, Hout=2 * h, Wout=2 * w_, Cout=Cout, ksize=3)
+            yf = torch.full((B, 2 * h, 2 * w_, Cout), float("nan"), device=DEV, dtype=torch.bfloat16)
+            hip.conv_fwd([dict(view=x, flags=hip.SRC_UP2)], wp, yf, bias=bias, **kw)
+            up = torch.full((B, 2 * h, 2 * w_, Cin), float("nan"), device=DEV, dtype=torch.bfloat16)
+            hip.up2_fwd(x, up)
+            yu = torch.full((B, 2 * h, 2 * w_, Cout), float("nan"), device=DEV, dtype=torch.bfloat16)
+            hip.conv_fwd([up], wp, yu, bias=bias, **kw)
+            rows.append(("bf16 storage conv3x3(up2 on load) vs up2_fwd + conv" + tag, rel(yf.float(), yu.float()), 1.2e-2))
+            if 2 * w_ >= 32:
+                dy = bf(nhwc(R(B, Cout, 2 * h, 2 * w_, seed=184)))
+                dWf, dbf = torch.zeros(Cout, Cin, 3, 3, device=DEV), torch.zeros(Cout, device=DEV)
+                hip.conv_wgrad([dict(view=x, flags=hip.SRC_UP2)], dy, dWf, dbf, **kw)
+                dWu, dbu = torch.zeros(Cout, Cin, 3, 3, device=DEV), torch.zeros(Cout, device=DEV)
+                hip.conv_wgrad([up], dy, dWu, dbu, **kw)
+                rows.append(("bf16 storage wgrad3x3(up2 on load) vs wgrad over up2_fwd" + tag, max(rel(dWf, dWu), rel(dbf, dbu)), 5e-3))
+    finally:
+        hip._MMA[0] = mma0
+    # ---- deterministic mode (fp32): LN backward in the conv epilogue (slot path of d gamma / d beta, both row orders) against
+    #      linear^T + lmn_ln_bwd, twice (bit-identical); the fused forwards are untouched by the mode but must still agree
+    det0 = hip.get_deterministic()
+    hip.set_deterministic(True)
+    try:
+        for Cn, Co, n in ((12, 36, 1043), (24, 72, 777), (48, 144, 333), (20, 8, 35)):
+            x = dev(R(n, Cn, seed=191) * 1.7 + 0.6)
+            g = dev(R(Cn, seed=192).abs() + 0.5)
+            b = dev(R(Cn, seed=193) * 0.3)
+            w = dev(R(Co, Cn, seed=194, scale=0.2))
+            dy, dres = dev(R(n, Co, seed=195)), dev(R(n, Cn, seed=196))
+            tag = " C=%d->%d n=%d" % (Cn, Co, n)
+            stats = torch.full((n, 2), float("nan"), device=DEV)
+            src = dict(view=x.view(1, 1, n, Cn), ln=(g, b, 1e-5, stats))
+            wp = hip.conv_pack(w.view(Co, Cn, 1, 1), 1, [Cn])
+            y = torch.full((1, 1, n, Co), float("nan"), device=DEV)
+            hip.conv_fwd([src], wp, y, B=1, Hin=1, Win=n, Hout=1, Wout=n, Cout=Co)
+            wpt = hip.conv_pack_t(w.view(Co, Cn, 1, 1), 1, 0, Cn, cred=Co)
+            dn = torch.full((1, 1, n, Cn), float("nan"), device=DEV)
+            hip.conv_fwd([dy.view(1, 1, n, Co)], wpt, dn, B=1, Hin=1, Win=n, Hout=1, Wout=n, Cout=Cn, transposed=1)
+            dxu, dgu, dbu = torch.full((n, Cn), float("nan"), device=DEV), torch.zeros(Cn, device=DEV), torch.zeros(Cn, device=DEV)
+            hip.ln_bwd(x, g, dn.view(n, Cn), None, dxu, dgu, dbu)
+            for swap in (0, 1):
+                got = []
+                for rep in range(2):
+                    gpair = torch.full((2, Cn), 0.25, device=DEV)
+                    dx2 = torch.full((1, 1, n, Cn), float("nan"), device=DEV)
+                    hip.conv_fwd([dy.view(1, 1, n, Co)], wpt, dx2, B=1, Hin=1, Win=n, Hout=1, Wout=n, Cout=Cn, transposed=1, epilogue=hip.EP_LN_BWD,
+                                 act=swap, aux=x.view(1, 1, n, Cn), p=(g, None, None, None, None, None, stats), residual=dres.view(1, 1, n, Cn),
+                                 stats=gpair, stats_mode=hip.STATS_EP)
+                    got.append((dx2.clone(), gpair.clone()))
+                dgf, dbf = (got[0][1][0], got[0][1][1]) if swap else (got[0][1][1], got[0][1][0])
+                rows.append(("deterministic LN_BWD epilogue vs linear^T + ln_bwd: dx" + tag + " swap=%d" % swap, rel(got[0][0].view(n, Cn), dxu + dres), 2e-5))
+                rows.append(("deterministic LN_BWD epilogue: dgamma / dbeta" + tag + " swap=%d" % swap, max(rel(dgf - 0.25, dgu), rel(dbf - 0.25, dbu)), 2e-5))
+                same = bool(torch.equal(got[0][0], got[1][0]) and torch.equal(got[0][1], got[1][1]))
+                rows.append(("deterministic LN_BWD epilogue: two launches bit-identical" + tag + " swap=%d" % swap, 0.0 if same else 1.0, 0.5))
+    finally:
+        hip.set_deterministic(det0)
+    return rows
+
+
 def check_bn_tail():
     """BatchNorm(batch stats)+GELU tail: bn_finalize, bnact_fwd, bnact_bwd_stats, bn_bwd_coef, bnact_bwd, colsum."""
     rows = []
