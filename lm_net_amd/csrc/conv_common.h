@@ -126,5 +126,9 @@ __device__ unsigned long long g_ct_timing[4096 * 8];
 int lmn_launch_conv_tile_1x1(const ConvParams& T, dim3 grid, size_t shmem, hipStream_t st, int tnct, int pm, int ek, bool rp, bool ln);
 int lmn_launch_conv_tile_3x3(const ConvParams& T, dim3 grid, size_t shmem, hipStream_t st, int tnct, int pm, int ek, bool wlk, bool up);
 int lmn_launch_conv_tile_3x3g(const ConvParams& T, dim3 grid, size_t shmem, hipStream_t st, int tnct, int pm, int ek, bool wlk);   // NPG = 4 (tnct <= 2)
+// LDS-DMA double-buffered 3x3 stride-1 kernel of the small-channel layers (conv_dma3.hip): one plain NHWC fp32 source of 12 / 24 channels,
+// Cout <= 32, plain epilogue (bias, residual, SUM_SQ statistics); T.tiles_x / tiles_y / total_tiles describe 8 x 16-pixel tiles
+size_t lmn_conv_dma3_lds(int C, int nct);
+int lmn_launch_conv_dma3(const ConvParams& T, int blocks, hipStream_t st);
 int lmn_launch_conv_tile_s2t(const ConvParams& T, dim3 grid, size_t shmem, hipStream_t st, int tnct, int pm, int ek);
 int lmn_launch_conv_tileM(const ConvParams& T, dim3 grid, size_t shmem, hipStream_t st, int taps, int ncw, int pm, int ek, bool rp, bool ln, bool up);

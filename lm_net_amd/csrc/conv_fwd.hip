@@ -291,6 +291,17 @@ int lmn_conv_pack_batch(const lmn_pack_job_t* jobs_dev, int njobs, int64_t total
   return lmn_launch_status("conv_pack_batch");
 }
 
+// LDS-DMA 3x3 kernel (conv_dma3.hip): -1 = read LMN_CONV_DMA at the first call (default on), 0 off, 1 on; calls with fewer 8 x 16-pixel
+// tiles than the threshold keep conv_tile_kernel (two resident blocks per CU want >= 512 tiles to pipeline)
+static int g_conv_dma_mode = -1;
+static int g_conv_dma_min_tiles = 512;
+int lmn_conv_dma_config(int mode, int min_tiles) {
+  const int prev = g_conv_dma_mode;
+  if (mode >= 0) g_conv_dma_mode = mode;
+  if (min_tiles >= 0) g_conv_dma_min_tiles = min_tiles;
+  return prev;
+}
+
 int lmn_conv_fwd(const lmn_conv_args_t* args, lmn_stream_t stream) {
   LMN_REQUIRE(args, "conv_fwd: null args");
   if (g_lmn_rec) {
@@ -309,6 +320,16 @@ int lmn_conv_fwd(const lmn_conv_args_t* args, lmn_stream_t stream) {
   LMN_REQUIRE(A.wpack, "conv_fwd: null packed weights");
   LMN_REQUIRE(A.out || A.stats, "conv_fwd: neither out nor stats requested");
   LMN_REQUIRE(!(A.transposed && A.nsrc != 1), "conv_fwd: transposed form takes one source");
+  {
+    static int trace = -1;   // LMN_CONV_TRACE=1: one line per call on stderr (which layer shapes reach which kernel form)
+    if (trace < 0) { const char* e = getenv("LMN_CONV_TRACE"); trace = e ? atoi(e) : 0; }
+    if (trace) {
+      fprintf(stderr, "conv_fwd k%d s%d T%d B%d %dx%d->%dx%d nsrc%d C", A.ksize, A.stride, A.transposed, A.B, A.Hin, A.Win, A.Hout, A.Wout, A.nsrc);
+      for (int s = 0; s < A.nsrc; ++s) fprintf(stderr, "%s%d/%d(f%d%s%s)", s ? "+" : "", A.src[s].C, A.src[s].cstride, A.src[s].flags, A.src[s].scale ? "s" : "", A.src[s].rp_w ? "r" : "");
+      fprintf(stderr, " Cout%d/%d ep%d st%d act%d drop%g res%d aux%d fin%d mma%d adt%d orp%d bias%d%d\n", A.Cout, A.out_cstride, A.epilogue, A.stats_mode, A.act, (double)A.drop_p,
+              A.residual != nullptr, A.aux != nullptr, A.fin.mode, A.mma_dtype, A.act_dtype, A.out_rp_w, A.bias != nullptr, A.bias2 != nullptr);
+    }
+  }
   ConvParams P;
   P.det_stats = nullptr;
   P.prio = 0;
@@ -659,6 +680,33 @@ int lmn_conv_fwd(const lmn_conv_args_t* args, lmn_stream_t stream) {
       lmn_launch_conv_tile_s2t(T, zgrid, shmem, st, tnct, pm, ek);
       det_finish();
       return lmn_launch_status("conv_fwd(tile, stride-2 data gradient)");
+    }
+    {
+      // LDS-DMA double-buffered kernel (conv_dma3.hip) for the small-channel 3x3 stride-1 calls: one plain NHWC fp32 source of 12 / 24
+      // channels, Cout <= 32, bias / residual / SUM_SQ statistics only, maps that give every CU tiles to pipeline (levels 0-1 at batch 8)
+      if (g_conv_dma_mode < 0) { const char* e = getenv("LMN_CONV_DMA"); g_conv_dma_mode = e ? atoi(e) : 1; }   // LMN_CONV_DMA: 0 = off (conv_tile_kernel everywhere, A/B runs)
+      const int dma_env = g_conv_dma_mode;
+      const lmn_src_t& s0 = a.src[0];
+      const int64_t dtiles = (int64_t)a.B * ((a.Wout + 15) / 16) * ((a.Hout + 7) / 8);
+      const bool dma_ok = dma_env != 0 && a.ksize == 3 && a.stride == 1 && !up2 && !ln && pm == 0 && a.nsrc == 1 && s0.flags == 0 && !s0.scale && s0.rp_w == 0 &&
+                          (s0.C == 12 || s0.C == 24) && P.NCTT <= 2 && a.epilogue == LMN_EP_LINEAR && (a.stats_mode == LMN_STATS_NONE || a.stats_mode == LMN_STATS_SUM_SQ) &&
+                          a.drop_p == 0.f && !a.aux && a.fin.mode == LMN_FIN_NONE && !a.out_rp_w && a.Hin == a.Hout && a.Win == a.Wout && dtiles >= g_conv_dma_min_tiles && dtiles < (1 << 30) &&
+                          (int64_t)a.B * a.Hin * a.Win * s0.cstride * 4 < 0x7fffffffLL && (int64_t)a.B * a.Hout * a.Wout * a.out_cstride * 4 < 0x7fffffffLL &&
+                          (!a.residual || (int64_t)a.B * a.Hout * a.Wout * a.res_cstride < 0x7fffffffLL);
+      if (dma_ok) {
+        ConvParams D = T;
+        D.tiles_x = (a.Wout + 15) / 16; D.tiles_y = (a.Hout + 7) / 8; D.total_tiles = (int)dtiles;
+        const size_t lds = lmn_conv_dma3_lds(s0.C, P.NCTT);
+        int bpc = (int)((160 * 1024) / (lds + 256));
+        bpc = bpc > 4 ? 4 : (bpc < 1 ? 1 : bpc);
+        int dblocks = 256 * bpc;
+        if (dblocks > D.total_tiles) dblocks = D.total_tiles;
+        if (int rc = det_prep(dblocks)) return rc;
+        D.det_stats = T.det_stats;
+        LMN_REQUIRE(lmn_launch_conv_dma3(D, dblocks, st) == 0, "conv_fwd: no LDS-DMA instance for C=%d, %d cout tiles", s0.C, P.NCTT);
+        det_finish();
+        return lmn_launch_status("conv_fwd(dma3)");
+      }
     }
     const dim3 grid(blocks, tchunks);
     LMN_REQUIRE(a.epilogue != LMN_EP_LN_BWD || (tchunks == 1 && a.ksize == 1 && T.rpw == 0 && !ln), "conv_fwd: LN_BWD needs every cout in one block (N-split 1x1 NHWC call)");

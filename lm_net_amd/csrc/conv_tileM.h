@@ -163,18 +163,22 @@ __global__ __launch_bounds__(256) void conv_tileM_kernel(const ConvParams P) {
         const float md = sm * invC;
         float var = sq * invC - md * md;
         var = var > 0.f ? var : 0.f;
-        const float mean = x0 + md;
-        // The sums are about channel 0.  When that channel sits far from the row mean (md^2 >> var) the subtraction above cancels
-        // digits the variance needs: such rows (uniform over a pixel's tpp threads -- the values are the reduced ones) take a second
-        // pass about the mean itself, as the N-split kernel's in-register two-pass form does.  Its loads hit L1 / L2.
+        float mean = x0 + md;
+        // The sums are about channel 0.  When that channel sits far from the row mean (md^2 >> var) both x0 + md and the subtraction
+        // above cancel digits: such rows (uniform over a pixel's tpp threads -- the values are the reduced ones) take a second pass
+        // about the first estimate of the mean, as the N-split kernel's in-register two-pass form does.  Its loads hit L1 / L2.
         if (md * md > 4.f * var) {
-          float s2 = 0.f;
+          float s1 = 0.f, s2 = 0.f;
           for (int f = h; f < C4; f += tpp) {
             const f32x4 d = ld4(px + f * 4) - mean;
+            s1 += (d[0] + d[1]) + (d[2] + d[3]);
             s2 += (d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3]);
           }
-          for (int m = tpp >> 1; m >= 1; m >>= 1) s2 += __shfl_xor(s2, m, 64);
-          var = s2 * invC;
+          for (int m = tpp >> 1; m >= 1; m >>= 1) { s1 += __shfl_xor(s1, m, 64); s2 += __shfl_xor(s2, m, 64); }
+          const float dm = s1 * invC;
+          mean += dm;
+          var = s2 * invC - dm * dm;
+          var = var > 0.f ? var : 0.f;
         }
         const float rstd = rsqrtf(var + S0.ln_eps);
         if (h == 0 && inp) {

@@ -5,3 +5,4 @@
 #include "conv_tile_3x3.hip"
 #include "conv_tileM.hip"
 #include "conv_wgrad.hip"
+#include "conv_dma3.hip"

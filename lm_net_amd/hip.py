@@ -124,7 +124,7 @@ class ReduceJob(C.Structure):
 # every symbol include/lmnet_hip.h declares (the CPU test suite checks the library exports all of them)
 SYMBOLS = [
     "lmn_abi_version", "lmn_sizeof_conv_args", "lmn_sizeof_src", "lmn_sizeof_wgrad_args", "lmn_last_error",
-    "lmn_conv_pack_size", "lmn_conv_pack", "lmn_conv_pack_batch", "lmn_sizeof_pack_job", "lmn_conv_fwd", "lmn_conv_wgrad", "lmn_conv_wgrad_workspace",
+    "lmn_conv_pack_size", "lmn_conv_pack", "lmn_conv_pack_batch", "lmn_sizeof_pack_job", "lmn_conv_fwd", "lmn_conv_dma_config", "lmn_conv_wgrad", "lmn_conv_wgrad_workspace",
     "lmn_conv_wgrad_job", "lmn_conv_wgrad_up2_ok", "lmn_wgrad_reduce_batch", "lmn_sizeof_reduce_job", "lmn_reparam_fold", "lmn_affine2", "lmn_reparam_wfin", "lmn_bnact_fwd_fin", "lmn_bnact_bwd_fin",
     "lmn_dw_stats", "lmn_dw_fwd", "lmn_dw_merge", "lmn_dw_finalize_merge", "lmn_dw_bwd_stats", "lmn_dw_bwd_coef", "lmn_dw_bwd", "lmn_dw_fwd_bn", "lmn_dw_bwd_bn",
     "lmn_se_fwd", "lmn_se_bwd", "lmn_se_bwd_dm", "lmn_se_bwd_params", "lmn_na_fwd", "lmn_na_bwd", "lmn_plan_host_profile", "lmn_set_deterministic", "lmn_get_deterministic", "lmn_gattn_fwd", "lmn_gattn_bwd",
@@ -495,6 +495,12 @@ def conv_fwd(srcs, wpack, out, *, B, Hin, Win, Hout, Wout, Cout, ksize=1, stride
     a.act_dtype = _dt(*[(s["view"] if isinstance(s, dict) else s) for s in srcs], aux, residual, out)
     a.seed_ctr = _SEED_CTR[0].data_ptr() if _SEED_CTR[0] is not None else None
     _check(load().lmn_conv_fwd(C.byref(a), _stream()), "conv_fwd")
+
+
+def conv_dma_config(mode=-1, min_tiles=-1):
+    """lmn_conv_dma_config: LDS-DMA 3x3 kernel on (1) / off (0), smallest call (in 8x16-pixel tiles) that takes it; -1 keeps a value.
+    Returns the previous mode."""
+    return int(load().lmn_conv_dma_config(int(mode), int(min_tiles)))
 
 
 def conv_wgrad_up2_ok(src, dy, *, B, Hin, Win, Cout):

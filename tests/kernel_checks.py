@@ -937,6 +937,90 @@ def check_fused_sources_modes():
     return rows
 
 
+def check_conv_dma3():
+    """conv_dma3_kernel (round 6): the LDS-DMA double-buffered 3x3 stride-1 kernel of the small-channel layers (skip-fuser convs, `nat`
+    patch embedding and their data gradients at levels 0-1; /root/reference/core/modules.py:22-39,83-143, core/LM_Net.py:58-74) vs fp64
+    F.conv2d / its autograd, and against the LDS-tiled kernel on the same call (lmn_conv_dma_config A/B).  Shapes: 12 / 24 source
+    channels x one / two cout tiles, maps that are not multiples of the 8 x 16 tile (zero padding and partial tiles come from the
+    DMA's bounds check), a one-tile-per-block and a many-tiles-per-block grid (prologue-only and steady-state pipeline), source / output
+    slices of wider buffers, residual, SUM_SQ statistics about a shift (4 slices), deterministic slots, the transposed (data-gradient) form."""
+    rows = []
+    prev = hip.conv_dma_config(1, 1)
+    try:
+        for (B, H, W, Cin, Cout) in ((2, 40, 50, 12, 12), (1, 33, 37, 24, 12), (2, 24, 32, 12, 24), (1, 17, 64, 24, 24), (3, 96, 112, 24, 12),
+                                     (8, 64, 96, 12, 12), (1, 8, 16, 24, 20), (1, 5, 7, 12, 8)):
+            tag = " %dx%dx%d %d->%d" % (B, H, W, Cin, Cout)
+            x = R(B, Cin + 8, H, W, seed=401)
+            w = R(Cout, Cin, 3, 3, seed=402, scale=0.15).requires_grad_(True)
+            b = R(Cout, seed=403)
+            res = R(B, Cout, H, W, seed=404)
+            xs = x[:, 4:4 + Cin].clone().requires_grad_(True)
+            z = F.conv2d(xs, w, b, padding=1)
+            y_ref = z + res
+            xb = nhwc(x)
+            wp = hip.conv_pack(dev(w.detach()), 3, [Cin])
+            shift = R(Cout, seed=405) * 0.3
+            got = {}
+            for mode in (1, 0):
+                hip.conv_dma_config(mode, 1)
+                outb = torch.full((B, H, W, Cout + 12), float("nan"), device=DEV)
+                srep = torch.zeros(4, 2, Cout, device=DEV)
+                hip.conv_fwd([hip.V(xb, 4, Cin)], wp, hip.V(outb, 8, Cout), B=B, Hin=H, Win=W, Hout=H, Wout=W, Cout=Cout, ksize=3, bias=dev(b),
+                             residual=nhwc(res), stats=srep, stats_mode=hip.STATS_SUM_SQ, stats_rep=4, p=(None, None, None, None, dev(shift)))
+                got[mode] = (outb, srep.sum(0))
+            hip.conv_dma_config(1, 1)
+            rows.append(("conv_dma3 fwd (slices, bias, residual)" + tag, rel(nchw(got[1][0][..., 8:8 + Cout]), y_ref), TOL))
+            rows.append(("conv_dma3 fwd vs LDS-tiled kernel" + tag, rel(got[1][0][..., 8:8 + Cout], got[0][0][..., 8:8 + Cout]), 2e-6))
+            rows.append(("conv_dma3 untouched slices stay NaN" + tag, 0.0 if bool(torch.isnan(got[1][0][..., :8]).all() and torch.isnan(got[1][0][..., 8 + Cout:]).all()) else 1.0, 0.5))
+            zd = (z - shift.view(1, -1, 1, 1)).detach()
+            sref = torch.stack([zd.sum((0, 2, 3)), (zd * zd).sum((0, 2, 3))])
+            rows.append(("conv_dma3 SUM_SQ statistics about a shift" + tag, rel(got[1][1], sref), 2e-4))
+            # plain call (no residual, no statistics, whole tensors), and statistics only (out = None)
+            xw = nhwc(xs.detach())
+            y1 = torch.full((B, H, W, Cout), float("nan"), device=DEV)
+            hip.conv_fwd([xw], wp, y1, B=B, Hin=H, Win=W, Hout=H, Wout=W, Cout=Cout, ksize=3, bias=dev(b))
+            rows.append(("conv_dma3 fwd plain" + tag, rel(nchw(y1), z), TOL))
+            s1 = torch.zeros(2, Cout, device=DEV)
+            hip.conv_fwd([xw], wp, None, B=B, Hin=H, Win=W, Hout=H, Wout=W, Cout=Cout, ksize=3, bias=dev(b), stats=s1, stats_mode=hip.STATS_SUM_SQ)
+            zz = z.detach()
+            rows.append(("conv_dma3 statistics only" + tag, rel(s1, torch.stack([zz.sum((0, 2, 3)), (zz * zz).sum((0, 2, 3))])), 2e-4))
+            # data gradient (transposed form: taps flipped, weights from conv_pack_t): dy has Cout channels -> only when the kernel takes them
+            if Cout in (12, 24) and Cin <= 32:
+                dy = R(B, Cout, H, W, seed=406)
+                z.backward(dy)
+                wpt = hip.conv_pack_t(dev(w.detach()), 3)
+                acc = R(B, Cin, H, W, seed=407)
+                dx = torch.full((B, H, W, Cin), float("nan"), device=DEV)
+                hip.conv_fwd([nhwc(dy)], wpt, dx, B=B, Hin=H, Win=W, Hout=H, Wout=W, Cout=Cin, ksize=3, transposed=1, residual=nhwc(acc))
+                rows.append(("conv_dma3 data gradient (+ accumulate)" + tag, rel(nchw(dx), xs.grad + acc), TOL))
+                hip.conv_dma_config(0, 1)
+                dx0 = torch.full((B, H, W, Cin), float("nan"), device=DEV)
+                hip.conv_fwd([nhwc(dy)], wpt, dx0, B=B, Hin=H, Win=W, Hout=H, Wout=W, Cout=Cin, ksize=3, transposed=1, residual=nhwc(acc))
+                hip.conv_dma_config(1, 1)
+                rows.append(("conv_dma3 data gradient vs LDS-tiled kernel" + tag, rel(dx, dx0), 2e-6))
+        # deterministic mode: statistics through the per-block slots, two launches bit-identical
+        det0 = hip.get_deterministic()
+        hip.set_deterministic(True)
+        try:
+            B, H, W, Cin, Cout = 2, 40, 50, 24, 12
+            x, w, b = nhwc(R(B, Cin, H, W, seed=411)), R(Cout, Cin, 3, 3, seed=412, scale=0.15), dev(R(Cout, seed=413))
+            wp = hip.conv_pack(dev(w), 3, [Cin])
+            outs = []
+            for rep in range(2):
+                y = torch.full((B, H, W, Cout), float("nan"), device=DEV)
+                st = torch.zeros(2, Cout, device=DEV)
+                hip.conv_fwd([x], wp, y, B=B, Hin=H, Win=W, Hout=H, Wout=W, Cout=Cout, ksize=3, bias=b, stats=st, stats_mode=hip.STATS_SUM_SQ)
+                outs.append((y, st))
+            zr = F.conv2d(nchw(x), w, b.double().cpu(), padding=1)
+            rows.append(("conv_dma3 deterministic statistics", rel(outs[0][1], torch.stack([zr.sum((0, 2, 3)), (zr * zr).sum((0, 2, 3))])), 2e-4))
+            rows.append(("conv_dma3 deterministic: two launches bit-identical", 0.0 if (torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])) else 1.0, 0.5))
+        finally:
+            hip.set_deterministic(det0)
+    finally:
+        hip.conv_dma_config(prev if prev >= 0 else 1, 512)
+    return rows
+
+
 def check_bn_tail():
     """BatchNorm(batch stats)+GELU tail: bn_finalize, bnact_fwd, bnact_bwd_stats, bn_bwd_coef, bnact_bwd, colsum."""
     rows = []
