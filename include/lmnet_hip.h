@@ -225,11 +225,15 @@ typedef struct {
 int lmn_sizeof_pack_job(void);
 int lmn_conv_pack_batch(const lmn_pack_job_t* jobs_dev, int njobs, int64_t total_blocks, lmn_stream_t stream);
 int lmn_conv_fwd(const lmn_conv_args_t* args, lmn_stream_t stream);
-/* (ABI 13) Kernel-form switch of lmn_conv_fwd for the small-channel 3x3 stride-1 calls (one plain NHWC fp32 source of 12 / 24
- * channels, Cout <= 32, bias / residual / SUM_SQ statistics): the LDS-DMA double-buffered kernel (conv_dma3.hip) or the LDS-tiled
- * one.  Same arithmetic either way (k-ordered fp32 MFMA chains over taps and channels; the ORDER of the channels inside a tap differs,
- * so results agree to fp32 rounding, not bit for bit).  mode: 0 off, 1 on, -1 keep; min_tiles: calls with fewer 8x16-pixel tiles keep
- * the LDS-tiled kernel (-1 keep; default 512).  Returns the previous mode (-1: not yet read from LMN_CONV_DMA).  Process-wide.     */
+/* (ABI 13) Kernel-form switch of lmn_conv_fwd: the LDS-DMA double-buffered kernels or the LDS-tiled one, for
+ *   bit 0 (1): the small-channel 3x3 stride-1 calls (one plain NHWC fp32 source of 12 / 24 channels, Cout <= 32, bias / residual /
+ *              SUM_SQ statistics; conv_dma3.hip) -- skip-fuser convs, `nat` patch embedding and their data gradients at levels 0-1
+ *              (core/modules.py:22-39,83-143, core/LM_Net.py:58-74);
+ *   bit 1 (2): the 1x1 convs of ReparamConv at levels 0-1 (conv_dma1.hip: expand conv, pointwise + shortcut, SE-gradient conv,
+ *              folded data gradient; core/modules.py:537-539,576-599).
+ * Same arithmetic either way (k-ordered fp32 MFMA chains; the ORDER of the channels inside a tap differs, so results agree to fp32
+ * rounding, not bit for bit).  mode: bit mask, 0 = off, -1 keep (default 3); min_tiles: calls with fewer pixel tiles keep the
+ * LDS-tiled kernel (-1 keep; default 512).  Returns the previous mode (-1: not yet read from LMN_CONV_DMA).  Process-wide.        */
 int lmn_conv_dma_config(int mode, int min_tiles);
 
 /* Weight/bias gradient:  dW[co][ci][ty][tx] += sum_pixels dy[p][co] * src(p*s + t - pad)[ci]

@@ -130,5 +130,10 @@ int lmn_launch_conv_tile_3x3g(const ConvParams& T, dim3 grid, size_t shmem, hipS
 // Cout <= 32, plain epilogue (bias, residual, SUM_SQ statistics); T.tiles_x / tiles_y / total_tiles describe 8 x 16-pixel tiles
 size_t lmn_conv_dma3_lds(int C, int nct);
 int lmn_launch_conv_dma3(const ConvParams& T, int blocks, hipStream_t st);
+// LDS-DMA streaming kernel of ReparamConv's HBM-bound 1x1 convs at levels 0-1 (conv_dma1.hip): instance lookup (tile pixels, 0: none),
+// LDS bytes, launch.  ks*: channel quads of the sources, aq: of the aux image, mode: 0 plain / 2 SUM_SQ / 5 SE_BWD, gs: GELU x gate on source 0
+int lmn_conv_dma1_tp(int ks0, int ks1, int ks2, int aq, int nct, int mode, int gs);
+size_t lmn_conv_dma1_lds(int ks0, int ks1, int ks2, int aq, int nct, int tp);
+int lmn_launch_conv_dma1(const ConvParams& T, int ks0, int ks1, int ks2, int aq, int nct, int mode, int gs, int blocks, hipStream_t st);
 int lmn_launch_conv_tile_s2t(const ConvParams& T, dim3 grid, size_t shmem, hipStream_t st, int tnct, int pm, int ek);
 int lmn_launch_conv_tileM(const ConvParams& T, dim3 grid, size_t shmem, hipStream_t st, int taps, int ncw, int pm, int ek, bool rp, bool ln, bool up);

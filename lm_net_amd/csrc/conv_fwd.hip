@@ -291,8 +291,8 @@ int lmn_conv_pack_batch(const lmn_pack_job_t* jobs_dev, int njobs, int64_t total
   return lmn_launch_status("conv_pack_batch");
 }
 
-// LDS-DMA 3x3 kernel (conv_dma3.hip): -1 = read LMN_CONV_DMA at the first call (default on), 0 off, 1 on; calls with fewer 8 x 16-pixel
-// tiles than the threshold keep conv_tile_kernel (two resident blocks per CU want >= 512 tiles to pipeline)
+// LDS-DMA kernels (conv_dma3.hip, conv_dma1.hip): -1 = read LMN_CONV_DMA at the first call (default 3), bit 0 = the 3x3 kernel, bit 1 = the
+// 1x1 kernel; calls with fewer tiles than the threshold keep conv_tile_kernel (the resident blocks want tiles to pipeline)
 static int g_conv_dma_mode = -1;
 static int g_conv_dma_min_tiles = 512;
 int lmn_conv_dma_config(int mode, int min_tiles) {
@@ -684,8 +684,8 @@ int lmn_conv_fwd(const lmn_conv_args_t* args, lmn_stream_t stream) {
     {
       // LDS-DMA double-buffered kernel (conv_dma3.hip) for the small-channel 3x3 stride-1 calls: one plain NHWC fp32 source of 12 / 24
       // channels, Cout <= 32, bias / residual / SUM_SQ statistics only, maps that give every CU tiles to pipeline (levels 0-1 at batch 8)
-      if (g_conv_dma_mode < 0) { const char* e = getenv("LMN_CONV_DMA"); g_conv_dma_mode = e ? atoi(e) : 1; }   // LMN_CONV_DMA: 0 = off (conv_tile_kernel everywhere, A/B runs)
-      const int dma_env = g_conv_dma_mode;
+      if (g_conv_dma_mode < 0) { const char* e = getenv("LMN_CONV_DMA"); g_conv_dma_mode = e ? atoi(e) : 3; }   // LMN_CONV_DMA: bit 0 = 3x3 kernel, bit 1 = 1x1 kernel; 0 = off (conv_tile_kernel everywhere, A/B runs)
+      const int dma_env = g_conv_dma_mode & 1;
       const lmn_src_t& s0 = a.src[0];
       const int64_t dtiles = (int64_t)a.B * ((a.Wout + 15) / 16) * ((a.Hout + 7) / 8);
       const bool dma_ok = dma_env != 0 && a.ksize == 3 && a.stride == 1 && !up2 && !ln && pm == 0 && a.nsrc == 1 && s0.flags == 0 && !s0.scale && s0.rp_w == 0 &&
@@ -706,6 +706,46 @@ int lmn_conv_fwd(const lmn_conv_args_t* args, lmn_stream_t stream) {
         LMN_REQUIRE(lmn_launch_conv_dma3(D, dblocks, st) == 0, "conv_fwd: no LDS-DMA instance for C=%d, %d cout tiles", s0.C, P.NCTT);
         det_finish();
         return lmn_launch_status("conv_fwd(dma3)");
+      }
+    }
+    if (a.ksize == 1 && g_conv_dma_mode != 0 && pm == 0 && !ln && a.drop_p == 0.f && a.fin.mode == LMN_FIN_NONE && !a.residual && P.NCTT <= 3) {
+      // LDS-DMA streaming kernel (conv_dma1.hip) for the HBM-bound 1x1 convs of ReparamConv at levels 0-1 (expand conv, pointwise +
+      // shortcut, SE-gradient conv, folded data gradient): plain / row-planar fp32 sources of 4..48 channels, at most GELU x gate on
+      // source 0, epilogues LINEAR (+ SUM_SQ statistics) and SE_BWD; the instance table decides (0 = keep conv_tile_kernel)
+      if (g_conv_dma_mode < 0) { const char* e = getenv("LMN_CONV_DMA"); g_conv_dma_mode = e ? atoi(e) : 3; }
+      int ks[3] = {0, 0, 0};
+      bool ok1 = (g_conv_dma_mode & 2) != 0;
+      int gs = 0;
+      for (int s = 0; s < a.nsrc && ok1; ++s) {
+        const lmn_src_t& S = a.src[s];
+        ks[s] = S.C / 4;
+        const int fl = S.flags;
+        if (s == 0 && fl == LMN_SRC_GELU) gs = 1;
+        else if (fl != 0 || S.scale) ok1 = false;
+        if (s == 0 && fl == 0 && S.scale) ok1 = false;
+        if (S.C % 4 || S.C > 48) ok1 = false;
+      }
+      const bool sebwd = a.epilogue == LMN_EP_SE_BWD && a.stats_mode == LMN_STATS_EP && a.aux;
+      const int mode = sebwd ? 5 : ((a.epilogue == LMN_EP_LINEAR && a.stats_mode == LMN_STATS_SUM_SQ) ? 2 : ((a.epilogue == LMN_EP_LINEAR && a.stats_mode == LMN_STATS_NONE) ? 0 : -1));
+      if (mode < 0 || (!sebwd && a.aux)) ok1 = false;
+      const int aq = sebwd ? a.Cout / 4 : 0;
+      const int tp = ok1 ? lmn_conv_dma1_tp(ks[0], ks[1], ks[2], aq, P.NCTT, mode, gs) : 0;
+      const int64_t npx = (int64_t)a.B * a.Win;   // (flattened: a.Win = H * W)
+      int64_t maxc = a.Cout > a.out_cstride ? a.Cout : a.out_cstride;
+      for (int s = 0; s < a.nsrc; ++s) maxc = a.src[s].cstride > maxc ? a.src[s].cstride : maxc;
+      if (tp > 0 && a.Win % tp == 0 && npx / tp >= g_conv_dma_min_tiles && npx * maxc * 4 < 0x7fffffffLL) {
+        ConvParams D = T;
+        D.total_tiles = (int)(npx / tp);
+        const size_t lds = lmn_conv_dma1_lds(ks[0], ks[1], ks[2], aq, P.NCTT, tp);
+        int bpc = (int)((160 * 1024) / (lds + 256));
+        bpc = bpc > 4 ? 4 : (bpc < 1 ? 1 : bpc);
+        int dblocks = 256 * bpc;
+        if (dblocks > D.total_tiles) dblocks = D.total_tiles;
+        if (int rc = det_prep(dblocks)) return rc;
+        D.det_stats = T.det_stats;
+        LMN_REQUIRE(lmn_launch_conv_dma1(D, ks[0], ks[1], ks[2], aq, P.NCTT, mode, gs, dblocks, st) == 0, "conv_fwd: LDS-DMA 1x1 instance table out of step");
+        det_finish();
+        return lmn_launch_status("conv_fwd(dma1)");
       }
     }
     const dim3 grid(blocks, tchunks);

@@ -6,3 +6,4 @@
 #include "conv_tileM.hip"
 #include "conv_wgrad.hip"
 #include "conv_dma3.hip"
+#include "conv_dma1.hip"

@@ -1017,7 +1017,105 @@ def check_conv_dma3():
         finally:
             hip.set_deterministic(det0)
     finally:
-        hip.conv_dma_config(prev if prev >= 0 else 1, 512)
+        hip.conv_dma_config(prev if prev >= 0 else 3, 512)
+    return rows
+
+
+def check_conv_dma1():
+    """conv_dma1_kernel (round 6): the LDS-DMA streaming form of ReparamConv's 1x1 convs at levels 0-1 (/root/reference/core/modules.py:
+    537-539, 576-599) -- expand conv (row-planar out + SUM_SQ statistics about a shift, in slices), pointwise + shortcut (row-planar
+    source with on-load GELU x gate + NHWC source), SE-gradient conv (row-planar out and aux, per-image sums), three-source folded data
+    gradient -- against the LDS-tiled kernel on the SAME call (lmn_conv_dma_config A/B; that kernel is pinned to fp64 by check_conv_fwd /
+    check_zpath / check_conv_rp) and against fp64 directly for the expand conv and the pointwise pair.  Channel sets of level 0 (12 / 24),
+    level 1 (24 / 48) and the RGB stem (4 -> 24); one tile per block, many tiles per block, several images per block (gate / SE-sum
+    hand-over at the image change), deterministic mode."""
+    rows = []
+    to_rp, to_nhwc = hip.nhwc_to_rp4, hip.rp4_to_nhwc
+    prev = hip.conv_dma_config(3, 1)
+    mk = lambda *sh: torch.full(sh, float("nan"), device=DEV)
+    try:
+        for (B, H, W, Cin, E) in [(2, 16, 24, 12, 24), (3, 8, 16, 24, 48), (2, 32, 64, 12, 24), (9, 16, 8, 24, 48), (2, 16, 16, 4, 24), (1, 64, 128, 12, 24), (1, 32, 96, 24, 48)]:
+            Cout = Cin
+            tag = " Cin=%d E=%d %dx%dx%d" % (Cin, E, B, H, W)
+            xr, prer = R(B, Cin, H, W, seed=501), R(B, E, H, W, seed=502)
+            x, pre, dy, dh = nhwc(xr), nhwc(prer), nhwc(R(B, Cout, H, W, seed=503)), nhwc(R(B, E, H, W, seed=504))
+            wer, ber = R(E, Cin, seed=505, scale=0.3), R(E, seed=506)
+            we, be = dev(wer), dev(ber)
+            wpwr, wscr, b2r = R(Cout, E, seed=507, scale=0.2), R(Cout, Cin, seed=508, scale=0.3), R(Cout, seed=510)
+            wpw, wsc = dev(wpwr), dev(wscr)
+            gater = R(B, E, seed=509).abs()
+            gate = dev(gater)
+            shift = dev(R(E, seed=511) * 0.2)
+            pre_r, dh_r = to_rp(pre), to_rp(dh)
+            kw = dict(B=B, Hin=H, Win=W, Hout=H, Wout=W)
+            res = {}
+            for mode in (3, 0):
+                hip.conv_dma_config(mode, 1)
+                r = {}
+                # F1: expand conv
+                wpe = hip.conv_pack(we, 1, [Cin])
+                z = hip.rp4(mk(B, H, W, E))
+                st = torch.zeros(4, 2, E, device=DEV)
+                hip.conv_fwd([x], wpe, z, Cout=E, bias=be, stats=st, stats_mode=hip.STATS_SUM_SQ, stats_rep=4, p=(None, None, None, None, shift), **kw)
+                r["z"], r["zst"] = to_nhwc(z), st.sum(0)
+                if Cin != 4:
+                    # F2: pointwise + shortcut
+                    n0, n1 = hip.conv_pack_size(1, Cout, [E]), hip.conv_pack_size(1, Cout, [Cin])
+                    wp2 = torch.empty(n0 + n1, device=DEV)
+                    hip.conv_pack(wpw, 1, [E], out=wp2[:n0])
+                    hip.conv_pack(wsc, 1, [Cin], out=wp2[n0:n0 + n1])
+                    y = mk(B, H, W, Cout)
+                    hip.conv_fwd([dict(view=pre_r, scale=gate, flags=hip.SRC_GELU), x], wp2, y, Cout=Cout, bias=dev(b2r), **kw)
+                    r["y"] = y
+                    # B1: SE-gradient conv
+                    wpt = hip.conv_pack_t(wpw, 1, 0, E, cred=Cout)
+                    u = hip.rp4(mk(B, H, W, E))
+                    ds = torch.zeros(B, E, device=DEV)
+                    hip.conv_fwd([dy], wpt, u, Cout=E, transposed=1, epilogue=hip.EP_SE_BWD, aux=pre_r, stats=ds, stats_mode=hip.STATS_EP, **kw)
+                    r["u"], r["ds"] = to_nhwc(u), ds
+                    # B2: three-source data gradient (any packed operator of that shape: expand^T | square | shortcut^T)
+                    wa, wb, wc = dev(R(Cin, E, seed=512, scale=0.2)), dev(R(Cin, Cin, seed=513, scale=0.3)), dev(R(Cin, Cout, seed=514, scale=0.3))
+                    m0, m1, m2 = hip.conv_pack_size(1, Cin, [E]), hip.conv_pack_size(1, Cin, [Cin]), hip.conv_pack_size(1, Cin, [Cout])
+                    wp3 = torch.empty(m0 + m1 + m2, device=DEV)
+                    hip.conv_pack(wa, 1, [E], out=wp3[:m0]); hip.conv_pack(wb, 1, [Cin], out=wp3[m0:m0 + m1]); hip.conv_pack(wc, 1, [Cout], out=wp3[m0 + m1:])
+                    dx = mk(B, H, W, Cin)
+                    hip.conv_fwd([dh_r, x, dy], wp3, dx, Cout=Cin, bias=dev(R(Cin, seed=515)), **kw)
+                    r["dx"] = dx
+                res[mode] = r
+            hip.conv_dma_config(3, 1)
+            for k_ in res[3]:
+                scale_ = 1e-2 if k_ in ("zst", "ds") else 1.0       # (sums: float-atomic order)
+                rows.append(("conv_dma1 vs LDS-tiled kernel: %s%s" % (k_, tag), rel(res[3][k_], res[0][k_]) * scale_, 2e-6))
+            zref = F.conv2d(xr, wer.view(E, Cin, 1, 1), ber)
+            rows.append(("conv_dma1 expand conv vs fp64" + tag, rel(nchw(res[3]["z"]), zref), TOL))
+            zd = zref - shift.double().cpu().view(1, -1, 1, 1)
+            rows.append(("conv_dma1 expand statistics vs fp64" + tag, rel(res[3]["zst"], torch.stack([zd.sum((0, 2, 3)), (zd * zd).sum((0, 2, 3))])), 2e-4))
+            if Cin != 4:
+                yref = F.conv2d(gelu(prer) * gater.view(B, E, 1, 1), wpwr.view(Cout, E, 1, 1)) + F.conv2d(xr, wscr.view(Cout, Cin, 1, 1), b2r)
+                rows.append(("conv_dma1 pointwise + shortcut vs fp64" + tag, rel(nchw(res[3]["y"]), yref), TOL))
+        # deterministic mode: the statistics of F1 and the per-image sums of B1 go through slots; two launches bit-identical
+        det0 = hip.get_deterministic()
+        hip.set_deterministic(True)
+        try:
+            B, H, W, Cin, E = 3, 16, 24, 12, 24
+            x, pre_r, dy = nhwc(R(B, Cin, H, W, seed=521)), to_rp(nhwc(R(B, E, H, W, seed=522))), nhwc(R(B, Cin, H, W, seed=523))
+            we, wpw = dev(R(E, Cin, seed=524, scale=0.3)), dev(R(Cin, E, seed=525, scale=0.2))
+            kw = dict(B=B, Hin=H, Win=W, Hout=H, Wout=W)
+            outs = {}
+            for mode in (3, 3, 0):
+                hip.conv_dma_config(mode, 1)
+                z, st = hip.rp4(mk(B, H, W, E)), torch.zeros(2, E, device=DEV)
+                hip.conv_fwd([x], hip.conv_pack(we, 1, [Cin]), z, Cout=E, stats=st, stats_mode=hip.STATS_SUM_SQ, **kw)
+                u, ds = hip.rp4(mk(B, H, W, E)), torch.zeros(B, E, device=DEV)
+                hip.conv_fwd([dy], hip.conv_pack_t(wpw, 1, 0, E, cred=Cin), u, Cout=E, transposed=1, epilogue=hip.EP_SE_BWD, aux=pre_r, stats=ds, stats_mode=hip.STATS_EP, **kw)
+                outs.setdefault(mode, []).append((z.clone(), st.clone(), u.clone(), ds.clone()))
+            a, b_, c = outs[3][0], outs[3][1], outs[0][0]
+            rows.append(("conv_dma1 deterministic: two launches bit-identical", 0.0 if all(torch.equal(p_, q_) for p_, q_ in zip(a, b_)) else 1.0, 0.5))
+            rows.append(("conv_dma1 deterministic vs LDS-tiled kernel", max(rel(a[0], c[0]), rel(a[1], c[1]) * 1e-2, rel(a[2], c[2]), rel(a[3], c[3]) * 1e-2), 2e-6))
+        finally:
+            hip.set_deterministic(det0)
+    finally:
+        hip.conv_dma_config(prev if prev >= 0 else 3, 512)
     return rows
 
 

@@ -3,8 +3,9 @@ at engine construction), so: N alternating child runs per setting, median report
     python tools/gpu_ab_wall.py "LMN_ZPATH=0" "LMN_ZPATH=1" [--runs 3]"""
 import os, subprocess, sys, json, statistics
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sets = [a for a in sys.argv[1:] if not a.startswith("--")]
 runs = int(sys.argv[sys.argv.index("--runs") + 1]) if "--runs" in sys.argv else 3
+_skip = {sys.argv.index("--runs") + 1} if "--runs" in sys.argv else set()
+sets = [a for i, a in enumerate(sys.argv) if i >= 1 and not a.startswith("--") and i not in _skip]
 res = {s: [] for s in sets}
 for r in range(runs):
     for s in sets:
