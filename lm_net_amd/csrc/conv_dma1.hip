@@ -22,6 +22,11 @@
 // vector, the SE sums -- changes a few times per block).
 #include "conv_tile.h"
 
+#ifdef D1_VAR
+#define D1_VARV D1_VAR
+#else
+#define D1_VARV 0
+#endif
 namespace {
 
 constexpr unsigned D1_OOB = 0x80000000u;
@@ -71,8 +76,8 @@ __global__ __launch_bounds__(256, BPC) void conv_dma1_kernel(const ConvParams P)
   const lmn_conv_args_t& A = P.a;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* const s_w = smem + 2 * NCH * 4;
-  float* const s_stats = s_w + WFL;
-  float* const s_par = s_stats + 2 * NCT * 16;
+  float* const s_red = s_w + WFL;                   // [4 waves][NCT*16]: block-level sums of the SE-gradient epilogue
+  float* const s_par = s_red + 4 * NCT * 16;        // 9 parameter vectors (conv_stage_params)
   const int tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int q = lane >> 4, n = lane & 15;
@@ -120,7 +125,9 @@ __global__ __launch_bounds__(256, BPC) void conv_dma1_kernel(const ConvParams P)
     stage_region(tile, lb + R0 * 16, dpf, NK0, TP * PS0, P.lay_src[0], rs0);
     if constexpr (KS1 > 0) stage_region(tile, lb + R1 * 16, dpf + NK0, NK1, TP * PS1, P.lay_src[1], rs1);
     if constexpr (KS2 > 0) stage_region(tile, lb + R2 * 16, dpf + NK0 + NK1, NK2, TP * PS2, P.lay_src[2], rs2);
+#if !(defined(D1_VAR) && D1_VAR == 3)
     if constexpr (AQ > 0) stage_region(tile, lb + RA * 16, dpf + NK0 + NK1 + NK2, NKA, TP * PSA, P.lay_aux, rsa);
+#endif
   };
 
   // contiguous tile range of the block
@@ -139,7 +146,6 @@ __global__ __launch_bounds__(256, BPC) void conv_dma1_kernel(const ConvParams P)
     const int ctg = min(ct, P.NCTT - 1);
     s_w[i] = A.wpack[((int64_t)(P.kb_off[sidx] + kb) * P.NCTT + ctg) * 256 + (qq * 16 + m) * 4 + jj];
   }
-  for (int i = tid; i < 2 * NCT * 16; i += 256) s_stats[i] = 0.f;
   conv_stage_params<NCT>(A, s_par, 0, tid, blockIdx.x == 0);
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
@@ -160,18 +166,26 @@ __global__ __launch_bounds__(256, BPC) void conv_dma1_kernel(const ConvParams P)
 #pragma unroll
   for (int s = 0; s < (GS ? KS0 : 1); ++s) gate[s] = 1.f;
   const bool det = P.det_stats != nullptr;
-  auto se_flush = [&]() __attribute__((always_inline)) {   // SE_BWD: the finished image's sums (16 pixel lanes -> one add per channel and wave)
+  // SE_BWD: the finished image's sums.  16 pixel lanes -> wave sum -> the four waves through LDS -> ONE atomic instruction per block
+  // and image (24 / 48 lanes).  Per-wave atomics (conv_tile_kernel's form) arrive from all 3,072 waves of the persistent grid at the
+  // same moment here -- 384 adds per address, serialised at the memory side: 70 of the kernel's 125 us at level 0 (round 6 probe).
+  // Called under a block-uniform condition (it holds two barriers).
+  auto se_flush = [&]() __attribute__((always_inline)) {
 #pragma unroll
     for (int c = 0; c < NCT; ++c)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         float t = st0[c][r];
         t += __shfl_xor(t, 1, 64); t += __shfl_xor(t, 2, 64); t += __shfl_xor(t, 4, 64); t += __shfl_xor(t, 8, 64);
-        const int co = c * 16 + q * 4 + r;
-        if (n == 0 && co < A.Cout)
-          lmn_red_add((det ? P.det_stats + (int64_t)(blockIdx.x * 4 + wv) * A.B * A.Cout : A.stats) + cur_b * A.Cout + co, t, det);
+        if (n == 0) s_red[wv * NCT * 16 + c * 16 + q * 4 + r] = t;
         st0[c][r] = 0.f;
       }
+    __syncthreads();
+    if (tid < NCT * 16 && tid < A.Cout) {
+      const float v = ((s_red[tid] + s_red[NCT * 16 + tid]) + s_red[2 * NCT * 16 + tid]) + s_red[3 * NCT * 16 + tid];
+      lmn_red_add((det ? P.det_stats + (int64_t)(blockIdx.x * 4) * A.B * A.Cout : A.stats) + cur_b * A.Cout + tid, v, det);
+    }
+    __syncthreads();
   };
 
   int it = 0;
@@ -186,7 +200,9 @@ __global__ __launch_bounds__(256, BPC) void conv_dma1_kernel(const ConvParams P)
     if (tile + 1 < t_end) stage(tile + 1, cur ^ 1);
     const int b = tile / tiles_img;
     if (b != cur_b) {                               // (block-uniform) a new image
+#if !(defined(D1_VAR) && D1_VAR == 4)
       if (MODE == 5 && cur_b >= 0) se_flush();
+#endif
       cur_b = b;
       if constexpr (GS) {
         if (A.src[0].scale) {
@@ -263,11 +279,19 @@ __global__ __launch_bounds__(256, BPC) void conv_dma1_kernel(const ConvParams P)
 #pragma unroll
           for (int r = 0; r < 4; ++r) { const float d = o[r] - shift4[c][r]; st0[c][r] += d; st1[c][r] += d * d; }
         }
-        if constexpr (MODE == 5) {
+        if constexpr (MODE == 5 && !(D1_VARV == 5)) {
           if (live) {
+#if defined(D1_VAR) && D1_VAR == 2
+            const f32x4 ax = o;
+#else
             const f32x4 ax = *reinterpret_cast<const f32x4*>(XS + (RA + pl * PSA + (co >> 2)) * 4);   // aux (pre) of this pixel and quad, from the image
+#endif
 #pragma unroll
+#if defined(D1_VAR) && D1_VAR == 1
+            for (int r = 0; r < 4; ++r) st0[c][r] += o[r] * ax[r];
+#else
             for (int r = 0; r < 4; ++r) st0[c][r] += o[r] * lmn_gelu(ax[r]);
+#endif
           }
         }
         const unsigned voff = (live && A.out) ? (obase + (uint32_t)(co >> 2) * (uint32_t)P.lay_out.qs) * 4u : D1_OOB;
@@ -275,7 +299,9 @@ __global__ __launch_bounds__(256, BPC) void conv_dma1_kernel(const ConvParams P)
       }
     }
   }
+#if !(defined(D1_VAR) && D1_VAR == 4)
   if (MODE == 5 && cur_b >= 0) se_flush();
+#endif
 
   // ---- SUM_SQ statistics (conv_tile_kernel's tail)
   if constexpr (MODE == 2) {
@@ -314,7 +340,7 @@ __global__ __launch_bounds__(256, BPC) void conv_dma1_kernel(const ConvParams P)
 // LDS bytes of an instance: two images, the weights, statistics slots + parameter vectors
 static size_t d1_lds(int ks0, int ks1, int ks2, int aq, int nct, int tp) {
   const int nch = tp * (d1_ps(ks0) + d1_ps(ks1) + d1_ps(ks2) + d1_ps(aq));
-  return (size_t)2 * nch * 16 + (size_t)nct * 64 * (ks0 + ks1 + ks2) * 4 + (size_t)(2 + 9) * nct * 16 * 4;
+  return (size_t)2 * nch * 16 + (size_t)nct * 64 * (ks0 + ks1 + ks2) * 4 + (size_t)(4 + 9) * nct * 16 * 4;
 }
 
 // Instance table: (quads of the three sources, aux quads, cout tiles, mode, GELU-scale source 0) -> tile pixels; 0: no instance
