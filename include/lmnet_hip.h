@@ -155,6 +155,28 @@ typedef struct {
   float* dbeta;
 } lmn_bn_fin_t;
 
+/* (ABI 13) A SECOND 1x1 conv chained behind a 1x1 lmn_conv_fwd call: out2 = W2 . out + bias2 per pixel, computed from the first
+ * conv's output tile while it is still in registers (the accumulator fragment of a 16x16x4 MFMA is the B fragment of the next one) --
+ * `out` is written as before, but never re-read, and one launch disappears.  Two uses inside a stage `Sequential(ReparamConv,
+ * ReparamConv)` (core/LM_Net.py:11-57):
+ *   forward : pointwise + shortcut of block A (core/modules.py:597-599) -> expand conv of block B (core/modules.py:537, 586):
+ *             epilogue LMN_EP_LINEAR, stats_mode LMN_STATS_SUM_SQ (about `shift`, slices, snapshot: as lmn_conv_args_t);
+ *   backward: folded data gradient of block B (lmn_reparam_fold) -> data gradient of block A's pointwise conv with the squeeze-excite
+ *             sums (epilogue LMN_EP_SE_BWD, aux = A's `pre`, stats [B][Cout], stats_mode LMN_STATS_EP).
+ * wpack: lmn_conv_pack / lmn_conv_pack_t of the second conv over ONE source of the first conv's Cout rounded up to 4 channels.
+ * Served by the LDS-DMA streaming kernel only (fp32, levels 0-1 of LM-Net at its instance table): lmn_conv_chain_ok says beforehand
+ * whether lmn_conv_fwd takes the arguments; it does not in deterministic mode (two statistics destinations, one slot scratch).    */
+typedef struct {
+  const float* wpack;    /* NULL: no chained conv                                                                                */
+  const float* bias;     /* [Cout] or NULL                                                                                       */
+  const float* shift;    /* SUM_SQ: statistics about shift[co] (NULL: about 0), as p4 of the first conv                          */
+  const void* aux;       /* SE_BWD: activation tensor sampled at the output element                                              */
+  void* out;             /* [pixels][Cout] activation tensor of the second conv (NHWC or row-planar)                             */
+  float* stats;          /* SUM_SQ: [stats_rep (+1 with stats_snap)][2][Cout]; SE_BWD: [B][Cout]                                */
+  int32_t Cout, out_cstride, out_rp_w, aux_cstride, aux_rp_w;
+  int32_t epilogue, stats_mode, stats_rep, stats_snap;
+} lmn_conv_chain_t;
+
 typedef struct {
   int32_t B, Hout, Wout, Hin, Win;
   int32_t ksize;      /* 1 or 3; padding = ksize/2                                                */
@@ -195,6 +217,7 @@ typedef struct {
   lmn_bn_fin_t fin;         /* optional in-kernel BatchNorm bookkeeping (fin.mode = LMN_FIN_NONE: off)                   */
   int32_t stats_snap;       /* LMN_STATS_SUM_SQ: also copy the shift vector p4 (zeros if NULL) to stats[stats_rep*2*Cout..]: */
   int32_t aux_rp_w;         /* a snapshot that stays valid when p4 is a running mean updated by the consuming pass        */
+  lmn_conv_chain_t chain;   /* (ABI 13) optional second 1x1 conv applied to the output tile of this one (chain.wpack NULL: none) */
 } lmn_conv_args_t;
 
 /* number of floats lmn_conv_pack writes for (ksize, Cout, src channel counts c[nsrc]) */
@@ -235,6 +258,9 @@ int lmn_conv_fwd(const lmn_conv_args_t* args, lmn_stream_t stream);
  * rounding, not bit for bit).  mode: bit mask, 0 = off, -1 keep (default 3); min_tiles: calls with fewer pixel tiles keep the
  * LDS-tiled kernel (-1 keep; default 512).  Returns the previous mode (-1: not yet read from LMN_CONV_DMA).  Process-wide.        */
 int lmn_conv_dma_config(int mode, int min_tiles);
+/* (ABI 13) 1 when lmn_conv_fwd accepts these arguments WITH their `chain` (see lmn_conv_chain_t), 0 when the caller launches the two
+ * convs separately.  Host arithmetic only, nothing is launched, lmn_last_error is left untouched.                                */
+int lmn_conv_chain_ok(const lmn_conv_args_t* args);
 
 /* Weight/bias gradient:  dW[co][ci][ty][tx] += sum_pixels dy[p][co] * src(p*s + t - pad)[ci]
  * (sources and their on-load transforms exactly as in the forward call), db[co] += sum dy.

@@ -28,6 +28,8 @@ struct ConvParams {
   LmnLay lay_src[3], lay_out, lay_aux;   // address forms of the operands (common.h: NHWC or row-planar)
   int32_t rpw;                           // image width of the row-planar operands of the call (0: none)
   uint32_t rp_magic;                     // floor(2^32 / rpw)
+  LmnLay lay_out2, lay_aux2;             // chained second conv (lmn_conv_chain_t): its out / aux address forms
+  int32_t NCTT2;                         // ... and its cout tiles
   int32_t prio;                          // LMN_CONV_PRIO (experiment): 1..3 = the co-resident waves of a SIMD get DISTINCT issue priorities;
                                          // >= 100: start stagger of (prio - 100) x 256 cycles per wave slot (lmn_wave_stagger)
 };
@@ -132,8 +134,8 @@ size_t lmn_conv_dma3_lds(int C, int nct);
 int lmn_launch_conv_dma3(const ConvParams& T, int blocks, hipStream_t st);
 // LDS-DMA streaming kernel of ReparamConv's HBM-bound 1x1 convs at levels 0-1 (conv_dma1.hip): instance lookup (tile pixels, 0: none),
 // LDS bytes, launch.  ks*: channel quads of the sources, aq: of the aux image, mode: 0 plain / 2 SUM_SQ / 5 SE_BWD, gs: GELU x gate on source 0
-int lmn_conv_dma1_tp(int ks0, int ks1, int ks2, int aq, int nct, int mode, int gs);
-size_t lmn_conv_dma1_lds(int ks0, int ks1, int ks2, int aq, int nct, int tp);
-int lmn_launch_conv_dma1(const ConvParams& T, int ks0, int ks1, int ks2, int aq, int nct, int mode, int gs, int blocks, hipStream_t st);
+int lmn_conv_dma1_tp(int ks0, int ks1, int ks2, int aq, int nct, int mode, int gs, int nct2, int mode2);
+size_t lmn_conv_dma1_lds(int ks0, int ks1, int ks2, int aq, int nct, int tp, int nct2);
+int lmn_launch_conv_dma1(const ConvParams& T, int ks0, int ks1, int ks2, int aq, int nct, int mode, int gs, int nct2, int mode2, int blocks, hipStream_t st);
 int lmn_launch_conv_tile_s2t(const ConvParams& T, dim3 grid, size_t shmem, hipStream_t st, int tnct, int pm, int ek);
 int lmn_launch_conv_tileM(const ConvParams& T, dim3 grid, size_t shmem, hipStream_t st, int taps, int ncw, int pm, int ek, bool rp, bool ln, bool up);

@@ -302,6 +302,60 @@ int lmn_conv_dma_config(int mode, int min_tiles) {
   return prev;
 }
 
+// Does the LDS-DMA streaming 1x1 kernel (conv_dma1.hip) take this call (UNFLATTENED arguments), and as which instance?
+struct Dma1Sel { int ks[3]; int aq, nct, mode, gs, nct2, mode2, tp; };
+static bool dma1_select(const lmn_conv_args_t& A, Dma1Sel& S) {
+  if (g_conv_dma_mode < 0) { const char* e = getenv("LMN_CONV_DMA"); g_conv_dma_mode = e ? atoi(e) : 3; }
+  if (!(g_conv_dma_mode & 2)) return false;
+  if (A.ksize != 1 || A.stride != 1 || A.mma_dtype != LMN_F32 || A.act_dtype != LMN_F32 || A.drop_p != 0.f || A.fin.mode != LMN_FIN_NONE || A.residual) return false;
+  if (A.nsrc < 1 || A.nsrc > 3 || A.Cout <= 0 || A.Cout % 4 || A.Cout > 48 || A.out_rp_w < 0) return false;
+  if (A.Hin != A.Hout || A.Win != A.Wout) return false;
+  S.ks[0] = S.ks[1] = S.ks[2] = 0;
+  S.gs = 0;
+  for (int s = 0; s < A.nsrc; ++s) {
+    const lmn_src_t& X = A.src[s];
+    if (!X.ptr || X.C <= 0 || X.C % 4 || X.C > 48) return false;
+    if (s == 0 && X.flags == LMN_SRC_GELU) S.gs = 1;
+    else if (X.flags != 0 || X.scale) return false;
+    if (X.rp_w && X.rp_w != A.Win) return false;
+    S.ks[s] = X.C / 4;
+  }
+  if ((A.out_rp_w && A.out_rp_w != A.Win) || (A.aux && A.aux_rp_w && A.aux_rp_w != A.Win)) return false;
+  const bool sebwd = A.epilogue == LMN_EP_SE_BWD && A.stats_mode == LMN_STATS_EP && A.aux && A.stats;
+  S.mode = sebwd ? 5 : ((A.epilogue == LMN_EP_LINEAR && A.stats_mode == LMN_STATS_SUM_SQ && A.stats) ? 2 : ((A.epilogue == LMN_EP_LINEAR && A.stats_mode == LMN_STATS_NONE) ? 0 : -1));
+  if (S.mode < 0 || (!sebwd && A.aux)) return false;
+  S.nct = (A.Cout + 15) / 16;
+  S.aq = sebwd ? A.Cout / 4 : 0;
+  S.nct2 = S.mode2 = 0;
+  int64_t maxc = A.Cout > A.out_cstride ? A.Cout : A.out_cstride;
+  if (sebwd && A.aux_cstride > maxc) maxc = A.aux_cstride;
+  for (int s = 0; s < A.nsrc; ++s) maxc = A.src[s].cstride > maxc ? A.src[s].cstride : maxc;
+  const lmn_conv_chain_t& C2 = A.chain;
+  if (C2.wpack) {
+    if (S.mode != 0 || !A.out || !C2.out || C2.Cout <= 0 || C2.Cout % 4 || C2.Cout > 48 || g_lmn_det) return false;
+    if ((C2.out_rp_w && C2.out_rp_w != A.Win) || (C2.aux && C2.aux_rp_w && C2.aux_rp_w != A.Win)) return false;
+    const bool se2 = C2.epilogue == LMN_EP_SE_BWD && C2.stats_mode == LMN_STATS_EP && C2.aux && C2.stats;
+    const bool sq2 = C2.epilogue == LMN_EP_LINEAR && C2.stats_mode == LMN_STATS_SUM_SQ && C2.stats && !C2.aux && C2.stats_rep >= 1;
+    if (!se2 && !sq2) return false;
+    S.mode2 = se2 ? 5 : 2;
+    S.nct2 = (C2.Cout + 15) / 16;
+    S.aq = se2 ? C2.Cout / 4 : 0;
+    if (C2.Cout > maxc) maxc = C2.Cout;
+    if (C2.out_cstride > maxc) maxc = C2.out_cstride;
+    if (se2 && C2.aux_cstride > maxc) maxc = C2.aux_cstride;
+  }
+  S.tp = lmn_conv_dma1_tp(S.ks[0], S.ks[1], S.ks[2], S.aq, S.nct, S.mode, S.gs, S.nct2, S.mode2);
+  if (S.tp <= 0) return false;
+  const int64_t hw = (int64_t)A.Hin * A.Win, npx = (int64_t)A.B * hw;
+  return hw % S.tp == 0 && npx / S.tp >= g_conv_dma_min_tiles && npx * maxc * 4 < 0x7fffffffLL;
+}
+
+int lmn_conv_chain_ok(const lmn_conv_args_t* args) {
+  if (!args || !args->chain.wpack) return 0;
+  Dma1Sel S;
+  return dma1_select(*args, S) ? 1 : 0;
+}
+
 int lmn_conv_fwd(const lmn_conv_args_t* args, lmn_stream_t stream) {
   LMN_REQUIRE(args, "conv_fwd: null args");
   if (g_lmn_rec) {
@@ -309,6 +363,10 @@ int lmn_conv_fwd(const lmn_conv_args_t* args, lmn_stream_t stream) {
     lmn_rec_push([copy, stream]() -> int { return lmn_conv_fwd(&copy, stream); }, "lmn_conv_fwd(");
   }
   const lmn_conv_args_t& A = *args;
+  if (A.chain.wpack) {
+    Dma1Sel Sc;
+    LMN_REQUIRE(dma1_select(A, Sc), "conv_fwd: these arguments do not take a chained second conv (lmn_conv_chain_ok says so beforehand)");
+  }
   LMN_REQUIRE(A.ksize == 1 || A.ksize == 3, "conv_fwd: ksize %d", A.ksize);
   LMN_REQUIRE(A.stride == 1 || A.stride == 2, "conv_fwd: stride %d", A.stride);
   LMN_REQUIRE(A.nsrc >= 1 && A.nsrc <= 3, "conv_fwd: nsrc %d", A.nsrc);
@@ -448,7 +506,12 @@ int lmn_conv_fwd(const lmn_conv_args_t* args, lmn_stream_t stream) {
     double by = ipix * cin + (A.out ? opix * A.Cout : 0.0);
     if (A.aux) by += opix * A.Cout;
     if (A.residual) by += opix * A.Cout;
-    lmn_prof_cost(2.0 * macs, (A.act_dtype == LMN_BF16 ? 2.0 : 4.0) * by);
+    double macs2 = 0.0;
+    if (A.chain.wpack) {   // chained second conv: its MACs and its output (+ aux); the first conv's output is written, never re-read
+      macs2 = opix * (double)A.Cout * A.chain.Cout;
+      by += opix * A.chain.Cout * (A.chain.aux ? 2.0 : 1.0);
+    }
+    lmn_prof_cost(2.0 * (macs + macs2), (A.act_dtype == LMN_BF16 ? 2.0 : 4.0) * by);
   }
   P.NCTT = (A.Cout + 15) / 16;
   P.ncls = (A.transposed && A.stride == 2) ? 4 : 1;
@@ -708,42 +771,28 @@ int lmn_conv_fwd(const lmn_conv_args_t* args, lmn_stream_t stream) {
         return lmn_launch_status("conv_fwd(dma3)");
       }
     }
-    if (a.ksize == 1 && g_conv_dma_mode != 0 && pm == 0 && !ln && a.drop_p == 0.f && a.fin.mode == LMN_FIN_NONE && !a.residual && P.NCTT <= 3) {
+    if (a.ksize == 1) {
       // LDS-DMA streaming kernel (conv_dma1.hip) for the HBM-bound 1x1 convs of ReparamConv at levels 0-1 (expand conv, pointwise +
-      // shortcut, SE-gradient conv, folded data gradient): plain / row-planar fp32 sources of 4..48 channels, at most GELU x gate on
-      // source 0, epilogues LINEAR (+ SUM_SQ statistics) and SE_BWD; the instance table decides (0 = keep conv_tile_kernel)
-      if (g_conv_dma_mode < 0) { const char* e = getenv("LMN_CONV_DMA"); g_conv_dma_mode = e ? atoi(e) : 3; }
-      int ks[3] = {0, 0, 0};
-      bool ok1 = (g_conv_dma_mode & 2) != 0;
-      int gs = 0;
-      for (int s = 0; s < a.nsrc && ok1; ++s) {
-        const lmn_src_t& S = a.src[s];
-        ks[s] = S.C / 4;
-        const int fl = S.flags;
-        if (s == 0 && fl == LMN_SRC_GELU) gs = 1;
-        else if (fl != 0 || S.scale) ok1 = false;
-        if (s == 0 && fl == 0 && S.scale) ok1 = false;
-        if (S.C % 4 || S.C > 48) ok1 = false;
-      }
-      const bool sebwd = a.epilogue == LMN_EP_SE_BWD && a.stats_mode == LMN_STATS_EP && a.aux;
-      const int mode = sebwd ? 5 : ((a.epilogue == LMN_EP_LINEAR && a.stats_mode == LMN_STATS_SUM_SQ) ? 2 : ((a.epilogue == LMN_EP_LINEAR && a.stats_mode == LMN_STATS_NONE) ? 0 : -1));
-      if (mode < 0 || (!sebwd && a.aux)) ok1 = false;
-      const int aq = sebwd ? a.Cout / 4 : 0;
-      const int tp = ok1 ? lmn_conv_dma1_tp(ks[0], ks[1], ks[2], aq, P.NCTT, mode, gs) : 0;
-      const int64_t npx = (int64_t)a.B * a.Win;   // (flattened: a.Win = H * W)
-      int64_t maxc = a.Cout > a.out_cstride ? a.Cout : a.out_cstride;
-      for (int s = 0; s < a.nsrc; ++s) maxc = a.src[s].cstride > maxc ? a.src[s].cstride : maxc;
-      if (tp > 0 && a.Win % tp == 0 && npx / tp >= g_conv_dma_min_tiles && npx * maxc * 4 < 0x7fffffffLL) {
+      // shortcut, SE-gradient conv, folded data gradient, and the chained pairs of lmn_conv_chain_t): dma1_select decides
+      Dma1Sel S1;
+      if (dma1_select(A, S1)) {
         ConvParams D = T;
-        D.total_tiles = (int)(npx / tp);
-        const size_t lds = lmn_conv_dma1_lds(ks[0], ks[1], ks[2], aq, P.NCTT, tp);
+        D.total_tiles = (int)((int64_t)A.B * A.Hin * A.Win / S1.tp);
+        D.NCTT2 = S1.nct2;
+        D.lay_out2 = lmn_lay_make(A.chain.out_rp_w, A.chain.Cout > 0 ? A.chain.Cout : 4, A.chain.out_cstride);
+        D.lay_aux2 = lmn_lay_make(A.chain.aux_rp_w, A.chain.Cout > 0 ? A.chain.Cout : 4, A.chain.aux_cstride);
+        if (S1.nct2) {
+          LMN_REQUIRE((!A.chain.out_rp_w || A.chain.out_rp_w == A.Win) && (!A.chain.aux_rp_w || A.chain.aux_rp_w == A.Win), "conv_fwd: row-planar tensors of the chained conv belong to images of the call's width");
+          if (A.chain.out_rp_w || A.chain.aux_rp_w) { D.rpw = A.Win; D.rp_magic = lmn_div_magic(A.Win); }
+        }
+        const size_t lds = lmn_conv_dma1_lds(S1.ks[0], S1.ks[1], S1.ks[2], S1.aq, S1.nct, S1.tp, S1.nct2);
         int bpc = (int)((160 * 1024) / (lds + 256));
         bpc = bpc > 4 ? 4 : (bpc < 1 ? 1 : bpc);
         int dblocks = 256 * bpc;
         if (dblocks > D.total_tiles) dblocks = D.total_tiles;
         if (int rc = det_prep(dblocks)) return rc;
         D.det_stats = T.det_stats;
-        LMN_REQUIRE(lmn_launch_conv_dma1(D, ks[0], ks[1], ks[2], aq, P.NCTT, mode, gs, dblocks, st) == 0, "conv_fwd: LDS-DMA 1x1 instance table out of step");
+        LMN_REQUIRE(lmn_launch_conv_dma1(D, S1.ks[0], S1.ks[1], S1.ks[2], S1.aq, S1.nct, S1.mode, S1.gs, S1.nct2, S1.mode2, dblocks, st) == 0, "conv_fwd: LDS-DMA 1x1 instance table out of step");
         det_finish();
         return lmn_launch_status("conv_fwd(dma1)");
       }

@@ -164,6 +164,7 @@ class Engine:
         # z-path of ReparamConv (include/lmnet_hip.h, lmn_dw_pre_t / lmn_reparam_fold): the expand conv's BatchNorm + Hardswish
         # applied inside the depthwise kernels, its backward folded into the weights of one three-source conv (LMN_ZPATH=0: A/B)
         self.zpath = os.environ.get("LMN_ZPATH", "1") != "0"
+        self.chain_on = os.environ.get("LMN_CONV_CHAIN", "1") != "0"   # chained 1x1 convs across the two blocks of a stage (hip.conv_fwd(chain=...))
         self.fwd_join = os.environ.get("LMN_FWD_JOIN", "1") != "0"   # the forward ends with a join of its weight-gradient stream (A/B)
         self.zpath_lds = 65536    # bytes of LDS lmn_reparam_fold may use (35 E floats): wider blocks keep the two-pass BatchNorm form (E > 468)
         # weight gradients of the branch chains issued late, beside the encoder's backward (LMN_LAZY_WGRAD=0: A/B runs)
@@ -476,13 +477,17 @@ class Engine:
         return mean, rstd, A, shift
 
     # ------------------------------------------------------------------ ReparamConv  (rows A1, A2, A3)
-    def reparam_fwd(self, m, x, cx, out=None):
-        """x: NHWC tensor [B,H,W,Cin] (Cin possibly zero-padded to 4).  Returns y [B,H,W,Cout]."""
+    def reparam_fwd(self, m, x, cx, out=None, chain=None, pre_z=None):
+        """x: NHWC tensor [B,H,W,Cin] (Cin possibly zero-padded to 4).  Returns y [B,H,W,Cout].
+        chain: the NEXT ReparamConv of the stage -- its expand conv (z + batch sums) is computed from this block's output tile inside
+        the pointwise + shortcut launch (hip.conv_fwd(chain=...), lmn_conv_chain_t) where the library takes the pair; returns
+        (y, pre_z) then, pre_z = None when the pair was not taken.  pre_z: what such a launch left for THIS block (its z-path skips
+        the expand conv)."""
         B, H, W, _ = x.shape
         E, Cout, N = m.cexp, m.cout, B * H * W
         ec, ebn = m.expand_conv[0], m.expand_conv[1]
         wpe = hip.conv_pack(ec.weight, 1, [x.shape[-1]])   # (a 3-channel weight on the NHWC4 input: zero column packed)
-        x1 = _R(x, B, H, W, E)
+        x1 = pre_z["x1"] if pre_z is not None else _R(x, B, H, W, E)
         # (lmn_reparam_fold keeps two [E]-wide operator panels of the expand conv in LDS: wider blocks take the two-pass BatchNorm form)
         zpath = self.training and self.fuse_bn and self.zpath and not m.deploy and 35 * E * 4 <= self.zpath_lds
         zp = None
@@ -490,10 +495,13 @@ class Engine:
             # z-path: ONE pass writes z = conv(x) + bias and its batch sums; the depthwise kernels form x1 = Hardswish(A1 z + sh1)
             # themselves when they stage their rows (lmn_dw_pre_t), the first of them (lmn_dw_stats) finalises the BatchNorm --
             # no statistics-only conv, no second read of x (x1 below HOLDS z)
-            sums1 = _Z(x, STATS_REP + 1, 2, E)
-            hip.conv_fwd([x], wpe, x1, B=B, Hin=H, Win=W, Hout=H, Wout=W, Cout=E, bias=ec.bias, stats=sums1,
-                         stats_mode=hip.STATS_SUM_SQ, stats_rep=STATS_REP, stats_snap=True,
-                         p=(None, None, None, None, ebn.running_mean))
+            if pre_z is not None:
+                sums1 = pre_z["sums1"]                       # x1 (z) and the batch sums were written by the previous block's pointwise launch
+            else:
+                sums1 = _Z(x, STATS_REP + 1, 2, E)
+                hip.conv_fwd([x], wpe, x1, B=B, Hin=H, Win=W, Hout=H, Wout=W, Cout=E, bias=ec.bias, stats=sums1,
+                             stats_mode=hip.STATS_SUM_SQ, stats_rep=STATS_REP, stats_snap=True,
+                             p=(None, None, None, None, ebn.running_mean))
             mean1, rstd1, A1, sh1 = (_E(x, E) for _ in range(4))
             zfin = dict(mode=hip.FIN_BN, sums=sums1, nrep=STATS_REP, count=N, gamma=ebn.weight, beta=ebn.bias, eps=ebn.eps,
                         momentum=ebn.momentum if ebn.momentum is not None else 0.1, about=sums1[STATS_REP, 0],
@@ -568,12 +576,28 @@ class Engine:
         wpw, wsc = m.pointwise_conv[0].weight, m.shortcut[0].weight
         wp3 = self._pack2(wpw, wsc, E, x.shape[-1], Cout, x)
         y = _A(x, B, H, W, Cout) if out is None else out
-        hip.conv_fwd([dict(view=pre, scale=sgate, flags=hip.SRC_GELU), x], wp3, y, B=B, Hin=H, Win=W, Hout=H, Wout=W,
-                     Cout=Cout, bias=m.pointwise_conv[0].bias, bias2=m.shortcut[0].bias)
+        kwc = dict(B=B, Hin=H, Win=W, Hout=H, Wout=W, Cout=Cout, bias=m.pointwise_conv[0].bias, bias2=m.shortcut[0].bias)
+        srcs = [dict(view=pre, scale=sgate, flags=hip.SRC_GELU), x]
+        pz = None
+        if chain is not None and self.chain_on and out is None:
+            # the next block's expand conv on this launch's output tile (its z-path conditions, its arguments: see the z-path branch above)
+            m2 = chain
+            E2 = m2.cexp
+            ec2, ebn2 = m2.expand_conv[0], m2.expand_conv[1]
+            if (self.training and self.fuse_bn and self.zpath and not m2.deploy and 35 * E2 * 4 <= self.zpath_lds
+                    and ec2.weight.shape[1] == Cout):
+                x1n, sums1n = _R(x, B, H, W, E2), _Z(x, STATS_REP + 1, 2, E2)
+                ch = dict(wpack=hip.conv_pack(ec2.weight, 1, [Cout]), Cout=E2, out=x1n, bias=ec2.bias, shift=ebn2.running_mean,
+                          stats=sums1n, stats_mode=hip.STATS_SUM_SQ, stats_rep=STATS_REP, stats_snap=True)
+                if hip.conv_fwd(srcs, wp3, y, chain=ch, query_chain=True, **kwc):
+                    hip.conv_fwd(srcs, wp3, y, chain=ch, **kwc)
+                    pz = dict(x1=x1n, sums1=sums1n)
+        if pz is None:
+            hip.conv_fwd(srcs, wp3, y, **kwc)
         if cx is not None:
             cx.t[m] = dict(x=x, x1=x1, pre=pre, gsum=gsum, s=sgate, hid=hid, wpe=wpe, mean1=mean1, rstd1=rstd1, A1=A1,
                            bmean=bmean, brstd=brstd, bA=bA, zp=zp)        # (zp: x1 holds z, the z-path)
-        return y
+        return (y, pz) if chain is not None else y
 
     @staticmethod
     def _pack2(w0, w1, c0, c1, cout, ref):
@@ -608,7 +632,10 @@ class Engine:
         hip.conv_pack_t(w1, 1, 0, rows, out=wp[n0 // h:(n0 + n1) // h], cred=cred1, persistent=own)
         return wp
 
-    def reparam_bwd(self, m, dy, cx, need_dx=True):
+    def reparam_bwd(self, m, dy, cx, need_dx=True, chain=None, pre_u=None):
+        """chain: the PREVIOUS ReparamConv of the stage (it consumes this block's dx as its dy): its SE-gradient conv is computed from
+        this block's dx tile inside the folded data-gradient launch where the library takes the pair; returns (dx, pre_u) then.
+        pre_u = (u, ds) left by such a launch for THIS block, which then skips its SE-gradient conv."""
         if m.deploy:
             raise NotImplementedError("backward through a deployed (re-parameterised) ReparamConv is not supported; "
                                       "deploy form is inference-only, as in the reference")
@@ -628,9 +655,12 @@ class Engine:
             dWp = _Z(x, Cout, Cin)
             self.wgrad([x], dy, None, None, Hin=H, Win=W, dW=dWp, db=G[sc.bias])
             hip.copy2d(dWp, G[sc.weight], Cout, cw, Cin, cw)      # un-pad (layout copy)
-        u = _R(x, B, H, W, E)
-        ds = _Z(x, B, E)
-        self.conv_T(dy, pw.weight, u, Hin=H, Win=W, epilogue=hip.EP_SE_BWD, aux=pre, stats=ds, stats_mode=hip.STATS_EP)
+        if pre_u is not None:
+            u, ds = pre_u                    # written by the next block's data-gradient launch (chained SE-gradient conv)
+        else:
+            u = _R(x, B, H, W, E)
+            ds = _Z(x, B, E)
+            self.conv_T(dy, pw.weight, u, Hin=H, Win=W, epilogue=hip.EP_SE_BWD, aux=pre, stats=ds, stats_mode=hip.STATS_EP)
         # (the shortcut's data gradient W_sc^T . dy is the second source of the LAST conv of this function: no dx_sc tensor)
         # ---- SE backward
         dm = None
@@ -701,10 +731,24 @@ class Engine:
                     self.wgrad([x], dz, None, None, Hin=H, Win=W, dW=dWp, db=G[ec.bias])
                     hip.copy2d(dWp, G[ec.weight], E, cw, Cin, cw)         # un-pad (layout copy)
             if not need_dx:
-                return None
+                return (None, None) if chain is not None else None
             dx = _A(x, B, H, W, Cin)
-            hip.conv_fwd([dh, x, dy], wp3, dx, B=B, Hin=H, Win=W, Hout=H, Wout=W, Cout=Cin, bias=kb)
-            return dx
+            kwc = dict(B=B, Hin=H, Win=W, Hout=H, Wout=W, Cout=Cin, bias=kb)
+            pu = None
+            if chain is not None and self.chain_on and not chain.deploy:
+                SA = cx.t[chain]
+                EA = chain.cexp
+                pwa = chain.pointwise_conv[0]
+                if pwa.weight.shape[0] == Cin:
+                    ua, dsa = _R(x, B, H, W, EA), _Z(x, B, EA)
+                    ch = dict(wpack=hip.conv_pack_t(pwa.weight, 1, 0, EA, cred=Cin), Cout=EA, out=ua, aux=SA["pre"], stats=dsa,
+                              epilogue=hip.EP_SE_BWD, stats_mode=hip.STATS_EP)
+                    if hip.conv_fwd([dh, x, dy], wp3, dx, chain=ch, query_chain=True, **kwc):
+                        hip.conv_fwd([dh, x, dy], wp3, dx, chain=ch, **kwc)
+                        pu = (ua, dsa)
+            if pu is None:
+                hip.conv_fwd([dh, x, dy], wp3, dx, **kwc)
+            return (dx, pu) if chain is not None else dx
         split = self.fuse_bn and self.split_dw and self.overlap_wgrad and not self.capturing
         if split:
             # dx1 (critical path) on this stream, the four weight gradients of the same pass on the side stream: the halves share
@@ -752,18 +796,24 @@ class Engine:
             self.wgrad([x], dz, None, None, Hin=H, Win=W, dW=dWp, db=G[ec.bias])
             hip.copy2d(dWp, G[ec.weight], E, cw, Cin, cw)         # un-pad (layout copy)
         if not need_dx:
-            return None
+            return (None, None) if chain is not None else None
         # dx = W_e^T . dz + W_sc^T . dy: one conv over two sources (the forward's expand + shortcut share x)
         dx = _A(x, B, H, W, Cin)
         wpt = self._pack2_t(ec.weight, sc.weight, E, self._c(dy), Cin, x)
         hip.conv_fwd([dz, dy], wpt, dx, B=B, Hin=H, Win=W, Hout=H, Wout=W, Cout=Cin)
-        return dx
+        return (dx, None) if chain is not None else dx
 
     def stage_fwd(self, seq, x, cx):
-        return self.reparam_fwd(seq[1], self.reparam_fwd(seq[0], x, cx), cx)
+        """Sequential(ReparamConv, ReparamConv) (core/LM_Net.py:11-57).  Where the library takes the pair (levels 0-1, fp32, training),
+        block A's pointwise + shortcut launch also computes block B's expand conv from its output tile (one launch and one read of the
+        intermediate tensor less)."""
+        y, pz = self.reparam_fwd(seq[0], x, cx, chain=seq[1])
+        return self.reparam_fwd(seq[1], y, cx, pre_z=pz)
 
     def stage_bwd(self, seq, dy, cx, need_dx=True):
-        return self.reparam_bwd(seq[0], self.reparam_bwd(seq[1], dy, cx), cx, need_dx)
+        """... and block B's folded data gradient also computes block A's SE-gradient conv (u = W_p^T dy and the per-image sums)."""
+        dxb, pu = self.reparam_bwd(seq[1], dy, cx, chain=seq[0])
+        return self.reparam_bwd(seq[0], dxb, cx, need_dx, pre_u=pu)
 
     # ------------------------------------------------------------------ plain 3x3 conv rows (A4, parts of A9/A10)
     def conv3_fwd(self, conv, x, out, s=1, **kw):

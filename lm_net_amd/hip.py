@@ -38,6 +38,14 @@ class BnFin(C.Structure):
 FIN_BN, FIN_BN_BWD = 1, 2
 
 
+class ConvChain(C.Structure):
+    """Mirror of lmn_conv_chain_t: a second 1x1 conv applied to the output tile of a 1x1 conv_fwd call."""
+    _fields_ = [("wpack", C.c_void_p), ("bias", C.c_void_p), ("shift", C.c_void_p), ("aux", C.c_void_p), ("out", C.c_void_p),
+                ("stats", C.c_void_p), ("Cout", C.c_int32), ("out_cstride", C.c_int32), ("out_rp_w", C.c_int32),
+                ("aux_cstride", C.c_int32), ("aux_rp_w", C.c_int32), ("epilogue", C.c_int32), ("stats_mode", C.c_int32),
+                ("stats_rep", C.c_int32), ("stats_snap", C.c_int32)]
+
+
 class ConvArgs(C.Structure):
     _fields_ = [("B", C.c_int32), ("Hout", C.c_int32), ("Wout", C.c_int32), ("Hin", C.c_int32), ("Win", C.c_int32),
                 ("ksize", C.c_int32), ("stride", C.c_int32), ("transposed", C.c_int32), ("nsrc", C.c_int32),
@@ -48,7 +56,8 @@ class ConvArgs(C.Structure):
                 ("epilogue", C.c_int32), ("act", C.c_int32), ("stats_mode", C.c_int32),
                 ("drop_p", C.c_float), ("drop_seed", C.c_uint32), ("seed_ctr", C.c_void_p), ("bias2", C.c_void_p),
                 ("stats_rep", C.c_int32), ("mma_dtype", C.c_int32), ("act_dtype", C.c_int32), ("out_rp_w", C.c_int32),
-                ("p5", C.c_void_p), ("p6", C.c_void_p), ("fin", BnFin), ("stats_snap", C.c_int32), ("aux_rp_w", C.c_int32)]
+                ("p5", C.c_void_p), ("p6", C.c_void_p), ("fin", BnFin), ("stats_snap", C.c_int32), ("aux_rp_w", C.c_int32),
+                ("chain", ConvChain)]
 
 
 class WgradArgs(C.Structure):
@@ -124,7 +133,7 @@ class ReduceJob(C.Structure):
 # every symbol include/lmnet_hip.h declares (the CPU test suite checks the library exports all of them)
 SYMBOLS = [
     "lmn_abi_version", "lmn_sizeof_conv_args", "lmn_sizeof_src", "lmn_sizeof_wgrad_args", "lmn_last_error",
-    "lmn_conv_pack_size", "lmn_conv_pack", "lmn_conv_pack_batch", "lmn_sizeof_pack_job", "lmn_conv_fwd", "lmn_conv_dma_config", "lmn_conv_wgrad", "lmn_conv_wgrad_workspace",
+    "lmn_conv_pack_size", "lmn_conv_pack", "lmn_conv_pack_batch", "lmn_sizeof_pack_job", "lmn_conv_fwd", "lmn_conv_dma_config", "lmn_conv_chain_ok", "lmn_conv_wgrad", "lmn_conv_wgrad_workspace",
     "lmn_conv_wgrad_job", "lmn_conv_wgrad_up2_ok", "lmn_wgrad_reduce_batch", "lmn_sizeof_reduce_job", "lmn_reparam_fold", "lmn_affine2", "lmn_reparam_wfin", "lmn_bnact_fwd_fin", "lmn_bnact_bwd_fin",
     "lmn_dw_stats", "lmn_dw_fwd", "lmn_dw_merge", "lmn_dw_finalize_merge", "lmn_dw_bwd_stats", "lmn_dw_bwd_coef", "lmn_dw_bwd", "lmn_dw_fwd_bn", "lmn_dw_bwd_bn",
     "lmn_se_fwd", "lmn_se_bwd", "lmn_se_bwd_dm", "lmn_se_bwd_params", "lmn_na_fwd", "lmn_na_bwd", "lmn_plan_host_profile", "lmn_set_deterministic", "lmn_get_deterministic", "lmn_gattn_fwd", "lmn_gattn_bwd",
@@ -461,8 +470,11 @@ def conv_pack_t(w, ksize, row_off=0, rows=None, out=None, cred=None, persistent=
 
 def conv_fwd(srcs, wpack, out, *, B, Hin, Win, Hout, Wout, Cout, ksize=1, stride=1, transposed=0, bias=None, bias2=None,
              epilogue=EP_LINEAR, act=ACT_NONE, p=(), aux=None, residual=None, stats=None, stats_mode=STATS_NONE,
-             drop_p=0.0, drop_seed=0, stats_rep=1, stats_snap=False, fin=None):
-    """fin: dict(mode=FIN_BN | FIN_BN_BWD, sums=[nrep(+1), 2, C] tensor, nrep, count, ...) -- in-kernel BatchNorm bookkeeping
+             drop_p=0.0, drop_seed=0, stats_rep=1, stats_snap=False, fin=None, chain=None, query_chain=False):
+    """chain: dict(wpack=, Cout=, out=, bias=None, shift=None, aux=None, stats=None, epilogue=EP_LINEAR, stats_mode=STATS_NONE, stats_rep=1,
+    stats_snap=False) -- a second 1x1 conv on the output tile (lmn_conv_chain_t); query_chain=True: nothing is launched, returns whether
+    the library takes the call with its chain (lmn_conv_chain_ok).
+    fin: dict(mode=FIN_BN | FIN_BN_BWD, sums=[nrep(+1), 2, C] tensor, nrep, count, ...) -- in-kernel BatchNorm bookkeeping
     (lmn_bn_fin_t): tensors for gamma / beta / about / mean / rstd / A / shift / rmean / rvar / Ain / dgamma / dbeta."""
     a = ConvArgs()
     a.B, a.Hout, a.Wout, a.Hin, a.Win = B, Hout, Wout, Hin, Win
@@ -494,6 +506,21 @@ def conv_fwd(srcs, wpack, out, *, B, Hin, Win, Hout, Wout, Cout, ksize=1, stride
     a.mma_dtype = _MMA[0]
     a.act_dtype = _dt(*[(s["view"] if isinstance(s, dict) else s) for s in srcs], aux, residual, out)
     a.seed_ctr = _SEED_CTR[0].data_ptr() if _SEED_CTR[0] is not None else None
+    if chain is not None:
+        c = a.chain
+        c.wpack = chain["wpack"].data_ptr()
+        c.bias = chain["bias"].data_ptr() if chain.get("bias") is not None else None
+        c.shift = chain["shift"].data_ptr() if chain.get("shift") is not None else None
+        c.stats = chain["stats"].data_ptr() if chain.get("stats") is not None else None
+        vo = _as_view(chain["out"])
+        c.out, c.out_cstride, c.out_rp_w, c.Cout = vo.ptr, vo.cstride, vo.rp, chain["Cout"]
+        if chain.get("aux") is not None:
+            va = _as_view(chain["aux"])
+            c.aux, c.aux_cstride, c.aux_rp_w = va.ptr, va.cstride, va.rp
+        c.epilogue, c.stats_mode = chain.get("epilogue", EP_LINEAR), chain.get("stats_mode", STATS_NONE)
+        c.stats_rep, c.stats_snap = chain.get("stats_rep", 1), int(bool(chain.get("stats_snap", False)))
+    if query_chain:
+        return bool(load().lmn_conv_chain_ok(C.byref(a)))
     _check(load().lmn_conv_fwd(C.byref(a), _stream()), "conv_fwd")
 
 

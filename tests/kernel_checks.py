@@ -1093,6 +1093,59 @@ def check_conv_dma1():
             if Cin != 4:
                 yref = F.conv2d(gelu(prer) * gater.view(B, E, 1, 1), wpwr.view(Cout, E, 1, 1)) + F.conv2d(xr, wscr.view(Cout, Cin, 1, 1), b2r)
                 rows.append(("conv_dma1 pointwise + shortcut vs fp64" + tag, rel(nchw(res[3]["y"]), yref), TOL))
+        # chained pairs (lmn_conv_chain_t): pointwise + shortcut of block A -> expand conv of block B (statistics about a shift, slices,
+        # snapshot), folded data gradient of block B -> SE-gradient conv of block A, against the two launches they replace
+        for (B, H, W, Cin, E) in [(2, 16, 24, 12, 24), (3, 8, 16, 24, 48), (2, 32, 64, 12, 24), (9, 16, 8, 12, 24), (1, 64, 128, 24, 48)]:
+            tag = " Cin=%d E=%d %dx%dx%d" % (Cin, E, B, H, W)
+            x, pre_r, dy = nhwc(R(B, Cin, H, W, seed=531)), to_rp(nhwc(R(B, E, H, W, seed=532))), nhwc(R(B, Cin, H, W, seed=533))
+            dh_r, preA_r = to_rp(nhwc(R(B, E, H, W, seed=534))), to_rp(nhwc(R(B, E, H, W, seed=535)))
+            gate = dev(R(B, E, seed=536).abs())
+            wpw, wsc, weB = dev(R(Cin, E, seed=537, scale=0.2)), dev(R(Cin, Cin, seed=538, scale=0.3)), dev(R(E, Cin, seed=539, scale=0.3))
+            bpw, bsc, beB, shift = dev(R(Cin, seed=540)), dev(R(Cin, seed=541)), dev(R(E, seed=542)), dev(R(E, seed=543) * 0.2)
+            kw = dict(B=B, Hin=H, Win=W, Hout=H, Wout=W)
+            n0, n1 = hip.conv_pack_size(1, Cin, [E]), hip.conv_pack_size(1, Cin, [Cin])
+            wp2 = torch.empty(n0 + n1, device=DEV)
+            hip.conv_pack(wpw, 1, [E], out=wp2[:n0]); hip.conv_pack(wsc, 1, [Cin], out=wp2[n0:])
+            wpeB = hip.conv_pack(weB, 1, [Cin])
+            srcs = [dict(view=pre_r, scale=gate, flags=hip.SRC_GELU), x]
+            # separate launches
+            y0, z0, st0_ = mk(B, H, W, Cin), hip.rp4(mk(B, H, W, E)), torch.zeros(5, 2, E, device=DEV)
+            hip.conv_fwd(srcs, wp2, y0, Cout=Cin, bias=bpw, bias2=bsc, **kw)
+            hip.conv_fwd([y0], wpeB, z0, Cout=E, bias=beB, stats=st0_, stats_mode=hip.STATS_SUM_SQ, stats_rep=4, stats_snap=True, p=(None, None, None, None, shift), **kw)
+            # one launch
+            y1, z1, st1_ = mk(B, H, W, Cin), hip.rp4(mk(B, H, W, E)), torch.zeros(5, 2, E, device=DEV)
+            ch = dict(wpack=wpeB, Cout=E, out=z1, bias=beB, shift=shift, stats=st1_, stats_mode=hip.STATS_SUM_SQ, stats_rep=4, stats_snap=True)
+            if Cin == 24 and E == 48 and H * W % 64 == 0 or Cin == 12:
+                ok = hip.conv_fwd(srcs, wp2, y1, Cout=Cin, bias=bpw, bias2=bsc, chain=ch, query_chain=True, **kw)
+                rows.append(("conv chain F2 -> F1': accepted" + tag, 0.0 if ok else 1.0, 0.5))
+                if ok:
+                    hip.conv_fwd(srcs, wp2, y1, Cout=Cin, bias=bpw, bias2=bsc, chain=ch, **kw)
+                    rows.append(("conv chain F2 -> F1': first output" + tag, rel(y1, y0), 1e-7))
+                    rows.append(("conv chain F2 -> F1': chained output" + tag, rel(to_nhwc(z1), to_nhwc(z0)), 2e-6))
+                    rows.append(("conv chain F2 -> F1': statistics slices + snapshot" + tag, max(rel(st1_[:4].sum(0), st0_[:4].sum(0)) * 1e-2, rel(st1_[4, 0], st0_[4, 0])), 2e-6))
+            if Cin == 12:
+                wa, wb, wc = dev(R(Cin, E, seed=544, scale=0.2)), dev(R(Cin, Cin, seed=545, scale=0.3)), dev(R(Cin, Cin, seed=546, scale=0.3))
+                m0, m1 = hip.conv_pack_size(1, Cin, [E]), hip.conv_pack_size(1, Cin, [Cin])
+                wp3 = torch.empty(m0 + 2 * m1, device=DEV)
+                hip.conv_pack(wa, 1, [E], out=wp3[:m0]); hip.conv_pack(wb, 1, [Cin], out=wp3[m0:m0 + m1]); hip.conv_pack(wc, 1, [Cin], out=wp3[m0 + m1:])
+                wptA = hip.conv_pack_t(dev(R(Cin, E, seed=547, scale=0.2)), 1, 0, E, cred=Cin)
+                kb = dev(R(Cin, seed=548))
+                dx0, u0, ds0 = mk(B, H, W, Cin), hip.rp4(mk(B, H, W, E)), torch.zeros(B, E, device=DEV)
+                hip.conv_fwd([dh_r, x, dy], wp3, dx0, Cout=Cin, bias=kb, **kw)
+                hip.conv_fwd([dx0], wptA, u0, Cout=E, transposed=1, epilogue=hip.EP_SE_BWD, aux=preA_r, stats=ds0, stats_mode=hip.STATS_EP, **kw)
+                dx1, u1, ds1 = mk(B, H, W, Cin), hip.rp4(mk(B, H, W, E)), torch.zeros(B, E, device=DEV)
+                ch = dict(wpack=wptA, Cout=E, out=u1, aux=preA_r, stats=ds1, epilogue=hip.EP_SE_BWD, stats_mode=hip.STATS_EP)
+                ok = hip.conv_fwd([dh_r, x, dy], wp3, dx1, Cout=Cin, bias=kb, chain=ch, query_chain=True, **kw)
+                rows.append(("conv chain B2 -> B1': accepted" + tag, 0.0 if ok else 1.0, 0.5))
+                if ok:
+                    hip.conv_fwd([dh_r, x, dy], wp3, dx1, Cout=Cin, bias=kb, chain=ch, **kw)
+                    rows.append(("conv chain B2 -> B1': first output" + tag, rel(dx1, dx0), 1e-7))
+                    rows.append(("conv chain B2 -> B1': chained output" + tag, rel(to_nhwc(u1), to_nhwc(u0)), 2e-6))
+                    rows.append(("conv chain B2 -> B1': per-image sums" + tag, rel(ds1, ds0) * 1e-2, 2e-6))
+        # a call the table does not hold must be refused by the query (and by the launch)
+        xb, wq = nhwc(R(1, 96, 8, 16, seed=551)), hip.conv_pack(dev(R(96, 96, seed=552)), 1, [96])
+        rows.append(("conv chain: refused outside the instance table", 1.0 if hip.conv_fwd([xb], wq, mk(1, 8, 16, 96), B=1, Hin=8, Win=16, Hout=8, Wout=16, Cout=96,
+                     chain=dict(wpack=wq, Cout=96, out=mk(1, 8, 16, 96), stats=torch.zeros(2, 96, device=DEV), stats_mode=hip.STATS_SUM_SQ), query_chain=True) else 0.0, 0.5))
         # deterministic mode: the statistics of F1 and the per-image sums of B1 go through slots; two launches bit-identical
         det0 = hip.get_deterministic()
         hip.set_deterministic(True)
