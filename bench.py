@@ -41,7 +41,7 @@ def dice_loss(logits, target, weight=(1.0, 4.0), smooth=1e-5):
 
 def _pmc():
     """The committed PMC reduction of this very command (profiles/rNN_pmc.json, newest round first), or None."""
-    for name in ("r05_pmc.json", "r04_pmc.json", "r03_pmc.json", "r02_pmc.json"):
+    for name in ("r06_pmc.json", "r05_pmc.json", "r04_pmc.json", "r03_pmc.json", "r02_pmc.json"):
         path = os.path.join(ROOT, "profiles", name)
         if os.path.isfile(path):
             try:
@@ -97,7 +97,7 @@ def rocprof_avg_us(kernel):
     list), in microseconds, with the file it came from -- or (None, None).  The profiled run mixes four-stream and serial steps,
     so this sits between avg_us (inside the step) and avg_us_alone."""
     import csv
-    for name in ("r05_bench_kernel_stats.csv", "r04_bench_kernel_stats.csv"):
+    for name in ("r06_bench_kernel_stats.csv", "r05_bench_kernel_stats.csv", "r04_bench_kernel_stats.csv"):
         path = os.path.join(ROOT, "profiles", name)
         if not os.path.isfile(path):
             continue
@@ -237,8 +237,8 @@ def roofline_block(dominant, live, survey, tot_us, B, H, W, step_s, alone, esz=4
         r[key] = row
     # the conv families, from the survey steps (every launch timed, four streams live): algorithmic bytes / FLOPs of all launches
     # of a family / the sum of their event durations, against the roofline that bounds the family as a whole
-    fam = {"conv 1x1 fwd + dgrad (rows A1, A3, A6/A8 linears)": ("conv_tile_kernel<1,", "conv_tileM_kernel<1,"),
-           "conv 3x3 fwd + dgrad (rows A4, A9-A11)": ("conv_tile_kernel<9,", "conv_tileM_kernel<9,"),
+    fam = {"conv 1x1 fwd + dgrad (rows A1, A3, A6/A8 linears)": ("conv_tile_kernel<1,", "conv_tileM_kernel<1,", "conv_dma1_kernel<"),
+           "conv 3x3 fwd + dgrad (rows A4, A9-A11)": ("conv_tile_kernel<9,", "conv_tileM_kernel<9,", "conv_dma3_kernel<"),
            "weight gradients 1x1": ("wgrad_1x1w_kernel", "wgrad_1x1_kernel", "wgrad_reduce_kernel<1,"),
            "weight gradients 3x3": ("wgrad3_kernel", "wgrad_lds_kernel", "wgrad_reduce_kernel<9,")}
     r["families_survey"] = {}

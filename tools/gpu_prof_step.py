@@ -62,5 +62,5 @@ print("wall %.2f ms/step (untimed-kernel run); kernel-time sum %.2f ms/step over
 print("%-44s %6s %9s %8s %7s %8s %7s" % ("kernel", "n/step", "us/step", "avg_us", "share", "GB/s", "TF/s"))
 for k, v in sorted(r.items(), key=lambda kv: -kv[1]["total_us"])[:a.top]:
     t = v["total_us"] * 1e-6
-    print("%-44s %6d %9.1f %8.1f %6.1f%% %8.0f %7.1f" % (k[:44], v["launches"] // a.steps, v["total_us"] / a.steps, v["total_us"] / v["launches"],
+    print("%-76s %6d %9.1f %8.1f %6.1f%% %8.0f %7.1f" % (k[:76], v["launches"] // a.steps, v["total_us"] / a.steps, v["total_us"] / v["launches"],
           100 * v["total_us"] / tot, v["bytes"] / t / 1e9 if t else 0, v["flops"] / t / 1e12 if t else 0))

@@ -44,7 +44,7 @@ for step in "$@"; do
     wgradbench) envrun "$arg" timeout 600 python tools/gpu_wgrad_bench.py > $O/$tag.log 2>&1; envrun "$arg" timeout 600 python tools/gpu_wgrad3_bench.py >> $O/$tag.log 2>&1; cat $O/$tag.log ;;
     dwprobe) envrun "$arg" timeout 600 python tools/gpu_dw_probe.py > $O/$tag.log 2>&1; tail -40 $O/$tag.log ;;
     naprobe) envrun "$arg" timeout 600 python tools/gpu_na_probe.py > $O/$tag.log 2>&1; tail -40 $O/$tag.log ;;
-    serial) envrun "$arg" timeout 900 python tools/gpu_prof_step.py --serial > $O/$tag.log 2>&1; head -70 $O/$tag.log ;;
+    serial) envrun "$arg" timeout 900 python tools/gpu_prof_step.py --serial --top 200 > $O/$tag.log 2>&1; head -70 $O/$tag.log ;;
     timeline) timeout 900 python tools/gpu_step_timeline.py > $O/$tag.log 2>&1; tail -60 $O/$tag.log ;;
     profiles) bash tools/collect_profiles.sh ${D}_prof ;;
     py)
