@@ -594,6 +594,8 @@ class LM_Net(nn.Module):
         sb = eng.slot_base                   # (four lmn event slots per engine: two models of one process do not share them)
         slots = {2: sb, 4: sb + 1, 6: sb + 2, 8: sb + 3}     # lmn event slot of each chain (by dropout tag)
 
+        bst2 = eng.branch_stream2(dev) if (fork and eng.branch2_on) else bst
+
         def chain(skip, nat, xs_in, tag):
             """Skip fuser + neighborhood-attention block of one level: needs only encoder outputs and is needed
             only by the decoder stage of its level, so it runs on the branch stream as soon as its inputs exist
@@ -602,11 +604,12 @@ class LM_Net(nn.Module):
             if not fork:
                 xs = eng.skip_fwd(skip, xs_in, cx)
                 return eng.nat_fwd(nat, xs, cx, tag=tag), None, xs
-            hip.stream_wait(bst, main)
-            with eng.on_stream(bst):
+            bs = bst2 if tag in (2, 4) else bst        # (LMN_BRANCH2: the small-map chains, which the decoder needs first, on a stream of their own)
+            hip.stream_wait(bs, main)
+            with eng.on_stream(bs):
                 xs = eng.skip_fwd(skip, xs_in, cx)
                 out = eng.nat_fwd(nat, xs, cx, tag=tag)
-            hip.event_record(slots[tag], bst)          # the point the decoder stage of this level waits for
+            hip.event_record(slots[tag], bs)           # the point the decoder stage of this level waits for
             return out, slots[tag], xs
 
         def need(res):
@@ -652,6 +655,8 @@ class LM_Net(nn.Module):
         x9 = eng.stage_fwd(self.dconv4, eng.up_fwd(self.up4, x8, x19, cx), cx)
         if fork:
             hip.stream_wait(main, bst)
+            if bst2 is not bst:
+                hip.stream_wait(main, bst2)
         # segmentation head: computed on rows padded to a multiple of 4 (the packed weight's extra rows are zeros, the
         # bias lives in a persistent 4-vector), then NHWC -> NCHW keeps the first n_classes channels
         ncp = (self.n_classes + 3) // 4 * 4

@@ -149,6 +149,8 @@ class Engine:
         self.capturing = False
         self.sides = {}           # issuing stream handle -> [weight-gradient stream, busy]
         self.branch = None        # second compute stream of the backward schedule (LM_Net._backward_body)
+        self.branch2 = None
+        self.branch2_on = os.environ.get("LMN_BRANCH2", "1") != "0"   # forward: the chains of levels 2-3 on a branch stream of their own (13.85 -> 13.76 ms)
         self.branch_overlap = True
         # BatchNorm bookkeeping inside the consuming conv (lmn_bn_fin_t) instead of separate launches (LMN_FUSE_BN=0: A/B runs)
         self.fuse_bn = os.environ.get("LMN_FUSE_BN", "1") != "0"
@@ -463,6 +465,13 @@ class Engine:
         if self.branch is None or self.branch.device != device:
             self.branch = torch.cuda.Stream(device=device, priority=self.branch_prio)
         return self.branch
+
+    def branch_stream2(self, device):
+        """A second branch stream (forward: the chains of levels 2-3, whose decoder stages come first, beside those of levels 0-1 --
+        LMN_BRANCH2=0: one branch stream, as in rounds 2-5)."""
+        if self.branch2 is None or self.branch2.device != device:
+            self.branch2 = torch.cuda.Stream(device=device, priority=self.branch_prio)
+        return self.branch2
 
     def bn_stats(self, bn, sums, count, ref):
         """(mean, rstd, A, shift) of a BatchNorm from batch sums [2,C] (training; taken about the running mean, see
