@@ -594,7 +594,7 @@ class LM_Net(nn.Module):
         sb = eng.slot_base                   # (four lmn event slots per engine: two models of one process do not share them)
         slots = {2: sb, 4: sb + 1, 6: sb + 2, 8: sb + 3}     # lmn event slot of each chain (by dropout tag)
 
-        bst2 = eng.branch_stream2(dev) if (fork and eng.branch2_on) else bst
+        fstreams = [eng.branch_stream_n(dev, i) for i in eng.branch_map_f] if fork else []   # per level 0..3
 
         def chain(skip, nat, xs_in, tag):
             """Skip fuser + neighborhood-attention block of one level: needs only encoder outputs and is needed
@@ -604,7 +604,7 @@ class LM_Net(nn.Module):
             if not fork:
                 xs = eng.skip_fwd(skip, xs_in, cx)
                 return eng.nat_fwd(nat, xs, cx, tag=tag), None, xs
-            bs = bst2 if tag in (2, 4) else bst        # (LMN_BRANCH2: the small-map chains, which the decoder needs first, on a stream of their own)
+            bs = fstreams[{8: 0, 6: 1, 4: 2, 2: 3}[tag]]   # (LMN_BRANCH_MAP_F: the small-map chains, which the decoder needs first, beside the others)
             hip.stream_wait(bs, main)
             with eng.on_stream(bs):
                 xs = eng.skip_fwd(skip, xs_in, cx)
@@ -654,9 +654,8 @@ class LM_Net(nn.Module):
         x19 = need(r4)
         x9 = eng.stage_fwd(self.dconv4, eng.up_fwd(self.up4, x8, x19, cx), cx)
         if fork:
-            hip.stream_wait(main, bst)
-            if bst2 is not bst:
-                hip.stream_wait(main, bst2)
+            for bs_ in {id(t): t for t in [bst] + fstreams}.values():
+                hip.stream_wait(main, bs_)
         # segmentation head: computed on rows padded to a multiple of 4 (the packed weight's extra rows are zeros, the
         # bias lives in a persistent 4-vector), then NHWC -> NCHW keeps the first n_classes channels
         ncp = (self.n_classes + 3) // 4 * 4
@@ -840,20 +839,27 @@ class LM_Net(nn.Module):
         # beside the encoder's backward like the weight gradients themselves)
         lazy = bool(fork and eng.lazy_wgrad)
 
-        def branch(nat, skip, dt):
+        bstreams = [eng.branch_stream_n(dev, i) for i in eng.branch_map_b] if fork else []   # per level 0..3
+        two = bool(fork and any(t is not bst for t in bstreams))
+        sbk = eng.slot_base
+        tok = [None]     # event slot recorded by the accumulating tail of the previous chain
+
+        def branch(nat, skip, dt, lvl=0):
             """Backward of one neighborhood-attention block and its skip fuser.  Their only input is dt (the decoder
             stage gradient) and nothing on the decoder chain waits for them, so they run on the branch stream while
             the main stream continues with the coarser decoder stages (few of those kernels fill 256 CUs alone)."""
             if not fork:
                 return nat, skip, dt
-            hip.stream_wait(bst, main)
+            bs = bstreams[lvl]                        # (LMN_BRANCH_MAP_B: the small-map chains beside the level-0 / 1 ones)
+            hip.stream_wait(bs, main)
             if eng.arena is None:
-                dt.record_stream(bst)
-            with eng.on_stream(bst):
+                dt.record_stream(bs)
+            with eng.on_stream(bs):
                 eng.lazy_on = lazy
                 try:
                     dxs = eng.nat_bwd(nat, dt, cx)
-                    eng.skip_bwd(skip, dxs, cx, gacc)
+                    eng.skip_bwd(skip, dxs, cx, gacc, order=(tok[0], sbk + lvl, bs) if two else None)
+                    tok[0] = sbk + lvl
                 finally:
                     eng.lazy_on = False
                 eng.join_side(dev)                       # this chain's weight gradients (none when they are issued late)
@@ -875,18 +881,21 @@ class LM_Net(nn.Module):
 
         # decoder (the branch work of level k is forked as soon as dt_k exists)
         dt4 = eng.stage_bwd(self.dconv4, dx9, cx); self._done("dconv4")
-        p4 = branch(self.natt4, self.skip4, dt4)
+        p4 = branch(self.natt4, self.skip4, dt4, 0)
         dx8 = eng.up_bwd(self.up4, dt4, cx, A["x8"].shape); self._done("up4")
         dt3 = eng.stage_bwd(self.dconv3, dx8, cx); self._done("dconv3")
-        p3 = branch(self.natt3, self.skip3, dt3)
+        p3 = branch(self.natt3, self.skip3, dt3, 1)
         dx7 = eng.up_bwd(self.up3, dt3, cx, A["x7"].shape); self._done("up3")
         dt2 = eng.stage_bwd(self.dconv2, dx7, cx); self._done("dconv2")
-        p2 = branch(self.natt2, self.skip2, dt2)
+        p2 = branch(self.natt2, self.skip2, dt2, 2)
         dx6 = eng.up_bwd(self.up2, dt2, cx, A["x6"].shape); self._done("up2")
         dt1 = eng.stage_bwd(self.dconv1, dx6, cx); self._done("dconv1")
-        p1 = branch(self.natt1, self.skip1, dt1)
+        p1 = branch(self.natt1, self.skip1, dt1, 3)
         dx5 = eng.up_bwd(self.up1, dt1, cx, A["x5"].shape); self._done("up1")
         if fork:
+            for bs_ in {id(t): t for t in bstreams}.values():
+                if bs_ is not bst:
+                    hip.stream_wait(bst, bs_)            # (the first branch stream carries on for all: late weight gradients, bucket hand-over, join)
             reported = False
             if not lazy:
                 reported = branch_blocks_done()          # natt* / skip*: complete on the branch stream from here on

@@ -149,8 +149,10 @@ class Engine:
         self.capturing = False
         self.sides = {}           # issuing stream handle -> [weight-gradient stream, busy]
         self.branch = None        # second compute stream of the backward schedule (LM_Net._backward_body)
-        self.branch2 = None
-        self.branch2_on = os.environ.get("LMN_BRANCH2", "1") != "0"   # forward: the chains of levels 2-3 on a branch stream of their own (13.85 -> 13.76 ms)
+        self.branches = []        # further branch streams (branch_stream_n)
+        # chain of level k (0 = 352^2 ... 3 = 44^2) -> branch stream index, forward / backward ("0000": one branch stream, rounds 2-5)
+        self.branch_map_f = [int(c) for c in os.environ.get("LMN_BRANCH_MAP_F", "0011")]
+        self.branch_map_b = [int(c) for c in os.environ.get("LMN_BRANCH_MAP_B", "0011")]
         self.branch_overlap = True
         # BatchNorm bookkeeping inside the consuming conv (lmn_bn_fin_t) instead of separate launches (LMN_FUSE_BN=0: A/B runs)
         self.fuse_bn = os.environ.get("LMN_FUSE_BN", "1") != "0"
@@ -466,12 +468,17 @@ class Engine:
             self.branch = torch.cuda.Stream(device=device, priority=self.branch_prio)
         return self.branch
 
-    def branch_stream2(self, device):
-        """A second branch stream (forward: the chains of levels 2-3, whose decoder stages come first, beside those of levels 0-1 --
-        LMN_BRANCH2=0: one branch stream, as in rounds 2-5)."""
-        if self.branch2 is None or self.branch2.device != device:
-            self.branch2 = torch.cuda.Stream(device=device, priority=self.branch_prio)
-        return self.branch2
+    def branch_stream_n(self, device, i):
+        """Branch stream i (0 = branch_stream): the skip / neighborhood-attention chains of the four levels are spread over them by
+        LMN_BRANCH_MAP_F / LMN_BRANCH_MAP_B (one digit per level 0..3; round 6: small-map chains beside the level-0 / 1 ones)."""
+        if i == 0:
+            return self.branch_stream(device)
+        while len(self.branches) < i:
+            self.branches.append(None)
+        b = self.branches[i - 1]
+        if b is None or b.device != device:
+            b = self.branches[i - 1] = torch.cuda.Stream(device=device, priority=self.branch_prio)
+        return b
 
     def bn_stats(self, bn, sums, count, ref):
         """(mean, rstd, A, shift) of a BatchNorm from batch sums [2,C] (training; taken about the running mean, see
@@ -913,8 +920,11 @@ class Engine:
             cx.t[m] = dict(xs=xs_in, cat=cat, up=up, z=z, mean=mean, rstd=rstd, A=A)
         return y
 
-    def skip_bwd(self, m, dy, cx, gacc):
-        """gacc: dict tensor-id -> GradSlot for the encoder activations (accumulated in place)."""
+    def skip_bwd(self, m, dy, cx, gacc, order=None):
+        """gacc: dict tensor-id -> GradSlot for the encoder activations (accumulated in place).
+        order = (event slot to wait for or None, event slot to record, stream): the chains of several levels accumulate into the SAME
+        encoder gradients; when they run on two branch streams the accumulating tail of each waits for the previous chain's (in fork
+        order: the sums keep the single-stream order, bit for bit)."""
         S = cx.t[m]
         xs_in, cat, up, z = S["xs"], S["cat"], S["up"], S["z"]
         three = len(xs_in) == 3
@@ -940,6 +950,8 @@ class Engine:
         self.conv_T(dz, fconv.weight, dcat, Hin=H, Win=W, k=3)
         xl = xs_in[0]
         sl = 2 if (three or bottom) else 1
+        if order is not None and order[0] is not None:
+            hip.event_wait(order[0], order[2])
         self._acc_conv(m.convl[0], xl, V(dcat, 0, C), sl, gacc)
         if three:
             self._acc_conv(m.convm[0], xs_in[1], V(dcat, C, C), 1, gacc)
@@ -966,6 +978,8 @@ class Engine:
                 tmp = _A(z, *xsm.shape)
                 hip.up2_bwd(dup, tmp)
                 hip.add(slot.g, tmp)
+        if order is not None:
+            hip.event_record(order[1], order[2])
 
     def _acc_conv(self, conv, x, dy, s, gacc):
         slot = gacc[id(x)]
