@@ -762,6 +762,9 @@ int lmn_conv_fwd(const lmn_conv_args_t* args, lmn_stream_t stream) {
         const size_t lds = lmn_conv_dma3_lds(s0.C, P.NCTT);
         int bpc = (int)((160 * 1024) / (lds + 256));
         bpc = bpc > 4 ? 4 : (bpc < 1 ? 1 : bpc);
+        static int bpc3_env = -1;   // LMN_DMA3_BPC: cap on the resident blocks per CU of the 3x3 LDS-DMA kernel (A/B runs)
+        if (bpc3_env < 0) { const char* e = getenv("LMN_DMA3_BPC"); bpc3_env = e ? atoi(e) : 0; }
+        if (bpc3_env > 0 && bpc > bpc3_env) bpc = bpc3_env;
         int dblocks = 256 * bpc;
         if (dblocks > D.total_tiles) dblocks = D.total_tiles;
         if (int rc = det_prep(dblocks)) return rc;
@@ -788,6 +791,9 @@ int lmn_conv_fwd(const lmn_conv_args_t* args, lmn_stream_t stream) {
         const size_t lds = lmn_conv_dma1_lds(S1.ks[0], S1.ks[1], S1.ks[2], S1.aq, S1.nct, S1.tp, S1.nct2);
         int bpc = (int)((160 * 1024) / (lds + 256));
         bpc = bpc > 4 ? 4 : (bpc < 1 ? 1 : bpc);
+        static int bpc1_env = -1;   // LMN_DMA1_BPC: cap on the resident blocks per CU of the 1x1 LDS-DMA kernel (A/B runs)
+        if (bpc1_env < 0) { const char* e = getenv("LMN_DMA1_BPC"); bpc1_env = e ? atoi(e) : 0; }
+        if (bpc1_env > 0 && bpc > bpc1_env) bpc = bpc1_env;
         int dblocks = 256 * bpc;
         if (dblocks > D.total_tiles) dblocks = D.total_tiles;
         if (int rc = det_prep(dblocks)) return rc;
