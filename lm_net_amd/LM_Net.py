@@ -823,9 +823,12 @@ class LM_Net(nn.Module):
         dy4 = _A(dev, B, H, W, ncp)
         hip.nchw_to_nhwc(dlogits, dy4)
         dWh, dbh = _Z(dev, ncp, c0), _Z(dev, ncp)
-        eng.wgrad([A["x9"]], dy4, None, None, Hin=H, Win=W, dW=dWh, db=dbh)
-        hip.copy2d(dWh, G[self.output_layer.weight], self.n_classes, c0, c0, c0)      # drop the padding rows
-        hip.copy2d(dbh, G[self.output_layer.bias], 1, self.n_classes, ncp, self.n_classes)
+        gwh, gbh, ncl = G[self.output_layer.weight], G[self.output_layer.bias], self.n_classes
+
+        def unpad_head():                                                     # drop the padding rows
+            hip.copy2d(dWh, gwh, ncl, c0, c0, c0)
+            hip.copy2d(dbh, gbh, 1, ncl, ncp, ncl)
+        eng.wgrad_unpad([A["x9"]], dy4, dWh, dbh, H, W, unpad_head, keep=(dbh,))
         dx9 = _A(dev, *A["x9"].shape)
         eng.conv_T(dy4, self.output_layer.weight, dx9, Hin=H, Win=W)
         self._done("output_layer")

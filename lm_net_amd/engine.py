@@ -205,6 +205,7 @@ class Engine:
         self.fuse_up_wgrad = os.environ.get("LMN_FUSE_UP_WGRAD", "1") != "0"
         # squeeze-excite parameter gradients in the launch of lmn_reparam_wfin (one launch instead of two per block; LMN_FUSE_SE_WFIN=0: A/B)
         self.fuse_se_wfin = os.environ.get("LMN_FUSE_SE_WFIN", "1") != "0"
+        self.unpad_side = os.environ.get("LMN_UNPAD_SIDE", "1") != "0"      # un-pad copies of padded weight gradients on the side stream
         # skip fusers: BatchNorm finalize / backward coefficients inside the BN + GELU tails (lmn_bnact_fwd_fin / lmn_bnact_bwd_fin;
         # LMN_FUSE_BN_TAIL=0: the lmn_bn_finalize / lmn_bn_bwd_coef launches, A/B runs)
         self.fuse_bn_tail = os.environ.get("LMN_FUSE_BN_TAIL", "1") != "0"
@@ -376,6 +377,16 @@ class Engine:
                     src["ln"][3].record_stream(side)      # the (mean, rstd) table of a LayerNorm-on-load source
         if explicit:
             self.join_side(d.device)
+
+    def wgrad_unpad(self, srcs, dy, dWp, db, H, W, unpad, keep=()):
+        """Weight gradient into a padded scratch `dWp`, then `unpad` (layout copies into the parameter's gradient).  The copies run
+        on the weight-gradient stream right after the reduction that completes the scratch: the main stream does not stop for a
+        gradient that nothing in the backward chain reads (LMN_UNPAD_SIDE=0: the round-5 order, main joins and copies)."""
+        if self.unpad_side:
+            self.wgrad(srcs, dy, None, None, Hin=H, Win=W, dW=dWp, db=db, join=False, keep=(dWp,) + tuple(keep), after=unpad)
+        else:
+            self.wgrad(srcs, dy, None, None, Hin=H, Win=W, dW=dWp, db=db)
+            unpad()
 
     def set_deterministic(self, on):
         """Fixed-order reductions in every kernel (hip.set_deterministic: process-wide) and no ticket-based squeeze-excite gate in the
@@ -669,8 +680,8 @@ class Engine:
         else:  # padded RGB input: gradient of the padded weight, keep the real columns
             self.wgrad([dict(view=pre, scale=sgate, flags=hip.SRC_GELU)], dy, pw.weight, pw.bias, Hin=H, Win=W)
             dWp = _Z(x, Cout, Cin)
-            self.wgrad([x], dy, None, None, Hin=H, Win=W, dW=dWp, db=G[sc.bias])
-            hip.copy2d(dWp, G[sc.weight], Cout, cw, Cin, cw)      # un-pad (layout copy)
+            gsc = G[sc.weight]
+            self.wgrad_unpad([x], dy, dWp, G[sc.bias], H, W, lambda: hip.copy2d(dWp, gsc, Cout, cw, Cin, cw))   # un-pad (layout copy)
         if pre_u is not None:
             u, ds = pre_u                    # written by the next block's data-gradient launch (chained SE-gradient conv)
         else:
@@ -744,8 +755,8 @@ class Engine:
                     self.wgrad([x], dz, ec.weight, ec.bias, Hin=H, Win=W)
                 else:
                     dWp = _Z(x, E, Cin)
-                    self.wgrad([x], dz, None, None, Hin=H, Win=W, dW=dWp, db=G[ec.bias])
-                    hip.copy2d(dWp, G[ec.weight], E, cw, Cin, cw)         # un-pad (layout copy)
+                    gec = G[ec.weight]
+                    self.wgrad_unpad([x], dz, dWp, G[ec.bias], H, W, lambda: hip.copy2d(dWp, gec, E, cw, Cin, cw))    # un-pad (layout copy)
             if not need_dx:
                 return (None, None) if chain is not None else None
             dx = _A(x, B, H, W, Cin)
@@ -809,8 +820,8 @@ class Engine:
             self.wgrad([x], dz, ec.weight, ec.bias, Hin=H, Win=W)
         else:
             dWp = _Z(x, E, Cin)
-            self.wgrad([x], dz, None, None, Hin=H, Win=W, dW=dWp, db=G[ec.bias])
-            hip.copy2d(dWp, G[ec.weight], E, cw, Cin, cw)         # un-pad (layout copy)
+            gec = G[ec.weight]
+            self.wgrad_unpad([x], dz, dWp, G[ec.bias], H, W, lambda: hip.copy2d(dWp, gec, E, cw, Cin, cw))    # un-pad (layout copy)
         if not need_dx:
             return (None, None) if chain is not None else None
         # dx = W_e^T . dz + W_sc^T . dy: one conv over two sources (the forward's expand + shortcut share x)

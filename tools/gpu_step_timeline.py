@@ -17,7 +17,7 @@ from lm_net_amd.optim import FusedAdamW
 ap = argparse.ArgumentParser()
 ap.add_argument("--batch", type=int, default=8); ap.add_argument("--size", type=int, default=352)
 ap.add_argument("--dtype", default="f32"); ap.add_argument("--steps", type=int, default=2)
-ap.add_argument("--no-plans", action="store_true")
+ap.add_argument("--no-plans", action="store_true"); ap.add_argument("--tail", type=int, default=0); ap.add_argument("--s0gaps", type=int, default=0)
 a = ap.parse_args()
 dev = torch.device("cuda", 0)
 net = LM_Net(3, 2).to(dev).train()
@@ -81,3 +81,28 @@ for s in streams:
         sname[s], len(rs) // a.steps, sum(r[3] - r[2] for r in rs) / 1e3 / a.steps, gap / 1e3 / a.steps))
     for k, (n, t) in sorted(by.items(), key=lambda kv: -kv[1][1])[:28]:
         print("    %-52s %4d x %7.1f us = %8.1f us/step" % (k[:52], n // a.steps, t / n, t / a.steps))
+
+# --tail N: the last N launches before each AdamW launch (what runs at the end of the backward), with stream and times relative to it
+if "--tail" in sys.argv:
+    n = int(sys.argv[sys.argv.index("--tail") + 1])
+    order = sorted(range(len(tl)), key=lambda i: tl[i][2])
+    for pos, i in enumerate(order):
+        if tl[i][0].startswith("adamw"):
+            t_ad = tl[i][2]
+            print("---- before adamw at %.2f ms" % ((t_ad - T0) / 1e3))
+            for j in order[max(0, pos - n):pos + 1]:
+                r = tl[j]
+                print("  %s  start %8.1f us  end %8.1f us  (%6.1f us)  %s" % (sname[r[1]], r[2] - t_ad, r[3] - t_ad, r[3] - r[2], r[0][:70]))
+            break
+
+# --s0gaps N: the N largest idle gaps of the main stream (the one with most launches) inside a step: where it waits for another stream
+if a.s0gaps:
+    main = max(streams, key=lambda s: sum(1 for r in tl if r[1] == s))
+    rs = sorted([r for r in tl if r[1] == main], key=lambda r: r[2])
+    gs = sorted(((b[2] - a_[3], a_, b) for a_, b in zip(rs, rs[1:]) if not b[0].startswith("nchw_to") and not a_[0].startswith("adamw")), key=lambda g: -g[0])[:a.s0gaps]
+    print("largest gaps of %s (main stream), total %.2f ms/step in gaps > 15 us:" % (sname[main], sum(max(0, b[2] - a_[3]) for a_, b in zip(rs, rs[1:]) if 15 < b[2] - a_[3] < 2000) / 1e3 / a.steps))
+    for g, a_, b in gs:
+        others = [r for r in tl if r[1] != main and r[3] > a_[3] and r[2] < b[2]]
+        print("  %7.1f us at %8.2f ms: %s -> %s" % (g, (a_[3] - T0) / 1e3, a_[0][:44], b[0][:44]))
+        for r in sorted(others, key=lambda r: r[2])[:8]:
+            print("        %s %7.1f..%7.1f  %s" % (sname[r[1]], r[2] - a_[3], r[3] - a_[3], r[0][:60]))
