@@ -135,6 +135,21 @@ def _Z(ref, *shape):
 STATS_REP = 16
 
 
+def _new_stream(device, priority):
+    """A stream of the given HIP priority (-1 high, 0 normal, 1 low).  torch clamps positive priorities to 0, so low-priority streams are
+    created through the runtime and wrapped (they live as long as the process)."""
+    if priority <= 0:
+        return torch.cuda.Stream(device=device, priority=priority)
+    import ctypes
+    rt = ctypes.CDLL("libamdhip64.so")
+    h = ctypes.c_void_p()
+    with torch.cuda.device(device):
+        rc = rt.hipStreamCreateWithPriority(ctypes.byref(h), ctypes.c_uint(1), ctypes.c_int(priority))      # 1 = hipStreamNonBlocking
+    if rc != 0:
+        raise RuntimeError("hipStreamCreateWithPriority(%d) failed: %d" % (priority, rc))
+    return torch.cuda.ExternalStream(h.value, device=device)
+
+
 class Engine:
     _instances = 0
 
@@ -424,7 +439,7 @@ class Engine:
         key = issuing.cuda_stream
         ent = self.sides.get(key)
         if ent is None:
-            ent = self.sides[key] = [torch.cuda.Stream(device=issuing.device, priority=self.side_prio), False]
+            ent = self.sides[key] = [_new_stream(issuing.device, self.side_prio), False]
         ent[1] = True
         return ent[0]
 
@@ -476,7 +491,7 @@ class Engine:
 
     def branch_stream(self, device):
         if self.branch is None or self.branch.device != device:
-            self.branch = torch.cuda.Stream(device=device, priority=self.branch_prio)
+            self.branch = _new_stream(device, self.branch_prio)
         return self.branch
 
     def branch_stream_n(self, device, i):
@@ -488,7 +503,7 @@ class Engine:
             self.branches.append(None)
         b = self.branches[i - 1]
         if b is None or b.device != device:
-            b = self.branches[i - 1] = torch.cuda.Stream(device=device, priority=self.branch_prio)
+            b = self.branches[i - 1] = _new_stream(device, self.branch_prio)
         return b
 
     def bn_stats(self, bn, sums, count, ref):
