@@ -48,7 +48,7 @@ extern "C" {
 
 typedef void* lmn_stream_t; /* hipStream_t */
 
-#define LMN_ABI_VERSION 13
+#define LMN_ABI_VERSION 14
 /* arithmetic type of the matrix-core operands of a dense contraction (accumulators, epilogues, statistics: fp32) */
 #define LMN_F32 0  /* v_mfma_f32_16x16x4_f32: exact fp32 (k-ordered fma chain)                                  */
 #define LMN_BF16 1 /* v_mfma_f32_16x16x16_bf16: operands rounded to bf16 (RNE) when staged / packed -- the mixed- */
@@ -635,6 +635,11 @@ int lmn_stream_wait(lmn_stream_t waiter, lmn_stream_t waited);
  * that is joined later, after more work has been queued behind the point); recorded by plans like any entry        */
 int lmn_event_record(int slot, lmn_stream_t stream);
 int lmn_event_wait(int slot, lmn_stream_t stream);
+/* The compute chain's stream (process-wide; on = 0 clears it).  The step is as long as the dependent chain of kernels on the caller's
+ * stream; the weight-gradient and branch streams have slack.  The conv and depthwise kernels launched on THIS stream raise their waves'
+ * issue priority (s_setprio 3) against the waves of the other streams' kernels on the same CU.  HIP stream priorities are no
+ * substitute: they starve the lower queue (INTEGRATION, switches).  Not recorded by plans: set it before recording.   (ABI 14)    */
+int lmn_set_priority_stream(lmn_stream_t stream, int on);
 /* Deterministic mode (process-wide; default off): every cross-block float reduction (BatchNorm / SE / LayerNorm statistics, bias /
  * gamma / beta / bias-table gradients, depthwise weight gradients, K-split weight-gradient partials) is summed in a FIXED order --
  * per-block partials in private slots of a per-stream scratch, folded by a sum kernel right after the producer -- instead of by

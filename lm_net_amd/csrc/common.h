@@ -42,6 +42,8 @@ extern int g_lmn_prof_on;
 //     copies of its destination arrays in a per-stream scratch -- with plain stores instead of float atomics, and a fixed-order
 //     sum kernel folds the slots into the real destination right after the producer (same stream, same entry).
 extern int g_lmn_det;
+// (4) lmn_set_priority_stream: is `st` the compute chain's stream (its kernels raise their waves' issue priority)?
+bool lmn_is_prio_stream(hipStream_t st);
 // a zeroed scratch region of `floats` floats on stream st (hipMemsetAsync; the scratch itself is hipMalloc'ed once per stream and
 // grown on demand: the one place where the library owns device memory; a region stays valid when a later request of the same entry
 // outgrows the block -- the old block is retired, not freed).  lmn_det_begin resets the stream's scratch (once per entry).

@@ -390,7 +390,7 @@ int lmn_conv_fwd(const lmn_conv_args_t* args, lmn_stream_t stream) {
   }
   ConvParams P;
   P.det_stats = nullptr;
-  P.prio = 0;
+  P.prio = lmn_is_prio_stream((hipStream_t)stream) ? 4 : 0;   // 4: uniform raised issue priority (the compute chain's stream)
   P.a = A;
   P.NKB = 0;
   for (int s = 0; s < 3; ++s) {
@@ -547,7 +547,7 @@ int lmn_conv_fwd(const lmn_conv_args_t* args, lmn_stream_t stream) {
     {
       static int prio_env = -1;   // LMN_CONV_PRIO: 0 off | 1, 2, 3 = distinct issue priorities per wave slot (lmn_wave_prio); 3x3 calls only unless +10
       if (prio_env < 0) { const char* e = getenv("LMN_CONV_PRIO"); prio_env = e ? atoi(e) : 0; }
-      T.prio = (a.ksize == 3 || prio_env >= 10) ? prio_env % 10 : 0;
+      if (prio_env > 0) T.prio = (a.ksize == 3 || prio_env >= 10) ? prio_env % 10 : 0;
       static int stag3 = -1, stag1 = -1;   // LMN_CONV_STAGGER / LMN_CONV_STAGGER1: start stagger of the 3x3 / 1x1 tile kernels, units of 256 cycles per wave slot
       if (stag3 < 0) { const char* e = getenv("LMN_CONV_STAGGER"); stag3 = e ? atoi(e) : 0; }
       if (stag1 < 0) { const char* e = getenv("LMN_CONV_STAGGER1"); stag1 = e ? atoi(e) : 0; }

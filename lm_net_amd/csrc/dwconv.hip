@@ -16,6 +16,10 @@
 // ALU floor; forward / backward statistics stream at 3.9 / 4.1 TB/s; the backward (120 FMAs per element) runs at ~70 % of its
 // ALU time inside the row loop.
 #include "common.h"
+// the launch's deterministic-mode argument carries the priority flag in bit 8 (lmn_set_priority_stream: kernels on the compute chain's
+// stream raise their waves' issue priority against the waves of the other streams' kernels on the same CU)
+#define LMN_DW_SETPRIO do { if (det & 0x100) __builtin_amdgcn_s_setprio(3); det &= 0xff; } while (0)
+#define DW_DET(st) (g_lmn_det | (lmn_is_prio_stream(st) ? 0x100 : 0))
 
 namespace {
 
@@ -294,6 +298,7 @@ __global__ __launch_bounds__(256, 4) void dw_stats0_kernel(const TA* __restrict_
   __shared__ f32x2 XSa[4][2][68];
   __shared__ float red[8 * 8];
   __shared__ __attribute__((aligned(16))) float pre_s[16];
+  LMN_DW_SETPRIO;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const GeoP g = decode_pair<ES>(E, H, W, strips, segs, seg_rows, chunks, wv);
@@ -404,6 +409,7 @@ __global__ __launch_bounds__(256, LMN_DWF_OCC) void dw_fwd_kernel(const TA* __re
   __shared__ int s_last;
   __shared__ __attribute__((aligned(16))) float pre_s[16];
   __shared__ float scr[2048];   // squeeze-excite gate: mean [E], hidden [R]
+  LMN_DW_SETPRIO;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const GeoP g = decode_pair<ES>(E, H, W, strips, segs, seg_rows, chunks, wv);
@@ -596,6 +602,7 @@ __global__ __launch_bounds__(256, 3) void dw_stats1_kernel(const TA* __restrict_
   __shared__ float red[5 * 8];
   __shared__ __attribute__((aligned(16))) float pre_s[16];
   __shared__ float scr[4096];   // squeeze-excite backward: dt [E], da [R], partial sums [256]
+  LMN_DW_SETPRIO;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const GeoP g = decode_pair<ES>(E, H, W, strips, segs, seg_rows, chunks, wv);
@@ -968,6 +975,7 @@ __global__ __launch_bounds__(256, WPS) void dw_bwd_kernel(
   __shared__ V XSa[4][5 * 68];
   __shared__ V ZSa[4][ZT && PART != 2 ? 5 * 64 : 1];
   __shared__ float red[4 * 44];
+  LMN_DW_SETPRIO;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   // decode: quad fastest, then strip, segment PAIR, image
@@ -1346,13 +1354,13 @@ static int launch_dw_stats(const void* x1, const void* pre, const void* u, const
   if (MODE == 0) {
     const bool zt = zp.A != nullptr || zp.fin.mode == LMN_FIN_BN;
 #define LMN_DS0(Z) LMN_ACT_DISPATCH(act_dtype, LMN_LAUNCH((dw_stats0_kernel<T, Z>), dim3((unsigned)nblk), dim3(256), 0, st, (const T*)x1, H, W, E, w5, w3, wv, wh, sdst, zp, strips, nseg, \
-                                          seg_rows, chunks, g_lmn_det))
+                                          seg_rows, chunks, DW_DET(st)))
     if (zt) LMN_DS0(true); else LMN_DS0(false);
 #undef LMN_DS0
   } else {
     const bool zt = zp.A != nullptr;
 #define LMN_DS1(Z) LMN_ACT_DISPATCH(act_dtype, LMN_LAUNCH((dw_stats1_kernel<T, Z>), dim3((unsigned)nblk), dim3(256), 0, st, (const T*)x1, (const T*)pre, (const T*)u, s, dm, (T*)dpre, H, W, E, \
-                                          w5, w3, wv, wh, sdst, sb, zp, strips, nseg, seg_rows, chunks, g_lmn_det))
+                                          w5, w3, wv, wh, sdst, sb, zp, strips, nseg, seg_rows, chunks, DW_DET(st)))
     if (zt) LMN_DS1(true); else LMN_DS1(false);
 #undef LMN_DS1
   }
@@ -1406,7 +1414,7 @@ static int dw_fwd_launch(const void* x1, void* pre, float* gsum, int B, int H, i
     LMN_REQUIRE(gdst, "%s: deterministic mode: no scratch", what);
   }
 #define LMN_DF(Z) LMN_ACT_DISPATCH(act_dtype, LMN_LAUNCH((dw_fwd_kernel<T, Z>), dim3((unsigned)nblk), dim3(256), 0, st, (const T*)x1, (T*)pre, gdst, H, W, E, keff, beff, fn, sf, \
-                                        DwPreS{zp.A, zp.shift}, strips, segs, seg_rows, chunks, g_lmn_det, B))
+                                        DwPreS{zp.A, zp.shift}, strips, segs, seg_rows, chunks, DW_DET(st), B))
   if (zp.A) LMN_DF(true); else LMN_DF(false);
 #undef LMN_DF
   if (g_lmn_det) lmn_det_sum(st, gdst, segs * strips, (int64_t)B * E, gsum);
@@ -1562,7 +1570,7 @@ static int dw_bwd_launch(const void* x1, const void* dpre, void* dx1, int B, int
     if (hstats) hs_ = gh + (size_t)nslots * 3 * E;
   }
 #define LMN_DWB4(PT, HL, Z, WP) LMN_ACT_DISPATCH(act_dtype, LMN_LAUNCH((dw_bwd_kernel<T, PT, HL, Z, WP>), dim3((unsigned)nblk), dim3(256), 0, st, (const T*)x1, (const T*)dpre, \
-                       (T*)dx1, B, H, W, E, w5, w3, wv, wh, cA, cC, cD, cf, g5, g3, gv, gh, DwPreS{zp.A, zp.shift}, hs_, strips, segs, seg_rows, chunks, g_lmn_det))
+                       (T*)dx1, B, H, W, E, w5, w3, wv, wh, cA, cC, cD, cf, g5, g3, gv, gh, DwPreS{zp.A, zp.shift}, hs_, strips, segs, seg_rows, chunks, DW_DET(st)))
 #define LMN_DWB3(PT, HL, WP) do { if (zp.A) LMN_DWB4(PT, HL, true, WP); else LMN_DWB4(PT, HL, false, WP); } while (0)
 #define LMN_DWB2(PT, WP) do { if (halo) LMN_DWB3(PT, true, WP); else LMN_DWB3(PT, false, WP); } while (0)
   if (part == 1) { LMN_DWB2(1, 3); } else if (part == 2) { LMN_DWB2(2, 2); } else { LMN_DWB2(0, 2); }

@@ -238,6 +238,10 @@ void lmn_det_sum(hipStream_t st, const float* slots, int nslots, int64_t size, f
   hipLaunchKernelGGL(det_sum_kernel, dim3((unsigned)((size + 7) / 8)), dim3(256), 0, st, slots, nslots, size, dst);
 }
 
+static bool g_prio_on = false;
+static hipStream_t g_prio_st = nullptr;
+bool lmn_is_prio_stream(hipStream_t st) { return g_prio_on && st == g_prio_st; }   // (common.h (4))
+
 extern "C" {
 
 // ---- stream ordering without torch: `waiter` waits for everything enqueued on `waited` so far
@@ -282,6 +286,13 @@ int lmn_event_wait(int slot, lmn_stream_t stream) {
   LMN_REQUIRE(e, "event_wait: slot %d", slot);
   const hipError_t r = hipStreamWaitEvent((hipStream_t)stream, e, 0);
   LMN_REQUIRE(r == hipSuccess, "event_wait: %s", hipGetErrorString(r));
+  return 0;
+}
+
+// ---- the compute chain's stream (see common.h (4))
+int lmn_set_priority_stream(lmn_stream_t stream, int on) {
+  g_prio_on = on != 0;
+  g_prio_st = (hipStream_t)stream;
   return 0;
 }
 

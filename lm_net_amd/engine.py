@@ -192,6 +192,7 @@ class Engine:
         self.lazy_q = []
         self.side_prio = int(os.environ.get("LMN_SIDE_PRIO", "0"))   # HIP priority of the weight-gradient streams (-1: high; A/B runs)
         self.branch_prio = int(os.environ.get("LMN_BRANCH_PRIO", "0"))
+        self.prio_main = os.environ.get("LMN_PRIO_MAIN", "1") != "0"  # raised wave priority (s_setprio) for the kernels of the caller's stream
         self.slot_base = 4 * (Engine._instances % 16)     # this engine's four numbered events (lmn_event_record / wait: 64 per process)
         Engine._instances += 1
         self.zpool_fwd, self.zpool_bwd = ZeroPool(), ZeroPool()
@@ -696,7 +697,7 @@ class Engine:
             self.wgrad([dict(view=pre, scale=sgate, flags=hip.SRC_GELU)], dy, pw.weight, pw.bias, Hin=H, Win=W)
             dWp = _Z(x, Cout, Cin)
             gsc = G[sc.weight]
-            self.wgrad_unpad([x], dy, dWp, G[sc.bias], H, W, lambda: hip.copy2d(dWp, gsc, Cout, cw, Cin, cw))   # un-pad (layout copy)
+            self.wgrad_unpad([x], dy, dWp, G[sc.bias], H, W, lambda d=dWp, g=gsc: hip.copy2d(d, g, Cout, cw, Cin, cw))   # un-pad (layout copy)
         if pre_u is not None:
             u, ds = pre_u                    # written by the next block's data-gradient launch (chained SE-gradient conv)
         else:
@@ -771,7 +772,7 @@ class Engine:
                 else:
                     dWp = _Z(x, E, Cin)
                     gec = G[ec.weight]
-                    self.wgrad_unpad([x], dz, dWp, G[ec.bias], H, W, lambda: hip.copy2d(dWp, gec, E, cw, Cin, cw))    # un-pad (layout copy)
+                    self.wgrad_unpad([x], dz, dWp, G[ec.bias], H, W, lambda d=dWp, g=gec: hip.copy2d(d, g, E, cw, Cin, cw))    # un-pad (layout copy)
             if not need_dx:
                 return (None, None) if chain is not None else None
             dx = _A(x, B, H, W, Cin)
@@ -836,7 +837,7 @@ class Engine:
         else:
             dWp = _Z(x, E, Cin)
             gec = G[ec.weight]
-            self.wgrad_unpad([x], dz, dWp, G[ec.bias], H, W, lambda: hip.copy2d(dWp, gec, E, cw, Cin, cw))    # un-pad (layout copy)
+            self.wgrad_unpad([x], dz, dWp, G[ec.bias], H, W, lambda d=dWp, g=gec: hip.copy2d(d, g, E, cw, Cin, cw))    # un-pad (layout copy)
         if not need_dx:
             return (None, None) if chain is not None else None
         # dx = W_e^T . dz + W_sc^T . dy: one conv over two sources (the forward's expand + shortcut share x)

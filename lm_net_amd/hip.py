@@ -10,7 +10,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.environ.get("LMNET_HIP_LIB") or os.path.join(_HERE, "liblmnet_hip.so")   # (override: A/B runs against another build)
+LIB_PATH = os.path.abspath(os.environ["LMNET_HIP_LIB"]) if os.environ.get("LMNET_HIP_LIB") else os.path.join(_HERE, "liblmnet_hip.so")   # (override: A/B runs against another build)
 
 # ---- constants mirrored from include/lmnet_hip.h
 SRC_GELU, SRC_DROP, SRC_LN, SRC_UP2 = 1, 2, 4, 8
@@ -19,7 +19,7 @@ ACT_NONE, ACT_HSWISH, ACT_GELU = 0, 1, 2
 STATS_NONE, STATS_SUM_SQ, STATS_EP = 0, 1, 2
 F32, BF16 = 0, 1            # matrix-core operand type of the dense contractions (LMN_F32 / LMN_BF16)
 _MMA = [F32]                # ... of the pass in flight (engine.begin_pass)
-ABI_VERSION = 13
+ABI_VERSION = 14
 
 
 class SrcT(C.Structure):
@@ -140,7 +140,7 @@ SYMBOLS = [
     "lmn_ln_fwd", "lmn_ln_bwd", "lmn_bnact_fwd", "lmn_bnact_bwd_stats", "lmn_bnact_bwd",
     "lmn_bn_finalize", "lmn_bn_fold", "lmn_bn_bwd_coef", "lmn_up2_fwd", "lmn_up2_bwd", "lmn_avgpool_fwd", "lmn_avgpool_bwd",
     "lmn_nchw_to_nhwc", "lmn_nhwc_to_nchw", "lmn_adamw_step", "lmn_segloss_fwd", "lmn_segloss_bwd", "lmn_confusion", "lmn_preprocess_u8", "lmn_fill", "lmn_add", "lmn_colsum", "lmn_copy_slice", "lmn_copy2d",
-    "lmn_stream_wait", "lmn_event_record", "lmn_event_wait", "lmn_plan_create", "lmn_plan_destroy", "lmn_plan_record_begin", "lmn_plan_record_end", "lmn_plan_size",
+    "lmn_stream_wait", "lmn_event_record", "lmn_event_wait", "lmn_set_priority_stream", "lmn_plan_create", "lmn_plan_destroy", "lmn_plan_record_begin", "lmn_plan_record_end", "lmn_plan_size",
     "lmn_plan_run", "lmn_prof_begin", "lmn_prof_end",
 ]
 
@@ -1041,6 +1041,18 @@ def event_record(slot, stream):
 
 def event_wait(slot, stream):
     _check(load().lmn_event_wait(slot, C.c_void_p(stream.cuda_stream)), "event_wait")
+
+
+_PRIO_STREAM = [None]
+
+
+def set_priority_stream(stream):
+    """The compute chain's stream (include/lmnet_hip.h, lmn_set_priority_stream): a torch stream, or None to clear.  Process-wide."""
+    key = None if stream is None else stream.cuda_stream
+    if _PRIO_STREAM[0] == (key, stream is not None):
+        return
+    _check(load().lmn_set_priority_stream(C.c_void_p(key or 0), 0 if stream is None else 1), "set_priority_stream")
+    _PRIO_STREAM[0] = (key, stream is not None)
 
 
 class Plan:
