@@ -239,7 +239,7 @@ class LM_Net(nn.Module):
             raise ValueError("H and W must be multiples of 16 and >= 32 (got %dx%d)" % (x.shape[2], x.shape[3]))
         hip.load()
         # the step is as long as the kernel chain on the caller's stream: its conv / depthwise kernels run at a raised wave priority
-        hip.set_priority_stream(torch.cuda.current_stream(x.device) if self._engine.prio_main else None)
+        hip.set_priority_stream(torch.cuda.current_stream(x.device), self._engine.prio_main)
         if hip.get_deterministic() != self._engine.deterministic:     # the switch is process-wide: every model follows it
             self._engine.set_deterministic(hip.get_deterministic())
         params = self._param_list()

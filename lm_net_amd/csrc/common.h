@@ -42,8 +42,16 @@ extern int g_lmn_prof_on;
 //     copies of its destination arrays in a per-stream scratch -- with plain stores instead of float atomics, and a fixed-order
 //     sum kernel folds the slots into the real destination right after the producer (same stream, same entry).
 extern int g_lmn_det;
-// (4) lmn_set_priority_stream: is `st` the compute chain's stream (its kernels raise their waves' issue priority)?
-bool lmn_is_prio_stream(hipStream_t st);
+// (4) lmn_set_priority_stream: the wave priority (0..3) of the kernels launched on `st` (3: the compute chain's stream)
+int lmn_prio_level(hipStream_t st);
+__device__ __forceinline__ void lmn_setprio_level(int lvl) {   // (s_setprio takes an immediate)
+  switch (lvl) {
+    case 1: __builtin_amdgcn_s_setprio(1); break;
+    case 2: __builtin_amdgcn_s_setprio(2); break;
+    case 3: __builtin_amdgcn_s_setprio(3); break;
+    default: break;
+  }
+}
 // a zeroed scratch region of `floats` floats on stream st (hipMemsetAsync; the scratch itself is hipMalloc'ed once per stream and
 // grown on demand: the one place where the library owns device memory; a region stays valid when a later request of the same entry
 // outgrows the block -- the old block is retired, not freed).  lmn_det_begin resets the stream's scratch (once per entry).

@@ -30,7 +30,7 @@ struct ConvParams {
   uint32_t rp_magic;                     // floor(2^32 / rpw)
   LmnLay lay_out2, lay_aux2;             // chained second conv (lmn_conv_chain_t): its out / aux address forms
   int32_t NCTT2;                         // ... and its cout tiles
-  int32_t prio;                          // 4: launched on the compute chain's stream (lmn_set_priority_stream): s_setprio 3 for every wave;
+  int32_t prio;                          // 4..6: launched on a stream of wave priority 3..1 (lmn_set_priority_stream): s_setprio for every wave;
                                          // LMN_CONV_PRIO (experiment): 1..3 = the co-resident waves of a SIMD get DISTINCT issue priorities;
                                          // >= 100: start stagger of (prio - 100) x 256 cycles per wave slot (lmn_wave_stagger)
 };
@@ -42,7 +42,7 @@ struct ConvParams {
 __device__ __forceinline__ void lmn_wave_prio(int mode) {
   uint32_t slot;
   asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID, 0, 4)" : "=s"(slot));   // wave slot of this wave on its SIMD
-  const uint32_t p = mode == 4 ? 3u : (mode == 2 ? 3u - (slot & 3u) : (mode == 3 ? (slot & 1u) * 3u : (slot & 3u)));   // 4: uniform (lmn_set_priority_stream)
+  const uint32_t p = mode >= 4 ? (uint32_t)(7 - mode) : (mode == 2 ? 3u - (slot & 3u) : (mode == 3 ? (slot & 1u) * 3u : (slot & 3u)));   // 4..6: uniform 3..1 (lmn_set_priority_stream)
   switch (p) {
     case 0: __builtin_amdgcn_s_setprio(0); break;
     case 1: __builtin_amdgcn_s_setprio(1); break;

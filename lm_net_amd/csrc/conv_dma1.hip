@@ -90,7 +90,7 @@ __global__ __launch_bounds__(256, BPC) void conv_dma1_kernel(const ConvParams P)
   float* const s_red = s_w2 + WFL2;                 // [4 waves][NCTS*16]: block-level sums of the SE-gradient epilogue
   float* const s_par2 = s_red + 4 * NCTS * 16;      // chained conv: bias, shift [2][NCT2*16]
   float* const s_par = s_par2 + 2 * (NCT2 ? NCT2 : 1) * 16;   // 9 parameter vectors of the first conv (conv_stage_params)
-  if (P.prio == 4) __builtin_amdgcn_s_setprio(3);   // (uniform: the compute chain's stream)
+  if (P.prio >= 4) lmn_setprio_level(7 - P.prio);   // (uniform: lmn_set_priority_stream)
   const int tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int q = lane >> 4, n = lane & 15;

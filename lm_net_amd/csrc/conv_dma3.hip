@@ -72,7 +72,7 @@ __global__ __launch_bounds__(256, BPC) void conv_dma3_kernel(const ConvParams P)
   float* const s_w = smem + 2 * NCH * 4;            // [tap][ct][lane][KS]
   float* const s_stats = s_w + WFL;                 // [2][NCT*16] (conv_stage_params's layout: statistics slots, then 9 parameter vectors)
   float* const s_par = s_stats + 2 * NCT * 16;
-  if (P.prio == 4) __builtin_amdgcn_s_setprio(3);   // (uniform: the compute chain's stream)
+  if (P.prio >= 4) lmn_setprio_level(7 - P.prio);   // (uniform: lmn_set_priority_stream)
   const int tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int q = lane >> 4, n = lane & 15;

@@ -118,12 +118,14 @@ struct FoldParams {
   const float* we; const float* be; const float* wsc;                          // [E][cinw], [E], [coutw][cinw]  (torch layouts, k = 1)
   float* wpack; float* kbias; float* coef; float* dgamma; float* dbeta;        // packed operators, [rows], [3][E], [E] +=, [E] +=
   float count; int batch_stats;
+  int prio;                               // wave priority of the launch stream (lmn_set_priority_stream)
   int E, rows, cinw, cred, coutw, bf16;   // rows: channels of x / dx (a multiple of 4 >= cinw); cred: channels of dy (>= coutw)
 };
 __global__ __launch_bounds__(256) void reparam_fold_kernel(const FoldParams P) {
   // one block per packed fragment tile (K16 block kb, row tile ct): 64 lanes x 4 elements.  The Q tiles need E-long dot
   // products of two 16-column panels of W_e: both panels are staged in LDS with coalesced 64-byte rows (read straight from
   // global memory, the loop was a chain of 2 * E dependent L2 round trips per thread: 24 us for a 2 MFLOP problem).
+  lmn_setprio_level(P.prio);
   extern __shared__ float sm[];   // a[E], b[E], c[E], panel R [E][16], panel K [E][16]
   float* sa = sm; float* sb = sm + P.E; float* sc = sm + 2 * P.E;
   float* pr = sm + 3 * P.E; float* pk = pr + P.E * 16;
@@ -390,7 +392,8 @@ int lmn_conv_fwd(const lmn_conv_args_t* args, lmn_stream_t stream) {
   }
   ConvParams P;
   P.det_stats = nullptr;
-  P.prio = lmn_is_prio_stream((hipStream_t)stream) ? 4 : 0;   // 4: uniform raised issue priority (the compute chain's stream)
+  P.prio = lmn_prio_level((hipStream_t)stream);
+  if (P.prio) P.prio = 7 - P.prio;   // 4..6: uniform raised issue priority 3..1 (lmn_set_priority_stream)
   P.a = A;
   P.NKB = 0;
   for (int s = 0; s < 3; ++s) {
@@ -835,6 +838,7 @@ int lmn_reparam_fold(const float* hstats, const float* mean, const float* rstd, 
   P.E = E; P.rows = rows; P.cinw = cin_w; P.cred = cred; P.coutw = cout_w; P.bf16 = dtype == LMN_BF16;
   const int ntiles = ((E + 15) / 16 + (rows + 15) / 16 + (cred + 15) / 16) * ((rows + 15) / 16);
   LMN_REQUIRE((size_t)35 * E * sizeof(float) <= 64 * 1024, "reparam_fold: E = %d too wide for the block's scratch", E);
+  P.prio = lmn_prio_level((hipStream_t)stream);
   LMN_LAUNCH(reparam_fold_kernel, dim3(ntiles + 1), dim3(256), (size_t)35 * E * sizeof(float), (hipStream_t)stream, P);
   return lmn_launch_status("reparam_fold");
 }

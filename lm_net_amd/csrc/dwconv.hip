@@ -16,10 +16,10 @@
 // ALU floor; forward / backward statistics stream at 3.9 / 4.1 TB/s; the backward (120 FMAs per element) runs at ~70 % of its
 // ALU time inside the row loop.
 #include "common.h"
-// the launch's deterministic-mode argument carries the priority flag in bit 8 (lmn_set_priority_stream: kernels on the compute chain's
-// stream raise their waves' issue priority against the waves of the other streams' kernels on the same CU)
-#define LMN_DW_SETPRIO do { if (det & 0x100) __builtin_amdgcn_s_setprio(3); det &= 0xff; } while (0)
-#define DW_DET(st) (g_lmn_det | (lmn_is_prio_stream(st) ? 0x100 : 0))
+// the launch's deterministic-mode argument carries the wave priority in bits 8-9 (lmn_set_priority_stream: kernels on the compute
+// chain's stream raise their waves' issue priority against the waves of the other streams' kernels on the same CU)
+#define LMN_DW_SETPRIO do { lmn_setprio_level(det >> 8); det &= 0xff; } while (0)
+#define DW_DET(st) (g_lmn_det | (lmn_prio_level(st) << 8))
 
 namespace {
 

@@ -18,6 +18,7 @@ typedef float f32x4g __attribute__((ext_vector_type(4)));
 struct GaGeom {
   int B, N, heads, hd, C;
   float scale;
+  int prio;   // wave priority of the launch stream (lmn_set_priority_stream)
 };
 
 // copy rows [r0, r0+GA_KC) of one (b, head, which) slab into LDS as [GA_KC][GA_D] (zero padded)
@@ -154,6 +155,7 @@ template <typename TA>
 __global__ __launch_bounds__(256) void gattn_fwd_mfma_kernel(const TA* __restrict__ qkv, TA* __restrict__ out,
                                                              float* __restrict__ lse, const GaGeom g) {
   __shared__ __attribute__((aligned(16))) float Ks[GA_KC * GM_LD], Vs[GA_KC * GM_LD], Ps[4][16 * 17];
+  lmn_setprio_level(g.prio);
   const int h = blockIdx.y, b = blockIdx.z;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int gq = lane >> 4, n = lane & 15;
@@ -237,6 +239,7 @@ __global__ __launch_bounds__(256) void gattn_bwd_q_mfma_kernel(const TA* __restr
                                                                TA* __restrict__ dqkv, float* __restrict__ delta,
                                                                const GaGeom g) {
   __shared__ __attribute__((aligned(16))) float Ks[GA_KC * GM_LD], Vs[GA_KC * GM_LD], Ps[4][16 * 17];
+  lmn_setprio_level(g.prio);
   const int h = blockIdx.y, b = blockIdx.z;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int gq = lane >> 4, n = lane & 15;
@@ -320,6 +323,7 @@ __global__ __launch_bounds__(256) void gattn_bwd_kv_mfma_kernel(const TA* __rest
                                                                 TA* __restrict__ dqkv, const GaGeom g) {
   __shared__ __attribute__((aligned(16))) float Qs[GA_KC * GM_LD], Ds[GA_KC * GM_LD], Ps[4][2][16 * 17];
   __shared__ float Ls[GA_KC], Dl[GA_KC];
+  lmn_setprio_level(g.prio);
   const int h = blockIdx.y, b = blockIdx.z;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int gq = lane >> 4, n = lane & 15;
@@ -533,7 +537,7 @@ int lmn_gattn_fwd(const void* qkv, void* out, float* lse, int B, int N, int head
   LMN_REQUIRE_DT(act_dtype, "gattn_fwd");
   LMN_REQUIRE(qkv && out && lse && B > 0 && N > 0 && heads > 0, "gattn_fwd: bad argument");
   LMN_REQUIRE(hd >= 1 && hd <= GA_D, "gattn_fwd: head_dim %d > %d", hd, GA_D);
-  GaGeom g{B, N, heads, hd, heads * hd, scale};
+  GaGeom g{B, N, heads, hd, heads * hd, scale, lmn_prio_level((hipStream_t)stream)};
   static int mf = -1;
   if (mf < 0) { const char* e = getenv("LMN_GATTN_MFMA"); mf = e ? atoi(e) : 1; }
   if (mf) {  // MFMA form (LMN_GATTN_MFMA=0: the VALU form, A/B runs)
@@ -550,7 +554,7 @@ int lmn_gattn_bwd(const void* qkv, const void* out, const void* dout, const floa
   LMN_REQUIRE_DT(act_dtype, "gattn_bwd");
   LMN_REQUIRE(qkv && out && dout && lse && dqkv && delta && B > 0 && N > 0 && heads > 0, "gattn_bwd: bad argument");
   LMN_REQUIRE(hd >= 1 && hd <= GA_D, "gattn_bwd: head_dim %d > %d", hd, GA_D);
-  GaGeom g{B, N, heads, hd, heads * hd, scale};
+  GaGeom g{B, N, heads, hd, heads * hd, scale, lmn_prio_level((hipStream_t)stream)};
   static int mf = -1;
   if (mf < 0) { const char* e = getenv("LMN_GATTN_MFMA"); mf = e ? atoi(e) : 1; }
   if (mf) {

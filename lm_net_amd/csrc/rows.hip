@@ -521,7 +521,8 @@ __device__ __forceinline__ float up_adj_weight(int o, int i, int n_in, int n_out
 }
 template <typename T>
 __global__ __launch_bounds__(256) void up2_bwd_kernel(const T* __restrict__ dy, T* __restrict__ dx, int B,
-                                                      int Hin, int Win, int C4, int dycs, int dxcs, uint32_t mC4) {
+                                                      int Hin, int Win, int C4, int dycs, int dxcs, uint32_t mC4, int prio) {
+  lmn_setprio_level(prio);   // (lmn_set_priority_stream)
   const int Hout = 2 * Hin, Wout = 2 * Win;
   const float sh = (float)(Hin - 1) / (float)(Hout - 1), sw = (float)(Win - 1) / (float)(Wout - 1);
   const int j = blockIdx.x * 256 + threadIdx.x;
@@ -558,8 +559,9 @@ __global__ __launch_bounds__(256) void up2_bwd_kernel(const T* __restrict__ dy, 
 // step against 12 alone: every one of its 3872 blocks is a chain of barriers that waits for CU slots next to the other streams.
 template <typename T>
 __global__ __launch_bounds__(256) void avgpool_fwd_wave_kernel(const T* __restrict__ x, T* __restrict__ y, int Hout, int Wout, int f,
-                                                               int C, int xcs, int ycs, int total, uint32_t mW, uint32_t mHW, uint32_t mC4) {
+                                                               int C, int xcs, int ycs, int total, uint32_t mW, uint32_t mHW, uint32_t mC4, int prio) {
   __shared__ __attribute__((aligned(16))) float park[4][64 * 4];
+  lmn_setprio_level(prio);   // (lmn_set_priority_stream)
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int op = blockIdx.x * 4 + wv;
   if (op >= total) return;                      // (wave-uniform; no block barrier below)
@@ -618,7 +620,8 @@ __global__ __launch_bounds__(256) void avgpool_fwd_kernel(const T* __restrict__ 
 template <typename T>
 __global__ __launch_bounds__(256) void avgpool_bwd_kernel(const T* __restrict__ dy, T* __restrict__ dx, int B,
                                                           int Hout, int Wout, int f, int C4, int dycs, int dxcs,
-                                                          int accumulate, uint32_t mC4, uint32_t mf) {
+                                                          int accumulate, uint32_t mC4, uint32_t mf, int prio) {
+  lmn_setprio_level(prio);   // (lmn_set_priority_stream)
   // one block row (grid-strided) = one input row of one image: the vertical index arithmetic is block-uniform; columns by magic
   // multipliers (the flat-index form: five 64- / 32-bit divisions per element around one load and one store)
   const int Hin = Hout * f, Win = Wout * f;
@@ -1199,7 +1202,7 @@ int lmn_up2_bwd(const void* dy, void* dx, int B, int Hin, int Win, int C, int dy
   LMN_REQUIRE((int64_t)2 * Win * dy_cstride < (1LL << 31) && (int64_t)B * Hin < (1LL << 31), "up2_bwd: image too large for 32-bit row offsets");
   const dim3 grid((unsigned)lmn_cdiv((int64_t)Win * (C / 4), 256), (unsigned)((int64_t)B * Hin < 65535 ? B * Hin : 65535));
   LMN_ACT_DISPATCH(act_dtype, LMN_LAUNCH((up2_bwd_kernel<T>), grid, dim3(256), 0, (hipStream_t)stream, (const T*)dy, (T*)dx, B, Hin, Win, C / 4,
-                     dy_cstride, dx_cstride, lmn_div_magic(C / 4)));
+                     dy_cstride, dx_cstride, lmn_div_magic(C / 4), lmn_prio_level((hipStream_t)stream)));
   return lmn_launch_status("up2_bwd");
 }
 
@@ -1211,7 +1214,7 @@ int lmn_avgpool_fwd(const void* x, void* y, int B, int Hout, int Wout, int f, in
   if (C <= 256 && (int64_t)B * Hout * Wout < (1LL << 30)) {   // wave per output pixel
     const int total = B * Hout * Wout;
     LMN_ACT_DISPATCH(act_dtype, LMN_LAUNCH((avgpool_fwd_wave_kernel<T>), dim3(lmn_cdiv(total, 4)), dim3(256), 0, (hipStream_t)stream, (const T*)x, (T*)y,
-                       Hout, Wout, f, C, x_cstride, y_cstride, total, lmn_div_magic(Wout), lmn_div_magic(Hout * Wout), lmn_div_magic(C / 4)));
+                       Hout, Wout, f, C, x_cstride, y_cstride, total, lmn_div_magic(Wout), lmn_div_magic(Hout * Wout), lmn_div_magic(C / 4), lmn_prio_level((hipStream_t)stream)));
     return lmn_launch_status("avgpool_fwd");
   }
   LMN_ACT_DISPATCH(act_dtype, LMN_LAUNCH((avgpool_fwd_kernel<T>), dim3(B * Hout * Wout), dim3(256), (size_t)(C + 4 * 256 + (C > 256 ? C : 256)) * sizeof(float), (hipStream_t)stream, (const T*)x, (T*)y,
@@ -1227,7 +1230,7 @@ int lmn_avgpool_bwd(const void* dy, void* dx, int B, int Hout, int Wout, int f, 
   LMN_REQUIRE((int64_t)B * Hout * f < (1LL << 31) && (int64_t)Wout * f * (C / 4) < (1LL << 31), "avgpool_bwd: image too large for 32-bit row / column indices");
   const dim3 grid((unsigned)lmn_cdiv((int64_t)Wout * f * (C / 4), 256), (unsigned)((int64_t)B * Hout * f < 65535 ? B * Hout * f : 65535));
   LMN_ACT_DISPATCH(act_dtype, LMN_LAUNCH((avgpool_bwd_kernel<T>), grid, dim3(256), 0, (hipStream_t)stream, (const T*)dy, (T*)dx, B, Hout, Wout,
-                     f, C / 4, dy_cstride, dx_cstride, accumulate, lmn_div_magic(C / 4), lmn_div_magic(f)));
+                     f, C / 4, dy_cstride, dx_cstride, accumulate, lmn_div_magic(C / 4), lmn_div_magic(f), lmn_prio_level((hipStream_t)stream)));
   return lmn_launch_status("avgpool_bwd");
 }
 

@@ -238,9 +238,12 @@ void lmn_det_sum(hipStream_t st, const float* slots, int nslots, int64_t size, f
   hipLaunchKernelGGL(det_sum_kernel, dim3((unsigned)((size + 7) / 8)), dim3(256), 0, st, slots, nslots, size, dst);
 }
 
-static bool g_prio_on = false;
-static hipStream_t g_prio_st = nullptr;
-bool lmn_is_prio_stream(hipStream_t st) { return g_prio_on && st == g_prio_st; }   // (common.h (4))
+static struct { hipStream_t st; int level; } g_prio[8];   // (common.h (4); level 0 = free entry)
+int lmn_prio_level(hipStream_t st) {
+  for (int i = 0; i < 8; ++i)
+    if (g_prio[i].level > 0 && g_prio[i].st == st) return g_prio[i].level;
+  return 0;
+}
 
 extern "C" {
 
@@ -290,9 +293,17 @@ int lmn_event_wait(int slot, lmn_stream_t stream) {
 }
 
 // ---- the compute chain's stream (see common.h (4))
-int lmn_set_priority_stream(lmn_stream_t stream, int on) {
-  g_prio_on = on != 0;
-  g_prio_st = (hipStream_t)stream;
+int lmn_set_priority_stream(lmn_stream_t stream, int level) {
+  LMN_REQUIRE(level >= 0 && level <= 3, "set_priority_stream: level %d", level);
+  hipStream_t st = (hipStream_t)stream;
+  int slot = -1;
+  for (int i = 0; i < 8; ++i) {
+    if (g_prio[i].level > 0 && g_prio[i].st == st) { slot = i; break; }
+    if (g_prio[i].level == 0 && slot < 0) slot = i;
+  }
+  LMN_REQUIRE(slot >= 0, "set_priority_stream: more than 8 streams");
+  g_prio[slot].st = st;
+  g_prio[slot].level = level;
   return 0;
 }
 

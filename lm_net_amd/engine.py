@@ -135,9 +135,17 @@ def _Z(ref, *shape):
 STATS_REP = 16
 
 
-def _new_stream(device, priority):
+def _new_stream(device, priority, wave_prio=0):
     """A stream of the given HIP priority (-1 high, 0 normal, 1 low).  torch clamps positive priorities to 0, so low-priority streams are
-    created through the runtime and wrapped (they live as long as the process)."""
+    created through the runtime and wrapped (they live as long as the process).  wave_prio > 0: the library's kernels on this stream
+    raise their waves' issue priority (hip.set_priority_stream)."""
+    s = _new_stream_raw(device, priority)
+    if wave_prio > 0:
+        hip.set_priority_stream(s, wave_prio)
+    return s
+
+
+def _new_stream_raw(device, priority):
     if priority <= 0:
         return torch.cuda.Stream(device=device, priority=priority)
     import ctypes
@@ -192,7 +200,8 @@ class Engine:
         self.lazy_q = []
         self.side_prio = int(os.environ.get("LMN_SIDE_PRIO", "0"))   # HIP priority of the weight-gradient streams (-1: high; A/B runs)
         self.branch_prio = int(os.environ.get("LMN_BRANCH_PRIO", "0"))
-        self.prio_main = os.environ.get("LMN_PRIO_MAIN", "1") != "0"  # raised wave priority (s_setprio) for the kernels of the caller's stream
+        self.prio_main = int(os.environ.get("LMN_PRIO_MAIN", "3"))     # wave priority (s_setprio) of the kernels on the caller's stream ...
+        self.prio_branch = int(os.environ.get("LMN_PRIO_BRANCH", "0")) # ... and on the branch streams (0: the default, as the weight-gradient streams)
         self.slot_base = 4 * (Engine._instances % 16)     # this engine's four numbered events (lmn_event_record / wait: 64 per process)
         Engine._instances += 1
         self.zpool_fwd, self.zpool_bwd = ZeroPool(), ZeroPool()
@@ -492,7 +501,7 @@ class Engine:
 
     def branch_stream(self, device):
         if self.branch is None or self.branch.device != device:
-            self.branch = _new_stream(device, self.branch_prio)
+            self.branch = _new_stream(device, self.branch_prio, self.prio_branch)
         return self.branch
 
     def branch_stream_n(self, device, i):
@@ -504,7 +513,7 @@ class Engine:
             self.branches.append(None)
         b = self.branches[i - 1]
         if b is None or b.device != device:
-            b = self.branches[i - 1] = _new_stream(device, self.branch_prio)
+            b = self.branches[i - 1] = _new_stream(device, self.branch_prio, self.prio_branch)
         return b
 
     def bn_stats(self, bn, sums, count, ref):

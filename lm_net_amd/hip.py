@@ -1043,16 +1043,16 @@ def event_wait(slot, stream):
     _check(load().lmn_event_wait(slot, C.c_void_p(stream.cuda_stream)), "event_wait")
 
 
-_PRIO_STREAM = [None]
+_PRIO_STREAMS = {}
 
 
-def set_priority_stream(stream):
-    """The compute chain's stream (include/lmnet_hip.h, lmn_set_priority_stream): a torch stream, or None to clear.  Process-wide."""
-    key = None if stream is None else stream.cuda_stream
-    if _PRIO_STREAM[0] == (key, stream is not None):
+def set_priority_stream(stream, level=3):
+    """Wave priority 0..3 of the kernels launched on a torch stream (include/lmnet_hip.h, lmn_set_priority_stream).  Process-wide."""
+    key = stream.cuda_stream
+    if _PRIO_STREAMS.get(key, 0) == level:
         return
-    _check(load().lmn_set_priority_stream(C.c_void_p(key or 0), 0 if stream is None else 1), "set_priority_stream")
-    _PRIO_STREAM[0] = (key, stream is not None)
+    _check(load().lmn_set_priority_stream(C.c_void_p(key), level), "set_priority_stream")
+    _PRIO_STREAMS[key] = level
 
 
 class Plan:

@@ -17,7 +17,7 @@ from lm_net_amd.optim import FusedAdamW
 ap = argparse.ArgumentParser()
 ap.add_argument("--batch", type=int, default=8); ap.add_argument("--size", type=int, default=352)
 ap.add_argument("--dtype", default="f32"); ap.add_argument("--steps", type=int, default=2)
-ap.add_argument("--no-plans", action="store_true"); ap.add_argument("--tail", type=int, default=0); ap.add_argument("--s0gaps", type=int, default=0)
+ap.add_argument("--no-plans", action="store_true"); ap.add_argument("--tail", type=int, default=0); ap.add_argument("--s0gaps", type=int, default=0); ap.add_argument("--top", type=int, default=28)
 a = ap.parse_args()
 dev = torch.device("cuda", 0)
 net = LM_Net(3, 2).to(dev).train()
@@ -79,7 +79,7 @@ for s in streams:
     gap = sum(max(0.0, b[2] - a_[3]) for a_, b in zip(rs, rs[1:]) if b[2] - a_[3] < 200.0)
     print("stream %s: %d launches/step, busy %.2f ms/step, gaps < 200 us between its launches %.2f ms/step" % (
         sname[s], len(rs) // a.steps, sum(r[3] - r[2] for r in rs) / 1e3 / a.steps, gap / 1e3 / a.steps))
-    for k, (n, t) in sorted(by.items(), key=lambda kv: -kv[1][1])[:28]:
+    for k, (n, t) in sorted(by.items(), key=lambda kv: -kv[1][1])[:a.top]:
         print("    %-52s %4d x %7.1f us = %8.1f us/step" % (k[:52], n // a.steps, t / n, t / a.steps))
 
 # --tail N: the last N launches before each AdamW launch (what runs at the end of the backward), with stream and times relative to it
