@@ -174,8 +174,8 @@ class Engine:
         self.branch = None        # second compute stream of the backward schedule (LM_Net._backward_body)
         self.branches = []        # further branch streams (branch_stream_n)
         # chain of level k (0 = 352^2 ... 3 = 44^2) -> branch stream index, forward / backward ("0000": one branch stream, rounds 2-5)
-        self.branch_map_f = [int(c) for c in os.environ.get("LMN_BRANCH_MAP_F", "0011")]
-        self.branch_map_b = [int(c) for c in os.environ.get("LMN_BRANCH_MAP_B", "0011")]
+        self.branch_map_f = [int(c) for c in os.environ.get("LMN_BRANCH_MAP_F", "0001")]
+        self.branch_map_b = [int(c) for c in os.environ.get("LMN_BRANCH_MAP_B", "0101")]
         self.branch_overlap = True
         # BatchNorm bookkeeping inside the consuming conv (lmn_bn_fin_t) instead of separate launches (LMN_FUSE_BN=0: A/B runs)
         self.fuse_bn = os.environ.get("LMN_FUSE_BN", "1") != "0"

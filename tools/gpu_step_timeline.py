@@ -17,7 +17,7 @@ from lm_net_amd.optim import FusedAdamW
 ap = argparse.ArgumentParser()
 ap.add_argument("--batch", type=int, default=8); ap.add_argument("--size", type=int, default=352)
 ap.add_argument("--dtype", default="f32"); ap.add_argument("--steps", type=int, default=2)
-ap.add_argument("--no-plans", action="store_true"); ap.add_argument("--tail", type=int, default=0); ap.add_argument("--s0gaps", type=int, default=0); ap.add_argument("--top", type=int, default=28)
+ap.add_argument("--no-plans", action="store_true"); ap.add_argument("--tail", type=int, default=0); ap.add_argument("--s0gaps", type=int, default=0); ap.add_argument("--top", type=int, default=28); ap.add_argument("--buckets", type=float, default=0)
 a = ap.parse_args()
 dev = torch.device("cuda", 0)
 net = LM_Net(3, 2).to(dev).train()
@@ -106,3 +106,22 @@ if a.s0gaps:
         print("  %7.1f us at %8.2f ms: %s -> %s" % (g, (a_[3] - T0) / 1e3, a_[0][:44], b[0][:44]))
         for r in sorted(others, key=lambda r: r[2])[:8]:
             print("        %s %7.1f..%7.1f  %s" % (sname[r[1]], r[2] - a_[3], r[3] - a_[3], r[0][:60]))
+
+# --buckets US: busy fraction of every stream per time bucket of the LAST timed step (where is the slack?), with the main stream's
+# first kernel of each bucket as a landmark
+if "--buckets" in sys.argv:
+    bw = float(sys.argv[sys.argv.index("--buckets") + 1])
+    ad = sorted(r[2] for r in tl if r[0].startswith("adamw"))
+    t_lo = ad[-2] if len(ad) > 1 else T0
+    t_hi = ad[-1]
+    main = max(streams, key=lambda s: sum(1 for r in tl if r[1] == s))
+    nb = int((t_hi - t_lo) / bw) + 1
+    print("---- busy fraction per %.0f us bucket, streams %s (last step, %.2f ms)" % (bw, " ".join(sname[s] for s in streams), (t_hi - t_lo) / 1e3))
+    for b in range(nb):
+        lo, hi = t_lo + b * bw, t_lo + (b + 1) * bw
+        fr = []
+        for s in streams:
+            fr.append(sum(max(0.0, min(r[3], hi) - max(r[2], lo)) for r in tl if r[1] == s and r[3] > lo and r[2] < hi) / bw)
+        first = [r for r in tl if r[1] == main and lo <= r[2] < hi]
+        first.sort(key=lambda r: r[2])
+        print("  %6.2f ms  %s   %s" % ((lo - t_lo) / 1e3, " ".join("%4.2f" % f for f in fr), first[0][0][:48] if first else ""))
