@@ -133,6 +133,10 @@ int lmn_launch_conv_tile_3x3g(const ConvParams& T, dim3 grid, size_t shmem, hipS
 // Cout <= 32, plain epilogue (bias, residual, SUM_SQ statistics); T.tiles_x / tiles_y / total_tiles describe 8 x 16-pixel tiles
 size_t lmn_conv_dma3_lds(int C, int nct);
 int lmn_launch_conv_dma3(const ConvParams& T, int blocks, hipStream_t st);
+// conv_dmaM.hip: the M-split tile of the wide 3x3 stride-1 convs with LDS-DMA window stages
+size_t lmn_conv_dmaM_lds(int XH, int XW);
+bool lmn_conv_dmaM_fits(int XH, int XW);
+int lmn_launch_conv_dmaM(const ConvParams& T, dim3 grid, hipStream_t st, int ek);
 // LDS-DMA streaming kernel of ReparamConv's HBM-bound 1x1 convs at levels 0-1 (conv_dma1.hip): instance lookup (tile pixels, 0: none),
 // LDS bytes, launch.  ks*: channel quads of the sources, aq: of the aux image, mode: 0 plain / 2 SUM_SQ / 5 SE_BWD, gs: GELU x gate on source 0
 int lmn_conv_dma1_tp(int ks0, int ks1, int ks2, int aq, int nct, int mode, int gs, int nct2, int mode2);

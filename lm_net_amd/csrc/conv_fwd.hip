@@ -297,6 +297,11 @@ int lmn_conv_pack_batch(const lmn_pack_job_t* jobs_dev, int njobs, int64_t total
 // 1x1 kernel; calls with fewer tiles than the threshold keep conv_tile_kernel (the resident blocks want tiles to pipeline)
 static int g_conv_dma_mode = -1;
 static int g_conv_dma_min_tiles = 512;
+static int dmam_maxb() {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("LMN_CONV_DMAM_MAXB"); v = e ? atoi(e) : 256; }
+  return v;
+}
 int lmn_conv_dma_config(int mode, int min_tiles) {
   const int prev = g_conv_dma_mode;
   if (mode >= 0) g_conv_dma_mode = mode;
@@ -307,7 +312,7 @@ int lmn_conv_dma_config(int mode, int min_tiles) {
 // Does the LDS-DMA streaming 1x1 kernel (conv_dma1.hip) take this call (UNFLATTENED arguments), and as which instance?
 struct Dma1Sel { int ks[3]; int aq, nct, mode, gs, nct2, mode2, tp; };
 static bool dma1_select(const lmn_conv_args_t& A, Dma1Sel& S) {
-  if (g_conv_dma_mode < 0) { const char* e = getenv("LMN_CONV_DMA"); g_conv_dma_mode = e ? atoi(e) : 3; }
+  if (g_conv_dma_mode < 0) { const char* e = getenv("LMN_CONV_DMA"); g_conv_dma_mode = e ? atoi(e) : 7; }
   if (!(g_conv_dma_mode & 2)) return false;
   if (A.ksize != 1 || A.stride != 1 || A.mma_dtype != LMN_F32 || A.act_dtype != LMN_F32 || A.drop_p != 0.f || A.fin.mode != LMN_FIN_NONE || A.residual) return false;
   if (A.nsrc < 1 || A.nsrc > 3 || A.Cout <= 0 || A.Cout % 4 || A.Cout > 48 || A.out_rp_w < 0) return false;
@@ -734,6 +739,29 @@ int lmn_conv_fwd(const lmn_conv_args_t* args, lmn_stream_t stream) {
       const int mmax = 2048 / mchunks > 256 ? 2048 / mchunks : 256;
       if (mblocks > mmax) mblocks = mmax;
       const dim3 mgrid(mblocks, mchunks);
+      {
+        // LDS-DMA staged form (conv_dmaM.hip) for the plain wide 3x3 stride-1 calls: one NHWC fp32 source without on-load transform,
+        // bias / residual / SUM_SQ statistics only (LMN_CONV_DMA bit 2).  One cout tile per wave (64 output channels per block).
+        if (g_conv_dma_mode < 0) { const char* e = getenv("LMN_CONV_DMA"); g_conv_dma_mode = e ? atoi(e) : 7; }
+        const lmn_src_t& s0 = a.src[0];
+        const bool dm_ok = (g_conv_dma_mode & 4) && a.ksize == 3 && a.stride == 1 && !up2 && !ln && pm == 0 && a.nsrc == 1 && s0.flags == 0 && !s0.scale && s0.rp_w == 0 &&
+                           s0.C % 4 == 0 && s0.cstride % 4 == 0 && a.epilogue == LMN_EP_LINEAR && (ek == 0 || ek == 2) && a.drop_p == 0.f && !a.aux && a.fin.mode == LMN_FIN_NONE &&
+                           !a.out_rp_w && a.Hin == a.Hout && a.Win == a.Wout && lmn_conv_dmaM_fits(T.XH, T.XW) &&
+                           (int64_t)a.B * a.Hin * a.Win * s0.cstride * 4 < 0x7fffffffLL && (int64_t)9 * P.NKB * P.NCTT * 1024 < 0x7fffffffLL &&
+                           // ~100 KB of LDS = one block per CU: only grids of one round (the 22^2 maps; 96 -> 96 at 44^2 with 288 blocks: 51 -> 58 us),
+                           // and enough stages per tile to amortise the exposed first one (LMN_CONV_DMAM_MAXB: A/B runs)
+                           (int64_t)T.total_tiles * ((P.NCTT + 3) / 4) <= dmam_maxb() && P.nkb[0] >= 6;
+        if (dm_ok) {
+          const int dchunks = (P.NCTT + 3) / 4;
+          int dblocks = T.total_tiles;
+          const int dmax = 1024 / dchunks > 256 ? 1024 / dchunks : 256;
+          if (dblocks > dmax) dblocks = dmax;
+          if (int rc = det_prep(dblocks)) return rc;
+          LMN_REQUIRE(lmn_launch_conv_dmaM(T, dim3(dblocks, dchunks), st, ek) == 0, "conv_fwd: no LDS-DMA M-split instance for epilogue %d", ek);
+          det_finish();
+          return lmn_launch_status("conv_fwd(dmaM)");
+        }
+      }
       if (int rc = det_prep(mblocks)) return rc;
       const size_t msh = ((size_t)T.XH * T.XW * T.CS + (2 + 9) * 4 * ncw * 16 + (ln ? 2 * T.XH * T.XW : 0)) * sizeof(float);
       lmn_launch_conv_tileM(T, mgrid, msh, st, a.ksize == 1 ? 1 : 9, ncw, pm, ek, a.ksize == 1 && T.rpw != 0, ln, up2);
@@ -750,7 +778,7 @@ int lmn_conv_fwd(const lmn_conv_args_t* args, lmn_stream_t stream) {
     {
       // LDS-DMA double-buffered kernel (conv_dma3.hip) for the small-channel 3x3 stride-1 calls: one plain NHWC fp32 source of 12 / 24
       // channels, Cout <= 32, bias / residual / SUM_SQ statistics only, maps that give every CU tiles to pipeline (levels 0-1 at batch 8)
-      if (g_conv_dma_mode < 0) { const char* e = getenv("LMN_CONV_DMA"); g_conv_dma_mode = e ? atoi(e) : 3; }   // LMN_CONV_DMA: bit 0 = 3x3 kernel, bit 1 = 1x1 kernel; 0 = off (conv_tile_kernel everywhere, A/B runs)
+      if (g_conv_dma_mode < 0) { const char* e = getenv("LMN_CONV_DMA"); g_conv_dma_mode = e ? atoi(e) : 7; }   // LMN_CONV_DMA: bit 0 = 3x3 kernel, bit 1 = 1x1 kernel; 0 = off (conv_tile_kernel everywhere, A/B runs)
       const int dma_env = g_conv_dma_mode & 1;
       const lmn_src_t& s0 = a.src[0];
       const int64_t dtiles = (int64_t)a.B * ((a.Wout + 15) / 16) * ((a.Hout + 7) / 8);

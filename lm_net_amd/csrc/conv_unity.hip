@@ -7,3 +7,4 @@
 #include "conv_wgrad.hip"
 #include "conv_dma3.hip"
 #include "conv_dma1.hip"
+#include "conv_dmaM.hip"

@@ -1017,7 +1017,85 @@ def check_conv_dma3():
         finally:
             hip.set_deterministic(det0)
     finally:
-        hip.conv_dma_config(prev if prev >= 0 else 3, 512)
+        hip.conv_dma_config(prev if prev >= 0 else 7, 512)
+    return rows
+
+
+def check_conv_dmaM():
+    """conv_dmaM_kernel (round 6): the M-split tile of the WIDE 3x3 stride-1 convs with LDS-DMA window stages (skip-fuser / bottleneck /
+    decoder convs at 88^2 / 44^2 / 22^2 and their data gradients; /root/reference/core/modules.py:83-143, core/LM_Net.py:14-39) vs fp64
+    F.conv2d / its autograd, and against conv_tileM_kernel on the same call (lmn_conv_dma_config bit 2).  Shapes: the model's (48 -> 96 /
+    144, 96 -> 96 / 192, 372 -> 372 on their maps: one and two cout tiles per wave, an odd number of K16 blocks, a last block of 4
+    channels), maps that are not multiples of the tile, several tiles per block (the stage pipeline crosses tile ends), source / output
+    slices of wider buffers, residual, SUM_SQ statistics about a shift (4 slices), deterministic slots, the transposed (data-gradient) form."""
+    rows = []
+    prev = hip.conv_dma_config(7, 1)
+    try:
+        for (B, H, W, Cin, Cout) in ((2, 22, 22, 372, 372), (2, 44, 44, 96, 192), (1, 44, 44, 96, 96), (2, 88, 88, 48, 144), (1, 88, 88, 48, 96),
+                                     (1, 19, 37, 52, 100), (9, 30, 41, 20, 112), (1, 5, 7, 36, 96)):
+            tag = " %dx%dx%d %d->%d" % (B, H, W, Cin, Cout)
+            x = R(B, Cin + 8, H, W, seed=501)
+            w = R(Cout, Cin, 3, 3, seed=502, scale=0.05).requires_grad_(True)
+            b = R(Cout, seed=503)
+            res = R(B, Cout, H, W, seed=504)
+            xs = x[:, 4:4 + Cin].clone().requires_grad_(True)
+            z = F.conv2d(xs, w, b, padding=1)
+            y_ref = z + res
+            xb = nhwc(x)
+            wp = hip.conv_pack(dev(w.detach()), 3, [Cin])
+            shift = R(Cout, seed=505) * 0.3
+            got = {}
+            for mode in (7, 3):
+                hip.conv_dma_config(mode, 1)
+                outb = torch.full((B, H, W, Cout + 12), float("nan"), device=DEV)
+                srep = torch.zeros(4, 2, Cout, device=DEV)
+                hip.conv_fwd([hip.V(xb, 4, Cin)], wp, hip.V(outb, 8, Cout), B=B, Hin=H, Win=W, Hout=H, Wout=W, Cout=Cout, ksize=3, bias=dev(b),
+                             residual=nhwc(res), stats=srep, stats_mode=hip.STATS_SUM_SQ, stats_rep=4, p=(None, None, None, None, dev(shift)))
+                got[mode] = (outb, srep.sum(0))
+            hip.conv_dma_config(7, 1)
+            rows.append(("conv_dmaM fwd (slices, bias, residual)" + tag, rel(nchw(got[7][0][..., 8:8 + Cout]), y_ref), TOL))
+            rows.append(("conv_dmaM fwd vs conv_tileM_kernel" + tag, rel(got[7][0][..., 8:8 + Cout], got[3][0][..., 8:8 + Cout]), 4e-6))
+            rows.append(("conv_dmaM untouched slices stay NaN" + tag, 0.0 if bool(torch.isnan(got[7][0][..., :8]).all() and torch.isnan(got[7][0][..., 8 + Cout:]).all()) else 1.0, 0.5))
+            zd = (z - shift.view(1, -1, 1, 1)).detach()
+            sref = torch.stack([zd.sum((0, 2, 3)), (zd * zd).sum((0, 2, 3))])
+            rows.append(("conv_dmaM SUM_SQ statistics about a shift" + tag, rel(got[7][1], sref), 2e-4))
+            xw = nhwc(xs.detach())
+            y1 = torch.full((B, H, W, Cout), float("nan"), device=DEV)
+            hip.conv_fwd([xw], wp, y1, B=B, Hin=H, Win=W, Hout=H, Wout=W, Cout=Cout, ksize=3, bias=dev(b))
+            rows.append(("conv_dmaM fwd plain" + tag, rel(nchw(y1), z), TOL))
+            # data gradient (transposed form: taps flipped, weights from conv_pack_t) when ITS output (Cin channels) is wide enough for the M-split
+            dy = R(B, Cout, H, W, seed=506)
+            z.backward(dy)
+            wpt = hip.conv_pack_t(dev(w.detach()), 3)
+            acc = R(B, Cin, H, W, seed=507)
+            dx = torch.full((B, H, W, Cin), float("nan"), device=DEV)
+            hip.conv_fwd([nhwc(dy)], wpt, dx, B=B, Hin=H, Win=W, Hout=H, Wout=W, Cout=Cin, ksize=3, transposed=1, residual=nhwc(acc))
+            rows.append(("conv_dmaM data gradient (+ accumulate)" + tag, rel(nchw(dx), xs.grad + acc), TOL))
+            hip.conv_dma_config(3, 1)
+            dx0 = torch.full((B, H, W, Cin), float("nan"), device=DEV)
+            hip.conv_fwd([nhwc(dy)], wpt, dx0, B=B, Hin=H, Win=W, Hout=H, Wout=W, Cout=Cin, ksize=3, transposed=1, residual=nhwc(acc))
+            hip.conv_dma_config(7, 1)
+            rows.append(("conv_dmaM data gradient vs the LDS-tiled kernels" + tag, rel(dx, dx0), 4e-6))
+        # deterministic mode: statistics through the per-block slots, two launches bit-identical
+        det0 = hip.get_deterministic()
+        hip.set_deterministic(True)
+        try:
+            B, H, W, Cin, Cout = 2, 44, 44, 96, 96
+            x, w, b = nhwc(R(B, Cin, H, W, seed=511)), R(Cout, Cin, 3, 3, seed=512, scale=0.05), dev(R(Cout, seed=513))
+            wp = hip.conv_pack(dev(w), 3, [Cin])
+            outs = []
+            for rep in range(2):
+                y = torch.full((B, H, W, Cout), float("nan"), device=DEV)
+                st = torch.zeros(2, Cout, device=DEV)
+                hip.conv_fwd([x], wp, y, B=B, Hin=H, Win=W, Hout=H, Wout=W, Cout=Cout, ksize=3, bias=b, stats=st, stats_mode=hip.STATS_SUM_SQ)
+                outs.append((y, st))
+            zr = F.conv2d(nchw(x), w, b.double().cpu(), padding=1)
+            rows.append(("conv_dmaM deterministic statistics", rel(outs[0][1], torch.stack([zr.sum((0, 2, 3)), (zr * zr).sum((0, 2, 3))])), 2e-4))
+            rows.append(("conv_dmaM deterministic: two launches bit-identical", 0.0 if (torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])) else 1.0, 0.5))
+        finally:
+            hip.set_deterministic(det0)
+    finally:
+        hip.conv_dma_config(prev if prev >= 0 else 7, 512)
     return rows
 
 
@@ -1168,7 +1246,7 @@ def check_conv_dma1():
         finally:
             hip.set_deterministic(det0)
     finally:
-        hip.conv_dma_config(prev if prev >= 0 else 3, 512)
+        hip.conv_dma_config(prev if prev >= 0 else 7, 512)
     return rows
 
 

@@ -4,7 +4,7 @@ over the product sources, no GPU needed) joined with the serial (alone) and in-s
 import os, re, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CS = os.path.join(ROOT, "lm_net_amd", "csrc")
-SRCS = ["conv_tile_1x1.hip", "conv_tile_3x3.hip", "conv_tileM.hip", "conv_dma1.hip", "conv_dma3.hip", "conv_wgrad.hip", "conv_fwd.hip", "dwconv.hip", "na.hip",
+SRCS = ["conv_tile_1x1.hip", "conv_tile_3x3.hip", "conv_tileM.hip", "conv_dma1.hip", "conv_dma3.hip", "conv_dmaM.hip", "conv_wgrad.hip", "conv_fwd.hip", "dwconv.hip", "na.hip",
         "gattn.hip", "rows.hip", "runtime.hip"]
 FLAGS = "-O3 -std=c++17 -fPIC --offload-arch=gfx950 -fno-gpu-rdc -mllvm -amdgpu-mfma-vgpr-form=1 --cuda-device-only -c -o /dev/null -Rpass-analysis=kernel-resource-usage".split()
 
