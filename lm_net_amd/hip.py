@@ -1052,6 +1052,8 @@ def set_priority_stream(stream, level=3):
     if _PRIO_STREAMS.get(key, 0) == level:
         return
     _check(load().lmn_set_priority_stream(C.c_void_p(key), level), "set_priority_stream")
+    if len(_PRIO_STREAMS) >= 8:      # (the library's table holds 8 streams and replaces the oldest: forget what this side believes is registered)
+        _PRIO_STREAMS.clear()
     _PRIO_STREAMS[key] = level
 
 
