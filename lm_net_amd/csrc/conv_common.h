@@ -133,7 +133,7 @@ int lmn_launch_conv_tile_3x3g(const ConvParams& T, dim3 grid, size_t shmem, hipS
 // Cout <= 32, plain epilogue (bias, residual, SUM_SQ statistics); T.tiles_x / tiles_y / total_tiles describe 8 x 16-pixel tiles
 size_t lmn_conv_dma3_lds(int C, int nct);
 int lmn_launch_conv_dma3(const ConvParams& T, int blocks, hipStream_t st);
-// conv_dmaM.hip: the M-split tile of the wide 3x3 stride-1 convs with LDS-DMA window stages
+// conv_dmaM.hip: the M-split tile of the wide 3x3 stride-1 convs with window and weights by LDS-DMA
 size_t lmn_conv_dmaM_lds(int XH, int XW);
 bool lmn_conv_dmaM_fits(int XH, int XW);
 int lmn_launch_conv_dmaM(const ConvParams& T, dim3 grid, hipStream_t st, int ek);

@@ -297,11 +297,6 @@ int lmn_conv_pack_batch(const lmn_pack_job_t* jobs_dev, int njobs, int64_t total
 // 1x1 kernel; calls with fewer tiles than the threshold keep conv_tile_kernel (the resident blocks want tiles to pipeline)
 static int g_conv_dma_mode = -1;
 static int g_conv_dma_min_tiles = 512;
-static int dmam_maxb() {
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("LMN_CONV_DMAM_MAXB"); v = e ? atoi(e) : 256; }
-  return v;
-}
 int lmn_conv_dma_config(int mode, int min_tiles) {
   const int prev = g_conv_dma_mode;
   if (mode >= 0) g_conv_dma_mode = mode;
@@ -740,21 +735,18 @@ int lmn_conv_fwd(const lmn_conv_args_t* args, lmn_stream_t stream) {
       if (mblocks > mmax) mblocks = mmax;
       const dim3 mgrid(mblocks, mchunks);
       {
-        // LDS-DMA staged form (conv_dmaM.hip) for the plain wide 3x3 stride-1 calls: one NHWC fp32 source without on-load transform,
+        // LDS-DMA form (conv_dmaM.hip) for the plain wide 3x3 stride-1 calls: one NHWC fp32 source without on-load transform,
         // bias / residual / SUM_SQ statistics only (LMN_CONV_DMA bit 2).  One cout tile per wave (64 output channels per block).
         if (g_conv_dma_mode < 0) { const char* e = getenv("LMN_CONV_DMA"); g_conv_dma_mode = e ? atoi(e) : 7; }
         const lmn_src_t& s0 = a.src[0];
         const bool dm_ok = (g_conv_dma_mode & 4) && a.ksize == 3 && a.stride == 1 && !up2 && !ln && pm == 0 && a.nsrc == 1 && s0.flags == 0 && !s0.scale && s0.rp_w == 0 &&
                            s0.C % 4 == 0 && s0.cstride % 4 == 0 && a.epilogue == LMN_EP_LINEAR && (ek == 0 || ek == 2) && a.drop_p == 0.f && !a.aux && a.fin.mode == LMN_FIN_NONE &&
                            !a.out_rp_w && a.Hin == a.Hout && a.Win == a.Wout && lmn_conv_dmaM_fits(T.XH, T.XW) &&
-                           (int64_t)a.B * a.Hin * a.Win * s0.cstride * 4 < 0x7fffffffLL && (int64_t)9 * P.NKB * P.NCTT * 1024 < 0x7fffffffLL &&
-                           // ~100 KB of LDS = one block per CU: only grids of one round (the 22^2 maps; 96 -> 96 at 44^2 with 288 blocks: 51 -> 58 us),
-                           // and enough stages per tile to amortise the exposed first one (LMN_CONV_DMAM_MAXB: A/B runs)
-                           (int64_t)T.total_tiles * ((P.NCTT + 3) / 4) <= dmam_maxb() && P.nkb[0] >= 6;
+                           (int64_t)a.B * a.Hin * a.Win * s0.cstride * 4 < 0x7fffffffLL && (int64_t)9 * P.NKB * P.NCTT * 1024 < 0x7fffffffLL;
         if (dm_ok) {
           const int dchunks = (P.NCTT + 3) / 4;
           int dblocks = T.total_tiles;
-          const int dmax = 1024 / dchunks > 256 ? 1024 / dchunks : 256;
+          const int dmax = 2048 / dchunks > 256 ? 2048 / dchunks : 256;
           if (dblocks > dmax) dblocks = dmax;
           if (int rc = det_prep(dblocks)) return rc;
           LMN_REQUIRE(lmn_launch_conv_dmaM(T, dim3(dblocks, dchunks), st, ek) == 0, "conv_fwd: no LDS-DMA M-split instance for epilogue %d", ek);

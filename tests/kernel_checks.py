@@ -1022,17 +1022,18 @@ def check_conv_dma3():
 
 
 def check_conv_dmaM():
-    """conv_dmaM_kernel (round 6): the M-split tile of the WIDE 3x3 stride-1 convs with LDS-DMA window stages (skip-fuser / bottleneck /
-    decoder convs at 88^2 / 44^2 / 22^2 and their data gradients; /root/reference/core/modules.py:83-143, core/LM_Net.py:14-39) vs fp64
-    F.conv2d / its autograd, and against conv_tileM_kernel on the same call (lmn_conv_dma_config bit 2).  Shapes: the model's (48 -> 96 /
-    144, 96 -> 96 / 192, 372 -> 372 on their maps: one and two cout tiles per wave, an odd number of K16 blocks, a last block of 4
-    channels), maps that are not multiples of the tile, several tiles per block (the stage pipeline crosses tile ends), source / output
-    slices of wider buffers, residual, SUM_SQ statistics about a shift (4 slices), deterministic slots, the transposed (data-gradient) form."""
+    """conv_dmaM_kernel (round 6): the M-split tile of the WIDE 3x3 stride-1 convs with window and weights by LDS-DMA (skip-fuser /
+    bottleneck / decoder convs at 88^2 / 44^2 / 22^2 and their data gradients; /root/reference/core/modules.py:83-143, core/LM_Net.py:14-39)
+    vs fp64 F.conv2d / its autograd, and against conv_tileM_kernel on the same call (lmn_conv_dma_config bit 2).  Shapes: the model's
+    (48 -> 96 / 144, 96 -> 96 / 192, 372 -> 372 on their maps: a last K16 block of 4 channels), one- and two-stage layers (the counted
+    waits of the weight ring run out differently there), maps that are not multiples of the tile, a grid whose blocks walk two tiles (the
+    drain at a tile's start), source / output slices of wider buffers, residual, SUM_SQ statistics about a shift (4 slices), deterministic
+    slots, the transposed (data-gradient) form."""
     rows = []
     prev = hip.conv_dma_config(7, 1)
     try:
         for (B, H, W, Cin, Cout) in ((2, 22, 22, 372, 372), (2, 44, 44, 96, 192), (1, 44, 44, 96, 96), (2, 88, 88, 48, 144), (1, 88, 88, 48, 96),
-                                     (1, 19, 37, 52, 100), (9, 30, 41, 20, 112), (1, 5, 7, 36, 96)):
+                                     (1, 19, 37, 52, 100), (9, 30, 41, 20, 112), (1, 5, 7, 36, 96), (2, 20, 20, 16, 96), (1, 12, 12, 8, 96), (40, 64, 64, 16, 100)):
             tag = " %dx%dx%d %d->%d" % (B, H, W, Cin, Cout)
             x = R(B, Cin + 8, H, W, seed=501)
             w = R(Cout, Cin, 3, 3, seed=502, scale=0.05).requires_grad_(True)
