@@ -525,8 +525,9 @@ def conv_fwd(srcs, wpack, out, *, B, Hin, Win, Hout, Wout, Cout, ksize=1, stride
 
 
 def conv_dma_config(mode=-1, min_tiles=-1):
-    """lmn_conv_dma_config: LDS-DMA 3x3 kernel on (1) / off (0), smallest call (in 8x16-pixel tiles) that takes it; -1 keeps a value.
-    Returns the previous mode."""
+    """lmn_conv_dma_config: which LDS-DMA kernel forms lmn_conv_fwd may pick (bit 0 conv_dma3, bit 1 conv_dma1, bit 2 conv_dmaM; 0 = the
+    LDS-tiled kernels everywhere), smallest call (in 8x16-pixel tiles) that takes the small-channel forms; -1 keeps a value.  Returns the
+    previous mode (-1: not set yet, the LMN_CONV_DMA default applies)."""
     return int(load().lmn_conv_dma_config(int(mode), int(min_tiles)))
 
 

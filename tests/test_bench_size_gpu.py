@@ -135,17 +135,23 @@ def test_hooks_plans_and_host_launches_agree_at_bench_size(names, dtype):
 
 
 @pytest.mark.parametrize("switch", [dict(fuse_bn=False), dict(split_se=False), dict(split_dw=True), dict(fuse_se=0), dict(zpath=False),
-                                    dict(zpath_m=False), dict(defer_reduce=False)],
+                                    dict(zpath_m=False), dict(defer_reduce=False), dict(unpad_side=False), dict(prio_main=0), dict(conv_dma=0),
+                                    dict(conv_dma=3)],
                          ids=lambda d: "%s=%s" % next(iter(d.items())))
 def test_ab_switches_agree_at_bench_size(switch, serial, names):
     """Every engine-level A/B switch of INTEGRATION.md section 5 computes the same step as the default configuration at batch 8 /
     352x352 (first training step): same loss to 1e-5 rel, every gradient tensor to 5e-4 of the largest gradient (the fp32 tolerance of the oracle tests;
     the switches regroup sums, they do not change what is summed)."""
     from lm_net_amd import hip
+    switch = dict(switch)
+    dma = switch.pop("conv_dma", None)       # (library-level switch: the kernel FORMS of lmn_conv_fwd, 0 = LDS-tiled kernels everywhere)
+    prev = hip.conv_dma_config(dma, -1) if dma is not None else None
     try:
         got = _train(switch, steps=1)
     finally:
         hip.set_deterministic(False)
+        if dma is not None:
+            hip.conv_dma_config(prev if prev >= 0 else 7, -1)
     # (the FIRST step of both: after an AdamW update -- m / sqrt(v) = +-1 on the first step whatever the gradient's size -- rounding
     # differences of near-zero gradients become lr-sized parameter differences)
     assert abs(got[2] - serial[2]) <= 1e-5 * abs(serial[2]), (switch, got[2], serial[2])
